@@ -1,0 +1,465 @@
+"""DFINECriterion: VFL + L1/GIoU + FGL/DDF (+ cropped mask BCE/Dice) over the main, auxiliary,
+pre, encoder and denoising heads.
+
+Same constructor, `forward(outputs, targets) -> dict[str, 0-d tensor]`, loss names and
+denominators as the reference (`src/d_fine/dfine_criterion.py`).  Restructured for the GPU:
+  * all L+2 Hungarian matchings of a step run in one launch (`matcher.match_heads`);
+  * matched (image, query, target) triples are uploaded once per index set and reused by
+    every loss of every head instead of being rebuilt from python lists per loss;
+  * no `.item()` / `torch.equal` / `mask.any()` host syncs inside the loss loops (the only
+    device->host copy of the step is the matcher's assignment vector).
+"""
+import copy
+
+import torch
+import torch.distributed
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .arch.utils import bbox2distance, box_cxcywh_to_xyxy, box_iou, generalized_box_iou, paired_iou_giou
+from .dist_utils import get_world_size, is_dist_available_and_initialized
+
+
+class _Plan:
+    """Device-side gather plan of one matching: which (image, query) pairs are matched to
+    which row of the batch-concatenated targets."""
+
+    def __init__(self, indices, offsets, device):
+        b = torch.cat([torch.full_like(s, i) for i, (s, _) in enumerate(indices)])
+        s = torch.cat([s for s, _ in indices])
+        t = torch.cat([t + offsets[i] for i, (_, t) in enumerate(indices)])
+        packed = torch.stack([b, s, t]).to(device, non_blocking=True)
+        self.batch, self.src, self.tgt = packed[0], packed[1], packed[2]
+        self.count = int(s.numel())
+        self.indices = indices
+
+
+class DFINECriterion(nn.Module):
+    __share__ = ["num_classes"]
+    __inject__ = ["matcher"]
+
+    def __init__(self, matcher, weight_dict, losses, alpha=0.2, gamma=2.0, num_classes=80,
+                 reg_max=32, boxes_weight_format=None, share_matched_indices=False,
+                 label_smoothing: float = 0.0):
+        super().__init__()
+        self.num_classes, self.matcher, self.weight_dict = num_classes, matcher, weight_dict
+        self.losses = losses
+        self.boxes_weight_format = boxes_weight_format
+        self.share_matched_indices = share_matched_indices
+        self.alpha, self.gamma, self.reg_max = alpha, gamma, reg_max
+        self.label_smoothing = label_smoothing
+        self._clear_cache()
+        self._tgt = None
+
+    # ------------------------------------------------------------------ bookkeeping
+    def _clear_cache(self):
+        self.fgl_targets, self.fgl_targets_dn = None, None
+        self.own_targets, self.own_targets_dn = None, None
+        self.num_pos, self.num_neg = None, None
+        self._plans = {}
+
+    def _targets_cat(self, targets):
+        """(labels [T], boxes [T,4], per-image offsets) of the batch, concatenated once."""
+        key = id(targets)
+        if self._tgt is None or self._tgt[0] != key:
+            sizes = [len(t["labels"]) for t in targets]
+            offs = [0]
+            for n in sizes:
+                offs.append(offs[-1] + n)
+            self._tgt = (key, torch.cat([t["labels"] for t in targets]),
+                         torch.cat([t["boxes"] for t in targets]), offs)
+        return self._tgt[1], self._tgt[2], self._tgt[3]
+
+    def _plan(self, indices, targets, device) -> _Plan:
+        key = id(indices)
+        if key not in self._plans:
+            self._plans[key] = _Plan(indices, self._targets_cat(targets)[2], device)
+        return self._plans[key]
+
+    def _get_src_permutation_idx(self, indices):
+        batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
+        return batch_idx, torch.cat([src for src, _ in indices])
+
+    def _get_tgt_permutation_idx(self, indices):
+        batch_idx = torch.cat([torch.full_like(tgt, i) for i, (_, tgt) in enumerate(indices)])
+        return batch_idx, torch.cat([tgt for _, tgt in indices])
+
+    def _matched_boxes(self, outputs, targets, indices):
+        p = self._plan(indices, targets, outputs["pred_boxes"].device)
+        src = outputs["pred_boxes"][p.batch, p.src]
+        tgt = self._targets_cat(targets)[1][p.tgt]
+        return p, src, tgt
+
+    # ------------------------------------------------------------------ classification
+    def _class_targets(self, src_logits, p: _Plan, labels):
+        cls = torch.full(src_logits.shape[:2], self.num_classes, dtype=torch.int64,
+                         device=src_logits.device)
+        cls[p.batch, p.src] = labels[p.tgt]
+        return cls
+
+    def loss_labels_focal(self, outputs, targets, indices, num_boxes):
+        """Sigmoid focal loss on one-hot (optionally smoothed) targets (ref :67-90)."""
+        x = outputs["pred_logits"]
+        p = self._plan(indices, targets, x.device)
+        cls = self._class_targets(x, p, self._targets_cat(targets)[0])
+        tgt = F.one_hot(cls, num_classes=self.num_classes + 1)[..., :-1].float()
+        if self.label_smoothing is not None and self.label_smoothing > 0:
+            tgt = tgt * (1 - self.label_smoothing) + self.label_smoothing / tgt.shape[-1]
+        prob = torch.sigmoid(x)
+        ce = F.binary_cross_entropy_with_logits(x, tgt, reduction="none")
+        p_t = prob * tgt + (1 - prob) * (1 - tgt)
+        loss = ce * ((1 - p_t) ** self.gamma)
+        if self.alpha >= 0:
+            loss = (self.alpha * tgt + (1 - self.alpha) * (1 - tgt)) * loss
+        return {"loss_focal": loss.mean(1).sum() * x.shape[1] / num_boxes}
+
+    def loss_labels_vfl(self, outputs, targets, indices, num_boxes, values=None):
+        """Varifocal loss: BCE against IoU-valued soft labels, negatives down-weighted by
+        alpha * p^gamma (ref dfine_criterion.py:92-122)."""
+        x = outputs["pred_logits"]
+        p, src, tgt = self._matched_boxes(outputs, targets, indices)
+        if values is None:
+            ious, _ = paired_iou_giou(box_cxcywh_to_xyxy(src), box_cxcywh_to_xyxy(tgt))
+            ious = ious.detach()
+        else:
+            ious = values
+        cls = self._class_targets(x, p, self._targets_cat(targets)[0])
+        onehot = F.one_hot(cls, num_classes=self.num_classes + 1)[..., :-1]
+        score = torch.zeros(x.shape[:2], dtype=x.dtype, device=x.device)
+        score[p.batch, p.src] = ious.to(x.dtype)
+        tgt_score = score.unsqueeze(-1) * onehot
+        prob = torch.sigmoid(x).detach()
+        weight = self.alpha * prob.pow(self.gamma) * (1 - onehot) + tgt_score
+        loss = F.binary_cross_entropy_with_logits(x, tgt_score, weight=weight, reduction="none")
+        return {"loss_vfl": loss.mean(1).sum() * x.shape[1] / num_boxes}
+
+    # ------------------------------------------------------------------ boxes
+    def loss_boxes(self, outputs, targets, indices, num_boxes, boxes_weight=None):
+        """L1 + (1 - GIoU) over matched pairs (ref dfine_criterion.py:124-143)."""
+        _, src, tgt = self._matched_boxes(outputs, targets, indices)
+        sx, tx = box_cxcywh_to_xyxy(src), box_cxcywh_to_xyxy(tgt)
+        if not sx.is_cuda:  # the reference asserts on degenerate boxes (arch/utils.py:41-42); on the
+            assert (sx[:, 2:] >= sx[:, :2]).all()  # GPU that check would be a host sync per loss call
+        _, giou = paired_iou_giou(sx, tx)
+        g = 1 - giou
+        if boxes_weight is not None:
+            g = g * boxes_weight
+        return {"loss_bbox": F.l1_loss(src, tgt, reduction="none").sum() / num_boxes,
+                "loss_giou": g.sum() / num_boxes}
+
+    # ------------------------------------------------------------------ FGL + DDF
+    def loss_local(self, outputs, targets, indices, num_boxes, T=5):
+        """Fine-grained localisation loss on the matched edge distributions and decoupled
+        distillation (KL to the last layer's distributions) on all of them
+        (ref dfine_criterion.py:145-237)."""
+        losses = {}
+        if "pred_corners" not in outputs:
+            return losses
+        nb = self.reg_max + 1
+        is_dn = "is_dn" in outputs
+        p, src, tgt = self._matched_boxes(outputs, targets, indices)
+        corners_all = outputs["pred_corners"]
+        pred = corners_all[p.batch, p.src].reshape(-1, nb)
+        ref = outputs["ref_points"][p.batch, p.src].detach()
+        tgt_xyxy = box_cxcywh_to_xyxy(tgt)
+        with torch.no_grad():
+            if is_dn and self.fgl_targets_dn is None:
+                self.fgl_targets_dn = bbox2distance(ref, tgt_xyxy, self.reg_max,
+                                                    outputs["reg_scale"], outputs["up"])
+            if not is_dn and self.fgl_targets is None:
+                self.fgl_targets = bbox2distance(ref, tgt_xyxy, self.reg_max,
+                                                 outputs["reg_scale"], outputs["up"])
+        t_corner, w_right, w_left = self.fgl_targets_dn if is_dn else self.fgl_targets
+
+        ious, _ = paired_iou_giou(box_cxcywh_to_xyxy(src), tgt_xyxy)
+        w_iou = ious.unsqueeze(-1).repeat(1, 1, 4).reshape(-1).detach()
+        losses["loss_fgl"] = self.unimodal_distribution_focal_loss(
+            pred, t_corner, w_right, w_left, w_iou, avg_factor=num_boxes)
+
+        if "teacher_corners" in outputs:
+            teacher = outputs["teacher_corners"]
+            if teacher is corners_all or (teacher.data_ptr() == corners_all.data_ptr()
+                                          and teacher.shape == corners_all.shape):
+                # the teacher itself (last dn layer): KL(p||p) == 0, as the reference's
+                # torch.equal branch (ref :197-198) - decided without a device sync
+                losses["loss_ddf"] = corners_all.sum() * 0
+            else:
+                b, q = corners_all.shape[:2]
+                w_loc = outputs["teacher_logits"].sigmoid().max(dim=-1)[0].detach().clone()
+                matched = torch.zeros(b, q, dtype=torch.bool, device=w_loc.device)
+                matched[p.batch, p.src] = True
+                w_loc[p.batch, p.src] = ious.detach().to(w_loc.dtype)
+                w_loc = w_loc.unsqueeze(-1).repeat(1, 1, 4).reshape(-1)
+                mask = matched.unsqueeze(-1).repeat(1, 1, 4).reshape(-1)
+                kl = F.kl_div(F.log_softmax(corners_all.reshape(-1, nb) / T, dim=1),
+                              F.softmax(teacher.reshape(-1, nb).detach() / T, dim=1),
+                              reduction="none").sum(-1)
+                per_row = w_loc * (T ** 2) * kl
+                n_pos = mask.sum()
+                n_neg = mask.numel() - n_pos
+                if not is_dn:
+                    scale = 8 / b  # keeps the pos/neg balance independent of the per-GPU batch
+                    self.num_pos, self.num_neg = (n_pos * scale) ** 0.5, (n_neg * scale) ** 0.5
+                fm = mask.to(per_row.dtype)
+                l_pos = (per_row * fm).sum() / n_pos.clamp(min=1)
+                l_neg = (per_row * (1 - fm)).sum() / n_neg.clamp(min=1)
+                losses["loss_ddf"] = (l_pos * self.num_pos + l_neg * self.num_neg) / (
+                    self.num_pos + self.num_neg)
+        return losses
+
+    def unimodal_distribution_focal_loss(self, pred, label, weight_right, weight_left,
+                                         weight=None, reduction="sum", avg_factor=None):
+        """Two-bin cross entropy against the left/right bins of a continuous target."""
+        left = label.long()
+        logp = F.log_softmax(pred, dim=1)
+        loss = -(logp.gather(1, left[:, None]).squeeze(1) * weight_left.reshape(-1)
+                 + logp.gather(1, left[:, None] + 1).squeeze(1) * weight_right.reshape(-1))
+        if weight is not None:
+            loss = loss * weight.float()
+        if avg_factor is not None:
+            return loss.sum() / avg_factor
+        return loss.mean() if reduction == "mean" else loss.sum()
+
+    # ------------------------------------------------------------------ masks (segment task)
+    def _prepare_target_masks(self, targets, indices, out_h, out_w, device):
+        chunks = []
+        for t, (_, j) in zip(targets, indices):
+            m = t.get("masks")
+            if m is None or m.numel() == 0 or m.dim() != 3 or j.numel() == 0:
+                continue
+            sel = m[j.to(m.device)].unsqueeze(1).float().to(device)
+            sel = F.interpolate(sel, size=(out_h, out_w), mode="bilinear", align_corners=False)
+            chunks.append(sel.squeeze(1).clamp_(0, 1))
+        if not chunks:
+            return torch.zeros(0, out_h, out_w, device=device, dtype=torch.float32), 0
+        out = torch.cat(chunks, dim=0)
+        return out, out.shape[0]
+
+    def _prepare_target_boxes_for_masks(self, targets, indices, out_h, out_w, device):
+        chunks = []
+        for t, (_, j) in zip(targets, indices):
+            m = t.get("masks")
+            if m is None or m.numel() == 0 or m.dim() != 3 or j.numel() == 0:
+                continue
+            b = t["boxes"][j.to(t["boxes"].device)]
+            cx, cy, w, h = b.unbind(1)
+            chunks.append(torch.stack([
+                ((cx - w / 2) * out_w).clamp(0, out_w - 1), ((cy - h / 2) * out_h).clamp(0, out_h - 1),
+                ((cx + w / 2) * out_w).clamp(1, out_w), ((cy + h / 2) * out_h).clamp(1, out_h)],
+                dim=1).to(device))
+        if not chunks:
+            return torch.zeros(0, 4, device=device, dtype=torch.float32)
+        return torch.cat(chunks, dim=0)
+
+    @staticmethod
+    def _inside(boxes, h, w, device, dtype):
+        ys = torch.arange(h, device=device, dtype=dtype)[None, :, None]
+        xs = torch.arange(w, device=device, dtype=dtype)[None, None, :]
+        x1, y1, x2, y2 = (boxes[:, i:i + 1, None] for i in range(4))
+        return ((xs >= x1) & (xs < x2)).float() * ((ys >= y1) & (ys < y2)).float(), (x1, y1, x2, y2)
+
+    @staticmethod
+    def _cropped_bce_loss(pred_logits, tgt_masks, boxes, eps=1e-6):
+        """BCE inside the GT box only, normalised by the box area (ref :335-386)."""
+        if pred_logits.shape[0] == 0:
+            return pred_logits.sum() * 0.0
+        _, h, w = pred_logits.shape
+        inside, (x1, y1, x2, y2) = DFINECriterion._inside(boxes, h, w, pred_logits.device,
+                                                          pred_logits.dtype)
+        bce = F.binary_cross_entropy_with_logits(pred_logits, tgt_masks, reduction="none") * inside
+        area = ((x2 - x1).reshape(-1) * (y2 - y1).reshape(-1)).clamp(min=1.0)
+        return (bce.sum(dim=(1, 2)) / area).mean()
+
+    @staticmethod
+    def _cropped_dice_loss(pred_logits, tgt_masks, boxes, eps=1e-6):
+        """Dice inside the GT box only (ref :404-450)."""
+        if pred_logits.shape[0] == 0:
+            return pred_logits.sum() * 0.0
+        _, h, w = pred_logits.shape
+        inside, _ = DFINECriterion._inside(boxes, h, w, pred_logits.device, pred_logits.dtype)
+        p = (pred_logits.sigmoid() * inside).flatten(1)
+        t = (tgt_masks * inside).flatten(1)
+        dice = 1.0 - (2.0 * (p * t).sum(1) + eps) / (p.sum(1) + t.sum(1) + eps)
+        return dice.mean()
+
+    @staticmethod
+    def _dice_loss(pred_logits, tgt_masks, eps=1e-6):
+        p = pred_logits.sigmoid().flatten(1)
+        t = tgt_masks.flatten(1)
+        dice = 1.0 - (2.0 * (p * t).sum(1) + eps) / (p.sum(1) + t.sum(1) + eps)
+        return dice.mean() if dice.numel() > 0 else pred_logits.sum() * 0.0
+
+    def loss_masks(self, outputs, targets, indices, num_boxes):
+        if "pred_masks" not in outputs:
+            return {}
+        pm = outputs["pred_masks"]
+        _, _, hm, wm = pm.shape
+        p = self._plan(indices, targets, pm.device)
+        if p.count == 0:
+            z = pm.sum() * 0
+            return {"loss_mask_bce": z, "loss_mask_dice": z}
+        sel = pm[p.batch, p.src]
+        tgt, valid = self._prepare_target_masks(targets, indices, hm, wm, device=pm.device)
+        if valid == 0:
+            z = sel.sum() * 0
+            return {"loss_mask_bce": z, "loss_mask_dice": z}
+        boxes = self._prepare_target_boxes_for_masks(targets, indices, hm, wm, device=pm.device)
+        if sel.shape[0] != tgt.shape[0]:
+            raise AssertionError(f"Mismatch between number of selected predictions ({sel.shape[0]})"
+                                 f"and target masks ({tgt.shape[0]})")
+        return {"loss_mask_bce": self._cropped_bce_loss(sel, tgt, boxes),
+                "loss_mask_dice": self._cropped_dice_loss(sel, tgt, boxes)}
+
+    # ------------------------------------------------------------------ GO indices
+    def _get_go_indices(self, indices, indices_aux_list):
+        """Union of the matchings of all heads; a query matched to different targets keeps the
+        target it was matched to most often (ref dfine_criterion.py:570-591, incl. the order
+        produced by torch.unique + torch.argsort(descending) on CPU)."""
+        results = []
+        for b in range(len(indices)):
+            rows = torch.cat([indices[b][0]] + [aux[b][0] for aux in indices_aux_list])
+            cols = torch.cat([indices[b][1]] + [aux[b][1] for aux in indices_aux_list])
+            pairs, counts = torch.unique(torch.stack([rows, cols], 1), return_counts=True, dim=0)
+            pairs = pairs[torch.argsort(counts, descending=True)].numpy()
+            seen = {}
+            for q, t in pairs:
+                if q not in seen:
+                    seen[q] = t
+            results.append((torch.tensor(list(seen.keys()), dtype=torch.int64),
+                            torch.tensor(list(seen.values()), dtype=torch.int64)))
+        return results
+
+    def get_loss(self, loss, outputs, targets, indices, num_boxes, **kwargs):
+        table = {"boxes": self.loss_boxes, "focal": self.loss_labels_focal,
+                 "vfl": self.loss_labels_vfl, "local": self.loss_local, "masks": self.loss_masks}
+        assert loss in table, f"do you really want to compute {loss} loss?"
+        return table[loss](outputs, targets, indices, num_boxes, **kwargs)
+
+    def _branch(self, outputs, targets, suffix, pick, losses_out, only_boxes_go=False):
+        """All configured losses of one prediction head; `pick(loss)` -> (indices, num_boxes)."""
+        for loss in self.losses:
+            idx, nb = pick(loss)
+            meta = self.get_loss_meta_info(loss, outputs, targets, idx)
+            ld = self.get_loss(loss, outputs, targets, idx, nb, **meta)
+            for k, v in ld.items():
+                if k in self.weight_dict:
+                    losses_out[k + suffix] = v * self.weight_dict[k]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, outputs, targets, **kwargs):
+        assert "aux_outputs" in outputs, ""
+        device = outputs["pred_logits"].device
+        main = {k: v for k, v in outputs.items() if "aux" not in k}
+        heads = [main] + list(outputs["aux_outputs"]) + [outputs["pre_outputs"]] + list(
+            outputs["enc_aux_outputs"])
+        if hasattr(self.matcher, "match_heads"):
+            matched = self.matcher.match_heads(heads, targets)
+        else:
+            matched = [self.matcher(h, targets)["indices"] for h in heads]
+        self._clear_cache()
+        self._tgt = None
+        n_aux = len(outputs["aux_outputs"])
+        indices = matched[0]
+        cached = matched[1: n_aux + 2]          # aux layers ... pre
+        cached_enc = matched[n_aux + 2:]
+        indices_go = self._get_go_indices(indices, matched[1:])
+
+        # the reference's two scalar all-reduces folded into one 2-float collective
+        counts = torch.tensor([float(sum(len(x[0]) for x in indices_go)),
+                               float(sum(len(t["labels"]) for t in targets))])
+        if is_dist_available_and_initialized():
+            counts = counts.to(device)
+            torch.distributed.all_reduce(counts)
+            counts = counts.cpu()
+        counts = torch.clamp(counts / get_world_size(), min=1)
+        num_boxes_go, num_boxes = counts[0].item(), counts[1].item()
+
+        def go_or(own, go_for=("boxes", "local")):
+            return lambda loss: (indices_go, num_boxes_go) if loss in go_for else (own, num_boxes)
+
+        losses = {}
+        self._branch(outputs, targets, "", go_or(indices), losses)
+
+        for i, aux in enumerate(outputs["aux_outputs"]):
+            aux["up"], aux["reg_scale"] = outputs["up"], outputs["reg_scale"]
+            self._branch(aux, targets, f"_aux_{i}", go_or(cached[i]), losses)
+
+        self._branch(outputs["pre_outputs"], targets, "_pre", go_or(cached[-1]), losses)
+
+        assert "enc_meta" in outputs, ""
+        agnostic = outputs["enc_meta"]["class_agnostic"]
+        enc_targets = targets
+        if agnostic:
+            orig_nc, self.num_classes = self.num_classes, 1
+            enc_targets = copy.deepcopy(targets)
+            for t in enc_targets:
+                t["labels"] = torch.zeros_like(t["labels"])
+            self._tgt = None
+        for i, aux in enumerate(outputs["enc_aux_outputs"]):
+            self._branch(aux, enc_targets, f"_enc_{i}", go_or(cached_enc[i], go_for=("boxes",)), losses)
+        if agnostic:
+            self.num_classes = orig_nc
+            self._tgt = None
+
+        if "dn_outputs" in outputs:
+            assert "dn_meta" in outputs, ""
+            indices_dn = self.get_cdn_matched_indices(outputs["dn_meta"], targets)
+            dn_boxes = num_boxes * outputs["dn_meta"]["dn_num_group"]
+            dn_boxes = dn_boxes if dn_boxes > 0 else 1
+            for i, aux in enumerate(outputs["dn_outputs"]):
+                aux["is_dn"] = True
+                aux["up"], aux["reg_scale"] = outputs["up"], outputs["reg_scale"]
+                self._branch(aux, targets, f"_dn_{i}", lambda loss: (indices_dn, dn_boxes), losses)
+            if "dn_pred_masks" in outputs and "masks" in self.losses:
+                final = {"pred_masks": outputs["dn_pred_masks"],
+                         "pred_boxes": outputs["dn_outputs"][-1]["pred_boxes"]}
+                for k, v in self.loss_masks(final, targets, indices_dn, dn_boxes).items():
+                    if k in self.weight_dict:
+                        losses[k + "_dn_final"] = v * self.weight_dict[k]
+            if "dn_pre_outputs" in outputs:
+                self._branch(outputs["dn_pre_outputs"], targets, "_dn_pre",
+                             lambda loss: (indices_dn, dn_boxes), losses)
+
+        return {k: torch.nan_to_num(v, nan=0.0) for k, v in losses.items()}
+
+    def get_loss_meta_info(self, loss, outputs, targets, indices):
+        if self.boxes_weight_format is None:
+            return {}
+        _, src, tgt = self._matched_boxes(outputs, targets, indices)
+        iou, giou = paired_iou_giou(box_cxcywh_to_xyxy(src.detach()), box_cxcywh_to_xyxy(tgt))
+        if self.boxes_weight_format == "iou":
+            val = iou
+        elif self.boxes_weight_format == "giou":
+            val = giou
+        else:
+            raise AttributeError()
+        if loss in ("boxes",):
+            return {"boxes_weight": val}
+        if loss in ("vfl",):
+            return {"values": val}
+        return {}
+
+    @staticmethod
+    def get_cdn_matched_indices(dn_meta, targets):
+        """Denoising queries are matched to their source GT by construction
+        (ref dfine_criterion.py:809-831)."""
+        pos, groups = dn_meta["dn_positive_idx"], dn_meta["dn_num_group"]
+        out = []
+        for i, t in enumerate(targets):
+            n = len(t["labels"])
+            if n > 0:
+                gt = torch.arange(n, dtype=torch.int64).tile(groups)
+                assert len(pos[i]) == len(gt)
+                out.append((pos[i].cpu(), gt))
+            else:
+                z = torch.zeros(0, dtype=torch.int64)
+                out.append((z, z))
+        return out
+
+    def feature_loss_function(self, fea, target_fea):
+        loss = (fea - target_fea) ** 2 * ((fea > 0) | (target_fea > 0)).float()
+        return torch.abs(loss)
+
+    def get_gradual_steps(self, outputs):
+        n = len(outputs["aux_outputs"]) + 1 if "aux_outputs" in outputs else 1
+        return [0.5 + 0.5 / (n - 1) * i for i in range(n)] if n > 1 else [1]

@@ -1,0 +1,122 @@
+"""torch.distributed helpers with the reference's names (`src/d_fine/dist_utils.py`).
+
+One process per GPU; backend "nccl" is RCCL on ROCm (xGMI between the 8 GPUs of a node),
+"gloo" on CPU-only hosts (used by the 2-process CPU tests).
+"""
+import os
+import warnings
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def is_dist_available_and_initialized() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def init_distributed_mode() -> None:
+    """torchrun-style env:// initialisation (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
+    if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
+        warnings.warn("DDP requested but RANK/WORLD_SIZE are not set; launch with "
+                      "`python -m torch.distributed.run --nproc-per-node N ...`")
+        return
+    if is_dist_available_and_initialized():
+        return
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if torch.cuda.is_available():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver
+        torch.cuda.set_device(local_rank)
+        try:
+            dist.init_process_group(backend="nccl", init_method="env://",
+                                    device_id=torch.device("cuda", local_rank))
+        except TypeError:
+            dist.init_process_group(backend="nccl", init_method="env://")
+    else:
+        dist.init_process_group(backend="gloo", init_method="env://")
+
+
+def cleanup_distributed() -> None:
+    if is_dist_available_and_initialized():
+        dist.destroy_process_group()
+
+
+def get_world_size() -> int:
+    return dist.get_world_size() if is_dist_available_and_initialized() else 1
+
+
+def get_rank() -> int:
+    return dist.get_rank() if is_dist_available_and_initialized() else 0
+
+
+def is_main_process() -> bool:
+    return get_rank() == 0
+
+
+def get_local_rank() -> int:
+    if "LOCAL_RANK" in os.environ:
+        return int(os.environ["LOCAL_RANK"])
+    if "RANK" in os.environ and torch.cuda.is_available():
+        return int(os.environ["RANK"]) % torch.cuda.device_count()
+    return 0
+
+
+def all_gather_object(obj):
+    if get_world_size() == 1:
+        return [obj]
+    out = [None] * get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def reduce_dict(input_dict, average: bool = True):
+    world = get_world_size()
+    if world < 2:
+        return input_dict
+    with torch.no_grad():
+        keys = sorted(input_dict.keys())
+        vals = torch.stack([input_dict[k] for k in keys])
+        dist.all_reduce(vals)
+        if average:
+            vals /= world
+        return dict(zip(keys, vals))
+
+
+def broadcast_scalar(value, src: int = 0):
+    if get_world_size() == 1:
+        return value
+    dev = (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available()
+           else torch.device("cpu"))
+    t = torch.tensor([float(value)], device=dev)
+    dist.broadcast(t, src=src)
+    return t.item()
+
+
+def _to_numpy_items(items):
+    return [{k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in it.items()}
+            for it in items]
+
+
+def _from_numpy_items(items):
+    return [{k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in it.items()}
+            for it in items]
+
+
+def gather_predictions(local_preds, local_gt):
+    """Gathers per-rank prediction / GT dict lists on rank 0 (others get (None, None))."""
+    if get_world_size() == 1:
+        return local_preds, local_gt
+    preds = all_gather_object(_to_numpy_items(local_preds))
+    gts = all_gather_object(_to_numpy_items(local_gt))
+    if get_rank() != 0:
+        return None, None
+    all_p, all_g = [], []
+    for p, g in zip(preds, gts):
+        all_p.extend(_from_numpy_items(p))
+        all_g.extend(_from_numpy_items(g))
+    return all_p, all_g
+
+
+def synchronize():
+    if get_world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,166 @@
+"""Torch-facing operators of the hot path.
+
+Every function here takes/returns torch tensors and, for CUDA(ROCm) tensors, launches the
+hand-written HIP kernels of `csrc/` through the C ABI (`custom_d_fine_amd.hip`, ctypes) on
+torch's current stream.  There is NO CPU implementation in the product: for a CPU tensor the
+HIP-backed operators raise, unless a test harness has installed the oracle backend
+(`oracle.torch_backend.install()` - used only by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg).
+
+Operators that are still composed from ATen calls (MIOpen convolutions, rocBLAS GEMMs, SDPA)
+are marked "ATen plumbing" - they run the same code on CPU and GPU and are the next ones to be
+replaced by HIP kernels (DESIGN.md "kernel status").
+"""
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_TEST_BACKEND = None  # set by oracle.torch_backend.install(); never by product code
+
+
+def _backend_for_cpu(op: str):
+    if _TEST_BACKEND is None:
+        raise RuntimeError(
+            f"custom_d_fine_amd.kernels.{op}: got a CPU tensor. This operator only exists as a "
+            "HIP kernel for gfx950 (MI355X); move the tensors to the GPU. (CPU execution is "
+            "available to the test-suite only, through oracle.torch_backend.install().)")
+    return getattr(_TEST_BACKEND, op)
+
+
+def _hip():
+    from . import hip  # raises loudly if libdfine_hip.so is missing / not loadable
+    return hip
+
+
+# =============================================================================================
+# A7  multi-scale deformable attention gather
+# =============================================================================================
+class _MSDA(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, value, loc, weight, shapes, points):
+        hip = _hip()
+        value = value.contiguous()
+        loc = loc.float().contiguous()
+        weight = weight.float().contiguous()
+        out = hip.msda_forward(value, loc, weight, shapes, points)
+        ctx.save_for_backward(value, loc, weight)
+        ctx.shapes, ctx.points = shapes, points
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        value, loc, weight = ctx.saved_tensors
+        gv, gl, gw = _hip().msda_backward(value, loc, weight, grad_out.contiguous(),
+                                          ctx.shapes, ctx.points)
+        return gv, gl, gw, None, None
+
+
+def msda(value: torch.Tensor, spatial_shapes, sampling_locations: torch.Tensor,
+         attention_weights: torch.Tensor, num_points_list: List[int]) -> torch.Tensor:
+    """value [B, sum(HW), H, hd]; sampling_locations [B, Lq, H, P, 2] in [0,1] (x, y);
+    attention_weights [B, Lq, H, P]; P = sum(num_points_list).  -> [B, Lq, H*hd] (value dtype).
+    Bilinear, zero padding, align_corners=False (pixel centre at (i+0.5)/size)."""
+    shapes = tuple((int(h), int(w)) for h, w in spatial_shapes)
+    points = tuple(int(p) for p in num_points_list)
+    if not value.is_cuda:
+        return _backend_for_cpu("msda")(value, shapes, sampling_locations, attention_weights, points)
+    return _MSDA.apply(value, sampling_locations, attention_weights, shapes, points)
+
+
+class _MSDAFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, value, ref, offsets, logits, shapes, points, offset_scale):
+        hip = _hip()
+        value = value.contiguous()
+        ref = ref.float().contiguous()
+        offsets = offsets.contiguous()
+        logits = logits.contiguous()
+        out = hip.msda_fused_forward(value, ref, offsets, logits, shapes, points, offset_scale)
+        ctx.save_for_backward(value, ref, offsets, logits)
+        ctx.cfg = (shapes, points, offset_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        value, ref, offsets, logits = ctx.saved_tensors
+        shapes, points, offset_scale = ctx.cfg
+        gv, goff, glog = _hip().msda_fused_backward(
+            value, ref, offsets, logits, grad_out.contiguous(), shapes, points, offset_scale)
+        return gv, None, goff, glog, None, None, None
+
+
+def msda_fused(value, spatial_shapes, ref_boxes, offsets, logits, num_points_list,
+               offset_scale: float = 0.5):
+    """Deformable gather with the location arithmetic and the point-softmax fused in:
+         loc = ref_xy + offsets * (1/points_of_level) * ref_wh * offset_scale
+         w   = softmax_P(logits)
+    value [B, L, H, hd]; ref_boxes [B, Lq, 4] cxcywh (no gradient: the decoder detaches them);
+    offsets [B, Lq, H, P, 2]; logits [B, Lq, H, P].  -> [B, Lq, H*hd]."""
+    shapes = tuple((int(h), int(w)) for h, w in spatial_shapes)
+    points = tuple(int(p) for p in num_points_list)
+    if not value.is_cuda:
+        return _backend_for_cpu("msda_fused")(value, shapes, ref_boxes, offsets, logits, points,
+                                              float(offset_scale))
+    return _MSDAFused.apply(value, ref_boxes.detach(), offsets, logits, shapes, points,
+                            float(offset_scale))
+
+
+# =============================================================================================
+# A11/A12  matcher: cost matrix + linear sum assignment, all heads of a step in one launch
+# =============================================================================================
+def hungarian_assign(logits: torch.Tensor, boxes: torch.Tensor, tgt_labels: torch.Tensor,
+                     tgt_boxes: torch.Tensor, sizes: List[int], w_class: float, w_bbox: float,
+                     w_giou: float, alpha: float, gamma: float, use_focal: bool = True,
+                     extra_cost: Optional[torch.Tensor] = None):
+    """logits [K, B, Q, C], boxes [K, B, Q, 4] (K prediction heads matched against the same
+    targets); tgt_labels [T] i64, tgt_boxes [T, 4] concatenated over the batch, `sizes` = targets
+    per image.  Returns (cols, cost): `cols` int32 [K, T] = the query assigned to every target
+    (-1 when an image has more targets than queries), `cost` [K, B, Q, Tmax] or None."""
+    if not logits.is_cuda:
+        return _backend_for_cpu("hungarian_assign")(
+            logits, boxes, tgt_labels, tgt_boxes, sizes, w_class, w_bbox, w_giou, alpha, gamma,
+            use_focal, extra_cost)
+    return _hip().hungarian_assign(logits, boxes, tgt_labels, tgt_boxes, sizes, w_class, w_bbox,
+                                   w_giou, alpha, gamma, use_focal, extra_cost)
+
+
+# =============================================================================================
+# ATen plumbing (same code on CPU and GPU) - to be replaced kernel by kernel
+# =============================================================================================
+def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Optional[nn.Module]):
+    """conv(bias=False) -> BN (batch stats in training) -> {None, relu, silu, gelu} -> scalar
+    affine.  A1/A2 building block.  [ATen plumbing: MIOpen conv + native batch_norm]"""
+    y = bn(conv(x))
+    if act is not None:
+        a = act.lower()
+        if a == "relu":
+            y = F.relu(y)
+        elif a in ("silu", "swish"):
+            y = F.silu(y)
+        elif a == "gelu":
+            y = F.gelu(y)
+        else:
+            raise RuntimeError(f"unsupported activation {act}")
+    if lab is not None:
+        y = lab.scale * y + lab.bias
+    return y
+
+
+def self_attention(qk, value, in_w, in_b, out_w, out_b, num_heads: int, attn_mask=None):
+    """Packed-QKV multi-head attention, q = k = `qk` (content+position), v = `value`;
+    boolean `attn_mask` [L, L], True = blocked.  [ATen plumbing: GEMM + SDPA]"""
+    b, l, e = qk.shape
+    hd = e // num_heads
+    q, k = F.linear(qk, in_w[: 2 * e], in_b[: 2 * e]).chunk(2, dim=-1)
+    v = F.linear(value, in_w[2 * e:], in_b[2 * e:])
+    q, k, v = (t.reshape(b, l, num_heads, hd).transpose(1, 2) for t in (q, k, v))
+    mask = None if attn_mask is None else ~attn_mask
+    o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+    return F.linear(o.transpose(1, 2).reshape(b, l, e), out_w, out_b)
+
+
+def topk_indices(score: torch.Tensor, k: int) -> torch.Tensor:
+    """Indices of the k largest entries per row, descending.  [ATen plumbing]"""
+    return torch.topk(score, k, dim=-1).indices

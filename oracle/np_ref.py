@@ -1,0 +1,239 @@
+"""numpy restatement of the reference arithmetic behind every HIP kernel - TEST ORACLE ONLY.
+
+Nothing here is imported by `custom_d_fine_amd`.  All functions are float32 unless noted and
+cite the reference (`/root/reference/src/d_fine/...`) lines they restate.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "_build", "liboracle.so")
+        if not os.path.exists(path):
+            import subprocess
+            subprocess.check_call(["make", "-C", _HERE, "-s"])
+        _LIB = ctypes.CDLL(path)
+        _LIB.oracle_lsap.restype = ctypes.c_int
+    return _LIB
+
+
+# ---------------------------------------------------------------------------------- A12 LSAP
+def lsap(cost):
+    """scipy.optimize.linear_sum_assignment restated in C (oracle/lsap.c); reference call sites
+    matcher.py:243,264.  cost [nr, nc] any float dtype -> (rows i64 ascending, cols i64)."""
+    c = np.ascontiguousarray(cost, dtype=np.float64)
+    nr, nc = c.shape
+    n = min(nr, nc)
+    rows = np.zeros(n, np.int64)
+    cols = np.zeros(n, np.int64)
+    if n == 0:
+        return rows, cols
+    ret = _lib().oracle_lsap(ctypes.c_int64(nr), ctypes.c_int64(nc),
+                             c.ctypes.data_as(ctypes.c_void_p),
+                             rows.ctypes.data_as(ctypes.c_void_p),
+                             cols.ctypes.data_as(ctypes.c_void_p))
+    if ret == -2:
+        raise ValueError("matrix contains invalid numeric entries")
+    if ret == -1:
+        raise ValueError("cost matrix is infeasible")
+    return rows, cols
+
+
+# ---------------------------------------------------------------------------------- A7 MSDA
+def _level_table(shapes, points):
+    """per sampling point: (level start row in value, H, W)."""
+    starts, hs, ws = [], [], []
+    off = 0
+    for (h, w), n in zip(shapes, points):
+        starts += [off] * n
+        hs += [h] * n
+        ws += [w] * n
+        off += h * w
+    return np.array(starts), np.array(hs), np.array(ws)
+
+
+def msda_forward(value, shapes, loc, weight, points):
+    """deformable_attention_core_func_v2 (arch/utils.py:191-264) for method="default":
+    per level F.grid_sample(value_l, 2*loc-1, bilinear, zeros, align_corners=False), i.e.
+    pixel coordinate = loc*size - 0.5, then sum_p weight * sample.
+
+    value [B, L, H, D] (row l of level k = start_k + y*W_k + x); loc [B, Lq, H, P, 2] (x, y);
+    weight [B, Lq, H, P] -> out [B, Lq, H*D] float32."""
+    value = np.asarray(value, np.float32)
+    loc = np.asarray(loc, np.float32)
+    weight = np.asarray(weight, np.float32)
+    B, L, H, D = value.shape
+    _, Lq, _, P, _ = loc.shape
+    start, hh, ww = _level_table(shapes, points)
+    x = loc[..., 0] * ww.astype(np.float32) - np.float32(0.5)
+    y = loc[..., 1] * hh.astype(np.float32) - np.float32(0.5)
+    x0 = np.floor(x)
+    y0 = np.floor(y)
+    fx = x - x0
+    fy = y - y0
+    out = np.zeros((B, Lq, H, D), np.float32)
+    bidx = np.arange(B)[:, None, None, None]
+    hidx = np.arange(H)[None, None, :, None]
+    for dy, dx in ((0, 0), (0, 1), (1, 0), (1, 1)):
+        xi = (x0 + dx).astype(np.int64)
+        yi = (y0 + dy).astype(np.int64)
+        wgt = (fx if dx else 1 - fx) * (fy if dy else 1 - fy)
+        ok = (xi >= 0) & (xi < ww) & (yi >= 0) & (yi < hh)
+        rows = start + np.clip(yi, 0, hh - 1) * ww + np.clip(xi, 0, ww - 1)
+        v = value[bidx, rows, hidx]                      # [B, Lq, H, P, D]
+        out += ((wgt * ok * weight)[..., None] * v).sum(3)
+    return out.reshape(B, Lq, H * D)
+
+
+def msda_backward(value, shapes, loc, weight, points, grad_out):
+    """Analytic gradients of msda_forward wrt value, loc, weight (what autograd derives from
+    grid_sample_backward + mul/sum in the reference).  Returns (g_value, g_loc, g_weight)."""
+    value = np.asarray(value, np.float32)
+    loc = np.asarray(loc, np.float32)
+    weight = np.asarray(weight, np.float32)
+    B, L, H, D = value.shape
+    _, Lq, _, P, _ = loc.shape
+    go = np.asarray(grad_out, np.float32).reshape(B, Lq, H, 1, D)
+    start, hh, ww = _level_table(shapes, points)
+    x = loc[..., 0] * ww.astype(np.float32) - np.float32(0.5)
+    y = loc[..., 1] * hh.astype(np.float32) - np.float32(0.5)
+    x0 = np.floor(x)
+    y0 = np.floor(y)
+    fx = x - x0
+    fy = y - y0
+    g_value = np.zeros_like(value)
+    g_w = np.zeros_like(weight)
+    g_x = np.zeros_like(weight)
+    g_y = np.zeros_like(weight)
+    bidx = np.broadcast_to(np.arange(B)[:, None, None, None], weight.shape)
+    hidx = np.broadcast_to(np.arange(H)[None, None, :, None], weight.shape)
+    for dy, dx in ((0, 0), (0, 1), (1, 0), (1, 1)):
+        xi = (x0 + dx).astype(np.int64)
+        yi = (y0 + dy).astype(np.int64)
+        wx = fx if dx else 1 - fx
+        wy = fy if dy else 1 - fy
+        ok = ((xi >= 0) & (xi < ww) & (yi >= 0) & (yi < hh)).astype(np.float32)
+        rows = start + np.clip(yi, 0, hh - 1) * ww + np.clip(xi, 0, ww - 1)
+        v = value[bidx, rows, hidx]                      # [B, Lq, H, P, D]
+        dot = (v * go).sum(-1) * ok                      # <grad_out, corner value>
+        g_w += wx * wy * dot
+        g_x += (1.0 if dx else -1.0) * wy * dot * weight
+        g_y += (1.0 if dy else -1.0) * wx * dot * weight
+        contrib = (wx * wy * ok * weight)[..., None] * go
+        np.add.at(g_value, (bidx, rows, hidx), contrib)
+    g_loc = np.stack([g_x * ww.astype(np.float32), g_y * hh.astype(np.float32)], -1)
+    return g_value, g_loc.astype(np.float32), g_w
+
+
+def softmax(x, axis=-1):
+    x = x - x.max(axis=axis, keepdims=True)
+    e = np.exp(x)
+    return e / e.sum(axis=axis, keepdims=True)
+
+
+def msda_prologue(ref, offsets, logits, points, offset_scale=0.5):
+    """MSDeformableAttention.forward, 4-d reference-box branch (dfine_decoder.py:147,156-166):
+    loc = ref_xy + offsets * (1/n_level) * ref_wh * offset_scale; w = softmax over points."""
+    scale = np.array([1.0 / n for n in points for _ in range(n)], np.float32)
+    ref = np.asarray(ref, np.float32)[:, :, None, None, :]            # [B,Lq,1,1,4]
+    off = np.asarray(offsets, np.float32) * scale[None, None, None, :, None] * ref[..., 2:] * \
+        np.float32(offset_scale)
+    return (ref[..., :2] + off).astype(np.float32), softmax(np.asarray(logits, np.float32), -1)
+
+
+# ---------------------------------------------------------------------------------- A11 costs
+def box_cxcywh_to_xyxy(b):
+    b = np.asarray(b, np.float32)
+    w = np.maximum(b[..., 2], 0) * np.float32(0.5)
+    h = np.maximum(b[..., 3], 0) * np.float32(0.5)
+    return np.stack([b[..., 0] - w, b[..., 1] - h, b[..., 0] + w, b[..., 1] + h], -1)
+
+
+def pairwise_iou_giou(a, b):
+    """box_iou / generalized_box_iou (arch/utils.py:12-51) on xyxy boxes a [N,4], b [M,4]."""
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = np.maximum(a[:, None, :2], b[None, :, :2])
+    rb = np.minimum(a[:, None, 2:], b[None, :, 2:])
+    wh = np.clip(rb - lt, 0, None)
+    inter = wh[..., 0] * wh[..., 1]
+    union = area_a[:, None] + area_b[None, :] - inter
+    iou = inter / union
+    lt2 = np.minimum(a[:, None, :2], b[None, :, :2])
+    rb2 = np.maximum(a[:, None, 2:], b[None, :, 2:])
+    wh2 = np.clip(rb2 - lt2, 0, None)
+    hull = wh2[..., 0] * wh2[..., 1]
+    return iou, iou - (hull - union) / hull
+
+
+def match_cost(logits, boxes, tgt_ids, tgt_boxes, w_class=2.0, w_bbox=5.0, w_giou=2.0,
+               alpha=0.25, gamma=2.0):
+    """HungarianMatcher cost block of ONE image (matcher.py:135-169,242), focal variant:
+    C = w_bbox * cdist_1(box, tgt) + w_class * (pos - neg) + w_giou * (-GIoU); NaN -> 1.
+    logits [Q, C], boxes [Q, 4] cxcywh, tgt_ids [T], tgt_boxes [T, 4] -> [Q, T] float32."""
+    x = np.asarray(logits, np.float32)
+    p = (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(np.float32)[:, np.asarray(tgt_ids)]
+    a, g = np.float32(alpha), np.float32(gamma)
+    neg = (1 - a) * (p ** g) * (-np.log(1 - p + np.float32(1e-8)))
+    pos = a * ((1 - p) ** g) * (-np.log(p + np.float32(1e-8)))
+    c_class = pos - neg
+    bx = np.asarray(boxes, np.float32)
+    tb = np.asarray(tgt_boxes, np.float32)
+    c_bbox = np.abs(bx[:, None, :] - tb[None, :, :]).sum(-1)
+    _, giou = pairwise_iou_giou(box_cxcywh_to_xyxy(bx), box_cxcywh_to_xyxy(tb))
+    c = np.float32(w_bbox) * c_bbox + np.float32(w_class) * c_class + np.float32(w_giou) * (-giou)
+    c = c.astype(np.float32)
+    c[np.isnan(c)] = 1.0
+    c[np.isposinf(c)] = np.finfo(np.float32).max
+    c[np.isneginf(c)] = np.finfo(np.float32).min
+    return c
+
+
+def hungarian(logits, boxes, tgt_ids, tgt_boxes, **kw):
+    """One image of HungarianMatcher.forward: cost block -> LSAP -> (query idx, target idx)."""
+    if len(tgt_ids) == 0:
+        z = np.zeros(0, np.int64)
+        return z, z
+    return lsap(match_cost(logits, boxes, tgt_ids, tgt_boxes, **kw))
+
+
+# ---------------------------------------------------------------------------------- A8 FDR
+def weighting_function(reg_max, up, reg_scale):
+    """W(n) (arch/utils.py:145-188), float32 like the reference's tensor arithmetic."""
+    up = np.float32(abs(up))
+    rs = np.float32(abs(reg_scale))
+    b1 = up * rs
+    b2 = b1 * np.float32(2)
+    step = np.float32((b1 + np.float32(1)) ** np.float32(2 / (reg_max - 2)))
+    half = reg_max // 2
+    neg = [-(step ** np.float32(i)) + np.float32(1) for i in range(half - 1, 0, -1)]
+    pos = [step ** np.float32(i) - np.float32(1) for i in range(1, half)]
+    return np.array([-b2] + neg + [0.0] + pos + [b2], np.float32)
+
+
+def integral(corners, project):
+    """Integral.forward (dfine_decoder.py:291-295): softmax over reg_max+1 bins . W(n)."""
+    nb = project.shape[0]
+    p = softmax(np.asarray(corners, np.float32).reshape(-1, nb), -1)
+    return (p @ project.astype(np.float32)).reshape(list(corners.shape[:-1]) + [-1])
+
+
+def distance2bbox(points, distance, reg_scale):
+    """arch/utils.py:119-142."""
+    rs = np.float32(abs(reg_scale))
+    p = np.asarray(points, np.float32)
+    d = np.asarray(distance, np.float32)
+    x1 = p[..., 0] - (np.float32(0.5) * rs + d[..., 0]) * (p[..., 2] / rs)
+    y1 = p[..., 1] - (np.float32(0.5) * rs + d[..., 1]) * (p[..., 3] / rs)
+    x2 = p[..., 0] + (np.float32(0.5) * rs + d[..., 2]) * (p[..., 2] / rs)
+    y2 = p[..., 1] + (np.float32(0.5) * rs + d[..., 3]) * (p[..., 3] / rs)
+    return np.stack([(x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1], -1)
