@@ -1,0 +1,64 @@
+// Shared helpers of the gfx950 kernels (wave = 64 lanes, 256 CUs in 8 XCDs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dfine_hip.h"
+
+namespace dfine {
+
+void set_last_error(hipError_t e);
+
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error(e);
+        return DFINE_E_LAUNCH;
+    }
+    return DFINE_OK;
+}
+
+// ---- bf16 <-> f32 (round to nearest even), raw 16-bit storage ------------------------------
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+struct f32x4 { float x, y, z, w; };
+
+// 4 consecutive channels -> fp32, for the two storage types
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ f32x4 load(const float *p) {
+        float4 v = *reinterpret_cast<const float4 *>(p);
+        return {v.x, v.y, v.z, v.w};
+    }
+    static __device__ __forceinline__ void store(float *p, f32x4 v) {
+        *reinterpret_cast<float4 *>(p) = make_float4(v.x, v.y, v.z, v.w);
+    }
+};
+template <> struct Vec4<uint16_t> {
+    static __device__ __forceinline__ f32x4 load(const uint16_t *p) {
+        uint2 v = *reinterpret_cast<const uint2 *>(p);
+        return {__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+    }
+    static __device__ __forceinline__ void store(uint16_t *p, f32x4 v) {
+        uint2 o;
+        o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+        o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+        *reinterpret_cast<uint2 *>(p) = o;
+    }
+};
+
+template <typename T> __device__ __forceinline__ float load_f(const T *p);
+template <> __device__ __forceinline__ float load_f<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float load_f<uint16_t>(const uint16_t *p) { return bf16_to_f32(*p); }
+template <typename T> __device__ __forceinline__ void store_f(T *p, float v);
+template <> __device__ __forceinline__ void store_f<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_f<uint16_t>(uint16_t *p, float v) { *p = f32_to_bf16(v); }
+
+}  // namespace dfine

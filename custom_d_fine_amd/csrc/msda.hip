@@ -1,0 +1,411 @@
+// A7 - multi-scale deformable attention gather, forward + backward, for gfx950.
+//
+// Reference semantics: deformable_attention_core_func_v2 (src/d_fine/arch/utils.py:191-264) =
+// per level F.grid_sample(value_l, 2*loc-1, bilinear, padding zeros, align_corners=False), i.e.
+// pixel coordinate = loc * size - 0.5, followed by sum_p weight_p * sample_p; the FUSED
+// variant also does MSDeformableAttention.forward's softmax over the P points and
+// loc = ref_xy + offset * (1/points_of_level) * ref_wh * offset_scale
+// (src/d_fine/arch/dfine_decoder.py:147,156-166).
+//
+// Data layout / mapping (HBM-bound gather, no MFMA):
+//  * value stays [B, L, H, D] - the encoder memory itself; the D channels of one (pixel, head)
+//    are one contiguous 64 B (bf16) / 128 B (f32) segment, read by D/4 adjacent lanes with one
+//    8 B / 16 B load each.
+//  * a "task" is one (b, q, head); D/4 lanes own a task and walk its P points x 4 corners with
+//    fp32 accumulation in registers; a 256-thread block owns 1024/D consecutive (b,q) of ONE
+//    head.
+//  * head = blockIdx % H: with H = 8 the dispatcher's round-robin (block b -> XCD b % 8) pins
+//    one head per XCD, so each XCD's 4 MiB L2 only ever sees its own 1/8 slice of `value`
+//    (0.5 MB bf16 per image) - placement affects speed only, never results.
+//  * sampling coordinates / weights of the block's tasks are staged once through LDS with
+//    coalesced loads (fused mode: raw offsets + logits, softmax done from LDS).
+//  * backward: same walk; d(value) by hardware f32 atomics into an f32 accumulator (zeroed by the
+//    caller), d(loc)/d(weight) reduced over the task's lanes with wave shuffles.
+#include "common.h"
+
+namespace dfine {
+
+struct MsdaLevels {
+    int n_points;                       // P
+    int start[DFINE_MAX_POINTS];        // first value row of the point's level
+    int h[DFINE_MAX_POINTS];
+    int w[DFINE_MAX_POINTS];
+    float inv_n[DFINE_MAX_POINTS];      // 1 / (points of that level)
+};
+
+constexpr int kThreads = 256;
+
+// -------------------------------------------------------------------------------------------
+// stage (x, y, w) of the block's tasks into LDS.  s_x/s_y/s_w are [QPB][P].
+// FUSED: x,y = sampling location from ref box + offsets; w = raw logit (softmax later).
+template <typename T, bool FUSED>
+__device__ __forceinline__ void stage_points(const MsdaLevels &lv, const float *__restrict__ loc,
+                                             const float *__restrict__ weight,
+                                             const float *__restrict__ ref,
+                                             const T *__restrict__ offsets,
+                                             const T *__restrict__ logits, float offset_scale,
+                                             int head, int H, int q0, int nq, int total_q,
+                                             float *s_x, float *s_y, float *s_w) {
+    const int P = lv.n_points;
+    for (int i = threadIdx.x; i < nq * P; i += kThreads) {
+        const int qi = i / P, p = i - qi * P;
+        const int64_t task = (int64_t)(q0 + qi) * H + head;
+        if (FUSED) {
+            const float4 r = *reinterpret_cast<const float4 *>(ref + (int64_t)(q0 + qi) * 4);
+            const float ox = load_f(offsets + (task * P + p) * 2);
+            const float oy = load_f(offsets + (task * P + p) * 2 + 1);
+            // same association as the reference: ((off * scale) * ref_wh) * offset_scale
+            s_x[i] = r.x + ox * lv.inv_n[p] * r.z * offset_scale;
+            s_y[i] = r.y + oy * lv.inv_n[p] * r.w * offset_scale;
+            s_w[i] = load_f(logits + task * P + p);
+        } else {
+            s_x[i] = loc[(task * P + p) * 2];
+            s_y[i] = loc[(task * P + p) * 2 + 1];
+            s_w[i] = weight[task * P + p];
+        }
+    }
+}
+
+struct Corner {
+    int64_t row[4];   // value row (clamped) of the 4 corners, order (y0,x0) (y0,x1) (y1,x0) (y1,x1)
+    float bw[4];      // bilinear weight, 0 when the corner is outside the map
+    float wx0, wx1, wy0, wy1;
+    float ok[4];
+};
+
+__device__ __forceinline__ Corner corners(float lx, float ly, int start, int h, int w) {
+    Corner c;
+    const float x = lx * (float)w - 0.5f, y = ly * (float)h - 0.5f;
+    const float xf = floorf(x), yf = floorf(y);
+    const float fx = x - xf, fy = y - yf;
+    // clamp before the int conversion so wild coordinates (inf/NaN offsets) stay defined
+    const int x0 = (int)fminf(fmaxf(xf, -2.f), (float)w + 1.f);
+    const int y0 = (int)fminf(fmaxf(yf, -2.f), (float)h + 1.f);
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    c.wx0 = 1.f - fx; c.wx1 = fx; c.wy0 = 1.f - fy; c.wy1 = fy;
+    const bool vx0 = x0 >= 0 && x0 < w, vx1 = x1 >= 0 && x1 < w;
+    const bool vy0 = y0 >= 0 && y0 < h, vy1 = y1 >= 0 && y1 < h;
+    const int cx0 = min(max(x0, 0), w - 1), cx1 = min(max(x1, 0), w - 1);
+    const int cy0 = min(max(y0, 0), h - 1), cy1 = min(max(y1, 0), h - 1);
+    c.row[0] = start + cy0 * w + cx0; c.row[1] = start + cy0 * w + cx1;
+    c.row[2] = start + cy1 * w + cx0; c.row[3] = start + cy1 * w + cx1;
+    c.ok[0] = (vy0 && vx0) ? 1.f : 0.f; c.ok[1] = (vy0 && vx1) ? 1.f : 0.f;
+    c.ok[2] = (vy1 && vx0) ? 1.f : 0.f; c.ok[3] = (vy1 && vx1) ? 1.f : 0.f;
+    c.bw[0] = c.wy0 * c.wx0 * c.ok[0]; c.bw[1] = c.wy0 * c.wx1 * c.ok[1];
+    c.bw[2] = c.wy1 * c.wx0 * c.ok[2]; c.bw[3] = c.wy1 * c.wx1 * c.ok[3];
+    return c;
+}
+
+// -------------------------------------------------------------------------------------------
+template <typename T, int D, bool FUSED>
+__global__ __launch_bounds__(kThreads) void msda_fwd_kernel(
+    const T *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ weight,
+    const float *__restrict__ ref, const T *__restrict__ offsets, const T *__restrict__ logits,
+    T *__restrict__ out, MsdaLevels lv, int L, int H, int Lq, int total_q, float offset_scale) {
+    constexpr int LPT = D / 4;              // lanes per task
+    constexpr int QPB = kThreads / LPT;     // (b,q) pairs per block
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int P = lv.n_points;
+    float *s_x = smem, *s_y = smem + QPB * P, *s_w = smem + 2 * QPB * P;
+
+    const int head = blockIdx.x % H;
+    const int q0 = (blockIdx.x / H) * QPB;
+    const int nq = min(QPB, total_q - q0);
+    stage_points<T, FUSED>(lv, loc, weight, ref, offsets, logits, offset_scale, head, H, q0, nq,
+                           total_q, s_x, s_y, s_w);
+    __syncthreads();
+
+    const int qi = threadIdx.x / LPT, c4 = (threadIdx.x % LPT) * 4;
+    if (qi >= nq) return;
+    const int gq = q0 + qi;                 // = b * Lq + q
+    const int b = gq / Lq;
+    const T *vbase = value + ((int64_t)b * L * H + head) * D + c4;
+    const float *px = s_x + qi * P, *py = s_y + qi * P, *pw = s_w + qi * P;
+
+    float wmax = 0.f, winv = 1.f;
+    if (FUSED) {
+        wmax = pw[0];
+        for (int p = 1; p < P; ++p) wmax = fmaxf(wmax, pw[p]);
+        float s = 0.f;
+        for (int p = 0; p < P; ++p) s += __expf(pw[p] - wmax);
+        winv = 1.f / s;
+    }
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int p = 0; p < P; ++p) {
+        const Corner c = corners(px[p], py[p], lv.start[p], lv.h[p], lv.w[p]);
+        const float aw = FUSED ? __expf(pw[p] - wmax) * winv : pw[p];
+        const int64_t stride = (int64_t)H * D;
+        const f32x4 v0 = Vec4<T>::load(vbase + c.row[0] * stride);
+        const f32x4 v1 = Vec4<T>::load(vbase + c.row[1] * stride);
+        const f32x4 v2 = Vec4<T>::load(vbase + c.row[2] * stride);
+        const f32x4 v3 = Vec4<T>::load(vbase + c.row[3] * stride);
+        const float w0 = aw * c.bw[0], w1 = aw * c.bw[1], w2 = aw * c.bw[2], w3 = aw * c.bw[3];
+        acc.x += w0 * v0.x + w1 * v1.x + w2 * v2.x + w3 * v3.x;
+        acc.y += w0 * v0.y + w1 * v1.y + w2 * v2.y + w3 * v3.y;
+        acc.z += w0 * v0.z + w1 * v1.z + w2 * v2.z + w3 * v3.z;
+        acc.w += w0 * v0.w + w1 * v1.w + w2 * v2.w + w3 * v3.w;
+    }
+    Vec4<T>::store(out + ((int64_t)gq * H + head) * D + c4, acc);
+}
+
+// -------------------------------------------------------------------------------------------
+template <int LPT> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int m = LPT / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+template <typename T, int D, bool FUSED>
+__global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
+    const T *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ weight,
+    const float *__restrict__ ref, const T *__restrict__ offsets, const T *__restrict__ logits,
+    const T *__restrict__ grad_out, float *__restrict__ grad_value, float *__restrict__ grad_loc,
+    float *__restrict__ grad_weight, T *__restrict__ grad_offsets, T *__restrict__ grad_logits,
+    MsdaLevels lv, int L, int H, int Lq, int total_q, float offset_scale) {
+    constexpr int LPT = D / 4;
+    constexpr int QPB = kThreads / LPT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int P = lv.n_points;
+    float *s_x = smem, *s_y = smem + QPB * P, *s_w = smem + 2 * QPB * P;
+    float *s_gx = smem + 3 * QPB * P, *s_gy = smem + 4 * QPB * P, *s_gw = smem + 5 * QPB * P;
+    float *s_dot = smem + 6 * QPB * P;      // [QPB] sum_p w_p * gw_p  (softmax backward)
+
+    const int head = blockIdx.x % H;
+    const int q0 = (blockIdx.x / H) * QPB;
+    const int nq = min(QPB, total_q - q0);
+    stage_points<T, FUSED>(lv, loc, weight, ref, offsets, logits, offset_scale, head, H, q0, nq,
+                           total_q, s_x, s_y, s_w);
+    __syncthreads();
+
+    const int qi = threadIdx.x / LPT, sub = threadIdx.x % LPT, c4 = sub * 4;
+    if (qi < nq) {
+        const int gq = q0 + qi;
+        const int b = gq / Lq;
+        const int64_t stride = (int64_t)H * D;
+        const int64_t base = ((int64_t)b * L * H + head) * D + c4;
+        const T *vbase = value + base;
+        float *gvbase = grad_value + base;
+        float *px = s_x + qi * P, *py = s_y + qi * P, *pw = s_w + qi * P;
+        const f32x4 go = Vec4<T>::load(grad_out + ((int64_t)gq * H + head) * D + c4);
+
+        float wmax = 0.f, winv = 1.f;
+        if (FUSED) {
+            wmax = pw[0];
+            for (int p = 1; p < P; ++p) wmax = fmaxf(wmax, pw[p]);
+            float s = 0.f;
+            for (int p = 0; p < P; ++p) s += __expf(pw[p] - wmax);
+            winv = 1.f / s;
+        }
+        float dot_acc = 0.f;
+        for (int p = 0; p < P; ++p) {
+            const Corner c = corners(px[p], py[p], lv.start[p], lv.h[p], lv.w[p]);
+            const float aw = FUSED ? __expf(pw[p] - wmax) * winv : pw[p];
+            float d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 v = Vec4<T>::load(vbase + c.row[k] * stride);
+                d[k] = (go.x * v.x + go.y * v.y + go.z * v.z + go.w * v.w) * c.ok[k];
+                const float g = aw * c.bw[k];
+                if (g != 0.f) {
+                    float *dst = gvbase + c.row[k] * stride;
+                    unsafeAtomicAdd(dst + 0, g * go.x);
+                    unsafeAtomicAdd(dst + 1, g * go.y);
+                    unsafeAtomicAdd(dst + 2, g * go.z);
+                    unsafeAtomicAdd(dst + 3, g * go.w);
+                }
+            }
+            // partial (over this lane's 4 channels) gradients wrt weight, x, y
+            float gw = c.wy0 * c.wx0 * d[0] + c.wy0 * c.wx1 * d[1] + c.wy1 * c.wx0 * d[2] + c.wy1 * c.wx1 * d[3];
+            float gx = (c.wy0 * (d[1] - d[0]) + c.wy1 * (d[3] - d[2])) * aw * (float)lv.w[p];
+            float gy = (c.wx0 * (d[2] - d[0]) + c.wx1 * (d[3] - d[1])) * aw * (float)lv.h[p];
+            gw = group_sum<LPT>(gw);
+            gx = group_sum<LPT>(gx);
+            gy = group_sum<LPT>(gy);
+            dot_acc += aw * gw;
+            if (sub == 0) {
+                s_gx[qi * P + p] = gx; s_gy[qi * P + p] = gy; s_gw[qi * P + p] = gw;
+                if (FUSED) pw[p] = aw;      // logits no longer needed: keep the softmax weight
+            }
+        }
+        if (sub == 0) s_dot[qi] = dot_acc;
+    }
+    __syncthreads();
+
+    // coalesced write-out of the per-point gradients
+    for (int i = threadIdx.x; i < nq * P; i += kThreads) {
+        const int qj = i / P, p = i - qj * P;
+        const int64_t task = (int64_t)(q0 + qj) * H + head;
+        if (FUSED) {
+            const float4 r = *reinterpret_cast<const float4 *>(ref + (int64_t)(q0 + qj) * 4);
+            const float sc = lv.inv_n[p] * offset_scale;
+            store_f(grad_offsets + (task * P + p) * 2, s_gx[i] * sc * r.z);
+            store_f(grad_offsets + (task * P + p) * 2 + 1, s_gy[i] * sc * r.w);
+            store_f(grad_logits + task * P + p, s_w[i] * (s_gw[i] - s_dot[qj]));
+        } else {
+            grad_loc[(task * P + p) * 2] = s_gx[i];
+            grad_loc[(task * P + p) * 2 + 1] = s_gy[i];
+            grad_weight[task * P + p] = s_gw[i];
+        }
+    }
+}
+
+__global__ void cast_f32_bf16_kernel(const float *__restrict__ src, uint16_t *__restrict__ dst, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += step) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + i);
+        Vec4<uint16_t>::store(dst + i, {v.x, v.y, v.z, v.w});
+    }
+    if (i < n && i + 3 >= n) for (int64_t j = i; j < n; ++j) dst[j] = f32_to_bf16(src[j]);
+}
+
+// -------------------------------------------------------------------------------------------
+static int fill_levels(MsdaLevels &lv, int L, int n_levels, const int *hw, const int *pts) {
+    if (n_levels < 1 || n_levels > DFINE_MAX_LEVELS || !hw || !pts) return DFINE_E_BADARG;
+    int p = 0, row = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const int h = hw[2 * l], w = hw[2 * l + 1], n = pts[l];
+        if (h < 1 || w < 1 || n < 1 || p + n > DFINE_MAX_POINTS) return DFINE_E_BADARG;
+        for (int k = 0; k < n; ++k, ++p) {
+            lv.start[p] = row; lv.h[p] = h; lv.w[p] = w; lv.inv_n[p] = 1.0f / (float)n;
+        }
+        row += h * w;
+    }
+    if (row != L) return DFINE_E_BADARG;
+    lv.n_points = p;
+    return DFINE_OK;
+}
+
+template <typename T, bool FUSED>
+static int launch_fwd(const void *value, const float *loc, const float *weight, const float *ref,
+                      const void *offsets, const void *logits, void *out, int B, int L, int H,
+                      int D, int Lq, const MsdaLevels &lv, float offset_scale, hipStream_t st) {
+    const int total_q = B * Lq;
+    if (total_q == 0) return DFINE_OK;
+#define DFINE_FWD(DD)                                                                          \
+    {                                                                                          \
+        constexpr int QPB = kThreads / (DD / 4);                                               \
+        const int nblk = ((total_q + QPB - 1) / QPB) * H;                                      \
+        const size_t sm = sizeof(float) * 3 * QPB * lv.n_points;                               \
+        hipLaunchKernelGGL((msda_fwd_kernel<T, DD, FUSED>), dim3(nblk), dim3(kThreads), sm, st, \
+                           (const T *)value, loc, weight, ref, (const T *)offsets,             \
+                           (const T *)logits, (T *)out, lv, L, H, Lq, total_q, offset_scale);  \
+    }
+    if (D == 32) DFINE_FWD(32) else if (D == 16) DFINE_FWD(16) else if (D == 64) DFINE_FWD(64)
+    else return DFINE_E_BADARG;
+#undef DFINE_FWD
+    return check_launch();
+}
+
+template <typename T, bool FUSED>
+static int launch_bwd(const void *value, const float *loc, const float *weight, const float *ref,
+                      const void *offsets, const void *logits, const void *grad_out,
+                      float *grad_value, float *grad_loc, float *grad_weight, void *grad_offsets,
+                      void *grad_logits, int B, int L, int H, int D, int Lq, const MsdaLevels &lv,
+                      float offset_scale, hipStream_t st) {
+    const int total_q = B * Lq;
+    if (total_q == 0) return DFINE_OK;
+#define DFINE_BWD(DD)                                                                          \
+    {                                                                                          \
+        constexpr int QPB = kThreads / (DD / 4);                                               \
+        const int nblk = ((total_q + QPB - 1) / QPB) * H;                                      \
+        const size_t sm = sizeof(float) * (6 * QPB * lv.n_points + QPB);                       \
+        hipLaunchKernelGGL((msda_bwd_kernel<T, DD, FUSED>), dim3(nblk), dim3(kThreads), sm, st, \
+                           (const T *)value, loc, weight, ref, (const T *)offsets,             \
+                           (const T *)logits, (const T *)grad_out, grad_value, grad_loc,       \
+                           grad_weight, (T *)grad_offsets, (T *)grad_logits, lv, L, H, Lq,     \
+                           total_q, offset_scale);                                             \
+    }
+    if (D == 32) DFINE_BWD(32) else if (D == 16) DFINE_BWD(16) else if (D == 64) DFINE_BWD(64)
+    else return DFINE_E_BADARG;
+#undef DFINE_BWD
+    return check_launch();
+}
+
+}  // namespace dfine
+
+using namespace dfine;
+
+extern "C" {
+
+int dfine_msda_fwd(const void *value, const float *loc, const float *weight, void *out, int dtype,
+                   int B, int L, int H, int D, int Lq, int n_levels, const int *level_hw,
+                   const int *level_points, void *stream) {
+    if (!value || !loc || !weight || !out || B < 0 || Lq < 0 || H < 1) return DFINE_E_BADARG;
+    MsdaLevels lv;
+    if (int e = fill_levels(lv, L, n_levels, level_hw, level_points)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DFINE_F32)
+        return launch_fwd<float, false>(value, loc, weight, nullptr, nullptr, nullptr, out, B, L, H, D, Lq, lv, 0.f, st);
+    if (dtype == DFINE_BF16)
+        return launch_fwd<uint16_t, false>(value, loc, weight, nullptr, nullptr, nullptr, out, B, L, H, D, Lq, lv, 0.f, st);
+    return DFINE_E_BADARG;
+}
+
+int dfine_msda_bwd(const void *value, const float *loc, const float *weight, const void *grad_out,
+                   float *grad_value_f32, float *grad_loc, float *grad_weight, int dtype, int B,
+                   int L, int H, int D, int Lq, int n_levels, const int *level_hw,
+                   const int *level_points, void *stream) {
+    if (!value || !loc || !weight || !grad_out || !grad_value_f32 || !grad_loc || !grad_weight ||
+        B < 0 || Lq < 0 || H < 1)
+        return DFINE_E_BADARG;
+    MsdaLevels lv;
+    if (int e = fill_levels(lv, L, n_levels, level_hw, level_points)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DFINE_F32)
+        return launch_bwd<float, false>(value, loc, weight, nullptr, nullptr, nullptr, grad_out, grad_value_f32,
+                                        grad_loc, grad_weight, nullptr, nullptr, B, L, H, D, Lq, lv, 0.f, st);
+    if (dtype == DFINE_BF16)
+        return launch_bwd<uint16_t, false>(value, loc, weight, nullptr, nullptr, nullptr, grad_out, grad_value_f32,
+                                           grad_loc, grad_weight, nullptr, nullptr, B, L, H, D, Lq, lv, 0.f, st);
+    return DFINE_E_BADARG;
+}
+
+int dfine_msda_fused_fwd(const void *value, const float *ref, const void *offsets, const void *logits,
+                         void *out, int dtype, int B, int L, int H, int D, int Lq, int n_levels,
+                         const int *level_hw, const int *level_points, float offset_scale, void *stream) {
+    if (!value || !ref || !offsets || !logits || !out || B < 0 || Lq < 0 || H < 1) return DFINE_E_BADARG;
+    MsdaLevels lv;
+    if (int e = fill_levels(lv, L, n_levels, level_hw, level_points)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DFINE_F32)
+        return launch_fwd<float, true>(value, nullptr, nullptr, ref, offsets, logits, out, B, L, H, D, Lq, lv, offset_scale, st);
+    if (dtype == DFINE_BF16)
+        return launch_fwd<uint16_t, true>(value, nullptr, nullptr, ref, offsets, logits, out, B, L, H, D, Lq, lv, offset_scale, st);
+    return DFINE_E_BADARG;
+}
+
+int dfine_msda_fused_bwd(const void *value, const float *ref, const void *offsets, const void *logits,
+                         const void *grad_out, float *grad_value_f32, void *grad_offsets,
+                         void *grad_logits, int dtype, int B, int L, int H, int D, int Lq, int n_levels,
+                         const int *level_hw, const int *level_points, float offset_scale, void *stream) {
+    if (!value || !ref || !offsets || !logits || !grad_out || !grad_value_f32 || !grad_offsets ||
+        !grad_logits || B < 0 || Lq < 0 || H < 1)
+        return DFINE_E_BADARG;
+    MsdaLevels lv;
+    if (int e = fill_levels(lv, L, n_levels, level_hw, level_points)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DFINE_F32)
+        return launch_bwd<float, true>(value, nullptr, nullptr, ref, offsets, logits, grad_out, grad_value_f32,
+                                       nullptr, nullptr, grad_offsets, grad_logits, B, L, H, D, Lq, lv, offset_scale, st);
+    if (dtype == DFINE_BF16)
+        return launch_bwd<uint16_t, true>(value, nullptr, nullptr, ref, offsets, logits, grad_out, grad_value_f32,
+                                          nullptr, nullptr, grad_offsets, grad_logits, B, L, H, D, Lq, lv, offset_scale, st);
+    return DFINE_E_BADARG;
+}
+
+int dfine_cast_f32_to_bf16(const float *src, void *dst, int64_t n, void *stream) {
+    if (n == 0) return DFINE_OK;
+    if (!src || !dst || n < 0) return DFINE_E_BADARG;
+    const int threads = 256;
+    int64_t blocks = (n / 4 + threads - 1) / threads;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(threads), 0,
+                       (hipStream_t)stream, src, (uint16_t *)dst, n);
+    return check_launch();
+}
+
+}  // extern "C"

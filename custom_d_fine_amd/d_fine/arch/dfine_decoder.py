@@ -173,8 +173,11 @@ class Integral(nn.Module):
 
     def forward(self, x, project):
         lead = list(x.shape[:-1])
-        p = F.softmax(x.reshape(-1, self.reg_max + 1), dim=1)
-        return F.linear(p, project.to(x.device)).reshape(lead + [-1])
+        # always fp32: under autocast the reference runs this 33-term dot product in half
+        # precision (F.linear is autocast-eligible), which costs ~3 digits of box position
+        with torch.autocast(x.device.type, enabled=False):
+            p = F.softmax(x.float().reshape(-1, self.reg_max + 1), dim=1)
+            return F.linear(p, project.to(x.device).float()).reshape(lead + [-1])
 
 
 class LQE(nn.Module):

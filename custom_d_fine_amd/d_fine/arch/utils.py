@@ -193,6 +193,30 @@ def deformable_attention_core_func_v2(
 
 
 # ------------------------------------------------------------------ contrastive denoising
+_NOISE_GENERATOR = None
+
+
+def set_denoising_generator(gen):
+    """Parity hook: draw the denoising noise from the CPU generator `gen` (then move it to the
+    targets' device) instead of the device RNG, so that a CPU run and a GPU run - or the
+    reference and this build - see identical noise.  `None` restores the device RNG."""
+    global _NOISE_GENERATOR
+    _NOISE_GENERATOR = gen
+
+
+def _rand_like(t, dtype=None):
+    if _NOISE_GENERATOR is None:
+        return torch.rand_like(t, dtype=dtype)
+    return torch.rand(t.shape, generator=_NOISE_GENERATOR, dtype=dtype or t.dtype).to(t.device)
+
+
+def _randint_like(t, low, high, dtype=None):
+    if _NOISE_GENERATOR is None:
+        return torch.randint_like(t, low, high, dtype=dtype)
+    return torch.randint(low, high, t.shape, generator=_NOISE_GENERATOR,
+                         dtype=dtype or t.dtype).to(t.device)
+
+
 def get_contrastive_denoising_training_group(
     targets, num_classes, num_queries, class_embed, num_denoising=100,
     label_noise_ratio=0.5, box_noise_scale=1.0,
@@ -238,15 +262,15 @@ def get_contrastive_denoising_training_group(
     total = int(gmax * 2 * groups)
 
     if label_noise_ratio > 0:
-        flip = torch.rand_like(cls, dtype=torch.float) < (label_noise_ratio * 0.5)
-        rnd = torch.randint_like(flip, 0, num_classes, dtype=cls.dtype)
+        flip = _rand_like(cls, dtype=torch.float) < (label_noise_ratio * 0.5)
+        rnd = _randint_like(flip, 0, num_classes, dtype=cls.dtype)
         cls = torch.where(flip & valid, rnd, cls)
 
     if box_noise_scale > 0:
         xyxy = box_cxcywh_to_xyxy(box)
         span = torch.tile(box[..., 2:] * 0.5, [1, 1, 2]) * box_noise_scale
-        sign = torch.randint_like(box, 0, 2) * 2.0 - 1.0
-        mag = torch.rand_like(box)
+        sign = _randint_like(box, 0, 2) * 2.0 - 1.0
+        mag = _rand_like(box)
         mag = (mag + 1.0) * neg + mag * (1 - neg)
         xyxy = torch.clip(xyxy + sign * mag * span, min=0.0, max=1.0)
         box = box_xyxy_to_cxcywh(xyxy)

@@ -346,8 +346,27 @@ class DFINECriterion(nn.Module):
                     losses_out[k + suffix] = v * self.weight_dict[k]
 
     # ------------------------------------------------------------------ forward
+    @staticmethod
+    def _upcast(obj, memo):
+        """fp32 view of a (nested) head dict.  The model may run under bf16 autocast; the loss is
+        always evaluated in fp32 (reference train.py:572-573 disables autocast around the loss).
+        Tensor identity is preserved through `memo` (the DDF teacher check relies on it)."""
+        if isinstance(obj, torch.Tensor):
+            if not obj.dtype.is_floating_point or obj.dtype == torch.float32:
+                return obj
+            if id(obj) not in memo:
+                memo[id(obj)] = obj.float()
+            return memo[id(obj)]
+        if isinstance(obj, dict):
+            return {k: (v if k in ("dn_meta", "enc_meta") else DFINECriterion._upcast(v, memo))
+                    for k, v in obj.items()}
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(DFINECriterion._upcast(v, memo) for v in obj)
+        return obj
+
     def forward(self, outputs, targets, **kwargs):
         assert "aux_outputs" in outputs, ""
+        outputs = self._upcast(outputs, {})
         device = outputs["pred_logits"].device
         main = {k: v for k, v in outputs.items() if "aux" not in k}
         heads = [main] + list(outputs["aux_outputs"]) + [outputs["pre_outputs"]] + list(

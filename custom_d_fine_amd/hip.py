@@ -1,0 +1,190 @@
+"""ctypes binding of libdfine_hip.so (C ABI in include/dfine_hip.h) + tensor-level launchers.
+
+Importing this module FAILS LOUDLY when the library is missing or does not export a declared
+symbol - there is no fallback path.  Every launcher passes `tensor.data_ptr()` and torch's
+current HIP stream, allocates outputs/workspaces with torch (device memory plumbing only) and
+raises RuntimeError on a non-zero status.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdfine_hip.so")
+ABI_VERSION = 1
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build the HIP library first "
+        "(`python -m custom_d_fine_amd.csrc.build` or `python -c 'import __graft_entry__ as g; g.build()'`)")
+
+_lib = ctypes.CDLL(LIB_PATH)
+
+_P, _I, _F, _L = c_void_p, c_int, c_float, c_int64
+_SIGNATURES = {
+    "dfine_abi_version": (c_int, []),
+    "dfine_last_error": (ctypes.c_char_p, []),
+    "dfine_msda_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "dfine_msda_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "dfine_msda_fused_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
+    "dfine_msda_fused_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
+    "dfine_cast_f32_to_bf16": (c_int, [_P, _P, _L, _P]),
+    "dfine_match_ws_bytes": (_L, [_I, _I, _I, _I]),
+    "dfine_match": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P]),
+    "dfine_lsap": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+}
+for _name, (_res, _args) in _SIGNATURES.items():
+    _fn = getattr(_lib, _name)  # AttributeError here = library/header mismatch
+    _fn.restype, _fn.argtypes = _res, _args
+
+if _lib.dfine_abi_version() != ABI_VERSION:
+    raise ImportError(f"libdfine_hip.so ABI {_lib.dfine_abi_version()} != binding ABI {ABI_VERSION}")
+
+EXPORTED = tuple(_SIGNATURES)
+_DTYPE = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def _check(status, what):
+    if status != 0:
+        raise RuntimeError(f"{what} failed with status {status}: {_lib.dfine_last_error().decode()}")
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _levels(shapes, points):
+    hw = (c_int * (2 * len(shapes)))(*[v for s in shapes for v in s])
+    pts = (c_int * len(points))(*points)
+    return hw, pts
+
+
+def _dtype_code(t):
+    if t.dtype not in _DTYPE:
+        raise TypeError(f"HIP kernels take float32 or bfloat16 tensors, got {t.dtype}")
+    return _DTYPE[t.dtype]
+
+
+# ------------------------------------------------------------------------------------- MSDA
+def msda_forward(value, loc, weight, shapes, points):
+    B, L, H, D = value.shape
+    Lq = loc.shape[1]
+    out = torch.empty(B, Lq, H * D, device=value.device, dtype=value.dtype)
+    hw, pts = _levels(shapes, points)
+    _check(_lib.dfine_msda_fwd(_ptr(value), _ptr(loc), _ptr(weight), _ptr(out), _dtype_code(value),
+                               B, L, H, D, Lq, len(shapes), hw, pts, _stream()), "dfine_msda_fwd")
+    return out
+
+
+def _finish_grad_value(gv32, dtype):
+    if dtype == torch.float32:
+        return gv32
+    out = torch.empty(gv32.shape, device=gv32.device, dtype=torch.bfloat16)
+    _check(_lib.dfine_cast_f32_to_bf16(_ptr(gv32), _ptr(out), gv32.numel(), _stream()),
+           "dfine_cast_f32_to_bf16")
+    return out
+
+
+def msda_backward(value, loc, weight, grad_out, shapes, points):
+    B, L, H, D = value.shape
+    Lq = loc.shape[1]
+    gv = torch.zeros(B, L, H, D, device=value.device, dtype=torch.float32)
+    gl = torch.empty_like(loc)
+    gw = torch.empty_like(weight)
+    hw, pts = _levels(shapes, points)
+    if grad_out.dtype != value.dtype:
+        grad_out = grad_out.to(value.dtype)
+    _check(_lib.dfine_msda_bwd(_ptr(value), _ptr(loc), _ptr(weight), _ptr(grad_out), _ptr(gv),
+                               _ptr(gl), _ptr(gw), _dtype_code(value), B, L, H, D, Lq,
+                               len(shapes), hw, pts, _stream()), "dfine_msda_bwd")
+    return _finish_grad_value(gv, value.dtype), gl, gw
+
+
+def msda_fused_forward(value, ref, offsets, logits, shapes, points, offset_scale):
+    B, L, H, D = value.shape
+    Lq = ref.shape[1]
+    if offsets.dtype != value.dtype:
+        offsets = offsets.to(value.dtype)
+    if logits.dtype != value.dtype:
+        logits = logits.to(value.dtype)
+    out = torch.empty(B, Lq, H * D, device=value.device, dtype=value.dtype)
+    hw, pts = _levels(shapes, points)
+    _check(_lib.dfine_msda_fused_fwd(_ptr(value), _ptr(ref), _ptr(offsets), _ptr(logits), _ptr(out),
+                                     _dtype_code(value), B, L, H, D, Lq, len(shapes), hw, pts,
+                                     float(offset_scale), _stream()), "dfine_msda_fused_fwd")
+    return out
+
+
+def msda_fused_backward(value, ref, offsets, logits, grad_out, shapes, points, offset_scale):
+    B, L, H, D = value.shape
+    Lq = ref.shape[1]
+    off_dtype, log_dtype = offsets.dtype, logits.dtype
+    if offsets.dtype != value.dtype:
+        offsets = offsets.to(value.dtype)
+    if logits.dtype != value.dtype:
+        logits = logits.to(value.dtype)
+    if grad_out.dtype != value.dtype:
+        grad_out = grad_out.to(value.dtype)
+    gv = torch.zeros(B, L, H, D, device=value.device, dtype=torch.float32)
+    goff = torch.empty_like(offsets)
+    glog = torch.empty_like(logits)
+    hw, pts = _levels(shapes, points)
+    _check(_lib.dfine_msda_fused_bwd(_ptr(value), _ptr(ref), _ptr(offsets), _ptr(logits),
+                                     _ptr(grad_out), _ptr(gv), _ptr(goff), _ptr(glog),
+                                     _dtype_code(value), B, L, H, D, Lq, len(shapes), hw, pts,
+                                     float(offset_scale), _stream()), "dfine_msda_fused_bwd")
+    return _finish_grad_value(gv, value.dtype), goff.to(off_dtype), glog.to(log_dtype)
+
+
+# ------------------------------------------------------------------------------------- matcher
+def hungarian_assign(logits, boxes, tgt_labels, tgt_boxes, sizes, w_class, w_bbox, w_giou, alpha,
+                     gamma, use_focal=True, extra_cost=None):
+    if not use_focal:
+        raise NotImplementedError("the HIP matcher implements the focal class cost (reference default)")
+    K, B, Q, C = logits.shape
+    dev = logits.device
+    T = int(sum(sizes))
+    tmax = int(max(sizes)) if sizes else 0
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + int(n))
+    cols = torch.full((K, T), -1, device=dev, dtype=torch.int32)
+    if T == 0:
+        return cols, None
+    tgt_offset = torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True)
+    logits = logits.float().contiguous()
+    boxes = boxes.float().contiguous()
+    tgt_labels = tgt_labels.to(torch.int64).contiguous()
+    tgt_boxes = tgt_boxes.float().contiguous()
+    cost = torch.empty(K, B, tmax, Q, device=dev, dtype=torch.float32)
+    extra = None
+    if extra_cost is not None:  # caller layout [K,B,Q,Tmax] -> target-major
+        extra = extra_cost.float().permute(0, 1, 3, 2).contiguous()
+    _check(_lib.dfine_match(_ptr(logits), _ptr(boxes), _ptr(tgt_labels), _ptr(tgt_boxes),
+                            _ptr(tgt_offset), _ptr(extra), _ptr(cost), c_void_p(0), _ptr(cols),
+                            K, B, Q, C, tmax, T, float(w_class), float(w_bbox), float(w_giou),
+                            float(alpha), float(gamma), _stream()), "dfine_match")
+    return cols, cost.permute(0, 1, 3, 2)
+
+
+def lsap(cost_tq, sizes):
+    """cost_tq [K, B, Tmax, Q] f32 (target-major) -> cols int32 [K, T]."""
+    K, B, tmax, Q = cost_tq.shape
+    T = int(sum(sizes))
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + int(n))
+    cols = torch.full((K, T), -1, device=cost_tq.device, dtype=torch.int32)
+    if T == 0:
+        return cols
+    tgt_offset = torch.tensor(offs, dtype=torch.int32).to(cost_tq.device)
+    cost_tq = cost_tq.float().contiguous()
+    _check(_lib.dfine_lsap(_ptr(cost_tq), _ptr(tgt_offset), c_void_p(0), _ptr(cols), K, B, Q, tmax,
+                           T, _stream()), "dfine_lsap")
+    return cols

@@ -1,0 +1,120 @@
+/* libdfine_hip.so - C ABI of the MI355X (gfx950) D-FINE hot-path kernels.
+ *
+ * Plain C entry points: raw DEVICE pointers + sizes + a hipStream_t (passed as void*), int
+ * status return (0 = ok, <0 = DFINE_E_*), no exceptions, no hidden allocation: every buffer,
+ * including scratch, is owned by the caller.  All launches are asynchronous on `stream`.
+ * Tensors are dense row-major ("contiguous") in the shapes given below.
+ *
+ * dtype codes: DFINE_F32 = 0, DFINE_BF16 = 1 (bf16 tensors are read/written as bf16 and all
+ * arithmetic is fp32).
+ *
+ * The reference is pure Python/ATen, so each entry point replaces a
+ * Python function / ATen call sequence of /root/reference rather than an existing FFI symbol;
+ * the file:line it replaces is cited on every declaration.  INTEGRATION.md shows the ctypes
+ * binding (custom_d_fine_amd/hip.py) that a maintainer of the reference would add.
+ */
+#ifndef DFINE_HIP_H
+#define DFINE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFINE_OK 0
+#define DFINE_E_BADARG (-1)   /* unsupported shape / dtype / null pointer */
+#define DFINE_E_LAUNCH (-2)   /* hipLaunch / runtime error (see dfine_last_error) */
+
+#define DFINE_F32 0
+#define DFINE_BF16 1
+
+#define DFINE_MAX_LEVELS 8
+#define DFINE_MAX_POINTS 32   /* sum of sampling points over levels */
+
+/* Library / build info: returns the ABI version (bumped on any signature change). */
+int dfine_abi_version(void);
+/* Text of the last HIP runtime error seen by this library on the calling thread ("" if none). */
+const char *dfine_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * A7  Multi-scale deformable attention gather.
+ * Replaces deformable_attention_core_func_v2 (src/d_fine/arch/utils.py:191-264): per level
+ * F.grid_sample(bilinear, zeros, align_corners=False) + concat + mul + sum.
+ *
+ *   value   [B, L, H, D]   dtype `dtype`; L = sum_l h_l*w_l, row of pixel (y,x) of level l =
+ *                          start_l + y*w_l + x   (the encoder memory as it is, no permute)
+ *   loc     [B, Lq, H, P, 2] f32, (x, y) in [0,1];   weight [B, Lq, H, P] f32
+ *   out     [B, Lq, H*D]   dtype `dtype`
+ *   level_hw[2*n_levels] = h0,w0,h1,w1,..  level_points[n_levels], P = sum level_points
+ * D must be 16, 32 or 64 (D-FINE: 32; size n: 16).
+ */
+int dfine_msda_fwd(const void *value, const float *loc, const float *weight, void *out,
+                   int dtype, int B, int L, int H, int D, int Lq, int n_levels,
+                   const int *level_hw, const int *level_points, void *stream);
+
+/* Backward of dfine_msda_fwd (reference: autograd through grid_sample_backward + mul/sum).
+ *   grad_out [B, Lq, H*D] dtype `dtype`
+ *   grad_value_f32 [B, L, H, D] f32, MUST be zero-filled by the caller (accumulated with
+ *                  hardware f32 atomics); grad_loc [B,Lq,H,P,2] f32; grad_weight [B,Lq,H,P] f32
+ */
+int dfine_msda_bwd(const void *value, const float *loc, const float *weight,
+                   const void *grad_out, float *grad_value_f32, float *grad_loc,
+                   float *grad_weight, int dtype, int B, int L, int H, int D, int Lq,
+                   int n_levels, const int *level_hw, const int *level_points, void *stream);
+
+/* Fused variant used by the decoder: also replaces MSDeformableAttention.forward's
+ * softmax over points and sampling-location arithmetic
+ * (src/d_fine/arch/dfine_decoder.py:147,156-166):
+ *     loc = ref_xy + offsets * (1 / points_of_level) * ref_wh * offset_scale
+ *     w   = softmax_P(logits)
+ *   ref [B, Lq, 4] f32 cxcywh;  offsets [B, Lq, H, P, 2] and logits [B, Lq, H, P] dtype `dtype`
+ */
+int dfine_msda_fused_fwd(const void *value, const float *ref, const void *offsets,
+                         const void *logits, void *out, int dtype, int B, int L, int H, int D,
+                         int Lq, int n_levels, const int *level_hw, const int *level_points,
+                         float offset_scale, void *stream);
+
+/* grad_offsets / grad_logits have dtype `dtype`; grad_value_f32 as in dfine_msda_bwd. */
+int dfine_msda_fused_bwd(const void *value, const float *ref, const void *offsets,
+                         const void *logits, const void *grad_out, float *grad_value_f32,
+                         void *grad_offsets, void *grad_logits, int dtype, int B, int L, int H,
+                         int D, int Lq, int n_levels, const int *level_hw,
+                         const int *level_points, float offset_scale, void *stream);
+
+/* f32 -> bf16 (round to nearest even) copy of n elements; used to hand the f32-accumulated
+ * grad_value back in the model's compute dtype. */
+int dfine_cast_f32_to_bf16(const float *src, void *dst, int64_t n, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A11 + A12  Hungarian matcher: per-image cost block + linear sum assignment on the device.
+ * Replaces HungarianMatcher.forward (src/d_fine/matcher.py:110-257): sigmoid/focal class cost,
+ * cdist(p=1), generalized_box_iou, nan_to_num, C.cpu() and scipy.optimize.
+ * linear_sum_assignment (scipy 1.15.x rectangular_lsap, float64, its tie-breaking rules).
+ * K prediction heads are matched against the same targets in one launch.
+ *
+ *   logits [K, B, Q, C] f32; boxes [K, B, Q, 4] f32 cxcywh
+ *   tgt_labels [T] i64; tgt_boxes [T, 4] f32; tgt_offset [B+1] i32 (prefix sums of the
+ *   per-image target counts, T = tgt_offset[B]); Tmax = max count
+ *   extra_cost [K, B, Tmax, Q] f32 or NULL (added before the NaN clean-up; mask costs)
+ *   cost_out   [K, B, Tmax, Q] f32 workspace ("target-major": one target's costs against all
+ *              queries are contiguous); on return holds the cost blocks (rows t >= T_b undefined)
+ *   lsap_ws    workspace of dfine_match_ws_bytes(K,B,Q,Tmax) bytes (may be unused)
+ *   match_out  [K, T] i32: query assigned to each target, -1 if unassigned (T_b > Q)
+ *   T_total = T = tgt_offset[B] (passed by value: tgt_offset lives on the device)
+ */
+int64_t dfine_match_ws_bytes(int K, int B, int Q, int Tmax);
+int dfine_match(const float *logits, const float *boxes, const int64_t *tgt_labels,
+                const float *tgt_boxes, const int *tgt_offset, const float *extra_cost,
+                float *cost_out, void *lsap_ws, int *match_out, int K, int B, int Q, int C,
+                int Tmax, int T_total, float w_class, float w_bbox, float w_giou, float alpha, float gamma,
+                void *stream);
+
+/* Assignment only, on caller-provided cost blocks (same layout as cost_out above). */
+int dfine_lsap(const float *cost, const int *tgt_offset, void *lsap_ws, int *match_out, int K,
+               int B, int Q, int Tmax, int T_total, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFINE_HIP_H */

@@ -181,7 +181,7 @@ def match_cost(logits, boxes, tgt_ids, tgt_boxes, w_class=2.0, w_bbox=5.0, w_gio
     C = w_bbox * cdist_1(box, tgt) + w_class * (pos - neg) + w_giou * (-GIoU); NaN -> 1.
     logits [Q, C], boxes [Q, 4] cxcywh, tgt_ids [T], tgt_boxes [T, 4] -> [Q, T] float32."""
     x = np.asarray(logits, np.float32)
-    p = (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(np.float32)[:, np.asarray(tgt_ids)]
+    p = (np.float32(1) / (np.float32(1) + np.exp(-x)))[:, np.asarray(tgt_ids)]
     a, g = np.float32(alpha), np.float32(gamma)
     neg = (1 - a) * (p ** g) * (-np.log(1 - p + np.float32(1e-8)))
     pos = a * ((1 - p) ** g) * (-np.log(p + np.float32(1e-8)))

@@ -1,0 +1,159 @@
+"""Deterministic inputs shared by tools/gen_golden.py (run once against the reference in the build
+container) and the tests (run anywhere).  Nothing here touches /root/reference."""
+import zlib
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = __file__.rsplit("/", 1)[0] + "/golden"
+
+
+def seeded_state_dict(state_dict):
+    """Pseudo-random weights derived from the KEY NAMES, so the reference model (in the generator)
+    and this build's model (in the tests) get identical weights without shipping them.
+    Structured / geometric tensors (anchors, masks, FDR constants, the deformable-offset ray
+    bias) keep their constructor values - both code bases compute them by the same formula."""
+    out = {}
+    for k, v in state_dict.items():
+        keep = (not v.dtype.is_floating_point or k.endswith(("anchors", "num_points_scale"))
+                or k in ("decoder.up", "decoder.reg_scale") or k.endswith("sampling_offsets.bias"))
+        if keep:
+            out[k] = v.clone()
+            continue
+        rng = np.random.default_rng(zlib.crc32(k.encode()))
+        shape = tuple(v.shape)
+        is_norm = any(s in k for s in (".bn.", ".norm.", "norm1.", "norm2.", "norm3.", ".norm"))
+        if k.endswith("running_var"):
+            a = rng.uniform(0.5, 1.5, shape)
+        elif k.endswith("running_mean"):
+            a = rng.normal(0, 0.1, shape)
+        elif k.endswith("lab.scale"):
+            a = rng.uniform(0.9, 1.1, shape)
+        elif k.endswith("lab.bias"):
+            a = rng.normal(0, 0.02, shape)
+        elif is_norm and k.endswith("weight"):
+            a = rng.uniform(0.8, 1.2, shape)
+        elif k.endswith("bias"):
+            a = rng.normal(0, 0.05, shape)
+        elif "class_embed" in k:
+            a = rng.normal(0, 1.0, shape)
+        else:
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+            a = rng.normal(0, 1.0 / np.sqrt(max(fan_in, 1)), shape)
+        out[k] = torch.from_numpy(a.astype(np.float32)).reshape(v.shape)
+    return out
+
+
+def make_images(batch, size, seed=123):
+    return torch.from_numpy(np.random.default_rng(seed).random((batch, 3, size, size), np.float32))
+
+
+def make_targets(batch, num_classes, seed=7, max_t=6, min_t=1, device="cpu"):
+    """COCO-shaped synthetic labels: boxes stay inside the image (cx,cy in [.2,.8], w,h in [.05,.35])."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(batch):
+        n = int(rng.integers(min_t, max_t + 1))
+        cxcy = rng.uniform(0.2, 0.8, (n, 2))
+        wh = rng.uniform(0.05, 0.35, (n, 2))
+        out.append({
+            "labels": torch.from_numpy(rng.integers(0, num_classes, n)).long().to(device),
+            "boxes": torch.from_numpy(np.concatenate([cxcy, wh], 1).astype(np.float32)).to(device),
+        })
+    return out
+
+
+def make_msda_case(seed, B=2, Lq=16, H=8, D=4, shapes=((8, 8), (4, 4), (2, 2)), points=(3, 6, 3)):
+    """Random value / sampling locations / weights incl. out-of-range and exactly-on-edge points."""
+    rng = np.random.default_rng(seed)
+    L = sum(h * w for h, w in shapes)
+    P = sum(points)
+    value = rng.normal(0, 1, (B, L, H, D)).astype(np.float32)
+    loc = rng.uniform(-0.15, 1.15, (B, Lq, H, P, 2)).astype(np.float32)
+    # exactly on pixel centres / borders / far outside
+    loc[0, 0, 0, :4] = [[0.0, 0.0], [1.0, 1.0], [0.5, 0.5], [0.0625, 0.9375]]
+    loc[0, 1, 1, :3] = [[-3.0, 0.5], [0.5, 7.0], [1e4, -1e4]]
+    w = rng.uniform(0, 1, (B, Lq, H, P)).astype(np.float32)
+    w /= w.sum(-1, keepdims=True)
+    grad_out = rng.normal(0, 1, (B, Lq, H * D)).astype(np.float32)
+    return value, loc, w, grad_out, tuple(shapes), tuple(points)
+
+
+def make_matcher_case(seed, B=3, Q=40, C=7, sizes=(5, 0, 9)):
+    rng = np.random.default_rng(seed)
+    logits = rng.normal(0, 2, (B, Q, C)).astype(np.float32)
+    boxes = np.concatenate([rng.uniform(0.2, 0.8, (B, Q, 2)), rng.uniform(0.05, 0.4, (B, Q, 2))], -1).astype(np.float32)
+    targets = []
+    for n in sizes:
+        targets.append({
+            "labels": torch.from_numpy(rng.integers(0, C, n)).long(),
+            "boxes": torch.from_numpy(np.concatenate([rng.uniform(0.2, 0.8, (n, 2)), rng.uniform(0.05, 0.4, (n, 2))], -1).astype(np.float32)),
+        })
+    return logits, boxes, targets
+
+
+def lsap_cases():
+    """Assignment problems pinned against SciPy in tests/golden/lsap.npz (name -> cost matrix)."""
+    rng = np.random.default_rng(2024)
+    cases = {}
+    for t in (1, 7, 50, 100, 300, 350):
+        cases[f"rand_300x{t}"] = rng.random((300, t)).astype(np.float32)
+    cases["zeros_6x3"] = np.zeros((6, 3), np.float32)
+    cases["dup_rows"] = np.array([[1, 1, 1], [1, 1, 1], [0, 0, 0], [1, 1, 1], [0, 0, 0]], np.float32)
+    cases["all_equal_300x20"] = np.full((300, 20), 0.25, np.float32)
+    cases["small_ints_40x12"] = rng.integers(0, 3, (40, 12)).astype(np.float32)
+    cases["small_ints_12x40"] = rng.integers(0, 3, (12, 40)).astype(np.float32)
+    cases["coarse_300x30"] = np.round(rng.random((300, 30)), 1).astype(np.float32)
+    dup = rng.random((300, 10)).astype(np.float32)
+    dup[:, 5] = dup[:, 2]
+    dup[100] = dup[7]
+    cases["dup_cols_rows_300x10"] = dup
+    nanc = rng.random((50, 6)).astype(np.float32)
+    nanc[3, 2] = np.nan
+    nanc[10, :] = np.nan
+    cases["nan_to_one_50x6"] = np.nan_to_num(nanc, nan=1.0)
+    return cases
+
+
+def make_criterion_outputs(seed, B=2, Q=24, C=6, L=3, dn=8, reg_max=32, device="cpu", requires_grad=True):
+    """A synthetic decoder output dict with the train-time structure of DFINETransformer.forward
+    (L decoder layers -> L-1 aux heads, pre, enc, dn heads) on tiny shapes."""
+    g = torch.Generator().manual_seed(seed)
+
+    def rnd(*shape, scale=1.0):
+        t = (torch.randn(*shape, generator=g) * scale).to(device)
+        return t.requires_grad_(requires_grad)
+
+    def boxes(*lead):
+        cxcy = torch.rand(*lead, 2, generator=g) * 0.6 + 0.2
+        wh = torch.rand(*lead, 2, generator=g) * 0.3 + 0.05
+        return torch.cat([cxcy, wh], -1).to(device).requires_grad_(requires_grad)
+
+    nb = 4 * (reg_max + 1)
+    ref = boxes(B, Q).detach()
+    dn_ref = boxes(B, dn).detach()
+    layers = [{"pred_logits": rnd(B, Q, C), "pred_boxes": boxes(B, Q), "pred_corners": rnd(B, Q, nb),
+               "ref_points": ref} for _ in range(L)]
+    dn_layers = [{"pred_logits": rnd(B, dn, C), "pred_boxes": boxes(B, dn), "pred_corners": rnd(B, dn, nb),
+                  "ref_points": dn_ref} for _ in range(L)]
+    up = torch.tensor([0.5], device=device)
+    reg_scale = torch.tensor([4.0], device=device)
+    out = dict(layers[-1], up=up, reg_scale=reg_scale)
+    out["aux_outputs"] = [dict(l, teacher_corners=layers[-1]["pred_corners"], teacher_logits=layers[-1]["pred_logits"]) for l in layers[:-1]]
+    out["enc_aux_outputs"] = [{"pred_logits": rnd(B, Q, C), "pred_boxes": boxes(B, Q)}]
+    out["pre_outputs"] = {"pred_logits": rnd(B, Q, C), "pred_boxes": boxes(B, Q)}
+    out["enc_meta"] = {"class_agnostic": False}
+    out["dn_outputs"] = [dict(l, teacher_corners=dn_layers[-1]["pred_corners"], teacher_logits=dn_layers[-1]["pred_logits"]) for l in dn_layers]
+    out["dn_pre_outputs"] = {"pred_logits": rnd(B, dn, C), "pred_boxes": boxes(B, dn)}
+    return out
+
+
+def criterion_targets_and_meta(B=2, dn=8, C=6, device="cpu"):
+    """Targets with 2 GT per image and the matching dn_meta (2 groups of 2 pos + 2 neg = 8 dn queries)."""
+    targets = [
+        {"labels": torch.tensor([1, 4], device=device), "boxes": torch.tensor([[.3, .4, .2, .2], [.6, .5, .3, .25]], device=device)},
+        {"labels": torch.tensor([2, 0], device=device), "boxes": torch.tensor([[.45, .4, .3, .2], [.7, .6, .2, .25]], device=device)},
+    ][:B]
+    pos = torch.tensor([0, 1, 4, 5])
+    meta = {"dn_positive_idx": tuple(pos.clone() for _ in range(B)), "dn_num_group": 2, "dn_num_split": [dn, 0]}
+    return targets, meta

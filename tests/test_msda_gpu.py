@@ -1,0 +1,142 @@
+"""A7 parity: HIP deformable-attention gather (through the C ABI) vs the oracle and the golden
+vectors from the reference.  fp32 tolerance 1e-5 (fwd) / 1e-4 (bwd, atomics reorder sums);
+bf16 storage tolerance 2e-2 relative to the output scale."""
+import numpy as np
+import pytest
+import torch
+
+from custom_d_fine_amd import kernels
+from oracle import np_ref
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+G = helpers.GOLDEN_DIR
+
+
+def _run(value, loc, w, go, shapes, points, dev, dtype=torch.float32):
+    v = torch.tensor(value, device=dev, dtype=dtype, requires_grad=True)
+    lc = torch.tensor(loc, device=dev, requires_grad=True)
+    ww = torch.tensor(w, device=dev, requires_grad=True)
+    out = kernels.msda(v, shapes, lc, ww, points)
+    out.backward(torch.tensor(go, device=dev, dtype=dtype))
+    return out.detach().float().cpu().numpy(), v.grad.float().cpu().numpy(), lc.grad.cpu().numpy(), ww.grad.cpu().numpy()
+
+
+def test_golden_case_d16(cuda):
+    g = np.load(f"{G}/msda.npz")
+    value, loc, w, go, shapes, points = helpers.make_msda_case(1, B=1, Lq=5, H=2, D=16, shapes=((5, 7), (3, 2)), points=(2, 4))
+    out, gv, gl, gw = _run(value, loc, w, go, shapes, points, cuda)
+    np.testing.assert_allclose(out, g["s1/out"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gv, g["s1/g_value"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gw, g["s1/g_weight"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gl, g["s1/g_loc"], rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("D,H,B,Lq", [(32, 8, 2, 37), (16, 8, 3, 70), (64, 4, 1, 9), (32, 5, 2, 33)])
+def test_vs_oracle_fp32_incl_edges(cuda, D, H, B, Lq):
+    value, loc, w, go, shapes, points = helpers.make_msda_case(D + H, B=B, Lq=Lq, H=H, D=D)
+    out, gv, gl, gw = _run(value, loc, w, go, shapes, points, cuda)
+    np.testing.assert_allclose(out, np_ref.msda_forward(value, shapes, loc, w, points), rtol=1e-5, atol=1e-5)
+    rv, rl, rw = np_ref.msda_backward(value, shapes, loc, w, points, go)
+    np.testing.assert_allclose(gv, rv, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gw, rw, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gl, rl, rtol=1e-4, atol=3e-4)
+
+
+def test_fused_matches_reference_module_golden(cuda):
+    g = np.load(f"{G}/msda.npz")
+    # golden module case has head_dim 4; the kernels need 16/32/64 -> tile the channels x4
+    shapes, points = ((8, 8), (4, 4), (2, 2)), (3, 6, 3)
+    value = np.tile(g["mod/value"], (1, 1, 1, 4))                       # [B, L, 8, 16]
+    go = np.tile(g["mod/grad_out"].reshape(2, 9, 8, 4), (1, 1, 1, 4)).reshape(2, 9, 128)
+    v = torch.tensor(value, device=cuda, requires_grad=True)
+    off = torch.tensor(g["mod/offsets"], device=cuda, requires_grad=True)
+    lg = torch.tensor(g["mod/logits"], device=cuda, requires_grad=True)
+    out = kernels.msda_fused(v, shapes, torch.tensor(g["mod/ref"], device=cuda), off, lg, points, 0.5)
+    out.backward(torch.tensor(go, device=cuda))
+    want = np.tile(g["mod/out"].reshape(2, 9, 8, 4), (1, 1, 1, 4)).reshape(2, 9, 128)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(v.grad.cpu().numpy(), np.tile(g["mod/g_value"], (1, 1, 1, 4)), rtol=1e-4, atol=1e-5)
+    # 4 identical channel groups -> 4x the gradient on the shared offsets / logits
+    np.testing.assert_allclose(off.grad.cpu().numpy(), 4 * g["mod/g_offsets"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(lg.grad.cpu().numpy(), 4 * g["mod/g_logits"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_vs_oracle(cuda, dtype):
+    rng = np.random.default_rng(3)
+    B, Lq, H, D = 2, 45, 8, 32
+    shapes, points = ((10, 12), (5, 6), (3, 3)), (3, 6, 3)
+    L, P = 120 + 30 + 9, 12
+    value = rng.normal(0, 1, (B, L, H, D)).astype(np.float32)
+    ref = np.concatenate([rng.uniform(0, 1, (B, Lq, 2)), rng.uniform(0.02, 0.6, (B, Lq, 2))], -1).astype(np.float32)
+    off = rng.normal(0, 2, (B, Lq, H, P, 2)).astype(np.float32)
+    lg = rng.normal(0, 2, (B, Lq, H, P)).astype(np.float32)
+    go = rng.normal(0, 1, (B, Lq, H * D)).astype(np.float32)
+    tv = torch.tensor(value, device=cuda, dtype=dtype, requires_grad=True)
+    to = torch.tensor(off, device=cuda, dtype=dtype, requires_grad=True)
+    tl = torch.tensor(lg, device=cuda, dtype=dtype, requires_grad=True)
+    out = kernels.msda_fused(tv, shapes, torch.tensor(ref, device=cuda), to, tl, points, 0.5)
+    out.backward(torch.tensor(go, device=cuda, dtype=dtype))
+    # oracle on the values the kernel actually saw (bf16-rounded inputs)
+    v_in, o_in, l_in = (t.detach().float().cpu().numpy() for t in (tv, to, tl))
+    go_in = torch.tensor(go).to(dtype).float().numpy()
+    loc, w = np_ref.msda_prologue(ref, o_in, l_in, points, 0.5)
+    want = np_ref.msda_forward(v_in, shapes, loc, w, points)
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(out.detach().float().cpu().numpy(), want, **tol)
+    rv, rl, rw = np_ref.msda_backward(v_in, shapes, loc, w, points, go_in)
+    scale = np.array([1 / n for n in points for _ in range(n)], np.float32)
+    g_off = rl * scale[None, None, None, :, None] * ref[:, :, None, None, 2:] * 0.5
+    g_log = w * (rw - (w * rw).sum(-1, keepdims=True))
+    btol = dict(rtol=1e-4, atol=3e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    np.testing.assert_allclose(tv.grad.float().cpu().numpy(), rv, **btol)
+    np.testing.assert_allclose(to.grad.float().cpu().numpy(), g_off, **btol)
+    np.testing.assert_allclose(tl.grad.float().cpu().numpy(), g_log, **btol)
+
+
+def test_empty_and_ragged(cuda):
+    shapes, points = ((4, 4), (2, 2)), (2, 2)
+    v = torch.randn(2, 20, 8, 32, device=cuda)
+    out = kernels.msda(v, shapes, torch.zeros(2, 0, 8, 4, 2, device=cuda), torch.zeros(2, 0, 8, 4, device=cuda), points)
+    assert out.shape == (2, 0, 256)
+    # a query count that is not a multiple of the per-block task count
+    loc = torch.rand(2, 33, 8, 4, 2, device=cuda)
+    w = torch.softmax(torch.randn(2, 33, 8, 4, device=cuda), -1)
+    out = kernels.msda(v, shapes, loc, w, points)
+    want = np_ref.msda_forward(v.cpu().numpy(), shapes, loc.cpu().numpy(), w.cpu().numpy(), points)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    with pytest.raises(RuntimeError):    # level table that does not cover the value rows
+        kernels.msda(v, ((4, 4),), loc[:, :, :, :2], w[:, :, :, :2], (2,))
+
+
+def test_full_size_properties_bf16(cuda):
+    """D-FINE-m / 640x640 / bs=32 shapes (BASELINE.json configs[2]): size-independent properties
+    - constant field stays constant for in-range samples, linearity in value, and the adjoint
+    identity <grad_out, A v> == <A^T grad_out, v> that ties backward to forward."""
+    torch.manual_seed(0)
+    B, Lq, H, D = 32, 496, 8, 32
+    shapes, points = ((80, 80), (40, 40), (20, 20)), (3, 6, 3)
+    L = 8400
+    ref = torch.cat([torch.rand(B, Lq, 2, device=cuda) * 0.6 + 0.2, torch.rand(B, Lq, 2, device=cuda) * 0.1], -1)
+    off = torch.randn(B, Lq, H, 12, 2, device=cuda).clamp(-2, 2)
+    lg = torch.randn(B, Lq, H, 12, device=cuda)
+    const = torch.full((B, L, H, D), 0.75, device=cuda, dtype=torch.bfloat16)
+    out = kernels.msda_fused(const, shapes, ref, off.bfloat16(), lg.bfloat16(), points, 0.5)
+    assert (out.float() - 0.75).abs().max() < 8e-3          # all samples in range -> weights sum to 1
+    v1 = torch.randn(B, L, H, D, device=cuda)
+    v2 = torch.randn(B, L, H, D, device=cuda)
+    f = lambda v: kernels.msda_fused(v, shapes, ref, off, lg, points, 0.5)
+    lin = f(2 * v1 - 3 * v2) - (2 * f(v1) - 3 * f(v2))
+    assert lin.abs().max() < 1e-4
+    v = v1.clone().requires_grad_(True)
+    go = torch.randn(B, Lq, H * D, device=cuda)
+    o = kernels.msda_fused(v, shapes, ref, off, lg, points, 0.5)
+    o.backward(go)
+    lhs = (go.double() * o.detach().double()).sum()
+    rhs = (v.grad.double() * v.detach().double()).sum()
+    assert abs(lhs - rhs) / abs(lhs) < 1e-5
+    # spot-check one image against the oracle
+    loc, w = np_ref.msda_prologue(ref[:1].cpu().numpy(), off[:1].cpu().numpy(), lg[:1].cpu().numpy(), points, 0.5)
+    want = np_ref.msda_forward(v1[:1].cpu().numpy(), shapes, loc, w, points)
+    np.testing.assert_allclose(o[:1].detach().cpu().numpy(), want, rtol=1e-4, atol=1e-4)
