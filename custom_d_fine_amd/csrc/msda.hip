@@ -333,6 +333,7 @@ extern "C" {
 int dfine_msda_fwd(const void *value, const float *loc, const float *weight, void *out, int dtype,
                    int B, int L, int H, int D, int Lq, int n_levels, const int *level_hw,
                    const int *level_points, void *stream) {
+    if (B == 0 || Lq == 0) return DFINE_OK;   // empty problem: nothing to launch
     if (!value || !loc || !weight || !out || B < 0 || Lq < 0 || H < 1) return DFINE_E_BADARG;
     MsdaLevels lv;
     if (int e = fill_levels(lv, L, n_levels, level_hw, level_points)) return e;
@@ -348,6 +349,7 @@ int dfine_msda_bwd(const void *value, const float *loc, const float *weight, con
                    float *grad_value_f32, float *grad_loc, float *grad_weight, int dtype, int B,
                    int L, int H, int D, int Lq, int n_levels, const int *level_hw,
                    const int *level_points, void *stream) {
+    if (B == 0 || Lq == 0) return DFINE_OK;   // empty problem: nothing to launch
     if (!value || !loc || !weight || !grad_out || !grad_value_f32 || !grad_loc || !grad_weight ||
         B < 0 || Lq < 0 || H < 1)
         return DFINE_E_BADARG;
@@ -366,6 +368,7 @@ int dfine_msda_bwd(const void *value, const float *loc, const float *weight, con
 int dfine_msda_fused_fwd(const void *value, const float *ref, const void *offsets, const void *logits,
                          void *out, int dtype, int B, int L, int H, int D, int Lq, int n_levels,
                          const int *level_hw, const int *level_points, float offset_scale, void *stream) {
+    if (B == 0 || Lq == 0) return DFINE_OK;   // empty problem: nothing to launch
     if (!value || !ref || !offsets || !logits || !out || B < 0 || Lq < 0 || H < 1) return DFINE_E_BADARG;
     MsdaLevels lv;
     if (int e = fill_levels(lv, L, n_levels, level_hw, level_points)) return e;
@@ -381,6 +384,7 @@ int dfine_msda_fused_bwd(const void *value, const float *ref, const void *offset
                          const void *grad_out, float *grad_value_f32, void *grad_offsets,
                          void *grad_logits, int dtype, int B, int L, int H, int D, int Lq, int n_levels,
                          const int *level_hw, const int *level_points, float offset_scale, void *stream) {
+    if (B == 0 || Lq == 0) return DFINE_OK;   // empty problem: nothing to launch
     if (!value || !ref || !offsets || !logits || !grad_out || !grad_value_f32 || !grad_offsets ||
         !grad_logits || B < 0 || Lq < 0 || H < 1)
         return DFINE_E_BADARG;

@@ -43,6 +43,43 @@ if _lib.dfine_abi_version() != ABI_VERSION:
     raise ImportError(f"libdfine_hip.so ABI {_lib.dfine_abi_version()} != binding ABI {ABI_VERSION}")
 
 EXPORTED = tuple(_SIGNATURES)
+
+# ---- optional per-kernel timing (bench.py roofline leg): HIP events recorded on the launch
+# stream (torch's current stream) right around the launch of the named entry points.
+_TIMED = {}          # name -> list of (start_event, end_event)
+
+
+def enable_timing(names):
+    _TIMED.clear()
+    for n in names:
+        _TIMED[n] = []
+
+
+def disable_timing():
+    _TIMED.clear()
+
+
+def timing_summary():
+    """name -> (launches, mean_ms) after a device synchronize."""
+    torch.cuda.synchronize()
+    return {n: (len(ev), sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1))
+            for n, ev in _TIMED.items()}
+
+
+class _timed:
+    def __init__(self, name):
+        self.ev = _TIMED.get(name)
+
+    def __enter__(self):
+        if self.ev is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if self.ev is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            self.ev.append((self.a, b))
 _DTYPE = {torch.float32: 0, torch.bfloat16: 1}
 
 
@@ -115,9 +152,10 @@ def msda_fused_forward(value, ref, offsets, logits, shapes, points, offset_scale
         logits = logits.to(value.dtype)
     out = torch.empty(B, Lq, H * D, device=value.device, dtype=value.dtype)
     hw, pts = _levels(shapes, points)
-    _check(_lib.dfine_msda_fused_fwd(_ptr(value), _ptr(ref), _ptr(offsets), _ptr(logits), _ptr(out),
-                                     _dtype_code(value), B, L, H, D, Lq, len(shapes), hw, pts,
-                                     float(offset_scale), _stream()), "dfine_msda_fused_fwd")
+    with _timed("dfine_msda_fused_fwd"):
+        _check(_lib.dfine_msda_fused_fwd(_ptr(value), _ptr(ref), _ptr(offsets), _ptr(logits), _ptr(out),
+                                         _dtype_code(value), B, L, H, D, Lq, len(shapes), hw, pts,
+                                         float(offset_scale), _stream()), "dfine_msda_fused_fwd")
     return out
 
 
@@ -135,10 +173,11 @@ def msda_fused_backward(value, ref, offsets, logits, grad_out, shapes, points, o
     goff = torch.empty_like(offsets)
     glog = torch.empty_like(logits)
     hw, pts = _levels(shapes, points)
-    _check(_lib.dfine_msda_fused_bwd(_ptr(value), _ptr(ref), _ptr(offsets), _ptr(logits),
-                                     _ptr(grad_out), _ptr(gv), _ptr(goff), _ptr(glog),
-                                     _dtype_code(value), B, L, H, D, Lq, len(shapes), hw, pts,
-                                     float(offset_scale), _stream()), "dfine_msda_fused_bwd")
+    with _timed("dfine_msda_fused_bwd"):
+        _check(_lib.dfine_msda_fused_bwd(_ptr(value), _ptr(ref), _ptr(offsets), _ptr(logits),
+                                         _ptr(grad_out), _ptr(gv), _ptr(goff), _ptr(glog),
+                                         _dtype_code(value), B, L, H, D, Lq, len(shapes), hw, pts,
+                                         float(offset_scale), _stream()), "dfine_msda_fused_bwd")
     return _finish_grad_value(gv, value.dtype), goff.to(off_dtype), glog.to(log_dtype)
 
 
