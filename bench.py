@@ -30,11 +30,13 @@ LRS = {"n": (8e-4, 4e-4), "s": (2.5e-4, 6e-5), "m": (1.5e-4, 2e-5), "l": (1.6e-4
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def build_step(model_name, img, device, amp_dtype, num_classes=80):
+def build_step(model_name, img, device, amp_dtype, num_classes=80, channels_last=False):
     from custom_d_fine_amd.d_fine import dfine
     from custom_d_fine_amd.dl.engine import ModelEMA, TrainStep, wrap_data_parallel
     base_lr, backbone_lr = LRS[model_name]
     model = dfine.build_model(model_name, num_classes, False, str(device), img_size=[img, img]).train()
+    if channels_last:
+        model = model.to(memory_format=torch.channels_last)
     criterion = dfine.build_loss(model_name, num_classes, 0.0, False)
     ema = ModelEMA(model, 0.9998)
     model = wrap_data_parallel(model, device)
@@ -87,6 +89,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-baseline steps (0 = skip)")
+    ap.add_argument("--channels-last", type=int, default=0)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,8 +109,10 @@ def main():
     from custom_d_fine_amd.dl.synthetic import make_batch
     torch.manual_seed(42 + rank)
     amp = torch.bfloat16 if args.dtype == "bf16" else None
-    step = build_step(args.model, args.img, device, amp)
+    step = build_step(args.model, args.img, device, amp, channels_last=bool(args.channels_last))
     images, targets = make_batch(args.batch, args.img, seed=42 + rank, device=device)
+    if args.channels_last:
+        images = images.contiguous(memory_format=torch.channels_last)
 
     for _ in range(args.warmup):
         step(images, targets)

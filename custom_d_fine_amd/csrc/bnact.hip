@@ -1,0 +1,329 @@
+// A1/A2 - fused BatchNorm2d (+ ReLU/SiLU) (+ learnable scalar affine "LAB"), NCHW, train + eval.
+//
+// Reference: every ConvBNAct / ConvNormLayer(_fuse) unit runs  bn(conv(x)) -> act -> lab  as separate
+// ATen ops (src/d_fine/arch/hgnetv2.py:25-32,75-80; src/d_fine/arch/hybrid_encoder.py:40-45,92-93):
+// MIOpen BN stats+apply, an activation kernel and two more elementwise kernels for the scalar affine,
+// plus the mirrored chain in backward.  Here (all HBM-bound, fp32 math, bf16 or f32 storage):
+//   forward  : bn_stats_kernel      x -> per-(channel, chunk) partial (sum, sum of squares)
+//              bn_finalize_kernel   partials -> mean, invstd (float64 combine), running stats
+//                                   update (momentum, unbiased var), folded scale/shift
+//              bn_apply_kernel      y = lab_s * act(x*scale + shift) + lab_b           (1R + 1W)
+//   backward : bn_bwd_reduce_kernel (dy, x) -> partial sums of dz, dz*xhat, dy*act(z), dy
+//              bn_bwd_finalize      -> dgamma, dbeta, dlab_s, dlab_b, per-channel coefficients
+//              bn_bwd_apply_kernel  dx = scale * (dz - mean(dz) - xhat * mean(dz*xhat))  (2R + 1W)
+// with z = x*scale + shift, dz = dy * lab_s * act'(z).  One (channel, image-range) per block; a
+// plane (H*W contiguous elements) is read with 16-byte loads when its size allows.
+#include "common.h"
+
+namespace dfine {
+
+constexpr int kBnThreads = 256;
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+    if (act == ACT_RELU) return fmaxf(z, 0.f);
+    if (act == ACT_SILU) return z / (1.f + __expf(-z));
+    return z;
+}
+__device__ __forceinline__ float act_grad(float z, int act) {
+    if (act == ACT_RELU) return z > 0.f ? 1.f : 0.f;
+    if (act == ACT_SILU) {
+        const float s = 1.f / (1.f + __expf(-z));
+        return s * (1.f + z * (1.f - s));
+    }
+    return 1.f;
+}
+
+template <int N> __device__ __forceinline__ void block_reduce(float (&v)[N], float *red /*[N][waves]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int WAVES = kBnThreads / 64;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float x = v[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+        if (lane == 0) red[i * WAVES + wave] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float x = 0.f;
+        for (int w = 0; w < WAVES; ++w) x += red[i * WAVES + w];
+        v[i] = x;
+    }
+}
+
+// partial layout: [C][nchunk][NVAL]
+template <typename T>
+__global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const T *__restrict__ x, float *__restrict__ part,
+                                                              int C, int HW, int B, int imgs_per_chunk) {
+    __shared__ float red[2 * kBnThreads / 64];
+    const int c = blockIdx.x, chunk = blockIdx.y;
+    const int b0 = chunk * imgs_per_chunk, b1 = min(B, b0 + imgs_per_chunk);
+    float v[2] = {0.f, 0.f};
+    for (int b = b0; b < b1; ++b) {
+        const T *p = x + ((int64_t)b * C + c) * HW;
+        if ((HW & 3) == 0) {
+            for (int i = threadIdx.x * 4; i < HW; i += kBnThreads * 4) {
+                const f32x4 a = Vec4<T>::load(p + i);
+                v[0] += (a.x + a.y) + (a.z + a.w);
+                v[1] += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += kBnThreads) {
+                const float a = load_f(p + i);
+                v[0] += a; v[1] += a * a;
+            }
+        }
+    }
+    block_reduce<2>(v, red);
+    if (threadIdx.x == 0) {
+        float *o = part + ((int64_t)c * gridDim.y + chunk) * 2;
+        o[0] = v[0]; o[1] = v[1];
+    }
+}
+
+// one thread per channel
+__global__ void bn_finalize_kernel(const float *__restrict__ part, int nchunk, int C, double count,
+                                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                                   float *__restrict__ running_mean, float *__restrict__ running_var,
+                                   float momentum, float eps, float *__restrict__ mean_out,
+                                   float *__restrict__ invstd_out, float *__restrict__ scale_out,
+                                   float *__restrict__ shift_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        s += (double)part[((int64_t)c * nchunk + k) * 2];
+        ss += (double)part[((int64_t)c * nchunk + k) * 2 + 1];
+    }
+    const double mean = s / count;
+    double var = ss / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    mean_out[c] = (float)mean;
+    invstd_out[c] = invstd;
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    scale_out[c] = g * invstd;
+    shift_out[c] = bt - (float)mean * g * invstd;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// eval / frozen statistics: scale/shift from running stats
+__global__ void bn_fold_kernel(int C, const float *__restrict__ gamma, const float *__restrict__ beta,
+                               const float *__restrict__ running_mean, const float *__restrict__ running_var,
+                               float eps, float *__restrict__ scale_out, float *__restrict__ shift_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = rsqrtf(running_var[c] + eps);
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    scale_out[c] = g * invstd;
+    shift_out[c] = bt - running_mean[c] * g * invstd;
+}
+
+// grid: (B*C planes, plane chunks)
+template <typename T>
+__global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const T *__restrict__ x, T *__restrict__ y,
+                                                              const float *__restrict__ scale,
+                                                              const float *__restrict__ shift,
+                                                              const float *__restrict__ lab_s, const float *__restrict__ lab_b,
+                                                              int C, int HW, int act) {
+    const int plane = blockIdx.x, c = plane % C;
+    const float sc = scale[c], sh = shift[c];
+    const float ls = lab_s ? lab_s[0] : 1.f, lb = lab_b ? lab_b[0] : 0.f;
+    const T *p = x + (int64_t)plane * HW;
+    T *q = y + (int64_t)plane * HW;
+    const int start = blockIdx.y * kBnThreads * 4 * 4;     // 4 vectors per thread per block
+    const int end = min(HW, start + kBnThreads * 16);
+    if ((HW & 3) == 0) {
+        for (int i = start + threadIdx.x * 4; i < end; i += kBnThreads * 4) {
+            f32x4 a = Vec4<T>::load(p + i);
+            a.x = ls * act_fwd(a.x * sc + sh, act) + lb;
+            a.y = ls * act_fwd(a.y * sc + sh, act) + lb;
+            a.z = ls * act_fwd(a.z * sc + sh, act) + lb;
+            a.w = ls * act_fwd(a.w * sc + sh, act) + lb;
+            Vec4<T>::store(q + i, a);
+        }
+    } else {
+        for (int i = start + threadIdx.x; i < end; i += kBnThreads)
+            store_f(q + i, ls * act_fwd(load_f(p + i) * sc + sh, act) + lb);
+    }
+}
+
+// partials: [C][nchunk][4] = sum dz, sum dz*xhat, sum dy*act(z), sum dy
+template <typename T>
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(
+    const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ part,
+    const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ lab_s, int C, int HW, int B,
+    int imgs_per_chunk, int act) {
+    __shared__ float red[4 * kBnThreads / 64];
+    const int c = blockIdx.x, chunk = blockIdx.y;
+    const int b0 = chunk * imgs_per_chunk, b1 = min(B, b0 + imgs_per_chunk);
+    const float mu = mean[c], is = invstd[c], sc = scale[c], sh = shift[c];
+    const float ls = lab_s ? lab_s[0] : 1.f;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    auto accum = [&](float xv, float g) {
+        const float z = xv * sc + sh;
+        const float dz = g * ls * act_grad(z, act);
+        v[0] += dz;
+        v[1] += dz * ((xv - mu) * is);
+        v[2] += g * act_fwd(z, act);
+        v[3] += g;
+    };
+    for (int b = b0; b < b1; ++b) {
+        const T *p = x + ((int64_t)b * C + c) * HW;
+        const T *g = dy + ((int64_t)b * C + c) * HW;
+        if ((HW & 3) == 0) {
+            for (int i = threadIdx.x * 4; i < HW; i += kBnThreads * 4) {
+                const f32x4 a = Vec4<T>::load(p + i), d = Vec4<T>::load(g + i);
+                accum(a.x, d.x); accum(a.y, d.y); accum(a.z, d.z); accum(a.w, d.w);
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += kBnThreads) accum(load_f(p + i), load_f(g + i));
+        }
+    }
+    block_reduce<4>(v, red);
+    if (threadIdx.x == 0) {
+        float *o = part + ((int64_t)c * gridDim.y + chunk) * 4;
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    }
+}
+
+// one thread per channel; lab grads accumulated with atomics into dlab[2] (zeroed by caller)
+__global__ void bn_bwd_finalize_kernel(const float *__restrict__ part, int nchunk, int C, double count,
+                                       float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                       float *__restrict__ dlab, float *__restrict__ coef /*[C][2]*/) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int k = 0; k < nchunk; ++k) {
+        const float *p = part + ((int64_t)c * nchunk + k) * 4;
+        s0 += p[0]; s1 += p[1]; s2 += p[2]; s3 += p[3];
+    }
+    if (dgamma) dgamma[c] = (float)s1;
+    if (dbeta) dbeta[c] = (float)s0;
+    coef[2 * c] = (float)(s0 / count);       // mean(dz)
+    coef[2 * c + 1] = (float)(s1 / count);   // mean(dz * xhat)
+    if (dlab) {
+        unsafeAtomicAdd(dlab, (float)s2);
+        unsafeAtomicAdd(dlab + 1, (float)s3);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(
+    const T *__restrict__ x, const T *__restrict__ dy, T *__restrict__ dx, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ lab_s, const float *__restrict__ coef, int C, int HW, int act, int train) {
+    const int plane = blockIdx.x, c = plane % C;
+    const float mu = mean ? mean[c] : 0.f, is = invstd ? invstd[c] : 0.f, sc = scale[c], sh = shift[c];
+    const float ls = lab_s ? lab_s[0] : 1.f;
+    const float m0 = train ? coef[2 * c] : 0.f, m1 = train ? coef[2 * c + 1] : 0.f;
+    const T *p = x + (int64_t)plane * HW;
+    const T *g = dy + (int64_t)plane * HW;
+    T *q = dx + (int64_t)plane * HW;
+    auto f = [&](float xv, float gv) {
+        const float z = xv * sc + sh;
+        const float dz = gv * ls * act_grad(z, act);
+        return sc * (dz - m0 - ((xv - mu) * is) * m1);
+    };
+    const int start = blockIdx.y * kBnThreads * 16;
+    const int end = min(HW, start + kBnThreads * 16);
+    if ((HW & 3) == 0) {
+        for (int i = start + threadIdx.x * 4; i < end; i += kBnThreads * 4) {
+            const f32x4 a = Vec4<T>::load(p + i), d = Vec4<T>::load(g + i);
+            Vec4<T>::store(q + i, {f(a.x, d.x), f(a.y, d.y), f(a.z, d.z), f(a.w, d.w)});
+        }
+    } else {
+        for (int i = start + threadIdx.x; i < end; i += kBnThreads) store_f(q + i, f(load_f(p + i), load_f(g + i)));
+    }
+}
+
+static int chunks_for(int B, int C, int HW, int *imgs_per_chunk) {
+    // aim at >= ~2048 blocks and <= 64K elements per block
+    int per = B;
+    while (per > 1 && ((int64_t)C * ((B + per - 1) / per) < 2048 || (int64_t)per * HW > 65536)) per = (per + 1) / 2;
+    *imgs_per_chunk = per;
+    return (B + per - 1) / per;
+}
+
+}  // namespace dfine
+
+using namespace dfine;
+
+extern "C" {
+
+int64_t dfine_bn_ws_floats(int B, int C, int HW) {
+    int per;
+    const int nchunk = chunks_for(B, C, HW, &per);
+    return (int64_t)C * nchunk * 4 + 2 * (int64_t)C;   // partials (max of fwd 2 / bwd 4) + coef
+}
+
+int dfine_bn_act_fwd(const void *x, void *y, const float *gamma, const float *beta, float *running_mean,
+                     float *running_var, const float *lab_scale, const float *lab_bias, float *save_mean, float *save_invstd,
+                     float *scale, float *shift, float *ws, int dtype, int B, int C, int HW, int act,
+                     int training, float momentum, float eps, void *stream) {
+    if (B == 0 || C == 0 || HW == 0) return DFINE_OK;
+    if (!x || !y || !scale || !shift || act < 0 || act > 2) return DFINE_E_BADARG;
+    if (dtype != DFINE_F32 && dtype != DFINE_BF16) return DFINE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int cb = (C + 127) / 128;
+    if (training) {
+        if (!ws || !save_mean || !save_invstd) return DFINE_E_BADARG;
+        int per;
+        const int nchunk = chunks_for(B, C, HW, &per);
+        if (dtype == DFINE_F32)
+            hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(C, nchunk), dim3(kBnThreads), 0, st, (const float *)x, ws, C, HW, B, per);
+        else
+            hipLaunchKernelGGL(bn_stats_kernel<uint16_t>, dim3(C, nchunk), dim3(kBnThreads), 0, st, (const uint16_t *)x, ws, C, HW, B, per);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(cb), dim3(128), 0, st, ws, nchunk, C, (double)B * HW, gamma, beta,
+                           running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
+    } else {
+        if (!running_mean || !running_var) return DFINE_E_BADARG;
+        hipLaunchKernelGGL(bn_fold_kernel, dim3(cb), dim3(128), 0, st, C, gamma, beta, running_mean, running_var, eps, scale, shift);
+    }
+    dim3 grid(B * C, (HW + kBnThreads * 16 - 1) / (kBnThreads * 16));
+    if (dtype == DFINE_F32)
+        hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(kBnThreads), 0, st, (const float *)x, (float *)y, scale, shift, lab_scale, lab_bias, C, HW, act);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<uint16_t>, grid, dim3(kBnThreads), 0, st, (const uint16_t *)x, (uint16_t *)y, scale, shift, lab_scale, lab_bias, C, HW, act);
+    return check_launch();
+}
+
+int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_mean, const float *save_invstd,
+                     const float *scale, const float *shift, const float *lab_scale, float *dgamma, float *dbeta,
+                     float *dlab, float *ws, int dtype, int B, int C, int HW, int act, int training, void *stream) {
+    if (B == 0 || C == 0 || HW == 0) return DFINE_OK;
+    if (!x || !dy || !dx || !scale || !shift || !ws || act < 0 || act > 2) return DFINE_E_BADARG;
+    if (dtype != DFINE_F32 && dtype != DFINE_BF16) return DFINE_E_BADARG;
+    if (training && (!save_mean || !save_invstd)) return DFINE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    int per;
+    const int nchunk = chunks_for(B, C, HW, &per);
+    float *coef = ws + (int64_t)C * nchunk * 4;
+    // the reductions are needed for the parameter gradients in both modes
+    if (dtype == DFINE_F32)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(C, nchunk), dim3(kBnThreads), 0, st, (const float *)x, (const float *)dy,
+                           ws, save_mean ? save_mean : scale, save_invstd ? save_invstd : scale, scale, shift, lab_scale, C, HW, B, per, act);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<uint16_t>, dim3(C, nchunk), dim3(kBnThreads), 0, st, (const uint16_t *)x,
+                           (const uint16_t *)dy, ws, save_mean ? save_mean : scale, save_invstd ? save_invstd : scale, scale, shift,
+                           lab_scale, C, HW, B, per, act);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, ws, nchunk, C, (double)B * HW,
+                       dgamma, dbeta, dlab, coef);
+    dim3 grid(B * C, (HW + kBnThreads * 16 - 1) / (kBnThreads * 16));
+    if (dtype == DFINE_F32)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(kBnThreads), 0, st, (const float *)x, (const float *)dy, (float *)dx,
+                           save_mean, save_invstd, scale, shift, lab_scale, coef, C, HW, act, training);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<uint16_t>, grid, dim3(kBnThreads), 0, st, (const uint16_t *)x, (const uint16_t *)dy,
+                           (uint16_t *)dx, save_mean, save_invstd, scale, shift, lab_scale, coef, C, HW, act, training);
+    return check_launch();
+}
+
+}  // extern "C"

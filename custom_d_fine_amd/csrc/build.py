@@ -15,6 +15,8 @@ SOURCES = {
     "runtime.cpp": [],
     "msda.hip": ["-munsafe-fp-atomics"],
     "matcher.hip": ["-ffp-contract=off"],
+    "dwconv.hip": ["-munsafe-fp-atomics"],
+    "bnact.hip": ["-munsafe-fp-atomics"],
 }
 
 

@@ -1,0 +1,230 @@
+// A1/A2 - depthwise k x k convolution (groups == channels), NCHW, forward + both gradients.
+//
+// Reference call sites: HGNetv2 LightConvBNAct.conv2 (5x5, stride 1) and HG_Stage.downsample
+// (3x3, stride 2) - src/d_fine/arch/hgnetv2.py:96-105,295-303; HybridEncoder SCDown.cv2 (3x3,
+// stride 2) - src/d_fine/arch/hybrid_encoder.py:96-103.  ATen routes these to MIOpen, which on
+// gfx950/bf16 falls back to naive_conv kernels (forward, data grad) and a per-image
+// im2col + GEMM loop (weight grad): ~20 ms per D-FINE-m step for 0.3 % of the FLOPs.
+//
+// These are HBM/L2-bound stencils: one (image, channel) plane is independent, a plane row is
+// contiguous.  Each block owns a strip of output rows of one plane, stages the needed input rows
+// (+halo) in LDS as fp32 with coalesced loads and computes from LDS; weights are read as fp32
+// master parameters (no bf16 weight copy), accumulation is fp32.
+//   dwconv_fwd   y[b,c,oy,ox]  = sum_{ky,kx} w[c,ky,kx] * x[b,c,oy*s+ky-p, ox*s+kx-p]
+//   dwconv_dgrad dx[b,c,iy,ix] = sum_{ky,kx} w[c,ky,kx] * dy[b,c,(iy+p-ky)/s,(ix+p-kx)/s]  (exact division only)
+//   dwconv_wgrad dw[c,ky,kx]   = sum_{b,oy,ox} dy[b,c,oy,ox] * x[b,c,oy*s+ky-p, ox*s+kx-p]  (fp32 atomics per block)
+#include "common.h"
+
+namespace dfine {
+
+constexpr int kDwThreads = 256;
+constexpr int kMaxK = 7;
+
+// ---- forward: block = (plane, strip of TR output rows) ---------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kDwThreads) void dwconv_fwd_kernel(
+    const T *__restrict__ x, const float *__restrict__ w, T *__restrict__ y, int C, int H, int W,
+    int OH, int OW, int K, int S, int P, int TR) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int plane = blockIdx.x;           // b * C + c
+    const int c = plane % C;
+    const int oy0 = blockIdx.y * TR;
+    const int rows_out = min(TR, OH - oy0);
+    const int iy0 = oy0 * S - P;
+    const int rows_in = (rows_out - 1) * S + K;
+    const int WP = W + 2 * P;               // padded row length in LDS
+    float *tile = smem;                      // [rows_in][WP]
+    float *wk = smem + rows_in * WP;         // [K*K]  (rows_in <= (TR-1)*S+K by construction)
+    const T *xp = x + (int64_t)plane * H * W;
+    for (int i = threadIdx.x; i < rows_in * WP; i += kDwThreads) {
+        const int r = i / WP, cx = i - r * WP;
+        const int iy = iy0 + r, ix = cx - P;
+        tile[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? load_f(xp + (int64_t)iy * W + ix) : 0.f;
+    }
+    if (threadIdx.x < K * K) wk[threadIdx.x] = w[c * K * K + threadIdx.x];
+    __syncthreads();
+    T *yp = y + (int64_t)plane * OH * OW + (int64_t)oy0 * OW;
+    for (int o = threadIdx.x; o < rows_out * OW; o += kDwThreads) {
+        const int r = o / OW, ox = o - r * OW;
+        const float *src = tile + (r * S) * WP + ox * S;
+        float acc = 0.f;
+        for (int ky = 0; ky < K; ++ky)
+            for (int kx = 0; kx < K; ++kx) acc += wk[ky * K + kx] * src[ky * WP + kx];
+        store_f(yp + o, acc);
+    }
+}
+
+// ---- data gradient: block = (plane, strip of TR input rows) ----------------------------------
+template <typename T>
+__global__ __launch_bounds__(kDwThreads) void dwconv_dgrad_kernel(
+    const T *__restrict__ dy, const float *__restrict__ w, T *__restrict__ dx, int C, int H, int W,
+    int OH, int OW, int K, int S, int P, int TR) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int plane = blockIdx.x;
+    const int c = plane % C;
+    const int iy0 = blockIdx.y * TR;
+    const int rows_in = min(TR, H - iy0);
+    // output rows that can touch input rows [iy0, iy0+rows_in): oy in [ceil((iy0+P-K+1)/S), floor((iy0+rows_in-1+P)/S)]
+    int oy_lo = iy0 + P - K + 1;
+    oy_lo = oy_lo <= 0 ? 0 : (oy_lo + S - 1) / S;
+    int oy_hi = (iy0 + rows_in - 1 + P) / S;
+    oy_hi = min(oy_hi, OH - 1);
+    const int rows_dy = max(oy_hi - oy_lo + 1, 0);
+    float *tile = smem;                       // [rows_dy][OW]
+    float *wk = smem + rows_dy * OW;
+    const T *dyp = dy + (int64_t)plane * OH * OW + (int64_t)oy_lo * OW;
+    for (int i = threadIdx.x; i < rows_dy * OW; i += kDwThreads) tile[i] = load_f(dyp + i);
+    if (threadIdx.x < K * K) wk[threadIdx.x] = w[c * K * K + threadIdx.x];
+    __syncthreads();
+    T *dxp = dx + (int64_t)plane * H * W + (int64_t)iy0 * W;
+    for (int o = threadIdx.x; o < rows_in * W; o += kDwThreads) {
+        const int r = o / W, ix = o - r * W;
+        const int iy = iy0 + r;
+        float acc = 0.f;
+        for (int ky = 0; ky < K; ++ky) {
+            const int ty = iy + P - ky;
+            if (ty < 0 || ty % S) continue;
+            const int oy = ty / S;
+            if (oy < oy_lo || oy > oy_hi) continue;
+            for (int kx = 0; kx < K; ++kx) {
+                const int tx = ix + P - kx;
+                if (tx < 0 || tx % S) continue;
+                const int ox = tx / S;
+                if (ox >= OW) continue;
+                acc += wk[ky * K + kx] * tile[(oy - oy_lo) * OW + ox];
+            }
+        }
+        store_f(dxp + o, acc);
+    }
+}
+
+// ---- weight gradient: block = (channel, chunk of images); K*K partial sums per thread ---------
+template <typename T, int KK>
+__global__ __launch_bounds__(kDwThreads) void dwconv_wgrad_kernel(
+    const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ dw, int B, int C, int H,
+    int W, int OH, int OW, int S, int P, int imgs_per_block) {
+    const int c = blockIdx.x;
+    const int b0 = blockIdx.y * imgs_per_block, b1 = min(B, b0 + imgs_per_block);
+    float acc[KK * KK];
+#pragma unroll
+    for (int i = 0; i < KK * KK; ++i) acc[i] = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const T *xp = x + ((int64_t)b * C + c) * H * W;
+        const T *dyp = dy + ((int64_t)b * C + c) * OH * OW;
+        for (int o = threadIdx.x; o < OH * OW; o += kDwThreads) {
+            const int oy = o / OW, ox = o - oy * OW;
+            const float g = load_f(dyp + o);
+            const int iy = oy * S - P, ix = ox * S - P;
+#pragma unroll
+            for (int ky = 0; ky < KK; ++ky) {
+                const int yy = iy + ky;
+                const bool vy = yy >= 0 && yy < H;
+#pragma unroll
+                for (int kx = 0; kx < KK; ++kx) {
+                    const int xx = ix + kx;
+                    const float v = (vy && xx >= 0 && xx < W) ? load_f(xp + (int64_t)yy * W + xx) : 0.f;
+                    acc[ky * KK + kx] += g * v;
+                }
+            }
+        }
+    }
+    __shared__ float red[kDwThreads / 64][KK * KK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < KK * KK; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < KK * KK) {
+        float v = 0.f;
+        for (int wv = 0; wv < kDwThreads / 64; ++wv) v += red[wv][threadIdx.x];
+        unsafeAtomicAdd(dw + c * KK * KK + threadIdx.x, v);
+    }
+}
+
+static int pick_rows(int rows_total, int row_len_lds, int K, int S, bool fwd) {
+    // strip height so that the LDS tile stays <= ~48 KiB and there are enough blocks
+    int tr = 16;
+    while (tr > 1) {
+        const int rows_in = fwd ? (tr - 1) * S + K : tr / S + K;
+        if ((size_t)rows_in * row_len_lds * 4 <= 48 * 1024) break;
+        tr >>= 1;
+    }
+    return tr > rows_total ? rows_total : tr;
+}
+
+}  // namespace dfine
+
+using namespace dfine;
+
+extern "C" {
+
+int dfine_dwconv_fwd(const void *x, const float *w, void *y, int dtype, int B, int C, int H, int W,
+                     int K, int stride, int pad, void *stream) {
+    if (B == 0 || C == 0) return DFINE_OK;
+    if (!x || !w || !y || K < 1 || K > kMaxK || stride < 1 || pad < 0) return DFINE_E_BADARG;
+    const int OH = (H + 2 * pad - K) / stride + 1, OW = (W + 2 * pad - K) / stride + 1;
+    if (OH < 1 || OW < 1) return DFINE_E_BADARG;
+    const int WP = W + 2 * pad;
+    const int TR = pick_rows(OH, WP, K, stride, true);
+    const size_t sm = sizeof(float) * ((size_t)((TR - 1) * stride + K) * WP + K * K);
+    dim3 grid(B * C, (OH + TR - 1) / TR);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DFINE_F32)
+        hipLaunchKernelGGL(dwconv_fwd_kernel<float>, grid, dim3(kDwThreads), sm, st, (const float *)x, w,
+                           (float *)y, C, H, W, OH, OW, K, stride, pad, TR);
+    else if (dtype == DFINE_BF16)
+        hipLaunchKernelGGL(dwconv_fwd_kernel<uint16_t>, grid, dim3(kDwThreads), sm, st, (const uint16_t *)x, w,
+                           (uint16_t *)y, C, H, W, OH, OW, K, stride, pad, TR);
+    else return DFINE_E_BADARG;
+    return check_launch();
+}
+
+int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, float *dw_f32, int dtype,
+                     int B, int C, int H, int W, int K, int stride, int pad, void *stream) {
+    if (B == 0 || C == 0) return DFINE_OK;
+    if (!w || !dy || K < 1 || K > kMaxK || stride < 1 || pad < 0) return DFINE_E_BADARG;
+    if (dtype != DFINE_F32 && dtype != DFINE_BF16) return DFINE_E_BADARG;
+    const int OH = (H + 2 * pad - K) / stride + 1, OW = (W + 2 * pad - K) / stride + 1;
+    if (OH < 1 || OW < 1) return DFINE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) {
+        const int TR = pick_rows(H, OW, K, stride, false);
+        const size_t sm = sizeof(float) * ((size_t)(TR / stride + K + 1) * OW + K * K);
+        dim3 grid(B * C, (H + TR - 1) / TR);
+        if (dtype == DFINE_F32)
+            hipLaunchKernelGGL(dwconv_dgrad_kernel<float>, grid, dim3(kDwThreads), sm, st, (const float *)dy, w,
+                               (float *)dx, C, H, W, OH, OW, K, stride, pad, TR);
+        else
+            hipLaunchKernelGGL(dwconv_dgrad_kernel<uint16_t>, grid, dim3(kDwThreads), sm, st, (const uint16_t *)dy, w,
+                               (uint16_t *)dx, C, H, W, OH, OW, K, stride, pad, TR);
+        if (int e = check_launch()) return e;
+    }
+    if (dw_f32) {
+        if (!x) return DFINE_E_BADARG;
+        // dw_f32 [C, K, K] must be zero-filled by the caller (atomic accumulation over image chunks)
+        int per = 1;
+        while ((int64_t)C * ((B + per - 1) / per) > 4096 && per < B) per *= 2;
+        dim3 grid(C, (B + per - 1) / per);
+#define DFINE_WG(KK, TT)                                                                         \
+    hipLaunchKernelGGL((dwconv_wgrad_kernel<TT, KK>), grid, dim3(kDwThreads), 0, st, (const TT *)x, \
+                       (const TT *)dy, dw_f32, B, C, H, W, OH, OW, stride, pad, per)
+        if (dtype == DFINE_F32) {
+            if (K == 3) DFINE_WG(3, float); else if (K == 5) DFINE_WG(5, float);
+            else if (K == 1) DFINE_WG(1, float); else if (K == 7) DFINE_WG(7, float);
+            else return DFINE_E_BADARG;
+        } else {
+            if (K == 3) DFINE_WG(3, uint16_t); else if (K == 5) DFINE_WG(5, uint16_t);
+            else if (K == 1) DFINE_WG(1, uint16_t); else if (K == 7) DFINE_WG(7, uint16_t);
+            else return DFINE_E_BADARG;
+        }
+#undef DFINE_WG
+        if (int e = check_launch()) return e;
+    }
+    return DFINE_OK;
+}
+
+}  // extern "C"

@@ -34,6 +34,11 @@ _SIGNATURES = {
     "dfine_match_ws_bytes": (_L, [_I, _I, _I, _I]),
     "dfine_match": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P]),
     "dfine_lsap": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfine_dwconv_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_dwconv_bwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_bn_ws_floats": (_L, [_I, _I, _I]),
+    "dfine_bn_act_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "dfine_bn_act_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 for _name, (_res, _args) in _SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here = library/header mismatch
@@ -227,3 +232,69 @@ def lsap(cost_tq, sizes):
     _check(_lib.dfine_lsap(_ptr(cost_tq), _ptr(tgt_offset), c_void_p(0), _ptr(cols), K, B, Q, tmax,
                            T, _stream()), "dfine_lsap")
     return cols
+
+
+# ------------------------------------------------------------------------------------- depthwise conv
+def dwconv_forward(x, w, stride, pad):
+    B, C, H, W = x.shape
+    K = w.shape[-1]
+    OH, OW = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    y = torch.empty(B, C, OH, OW, device=x.device, dtype=x.dtype)
+    with _timed("dfine_dwconv_fwd"):
+        _check(_lib.dfine_dwconv_fwd(_ptr(x), _ptr(w), _ptr(y), _dtype_code(x), B, C, H, W, K, stride, pad,
+                                     _stream()), "dfine_dwconv_fwd")
+    return y
+
+
+def dwconv_backward(x, w, dy, stride, pad, need_dx=True, need_dw=True):
+    B, C, H, W = x.shape
+    K = w.shape[-1]
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.zeros(w.shape, device=x.device, dtype=torch.float32) if need_dw else None
+    with _timed("dfine_dwconv_bwd"):
+        _check(_lib.dfine_dwconv_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _dtype_code(x), B, C, H, W,
+                                     K, stride, pad, _stream()), "dfine_dwconv_bwd")
+    return dx, dw
+
+
+# ------------------------------------------------------------------------------------- fused BN
+_ACT = {None: 0, "relu": 1, "silu": 2, "swish": 2}
+
+
+def bn_act_forward(x, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, training,
+                   momentum, eps):
+    """x [B, C, H, W] contiguous.  Returns (y, saved) where saved feeds bn_act_backward."""
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // max(B * C, 1)
+    dev = x.device
+    y = torch.empty_like(x)
+    stats = torch.empty(4, C, device=dev, dtype=torch.float32)     # mean, invstd, scale, shift
+    ws = torch.empty(int(_lib.dfine_bn_ws_floats(B, C, HW)), device=dev, dtype=torch.float32)
+    with _timed("dfine_bn_act_fwd"):
+        _check(_lib.dfine_bn_act_fwd(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                     _ptr(running_var), _ptr(lab_scale), _ptr(lab_bias), _ptr(stats[0]),
+                                     _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(ws), _dtype_code(x),
+                                     B, C, HW, _ACT[act], 1 if training else 0, float(momentum), float(eps),
+                                     _stream()), "dfine_bn_act_fwd")
+    if not training:
+        stats[0].copy_(running_mean)
+        torch.rsqrt(running_var + eps, out=stats[1])
+    return y, stats
+
+
+def bn_act_backward(x, dy, stats, lab_scale, act, training, need_affine=True, need_lab=True):
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // max(B * C, 1)
+    dev = x.device
+    dx = torch.empty_like(x)
+    dparam = torch.empty(2, C, device=dev, dtype=torch.float32) if need_affine else None
+    dlab = torch.zeros(2, device=dev, dtype=torch.float32) if need_lab else None
+    ws = torch.empty(int(_lib.dfine_bn_ws_floats(B, C, HW)), device=dev, dtype=torch.float32)
+    with _timed("dfine_bn_act_bwd"):
+        _check(_lib.dfine_bn_act_bwd(_ptr(x), _ptr(dy), _ptr(dx), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]),
+                                     _ptr(stats[3]), _ptr(lab_scale),
+                                     _ptr(dparam[0]) if need_affine else c_void_p(0),
+                                     _ptr(dparam[1]) if need_affine else c_void_p(0), _ptr(dlab), _ptr(ws),
+                                     _dtype_code(x), B, C, HW, _ACT[act], 1 if training else 0, _stream()),
+               "dfine_bn_act_bwd")
+    return dx, dparam, dlab

@@ -127,12 +127,88 @@ def hungarian_assign(logits: torch.Tensor, boxes: torch.Tensor, tgt_labels: torc
 
 
 # =============================================================================================
-# ATen plumbing (same code on CPU and GPU) - to be replaced kernel by kernel
+# A1/A2  conv -> BatchNorm -> activation -> learnable affine units of backbone and encoder
 # =============================================================================================
+class _DepthwiseConv(torch.autograd.Function):
+    """Depthwise k x k conv, NCHW (HIP: dwconv.hip).  Weights stay fp32 master parameters."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        x = x.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad)
+        return _hip().dwconv_forward(x, weight.detach().float().contiguous(), stride, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad = ctx.cfg
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dx, dw = _hip().dwconv_backward(x, weight.detach().float().contiguous(), dy, stride, pad,
+                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dx, (dw.to(weight.dtype) if dw is not None else None), None, None
+
+
+class _BNAct(torch.autograd.Function):
+    """BatchNorm2d (+ReLU/SiLU) (+scalar affine) in one op (HIP: bnact.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, lab_scale, lab_bias, running_mean, running_var, act, training,
+                momentum, eps):
+        x = x.contiguous()
+        y, stats = _hip().bn_act_forward(x, gamma, beta, running_mean, running_var, lab_scale, lab_bias,
+                                         act, training, momentum, eps)
+        ctx.save_for_backward(x, stats, lab_scale)
+        ctx.cfg = (act, training, gamma is not None, lab_scale is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, lab_scale = ctx.saved_tensors
+        act, training, has_affine, has_lab = ctx.cfg
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dx, dparam, dlab = _hip().bn_act_backward(x, dy, stats, lab_scale, act, training, has_affine, has_lab)
+        dg = dparam[0] if has_affine else None
+        db = dparam[1] if has_affine else None
+        dls = dlab[0:1] if has_lab else None
+        dlb = dlab[1:2] if has_lab else None
+        return dx, dg, db, dls, dlb, None, None, None, None, None, None
+
+
+def _is_depthwise(conv):
+    return (conv.groups > 1 and conv.groups == conv.in_channels == conv.out_channels
+            and conv.kernel_size[0] == conv.kernel_size[1] <= 7 and conv.stride[0] == conv.stride[1]
+            and conv.padding[0] == conv.padding[1] and conv.dilation == (1, 1) and conv.bias is None
+            and isinstance(conv.padding, tuple))
+
+
 def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Optional[nn.Module]):
-    """conv(bias=False) -> BN (batch stats in training) -> {None, relu, silu, gelu} -> scalar
-    affine.  A1/A2 building block.  [ATen plumbing: MIOpen conv + native batch_norm]"""
-    y = bn(conv(x))
+    """conv(bias=False) -> BN (batch stats in training) -> {None, relu, silu} -> scalar affine; the
+    building block of HGNetv2 and the HybridEncoder.
+    GPU: depthwise convs and the whole BN/act/affine tail are HIP kernels; dense convs are still
+    MIOpen calls [ATen plumbing].  CPU tensors take the plain ATen composition below."""
+    a = act.lower() if isinstance(act, str) else act
+    if x.is_cuda and a in (None, "relu", "silu", "swish"):
+        y = _DepthwiseConv.apply(x, conv.weight, conv.stride[0], conv.padding[0]) if _is_depthwise(conv) else conv(x)
+        if isinstance(bn, nn.BatchNorm2d) and bn.track_running_stats and bn.momentum is not None:
+            training = bn.training
+            if training:
+                bn.num_batches_tracked.add_(1)
+            return _BNAct.apply(y, bn.weight, bn.bias, lab.scale if lab is not None else None,
+                                lab.bias if lab is not None else None, bn.running_mean, bn.running_var,
+                                a, training, bn.momentum, bn.eps)
+        if hasattr(bn, "running_var") and hasattr(bn, "affine") is False and hasattr(bn, "eps"):
+            # FrozenBatchNorm2d: buffers only, always "eval" statistics
+            return _BNAct.apply(y, bn.weight, bn.bias, lab.scale if lab is not None else None,
+                                lab.bias if lab is not None else None, bn.running_mean, bn.running_var,
+                                a, False, 0.0, bn.eps)
+        y = bn(y)
+    else:
+        y = bn(conv(x))
     if act is not None:
         a = act.lower()
         if a == "relu":

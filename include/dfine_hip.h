@@ -114,6 +114,46 @@ int dfine_match(const float *logits, const float *boxes, const int64_t *tgt_labe
 int dfine_lsap(const float *cost, const int *tgt_offset, void *lsap_ws, int *match_out, int K,
                int B, int Q, int Tmax, int T_total, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * A1/A2  Depthwise k x k convolution (groups == channels), NCHW.
+ * Replaces nn.Conv2d(groups=C) inside LightConvBNAct.conv2 / HG_Stage.downsample
+ * (src/d_fine/arch/hgnetv2.py:96-105,295-303) and SCDown.cv2 (src/d_fine/arch/hybrid_encoder.py:
+ * 96-103), forward and both gradients (ATen: MIOpen naive_conv / per-image im2col+GEMM).
+ *   x [B, C, H, W] dtype; w [C, 1, K, K] f32 (the fp32 master weights); y [B, C, OH, OW] dtype,
+ *   OH = (H + 2*pad - K)/stride + 1.  K <= 7.
+ *   bwd: dx (dtype, may be NULL), dw_f32 [C,1,K,K] f32 ZERO-FILLED by the caller (may be NULL; K in
+ *   {1,3,5,7}).
+ */
+int dfine_dwconv_fwd(const void *x, const float *w, void *y, int dtype, int B, int C, int H, int W,
+                     int K, int stride, int pad, void *stream);
+int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, float *dw_f32,
+                     int dtype, int B, int C, int H, int W, int K, int stride, int pad, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A1/A2  Fused BatchNorm2d (+ activation) (+ LearnableAffineBlock), NCHW.
+ * Replaces the bn -> act -> lab chain of ConvBNAct.forward (src/d_fine/arch/hgnetv2.py:25-32,
+ * 75-80) and norm -> act of ConvNormLayer(_fuse).forward (src/d_fine/arch/hybrid_encoder.py:
+ * 40-45,92-93), train (batch statistics, running-stat update with `momentum`, unbiased running
+ * variance) and eval (running statistics) modes.
+ *   y = lab_scale * act(gamma * (x - mean) * invstd + beta) + lab_bias
+ *   act: 0 none, 1 ReLU, 2 SiLU.  x, y [B, C, HW] dtype; gamma/beta/running_* [C] f32 (gamma/beta
+ *   may be NULL = 1/0); lab_scale/lab_bias scalars on the device or NULL.
+ *   save_mean/save_invstd/scale/shift [C] f32 outputs (scale/shift: folded per-channel affine, also
+ *   needed by the backward); ws: dfine_bn_ws_floats(B,C,HW) floats.
+ *   bwd: dgamma/dbeta [C] f32 (may be NULL); dlab [2] f32 ZERO-FILLED (d lab_scale, d lab_bias) or
+ *   NULL; in eval mode pass the running mean and rsqrt(running_var + eps) as save_mean/save_invstd.
+ */
+int64_t dfine_bn_ws_floats(int B, int C, int HW);
+int dfine_bn_act_fwd(const void *x, void *y, const float *gamma, const float *beta,
+                     float *running_mean, float *running_var, const float *lab_scale,
+                     const float *lab_bias, float *save_mean, float *save_invstd, float *scale,
+                     float *shift, float *ws, int dtype, int B, int C, int HW, int act, int training,
+                     float momentum, float eps, void *stream);
+int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_mean,
+                     const float *save_invstd, const float *scale, const float *shift,
+                     const float *lab_scale, float *dgamma, float *dbeta, float *dlab, float *ws,
+                     int dtype, int B, int C, int HW, int act, int training, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

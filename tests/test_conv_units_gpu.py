@@ -1,0 +1,107 @@
+"""A1/A2 parity: HIP depthwise convolution and fused BatchNorm+activation+affine vs a plain PyTorch
+fp32 reference of the same op (float kernels: tolerance 1e-4 fp32, 3e-2 bf16 storage)."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from custom_d_fine_amd import kernels
+from custom_d_fine_amd.d_fine.arch.hgnetv2 import ConvBNAct, LightConvBNAct
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,C,H,W,K,S", [(3, 16, 40, 40, 5, 1), (2, 24, 81, 79, 3, 2), (2, 8, 160, 160, 3, 2),
+                                          (1, 5, 7, 9, 5, 1), (2, 6, 20, 20, 3, 1)])
+def test_depthwise_conv_fwd_bwd(cuda, B, C, H, W, K, S):
+    torch.manual_seed(K * 10 + S)
+    x = torch.randn(B, C, H, W)
+    w = torch.randn(C, 1, K, K) * 0.3
+    P = (K - 1) // 2
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, stride=S, padding=P, groups=C)
+    go = torch.randn_like(yr)
+    yr.backward(go)
+    xg, wg = x.to(cuda).requires_grad_(True), w.to(cuda).requires_grad_(True)
+    y = kernels._DepthwiseConv.apply(xg, wg, S, P)
+    y.backward(go.to(cuda))
+    assert torch.allclose(y.cpu(), yr, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(xg.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(wg.grad.cpu(), wr.grad, rtol=1e-3, atol=1e-3 * wr.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("act", [None, "relu", "silu"])
+@pytest.mark.parametrize("shape", [(4, 12, 20, 20), (2, 7, 9, 11), (3, 32, 80, 80)])
+@pytest.mark.parametrize("lab", [False, True])
+def test_bn_act_train_fwd_bwd(cuda, act, shape, lab):
+    torch.manual_seed(0)
+    B, C, H, W = shape
+    x = torch.randn(B, C, H, W) * 2 + 0.5
+    bn = nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    ls = torch.tensor([1.3]); lb = torch.tensor([-0.2])
+    f = {None: lambda t: t, "relu": F.relu, "silu": F.silu}[act]
+
+    def ref(xin, g, b, s, t, rm, rv, training):
+        y = f(F.batch_norm(xin, rm, rv, g, b, training, 0.1, 1e-5))
+        return s * y + t if lab else y
+
+    xr = x.clone().requires_grad_(True)
+    g, b = bn.weight.detach().clone().requires_grad_(True), bn.bias.detach().clone().requires_grad_(True)
+    s, t = ls.clone().requires_grad_(True), lb.clone().requires_grad_(True)
+    rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+    yr = ref(xr, g, b, s, t, rm, rv, True)
+    go = torch.randn_like(yr)
+    yr.backward(go)
+
+    xg = x.to(cuda).requires_grad_(True)
+    gg, bg = bn.weight.detach().to(cuda).requires_grad_(True), bn.bias.detach().to(cuda).requires_grad_(True)
+    sg, tg = ls.to(cuda).requires_grad_(True), lb.to(cuda).requires_grad_(True)
+    rmg, rvg = bn.running_mean.clone().to(cuda), bn.running_var.clone().to(cuda)
+    y = kernels._BNAct.apply(xg, gg, bg, sg if lab else None, tg if lab else None, rmg, rvg, act, True, 0.1, 1e-5)
+    y.backward(go.to(cuda))
+    assert torch.allclose(y.cpu(), yr, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(rmg.cpu(), rm, rtol=1e-5, atol=1e-6) and torch.allclose(rvg.cpu(), rv, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(xg.grad.cpu(), xr.grad, rtol=1e-3, atol=1e-4)
+    assert torch.allclose(gg.grad.cpu(), g.grad, rtol=1e-3, atol=1e-3)
+    assert torch.allclose(bg.grad.cpu(), b.grad, rtol=1e-3, atol=1e-3)
+    if lab:
+        assert torch.allclose(sg.grad.cpu(), s.grad, rtol=1e-3, atol=1e-2)
+        assert torch.allclose(tg.grad.cpu(), t.grad, rtol=1e-3, atol=1e-2)
+
+
+def test_bn_act_eval_mode(cuda):
+    torch.manual_seed(1)
+    x = torch.randn(2, 6, 10, 10)
+    rm, rv = torch.randn(6) * 0.2, torch.rand(6) + 0.5
+    g, b = torch.rand(6) + 0.5, torch.randn(6) * 0.1
+    xr = x.clone().requires_grad_(True)
+    yr = F.relu(F.batch_norm(xr, rm, rv, g, b, False, 0.1, 1e-5))
+    go = torch.randn_like(yr)
+    yr.backward(go)
+    xg = x.to(cuda).requires_grad_(True)
+    rmg, rvg = rm.to(cuda), rv.to(cuda)
+    y = kernels._BNAct.apply(xg, g.to(cuda), b.to(cuda), None, None, rmg, rvg, "relu", False, 0.1, 1e-5)
+    y.backward(go.to(cuda))
+    assert torch.allclose(y.cpu(), yr, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(xg.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-5)
+    assert torch.equal(rmg.cpu(), rm) and torch.equal(rvg.cpu(), rv)          # untouched in eval
+
+
+def test_units_match_aten_composition_bf16(cuda):
+    """Whole ConvBNAct / LightConvBNAct units (HIP tail, HIP depthwise) vs the same modules on CPU fp32."""
+    torch.manual_seed(2)
+    for unit in (ConvBNAct(16, 24, 3, use_lab=True), LightConvBNAct(16, 32, 5, use_lab=True),
+                 ConvBNAct(24, 24, 3, stride=2, groups=24, use_act=False, use_lab=True)):
+        x = torch.randn(4, unit.conv1.conv.in_channels if hasattr(unit, "conv1") else unit.conv.in_channels, 40, 40)
+        unit.train()
+        ref = unit(x)
+        import copy
+        g = copy.deepcopy(unit).to(cuda)
+        for dt, tol in ((torch.float32, 2e-3), (torch.bfloat16, 6e-2)):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+                out = g(x.to(cuda))
+            assert out.dtype == dt
+            assert (out.float().cpu() - ref).abs().max() < tol * max(1.0, ref.abs().max().item())

@@ -7,7 +7,7 @@ import torch
 from custom_d_fine_amd.d_fine import dfine
 from custom_d_fine_amd.d_fine.arch import utils as U
 from tests import helpers
-from tests.test_model_cpu import _sorted_by_query
+from tests.test_model_cpu import assert_same_query_set
 
 pytestmark = pytest.mark.gpu
 G = helpers.GOLDEN_DIR
@@ -36,10 +36,8 @@ def test_eval_forward_matches_reference(cuda, size, img, batch, name):
     m = m.to(cuda).eval()
     with torch.no_grad():
         o = m(helpers.make_images(batch, img).to(cuda))
-    a = _sorted_by_query(o["pred_logits"].cpu(), o["pred_boxes"].cpu())
-    b = _sorted_by_query(torch.tensor(g["eval/pred_logits"]), torch.tensor(g["eval/pred_boxes"]))
-    assert (a[0] - b[0]).abs().max() < 1e-3
-    assert (a[1] - b[1]).abs().max() < 1e-3
+    assert_same_query_set(o["pred_logits"].cpu(), o["pred_boxes"].cpu(), torch.tensor(g["eval/pred_logits"]),
+                          torch.tensor(g["eval/pred_boxes"]))
 
 
 def test_train_step_matches_reference_n320(cuda):
