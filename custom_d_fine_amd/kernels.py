@@ -193,7 +193,12 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
     MIOpen calls [ATen plumbing].  CPU tensors take the plain ATen composition below."""
     a = act.lower() if isinstance(act, str) else act
     if x.is_cuda and a in (None, "relu", "silu", "swish"):
-        y = _DepthwiseConv.apply(x, conv.weight, conv.stride[0], conv.padding[0]) if _is_depthwise(conv) else conv(x)
+        if _is_depthwise(conv):
+            if torch.is_autocast_enabled() and x.dtype == torch.float32:
+                x = x.to(torch.get_autocast_dtype("cuda"))      # what autocast would do for F.conv2d
+            y = _DepthwiseConv.apply(x, conv.weight, conv.stride[0], conv.padding[0])
+        else:
+            y = conv(x)
         if isinstance(bn, nn.BatchNorm2d) and bn.track_running_stats and bn.momentum is not None:
             training = bn.training
             if training:
