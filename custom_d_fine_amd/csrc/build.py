@@ -17,6 +17,7 @@ SOURCES = {
     "matcher.hip": ["-ffp-contract=off"],
     "dwconv.hip": ["-munsafe-fp-atomics"],
     "bnact.hip": ["-munsafe-fp-atomics"],
+    "losses.hip": ["-munsafe-fp-atomics"],
 }
 
 

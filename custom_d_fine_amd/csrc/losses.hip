@@ -1,0 +1,358 @@
+// A13/A14 - fused set-criterion losses of one prediction head, forward values AND gradients in
+// one pass (the gradient of every term is closed-form, so the backward of the autograd node is a
+// scale of the stored buffers).
+//
+// Reference: DFINECriterion.loss_labels_vfl / loss_boxes / loss_local / unimodal_distribution_
+// focal_loss (src/d_fine/dfine_criterion.py:92-237,837-858) with bbox2distance / translate_gt /
+// weighting_function (src/d_fine/arch/utils.py:145-188,267-354) and box_iou /
+// generalized_box_iou (src/d_fine/arch/utils.py:12-51).  The reference issues ~20 small ATen
+// kernels per loss term, 48 terms per step for D-FINE-m - the criterion is host-bound (28 ms of
+// launch overhead per step on MI355X).  Here one head costs 3-6 launches:
+//   pair_box_kernel   per matched (image, query, target): IoU, GIoU, L1 (+ gradients wrt the
+//                     predicted box) and the (image,query) -> pair map
+//   vfl_kernel        varifocal loss over all B*Q*C logits
+//   row_weight_kernel per (image, query): sigmoid(max_c teacher_logit)   [DDF weights]
+//   ddf_kernel        T^2 * KL(softmax(teacher/T) || softmax(pred/T)) over all B*Q*4 edge rows
+//   fgl_kernel        fine-grained localisation CE on the matched rows, targets derived in-kernel
+// Inputs may be strided views (batch / query strides) of fp32 or bf16 tensors; math is fp32.
+// Loss sums are accumulated with one atomic per block into out[] (zeroed by the entry point).
+#include "common.h"
+
+namespace dfine {
+
+constexpr int kLT = 256;
+
+__device__ __forceinline__ float block_sum(float v, float *red) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < kLT / 64; ++w) s += red[w];
+    __syncthreads();
+    return s;   // valid on thread 0
+}
+
+struct View {            // [B, Q, inner] tensor view with unit inner stride
+    int64_t sb, sq;      // element strides of the batch and query dims
+};
+
+// ---------------------------------------------------------------------------------------------
+// plan: int64 [3, M] = (image, query, target row).  boxes cxcywh.
+template <typename T>
+__global__ __launch_bounds__(kLT) void pair_box_kernel(
+    const T *__restrict__ boxes, View bv, const float *__restrict__ tgt_boxes,
+    const int64_t *__restrict__ plan, int M, int Q, float *__restrict__ iou_out,
+    int *__restrict__ map, float *__restrict__ grad_l1, float *__restrict__ grad_giou,
+    float *__restrict__ out /* [0]+=l1 sum, [1]+=(1-giou) sum */, int with_loss, float s_l1, float s_giou) {
+    __shared__ float red[kLT / 64];
+    const int m = blockIdx.x * kLT + threadIdx.x;
+    float l1 = 0.f, lg = 0.f;
+    if (m < M) {
+        const int64_t b = plan[m], q = plan[M + m], t = plan[2 * M + m];
+        const T *sp = boxes + b * bv.sb + q * bv.sq;
+        const float cx = load_f(sp), cy = load_f(sp + 1), w = load_f(sp + 2), h = load_f(sp + 3);
+        const float4 tb = *reinterpret_cast<const float4 *>(tgt_boxes + t * 4);
+        const float hw = 0.5f * fmaxf(w, 0.f), hh = 0.5f * fmaxf(h, 0.f);
+        const float ax0 = cx - hw, ay0 = cy - hh, ax1 = cx + hw, ay1 = cy + hh;
+        const float tw = 0.5f * fmaxf(tb.z, 0.f), th = 0.5f * fmaxf(tb.w, 0.f);
+        const float bx0 = tb.x - tw, by0 = tb.y - th, bx1 = tb.x + tw, by1 = tb.y + th;
+        const float aw = ax1 - ax0, ah = ay1 - ay0;
+        const float area_a = aw * ah, area_b = (bx1 - bx0) * (by1 - by0);
+        const float iwr = fminf(ax1, bx1) - fmaxf(ax0, bx0), ihr = fminf(ay1, by1) - fmaxf(ay0, by0);
+        const float iw = fmaxf(iwr, 0.f), ih = fmaxf(ihr, 0.f);
+        const float inter = iw * ih;
+        const float uni = area_a + area_b - inter;
+        const float iou = inter / uni;
+        const float cwr = fmaxf(ax1, bx1) - fminf(ax0, bx0), chr_ = fmaxf(ay1, by1) - fminf(ay0, by0);
+        const float cw = fmaxf(cwr, 0.f), ch = fmaxf(chr_, 0.f);
+        const float hull = cw * ch;
+        const float giou = iou - (hull - uni) / hull;
+        if (iou_out) iou_out[m] = iou;
+        if (map) map[b * Q + q] = m;
+        if (with_loss) {
+            const float d0 = cx - tb.x, d1 = cy - tb.y, d2 = w - tb.z, d3 = h - tb.w;
+            l1 = fabsf(d0) + fabsf(d1) + fabsf(d2) + fabsf(d3);
+            lg = 1.f - giou;
+            float *g1 = grad_l1 + (b * Q + q) * 4;
+            g1[0] = d0 > 0.f ? s_l1 : (d0 < 0.f ? -s_l1 : 0.f);
+            g1[1] = d1 > 0.f ? s_l1 : (d1 < 0.f ? -s_l1 : 0.f);
+            g1[2] = d2 > 0.f ? s_l1 : (d2 < 0.f ? -s_l1 : 0.f);
+            g1[3] = d3 > 0.f ? s_l1 : (d3 < 0.f ? -s_l1 : 0.f);
+            // d giou / d (ax0, ay0, ax1, ay1)
+            const float ix = iwr > 0.f ? 1.f : 0.f, iy = ihr > 0.f ? 1.f : 0.f;
+            const float di[4] = {ih * ix * (ax0 > bx0 ? -1.f : 0.f), iw * iy * (ay0 > by0 ? -1.f : 0.f),
+                                 ih * ix * (ax1 < bx1 ? 1.f : 0.f), iw * iy * (ay1 < by1 ? 1.f : 0.f)};
+            const float da[4] = {-ah, -aw, ah, aw};
+            const float hx = cwr > 0.f ? 1.f : 0.f, hy = chr_ > 0.f ? 1.f : 0.f;
+            const float dh[4] = {ch * hx * (ax0 < bx0 ? -1.f : 0.f), cw * hy * (ay0 < by0 ? -1.f : 0.f),
+                                 ch * hx * (ax1 > bx1 ? 1.f : 0.f), cw * hy * (ay1 > by1 ? 1.f : 0.f)};
+            float dg[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float du = da[k] - di[k];
+                const float diou = (di[k] * uni - inter * du) / (uni * uni);
+                dg[k] = diou + (du * hull - uni * dh[k]) / (hull * hull);
+            }
+            const float sw = w > 0.f ? 0.5f : 0.f, sh = h > 0.f ? 0.5f : 0.f;
+            float *g2 = grad_giou + (b * Q + q) * 4;     // d (1 - giou) / d (cx, cy, w, h)
+            g2[0] = -s_giou * (dg[0] + dg[2]);
+            g2[1] = -s_giou * (dg[1] + dg[3]);
+            g2[2] = -s_giou * (sw * (dg[2] - dg[0]));
+            g2[3] = -s_giou * (sh * (dg[3] - dg[1]));
+        }
+    }
+    if (with_loss) {
+        const float s1 = block_sum(l1, red);
+        const float s2 = block_sum(lg, red);
+        if (threadIdx.x == 0) { unsafeAtomicAdd(out, s_l1 * s1); unsafeAtomicAdd(out + 1, s_giou * s2); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kLT) void vfl_kernel(const T *__restrict__ logits, View lv,
+                                                  const int *__restrict__ map,
+                                                  const int64_t *__restrict__ plan, int M,
+                                                  const int64_t *__restrict__ labels,
+                                                  const float *__restrict__ iou, int B, int Q, int C,
+                                                  float alpha, float gamma, float s_vfl,
+                                                  T *__restrict__ grad, float *__restrict__ out) {
+    __shared__ float red[kLT / 64];
+    const int64_t n = (int64_t)B * Q * C;
+    float acc = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * kLT + threadIdx.x; e < n; e += (int64_t)gridDim.x * kLT) {
+        const int64_t row = e / C;
+        const int c = (int)(e - row * C);
+        const int64_t b = row / Q, q = row - b * Q;
+        const float x = load_f(logits + b * lv.sb + q * lv.sq + c);
+        const float p = 1.f / (1.f + __expf(-x));
+        const int m = map[row];
+        float t = 0.f, w;
+        if (m >= 0 && labels[plan[2 * M + m]] == c) { t = iou[m]; w = t; }
+        else w = alpha * (gamma == 2.f ? p * p : __powf(p, gamma));
+        const float bce = fmaxf(x, 0.f) - x * t + log1pf(__expf(-fabsf(x)));
+        acc += w * bce;
+        store_f(grad + e, s_vfl * w * (p - t));
+    }
+    const float s = block_sum(acc, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, s_vfl * s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// w[b,q] = matched ? iou : sigmoid(max_c teacher_logits)
+template <typename T>
+__global__ __launch_bounds__(kLT) void row_weight_kernel(const T *__restrict__ tlogits, View tv,
+                                                         const int *__restrict__ map,
+                                                         const float *__restrict__ iou, int B, int Q,
+                                                         int C, float *__restrict__ wrow) {
+    const int row = blockIdx.x * kLT + threadIdx.x;
+    if (row >= B * Q) return;
+    const int m = map[row];
+    if (m >= 0) { wrow[row] = iou[m]; return; }
+    const int b = row / Q, q = row - b * Q;
+    const T *p = tlogits + (int64_t)b * tv.sb + (int64_t)q * tv.sq;
+    float mx = load_f(p);
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, load_f(p + c));
+    wrow[row] = 1.f / (1.f + __expf(-mx));
+}
+
+// one thread per (b, q, edge) row of NB bins
+template <typename T, int NB>
+__global__ __launch_bounds__(kLT) void ddf_kernel(const T *__restrict__ pred, View pv,
+                                                  const T *__restrict__ teacher, View tv,
+                                                  const int *__restrict__ map,
+                                                  const float *__restrict__ wrow, int B, int Q,
+                                                  float temp, float c_pos, float c_neg,
+                                                  T *__restrict__ grad /* [B,Q,4*NB] */,
+                                                  float *__restrict__ out) {
+    __shared__ float red[kLT / 64];
+    const int r = blockIdx.x * kLT + threadIdx.x;
+    float loss = 0.f;
+    if (r < B * Q * 4) {
+        const int row = r >> 2, edge = r & 3;
+        const int b = row / Q, q = row - b * Q;
+        const T *pp = pred + (int64_t)b * pv.sb + (int64_t)q * pv.sq + edge * NB;
+        const T *tp = teacher + (int64_t)b * tv.sb + (int64_t)q * tv.sq + edge * NB;
+        float pm = -INFINITY, tm = -INFINITY;
+        float pl[NB], tl[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            pl[j] = load_f(pp + j) / temp; tl[j] = load_f(tp + j) / temp;
+            pm = fmaxf(pm, pl[j]); tm = fmaxf(tm, tl[j]);
+        }
+        float ps = 0.f, ts = 0.f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { ps += __expf(pl[j] - pm); ts += __expf(tl[j] - tm); }
+        const float plz = pm + __logf(ps), tlz = tm + __logf(ts);
+        const bool pos = map[row] >= 0;
+        const float coef = (pos ? c_pos : c_neg) * wrow[row];
+        float kl = 0.f;
+        T *gp = grad + ((int64_t)row * 4 + edge) * NB;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const float lq = pl[j] - plz, lt = tl[j] - tlz;
+            const float tj = __expf(lt);
+            kl += tj > 0.f ? tj * (lt - lq) : 0.f;
+            store_f(gp + j, coef * temp * (__expf(lq) - tj));
+        }
+        loss = coef * temp * temp * kl;
+    }
+    const float s = block_sum(loss, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, s);
+}
+
+struct FglTable { float w[64]; int reg_max; float reg_scale; };
+
+// one thread per (pair, edge); ADDS its gradient onto grad (written by ddf_kernel or zeroed)
+template <typename T, int NB>
+__global__ __launch_bounds__(kLT) void fgl_kernel(const T *__restrict__ pred, View pv,
+                                                  const float *__restrict__ ref, View rv,
+                                                  const float *__restrict__ tgt_boxes,
+                                                  const int64_t *__restrict__ plan, int M, int Q,
+                                                  const float *__restrict__ iou, FglTable tab,
+                                                  float s_fgl, T *__restrict__ grad,
+                                                  float *__restrict__ out) {
+    __shared__ float red[kLT / 64];
+    const int r = blockIdx.x * kLT + threadIdx.x;
+    float loss = 0.f;
+    if (r < M * 4) {
+        const int m = r >> 2, edge = r & 3;
+        const int64_t b = plan[m], q = plan[M + m], t = plan[2 * M + m];
+        const float *rp = ref + b * rv.sb + q * rv.sq;
+        const float px = rp[0], py = rp[1], pw = rp[2], ph = rp[3];
+        const float4 tb = *reinterpret_cast<const float4 *>(tgt_boxes + t * 4);
+        const float tw = 0.5f * fmaxf(tb.z, 0.f), th = 0.5f * fmaxf(tb.w, 0.f);
+        const float rs = fabsf(tab.reg_scale);
+        // bbox2distance (arch/utils.py:328-354)
+        float d;
+        if (edge == 0) d = (px - (tb.x - tw)) / (pw / rs + 1e-16f) - 0.5f * rs;
+        else if (edge == 1) d = (py - (tb.y - th)) / (ph / rs + 1e-16f) - 0.5f * rs;
+        else if (edge == 2) d = ((tb.x + tw) - px) / (pw / rs + 1e-16f) - 0.5f * rs;
+        else d = ((tb.y + th) - py) / (ph / rs + 1e-16f) - 0.5f * rs;
+        // translate_gt (arch/utils.py:267-325)
+        int cnt = 0;
+        for (int j = 0; j <= tab.reg_max; ++j) cnt += (tab.w[j] - d) <= 0.f ? 1 : 0;
+        const int idx = cnt - 1;
+        float fidx, wr, wl;
+        if (idx < 0) { fidx = 0.f; wr = 0.f; wl = 1.f; }
+        else if (idx >= tab.reg_max) { fidx = (float)tab.reg_max - 0.1f; wr = 1.f; wl = 0.f; }
+        else {
+            const float dl = fabsf(d - tab.w[idx]), dr = fabsf(tab.w[idx + 1] - d);
+            wr = dl / (dl + dr); wl = 1.f - wr; fidx = (float)idx;
+        }
+        fidx = fminf(fmaxf(fidx, 0.f), (float)tab.reg_max - 0.1f);
+        const int left = (int)fidx;
+        // two-bin cross entropy (dfine_criterion.py:837-858)
+        const T *pp = pred + b * pv.sb + q * pv.sq + edge * NB;
+        float x[NB], mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { x[j] = load_f(pp + j); mx = fmaxf(mx, x[j]); }
+        float se = 0.f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) se += __expf(x[j] - mx);
+        const float lz = mx + __logf(se);
+        float xl = 0.f, xr = 0.f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { xl = j == left ? x[j] : xl; xr = j == left + 1 ? x[j] : xr; }
+        const float wi = s_fgl * iou[m];
+        loss = wi * (wl * (lz - xl) + wr * (lz - xr));
+        T *gp = grad + ((b * Q + q) * 4 + edge) * NB;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const float g = wi * ((wl + wr) * __expf(x[j] - lz) - (j == left ? wl : 0.f) - (j == left + 1 ? wr : 0.f));
+            store_f(gp + j, load_f(gp + j) + g);
+        }
+    }
+    const float s = block_sum(loss, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, s);
+}
+
+}  // namespace dfine
+
+using namespace dfine;
+
+extern "C" {
+
+// out[5] = {vfl, l1, giou, fgl, ddf} sums (zeroed here).  See include/dfine_hip.h.
+int dfine_head_losses(
+    const void *logits, int64_t l_sb, int64_t l_sq, const float *boxes, int64_t b_sb, int64_t b_sq,
+    const void *corners, int64_t c_sb, int64_t c_sq, const float *ref, int64_t r_sb, int64_t r_sq,
+    const void *teacher_corners, int64_t tc_sb, int64_t tc_sq, const void *teacher_logits,
+    int64_t tl_sb, int64_t tl_sq, const int64_t *cls_plan, int M_cls, const int64_t *box_plan,
+    int M_box, const int64_t *tgt_labels, const float *tgt_boxes, const float *wtable, int reg_max,
+    float reg_scale, float alpha, float gamma, float temp, float s_vfl, float s_l1, float s_giou,
+    float s_fgl, float ddf_c_pos, float ddf_c_neg,
+    void *grad_logits, float *grad_l1, float *grad_giou, void *grad_corners_fgl,
+    void *grad_corners_ddf, float *iou_cls, float *iou_box, int *map_cls, int *map_box, float *wrow,
+    float *out, int dtype, int B, int Q, int C, void *stream) {
+    if (!logits || !boxes || !out || !tgt_boxes || !tgt_labels || !grad_logits || !grad_l1 || !grad_giou ||
+        !map_cls || !map_box || B < 1 || Q < 1 || C < 1)
+        return DFINE_E_BADARG;
+    if (dtype != DFINE_F32 && dtype != DFINE_BF16) return DFINE_E_BADARG;
+    if (corners && (reg_max != 32 || !ref || !wtable || !grad_corners_fgl)) return DFINE_E_BADARG;
+    if ((M_cls > 0 && (!cls_plan || !iou_cls)) || (M_box > 0 && (!box_plan || !iou_box))) return DFINE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t esz = dtype == DFINE_F32 ? 4 : 2;
+    (void)hipMemsetAsync(out, 0, 5 * sizeof(float), st);
+    (void)hipMemsetAsync(map_cls, 0xFF, sizeof(int) * (size_t)B * Q, st);
+    (void)hipMemsetAsync(map_box, 0xFF, sizeof(int) * (size_t)B * Q, st);
+    (void)hipMemsetAsync(grad_l1, 0, sizeof(float) * (size_t)B * Q * 4, st);
+    (void)hipMemsetAsync(grad_giou, 0, sizeof(float) * (size_t)B * Q * 4, st);
+    const View bv{b_sb, b_sq};
+    if (M_cls > 0)   // IoU of the classification matching (VFL soft labels)
+        hipLaunchKernelGGL(pair_box_kernel<float>, dim3((M_cls + kLT - 1) / kLT), dim3(kLT), 0, st, boxes, bv, tgt_boxes,
+                           cls_plan, M_cls, Q, iou_cls, map_cls, nullptr, nullptr, nullptr, 0, 0.f, 0.f);
+    if (M_box > 0)   // L1 / GIoU of the box matching (+ IoU weights of FGL / DDF)
+        hipLaunchKernelGGL(pair_box_kernel<float>, dim3((M_box + kLT - 1) / kLT), dim3(kLT), 0, st, boxes, bv, tgt_boxes,
+                           box_plan, M_box, Q, iou_box, map_box, grad_l1, grad_giou, out + 1, 1, s_l1, s_giou);
+    const int64_t n = (int64_t)B * Q * C;
+    const int vb = (int)((n + kLT - 1) / kLT < 2048 ? (n + kLT - 1) / kLT : 2048);
+    const View lv{l_sb, l_sq};
+    if (dtype == DFINE_F32)
+        hipLaunchKernelGGL(vfl_kernel<float>, dim3(vb), dim3(kLT), 0, st, (const float *)logits, lv, map_cls, cls_plan, M_cls,
+                           tgt_labels, iou_cls, B, Q, C, alpha, gamma, s_vfl, (float *)grad_logits, out);
+    else
+        hipLaunchKernelGGL(vfl_kernel<uint16_t>, dim3(vb), dim3(kLT), 0, st, (const uint16_t *)logits, lv, map_cls, cls_plan,
+                           M_cls, tgt_labels, iou_cls, B, Q, C, alpha, gamma, s_vfl, (uint16_t *)grad_logits, out);
+    if (corners) {
+        const View pv{c_sb, c_sq};
+        const int rows = B * Q * 4;
+        if (teacher_corners) {
+            if (!teacher_logits || !wrow || !grad_corners_ddf) return DFINE_E_BADARG;
+            const View tcv{tc_sb, tc_sq}, tlv{tl_sb, tl_sq};
+            if (dtype == DFINE_F32) {
+                hipLaunchKernelGGL(row_weight_kernel<float>, dim3((B * Q + kLT - 1) / kLT), dim3(kLT), 0, st,
+                                   (const float *)teacher_logits, tlv, map_box, iou_box, B, Q, C, wrow);
+                hipLaunchKernelGGL((ddf_kernel<float, 33>), dim3((rows + kLT - 1) / kLT), dim3(kLT), 0, st, (const float *)corners,
+                                   pv, (const float *)teacher_corners, tcv, map_box, wrow, B, Q, temp, ddf_c_pos, ddf_c_neg,
+                                   (float *)grad_corners_ddf, out + 4);
+            } else {
+                hipLaunchKernelGGL(row_weight_kernel<uint16_t>, dim3((B * Q + kLT - 1) / kLT), dim3(kLT), 0, st,
+                                   (const uint16_t *)teacher_logits, tlv, map_box, iou_box, B, Q, C, wrow);
+                hipLaunchKernelGGL((ddf_kernel<uint16_t, 33>), dim3((rows + kLT - 1) / kLT), dim3(kLT), 0, st,
+                                   (const uint16_t *)corners, pv, (const uint16_t *)teacher_corners, tcv, map_box, wrow, B, Q,
+                                   temp, ddf_c_pos, ddf_c_neg, (uint16_t *)grad_corners_ddf, out + 4);
+            }
+        }
+        (void)hipMemsetAsync(grad_corners_fgl, 0, esz * (size_t)B * Q * 4 * 33, st);
+        if (M_box > 0) {
+            FglTable tab;
+            for (int j = 0; j <= reg_max; ++j) tab.w[j] = wtable[j];
+            tab.reg_max = reg_max; tab.reg_scale = reg_scale;
+            const View rv{r_sb, r_sq};
+            if (dtype == DFINE_F32)
+                hipLaunchKernelGGL((fgl_kernel<float, 33>), dim3((M_box * 4 + kLT - 1) / kLT), dim3(kLT), 0, st, (const float *)corners,
+                                   pv, ref, rv, tgt_boxes, box_plan, M_box, Q, iou_box, tab, s_fgl, (float *)grad_corners_fgl, out + 3);
+            else
+                hipLaunchKernelGGL((fgl_kernel<uint16_t, 33>), dim3((M_box * 4 + kLT - 1) / kLT), dim3(kLT), 0, st,
+                                   (const uint16_t *)corners, pv, ref, rv, tgt_boxes, box_plan, M_box, Q, iou_box, tab,
+                                   s_fgl, (uint16_t *)grad_corners_fgl, out + 3);
+        }
+    }
+    return check_launch();
+}
+
+}  // extern "C"

@@ -29,6 +29,7 @@ class _Plan:
         s = torch.cat([s for s, _ in indices])
         t = torch.cat([t + offsets[i] for i, (_, t) in enumerate(indices)])
         packed = torch.stack([b, s, t]).to(device, non_blocking=True)
+        self.packed = packed
         self.batch, self.src, self.tgt = packed[0], packed[1], packed[2]
         self.count = int(s.numel())
         self.indices = indices
@@ -366,8 +367,10 @@ class DFINECriterion(nn.Module):
 
     def forward(self, outputs, targets, **kwargs):
         assert "aux_outputs" in outputs, ""
-        outputs = self._upcast(outputs, {})
         device = outputs["pred_logits"].device
+        fused = device.type == "cuda" and self._fusable(outputs)
+        if not fused:
+            outputs = self._upcast(outputs, {})
         main = {k: v for k, v in outputs.items() if "aux" not in k}
         heads = [main] + list(outputs["aux_outputs"]) + [outputs["pre_outputs"]] + list(
             outputs["enc_aux_outputs"])
@@ -395,6 +398,10 @@ class DFINECriterion(nn.Module):
 
         def go_or(own, go_for=("boxes", "local")):
             return lambda loss: (indices_go, num_boxes_go) if loss in go_for else (own, num_boxes)
+
+        if fused:
+            return self._forward_fused(outputs, targets, indices, cached, cached_enc, indices_go,
+                                       num_boxes, num_boxes_go)
 
         losses = {}
         self._branch(outputs, targets, "", go_or(indices), losses)
@@ -440,6 +447,108 @@ class DFINECriterion(nn.Module):
                              lambda loss: (indices_dn, dn_boxes), losses)
 
         return {k: torch.nan_to_num(v, nan=0.0) for k, v in losses.items()}
+
+    # ------------------------------------------------------------------ fused GPU path
+    def _fusable(self, outputs):
+        """The HIP head-loss kernels cover the reference's default configuration."""
+        return (set(self.losses) <= {"vfl", "boxes", "local"} and self.boxes_weight_format is None
+                and self.reg_max == 32 and not outputs["enc_meta"]["class_agnostic"])
+
+    def _fdr_constants(self, outputs):
+        """W(n) table and reg_scale as host numbers (model constants; fetched once)."""
+        key = (id(outputs["up"]), id(outputs["reg_scale"]))
+        if getattr(self, "_fdr_cache", (None,))[0] != key:
+            from .arch.utils import weighting_function
+            w = weighting_function(self.reg_max, outputs["up"].detach().float(),
+                                   outputs["reg_scale"].detach().float()).cpu().tolist()
+            self._fdr_cache = (key, w, float(outputs["reg_scale"].detach().float().cpu()))
+        return self._fdr_cache[1], self._fdr_cache[2]
+
+    def _forward_fused(self, outputs, targets, indices, cached, cached_enc, indices_go, num_boxes,
+                       num_boxes_go):
+        from .. import kernels
+        dev = outputs["pred_logits"].device
+        labels, tboxes, _ = self._targets_cat(targets)
+        labels = labels.to(torch.int64)
+        tboxes = tboxes.float().contiguous()
+        wd = self.weight_dict
+        wtable, reg_scale = self._fdr_constants(outputs)
+        want_vfl, want_box, want_local = ("vfl" in self.losses, "boxes" in self.losses, "local" in self.losses)
+        go = self._plan(indices_go, targets, dev)
+        names, vecs = [], []
+
+        def run(head, suffix, cls_idx, box_idx, n_cls, n_box, local, is_dn=False, box_go_only=False):
+            cls_plan = self._plan(cls_idx, targets, dev)
+            box_plan = self._plan(box_idx, targets, dev)
+            b, q = head["pred_logits"].shape[:2]
+            corners = head.get("pred_corners") if (local and want_local) else None
+            teacher = head.get("teacher_corners") if corners is not None else None
+            c_pos = c_neg = 0.0
+            if teacher is not None:
+                if teacher is corners or (teacher.data_ptr() == corners.data_ptr() and teacher.shape == corners.shape):
+                    teacher = None          # the teacher itself: KL == 0 (ref dfine_criterion.py:197-198)
+                else:
+                    rows_pos = 4.0 * box_plan.count
+                    rows_neg = 4.0 * (b * q) - rows_pos
+                    if not is_dn:           # cached for the dn heads like the reference (:223-229)
+                        scale = 8.0 / b
+                        self.num_pos, self.num_neg = (rows_pos * scale) ** 0.5, (rows_neg * scale) ** 0.5
+                    den = self.num_pos + self.num_neg
+                    c_pos = wd["loss_ddf"] * self.num_pos / (den * rows_pos) if rows_pos > 0 else 0.0
+                    c_neg = wd["loss_ddf"] * self.num_neg / (den * rows_neg) if rows_neg > 0 else 0.0
+            cfg = {"wtable": wtable, "reg_max": self.reg_max, "reg_scale": reg_scale, "alpha": self.alpha,
+                   "gamma": self.gamma, "temp": 5.0,
+                   "s_vfl": wd["loss_vfl"] / n_cls if want_vfl else 0.0,
+                   "s_l1": wd["loss_bbox"] / n_box if want_box else 0.0,
+                   "s_giou": wd["loss_giou"] / n_box if want_box else 0.0,
+                   "s_fgl": wd["loss_fgl"] / n_box, "c_pos": c_pos, "c_neg": c_neg}
+            vec = kernels.head_losses(
+                head["pred_logits"], head["pred_boxes"], corners,
+                head["ref_points"].detach() if corners is not None else None, teacher,
+                head.get("teacher_logits") if teacher is not None else None, cls_plan.packed,
+                box_plan.packed, labels, tboxes, cfg)
+            keys = []
+            if want_vfl:
+                keys.append(("loss_vfl", 0))
+            if want_box:
+                keys += [("loss_bbox", 1), ("loss_giou", 2)]
+            if corners is not None:
+                keys.append(("loss_fgl", 3))
+                if "teacher_corners" in head:
+                    keys.append(("loss_ddf", 4))
+            vecs.append(vec)
+            names.append([(k + suffix, j) for k, j in keys])
+
+        run(outputs, "", indices, indices_go, num_boxes, num_boxes_go, True)
+        for i, aux in enumerate(outputs["aux_outputs"]):
+            run(aux, f"_aux_{i}", cached[i], indices_go, num_boxes, num_boxes_go, True)
+        run(outputs["pre_outputs"], "_pre", cached[-1], indices_go, num_boxes, num_boxes_go, False)
+        for i, aux in enumerate(outputs["enc_aux_outputs"]):
+            run(aux, f"_enc_{i}", cached_enc[i], indices_go, num_boxes, num_boxes_go, False)
+        if "dn_outputs" in outputs:
+            indices_dn = self.get_cdn_matched_indices(outputs["dn_meta"], targets)
+            dn_boxes = num_boxes * outputs["dn_meta"]["dn_num_group"]
+            dn_boxes = dn_boxes if dn_boxes > 0 else 1
+            for i, aux in enumerate(outputs["dn_outputs"]):
+                run(aux, f"_dn_{i}", indices_dn, indices_dn, dn_boxes, dn_boxes, True, is_dn=True)
+            if "dn_pre_outputs" in outputs:
+                run(outputs["dn_pre_outputs"], "_dn_pre", indices_dn, indices_dn, dn_boxes, dn_boxes, False,
+                    is_dn=True)
+        table = torch.nan_to_num(torch.stack(vecs), nan=0.0)      # [heads, 5]
+        self._last_table = table
+        losses = {}
+        for h, keys in enumerate(names):
+            for k, j in keys:
+                losses[k] = table[h, j]
+        return losses
+
+    def total(self, loss_dict):
+        """Sum of all returned losses.  On the fused path the values are views of one table, so
+        the sum is one reduction instead of len(loss_dict) - 1 scalar adds."""
+        t = getattr(self, "_last_table", None)
+        if t is not None and loss_dict and next(iter(loss_dict.values()))._base is t:
+            return t.sum()
+        return sum(loss_dict.values())
 
     def get_loss_meta_info(self, loss, outputs, targets, indices):
         if self.boxes_weight_format is None:

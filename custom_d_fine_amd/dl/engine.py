@@ -92,7 +92,8 @@ class TrainStep:
             outputs = self.model(images, targets=targets)
         with torch.autocast(dev_type, enabled=False):
             loss_dict = self.criterion(outputs, targets)
-        loss = sum(loss_dict.values()) / self.accum_steps
+        total = self.criterion.total(loss_dict) if hasattr(self.criterion, "total") else sum(loss_dict.values())
+        loss = total / self.accum_steps
         loss.backward()
         self._micro += 1
         if self._micro % self.accum_steps == 0:

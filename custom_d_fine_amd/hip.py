@@ -38,6 +38,9 @@ _SIGNATURES = {
     "dfine_dwconv_bwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_bn_ws_floats": (_L, [_I, _I, _I]),
     "dfine_bn_act_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "dfine_head_losses": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _P, _I,
+                                   _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P,
+                                   _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_bn_act_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 for _name, (_res, _args) in _SIGNATURES.items():
@@ -298,3 +301,51 @@ def bn_act_backward(x, dy, stats, lab_scale, act, training, need_affine=True, ne
                                      _dtype_code(x), B, C, HW, _ACT[act], 1 if training else 0, _stream()),
                "dfine_bn_act_bwd")
     return dx, dparam, dlab
+
+
+# ------------------------------------------------------------------------------------- losses
+def _view3(t):
+    """(ptr, batch stride, query stride) of a [B, Q, inner] view with unit inner stride."""
+    if t is None:
+        return c_void_p(0), 0, 0
+    assert t.dim() == 3 and t.stride(2) == 1, "loss kernels need a unit inner stride"
+    return _ptr(t), t.stride(0), t.stride(1)
+
+
+def head_losses(logits, boxes, corners, ref, teacher_corners, teacher_logits, cls_plan, box_plan,
+                tgt_labels, tgt_boxes, wtable, reg_max, reg_scale, alpha, gamma, temp, s_vfl, s_l1,
+                s_giou, s_fgl, c_pos, c_neg):
+    """One launch group for all losses of a head.  Returns (out[5], grad_logits, grad_l1, grad_giou,
+    grad_corners_fgl, grad_corners_ddf) - see dfine_head_losses in include/dfine_hip.h."""
+    B, Q, C = logits.shape
+    dev = logits.device
+    dt = logits.dtype
+    m_cls, m_box = int(cls_plan.shape[1]), int(box_plan.shape[1])
+    out = torch.empty(5, device=dev, dtype=torch.float32)
+    g_logits = torch.empty(B, Q, C, device=dev, dtype=dt)
+    g_box = torch.empty(2, B, Q, 4, device=dev, dtype=torch.float32)
+    scratch_f = torch.empty(m_cls + m_box + B * Q, device=dev, dtype=torch.float32)
+    scratch_i = torch.empty(2, B * Q, device=dev, dtype=torch.int32)
+    g_fgl = g_ddf = None
+    if corners is not None:
+        nb = corners.shape[-1]
+        g_fgl = torch.empty(B, Q, nb, device=dev, dtype=dt)
+        if teacher_corners is not None:
+            g_ddf = torch.empty(B, Q, nb, device=dev, dtype=dt)
+    lp, lsb, lsq = _view3(logits)
+    bp, bsb, bsq = _view3(boxes)
+    cp, csb, csq = _view3(corners)
+    rp, rsb, rsq = _view3(ref)
+    tcp, tcsb, tcsq = _view3(teacher_corners)
+    tlp, tlsb, tlsq = _view3(teacher_logits)
+    wt = (c_float * len(wtable))(*wtable) if wtable is not None else None
+    _check(_lib.dfine_head_losses(
+        lp, lsb, lsq, bp, bsb, bsq, cp, csb, csq, rp, rsb, rsq, tcp, tcsb, tcsq, tlp, tlsb, tlsq,
+        _ptr(cls_plan), m_cls, _ptr(box_plan), m_box, _ptr(tgt_labels), _ptr(tgt_boxes), wt,
+        int(reg_max), float(reg_scale), float(alpha), float(gamma), float(temp), float(s_vfl),
+        float(s_l1), float(s_giou), float(s_fgl), float(c_pos), float(c_neg), _ptr(g_logits),
+        _ptr(g_box[0]), _ptr(g_box[1]), _ptr(g_fgl), _ptr(g_ddf), _ptr(scratch_f[:m_cls]),
+        _ptr(scratch_f[m_cls:m_cls + m_box]), _ptr(scratch_i[0]), _ptr(scratch_i[1]),
+        _ptr(scratch_f[m_cls + m_box:]), _ptr(out), _dtype_code(logits), B, Q, C, _stream()),
+        "dfine_head_losses")
+    return out, g_logits, g_box[0], g_box[1], g_fgl, g_ddf

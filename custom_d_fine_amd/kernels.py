@@ -127,6 +127,63 @@ def hungarian_assign(logits: torch.Tensor, boxes: torch.Tensor, tgt_labels: torc
 
 
 # =============================================================================================
+# A13/A14  set-criterion losses of one prediction head (values + gradients in one launch group)
+# =============================================================================================
+class _HeadLosses(torch.autograd.Function):
+    """-> tensor[5] = (vfl, l1, giou, fgl, ddf), already weighted and normalised.  The kernels
+    compute the closed-form gradients in the forward pass; backward only scales them."""
+
+    @staticmethod
+    def forward(ctx, logits, boxes, corners, ref, teacher_corners, teacher_logits, cls_plan,
+                box_plan, tgt_labels, tgt_boxes, cfg):
+        hip = _hip()
+        if boxes.dtype != torch.float32:
+            boxes = boxes.float()
+        dt = logits.dtype
+
+        def same(t):
+            return None if t is None else (t if t.dtype == dt else t.to(dt))
+
+        corners_k, tc, tl = same(corners), same(teacher_corners), same(teacher_logits)
+        out, g_logits, g_l1, g_giou, g_fgl, g_ddf = hip.head_losses(
+            logits, boxes, corners_k, None if ref is None else ref.float(), tc, tl, cls_plan,
+            box_plan, tgt_labels, tgt_boxes, cfg["wtable"], cfg["reg_max"], cfg["reg_scale"],
+            cfg["alpha"], cfg["gamma"], cfg["temp"], cfg["s_vfl"], cfg["s_l1"], cfg["s_giou"],
+            cfg["s_fgl"], cfg["c_pos"], cfg["c_neg"])
+        ctx.grads = (g_logits, g_l1, g_giou, g_fgl, g_ddf)
+        ctx.dtypes = (boxes.dtype, None if corners is None else corners.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g_logits, g_l1, g_giou, g_fgl, g_ddf = ctx.grads
+        ctx.grads = None
+        d_logits = g_logits * g[0].to(g_logits.dtype)
+        d_boxes = g_l1 * g[1] + g_giou * g[2]
+        d_corners = None
+        if g_fgl is not None:
+            d_corners = g_fgl * g[3].to(g_fgl.dtype)
+            if g_ddf is not None:
+                d_corners = d_corners + g_ddf * g[4].to(g_ddf.dtype)
+            if ctx.dtypes[1] is not None and d_corners.dtype != ctx.dtypes[1]:
+                d_corners = d_corners.to(ctx.dtypes[1])
+        return d_logits, d_boxes, d_corners, None, None, None, None, None, None, None, None
+
+
+def head_losses(logits, boxes, corners, ref, teacher_corners, teacher_logits, cls_plan, box_plan,
+                tgt_labels, tgt_boxes, cfg):
+    """Fused VFL + L1/GIoU + FGL + DDF of one head on the GPU (csrc/losses.hip).  logits [B,Q,C],
+    boxes [B,Q,4], corners/teacher_* [B,Q,4*(reg_max+1)] or None may be strided views;
+    *_plan int64 [3, M] (image, query, target row).  No CPU form: the criterion composes the same
+    terms from torch ops for CPU tensors."""
+    if not logits.is_cuda:
+        raise RuntimeError("kernels.head_losses is a HIP operator (CPU tensors use the torch composition "
+                           "in DFINECriterion)")
+    return _HeadLosses.apply(logits, boxes, corners, ref, teacher_corners, teacher_logits, cls_plan,
+                             box_plan, tgt_labels, tgt_boxes, cfg)
+
+
+# =============================================================================================
 # A1/A2  conv -> BatchNorm -> activation -> learnable affine units of backbone and encoder
 # =============================================================================================
 class _DepthwiseConv(torch.autograd.Function):

@@ -154,6 +154,38 @@ int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_
                      const float *lab_scale, float *dgamma, float *dbeta, float *dlab, float *ws,
                      int dtype, int B, int C, int HW, int act, int training, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * A13/A14  All set-criterion losses of ONE prediction head, values and gradients in one call.
+ * Replaces DFINECriterion.loss_labels_vfl / loss_boxes / loss_local (+ unimodal_distribution_
+ * focal_loss, bbox2distance, translate_gt, box_iou, generalized_box_iou):
+ * src/d_fine/dfine_criterion.py:92-237,837-858; src/d_fine/arch/utils.py:12-51,267-354.
+ *
+ *   logits  [B,Q,C] dtype, strided view (element strides l_sb, l_sq; inner stride 1)
+ *   boxes   [B,Q,4] f32 view (cxcywh);  corners [B,Q,4*(reg_max+1)] dtype view or NULL;
+ *   ref [B,Q,4] f32 view (FDR reference boxes);  teacher_corners / teacher_logits dtype views or
+ *   NULL (no distillation term);  reg_max must be 32 when corners are given.
+ *   cls_plan / box_plan: i64 [3, M] = (image, query, row of the batch-concatenated targets) of the
+ *   matching used for the classification term resp. the box / local terms (the "GO" union);
+ *   tgt_labels [T] i64, tgt_boxes [T,4] f32;  wtable [reg_max+1] HOST array W(n).
+ *   s_vfl, s_l1, s_giou, s_fgl: final scale of each term (loss weight / normaliser);
+ *   ddf_c_pos / ddf_c_neg: coefficient of a matched / unmatched edge row
+ *        = w_ddf * sqrt(n) / ((sqrt(n_pos)+sqrt(n_neg)) * rows)   (dfine_criterion.py:223-235).
+ *   outputs: out[5] = {vfl, l1, giou, fgl, ddf} (scaled);  grad_logits [B,Q,C] dtype;
+ *   grad_l1, grad_giou [B,Q,4] f32;  grad_corners_fgl, grad_corners_ddf [B,Q,4*33] dtype.
+ *   scratch: iou_cls [M_cls], iou_box [M_box] f32; map_cls, map_box [B*Q] i32; wrow [B*Q] f32.
+ */
+int dfine_head_losses(
+    const void *logits, int64_t l_sb, int64_t l_sq, const float *boxes, int64_t b_sb, int64_t b_sq,
+    const void *corners, int64_t c_sb, int64_t c_sq, const float *ref, int64_t r_sb, int64_t r_sq,
+    const void *teacher_corners, int64_t tc_sb, int64_t tc_sq, const void *teacher_logits,
+    int64_t tl_sb, int64_t tl_sq, const int64_t *cls_plan, int M_cls, const int64_t *box_plan,
+    int M_box, const int64_t *tgt_labels, const float *tgt_boxes, const float *wtable, int reg_max,
+    float reg_scale, float alpha, float gamma, float temp, float s_vfl, float s_l1, float s_giou,
+    float s_fgl, float ddf_c_pos, float ddf_c_neg, void *grad_logits, float *grad_l1,
+    float *grad_giou, void *grad_corners_fgl, void *grad_corners_ddf, float *iou_cls, float *iou_box,
+    int *map_cls, int *map_box, float *wrow, float *out, int dtype, int B, int Q, int C,
+    void *stream);
+
 #ifdef __cplusplus
 }
 #endif
