@@ -39,13 +39,22 @@ def build_step(model_name, img, device, amp_dtype, num_classes=80, channels_last
         model = model.to(memory_format=torch.channels_last)
     criterion = dfine.build_loss(model_name, num_classes, 0.0, False)
     ema = ModelEMA(model, 0.9998)
-    model = wrap_data_parallel(model, device)
+    fused = None
     opt = dfine.build_optimizer(model, lr=base_lr, backbone_lr=backbone_lr, betas=(0.9, 0.999),
                                 weight_decay=1.25e-4, base_lr=base_lr)
+    if device.type == "cuda" and os.environ.get("DFINE_FUSED_OPT", "1") == "1":
+        # flat-buffer clip + AdamW + EMA kernels; data parallelism = one all-reduce of the flat grads
+        from custom_d_fine_amd.dl.fused_optim import FusedAdamWEMA
+        fused = FusedAdamWEMA(model, opt, ema, clip_max_norm=0.1)
+        fused.broadcast_from_rank0()
+    else:
+        model = wrap_data_parallel(model, device)
+        opt = dfine.build_optimizer(model, lr=base_lr, backbone_lr=backbone_lr, betas=(0.9, 0.999),
+                                    weight_decay=1.25e-4, base_lr=base_lr)
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=base_lr * 2, total_steps=100000,
                                                 pct_start=0.1, cycle_momentum=False)
     return TrainStep(model, criterion, opt, amp_dtype=amp_dtype, clip_max_norm=0.1, ema=ema,
-                     scheduler=sched)
+                     scheduler=sched, fused_optimizer=fused)
 
 
 def msda_algorithmic_bytes(batch, lq, heads=8, head_dim=32, points=12, elt=2):

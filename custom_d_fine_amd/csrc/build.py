@@ -18,6 +18,7 @@ SOURCES = {
     "dwconv.hip": ["-munsafe-fp-atomics"],
     "bnact.hip": ["-munsafe-fp-atomics"],
     "losses.hip": ["-munsafe-fp-atomics"],
+    "optim.hip": ["-munsafe-fp-atomics"],
 }
 
 

@@ -21,6 +21,8 @@
 //    coalesced loads (fused mode: raw offsets + logits, softmax done from LDS).
 //  * backward: same walk; d(value) by hardware f32 atomics into an f32 accumulator (zeroed by the
 //    caller), d(loc)/d(weight) reduced over the task's lanes with wave shuffles.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace dfine {
@@ -251,6 +253,93 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
     }
 }
 
+// Backward, "wide" mapping: D lanes per task, one channel per lane.  The f32 atomics of one
+// (task, corner) then cover one contiguous 4*D-byte run (a single 128 B line for D = 32) instead of
+// four quarter-filled lines - the L2 atomic units are paced by line operations, not by bytes.
+template <typename T, int D, bool FUSED>
+__global__ __launch_bounds__(kThreads) void msda_bwd_wide_kernel(
+    const T *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ weight,
+    const float *__restrict__ ref, const T *__restrict__ offsets, const T *__restrict__ logits,
+    const T *__restrict__ grad_out, float *__restrict__ grad_value, float *__restrict__ grad_loc,
+    float *__restrict__ grad_weight, T *__restrict__ grad_offsets, T *__restrict__ grad_logits,
+    MsdaLevels lv, int L, int H, int Lq, int total_q, float offset_scale) {
+    constexpr int LPT = D;
+    constexpr int QPB = kThreads / LPT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int P = lv.n_points;
+    float *s_x = smem, *s_y = smem + QPB * P, *s_w = smem + 2 * QPB * P;
+    float *s_gx = smem + 3 * QPB * P, *s_gy = smem + 4 * QPB * P, *s_gw = smem + 5 * QPB * P;
+    float *s_dot = smem + 6 * QPB * P;
+
+    const int head = blockIdx.x % H;
+    const int q0 = (blockIdx.x / H) * QPB;
+    const int nq = min(QPB, total_q - q0);
+    stage_points<T, FUSED>(lv, loc, weight, ref, offsets, logits, offset_scale, head, H, q0, nq,
+                           total_q, s_x, s_y, s_w);
+    __syncthreads();
+
+    const int qi = threadIdx.x / LPT, ch = threadIdx.x % LPT;
+    if (qi < nq) {
+        const int gq = q0 + qi;
+        const int b = gq / Lq;
+        const int64_t stride = (int64_t)H * D;
+        const int64_t base = ((int64_t)b * L * H + head) * D + ch;
+        const T *vbase = value + base;
+        float *gvbase = grad_value + base;
+        float *px = s_x + qi * P, *py = s_y + qi * P, *pw = s_w + qi * P;
+        const float go = load_f(grad_out + ((int64_t)gq * H + head) * D + ch);
+
+        float wmax = 0.f, winv = 1.f;
+        if (FUSED) {
+            wmax = pw[0];
+            for (int p = 1; p < P; ++p) wmax = fmaxf(wmax, pw[p]);
+            float s = 0.f;
+            for (int p = 0; p < P; ++p) s += __expf(pw[p] - wmax);
+            winv = 1.f / s;
+        }
+        float dot_acc = 0.f;
+        for (int p = 0; p < P; ++p) {
+            const Corner c = corners(px[p], py[p], lv.start[p], lv.h[p], lv.w[p]);
+            const float aw = FUSED ? __expf(pw[p] - wmax) * winv : pw[p];
+            float d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                d[k] = go * load_f(vbase + c.row[k] * stride) * c.ok[k];
+                const float g = aw * c.bw[k];
+                if (g != 0.f) unsafeAtomicAdd(gvbase + c.row[k] * stride, g * go);
+            }
+            float gw = c.wy0 * c.wx0 * d[0] + c.wy0 * c.wx1 * d[1] + c.wy1 * c.wx0 * d[2] + c.wy1 * c.wx1 * d[3];
+            float gx = (c.wy0 * (d[1] - d[0]) + c.wy1 * (d[3] - d[2])) * aw * (float)lv.w[p];
+            float gy = (c.wx0 * (d[2] - d[0]) + c.wx1 * (d[3] - d[1])) * aw * (float)lv.h[p];
+            gw = group_sum<LPT>(gw);
+            gx = group_sum<LPT>(gx);
+            gy = group_sum<LPT>(gy);
+            dot_acc += aw * gw;
+            if (ch == 0) {
+                s_gx[qi * P + p] = gx; s_gy[qi * P + p] = gy; s_gw[qi * P + p] = gw;
+                if (FUSED) pw[p] = aw;
+            }
+        }
+        if (ch == 0) s_dot[qi] = dot_acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nq * P; i += kThreads) {
+        const int qj = i / P, p = i - qj * P;
+        const int64_t task = (int64_t)(q0 + qj) * H + head;
+        if (FUSED) {
+            const float4 r = *reinterpret_cast<const float4 *>(ref + (int64_t)(q0 + qj) * 4);
+            const float sc = lv.inv_n[p] * offset_scale;
+            store_f(grad_offsets + (task * P + p) * 2, s_gx[i] * sc * r.z);
+            store_f(grad_offsets + (task * P + p) * 2 + 1, s_gy[i] * sc * r.w);
+            store_f(grad_logits + task * P + p, s_w[i] * (s_gw[i] - s_dot[qj]));
+        } else {
+            grad_loc[(task * P + p) * 2] = s_gx[i];
+            grad_loc[(task * P + p) * 2 + 1] = s_gy[i];
+            grad_weight[task * P + p] = s_gw[i];
+        }
+    }
+}
+
 __global__ void cast_f32_bf16_kernel(const float *__restrict__ src, uint16_t *__restrict__ dst, int64_t n) {
     int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int64_t step = (int64_t)gridDim.x * blockDim.x * 4;
@@ -307,6 +396,23 @@ static int launch_bwd(const void *value, const float *loc, const float *weight, 
                       float offset_scale, hipStream_t st) {
     const int total_q = B * Lq;
     if (total_q == 0) return DFINE_OK;
+    static const int variant = [] { const char *e = getenv("DFINE_MSDA_BWD"); return e ? atoi(e) : 1; }();
+    if (variant == 1 && (D == 32 || D == 16 || D == 64)) {
+#define DFINE_BWDW(DD)                                                                         \
+    {                                                                                          \
+        constexpr int QPB = kThreads / DD;                                                     \
+        const int nblk = ((total_q + QPB - 1) / QPB) * H;                                      \
+        const size_t sm = sizeof(float) * (6 * QPB * lv.n_points + QPB);                       \
+        hipLaunchKernelGGL((msda_bwd_wide_kernel<T, DD, FUSED>), dim3(nblk), dim3(kThreads), sm, st, \
+                           (const T *)value, loc, weight, ref, (const T *)offsets,             \
+                           (const T *)logits, (const T *)grad_out, grad_value, grad_loc,       \
+                           grad_weight, (T *)grad_offsets, (T *)grad_logits, lv, L, H, Lq,     \
+                           total_q, offset_scale);                                             \
+    }
+        if (D == 32) DFINE_BWDW(32) else if (D == 16) DFINE_BWDW(16) else DFINE_BWDW(64)
+#undef DFINE_BWDW
+        return check_launch();
+    }
 #define DFINE_BWD(DD)                                                                          \
     {                                                                                          \
         constexpr int QPB = kThreads / (DD / 4);                                               \

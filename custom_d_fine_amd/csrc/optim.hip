@@ -1,0 +1,130 @@
+// A16 - optimizer step on flat fp32 buffers: global-norm gradient clipping + AdamW + EMA (+ the
+// zero_grad of the next step) in two launches per parameter group.
+//
+// Reference: Trainer.optimizer_step (src/dl/train.py:512-535) = clip_grad_norm_(max_norm) ->
+// AdamW.step -> zero_grad -> ModelEMA.update (src/dl/train.py:52-73; two ops per state-dict tensor,
+// 2106 launches for D-FINE-m) with the four parameter groups of build_optimizer
+// (src/d_fine/dfine.py:87-124).  Here parameters, gradients, both Adam moments and the EMA copy
+// live in flat buffers (the nn.Parameters are views), so the whole step is HBM-streaming work:
+//   sqnorm_kernel   sum g^2 over all trainable parameters            (1 read)
+//   adamw_ema_kernel per group: reads p, g, m, v, ema; writes p, m, v, ema, g := 0
+// PyTorch semantics reproduced: clip coefficient min(1, max_norm / (norm + 1e-6)); decoupled weight
+// decay p *= 1 - lr*wd; m, v moments; bias corrections 1 - beta^t; denom = sqrt(v)/sqrt(bc2) + eps.
+#include "common.h"
+
+namespace dfine {
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float *__restrict__ g, int64_t n, float grad_scale,
+                                                     float *__restrict__ out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int64_t step = (int64_t)gridDim.x * 256 * 4;
+    for (; i + 3 < n; i += step) {
+        const float4 v = *reinterpret_cast<const float4 *>(g + i);
+        acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    if (i < n) for (int64_t j = i; j < n && j < i + 4; ++j) acc += g[j] * g[j];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, (red[0] + red[1] + red[2] + red[3]) * grad_scale * grad_scale);
+}
+
+struct AdamArgs {
+    float lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale, max_norm, ema_momentum;
+};
+
+__global__ __launch_bounds__(256) void adamw_ema_kernel(float *__restrict__ p, float *__restrict__ g,
+                                                        float *__restrict__ m, float *__restrict__ v,
+                                                        float *__restrict__ ema, int64_t n,
+                                                        const float *__restrict__ sqnorm, AdamArgs a) {
+    float clip = 1.f;
+    if (a.max_norm > 0.f && sqnorm) {
+        const float c = a.max_norm / (sqrtf(sqnorm[0]) + 1e-6f);
+        clip = c < 1.f ? c : 1.f;
+    }
+    const float gs = a.grad_scale * clip;
+    const float decay = 1.f - a.lr * a.weight_decay;
+    const float step_size = a.lr / a.bc1;
+    auto upd = [&](float &pp, float gg, float &mm, float &vv, float &ee) {
+        gg *= gs;
+        pp *= decay;
+        mm = a.beta1 * mm + (1.f - a.beta1) * gg;
+        vv = a.beta2 * vv + (1.f - a.beta2) * gg * gg;
+        pp -= step_size * mm / (sqrtf(vv) / a.bc2_sqrt + a.eps);
+        ee = ee * a.ema_momentum + (1.f - a.ema_momentum) * pp;
+    };
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int64_t step = (int64_t)gridDim.x * 256 * 4;
+    for (; i + 3 < n; i += step) {
+        float4 P = *reinterpret_cast<float4 *>(p + i), G = *reinterpret_cast<float4 *>(g + i);
+        float4 M = *reinterpret_cast<float4 *>(m + i), V = *reinterpret_cast<float4 *>(v + i);
+        float4 E = ema ? *reinterpret_cast<float4 *>(ema + i) : make_float4(0, 0, 0, 0);
+        upd(P.x, G.x, M.x, V.x, E.x); upd(P.y, G.y, M.y, V.y, E.y);
+        upd(P.z, G.z, M.z, V.z, E.z); upd(P.w, G.w, M.w, V.w, E.w);
+        *reinterpret_cast<float4 *>(p + i) = P; *reinterpret_cast<float4 *>(m + i) = M;
+        *reinterpret_cast<float4 *>(v + i) = V;
+        if (ema) *reinterpret_cast<float4 *>(ema + i) = E;
+        *reinterpret_cast<float4 *>(g + i) = make_float4(0, 0, 0, 0);
+    }
+    if (i < n)
+        for (int64_t j = i; j < n && j < i + 4; ++j) {
+            float e = ema ? ema[j] : 0.f;
+            upd(p[j], g[j], m[j], v[j], e);
+            if (ema) ema[j] = e;
+            g[j] = 0.f;
+        }
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(float *__restrict__ ema, const float *__restrict__ src, int64_t n,
+                                                  float momentum) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * 256;
+    for (; i < n; i += step) ema[i] = ema[i] * momentum + (1.f - momentum) * src[i];
+}
+
+static int grid_for(int64_t n, int per_thread) {
+    int64_t b = (n / per_thread + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace dfine
+
+using namespace dfine;
+
+extern "C" {
+
+int dfine_grad_sqnorm(const float *grad, int64_t n, float grad_scale, float *out_zeroed, void *stream) {
+    if (n == 0) return DFINE_OK;
+    if (!grad || !out_zeroed || n < 0) return DFINE_E_BADARG;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, grad, n, grad_scale, out_zeroed);
+    return check_launch();
+}
+
+int dfine_adamw_ema_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, float *ema, int64_t n,
+                         const float *sqnorm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         int step, float grad_scale, float max_norm, float ema_momentum, void *stream) {
+    if (n == 0) return DFINE_OK;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return DFINE_E_BADARG;
+    AdamArgs a;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    a.grad_scale = grad_scale; a.max_norm = max_norm; a.ema_momentum = ema_momentum;
+    hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, ema, n, sqnorm, a);
+    return check_launch();
+}
+
+int dfine_ema_update(float *ema, const float *src, int64_t n, float momentum, void *stream) {
+    if (n == 0) return DFINE_OK;
+    if (!ema || !src || n < 0) return DFINE_E_BADARG;
+    hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n, 1)), dim3(256), 0, (hipStream_t)stream, ema, src, n, momentum);
+    return check_launch();
+}
+
+}  // extern "C"

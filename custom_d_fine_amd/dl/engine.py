@@ -64,15 +64,22 @@ class TrainStep:
     """fwd (autocast) -> criterion (fp32) -> bwd -> clip -> AdamW -> [scheduler] -> EMA."""
 
     def __init__(self, model, criterion, optimizer, *, amp_dtype=None, clip_max_norm=0.1,
-                 ema=None, scheduler=None, accum_steps=1):
+                 ema=None, scheduler=None, accum_steps=1, fused_optimizer=None):
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
         self.amp_dtype, self.clip_max_norm = amp_dtype, clip_max_norm
         self.ema, self.scheduler, self.accum_steps = ema, scheduler, max(accum_steps, 1)
         self.iters = 0
         self._micro = 0
         self._params = [p for p in model.parameters() if p.requires_grad]
+        self.fused = fused_optimizer      # FusedAdamWEMA (GPU): clip + AdamW + EMA + zero_grad + all-reduce
 
     def optimizer_step(self, step_scheduler=True):
+        if self.fused is not None:
+            self.fused.step()
+            if step_scheduler and self.scheduler is not None:
+                self.scheduler.step()
+            self.iters += 1
+            return
         if self.clip_max_norm:
             torch.nn.utils.clip_grad_norm_(self._params, self.clip_max_norm, foreach=True)
         self.optimizer.step()

@@ -1,0 +1,139 @@
+"""Flat-buffer optimizer step for the GPU: global-norm clip + AdamW + EMA + zero_grad in
+(1 + number of parameter groups + 1) HIP launches (csrc/optim.hip), and data-parallel gradient
+averaging as ONE RCCL all-reduce of the flat gradient buffer.
+
+The step semantics are the reference's (`src/dl/train.py:512-535`, `ModelEMA` `:52-73`,
+parameter groups from `build_optimizer`, `src/d_fine/dfine.py:87-124`); hyper-parameters - including
+the per-group learning rates a scheduler may have updated - are read from the torch optimizer that
+`build_optimizer` returned, every step.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from ..d_fine.dist_utils import get_world_size, is_dist_available_and_initialized
+
+
+def _flatten_into(tensors, flat):
+    """Copies `tensors` into consecutive slices of `flat` and returns views shaped like them."""
+    views, off = [], 0
+    for t in tensors:
+        n = t.numel()
+        v = flat[off:off + n].view_as(t)
+        v.copy_(t)
+        views.append(v)
+        off += n
+    return views
+
+
+class FusedAdamWEMA:
+    """Wraps a torch AdamW (for its param_groups / scheduler interface) and a ModelEMA.
+
+    After construction every trainable parameter of `model` (and of the EMA copy) is a view into
+    one flat fp32 buffer, `.grad` is a persistent view into a flat gradient buffer (autograd
+    accumulates in place), and float buffers (BatchNorm statistics) are views into a flat buffer
+    too, so EMA is a handful of streaming kernels instead of two launches per tensor.
+    """
+
+    def __init__(self, model, optimizer, ema=None, clip_max_norm=0.1):
+        from .. import hip
+        self.hip = hip
+        self.model, self.optimizer, self.ema = model, optimizer, ema
+        self.clip_max_norm = float(clip_max_norm or 0.0)
+        self.step_count = 0
+        self.ema_iters = 0
+        dev = next(model.parameters()).device
+        assert dev.type == "cuda", "FusedAdamWEMA drives HIP kernels; parameters must live on the GPU"
+
+        groups = [[p for p in g["params"] if p.requires_grad] for g in optimizer.param_groups]
+        for g in groups:
+            for p in g:
+                assert p.dtype == torch.float32
+        sizes = [sum(p.numel() for p in g) for g in groups]
+        # keep each group 16-byte aligned for the float4 kernels
+        padded = [(s + 3) // 4 * 4 for s in sizes]
+        total = sum(padded)
+        self.flat_param = torch.zeros(total, device=dev)
+        self.flat_grad = torch.zeros(total, device=dev)
+        self.exp_avg = torch.zeros(total, device=dev)
+        self.exp_avg_sq = torch.zeros(total, device=dev)
+        self.flat_ema = torch.zeros(total, device=dev) if ema is not None else None
+        self.sqnorm = torch.zeros(1, device=dev)
+        self.segments = []
+        ema_params = dict(ema.model.named_parameters()) if ema is not None else {}
+        names = {id(p): n for n, p in model.named_parameters()}
+        off = 0
+        for g, size, pad in zip(groups, sizes, padded):
+            seg = slice(off, off + size)
+            views = _flatten_into([p.data for p in g], self.flat_param[seg])
+            gviews = _flatten_into([torch.zeros_like(p) for p in g], self.flat_grad[seg])
+            for p, v, gv in zip(g, views, gviews):
+                p.data = v
+                p.grad = gv
+            if ema is not None:
+                eps_ = [ema_params[names[id(p)].replace("module.", "", 1) if names[id(p)].startswith("module.")
+                                   else names[id(p)]] for p in g]
+                eviews = _flatten_into([e.data for e in eps_], self.flat_ema[seg])
+                for e, v in zip(eps_, eviews):
+                    e.data = v
+            self.segments.append((off, size))
+            off += pad
+
+        # float buffers (BatchNorm running statistics, anchors, ...) for the EMA of the buffers
+        self.flat_buf = self.flat_ema_buf = None
+        if ema is not None:
+            stu_bufs = [(n, b) for n, b in model.named_buffers() if b.dtype == torch.float32]
+            ema_bufs = dict(ema.model.named_buffers())
+            if stu_bufs:
+                nb = sum(b.numel() for _, b in stu_bufs)
+                self.flat_buf = torch.zeros(nb, device=dev)
+                self.flat_ema_buf = torch.zeros(nb, device=dev)
+                sviews = _flatten_into([b for _, b in stu_bufs], self.flat_buf)
+                eviews = _flatten_into([ema_bufs[n.replace("module.", "", 1) if n.startswith("module.") else n]
+                                        for n, _ in stu_bufs], self.flat_ema_buf)
+                for (n, b), sv, ev in zip(stu_bufs, sviews, eviews):
+                    b.data = sv                # in-place kernels (BN running stats) now write the flat buffer
+                    key = n.replace("module.", "", 1) if n.startswith("module.") else n
+                    ema_bufs[key].data = ev
+            # parameters outside the optimizer (frozen) never change: their EMA stays equal
+
+    # -------------------------------------------------------------------------------------
+    def broadcast_from_rank0(self):
+        if is_dist_available_and_initialized() and get_world_size() > 1:
+            dist.broadcast(self.flat_param, 0)
+            if self.flat_buf is not None:
+                dist.broadcast(self.flat_buf, 0)
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+    def step(self):
+        """all-reduce (if data parallel) -> norm -> per-group AdamW+EMA (also zeroes the grads)."""
+        hip = self.hip
+        world = get_world_size()
+        if world > 1:
+            # one large collective over xGMI instead of per-bucket calls: 78 MB for D-FINE-m
+            dist.all_reduce(self.flat_grad)
+        grad_scale = 1.0 / world
+        self.step_count += 1
+        if self.clip_max_norm > 0:
+            self.sqnorm.zero_()
+            hip.grad_sqnorm(self.flat_grad, grad_scale, self.sqnorm)
+        mom = 0.0
+        if self.ema is not None:
+            self.ema_iters += 1
+            mom = self.ema.ema_scheduler(self.ema_iters)
+        for (off, size), group in zip(self.segments, self.optimizer.param_groups):
+            if size == 0:
+                continue
+            b1, b2 = group["betas"]
+            seg = slice(off, off + size)
+            hip.adamw_ema_step(self.flat_param[seg], self.flat_grad[seg], self.exp_avg[seg], self.exp_avg_sq[seg],
+                               self.flat_ema[seg] if self.flat_ema is not None else None,
+                               self.sqnorm if self.clip_max_norm > 0 else None, group["lr"], b1, b2, group["eps"],
+                               group["weight_decay"], self.step_count, grad_scale, self.clip_max_norm, mom)
+        if self.flat_buf is not None:
+            hip.ema_update(self.flat_ema_buf, self.flat_buf, mom)
+        # keep torch's scheduler bookkeeping consistent (it warns if optimizer.step was never called)
+        self.optimizer._opt_called = True

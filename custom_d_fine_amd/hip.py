@@ -41,6 +41,9 @@ _SIGNATURES = {
     "dfine_head_losses": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _P, _I,
                                    _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P,
                                    _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfine_grad_sqnorm": (c_int, [_P, _L, _F, _P, _P]),
+    "dfine_adamw_ema_step": (c_int, [_P, _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _I, _F, _F, _F, _P]),
+    "dfine_ema_update": (c_int, [_P, _P, _L, _F, _P]),
     "dfine_bn_act_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 for _name, (_res, _args) in _SIGNATURES.items():
@@ -349,3 +352,21 @@ def head_losses(logits, boxes, corners, ref, teacher_corners, teacher_logits, cl
         _ptr(scratch_f[m_cls + m_box:]), _ptr(out), _dtype_code(logits), B, Q, C, _stream()),
         "dfine_head_losses")
     return out, g_logits, g_box[0], g_box[1], g_fgl, g_ddf
+
+
+# ------------------------------------------------------------------------------------- optimizer
+def grad_sqnorm(flat_grad, grad_scale, out):
+    _check(_lib.dfine_grad_sqnorm(_ptr(flat_grad), flat_grad.numel(), float(grad_scale), _ptr(out), _stream()),
+           "dfine_grad_sqnorm")
+
+
+def adamw_ema_step(param, grad, exp_avg, exp_avg_sq, ema, sqnorm, lr, beta1, beta2, eps, weight_decay, step,
+                   grad_scale, max_norm, ema_momentum):
+    _check(_lib.dfine_adamw_ema_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(ema),
+                                     param.numel(), _ptr(sqnorm), float(lr), float(beta1), float(beta2), float(eps),
+                                     float(weight_decay), int(step), float(grad_scale), float(max_norm),
+                                     float(ema_momentum), _stream()), "dfine_adamw_ema_step")
+
+
+def ema_update(ema, src, momentum):
+    _check(_lib.dfine_ema_update(_ptr(ema), _ptr(src), ema.numel(), float(momentum), _stream()), "dfine_ema_update")

@@ -186,6 +186,25 @@ int dfine_head_losses(
     int *map_cls, int *map_box, float *wrow, float *out, int dtype, int B, int Q, int C,
     void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * A16  Optimizer step on flat fp32 buffers (parameters are views into them).
+ * Replaces clip_grad_norm_ + AdamW.step + zero_grad + ModelEMA.update
+ * (src/dl/train.py:52-73,512-535; parameter groups: src/d_fine/dfine.py:87-124).
+ *   dfine_grad_sqnorm      out_zeroed[0] += grad_scale^2 * sum(grad^2)   (all groups, then sqrt in
+ *                          the step kernel: global L2 norm of the averaged gradient)
+ *   dfine_adamw_ema_step   one parameter group: g' = grad * grad_scale * min(1, max_norm /
+ *                          (sqrt(sqnorm) + 1e-6)) (max_norm <= 0 or sqnorm NULL: no clipping);
+ *                          AdamW update (torch.optim.AdamW semantics, `step` = 1-based step count);
+ *                          ema = ema * m + (1 - m) * param (ema may be NULL); grad := 0.
+ *   dfine_ema_update       ema = ema * m + (1 - m) * src   (BatchNorm statistics buffers)
+ */
+int dfine_grad_sqnorm(const float *grad, int64_t n, float grad_scale, float *out_zeroed, void *stream);
+int dfine_adamw_ema_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, float *ema,
+                         int64_t n, const float *sqnorm, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int step, float grad_scale, float max_norm,
+                         float ema_momentum, void *stream);
+int dfine_ema_update(float *ema, const float *src, int64_t n, float momentum, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
