@@ -116,6 +116,8 @@ def main():
 
     from custom_d_fine_amd import hip
     from custom_d_fine_amd.dl.synthetic import make_batch
+    if os.environ.get("DFINE_MIOPEN_BENCHMARK", "0") == "1":
+        torch.backends.cudnn.benchmark = True
     torch.manual_seed(42 + rank)
     amp = torch.bfloat16 if args.dtype == "bf16" else None
     step = build_step(args.model, args.img, device, amp, channels_last=bool(args.channels_last))

@@ -31,8 +31,8 @@ class FusedAdamWEMA:
     """Wraps a torch AdamW (for its param_groups / scheduler interface) and a ModelEMA.
 
     After construction every trainable parameter of `model` (and of the EMA copy) is a view into
-    one flat fp32 buffer, `.grad` is a persistent view into a flat gradient buffer (autograd
-    accumulates in place), and float buffers (BatchNorm statistics) are views into a flat buffer
+    one flat fp32 buffer, gradients are gathered into a flat gradient buffer right before the step,
+    and float buffers (BatchNorm statistics) are views into a flat buffer
     too, so EMA is a handful of streaming kernels instead of two launches per tensor.
     """
 
@@ -61,6 +61,7 @@ class FusedAdamWEMA:
         self.flat_ema = torch.zeros(total, device=dev) if ema is not None else None
         self.sqnorm = torch.zeros(1, device=dev)
         self.segments = []
+        self._params, self._grad_views = [], []
         ema_params = dict(ema.model.named_parameters()) if ema is not None else {}
         names = {id(p): n for n, p in model.named_parameters()}
         off = 0
@@ -70,7 +71,8 @@ class FusedAdamWEMA:
             gviews = _flatten_into([torch.zeros_like(p) for p in g], self.flat_grad[seg])
             for p, v, gv in zip(g, views, gviews):
                 p.data = v
-                p.grad = gv
+            self._params.extend(g)
+            self._grad_views.extend(gviews)
             if ema is not None:
                 eps_ = [ema_params[names[id(p)].replace("module.", "", 1) if names[id(p)].startswith("module.")
                                    else names[id(p)]] for p in g]
@@ -107,11 +109,27 @@ class FusedAdamWEMA:
 
     def zero_grad(self):
         self.flat_grad.zero_()
+        for p in self._params:
+            p.grad = None
+
+    def _collect_grads(self):
+        """Gathers the per-parameter gradients autograd produced into the flat buffer with one
+        multi-tensor copy and drops them.  (Keeping `.grad` as persistent views instead makes
+        autograd ADD into them - one tiny kernel per parameter, 646 per step for D-FINE-m.)"""
+        views, grads = [], []
+        for p, v in zip(self._params, self._grad_views):
+            if p.grad is not None:
+                views.append(v)
+                grads.append(p.grad)
+                p.grad = None
+        if grads:
+            torch._foreach_copy_(views, grads)
 
     def step(self):
         """all-reduce (if data parallel) -> norm -> per-group AdamW+EMA (also zeroes the grads)."""
         hip = self.hip
         world = get_world_size()
+        self._collect_grads()
         if world > 1:
             # one large collective over xGMI instead of per-bucket calls: 78 MB for D-FINE-m
             dist.all_reduce(self.flat_grad)
