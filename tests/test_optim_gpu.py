@@ -14,13 +14,14 @@ from custom_d_fine_amd.dl.fused_optim import FusedAdamWEMA
 pytestmark = pytest.mark.gpu
 
 
-# NB: no conv bias in front of BatchNorm (as in D-FINE): such a bias has an exactly-zero gradient, Adam
+# NB: no conv bias / affine shift directly in front of a BatchNorm (as in D-FINE): such a parameter has
+# an exactly-zero gradient, Adam
 # turns its float noise into +-lr updates and any two correct implementations diverge on it.
 class Tiny(nn.Module):
     def __init__(self):
         super().__init__()
-        self.backbone = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1, bias=False), nn.BatchNorm2d(8))
-        self.encoder = nn.Sequential(nn.Conv2d(8, 8, 1, bias=False), nn.BatchNorm2d(8))
+        self.backbone = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1, bias=False), nn.BatchNorm2d(8), nn.ReLU())
+        self.encoder = nn.Sequential(nn.Conv2d(8, 8, 1, bias=False), nn.BatchNorm2d(8), nn.ReLU())
         self.decoder = nn.Linear(8, 5)
         self.register_buffer("anchors", torch.rand(1, 7, 4))
 
