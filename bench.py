@@ -66,6 +66,19 @@ def msda_algorithmic_bytes(batch, lq, heads=8, head_dim=32, points=12, elt=2):
     return per_img * batch
 
 
+def msda_pmc_traffic(batch, lq, dtype):
+    """HBM bytes per launch of the gather kernel from the committed PMC passes (profiles/), or None
+    when this run's shape differs from the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r01_msda_pmc.json")
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    sh = rec["shape"]
+    if (sh["B"], sh["Lq"], sh["dtype"]) != (batch, lq, dtype):
+        return None
+    return rec["traffic_bytes_per_launch"]
+
+
 def cpu_baseline(model_name, img, steps):
     """The same train step on the host through the oracle backend (kind 'port')."""
     from oracle import torch_backend
@@ -170,7 +183,8 @@ def main():
                        "global_batch": args.batch * world, "queries": lq, "parallelism": f"dp{world}"},
             "roofline": {"kernel": "msda_fwd_kernel (dfine_msda_fused_fwd)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": msda_pmc_traffic(args.batch, lq, args.dtype),
                          "algorithmic_bytes_per_launch": algo, "launches": n_fwd,
                          "avg_launch_ms": round(ms_fwd, 4),
                          "bwd_avg_launch_ms": round(ms_bwd, 4), "bwd_launches": n_bwd},

@@ -1,0 +1,85 @@
+"""Deployment-side pieces of the hot path: the fused detection post-processor and the wrapper
+that bakes it behind the model (reference `src/dl/export.py:20-128`).  The reference's ONNX ->
+TensorRT / OpenVINO exporters are NVIDIA/Intel tool-chains and out of scope (SURVEY.md section 2
+row 13); `export_torchscript` writes a TorchScript-free `torch.export`-style artefact instead: the
+plain state dict plus the post-processor configuration.
+"""
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..d_fine.dfine import build_model
+
+
+class DFINEPostProcessor(nn.Module):
+    """sigmoid -> top-K over Q*C -> (label = idx % C, query = idx // C) -> absolute xyxy boxes.
+    Returns (labels [B,K] i64, boxes [B,K,4] f32, scores [B,K] f32[, masks [B,K,Hm,Wm]])."""
+
+    def __init__(self, num_classes: int, num_top_queries: int = 300, use_focal_loss: bool = True):
+        super().__init__()
+        self.num_classes, self.num_top_queries = num_classes, num_top_queries
+        self.use_focal_loss = use_focal_loss
+
+    @staticmethod
+    def norm_xywh_to_abs_xyxy(boxes: torch.Tensor, height: int, width: int, to_round=True) -> torch.Tensor:
+        cx, cy = boxes[:, 0] * width, boxes[:, 1] * height
+        hw, hh = boxes[:, 2] * width / 2, boxes[:, 3] * height / 2
+        x0, y0, x1, y1 = cx - hw, cy - hh, cx + hw, cy + hh
+        if to_round:      # floor/ceil and keep one pixel of margin, like the reference (export.py:49-53)
+            x0, y0 = torch.clamp(torch.floor(x0), min=1), torch.clamp(torch.floor(y0), min=1)
+            x1 = torch.clamp(torch.ceil(x1), max=width - 1)
+            y1 = torch.clamp(torch.ceil(y1), max=height - 1)
+        else:
+            x0, y0 = torch.clamp(x0, min=0), torch.clamp(y0, min=0)
+            x1, y1 = torch.clamp(x1, max=width), torch.clamp(y1, max=height)
+        return torch.stack([x0, y0, x1, y1], dim=1)
+
+    def forward(self, outputs: dict, input_h: int, input_w: int):
+        logits, boxes = outputs["pred_logits"], outputs["pred_boxes"]
+        masks = outputs.get("pred_masks", None)
+        b, q = boxes.shape[:2]
+        abs_boxes = self.norm_xywh_to_abs_xyxy(boxes.flatten(0, 1), input_h, input_w).view(b, q, 4)
+        if self.use_focal_loss:
+            flat = torch.sigmoid(logits).flatten(1)
+            k = min(self.num_top_queries, flat.shape[1])
+            scores, idx = torch.topk(flat, k, dim=-1)
+            labels, qidx = idx % self.num_classes, idx // self.num_classes
+        else:
+            probs = F.softmax(logits, dim=-1)[:, :, :-1]
+            scores, labels = probs.max(dim=-1)
+            k = min(self.num_top_queries, scores.shape[1])
+            scores, qidx = torch.topk(scores, k, dim=-1)
+            labels = labels.gather(1, qidx)
+        out = (labels, abs_boxes.gather(1, qidx.unsqueeze(-1).expand(-1, -1, 4)), scores)
+        if masks is not None:
+            hm, wm = masks.shape[2:]
+            out = out + (masks.gather(1, qidx[..., None, None].expand(-1, -1, hm, wm)),)
+        return out
+
+
+class ExportWrapper(nn.Module):
+    def __init__(self, model: nn.Module, postprocessor: DFINEPostProcessor, input_size):
+        super().__init__()
+        self.model, self.postprocessor = model, postprocessor
+        self.input_h, self.input_w = input_size[0], input_size[1]
+
+    def forward(self, x):
+        return self.postprocessor(self.model(x), self.input_h, self.input_w)
+
+
+def prepare_model(cfg, device):
+    """cfg: mapping with model_name, task, train.{label_to_name,img_size,path_to_save}."""
+    model = build_model(cfg["model_name"], len(cfg["train"]["label_to_name"]),
+                        enable_mask_head=cfg.get("task", "detect") == "segment", device=device,
+                        img_size=cfg["train"]["img_size"])
+    model.load_state_dict(torch.load(Path(cfg["train"]["path_to_save"]) / "model.pt", weights_only=True))
+    return model.eval()
+
+
+def export_artifact(model, num_classes, img_size, path):
+    """Self-describing checkpoint for the HIP runtime: weights + post-processor configuration."""
+    torch.save({"state_dict": model.state_dict(), "num_classes": num_classes, "img_size": list(img_size),
+                "postprocessor": {"num_top_queries": 300, "use_focal_loss": True}}, path)
+    return path

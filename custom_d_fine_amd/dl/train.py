@@ -1,0 +1,145 @@
+"""`python -m custom_d_fine_amd.dl.train [key=value ...]` (alias: `python -m src.dl.train`).
+
+Train-loop counterpart of the reference's `src/dl/train.py` for the hot path only: model / loss /
+optimizer construction, data-parallel set-up, AMP, the optimisation step, `last.pt` / `model.pt`
+weight-only checkpoints.  Dataset loading, evaluation and logging
+are outside the path; a synthetic COCO-shaped loader stands in for the data pipeline.
+Configuration: the reference's YAML keys (`config.yaml`) given as `key=value` overrides or a YAML
+file via `config=path.yaml`; no hydra.
+"""
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+from ..d_fine import dist_utils
+from ..d_fine.dfine import build_loss, build_model, build_optimizer
+from .engine import ModelEMA, TrainStep, wrap_data_parallel
+from .synthetic import make_batch
+
+DEFAULTS = {
+    "model_name": "m", "task": "detect", "exp": "exp",
+    "train": {
+        "device": "cuda", "num_classes": 80, "img_size": [640, 640], "batch_size": 32, "b_accum_steps": 1,
+        "epochs": 1, "steps_per_epoch": 50, "amp_enabled": True, "amp_dtype": "bf16", "clip_max_norm": 0.1,
+        "use_ema": True, "ema_momentum": 0.9998, "base_lr": 1.5e-4, "backbone_lr": 2e-5,
+        "betas": [0.9, 0.999], "weight_decay": 1.25e-4, "cycler_pct_start": 0.1, "use_scheduler": True,
+        "label_smoothing": 0.0, "seed": 42, "ddp": {"enabled": False}, "path_to_save": "output/models/exp",
+        "pretrained_model_path": None,
+    },
+}
+
+
+def _merge(cfg, key, value):
+    parts = key.split(".")
+    d = cfg
+    for p in parts[:-1]:
+        d = d.setdefault(p, {})
+    import yaml
+    d[parts[-1]] = yaml.safe_load(value)
+
+
+def load_config(argv):
+    import copy
+    import yaml
+    cfg = copy.deepcopy(DEFAULTS)
+    for a in argv:
+        k, _, v = a.partition("=")
+        if k == "config":
+            user = yaml.safe_load(open(v))
+
+            def rec(dst, src):
+                for kk, vv in src.items():
+                    if isinstance(vv, dict) and isinstance(dst.get(kk), dict):
+                        rec(dst[kk], vv)
+                    else:
+                        dst[kk] = vv
+            rec(cfg, user)
+    for a in argv:
+        k, _, v = a.partition("=")
+        if k != "config":
+            _merge(cfg, k, v)
+    return cfg
+
+
+class Trainer:
+    def __init__(self, cfg):
+        t = cfg["train"]
+        self.cfg = cfg
+        self.distributed = bool(t["ddp"]["enabled"]) and dist_utils.is_dist_available_and_initialized()
+        self.rank, self.world = dist_utils.get_rank(), dist_utils.get_world_size()
+        if t["device"] == "cuda" and torch.cuda.is_available():
+            self.device = torch.device("cuda", dist_utils.get_local_rank())
+        else:
+            self.device = torch.device("cpu")
+        torch.manual_seed(t["seed"] + (self.rank if self.distributed else 0))
+        mask = cfg["task"] == "segment"
+        self.model = build_model(cfg["model_name"], t["num_classes"], mask, str(self.device),
+                                 img_size=t["img_size"], pretrained_model_path=t["pretrained_model_path"]).train()
+        self.loss_fn = build_loss(cfg["model_name"], t["num_classes"], t["label_smoothing"], mask)
+        self.ema = ModelEMA(self.model, t["ema_momentum"]) if t["use_ema"] else None
+        self.optimizer = build_optimizer(self.model, lr=t["base_lr"], backbone_lr=t["backbone_lr"],
+                                         betas=tuple(t["betas"]), weight_decay=t["weight_decay"],
+                                         base_lr=t["base_lr"])
+        fused = None
+        if self.device.type == "cuda":
+            from .fused_optim import FusedAdamWEMA
+            fused = FusedAdamWEMA(self.model, self.optimizer, self.ema, clip_max_norm=t["clip_max_norm"])
+            fused.broadcast_from_rank0()
+        elif self.distributed:
+            self.model = wrap_data_parallel(self.model, self.device)
+        sched = None
+        if t["use_scheduler"]:
+            sched = torch.optim.lr_scheduler.OneCycleLR(
+                self.optimizer, max_lr=t["base_lr"] * 2, epochs=t["epochs"],
+                steps_per_epoch=max(t["steps_per_epoch"] // max(t["b_accum_steps"], 1), 1),
+                pct_start=t["cycler_pct_start"], cycle_momentum=False)
+        amp = None
+        if t["amp_enabled"] and self.device.type == "cuda":
+            amp = torch.bfloat16 if t["amp_dtype"] == "bf16" else torch.float16
+        self.step = TrainStep(self.model, self.loss_fn, self.optimizer, amp_dtype=amp,
+                              clip_max_norm=t["clip_max_norm"], ema=self.ema, scheduler=sched,
+                              accum_steps=t["b_accum_steps"], fused_optimizer=fused)
+        self.path_to_save = Path(t["path_to_save"])
+
+    def save_model(self):
+        """Weight-only checkpoints, EMA weights when enabled (reference train.py:476-503)."""
+        m = self.ema.model if self.ema is not None else self.model
+        m = m.module if hasattr(m, "module") else m
+        self.path_to_save.mkdir(parents=True, exist_ok=True)
+        torch.save(m.state_dict(), self.path_to_save / "last.pt")
+        torch.save(m.state_dict(), self.path_to_save / "model.pt")
+
+    def train(self):
+        t = self.cfg["train"]
+        size = t["img_size"][0]
+        for epoch in range(1, t["epochs"] + 1):
+            t0, losses = time.time(), []
+            for it in range(t["steps_per_epoch"]):
+                images, targets = make_batch(t["batch_size"], size, t["num_classes"],
+                                             seed=t["seed"] + self.rank + 1000 * it, device=self.device,
+                                             with_masks=self.cfg["task"] == "segment")
+                loss, _ = self.step(images, targets)
+                losses.append(loss)
+            mean = torch.stack(losses).mean().item()
+            if self.rank == 0:
+                n = t["steps_per_epoch"] * t["batch_size"] * self.world
+                print(f"epoch {epoch}: loss {mean:.4f}, {n / (time.time() - t0):.1f} img/s", flush=True)
+                self.save_model()
+            dist_utils.synchronize()
+
+
+def main(argv=None):
+    cfg = load_config(sys.argv[1:] if argv is None else argv)
+    if cfg["train"]["ddp"]["enabled"]:
+        dist_utils.init_distributed_mode()
+    try:
+        Trainer(cfg).train()
+    finally:
+        dist_utils.cleanup_distributed()
+
+
+if __name__ == "__main__":
+    main()
