@@ -44,6 +44,9 @@ _SIGNATURES = {
     "dfine_grad_sqnorm": (c_int, [_P, _L, _F, _P, _P]),
     "dfine_adamw_ema_step": (c_int, [_P, _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _I, _F, _F, _F, _P]),
     "dfine_ema_update": (c_int, [_P, _P, _L, _F, _P]),
+    "dfine_conv_packed_elems": (_L, [_I, _I, _I, _I]),
+    "dfine_conv_pack_weights": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "dfine_conv_fwd_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_bn_act_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 for _name, (_res, _args) in _SIGNATURES.items():
@@ -370,3 +373,23 @@ def adamw_ema_step(param, grad, exp_avg, exp_avg_sq, ema, sqnorm, lr, beta1, bet
 
 def ema_update(ema, src, momentum):
     _check(_lib.dfine_ema_update(_ptr(ema), _ptr(src), ema.numel(), float(momentum), _stream()), "dfine_ema_update")
+
+
+# ------------------------------------------------------------------------------------- MFMA conv
+def conv_pack_weights(weight_f32, dgrad):
+    cout, cin, ks, _ = weight_f32.shape
+    n = int(_lib.dfine_conv_packed_elems(cout, cin, ks, 1 if dgrad else 0))
+    w2 = torch.empty(n, device=weight_f32.device, dtype=torch.bfloat16)
+    _check(_lib.dfine_conv_pack_weights(_ptr(weight_f32), _ptr(w2), cout, cin, ks, 1 if dgrad else 0, _stream()),
+           "dfine_conv_pack_weights")
+    return w2
+
+
+def conv_forward_bf16(x, w2, cout, ks):
+    """x [B, Cin, H, W] bf16 contiguous, w2 packed by conv_pack_weights -> y [B, cout, H, W] bf16."""
+    B, cin, H, W = x.shape
+    y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.bfloat16)
+    with _timed("dfine_conv_fwd_bf16"):
+        _check(_lib.dfine_conv_fwd_bf16(_ptr(x), _ptr(w2), _ptr(y), B, cin, cout, H, W, ks, _stream()),
+               "dfine_conv_fwd_bf16")
+    return y

@@ -11,6 +11,7 @@ Operators that are still composed from ATen calls (MIOpen convolutions, rocBLAS 
 are marked "ATen plumbing" - they run the same code on CPU and GPU and are the next ones to be
 replaced by HIP kernels (DESIGN.md "kernel status").
 """
+import os
 from typing import List, Optional
 
 import torch
@@ -236,6 +237,50 @@ class _BNAct(torch.autograd.Function):
         return dx, dg, db, dls, dlb, None, None, None, None, None, None
 
 
+class _DenseConvMFMA(torch.autograd.Function):
+    """1x1 / 3x3 stride-1 dense convolution, NCHW bf16 (HIP: conv.hip).  Forward and data gradient run
+    on the implicit-GEMM MFMA kernel; the weight gradient is still MIOpen's [ATen plumbing]."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        hip = _hip()
+        x = x.contiguous()
+        w32 = weight.detach().float().contiguous()
+        ks = weight.shape[-1]
+        y = hip.conv_forward_bf16(x, hip.conv_pack_weights(w32, False), weight.shape[0], ks)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        hip = _hip()
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        ks = weight.shape[-1]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            w2d = hip.conv_pack_weights(weight.detach().float().contiguous(), True)
+            dx = hip.conv_forward_bf16(dy, w2d, weight.shape[1], ks)
+        if ctx.needs_input_grad[1]:
+            pad = ks // 2
+            dw = torch.ops.aten.convolution_backward(
+                dy, x, weight.detach().to(torch.bfloat16), None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
+                [False, True, False])[1].to(weight.dtype)
+        return dx, dw
+
+
+def _mfma_conv_ok(conv, x):
+    k = conv.kernel_size
+    return (os.environ.get("DFINE_MFMA_CONV", "1") == "1" and conv.groups == 1 and k[0] == k[1] and k[0] in (1, 3)
+            and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.bias is None
+            and isinstance(conv.padding, tuple) and conv.padding == (k[0] // 2, k[0] // 2)
+            and conv.in_channels % 16 == 0 and conv.out_channels % 16 == 0 and x.dim() == 4
+            and (k[0] == 1 or (x.shape[-1] % 2 == 0 and x.shape[-1] <= 160))
+            and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+
+
 def _is_depthwise(conv):
     return (conv.groups > 1 and conv.groups == conv.in_channels == conv.out_channels
             and conv.kernel_size[0] == conv.kernel_size[1] <= 7 and conv.stride[0] == conv.stride[1]
@@ -254,6 +299,8 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
             if torch.is_autocast_enabled() and x.dtype == torch.float32:
                 x = x.to(torch.get_autocast_dtype("cuda"))      # what autocast would do for F.conv2d
             y = _DepthwiseConv.apply(x, conv.weight, conv.stride[0], conv.padding[0])
+        elif _mfma_conv_ok(conv, x):
+            y = _DenseConvMFMA.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv.weight)
         else:
             y = conv(x)
         if isinstance(bn, nn.BatchNorm2d) and bn.track_running_stats and bn.momentum is not None:

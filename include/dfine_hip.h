@@ -205,6 +205,22 @@ int dfine_adamw_ema_step(float *param, float *grad, float *exp_avg, float *exp_a
                          float ema_momentum, void *stream);
 int dfine_ema_update(float *ema, const float *src, int64_t n, float momentum, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * A1/A2  Dense 1x1 / 3x3 stride-1 "same" convolution on the MFMA units (NCHW, bf16, fp32 accumulate).
+ * Replaces nn.Conv2d in ConvBNAct / ConvNormLayer(_fuse) / VGGBlock (src/d_fine/arch/hgnetv2.py:
+ * 35-80, src/d_fine/arch/hybrid_encoder.py:21-156) for the forward pass and the data gradient.
+ *   dfine_conv_pack_weights: fp32 [Cout, Cin, KS, KS] -> bf16 [KS*KS][NP][KP] (NP = n rounded up to
+ *     16, KP = k rounded up to 32, zero padded; dfine_conv_packed_elems gives the element count).
+ *     dgrad = 0: (n, k) = (Cout, Cin).  dgrad = 1: (n, k) = (Cin, Cout), taps flipped - feeding these to
+ *     dfine_conv_fwd_bf16 with Cin/Cout exchanged yields dX from dY.
+ *   dfine_conv_fwd_bf16: y [B, Cout, H, W] = conv(x [B, Cin, H, W]); KS in {1, 3}; Cin even; for
+ *     KS = 3: W even and <= 160.
+ */
+int64_t dfine_conv_packed_elems(int Cout, int Cin, int KS, int dgrad);
+int dfine_conv_pack_weights(const float *w, void *w2, int Cout, int Cin, int KS, int dgrad, void *stream);
+int dfine_conv_fwd_bf16(const void *x, const void *w2, void *y, int B, int Cin, int Cout, int H, int W,
+                        int KS, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
