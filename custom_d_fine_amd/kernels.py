@@ -277,7 +277,8 @@ def _mfma_conv_ok(conv, x):
             and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.bias is None
             and isinstance(conv.padding, tuple) and conv.padding == (k[0] // 2, k[0] // 2)
             and conv.in_channels % 16 == 0 and conv.out_channels % 16 == 0 and x.dim() == 4
-            and (k[0] == 1 or (x.shape[-1] % 2 == 0 and x.shape[-1] <= 160))
+            and ((k[0] == 1 and (x.shape[-1] * x.shape[-2]) % 2 == 0)
+                 or (k[0] == 3 and x.shape[-1] % 2 == 0 and x.shape[-1] <= 160))
             and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
 
 
