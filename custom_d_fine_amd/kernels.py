@@ -272,7 +272,13 @@ class _DenseConvMFMA(torch.autograd.Function):
 
 
 def _mfma_conv_ok(conv, x):
+    """Shapes the implicit-GEMM kernel serves today: every 3x3, and the 1x1 layers below ~2.5 GFLOP
+    (latency-bound in MIOpen; the large GEMM-like 1x1 layers stay on MIOpen's 400-600 TF/s kernels
+    until the kernel gets a deeper K pipeline - profiles/r01_conv_survey_hip_vs_miopen.txt)."""
     k = conv.kernel_size
+    if k[0] == 1 and 2.0 * x.shape[0] * x.shape[-1] * x.shape[-2] * conv.in_channels * conv.out_channels > float(
+            os.environ.get("DFINE_MFMA_1X1_MAX_FLOP", "2.5e9")):
+        return False
     return (os.environ.get("DFINE_MFMA_CONV", "1") == "1" and conv.groups == 1 and k[0] == k[1] and k[0] in (1, 3)
             and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.bias is None
             and isinstance(conv.padding, tuple) and conv.padding == (k[0] // 2, k[0] // 2)
