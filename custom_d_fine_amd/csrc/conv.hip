@@ -181,6 +181,136 @@ __global__ __launch_bounds__(kConvThreads) void conv_igemm_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient: dW[n][c][tap] = sum_{b, p} dY[b][n][p] * X[b][c][p + shift(tap)].
+// GEMM view: M = output channels, N = input channels, K = pixels - in NCHW BOTH operands are
+// contiguous along K, so fragments are plain 16-byte reads: dY straight from global, X from an LDS
+// copy of the strip (+halo, zero padded) in its natural [channel][row][col] layout.  The +-1 column
+// shifts of a 3x3 kernel are made from the aligned 16-byte chunk plus one neighbouring dword with
+// v_alignbit (no unaligned LDS access).  A block owns a 64 x 64 (n, c) tile pair for a range of
+// (image, strip) units and writes fp32 partial sums; conv_wgrad_reduce_kernel adds the splits.
+template <int KS>
+__global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
+    const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy, float *__restrict__ part, int Cin,
+    int Cout, int H, int W, int R, int strips, int total_units, int units_per_split, int nct64, int NP64,
+    int CP64) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int PAD = KS / 2;
+    constexpr int LPAD = KS == 3 ? 8 : 0;
+    constexpr int TAPS = KS * KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt64 = blockIdx.x / nct64, ct64 = blockIdx.x - nt64 * nct64;
+    const int split = blockIdx.y;
+    const int PW = W + 2 * LPAD, rows_l = R + 2 * PAD;
+    uint16_t *xs = reinterpret_cast<uint16_t *>(lds);            // [64][rows_l][PW]
+    {   // zero once: the pad columns are never written again
+        uint32_t *z = reinterpret_cast<uint32_t *>(lds);
+        for (int i = tid; i < 64 * rows_l * PW / 2; i += kConvThreads) z[i] = 0u;
+    }
+    f32x4v acc[4][TAPS];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) acc[ct][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const int n_lane = nt64 * 64 + wave * 16 + (lane & 15);
+    const int c_base = ct64 * 64;
+    const int nv = W / 8;
+    __syncthreads();
+
+    const int u0 = split * units_per_split, u1 = min(total_units, u0 + units_per_split);
+    for (int u = u0; u < u1; ++u) {
+        const int b = u / strips, strip = u - b * strips;
+        const int r0 = strip * R;
+        const int rows = min(R, H - r0);
+        // ---- stage X[b][c_base .. +63][r0-PAD .. r0+R-1+PAD][:] (zeros outside the image / Cin) ----
+        const uint16_t *xb = x + (int64_t)b * Cin * H * W;
+        for (int it = tid; it < 64 * rows_l * nv; it += kConvThreads) {
+            const int ch = it / (rows_l * nv);
+            const int rem = it - ch * rows_l * nv;
+            const int lr = rem / nv, xv = (rem - lr * nv) * 8;
+            const int gy = r0 - PAD + lr, c = c_base + ch;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gy >= 0 && gy < H && gy < r0 + rows + PAD && c < Cin)
+                v = *reinterpret_cast<const uint4 *>(xb + ((int64_t)c * H + gy) * W + xv);
+            *reinterpret_cast<uint4 *>(xs + ((ch * rows_l + lr) * PW + LPAD + xv)) = v;
+        }
+        __syncthreads();
+        const uint16_t *dyb = dy + ((int64_t)b * Cout * H + r0) * W;
+        const int tp = rows * W;
+        for (int k0 = 0; k0 < tp; k0 += 32) {
+            const int px = k0 + 8 * (lane >> 4);
+            uint4 av = make_uint4(0, 0, 0, 0);
+            if (px < tp && n_lane < Cout) av = *reinterpret_cast<const uint4 *>(dyb + (int64_t)n_lane * H * W + px);
+            const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+            const int pxc = px < tp ? px : 0;
+            const int row = pxc / W, col = pxc - row * W;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int cc = ct * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < KS; ++r) {
+                    const uint16_t *e = xs + ((cc * rows_l + row + r) * PW + LPAD + col);
+                    const uint4 c1 = *reinterpret_cast<const uint4 *>(e);
+                    if (KS == 1) {
+                        acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, c1), acc[ct][0], 0, 0, 0);
+                    } else {
+                        const uint32_t lw = *reinterpret_cast<const uint32_t *>(e - 2);
+                        const uint32_t rw = *reinterpret_cast<const uint32_t *>(e + 8);
+                        uint4 b0, b2;
+                        b0.x = (lw >> 16) | (c1.x << 16); b0.y = (c1.x >> 16) | (c1.y << 16);
+                        b0.z = (c1.y >> 16) | (c1.z << 16); b0.w = (c1.z >> 16) | (c1.w << 16);
+                        b2.x = (c1.x >> 16) | (c1.y << 16); b2.y = (c1.y >> 16) | (c1.z << 16);
+                        b2.z = (c1.z >> 16) | (c1.w << 16); b2.w = (c1.w >> 16) | (rw << 16);
+                        acc[ct][r * KS + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, b0), acc[ct][r * KS + 0], 0, 0, 0);
+                        acc[ct][r * KS + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, c1), acc[ct][r * KS + 1], 0, 0, 0);
+                        acc[ct][r * KS + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, b2), acc[ct][r * KS + 2], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- partial sums: part[split][n][c][tap] -------------------------------------------------
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int c = c_base + ct * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nt64 * 64 + wave * 16 + 4 * (lane >> 4) + r;
+            float *dst = part + (((int64_t)split * NP64 + n) * CP64 + c) * TAPS;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) dst[t] = acc[ct][t][r];
+        }
+    }
+}
+
+__global__ void conv_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, int splits, int Cout,
+                                         int Cin, int taps, int NP64, int CP64) {
+    const int64_t total = (int64_t)Cout * Cin * taps;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % taps);
+        const int c = (int)((i / taps) % Cin);
+        const int n = (int)(i / ((int64_t)taps * Cin));
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += part[(((int64_t)k * NP64 + n) * CP64 + c) * taps + t];
+        dw[i] = s;
+    }
+}
+
+static void wgrad_plan(int B, int Cin, int Cout, int H, int W, int *R, int *strips, int *splits, int *ups) {
+    *R = 160 / W < 1 ? 1 : 160 / W;
+    if (*R > H) *R = H;
+    *strips = (H + *R - 1) / *R;
+    const int units = B * *strips;
+    const int pairs = ((Cout + 63) / 64) * ((Cin + 63) / 64);
+    int sp = 512 / pairs;
+    if (sp < 1) sp = 1;
+    if (sp > 64) sp = 64;
+    if (sp > units) sp = units;
+    *ups = (units + sp - 1) / sp;
+    *splits = (units + *ups - 1) / *ups;
+}
+
 static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B, int Cin, int Cout, int NP, int KP,
                        int H, int W, int KS, hipStream_t st) {
     // strip height: as many rows as fit in 160 pixels
@@ -249,6 +379,58 @@ int dfine_conv_fwd_bf16(const void *x, const void *w2, void *y, int B, int Cin, 
     if (w % 2 || w > 160) return DFINE_E_BADARG;
     return launch_conv((const uint16_t *)x, (const uint16_t *)w2, (uint16_t *)y, B, Cin, Cout, NP, KP, h, w, KS,
                        (hipStream_t)stream);
+}
+
+// Weight gradient of the same convolution.  x [B,Cin,H,W], dy [B,Cout,H,W] bf16 -> dw [Cout,Cin,KS,KS]
+// f32 (overwritten).  ws: dfine_conv_wgrad_ws_floats(...) floats.  KS = 3 needs W % 8 == 0 and
+// W <= 160; KS = 1 needs (H*W) % 8 == 0.
+int64_t dfine_conv_wgrad_ws_floats(int B, int Cin, int Cout, int H, int W, int KS) {
+    int h = H, w = W;
+    if (KS == 1) { const int hw = H * W; w = 160; while (w > 8 && (hw % w || w % 8)) --w; h = hw / w; }
+    int R, strips, splits, ups;
+    wgrad_plan(B, Cin, Cout, h, w, &R, &strips, &splits, &ups);
+    return (int64_t)splits * ((Cout + 63) / 64 * 64) * ((Cin + 63) / 64 * 64) * KS * KS;
+}
+
+int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, int B, int Cin, int Cout, int H,
+                          int W, int KS, void *stream) {
+    if (B == 0) return DFINE_OK;
+    if (!x || !dy || !dw || !ws || Cin < 1 || Cout < 1 || (KS != 1 && KS != 3)) return DFINE_E_BADARG;
+    int h = H, w = W;
+    if (KS == 1) {
+        const int hw = H * W;
+        w = 160;
+        while (w > 8 && (hw % w || w % 8)) --w;
+        if (hw % w || w % 8) return DFINE_E_BADARG;
+        h = hw / w;
+    }
+    if (w % 8 || w > 160) return DFINE_E_BADARG;
+    int R, strips, splits, ups;
+    wgrad_plan(B, Cin, Cout, h, w, &R, &strips, &splits, &ups);
+    const int nnt64 = (Cout + 63) / 64, nct64 = (Cin + 63) / 64;
+    const int pad = KS / 2, lpad = KS == 3 ? 8 : 0;
+    const size_t ldsb = (size_t)64 * (R + 2 * pad) * (w + 2 * lpad) * 2;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(nnt64 * nct64, splits);
+    if (KS == 3) {
+        if (ldsb > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_kernel<3>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+            if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
+        }
+        hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(kConvThreads), ldsb, st, (const uint16_t *)x, (const uint16_t *)dy, ws,
+                           Cin, Cout, h, w, R, strips, B * strips, ups, nct64, nnt64 * 64, nct64 * 64);
+    } else {
+        hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(kConvThreads), ldsb, st, (const uint16_t *)x, (const uint16_t *)dy, ws,
+                           Cin, Cout, h, w, R, strips, B * strips, ups, nct64, nnt64 * 64, nct64 * 64);
+    }
+    if (int e = check_launch()) return e;
+    const int64_t total = (int64_t)Cout * Cin * KS * KS;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, splits, Cout, Cin, KS * KS,
+                       nnt64 * 64, nct64 * 64);
+    return check_launch();
 }
 
 }  // extern "C"

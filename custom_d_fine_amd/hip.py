@@ -47,6 +47,8 @@ _SIGNATURES = {
     "dfine_conv_packed_elems": (_L, [_I, _I, _I, _I]),
     "dfine_conv_pack_weights": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "dfine_conv_fwd_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_conv_wgrad_ws_floats": (_L, [_I, _I, _I, _I, _I, _I]),
+    "dfine_conv_wgrad_bf16": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_bn_act_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 for _name, (_res, _args) in _SIGNATURES.items():
@@ -393,3 +395,19 @@ def conv_forward_bf16(x, w2, cout, ks):
         _check(_lib.dfine_conv_fwd_bf16(_ptr(x), _ptr(w2), _ptr(y), B, cin, cout, H, W, ks, _stream()),
                "dfine_conv_fwd_bf16")
     return y
+
+
+def conv_wgrad_supported(H, W, ks):
+    return (ks == 3 and W % 8 == 0 and W <= 160) or (ks == 1 and (H * W) % 8 == 0)
+
+
+def conv_wgrad_bf16(x, dy, ks):
+    """x [B,Cin,H,W], dy [B,Cout,H,W] bf16 contiguous -> dw [Cout,Cin,ks,ks] f32."""
+    B, cin, H, W = x.shape
+    cout = dy.shape[1]
+    dw = torch.empty(cout, cin, ks, ks, device=x.device, dtype=torch.float32)
+    ws = torch.empty(int(_lib.dfine_conv_wgrad_ws_floats(B, cin, cout, H, W, ks)), device=x.device, dtype=torch.float32)
+    with _timed("dfine_conv_wgrad_bf16"):
+        _check(_lib.dfine_conv_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ks, _stream()),
+               "dfine_conv_wgrad_bf16")
+    return dw

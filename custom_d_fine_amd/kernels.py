@@ -238,8 +238,8 @@ class _BNAct(torch.autograd.Function):
 
 
 class _DenseConvMFMA(torch.autograd.Function):
-    """1x1 / 3x3 stride-1 dense convolution, NCHW bf16 (HIP: conv.hip).  Forward and data gradient run
-    on the implicit-GEMM MFMA kernel; the weight gradient is still MIOpen's [ATen plumbing]."""
+    """1x1 / 3x3 stride-1 dense convolution, NCHW bf16 (HIP: conv.hip): forward, data gradient and
+    weight gradient on the MFMA units (weight gradient falls back to MIOpen when W % 8 != 0)."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -263,7 +263,10 @@ class _DenseConvMFMA(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             w2d = hip.conv_pack_weights(weight.detach().float().contiguous(), True)
             dx = hip.conv_forward_bf16(dy, w2d, weight.shape[1], ks)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and hip.conv_wgrad_supported(x.shape[2], x.shape[3], ks) \
+                and os.environ.get("DFINE_MFMA_WGRAD", "1") == "1":
+            dw = hip.conv_wgrad_bf16(x, dy, ks).to(weight.dtype)
+        elif ctx.needs_input_grad[1]:
             pad = ks // 2
             dw = torch.ops.aten.convolution_backward(
                 dy, x, weight.detach().to(torch.bfloat16), None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,

@@ -220,6 +220,12 @@ int64_t dfine_conv_packed_elems(int Cout, int Cin, int KS, int dgrad);
 int dfine_conv_pack_weights(const float *w, void *w2, int Cout, int Cin, int KS, int dgrad, void *stream);
 int dfine_conv_fwd_bf16(const void *x, const void *w2, void *y, int B, int Cin, int Cout, int H, int W,
                         int KS, void *stream);
+/* Weight gradient of the same convolution: dw [Cout, Cin, KS, KS] f32 (overwritten) from x [B,Cin,H,W]
+ * and dy [B,Cout,H,W] (bf16); ws = dfine_conv_wgrad_ws_floats(...) floats of scratch (split-K
+ * partial sums).  KS = 3: W % 8 == 0 and W <= 160.  KS = 1: (H*W) % 8 == 0. */
+int64_t dfine_conv_wgrad_ws_floats(int B, int Cin, int Cout, int H, int W, int KS);
+int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, int B, int Cin, int Cout,
+                          int H, int W, int KS, void *stream);
 
 #ifdef __cplusplus
 }

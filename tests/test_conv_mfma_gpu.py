@@ -34,11 +34,11 @@ def test_conv_fwd_and_dgrad(cuda, B, Cin, Cout, H, W, KS):
     assert (y.float() - yr).abs().max().item() < 1.5e-2 * scale
     gscale = xr.grad.abs().max().item()
     assert (xg.grad.float() - xr.grad).abs().max().item() < 1.5e-2 * gscale
-    # weight gradient (MIOpen for now) sanity: matches the fp32 reference direction
+    # weight gradient (MFMA split-K kernel, or MIOpen when W % 8 != 0)
     wr = wb.clone().requires_grad_(True)
     F.conv2d(x.float(), wr, padding=KS // 2).backward(go.float())
-    cos = F.cosine_similarity(wg.grad.flatten(), wr.grad.flatten(), dim=0).item()
-    assert cos > 0.999
+    wscale = wr.grad.abs().max().item()
+    assert (wg.grad - wr.grad).abs().max().item() < 1.5e-2 * wscale
 
 
 def test_asymmetric_layout_check(cuda):

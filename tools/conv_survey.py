@@ -32,7 +32,7 @@ for (ishape, wshape, stride, pad), cnt in cfgs.items():
     t0 = time.perf_counter()
     for _ in range(10): y = fwd(); y.backward(go)
     torch.cuda.synchronize(); tb = (time.perf_counter() - t0) / 10 - tf
-    mine_f = mine_d = float("nan")
+    mine_f = mine_d = mine_w = float("nan")
     from custom_d_fine_amd import hip as H
     ks = wshape[2]
     if stride == (1, 1) and ks in (1, 3) and ishape[1] % 16 == 0 and wshape[0] % 16 == 0 and ishape[3] <= 160:
@@ -47,14 +47,19 @@ for (ishape, wshape, stride, pad), cnt in cfgs.items():
         t0 = time.perf_counter()
         for _ in range(10): md()
         torch.cuda.synchronize(); mine_d = (time.perf_counter() - t0) / 10
+        if H.conv_wgrad_supported(ishape[2], ishape[3], ks):
+            for _ in range(3): H.conv_wgrad_bf16(xi_c, go, ks)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(10): H.conv_wgrad_bf16(xi_c, go, ks)
+            torch.cuda.synchronize(); mine_w = (time.perf_counter() - t0) / 10
     flops = 2 * y.numel() * wshape[1] * wshape[2] * wshape[3]
     byts = 2 * (xi.numel() + y.numel())
-    rows.append((cnt * (tf + tb), cnt, ishape, wshape, stride, tf * 1e3, tb * 1e3, flops / tf / 1e12, 2 * flops / max(tb, 1e-9) / 1e12, byts / 1e6, mine_f * 1e3, mine_d * 1e3))
+    rows.append((cnt * (tf + tb), cnt, ishape, wshape, stride, tf * 1e3, tb * 1e3, flops / tf / 1e12, 2 * flops / max(tb, 1e-9) / 1e12, byts / 1e6, mine_f * 1e3, mine_d * 1e3, mine_w * 1e3))
 rows.sort(reverse=True)
 tot_f = sum(r[1] * r[5] for r in rows); tot_b = sum(r[1] * r[6] for r in rows)
 print(f"dense convs: {sum(r[1] for r in rows)} calls, fwd {tot_f:.1f} ms, bwd {tot_b:.1f} ms")
 for r in rows:
-    print(f"{r[0]*1e3:7.2f} ms x{r[1]:2d} in{list(r[2])} w{list(r[3])} s{r[4][0]} fwd {r[5]:.3f} ms ({r[7]:.0f} TF) bwd {r[6]:.3f} ms ({r[8]:.0f} TF) io {r[9]:.0f} MB | HIP fwd {r[10]:.3f} dgrad {r[11]:.3f} ms")
+    print(f"{r[0]*1e3:7.2f} ms x{r[1]:2d} in{list(r[2])} w{list(r[3])} s{r[4][0]} fwd {r[5]:.3f} ms ({r[7]:.0f} TF) bwd {r[6]:.3f} ms ({r[8]:.0f} TF) io {r[9]:.0f} MB | HIP fwd {r[10]:.3f} dgrad {r[11]:.3f} wgrad {r[12]:.3f} ms")
 import math
 print("HIP fwd total (eligible): %.2f ms vs MIOpen fwd %.2f ms on the same layers; HIP dgrad total %.2f ms" % (
     sum(r[1]*r[10] for r in rows if not math.isnan(r[10])), sum(r[1]*r[5] for r in rows if not math.isnan(r[10])),
