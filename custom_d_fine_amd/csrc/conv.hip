@@ -109,7 +109,57 @@ __global__ __launch_bounds__(kConvThreads) void conv_igemm_kernel(
     const uint16_t *xb = x + (int64_t)b * Cin * H * W;
     __syncthreads();
 
+    // Software pipeline: the global loads of slab c0+32 are issued right after slab c0 has been
+    // written to LDS, so their latency is covered by the MFMA work on slab c0 (single LDS buffer,
+    // the next slab waits in registers).
+    constexpr int MAXI = 4;                                   // staged items per thread held in registers
+    typedef typename PixVec<VEC>::type PV;
+    PV ra[MAXI], rb[MAXI];
+    const bool pipelined = 16 * nvec <= MAXI * kConvThreads;
+    auto load_slab = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int it = tid + i * kConvThreads;
+            ra[i] = PV{}; rb[i] = PV{};
+            if (it < 16 * nvec) {
+                const int pair = it & 15, v = it >> 4;
+                const int lr = v / nvec_row, xv = (v - lr * nvec_row) * VEC;
+                const int gy = r0 - PAD + lr;
+                const int ca = c0 + 2 * pair;
+                if (gy >= 0 && gy < H) {
+                    if (ca < Cin) ra[i] = *reinterpret_cast<const PV *>(xb + ((int64_t)ca * H + gy) * W + xv);
+                    if (ca + 1 < Cin) rb[i] = *reinterpret_cast<const PV *>(xb + ((int64_t)(ca + 1) * H + gy) * W + xv);
+                }
+            }
+        }
+    };
+    auto store_slab = [&]() {
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int it = tid + i * kConvThreads;
+            if (it < 16 * nvec) {
+                const int pair = it & 15, v = it >> 4;
+                const int lr = v / nvec_row, xv = (v - lr * nvec_row) * VEC;
+                const int gy = r0 - PAD + lr;
+                if (gy >= 0 && gy < H) {
+                    uint16_t e0[VEC], e1[VEC];
+                    unpack<VEC>(ra[i], e0);
+                    unpack<VEC>(rb[i], e1);
+                    uint32_t *dst = lds32 + (lr * WL + xv + PAD) * 16 + pair;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) dst[k * 16] = (uint32_t)e0[k] | ((uint32_t)e1[k] << 16);
+                }
+            }
+        }
+    };
+    if (pipelined) load_slab(0);
+
     for (int c0 = 0; c0 < KP; c0 += 32) {
+        if (pipelined) {
+            store_slab();
+            __syncthreads();
+            if (c0 + 32 < KP) load_slab(c0 + 32);
+        } else {
         // ---- stage the [32 channels] x [strip + halo] slab, transposed to [pixel][channel] -----
         for (int it = tid; it < 16 * nvec; it += kConvThreads) {
             const int pair = it & 15, v = it >> 4;
@@ -135,6 +185,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_igemm_kernel(
             for (int i = 0; i < VEC; ++i) dst[i * 16] = (uint32_t)e0[i] | ((uint32_t)e1[i] << 16);
         }
         __syncthreads();
+        }
         // ---- MFMA over the taps ----------------------------------------------------------------
 #pragma unroll
         for (int tap = 0; tap < KS * KS; ++tap) {
@@ -192,8 +243,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_igemm_kernel(
 template <int KS>
 __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
     const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy, float *__restrict__ part, int Cin,
-    int Cout, int H, int W, int R, int strips, int total_units, int units_per_split, int nct64, int NP64,
-    int CP64) {
+    int Cout, int H, int W, int R, int strips, int total_units, int units_per_split, int nct64, int NP16,
+    int CP16, int CS /* LDS elements per channel: = 8 (mod 128) -> the 16 channel lanes of a b128 read hit 16 distinct 16-byte bank slots */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int PAD = KS / 2;
     constexpr int LPAD = KS == 3 ? 8 : 0;
@@ -205,7 +256,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
     uint16_t *xs = reinterpret_cast<uint16_t *>(lds);            // [64][rows_l][PW]
     {   // zero once: the pad columns are never written again
         uint32_t *z = reinterpret_cast<uint32_t *>(lds);
-        for (int i = tid; i < 64 * rows_l * PW / 2; i += kConvThreads) z[i] = 0u;
+        for (int i = tid; i < 64 * CS / 2; i += kConvThreads) z[i] = 0u;
     }
     f32x4v acc[4][TAPS];
 #pragma unroll
@@ -213,6 +264,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) acc[ct][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
     const int n_lane = nt64 * 64 + wave * 16 + (lane & 15);
+    const bool wave_active = nt64 * 64 + wave * 16 < Cout;
     const int c_base = ct64 * 64;
     const int nv = W / 8;
     __syncthreads();
@@ -232,7 +284,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
             uint4 v = make_uint4(0, 0, 0, 0);
             if (gy >= 0 && gy < H && gy < r0 + rows + PAD && c < Cin)
                 v = *reinterpret_cast<const uint4 *>(xb + ((int64_t)c * H + gy) * W + xv);
-            *reinterpret_cast<uint4 *>(xs + ((ch * rows_l + lr) * PW + LPAD + xv)) = v;
+            *reinterpret_cast<uint4 *>(xs + (ch * CS + lr * PW + LPAD + xv)) = v;
         }
         __syncthreads();
         const uint16_t *dyb = dy + ((int64_t)b * Cout * H + r0) * W;
@@ -246,10 +298,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
             const int row = pxc / W, col = pxc - row * W;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
+                if (c_base + ct * 16 >= Cin || !wave_active) continue;       // uniform per wave
                 const int cc = ct * 16 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < KS; ++r) {
-                    const uint16_t *e = xs + ((cc * rows_l + row + r) * PW + LPAD + col);
+                    const uint16_t *e = xs + (cc * CS + (row + r) * PW + LPAD + col);
                     const uint4 c1 = *reinterpret_cast<const uint4 *>(e);
                     if (KS == 1) {
                         acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, c1), acc[ct][0], 0, 0, 0);
@@ -274,10 +327,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
         const int c = c_base + ct * 16 + (lane & 15);
+        if (c >= CP16) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = nt64 * 64 + wave * 16 + 4 * (lane >> 4) + r;
-            float *dst = part + (((int64_t)split * NP64 + n) * CP64 + c) * TAPS;
+            if (n >= NP16) continue;
+            float *dst = part + (((int64_t)split * NP16 + n) * CP16 + c) * TAPS;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) dst[t] = acc[ct][t][r];
         }
@@ -285,14 +340,14 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
 }
 
 __global__ void conv_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, int splits, int Cout,
-                                         int Cin, int taps, int NP64, int CP64) {
+                                         int Cin, int taps, int NP16, int CP16) {
     const int64_t total = (int64_t)Cout * Cin * taps;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int t = (int)(i % taps);
         const int c = (int)((i / taps) % Cin);
         const int n = (int)(i / ((int64_t)taps * Cin));
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += part[(((int64_t)k * NP64 + n) * CP64 + c) * taps + t];
+        for (int k = 0; k < splits; ++k) s += part[(((int64_t)k * NP16 + n) * CP16 + c) * taps + t];
         dw[i] = s;
     }
 }
@@ -303,9 +358,9 @@ static void wgrad_plan(int B, int Cin, int Cout, int H, int W, int *R, int *stri
     *strips = (H + *R - 1) / *R;
     const int units = B * *strips;
     const int pairs = ((Cout + 63) / 64) * ((Cin + 63) / 64);
-    int sp = 512 / pairs;
+    int sp = 768 / pairs;
     if (sp < 1) sp = 1;
-    if (sp > 64) sp = 64;
+    if (sp > 512) sp = 512;
     if (sp > units) sp = units;
     *ups = (units + sp - 1) / sp;
     *splits = (units + *ups - 1) / *ups;
@@ -389,7 +444,7 @@ int64_t dfine_conv_wgrad_ws_floats(int B, int Cin, int Cout, int H, int W, int K
     if (KS == 1) { const int hw = H * W; w = 160; while (w > 8 && (hw % w || w % 8)) --w; h = hw / w; }
     int R, strips, splits, ups;
     wgrad_plan(B, Cin, Cout, h, w, &R, &strips, &splits, &ups);
-    return (int64_t)splits * ((Cout + 63) / 64 * 64) * ((Cin + 63) / 64 * 64) * KS * KS;
+    return (int64_t)splits * ((Cout + 15) / 16 * 16) * ((Cin + 15) / 16 * 16) * KS * KS;
 }
 
 int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, int B, int Cin, int Cout, int H,
@@ -409,7 +464,9 @@ int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, i
     wgrad_plan(B, Cin, Cout, h, w, &R, &strips, &splits, &ups);
     const int nnt64 = (Cout + 63) / 64, nct64 = (Cin + 63) / 64;
     const int pad = KS / 2, lpad = KS == 3 ? 8 : 0;
-    const size_t ldsb = (size_t)64 * (R + 2 * pad) * (w + 2 * lpad) * 2;
+    const int np16 = (Cout + 15) / 16 * 16, cp16 = (Cin + 15) / 16 * 16;
+    const int cs = ((R + 2 * pad) * (w + 2 * lpad) + 127) / 128 * 128 + 8;
+    const size_t ldsb = (size_t)64 * cs * 2;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(nnt64 * nct64, splits);
     if (KS == 3) {
@@ -419,17 +476,17 @@ int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, i
             if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
         }
         hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(kConvThreads), ldsb, st, (const uint16_t *)x, (const uint16_t *)dy, ws,
-                           Cin, Cout, h, w, R, strips, B * strips, ups, nct64, nnt64 * 64, nct64 * 64);
+                           Cin, Cout, h, w, R, strips, B * strips, ups, nct64, np16, cp16, cs);
     } else {
         hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(kConvThreads), ldsb, st, (const uint16_t *)x, (const uint16_t *)dy, ws,
-                           Cin, Cout, h, w, R, strips, B * strips, ups, nct64, nnt64 * 64, nct64 * 64);
+                           Cin, Cout, h, w, R, strips, B * strips, ups, nct64, np16, cp16, cs);
     }
     if (int e = check_launch()) return e;
     const int64_t total = (int64_t)Cout * Cin * KS * KS;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, splits, Cout, Cin, KS * KS,
-                       nnt64 * 64, nct64 * 64);
+                       np16, cp16);
     return check_launch();
 }
 
