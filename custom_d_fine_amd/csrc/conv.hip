@@ -109,57 +109,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_igemm_kernel(
     const uint16_t *xb = x + (int64_t)b * Cin * H * W;
     __syncthreads();
 
-    // Software pipeline: the global loads of slab c0+32 are issued right after slab c0 has been
-    // written to LDS, so their latency is covered by the MFMA work on slab c0 (single LDS buffer,
-    // the next slab waits in registers).
-    constexpr int MAXI = 4;                                   // staged items per thread held in registers
-    typedef typename PixVec<VEC>::type PV;
-    PV ra[MAXI], rb[MAXI];
-    const bool pipelined = 16 * nvec <= MAXI * kConvThreads;
-    auto load_slab = [&](int c0) {
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            const int it = tid + i * kConvThreads;
-            ra[i] = PV{}; rb[i] = PV{};
-            if (it < 16 * nvec) {
-                const int pair = it & 15, v = it >> 4;
-                const int lr = v / nvec_row, xv = (v - lr * nvec_row) * VEC;
-                const int gy = r0 - PAD + lr;
-                const int ca = c0 + 2 * pair;
-                if (gy >= 0 && gy < H) {
-                    if (ca < Cin) ra[i] = *reinterpret_cast<const PV *>(xb + ((int64_t)ca * H + gy) * W + xv);
-                    if (ca + 1 < Cin) rb[i] = *reinterpret_cast<const PV *>(xb + ((int64_t)(ca + 1) * H + gy) * W + xv);
-                }
-            }
-        }
-    };
-    auto store_slab = [&]() {
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            const int it = tid + i * kConvThreads;
-            if (it < 16 * nvec) {
-                const int pair = it & 15, v = it >> 4;
-                const int lr = v / nvec_row, xv = (v - lr * nvec_row) * VEC;
-                const int gy = r0 - PAD + lr;
-                if (gy >= 0 && gy < H) {
-                    uint16_t e0[VEC], e1[VEC];
-                    unpack<VEC>(ra[i], e0);
-                    unpack<VEC>(rb[i], e1);
-                    uint32_t *dst = lds32 + (lr * WL + xv + PAD) * 16 + pair;
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) dst[k * 16] = (uint32_t)e0[k] | ((uint32_t)e1[k] << 16);
-                }
-            }
-        }
-    };
-    if (pipelined) load_slab(0);
-
     for (int c0 = 0; c0 < KP; c0 += 32) {
-        if (pipelined) {
-            store_slab();
-            __syncthreads();
-            if (c0 + 32 < KP) load_slab(c0 + 32);
-        } else {
         // ---- stage the [32 channels] x [strip + halo] slab, transposed to [pixel][channel] -----
         for (int it = tid; it < 16 * nvec; it += kConvThreads) {
             const int pair = it & 15, v = it >> 4;
@@ -185,7 +135,6 @@ __global__ __launch_bounds__(kConvThreads) void conv_igemm_kernel(
             for (int i = 0; i < VEC; ++i) dst[i * 16] = (uint32_t)e0[i] | ((uint32_t)e1[i] << 16);
         }
         __syncthreads();
-        }
         // ---- MFMA over the taps ----------------------------------------------------------------
 #pragma unroll
         for (int tap = 0; tap < KS * KS; ++tap) {
@@ -352,15 +301,21 @@ __global__ void conv_wgrad_reduce_kernel(const float *__restrict__ part, float *
     }
 }
 
-static void wgrad_plan(int B, int Cin, int Cout, int H, int W, int *R, int *strips, int *splits, int *ups) {
+static void wgrad_plan(int B, int Cin, int Cout, int H, int W, int KS, int *R, int *strips, int *splits, int *ups) {
     *R = 160 / W < 1 ? 1 : 160 / W;
     if (*R > H) *R = H;
     *strips = (H + *R - 1) / *R;
     const int units = B * *strips;
     const int pairs = ((Cout + 63) / 64) * ((Cin + 63) / 64);
+    // enough blocks to fill the chip, but keep the fp32 partial-sum buffer (written once, read once by
+    // the reduce kernel) below ~24 MB
+    const int64_t bytes_per_split = (int64_t)((Cout + 15) / 16 * 16) * ((Cin + 15) / 16 * 16) * KS * KS * 4;
+    int cap = (int)(24000000 / bytes_per_split);
+    if (cap < 8) cap = 8;
+    if (cap > 512) cap = 512;
     int sp = 768 / pairs;
     if (sp < 1) sp = 1;
-    if (sp > 512) sp = 512;
+    if (sp > cap) sp = cap;
     if (sp > units) sp = units;
     *ups = (units + sp - 1) / sp;
     *splits = (units + *ups - 1) / *ups;
@@ -443,7 +398,7 @@ int64_t dfine_conv_wgrad_ws_floats(int B, int Cin, int Cout, int H, int W, int K
     int h = H, w = W;
     if (KS == 1) { const int hw = H * W; w = 160; while (w > 8 && (hw % w || w % 8)) --w; h = hw / w; }
     int R, strips, splits, ups;
-    wgrad_plan(B, Cin, Cout, h, w, &R, &strips, &splits, &ups);
+    wgrad_plan(B, Cin, Cout, h, w, KS, &R, &strips, &splits, &ups);
     return (int64_t)splits * ((Cout + 15) / 16 * 16) * ((Cin + 15) / 16 * 16) * KS * KS;
 }
 
@@ -461,7 +416,7 @@ int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, i
     }
     if (w % 8 || w > 160) return DFINE_E_BADARG;
     int R, strips, splits, ups;
-    wgrad_plan(B, Cin, Cout, h, w, &R, &strips, &splits, &ups);
+    wgrad_plan(B, Cin, Cout, h, w, KS, &R, &strips, &splits, &ups);
     const int nnt64 = (Cout + 63) / 64, nct64 = (Cin + 63) / 64;
     const int pad = KS / 2, lpad = KS == 3 ? 8 : 0;
     const int np16 = (Cout + 15) / 16 * 16, cp16 = (Cin + 15) / 16 * 16;

@@ -237,51 +237,127 @@ class _BNAct(torch.autograd.Function):
         return dx, dg, db, dls, dlb, None, None, None, None, None, None
 
 
-class _DenseConvMFMA(torch.autograd.Function):
-    """1x1 / 3x3 stride-1 dense convolution, NCHW bf16 (HIP: conv.hip): forward, data gradient and
-    weight gradient on the MFMA units (weight gradient falls back to MIOpen when W % 8 != 0)."""
+# Per-shape choice between the HIP implicit-GEMM kernels and MIOpen for forward / data gradient /
+# weight gradient of a dense conv: measured once per (shape, op) on first use ("measure, don't guess":
+# the HIP kernels win on every 3x3 and on the small latency-bound 1x1 layers, MIOpen's GEMM-like
+# kernels win on the large 1x1 layers - profiles/r01_conv_survey_hip_vs_miopen.txt).
+_CONV_PLAN = {}
+
+
+def _time_op(fn, reps=4):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def _conv_plan(x, weight):
+    """{'fwd','dgrad','wgrad'} -> True when the HIP kernel is the faster one for this shape."""
+    hip = _hip()
+    B, cin, H, W = x.shape
+    cout, _, ks, _ = weight.shape
+    key = (B, cin, cout, H, W, ks)
+    plan = _CONV_PLAN.get(key)
+    if plan is not None:
+        return plan
+    mode = os.environ.get("DFINE_CONV_TUNE", "1")
+    if mode != "1":                      # "hip" / "aten": force one side (debugging, A/B runs)
+        plan = {k: mode == "hip" for k in ("fwd", "dgrad", "wgrad")}
+        plan["wgrad"] = plan["wgrad"] and hip.conv_wgrad_supported(H, W, ks)
+        _CONV_PLAN[key] = plan
+        return plan
+    pad = ks // 2
+    with torch.no_grad():
+        xs = torch.randn(x.shape, device=x.device, dtype=torch.bfloat16)
+        dy = torch.randn(B, cout, H, W, device=x.device, dtype=torch.bfloat16)
+        w32 = weight.detach().float().contiguous()
+        wb = w32.to(torch.bfloat16)
+
+        def aten_bwd(mask):
+            return torch.ops.aten.convolution_backward(dy, xs, wb, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1, mask)
+
+        plan = {
+            "fwd": _time_op(lambda: hip.conv_forward_bf16(xs, hip.conv_pack_weights(w32, False), cout, ks))
+            < _time_op(lambda: F.conv2d(xs, w32.to(torch.bfloat16), None, 1, pad)),
+            "dgrad": _time_op(lambda: hip.conv_forward_bf16(dy, hip.conv_pack_weights(w32, True), cin, ks))
+            < _time_op(lambda: aten_bwd([True, False, False])),
+            "wgrad": hip.conv_wgrad_supported(H, W, ks)
+            and _time_op(lambda: hip.conv_wgrad_bf16(xs, dy, ks)) < _time_op(lambda: aten_bwd([False, True, False])[1].float()),
+        }
+    _CONV_PLAN[key] = plan
+    return plan
+
+
+class _DenseConv(torch.autograd.Function):
+    """1x1 / 3x3 stride-1 dense convolution, NCHW bf16.  Each of forward / data gradient / weight
+    gradient runs on the HIP implicit-GEMM MFMA kernels (conv.hip) or on MIOpen [ATen plumbing],
+    whichever `_conv_plan` measured to be faster for the shape."""
 
     @staticmethod
     def forward(ctx, x, weight):
         hip = _hip()
         x = x.contiguous()
-        w32 = weight.detach().float().contiguous()
+        plan = _conv_plan(x, weight)
         ks = weight.shape[-1]
-        y = hip.conv_forward_bf16(x, hip.conv_pack_weights(w32, False), weight.shape[0], ks)
+        if plan["fwd"]:
+            y = hip.conv_forward_bf16(x, hip.conv_pack_weights(weight.detach().float().contiguous(), False),
+                                      weight.shape[0], ks)
+        else:
+            y = F.conv2d(x, weight.detach().to(torch.bfloat16), None, 1, ks // 2)
         ctx.save_for_backward(x, weight)
+        ctx.plan = plan
         return y
 
     @staticmethod
     def backward(ctx, dy):
         hip = _hip()
         x, weight = ctx.saved_tensors
+        plan = ctx.plan
         dy = dy.contiguous()
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         ks = weight.shape[-1]
+        pad = ks // 2
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dx = dw = None
-        if ctx.needs_input_grad[0]:
-            w2d = hip.conv_pack_weights(weight.detach().float().contiguous(), True)
-            dx = hip.conv_forward_bf16(dy, w2d, weight.shape[1], ks)
-        if ctx.needs_input_grad[1] and hip.conv_wgrad_supported(x.shape[2], x.shape[3], ks) \
-                and os.environ.get("DFINE_MFMA_WGRAD", "1") == "1":
-            dw = hip.conv_wgrad_bf16(x, dy, ks).to(weight.dtype)
-        elif ctx.needs_input_grad[1]:
-            pad = ks // 2
-            dw = torch.ops.aten.convolution_backward(
+        aten_dx, aten_dw = need_dx and not plan["dgrad"], need_dw and not plan["wgrad"]
+        if aten_dx or aten_dw:
+            res = torch.ops.aten.convolution_backward(
                 dy, x, weight.detach().to(torch.bfloat16), None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
-                [False, True, False])[1].to(weight.dtype)
+                [aten_dx, aten_dw, False])
+            dx = res[0] if aten_dx else None
+            dw = res[1].to(weight.dtype) if aten_dw else None
+        if need_dx and plan["dgrad"]:
+            dx = hip.conv_forward_bf16(dy, hip.conv_pack_weights(weight.detach().float().contiguous(), True),
+                                       weight.shape[1], ks)
+        if need_dw and plan["wgrad"]:
+            dw = hip.conv_wgrad_bf16(x, dy, ks).to(weight.dtype)
         return dx, dw
 
 
+class _DenseConvMFMA(_DenseConv):
+    """Same op with the HIP kernels forced (used by the parity tests)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        hip = _hip()
+        x = x.contiguous()
+        ks = weight.shape[-1]
+        y = hip.conv_forward_bf16(x, hip.conv_pack_weights(weight.detach().float().contiguous(), False),
+                                  weight.shape[0], ks)
+        ctx.save_for_backward(x, weight)
+        ctx.plan = {"fwd": True, "dgrad": True, "wgrad": hip.conv_wgrad_supported(x.shape[2], x.shape[3], ks)}
+        return y
+
+
 def _mfma_conv_ok(conv, x):
-    """Shapes the implicit-GEMM kernel serves today: every 3x3, and the 1x1 layers below ~2.5 GFLOP
-    (latency-bound in MIOpen; the large GEMM-like 1x1 layers stay on MIOpen's 400-600 TF/s kernels
-    until the kernel gets a deeper K pipeline - profiles/r01_conv_survey_hip_vs_miopen.txt)."""
+    """Layers the implicit-GEMM kernels can serve (1x1 / 3x3, stride 1, 'same' padding, bf16 autocast)."""
     k = conv.kernel_size
-    if k[0] == 1 and 2.0 * x.shape[0] * x.shape[-1] * x.shape[-2] * conv.in_channels * conv.out_channels > float(
-            os.environ.get("DFINE_MFMA_1X1_MAX_FLOP", "2.5e9")):
-        return False
     return (os.environ.get("DFINE_MFMA_CONV", "1") == "1" and conv.groups == 1 and k[0] == k[1] and k[0] in (1, 3)
             and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.bias is None
             and isinstance(conv.padding, tuple) and conv.padding == (k[0] // 2, k[0] // 2)
@@ -310,7 +386,7 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
                 x = x.to(torch.get_autocast_dtype("cuda"))      # what autocast would do for F.conv2d
             y = _DepthwiseConv.apply(x, conv.weight, conv.stride[0], conv.padding[0])
         elif _mfma_conv_ok(conv, x):
-            y = _DenseConvMFMA.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv.weight)
+            y = _DenseConv.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv.weight)
         else:
             y = conv(x)
         if isinstance(bn, nn.BatchNorm2d) and bn.track_running_stats and bn.momentum is not None:
