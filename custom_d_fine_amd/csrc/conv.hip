@@ -295,9 +295,16 @@ __global__ void conv_wgrad_reduce_kernel(const float *__restrict__ part, float *
         const int t = (int)(i % taps);
         const int c = (int)((i / taps) % Cin);
         const int n = (int)(i / ((int64_t)taps * Cin));
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += part[(((int64_t)k * NP16 + n) * CP16 + c) * taps + t];
-        dw[i] = s;
+        const float *src = part + ((int64_t)n * CP16 + c) * taps + t;
+        const int64_t stride = (int64_t)NP16 * CP16 * taps;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = 0;
+        for (; k + 3 < splits; k += 4) {          // 4 independent loads in flight per thread
+            s0 += src[(int64_t)k * stride]; s1 += src[(int64_t)(k + 1) * stride];
+            s2 += src[(int64_t)(k + 2) * stride]; s3 += src[(int64_t)(k + 3) * stride];
+        }
+        for (; k < splits; ++k) s0 += src[(int64_t)k * stride];
+        dw[i] = (s0 + s1) + (s2 + s3);
     }
 }
 
@@ -313,7 +320,7 @@ static void wgrad_plan(int B, int Cin, int Cout, int H, int W, int KS, int *R, i
     int cap = (int)(24000000 / bytes_per_split);
     if (cap < 8) cap = 8;
     if (cap > 512) cap = 512;
-    int sp = 768 / pairs;
+    int sp = 512 / pairs;
     if (sp < 1) sp = 1;
     if (sp > cap) sp = cap;
     if (sp > units) sp = units;

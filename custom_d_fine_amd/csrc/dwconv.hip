@@ -21,10 +21,11 @@ constexpr int kDwThreads = 256;
 constexpr int kMaxK = 7;
 
 // ---- forward: block = (plane, strip of TR output rows) ---------------------------------------
-template <typename T>
+template <typename T, int KT, int ST>
 __global__ __launch_bounds__(kDwThreads) void dwconv_fwd_kernel(
     const T *__restrict__ x, const float *__restrict__ w, T *__restrict__ y, int C, int H, int W,
-    int OH, int OW, int K, int S, int P, int TR) {
+    int OH, int OW, int Krt, int Srt, int P, int TR) {
+    const int K = KT ? KT : Krt, S = ST ? ST : Srt;       // compile-time when specialised
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int plane = blockIdx.x;           // b * C + c
     const int c = plane % C;
@@ -48,17 +49,20 @@ __global__ __launch_bounds__(kDwThreads) void dwconv_fwd_kernel(
         const int r = o / OW, ox = o - r * OW;
         const float *src = tile + (r * S) * WP + ox * S;
         float acc = 0.f;
+#pragma unroll
         for (int ky = 0; ky < K; ++ky)
+#pragma unroll
             for (int kx = 0; kx < K; ++kx) acc += wk[ky * K + kx] * src[ky * WP + kx];
         store_f(yp + o, acc);
     }
 }
 
 // ---- data gradient: block = (plane, strip of TR input rows) ----------------------------------
-template <typename T>
+template <typename T, int KT, int ST>
 __global__ __launch_bounds__(kDwThreads) void dwconv_dgrad_kernel(
     const T *__restrict__ dy, const float *__restrict__ w, T *__restrict__ dx, int C, int H, int W,
-    int OH, int OW, int K, int S, int P, int TR) {
+    int OH, int OW, int Krt, int Srt, int P, int TR) {
+    const int K = KT ? KT : Krt, S = ST ? ST : Srt;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int plane = blockIdx.x;
     const int c = plane % C;
@@ -81,17 +85,18 @@ __global__ __launch_bounds__(kDwThreads) void dwconv_dgrad_kernel(
         const int r = o / W, ix = o - r * W;
         const int iy = iy0 + r;
         float acc = 0.f;
+#pragma unroll
         for (int ky = 0; ky < K; ++ky) {
             const int ty = iy + P - ky;
-            if (ty < 0 || ty % S) continue;
             const int oy = ty / S;
-            if (oy < oy_lo || oy > oy_hi) continue;
+            const bool vy = ty >= 0 && ty - oy * S == 0 && oy >= oy_lo && oy <= oy_hi;
+#pragma unroll
             for (int kx = 0; kx < K; ++kx) {
                 const int tx = ix + P - kx;
-                if (tx < 0 || tx % S) continue;
                 const int ox = tx / S;
-                if (ox >= OW) continue;
-                acc += wk[ky * K + kx] * tile[(oy - oy_lo) * OW + ox];
+                const bool v = vy && tx >= 0 && tx - ox * S == 0 && ox < OW;
+                const float t = tile[v ? (oy - oy_lo) * OW + ox : 0];
+                acc += v ? wk[ky * K + kx] * t : 0.f;
             }
         }
         store_f(dxp + o, acc);
@@ -145,6 +150,61 @@ __global__ __launch_bounds__(kDwThreads) void dwconv_wgrad_kernel(
     }
 }
 
+// ---- weight gradient, LDS-tiled: the x plane (+halo) and the dy plane of one (image, channel) are
+// staged once, then every thread accumulates its K*K taps from LDS (the direct kernel above re-reads
+// each x element K*K/S^2 times from L1/L2).
+template <typename T, int KK, int SS>
+__global__ __launch_bounds__(kDwThreads) void dwconv_wgrad_lds_kernel(
+    const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ dw, int B, int C, int H,
+    int W, int OH, int OW, int P, int imgs_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int c = blockIdx.x;
+    const int b0 = blockIdx.y * imgs_per_block, b1 = min(B, b0 + imgs_per_block);
+    const int HP = H + 2 * P, WP = W + 2 * P;
+    float *xt = smem;                  // [HP][WP], zero border
+    float *gt = smem + HP * WP;        // [OH][OW]
+    for (int i = threadIdx.x; i < HP * WP; i += kDwThreads) xt[i] = 0.f;
+    float acc[KK * KK];
+#pragma unroll
+    for (int i = 0; i < KK * KK; ++i) acc[i] = 0.f;
+    __syncthreads();
+    for (int b = b0; b < b1; ++b) {
+        const T *xp = x + ((int64_t)b * C + c) * H * W;
+        const T *dyp = dy + ((int64_t)b * C + c) * OH * OW;
+        for (int i = threadIdx.x; i < H * W; i += kDwThreads) {
+            const int yy = i / W, xx = i - yy * W;
+            xt[(yy + P) * WP + xx + P] = load_f(xp + i);
+        }
+        for (int i = threadIdx.x; i < OH * OW; i += kDwThreads) gt[i] = load_f(dyp + i);
+        __syncthreads();
+        for (int o = threadIdx.x; o < OH * OW; o += kDwThreads) {
+            const int oy = o / OW, ox = o - oy * OW;
+            const float g = gt[o];
+            const float *src = xt + (oy * SS) * WP + ox * SS;
+#pragma unroll
+            for (int ky = 0; ky < KK; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < KK; ++kx) acc[ky * KK + kx] += g * src[ky * WP + kx];
+        }
+        __syncthreads();
+    }
+    float *red = smem;                 // reuse
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < KK * KK; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if (lane == 0) red[wave * KK * KK + i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < KK * KK) {
+        float v = 0.f;
+        for (int wv = 0; wv < kDwThreads / 64; ++wv) v += red[wv * KK * KK + threadIdx.x];
+        unsafeAtomicAdd(dw + c * KK * KK + threadIdx.x, v);
+    }
+}
+
 static int pick_rows(int rows_total, int row_len_lds, int K, int S, bool fwd) {
     // strip height so that the LDS tile stays <= ~48 KiB and there are enough blocks
     int tr = 16;
@@ -173,13 +233,17 @@ int dfine_dwconv_fwd(const void *x, const float *w, void *y, int dtype, int B, i
     const size_t sm = sizeof(float) * ((size_t)((TR - 1) * stride + K) * WP + K * K);
     dim3 grid(B * C, (OH + TR - 1) / TR);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DFINE_F32)
-        hipLaunchKernelGGL(dwconv_fwd_kernel<float>, grid, dim3(kDwThreads), sm, st, (const float *)x, w,
-                           (float *)y, C, H, W, OH, OW, K, stride, pad, TR);
-    else if (dtype == DFINE_BF16)
-        hipLaunchKernelGGL(dwconv_fwd_kernel<uint16_t>, grid, dim3(kDwThreads), sm, st, (const uint16_t *)x, w,
-                           (uint16_t *)y, C, H, W, OH, OW, K, stride, pad, TR);
+#define DFINE_DWF(TT, KK, SS)                                                                     \
+    hipLaunchKernelGGL((dwconv_fwd_kernel<TT, KK, SS>), grid, dim3(kDwThreads), sm, st, (const TT *)x, w, (TT *)y, C, H, \
+                       W, OH, OW, K, stride, pad, TR)
+#define DFINE_DWF_KS(TT)                                                                          \
+    { if (K == 3 && stride == 2) DFINE_DWF(TT, 3, 2); else if (K == 5 && stride == 1) DFINE_DWF(TT, 5, 1);      \
+      else if (K == 3 && stride == 1) DFINE_DWF(TT, 3, 1); else DFINE_DWF(TT, 0, 0); }
+    if (dtype == DFINE_F32) DFINE_DWF_KS(float)
+    else if (dtype == DFINE_BF16) DFINE_DWF_KS(uint16_t)
     else return DFINE_E_BADARG;
+#undef DFINE_DWF_KS
+#undef DFINE_DWF
     return check_launch();
 }
 
@@ -195,12 +259,15 @@ int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, fl
         const int TR = pick_rows(H, OW, K, stride, false);
         const size_t sm = sizeof(float) * ((size_t)(TR / stride + K + 1) * OW + K * K);
         dim3 grid(B * C, (H + TR - 1) / TR);
-        if (dtype == DFINE_F32)
-            hipLaunchKernelGGL(dwconv_dgrad_kernel<float>, grid, dim3(kDwThreads), sm, st, (const float *)dy, w,
-                               (float *)dx, C, H, W, OH, OW, K, stride, pad, TR);
-        else
-            hipLaunchKernelGGL(dwconv_dgrad_kernel<uint16_t>, grid, dim3(kDwThreads), sm, st, (const uint16_t *)dy, w,
-                               (uint16_t *)dx, C, H, W, OH, OW, K, stride, pad, TR);
+#define DFINE_DWD(TT, KK, SS)                                                                     \
+    hipLaunchKernelGGL((dwconv_dgrad_kernel<TT, KK, SS>), grid, dim3(kDwThreads), sm, st, (const TT *)dy, w, (TT *)dx, C, \
+                       H, W, OH, OW, K, stride, pad, TR)
+#define DFINE_DWD_KS(TT)                                                                          \
+    { if (K == 3 && stride == 2) DFINE_DWD(TT, 3, 2); else if (K == 5 && stride == 1) DFINE_DWD(TT, 5, 1);      \
+      else if (K == 3 && stride == 1) DFINE_DWD(TT, 3, 1); else DFINE_DWD(TT, 0, 0); }
+        if (dtype == DFINE_F32) DFINE_DWD_KS(float) else DFINE_DWD_KS(uint16_t)
+#undef DFINE_DWD_KS
+#undef DFINE_DWD
         if (int e = check_launch()) return e;
     }
     if (dw_f32) {
@@ -209,6 +276,19 @@ int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, fl
         int per = 1;
         while ((int64_t)C * ((B + per - 1) / per) > 4096 && per < B) per *= 2;
         dim3 grid(C, (B + per - 1) / per);
+        const size_t lds_need = sizeof(float) * ((size_t)(H + 2 * pad) * (W + 2 * pad) + (size_t)OH * OW);
+        const bool spec = (K == 5 && stride == 1) || (K == 3 && stride == 2) || (K == 3 && stride == 1);
+        if (spec && lds_need <= 60 * 1024) {
+#define DFINE_WGL(TT, KK, SS)                                                                    \
+    hipLaunchKernelGGL((dwconv_wgrad_lds_kernel<TT, KK, SS>), grid, dim3(kDwThreads), lds_need, st, (const TT *)x, \
+                       (const TT *)dy, dw_f32, B, C, H, W, OH, OW, pad, per)
+#define DFINE_WGL_KS(TT)                                                                         \
+    { if (K == 5) DFINE_WGL(TT, 5, 1); else if (stride == 2) DFINE_WGL(TT, 3, 2); else DFINE_WGL(TT, 3, 1); }
+            if (dtype == DFINE_F32) DFINE_WGL_KS(float) else DFINE_WGL_KS(uint16_t)
+#undef DFINE_WGL_KS
+#undef DFINE_WGL
+            return check_launch();
+        }
 #define DFINE_WG(KK, TT)                                                                         \
     hipLaunchKernelGGL((dwconv_wgrad_kernel<TT, KK>), grid, dim3(kDwThreads), 0, st, (const TT *)x, \
                        (const TT *)dy, dw_f32, B, C, H, W, OH, OW, stride, pad, per)

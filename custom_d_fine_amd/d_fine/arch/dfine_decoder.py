@@ -477,11 +477,28 @@ class DFINETransformer(nn.Module):
         if memory.shape[0] > 1:
             anchors = anchors.expand(memory.shape[0], -1, -1)
         memory = valid.to(memory.dtype) * memory
-        out_mem = self.enc_output(memory)
-        enc_logits = self.enc_score_head(out_mem)
+        if self.training and torch.is_grad_enabled():
+            # Query selection only needs the scores of all anchors to pick indices; every op on this
+            # path (Linear, LayerNorm, score head) is row-wise and gradients only flow through the
+            # selected rows.  So: score all sum(HW) rows WITHOUT autograd, then recompute the 300
+            # selected rows with autograd.  Same values and gradients as the reference
+            # (dfine_decoder.py:842-853), but the backward no longer runs three GEMMs + a LayerNorm
+            # over B*8400 mostly-zero gradient rows.
+            with torch.no_grad():
+                scores_all = self.enc_score_head(self.enc_output(memory))
+            ind = self._topk_indices(scores_all, self.num_queries)
 
-        top_mem, top_logits, top_anchor = self._select_topk(out_mem, enc_logits, anchors,
-                                                            self.num_queries)
+            def take(t):
+                return t.gather(dim=1, index=ind.unsqueeze(-1).expand(-1, -1, t.shape[-1]))
+
+            top_mem = self.enc_output(take(memory))
+            top_logits = self.enc_score_head(top_mem)
+            top_anchor = take(anchors)
+        else:
+            out_mem = self.enc_output(memory)
+            enc_logits = self.enc_score_head(out_mem)
+            top_mem, top_logits, top_anchor = self._select_topk(out_mem, enc_logits, anchors,
+                                                                self.num_queries)
         box_unact = self.enc_bbox_head(top_mem) + top_anchor
         enc_boxes, enc_logits_list = [], []
         if self.training:
@@ -498,7 +515,7 @@ class DFINETransformer(nn.Module):
             content = torch.concat([denoising_logits, content], dim=1)
         return content, box_unact, enc_boxes, enc_logits_list
 
-    def _select_topk(self, memory, outputs_logits, outputs_anchors_unact, topk: int):
+    def _topk_indices(self, outputs_logits, topk: int):
         if self.query_select_method == "default":
             score = outputs_logits.max(-1).values
         elif self.query_select_method == "one2many":
@@ -508,6 +525,10 @@ class DFINETransformer(nn.Module):
         ind = kernels.topk_indices(score, topk)
         if self.query_select_method == "one2many":
             ind = ind // self.num_classes
+        return ind
+
+    def _select_topk(self, memory, outputs_logits, outputs_anchors_unact, topk: int):
+        ind = self._topk_indices(outputs_logits, topk)
 
         def take(t):
             return t.gather(dim=1, index=ind.unsqueeze(-1).expand(-1, -1, t.shape[-1]))
