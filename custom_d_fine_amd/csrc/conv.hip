@@ -432,10 +432,12 @@ int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, i
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(nnt64 * nct64, splits);
     if (KS == 3) {
-        if (ldsb > 64 * 1024) {
+        static bool attr_set = false;       // once: not a stream operation, keep it out of graph capture
+        if (!attr_set) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_kernel<3>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
+            attr_set = true;
         }
         hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(kConvThreads), ldsb, st, (const uint16_t *)x, (const uint16_t *)dy, ws,
                            Cin, Cout, h, w, R, strips, B * strips, ups, nct64, np16, cp16, cs);
