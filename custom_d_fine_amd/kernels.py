@@ -380,7 +380,7 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
     GPU: depthwise convs and the whole BN/act/affine tail are HIP kernels; dense convs are still
     MIOpen calls [ATen plumbing].  CPU tensors take the plain ATen composition below."""
     a = act.lower() if isinstance(act, str) else act
-    if x.is_cuda and a in (None, "relu", "silu", "swish"):
+    if x.is_cuda and a in (None, "relu", "silu", "swish") and os.environ.get("DFINE_HIP_UNITS", "1") == "1":
         if _is_depthwise(conv):
             if torch.is_autocast_enabled() and x.dtype == torch.float32:
                 x = x.to(torch.get_autocast_dtype("cuda"))      # what autocast would do for F.conv2d
