@@ -152,6 +152,66 @@ __global__ __launch_bounds__(kThreads) void msda_fwd_kernel(
     Vec4<T>::store(out + ((int64_t)gq * H + head) * D + c4, acc);
 }
 
+// Forward, bf16, 8 channels (one 16-byte load) per lane: D/8 lanes per task, 2x fewer load
+// instructions per gathered byte than the 4-channel mapping.
+template <int D, bool FUSED>
+__global__ __launch_bounds__(kThreads) void msda_fwd8_kernel(
+    const uint16_t *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ weight,
+    const float *__restrict__ ref, const uint16_t *__restrict__ offsets, const uint16_t *__restrict__ logits,
+    uint16_t *__restrict__ out, MsdaLevels lv, int L, int H, int Lq, int total_q, float offset_scale) {
+    constexpr int LPT = D / 8;
+    constexpr int QPB = kThreads / LPT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int P = lv.n_points;
+    float *s_x = smem, *s_y = smem + QPB * P, *s_w = smem + 2 * QPB * P;
+    const int head = blockIdx.x % H;
+    const int q0 = (blockIdx.x / H) * QPB;
+    const int nq = min(QPB, total_q - q0);
+    stage_points<uint16_t, FUSED>(lv, loc, weight, ref, offsets, logits, offset_scale, head, H, q0, nq,
+                                  total_q, s_x, s_y, s_w);
+    __syncthreads();
+    const int qi = threadIdx.x / LPT, c8 = (threadIdx.x % LPT) * 8;
+    if (qi >= nq) return;
+    const int gq = q0 + qi;
+    const int b = gq / Lq;
+    const uint16_t *vbase = value + ((int64_t)b * L * H + head) * D + c8;
+    const float *px = s_x + qi * P, *py = s_y + qi * P, *pw = s_w + qi * P;
+    float wmax = 0.f, winv = 1.f;
+    if (FUSED) {
+        wmax = pw[0];
+        for (int p = 1; p < P; ++p) wmax = fmaxf(wmax, pw[p]);
+        float s = 0.f;
+        for (int p = 0; p < P; ++p) s += __expf(pw[p] - wmax);
+        winv = 1.f / s;
+    }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int64_t stride = (int64_t)H * D;
+#pragma unroll 2
+    for (int p = 0; p < P; ++p) {
+        const Corner c = corners(px[p], py[p], lv.start[p], lv.h[p], lv.w[p]);
+        const float aw = FUSED ? __expf(pw[p] - wmax) * winv : pw[p];
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const uint4 *>(vbase + c.row[k] * stride);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float w = aw * c.bw[k];
+            const uint32_t u[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[2 * j] += w * __uint_as_float(u[j] << 16);
+                acc[2 * j + 1] += w * __uint_as_float(u[j] & 0xffff0000u);
+            }
+        }
+    }
+    uint4 o;
+    o.x = (uint32_t)f32_to_bf16(acc[0]) | ((uint32_t)f32_to_bf16(acc[1]) << 16);
+    o.y = (uint32_t)f32_to_bf16(acc[2]) | ((uint32_t)f32_to_bf16(acc[3]) << 16);
+    o.z = (uint32_t)f32_to_bf16(acc[4]) | ((uint32_t)f32_to_bf16(acc[5]) << 16);
+    o.w = (uint32_t)f32_to_bf16(acc[6]) | ((uint32_t)f32_to_bf16(acc[7]) << 16);
+    *reinterpret_cast<uint4 *>(out + ((int64_t)gq * H + head) * D + c8) = o;
+}
+
 // -------------------------------------------------------------------------------------------
 template <int LPT> __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
@@ -373,6 +433,21 @@ static int launch_fwd(const void *value, const float *loc, const float *weight, 
                       int D, int Lq, const MsdaLevels &lv, float offset_scale, hipStream_t st) {
     const int total_q = B * Lq;
     if (total_q == 0) return DFINE_OK;
+    static const int fwd_variant = [] { const char *e = getenv("DFINE_MSDA_FWD"); return e ? atoi(e) : 1; }();
+    if (fwd_variant == 1 && sizeof(T) == 2 && (D == 32 || D == 16 || D == 64)) {
+#define DFINE_FWD8(DD)                                                                         \
+    {                                                                                          \
+        constexpr int QPB = kThreads / (DD / 8);                                               \
+        const int nblk = ((total_q + QPB - 1) / QPB) * H;                                      \
+        const size_t sm = sizeof(float) * 3 * QPB * lv.n_points;                               \
+        hipLaunchKernelGGL((msda_fwd8_kernel<DD, FUSED>), dim3(nblk), dim3(kThreads), sm, st,  \
+                           (const uint16_t *)value, loc, weight, ref, (const uint16_t *)offsets, \
+                           (const uint16_t *)logits, (uint16_t *)out, lv, L, H, Lq, total_q, offset_scale); \
+    }
+        if (D == 32) DFINE_FWD8(32) else if (D == 16) DFINE_FWD8(16) else DFINE_FWD8(64)
+#undef DFINE_FWD8
+        return check_launch();
+    }
 #define DFINE_FWD(DD)                                                                          \
     {                                                                                          \
         constexpr int QPB = kThreads / (DD / 4);                                               \
