@@ -253,6 +253,16 @@ class TransformerDecoder(nn.Module):
             value = value * memory_mask.to(value.dtype).unsqueeze(-1)
         return value.reshape(value.shape[0], value.shape[1], self.num_head, -1)
 
+    def _fdr_constants(self, project, reg_scale):
+        """W(n) and reg_scale as host numbers for the HIP FDR kernel (model constants: one D2H)."""
+        key = (project.data_ptr() if hasattr(self, "project") else (self.up._version, self.reg_scale._version,
+                                                                    self.up.data_ptr()), float(self.reg_max))
+        cache = getattr(self, "_fdr_cache", None)
+        if cache is None or cache[0] != key:
+            self._fdr_cache = (key, project.detach().float().cpu().tolist(),
+                               float(reg_scale.detach().float().cpu()) if torch.is_tensor(reg_scale) else float(reg_scale))
+        return self._fdr_cache[1], self._fdr_cache[2]
+
     def convert_to_deploy(self):
         self.project = weighting_function(self.reg_max, self.up, self.reg_scale, deploy=True)
         self.layers = self.layers[: self.eval_idx + 1]
@@ -292,10 +302,19 @@ class TransformerDecoder(nn.Module):
 
             # FDR: residual update of the edge distributions, decoded around the initial box
             pred_corners = bbox_head[i](out + out_detach) + prev_corners
-            box = distance2bbox(ref_initial, integral(pred_corners, project), reg_scale)
+            fused = pred_corners.is_cuda and self.reg_max == 32 and isinstance(self.lqe_layers[i], LQE) \
+                and self.lqe_layers[i].k == 4
+            if fused:   # Integral + distance2bbox + LQE statistics in one HIP kernel
+                wtable, rs = self._fdr_constants(project, reg_scale)
+                box, stat = kernels.fdr_decode(pred_corners, ref_initial, wtable, rs)
+            else:
+                box = distance2bbox(ref_initial, integral(pred_corners, project), reg_scale)
 
             if self.training or i == self.eval_idx:
-                scores = self.lqe_layers[i](score_head[i](out), pred_corners)
+                if fused:
+                    scores = score_head[i](out) + self.lqe_layers[i].reg_conf(stat)
+                else:
+                    scores = self.lqe_layers[i](score_head[i](out), pred_corners)
                 logits.append(scores)
                 boxes.append(box)
                 corners.append(pred_corners)

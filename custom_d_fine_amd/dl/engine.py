@@ -101,6 +101,8 @@ class TrainStep:
         if self.clip_max_norm:
             torch.nn.utils.clip_grad_norm_(self._params, self.clip_max_norm, foreach=True)
         self.optimizer.step()
+        from .. import kernels
+        kernels.bump_weight_epoch()
         if step_scheduler and self.scheduler is not None:
             self.scheduler.step()
         self.optimizer.zero_grad(set_to_none=True)

@@ -153,5 +153,7 @@ class FusedAdamWEMA:
                                group["weight_decay"], self.step_count, grad_scale, self.clip_max_norm, mom)
         if self.flat_buf is not None:
             hip.ema_update(self.flat_ema_buf, self.flat_buf, mom)
+        from .. import kernels
+        kernels.bump_weight_epoch()          # cached packed conv weights are stale now
         # keep torch's scheduler bookkeeping consistent (it warns if optimizer.step was never called)
         self.optimizer._opt_called = True

@@ -49,6 +49,8 @@ _SIGNATURES = {
     "dfine_conv_fwd_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_conv_wgrad_ws_floats": (_L, [_I, _I, _I, _I, _I, _I]),
     "dfine_conv_wgrad_bf16": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_fdr_fwd": (c_int, [_P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfine_fdr_bwd": (c_int, [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_bn_act_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 for _name, (_res, _args) in _SIGNATURES.items():
@@ -270,6 +272,18 @@ def dwconv_backward(x, w, dy, stride, pad, need_dx=True, need_dw=True):
 
 # ------------------------------------------------------------------------------------- fused BN
 _ACT = {None: 0, "relu": 1, "silu": 2, "swish": 2}
+_BN_WS = {}
+
+
+def _bn_workspace(dev, nfloats):
+    """Scratch for the partial sums: consumed inside the same call by stream-ordered kernels, so one
+    growing buffer per (device, stream) is reused by every BatchNorm unit instead of an allocation each."""
+    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    ws = _BN_WS.get(key)
+    if ws is None or ws.numel() < nfloats:
+        ws = torch.empty(max(nfloats, 1 << 16), device=dev, dtype=torch.float32)
+        _BN_WS[key] = ws
+    return ws
 
 
 def bn_act_forward(x, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, training,
@@ -280,7 +294,7 @@ def bn_act_forward(x, gamma, beta, running_mean, running_var, lab_scale, lab_bia
     dev = x.device
     y = torch.empty_like(x)
     stats = torch.empty(4, C, device=dev, dtype=torch.float32)     # mean, invstd, scale, shift
-    ws = torch.empty(int(_lib.dfine_bn_ws_floats(B, C, HW)), device=dev, dtype=torch.float32)
+    ws = _bn_workspace(dev, int(_lib.dfine_bn_ws_floats(B, C, HW)))
     with _timed("dfine_bn_act_fwd"):
         _check(_lib.dfine_bn_act_fwd(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(running_mean),
                                      _ptr(running_var), _ptr(lab_scale), _ptr(lab_bias), _ptr(stats[0]),
@@ -300,7 +314,7 @@ def bn_act_backward(x, dy, stats, lab_scale, act, training, need_affine=True, ne
     dx = torch.empty_like(x)
     dparam = torch.empty(2, C, device=dev, dtype=torch.float32) if need_affine else None
     dlab = torch.zeros(2, device=dev, dtype=torch.float32) if need_lab else None
-    ws = torch.empty(int(_lib.dfine_bn_ws_floats(B, C, HW)), device=dev, dtype=torch.float32)
+    ws = _bn_workspace(dev, int(_lib.dfine_bn_ws_floats(B, C, HW)))
     with _timed("dfine_bn_act_bwd"):
         _check(_lib.dfine_bn_act_bwd(_ptr(x), _ptr(dy), _ptr(dx), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]),
                                      _ptr(stats[3]), _ptr(lab_scale),
@@ -411,3 +425,27 @@ def conv_wgrad_bf16(x, dy, ks):
         _check(_lib.dfine_conv_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ks, _stream()),
                "dfine_conv_wgrad_bf16")
     return dw
+
+
+# ------------------------------------------------------------------------------------- FDR head
+def fdr_forward(corners, ref, wtable, reg_scale, k=4):
+    n = corners.numel() // corners.shape[-1]
+    reg_max = corners.shape[-1] // 4 - 1
+    dev = corners.device
+    boxes = torch.empty(n, 4, device=dev, dtype=torch.float32)
+    stat = torch.empty(n, 4 * (k + 1), device=dev, dtype=torch.float32)
+    idx = torch.empty(n * 4 * k, device=dev, dtype=torch.uint8)
+    wt = (c_float * len(wtable))(*wtable)
+    _check(_lib.dfine_fdr_fwd(_ptr(corners), _ptr(ref), wt, float(reg_scale), _ptr(boxes), _ptr(stat), _ptr(idx),
+                              _dtype_code(corners), n, reg_max, k, _stream()), "dfine_fdr_fwd")
+    return boxes, stat, idx
+
+
+def fdr_backward(corners, ref, wtable, reg_scale, g_boxes, g_stat, idx, k=4):
+    n = corners.numel() // corners.shape[-1]
+    reg_max = corners.shape[-1] // 4 - 1
+    g = torch.empty_like(corners)
+    wt = (c_float * len(wtable))(*wtable)
+    _check(_lib.dfine_fdr_bwd(_ptr(corners), _ptr(ref), wt, float(reg_scale), _ptr(g_boxes), _ptr(g_stat), _ptr(idx),
+                              _ptr(g), _dtype_code(corners), n, reg_max, k, _stream()), "dfine_fdr_bwd")
+    return g

@@ -128,6 +128,40 @@ def hungarian_assign(logits: torch.Tensor, boxes: torch.Tensor, tgt_labels: torc
 
 
 # =============================================================================================
+# A8  FDR head: Integral + distance2bbox + LQE statistics
+# =============================================================================================
+class _FDRDecode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, corners, ref, wtable, reg_scale):
+        hip = _hip()
+        lead = corners.shape[:-1]
+        c = corners.contiguous()
+        r = ref.detach().float().contiguous()
+        boxes, stat, idx = hip.fdr_forward(c, r, wtable, reg_scale)
+        ctx.save_for_backward(c, r, idx)
+        ctx.cfg = (wtable, reg_scale)
+        ctx.mark_non_differentiable(idx)
+        return boxes.view(*lead, 4), stat.view(*lead, stat.shape[-1])
+
+    @staticmethod
+    def backward(ctx, g_boxes, g_stat):
+        c, r, idx = ctx.saved_tensors
+        wtable, reg_scale = ctx.cfg
+        gb = None if g_boxes is None else g_boxes.float().contiguous()
+        gs = None if g_stat is None else g_stat.float().contiguous()
+        return _hip().fdr_backward(c, r, wtable, reg_scale, gb, gs, idx), None, None, None
+
+
+def fdr_decode(corners, ref_boxes, wtable, reg_scale):
+    """corners [..., 4*(reg_max+1)] edge-distribution logits, ref_boxes [..., 4] (detached) ->
+    (boxes [..., 4] f32 cxcywh, stat [..., 4*(k+1)] f32: top-4 bin probabilities + mean per edge).
+    GPU only (csrc/fdr.hip); CPU tensors use the Integral / distance2bbox / LQE torch composition."""
+    if not corners.is_cuda:
+        raise RuntimeError("kernels.fdr_decode is a HIP operator")
+    return _FDRDecode.apply(corners, ref_boxes, wtable, reg_scale)
+
+
+# =============================================================================================
 # A13/A14  set-criterion losses of one prediction head (values + gradients in one launch group)
 # =============================================================================================
 class _HeadLosses(torch.autograd.Function):
@@ -243,6 +277,28 @@ class _BNAct(torch.autograd.Function):
 # kernels win on the large 1x1 layers - profiles/r01_conv_survey_hip_vs_miopen.txt).
 _CONV_PLAN = {}
 
+# Packed bf16 copies of the conv weights (forward and data-gradient layouts) are rebuilt only when the
+# weights changed: `_WEIGHT_EPOCH` is bumped by the optimizer step (the fused optimizer updates the flat
+# buffer through raw pointers, invisible to tensor._version), `_version` covers in-place torch updates.
+_WEIGHT_EPOCH = 0
+_PACK_CACHE = {}
+
+
+def bump_weight_epoch():
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
+
+
+def _packed_weights(weight, dgrad):
+    key = (id(weight), dgrad)
+    tag = (_WEIGHT_EPOCH, weight._version, weight.data_ptr())
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    w2 = _hip().conv_pack_weights(weight.detach().float().contiguous(), dgrad)
+    _PACK_CACHE[key] = (tag, w2)
+    return w2
+
 
 def _time_op(fn, reps=4):
     fn()
@@ -281,10 +337,11 @@ def _conv_plan(x, weight):
         def aten_bwd(mask):
             return torch.ops.aten.convolution_backward(dy, xs, wb, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1, mask)
 
+        w2f, w2d = hip.conv_pack_weights(w32, False), hip.conv_pack_weights(w32, True)   # cached per step
         plan = {
-            "fwd": _time_op(lambda: hip.conv_forward_bf16(xs, hip.conv_pack_weights(w32, False), cout, ks))
+            "fwd": _time_op(lambda: hip.conv_forward_bf16(xs, w2f, cout, ks))
             < _time_op(lambda: F.conv2d(xs, w32.to(torch.bfloat16), None, 1, pad)),
-            "dgrad": _time_op(lambda: hip.conv_forward_bf16(dy, hip.conv_pack_weights(w32, True), cin, ks))
+            "dgrad": _time_op(lambda: hip.conv_forward_bf16(dy, w2d, cin, ks))
             < _time_op(lambda: aten_bwd([True, False, False])),
             "wgrad": hip.conv_wgrad_supported(H, W, ks)
             and _time_op(lambda: hip.conv_wgrad_bf16(xs, dy, ks)) < _time_op(lambda: aten_bwd([False, True, False])[1].float()),
@@ -305,8 +362,7 @@ class _DenseConv(torch.autograd.Function):
         plan = _conv_plan(x, weight)
         ks = weight.shape[-1]
         if plan["fwd"]:
-            y = hip.conv_forward_bf16(x, hip.conv_pack_weights(weight.detach().float().contiguous(), False),
-                                      weight.shape[0], ks)
+            y = hip.conv_forward_bf16(x, _packed_weights(weight, False), weight.shape[0], ks)
         else:
             y = F.conv2d(x, weight.detach().to(torch.bfloat16), None, 1, ks // 2)
         ctx.save_for_backward(x, weight)
@@ -333,8 +389,7 @@ class _DenseConv(torch.autograd.Function):
             dx = res[0] if aten_dx else None
             dw = res[1].to(weight.dtype) if aten_dw else None
         if need_dx and plan["dgrad"]:
-            dx = hip.conv_forward_bf16(dy, hip.conv_pack_weights(weight.detach().float().contiguous(), True),
-                                       weight.shape[1], ks)
+            dx = hip.conv_forward_bf16(dy, _packed_weights(weight, True), weight.shape[1], ks)
         if need_dw and plan["wgrad"]:
             dw = hip.conv_wgrad_bf16(x, dy, ks).to(weight.dtype)
         return dx, dw

@@ -227,6 +227,22 @@ int64_t dfine_conv_wgrad_ws_floats(int B, int Cin, int Cout, int H, int W, int K
 int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, int B, int Cin, int Cout,
                           int H, int W, int KS, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * A8  Fine-grained distribution refinement head: Integral + distance2bbox + LQE statistics.
+ * Replaces Integral.forward, distance2bbox and the softmax/top-k/mean half of LQE.forward
+ * (src/d_fine/arch/dfine_decoder.py:291-295,307-311; src/d_fine/arch/utils.py:119-142).
+ *   corners [N, 4*(reg_max+1)] dtype (N = B*Lq rows, contiguous); ref [N, 4] f32 cxcywh (detached
+ *   reference boxes); wtable [reg_max+1] HOST array W(n); reg_max = 32, K = 4.
+ *   fwd: boxes [N, 4] f32 cxcywh; stat [N, 4*(K+1)] f32 (per edge: top-K bin probabilities descending,
+ *        then their mean); top_idx [N*4*K] u8 (saved for backward).
+ *   bwd: g_boxes [N,4] f32 or NULL, g_stat [N, 4*(K+1)] f32 or NULL -> g_corners [N, 4*(reg_max+1)] dtype.
+ */
+int dfine_fdr_fwd(const void *corners, const float *ref, const float *wtable, float reg_scale, float *boxes,
+                  float *stat, uint8_t *top_idx, int dtype, int N, int reg_max, int K, void *stream);
+int dfine_fdr_bwd(const void *corners, const float *ref, const float *wtable, float reg_scale,
+                  const float *g_boxes, const float *g_stat, const uint8_t *top_idx, void *g_corners,
+                  int dtype, int N, int reg_max, int K, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
