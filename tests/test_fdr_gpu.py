@@ -51,4 +51,4 @@ def test_fdr_forward_backward(cuda, dtype):
     # numpy oracle (reference restatement) for the box decode
     d = np_ref.integral(corners.detach().float().cpu().numpy(), np_ref.weighting_function(32, 0.5, 4.0))
     nb = np_ref.distance2bbox(ref.cpu().numpy(), d, 4.0)
-    np.testing.assert_allclose(box.cpu().numpy(), nb, rtol=tol * 10, atol=tol * 10)
+    np.testing.assert_allclose(box.detach().cpu().numpy(), nb, rtol=tol * 10, atol=tol * 10)
