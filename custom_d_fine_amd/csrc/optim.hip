@@ -85,6 +85,25 @@ __global__ __launch_bounds__(256) void ema_kernel(float *__restrict__ ema, const
     for (; i < n; i += step) ema[i] = ema[i] * momentum + (1.f - momentum) * src[i];
 }
 
+// Gathers many separately allocated fp32 tensors (the per-parameter gradients autograd produced) into
+// one flat buffer: table[i] = {src pointer, destination offset, element count}, one entry per <= 64 K
+// element chunk, one block per entry.
+struct CopyEntry { const float *src; int64_t dst_off; int64_t n; };
+
+__global__ __launch_bounds__(256) void multi_copy_kernel(const CopyEntry *__restrict__ table, float *__restrict__ dst) {
+    const CopyEntry e = table[blockIdx.x];
+    float *d = dst + e.dst_off;
+    const bool aligned = (((uintptr_t)e.src | (uintptr_t)d) & 15) == 0;
+    if (aligned) {
+        const int64_t n4 = e.n >> 2;
+        for (int64_t i = threadIdx.x; i < n4; i += 256)
+            reinterpret_cast<float4 *>(d)[i] = reinterpret_cast<const float4 *>(e.src)[i];
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < e.n; i += 256) d[i] = e.src[i];
+    } else {
+        for (int64_t i = threadIdx.x; i < e.n; i += 256) d[i] = e.src[i];
+    }
+}
+
 static int grid_for(int64_t n, int per_thread) {
     int64_t b = (n / per_thread + 255) / 256;
     if (b > 4096) b = 4096;
@@ -117,6 +136,14 @@ int dfine_adamw_ema_step(float *param, float *grad, float *exp_avg, float *exp_a
     a.grad_scale = grad_scale; a.max_norm = max_norm; a.ema_momentum = ema_momentum;
     hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, ema, n, sqnorm, a);
+    return check_launch();
+}
+
+// table: DEVICE array of n_entries {const float* src; int64 dst_off; int64 n} records (24 bytes each).
+int dfine_multi_copy_f32(const void *table, int n_entries, float *dst, void *stream) {
+    if (n_entries == 0) return DFINE_OK;
+    if (!table || !dst || n_entries < 0) return DFINE_E_BADARG;
+    hipLaunchKernelGGL(multi_copy_kernel, dim3(n_entries), dim3(256), 0, (hipStream_t)stream, (const CopyEntry *)table, dst);
     return check_launch();
 }
 

@@ -61,7 +61,7 @@ class FusedAdamWEMA:
         self.flat_ema = torch.zeros(total, device=dev) if ema is not None else None
         self.sqnorm = torch.zeros(1, device=dev)
         self.segments = []
-        self._params, self._grad_views = [], []
+        self._params, self._grad_views, self._grad_offsets = [], [], []
         ema_params = dict(ema.model.named_parameters()) if ema is not None else {}
         names = {id(p): n for n, p in model.named_parameters()}
         off = 0
@@ -73,6 +73,10 @@ class FusedAdamWEMA:
                 p.data = v
             self._params.extend(g)
             self._grad_views.extend(gviews)
+            o = off
+            for p in g:
+                self._grad_offsets.append(o)
+                o += p.numel()
             if ema is not None:
                 eps_ = [ema_params[names[id(p)].replace("module.", "", 1) if names[id(p)].startswith("module.")
                                    else names[id(p)]] for p in g]
@@ -116,14 +120,19 @@ class FusedAdamWEMA:
         """Gathers the per-parameter gradients autograd produced into the flat buffer with one
         multi-tensor copy and drops them.  (Keeping `.grad` as persistent views instead makes
         autograd ADD into them - one tiny kernel per parameter, 646 per step for D-FINE-m.)"""
-        views, grads = [], []
-        for p, v in zip(self._params, self._grad_views):
-            if p.grad is not None:
-                views.append(v)
-                grads.append(p.grad)
+        grads, offs = [], []
+        for p, off in zip(self._params, self._grad_offsets):
+            g = p.grad
+            if g is not None:
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    g = g.float().contiguous()
+                grads.append(g)
+                offs.append(off)
                 p.grad = None
         if grads:
-            torch._foreach_copy_(views, grads)
+            # one HIP launch driven by a pointer table (torch._foreach_copy_ degrades to one DtoD memcpy
+            # per tensor here: 646 launches per step for D-FINE-m)
+            self._live = (grads, self.hip.multi_copy_f32(grads, offs, self.flat_grad))
 
     def step(self):
         """all-reduce (if data parallel) -> norm -> per-group AdamW+EMA (also zeroes the grads)."""

@@ -44,6 +44,7 @@ _SIGNATURES = {
     "dfine_grad_sqnorm": (c_int, [_P, _L, _F, _P, _P]),
     "dfine_adamw_ema_step": (c_int, [_P, _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _I, _F, _F, _F, _P]),
     "dfine_ema_update": (c_int, [_P, _P, _L, _F, _P]),
+    "dfine_multi_copy_f32": (c_int, [_P, _I, _P, _P]),
     "dfine_conv_packed_elems": (_L, [_I, _I, _I, _I]),
     "dfine_conv_pack_weights": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "dfine_conv_fwd_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -449,3 +450,18 @@ def fdr_backward(corners, ref, wtable, reg_scale, g_boxes, g_stat, idx, k=4):
     _check(_lib.dfine_fdr_bwd(_ptr(corners), _ptr(ref), wt, float(reg_scale), _ptr(g_boxes), _ptr(g_stat), _ptr(idx),
                               _ptr(g), _dtype_code(corners), n, reg_max, k, _stream()), "dfine_fdr_bwd")
     return g
+
+
+def multi_copy_f32(srcs, dst_offsets, dst_flat, chunk=1 << 16):
+    """Copies the fp32 tensors `srcs` to dst_flat[dst_offsets[i] : +numel] with one launch."""
+    import numpy as np
+    rows = []
+    for t, off in zip(srcs, dst_offsets):
+        n, p = t.numel(), t.data_ptr()
+        for c0 in range(0, n, chunk):
+            rows.append((p + 4 * c0, off + c0, min(chunk, n - c0)))
+    if not rows:
+        return
+    table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dst_flat.device, non_blocking=True)
+    _check(_lib.dfine_multi_copy_f32(_ptr(table), len(rows), _ptr(dst_flat), _stream()), "dfine_multi_copy_f32")
+    return table      # keep alive until the stream has consumed it

@@ -204,6 +204,10 @@ int dfine_adamw_ema_step(float *param, float *grad, float *exp_avg, float *exp_a
                          float weight_decay, int step, float grad_scale, float max_norm,
                          float ema_momentum, void *stream);
 int dfine_ema_update(float *ema, const float *src, int64_t n, float momentum, void *stream);
+/* Gather of many fp32 tensors into one flat buffer (per-parameter gradients -> flat gradient buffer):
+ * table = DEVICE array of n_entries records {const float *src; int64_t dst_offset; int64_t count}
+ * (24 bytes each, one block per record; split large tensors into <= 64 K element records). */
+int dfine_multi_copy_f32(const void *table, int n_entries, float *dst, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A1/A2  Dense 1x1 / 3x3 stride-1 "same" convolution on the MFMA units (NCHW, bf16, fp32 accumulate).
