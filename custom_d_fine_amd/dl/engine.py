@@ -69,12 +69,81 @@ class _BackboneEncoder(nn.Module):
         return tuple(self.encoder(self.backbone(x)))
 
 
+class GraphedSegment:
+    """A module with static shapes whose forward and backward are each captured ONCE into a HIP graph and
+    replayed afterwards (two launches instead of thousands of host-side kernel launches).
+
+    Hand-rolled equivalent of torch.cuda.make_graphed_callables - which segfaults on torch 2.10.0+rocm7.0
+    even for a two-layer MLP (tools/graph_probe2.py), while explicit torch.cuda.graph capture with
+    torch.autograd.grad inside works (tools/graph_probe3.py).  Inputs are copied into static buffers,
+    outputs / parameter gradients are returned as the graph's static tensors."""
+
+    def __init__(self, module, sample_inputs, amp_dtype=None, warmup=2):
+        self.module = module
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.amp_dtype = amp_dtype
+        self.static_in = [t.detach().clone().requires_grad_(t.requires_grad) for t in sample_inputs]
+        self.grad_in_idx = [i for i, t in enumerate(self.static_in) if t.requires_grad]
+
+        def run():
+            with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None, cache_enabled=False):
+                return tuple(module(*self.static_in))
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                outs = run()
+                torch.autograd.grad(outs, [self.static_in[i] for i in self.grad_in_idx] + self.params,
+                                    [torch.ones_like(o) for o in outs], allow_unused=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+        self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fwd_graph):
+            self.static_out = run()
+        self.static_gout = [torch.zeros_like(o) for o in self.static_out]
+        with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool()):
+            self.static_grads = torch.autograd.grad(
+                self.static_out, [self.static_in[i] for i in self.grad_in_idx] + self.params,
+                self.static_gout, allow_unused=True)
+        seg = self
+
+        class _Replay(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, *args):           # args = inputs + params (params only to hook autograd up)
+                for dst, src in zip(seg.static_in, args[:len(seg.static_in)]):
+                    if dst.data_ptr() != src.data_ptr():
+                        dst.copy_(src)
+                seg.fwd_graph.replay()
+                return tuple(o.detach() for o in seg.static_out)
+
+            @staticmethod
+            def backward(ctx, *gouts):
+                for dst, src in zip(seg.static_gout, gouts):
+                    if src is None:
+                        dst.zero_()
+                    elif dst.data_ptr() != src.data_ptr():
+                        dst.copy_(src)
+                seg.bwd_graph.replay()
+                grads = [None] * len(seg.static_in)
+                it = iter(seg.static_grads)
+                for i in seg.grad_in_idx:
+                    grads[i] = next(it)
+                return tuple(grads) + tuple(g.detach() if g is not None else None for g in it)
+
+        self._fn = _Replay
+
+    def __call__(self, *inputs):
+        return self._fn.apply(*inputs, *self.params)
+
+
 class TrainStep:
     """fwd (autocast) -> criterion (fp32) -> bwd -> clip -> AdamW -> [scheduler] -> EMA.
 
     `hip_graph=True` (GPU): backbone + encoder - static shapes, ~70 % of the step's kernel launches
     (conv / BN / depthwise units, forward and backward) - are captured once into HIP graphs
-    (torch.cuda.make_graphed_callables) and replayed, which removes their host-side launch cost; the
+    and replayed, which removes their host-side launch cost; the
     decoder (query count depends on the batch's targets) and the criterion (one D2H copy of the
     assignment) stay eager."""
 
@@ -119,10 +188,11 @@ class TrainStep:
         if self._graphed is None or self._graph_shape != tuple(images.shape):
             # eager warm-up calls (autotuning, MIOpen find, BN buffers) are done: capture fwd + bwd
             be = _BackboneEncoder(model.backbone, model.encoder)
-            sample = images.detach().clone()
-            self._graphed = torch.cuda.make_graphed_callables(be, (sample,), num_warmup_iters=2)
+            self._graphed = GraphedSegment(be, (images,), amp_dtype=self.amp_dtype)
             self._graph_shape = tuple(images.shape)
-        return model.decoder(list(self._graphed(images)), targets)
+        with torch.autocast("cuda", enabled=False):
+            feats = self._graphed(images)
+        return model.decoder(list(feats), targets)
 
     def __call__(self, images, targets):
         dev_type = images.device.type

@@ -290,6 +290,10 @@ def bump_weight_epoch():
 
 
 def _packed_weights(weight, dgrad):
+    if torch.cuda.is_current_stream_capturing():
+        # inside a HIP-graph capture the pack launch itself must be recorded (the weights change
+        # between replays), so never serve or fill the cache here
+        return _hip().conv_pack_weights(weight.detach().float().contiguous(), dgrad)
     key = (id(weight), dgrad)
     tag = (_WEIGHT_EPOCH, weight._version, weight.data_ptr())
     hit = _PACK_CACHE.get(key)
