@@ -149,7 +149,7 @@ class TrainStep:
 
     def __init__(self, model, criterion, optimizer, *, amp_dtype=None, clip_max_norm=0.1,
                  ema=None, scheduler=None, accum_steps=1, fused_optimizer=None, hip_graph=False,
-                 graph_after=2):
+                 graph_after=0):
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
         self.amp_dtype, self.clip_max_norm = amp_dtype, clip_max_norm
         self.ema, self.scheduler, self.accum_steps = ema, scheduler, max(accum_steps, 1)
@@ -186,7 +186,10 @@ class TrainStep:
         if not use_graph:
             return model(images, targets=targets)
         if self._graphed is None or self._graph_shape != tuple(images.shape):
-            # eager warm-up calls (autotuning, MIOpen find, BN buffers) are done: capture fwd + bwd
+            # Capture on the FIRST call, before any eager .backward(): an AccumulateGrad node created on
+            # the default stream by an earlier eager backward makes the later capture segfault on this
+            # torch/ROCm build (tools/graph_probe6.py).  GraphedSegment's own warm-up iterations (side
+            # stream, torch.autograd.grad) run the conv autotuner / MIOpen find eagerly first.
             be = _BackboneEncoder(model.backbone, model.encoder)
             self._graphed = GraphedSegment(be, (images,), amp_dtype=self.amp_dtype)
             self._graph_shape = tuple(images.shape)
