@@ -52,6 +52,7 @@ _SIGNATURES = {
     "dfine_conv_wgrad_bf16": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_fdr_fwd": (c_int, [_P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_fdr_bwd": (c_int, [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfine_topk_anchors": (c_int, [_P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfine_bn_act_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 for _name, (_res, _args) in _SIGNATURES.items():
@@ -465,3 +466,16 @@ def multi_copy_f32(srcs, dst_offsets, dst_flat, chunk=1 << 16):
     table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dst_flat.device, non_blocking=True)
     _check(_lib.dfine_multi_copy_f32(_ptr(table), len(rows), _ptr(dst_flat), _stream()), "dfine_multi_copy_f32")
     return table      # keep alive until the stream has consumed it
+
+
+# ------------------------------------------------------------------------------------- query selection
+def topk_anchors(logits, k, with_scores=False):
+    """logits [B, Q, C] (unit class stride) -> indices [B, k] i64 of the k anchors with the largest
+    max-over-classes logit, descending (ties: ascending index)."""
+    assert logits.dim() == 3 and logits.stride(2) == 1
+    B, Q, C = logits.shape
+    idx = torch.empty(B, k, device=logits.device, dtype=torch.int64)
+    sc = torch.empty(B, k, device=logits.device, dtype=torch.float32) if with_scores else None
+    _check(_lib.dfine_topk_anchors(_ptr(logits), logits.stride(0), logits.stride(1), _ptr(idx), _ptr(sc),
+                                   _dtype_code(logits), B, Q, C, k, _stream()), "dfine_topk_anchors")
+    return (idx, sc) if with_scores else idx

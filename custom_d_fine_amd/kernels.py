@@ -491,6 +491,16 @@ def self_attention(qk, value, in_w, in_b, out_w, out_b, num_heads: int, attn_mas
     return F.linear(o.transpose(1, 2).reshape(b, l, e), out_w, out_b)
 
 
+def topk_anchors(logits: torch.Tensor, k: int) -> torch.Tensor:
+    """A3 query selection: indices [B, k] of the anchors with the largest max-over-classes logit,
+    descending.  GPU: one fused HIP kernel (csrc/topk.hip) instead of a max-reduce + torch.topk."""
+    b, q, c = logits.shape
+    if logits.is_cuda and logits.dtype in (torch.float32, torch.bfloat16) and logits.stride(2) == 1 \
+            and q <= 16384 and k <= min(q, 1024):
+        return _hip().topk_anchors(logits, k)
+    return torch.topk(logits.max(-1).values, k, dim=-1).indices
+
+
 def topk_indices(score: torch.Tensor, k: int) -> torch.Tensor:
     """Indices of the k largest entries per row, descending.  [ATen plumbing]"""
     return torch.topk(score, k, dim=-1).indices

@@ -247,6 +247,16 @@ int dfine_fdr_bwd(const void *corners, const float *ref, const float *wtable, fl
                   const float *g_boxes, const float *g_stat, const uint8_t *top_idx, void *g_corners,
                   int dtype, int N, int reg_max, int K, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * A3  Query selection: score = max over classes, top-K anchors per image (descending score; ties by
+ * ascending index).  Replaces torch.topk(outputs_logits.max(-1).values, K) of
+ * DFINETransformer._select_topk (src/d_fine/arch/dfine_decoder.py:875-910).
+ *   logits [B, Q, C] dtype with element strides (sb, sq) and unit class stride; out_idx [B, K] i64;
+ *   out_score [B, K] f32 or NULL.  Q <= 16384, K <= min(Q, 1024).
+ */
+int dfine_topk_anchors(const void *logits, int64_t sb, int64_t sq, int64_t *out_idx, float *out_score,
+                       int dtype, int B, int Q, int C, int K, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
