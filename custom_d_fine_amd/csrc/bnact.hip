@@ -61,15 +61,17 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const T *__restric
     const int c = blockIdx.x, chunk = blockIdx.y;
     const int b0 = chunk * imgs_per_chunk, b1 = min(B, b0 + imgs_per_chunk);
     float v[2] = {0.f, 0.f};
-    for (int b = b0; b < b1; ++b) {
-        const T *p = x + ((int64_t)b * C + c) * HW;
-        if ((HW & 3) == 0) {
-            for (int i = threadIdx.x * 4; i < HW; i += kBnThreads * 4) {
-                const f32x4 a = Vec4<T>::load(p + i);
-                v[0] += (a.x + a.y) + (a.z + a.w);
-                v[1] += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
-            }
-        } else {
+    if ((HW & 3) == 0) {
+        const int nv = HW >> 2, total = (b1 - b0) * nv;            // (image, 4-vector) pairs of this chunk
+        for (int i = threadIdx.x; i < total; i += kBnThreads) {
+            const int bi = i / nv, vi = i - bi * nv;
+            const f32x4 a = Vec4<T>::load(x + ((int64_t)(b0 + bi) * C + c) * HW + vi * 4);
+            v[0] += (a.x + a.y) + (a.z + a.w);
+            v[1] += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+        }
+    } else {
+        for (int b = b0; b < b1; ++b) {
+            const T *p = x + ((int64_t)b * C + c) * HW;
             for (int i = threadIdx.x; i < HW; i += kBnThreads) {
                 const float a = load_f(p + i);
                 v[0] += a; v[1] += a * a;
@@ -125,6 +127,61 @@ __global__ void bn_fold_kernel(int C, const float *__restrict__ gamma, const flo
     shift_out[c] = bt - running_mean[c] * g * invstd;
 }
 
+// Flat variant for planes whose size is a multiple of 4: grid-stride over all 4-vectors of the tensor,
+// per-channel constants staged in LDS - keeps every thread busy for small planes (20x20, 40x40), where
+// one block per plane leaves most lanes idle.
+template <typename T>
+__global__ __launch_bounds__(kBnThreads) void bn_apply_flat_kernel(const T *__restrict__ x, T *__restrict__ y,
+                                                                   const float *__restrict__ scale,
+                                                                   const float *__restrict__ shift,
+                                                                   const float *__restrict__ lab_s,
+                                                                   const float *__restrict__ lab_b, int C, int HW,
+                                                                   int64_t nvec, int act) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_sc = smem, *s_sh = smem + C;
+    for (int i = threadIdx.x; i < C; i += kBnThreads) { s_sc[i] = scale[i]; s_sh[i] = shift[i]; }
+    const float ls = lab_s ? lab_s[0] : 1.f, lb = lab_b ? lab_b[0] : 0.f;
+    __syncthreads();
+    const int nv = HW >> 2;
+    for (int64_t v = (int64_t)blockIdx.x * kBnThreads + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * kBnThreads) {
+        const int c = (int)((v / nv) % C);
+        const float sc = s_sc[c], sh = s_sh[c];
+        f32x4 a = Vec4<T>::load(x + v * 4);
+        a.x = ls * act_fwd(a.x * sc + sh, act) + lb; a.y = ls * act_fwd(a.y * sc + sh, act) + lb;
+        a.z = ls * act_fwd(a.z * sc + sh, act) + lb; a.w = ls * act_fwd(a.w * sc + sh, act) + lb;
+        Vec4<T>::store(y + v * 4, a);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_flat_kernel(
+    const T *__restrict__ x, const T *__restrict__ dy, T *__restrict__ dx, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ lab_s, const float *__restrict__ coef, int C, int HW, int64_t nvec, int act,
+    int train) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_mu = smem, *s_is = smem + C, *s_sc = smem + 2 * C, *s_sh = smem + 3 * C, *s_m0 = smem + 4 * C,
+          *s_m1 = smem + 5 * C;
+    for (int i = threadIdx.x; i < C; i += kBnThreads) {
+        s_mu[i] = mean ? mean[i] : 0.f; s_is[i] = invstd ? invstd[i] : 0.f; s_sc[i] = scale[i]; s_sh[i] = shift[i];
+        s_m0[i] = train ? coef[2 * i] : 0.f; s_m1[i] = train ? coef[2 * i + 1] : 0.f;
+    }
+    const float ls = lab_s ? lab_s[0] : 1.f;
+    __syncthreads();
+    const int nv = HW >> 2;
+    for (int64_t v = (int64_t)blockIdx.x * kBnThreads + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * kBnThreads) {
+        const int c = (int)((v / nv) % C);
+        const float mu = s_mu[c], is = s_is[c], sc = s_sc[c], sh = s_sh[c], m0 = s_m0[c], m1 = s_m1[c];
+        auto f = [&](float xv, float gv) {
+            const float z = xv * sc + sh;
+            const float dz = gv * ls * act_grad(z, act);
+            return sc * (dz - m0 - ((xv - mu) * is) * m1);
+        };
+        const f32x4 a = Vec4<T>::load(x + v * 4), d = Vec4<T>::load(dy + v * 4);
+        Vec4<T>::store(dx + v * 4, {f(a.x, d.x), f(a.y, d.y), f(a.z, d.z), f(a.w, d.w)});
+    }
+}
+
 // grid: (B*C planes, plane chunks)
 template <typename T>
 __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const T *__restrict__ x, T *__restrict__ y,
@@ -175,15 +232,18 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(
         v[2] += g * act_fwd(z, act);
         v[3] += g;
     };
-    for (int b = b0; b < b1; ++b) {
-        const T *p = x + ((int64_t)b * C + c) * HW;
-        const T *g = dy + ((int64_t)b * C + c) * HW;
-        if ((HW & 3) == 0) {
-            for (int i = threadIdx.x * 4; i < HW; i += kBnThreads * 4) {
-                const f32x4 a = Vec4<T>::load(p + i), d = Vec4<T>::load(g + i);
-                accum(a.x, d.x); accum(a.y, d.y); accum(a.z, d.z); accum(a.w, d.w);
-            }
-        } else {
+    if ((HW & 3) == 0) {
+        const int nv = HW >> 2, total = (b1 - b0) * nv;
+        for (int i = threadIdx.x; i < total; i += kBnThreads) {
+            const int bi = i / nv, vi = i - bi * nv;
+            const int64_t off = ((int64_t)(b0 + bi) * C + c) * HW + vi * 4;
+            const f32x4 a = Vec4<T>::load(x + off), d = Vec4<T>::load(dy + off);
+            accum(a.x, d.x); accum(a.y, d.y); accum(a.z, d.z); accum(a.w, d.w);
+        }
+    } else {
+        for (int b = b0; b < b1; ++b) {
+            const T *p = x + ((int64_t)b * C + c) * HW;
+            const T *g = dy + ((int64_t)b * C + c) * HW;
             for (int i = threadIdx.x; i < HW; i += kBnThreads) accum(load_f(p + i), load_f(g + i));
         }
     }
@@ -287,6 +347,19 @@ int dfine_bn_act_fwd(const void *x, void *y, const float *gamma, const float *be
         if (!running_mean || !running_var) return DFINE_E_BADARG;
         hipLaunchKernelGGL(bn_fold_kernel, dim3(cb), dim3(128), 0, st, C, gamma, beta, running_mean, running_var, eps, scale, shift);
     }
+    if ((HW & 3) == 0 && C <= 4096) {
+        const int64_t nvec = (int64_t)B * C * HW / 4;
+        int64_t nb = (nvec + kBnThreads * 4 - 1) / (kBnThreads * 4);
+        if (nb > 4096) nb = 4096;
+        const size_t sm = sizeof(float) * 2 * C;
+        if (dtype == DFINE_F32)
+            hipLaunchKernelGGL(bn_apply_flat_kernel<float>, dim3((unsigned)nb), dim3(kBnThreads), sm, st, (const float *)x, (float *)y,
+                               scale, shift, lab_scale, lab_bias, C, HW, nvec, act);
+        else
+            hipLaunchKernelGGL(bn_apply_flat_kernel<uint16_t>, dim3((unsigned)nb), dim3(kBnThreads), sm, st, (const uint16_t *)x,
+                               (uint16_t *)y, scale, shift, lab_scale, lab_bias, C, HW, nvec, act);
+        return check_launch();
+    }
     dim3 grid(B * C, (HW + kBnThreads * 16 - 1) / (kBnThreads * 16));
     if (dtype == DFINE_F32)
         hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(kBnThreads), 0, st, (const float *)x, (float *)y, scale, shift, lab_scale, lab_bias, C, HW, act);
@@ -316,6 +389,21 @@ int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_
                            lab_scale, C, HW, B, per, act);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, ws, nchunk, C, (double)B * HW,
                        dgamma, dbeta, dlab, coef);
+    if ((HW & 3) == 0 && C <= 2048) {
+        const int64_t nvec = (int64_t)B * C * HW / 4;
+        int64_t nb = (nvec + kBnThreads * 4 - 1) / (kBnThreads * 4);
+        if (nb > 4096) nb = 4096;
+        const size_t sm = sizeof(float) * 6 * C;
+        if (dtype == DFINE_F32)
+            hipLaunchKernelGGL(bn_bwd_apply_flat_kernel<float>, dim3((unsigned)nb), dim3(kBnThreads), sm, st, (const float *)x,
+                               (const float *)dy, (float *)dx, save_mean, save_invstd, scale, shift, lab_scale, coef, C, HW, nvec,
+                               act, training);
+        else
+            hipLaunchKernelGGL(bn_bwd_apply_flat_kernel<uint16_t>, dim3((unsigned)nb), dim3(kBnThreads), sm, st, (const uint16_t *)x,
+                               (const uint16_t *)dy, (uint16_t *)dx, save_mean, save_invstd, scale, shift, lab_scale, coef, C, HW,
+                               nvec, act, training);
+        return check_launch();
+    }
     dim3 grid(B * C, (HW + kBnThreads * 16 - 1) / (kBnThreads * 16));
     if (dtype == DFINE_F32)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(kBnThreads), 0, st, (const float *)x, (const float *)dy, (float *)dx,

@@ -536,10 +536,8 @@ class DFINETransformer(nn.Module):
 
     def _topk_indices(self, outputs_logits, topk: int):
         if self.query_select_method == "default":
-            return kernels.topk_anchors(outputs_logits, topk)
-        if self.query_select_method == "default":
-            score = outputs_logits.max(-1).values
-        elif self.query_select_method == "one2many":
+            return kernels.topk_anchors(outputs_logits, topk)      # max over classes + top-k, fused
+        if self.query_select_method == "one2many":
             score = outputs_logits.flatten(1)
         else:
             score = outputs_logits.squeeze(-1)
