@@ -36,8 +36,9 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for layer in self.layers[:-1]:
-            x = self.act(layer(x))
-        return self.layers[-1](x)
+            x = self.act(kernels.linear(x, layer.weight, layer.bias))
+        last = self.layers[-1]
+        return kernels.linear(x, last.weight, last.bias)
 
 
 class MSDeformableAttention(nn.Module):
@@ -83,8 +84,10 @@ class MSDeformableAttention(nn.Module):
         value [B, sum(HW), heads, head_dim] (native) or the reference's per-level list."""
         bs, lq = query.shape[:2]
         npts = sum(self.num_points_list)
-        offsets = self.sampling_offsets(query).reshape(bs, lq, self.num_heads, npts, 2)
-        logits = self.attention_weights(query).reshape(bs, lq, self.num_heads, npts)
+        offsets = kernels.linear(query, self.sampling_offsets.weight, self.sampling_offsets.bias).reshape(
+            bs, lq, self.num_heads, npts, 2)
+        logits = kernels.linear(query, self.attention_weights.weight, self.attention_weights.bias).reshape(
+            bs, lq, self.num_heads, npts)
         if isinstance(value, (list, tuple)):
             value = torch.cat(list(value), dim=-1).permute(0, 3, 1, 2).contiguous()
 
@@ -116,7 +119,8 @@ class Gate(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, x1, x2):
-        g1, g2 = torch.sigmoid(self.gate(torch.cat([x1, x2], dim=-1))).chunk(2, dim=-1)
+        g1, g2 = torch.sigmoid(kernels.linear(torch.cat([x1, x2], dim=-1), self.gate.weight,
+                                              self.gate.bias)).chunk(2, dim=-1)
         return self.norm(g1 * x1 + g2 * x2)
 
 
@@ -151,7 +155,8 @@ class TransformerDecoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, tgt):
-        return self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        h = self.dropout3(self.activation(kernels.linear(tgt, self.linear1.weight, self.linear1.bias)))
+        return kernels.linear(h, self.linear2.weight, self.linear2.bias)
 
     def forward(self, target, reference_points, value, spatial_shapes, attn_mask=None,
                 query_pos_embed=None):
@@ -297,7 +302,7 @@ class TransformerDecoder(nn.Module):
             if i == 0:
                 # classic sigmoid-space box head on the first layer seeds the FDR reference
                 pre_bboxes = F.sigmoid(pre_bbox_head(out) + inverse_sigmoid(ref_detach))
-                pre_scores = score_head[0](out)
+                pre_scores = kernels.linear(out, score_head[0].weight, score_head[0].bias)
                 ref_initial = pre_bboxes.detach()
 
             # FDR: residual update of the edge distributions, decoded around the initial box
@@ -312,7 +317,8 @@ class TransformerDecoder(nn.Module):
 
             if self.training or i == self.eval_idx:
                 if fused:
-                    scores = score_head[i](out) + self.lqe_layers[i].reg_conf(stat)
+                    scores = kernels.linear(out, score_head[i].weight, score_head[i].bias) \
+                        + self.lqe_layers[i].reg_conf(stat)
                 else:
                     scores = self.lqe_layers[i](score_head[i](out), pred_corners)
                 logits.append(scores)

@@ -205,7 +205,8 @@ class TransformerEncoderLayer(nn.Module):
         if not self.normalize_before:
             src = self.norm1(src)
         x = self.norm2(src) if self.normalize_before else src
-        x = self.linear2(self.dropout(self.activation(self.linear1(x))))
+        x = kernels.linear(self.dropout(self.activation(kernels.linear(x, self.linear1.weight, self.linear1.bias))),
+                           self.linear2.weight, self.linear2.bias)
         src = src + self.dropout2(x)
         return src if self.normalize_before else self.norm2(src)
 

@@ -165,6 +165,8 @@ class TrainStep:
         self._graphed, self._calls, self._graph_shape = None, 0, None
 
     def optimizer_step(self, step_scheduler=True):
+        from .. import kernels
+        kernels.flush_bn_counters()
         if self.fused is not None:
             self.fused.step()
             if step_scheduler and self.scheduler is not None:
@@ -204,6 +206,9 @@ class TrainStep:
     def __call__(self, images, targets):
         dev_type = images.device.type
         self._calls += 1
+        if images.is_cuda:
+            from .. import kernels
+            kernels.defer_bn_counters(True)      # one multi-tensor add per step instead of 133 scalar adds
         if self.amp_dtype is not None:
             with torch.autocast(dev_type, dtype=self.amp_dtype, cache_enabled=not self.hip_graph):
                 outputs = self._forward(images, targets)

@@ -451,7 +451,11 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
         if isinstance(bn, nn.BatchNorm2d) and bn.track_running_stats and bn.momentum is not None:
             training = bn.training
             if training:
-                bn.num_batches_tracked.add_(1)
+                if _BN_DEFER:
+                    ent = _BN_PENDING.get(id(bn))
+                    _BN_PENDING[id(bn)] = (bn.num_batches_tracked, 1 if ent is None else ent[1] + 1)
+                else:
+                    bn.num_batches_tracked.add_(1)
             return _BNAct.apply(y, bn.weight, bn.bias, lab.scale if lab is not None else None,
                                 lab.bias if lab is not None else None, bn.running_mean, bn.running_var,
                                 a, training, bn.momentum, bn.eps)
@@ -478,17 +482,84 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
     return y
 
 
+class _LinearSplitK(torch.autograd.Function):
+    """y = x W^T + b for x [B, L, K] with B*L >> N*K (every decoder / encoder linear: 15 744 rows
+    against <= 1024 x 1024 weights).  The weight gradient dW = dY^T X is a GEMM with a tiny output and
+    a 15 744-long reduction; as one `mm` hipBLASLt runs it on <= 16 workgroups (91 us whatever the
+    size - 57 calls, 5.2 ms per D-FINE-m step).  Here it is a batched GEMM over the B images (split-K:
+    B x more tiles) followed by a sum over the batch.  [ATen plumbing: hipBLASLt GEMMs]"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
+        xc = x if x.dtype == dt else x.to(dt)
+        wc = weight if weight.dtype == dt else weight.to(dt)
+        bc = None if bias is None else (bias if bias.dtype == dt else bias.to(dt))
+        ctx.save_for_backward(xc, wc)
+        ctx.meta = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        return F.linear(xc, wc, bc)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wc = ctx.saved_tensors
+        xdt, wdt, bdt = ctx.meta
+        dy = dy if dy.dtype == xc.dtype else dy.to(xc.dtype)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.matmul(dy, wc)
+            dx = dx if dx.dtype == xdt else dx.to(xdt)
+        if ctx.needs_input_grad[1]:
+            b = xc.shape[0]
+            dw = torch.bmm(dy.reshape(b, -1, dy.shape[-1]).transpose(1, 2), xc.reshape(b, -1, xc.shape[-1])).sum(0, dtype=torch.float32)
+            dw = dw if dw.dtype == wdt else dw.to(wdt)
+        if bdt is not None and ctx.needs_input_grad[2]:
+            db = dy.reshape(-1, dy.shape[-1]).sum(0, dtype=torch.float32)
+            db = db if db.dtype == bdt else db.to(bdt)
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    """nn.Linear forward for the [B, L, K] activations of the decoder / encoder token streams."""
+    if x.is_cuda and x.dim() == 3 and x.shape[0] > 1 and x.shape[0] * x.shape[1] >= 4096 \
+            and os.environ.get("DFINE_SPLITK_LINEAR", "1") == "1" and torch.is_grad_enabled():
+        return _LinearSplitK.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
+# BatchNorm bookkeeping: nn.BatchNorm2d bumps `num_batches_tracked` (an int64 device scalar) every forward -
+# 133 tiny launches per step.  A train loop may defer them and flush once per step with one multi-tensor add.
+_BN_DEFER = False
+_BN_PENDING = {}
+
+
+def defer_bn_counters(flag=True):
+    global _BN_DEFER
+    _BN_DEFER = flag
+
+
+def flush_bn_counters():
+    if _BN_PENDING:
+        bufs = [b for b, _ in _BN_PENDING.values()]
+        counts = [n for _, n in _BN_PENDING.values()]
+        if len(set(counts)) == 1:
+            torch._foreach_add_(bufs, counts[0])
+        else:
+            for b, n in zip(bufs, counts):
+                b.add_(n)
+        _BN_PENDING.clear()
+
+
 def self_attention(qk, value, in_w, in_b, out_w, out_b, num_heads: int, attn_mask=None):
     """Packed-QKV multi-head attention, q = k = `qk` (content+position), v = `value`;
     boolean `attn_mask` [L, L], True = blocked.  [ATen plumbing: GEMM + SDPA]"""
     b, l, e = qk.shape
     hd = e // num_heads
-    q, k = F.linear(qk, in_w[: 2 * e], in_b[: 2 * e]).chunk(2, dim=-1)
-    v = F.linear(value, in_w[2 * e:], in_b[2 * e:])
+    q, k = linear(qk, in_w[: 2 * e], in_b[: 2 * e]).chunk(2, dim=-1)
+    v = linear(value, in_w[2 * e:], in_b[2 * e:])
     q, k, v = (t.reshape(b, l, num_heads, hd).transpose(1, 2) for t in (q, k, v))
     mask = None if attn_mask is None else ~attn_mask
     o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
-    return F.linear(o.transpose(1, 2).reshape(b, l, e), out_w, out_b)
+    return linear(o.transpose(1, 2).reshape(b, l, e), out_w, out_b)
 
 
 def topk_anchors(logits: torch.Tensor, k: int) -> torch.Tensor:
