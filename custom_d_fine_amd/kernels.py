@@ -497,7 +497,15 @@ class _LinearSplitK(torch.autograd.Function):
         bc = None if bias is None else (bias if bias.dtype == dt else bias.to(dt))
         ctx.save_for_backward(xc, wc)
         ctx.meta = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
-        return F.linear(xc, wc, bc)
+        # write into a fresh base tensor: F.linear on 3-d input returns a VIEW of its 2-d result, which
+        # autograd refuses to let callers modify in place (ReLU(inplace=True) in the MLP heads)
+        out = torch.empty(*xc.shape[:-1], wc.shape[0], device=xc.device, dtype=dt)
+        x2d = xc.reshape(-1, xc.shape[-1])
+        if bc is None:
+            torch.mm(x2d, wc.t(), out=out.view(-1, wc.shape[0]))
+        else:
+            torch.addmm(bc, x2d, wc.t(), out=out.view(-1, wc.shape[0]))
+        return out
 
     @staticmethod
     def backward(ctx, dy):
