@@ -529,7 +529,7 @@ class _LinearSplitK(torch.autograd.Function):
 def linear(x, weight, bias=None):
     """nn.Linear forward for the [B, L, K] activations of the decoder / encoder token streams."""
     if x.is_cuda and x.dim() == 3 and x.shape[0] > 1 and x.shape[0] * x.shape[1] >= 4096 \
-            and os.environ.get("DFINE_SPLITK_LINEAR", "1") == "1" and torch.is_grad_enabled():
+            and os.environ.get("DFINE_SPLITK_LINEAR", "0") == "1" and torch.is_grad_enabled():
         return _LinearSplitK.apply(x, weight, bias)
     return F.linear(x, weight, bias)
 
