@@ -308,6 +308,87 @@ __global__ void conv_wgrad_reduce_kernel(const float *__restrict__ part, float *
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of a token-stream linear layer: dW[n][k] = sum_m dY[m][n] * X[m][k] with ROW-major
+// activations X [M, K], dY [M, N] (M = B*Lq = 15 744 rows, N, K <= 1024).  A GEMM with a tiny output and
+// a very long reduction: as a single hipBLASLt `mm` it occupies <= 16 workgroups (91 us per call, 57 calls
+// per D-FINE-m step).  Here the reduction is split over `splits` blocks per 64 x 64 output tile.
+// The reduction index is the ROW index of both operands, so MFMA fragments (8 consecutive m per lane) are
+// columns of the staged tiles: read from LDS with 16-bit loads (row pitch 66 elements -> the 4 row groups of
+// a wave hit different banks).  LDS-read bound at ~20 % of the MFMA rate, far above what 2 GFLOP needs.
+__global__ __launch_bounds__(kConvThreads) void linear_wgrad_kernel(const uint16_t *__restrict__ x,
+                                                                    const uint16_t *__restrict__ dy,
+                                                                    float *__restrict__ part, int M, int N, int K,
+                                                                    int rows_per_split, int nct64, int NP16, int CP16) {
+    constexpr int PITCH = 66;
+    __shared__ __attribute__((aligned(16))) uint16_t s_dy[32 * PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t s_x[32 * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt64 = blockIdx.x / nct64, ct64 = blockIdx.x - nt64 * nct64;
+    const int n0 = nt64 * 64, k0 = ct64 * 64;
+    const int m_begin = blockIdx.y * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+    f32x4v acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const bool wave_active = n0 + wave * 16 < N;
+    // staging role: thread -> (tile, row, 8-element chunk)
+    const int st_tile = tid >> 7, st_row = (tid >> 2) & 31, st_chunk = tid & 3;       // 2 chunks of 8 per thread
+    for (int m0 = m_begin; m0 < m_end; m0 += 32) {
+        {
+            const int m = m0 + st_row;
+            const uint16_t *src = st_tile == 0 ? dy + (int64_t)m * N + n0 : x + (int64_t)m * K + k0;
+            const int width = st_tile == 0 ? N - n0 : K - k0;
+            uint16_t *dst = (st_tile == 0 ? s_dy : s_x) + st_row * PITCH;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int col = (st_chunk + 4 * h) * 8;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                const bool vec_ok = ((st_tile == 0 ? N : K) & 7) == 0;          // rows 16-byte aligned
+                if (m < m_end && vec_ok && col + 8 <= width) v = *reinterpret_cast<const uint4 *>(src + col);
+                else if (m < m_end && col < width) {      // odd widths (132, 20, 4, 1 ...): element loads
+                    uint16_t tmp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (int e = 0; e < min(8, width - col); ++e) tmp[e] = src[col + e];
+                    v = *reinterpret_cast<uint4 *>(tmp);
+                }
+                uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + col);      // pitch 66 -> 4-byte aligned only
+                d32[0] = v.x; d32[1] = v.y; d32[2] = v.z; d32[3] = v.w;
+            }
+        }
+        __syncthreads();
+        if (wave_active) {
+            const int g = lane >> 4, i = lane & 15;
+            uint32_t a32[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                a32[t] = (uint32_t)s_dy[(8 * g + 2 * t) * PITCH + wave * 16 + i] |
+                         ((uint32_t)s_dy[(8 * g + 2 * t + 1) * PITCH + wave * 16 + i] << 16);
+            const bf16x8 a = __builtin_bit_cast(bf16x8, make_uint4(a32[0], a32[1], a32[2], a32[3]));
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                if (k0 + ct * 16 >= K) continue;
+                uint32_t b32[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    b32[t] = (uint32_t)s_x[(8 * g + 2 * t) * PITCH + ct * 16 + i] |
+                             ((uint32_t)s_x[(8 * g + 2 * t + 1) * PITCH + ct * 16 + i] << 16);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, make_uint4(b32[0], b32[1], b32[2], b32[3])),
+                                                                  acc[ct], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int c = k0 + ct * 16 + (lane & 15);
+        if (c >= CP16) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wave * 16 + 4 * (lane >> 4) + r;
+            if (n < NP16) part[((int64_t)blockIdx.y * NP16 + n) * CP16 + c] = acc[ct][r];
+        }
+    }
+}
+
 static void wgrad_plan(int B, int Cin, int Cout, int H, int W, int KS, int *R, int *strips, int *splits, int *ups) {
     *R = 160 / W < 1 ? 1 : 160 / W;
     if (*R > H) *R = H;
@@ -451,6 +532,43 @@ int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, i
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, splits, Cout, Cin, KS * KS,
                        np16, cp16);
+    return check_launch();
+}
+
+static void linear_wgrad_plan(int M, int N, int K, int *splits, int *rows) {
+    const int pairs = ((N + 63) / 64) * ((K + 63) / 64);
+    int sp = 1024 / pairs;
+    if (sp < 1) sp = 1;
+    if (sp > 128) sp = 128;
+    int r = ((M + sp - 1) / sp + 31) / 32 * 32;
+    if (r < 32) r = 32;
+    *rows = r;
+    *splits = (M + r - 1) / r;
+}
+
+int64_t dfine_linear_wgrad_ws_floats(int M, int N, int K) {
+    int splits, rows;
+    linear_wgrad_plan(M, N, K, &splits, &rows);
+    return (int64_t)splits * ((N + 15) / 16 * 16) * ((K + 15) / 16 * 16);
+}
+
+// dw [N, K] f32 (overwritten) = dy[M, N]^T x[M, K]; x, dy row-major bf16 (16-byte loads when the row length is a
+// multiple of 8, element loads otherwise).
+int dfine_linear_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, int M, int N, int K, void *stream) {
+    if (M == 0) return DFINE_OK;
+    if (!x || !dy || !dw || !ws || M < 1 || N < 1 || K < 1) return DFINE_E_BADARG;
+    int splits, rows;
+    linear_wgrad_plan(M, N, K, &splits, &rows);
+    const int nnt64 = (N + 63) / 64, nct64 = (K + 63) / 64;
+    const int np16 = (N + 15) / 16 * 16, cp16 = (K + 15) / 16 * 16;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(linear_wgrad_kernel, dim3(nnt64 * nct64, splits), dim3(kConvThreads), 0, st, (const uint16_t *)x,
+                       (const uint16_t *)dy, ws, M, N, K, rows, nct64, np16, cp16);
+    if (int e = check_launch()) return e;
+    const int64_t total = (int64_t)N * K;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, splits, N, K, 1, np16, cp16);
     return check_launch();
 }
 

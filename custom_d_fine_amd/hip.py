@@ -53,6 +53,8 @@ _SIGNATURES = {
     "dfine_fdr_fwd": (c_int, [_P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_fdr_bwd": (c_int, [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_topk_anchors": (c_int, [_P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfine_linear_wgrad_ws_floats": (_L, [_I, _I, _I]),
+    "dfine_linear_wgrad_bf16": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "dfine_bn_act_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 for _name, (_res, _args) in _SIGNATURES.items():
@@ -479,3 +481,25 @@ def topk_anchors(logits, k, with_scores=False):
     _check(_lib.dfine_topk_anchors(_ptr(logits), logits.stride(0), logits.stride(1), _ptr(idx), _ptr(sc),
                                    _dtype_code(logits), B, Q, C, k, _stream()), "dfine_topk_anchors")
     return (idx, sc) if with_scores else idx
+
+
+# ------------------------------------------------------------------------------------- linear wgrad
+_LW_WS = {}
+
+
+def linear_wgrad_bf16(x2d, dy2d):
+    """x2d [M, K], dy2d [M, N] bf16 contiguous -> dw [N, K] f32 = dy2d^T x2d."""
+    M, K = x2d.shape
+    N = dy2d.shape[1]
+    dev = x2d.device
+    need = int(_lib.dfine_linear_wgrad_ws_floats(M, N, K))
+    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    ws = _LW_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), device=dev, dtype=torch.float32)
+        _LW_WS[key] = ws
+    dw = torch.empty(N, K, device=dev, dtype=torch.float32)
+    with _timed("dfine_linear_wgrad_bf16"):
+        _check(_lib.dfine_linear_wgrad_bf16(_ptr(x2d), _ptr(dy2d), _ptr(dw), _ptr(ws), M, N, K, _stream()),
+               "dfine_linear_wgrad_bf16")
+    return dw

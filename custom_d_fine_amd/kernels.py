@@ -486,8 +486,9 @@ class _LinearSplitK(torch.autograd.Function):
     """y = x W^T + b for x [B, L, K] with B*L >> N*K (every decoder / encoder linear: 15 744 rows
     against <= 1024 x 1024 weights).  The weight gradient dW = dY^T X is a GEMM with a tiny output and
     a 15 744-long reduction; as one `mm` hipBLASLt runs it on <= 16 workgroups (91 us whatever the
-    size - 57 calls, 5.2 ms per D-FINE-m step).  Here it is a batched GEMM over the B images (split-K:
-    B x more tiles) followed by a sum over the batch.  [ATen plumbing: hipBLASLt GEMMs]"""
+    size - 57 calls, 5.2 ms per D-FINE-m step; torch.bmm split over the batch is 3x faster on the device
+    but costs 0.6 ms of HOST time per call in hipBLASLt's heuristics).  Here: the HIP split-K kernel
+    linear_wgrad_kernel (conv.hip).  Forward and dX stay hipBLASLt GEMMs [ATen plumbing]."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -517,8 +518,11 @@ class _LinearSplitK(torch.autograd.Function):
             dx = torch.matmul(dy, wc)
             dx = dx if dx.dtype == xdt else dx.to(xdt)
         if ctx.needs_input_grad[1]:
-            b = xc.shape[0]
-            dw = torch.bmm(dy.reshape(b, -1, dy.shape[-1]).transpose(1, 2), xc.reshape(b, -1, xc.shape[-1])).sum(0, dtype=torch.float32)
+            if xc.dtype == torch.bfloat16:      # HIP split-K MFMA kernel on the row-major operands
+                dw = _hip().linear_wgrad_bf16(xc.reshape(-1, xc.shape[-1]).contiguous(),
+                                              dy.reshape(-1, dy.shape[-1]).contiguous())
+            else:
+                dw = torch.matmul(dy.reshape(-1, dy.shape[-1]).t(), xc.reshape(-1, xc.shape[-1]))
             dw = dw if dw.dtype == wdt else dw.to(wdt)
         if bdt is not None and ctx.needs_input_grad[2]:
             db = dy.reshape(-1, dy.shape[-1]).sum(0, dtype=torch.float32)
@@ -529,7 +533,7 @@ class _LinearSplitK(torch.autograd.Function):
 def linear(x, weight, bias=None):
     """nn.Linear forward for the [B, L, K] activations of the decoder / encoder token streams."""
     if x.is_cuda and x.dim() == 3 and x.shape[0] > 1 and x.shape[0] * x.shape[1] >= 4096 \
-            and os.environ.get("DFINE_SPLITK_LINEAR", "0") == "1" and torch.is_grad_enabled():
+            and os.environ.get("DFINE_SPLITK_LINEAR", "1") == "1" and torch.is_grad_enabled():
         return _LinearSplitK.apply(x, weight, bias)
     return F.linear(x, weight, bias)
 

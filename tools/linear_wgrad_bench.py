@@ -9,7 +9,7 @@ def t(fn, n=20):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
-for (N, K) in ((256, 256), (1024, 256), (256, 1024), (80, 256), (512, 512)):
+for (N, K) in ((256, 256), (1024, 256), (256, 1024), (80, 256), (512, 512), (132, 256), (512, 4), (64, 20), (1, 64)):
     B, L = 32, 492
     x = torch.randn(B, L, K, device=dev, dtype=torch.bfloat16)
     dy = torch.randn(B, L, N, device=dev, dtype=torch.bfloat16)
@@ -22,5 +22,18 @@ for (N, K) in ((256, 256), (1024, 256), (256, 1024), (80, 256), (512, 512)):
     c = t(hipw)
     err = (hipw().view(N, K) - ref).abs().max().item() / ref.abs().max().item()
     # split via mm on chunks stacked (einsum)
-    d = t(lambda: torch.einsum("bln,blk->nk", dy, x))
-    print(f"N={N:4d} K={K:4d}: mm {a:7.1f} us | bmm+sum {b:7.1f} us | transpose+HIP split-K {c:7.1f} us (rel err {err:.1e}) | einsum {d:7.1f} us")
+    d = t(lambda: hip.linear_wgrad_bf16(x.reshape(-1, K), dy.reshape(-1, N)))
+    err2 = (hip.linear_wgrad_bf16(x.reshape(-1, K), dy.reshape(-1, N)) - ref).abs().max().item() / ref.abs().max().item()
+    print(f"N={N:4d} K={K:4d}: mm {a:7.1f} us | bmm+sum {b:7.1f} us | transpose+HIP split-K {c:7.1f} us (rel err {err:.1e}) | HIP row-major split-K {d:7.1f} us (rel err {err2:.1e})")
+
+print("forward variants")
+import torch.nn.functional as F
+for (N, K) in ((1024, 256), (256, 1024), (256, 256)):
+    x = torch.randn(32, 492, K, device=dev, dtype=torch.bfloat16)
+    w = torch.randn(N, K, device=dev, dtype=torch.bfloat16); b = torch.randn(N, device=dev, dtype=torch.bfloat16)
+    out = torch.empty(32, 492, N, device=dev, dtype=torch.bfloat16)
+    a = t(lambda: F.linear(x, w, b))
+    c = t(lambda: torch.addmm(b, x.reshape(-1, K), w.t(), out=out.view(-1, N)))
+    d = t(lambda: torch.addmm(b, x.reshape(-1, K), w.t()))
+    e = t(lambda: torch.matmul(torch.randn(32, 492, N, device=dev, dtype=torch.bfloat16), w))
+    print(f"N={N} K={K}: F.linear {a:.1f} us | addmm(out=) {c:.1f} us | addmm {d:.1f} us | dx matmul(+randn) {e:.1f} us")
