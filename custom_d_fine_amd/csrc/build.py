@@ -19,6 +19,7 @@ SOURCES = {
     "bnact.hip": ["-munsafe-fp-atomics"],
     "losses.hip": ["-munsafe-fp-atomics"],
     "optim.hip": ["-munsafe-fp-atomics"],
+    "conv.hip": ["-munsafe-fp-atomics"],
 }
 
 

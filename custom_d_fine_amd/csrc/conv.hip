@@ -318,8 +318,9 @@ __global__ void conv_wgrad_reduce_kernel(const float *__restrict__ part, float *
 // a wave hit different banks).  LDS-read bound at ~20 % of the MFMA rate, far above what 2 GFLOP needs.
 __global__ __launch_bounds__(kConvThreads) void linear_wgrad_kernel(const uint16_t *__restrict__ x,
                                                                     const uint16_t *__restrict__ dy,
-                                                                    float *__restrict__ part, int M, int N, int K,
-                                                                    int rows_per_split, int nct64, int NP16, int CP16) {
+                                                                    float *__restrict__ part, float *__restrict__ db,
+                                                                    int M, int N, int K, int rows_per_split, int nct64,
+                                                                    int NP16, int CP16) {
     constexpr int PITCH = 66;
     __shared__ __attribute__((aligned(16))) uint16_t s_dy[32 * PITCH];
     __shared__ __attribute__((aligned(16))) uint16_t s_x[32 * PITCH];
@@ -330,6 +331,8 @@ __global__ __launch_bounds__(kConvThreads) void linear_wgrad_kernel(const uint16
     f32x4v acc[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    f32x4v acc_b = f32x4v{0.f, 0.f, 0.f, 0.f};        // bias gradient: dY^T * ones (one extra MFMA per k-step)
+    const bool want_db = db != nullptr && ct64 == 0;
     const bool wave_active = n0 + wave * 16 < N;
     // staging role: thread -> (tile, row, 8-element chunk)
     const int st_tile = tid >> 7, st_row = (tid >> 2) & 31, st_chunk = tid & 3;       // 2 chunks of 8 per thread
@@ -363,6 +366,9 @@ __global__ __launch_bounds__(kConvThreads) void linear_wgrad_kernel(const uint16
                 a32[t] = (uint32_t)s_dy[(8 * g + 2 * t) * PITCH + wave * 16 + i] |
                          ((uint32_t)s_dy[(8 * g + 2 * t + 1) * PITCH + wave * 16 + i] << 16);
             const bf16x8 a = __builtin_bit_cast(bf16x8, make_uint4(a32[0], a32[1], a32[2], a32[3]));
+            if (want_db)
+                acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    a, __builtin_bit_cast(bf16x8, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u)), acc_b, 0, 0, 0);
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 if (k0 + ct * 16 >= K) continue;
@@ -385,6 +391,13 @@ __global__ __launch_bounds__(kConvThreads) void linear_wgrad_kernel(const uint16
         for (int r = 0; r < 4; ++r) {
             const int n = n0 + wave * 16 + 4 * (lane >> 4) + r;
             if (n < NP16) part[((int64_t)blockIdx.y * NP16 + n) * CP16 + c] = acc[ct][r];
+        }
+    }
+    if (want_db && wave_active && (lane & 15) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wave * 16 + 4 * (lane >> 4) + r;
+            if (n < N) unsafeAtomicAdd(db + n, acc_b[r]);
         }
     }
 }
@@ -552,9 +565,10 @@ int64_t dfine_linear_wgrad_ws_floats(int M, int N, int K) {
     return (int64_t)splits * ((N + 15) / 16 * 16) * ((K + 15) / 16 * 16);
 }
 
-// dw [N, K] f32 (overwritten) = dy[M, N]^T x[M, K]; x, dy row-major bf16 (16-byte loads when the row length is a
+// dw [N, K] f32 (overwritten) = dy[M, N]^T x[M, K]; db [N] f32 (overwritten, may be NULL) = column sums of dy; x, dy row-major bf16 (16-byte loads when the row length is a
 // multiple of 8, element loads otherwise).
-int dfine_linear_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, int M, int N, int K, void *stream) {
+int dfine_linear_wgrad_bf16(const void *x, const void *dy, float *dw, float *db, float *ws, int M, int N, int K,
+                            void *stream) {
     if (M == 0) return DFINE_OK;
     if (!x || !dy || !dw || !ws || M < 1 || N < 1 || K < 1) return DFINE_E_BADARG;
     int splits, rows;
@@ -562,8 +576,9 @@ int dfine_linear_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws,
     const int nnt64 = (N + 63) / 64, nct64 = (K + 63) / 64;
     const int np16 = (N + 15) / 16 * 16, cp16 = (K + 15) / 16 * 16;
     hipStream_t st = (hipStream_t)stream;
+    if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)N, st);
     hipLaunchKernelGGL(linear_wgrad_kernel, dim3(nnt64 * nct64, splits), dim3(kConvThreads), 0, st, (const uint16_t *)x,
-                       (const uint16_t *)dy, ws, M, N, K, rows, nct64, np16, cp16);
+                       (const uint16_t *)dy, ws, db, M, N, K, rows, nct64, np16, cp16);
     if (int e = check_launch()) return e;
     const int64_t total = (int64_t)N * K;
     int blocks = (int)((total + 255) / 256);

@@ -54,7 +54,7 @@ _SIGNATURES = {
     "dfine_fdr_bwd": (c_int, [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_topk_anchors": (c_int, [_P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfine_linear_wgrad_ws_floats": (_L, [_I, _I, _I]),
-    "dfine_linear_wgrad_bf16": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "dfine_linear_wgrad_bf16": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dfine_bn_act_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 for _name, (_res, _args) in _SIGNATURES.items():
@@ -487,8 +487,8 @@ def topk_anchors(logits, k, with_scores=False):
 _LW_WS = {}
 
 
-def linear_wgrad_bf16(x2d, dy2d):
-    """x2d [M, K], dy2d [M, N] bf16 contiguous -> dw [N, K] f32 = dy2d^T x2d."""
+def linear_wgrad_bf16(x2d, dy2d, with_bias=False):
+    """x2d [M, K], dy2d [M, N] bf16 contiguous -> dw [N, K] f32 = dy2d^T x2d (, db [N] f32 = column sums)."""
     M, K = x2d.shape
     N = dy2d.shape[1]
     dev = x2d.device
@@ -499,7 +499,8 @@ def linear_wgrad_bf16(x2d, dy2d):
         ws = torch.empty(max(need, 1 << 20), device=dev, dtype=torch.float32)
         _LW_WS[key] = ws
     dw = torch.empty(N, K, device=dev, dtype=torch.float32)
+    db = torch.empty(N, device=dev, dtype=torch.float32) if with_bias else None
     with _timed("dfine_linear_wgrad_bf16"):
-        _check(_lib.dfine_linear_wgrad_bf16(_ptr(x2d), _ptr(dy2d), _ptr(dw), _ptr(ws), M, N, K, _stream()),
+        _check(_lib.dfine_linear_wgrad_bf16(_ptr(x2d), _ptr(dy2d), _ptr(dw), _ptr(db), _ptr(ws), M, N, K, _stream()),
                "dfine_linear_wgrad_bf16")
-    return dw
+    return (dw, db) if with_bias else dw

@@ -517,14 +517,21 @@ class _LinearSplitK(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.matmul(dy, wc)
             dx = dx if dx.dtype == xdt else dx.to(xdt)
+        want_db = bdt is not None and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if xc.dtype == torch.bfloat16:      # HIP split-K MFMA kernel on the row-major operands
-                dw = _hip().linear_wgrad_bf16(xc.reshape(-1, xc.shape[-1]).contiguous(),
-                                              dy.reshape(-1, dy.shape[-1]).contiguous())
+                res = _hip().linear_wgrad_bf16(xc.reshape(-1, xc.shape[-1]).contiguous(),
+                                               dy.reshape(-1, dy.shape[-1]).contiguous(), with_bias=want_db)
+                if want_db:                     # bias gradient comes out of the same kernel
+                    dw, db = res
+                    db = db if db.dtype == bdt else db.to(bdt)
+                    want_db = False
+                else:
+                    dw = res
             else:
                 dw = torch.matmul(dy.reshape(-1, dy.shape[-1]).t(), xc.reshape(-1, xc.shape[-1]))
             dw = dw if dw.dtype == wdt else dw.to(wdt)
-        if bdt is not None and ctx.needs_input_grad[2]:
+        if want_db:
             db = dy.reshape(-1, dy.shape[-1]).sum(0, dtype=torch.float32)
             db = db if db.dtype == bdt else db.to(bdt)
         return dx, dw, db

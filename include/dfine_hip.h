@@ -261,11 +261,12 @@ int dfine_topk_anchors(const void *logits, int64_t sb, int64_t sq, int64_t *out_
  * A5/A6  Weight gradient of a token-stream nn.Linear: dw [N, K] f32 = dy [M, N]^T x [M, K] (bf16,
  * row-major; M = B*Lq rows), split over the M reduction (the autograd formula of F.linear used by
  * MLP / FFN / Gate / attention projections, src/d_fine/arch/dfine_decoder.py:33-46,214-271).
+ *   db [N] f32 or NULL: bias gradient (column sums of dy), produced by one extra MFMA per k-step.
  *   ws: dfine_linear_wgrad_ws_floats(M, N, K) floats.
  */
 int64_t dfine_linear_wgrad_ws_floats(int M, int N, int K);
-int dfine_linear_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, int M, int N, int K,
-                            void *stream);
+int dfine_linear_wgrad_bf16(const void *x, const void *dy, float *dw, float *db, float *ws, int M, int N,
+                            int K, void *stream);
 
 #ifdef __cplusplus
 }
