@@ -305,9 +305,12 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(
 }
 
 static int chunks_for(int B, int C, int HW, int *imgs_per_chunk) {
-    // aim at >= ~2048 blocks and <= 64K elements per block
+    // One block reduces `per` images of one channel.  Split the batch further only while the grid is still
+    // small (< 1024 blocks) AND a block keeps >= 8192 elements of work - thousands of tiny blocks are
+    // dominated by the block-reduce / partial-write tail (small planes: 20x20, 40x40).
     int per = B;
-    while (per > 1 && ((int64_t)C * ((B + per - 1) / per) < 2048 || (int64_t)per * HW > 65536)) per = (per + 1) / 2;
+    while (per > 1 && (int64_t)C * ((B + per - 1) / per) < 1024 && (int64_t)(per / 2) * HW >= 8192) per = (per + 1) / 2;
+    while (per > 1 && (int64_t)per * HW > 262144) per = (per + 1) / 2;
     *imgs_per_chunk = per;
     return (B + per - 1) / per;
 }
