@@ -71,7 +71,9 @@ template <> __device__ __forceinline__ void unpack<2>(const uint32_t &v, uint16_
 
 // x [B, Cin, H, W] bf16; w2 [KS*KS][NP][KP] bf16 (NP = Cout rounded up to 16, KP = Cin rounded up to 32);
 // y [B, Cout, H, W] bf16.  H*W, W describe the (possibly flattened, for 1x1) plane.
-template <int KS, int NTN, int VEC>
+// KC = number of 32-channel slabs staged per barrier pair: layers with many input channels are otherwise
+// bound by the (global load -> LDS -> barrier) latency of each 32-channel step, not by MFMA or HBM.
+template <int KS, int NTN, int VEC, int KC>
 __global__ __launch_bounds__(kConvThreads) void conv_igemm_kernel(
     const uint16_t *__restrict__ x, const uint16_t *__restrict__ w2, uint16_t *__restrict__ y, int Cin,
     int Cout, int NP, int KP, int H, int W, int R, int strips) {
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_igemm_kernel(
     const int WL = W + 2 * PAD, rows_l = R + 2 * PAD;
     const int npxl = rows_l * WL;
     uint32_t *lds32 = reinterpret_cast<uint32_t *>(lds);
-    for (int i = tid; i < npxl * 16; i += kConvThreads) lds32[i] = 0u;
+    for (int i = tid; i < npxl * 16 * KC; i += kConvThreads) lds32[i] = 0u;
 
     // per column-tile LDS byte offset of this lane's pixel (tap (0,0)) + its 16-byte channel group
     int pl[kMaxPixTiles];
@@ -109,14 +111,15 @@ __global__ __launch_bounds__(kConvThreads) void conv_igemm_kernel(
     const uint16_t *xb = x + (int64_t)b * Cin * H * W;
     __syncthreads();
 
-    for (int c0 = 0; c0 < KP; c0 += 32) {
-        // ---- stage the [32 channels] x [strip + halo] slab, transposed to [pixel][channel] -----
-        for (int it = tid; it < 16 * nvec; it += kConvThreads) {
-            const int pair = it & 15, v = it >> 4;
+    for (int c0 = 0; c0 < KP; c0 += 32 * KC) {
+        // ---- stage KC x [32 channels] x [strip + halo] slabs, each transposed to [pixel][channel] ----
+        for (int it = tid; it < 16 * nvec * KC; it += kConvThreads) {
+            const int pair = it & 15, vs = it >> 4;
+            const int slab = KC == 1 ? 0 : vs / nvec, v = KC == 1 ? vs : vs - slab * nvec;
             const int lr = v / nvec_row, xv = (v - lr * nvec_row) * VEC;
             const int gy = r0 - PAD + lr;
             if (gy < 0 || gy >= H) continue;                   // stays zero (never written)
-            const int ca = c0 + 2 * pair;
+            const int ca = c0 + 32 * slab + 2 * pair;
             uint16_t e0[VEC], e1[VEC];
             if (ca < Cin) {
                 unpack<VEC>(*reinterpret_cast<const typename PixVec<VEC>::type *>(xb + ((int64_t)ca * H + gy) * W + xv), e0);
@@ -130,31 +133,37 @@ __global__ __launch_bounds__(kConvThreads) void conv_igemm_kernel(
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) e1[i] = 0;
             }
-            uint32_t *dst = lds32 + (lr * WL + xv + PAD) * 16 + pair;
+            uint32_t *dst = lds32 + slab * npxl * 16 + (lr * WL + xv + PAD) * 16 + pair;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) dst[i * 16] = (uint32_t)e0[i] | ((uint32_t)e1[i] << 16);
         }
         __syncthreads();
-        // ---- MFMA over the taps ----------------------------------------------------------------
+        // ---- MFMA over the slabs and taps --------------------------------------------------------
 #pragma unroll
-        for (int tap = 0; tap < KS * KS; ++tap) {
-            const int toff = ((tap / KS) * WL + (tap % KS)) * 64;
-            bf16x8 a[NTN];
+        for (int slab = 0; slab < KC; ++slab) {
+            const int cs = c0 + 32 * slab;
+            if (KC > 1 && cs >= KP) break;
+            const unsigned char *slds = lds + slab * npxl * 64;
 #pragma unroll
-            for (int t = 0; t < NTN; ++t) {
-                const int n = n_wave + t * 16 + (lane & 15);
-                uint4 av = make_uint4(0, 0, 0, 0);
-                if (n < NP) av = *reinterpret_cast<const uint4 *>(w2 + ((int64_t)tap * NP + n) * KP + c0 + 8 * (lane >> 4));
-                a[t] = __builtin_bit_cast(bf16x8, av);
-            }
+            for (int tap = 0; tap < KS * KS; ++tap) {
+                const int toff = ((tap / KS) * WL + (tap % KS)) * 64;
+                bf16x8 a[NTN];
 #pragma unroll
-            for (int jt = 0; jt < kMaxPixTiles; ++jt) {
-                if (jt < ntile) {
-                    const uint4 bv = *reinterpret_cast<const uint4 *>(lds + pl[jt] + toff);
-                    const bf16x8 bf = __builtin_bit_cast(bf16x8, bv);
+                for (int t = 0; t < NTN; ++t) {
+                    const int n = n_wave + t * 16 + (lane & 15);
+                    uint4 av = make_uint4(0, 0, 0, 0);
+                    if (n < NP) av = *reinterpret_cast<const uint4 *>(w2 + ((int64_t)tap * NP + n) * KP + cs + 8 * (lane >> 4));
+                    a[t] = __builtin_bit_cast(bf16x8, av);
+                }
 #pragma unroll
-                    for (int t = 0; t < NTN; ++t)
-                        acc[t][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], bf, acc[t][jt], 0, 0, 0);
+                for (int jt = 0; jt < kMaxPixTiles; ++jt) {
+                    if (jt < ntile) {
+                        const uint4 bv = *reinterpret_cast<const uint4 *>(slds + pl[jt] + toff);
+                        const bf16x8 bf = __builtin_bit_cast(bf16x8, bv);
+#pragma unroll
+                        for (int t = 0; t < NTN; ++t)
+                            acc[t][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], bf, acc[t][jt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -430,20 +439,29 @@ static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B
     if (R > H) R = H;
     const int strips = (H + R - 1) / R;
     const int pad = KS / 2;
-    const size_t ldsb = (size_t)(R + 2 * pad) * (W + 2 * pad) * 64;
+    const size_t slab_bytes = (size_t)(R + 2 * pad) * (W + 2 * pad) * 64;
+    // slabs per stage: deep input-channel counts amortise the stage latency over 64 / 128 channels
+    static const int kc_env = [] { const char *e = getenv("DFINE_CONV_KC"); return e ? atoi(e) : 0; }();
+    int kc = KP >= 256 ? 4 : (KP >= 64 ? 2 : 1);
+    if (kc_env) kc = kc_env;
+    while (kc > 1 && (slab_bytes * kc > 65536 || KP < 32 * kc)) kc >>= 1;
+    const size_t ldsb = slab_bytes * kc;
     const int vec = (W % 8 == 0) ? 8 : (W % 4 == 0 ? 4 : 2);
     const int nblk64 = (NP + 63) / 64;
     const bool wide = (NP % 128 == 0) && ((int64_t)B * strips * (NP / 128) >= 512);
     dim3 grid(B * strips, wide ? NP / 128 : nblk64);
-#define DFINE_CONV(KSS, NTNN, VECC)                                                                   \
-    hipLaunchKernelGGL((conv_igemm_kernel<KSS, NTNN, VECC>), grid, dim3(kConvThreads), ldsb, st, x, w2, y, Cin, \
+#define DFINE_CONV(KSS, NTNN, VECC, KCC)                                                                   \
+    hipLaunchKernelGGL((conv_igemm_kernel<KSS, NTNN, VECC, KCC>), grid, dim3(kConvThreads), ldsb, st, x, w2, y, Cin, \
                        Cout, NP, KP, H, W, R, strips)
+#define DFINE_CONV_K(KSS, NTNN, VECC)                                                                 \
+    { if (kc == 4) DFINE_CONV(KSS, NTNN, VECC, 4); else if (kc == 2) DFINE_CONV(KSS, NTNN, VECC, 2); else DFINE_CONV(KSS, NTNN, VECC, 1); }
 #define DFINE_CONV_V(KSS, NTNN)                                                                       \
-    { if (vec == 8) DFINE_CONV(KSS, NTNN, 8); else if (vec == 4) DFINE_CONV(KSS, NTNN, 4); else DFINE_CONV(KSS, NTNN, 2); }
+    { if (vec == 8) DFINE_CONV_K(KSS, NTNN, 8) else if (vec == 4) DFINE_CONV_K(KSS, NTNN, 4) else DFINE_CONV_K(KSS, NTNN, 2) }
     if (KS == 3) { if (wide) DFINE_CONV_V(3, 2) else DFINE_CONV_V(3, 1) }
     else if (KS == 1) { if (wide) DFINE_CONV_V(1, 2) else DFINE_CONV_V(1, 1) }
     else return DFINE_E_BADARG;
 #undef DFINE_CONV_V
+#undef DFINE_CONV_K
 #undef DFINE_CONV
     return check_launch();
 }
