@@ -198,6 +198,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_igemm_kernel(
 // shifts of a 3x3 kernel are made from the aligned 16-byte chunk plus one neighbouring dword with
 // v_alignbit (no unaligned LDS access).  A block owns a 64 x 64 (n, c) tile pair for a range of
 // (image, strip) units and writes fp32 partial sums; conv_wgrad_reduce_kernel adds the splits.
+// A 3x3 kernel is split by kernel ROW over blockIdx.z (3 x the blocks for the same partial-sum buffer,
+// no row halo in LDS, 3 instead of 9 accumulator sets); the next unit's X slab is prefetched into registers
+// while the MFMAs of the current one run, and the dY fragment of the next K step is loaded one step ahead.
 template <int KS>
 __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
     const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy, float *__restrict__ part, int Cin,
@@ -207,81 +210,104 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
     constexpr int PAD = KS / 2;
     constexpr int LPAD = KS == 3 ? 8 : 0;
     constexpr int TAPS = KS * KS;
+    constexpr int NPF = 5;                                       // 64 ch x <= 160 px / 8 / 256 threads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt64 = blockIdx.x / nct64, ct64 = blockIdx.x - nt64 * nct64;
     const int split = blockIdx.y;
-    const int PW = W + 2 * LPAD, rows_l = R + 2 * PAD;
-    uint16_t *xs = reinterpret_cast<uint16_t *>(lds);            // [64][rows_l][PW]
+    const int kr = blockIdx.z;                                   // kernel row handled by this block
+    const int PW = W + 2 * LPAD;
+    uint16_t *xs = reinterpret_cast<uint16_t *>(lds);            // [64][R][PW]
     {   // zero once: the pad columns are never written again
         uint32_t *z = reinterpret_cast<uint32_t *>(lds);
         for (int i = tid; i < 64 * CS / 2; i += kConvThreads) z[i] = 0u;
     }
-    f32x4v acc[4][TAPS];
+    f32x4v acc[4][KS];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) acc[ct][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < KS; ++t) acc[ct][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
     const int n_lane = nt64 * 64 + wave * 16 + (lane & 15);
     const bool wave_active = nt64 * 64 + wave * 16 < Cout;
     const int c_base = ct64 * 64;
     const int nv = W / 8;
-    __syncthreads();
+    const int nstage = 64 * R * nv;
+
+    // per-thread slab coordinates are the same for every unit
+    int st_c[NPF], st_lr[NPF], st_xv[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+        const int it = tid + j * kConvThreads;
+        const int ch = it / (R * nv), rem = it - ch * (R * nv);
+        st_c[j] = ch; st_lr[j] = rem / nv; st_xv[j] = (rem - st_lr[j] * nv) * 8;
+    }
+    uint4 pf[NPF];
+    auto fetch_unit = [&](int u) {
+        const int b = u / strips, strip = u - b * strips;
+        const int r0 = strip * R;
+        const uint16_t *xb = x + (int64_t)b * Cin * H * W;
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            pf[j] = make_uint4(0, 0, 0, 0);
+            const int gy = r0 + st_lr[j] + kr - PAD, c = c_base + st_c[j];
+            if (tid + j * kConvThreads < nstage && gy >= 0 && gy < H && c < Cin)
+                pf[j] = *reinterpret_cast<const uint4 *>(xb + ((int64_t)c * H + gy) * W + st_xv[j]);
+        }
+    };
 
     const int u0 = split * units_per_split, u1 = min(total_units, u0 + units_per_split);
+    if (u0 < u1) fetch_unit(u0);
+    __syncthreads();
     for (int u = u0; u < u1; ++u) {
         const int b = u / strips, strip = u - b * strips;
         const int r0 = strip * R;
         const int rows = min(R, H - r0);
-        // ---- stage X[b][c_base .. +63][r0-PAD .. r0+R-1+PAD][:] (zeros outside the image / Cin) ----
-        const uint16_t *xb = x + (int64_t)b * Cin * H * W;
-        for (int it = tid; it < 64 * rows_l * nv; it += kConvThreads) {
-            const int ch = it / (rows_l * nv);
-            const int rem = it - ch * rows_l * nv;
-            const int lr = rem / nv, xv = (rem - lr * nv) * 8;
-            const int gy = r0 - PAD + lr, c = c_base + ch;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gy >= 0 && gy < H && gy < r0 + rows + PAD && c < Cin)
-                v = *reinterpret_cast<const uint4 *>(xb + ((int64_t)c * H + gy) * W + xv);
-            *reinterpret_cast<uint4 *>(xs + (ch * CS + lr * PW + LPAD + xv)) = v;
-        }
+#pragma unroll
+        for (int j = 0; j < NPF; ++j)
+            if (tid + j * kConvThreads < nstage)
+                *reinterpret_cast<uint4 *>(xs + (st_c[j] * CS + st_lr[j] * PW + LPAD + st_xv[j])) = pf[j];
         __syncthreads();
+        if (u + 1 < u1) fetch_unit(u + 1);                         // in flight during the MFMAs below
         const uint16_t *dyb = dy + ((int64_t)b * Cout * H + r0) * W;
         const int tp = rows * W;
-        for (int k0 = 0; k0 < tp; k0 += 32) {
+        auto load_a = [&](int k0) {
             const int px = k0 + 8 * (lane >> 4);
             uint4 av = make_uint4(0, 0, 0, 0);
             if (px < tp && n_lane < Cout) av = *reinterpret_cast<const uint4 *>(dyb + (int64_t)n_lane * H * W + px);
+            return av;
+        };
+        uint4 av = load_a(0);
+        for (int k0 = 0; k0 < tp; k0 += 32) {
+            const uint4 an = load_a(k0 + 32);                     // zero beyond the strip
             const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+            const int px = k0 + 8 * (lane >> 4);
             const int pxc = px < tp ? px : 0;
             const int row = pxc / W, col = pxc - row * W;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 if (c_base + ct * 16 >= Cin || !wave_active) continue;       // uniform per wave
                 const int cc = ct * 16 + (lane & 15);
-#pragma unroll
-                for (int r = 0; r < KS; ++r) {
-                    const uint16_t *e = xs + (cc * CS + (row + r) * PW + LPAD + col);
-                    const uint4 c1 = *reinterpret_cast<const uint4 *>(e);
-                    if (KS == 1) {
-                        acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, c1), acc[ct][0], 0, 0, 0);
-                    } else {
-                        const uint32_t lw = *reinterpret_cast<const uint32_t *>(e - 2);
-                        const uint32_t rw = *reinterpret_cast<const uint32_t *>(e + 8);
-                        uint4 b0, b2;
-                        b0.x = (lw >> 16) | (c1.x << 16); b0.y = (c1.x >> 16) | (c1.y << 16);
-                        b0.z = (c1.y >> 16) | (c1.z << 16); b0.w = (c1.z >> 16) | (c1.w << 16);
-                        b2.x = (c1.x >> 16) | (c1.y << 16); b2.y = (c1.y >> 16) | (c1.z << 16);
-                        b2.z = (c1.z >> 16) | (c1.w << 16); b2.w = (c1.w >> 16) | (rw << 16);
-                        acc[ct][r * KS + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, b0), acc[ct][r * KS + 0], 0, 0, 0);
-                        acc[ct][r * KS + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, c1), acc[ct][r * KS + 1], 0, 0, 0);
-                        acc[ct][r * KS + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, b2), acc[ct][r * KS + 2], 0, 0, 0);
-                    }
+                const uint16_t *e = xs + (cc * CS + row * PW + LPAD + col);
+                const uint4 c1 = *reinterpret_cast<const uint4 *>(e);
+                if (KS == 1) {
+                    acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, c1), acc[ct][0], 0, 0, 0);
+                } else {
+                    const uint32_t lw = *reinterpret_cast<const uint32_t *>(e - 2);
+                    const uint32_t rw = *reinterpret_cast<const uint32_t *>(e + 8);
+                    uint4 b0, b2;
+                    b0.x = (lw >> 16) | (c1.x << 16); b0.y = (c1.x >> 16) | (c1.y << 16);
+                    b0.z = (c1.y >> 16) | (c1.z << 16); b0.w = (c1.z >> 16) | (c1.w << 16);
+                    b2.x = (c1.x >> 16) | (c1.y << 16); b2.y = (c1.y >> 16) | (c1.z << 16);
+                    b2.z = (c1.z >> 16) | (c1.w << 16); b2.w = (c1.w >> 16) | (rw << 16);
+                    acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, b0), acc[ct][0], 0, 0, 0);
+                    acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, c1), acc[ct][1], 0, 0, 0);
+                    acc[ct][KS - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, b2), acc[ct][KS - 1], 0, 0, 0);
                 }
             }
+            av = an;
         }
         __syncthreads();
     }
-    // ---- partial sums: part[split][n][c][tap] -------------------------------------------------
+    // ---- partial sums: part[split][n][c][tap], this block's taps = kr * KS .. + KS - 1 ------------
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
         const int c = c_base + ct * 16 + (lane & 15);
@@ -290,9 +316,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
         for (int r = 0; r < 4; ++r) {
             const int n = nt64 * 64 + wave * 16 + 4 * (lane >> 4) + r;
             if (n >= NP16) continue;
-            float *dst = part + (((int64_t)split * NP16 + n) * CP16 + c) * TAPS;
+            float *dst = part + (((int64_t)split * NP16 + n) * CP16 + c) * TAPS + kr * KS;
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) dst[t] = acc[ct][t][r];
+            for (int t = 0; t < KS; ++t) dst[t] = acc[ct][t][r];
         }
     }
 }
@@ -423,7 +449,8 @@ static void wgrad_plan(int B, int Cin, int Cout, int H, int W, int KS, int *R, i
     int cap = (int)(24000000 / bytes_per_split);
     if (cap < 8) cap = 8;
     if (cap > 512) cap = 512;
-    int sp = 512 / pairs;
+    static const int target = [] { const char *e = getenv("DFINE_WGRAD_BLOCKS"); return e ? atoi(e) : 1024; }();
+    int sp = target / (pairs * KS);
     if (sp < 1) sp = 1;
     if (sp > cap) sp = cap;
     if (sp > units) sp = units;
@@ -537,12 +564,12 @@ int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, i
     int R, strips, splits, ups;
     wgrad_plan(B, Cin, Cout, h, w, KS, &R, &strips, &splits, &ups);
     const int nnt64 = (Cout + 63) / 64, nct64 = (Cin + 63) / 64;
-    const int pad = KS / 2, lpad = KS == 3 ? 8 : 0;
+    const int lpad = KS == 3 ? 8 : 0;
     const int np16 = (Cout + 15) / 16 * 16, cp16 = (Cin + 15) / 16 * 16;
-    const int cs = ((R + 2 * pad) * (w + 2 * lpad) + 127) / 128 * 128 + 8;
+    const int cs = (R * (w + 2 * lpad) + 127) / 128 * 128 + 8;      // one kernel row per block: no row halo
     const size_t ldsb = (size_t)64 * cs * 2;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(nnt64 * nct64, splits);
+    dim3 grid(nnt64 * nct64, splits, KS);
     if (KS == 3) {
         static bool attr_set = false;       // once: not a stream operation, keep it out of graph capture
         if (!attr_set) {
