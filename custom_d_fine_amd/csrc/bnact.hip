@@ -53,6 +53,15 @@ template <int N> __device__ __forceinline__ void block_reduce(float (&v)[N], flo
     }
 }
 
+// 8 bf16 (one 16-byte load) -> 8 floats
+__device__ __forceinline__ void bf16x8_to_f32(const uint4 &r, float (&o)[8]) {
+    o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
+    o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+    o[4] = __uint_as_float(r.z << 16); o[5] = __uint_as_float(r.z & 0xffff0000u);
+    o[6] = __uint_as_float(r.w << 16); o[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+constexpr int kRedUnroll = 4;      // independent 16-byte loads in flight per thread in the reductions
+
 // partial layout: [C][nchunk][NVAL]
 template <typename T>
 __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const T *__restrict__ x, float *__restrict__ part,
@@ -61,7 +70,29 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const T *__restric
     const int c = blockIdx.x, chunk = blockIdx.y;
     const int b0 = chunk * imgs_per_chunk, b1 = min(B, b0 + imgs_per_chunk);
     float v[2] = {0.f, 0.f};
-    if ((HW & 3) == 0) {
+    if (sizeof(T) == 2 && (HW & 7) == 0) {
+        const int nv = HW >> 3, total = (b1 - b0) * nv;            // (image, 8-vector) pairs of this chunk
+        const uint16_t *xb = reinterpret_cast<const uint16_t *>(x);
+        for (int i0 = threadIdx.x; i0 < total; i0 += kRedUnroll * kBnThreads) {
+            uint4 r[kRedUnroll];
+#pragma unroll
+            for (int j = 0; j < kRedUnroll; ++j) {
+                const int i = i0 + j * kBnThreads;
+                r[j] = make_uint4(0, 0, 0, 0);
+                if (i < total) {
+                    const int bi = i / nv, vi = i - bi * nv;
+                    r[j] = *reinterpret_cast<const uint4 *>(xb + ((int64_t)(b0 + bi) * C + c) * HW + vi * 8);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kRedUnroll; ++j) {
+                float a[8];
+                bf16x8_to_f32(r[j], a);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[0] += a[e]; v[1] += a[e] * a[e]; }
+            }
+        }
+    } else if ((HW & 3) == 0) {
         const int nv = HW >> 2, total = (b1 - b0) * nv;            // (image, 4-vector) pairs of this chunk
         for (int i = threadIdx.x; i < total; i += kBnThreads) {
             const int bi = i / nv, vi = i - bi * nv;
@@ -153,6 +184,90 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_flat_kernel(const T *__re
     }
 }
 
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// bf16, HW % 8 == 0: 16-byte vectors, two independent vectors per thread and iteration
+__global__ __launch_bounds__(kBnThreads) void bn_apply_flat8_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ y,
+                                                                    const float *__restrict__ scale,
+                                                                    const float *__restrict__ shift,
+                                                                    const float *__restrict__ lab_s,
+                                                                    const float *__restrict__ lab_b, int C, int HW,
+                                                                    int64_t nvec, int act) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_sc = smem, *s_sh = smem + C;
+    for (int i = threadIdx.x; i < C; i += kBnThreads) { s_sc[i] = scale[i]; s_sh[i] = shift[i]; }
+    const float ls = lab_s ? lab_s[0] : 1.f, lb = lab_b ? lab_b[0] : 0.f;
+    __syncthreads();
+    const uint32_t nv = HW >> 3;
+    const int64_t stride = (int64_t)gridDim.x * kBnThreads;
+    for (int64_t v0 = (int64_t)blockIdx.x * kBnThreads + threadIdx.x; v0 < nvec; v0 += 2 * stride) {
+        const int64_t v1 = v0 + stride;
+        const bool has1 = v1 < nvec;
+        const uint4 r0 = *reinterpret_cast<const uint4 *>(x + v0 * 8);
+        uint4 r1 = make_uint4(0, 0, 0, 0);
+        if (has1) r1 = *reinterpret_cast<const uint4 *>(x + v1 * 8);
+        auto apply = [&](const uint4 &r, int64_t v) {
+            const int c = (int)((v / nv) % C);
+            const float sc = s_sc[c], sh = s_sh[c];
+            float a[8];
+            bf16x8_to_f32(r, a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = ls * act_fwd(a[e] * sc + sh, act) + lb;
+            uint4 o;
+            o.x = pack_bf16x2(a[0], a[1]); o.y = pack_bf16x2(a[2], a[3]);
+            o.z = pack_bf16x2(a[4], a[5]); o.w = pack_bf16x2(a[6], a[7]);
+            *reinterpret_cast<uint4 *>(y + v * 8) = o;
+        };
+        apply(r0, v0);
+        if (has1) apply(r1, v1);
+    }
+}
+
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_flat8_kernel(
+    const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy, uint16_t *__restrict__ dx,
+    const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ lab_s, const float *__restrict__ coef, int C, int HW,
+    int64_t nvec, int act, int train) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_mu = smem, *s_is = smem + C, *s_sc = smem + 2 * C, *s_sh = smem + 3 * C, *s_m0 = smem + 4 * C,
+          *s_m1 = smem + 5 * C;
+    for (int i = threadIdx.x; i < C; i += kBnThreads) {
+        s_mu[i] = mean ? mean[i] : 0.f; s_is[i] = invstd ? invstd[i] : 0.f; s_sc[i] = scale[i]; s_sh[i] = shift[i];
+        s_m0[i] = train ? coef[2 * i] : 0.f; s_m1[i] = train ? coef[2 * i + 1] : 0.f;
+    }
+    const float ls = lab_s ? lab_s[0] : 1.f;
+    __syncthreads();
+    const uint32_t nv = HW >> 3;
+    const int64_t stride = (int64_t)gridDim.x * kBnThreads;
+    for (int64_t v0 = (int64_t)blockIdx.x * kBnThreads + threadIdx.x; v0 < nvec; v0 += 2 * stride) {
+        const int64_t v1 = v0 + stride;
+        const bool has1 = v1 < nvec;
+        const uint4 x0 = *reinterpret_cast<const uint4 *>(x + v0 * 8), g0 = *reinterpret_cast<const uint4 *>(dy + v0 * 8);
+        uint4 x1 = make_uint4(0, 0, 0, 0), g1 = make_uint4(0, 0, 0, 0);
+        if (has1) { x1 = *reinterpret_cast<const uint4 *>(x + v1 * 8); g1 = *reinterpret_cast<const uint4 *>(dy + v1 * 8); }
+        auto apply = [&](const uint4 &rx, const uint4 &rg, int64_t v) {
+            const int c = (int)((v / nv) % C);
+            const float mu = s_mu[c], is = s_is[c], sc = s_sc[c], sh = s_sh[c], m0 = s_m0[c], m1 = s_m1[c];
+            float a[8], g[8], o[8];
+            bf16x8_to_f32(rx, a); bf16x8_to_f32(rg, g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float z = a[e] * sc + sh;
+                const float dz = g[e] * ls * act_grad(z, act);
+                o[e] = sc * (dz - m0 - ((a[e] - mu) * is) * m1);
+            }
+            uint4 w;
+            w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
+            w.z = pack_bf16x2(o[4], o[5]); w.w = pack_bf16x2(o[6], o[7]);
+            *reinterpret_cast<uint4 *>(dx + v * 8) = w;
+        };
+        apply(x0, g0, v0);
+        if (has1) apply(x1, g1, v1);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_flat_kernel(
     const T *__restrict__ x, const T *__restrict__ dy, T *__restrict__ dx, const float *__restrict__ mean,
@@ -232,7 +347,32 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(
         v[2] += g * act_fwd(z, act);
         v[3] += g;
     };
-    if ((HW & 3) == 0) {
+    if (sizeof(T) == 2 && (HW & 7) == 0) {
+        const int nv = HW >> 3, total = (b1 - b0) * nv;
+        const uint16_t *xb = reinterpret_cast<const uint16_t *>(x), *gb = reinterpret_cast<const uint16_t *>(dy);
+        constexpr int U = kRedUnroll / 2;                             // two streams -> 4 loads in flight
+        for (int i0 = threadIdx.x; i0 < total; i0 += U * kBnThreads) {
+            uint4 rx[U], rg[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int i = i0 + j * kBnThreads;
+                rx[j] = make_uint4(0, 0, 0, 0); rg[j] = make_uint4(0, 0, 0, 0);
+                if (i < total) {
+                    const int bi = i / nv, vi = i - bi * nv;
+                    const int64_t off = ((int64_t)(b0 + bi) * C + c) * HW + vi * 8;
+                    rx[j] = *reinterpret_cast<const uint4 *>(xb + off);
+                    rg[j] = *reinterpret_cast<const uint4 *>(gb + off);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                float a[8], d[8];
+                bf16x8_to_f32(rx[j], a); bf16x8_to_f32(rg[j], d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) accum(a[e], d[e]);      // padded lanes carry g = 0 -> contribute 0
+            }
+        }
+    } else if ((HW & 3) == 0) {
         const int nv = HW >> 2, total = (b1 - b0) * nv;
         for (int i = threadIdx.x; i < total; i += kBnThreads) {
             const int bi = i / nv, vi = i - bi * nv;
@@ -355,6 +495,14 @@ int dfine_bn_act_fwd(const void *x, void *y, const float *gamma, const float *be
         int64_t nb = (nvec + kBnThreads * 4 - 1) / (kBnThreads * 4);
         if (nb > 4096) nb = 4096;
         const size_t sm = sizeof(float) * 2 * C;
+        if (dtype != DFINE_F32 && (HW & 7) == 0) {
+            const int64_t nvec8 = nvec / 2;
+            int64_t nb8 = (nvec8 + kBnThreads * 4 - 1) / (kBnThreads * 4);
+            if (nb8 > 4096) nb8 = 4096;
+            hipLaunchKernelGGL(bn_apply_flat8_kernel, dim3((unsigned)nb8), dim3(kBnThreads), sm, st, (const uint16_t *)x,
+                               (uint16_t *)y, scale, shift, lab_scale, lab_bias, C, HW, nvec8, act);
+            return check_launch();
+        }
         if (dtype == DFINE_F32)
             hipLaunchKernelGGL(bn_apply_flat_kernel<float>, dim3((unsigned)nb), dim3(kBnThreads), sm, st, (const float *)x, (float *)y,
                                scale, shift, lab_scale, lab_bias, C, HW, nvec, act);
@@ -397,6 +545,15 @@ int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_
         int64_t nb = (nvec + kBnThreads * 4 - 1) / (kBnThreads * 4);
         if (nb > 4096) nb = 4096;
         const size_t sm = sizeof(float) * 6 * C;
+        if (dtype != DFINE_F32 && (HW & 7) == 0) {
+            const int64_t nvec8 = nvec / 2;
+            int64_t nb8 = (nvec8 + kBnThreads * 4 - 1) / (kBnThreads * 4);
+            if (nb8 > 4096) nb8 = 4096;
+            hipLaunchKernelGGL(bn_bwd_apply_flat8_kernel, dim3((unsigned)nb8), dim3(kBnThreads), sm, st, (const uint16_t *)x,
+                               (const uint16_t *)dy, (uint16_t *)dx, save_mean, save_invstd, scale, shift, lab_scale, coef, C, HW,
+                               nvec8, act, training);
+            return check_launch();
+        }
         if (dtype == DFINE_F32)
             hipLaunchKernelGGL(bn_bwd_apply_flat_kernel<float>, dim3((unsigned)nb), dim3(kBnThreads), sm, st, (const float *)x,
                                (const float *)dy, (float *)dx, save_mean, save_invstd, scale, shift, lab_scale, coef, C, HW, nvec,

@@ -11,6 +11,7 @@ denominators as the reference (`src/d_fine/dfine_criterion.py`).  Restructured f
 """
 import copy
 
+import numpy as np
 import torch
 import torch.distributed
 import torch.nn as nn
@@ -20,19 +21,28 @@ from .arch.utils import bbox2distance, box_cxcywh_to_xyxy, box_iou, generalized_
 from .dist_utils import get_world_size, is_dist_available_and_initialized
 
 
+def _as_matching(indices):
+    from .matcher import Matching
+    return indices if isinstance(indices, Matching) else Matching.from_pairs(indices)
+
+
 class _Plan:
     """Device-side gather plan of one matching: which (image, query) pairs are matched to
-    which row of the batch-concatenated targets."""
+    which row of the batch-concatenated targets, packed as int64 [3, M]."""
 
-    def __init__(self, indices, offsets, device):
-        b = torch.cat([torch.full_like(s, i) for i, (s, _) in enumerate(indices)])
-        s = torch.cat([s for s, _ in indices])
-        t = torch.cat([t + offsets[i] for i, (_, t) in enumerate(indices)])
-        packed = torch.stack([b, s, t]).to(device, non_blocking=True)
+    def __init__(self, indices, offsets, device, packed=None):
+        m = _as_matching(indices)
+        if packed is None:
+            packed = torch.from_numpy(self.pack(m, offsets)).to(device, non_blocking=True)
         self.packed = packed
         self.batch, self.src, self.tgt = packed[0], packed[1], packed[2]
-        self.count = int(s.numel())
+        self.count = int(m.src.size)
         self.indices = indices
+
+    @staticmethod
+    def pack(m, offsets):
+        offs = np.asarray(offsets[:-1], dtype=np.int64)
+        return np.stack([m.img, m.src, m.tgt + (offs[m.img] if m.img.size else m.img)])
 
 
 class DFINECriterion(nn.Module):
@@ -76,6 +86,21 @@ class DFINECriterion(nn.Module):
         if key not in self._plans:
             self._plans[key] = _Plan(indices, self._targets_cat(targets)[2], device)
         return self._plans[key]
+
+    def _build_plans(self, index_sets, targets, device):
+        """All gather plans of a step in ONE host->device copy (each pageable H2D copy stalls the
+        launch queue for ~0.1 ms)."""
+        offsets = self._targets_cat(targets)[2]
+        todo = [ix for ix in index_sets if id(ix) not in self._plans]
+        if not todo:
+            return
+        packs = [_Plan.pack(_as_matching(ix), offsets) for ix in todo]
+        flat = torch.from_numpy(np.concatenate([p.reshape(-1) for p in packs])).to(device, non_blocking=True)
+        off = 0
+        for ix, p in zip(todo, packs):
+            n = p.size
+            self._plans[id(ix)] = _Plan(ix, offsets, device, packed=flat[off: off + n].view(3, -1))
+            off += n
 
     def _get_src_permutation_idx(self, indices):
         batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
@@ -314,21 +339,32 @@ class DFINECriterion(nn.Module):
     # ------------------------------------------------------------------ GO indices
     def _get_go_indices(self, indices, indices_aux_list):
         """Union of the matchings of all heads; a query matched to different targets keeps the
-        target it was matched to most often (ref dfine_criterion.py:570-591, incl. the order
-        produced by torch.unique + torch.argsort(descending) on CPU)."""
-        results = []
-        for b in range(len(indices)):
-            rows = torch.cat([indices[b][0]] + [aux[b][0] for aux in indices_aux_list])
-            cols = torch.cat([indices[b][1]] + [aux[b][1] for aux in indices_aux_list])
-            pairs, counts = torch.unique(torch.stack([rows, cols], 1), return_counts=True, dim=0)
-            pairs = pairs[torch.argsort(counts, descending=True)].numpy()
-            seen = {}
-            for q, t in pairs:
-                if q not in seen:
-                    seen[q] = t
-            results.append((torch.tensor(list(seen.keys()), dtype=torch.int64),
-                            torch.tensor(list(seen.values()), dtype=torch.int64)))
-        return results
+        target it was matched to most often (ref dfine_criterion.py:570-591).  The reference does this
+        per image with torch.unique(dim=0) (lexicographic pairs) + torch.argsort(counts, descending)
+        + first-seen-per-query.  CPU argsort is not stable, so ties are broken by whatever ATen's sort
+        does: the one thing kept per image is that very call on the same counts vector; the unique /
+        first-seen bookkeeping around it is batch-wide numpy."""
+        from .matcher import Matching
+        sets = [_as_matching(indices)] + [_as_matching(a) for a in indices_aux_list]
+        nimg = sets[0].num_images
+        img = np.concatenate([m.img for m in sets])
+        src = np.concatenate([m.src for m in sets])
+        tgt = np.concatenate([m.tgt for m in sets])
+        if img.size == 0:
+            return Matching(img, src, tgt, nimg)
+        qs, ts = int(src.max()) + 1, int(tgt.max()) + 1
+        key, counts = np.unique((img * qs + src) * ts + tgt, return_counts=True)   # lexicographic (img, q, t)
+        iq, t = key // ts, key % ts                           # iq = image * qs + query
+        bounds = np.searchsorted(iq // qs, np.arange(nimg + 1))
+        counts_t = torch.from_numpy(counts)
+        perm = [a + torch.argsort(counts_t[a:b], descending=True).numpy()
+                for a, b in zip(bounds[:-1].tolist(), bounds[1:].tolist()) if b > a]
+        perm = np.concatenate(perm)
+        iq, t = iq[perm], t[perm]
+        _, first = np.unique(iq, return_index=True)           # first appearance of every (image, query)
+        first.sort()                                          # ... in order of appearance
+        iq, t = iq[first], t[first]
+        return Matching(iq // qs, iq % qs, t, nimg)
 
     def get_loss(self, loss, outputs, targets, indices, num_boxes, **kwargs):
         table = {"boxes": self.loss_boxes, "focal": self.loss_labels_focal,
@@ -387,7 +423,7 @@ class DFINECriterion(nn.Module):
         indices_go = self._get_go_indices(indices, matched[1:])
 
         # the reference's two scalar all-reduces folded into one 2-float collective
-        counts = torch.tensor([float(sum(len(x[0]) for x in indices_go)),
+        counts = torch.tensor([float(indices_go.src.size),
                                float(sum(len(t["labels"]) for t in targets))])
         if is_dist_available_and_initialized():
             counts = counts.to(device)
@@ -474,7 +510,11 @@ class DFINECriterion(nn.Module):
         wd = self.weight_dict
         wtable, reg_scale = self._fdr_constants(outputs)
         want_vfl, want_box, want_local = ("vfl" in self.losses, "boxes" in self.losses, "local" in self.losses)
-        go = self._plan(indices_go, targets, dev)
+        indices_dn = None
+        if "dn_outputs" in outputs:
+            indices_dn = self.get_cdn_matched_indices(outputs["dn_meta"], targets)
+        self._build_plans([indices, *cached, *cached_enc, indices_go] + ([indices_dn] if indices_dn is not None else []),
+                          targets, dev)
         names, vecs = [], []
 
         def run(head, suffix, cls_idx, box_idx, n_cls, n_box, local, is_dn=False, box_go_only=False):
@@ -525,8 +565,7 @@ class DFINECriterion(nn.Module):
         run(outputs["pre_outputs"], "_pre", cached[-1], indices_go, num_boxes, num_boxes_go, False)
         for i, aux in enumerate(outputs["enc_aux_outputs"]):
             run(aux, f"_enc_{i}", cached_enc[i], indices_go, num_boxes, num_boxes_go, False)
-        if "dn_outputs" in outputs:
-            indices_dn = self.get_cdn_matched_indices(outputs["dn_meta"], targets)
+        if indices_dn is not None:
             dn_boxes = num_boxes * outputs["dn_meta"]["dn_num_group"]
             dn_boxes = dn_boxes if dn_boxes > 0 else 1
             for i, aux in enumerate(outputs["dn_outputs"]):
@@ -536,10 +575,11 @@ class DFINECriterion(nn.Module):
                     is_dn=True)
         table = torch.nan_to_num(torch.stack(vecs), nan=0.0)      # [heads, 5]
         self._last_table = table
+        cells = table.view(-1).unbind(0)                            # one op instead of ~60 selects
         losses = {}
         for h, keys in enumerate(names):
             for k, j in keys:
-                losses[k] = table[h, j]
+                losses[k] = cells[h * 5 + j]
         return losses
 
     def total(self, loss_dict):

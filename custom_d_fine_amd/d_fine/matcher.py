@@ -53,6 +53,59 @@ def _cols_to_pairs(cols: np.ndarray, sizes: List[int]):
     return out
 
 
+class Matching:
+    """One head's matching of a whole batch as three flat int64 arrays (image, query, target-in-image),
+    ordered like the reference's per-image (rows ascending, cols) pairs concatenated over the batch.
+    Behaves like the reference's `indices` list ([(rows, cols)] * B of CPU int64 tensors) when it is
+    indexed / iterated; the criterion's hot path reads the flat arrays and never builds that list."""
+
+    __slots__ = ("img", "src", "tgt", "num_images", "_pairs")
+
+    def __init__(self, img, src, tgt, num_images):
+        self.img, self.src, self.tgt, self.num_images = img, src, tgt, num_images
+        self._pairs = None
+
+    @classmethod
+    def from_pairs(cls, pairs):
+        lens = [len(s) for s, _ in pairs]
+        img = np.repeat(np.arange(len(pairs), dtype=np.int64), lens)
+        src = np.concatenate([np.asarray(s, dtype=np.int64).reshape(-1) for s, _ in pairs]) if pairs else img
+        tgt = np.concatenate([np.asarray(t, dtype=np.int64).reshape(-1) for _, t in pairs]) if pairs else img
+        return cls(img, src, tgt, len(pairs))
+
+    def pairs(self):
+        if self._pairs is None:
+            bounds = np.searchsorted(self.img, np.arange(self.num_images + 1))
+            src, tgt = torch.from_numpy(self.src), torch.from_numpy(self.tgt)
+            self._pairs = [(src[a:b], tgt[a:b]) for a, b in zip(bounds[:-1], bounds[1:])]
+        return self._pairs
+
+    def __len__(self):
+        return self.num_images
+
+    def __getitem__(self, i):
+        return self.pairs()[i]
+
+    def __iter__(self):
+        return iter(self.pairs())
+
+
+def _cols_to_matchings(cols: np.ndarray, sizes: List[int]):
+    """[K, T] target->query vectors of K heads -> K `Matching`s, no per-image Python loop."""
+    sizes = np.asarray(sizes, dtype=np.int64)
+    nimg = len(sizes)
+    img_of_t = np.repeat(np.arange(nimg, dtype=np.int64), sizes)
+    t_local = np.arange(int(sizes.sum()), dtype=np.int64) - np.repeat(np.cumsum(sizes) - sizes, sizes)
+    out = []
+    for k in range(cols.shape[0]):
+        q = cols[k].astype(np.int64)
+        keep = np.nonzero(q >= 0)[0]
+        img, src, tgt = img_of_t[keep], q[keep], t_local[keep]
+        order = np.lexsort((src, img))                 # by image, then query ascending (queries are unique)
+        out.append(Matching(img[order], src[order], tgt[order], nimg))
+    return out
+
+
 class HungarianMatcher(nn.Module):
     __share__ = ["use_focal_loss"]
 
@@ -100,7 +153,7 @@ class HungarianMatcher(nn.Module):
     def match_heads(self, heads: List[Dict[str, torch.Tensor]], targets):
         """Matches every prediction head in `heads` (dicts with pred_logits [B,Q,C] and
         pred_boxes [B,Q,4]) against the same targets.  One cost+assignment launch and one
-        D2H copy for all heads.  Returns one reference-style indices list per head."""
+        D2H copy for all heads.  Returns one `Matching` (list-like: reference-style indices) per head."""
         sizes = [len(t["boxes"]) for t in targets]
         logits = torch.stack([h["pred_logits"] for h in heads]).float()
         boxes = torch.stack([h["pred_boxes"] for h in heads]).float()
@@ -108,8 +161,8 @@ class HungarianMatcher(nn.Module):
         tgt_box = torch.cat([t["boxes"] for t in targets]).float()
         tmax = max(sizes) if sizes else 0
         if tmax == 0:
-            empty = (torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64))
-            return [[empty for _ in sizes] for _ in heads]
+            z = np.zeros(0, dtype=np.int64)
+            return [Matching(z, z, z, len(sizes)) for _ in heads]
         extra = None
         per_head = [self._mask_cost(h, targets, logits.shape[2], tmax) for h in heads]
         if any(e is not None for e in per_head):
@@ -119,13 +172,13 @@ class HungarianMatcher(nn.Module):
             logits, boxes, tgt_ids, tgt_box, sizes, float(self.cost_class), float(self.cost_bbox),
             float(self.cost_giou), float(self.alpha), float(self.gamma), self.use_focal_loss, extra)
         cols = cols.cpu().numpy()  # the step's single matcher D2H
-        return [_cols_to_pairs(cols[k], sizes) for k in range(len(heads))]
+        return _cols_to_matchings(cols, sizes)
 
     @torch.no_grad()
     def forward(self, outputs: Dict[str, torch.Tensor], targets, return_topk=False):
         if return_topk:
             return {"indices_o2m": self.get_top_k_matches(outputs, targets, k=return_topk)}
-        return {"indices": self.match_heads([outputs], targets)[0]}
+        return {"indices": self.match_heads([outputs], targets)[0].pairs()}
 
     @torch.no_grad()
     def get_top_k_matches(self, outputs, targets, k=1):

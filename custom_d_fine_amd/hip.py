@@ -347,9 +347,10 @@ def head_losses(logits, boxes, corners, ref, teacher_corners, teacher_logits, cl
     dev = logits.device
     dt = logits.dtype
     m_cls, m_box = int(cls_plan.shape[1]), int(box_plan.shape[1])
-    out = torch.empty(5, device=dev, dtype=torch.float32)
+    zbuf = torch.empty(8 + 2 * B * Q * 4, device=dev, dtype=torch.float32)   # [out | grad_l1 | grad_giou]: one fill
+    out = zbuf[:5]
+    g_box = zbuf[8:].view(2, B, Q, 4)
     g_logits = torch.empty(B, Q, C, device=dev, dtype=dt)
-    g_box = torch.empty(2, B, Q, 4, device=dev, dtype=torch.float32)
     scratch_f = torch.empty(m_cls + m_box + B * Q, device=dev, dtype=torch.float32)
     scratch_i = torch.empty(2, B * Q, device=dev, dtype=torch.int32)
     g_fgl = g_ddf = None

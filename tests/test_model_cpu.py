@@ -156,3 +156,53 @@ def test_denoising_group_structure():
     none = U.get_contrastive_denoising_training_group(
         [{"labels": torch.zeros(0, dtype=torch.long), "boxes": torch.zeros(0, 4)}], 10, 300, emb)
     assert none[0] is None and none[3]["dn_num_split"] == [0, 300]
+
+
+def _go_indices_per_image(indices, indices_aux_list):
+    """Literal per-image procedure (ref dfine_criterion.py:570-591): unique pairs, argsort of the
+    counts (descending), first target seen per query."""
+    results = []
+    for b in range(len(indices)):
+        rows = torch.cat([indices[b][0]] + [aux[b][0] for aux in indices_aux_list])
+        cols = torch.cat([indices[b][1]] + [aux[b][1] for aux in indices_aux_list])
+        pairs, counts = torch.unique(torch.stack([rows, cols], 1), return_counts=True, dim=0)
+        pairs = pairs[torch.argsort(counts, descending=True)].numpy()
+        seen = {}
+        for q, t in pairs:
+            if q not in seen:
+                seen[q] = t
+        results.append((list(seen.keys()), list(seen.values())))
+    return results
+
+
+def test_go_indices_batchwide_equals_per_image_procedure():
+    from custom_d_fine_amd.d_fine.matcher import Matching, _cols_to_matchings, _cols_to_pairs
+    rng = np.random.default_rng(5)
+    crit = dfine.build_loss("n", 80, 0.0, False)
+    for trial in range(20):
+        sizes = [int(rng.integers(0, 30)) for _ in range(6)]
+        if trial == 0:
+            sizes = [0, 3, 0, 7, 1, 0]
+        heads = 6
+        cols = np.full((heads, sum(sizes)), -1, dtype=np.int32)
+        off = 0
+        for n in sizes:                                   # few distinct queries -> many count ties
+            for k in range(heads):
+                cols[k, off: off + n] = rng.permutation(40)[:n]
+                if n and rng.random() < 0.3:
+                    cols[k, off + int(rng.integers(0, n))] = -1
+            off += n
+        ms = _cols_to_matchings(cols, sizes)
+        lists = [_cols_to_pairs(cols[k], sizes) for k in range(heads)]
+        for m, l in zip(ms, lists):                       # Matching == the per-image pair lists
+            assert len(m) == len(l)
+            for (a, b), (c, d) in zip(m, l):
+                assert torch.equal(a, c) and torch.equal(b, d)
+        if sum(sizes) == 0:
+            continue
+        got = crit._get_go_indices(ms[0], ms[1:])
+        want = _go_indices_per_image(lists[0], lists[1:])
+        for (a, b), (c, d) in zip(got, want):
+            assert a.tolist() == [int(x) for x in c] and b.tolist() == [int(x) for x in d]
+        again = crit._get_go_indices(lists[0], lists[1:])  # plain reference-style lists are accepted too
+        assert np.array_equal(again.src, got.src) and np.array_equal(again.tgt, got.tgt)
