@@ -6,6 +6,7 @@ arithmetic-heavy ones dispatch to the HIP library through `custom_d_fine_amd.ker
 import math
 from typing import List
 
+import numpy as np
 import torch
 import torch.nn as nn
 from torch import Tensor
@@ -204,6 +205,15 @@ def set_denoising_generator(gen):
     _NOISE_GENERATOR = gen
 
 
+def upload(array, device):
+    """Host numpy array / CPU tensor -> device without stalling the host: pinned staging + async copy for
+    CUDA devices (a pageable-memory copy waits for the device queue to drain), plain conversion on CPU."""
+    t = torch.from_numpy(array) if isinstance(array, np.ndarray) else array
+    if torch.device(device).type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def _rand_like(t, dtype=None):
     if _NOISE_GENERATOR is None:
         return torch.rand_like(t, dtype=dtype)
@@ -239,14 +249,19 @@ def get_contrastive_denoising_training_group(
     groups = max(num_denoising // gmax, 1)
     bs = len(counts)
 
-    # pad labels / boxes to [bs, gmax]
-    cnt = torch.tensor(counts, device=device)
-    valid = torch.arange(gmax, device=device)[None, :] < cnt[:, None]
-    cls = torch.full([bs, gmax], num_classes, dtype=torch.int32, device=device)
-    box = torch.zeros([bs, gmax, 4], device=device)
+    # pad labels / boxes to [bs, gmax].  The slot of every real GT is known from the host-side counts, so
+    # the padded tensors are filled with an index_copy through ONE async upload - a boolean-mask assignment
+    # or torch.tensor(list, device=cuda) would each block the host until the device queue drains.
+    slots = np.concatenate([i * gmax + np.arange(n, dtype=np.int64) for i, n in enumerate(counts)])
+    slots = upload(slots, device)
+    valid = torch.zeros(bs * gmax, dtype=torch.bool, device=device)
+    cls = torch.full([bs * gmax], num_classes, dtype=torch.int32, device=device)
+    box = torch.zeros([bs * gmax, 4], device=device)
     if sum(counts):
-        cls[valid] = torch.cat([t["labels"] for t in targets]).to(torch.int32)
-        box[valid] = torch.cat([t["boxes"] for t in targets]).to(box.dtype)
+        valid.index_fill_(0, slots, True)
+        cls.index_copy_(0, slots, torch.cat([t["labels"] for t in targets]).to(torch.int32))
+        box.index_copy_(0, slots, torch.cat([t["boxes"] for t in targets]).to(box.dtype))
+    valid, cls, box = valid.view(bs, gmax), cls.view(bs, gmax), box.view(bs, gmax, 4)
 
     cls = cls.tile([1, 2 * groups])
     box = box.tile([1, 2 * groups, 1])

@@ -17,7 +17,7 @@ import torch.distributed
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .arch.utils import bbox2distance, box_cxcywh_to_xyxy, box_iou, generalized_box_iou, paired_iou_giou
+from .arch.utils import upload, bbox2distance, box_cxcywh_to_xyxy, box_iou, generalized_box_iou, paired_iou_giou
 from .dist_utils import get_world_size, is_dist_available_and_initialized
 
 
@@ -33,7 +33,7 @@ class _Plan:
     def __init__(self, indices, offsets, device, packed=None):
         m = _as_matching(indices)
         if packed is None:
-            packed = torch.from_numpy(self.pack(m, offsets)).to(device, non_blocking=True)
+            packed = upload(self.pack(m, offsets), device)
         self.packed = packed
         self.batch, self.src, self.tgt = packed[0], packed[1], packed[2]
         self.count = int(m.src.size)
@@ -95,7 +95,7 @@ class DFINECriterion(nn.Module):
         if not todo:
             return
         packs = [_Plan.pack(_as_matching(ix), offsets) for ix in todo]
-        flat = torch.from_numpy(np.concatenate([p.reshape(-1) for p in packs])).to(device, non_blocking=True)
+        flat = upload(np.concatenate([p.reshape(-1) for p in packs]), device)
         off = 0
         for ix, p in zip(todo, packs):
             n = p.size

@@ -79,6 +79,8 @@ class GraphedSegment:
     outputs / parameter gradients are returned as the graph's static tensors."""
 
     def __init__(self, module, sample_inputs, amp_dtype=None, warmup=2):
+        from .. import kernels
+        kernels._CAPTURE_POSSIBLE = True
         self.module = module
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.amp_dtype = amp_dtype

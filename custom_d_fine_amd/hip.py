@@ -110,12 +110,20 @@ def _check(status, what):
         raise RuntimeError(f"{what} failed with status {status}: {_lib.dfine_last_error().decode()}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw hipStream_t of torch's current stream (the private getter is ~20x cheaper than building a
+    torch.cuda.Stream object per launch; ~500 launches per step go through here)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _ptr(t):
-    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+    """Device address as a plain int (ctypes converts it for the c_void_p parameters); None -> NULL."""
+    return t.data_ptr() if t is not None else None
 
 
 def _levels(shapes, points):
@@ -282,7 +290,7 @@ _BN_WS = {}
 def _bn_workspace(dev, nfloats):
     """Scratch for the partial sums: consumed inside the same call by stream-ordered kernels, so one
     growing buffer per (device, stream) is reused by every BatchNorm unit instead of an allocation each."""
-    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    key = (dev.index, _stream())
     ws = _BN_WS.get(key)
     if ws is None or ws.numel() < nfloats:
         ws = torch.empty(max(nfloats, 1 << 16), device=dev, dtype=torch.float32)
@@ -494,7 +502,7 @@ def linear_wgrad_bf16(x2d, dy2d, with_bias=False):
     N = dy2d.shape[1]
     dev = x2d.device
     need = int(_lib.dfine_linear_wgrad_ws_floats(M, N, K))
-    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    key = (dev.index, _stream())
     ws = _LW_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1 << 20), device=dev, dtype=torch.float32)

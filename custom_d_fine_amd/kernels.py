@@ -277,6 +277,22 @@ class _BNAct(torch.autograd.Function):
 # kernels win on the large 1x1 layers - profiles/r01_conv_survey_hip_vs_miopen.txt).
 _CONV_PLAN = {}
 
+# Environment switches are read once (an os.environ lookup per layer call is ~1 us x 800 calls per step);
+# `reload_env()` re-reads them (tests / tools that flip a switch after import).
+_ENV = {}
+
+
+def _env(name, default):
+    v = _ENV.get(name)
+    if v is None:
+        v = _ENV[name] = os.environ.get(name, default)
+    return v
+
+
+def reload_env():
+    _ENV.clear()
+    _CONV_PLAN.clear()
+
 # Packed bf16 copies of the conv weights (forward and data-gradient layouts) are rebuilt only when the
 # weights changed: `_WEIGHT_EPOCH` is bumped by the optimizer step (the fused optimizer updates the flat
 # buffer through raw pointers, invisible to tensor._version), `_version` covers in-place torch updates.
@@ -289,8 +305,11 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH += 1
 
 
+_CAPTURE_POSSIBLE = False      # set by dl.engine.GraphedSegment: only then is the capture query worth a call per layer
+
+
 def _packed_weights(weight, dgrad):
-    if torch.cuda.is_current_stream_capturing():
+    if _CAPTURE_POSSIBLE and torch.cuda.is_current_stream_capturing():
         # inside a HIP-graph capture the pack launch itself must be recorded (the weights change
         # between replays), so never serve or fill the cache here
         return _hip().conv_pack_weights(weight.detach().float().contiguous(), dgrad)
@@ -325,7 +344,7 @@ def _conv_plan(x, weight):
     plan = _CONV_PLAN.get(key)
     if plan is not None:
         return plan
-    mode = os.environ.get("DFINE_CONV_TUNE", "1")
+    mode = _env("DFINE_CONV_TUNE", "1")
     if mode != "1":                      # "hip" / "aten": force one side (debugging, A/B runs)
         plan = {k: mode == "hip" for k in ("fwd", "dgrad", "wgrad")}
         plan["wgrad"] = plan["wgrad"] and hip.conv_wgrad_supported(H, W, ks)
@@ -417,7 +436,7 @@ class _DenseConvMFMA(_DenseConv):
 def _mfma_conv_ok(conv, x):
     """Layers the implicit-GEMM kernels can serve (1x1 / 3x3, stride 1, 'same' padding, bf16 autocast)."""
     k = conv.kernel_size
-    return (os.environ.get("DFINE_MFMA_CONV", "1") == "1" and conv.groups == 1 and k[0] == k[1] and k[0] in (1, 3)
+    return (_env("DFINE_MFMA_CONV", "1") == "1" and conv.groups == 1 and k[0] == k[1] and k[0] in (1, 3)
             and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.bias is None
             and isinstance(conv.padding, tuple) and conv.padding == (k[0] // 2, k[0] // 2)
             and conv.in_channels % 16 == 0 and conv.out_channels % 16 == 0 and x.dim() == 4
@@ -439,7 +458,7 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
     GPU: depthwise convs and the whole BN/act/affine tail are HIP kernels; dense convs are still
     MIOpen calls [ATen plumbing].  CPU tensors take the plain ATen composition below."""
     a = act.lower() if isinstance(act, str) else act
-    if x.is_cuda and a in (None, "relu", "silu", "swish") and os.environ.get("DFINE_HIP_UNITS", "1") == "1":
+    if x.is_cuda and a in (None, "relu", "silu", "swish") and _env("DFINE_HIP_UNITS", "1") == "1":
         if _is_depthwise(conv):
             if torch.is_autocast_enabled() and x.dtype == torch.float32:
                 x = x.to(torch.get_autocast_dtype("cuda"))      # what autocast would do for F.conv2d
@@ -540,7 +559,7 @@ class _LinearSplitK(torch.autograd.Function):
 def linear(x, weight, bias=None):
     """nn.Linear forward for the [B, L, K] activations of the decoder / encoder token streams."""
     if x.is_cuda and x.dim() == 3 and x.shape[0] > 1 and x.shape[0] * x.shape[1] >= 4096 \
-            and os.environ.get("DFINE_SPLITK_LINEAR", "1") == "1" and torch.is_grad_enabled():
+            and _env("DFINE_SPLITK_LINEAR", "1") == "1" and torch.is_grad_enabled():
         return _LinearSplitK.apply(x, weight, bias)
     return F.linear(x, weight, bias)
 
