@@ -410,12 +410,22 @@ class DFINECriterion(nn.Module):
         main = {k: v for k, v in outputs.items() if "aux" not in k}
         heads = [main] + list(outputs["aux_outputs"]) + [outputs["pre_outputs"]] + list(
             outputs["enc_aux_outputs"])
-        if hasattr(self.matcher, "match_heads"):
+        self._clear_cache()
+        self._tgt = None
+        indices_dn = None
+        if hasattr(self.matcher, "match_heads_async"):
+            finish = self.matcher.match_heads_async(heads, targets)
+            # host / launch work that does not need the assignment runs while the device computes it
+            self._targets_cat(targets)
+            if fused:
+                self._fdr_constants(outputs)
+                if "dn_outputs" in outputs:
+                    indices_dn = self.get_cdn_matched_indices(outputs["dn_meta"], targets)
+            matched = finish()
+        elif hasattr(self.matcher, "match_heads"):
             matched = self.matcher.match_heads(heads, targets)
         else:
             matched = [self.matcher(h, targets)["indices"] for h in heads]
-        self._clear_cache()
-        self._tgt = None
         n_aux = len(outputs["aux_outputs"])
         indices = matched[0]
         cached = matched[1: n_aux + 2]          # aux layers ... pre
@@ -437,7 +447,7 @@ class DFINECriterion(nn.Module):
 
         if fused:
             return self._forward_fused(outputs, targets, indices, cached, cached_enc, indices_go,
-                                       num_boxes, num_boxes_go)
+                                       num_boxes, num_boxes_go, indices_dn)
 
         losses = {}
         self._branch(outputs, targets, "", go_or(indices), losses)
@@ -501,7 +511,7 @@ class DFINECriterion(nn.Module):
         return self._fdr_cache[1], self._fdr_cache[2]
 
     def _forward_fused(self, outputs, targets, indices, cached, cached_enc, indices_go, num_boxes,
-                       num_boxes_go):
+                       num_boxes_go, indices_dn=None):
         from .. import kernels
         dev = outputs["pred_logits"].device
         labels, tboxes, _ = self._targets_cat(targets)
@@ -510,8 +520,7 @@ class DFINECriterion(nn.Module):
         wd = self.weight_dict
         wtable, reg_scale = self._fdr_constants(outputs)
         want_vfl, want_box, want_local = ("vfl" in self.losses, "boxes" in self.losses, "local" in self.losses)
-        indices_dn = None
-        if "dn_outputs" in outputs:
+        if indices_dn is None and "dn_outputs" in outputs:
             indices_dn = self.get_cdn_matched_indices(outputs["dn_meta"], targets)
         self._build_plans([indices, *cached, *cached_enc, indices_go] + ([indices_dn] if indices_dn is not None else []),
                           targets, dev)

@@ -154,15 +154,23 @@ class HungarianMatcher(nn.Module):
         """Matches every prediction head in `heads` (dicts with pred_logits [B,Q,C] and
         pred_boxes [B,Q,4]) against the same targets.  One cost+assignment launch and one
         D2H copy for all heads.  Returns one `Matching` (list-like: reference-style indices) per head."""
+        return self.match_heads_async(heads, targets)()
+
+    @torch.no_grad()
+    def match_heads_async(self, heads: List[Dict[str, torch.Tensor]], targets):
+        """Launches the matching and the (pinned, asynchronous) D2H copy of its result and returns a
+        `finish()` callable that waits for it - the step's one host<->device sync - so that the caller
+        can do host work that does not depend on the assignment while the device is still busy."""
         sizes = [len(t["boxes"]) for t in targets]
+        tmax = max(sizes) if sizes else 0
+        if tmax == 0:
+            z = np.zeros(0, dtype=np.int64)
+            empty = [Matching(z, z, z, len(sizes)) for _ in heads]
+            return lambda: empty
         logits = torch.stack([h["pred_logits"] for h in heads]).float()
         boxes = torch.stack([h["pred_boxes"] for h in heads]).float()
         tgt_ids = torch.cat([t["labels"] for t in targets])
         tgt_box = torch.cat([t["boxes"] for t in targets]).float()
-        tmax = max(sizes) if sizes else 0
-        if tmax == 0:
-            z = np.zeros(0, dtype=np.int64)
-            return [Matching(z, z, z, len(sizes)) for _ in heads]
         extra = None
         per_head = [self._mask_cost(h, targets, logits.shape[2], tmax) for h in heads]
         if any(e is not None for e in per_head):
@@ -171,8 +179,18 @@ class HungarianMatcher(nn.Module):
         cols, _ = kernels.hungarian_assign(
             logits, boxes, tgt_ids, tgt_box, sizes, float(self.cost_class), float(self.cost_bbox),
             float(self.cost_giou), float(self.alpha), float(self.gamma), self.use_focal_loss, extra)
-        cols = cols.cpu().numpy()  # the step's single matcher D2H
-        return _cols_to_matchings(cols, sizes)
+        if not cols.is_cuda:
+            return lambda: _cols_to_matchings(cols.numpy(), sizes)
+        host = torch.empty(cols.shape, dtype=cols.dtype, pin_memory=True)
+        host.copy_(cols, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+
+        def finish():
+            done.synchronize()               # the step's single host<->device sync
+            return _cols_to_matchings(host.numpy(), sizes)
+
+        return finish
 
     @torch.no_grad()
     def forward(self, outputs: Dict[str, torch.Tensor], targets, return_topk=False):
