@@ -271,9 +271,9 @@ def get_contrastive_denoising_training_group(
     neg = neg.tile([1, groups, 1])
     # positive (first-half) slots of every group that hold a real GT; known from the counts alone,
     # so built on the host (the reference derives them with a device nonzero + split)
-    pos_idx = tuple(
-        (torch.arange(groups)[:, None] * (2 * gmax) + torch.arange(n)[None, :]).reshape(-1)
-        for n in counts)
+    pos_np = [(np.arange(groups, dtype=np.int64)[:, None] * (2 * gmax) + np.arange(n, dtype=np.int64)[None, :]).reshape(-1)
+              for n in counts]
+    pos_idx = tuple(torch.from_numpy(p) for p in pos_np)
     total = int(gmax * 2 * groups)
 
     if label_noise_ratio > 0:
@@ -301,5 +301,6 @@ def get_contrastive_denoising_training_group(
     gid = torch.arange(total, device=device) // g
     mask[:total, :total] = gid[:, None] != gid[None, :]  # groups are mutually invisible
 
-    meta = {"dn_positive_idx": pos_idx, "dn_num_group": groups, "dn_num_split": [total, num_queries]}
+    meta = {"dn_positive_idx": pos_idx, "dn_num_group": groups, "dn_num_split": [total, num_queries],
+            "dn_positive_flat": np.concatenate(pos_np)}
     return logits, box_unact, mask, meta

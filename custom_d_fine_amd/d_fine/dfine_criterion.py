@@ -35,9 +35,21 @@ class _Plan:
         if packed is None:
             packed = upload(self.pack(m, offsets), device)
         self.packed = packed
-        self.batch, self.src, self.tgt = packed[0], packed[1], packed[2]
         self.count = int(m.src.size)
         self.indices = indices
+
+    # rows of the packed plan (only the torch-composition path reads them)
+    @property
+    def batch(self):
+        return self.packed[0]
+
+    @property
+    def src(self):
+        return self.packed[1]
+
+    @property
+    def tgt(self):
+        return self.packed[2]
 
     @staticmethod
     def pack(m, offsets):
@@ -583,7 +595,7 @@ class DFINECriterion(nn.Module):
                 run(outputs["dn_pre_outputs"], "_dn_pre", indices_dn, indices_dn, dn_boxes, dn_boxes, False,
                     is_dn=True)
         table = torch.nan_to_num(torch.stack(vecs), nan=0.0)      # [heads, 5]
-        self._last_table = table
+        self.__dict__["_last_table"] = table      # plain attribute: nn.Module.__setattr__ is not needed here
         cells = table.view(-1).unbind(0)                            # one op instead of ~60 selects
         losses = {}
         for h, keys in enumerate(names):
@@ -594,7 +606,11 @@ class DFINECriterion(nn.Module):
     def total(self, loss_dict):
         """Sum of all returned losses.  On the fused path the values are views of one table, so
         the sum is one reduction instead of len(loss_dict) - 1 scalar adds."""
-        t = getattr(self, "_last_table", None)
+        t = self.__dict__.get("_last_table")
+        # the table is dropped here: holding it until the next step would keep that step's whole autograd
+        # graph alive and free it (~1 ms of node destructors) in the middle of the next criterion call,
+        # while the device idles
+        self.__dict__["_last_table"] = None
         if t is not None and loss_dict and next(iter(loss_dict.values()))._base is t:
             return t.sum()
         return sum(loss_dict.values())
@@ -619,19 +635,23 @@ class DFINECriterion(nn.Module):
     @staticmethod
     def get_cdn_matched_indices(dn_meta, targets):
         """Denoising queries are matched to their source GT by construction
-        (ref dfine_criterion.py:809-831)."""
+        (ref dfine_criterion.py:809-831): positive slot g * 2 * gmax + j of image i <-> its GT j, for every
+        group g.  Built batch-wide from the per-image GT counts (list-like result, see matcher.Matching)."""
+        from .matcher import Matching
         pos, groups = dn_meta["dn_positive_idx"], dn_meta["dn_num_group"]
-        out = []
-        for i, t in enumerate(targets):
-            n = len(t["labels"])
-            if n > 0:
-                gt = torch.arange(n, dtype=torch.int64).tile(groups)
-                assert len(pos[i]) == len(gt)
-                out.append((pos[i].cpu(), gt))
-            else:
-                z = torch.zeros(0, dtype=torch.int64)
-                out.append((z, z))
-        return out
+        counts = np.asarray([len(t["labels"]) for t in targets], dtype=np.int64)
+        for i, n in enumerate(counts):
+            assert n == 0 or len(pos[i]) == n * groups
+        flat = dn_meta.get("dn_positive_flat")
+        if flat is None:
+            src = (np.concatenate([np.asarray(p, dtype=np.int64).reshape(-1) for p in pos])
+                   if len(pos) else np.zeros(0, np.int64))
+        else:
+            src = flat
+        img = np.repeat(np.arange(len(counts), dtype=np.int64), counts * groups)
+        tgt = (np.concatenate([np.tile(np.arange(n, dtype=np.int64), groups) for n in counts])
+               if len(counts) else np.zeros(0, np.int64))
+        return Matching(img, src, tgt, len(counts))
 
     def feature_loss_function(self, fea, target_fea):
         loss = (fea - target_fea) ** 2 * ((fea > 0) | (target_fea > 0)).float()

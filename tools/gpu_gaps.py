@@ -27,13 +27,15 @@ evs.sort(key=lambda e: e.time_range.start)
 busy = sum(e.time_range.end - e.time_range.start for e in evs)
 span = evs[-1].time_range.end - evs[0].time_range.start
 print(f"{len(evs)} device events over {a.steps} steps: span {span/1e3/a.steps:.2f} ms/step, busy {busy/1e3/a.steps:.2f} ms/step")
+cpu = [e for e in prof.events() if str(e.device_type).endswith("CPU")]
+cpu.sort(key=lambda e: e.time_range.start)
 gaps = []
 end = evs[0].time_range.end
 prev = evs[0]
 for e in evs[1:]:
     g = e.time_range.start - end
     if g > a.min_us:
-        gaps.append((g, prev.name[:70], e.name[:70], (e.time_range.start - evs[0].time_range.start) / 1e3))
+        gaps.append((g, prev.name[:70], e.name[:70], (e.time_range.start - evs[0].time_range.start) / 1e3, end, e.time_range.start))
     if e.time_range.end > end:
         end = e.time_range.end
         prev = e
@@ -43,3 +45,16 @@ small = span - busy - tot
 print(f"remaining (sub-{a.min_us} us launch gaps): {small/1e3/a.steps:.2f} ms/step")
 for g in sorted(gaps, reverse=True)[: a.rows]:
     print(f"{g[0]:9.1f} us at t={g[3]:8.2f} ms   after [{g[1]}]   before [{g[2]}]")
+
+print("\nhost ops running inside the 8 largest gaps (top-level ops only):")
+for g in sorted(gaps, reverse=True)[:8]:
+    lo, hi = g[4], g[5]
+    inside = [c for c in cpu if c.time_range.start >= lo - 50 and c.time_range.start < hi]
+    top, last_end = [], -1
+    for c in inside:                      # keep outermost ops
+        if c.time_range.start >= last_end:
+            top.append(c)
+            last_end = c.time_range.end
+    print(f"--- gap {g[0]:.0f} us at t={g[3]:.2f} ms: {len(inside)} host ops, outermost:")
+    for c in top[:40]:
+        print(f"      {c.time_range.start - lo:8.1f} us  +{c.time_range.end - c.time_range.start:7.1f}  {c.name[:80]}")
