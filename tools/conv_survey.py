@@ -19,7 +19,13 @@ with torch.autocast("cuda", dtype=torch.bfloat16):
     m(x, t)
 for h in hs: h.remove()
 rows = []
+# CONV_SURVEY_BENCHMARK=1: let MIOpen search its solvers exhaustively (slow: seconds per layer);
+# CONV_SURVEY_MAXCIN=n: only layers with <= n input channels (48 = the stem)
+torch.backends.cudnn.benchmark = os.environ.get("CONV_SURVEY_BENCHMARK", "0") == "1"
+max_cin = int(os.environ.get("CONV_SURVEY_MAXCIN", "100000"))
 for (ishape, wshape, stride, pad), cnt in cfgs.items():
+    if ishape[1] > max_cin:
+        continue
     xi = torch.randn(ishape, device=dev, dtype=torch.bfloat16, requires_grad=True)
     w = torch.randn(wshape, device=dev, dtype=torch.bfloat16, requires_grad=True)
     def fwd(): return F.conv2d(xi, w, None, stride, pad)
