@@ -20,6 +20,7 @@ SOURCES = {
     "losses.hip": ["-munsafe-fp-atomics"],
     "optim.hip": ["-munsafe-fp-atomics"],
     "conv.hip": ["-munsafe-fp-atomics"],
+    "stem.hip": ["-munsafe-fp-atomics"],
 }
 
 

@@ -1,0 +1,573 @@
+// A1 - HGNetv2 stem (src/d_fine/arch/hgnetv2.py:115-166): the five convolutions in front of stage 1 have
+// 3..48 channels on 640x640..160x160 planes.  They are pure bandwidth layers (236-354 MB of bf16
+// activations, 2-17 GFLOP), but MIOpen serves them with generic kernels at 15-30 TFLOP/s: 1.65 ms forward
+// and 4.2 ms backward per D-FINE-m step (profiles/r01_conv_survey_hip_vs_miopen.txt), plus two F.pad
+// copies and a max-pool over the padded map.  Here:
+//   * stem_conv_kernel      direct convolution, one thread per output pixel holding all output channels in
+//                           registers; weights are wave-uniform and come through the scalar cache.  Reads
+//                           outside the plane return 0, which also implements F.pad(x, (0,1,0,1)) in front
+//                           of the 2x2 convs.  With flipped/transposed weights the same kernel is the data
+//                           gradient of the stride-1 layers.
+//   * stem_dgrad_s2_kernel  data gradient of the 3x3 stride-2 layer: a thread owns two adjacent input
+//                           pixels of one row, so the tap set is uniform per block (row parity) and fixed
+//                           per pixel of the pair.
+//   * stem_wgrad_kernel     weight gradient on the MFMA units: M = output channels, N = (input channel,
+//                           tap) columns, K = 32 consecutive output pixels; every wave is an independent
+//                           worker (column group, pixel range) and writes fp32 partial sums.
+//   * stem_pool_*           2x2 stride-1 max-pool over the zero-padded map, forward and backward
+//                           (argmax recomputed from the input, first maximum in scan order like ATen).
+#include "common.h"
+
+namespace dfine {
+
+constexpr int kStemThreads = 256;
+typedef __attribute__((ext_vector_type(8))) __bf16 stem_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float stem_f32x4;
+
+// mode 0: wp[(ci*KS+ky)*KS+kx][co] = w[co][ci][ky][kx]                        (forward)
+// mode 1: wp[(co*KS+ky)*KS+kx][ci] = w[co][ci][KS-1-ky][KS-1-kx]              (stride-1 data gradient)
+// mode 2: wp[(co*KS+ky)*KS+kx][ci] = w[co][ci][ky][kx]                        (stride-2 data gradient)
+__global__ void stem_pack_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout, int Cin, int KS,
+                                 int mode) {
+    const int total = Cout * Cin * KS * KS;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int kx = i % KS, ky = (i / KS) % KS, ci = (i / (KS * KS)) % Cin, co = i / (KS * KS * Cin);
+    const float v = w[i];
+    if (mode == 0) wp[((ci * KS + ky) * KS + kx) * Cout + co] = v;
+    else if (mode == 1) wp[((co * KS + (KS - 1 - ky)) * KS + (KS - 1 - kx)) * Cin + ci] = v;
+    else wp[((co * KS + ky) * KS + kx) * Cin + ci] = v;
+}
+
+// y[b][co][yo][xo] = sum_{ci,ky,kx} x[b][ci][yo*S+ky-pad][xo*S+kx-pad] * wp[(ci,ky,kx)][co]   (0 outside the plane)
+template <int CIN, int COUT, int KS, int S>
+__global__ __launch_bounds__(kStemThreads) void stem_conv_kernel(const uint16_t *__restrict__ x,
+                                                                 const float *__restrict__ wp,
+                                                                 uint16_t *__restrict__ y, int H, int W, int Ho,
+                                                                 int Wo, int pad) {
+    const int p = blockIdx.x * kStemThreads + threadIdx.x;
+    const int b = blockIdx.y;
+    if (p >= Ho * Wo) return;
+    const int yo = p / Wo, xo = p - yo * Wo;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+    const uint16_t *xb = x + (int64_t)b * CIN * H * W;
+    const int yi0 = yo * S - pad, xi0 = xo * S - pad;
+    // tap offsets / validity do not depend on the channel; loads are unconditional (clamped address, value
+    // zeroed afterwards) so that the KS*KS loads of a channel are all in flight before the first FMA
+    int toff[KS * KS];
+    bool tok[KS * KS];
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const int yi = yi0 + ky, xi = xi0 + kx;
+            const bool ok = (unsigned)yi < (unsigned)H && (unsigned)xi < (unsigned)W;
+            tok[ky * KS + kx] = ok;
+            toff[ky * KS + kx] = ok ? yi * W + xi : 0;
+        }
+    }
+    uint16_t raw[KS * KS], nxt[KS * KS];
+#pragma unroll
+    for (int t = 0; t < KS * KS; ++t) raw[t] = xb[toff[t]];
+    for (int ci = 0; ci < CIN; ++ci) {
+        const float *wc = wp + ci * (KS * KS * COUT);           // wave-uniform -> scalar loads
+        const uint16_t *xn = xb + (int64_t)min(ci + 1, CIN - 1) * H * W;        // next channel's taps in flight
+#pragma unroll
+        for (int t = 0; t < KS * KS; ++t) nxt[t] = xn[toff[t]];
+#pragma unroll
+        for (int t = 0; t < KS * KS; ++t) {
+            const float v = tok[t] ? bf16_to_f32(raw[t]) : 0.f;
+            const float *wk = wc + t * COUT;
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[co] = fmaf(v, wk[co], acc[co]);
+        }
+#pragma unroll
+        for (int t = 0; t < KS * KS; ++t) raw[t] = nxt[t];
+    }
+    uint16_t *yb = y + (int64_t)b * COUT * Ho * Wo + p;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) yb[(int64_t)co * Ho * Wo] = f32_to_bf16(acc[co]);
+}
+
+// dx[b][ci][yi][xi] of a 3x3 / stride 2 / pad 1 convolution; dy [B, COUT, Ho, Wo], H = 2*Ho, W = 2*Wo.
+// wq[((co*3+ky)*3+kx)][ci].  thread = (row yi, pixel pair 2c / 2c+1).
+template <int CIN, int COUT>
+__global__ __launch_bounds__(kStemThreads) void stem_dgrad_s2_kernel(const uint16_t *__restrict__ dy,
+                                                                     const float *__restrict__ wq,
+                                                                     uint16_t *__restrict__ dx, int H, int W, int Ho,
+                                                                     int Wo) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int yi = blockIdx.y, b = blockIdx.z;
+    if (c >= Wo) return;
+    float a0[CIN], a1[CIN];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) { a0[ci] = 0.f; a1[ci] = 0.f; }
+    const bool odd = yi & 1;
+    const int ntap = odd ? 2 : 1;
+    const uint16_t *dyb = dy + (int64_t)b * COUT * Ho * Wo;
+    const bool has1 = c + 1 < Wo;
+    const int c1 = has1 ? c + 1 : c;
+    // rows of dy feeding this input row: (yi + 1 - ky) even -> ky = 1 (even yi) or ky in {0, 2} (odd yi)
+    int ky_t[2], yo_t[2];
+    bool ok_t[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        ky_t[t] = odd ? 2 * t : 1;
+        yo_t[t] = (yi + 1 - ky_t[t]) >> 1;
+        ok_t[t] = t < ntap && yo_t[t] >= 0 && yo_t[t] < Ho;      // uniform per block
+        yo_t[t] = min(max(yo_t[t], 0), Ho - 1);
+    }
+    const int total = COUT * ntap;
+    uint16_t r0 = dyb[(int64_t)yo_t[0] * Wo + c], r1 = dyb[(int64_t)yo_t[0] * Wo + c1];
+    for (int it = 0; it < total; ++it) {
+        const int co = odd ? it >> 1 : it, t = odd ? it & 1 : 0;
+        // next (co, tap) pair's two loads are issued before this pair's FMAs
+        const int itn = min(it + 1, total - 1);
+        const int con = odd ? itn >> 1 : itn, tn = odd ? itn & 1 : 0;
+        const uint16_t *rown = dyb + ((int64_t)con * Ho + yo_t[tn]) * Wo;
+        const uint16_t n0 = rown[c], n1 = rown[c1];
+        if (ok_t[t]) {
+            const float d0 = bf16_to_f32(r0);
+            const float d1 = has1 ? bf16_to_f32(r1) : 0.f;
+            const float *wk = wq + (co * 3 + ky_t[t]) * 3 * CIN;  // wave-uniform
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                a0[ci] = fmaf(d0, wk[CIN + ci], a0[ci]);                           // xi = 2c   : kx = 1, xo = c
+                a1[ci] = fmaf(d1, wk[ci], fmaf(d0, wk[2 * CIN + ci], a1[ci]));     // xi = 2c+1 : kx = 0 (xo = c+1), kx = 2 (xo = c)
+            }
+        }
+        r0 = n0; r1 = n1;
+    }
+    uint16_t *o = dx + ((int64_t)b * CIN * H + yi) * W + 2 * c;
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+        *reinterpret_cast<uint32_t *>(o + (int64_t)ci * H * W) = (uint32_t)f32_to_bf16(a0[ci]) | ((uint32_t)f32_to_bf16(a1[ci]) << 16);
+}
+
+// 8 bf16 elements x[xi0 + j*S], j = 0..7, of one plane row as a packed MFMA fragment (0 outside [0, W)).
+// One (S = 1) or two (S = 2) 16-byte loads from a start clamped into the row - 2-byte aligned, the hardware
+// runs in unaligned-access mode - then a shift by the clamp distance (|d| <= 1 element: pad <= 1, KS <= 3).
+typedef uint32_t stem_u32x4_u __attribute__((ext_vector_type(4), aligned(2)));
+
+template <int S>
+__device__ __forceinline__ uint4 stem_row8(const uint16_t *rowp, int xi0, int W, bool row_ok) {
+    constexpr int SPAN = 8 * S;
+    const int xs = min(max(xi0, 0), W - SPAN);
+    const int d = xs - xi0;                                      // +1: window starts one element late, -1: one early
+    uint4 r;
+    if (S == 1) {
+        const stem_u32x4_u v = *reinterpret_cast<const stem_u32x4_u *>(rowp + xs);
+        if (d == 0) { r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; }
+        else if (d > 0) { r.x = v.x << 16; r.y = (v.y << 16) | (v.x >> 16); r.z = (v.z << 16) | (v.y >> 16); r.w = (v.w << 16) | (v.z >> 16); }
+        else { r.x = (v.x >> 16) | (v.y << 16); r.y = (v.y >> 16) | (v.z << 16); r.z = (v.z >> 16) | (v.w << 16); r.w = v.w >> 16; }
+    } else {
+        const stem_u32x4_u a = *reinterpret_cast<const stem_u32x4_u *>(rowp + xs);
+        const stem_u32x4_u b = *reinterpret_cast<const stem_u32x4_u *>(rowp + xs + 8);
+        if (d == 0) {          // element j = low half of dword j
+            r.x = (a.x & 0xffffu) | (a.y << 16); r.y = (a.z & 0xffffu) | (a.w << 16);
+            r.z = (b.x & 0xffffu) | (b.y << 16); r.w = (b.z & 0xffffu) | (b.w << 16);
+        } else if (d < 0) {    // element j = high half of dword j
+            r.x = (a.x >> 16) | (a.y & 0xffff0000u); r.y = (a.z >> 16) | (a.w & 0xffff0000u);
+            r.z = (b.x >> 16) | (b.y & 0xffff0000u); r.w = (b.z >> 16) | (b.w & 0xffff0000u);
+        } else {               // element 0 is outside, element j = high half of dword j - 1
+            r.x = a.x & 0xffff0000u;                 r.y = (a.y >> 16) | (a.z & 0xffff0000u);
+            r.z = (a.w >> 16) | (b.x & 0xffff0000u); r.w = (b.y >> 16) | (b.z & 0xffff0000u);
+        }
+    }
+    if (!row_ok) r = make_uint4(0, 0, 0, 0);
+    return r;
+}
+
+// dw[co][ci][ky][kx] = sum_{b,yo,xo} dy[b][co][yo][xo] * x[b][ci][yo*S+ky-pad][xo*S+kx-pad].
+// part[split][co][n], n = (ci*KS+ky)*KS+kx.  Wo % 32 == 0, COUT <= 32.
+constexpr int kStemNT = 4;          // 16-column tiles per worker
+template <int S>
+__global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(const uint16_t *__restrict__ x,
+                                                                  const uint16_t *__restrict__ dy,
+                                                                  float *__restrict__ part, int CIN, int COUT, int KS,
+                                                                  int pad, int H, int W, int Ho, int Wo,
+                                                                  int ngroups, int nsplit, int total_steps,
+                                                                  int steps_per_split) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int worker = blockIdx.x * (kStemThreads / 64) + wave;
+    const int g = worker % ngroups, split = worker / ngroups;
+    if (split >= nsplit) return;
+    const int ncols = CIN * KS * KS;
+    const int kk = KS * KS;
+    int col_off[kStemNT], col_ky[kStemNT], col_kx[kStemNT];
+#pragma unroll
+    for (int t = 0; t < kStemNT; ++t) {
+        const int n = (g * kStemNT + t) * 16 + (lane & 15);
+        const bool ok = n < ncols;
+        const int ci = ok ? n / kk : 0, tap = ok ? n - ci * kk : 0;
+        col_off[t] = ok ? ci * H * W : -1;
+        col_ky[t] = tap / KS;
+        col_kx[t] = tap - (tap / KS) * KS;
+    }
+    stem_f32x4 acc[kStemNT][2];
+#pragma unroll
+    for (int t = 0; t < kStemNT; ++t) { acc[t][0] = stem_f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = stem_f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int wsteps = Wo / 32;
+    const int kg = lane >> 4;
+    const int s0 = split * steps_per_split, s1 = min(total_steps, s0 + steps_per_split);
+    for (int step = s0; step < s1; ++step) {
+        const int b = step / (Ho * wsteps);
+        const int r = step - b * (Ho * wsteps);
+        const int yo = r / wsteps, xo0 = (r - yo * wsteps) * 32 + 8 * kg;
+        stem_bf16x8 a[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int co = mt * 16 + (lane & 15);
+            uint4 av = make_uint4(0, 0, 0, 0);
+            if (co < COUT) av = *reinterpret_cast<const uint4 *>(dy + (((int64_t)b * COUT + co) * Ho + yo) * Wo + xo0);
+            a[mt] = __builtin_bit_cast(stem_bf16x8, av);
+        }
+        const uint16_t *xb = x + (int64_t)b * CIN * H * W;
+#pragma unroll
+        for (int t = 0; t < kStemNT; ++t) {
+            if ((g * kStemNT + t) * 16 >= ncols) break;          // uniform
+            const int yi = yo * S + col_ky[t] - pad;
+            const bool row_ok = col_off[t] >= 0 && (unsigned)yi < (unsigned)H;
+            const uint16_t *rowp = xb + (row_ok ? col_off[t] + yi * W : 0);
+            const int xi0 = xo0 * S + col_kx[t] - pad;
+            const uint4 bv = stem_row8<S>(rowp, xi0, W, row_ok);
+            const stem_bf16x8 bf = __builtin_bit_cast(stem_bf16x8, bv);
+            acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bf, acc[t][0], 0, 0, 0);
+            if (COUT > 16) acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bf, acc[t][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kStemNT; ++t) {
+        const int n = (g * kStemNT + t) * 16 + (lane & 15);
+        if (n >= ncols) continue;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = mt * 16 + 4 * kg + r;
+                if (co < COUT) part[((int64_t)split * COUT + co) * ncols + n] = acc[t][mt][r];
+            }
+        }
+    }
+}
+
+// dw (zeroed by the caller) += sum over this block's chunk of splits; 64 columns x 4 split lanes per block
+__global__ void stem_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, int nsplit, int total,
+                                         int splits_per_block) {
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;
+    const int k0 = blockIdx.y * splits_per_block, k1 = min(nsplit, k0 + splits_per_block);
+    float s0 = 0.f, s1 = 0.f;
+    if (i < total) {
+        int k = k0 + q;
+        for (; k + 4 < k1; k += 8) { s0 += part[(int64_t)k * total + i]; s1 += part[(int64_t)(k + 4) * total + i]; }
+        for (; k < k1; k += 4) s0 += part[(int64_t)k * total + i];
+    }
+    red[q][col] = s0 + s1;
+    __syncthreads();
+    if (q == 0 && i < total) unsafeAtomicAdd(dw + i, (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]));
+}
+
+// 2x2 / stride 1 max-pool over the map padded by one zero row / column at the bottom / right.
+__global__ void stem_pool_fwd_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ y, int H, int W, int64_t planes) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * H * W) return;
+    const int64_t pl = i / (H * W);
+    const int r = (int)(i - pl * H * W);
+    const int yy = r / W, xx = r - yy * W;
+    const uint16_t *p = x + pl * H * W;
+    const bool hx = xx + 1 < W, hy = yy + 1 < H;
+    const int y1 = hy ? yy + 1 : yy, x1 = hx ? xx + 1 : xx;
+    const uint16_t r00 = p[yy * W + xx], r01 = p[yy * W + x1], r10 = p[y1 * W + xx], r11 = p[y1 * W + x1];
+    float m = bf16_to_f32(r00);
+    float v = hx ? bf16_to_f32(r01) : 0.f;
+    if (v > m || v != v) m = v;
+    v = hy ? bf16_to_f32(r10) : 0.f;
+    if (v > m || v != v) m = v;
+    v = (hx && hy) ? bf16_to_f32(r11) : 0.f;
+    if (v > m || v != v) m = v;
+    y[i] = f32_to_bf16(m);
+}
+
+// position (0..3) of the first maximum among (a, b, c, d) = window scan order, strict >
+__device__ __forceinline__ int first_max4(float a, float b, float c, float d) {
+    float m = a;
+    int k = 0;
+    if (b > m || b != b) { m = b; k = 1; }
+    if (c > m || c != c) { m = c; k = 2; }
+    if (d > m || d != d) { k = 3; }
+    return k;
+}
+
+__global__ void stem_pool_bwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy, uint16_t *__restrict__ dx,
+                                     int H, int W, int64_t planes) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * H * W) return;
+    const int64_t pl = i / (H * W);
+    const int r = (int)(i - pl * H * W);
+    const int yy = r / W, xx = r - yy * W;
+    const uint16_t *p = x + pl * H * W, *g = dy + pl * H * W;
+    // 3x3 neighbourhood of x around (yy, xx) (0 past the bottom / right edge = the zero pad; rows / columns
+    // before the plane only belong to windows that do not exist) and the four window gradients
+    const int ym = yy > 0 ? yy - 1 : yy, xm = xx > 0 ? xx - 1 : xx;
+    const bool hx = xx + 1 < W, hy = yy + 1 < H;
+    const int yp = hy ? yy + 1 : yy, xp = hx ? xx + 1 : xx;
+    uint16_t raw[9];
+    raw[0] = p[ym * W + xm]; raw[1] = p[ym * W + xx]; raw[2] = p[ym * W + xp];
+    raw[3] = p[yy * W + xm]; raw[4] = p[yy * W + xx]; raw[5] = p[yy * W + xp];
+    raw[6] = p[yp * W + xm]; raw[7] = p[yp * W + xx]; raw[8] = p[yp * W + xp];
+    const uint16_t g00 = g[ym * W + xm], g01 = g[ym * W + xx], g10 = g[yy * W + xm], g11 = g[yy * W + xx];
+    float n[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) n[k] = bf16_to_f32(raw[k]);
+    if (!hx) { n[2] = 0.f; n[5] = 0.f; n[8] = 0.f; }
+    if (!hy) { n[6] = 0.f; n[7] = 0.f; n[8] = 0.f; }
+    float s = 0.f;
+    // window origin (yy-1, xx-1): (yy, xx) is its position 3; (yy-1, xx): position 2; (yy, xx-1): position 1; (yy, xx): 0
+    if (yy > 0 && xx > 0 && first_max4(n[0], n[1], n[3], n[4]) == 3) s += bf16_to_f32(g00);
+    if (yy > 0 && first_max4(n[1], n[2], n[4], n[5]) == 2) s += bf16_to_f32(g01);
+    if (xx > 0 && first_max4(n[3], n[4], n[6], n[7]) == 1) s += bf16_to_f32(g10);
+    if (first_max4(n[4], n[5], n[7], n[8]) == 0) s += bf16_to_f32(g11);
+    dx[i] = f32_to_bf16(s);
+}
+
+// ---- 8 pixels per thread (W % 8 == 0): one 16-byte load per row instead of eight 2-byte loads -----------------
+__device__ __forceinline__ void unpack8(const uint4 &v, float (&o)[8]) {
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&o)[8]) {
+    uint4 r;
+    r.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+    r.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+    r.z = (uint32_t)f32_to_bf16(o[4]) | ((uint32_t)f32_to_bf16(o[5]) << 16);
+    r.w = (uint32_t)f32_to_bf16(o[6]) | ((uint32_t)f32_to_bf16(o[7]) << 16);
+    return r;
+}
+// row[-1 .. 8] of a plane row around column x0 (x0 % 8 == 0): e[0] = column x0-1, e[1..8] = x0..x0+7, e[9] = x0+8;
+// columns outside [0, W) and rows outside [0, H) read as `fill`
+__device__ __forceinline__ void load_row10(const uint16_t *p, int y, int x0, int H, int W, float fill, float (&e)[10]) {
+    const bool row_ok = y >= 0 && y < H;
+    const int yc = min(max(y, 0), H - 1);
+    const uint16_t *r = p + (int64_t)yc * W;
+    const uint4 v = *reinterpret_cast<const uint4 *>(r + x0);
+    const uint16_t l = r[max(x0 - 1, 0)], rr = r[min(x0 + 8, W - 1)];
+    float m[8];
+    unpack8(v, m);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j + 1] = row_ok ? m[j] : fill;
+    e[0] = (row_ok && x0 > 0) ? bf16_to_f32(l) : fill;
+    e[9] = (row_ok && x0 + 8 < W) ? bf16_to_f32(rr) : fill;
+}
+
+__global__ void stem_pool_fwd8_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ y, int H, int W, int64_t planes) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // 8-pixel vector index
+    const int wv = W >> 3;
+    if (i >= planes * H * wv) return;
+    const int64_t pl = i / (H * wv);
+    const int r = (int)(i - pl * H * wv);
+    const int yy = r / wv, x0 = (r - yy * wv) * 8;
+    const uint16_t *p = x + pl * H * W;
+    float a[10], b[10], o[8];
+    load_row10(p, yy, x0, H, W, 0.f, a);
+    load_row10(p, yy + 1, x0, H, W, 0.f, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float m = a[j + 1], v = a[j + 2];
+        if (v > m || v != v) m = v;
+        v = b[j + 1];
+        if (v > m || v != v) m = v;
+        v = b[j + 2];
+        if (v > m || v != v) m = v;
+        o[j] = m;
+    }
+    *reinterpret_cast<uint4 *>(y + pl * H * W + (int64_t)yy * W + x0) = pack8(o);
+}
+
+__global__ void stem_pool_bwd8_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy, uint16_t *__restrict__ dx,
+                                      int H, int W, int64_t planes) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int wv = W >> 3;
+    if (i >= planes * H * wv) return;
+    const int64_t pl = i / (H * wv);
+    const int r = (int)(i - pl * H * wv);
+    const int yy = r / wv, x0 = (r - yy * wv) * 8;
+    const uint16_t *p = x + pl * H * W, *g = dy + pl * H * W;
+    float n0[10], n1[10], n2[10], g0[10], g1[10], o[8];
+    load_row10(p, yy - 1, x0, H, W, 0.f, n0);       // rows / columns before the plane only feed windows that do not exist
+    load_row10(p, yy, x0, H, W, 0.f, n1);
+    load_row10(p, yy + 1, x0, H, W, 0.f, n2);
+    load_row10(g, yy - 1, x0, H, W, 0.f, g0);
+    load_row10(g, yy, x0, H, W, 0.f, g1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = j + 1, xx = x0 + j;             // e[c] = column xx
+        float s = 0.f;
+        if (yy > 0 && xx > 0 && first_max4(n0[c - 1], n0[c], n1[c - 1], n1[c]) == 3) s += g0[c - 1];
+        if (yy > 0 && first_max4(n0[c], n0[c + 1], n1[c], n1[c + 1]) == 2) s += g0[c];
+        if (xx > 0 && first_max4(n1[c - 1], n1[c], n2[c - 1], n2[c]) == 1) s += g1[c - 1];
+        if (first_max4(n1[c], n1[c + 1], n2[c], n2[c + 1]) == 0) s += g1[c];
+        o[j] = s;
+    }
+    *reinterpret_cast<uint4 *>(dx + pl * H * W + (int64_t)yy * W + x0) = pack8(o);
+}
+
+struct StemCfg { int cin, cout, ks, s; };
+
+template <int CIN, int COUT, int KS, int S>
+static void launch_stem(const uint16_t *x, const float *wp, uint16_t *y, int B, int H, int W, int Ho, int Wo, int pad,
+                        hipStream_t st) {
+    dim3 grid((Ho * Wo + kStemThreads - 1) / kStemThreads, B);
+    hipLaunchKernelGGL((stem_conv_kernel<CIN, COUT, KS, S>), grid, dim3(kStemThreads), 0, st, x, wp, y, H, W, Ho, Wo, pad);
+}
+
+}  // namespace dfine
+
+using namespace dfine;
+
+extern "C" {
+
+int dfine_stem_supported(int Cin, int Cout, int KS, int stride) {
+    // forward configurations (the data gradient of a stride-1 layer is the same kernel with the channel counts swapped)
+    static const StemCfg ok[] = {{3, 24, 3, 2}, {24, 12, 2, 1}, {12, 24, 2, 1}, {48, 24, 3, 2}, {24, 32, 1, 1},
+                                 {3, 16, 3, 2}, {16, 8, 2, 1}, {8, 16, 2, 1}, {32, 16, 3, 2}, {16, 16, 1, 1},
+                                 {3, 32, 3, 2}, {32, 16, 2, 1}, {16, 32, 2, 1}, {64, 32, 3, 2}, {32, 48, 1, 1}, {32, 64, 1, 1},
+                                 {32, 24, 1, 1}, {48, 32, 1, 1}, {64, 32, 1, 1}};
+    for (const StemCfg &c : ok)
+        if (c.cin == Cin && c.cout == Cout && c.ks == KS && c.s == stride) return 1;
+    return 0;
+}
+
+int dfine_stem_pack_weights(const float *w, float *wp, int Cout, int Cin, int KS, int mode, void *stream) {
+    if (!w || !wp || Cout < 1 || Cin < 1 || KS < 1 || mode < 0 || mode > 2) return DFINE_E_BADARG;
+    const int total = Cout * Cin * KS * KS;
+    hipLaunchKernelGGL(stem_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, KS, mode);
+    return check_launch();
+}
+
+// Direct convolution y[B,Cout,Ho,Wo] = conv(x[B,Cin,H,W]) with zero fill outside the plane; wp from
+// dfine_stem_pack_weights(mode 0) - or mode 1 with Cin/Cout exchanged (stride-1 data gradient, pad' = KS-1-pad).
+int dfine_stem_conv_bf16(const void *x, const float *wp, void *y, int B, int Cin, int Cout, int H, int W, int Ho, int Wo,
+                         int KS, int stride, int pad, void *stream) {
+    if (B == 0) return DFINE_OK;
+    if (!x || !wp || !y || H < 1 || W < 1 || Ho < 1 || Wo < 1) return DFINE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const uint16_t *xs = (const uint16_t *)x;
+    uint16_t *ys = (uint16_t *)y;
+#define STEM_CASE(CI, CO, K, S_)                                                         \
+    if (Cin == CI && Cout == CO && KS == K && stride == S_) {                            \
+        launch_stem<CI, CO, K, S_>(xs, wp, ys, B, H, W, Ho, Wo, pad, st);                \
+        return check_launch();                                                           \
+    }
+    // B2 (D-FINE-m): 3->24, 24->12, 12->24, 48->24, 24->32 and the stride-1 data gradients (channels swapped)
+    STEM_CASE(3, 24, 3, 2) STEM_CASE(24, 12, 2, 1) STEM_CASE(12, 24, 2, 1) STEM_CASE(48, 24, 3, 2) STEM_CASE(24, 32, 1, 1)
+    STEM_CASE(32, 24, 1, 1)
+    // B0 (n / s): 3->16, 16->8, 8->16, 32->16, 16->16
+    STEM_CASE(3, 16, 3, 2) STEM_CASE(16, 8, 2, 1) STEM_CASE(8, 16, 2, 1) STEM_CASE(32, 16, 3, 2) STEM_CASE(16, 16, 1, 1)
+    // B4 / B5 (l / x): 3->32, 32->16, 16->32, 64->32, 32->48 / 32->64
+    STEM_CASE(3, 32, 3, 2) STEM_CASE(32, 16, 2, 1) STEM_CASE(16, 32, 2, 1) STEM_CASE(64, 32, 3, 2) STEM_CASE(32, 48, 1, 1)
+    STEM_CASE(48, 32, 1, 1) STEM_CASE(32, 64, 1, 1) STEM_CASE(64, 32, 1, 1)
+#undef STEM_CASE
+    return DFINE_E_BADARG;
+}
+
+// Data gradient of a 3x3 / stride 2 / pad 1 layer: dy [B,Cout,Ho,Wo] -> dx [B,Cin,2*Ho,2*Wo]; wq from
+// dfine_stem_pack_weights(mode 2).
+int dfine_stem_dgrad_s2_bf16(const void *dy, const float *wq, void *dx, int B, int Cin, int Cout, int Ho, int Wo,
+                             void *stream) {
+    if (B == 0) return DFINE_OK;
+    if (!dy || !wq || !dx || Ho < 1 || Wo < 1) return DFINE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int bt = Wo >= kStemThreads ? kStemThreads : (Wo + 63) / 64 * 64;       // e.g. Wo = 160 -> 192 threads
+    dim3 grid((Wo + bt - 1) / bt, 2 * Ho, B);
+#define STEM_DG(CI, CO)                                                                                         \
+    if (Cin == CI && Cout == CO) {                                                                              \
+        hipLaunchKernelGGL((stem_dgrad_s2_kernel<CI, CO>), grid, dim3(bt), 0, st, (const uint16_t *)dy, wq, \
+                           (uint16_t *)dx, 2 * Ho, 2 * Wo, Ho, Wo);                                             \
+        return check_launch();                                                                                  \
+    }
+    STEM_DG(48, 24) STEM_DG(32, 16) STEM_DG(64, 32)
+#undef STEM_DG
+    return DFINE_E_BADARG;
+}
+
+static void stem_wgrad_plan(int B, int Cin, int KS, int Ho, int Wo, int *ngroups, int *nsplit, int *steps) {
+    const int ntile = (Cin * KS * KS + 15) / 16;
+    *ngroups = (ntile + kStemNT - 1) / kStemNT;
+    const int total = B * Ho * (Wo / 32);
+    int sp = 6144 / *ngroups;                          // ~6000 workers = 24 waves per CU
+    const int cap = (int)(32000000 / ((int64_t)Cin * KS * KS * 32 * 4)) + 1;   // fp32 partials <= ~32 MB
+    if (sp > cap) sp = cap;
+    if (sp > total) sp = total;
+    if (sp < 1) sp = 1;
+    *steps = (total + sp - 1) / sp;
+    *nsplit = (total + *steps - 1) / *steps;
+}
+
+int64_t dfine_stem_wgrad_ws_floats(int B, int Cin, int Cout, int KS, int Ho, int Wo) {
+    int ng, ns, st;
+    stem_wgrad_plan(B, Cin, KS, Ho, Wo, &ng, &ns, &st);
+    return (int64_t)ns * Cout * Cin * KS * KS;
+}
+
+// dw [Cout,Cin,KS,KS] f32 (overwritten).  Wo % 32 == 0, Cout <= 32.
+int dfine_stem_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, int B, int Cin, int Cout, int H, int W,
+                          int Ho, int Wo, int KS, int stride, int pad, void *stream) {
+    if (B == 0) return DFINE_OK;
+    if (!x || !dy || !dw || !ws || Cout > 32 || Cout < 1 || Cin < 1 || Wo % 32 || KS < 1 || KS > 3 || pad > 1 ||
+        (stride != 1 && stride != 2) || W < 8 * stride)
+        return DFINE_E_BADARG;
+    int ng, ns, steps;
+    stem_wgrad_plan(B, Cin, KS, Ho, Wo, &ng, &ns, &steps);
+    const int workers = ng * ns;
+    hipStream_t st = (hipStream_t)stream;
+    if (stride == 1)
+        hipLaunchKernelGGL(stem_wgrad_kernel<1>, dim3((workers + 3) / 4), dim3(kStemThreads), 0, st, (const uint16_t *)x,
+                           (const uint16_t *)dy, ws, Cin, Cout, KS, pad, H, W, Ho, Wo, ng, ns, B * Ho * (Wo / 32), steps);
+    else
+        hipLaunchKernelGGL(stem_wgrad_kernel<2>, dim3((workers + 3) / 4), dim3(kStemThreads), 0, st, (const uint16_t *)x,
+                           (const uint16_t *)dy, ws, Cin, Cout, KS, pad, H, W, Ho, Wo, ng, ns, B * Ho * (Wo / 32), steps);
+    if (int e = check_launch()) return e;
+    const int total = Cout * Cin * KS * KS;
+    (void)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)total, st);
+    const int colblocks = (total + 63) / 64;
+    int chunks = 1024 / colblocks;                       // ~1024 blocks whatever the weight size
+    if (chunks < 1) chunks = 1;
+    if (chunks > ns) chunks = ns;
+    const int spb = (ns + chunks - 1) / chunks;
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(colblocks, (ns + spb - 1) / spb), dim3(256), 0, st, ws, dw, ns, total, spb);
+    return check_launch();
+}
+
+int dfine_stem_pool_fwd(const void *x, void *y, int64_t planes, int H, int W, void *stream) {
+    if (planes == 0) return DFINE_OK;
+    if (!x || !y || H < 1 || W < 1) return DFINE_E_BADARG;
+    const int64_t n = planes * H * W;
+    if (W % 8 == 0)
+        hipLaunchKernelGGL(stem_pool_fwd8_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t *)x, (uint16_t *)y, H, W, planes);
+    else
+        hipLaunchKernelGGL(stem_pool_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t *)x, (uint16_t *)y, H, W, planes);
+    return check_launch();
+}
+
+int dfine_stem_pool_bwd(const void *x, const void *dy, void *dx, int64_t planes, int H, int W, void *stream) {
+    if (planes == 0) return DFINE_OK;
+    if (!x || !dy || !dx || H < 1 || W < 1) return DFINE_E_BADARG;
+    const int64_t n = planes * H * W;
+    if (W % 8 == 0)
+        hipLaunchKernelGGL(stem_pool_bwd8_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t *)x, (const uint16_t *)dy, (uint16_t *)dx, H, W, planes);
+    else
+        hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t *)x, (const uint16_t *)dy, (uint16_t *)dx, H, W, planes);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -47,14 +47,15 @@ class ConvBNAct(nn.Module):
         self.act = nn.ReLU() if use_act else nn.Identity()
         self.lab = LearnableAffineBlock() if (use_act and use_lab) else nn.Identity()
 
-    def forward(self, x):
+    def forward(self, x, pad_br=False):
+        """pad_br: the input stands for F.pad(x, (0, 1, 0, 1)) (StemBlock); the pad is applied inside."""
         if isinstance(self.conv, nn.Sequential):
             x = self.conv[0](x)
             conv = self.conv[1]
         else:
             conv = self.conv
         lab = self.lab if isinstance(self.lab, LearnableAffineBlock) else None
-        return kernels.conv_bn_act(x, conv, self.bn, "relu" if self.use_act else None, lab)
+        return kernels.conv_bn_act(x, conv, self.bn, "relu" if self.use_act else None, lab, pad_br=pad_br)
 
 
 class LightConvBNAct(nn.Module):
@@ -83,9 +84,11 @@ class StemBlock(nn.Module):
         self.pool = nn.MaxPool2d(kernel_size=2, stride=1, ceil_mode=True)
 
     def forward(self, x):
-        x = F.pad(self.stem1(x), (0, 1, 0, 1))
-        branch = self.stem2b(F.pad(self.stem2a(x), (0, 1, 0, 1)))
-        x = torch.cat([self.pool(x), branch], dim=1)
+        # the two F.pad(., (0,1,0,1)) of the reference are folded into their consumers: the 2x2 convs and
+        # the max-pool read zeros past the bottom / right edge (HIP stem kernels; ATen composition on CPU)
+        x = self.stem1(x)
+        branch = self.stem2b(self.stem2a(x, pad_br=True), pad_br=True)
+        x = torch.cat([kernels.stem_pool(x), branch], dim=1)
         return self.stem4(self.stem3(x))
 
 

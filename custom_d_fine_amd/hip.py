@@ -55,6 +55,14 @@ _SIGNATURES = {
     "dfine_topk_anchors": (c_int, [_P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfine_linear_wgrad_ws_floats": (_L, [_I, _I, _I]),
     "dfine_linear_wgrad_bf16": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "dfine_stem_supported": (c_int, [_I, _I, _I, _I]),
+    "dfine_stem_pack_weights": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "dfine_stem_conv_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_stem_dgrad_s2_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfine_stem_wgrad_ws_floats": (_L, [_I, _I, _I, _I, _I, _I]),
+    "dfine_stem_wgrad_bf16": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_stem_pool_fwd": (c_int, [_P, _P, _L, _I, _I, _P]),
+    "dfine_stem_pool_bwd": (c_int, [_P, _P, _P, _L, _I, _I, _P]),
     "dfine_bn_act_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 for _name, (_res, _args) in _SIGNATURES.items():
@@ -513,3 +521,67 @@ def linear_wgrad_bf16(x2d, dy2d, with_bias=False):
         _check(_lib.dfine_linear_wgrad_bf16(_ptr(x2d), _ptr(dy2d), _ptr(dw), _ptr(db), _ptr(ws), M, N, K, _stream()),
                "dfine_linear_wgrad_bf16")
     return (dw, db) if with_bias else dw
+
+
+# ------------------------------------------------------------------------------------- HGNetv2 stem
+def stem_supported(cin, cout, ks, stride):
+    return bool(_lib.dfine_stem_supported(cin, cout, ks, stride))
+
+
+def stem_pack_weights(weight_f32, mode):
+    """mode 0 forward, 1 stride-1 data gradient, 2 stride-2 data gradient (see dfine_hip.h)."""
+    cout, cin, ks, _ = weight_f32.shape
+    wp = torch.empty(weight_f32.numel(), device=weight_f32.device, dtype=torch.float32)
+    _check(_lib.dfine_stem_pack_weights(_ptr(weight_f32), _ptr(wp), cout, cin, ks, mode, _stream()),
+           "dfine_stem_pack_weights")
+    return wp
+
+
+def stem_conv(x, wp, cout, ks, stride, pad, out_hw):
+    """x [B, Cin, H, W] bf16 contiguous -> y [B, cout, *out_hw] bf16 (zero fill outside the plane)."""
+    B, cin, H, W = x.shape
+    ho, wo = out_hw
+    y = torch.empty(B, cout, ho, wo, device=x.device, dtype=torch.bfloat16)
+    with _timed("dfine_stem_conv_bf16"):
+        _check(_lib.dfine_stem_conv_bf16(_ptr(x), _ptr(wp), _ptr(y), B, cin, cout, H, W, ho, wo, ks, stride, pad,
+                                         _stream()), "dfine_stem_conv_bf16")
+    return y
+
+
+def stem_dgrad_s2(dy, wq, cin):
+    B, cout, ho, wo = dy.shape
+    dx = torch.empty(B, cin, 2 * ho, 2 * wo, device=dy.device, dtype=torch.bfloat16)
+    _check(_lib.dfine_stem_dgrad_s2_bf16(_ptr(dy), _ptr(wq), _ptr(dx), B, cin, cout, ho, wo, _stream()),
+           "dfine_stem_dgrad_s2_bf16")
+    return dx
+
+
+_STEM_WS = {}
+
+
+def stem_wgrad(x, dy, ks, stride, pad):
+    B, cin, H, W = x.shape
+    _, cout, ho, wo = dy.shape
+    need = int(_lib.dfine_stem_wgrad_ws_floats(B, cin, cout, ks, ho, wo))
+    key = (x.device.index, _stream())
+    ws = _STEM_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _STEM_WS[key] = torch.empty(need, device=x.device, dtype=torch.float32)
+    dw = torch.empty(cout, cin, ks, ks, device=x.device, dtype=torch.float32)
+    _check(_lib.dfine_stem_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ho, wo, ks, stride,
+                                      pad, _stream()), "dfine_stem_wgrad_bf16")
+    return dw
+
+
+def stem_pool_forward(x):
+    B, C, H, W = x.shape
+    y = torch.empty_like(x)
+    _check(_lib.dfine_stem_pool_fwd(_ptr(x), _ptr(y), B * C, H, W, _stream()), "dfine_stem_pool_fwd")
+    return y
+
+
+def stem_pool_backward(x, dy):
+    B, C, H, W = x.shape
+    dx = torch.empty_like(x)
+    _check(_lib.dfine_stem_pool_bwd(_ptr(x), _ptr(dy), _ptr(dx), B * C, H, W, _stream()), "dfine_stem_pool_bwd")
+    return dx

@@ -433,6 +433,120 @@ class _DenseConvMFMA(_DenseConv):
         return y
 
 
+# ---- HGNetv2 stem: direct small-channel convolutions + pad-fused max-pool (csrc/stem.hip) ------------
+_STEM_DGRAD_S2 = {(48, 24), (32, 16), (64, 32)}      # (Cin, Cout) of the instantiated 3x3 / stride-2 data gradients
+
+
+def _packed_stem(weight, mode):
+    key = (id(weight), "stem", mode)
+    tag = (_WEIGHT_EPOCH, weight._version, weight.data_ptr())
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    wp = _hip().stem_pack_weights(weight.detach().float().contiguous(), mode)
+    _PACK_CACHE[key] = (tag, wp)
+    return wp
+
+
+class _StemConv(torch.autograd.Function):
+    """Stem convolution (3x3/s2, 2x2/s1 on the bottom/right zero-padded map, 1x1), NCHW bf16."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad, pad_br):
+        hip = _hip()
+        x = x.contiguous()
+        cout, cin, ks, _ = weight.shape
+        H, W = x.shape[2], x.shape[3]
+        if pad_br:
+            ho, wo = (H + 1 + 2 * pad - ks) // stride + 1, (W + 1 + 2 * pad - ks) // stride + 1
+        else:
+            ho, wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+        y = hip.stem_conv(x, _packed_stem(weight, 0), cout, ks, stride, pad, (ho, wo))
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        hip = _hip()
+        x, weight = ctx.saved_tensors
+        stride, pad = ctx.cfg
+        cout, cin, ks, _ = weight.shape
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if stride == 1:
+                dx = hip.stem_conv(dy, _packed_stem(weight, 1), cin, ks, 1, ks - 1 - pad, (x.shape[2], x.shape[3]))
+            else:
+                dx = hip.stem_dgrad_s2(dy, _packed_stem(weight, 2), cin)
+        if ctx.needs_input_grad[1]:
+            dw = hip.stem_wgrad(x, dy, ks, stride, pad).to(weight.dtype)
+        return dx, dw, None, None, None
+
+
+class _StemPool(torch.autograd.Function):
+    """MaxPool2d(2, stride 1, ceil_mode) of F.pad(x, (0, 1, 0, 1)) without materialising the padded map."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return _hip().stem_pool_forward(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        return _hip().stem_pool_backward(x, dy)
+
+
+def stem_fast_path(x):
+    """The stem kernels serve CUDA tensors under bf16 autocast (the training / bf16 inference path)."""
+    return (x.is_cuda and _env("DFINE_HIP_UNITS", "1") == "1" and _env("DFINE_STEM", "1") == "1"
+            and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+
+
+def stem_pool(x):
+    """pool(F.pad(x, (0,1,0,1))) of StemBlock (ref hgnetv2.py:158-160)."""
+    if stem_fast_path(x) and x.dtype == torch.bfloat16:
+        return _StemPool.apply(x)
+    return F.max_pool2d(F.pad(x, (0, 1, 0, 1)), kernel_size=2, stride=1, ceil_mode=True)
+
+
+def _stem_conv_ok(conv, x, pad_br):
+    if not (stem_fast_path(x) and x.dim() == 4 and conv.groups == 1 and conv.bias is None and conv.dilation == (1, 1)):
+        return False
+    k, s = conv.kernel_size, conv.stride
+    if k[0] != k[1] or s[0] != s[1] or not isinstance(conv.padding, tuple) or conv.padding[0] != conv.padding[1]:
+        return False
+    ks, st, pad = k[0], s[0], conv.padding[0]
+    cin, cout = conv.in_channels, conv.out_channels
+    hip = _hip()
+    if not hip.stem_supported(cin, cout, ks, st) or cout > 32:
+        return False
+    H, W = x.shape[2], x.shape[3]
+    if pad_br:
+        if not (ks == 2 and st == 1 and pad == 0):
+            return False
+        wo = W
+    else:
+        if ks == 2:
+            return False
+        wo = (W + 2 * pad - ks) // st + 1
+    if wo % 32:
+        return False                                    # MFMA weight-gradient kernel: 32-pixel K steps
+    if st == 1:
+        return hip.stem_supported(cout, cin, ks, 1)     # data gradient = same kernel, channels swapped
+    if st == 2:
+        return ks == 3 and pad == 1 and H % 2 == 0 and W % 2 == 0 and (
+            (cin, cout) in _STEM_DGRAD_S2 or not x.requires_grad)
+    return False
+
+
 def _mfma_conv_ok(conv, x):
     """Layers the implicit-GEMM kernels can serve (1x1 / 3x3, stride 1, 'same' padding, bf16 autocast)."""
     k = conv.kernel_size
@@ -452,7 +566,8 @@ def _is_depthwise(conv):
             and isinstance(conv.padding, tuple))
 
 
-def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Optional[nn.Module]):
+def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Optional[nn.Module],
+                pad_br: bool = False):
     """conv(bias=False) -> BN (batch stats in training) -> {None, relu, silu} -> scalar affine; the
     building block of HGNetv2 and the HybridEncoder.
     GPU: depthwise convs and the whole BN/act/affine tail are HIP kernels; dense convs are still
@@ -463,10 +578,13 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
             if torch.is_autocast_enabled() and x.dtype == torch.float32:
                 x = x.to(torch.get_autocast_dtype("cuda"))      # what autocast would do for F.conv2d
             y = _DepthwiseConv.apply(x, conv.weight, conv.stride[0], conv.padding[0])
-        elif _mfma_conv_ok(conv, x):
+        elif not pad_br and _mfma_conv_ok(conv, x):
             y = _DenseConv.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv.weight)
+        elif _stem_conv_ok(conv, x, pad_br):
+            y = _StemConv.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv.weight,
+                                conv.stride[0], conv.padding[0], pad_br)
         else:
-            y = conv(x)
+            y = conv(F.pad(x, (0, 1, 0, 1)) if pad_br else x)
         if isinstance(bn, nn.BatchNorm2d) and bn.track_running_stats and bn.momentum is not None:
             training = bn.training
             if training:
@@ -485,7 +603,7 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
                                 a, False, 0.0, bn.eps)
         y = bn(y)
     else:
-        y = bn(conv(x))
+        y = bn(conv(F.pad(x, (0, 1, 0, 1)) if pad_br else x))
     if act is not None:
         a = act.lower()
         if a == "relu":

@@ -268,6 +268,36 @@ int64_t dfine_linear_wgrad_ws_floats(int M, int N, int K);
 int dfine_linear_wgrad_bf16(const void *x, const void *dy, float *dw, float *db, float *ws, int M, int N,
                             int K, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * A1  HGNetv2 stem (src/d_fine/arch/hgnetv2.py:115-166: stem1 3x3/s2, F.pad + stem2a / stem2b 2x2,
+ * MaxPool2d(2, 1, ceil_mode) on the padded map, stem3 3x3/s2, stem4 1x1): direct small-channel
+ * convolutions in NCHW bf16 with fp32 accumulation.  Reads outside the plane return 0, which is both the
+ * symmetric conv padding and the F.pad(x, (0, 1, 0, 1)) in front of the 2x2 layers.
+ *   dfine_stem_supported      1 when (Cin, Cout, KS, stride) is an instantiated forward configuration.
+ *   dfine_stem_pack_weights   fp32 master weights [Cout,Cin,KS,KS] -> wp (same element count).
+ *                             mode 0: forward [(ci,ky,kx)][co]; mode 1: stride-1 data gradient
+ *                             [(co,ky,kx) flipped][ci]; mode 2: stride-2 data gradient [(co,ky,kx)][ci].
+ *   dfine_stem_conv_bf16      y [B,Cout,Ho,Wo] = conv(x [B,Cin,H,W]); with mode-1 weights, Cin/Cout
+ *                             exchanged and pad' = KS-1-pad it is the data gradient of a stride-1 layer.
+ *   dfine_stem_dgrad_s2_bf16  data gradient of a 3x3 / stride 2 / pad 1 layer (dx [B,Cin,2Ho,2Wo]).
+ *   dfine_stem_wgrad_bf16     dw [Cout,Cin,KS,KS] f32 (overwritten) on the MFMA units; Wo % 32 == 0,
+ *                             Cout <= 32; ws: dfine_stem_wgrad_ws_floats(...) floats.
+ *   dfine_stem_pool_fwd/_bwd  2x2 / stride 1 max-pool over the map padded by one zero row and column
+ *                             (bottom / right); the backward pass recomputes the argmax (first maximum in
+ *                             scan order, as ATen's max_pool2d) from x.  planes = B * C.
+ */
+int dfine_stem_supported(int Cin, int Cout, int KS, int stride);
+int dfine_stem_pack_weights(const float *w, float *wp, int Cout, int Cin, int KS, int mode, void *stream);
+int dfine_stem_conv_bf16(const void *x, const float *wp, void *y, int B, int Cin, int Cout, int H, int W,
+                         int Ho, int Wo, int KS, int stride, int pad, void *stream);
+int dfine_stem_dgrad_s2_bf16(const void *dy, const float *wq, void *dx, int B, int Cin, int Cout, int Ho,
+                             int Wo, void *stream);
+int64_t dfine_stem_wgrad_ws_floats(int B, int Cin, int Cout, int KS, int Ho, int Wo);
+int dfine_stem_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, int B, int Cin, int Cout,
+                          int H, int W, int Ho, int Wo, int KS, int stride, int pad, void *stream);
+int dfine_stem_pool_fwd(const void *x, void *y, int64_t planes, int H, int W, void *stream);
+int dfine_stem_pool_bwd(const void *x, const void *dy, void *dx, int64_t planes, int H, int W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
