@@ -12,6 +12,7 @@ are marked "ATen plumbing" - they run the same code on CPU and GPU and are the n
 replaced by HIP kernels (DESIGN.md "kernel status").
 """
 import os
+import weakref
 from typing import List, Optional
 
 import torch
@@ -316,10 +317,10 @@ def _packed_weights(weight, dgrad):
     key = (id(weight), dgrad)
     tag = (_WEIGHT_EPOCH, weight._version, weight.data_ptr())
     hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0] == tag:
+    if hit is not None and hit[0] == tag and hit[2]() is weight:     # id() of a freed tensor can be reused
         return hit[1]
     w2 = _hip().conv_pack_weights(weight.detach().float().contiguous(), dgrad)
-    _PACK_CACHE[key] = (tag, w2)
+    _PACK_CACHE[key] = (tag, w2, weakref.ref(weight))
     return w2
 
 
@@ -441,10 +442,10 @@ def _packed_stem(weight, mode):
     key = (id(weight), "stem", mode)
     tag = (_WEIGHT_EPOCH, weight._version, weight.data_ptr())
     hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0] == tag:
+    if hit is not None and hit[0] == tag and hit[2]() is weight:
         return hit[1]
     wp = _hip().stem_pack_weights(weight.detach().float().contiguous(), mode)
-    _PACK_CACHE[key] = (tag, wp)
+    _PACK_CACHE[key] = (tag, wp, weakref.ref(weight))
     return wp
 
 
