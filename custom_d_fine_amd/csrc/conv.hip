@@ -52,6 +52,30 @@ __global__ void conv_pack_weights_kernel(const float *__restrict__ w, uint16_t *
     }
 }
 
+// All layers in one launch: table rows of 8 x int64 = {src ptr, dst ptr, Cout, Cin, KS, NP, KP, dgrad}; blockIdx.y =
+// row, blockIdx.x strides over the row's packed elements (176 pack launches per train step otherwise).
+__global__ void conv_pack_weights_multi_kernel(const int64_t *__restrict__ table) {
+    const int64_t *e = table + (int64_t)blockIdx.y * 8;
+    const float *w = reinterpret_cast<const float *>(e[0]);
+    uint16_t *w2 = reinterpret_cast<uint16_t *>(e[1]);
+    const int Cout = (int)e[2], Cin = (int)e[3], KS = (int)e[4], NP = (int)e[5], KP = (int)e[6], dgrad = (int)e[7];
+    const int total = KS * KS * NP * KP;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int k = i % KP;
+        const int n = (i / KP) % NP;
+        const int tap = i / (KP * NP);
+        float v = 0.f;
+        if (!dgrad) {
+            if (n < Cout && k < Cin) v = w[((int64_t)n * Cin + k) * KS * KS + tap];
+        } else {
+            const int r = tap / KS, s = tap % KS;
+            const int src_tap = (KS - 1 - r) * KS + (KS - 1 - s);
+            if (n < Cin && k < Cout) v = w[((int64_t)k * Cin + n) * KS * KS + src_tap];
+        }
+        w2[i] = f32_to_bf16(v);
+    }
+}
+
 template <int VEC> struct PixVec;
 template <> struct PixVec<8> { typedef uint4 type; };
 template <> struct PixVec<4> { typedef uint2 type; };
@@ -513,6 +537,16 @@ int dfine_conv_pack_weights(const float *w, void *w2, int Cout, int Cin, int KS,
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (uint16_t *)w2, Cout,
                        Cin, KS, NP, KP, dgrad);
+    return check_launch();
+}
+
+// Packs n_entries weight tensors with one launch.  table: device int64 [n_entries][8] =
+// {w ptr (fp32 [Cout,Cin,KS,KS]), w2 ptr, Cout, Cin, KS, NP, KP, dgrad} with NP / KP as in dfine_conv_packed_elems.
+int dfine_conv_pack_weights_multi(const void *table, int n_entries, void *stream) {
+    if (n_entries == 0) return DFINE_OK;
+    if (!table || n_entries < 0) return DFINE_E_BADARG;
+    hipLaunchKernelGGL(conv_pack_weights_multi_kernel, dim3(64, n_entries), dim3(256), 0, (hipStream_t)stream,
+                       (const int64_t *)table);
     return check_launch();
 }
 

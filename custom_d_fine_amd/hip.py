@@ -47,6 +47,7 @@ _SIGNATURES = {
     "dfine_multi_copy_f32": (c_int, [_P, _I, _P, _P]),
     "dfine_conv_packed_elems": (_L, [_I, _I, _I, _I]),
     "dfine_conv_pack_weights": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "dfine_conv_pack_weights_multi": (c_int, [_P, _I, _P]),
     "dfine_conv_fwd_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_conv_wgrad_ws_floats": (_L, [_I, _I, _I, _I, _I, _I]),
     "dfine_conv_wgrad_bf16": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -420,6 +421,15 @@ def conv_pack_weights(weight_f32, dgrad):
     _check(_lib.dfine_conv_pack_weights(_ptr(weight_f32), _ptr(w2), cout, cin, ks, 1 if dgrad else 0, _stream()),
            "dfine_conv_pack_weights")
     return w2
+
+
+def conv_packed_elems(cout, cin, ks, dgrad):
+    return int(_lib.dfine_conv_packed_elems(cout, cin, ks, 1 if dgrad else 0))
+
+
+def conv_pack_weights_multi(table, n_entries):
+    """table: device int64 [n_entries, 8] (see dfine_conv_pack_weights_multi)."""
+    _check(_lib.dfine_conv_pack_weights_multi(_ptr(table), n_entries, _stream()), "dfine_conv_pack_weights_multi")
 
 
 def conv_forward_bf16(x, w2, cout, ks):

@@ -309,18 +309,65 @@ def bump_weight_epoch():
 _CAPTURE_POSSIBLE = False      # set by dl.engine.GraphedSegment: only then is the capture query worth a call per layer
 
 
+# Every (weight, layout) pair the model has asked for is remembered; the first request after an optimizer step
+# repacks ALL of them with one launch (their master weights are views of the flat parameter buffer and the
+# packed buffers persist, so the device table is built once) instead of one pack launch per layer and layout.
+_PACK_REGISTRY = {}        # key -> [weakref(weight), dgrad, packed tensor, data_ptr, version]
+_PACK_TABLE = None         # (device table, n_entries, registry size when built)
+_PACK_BATCH_EPOCH = -1
+
+
+def _pack_all_registered(device):
+    global _PACK_TABLE, _PACK_BATCH_EPOCH
+    import numpy as np
+    hip = _hip()
+    dead = [k for k, e in _PACK_REGISTRY.items() if e[0]() is None]
+    for k in dead:
+        del _PACK_REGISTRY[k]
+        _PACK_TABLE = None
+    stale = _PACK_TABLE is None or _PACK_TABLE[2] != len(_PACK_REGISTRY)
+    if not stale:
+        for e in _PACK_REGISTRY.values():
+            if e[0]().data_ptr() != e[3]:
+                stale = True
+                break
+    if stale:
+        rows = []
+        for e in _PACK_REGISTRY.values():
+            w = e[0]()
+            cout, cin, ks, _ = w.shape
+            n, kk = (cin, cout) if e[1] else (cout, cin)
+            rows.append((w.data_ptr(), e[2].data_ptr(), cout, cin, ks, (n + 15) // 16 * 16, (kk + 31) // 32 * 32, int(e[1])))
+            e[3] = w.data_ptr()
+        from .d_fine.arch.utils import upload
+        _PACK_TABLE = (upload(np.asarray(rows, dtype=np.int64), device), len(rows), len(_PACK_REGISTRY))
+    hip.conv_pack_weights_multi(_PACK_TABLE[0], _PACK_TABLE[1])
+    for e in _PACK_REGISTRY.values():
+        e[4] = e[0]()._version
+    _PACK_BATCH_EPOCH = _WEIGHT_EPOCH
+
+
 def _packed_weights(weight, dgrad):
     if _CAPTURE_POSSIBLE and torch.cuda.is_current_stream_capturing():
         # inside a HIP-graph capture the pack launch itself must be recorded (the weights change
         # between replays), so never serve or fill the cache here
         return _hip().conv_pack_weights(weight.detach().float().contiguous(), dgrad)
     key = (id(weight), dgrad)
-    tag = (_WEIGHT_EPOCH, weight._version, weight.data_ptr())
-    hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0] == tag and hit[2]() is weight:     # id() of a freed tensor can be reused
-        return hit[1]
+    ent = _PACK_REGISTRY.get(key)
+    batchable = weight.dtype == torch.float32 and weight.is_contiguous()
+    if ent is not None and ent[0]() is weight and batchable:
+        if _PACK_BATCH_EPOCH != _WEIGHT_EPOCH:
+            _pack_all_registered(weight.device)
+        if ent[4] == weight._version and ent[3] == weight.data_ptr():
+            return ent[2]
+        # updated in place by torch since the batch pack (plain optimizers): repack this one
+        _check_w = _hip().conv_pack_weights(weight.detach(), dgrad)
+        ent[2].copy_(_check_w)
+        ent[3], ent[4] = weight.data_ptr(), weight._version
+        return ent[2]
     w2 = _hip().conv_pack_weights(weight.detach().float().contiguous(), dgrad)
-    _PACK_CACHE[key] = (tag, w2, weakref.ref(weight))
+    if batchable:
+        _PACK_REGISTRY[key] = [weakref.ref(weight), dgrad, w2, weight.data_ptr(), weight._version]
     return w2
 
 

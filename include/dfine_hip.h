@@ -222,6 +222,9 @@ int dfine_multi_copy_f32(const void *table, int n_entries, float *dst, void *str
  */
 int64_t dfine_conv_packed_elems(int Cout, int Cin, int KS, int dgrad);
 int dfine_conv_pack_weights(const float *w, void *w2, int Cout, int Cin, int KS, int dgrad, void *stream);
+/* All layers of a step in one launch: device table int64 [n_entries][8] = {w, w2, Cout, Cin, KS, NP, KP, dgrad}
+ * (NP = n rounded up to 16, KP = k rounded up to 32 with (n, k) = dgrad ? (Cin, Cout) : (Cout, Cin)). */
+int dfine_conv_pack_weights_multi(const void *table, int n_entries, void *stream);
 int dfine_conv_fwd_bf16(const void *x, const void *w2, void *y, int B, int Cin, int Cout, int H, int W,
                         int KS, void *stream);
 /* Weight gradient of the same convolution: dw [Cout, Cin, KS, KS] f32 (overwritten) from x [B,Cin,H,W]
