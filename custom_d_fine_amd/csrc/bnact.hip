@@ -188,16 +188,61 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 
+// Finalize folded into the apply kernels (layers with C * nchunk <= kBnFuseMax): part == nullptr -> not fused.
+constexpr int kBnFuseMax = 8192;
+struct BnFusedFin {
+    const float *part;
+    int nchunk;
+    double count;
+    const float *gamma, *beta;
+    float *running_mean, *running_var, *mean_out, *invstd_out, *scale_out, *shift_out;
+    float momentum, eps;
+};
+struct BnFusedBwdFin {
+    const float *part;                 // [C][nchunk][4]
+    int nchunk;
+    double count;
+    float *dgamma, *dbeta, *dlab, *coef;
+};
+
 // bf16, HW % 8 == 0: 16-byte vectors, two independent vectors per thread and iteration
 __global__ __launch_bounds__(kBnThreads) void bn_apply_flat8_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ y,
                                                                     const float *__restrict__ scale,
                                                                     const float *__restrict__ shift,
                                                                     const float *__restrict__ lab_s,
                                                                     const float *__restrict__ lab_b, int C, int HW,
-                                                                    int64_t nvec, int act) {
+                                                                    int64_t nvec, int act, BnFusedFin fin) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_sc = smem, *s_sh = smem + C;
-    for (int i = threadIdx.x; i < C; i += kBnThreads) { s_sc[i] = scale[i]; s_sh[i] = shift[i]; }
+    if (fin.part) {
+        // small layers: every block folds the chunk partials of all channels itself (a few KB of L2 reads) instead
+        // of waiting for a separate finalize launch; block 0 also publishes the statistics
+        for (int c = threadIdx.x; c < C; c += kBnThreads) {
+            double sm = 0.0, ss = 0.0;
+            for (int k = 0; k < fin.nchunk; ++k) {
+                sm += (double)fin.part[((int64_t)c * fin.nchunk + k) * 2];
+                ss += (double)fin.part[((int64_t)c * fin.nchunk + k) * 2 + 1];
+            }
+            const double mean = sm / fin.count;
+            double var = ss / fin.count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)fin.eps));
+            const float g = fin.gamma ? fin.gamma[c] : 1.f, bt = fin.beta ? fin.beta[c] : 0.f;
+            const float sc = g * invstd, sh = bt - (float)mean * g * invstd;
+            s_sc[c] = sc; s_sh[c] = sh;
+            if (blockIdx.x == 0) {
+                fin.mean_out[c] = (float)mean; fin.invstd_out[c] = invstd;
+                fin.scale_out[c] = sc; fin.shift_out[c] = sh;
+                if (fin.running_mean) {
+                    const double unbiased = fin.count > 1.0 ? var * fin.count / (fin.count - 1.0) : var;
+                    fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * (float)mean;
+                    fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unbiased;
+                }
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < C; i += kBnThreads) { s_sc[i] = scale[i]; s_sh[i] = shift[i]; }
+    }
     const float ls = lab_s ? lab_s[0] : 1.f, lb = lab_b ? lab_b[0] : 0.f;
     __syncthreads();
     const uint32_t nv = HW >> 3;
@@ -229,13 +274,31 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_flat8_kernel(
     const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy, uint16_t *__restrict__ dx,
     const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ scale,
     const float *__restrict__ shift, const float *__restrict__ lab_s, const float *__restrict__ coef, int C, int HW,
-    int64_t nvec, int act, int train) {
+    int64_t nvec, int act, int train, BnFusedBwdFin fin) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_mu = smem, *s_is = smem + C, *s_sc = smem + 2 * C, *s_sh = smem + 3 * C, *s_m0 = smem + 4 * C,
           *s_m1 = smem + 5 * C;
     for (int i = threadIdx.x; i < C; i += kBnThreads) {
         s_mu[i] = mean ? mean[i] : 0.f; s_is[i] = invstd ? invstd[i] : 0.f; s_sc[i] = scale[i]; s_sh[i] = shift[i];
-        s_m0[i] = train ? coef[2 * i] : 0.f; s_m1[i] = train ? coef[2 * i + 1] : 0.f;
+        if (fin.part) {
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            for (int k = 0; k < fin.nchunk; ++k) {
+                const float *p = fin.part + ((int64_t)i * fin.nchunk + k) * 4;
+                s0 += p[0]; s1 += p[1]; s2 += p[2]; s3 += p[3];
+            }
+            const float m0 = (float)(s0 / fin.count), m1 = (float)(s1 / fin.count);
+            s_m0[i] = train ? m0 : 0.f; s_m1[i] = train ? m1 : 0.f;
+            if (blockIdx.x == 0) {
+                if (fin.dgamma) fin.dgamma[i] = (float)s1;
+                if (fin.dbeta) fin.dbeta[i] = (float)s0;
+                if (fin.dlab) {                                  // zeroed by the caller
+                    unsafeAtomicAdd(fin.dlab, (float)s2);
+                    unsafeAtomicAdd(fin.dlab + 1, (float)s3);
+                }
+            }
+        } else {
+            s_m0[i] = train ? coef[2 * i] : 0.f; s_m1[i] = train ? coef[2 * i + 1] : 0.f;
+        }
     }
     const float ls = lab_s ? lab_s[0] : 1.f;
     __syncthreads();
@@ -476,6 +539,8 @@ int dfine_bn_act_fwd(const void *x, void *y, const float *gamma, const float *be
     if (dtype != DFINE_F32 && dtype != DFINE_BF16) return DFINE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const int cb = (C + 127) / 128;
+    bool fuse_fin = false;
+    BnFusedFin ffin{};
     if (training) {
         if (!ws || !save_mean || !save_invstd) return DFINE_E_BADARG;
         int per;
@@ -484,8 +549,13 @@ int dfine_bn_act_fwd(const void *x, void *y, const float *gamma, const float *be
             hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(C, nchunk), dim3(kBnThreads), 0, st, (const float *)x, ws, C, HW, B, per);
         else
             hipLaunchKernelGGL(bn_stats_kernel<uint16_t>, dim3(C, nchunk), dim3(kBnThreads), 0, st, (const uint16_t *)x, ws, C, HW, B, per);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(cb), dim3(128), 0, st, ws, nchunk, C, (double)B * HW, gamma, beta,
-                           running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
+        fuse_fin = dtype != DFINE_F32 && (HW & 7) == 0 && C <= 4096 && (int64_t)C * nchunk <= kBnFuseMax;
+        if (fuse_fin)
+            ffin = BnFusedFin{ws, nchunk, (double)B * HW, gamma, beta, running_mean, running_var, save_mean, save_invstd,
+                              scale, shift, momentum, eps};
+        else
+            hipLaunchKernelGGL(bn_finalize_kernel, dim3(cb), dim3(128), 0, st, ws, nchunk, C, (double)B * HW, gamma, beta,
+                               running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
     } else {
         if (!running_mean || !running_var) return DFINE_E_BADARG;
         hipLaunchKernelGGL(bn_fold_kernel, dim3(cb), dim3(128), 0, st, C, gamma, beta, running_mean, running_var, eps, scale, shift);
@@ -500,7 +570,7 @@ int dfine_bn_act_fwd(const void *x, void *y, const float *gamma, const float *be
             int64_t nb8 = (nvec8 + kBnThreads * 4 - 1) / (kBnThreads * 4);
             if (nb8 > 4096) nb8 = 4096;
             hipLaunchKernelGGL(bn_apply_flat8_kernel, dim3((unsigned)nb8), dim3(kBnThreads), sm, st, (const uint16_t *)x,
-                               (uint16_t *)y, scale, shift, lab_scale, lab_bias, C, HW, nvec8, act);
+                               (uint16_t *)y, scale, shift, lab_scale, lab_bias, C, HW, nvec8, act, ffin);
             return check_launch();
         }
         if (dtype == DFINE_F32)
@@ -538,8 +608,13 @@ int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<uint16_t>, dim3(C, nchunk), dim3(kBnThreads), 0, st, (const uint16_t *)x,
                            (const uint16_t *)dy, ws, save_mean ? save_mean : scale, save_invstd ? save_invstd : scale, scale, shift,
                            lab_scale, C, HW, B, per, act);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, ws, nchunk, C, (double)B * HW,
-                       dgamma, dbeta, dlab, coef);
+    const bool fuse_fin = dtype != DFINE_F32 && (HW & 7) == 0 && (HW & 3) == 0 && C <= 2048 && (int64_t)C * nchunk <= kBnFuseMax;
+    BnFusedBwdFin bfin{};
+    if (fuse_fin)
+        bfin = BnFusedBwdFin{ws, nchunk, (double)B * HW, dgamma, dbeta, dlab, coef};
+    else
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, ws, nchunk, C, (double)B * HW,
+                           dgamma, dbeta, dlab, coef);
     if ((HW & 3) == 0 && C <= 2048) {
         const int64_t nvec = (int64_t)B * C * HW / 4;
         int64_t nb = (nvec + kBnThreads * 4 - 1) / (kBnThreads * 4);
@@ -551,7 +626,7 @@ int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_
             if (nb8 > 4096) nb8 = 4096;
             hipLaunchKernelGGL(bn_bwd_apply_flat8_kernel, dim3((unsigned)nb8), dim3(kBnThreads), sm, st, (const uint16_t *)x,
                                (const uint16_t *)dy, (uint16_t *)dx, save_mean, save_invstd, scale, shift, lab_scale, coef, C, HW,
-                               nvec8, act, training);
+                               nvec8, act, training, bfin);
             return check_launch();
         }
         if (dtype == DFINE_F32)
