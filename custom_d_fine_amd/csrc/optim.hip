@@ -104,6 +104,15 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(const CopyEntry *__rest
     }
 }
 
+// bf16 shadow copies of many fp32 parameters with one launch: table[i] = {src pointer, dst (bf16) pointer, count}.
+struct CastEntry { const float *src; uint16_t *dst; int64_t n; };
+
+__global__ __launch_bounds__(256) void multi_cast_bf16_kernel(const CastEntry *__restrict__ table) {
+    const CastEntry e = table[blockIdx.y];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < e.n; i += (int64_t)gridDim.x * 256)
+        e.dst[i] = f32_to_bf16(e.src[i]);
+}
+
 static int grid_for(int64_t n, int per_thread) {
     int64_t b = (n / per_thread + 255) / 256;
     if (b > 4096) b = 4096;
@@ -144,6 +153,14 @@ int dfine_multi_copy_f32(const void *table, int n_entries, float *dst, void *str
     if (n_entries == 0) return DFINE_OK;
     if (!table || !dst || n_entries < 0) return DFINE_E_BADARG;
     hipLaunchKernelGGL(multi_copy_kernel, dim3(n_entries), dim3(256), 0, (hipStream_t)stream, (const CopyEntry *)table, dst);
+    return check_launch();
+}
+
+// table: DEVICE array of n_entries {const float* src; bf16* dst; int64 n} records (24 bytes each).
+int dfine_multi_cast_bf16(const void *table, int n_entries, void *stream) {
+    if (n_entries == 0) return DFINE_OK;
+    if (!table || n_entries < 0) return DFINE_E_BADARG;
+    hipLaunchKernelGGL(multi_cast_bf16_kernel, dim3(16, n_entries), dim3(256), 0, (hipStream_t)stream, (const CastEntry *)table);
     return check_launch();
 }
 

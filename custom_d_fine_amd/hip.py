@@ -45,6 +45,7 @@ _SIGNATURES = {
     "dfine_adamw_ema_step": (c_int, [_P, _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _I, _F, _F, _F, _P]),
     "dfine_ema_update": (c_int, [_P, _P, _L, _F, _P]),
     "dfine_multi_copy_f32": (c_int, [_P, _I, _P, _P]),
+    "dfine_multi_cast_bf16": (c_int, [_P, _I, _P]),
     "dfine_conv_packed_elems": (_L, [_I, _I, _I, _I]),
     "dfine_conv_pack_weights": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "dfine_conv_pack_weights_multi": (c_int, [_P, _I, _P]),
@@ -495,6 +496,11 @@ def multi_copy_f32(srcs, dst_offsets, dst_flat, chunk=1 << 16):
     table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dst_flat.device, non_blocking=True)
     _check(_lib.dfine_multi_copy_f32(_ptr(table), len(rows), _ptr(dst_flat), _stream()), "dfine_multi_copy_f32")
     return table      # keep alive until the stream has consumed it
+
+
+def multi_cast_bf16(table, n_entries):
+    """table: device int64 [n_entries, 3] = (fp32 src pointer, bf16 dst pointer, element count)."""
+    _check(_lib.dfine_multi_cast_bf16(_ptr(table), n_entries, _stream()), "dfine_multi_cast_bf16")
 
 
 # ------------------------------------------------------------------------------------- query selection

@@ -371,6 +371,60 @@ def _packed_weights(weight, dgrad):
     return w2
 
 
+# bf16 shadow copies of fp32 parameters (what autocast would re-cast at every use): all registered parameters are
+# refreshed with ONE launch on the first request after an optimizer step (same protocol as the packed conv weights).
+_BF16_REGISTRY = {}        # id(param) -> [weakref(param), bf16 copy, data_ptr, version]
+_BF16_TABLE = None
+_BF16_EPOCH = -1
+
+
+def _refresh_bf16_params(device):
+    global _BF16_TABLE, _BF16_EPOCH
+    import numpy as np
+    dead = [k for k, e in _BF16_REGISTRY.items() if e[0]() is None]
+    for k in dead:
+        del _BF16_REGISTRY[k]
+        _BF16_TABLE = None
+    stale = _BF16_TABLE is None or _BF16_TABLE[2] != len(_BF16_REGISTRY)
+    if not stale:
+        for e in _BF16_REGISTRY.values():
+            if e[0]().data_ptr() != e[2]:
+                stale = True
+                break
+    if stale:
+        rows = []
+        for e in _BF16_REGISTRY.values():
+            p = e[0]()
+            rows.append((p.data_ptr(), e[1].data_ptr(), p.numel()))
+            e[2] = p.data_ptr()
+        from .d_fine.arch.utils import upload
+        _BF16_TABLE = (upload(np.asarray(rows, dtype=np.int64), device), len(rows), len(_BF16_REGISTRY))
+    _hip().multi_cast_bf16(_BF16_TABLE[0], _BF16_TABLE[1])
+    for e in _BF16_REGISTRY.values():
+        e[3] = e[0]()._version
+    _BF16_EPOCH = _WEIGHT_EPOCH
+
+
+def bf16_param(p):
+    """bf16 copy of an fp32 CUDA parameter, cached until the weights change."""
+    if p.dtype == torch.bfloat16:
+        return p.detach()
+    if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()) or (
+            _CAPTURE_POSSIBLE and torch.cuda.is_current_stream_capturing()):
+        return p.detach().to(torch.bfloat16)
+    ent = _BF16_REGISTRY.get(id(p))
+    if ent is not None and ent[0]() is p:
+        if _BF16_EPOCH != _WEIGHT_EPOCH:
+            _refresh_bf16_params(p.device)
+        if ent[3] != p._version or ent[2] != p.data_ptr():       # changed in place by plain torch code
+            ent[1].copy_(p.detach())
+            ent[2], ent[3] = p.data_ptr(), p._version
+        return ent[1]
+    c = p.detach().to(torch.bfloat16)
+    _BF16_REGISTRY[id(p)] = [weakref.ref(p), c, p.data_ptr(), p._version]
+    return c
+
+
 def _time_op(fn, reps=4):
     fn()
     torch.cuda.synchronize()
@@ -435,7 +489,7 @@ class _DenseConv(torch.autograd.Function):
         if plan["fwd"]:
             y = hip.conv_forward_bf16(x, _packed_weights(weight, False), weight.shape[0], ks)
         else:
-            y = F.conv2d(x, weight.detach().to(torch.bfloat16), None, 1, ks // 2)
+            y = F.conv2d(x, bf16_param(weight), None, 1, ks // 2)
         ctx.save_for_backward(x, weight)
         ctx.plan = plan
         return y
@@ -455,7 +509,7 @@ class _DenseConv(torch.autograd.Function):
         aten_dx, aten_dw = need_dx and not plan["dgrad"], need_dw and not plan["wgrad"]
         if aten_dx or aten_dw:
             res = torch.ops.aten.convolution_backward(
-                dy, x, weight.detach().to(torch.bfloat16), None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
+                dy, x, bf16_param(weight), None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
                 [aten_dx, aten_dw, False])
             dx = res[0] if aten_dx else None
             dw = res[1].to(weight.dtype) if aten_dw else None
@@ -679,8 +733,12 @@ class _LinearSplitK(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
         xc = x if x.dtype == dt else x.to(dt)
-        wc = weight if weight.dtype == dt else weight.to(dt)
-        bc = None if bias is None else (bias if bias.dtype == dt else bias.to(dt))
+        if dt == torch.bfloat16:
+            wc = bf16_param(weight)
+            bc = None if bias is None else bf16_param(bias)
+        else:
+            wc = weight if weight.dtype == dt else weight.to(dt)
+            bc = None if bias is None else (bias if bias.dtype == dt else bias.to(dt))
         ctx.save_for_backward(xc, wc)
         ctx.meta = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
         # write into a fresh base tensor: F.linear on 3-d input returns a VIEW of its 2-d result, which

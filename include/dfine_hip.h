@@ -208,6 +208,10 @@ int dfine_ema_update(float *ema, const float *src, int64_t n, float momentum, vo
  * table = DEVICE array of n_entries records {const float *src; int64_t dst_offset; int64_t count}
  * (24 bytes each, one block per record; split large tensors into <= 64 K element records). */
 int dfine_multi_copy_f32(const void *table, int n_entries, float *dst, void *stream);
+/* bf16 shadow copies of the fp32 master weights (what autocast's per-call casts of nn.Linear / nn.Conv2d weights
+ * produce, the modules of src/d_fine/arch under torch.autocast in src/dl/train.py:524-531) refreshed once per optimizer step:
+ * device table of {const float *src; bf16 *dst; int64 n} records. */
+int dfine_multi_cast_bf16(const void *table, int n_entries, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A1/A2  Dense 1x1 / 3x3 stride-1 "same" convolution on the MFMA units (NCHW, bf16, fp32 accumulate).
