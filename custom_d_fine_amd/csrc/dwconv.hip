@@ -205,6 +205,169 @@ __global__ __launch_bounds__(kDwThreads) void dwconv_wgrad_lds_kernel(
     }
 }
 
+// ---- stride-1 "same" depthwise conv, bf16, register-tiled: a thread owns VW consecutive outputs of a row --------
+// The generic kernels above read K*K LDS words (+ K*K weights) per output: LDS-bound at ~0.7 TB/s effective on the
+// 5x5 layers of HGNetv2 stages 3/4 (128 ch @ 40x40, 256 ch @ 20x20, 16 layers per step).  Here the padded input
+// rows sit in LDS as fp32 with the data starting at column 4, so the VW + K - 1 inputs a thread needs from a row
+// are VW/4 + 2 aligned 16-byte reads, the weights live in registers (block-uniform), and global traffic is
+// 16-byte (VW = 8) or 8-byte (VW = 4) vectors.  FLIP = true reverses the taps: the data gradient.
+template <int VW> struct DwVec;
+template <> struct DwVec<8> {
+    typedef uint4 raw;
+    static __device__ __forceinline__ void unpack(const uint4 &v, float (&o)[8]) {
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+        o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+        o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ uint4 pack(const float (&o)[8]) {
+        uint4 r;
+        r.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+        r.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+        r.z = (uint32_t)f32_to_bf16(o[4]) | ((uint32_t)f32_to_bf16(o[5]) << 16);
+        r.w = (uint32_t)f32_to_bf16(o[6]) | ((uint32_t)f32_to_bf16(o[7]) << 16);
+        return r;
+    }
+};
+template <> struct DwVec<4> {
+    typedef uint2 raw;
+    static __device__ __forceinline__ void unpack(const uint2 &v, float (&o)[4]) {
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    }
+    static __device__ __forceinline__ uint2 pack(const float (&o)[4]) {
+        uint2 r;
+        r.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+        r.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+        return r;
+    }
+};
+
+// stage rows [y0 - P, y0 - P + rows_in) of one plane into tile[rows_in][W + 8] (fp32, data at column 4, zero borders)
+template <int VW>
+__device__ __forceinline__ void dw_stage_rows(const uint16_t *plane, float *tile, int y_first, int rows_in, int H, int W) {
+    const int WPD = W + 8, nv = W / VW;
+    for (int i = threadIdx.x; i < rows_in * 2; i += kDwThreads) {      // left / right zero borders
+        const int r = i >> 1;
+        float4 *z = reinterpret_cast<float4 *>(tile + r * WPD + ((i & 1) ? W + 4 : 0));
+        *z = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int i = threadIdx.x; i < rows_in * nv; i += kDwThreads) {
+        const int r = i / nv, v = i - r * nv;
+        const int gy = y_first + r;
+        float o[VW];
+        if (gy >= 0 && gy < H) {
+            const typename DwVec<VW>::raw raw = *reinterpret_cast<const typename DwVec<VW>::raw *>(plane + (int64_t)gy * W + v * VW);
+            DwVec<VW>::unpack(raw, o);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) o[e] = 0.f;
+        }
+        float4 *d = reinterpret_cast<float4 *>(tile + r * WPD + 4 + v * VW);
+#pragma unroll
+        for (int q = 0; q < VW / 4; ++q) d[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    }
+}
+
+template <int K, int VW, bool FLIP>
+__global__ __launch_bounds__(kDwThreads) void dwconv_s1_vec_kernel(const uint16_t *__restrict__ x, const float *__restrict__ w,
+                                                                  uint16_t *__restrict__ y, int C, int H, int W, int TR) {
+    constexpr int P = K / 2, NQ = VW / 4 + 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int plane = blockIdx.x, c = plane % C;
+    const int y0 = blockIdx.y * TR;
+    const int rows_out = min(TR, H - y0), rows_in = rows_out + K - 1;
+    const int WPD = W + 8, nv = W / VW;
+    float wk[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) wk[i] = w[c * K * K + (FLIP ? K * K - 1 - i : i)];      // block-uniform
+    const uint16_t *xp = x + (int64_t)plane * H * W;
+    dw_stage_rows<VW>(xp, smem, y0 - P, rows_in, H, W);
+    __syncthreads();
+    uint16_t *yp = y + (int64_t)plane * H * W;
+    for (int s = threadIdx.x; s < rows_out * nv; s += kDwThreads) {
+        const int r = s / nv, v = s - r * nv;
+        float acc[VW];
+#pragma unroll
+        for (int e = 0; e < VW; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const float4 *src = reinterpret_cast<const float4 *>(smem + (r + ky) * WPD + v * VW);
+            float in[4 * NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { const float4 t = src[q]; in[4 * q] = t.x; in[4 * q + 1] = t.y; in[4 * q + 2] = t.z; in[4 * q + 3] = t.w; }
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                for (int e = 0; e < VW; ++e) acc[e] = fmaf(wk[ky * K + kx], in[e + kx + 4 - P], acc[e]);
+        }
+        *reinterpret_cast<typename DwVec<VW>::raw *>(yp + (int64_t)(y0 + r) * W + v * VW) = DwVec<VW>::pack(acc);
+    }
+}
+
+// weight gradient of the same layers: block = (channel, chunk of images); the whole padded plane of x in LDS, the
+// thread's VW dy values straight from global; K*K accumulators per thread, block reduce, atomics over image chunks.
+template <int K, int VW>
+__global__ __launch_bounds__(kDwThreads) void dwconv_wgrad_s1_vec_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy,
+                                                                        float *__restrict__ dw, int B, int C, int H, int W,
+                                                                        int imgs_per_block) {
+    constexpr int P = K / 2, NQ = VW / 4 + 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int c = blockIdx.x;
+    const int b0 = blockIdx.y * imgs_per_block, b1 = min(B, b0 + imgs_per_block);
+    const int WPD = W + 8, nv = W / VW, rows_in = H + K - 1;
+    float acc[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const int64_t pl = ((int64_t)b * C + c) * H * W;
+        dw_stage_rows<VW>(x + pl, smem, -P, rows_in, H, W);
+        __syncthreads();
+        for (int s = threadIdx.x; s < H * nv; s += kDwThreads) {
+            const int r = s / nv, v = s - r * nv;
+            float g[VW];
+            DwVec<VW>::unpack(*reinterpret_cast<const typename DwVec<VW>::raw *>(dy + pl + (int64_t)r * W + v * VW), g);
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                const float4 *src = reinterpret_cast<const float4 *>(smem + (r + ky) * WPD + v * VW);
+                float in[4 * NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) { const float4 t = src[q]; in[4 * q] = t.x; in[4 * q + 1] = t.y; in[4 * q + 2] = t.z; in[4 * q + 3] = t.w; }
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    float a = acc[ky * K + kx];
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) a = fmaf(g[e], in[e + kx + 4 - P], a);
+                    acc[ky * K + kx] = a;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *red = smem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if (lane == 0) red[wave * K * K + i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < K * K) {
+        float v = 0.f;
+        for (int wv = 0; wv < kDwThreads / 64; ++wv) v += red[wv * K * K + threadIdx.x];
+        unsafeAtomicAdd(dw + c * K * K + threadIdx.x, v);
+    }
+}
+
+// stride-1 "same" layers the register-tiled kernels cover
+static bool dw_vec_ok(int dtype, int H, int W, int K, int stride, int pad, int *vw) {
+    if (dtype != DFINE_BF16 || stride != 1 || (K != 3 && K != 5) || pad != K / 2 || W > 160) return false;
+    *vw = (W % 8 == 0) ? 8 : (W % 4 == 0 ? 4 : 0);
+    return *vw != 0 && (size_t)(H + K - 1) * (W + 8) * 4 <= 60 * 1024;
+}
+
 static int pick_rows(int rows_total, int row_len_lds, int K, int S, bool fwd) {
     // strip height so that the LDS tile stays <= ~48 KiB and there are enough blocks
     int tr = 16;
@@ -228,6 +391,21 @@ int dfine_dwconv_fwd(const void *x, const float *w, void *y, int dtype, int B, i
     if (!x || !w || !y || K < 1 || K > kMaxK || stride < 1 || pad < 0) return DFINE_E_BADARG;
     const int OH = (H + 2 * pad - K) / stride + 1, OW = (W + 2 * pad - K) / stride + 1;
     if (OH < 1 || OW < 1) return DFINE_E_BADARG;
+    hipStream_t st0 = (hipStream_t)stream;
+    int vw = 0;
+    if (dw_vec_ok(dtype, H, W, K, stride, pad, &vw)) {
+        // rows per block: as many as 256 threads cover with one strip each
+        int TRv = kDwThreads / (W / vw);
+        if (TRv > H) TRv = H;
+        const size_t smv = sizeof(float) * (size_t)(TRv + K - 1) * (W + 8);
+        dim3 gridv(B * C, (H + TRv - 1) / TRv);
+#define DFINE_DWV(KK, VV) hipLaunchKernelGGL((dwconv_s1_vec_kernel<KK, VV, false>), gridv, dim3(kDwThreads), smv, st0, \
+                                             (const uint16_t *)x, w, (uint16_t *)y, C, H, W, TRv)
+        if (K == 5) { if (vw == 8) DFINE_DWV(5, 8); else DFINE_DWV(5, 4); }
+        else { if (vw == 8) DFINE_DWV(3, 8); else DFINE_DWV(3, 4); }
+#undef DFINE_DWV
+        return check_launch();
+    }
     const int WP = W + 2 * pad;
     const int TR = pick_rows(OH, WP, K, stride, true);
     const size_t sm = sizeof(float) * ((size_t)((TR - 1) * stride + K) * WP + K * K);
@@ -255,7 +433,20 @@ int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, fl
     const int OH = (H + 2 * pad - K) / stride + 1, OW = (W + 2 * pad - K) / stride + 1;
     if (OH < 1 || OW < 1) return DFINE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    if (dx) {
+    int vw = 0;
+    const bool vec = dw_vec_ok(dtype, H, W, K, stride, pad, &vw);
+    if (dx && vec) {
+        int TRv = kDwThreads / (W / vw);
+        if (TRv > H) TRv = H;
+        const size_t smv = sizeof(float) * (size_t)(TRv + K - 1) * (W + 8);
+        dim3 gridv(B * C, (H + TRv - 1) / TRv);
+#define DFINE_DWV(KK, VV) hipLaunchKernelGGL((dwconv_s1_vec_kernel<KK, VV, true>), gridv, dim3(kDwThreads), smv, st, \
+                                             (const uint16_t *)dy, w, (uint16_t *)dx, C, H, W, TRv)
+        if (K == 5) { if (vw == 8) DFINE_DWV(5, 8); else DFINE_DWV(5, 4); }
+        else { if (vw == 8) DFINE_DWV(3, 8); else DFINE_DWV(3, 4); }
+#undef DFINE_DWV
+        if (int e = check_launch()) return e;
+    } else if (dx) {
         const int TR = pick_rows(H, OW, K, stride, false);
         const size_t sm = sizeof(float) * ((size_t)(TR / stride + K + 1) * OW + K * K);
         dim3 grid(B * C, (H + TR - 1) / TR);
@@ -276,6 +467,22 @@ int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, fl
         int per = 1;
         while ((int64_t)C * ((B + per - 1) / per) > 4096 && per < B) per *= 2;
         dim3 grid(C, (B + per - 1) / per);
+        if (vec) {
+            // ~1024 blocks: several images per block amortise the K*K-value block reduction + atomics
+            int perv = (int)(((int64_t)B * C + 1023) / 1024);
+            if (perv < 1) perv = 1;
+            if (perv > B) perv = B;
+            per = perv;
+            grid = dim3(C, (B + per - 1) / per);
+            size_t smv = sizeof(float) * (size_t)(H + K - 1) * (W + 8);
+            if (smv < sizeof(float) * (kDwThreads / 64) * K * K) smv = sizeof(float) * (kDwThreads / 64) * K * K;
+#define DFINE_WGV(KK, VV) hipLaunchKernelGGL((dwconv_wgrad_s1_vec_kernel<KK, VV>), grid, dim3(kDwThreads), smv, st, \
+                                             (const uint16_t *)x, (const uint16_t *)dy, dw_f32, B, C, H, W, per)
+            if (K == 5) { if (vw == 8) DFINE_WGV(5, 8); else DFINE_WGV(5, 4); }
+            else { if (vw == 8) DFINE_WGV(3, 8); else DFINE_WGV(3, 4); }
+#undef DFINE_WGV
+            return check_launch();
+        }
         const size_t lds_need = sizeof(float) * ((size_t)(H + 2 * pad) * (W + 2 * pad) + (size_t)OH * OW);
         const bool spec = (K == 5 && stride == 1) || (K == 3 && stride == 2) || (K == 3 && stride == 1);
         if (spec && lds_need <= 60 * 1024) {
