@@ -361,6 +361,142 @@ __global__ __launch_bounds__(kDwThreads) void dwconv_wgrad_s1_vec_kernel(const u
     }
 }
 
+// ---- 3x3 / stride 2 / pad 1 depthwise (HG_Stage.downsample, SCDown.cv2), bf16, register-tiled -------------------
+// forward: a thread owns 4 consecutive outputs (inputs 2x-1 .. 2x+7 of three rows = 3 aligned 16-byte LDS reads per row)
+__global__ __launch_bounds__(kDwThreads) void dwconv_s2_fwd_vec_kernel(const uint16_t *__restrict__ x, const float *__restrict__ w,
+                                                                      uint16_t *__restrict__ y, int C, int H, int W, int TRo) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int plane = blockIdx.x, c = plane % C;
+    const int OH = H / 2, OW = W / 2;
+    const int oy0 = blockIdx.y * TRo;
+    const int rows_out = min(TRo, OH - oy0), rows_in = 2 * rows_out + 1;
+    const int WPD = W + 8, nv = OW / 4;
+    float wk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
+    dw_stage_rows<8>(x + (int64_t)plane * H * W, smem, 2 * oy0 - 1, rows_in, H, W);
+    __syncthreads();
+    uint16_t *yp = y + (int64_t)plane * OH * OW;
+    for (int s = threadIdx.x; s < rows_out * nv; s += kDwThreads) {
+        const int r = s / nv, v = s - r * nv;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float4 *src = reinterpret_cast<const float4 *>(smem + (2 * r + ky) * WPD + v * 8);
+            float in[12];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { const float4 t = src[q]; in[4 * q] = t.x; in[4 * q + 1] = t.y; in[4 * q + 2] = t.z; in[4 * q + 3] = t.w; }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(wk[ky * 3 + kx], in[2 * e + kx + 3], acc[e]);
+        }
+        *reinterpret_cast<uint2 *>(yp + (int64_t)(oy0 + r) * OW + v * 4) = DwVec<4>::pack(acc);
+    }
+}
+
+// data gradient: a thread owns 8 consecutive dx of one row; row parity picks the kernel rows, column parity the columns
+template <int VD>          // vector width used to stage dy rows (OW % VD == 0)
+__global__ __launch_bounds__(kDwThreads) void dwconv_s2_dgrad_vec_kernel(const uint16_t *__restrict__ dy, const float *__restrict__ w,
+                                                                        uint16_t *__restrict__ dx, int C, int H, int W, int TR) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int plane = blockIdx.x, c = plane % C;
+    const int OH = H / 2, OW = W / 2;
+    const int y0 = blockIdx.y * TR;                              // TR even
+    const int rows = min(TR, H - y0);
+    const int oy_lo = y0 / 2, rows_dy = rows / 2 + 1;
+    const int WPD = OW + 8, nv = W / 8;
+    float wk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
+    dw_stage_rows<VD>(dy + (int64_t)plane * OH * OW, smem, oy_lo, rows_dy, OH, OW);    // rows >= OH read as zeros
+    __syncthreads();
+    uint16_t *dxp = dx + (int64_t)plane * H * W;
+    for (int s = threadIdx.x; s < rows * nv; s += kDwThreads) {
+        const int r = s / nv, v = s - r * nv;
+        const int yy = y0 + r;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        // yy even: ky = 1, oy = yy / 2.   yy odd: ky = 0 -> oy = (yy + 1) / 2, ky = 2 -> oy = (yy - 1) / 2
+        const int nky = (yy & 1) ? 2 : 1;
+        for (int t = 0; t < nky; ++t) {
+            const int ky = (yy & 1) ? 2 * t : 1;
+            const int oy = (yy + 1 - ky) >> 1;
+            const float4 *src = reinterpret_cast<const float4 *>(smem + (oy - oy_lo) * WPD + 4 + v * 4);
+            const float4 a = src[0], b = src[1];
+            const float g[5] = {a.x, a.y, a.z, a.w, b.x};       // dy columns c0 .. c0 + 4 (c0 = 4 v)
+            const float w0 = wk[ky * 3], w1 = wk[ky * 3 + 1], w2 = wk[ky * 3 + 2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[2 * j] = fmaf(w1, g[j], acc[2 * j]);                                   // x = 2c     : kx = 1
+                acc[2 * j + 1] = fmaf(w0, g[j + 1], fmaf(w2, g[j], acc[2 * j + 1]));       // x = 2c + 1 : kx = 0 (c+1), kx = 2 (c)
+            }
+        }
+        *reinterpret_cast<uint4 *>(dxp + (int64_t)yy * W + v * 8) = DwVec<8>::pack(acc);
+    }
+}
+
+// weight gradient: block = (channel, image chunk); padded x plane in LDS, 4 dy values per thread from global
+__global__ __launch_bounds__(kDwThreads) void dwconv_s2_wgrad_vec_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy,
+                                                                        float *__restrict__ dw, int B, int C, int H, int W,
+                                                                        int imgs_per_block, int TRo) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int c = blockIdx.x;
+    const int b0 = blockIdx.y * imgs_per_block, b1 = min(B, b0 + imgs_per_block);
+    const int OH = H / 2, OW = W / 2, WPD = W + 8, nv = OW / 4;
+    float acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const int64_t pl = (int64_t)b * C + c;
+        for (int oy0 = 0; oy0 < OH; oy0 += TRo) {                 // row tiles: the whole plane need not fit in LDS
+            const int rows_out = min(TRo, OH - oy0);
+            dw_stage_rows<8>(x + pl * H * W, smem, 2 * oy0 - 1, 2 * rows_out + 1, H, W);
+            __syncthreads();
+            for (int s = threadIdx.x; s < rows_out * nv; s += kDwThreads) {
+                const int r = s / nv, v = s - r * nv;
+                float g[4];
+                DwVec<4>::unpack(*reinterpret_cast<const uint2 *>(dy + pl * OH * OW + (int64_t)(oy0 + r) * OW + v * 4), g);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float4 *src = reinterpret_cast<const float4 *>(smem + (2 * r + ky) * WPD + v * 8);
+                    float in[12];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) { const float4 t = src[q]; in[4 * q] = t.x; in[4 * q + 1] = t.y; in[4 * q + 2] = t.z; in[4 * q + 3] = t.w; }
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float a = acc[ky * 3 + kx];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a = fmaf(g[e], in[2 * e + kx + 3], a);
+                        acc[ky * 3 + kx] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    float *red = smem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if (lane == 0) red[wave * 9 + i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        float v = 0.f;
+        for (int wv = 0; wv < kDwThreads / 64; ++wv) v += red[wv * 9 + threadIdx.x];
+        unsafeAtomicAdd(dw + c * 9 + threadIdx.x, v);
+    }
+}
+
+static bool dw_s2_ok(int dtype, int H, int W, int K, int stride, int pad) {
+    return dtype == DFINE_BF16 && stride == 2 && K == 3 && pad == 1 && H % 2 == 0 && W % 8 == 0 && W <= 320;
+}
+
 // stride-1 "same" layers the register-tiled kernels cover
 static bool dw_vec_ok(int dtype, int H, int W, int K, int stride, int pad, int *vw) {
     if (dtype != DFINE_BF16 || stride != 1 || (K != 3 && K != 5) || pad != K / 2 || W > 160) return false;
@@ -406,6 +542,15 @@ int dfine_dwconv_fwd(const void *x, const float *w, void *y, int dtype, int B, i
 #undef DFINE_DWV
         return check_launch();
     }
+    if (dw_s2_ok(dtype, H, W, K, stride, pad)) {
+        int TRo = kDwThreads / (OW / 4);
+        if (TRo < 1) TRo = 1;
+        if (TRo > OH) TRo = OH;
+        const size_t smv = sizeof(float) * (size_t)(2 * TRo + 1) * (W + 8);
+        hipLaunchKernelGGL(dwconv_s2_fwd_vec_kernel, dim3(B * C, (OH + TRo - 1) / TRo), dim3(kDwThreads), smv, st0,
+                           (const uint16_t *)x, w, (uint16_t *)y, C, H, W, TRo);
+        return check_launch();
+    }
     const int WP = W + 2 * pad;
     const int TR = pick_rows(OH, WP, K, stride, true);
     const size_t sm = sizeof(float) * ((size_t)((TR - 1) * stride + K) * WP + K * K);
@@ -446,6 +591,19 @@ int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, fl
         else { if (vw == 8) DFINE_DWV(3, 8); else DFINE_DWV(3, 4); }
 #undef DFINE_DWV
         if (int e = check_launch()) return e;
+    } else if (dx && dw_s2_ok(dtype, H, W, K, stride, pad)) {
+        int TRd = kDwThreads / (W / 8);
+        TRd = TRd < 2 ? 2 : (TRd & ~1);
+        if (TRd > H) TRd = H;
+        const size_t smv = sizeof(float) * (size_t)(TRd / 2 + 1) * (OW + 8);
+        dim3 gridv(B * C, (H + TRd - 1) / TRd);
+        if (OW % 8 == 0)
+            hipLaunchKernelGGL(dwconv_s2_dgrad_vec_kernel<8>, gridv, dim3(kDwThreads), smv, st, (const uint16_t *)dy, w,
+                               (uint16_t *)dx, C, H, W, TRd);
+        else
+            hipLaunchKernelGGL(dwconv_s2_dgrad_vec_kernel<4>, gridv, dim3(kDwThreads), smv, st, (const uint16_t *)dy, w,
+                               (uint16_t *)dx, C, H, W, TRd);
+        if (int e = check_launch()) return e;
     } else if (dx) {
         const int TR = pick_rows(H, OW, K, stride, false);
         const size_t sm = sizeof(float) * ((size_t)(TR / stride + K + 1) * OW + K * K);
@@ -481,6 +639,18 @@ int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, fl
             if (K == 5) { if (vw == 8) DFINE_WGV(5, 8); else DFINE_WGV(5, 4); }
             else { if (vw == 8) DFINE_WGV(3, 8); else DFINE_WGV(3, 4); }
 #undef DFINE_WGV
+            return check_launch();
+        }
+        if (dw_s2_ok(dtype, H, W, K, stride, pad)) {
+            int perv = (int)(((int64_t)B * C + 1023) / 1024);
+            if (perv < 1) perv = 1;
+            if (perv > B) perv = B;
+            int TRo = kDwThreads / (OW / 4);
+            if (TRo < 1) TRo = 1;
+            if (TRo > OH) TRo = OH;
+            size_t smv = sizeof(float) * (size_t)(2 * TRo + 1) * (W + 8);
+            hipLaunchKernelGGL(dwconv_s2_wgrad_vec_kernel, dim3(C, (B + perv - 1) / perv), dim3(kDwThreads), smv, st,
+                               (const uint16_t *)x, (const uint16_t *)dy, dw_f32, B, C, H, W, perv, TRo);
             return check_launch();
         }
         const size_t lds_need = sizeof(float) * ((size_t)(H + 2 * pad) * (W + 2 * pad) + (size_t)OH * OW);

@@ -30,6 +30,30 @@ def test_depthwise_conv_fwd_bwd(cuda, B, C, H, W, K, S):
     assert torch.allclose(wg.grad.cpu(), wr.grad, rtol=1e-3, atol=1e-3 * wr.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("B,C,H,W,K,S", [(3, 16, 40, 40, 5, 1), (2, 8, 20, 20, 5, 1), (2, 8, 80, 80, 3, 1),
+                                          (2, 6, 24, 12, 3, 1), (2, 8, 160, 160, 3, 2), (3, 12, 40, 40, 3, 2),
+                                          (2, 6, 20, 24, 3, 2), (2, 4, 80, 72, 3, 2)])
+def test_depthwise_conv_bf16_vector_kernels(cuda, B, C, H, W, K, S):
+    """The register-tiled bf16 kernels (stride 1: 16 / 8-byte strips; 3x3 stride 2) against fp32 conv2d on the
+    same bf16-rounded inputs; outputs are rounded to bf16 once, gradients of the weights stay fp32."""
+    torch.manual_seed(K * 10 + S)
+    x = torch.randn(B, C, H, W).to(torch.bfloat16)
+    w = torch.randn(C, 1, K, K) * 0.3
+    P = (K - 1) // 2
+    xr, wr = x.float().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, stride=S, padding=P, groups=C)
+    go = torch.randn_like(yr).to(torch.bfloat16)
+    yr.backward(go.float())
+    xg, wg = x.to(cuda).requires_grad_(True), w.to(cuda).requires_grad_(True)
+    y = kernels._DepthwiseConv.apply(xg, wg, S, P)
+    assert y.dtype == torch.bfloat16
+    y.backward(go.to(cuda))
+    tol = 2 ** -7
+    assert (y.float().cpu() - yr).abs().max() <= tol * yr.abs().max()
+    assert (xg.grad.float().cpu() - xr.grad).abs().max() <= tol * xr.grad.abs().max()
+    assert torch.allclose(wg.grad.cpu(), wr.grad, rtol=1e-3, atol=1e-3 * wr.grad.abs().max().item())
+
+
 @pytest.mark.parametrize("act", [None, "relu", "silu"])
 @pytest.mark.parametrize("shape", [(4, 12, 20, 20), (2, 7, 9, 11), (3, 32, 80, 80)])
 @pytest.mark.parametrize("lab", [False, True])
