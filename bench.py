@@ -182,7 +182,7 @@ def main():
             "config": {"workload": f"D-FINE-{args.model} {args.img}x{args.img} bs={args.batch}/GPU full train step "
                                    "(fwd + Hungarian matcher/criterion + bwd + clip + AdamW + EMA), COCO-80 synthetic labels",
                        "global_batch": args.batch * world, "queries": lq, "parallelism": f"dp{world}"},
-            "roofline": {"kernel": "msda_fwd_kernel (dfine_msda_fused_fwd)", "bound": "hbm",
+            "roofline": {"kernel": "msda_fwd8_kernel (dfine_msda_fused_fwd)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": msda_pmc_traffic(args.batch, lq, args.dtype),

@@ -18,6 +18,23 @@ images, targets = make_batch(32, 640, seed=42, device=dev)
 for _ in range(a.warmup):
     step(images, targets)
 torch.cuda.synchronize()
+# un-profiled: how long does the host wait for the device (matcher sync + final sync)?  step - wait = host work
+_orig_sync = torch.cuda.Event.synchronize
+_wait = [0.0]
+def _timed_sync(self):
+    t = time.perf_counter(); _orig_sync(self); _wait[0] += time.perf_counter() - t
+torch.cuda.Event.synchronize = _timed_sync
+torch.cuda.synchronize()
+n = 8
+t0 = time.perf_counter()
+for _ in range(n):
+    step(images, targets)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+torch.cuda.Event.synchronize = _orig_sync
+print(f"un-profiled: {1e3*(t2-t0)/n:.1f} ms/step wall; host waits at the matcher sync {1e3*_wait[0]/n:.1f} ms/step, final drain {1e3*(t2-t1):.1f} ms"
+      f" -> host work ~{1e3*((t1-t0)-_wait[0])/n:.1f} ms/step")
 pr = cProfile.Profile()
 t0 = time.perf_counter()
 pr.enable()
