@@ -14,8 +14,11 @@
 
 namespace dfine {
 
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float *__restrict__ g, int64_t n, float grad_scale,
-                                                     float *__restrict__ out) {
+// Two deterministic stages (a fixed grid, fixed summation order): every data-parallel rank must derive the SAME
+// clip coefficient from the same all-reduced gradient, bit for bit - an atomics-based sum drifts the replicas
+// apart by ulps per step.  partial[b] = block b's sum; sqnorm_final_kernel adds the partials in index order.
+constexpr int kSqnormBlocks = 4096;
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float *__restrict__ g, int64_t n, float *__restrict__ partial) {
     __shared__ float red[4];
     float acc = 0.f;
     int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -29,7 +32,21 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float *__restrict__ g
     for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, (red[0] + red[1] + red[2] + red[3]) * grad_scale * grad_scale);
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(const float *__restrict__ partial, int nblocks, float grad_scale,
+                                                           float *__restrict__ out) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) acc += partial[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] * grad_scale * grad_scale;
 }
 
 struct AdamArgs {
@@ -126,10 +143,16 @@ using namespace dfine;
 
 extern "C" {
 
-int dfine_grad_sqnorm(const float *grad, int64_t n, float grad_scale, float *out_zeroed, void *stream) {
+int64_t dfine_grad_sqnorm_ws_floats(void) { return 1 + kSqnormBlocks; }
+
+// out: dfine_grad_sqnorm_ws_floats() floats; out[0] = grad_scale^2 * sum(grad^2) (overwritten), the rest is scratch.
+int dfine_grad_sqnorm(const float *grad, int64_t n, float grad_scale, float *out, void *stream) {
     if (n == 0) return DFINE_OK;
-    if (!grad || !out_zeroed || n < 0) return DFINE_E_BADARG;
-    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, grad, n, grad_scale, out_zeroed);
+    if (!grad || !out || n < 0) return DFINE_E_BADARG;
+    int nb = grid_for(n, 4);
+    if (nb > kSqnormBlocks) nb = kSqnormBlocks;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, grad, n, out + 1);
+    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out + 1, nb, grad_scale, out);
     return check_launch();
 }
 

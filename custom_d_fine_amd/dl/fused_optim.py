@@ -59,7 +59,7 @@ class FusedAdamWEMA:
         self.exp_avg = torch.zeros(total, device=dev)
         self.exp_avg_sq = torch.zeros(total, device=dev)
         self.flat_ema = torch.zeros(total, device=dev) if ema is not None else None
-        self.sqnorm = torch.zeros(1, device=dev)
+        self.sqnorm = self.hip.grad_sqnorm_buffer(dev)      # [0] = squared norm, rest scratch
         self.segments = []
         self._params, self._grad_views, self._grad_offsets = [], [], []
         ema_params = dict(ema.model.named_parameters()) if ema is not None else {}
@@ -145,7 +145,6 @@ class FusedAdamWEMA:
         grad_scale = 1.0 / world
         self.step_count += 1
         if self.clip_max_norm > 0:
-            self.sqnorm.zero_()
             hip.grad_sqnorm(self.flat_grad, grad_scale, self.sqnorm)
         mom = 0.0
         if self.ema is not None:

@@ -42,6 +42,7 @@ _SIGNATURES = {
                                    _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P,
                                    _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_grad_sqnorm": (c_int, [_P, _L, _F, _P, _P]),
+    "dfine_grad_sqnorm_ws_floats": (_L, []),
     "dfine_adamw_ema_step": (c_int, [_P, _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _I, _F, _F, _F, _P]),
     "dfine_ema_update": (c_int, [_P, _P, _L, _F, _P]),
     "dfine_multi_copy_f32": (c_int, [_P, _I, _P, _P]),
@@ -397,6 +398,11 @@ def head_losses(logits, boxes, corners, ref, teacher_corners, teacher_logits, cl
 
 
 # ------------------------------------------------------------------------------------- optimizer
+def grad_sqnorm_buffer(device):
+    """Result + scratch buffer of grad_sqnorm (element 0 is the squared norm)."""
+    return torch.zeros(int(_lib.dfine_grad_sqnorm_ws_floats()), device=device, dtype=torch.float32)
+
+
 def grad_sqnorm(flat_grad, grad_scale, out):
     _check(_lib.dfine_grad_sqnorm(_ptr(flat_grad), flat_grad.numel(), float(grad_scale), _ptr(out), _stream()),
            "dfine_grad_sqnorm")

@@ -190,15 +190,18 @@ int dfine_head_losses(
  * A16  Optimizer step on flat fp32 buffers (parameters are views into them).
  * Replaces clip_grad_norm_ + AdamW.step + zero_grad + ModelEMA.update
  * (src/dl/train.py:52-73,512-535; parameter groups: src/d_fine/dfine.py:87-124).
- *   dfine_grad_sqnorm      out_zeroed[0] += grad_scale^2 * sum(grad^2)   (all groups, then sqrt in
- *                          the step kernel: global L2 norm of the averaged gradient)
+ *   dfine_grad_sqnorm      out[0] = grad_scale^2 * sum(grad^2)   (all groups, then sqrt in the step kernel:
+ *                          global L2 norm of the averaged gradient).  Deterministic (fixed grid, fixed
+ *                          summation order): data-parallel ranks must agree on the clip coefficient bit
+ *                          for bit.  out: dfine_grad_sqnorm_ws_floats() floats (result + scratch).
  *   dfine_adamw_ema_step   one parameter group: g' = grad * grad_scale * min(1, max_norm /
  *                          (sqrt(sqnorm) + 1e-6)) (max_norm <= 0 or sqnorm NULL: no clipping);
  *                          AdamW update (torch.optim.AdamW semantics, `step` = 1-based step count);
  *                          ema = ema * m + (1 - m) * param (ema may be NULL); grad := 0.
  *   dfine_ema_update       ema = ema * m + (1 - m) * src   (BatchNorm statistics buffers)
  */
-int dfine_grad_sqnorm(const float *grad, int64_t n, float grad_scale, float *out_zeroed, void *stream);
+int64_t dfine_grad_sqnorm_ws_floats(void);
+int dfine_grad_sqnorm(const float *grad, int64_t n, float grad_scale, float *out, void *stream);
 int dfine_adamw_ema_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, float *ema,
                          int64_t n, const float *sqnorm, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int step, float grad_scale, float max_norm,

@@ -1,0 +1,65 @@
+"""The fused data-parallel train step (flat-buffer all-reduce + HIP clip/AdamW/EMA kernels) with world_size 2.
+The GPU test box has ONE MI355X, and RCCL refuses two ranks on one device, so both ranks share cuda:0 and the
+collectives go through gloo (device tensors are staged through the host): same code path as `bench.py --gpus N`
+(FusedAdamWEMA.broadcast_from_rank0 / step, the criterion's folded all-reduce), different transport."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), DFINE_CONV_TUNE="hip")      # no per-shape timing runs in the test
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
+    from custom_d_fine_amd.d_fine import dfine
+    from custom_d_fine_amd.dl.engine import ModelEMA, TrainStep
+    from custom_d_fine_amd.dl.fused_optim import FusedAdamWEMA
+    from custom_d_fine_amd.dl.synthetic import make_batch
+
+    torch.manual_seed(100 + rank)                      # different initial weights: rank 0's must win
+    model = dfine.build_model("n", 5, False, "cuda:0", img_size=[320, 320]).train()
+    crit = dfine.build_loss("n", 5, 0.0, False)
+    ema = ModelEMA(model, 0.9998)
+    opt = dfine.build_optimizer(model, lr=8e-4, backbone_lr=4e-4, betas=(0.9, 0.999), weight_decay=1.25e-4, base_lr=8e-4)
+    fused = FusedAdamWEMA(model, opt, ema, clip_max_norm=0.1)
+    fused.broadcast_from_rank0()
+    step = TrainStep(model, crit, opt, amp_dtype=torch.bfloat16, clip_max_norm=0.1, ema=ema, fused_optimizer=fused)
+    images, targets = make_batch(2, 320, num_classes=5, seed=42 + rank, device=dev)      # different data per rank
+    losses = []
+    for _ in range(2):
+        loss, loss_dict = step(images, targets)
+        losses.append(loss.item())
+    torch.cuda.synchronize()
+    flat = fused.flat_param.detach().cpu()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert torch.equal(gathered[0], gathered[1]), "ranks diverged: the averaged-gradient step must keep them identical"
+    assert all(torch.isfinite(torch.tensor(l)) for l in losses)
+    torch.save({"losses": losses, "n_losses": len(loss_dict), "checksum": flat.double().sum().item()},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_fused_train_step_shared_gpu(cuda, tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert r0["checksum"] == r1["checksum"] and r0["n_losses"] == r1["n_losses"]
+    assert r0["losses"] != r1["losses"]                # different data per rank
