@@ -31,13 +31,23 @@ typedef __attribute__((ext_vector_type(4))) float f32x4v;
 constexpr int kConvThreads = 256;
 constexpr int kMaxPixTiles = 10;     // 160 pixels per strip
 
+// 1x1 layers feed the MFMA B operand with ds_read_b64_tr_b16 (conv1x1_tr_kernel): one transpose-read returns, for
+// the lane's pixel, 4 channels that are 4 consecutive LDS rows, and the four 16-lane groups of a wave read 16
+// distinct rows per instruction.  MFMA k index 8 g + e of a 32-channel slab therefore stands for channel
+// (e < 4 ? 4 g + e : 16 + 4 g + e - 4); the packed weights use the same order so the A fragment stays one 16-byte load.
+__host__ __device__ __forceinline__ int tr_slab_channel(int kk) {
+    const int g = kk >> 3, e = kk & 7;
+    return e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4);
+}
+
 // ---- weight packing: fp32 master [Cout][Cin][KS][KS] -> bf16 [KS*KS][NP][KP] (zero padded) -----
 // dgrad = 0: n = cout, k = cin.   dgrad = 1: n = cin, k = cout, taps flipped.
 __global__ void conv_pack_weights_kernel(const float *__restrict__ w, uint16_t *__restrict__ w2, int Cout,
                                          int Cin, int KS, int NP, int KP, int dgrad) {
     const int64_t total = (int64_t)KS * KS * NP * KP;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int k = (int)(i % KP);
+        int k = (int)(i % KP);
+        if (KS == 1) k = (k & ~31) + tr_slab_channel(k & 31);          // position -> source channel
         const int n = (int)((i / KP) % NP);
         const int tap = (int)(i / ((int64_t)KP * NP));
         float v = 0.f;
@@ -61,7 +71,8 @@ __global__ void conv_pack_weights_multi_kernel(const int64_t *__restrict__ table
     const int Cout = (int)e[2], Cin = (int)e[3], KS = (int)e[4], NP = (int)e[5], KP = (int)e[6], dgrad = (int)e[7];
     const int total = KS * KS * NP * KP;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int k = i % KP;
+        int k = i % KP;
+        if (KS == 1) k = (k & ~31) + tr_slab_channel(k & 31);
         const int n = (i / KP) % NP;
         const int tap = i / (KP * NP);
         float v = 0.f;
@@ -212,6 +223,154 @@ __global__ __launch_bounds__(kConvThreads) void conv_igemm_kernel(
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1x1 convolution = per image Y[n, p] = sum_c W[n, c] X[c, p] with X in its NATURAL NCHW layout in LDS:
+// rows = channels, pixels contiguous, written with plain 16-byte copies; the MFMA B fragment (8 channels of one
+// pixel) comes from two ds_read_b64_tr_b16 (gfx950 LDS transpose-read).  Row pitch = 144 elements (288 B = 32 B
+// mod 256 B): the 8 rows a 32-lane half touches fall into 8 different 32-byte bank groups.  The next stage's
+// global loads are issued before the MFMAs of the current one (register staging, one LDS buffer).
+//   block = 256 threads: 128 pixels x (64 * NTN) output channels; wave w -> channels [16 NTN w, 16 NTN (w + 1)).
+typedef short tr_v4s __attribute__((ext_vector_type(4)));
+constexpr int kTrPix = 128, kTrPitch = 144;
+
+template <int NTN, int KC, int VEC>
+__global__ __launch_bounds__(kConvThreads) void conv1x1_tr_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w2,
+                                                                 uint16_t *__restrict__ y, int Cin, int Cout, int NP, int KP,
+                                                                 int HW, int ptiles, int total_tiles, int nblk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    uint16_t *tile = reinterpret_cast<uint16_t *>(lds);          // [KC * 32][kTrPitch]
+    constexpr int ROWS = KC * 32, VPR = kTrPix / VEC;            // vectors per row
+    constexpr int NLD = (ROWS * VPR + kConvThreads - 1) / kConvThreads;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware order: workgroup L runs on XCD L % 8 (round-robin dispatch), and every XCD has its own L2.  The
+    // nblk output-channel blocks that re-read the same pixel tile of x are made CONSECUTIVE workgroups of ONE XCD,
+    // so the tile is fetched from HBM once and re-read from that XCD's L2 (x is re-read nblk = Cout / (64 NTN) times).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nb = slot % nblk, tile_id = (slot / nblk) * 8 + xcd;
+    if (tile_id >= total_tiles) return;
+    const int b = tile_id / ptiles, pt = tile_id - b * ptiles;
+    const int p0 = pt * kTrPix;
+    const int npix = min(kTrPix, HW - p0);
+    const int ntile = (npix + 15) / 16;
+    const uint16_t *xb = x + (int64_t)b * Cin * HW + p0;
+    const int n_wave = nb * 64 * NTN + wave * 16 * NTN;
+    const int g = lane >> 4, i16 = lane & 15;
+    f32x4v acc[NTN][kTrPix / 16];
+#pragma unroll
+    for (int t = 0; t < NTN; ++t)
+#pragma unroll
+        for (int jt = 0; jt < kTrPix / 16; ++jt) acc[t][jt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    typename PixVec<VEC>::type pf[NLD];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int it = tid + j * kConvThreads;
+            const int row = it / VPR, v = it - row * VPR;
+            typename PixVec<VEC>::type val{};
+            if (it < ROWS * VPR && c0 + row < Cin && v * VEC < npix)
+                val = *reinterpret_cast<const typename PixVec<VEC>::type *>(xb + (int64_t)(c0 + row) * HW + v * VEC);
+            pf[j] = val;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int it = tid + j * kConvThreads;
+            const int row = it / VPR, v = it - row * VPR;
+            if (it < ROWS * VPR) *reinterpret_cast<typename PixVec<VEC>::type *>(tile + row * kTrPitch + v * VEC) = pf[j];
+        }
+    };
+    auto load_a = [&](int cs, bf16x8 (&a)[NTN]) {
+#pragma unroll
+        for (int t = 0; t < NTN; ++t) {
+            const int n = n_wave + t * 16 + i16;
+            uint4 av = make_uint4(0, 0, 0, 0);
+            if (n < NP) av = *reinterpret_cast<const uint4 *>(w2 + (int64_t)n * KP + cs + 8 * g);
+            a[t] = __builtin_bit_cast(bf16x8, av);
+        }
+    };
+    // per-lane transpose-read base: row 4 g + i/4 of a slab, pixels 4 (i % 4) .. + 3 of a 16-pixel tile
+    const int tr_off = (4 * g + (i16 >> 2)) * kTrPitch + 4 * (i16 & 3);
+
+    fetch(0);
+    for (int c0 = 0; c0 < KP; c0 += 32 * KC) {
+        stash();
+        __syncthreads();
+        if (c0 + 32 * KC < KP) fetch(c0 + 32 * KC);               // in flight during the MFMAs below
+        bf16x8 a[NTN];
+        load_a(c0, a);
+#pragma unroll 1                                                 // one slab's 16 transpose-reads live at a time
+        for (int slab = 0; slab < KC; ++slab) {
+            const int cs = c0 + 32 * slab;
+            if (KC > 1 && cs >= KP) break;
+            bf16x8 an[NTN];
+            load_a(min(cs + 32, KP - 32), an);                   // next slab's weights: L2 latency behind this slab's MFMAs
+            const uint16_t *sl = tile + slab * 32 * kTrPitch + tr_off;
+#pragma unroll
+            for (int jt = 0; jt < kTrPix / 16; ++jt) {
+                if (jt < ntile) {
+                    const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (tr_v4s __attribute__((address_space(3))) *)(sl + jt * 16));
+                    const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (tr_v4s __attribute__((address_space(3))) *)(sl + jt * 16 + 16 * kTrPitch));
+                    typedef short tr_v8s __attribute__((ext_vector_type(8)));
+                    const tr_v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8 bf = __builtin_bit_cast(bf16x8, both);
+#pragma unroll
+                    for (int t = 0; t < NTN; ++t)
+                        acc[t][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], bf, acc[t][jt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NTN; ++t) a[t] = an[t];
+        }
+        __syncthreads();
+    }
+    uint16_t *yb = y + (int64_t)b * Cout * HW + p0;
+#pragma unroll
+    for (int t = 0; t < NTN; ++t) {
+#pragma unroll
+        for (int jt = 0; jt < kTrPix / 16; ++jt) {
+            const int q = jt * 16 + i16;
+            if (jt < ntile && q < npix) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n_wave + t * 16 + 4 * g + r;
+                    if (n < Cout) yb[(int64_t)n * HW + q] = f32_to_bf16(acc[t][jt][r]);
+                }
+            }
+        }
+    }
+}
+
+static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B, int Cin, int Cout, int NP, int KP, int HW,
+                          hipStream_t st) {
+    const int ptiles = (HW + kTrPix - 1) / kTrPix;
+    const int vec = (HW % 8 == 0) ? 8 : (HW % 4 == 0 ? 4 : 2);
+    static const int kc_env = [] { const char *e = getenv("DFINE_CONV_KC"); return e ? atoi(e) : 0; }();
+    int kc = KP >= 128 ? 4 : (KP >= 64 ? 2 : 1);
+    if (kc_env) kc = kc_env;
+    while (kc > 1 && KP < 32 * kc) kc >>= 1;
+    const bool wide = (NP % 128 == 0) && ((int64_t)B * ptiles * (NP / 128) >= 512);
+    const int nblk = wide ? NP / 128 : (NP + 63) / 64;
+    const int total_tiles = B * ptiles;
+    dim3 grid(8 * ((total_tiles + 7) / 8) * nblk);
+    const size_t ldsb = (size_t)kc * 32 * kTrPitch * 2;
+#define DFINE_TR(NTNN, KCC, VECC)                                                                            \
+    hipLaunchKernelGGL((conv1x1_tr_kernel<NTNN, KCC, VECC>), grid, dim3(kConvThreads), ldsb, st, x, w2, y, Cin, Cout, NP, \
+                       KP, HW, ptiles, total_tiles, nblk)
+#define DFINE_TR_K(NTNN, VECC)                                                                               \
+    { if (kc == 4) DFINE_TR(NTNN, 4, VECC); else if (kc == 2) DFINE_TR(NTNN, 2, VECC); else DFINE_TR(NTNN, 1, VECC); }
+#define DFINE_TR_V(NTNN)                                                                                     \
+    { if (vec == 8) DFINE_TR_K(NTNN, 8) else if (vec == 4) DFINE_TR_K(NTNN, 4) else DFINE_TR_K(NTNN, 2) }
+    if (wide) DFINE_TR_V(2) else DFINE_TR_V(1)
+#undef DFINE_TR_V
+#undef DFINE_TR_K
+#undef DFINE_TR
+    return check_launch();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -559,13 +718,12 @@ int dfine_conv_fwd_bf16(const void *x, const void *w2, void *y, int B, int Cin, 
     if (!x || !w2 || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (KS != 1 && KS != 3)) return DFINE_E_BADARG;
     if (Cin % 2) return DFINE_E_BADARG;
     const int NP = (Cout + 15) / 16 * 16, KP = (Cin + 31) / 32 * 32;
-    int h = H, w = W;
-    if (KS == 1) {             // no spatial structure: treat the plane as rows of <= 160 pixels
-        const int hw = H * W;
-        w = 160;
-        while (w > 1 && (hw % w || w % 2)) --w;
-        if (w < 16) { h = H; w = W; } else h = hw / w;
+    if (KS == 1) {             // no spatial structure: flattened planes, LDS transpose-read kernel
+        if ((H * W) % 2) return DFINE_E_BADARG;
+        return launch_conv1x1((const uint16_t *)x, (const uint16_t *)w2, (uint16_t *)y, B, Cin, Cout, NP, KP, H * W,
+                              (hipStream_t)stream);
     }
+    const int h = H, w = W;
     if (w % 2 || w > 160) return DFINE_E_BADARG;
     return launch_conv((const uint16_t *)x, (const uint16_t *)w2, (uint16_t *)y, B, Cin, Cout, NP, KP, h, w, KS,
                        (hipStream_t)stream);
