@@ -119,9 +119,8 @@ class Gate(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, x1, x2):
-        g1, g2 = torch.sigmoid(kernels.linear(torch.cat([x1, x2], dim=-1), self.gate.weight,
-                                              self.gate.bias)).chunk(2, dim=-1)
-        return self.norm(g1 * x1 + g2 * x2)
+        g = kernels.linear(torch.cat([x1, x2], dim=-1), self.gate.weight, self.gate.bias)
+        return kernels.gate_layer_norm(g, x1, x2, self.norm)
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -161,12 +160,12 @@ class TransformerDecoderLayer(nn.Module):
     def forward(self, target, reference_points, value, spatial_shapes, attn_mask=None,
                 query_pos_embed=None):
         qk = self.with_pos_embed(target, query_pos_embed)
-        target = self.norm1(target + self.dropout1(self.self_attn(qk, target, attn_mask=attn_mask)))
+        target = kernels.add_layer_norm(target, self.dropout1(self.self_attn(qk, target, attn_mask=attn_mask)),
+                                        self.norm1)
         cross = self.cross_attn(self.with_pos_embed(target, query_pos_embed), reference_points,
                                 value, spatial_shapes)
         target = self.gateway(target, self.dropout2(cross))
-        target = target + self.dropout4(self.forward_ffn(target))
-        return self.norm3(target.clamp(min=-65504, max=65504))
+        return kernels.add_layer_norm(target, self.dropout4(self.forward_ffn(target)), self.norm3, clamp=65504.0)
 
 
 class Integral(nn.Module):

@@ -201,14 +201,16 @@ class TransformerEncoderLayer(nn.Module):
     def forward(self, src, src_mask=None, pos_embed=None) -> torch.Tensor:
         x = self.norm1(src) if self.normalize_before else src
         attn = self.self_attn(self.with_pos_embed(x, pos_embed), x, attn_mask=src_mask)
-        src = src + self.dropout1(attn)
-        if not self.normalize_before:
-            src = self.norm1(src)
+        if self.normalize_before:
+            src = src + self.dropout1(attn)
+        else:                                    # post-norm (the reference's configuration): residual + LN in one pass
+            src = kernels.add_layer_norm(src, self.dropout1(attn), self.norm1)
         x = self.norm2(src) if self.normalize_before else src
         x = kernels.linear(self.dropout(self.activation(kernels.linear(x, self.linear1.weight, self.linear1.bias))),
                            self.linear2.weight, self.linear2.bias)
-        src = src + self.dropout2(x)
-        return src if self.normalize_before else self.norm2(src)
+        if self.normalize_before:
+            return src + self.dropout2(x)
+        return kernels.add_layer_norm(src, self.dropout2(x), self.norm2)
 
 
 class TransformerEncoder(nn.Module):

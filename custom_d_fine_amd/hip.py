@@ -58,6 +58,9 @@ _SIGNATURES = {
     "dfine_topk_anchors": (c_int, [_P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfine_linear_wgrad_ws_floats": (_L, [_I, _I, _I]),
     "dfine_linear_wgrad_bf16": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "dfine_ln_fused_fwd": (c_int, [_I, _P, _I, _P, _I, _P, _I, _P, _P, _F, _F, _P, _P, _P, _L, _I, _P]),
+    "dfine_ln_fused_bwd": (c_int, [_I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "dfine_ln_fused_bwd_ws_floats": (_L, [_L, _I]),
     "dfine_stem_supported": (c_int, [_I, _I, _I, _I]),
     "dfine_stem_pack_weights": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "dfine_stem_conv_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -607,3 +610,38 @@ def stem_pool_backward(x, dy):
     dx = torch.empty_like(x)
     _check(_lib.dfine_stem_pool_bwd(_ptr(x), _ptr(dy), _ptr(dx), B * C, H, W, _stream()), "dfine_stem_pool_bwd")
     return dx
+
+
+# ------------------------------------------------------------------------------------- residual / gate + LayerNorm
+def _dt(t):
+    return 0 if t is None else _DTYPE[t.dtype]
+
+
+def ln_fused_forward(mode, a, b, gate, weight, bias, eps, clampv):
+    """a [.., D] (f32 / bf16), b same shape or None, gate [.., 2D] (mode 2) -> (y f32, mean, rstd)."""
+    D = a.shape[-1]
+    rows = a.numel() // D
+    y = torch.empty(a.shape, device=a.device, dtype=torch.float32)
+    mean = torch.empty(rows, device=a.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=a.device, dtype=torch.float32)
+    _check(_lib.dfine_ln_fused_fwd(mode, _ptr(a), _dt(a), _ptr(b), _dt(b), _ptr(gate), _dt(gate), _ptr(weight), _ptr(bias),
+                                   float(eps), float(clampv), _ptr(y), _ptr(mean), _ptr(rstd), rows, D, _stream()),
+           "dfine_ln_fused_fwd")
+    return y, mean, rstd
+
+
+def ln_fused_backward(mode, a, b, gate, weight, mean, rstd, dy, clampv, need_a, need_b, need_gate, need_affine):
+    D = a.shape[-1]
+    rows = a.numel() // D
+    da = torch.empty_like(a) if need_a else None
+    db = torch.empty_like(b) if (need_b and b is not None) else None
+    dg = torch.empty_like(gate) if (need_gate and gate is not None) else None
+    dwb = ws = None
+    if need_affine:
+        dwb = torch.empty(2, D, device=a.device, dtype=torch.float32)
+        ws = torch.empty(int(_lib.dfine_ln_fused_bwd_ws_floats(rows, D)), device=a.device, dtype=torch.float32)
+    _check(_lib.dfine_ln_fused_bwd(mode, _ptr(a), _dt(a), _ptr(b), _dt(b), _ptr(gate), _dt(gate), _ptr(weight), _ptr(mean),
+                                   _ptr(rstd), _ptr(dy), float(clampv), _ptr(da), _ptr(db), _ptr(dg),
+                                   _ptr(dwb[0]) if need_affine else None, _ptr(dwb[1]) if need_affine else None, _ptr(ws),
+                                   rows, D, _stream()), "dfine_ln_fused_bwd")
+    return da, db, dg, (dwb[0] if need_affine else None), (dwb[1] if need_affine else None)

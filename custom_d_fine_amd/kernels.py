@@ -721,6 +721,65 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
     return y
 
 
+# =============================================================================================
+# A5/A6  residual / gate + LayerNorm of the token streams (csrc/lnfused.hip)
+# =============================================================================================
+_LN_DIMS = (64, 128, 256, 384, 512, 1024)
+
+
+class _LNFused(torch.autograd.Function):
+    """mode 0: LN(a + b); mode 1: LN(clamp(a + b)); mode 2: LN(sigmoid(g[:, :D]) * a + sigmoid(g[:, D:]) * b)."""
+
+    @staticmethod
+    def forward(ctx, mode, a, b, gate, weight, bias, eps, clampv):
+        a = a.contiguous()
+        b = None if b is None else b.contiguous()
+        gate = None if gate is None else gate.contiguous()
+        y, mean, rstd = _hip().ln_fused_forward(mode, a, b, gate, weight, bias, eps, clampv)
+        ctx.save_for_backward(a, b, gate, weight, mean, rstd)
+        ctx.cfg = (mode, clampv, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b, gate, weight, mean, rstd = ctx.saved_tensors
+        mode, clampv, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        if dy.dtype != torch.float32:
+            dy = dy.float()
+        need = ctx.needs_input_grad
+        da, db, dg, dw, dbias = _hip().ln_fused_backward(mode, a, b, gate, weight, mean, rstd, dy, clampv, need[1],
+                                                         need[2], need[3], need[4] or (has_bias and need[5]))
+        return None, da, db, dg, (dw if need[4] else None), (dbias if has_bias and need[5] else None), None, None
+
+
+def _ln_fast(x, norm):
+    return (x.is_cuda and _env("DFINE_LN_FUSED", "1") == "1" and isinstance(norm, nn.LayerNorm)
+            and norm.elementwise_affine and len(norm.normalized_shape) == 1 and norm.normalized_shape[0] in _LN_DIMS
+            and x.shape[-1] == norm.normalized_shape[0] and x.dtype in (torch.float32, torch.bfloat16))
+
+
+def add_layer_norm(x, branch, norm: nn.LayerNorm, clamp: Optional[float] = None):
+    """norm(x + branch) or norm((x + branch).clamp(-clamp, clamp)) - the residual LayerNorms of the decoder /
+    encoder layers (ref dfine_decoder.py:238-255, hybrid_encoder.py:243-280).  One HIP pass on CUDA tensors."""
+    if _ln_fast(x, norm) and branch.dtype in (torch.float32, torch.bfloat16) and branch.shape == x.shape:
+        return _LNFused.apply(0 if clamp is None else 1, x, branch, None, norm.weight, norm.bias, norm.eps,
+                              0.0 if clamp is None else float(clamp))
+    z = x + branch
+    if clamp is not None:
+        z = z.clamp(min=-clamp, max=clamp)
+    return norm(z)
+
+
+def gate_layer_norm(gate_logits, x1, x2, norm: nn.LayerNorm):
+    """norm(sigmoid(g)[..., :D] * x1 + sigmoid(g)[..., D:] * x2), g = Gate.gate([x1, x2]) (ref dfine_decoder.py:258-271)."""
+    if (_ln_fast(x1, norm) and x2.shape == x1.shape and gate_logits.shape[-1] == 2 * x1.shape[-1]
+            and x2.dtype in (torch.float32, torch.bfloat16) and gate_logits.dtype in (torch.float32, torch.bfloat16)):
+        return _LNFused.apply(2, x1, x2, gate_logits, norm.weight, norm.bias, norm.eps, 0.0)
+    g1, g2 = torch.sigmoid(gate_logits).chunk(2, dim=-1)
+    return norm(g1 * x1 + g2 * x2)
+
+
 class _LinearSplitK(torch.autograd.Function):
     """y = x W^T + b for x [B, L, K] with B*L >> N*K (every decoder / encoder linear: 15 744 rows
     against <= 1024 x 1024 weights).  The weight gradient dW = dY^T X is a GEMM with a tiny output and
