@@ -10,8 +10,11 @@
 // GEMM view per image:  Y[n, p] = sum_{tap, c} W2[tap][n][c] * X[c, p + shift(tap)]
 //   M = output channels (A operand = packed weights, c contiguous -> k-packed fragments straight
 //       from global / L2), N = pixels, K = input channels x taps.
-// NCHW keeps PIXELS contiguous, but an MFMA B fragment needs 8 consecutive K (= channels) per
-// pixel, so each 32-channel slab of the input strip (+1-pixel halo) is staged once in LDS
+// NCHW keeps PIXELS contiguous, but an MFMA B fragment needs 8 consecutive K (= channels) per pixel.
+//   1x1 layers (conv1x1_tr_kernel): X rows go to LDS as they are ([channel][pixel], 16-byte copies) and the
+//   fragments come from gfx950's LDS transpose-read, ds_read_b64_tr_b16 - see that kernel.
+//   3x3 layers (conv_igemm_kernel): a tap shifts the pixel index by +-1 = 2 bytes, which the transpose-read's
+//   8-byte alignment cannot follow, so each 32-channel slab of the input strip (+1-pixel halo) is staged in LDS
 // TRANSPOSED to [pixel][32 channels] (64 B per pixel: every ds_read_b128 of a wave is one linear
 // 1 KiB run, conflict-free) and then reused by all KS*KS taps (a tap is just an LDS address offset)
 // and by the block's 4 waves.  Almost every layer of this network is HBM-bound at bf16 (DESIGN.md
@@ -668,8 +671,7 @@ static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B
 #define DFINE_CONV_V(KSS, NTNN)                                                                       \
     { if (vec == 8) DFINE_CONV_K(KSS, NTNN, 8) else if (vec == 4) DFINE_CONV_K(KSS, NTNN, 4) else DFINE_CONV_K(KSS, NTNN, 2) }
     if (KS == 3) { if (wide) DFINE_CONV_V(3, 2) else DFINE_CONV_V(3, 1) }
-    else if (KS == 1) { if (wide) DFINE_CONV_V(1, 2) else DFINE_CONV_V(1, 1) }
-    else return DFINE_E_BADARG;
+    else return DFINE_E_BADARG;                       // 1x1 layers: conv1x1_tr_kernel (launch_conv1x1)
 #undef DFINE_CONV_V
 #undef DFINE_CONV_K
 #undef DFINE_CONV
