@@ -542,9 +542,15 @@ __global__ __launch_bounds__(kConvThreads) void linear_wgrad_kernel(const uint16
                                                                     float *__restrict__ part, float *__restrict__ db,
                                                                     int M, int N, int K, int rows_per_split, int nct64,
                                                                     int NP16, int CP16) {
-    constexpr int PITCH = 66;
-    __shared__ __attribute__((aligned(16))) uint16_t s_dy[32 * PITCH];
-    __shared__ __attribute__((aligned(16))) uint16_t s_x[32 * PITCH];
+    // Both MFMA operands are COLUMNS of row-major tiles (the reduction index m is the row): gfx950's LDS
+    // transpose-read delivers them - lane (column i, group g) gets rows 4g..4g+3 (first read) and 16+4g..16+4g+3
+    // (second read) of its column; A and B use the same row order, and a sum over m does not care about it.
+    // Row pitch 80 elements = 160 B: the 8 rows a 32-lane half touches hit 8 different 32-byte bank groups.
+    constexpr int PITCH = 80, ROWS = 64;                 // rows staged per barrier pair (two 32-row MFMA k-steps)
+    __shared__ __attribute__((aligned(16))) uint16_t s_dy[ROWS * PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t s_x[ROWS * PITCH];
+    typedef short tr4 __attribute__((ext_vector_type(4)));
+    typedef short tr8 __attribute__((ext_vector_type(8)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt64 = blockIdx.x / nct64, ct64 = blockIdx.x - nt64 * nct64;
     const int n0 = nt64 * 64, k0 = ct64 * 64;
@@ -555,51 +561,60 @@ __global__ __launch_bounds__(kConvThreads) void linear_wgrad_kernel(const uint16
     f32x4v acc_b = f32x4v{0.f, 0.f, 0.f, 0.f};        // bias gradient: dY^T * ones (one extra MFMA per k-step)
     const bool want_db = db != nullptr && ct64 == 0;
     const bool wave_active = n0 + wave * 16 < N;
-    // staging role: thread -> (tile, row, 8-element chunk)
-    const int st_tile = tid >> 7, st_row = (tid >> 2) & 31, st_chunk = tid & 3;       // 2 chunks of 8 per thread
-    for (int m0 = m_begin; m0 < m_end; m0 += 32) {
-        {
-            const int m = m0 + st_row;
-            const uint16_t *src = st_tile == 0 ? dy + (int64_t)m * N + n0 : x + (int64_t)m * K + k0;
-            const int width = st_tile == 0 ? N - n0 : K - k0;
-            uint16_t *dst = (st_tile == 0 ? s_dy : s_x) + st_row * PITCH;
+    // staging role: 128 threads per tile, thread -> 4 (row, 8-element chunk) vectors
+    const int st_tile = tid >> 7, st_t = tid & 127;
+    const uint16_t *st_src = st_tile == 0 ? dy + n0 : x + k0;
+    const int st_ld = st_tile == 0 ? N : K;
+    const int st_width = st_tile == 0 ? N - n0 : K - k0;
+    const bool vec_ok = (st_ld & 7) == 0;                         // rows 16-byte aligned
+    uint16_t *st_dst = st_tile == 0 ? s_dy : s_x;
+    const int g = lane >> 4, i = lane & 15;
+    const int tr_off = (4 * g + (i >> 2)) * PITCH + 4 * (i & 3);
+    uint4 pf[4];
+    auto fetch = [&](int m0) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int col = (st_chunk + 4 * h) * 8;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                const bool vec_ok = ((st_tile == 0 ? N : K) & 7) == 0;          // rows 16-byte aligned
-                if (m < m_end && vec_ok && col + 8 <= width) v = *reinterpret_cast<const uint4 *>(src + col);
-                else if (m < m_end && col < width) {      // odd widths (132, 20, 4, 1 ...): element loads
-                    uint16_t tmp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    for (int e = 0; e < min(8, width - col); ++e) tmp[e] = src[col + e];
-                    v = *reinterpret_cast<uint4 *>(tmp);
-                }
-                uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + col);      // pitch 66 -> 4-byte aligned only
-                d32[0] = v.x; d32[1] = v.y; d32[2] = v.z; d32[3] = v.w;
+        for (int h = 0; h < 4; ++h) {
+            const int vi = st_t + 128 * h;                       // 0 .. 511
+            const int row = vi >> 3, col = (vi & 7) * 8;
+            const int m = m0 + row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m < m_end && vec_ok && col + 8 <= st_width) v = *reinterpret_cast<const uint4 *>(st_src + (int64_t)m * st_ld + col);
+            else if (m < m_end && col < st_width) {               // odd widths (132, 20, 4, 1 ...): element loads
+                uint16_t tmp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int e = 0; e < min(8, st_width - col); ++e) tmp[e] = st_src[(int64_t)m * st_ld + col + e];
+                v = *reinterpret_cast<uint4 *>(tmp);
             }
+            pf[h] = v;
+        }
+    };
+    fetch(m_begin);
+    for (int m0 = m_begin; m0 < m_end; m0 += ROWS) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int vi = st_t + 128 * h;
+            *reinterpret_cast<uint4 *>(st_dst + (vi >> 3) * PITCH + (vi & 7) * 8) = pf[h];
         }
         __syncthreads();
+        if (m0 + ROWS < m_end) fetch(m0 + ROWS);                   // next stage in flight during the MFMAs
         if (wave_active) {
-            const int g = lane >> 4, i = lane & 15;
-            uint32_t a32[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                a32[t] = (uint32_t)s_dy[(8 * g + 2 * t) * PITCH + wave * 16 + i] |
-                         ((uint32_t)s_dy[(8 * g + 2 * t + 1) * PITCH + wave * 16 + i] << 16);
-            const bf16x8 a = __builtin_bit_cast(bf16x8, make_uint4(a32[0], a32[1], a32[2], a32[3]));
-            if (want_db)
-                acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    a, __builtin_bit_cast(bf16x8, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u)), acc_b, 0, 0, 0);
+            for (int ks = 0; ks < ROWS / 32; ++ks) {
+                const uint16_t *pa = s_dy + ks * 32 * PITCH + tr_off + wave * 16;
+                const tr4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4 __attribute__((address_space(3))) *)pa);
+                const tr4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4 __attribute__((address_space(3))) *)(pa + 16 * PITCH));
+                const bf16x8 a = __builtin_bit_cast(bf16x8, (tr8)__builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7));
+                if (want_db)
+                    acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        a, __builtin_bit_cast(bf16x8, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u)), acc_b, 0, 0, 0);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                if (k0 + ct * 16 >= K) continue;
-                uint32_t b32[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    b32[t] = (uint32_t)s_x[(8 * g + 2 * t) * PITCH + ct * 16 + i] |
-                             ((uint32_t)s_x[(8 * g + 2 * t + 1) * PITCH + ct * 16 + i] << 16);
-                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, make_uint4(b32[0], b32[1], b32[2], b32[3])),
-                                                                  acc[ct], 0, 0, 0);
+                for (int ct = 0; ct < 4; ++ct) {
+                    if (k0 + ct * 16 >= K) continue;
+                    const uint16_t *pb = s_x + ks * 32 * PITCH + tr_off + ct * 16;
+                    const tr4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4 __attribute__((address_space(3))) *)pb);
+                    const tr4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4 __attribute__((address_space(3))) *)(pb + 16 * PITCH));
+                    const bf16x8 bf = __builtin_bit_cast(bf16x8, (tr8)__builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf, acc[ct], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -792,7 +807,7 @@ static void linear_wgrad_plan(int M, int N, int K, int *splits, int *rows) {
     int sp = 1024 / pairs;
     if (sp < 1) sp = 1;
     if (sp > 128) sp = 128;
-    int r = ((M + sp - 1) / sp + 31) / 32 * 32;
+    int r = ((M + sp - 1) / sp + 63) / 64 * 64;
     if (r < 32) r = 32;
     *rows = r;
     *splits = (M + r - 1) / r;
