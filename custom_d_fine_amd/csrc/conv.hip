@@ -426,7 +426,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
         const int ch = it / (R * nv), rem = it - ch * (R * nv);
         st_c[j] = ch; st_lr[j] = rem / nv; st_xv[j] = (rem - st_lr[j] * nv) * 8;
     }
-    uint4 pf[NPF];
+    constexpr int NKS = KS == 3 ? 5 : 1;                         // K steps of 32 pixels per unit (<= 160 pixels)
+    uint4 pf[NPF], apf[NKS];
     auto fetch_unit = [&](int u) {
         const int b = u / strips, strip = u - b * strips;
         const int r0 = strip * R;
@@ -437,6 +438,18 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
             const int gy = r0 + st_lr[j] + kr - PAD, c = c_base + st_c[j];
             if (tid + j * kConvThreads < nstage && gy >= 0 && gy < H && c < Cin)
                 pf[j] = *reinterpret_cast<const uint4 *>(xb + ((int64_t)c * H + gy) * W + st_xv[j]);
+        }
+        if (KS == 3) {
+            // 3x3: the unit's dY fragments (<= 160 pixels = 5 K steps) are fetched a whole unit ahead like the X slab
+            // (the 1x1 kernel measured SLOWER with this front-loaded fetch and keeps its one-step-ahead loads)
+            const int tpu = min(R, H - r0) * W;
+            const uint16_t *dyu = dy + ((int64_t)b * Cout * H + r0) * W;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int px = ks * 32 + 8 * (lane >> 4);
+                apf[ks] = make_uint4(0, 0, 0, 0);
+                if (px < tpu && n_lane < Cout) apf[ks] = *reinterpret_cast<const uint4 *>(dyu + (int64_t)n_lane * H * W + px);
+            }
         }
     };
 
@@ -451,6 +464,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
         for (int j = 0; j < NPF; ++j)
             if (tid + j * kConvThreads < nstage)
                 *reinterpret_cast<uint4 *>(xs + (st_c[j] * CS + st_lr[j] * PW + LPAD + st_xv[j])) = pf[j];
+        uint4 acur[NKS];
+        if (KS == 3) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) acur[ks] = apf[ks];
+        }
         __syncthreads();
         if (u + 1 < u1) fetch_unit(u + 1);                         // in flight during the MFMAs below
         const uint16_t *dyb = dy + ((int64_t)b * Cout * H + r0) * W;
@@ -461,9 +479,17 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
             if (px < tp && n_lane < Cout) av = *reinterpret_cast<const uint4 *>(dyb + (int64_t)n_lane * H * W + px);
             return av;
         };
-        uint4 av = load_a(0);
+        uint4 av = KS == 3 ? acur[0] : load_a(0);
         for (int k0 = 0; k0 < tp; k0 += 32) {
-            const uint4 an = load_a(k0 + 32);                     // zero beyond the strip
+            uint4 an;
+            if (KS == 3) {                                        // select, no dynamic register indexing
+                const int ksn = (k0 >> 5) + 1;
+                an = make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int q = 1; q < NKS; ++q) if (ksn == q) an = acur[q];
+            } else {
+                an = load_a(k0 + 32);                             // zero beyond the strip
+            }
             const bf16x8 a = __builtin_bit_cast(bf16x8, av);
             const int px = k0 + 8 * (lane >> 4);
             const int pxc = px < tp ? px : 0;
