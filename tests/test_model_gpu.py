@@ -107,3 +107,45 @@ def test_bf16_autocast_train_step_runs_and_is_close(cuda):
         assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
         m.zero_grad()
     assert abs(totals[0] - totals[1]) < 0.03 * totals[0], totals
+
+
+def test_full_size_train_step_properties(cuda, monkeypatch):
+    """BASELINE.json's bench configuration (D-FINE-m, 640x640, batch 32, bf16): the CPU oracle takes minutes there,
+    so the full-size check is through properties - finite losses / gradients, every parameter updated, the fused HIP
+    criterion equal to the torch composition (the reference's formulas, on the GPU) on the SAME model outputs, and
+    matcher indices that are valid one-to-one assignments."""
+    import bench
+    from custom_d_fine_amd import kernels
+    from custom_d_fine_amd.dl.synthetic import make_batch
+    monkeypatch.setenv("DFINE_CONV_TUNE", "hip")            # no per-shape timing runs inside a test
+    kernels.reload_env()
+    try:
+        step = bench.build_step("m", 640, cuda, torch.bfloat16)
+        images, targets = make_batch(32, 640, seed=42, device=cuda)
+        before = step.fused.flat_param.detach().clone()
+        loss, loss_dict = step(images, targets)
+        assert torch.isfinite(loss) and len(loss_dict) >= 38
+        assert all(torch.isfinite(v) for v in loss_dict.values())
+        after = step.fused.flat_param
+        assert torch.isfinite(after).all() and (after != before).float().mean().item() > 0.9   # zero-init heads keep zeros
+
+        model, crit = step.model, step.criterion
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(images, targets)
+        fused = crit(out, targets)
+        monkeypatch.setattr(type(crit), "_fusable", lambda self, outputs: False)
+        plain = crit(out, targets)                           # torch composition of the same losses, fp32, on the GPU
+        assert set(fused) == set(plain)
+        for k in plain:
+            a, b = fused[k].item(), plain[k].item()
+            assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (k, a, b)
+
+        heads = [{k: v for k, v in out.items() if "aux" not in k}] + list(out["aux_outputs"])
+        for m in crit.matcher.match_heads(heads, targets):
+            for (rows, cols), t in zip(m, targets):
+                n = len(t["labels"])
+                assert len(rows) == len(cols) == min(n, 300)
+                assert len(set(rows.tolist())) == len(rows) and sorted(cols.tolist()) == list(range(n))
+    finally:
+        monkeypatch.delenv("DFINE_CONV_TUNE", raising=False)
+        kernels.reload_env()
