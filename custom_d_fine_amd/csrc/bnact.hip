@@ -13,6 +13,8 @@
 //              bn_bwd_apply_kernel  dx = scale * (dz - mean(dz) - xhat * mean(dz*xhat))  (2R + 1W)
 // with z = x*scale + shift, dz = dy * lab_s * act'(z).  One (channel, image-range) per block; a
 // plane (H*W contiguous elements) is read with 16-byte loads when its size allows.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace dfine {
@@ -518,6 +520,234 @@ static int chunks_for(int B, int C, int HW, int *imgs_per_chunk) {
     return (B + per - 1) / per;
 }
 
+// ---- small planes: ONE block per channel holds the channel's B * HW <= 65 536 elements in registers ----------------
+// The 40x40 / 20x20 layers (about 100 of the 133 BN units of D-FINE-m) are launch-floor bound with the chunked
+// two / three-kernel scheme above (~20 us forward, ~28 us backward per unit for 3-13 MB of data).  Here a 1024-thread
+// block reads its channel once (16-byte vectors, <= 8 per thread), reduces through LDS, finalizes the statistics and
+// applies / forms dx straight from the registers: one launch, one read pass, no workspace.
+constexpr int kBnOneThreads = 1024;
+constexpr int kBnOneMaxElems = 65536;
+
+template <int N> __device__ __forceinline__ void block_reduce_one(float (&v)[N], float *red /*[N][16]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int WAVES = kBnOneThreads / 64;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float x = v[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+        if (lane == 0) red[i * WAVES + wave] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float x = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) x += red[i * WAVES + w];       // same order in every thread: identical totals
+        v[i] = x;
+    }
+}
+
+template <int VPT, int ACT>
+__global__ __launch_bounds__(kBnOneThreads) void bn_one_fwd_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ y,
+                                                                  const float *__restrict__ lab_s,
+                                                                  const float *__restrict__ lab_b, int C, int HW, int B,
+                                                                  BnFusedFin fin) {
+    constexpr int act = ACT;
+    __shared__ float red[2 * kBnOneThreads / 64];
+    const int c = blockIdx.x;
+    const int nvhw = HW >> 3, nvec = B * nvhw;
+    uint4 xv[VPT];
+    int64_t off[VPT];
+    float v[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        const int i = threadIdx.x + k * kBnOneThreads;
+        const int b = i / nvhw, r = i - b * nvhw;
+        off[k] = i < nvec ? ((int64_t)b * C + c) * HW + r * 8 : -1;
+        xv[k] = make_uint4(0, 0, 0, 0);
+        if (off[k] >= 0) xv[k] = *reinterpret_cast<const uint4 *>(x + off[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        float a[8];
+        bf16x8_to_f32(xv[k], a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[0] += a[e]; v[1] += a[e] * a[e]; }
+    }
+    block_reduce_one<2>(v, red);
+    const double mean = (double)v[0] / fin.count;
+    double var = (double)v[1] / fin.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)fin.eps));
+    const float g = fin.gamma ? fin.gamma[c] : 1.f, bt = fin.beta ? fin.beta[c] : 0.f;
+    const float sc = g * invstd, sh = bt - (float)mean * g * invstd;
+    if (threadIdx.x == 0) {
+        fin.mean_out[c] = (float)mean; fin.invstd_out[c] = invstd; fin.scale_out[c] = sc; fin.shift_out[c] = sh;
+        if (fin.running_mean) {
+            const double unbiased = fin.count > 1.0 ? var * fin.count / (fin.count - 1.0) : var;
+            fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * (float)mean;
+            fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unbiased;
+        }
+    }
+    const float ls = lab_s ? lab_s[0] : 1.f, lb = lab_b ? lab_b[0] : 0.f;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        if (off[k] < 0) continue;
+        float a[8];
+        bf16x8_to_f32(xv[k], a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = ls * act_fwd(a[e] * sc + sh, act) + lb;
+        uint4 o;
+        o.x = pack_bf16x2(a[0], a[1]); o.y = pack_bf16x2(a[2], a[3]);
+        o.z = pack_bf16x2(a[4], a[5]); o.w = pack_bf16x2(a[6], a[7]);
+        *reinterpret_cast<uint4 *>(y + off[k]) = o;
+    }
+}
+
+template <int VPT, int ACT>
+__global__ __launch_bounds__(kBnOneThreads) void bn_one_bwd_kernel(
+    const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy, uint16_t *__restrict__ dx,
+    const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ lab_s, float *__restrict__ dgamma,
+    float *__restrict__ dbeta, float *__restrict__ dlab, int C, int HW, int B, double count) {
+    constexpr int act = ACT;
+    __shared__ float red[4 * kBnOneThreads / 64];
+    const int c = blockIdx.x;
+    const int nvhw = HW >> 3, nvec = B * nvhw;
+    const float mu = mean[c], is = invstd[c], sc = scale[c], sh = shift[c];
+    const float ls = lab_s ? lab_s[0] : 1.f;
+    // element offset of this thread's k-th vector, as 32-bit numbers stepped incrementally (vector i + 1024 is
+    // (1024 / nvhw) images and (1024 % nvhw) vectors further): no per-vector divisions, no 64-bit pairs - the
+    // 128-VGPR budget of a 1024-thread block is tight with 8 packed vectors resident
+    const int qb = kBnOneThreads / nvhw, qr = kBnOneThreads - qb * nvhw;
+    int vb0 = threadIdx.x / nvhw, vr0 = threadIdx.x - vb0 * nvhw;
+    int offs[VPT];
+    {
+        int b = vb0, r = vr0;
+#pragma unroll
+        for (int k = 0; k < VPT; ++k) {
+            offs[k] = (threadIdx.x + k * kBnOneThreads) < nvec ? (b * C + c) * HW + r * 8 : -1;
+            r += qr; b += qb;
+            if (r >= nvhw) { r -= nvhw; ++b; }
+        }
+    }
+    auto voff = [&](int k) -> int { return offs[k]; };
+    // x stays in registers for both passes; dy is kept too only when it fits the 128-VGPR budget (VPT <= 2), otherwise it
+    // is read again in the second pass (from L2: the first pass just touched it)
+    constexpr bool KEEP_G = VPT <= 2;
+    uint4 xv[VPT], gv[KEEP_G ? VPT : 1];
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    auto pair_terms = [&](uint32_t xw, uint32_t gw, float &o0, float &o1, bool accumulate, float m0, float m1) {
+        const float a0 = __uint_as_float(xw << 16), a1 = __uint_as_float(xw & 0xffff0000u);
+        const float g0 = __uint_as_float(gw << 16), g1 = __uint_as_float(gw & 0xffff0000u);
+        const float z0 = a0 * sc + sh, z1 = a1 * sc + sh;
+        const float d0 = g0 * ls * act_grad(z0, act), d1 = g1 * ls * act_grad(z1, act);
+        const float h0 = (a0 - mu) * is, h1 = (a1 - mu) * is;
+        if (accumulate) {                                         // padded slots carry g = 0 and contribute nothing
+            v[0] += d0 + d1; v[1] += d0 * h0 + d1 * h1;
+            v[2] += g0 * act_fwd(z0, act) + g1 * act_fwd(z1, act); v[3] += g0 + g1;
+        } else {
+            o0 = sc * (d0 - m0 - h0 * m1); o1 = sc * (d1 - m0 - h1 * m1);
+        }
+    };
+    float t0, t1;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        const int o = voff(k);
+        uint4 g = make_uint4(0, 0, 0, 0);
+        xv[k] = make_uint4(0, 0, 0, 0);
+        if (o >= 0) { xv[k] = *reinterpret_cast<const uint4 *>(x + o); g = *reinterpret_cast<const uint4 *>(dy + o); }
+        if (KEEP_G) gv[k] = g;
+        pair_terms(xv[k].x, g.x, t0, t1, true, 0.f, 0.f); pair_terms(xv[k].y, g.y, t0, t1, true, 0.f, 0.f);
+        pair_terms(xv[k].z, g.z, t0, t1, true, 0.f, 0.f); pair_terms(xv[k].w, g.w, t0, t1, true, 0.f, 0.f);
+        if (VPT > 2 && (k & 1)) __builtin_amdgcn_sched_barrier(0);   // keep at most two vectors' temporaries live
+    }
+    block_reduce_one<4>(v, red);
+    const float m0 = (float)((double)v[0] / count), m1 = (float)((double)v[1] / count);
+    if (threadIdx.x == 0) {
+        if (dgamma) dgamma[c] = v[1];
+        if (dbeta) dbeta[c] = v[0];
+        if (dlab) { unsafeAtomicAdd(dlab, v[2]); unsafeAtomicAdd(dlab + 1, v[3]); }   // zeroed by the caller
+    }
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        const int o = voff(k);
+        if (o < 0) continue;
+        const uint4 g = KEEP_G ? gv[KEEP_G ? k : 0] : *reinterpret_cast<const uint4 *>(dy + o);
+        uint4 w;
+        pair_terms(xv[k].x, g.x, t0, t1, false, m0, m1); w.x = pack_bf16x2(t0, t1);
+        pair_terms(xv[k].y, g.y, t0, t1, false, m0, m1); w.y = pack_bf16x2(t0, t1);
+        pair_terms(xv[k].z, g.z, t0, t1, false, m0, m1); w.z = pack_bf16x2(t0, t1);
+        pair_terms(xv[k].w, g.w, t0, t1, false, m0, m1); w.w = pack_bf16x2(t0, t1);
+        *reinterpret_cast<uint4 *>(dx + o) = w;
+        if (VPT > 2 && (k & 1)) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Same one-block-per-channel backward for planes whose x + dy do not fit the registers (B * HW up to 65 536): both
+// passes stream the channel from global memory - the second one re-reads what the block itself just pulled into
+// L2 - so it is still one launch without workspace or finalize, just not one read pass.
+template <int ACT>
+__global__ __launch_bounds__(kBnOneThreads) void bn_one_bwd_stream_kernel(
+    const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy, uint16_t *__restrict__ dx,
+    const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ lab_s, float *__restrict__ dgamma,
+    float *__restrict__ dbeta, float *__restrict__ dlab, int C, int HW, int B, double count) {
+    constexpr int act = ACT;
+    __shared__ float red[4 * kBnOneThreads / 64];
+    const int c = blockIdx.x;
+    const int nvhw = HW >> 3, nvec = B * nvhw;
+    const float mu = mean[c], is = invstd[c], sc = scale[c], sh = shift[c];
+    const float ls = lab_s ? lab_s[0] : 1.f;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < nvec; i += kBnOneThreads) {
+        const int b = i / nvhw, r = i - b * nvhw;
+        const int64_t o = ((int64_t)b * C + c) * HW + r * 8;
+        float a[8], g[8];
+        bf16x8_to_f32(*reinterpret_cast<const uint4 *>(x + o), a);
+        bf16x8_to_f32(*reinterpret_cast<const uint4 *>(dy + o), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float z = a[e] * sc + sh;
+            const float dz = g[e] * ls * act_grad(z, act);
+            v[0] += dz; v[1] += dz * ((a[e] - mu) * is); v[2] += g[e] * act_fwd(z, act); v[3] += g[e];
+        }
+    }
+    block_reduce_one<4>(v, red);
+    const float m0 = (float)((double)v[0] / count), m1 = (float)((double)v[1] / count);
+    if (threadIdx.x == 0) {
+        if (dgamma) dgamma[c] = v[1];
+        if (dbeta) dbeta[c] = v[0];
+        if (dlab) { unsafeAtomicAdd(dlab, v[2]); unsafeAtomicAdd(dlab + 1, v[3]); }   // zeroed by the caller
+    }
+    for (int i = threadIdx.x; i < nvec; i += kBnOneThreads) {
+        const int b = i / nvhw, r = i - b * nvhw;
+        const int64_t o = ((int64_t)b * C + c) * HW + r * 8;
+        float a[8], g[8], w[8];
+        bf16x8_to_f32(*reinterpret_cast<const uint4 *>(x + o), a);
+        bf16x8_to_f32(*reinterpret_cast<const uint4 *>(dy + o), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float z = a[e] * sc + sh;
+            const float dz = g[e] * ls * act_grad(z, act);
+            w[e] = sc * (dz - m0 - ((a[e] - mu) * is) * m1);
+        }
+        uint4 ov;
+        ov.x = pack_bf16x2(w[0], w[1]); ov.y = pack_bf16x2(w[2], w[3]);
+        ov.z = pack_bf16x2(w[4], w[5]); ov.w = pack_bf16x2(w[6], w[7]);
+        *reinterpret_cast<uint4 *>(dx + o) = ov;
+    }
+}
+
+static bool bn_one_ok(int dtype, int B, int HW, int *vpt) {
+    static const int on = [] { const char *e = getenv("DFINE_BN_ONE"); return e ? atoi(e) : 1; }();
+    if (!on || dtype != DFINE_BF16 || (HW & 7) || (int64_t)B * HW > kBnOneMaxElems) return false;
+    const int per = (B * (HW >> 3) + kBnOneThreads - 1) / kBnOneThreads;
+    *vpt = per <= 1 ? 1 : (per <= 2 ? 2 : (per <= 4 ? 4 : 8));
+    return true;
+}
+
 }  // namespace dfine
 
 using namespace dfine;
@@ -541,6 +771,18 @@ int dfine_bn_act_fwd(const void *x, void *y, const float *gamma, const float *be
     const int cb = (C + 127) / 128;
     bool fuse_fin = false;
     BnFusedFin ffin{};
+    int vpt = 0;
+    if (training && save_mean && save_invstd && bn_one_ok(dtype, B, HW, &vpt)) {
+        BnFusedFin f1{nullptr, 0, (double)B * HW, gamma, beta, running_mean, running_var, save_mean, save_invstd, scale, shift,
+                      momentum, eps};
+#define DFINE_BN1F(V, A) hipLaunchKernelGGL((bn_one_fwd_kernel<V, A>), dim3(C), dim3(kBnOneThreads), 0, st, (const uint16_t *)x, \
+                                            (uint16_t *)y, lab_scale, lab_bias, C, HW, B, f1)
+#define DFINE_BN1F_A(V) { if (act == 0) DFINE_BN1F(V, 0); else if (act == 1) DFINE_BN1F(V, 1); else DFINE_BN1F(V, 2); }
+        if (vpt == 1) DFINE_BN1F_A(1) else if (vpt == 2) DFINE_BN1F_A(2) else if (vpt == 4) DFINE_BN1F_A(4) else DFINE_BN1F_A(8)
+#undef DFINE_BN1F_A
+#undef DFINE_BN1F
+        return check_launch();
+    }
     if (training) {
         if (!ws || !save_mean || !save_invstd) return DFINE_E_BADARG;
         int per;
@@ -597,6 +839,27 @@ int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_
     if (dtype != DFINE_F32 && dtype != DFINE_BF16) return DFINE_E_BADARG;
     if (training && (!save_mean || !save_invstd)) return DFINE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    int vpt = 0;
+    // backward: only while x AND dy of the channel fit the 128-VGPR budget of a 1024-thread block (<= 2 vectors per
+    // thread = B * HW <= 16 384: the 20x20 planes); the 8-vector instantiation spills ~260 registers
+    if (training && bn_one_ok(dtype, B, HW, &vpt) && vpt <= 2) {
+#define DFINE_BN1B(V, A) hipLaunchKernelGGL((bn_one_bwd_kernel<V, A>), dim3(C), dim3(kBnOneThreads), 0, st, (const uint16_t *)x, \
+                                            (const uint16_t *)dy, (uint16_t *)dx, save_mean, save_invstd, scale, shift, lab_scale, \
+                                            dgamma, dbeta, dlab, C, HW, B, (double)B * HW)
+#define DFINE_BN1B_A(V) { if (act == 0) DFINE_BN1B(V, 0); else if (act == 1) DFINE_BN1B(V, 1); else DFINE_BN1B(V, 2); }
+        if (vpt == 1) DFINE_BN1B_A(1) else DFINE_BN1B_A(2)
+#undef DFINE_BN1B_A
+#undef DFINE_BN1B
+        return check_launch();
+    }
+    if (training && bn_one_ok(dtype, B, HW, &vpt)) {              // 3 .. 8 vectors per thread: streaming variant
+#define DFINE_BN1S(A) hipLaunchKernelGGL((bn_one_bwd_stream_kernel<A>), dim3(C), dim3(kBnOneThreads), 0, st, (const uint16_t *)x, \
+                                         (const uint16_t *)dy, (uint16_t *)dx, save_mean, save_invstd, scale, shift, lab_scale, \
+                                         dgamma, dbeta, dlab, C, HW, B, (double)B * HW)
+        if (act == 0) DFINE_BN1S(0); else if (act == 1) DFINE_BN1S(1); else DFINE_BN1S(2);
+#undef DFINE_BN1S
+        return check_launch();
+    }
     int per;
     const int nchunk = chunks_for(B, C, HW, &per);
     float *coef = ws + (int64_t)C * nchunk * 4;
