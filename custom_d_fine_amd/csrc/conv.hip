@@ -391,15 +391,28 @@ template <int KS>
 __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
     const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy, float *__restrict__ part, int Cin,
     int Cout, int H, int W, int R, int strips, int total_units, int units_per_split, int nct64, int NP16,
-    int CP16, int CS /* LDS elements per channel: = 8 (mod 128) -> the 16 channel lanes of a b128 read hit 16 distinct 16-byte bank slots */) {
+    int CP16, int CS /* LDS elements per channel: = 8 (mod 128) -> the 16 channel lanes of a b128 read hit 16 distinct 16-byte bank slots */,
+    int npairs, int nsplits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int PAD = KS / 2;
     constexpr int LPAD = KS == 3 ? 8 : 0;
     constexpr int TAPS = KS * KS;
     constexpr int NPF = 5;                                       // 64 ch x <= 160 px / 8 / 256 threads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nt64 = blockIdx.x / nct64, ct64 = blockIdx.x - nt64 * nct64;
-    const int split = blockIdx.y;
+    // XCD-aware order (workgroup L runs on XCD L % 8, each XCD has its own L2): all (n, c) tile pairs of ONE split -
+    // the blocks that read the same pixels of x and dY - are consecutive workgroups of one XCD, so those pixels come
+    // from HBM once.  With the pair index fastest instead, an XCD sees one c tile with every n tile and dY is fetched
+    // once per XCD: 1.9 GB instead of 0.42 GB on the 512 x 512 @ 80x80 layer (FETCH_SIZE, profiles/r01_conv_pmc.txt).
+    // (used when the split count is a multiple of 8 - wgrad_plan rounds it - so that every XCD gets the same work)
+    int pair, split;
+    if ((nsplits & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        pair = slot % npairs; split = (slot / npairs) * 8 + xcd;
+    } else {
+        pair = blockIdx.x % npairs; split = blockIdx.x / npairs;
+    }
+    if (split >= nsplits) return;
+    const int nt64 = pair / nct64, ct64 = pair - nt64 * nct64;
     const int kr = blockIdx.z;                                   // kernel row handled by this block
     const int PW = W + 2 * LPAD;
     uint16_t *xs = reinterpret_cast<uint16_t *>(lds);            // [64][R][PW]
@@ -683,6 +696,14 @@ static void wgrad_plan(int B, int Cin, int Cout, int H, int W, int KS, int *R, i
     if (sp > units) sp = units;
     *ups = (units + sp - 1) / sp;
     *splits = (units + *ups - 1) / *ups;
+    // a multiple of 8 splits lets the kernel give every XCD whole splits (see conv_wgrad_kernel): search the nearby
+    // units-per-split values for one that yields it without shrinking the grid by more than a quarter
+    if (*splits >= 8 && (*splits & 7)) {
+        for (int u = *ups; u <= *ups * 4 / 3 + 1; ++u) {
+            const int spl = (units + u - 1) / u;
+            if (spl >= 8 && (spl & 7) == 0) { *ups = u; *splits = spl; break; }
+        }
+    }
 }
 
 static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B, int Cin, int Cout, int NP, int KP,
@@ -804,7 +825,8 @@ int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, i
     const int cs = (R * (w + 2 * lpad) + 127) / 128 * 128 + 8;      // one kernel row per block: no row halo
     const size_t ldsb = (size_t)64 * cs * 2;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(nnt64 * nct64, splits, KS);
+    const int npairs = nnt64 * nct64;
+    dim3 grid(splits * npairs, 1, KS);
     if (KS == 3) {
         static bool attr_set = false;       // once: not a stream operation, keep it out of graph capture
         if (!attr_set) {
@@ -814,10 +836,10 @@ int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, i
             attr_set = true;
         }
         hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(kConvThreads), ldsb, st, (const uint16_t *)x, (const uint16_t *)dy, ws,
-                           Cin, Cout, h, w, R, strips, B * strips, ups, nct64, np16, cp16, cs);
+                           Cin, Cout, h, w, R, strips, B * strips, ups, nct64, np16, cp16, cs, npairs, splits);
     } else {
         hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(kConvThreads), ldsb, st, (const uint16_t *)x, (const uint16_t *)dy, ws,
-                           Cin, Cout, h, w, R, strips, B * strips, ups, nct64, np16, cp16, cs);
+                           Cin, Cout, h, w, R, strips, B * strips, ups, nct64, np16, cp16, cs, npairs, splits);
     }
     if (int e = check_launch()) return e;
     const int64_t total = (int64_t)Cout * Cin * KS * KS;
