@@ -822,7 +822,12 @@ int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, i
     const int nnt64 = (Cout + 63) / 64, nct64 = (Cin + 63) / 64;
     const int lpad = KS == 3 ? 8 : 0;
     const int np16 = (Cout + 15) / 16 * 16, cp16 = (Cin + 15) / 16 * 16;
-    const int cs = (R * (w + 2 * lpad) + 127) / 128 * 128 + 8;      // one kernel row per block: no row halo
+    // LDS elements per channel.  ds_read_b128 is serviced in four NON-contiguous 16-lane groups ({0-3,12-15,20-27}, ...),
+    // each mixing two of the wave's K groups (pixel offset +16 B): with a channel stride of 16 B (mod 256 B) lanes
+    // (channel 12, group 0) and (channel 11, group 1) share a 16-byte slot and every read costs 2x (42 % conflict
+    // cycles, profiles/r01_conv_pmc.txt); a stride of 32 B (mod 256 B) puts group 0 on even and group 1 on odd slots.
+    // The 3x3 kernel keeps 16 B: its two extra ds_read_b32 per fragment would be 4-way conflicted at 32 B.
+    const int cs = (R * (w + 2 * lpad) + 127) / 128 * 128 + (KS == 1 ? 16 : 8);
     const size_t ldsb = (size_t)64 * cs * 2;
     hipStream_t st = (hipStream_t)stream;
     const int npairs = nnt64 * nct64;
