@@ -15,9 +15,11 @@
 //   fragments come from gfx950's LDS transpose-read, ds_read_b64_tr_b16 - see that kernel.
 //   3x3 layers (conv_igemm_kernel): a tap shifts the pixel index by +-1 = 2 bytes, which the transpose-read's
 //   8-byte alignment cannot follow, so each 32-channel slab of the input strip (+1-pixel halo) is staged in LDS
-// TRANSPOSED to [pixel][32 channels] (64 B per pixel: every ds_read_b128 of a wave is one linear
-// 1 KiB run, conflict-free) and then reused by all KS*KS taps (a tap is just an LDS address offset)
-// and by the block's 4 waves.  Almost every layer of this network is HBM-bound at bf16 (DESIGN.md
+// TRANSPOSED to [pixel][32 channels] (64 B per pixel) and then reused by all KS*KS taps (a tap is just an LDS
+// address offset) and by the block's 4 waves.  PMC: ds_read_b128's non-contiguous 16-lane service groups make
+// pixels p and p + 4 share a 16-byte slot here (2-way conflict, 49 % of the LDS cycles); the conflict-free
+// [K group][pixel][8 channels] image was measured and is slower overall (the staging loop is
+// VALU bound).  Almost every layer of this network is HBM-bound at bf16 (DESIGN.md
 // section 5), so the kernel is organised around reading X once per output-channel block and
 // writing Y once, not around peak MFMA rate.
 //   block  = 256 threads, one (image, strip of R rows, 64*NTN output channels); wave w owns
