@@ -550,24 +550,28 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
     }
 }
 
-__global__ void conv_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, int splits, int Cout,
-                                         int Cin, int taps, int NP16, int CP16) {
+// 64 outputs x 4 split lanes per block (a 128 x 128 layer has only 16 K outputs: one thread per output left 3/4 of
+// the chip idle while every thread walked its ~256 partials one after the other).
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw,
+                                                               int splits, int Cout, int Cin, int taps, int NP16, int CP16) {
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int64_t total = (int64_t)Cout * Cin * taps;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = (int64_t)blockIdx.x * 64 + col;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < total) {
         const int t = (int)(i % taps);
         const int c = (int)((i / taps) % Cin);
         const int n = (int)(i / ((int64_t)taps * Cin));
         const float *src = part + ((int64_t)n * CP16 + c) * taps + t;
         const int64_t stride = (int64_t)NP16 * CP16 * taps;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int k = 0;
-        for (; k + 3 < splits; k += 4) {          // 4 independent loads in flight per thread
-            s0 += src[(int64_t)k * stride]; s1 += src[(int64_t)(k + 1) * stride];
-            s2 += src[(int64_t)(k + 2) * stride]; s3 += src[(int64_t)(k + 3) * stride];
-        }
-        for (; k < splits; ++k) s0 += src[(int64_t)k * stride];
-        dw[i] = (s0 + s1) + (s2 + s3);
+        int k = q;
+        for (; k + 4 < splits; k += 8) { s0 += src[(int64_t)k * stride]; s1 += src[(int64_t)(k + 4) * stride]; }
+        for (; k < splits; k += 4) s0 += src[(int64_t)k * stride];
     }
+    red[q][col] = s0 + s1;
+    __syncthreads();
+    if (q == 0 && i < total) dw[i] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -850,8 +854,7 @@ int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, i
     }
     if (int e = check_launch()) return e;
     const int64_t total = (int64_t)Cout * Cin * KS * KS;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    const int blocks = (int)((total + 63) / 64);
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, splits, Cout, Cin, KS * KS,
                        np16, cp16);
     return check_launch();
@@ -890,8 +893,7 @@ int dfine_linear_wgrad_bf16(const void *x, const void *dy, float *dw, float *db,
                        (const uint16_t *)dy, ws, db, M, N, K, rows, nct64, np16, cp16);
     if (int e = check_launch()) return e;
     const int64_t total = (int64_t)N * K;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    const int blocks = (int)((total + 63) / 64);
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, splits, N, K, 1, np16, cp16);
     return check_launch();
 }
