@@ -361,8 +361,7 @@ def _packed_weights(weight, dgrad):
         if ent[4] == weight._version and ent[3] == weight.data_ptr():
             return ent[2]
         # updated in place by torch since the batch pack (plain optimizers): repack this one
-        _check_w = _hip().conv_pack_weights(weight.detach(), dgrad)
-        ent[2].copy_(_check_w)
+        ent[2].copy_(_hip().conv_pack_weights(weight.detach(), dgrad))
         ent[3], ent[4] = weight.data_ptr(), weight._version
         return ent[2]
     w2 = _hip().conv_pack_weights(weight.detach().float().contiguous(), dgrad)
