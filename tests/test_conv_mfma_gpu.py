@@ -49,3 +49,46 @@ def test_asymmetric_layout_check(cuda):
     y = kernels._DenseConvMFMA.apply(x.bfloat16(), w)
     ref = F.conv2d(x, w.bfloat16().float(), padding=1)
     assert torch.allclose(y.float(), ref, rtol=1e-2, atol=1e-2)
+
+
+def test_packed_weight_caches_follow_weight_updates(cuda):
+    """The packed-weight / bf16-shadow caches must notice (a) in-place torch updates (tensor._version) and (b) raw-pointer
+    updates by the fused optimizer kernels, which only `bump_weight_epoch()` announces."""
+    from custom_d_fine_amd import hip, kernels
+    torch.manual_seed(0)
+    x = torch.randn(2, 64, 16, 16, device=cuda).to(torch.bfloat16)
+    w = torch.nn.Parameter(torch.randn(64, 64, 1, 1, device=cuda) * 0.1)
+    lin_w = torch.nn.Parameter(torch.randn(32, 64, device=cuda) * 0.1)
+
+    def run():
+        with torch.no_grad():
+            return kernels._DenseConv.apply(x, w).float()
+
+    kernels._CONV_PLAN.clear()
+    import os
+    os.environ["DFINE_CONV_TUNE"] = "hip"
+    kernels.reload_env()
+    try:
+        y1 = run()
+        y1b = run()                                           # served from the cache
+        assert torch.equal(y1, y1b)
+        with torch.no_grad():
+            w.mul_(2.0)                                       # (a) in-place: _version changes
+        y2 = run()
+        assert torch.allclose(y2, 2 * y1, rtol=2e-2, atol=1e-3)
+        # (b) raw-pointer update (what adamw_ema_kernel does): ema := 0 * ema + 1 * src through the C ABI
+        src = (w.detach() * 0.5).contiguous()
+        hip.ema_update(w.detach().view(-1), src.view(-1), 0.0)
+        stale = run()
+        assert torch.allclose(stale, y2)                      # nothing announced the change yet
+        kernels.bump_weight_epoch()
+        y3 = run()
+        assert torch.allclose(y3, y1, rtol=2e-2, atol=1e-3)
+        # bf16 shadows follow the same protocol
+        b1 = kernels.bf16_param(lin_w).clone()
+        with torch.no_grad():
+            lin_w.add_(1.0)
+        assert torch.allclose(kernels.bf16_param(lin_w).float(), b1.float() + 1.0, atol=2e-2)
+    finally:
+        os.environ.pop("DFINE_CONV_TUNE", None)
+        kernels.reload_env()
