@@ -552,10 +552,23 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
 
 // 64 outputs x 4 split lanes per block (a 128 x 128 layer has only 16 K outputs: one thread per output left 3/4 of
 // the chip idle while every thread walked its ~256 partials one after the other).
+// Blocks past the weight range (bias_blocks of them) sum the per-split bias partials part_b[split][NP16] -> db.
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw,
-                                                               int splits, int Cout, int Cin, int taps, int NP16, int CP16) {
+                                                               int splits, int Cout, int Cin, int taps, int NP16, int CP16,
+                                                               const float *__restrict__ part_b = nullptr,
+                                                               float *__restrict__ db = nullptr, int w_blocks = 0) {
     __shared__ float red[4][64];
     const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
+    if (db && (int)blockIdx.x >= w_blocks) {
+        const int n = ((int)blockIdx.x - w_blocks) * 64 + col;
+        float s = 0.f;
+        if (n < Cout)
+            for (int k = q; k < splits; k += 4) s += part_b[(int64_t)k * NP16 + n];
+        red[q][col] = s;
+        __syncthreads();
+        if (q == 0 && n < Cout) db[n] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        return;
+    }
     const int64_t total = (int64_t)Cout * Cin * taps;
     const int64_t i = (int64_t)blockIdx.x * 64 + col;
     float s0 = 0.f, s1 = 0.f;
@@ -674,11 +687,11 @@ __global__ __launch_bounds__(kConvThreads) void linear_wgrad_kernel(const uint16
             if (n < NP16) part[((int64_t)blockIdx.y * NP16 + n) * CP16 + c] = acc[ct][r];
         }
     }
-    if (want_db && wave_active && (lane & 15) == 0) {
+    if (want_db && wave_active && (lane & 15) == 0) {          // per-split partial: no zero-fill, no atomics
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = n0 + wave * 16 + 4 * (lane >> 4) + r;
-            if (n < N) unsafeAtomicAdd(db + n, acc_b[r]);
+            if (n < NP16) db[(int64_t)blockIdx.y * NP16 + n] = acc_b[r];
         }
     }
 }
@@ -874,7 +887,8 @@ static void linear_wgrad_plan(int M, int N, int K, int *splits, int *rows) {
 int64_t dfine_linear_wgrad_ws_floats(int M, int N, int K) {
     int splits, rows;
     linear_wgrad_plan(M, N, K, &splits, &rows);
-    return (int64_t)splits * ((N + 15) / 16 * 16) * ((K + 15) / 16 * 16);
+    const int64_t np16 = (N + 15) / 16 * 16;
+    return (int64_t)splits * np16 * ((K + 15) / 16 * 16) + (int64_t)splits * np16;     // weight partials + bias partials
 }
 
 // dw [N, K] f32 (overwritten) = dy[M, N]^T x[M, K]; db [N] f32 (overwritten, may be NULL) = column sums of dy; x, dy row-major bf16 (16-byte loads when the row length is a
@@ -888,13 +902,15 @@ int dfine_linear_wgrad_bf16(const void *x, const void *dy, float *dw, float *db,
     const int nnt64 = (N + 63) / 64, nct64 = (K + 63) / 64;
     const int np16 = (N + 15) / 16 * 16, cp16 = (K + 15) / 16 * 16;
     hipStream_t st = (hipStream_t)stream;
-    if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)N, st);
+    float *part_b = db ? ws + (int64_t)splits * np16 * cp16 : nullptr;
     hipLaunchKernelGGL(linear_wgrad_kernel, dim3(nnt64 * nct64, splits), dim3(kConvThreads), 0, st, (const uint16_t *)x,
-                       (const uint16_t *)dy, ws, db, M, N, K, rows, nct64, np16, cp16);
+                       (const uint16_t *)dy, ws, part_b, M, N, K, rows, nct64, np16, cp16);
     if (int e = check_launch()) return e;
     const int64_t total = (int64_t)N * K;
     const int blocks = (int)((total + 63) / 64);
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, splits, N, K, 1, np16, cp16);
+    const int bias_blocks = db ? (N + 63) / 64 : 0;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks + bias_blocks), dim3(256), 0, st, ws, dw, splits, N, K, 1, np16,
+                       cp16, (const float *)part_b, db, blocks);
     return check_launch();
 }
 
