@@ -2,20 +2,29 @@
 (BASELINE.json metric / configs[2]) - fwd (bf16 autocast) + Hungarian matcher + criterion (fp32)
 + bwd + grad clip + AdamW + EMA on a device-resident synthetic batch.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself through
+                                                             torch.distributed.run, one rank per GPU over RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline      for the dominant hand-written kernel (the fused deformable-attention gather,
-                dfine_msda_fused_fwd): algorithmic bytes per launch / mean launch time measured
-                with HIP events on the launch stream inside the timed region
-  cpu_baseline  the same train step through the CPU oracle backend ("port") on the host cores,
-                D-FINE-m 640x640 at bs=2, bounded to a few steps.
+Rank 0 prints ONE JSON line (contract in the task statement).  `value` = images of all ranks / wall time of the K timed
+steps (barrier + device synchronize on both sides, max over ranks); `median_ms_per_step` = median of the K per-step
+durations (HIP events around every step).  Extra objects:
+  roofline          the dominant kernel FAMILY by device time: the dense-convolution implicit GEMMs of backbone + encoder
+                    (forward, data gradient, weight gradient; MFMA roof).  achieved = algorithmic FLOPs of the timed
+                    launches / their summed duration, both taken live with HIP events on the launch stream inside the
+                    timed region (every `--sample-every`-th step is instrumented, hip.py `_timed`).
+  roofline_kernels  the same figures per kernel group (1x1 / 3x3 forward+dgrad, weight gradients, stem, token-stream
+                    linear weight gradients) and the two deformable-attention kernels against the HBM roof
+                    (algorithmic bytes of SURVEY.md 8(d); `traffic` = PMC HBM bytes from profiles/).
+  cpu_baseline      the same train step through the CPU oracle backend ("port") on the host cores, D-FINE-m 640x640 at
+                    bs=2, bounded to a few steps.
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -27,23 +36,25 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 LRS = {"n": (8e-4, 4e-4), "s": (2.5e-4, 6e-5), "m": (1.5e-4, 2e-5), "l": (1.6e-4, 1e-5), "x": (2e-4, 2e-6)}
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+MFMA_GROUPS = ("conv1x1", "conv3x3", "conv1x1_wgrad", "conv3x3_wgrad", "stem_conv", "stem_wgrad", "miopen_conv")
 
 
-def build_step(model_name, img, device, amp_dtype, num_classes=80, channels_last=False):
+def build_step(model_name, img, device, amp_dtype, num_classes=80, channels_last=False, mask=False):
     from custom_d_fine_amd.d_fine import dfine
     from custom_d_fine_amd.dl.engine import ModelEMA, TrainStep, wrap_data_parallel
     base_lr, backbone_lr = LRS[model_name]
-    model = dfine.build_model(model_name, num_classes, False, str(device), img_size=[img, img]).train()
+    model = dfine.build_model(model_name, num_classes, mask, str(device), img_size=[img, img]).train()
     if channels_last:
         model = model.to(memory_format=torch.channels_last)
-    criterion = dfine.build_loss(model_name, num_classes, 0.0, False)
+    criterion = dfine.build_loss(model_name, num_classes, 0.0, mask)
     ema = ModelEMA(model, 0.9998)
     fused = None
     opt = dfine.build_optimizer(model, lr=base_lr, backbone_lr=backbone_lr, betas=(0.9, 0.999),
                                 weight_decay=1.25e-4, base_lr=base_lr)
     if device.type == "cuda" and os.environ.get("DFINE_FUSED_OPT", "1") == "1":
-        # flat-buffer clip + AdamW + EMA kernels; data parallelism = one all-reduce of the flat grads
+        # flat-buffer clip + AdamW + EMA kernels; data parallelism = bucketed all-reduce of the flat grads
         from custom_d_fine_amd.dl.fused_optim import FusedAdamWEMA
         fused = FusedAdamWEMA(model, opt, ema, clip_max_norm=0.1)
         fused.broadcast_from_rank0()
@@ -58,26 +69,24 @@ def build_step(model_name, img, device, amp_dtype, num_classes=80, channels_last
                      hip_graph=device.type == "cuda" and os.environ.get("DFINE_HIPGRAPH", "0") == "1")
 
 
-def msda_algorithmic_bytes(batch, lq, heads=8, head_dim=32, points=12, elt=2):
-    """SURVEY.md 8(d) per-image-per-layer figure x images of one launch (forward):
-    gathered value reads Lq*H*P*4 corners*hd*elt + offsets Lq*H*P*2*elt + logits Lq*H*P*elt
-    + reference boxes Lq*4*4 + output Lq*H*hd*elt."""
-    per_img = (lq * heads * points * 4 * head_dim * elt + lq * heads * points * 2 * elt
-               + lq * heads * points * elt + lq * 16 + lq * heads * head_dim * elt)
-    return per_img * batch
+def msda_algorithmic_bytes(batch, lq, heads=8, head_dim=32, points=12, elt=2, backward=False):
+    from custom_d_fine_amd import hip
+    return hip.msda_algorithmic_bytes(batch, lq, heads, head_dim, points, elt, backward)
 
 
-def msda_pmc_traffic(batch, lq, dtype):
-    """HBM bytes per launch of the gather kernel from the committed PMC passes (profiles/), or None
-    when this run's shape differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_msda_pmc.json")
-    if not os.path.exists(path):
-        return None
-    rec = json.load(open(path))
-    sh = rec["shape"]
-    if (sh["B"], sh["Lq"], sh["dtype"]) != (batch, lq, dtype):
-        return None
-    return rec["traffic_bytes_per_launch"]
+def pmc_traffic(kernel, batch, lq, dtype):
+    """HBM bytes per launch from the committed PMC passes (profiles/*_msda_pmc.json: list of records), or None when
+    no record matches this run's kernel and shape."""
+    best = None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+        if not name.endswith("_msda_pmc.json"):
+            continue
+        recs = json.load(open(os.path.join(ROOT, "profiles", name)))
+        for rec in recs if isinstance(recs, list) else [recs]:
+            sh = rec.get("shape", {})
+            if rec.get("bench_key") == kernel and (sh.get("B"), sh.get("Lq"), sh.get("dtype")) == (batch, lq, dtype):
+                best = rec["traffic_bytes_per_launch"]           # later rounds override earlier ones
+    return best
 
 
 def cpu_baseline(model_name, img, steps):
@@ -102,45 +111,59 @@ def cpu_baseline(model_name, img, steps):
                       f"({dt:.1f} s) through oracle/torch_backend.py on {os.cpu_count()} logical host CPUs"}
 
 
+def _self_spawn(n):
+    """`python bench.py --gpus N` without a launcher: one rank per GPU through torch.distributed.run."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="m")
     ap.add_argument("--img", type=int, default=640)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--mask", type=int, default=0, help="1: segmentation head (BASELINE configs[4])")
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-baseline steps (0 = skip)")
+    ap.add_argument("--sample-every", type=int, default=5, help="instrument every n-th timed step with HIP events (0 = none)")
     ap.add_argument("--channels-last", type=int, default=0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_spawn(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py measures the HIP path and needs an MI355X (no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", init_method="env://", device_id=device)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from custom_d_fine_amd import hip
     from custom_d_fine_amd.dl.synthetic import make_batch
-    if os.environ.get("DFINE_MIOPEN_BENCHMARK", "0") == "1":
-        torch.backends.cudnn.benchmark = True
-    torch.manual_seed(42 + rank)
+    torch.manual_seed(42)        # identical initial weights on every rank; the per-rank stream is the DATA (seed 42 + rank)
     amp = torch.bfloat16 if args.dtype == "bf16" else None
-    step = build_step(args.model, args.img, device, amp, channels_last=bool(args.channels_last))
-    images, targets = make_batch(args.batch, args.img, seed=42 + rank, device=device)
+    step = build_step(args.model, args.img, device, amp, channels_last=bool(args.channels_last), mask=bool(args.mask))
+    images, targets = make_batch(args.batch, args.img, seed=42 + rank, device=device, with_masks=bool(args.mask))
     if args.channels_last:
         images = images.contiguous(memory_format=torch.channels_last)
 
-    # W untimed warm-up steps; at least two untimed steps always run, because the first step measures the per-shape
-    # conv plans (and MIOpen's find) and the second builds the batched weight-pack / bf16-shadow tables
+    # W untimed warm-up steps (at least two: the second builds the batched weight-pack / bf16-shadow tables)
     for _ in range(max(args.warmup, 2)):
         step(images, targets)
 
@@ -150,13 +173,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    hip.enable_timing(["dfine_msda_fused_fwd", "dfine_msda_fused_bwd"])
+    hip.enable_timing(None)
+    hip.timing_active(False)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
+        hip.timing_active(args.sample_every > 0 and i % args.sample_every == args.sample_every - 1)
         step(images, targets)
+        marks[i + 1].record()
+    hip.timing_active(False)
     fence()
     elapsed = time.perf_counter() - t0
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     timing = hip.timing_summary()
     hip.disable_timing()
     if world > 1:
@@ -168,29 +198,54 @@ def main():
         max_t = max(len(t["labels"]) for t in targets)
         dn = 2 * max_t * max(100 // max_t, 1)
         lq = 300 + dn
-        elt = 2 if args.dtype == "bf16" else 4
-        n_fwd, ms_fwd = timing["dfine_msda_fused_fwd"]
-        n_bwd, ms_bwd = timing["dfine_msda_fused_bwd"]
-        algo = msda_algorithmic_bytes(args.batch, lq, elt=elt)
-        achieved = algo / (ms_fwd * 1e-3) / 1e9 if ms_fwd > 0 else 0.0
+        sampled = sum(1 for i in range(args.steps) if args.sample_every > 0 and i % args.sample_every == args.sample_every - 1)
+
+        def mfma_entry(keys, label):
+            n = sum(timing[k][0] for k in keys if k in timing)
+            ms = sum(timing[k][2] for k in keys if k in timing)
+            fl = sum(timing[k][3] for k in keys if k in timing)
+            tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            return {"kernel": label, "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
+                    "frac": round(tf / MFMA_BF16_PEAK_TFS, 4), "traffic": None,
+                    "launches_per_step": round(n / max(sampled, 1), 1), "ms_per_step": round(ms / max(sampled, 1), 3),
+                    "algorithmic_tflop_per_step": round(fl / max(sampled, 1) / 1e12, 3)}
+
+        def hbm_entry(key, label):
+            if key not in timing or timing[key][2] <= 0:
+                return None
+            n, mean_ms, tot_ms, work = timing[key]
+            gbs = work / (tot_ms * 1e-3) / 1e9
+            return {"kernel": label, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(key, args.batch, lq, args.dtype),
+                    "algorithmic_bytes_per_launch": int(work / n), "launches_per_step": round(n / max(sampled, 1), 1),
+                    "avg_launch_ms": round(mean_ms, 4), "ms_per_step": round(tot_ms / max(sampled, 1), 3)}
+
+        family = mfma_entry(MFMA_GROUPS, "dense-conv implicit GEMMs of backbone + encoder: conv1x1_tr / conv_igemm (fwd + dgrad), "
+                            "conv_wgrad<1|3>, stem_* (+ MIOpen launches where the plan still picks them)")
+        kernels_ = [mfma_entry(("conv1x1",), "conv1x1_tr_kernel fwd+dgrad"), mfma_entry(("conv3x3",), "conv_igemm_kernel<3> fwd+dgrad"),
+                    mfma_entry(("conv1x1_wgrad",), "conv_wgrad_kernel<1> + reduce"), mfma_entry(("conv3x3_wgrad",), "conv_wgrad_kernel<3> + reduce"),
+                    mfma_entry(("stem_conv", "stem_wgrad"), "stem_conv / stem_dgrad_s2 / stem_wgrad"),
+                    mfma_entry(("linear_wgrad",), "linear_wgrad_kernel (token-stream linears)"),
+                    mfma_entry(("linear", "attention"), "linear_act / attention kernels (token streams)"),
+                    mfma_entry(("miopen_conv",), "MIOpen convolutions still dispatched by the per-shape plan"),
+                    hbm_entry("msda_fwd", "msda_fwd8_kernel (dfine_msda_fused_fwd)"),
+                    hbm_entry("msda_bwd", "msda_bwd kernels incl. staging (dfine_msda_fused_bwd)")]
         line = {
             "metric": "images/sec train step D-FINE-m 640x640 bs=32 at 1/2/4/8 MI355X",
             "value": round(args.batch * world * args.steps / elapsed, 3),
             "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "median_ms_per_step": round(statistics.median(per_step), 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"D-FINE-{args.model} {args.img}x{args.img} bs={args.batch}/GPU full train step "
+            "config": {"workload": f"D-FINE-{args.model}{'+mask' if args.mask else ''} {args.img}x{args.img} bs={args.batch}/GPU full train step "
                                    "(fwd + Hungarian matcher/criterion + bwd + clip + AdamW + EMA), COCO-80 synthetic labels",
-                       "global_batch": args.batch * world, "queries": lq, "parallelism": f"dp{world}"},
-            "roofline": {"kernel": "msda_fwd8_kernel (dfine_msda_fused_fwd)", "bound": "hbm",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": msda_pmc_traffic(args.batch, lq, args.dtype),
-                         "algorithmic_bytes_per_launch": algo, "launches": n_fwd,
-                         "avg_launch_ms": round(ms_fwd, 4),
-                         "bwd_avg_launch_ms": round(ms_bwd, 4), "bwd_launches": n_bwd},
+                       "global_batch": args.batch * world, "queries": lq, "parallelism": f"dp{world}",
+                       "collective": f"RCCL all-reduce over {world} ranks" if world > 1 else "none",
+                       "instrumented_steps": sampled},
+            "roofline": family,
+            "roofline_kernels": [k for k in kernels_ if k is not None and k.get("launches_per_step", 0) > 0],
         }
         if world == 1 and args.cpu_steps > 0:
             line["cpu_baseline"] = cpu_baseline(args.model, args.img, args.cpu_steps)

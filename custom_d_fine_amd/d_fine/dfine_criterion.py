@@ -444,15 +444,13 @@ class DFINECriterion(nn.Module):
         cached_enc = matched[n_aux + 2:]
         indices_go = self._get_go_indices(indices, matched[1:])
 
-        # the reference's two scalar all-reduces folded into one 2-float collective
-        counts = torch.tensor([float(indices_go.src.size),
-                               float(sum(len(t["labels"]) for t in targets))])
-        if is_dist_available_and_initialized():
-            counts = counts.to(device)
-            torch.distributed.all_reduce(counts)
-            counts = counts.cpu()
-        counts = torch.clamp(counts / get_world_size(), min=1)
-        num_boxes_go, num_boxes = counts[0].item(), counts[1].item()
+        # the reference's two scalar all-reduces (dfine_criterion.py:639-652) folded into one 2-float host-side collective
+        from .dist_utils import host_all_reduce_sum
+        world = get_world_size()
+        tot = host_all_reduce_sum([float(indices_go.src.size), float(sum(len(t["labels"]) for t in targets))])
+        # fp32 division like the reference's torch.clamp(t / world, min=1).item()
+        num_boxes_go = max(float(np.float32(tot[0]) / np.float32(world)), 1.0)
+        num_boxes = max(float(np.float32(tot[1]) / np.float32(world)), 1.0)
 
         def go_or(own, go_for=("boxes", "local")):
             return lambda loss: (indices_go, num_boxes_go) if loss in go_for else (own, num_boxes)

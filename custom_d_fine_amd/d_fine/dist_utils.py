@@ -37,6 +37,8 @@ def init_distributed_mode() -> None:
 
 
 def cleanup_distributed() -> None:
+    global _HOST_GROUP
+    _HOST_GROUP = None
     if is_dist_available_and_initialized():
         dist.destroy_process_group()
 
@@ -59,6 +61,27 @@ def get_local_rank() -> int:
     if "RANK" in os.environ and torch.cuda.is_available():
         return int(os.environ["RANK"]) % torch.cuda.device_count()
     return 0
+
+
+_HOST_GROUP = None
+
+
+def host_all_reduce_sum(values):
+    """Sum of a few Python floats over the ranks WITHOUT touching the device stream: a gloo side group carries the
+    criterion's two normalisers (reference dfine_criterion.py:639-652 runs two device all-reduces + .item() syncs).
+    With an RCCL default group the device round trip (H2D, collective kernel, D2H, stream sync) would be the step's
+    second host<->device synchronisation; the host values are already known after the matcher's sync."""
+    global _HOST_GROUP
+    if get_world_size() == 1:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+    if dist.get_backend() == "gloo":
+        dist.all_reduce(t)
+    else:
+        if _HOST_GROUP is None:
+            _HOST_GROUP = dist.new_group(backend="gloo")
+        dist.all_reduce(t, group=_HOST_GROUP)
+    return t.tolist()
 
 
 def all_gather_object(obj):

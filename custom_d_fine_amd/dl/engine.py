@@ -220,6 +220,8 @@ class TrainStep:
             loss_dict = self.criterion(outputs, targets)
         total = self.criterion.total(loss_dict) if hasattr(self.criterion, "total") else sum(loss_dict.values())
         loss = total / self.accum_steps
+        if self.fused is not None:           # gradient buckets are reduced from backward hooks on the LAST micro-step only
+            self.fused.accumulating = (self._micro + 1) % self.accum_steps != 0
         loss.backward()
         self._micro += 1
         if self._micro % self.accum_steps == 0:

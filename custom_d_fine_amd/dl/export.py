@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import kernels
 from ..d_fine.dfine import build_model
 
 
@@ -39,20 +40,19 @@ class DFINEPostProcessor(nn.Module):
     def forward(self, outputs: dict, input_h: int, input_w: int):
         logits, boxes = outputs["pred_logits"], outputs["pred_boxes"]
         masks = outputs.get("pred_masks", None)
-        b, q = boxes.shape[:2]
-        abs_boxes = self.norm_xywh_to_abs_xyxy(boxes.flatten(0, 1), input_h, input_w).view(b, q, 4)
         if self.use_focal_loss:
-            flat = torch.sigmoid(logits).flatten(1)
-            k = min(self.num_top_queries, flat.shape[1])
-            scores, idx = torch.topk(flat, k, dim=-1)
-            labels, qidx = idx % self.num_classes, idx // self.num_classes
+            k = min(self.num_top_queries, logits.shape[1] * logits.shape[2])
+            labels, qidx, out_boxes, scores = kernels.detection_topk(logits, boxes, k, input_h, input_w)   # one HIP kernel
         else:
+            b, q = boxes.shape[:2]
+            abs_boxes = self.norm_xywh_to_abs_xyxy(boxes.flatten(0, 1), input_h, input_w).view(b, q, 4)
             probs = F.softmax(logits, dim=-1)[:, :, :-1]
             scores, labels = probs.max(dim=-1)
             k = min(self.num_top_queries, scores.shape[1])
             scores, qidx = torch.topk(scores, k, dim=-1)
             labels = labels.gather(1, qidx)
-        out = (labels, abs_boxes.gather(1, qidx.unsqueeze(-1).expand(-1, -1, 4)), scores)
+            out_boxes = abs_boxes.gather(1, qidx.unsqueeze(-1).expand(-1, -1, 4))
+        out = (labels, out_boxes, scores)
         if masks is not None:
             hm, wm = masks.shape[2:]
             out = out + (masks.gather(1, qidx[..., None, None].expand(-1, -1, hm, wm)),)

@@ -1,6 +1,8 @@
 """Flat-buffer optimizer step for the GPU: global-norm clip + AdamW + EMA + zero_grad in
 (1 + number of parameter groups + 1) HIP launches (csrc/optim.hip), and data-parallel gradient
-averaging as ONE RCCL all-reduce of the flat gradient buffer.
+averaging as a few large RCCL all-reduces over contiguous ranges of the flat gradient buffer, launched from
+backward hooks as soon as a range is complete so that they overlap the rest of the backward pass
+(reference: DDP's bucketed reducer, src/dl/train.py:167-179).
 
 The step semantics are the reference's (`src/dl/train.py:512-535`, `ModelEMA` `:52-73`,
 parameter groups from `build_optimizer`, `src/d_fine/dfine.py:87-124`); hyper-parameters - including
@@ -36,13 +38,18 @@ class FusedAdamWEMA:
     too, so EMA is a handful of streaming kernels instead of two launches per tensor.
     """
 
-    def __init__(self, model, optimizer, ema=None, clip_max_norm=0.1):
+    def __init__(self, model, optimizer, ema=None, clip_max_norm=0.1, overlap=None, bucket_mb=32):
+        """overlap: all-reduce gradient buckets during backward (default: on when world_size > 1; the
+        DFINE_GRAD_OVERLAP environment variable overrides).  bucket_mb: xGMI is point-to-point (7 links x ~153 GB/s), a ring
+        all-reduce is per-link bound and its fixed latency is paid per call, so buckets are few and large."""
+        import os
         from .. import hip
         self.hip = hip
         self.model, self.optimizer, self.ema = model, optimizer, ema
         self.clip_max_norm = float(clip_max_norm or 0.0)
         self.step_count = 0
         self.ema_iters = 0
+        self._live = []
         dev = next(model.parameters()).device
         assert dev.type == "cuda", "FusedAdamWEMA drives HIP kernels; parameters must live on the GPU"
 
@@ -104,44 +111,133 @@ class FusedAdamWEMA:
                     ema_bufs[key].data = ev
             # parameters outside the optimizer (frozen) never change: their EMA stays equal
 
+        # ---- gradient buckets: contiguous flat ranges, filled from the END of every parameter group (backward produces
+        # the gradients roughly in reverse forward order); a bucket is reduced as soon as its last gradient arrived
+        env = os.environ.get("DFINE_GRAD_OVERLAP")
+        self.overlap = (get_world_size() > 1) if overlap is None else bool(overlap)
+        if env is not None:
+            self.overlap = env == "1"
+        self.accumulating = False            # TrainStep sets it on all but the last micro-step of an accumulation window
+        self._buckets, self._works = [], []
+        cap = max(int(bucket_mb * (1 << 20) // 4), 1)
+        pidx = 0
+        index_of = {}
+        for g, (off, size) in zip(groups, self.segments):
+            entries = []
+            for p in g:
+                entries.append((pidx, self._grad_offsets[pidx], p.numel()))
+                pidx += 1
+            cur, hi = [], off + size
+            for e in reversed(entries):
+                cur.append(e)
+                if hi - e[1] >= cap:
+                    self._buckets.append({"lo": e[1], "hi": hi, "params": [c[0] for c in cur], "ready": 0, "done": False})
+                    cur, hi = [], e[1]
+            if cur:
+                self._buckets.append({"lo": cur[-1][1], "hi": hi, "params": [c[0] for c in cur], "ready": 0, "done": False})
+        for bi, b in enumerate(self._buckets):
+            for i in b["params"]:
+                index_of[i] = bi
+        if self.overlap:
+            for i, p in enumerate(self._params):
+                p.register_post_accumulate_grad_hook(self._make_hook(index_of[i]))
+
     # -------------------------------------------------------------------------------------
     def broadcast_from_rank0(self):
-        if is_dist_available_and_initialized() and get_world_size() > 1:
-            dist.broadcast(self.flat_param, 0)
-            if self.flat_buf is not None:
-                dist.broadcast(self.flat_buf, 0)
+        """Every rank starts from rank 0's model, like the reference's DDP wrap (train.py:167-179 broadcasts the whole
+        module state): trainable parameters and float buffers through the flat buffers, then whatever lives outside them
+        (frozen parameters - the l/x configs freeze the HGNetv2 stem - and integer buffers), then the EMA copy is re-derived
+        from the synchronised student."""
+        if not (is_dist_available_and_initialized() and get_world_size() > 1):
+            return
+        dist.broadcast(self.flat_param, 0)
+        if self.flat_buf is not None:
+            dist.broadcast(self.flat_buf, 0)
+        flat_ids = {id(p) for p in self._params}
+        rest = [p.data for p in self.model.parameters() if id(p) not in flat_ids]
+        rest += [b.data for b in self.model.buffers() if self.flat_buf is None or b.dtype != torch.float32]
+        for t in rest:
+            if t.numel():
+                dist.broadcast(t, 0)
+        if self.ema is not None:
+            self.flat_ema.copy_(self.flat_param)
+            if self.flat_ema_buf is not None:
+                self.flat_ema_buf.copy_(self.flat_buf)
+            stu = dict(self.model.named_parameters())
+            stu.update(dict(self.model.named_buffers()))
+            with torch.no_grad():
+                for n, t in list(self.ema.model.named_parameters()) + list(self.ema.model.named_buffers()):
+                    src = stu.get(n, stu.get("module." + n))
+                    if src is not None and t.data_ptr() != src.data_ptr() and not (
+                            self.flat_ema.data_ptr() <= t.data_ptr() < self.flat_ema.data_ptr() + self.flat_ema.numel() * 4):
+                        t.copy_(src)
 
     def zero_grad(self):
         self.flat_grad.zero_()
         for p in self._params:
             p.grad = None
 
-    def _collect_grads(self):
-        """Gathers the per-parameter gradients autograd produced into the flat buffer with one
-        multi-tensor copy and drops them.  (Keeping `.grad` as persistent views instead makes
-        autograd ADD into them - one tiny kernel per parameter, 646 per step for D-FINE-m.)"""
+    def _make_hook(self, bi):
+        b = self._buckets[bi]
+        n = len(b["params"])
+
+        def hook(_param):
+            if self.accumulating:
+                return
+            b["ready"] += 1
+            if b["ready"] == n:
+                self._reduce_bucket(b)
+        return hook
+
+    def _gather(self, indices):
+        """Moves the listed parameters' gradients into their flat slots with one multi-tensor copy and drops them.
+        (Keeping `.grad` as persistent views instead makes autograd ADD into them - one tiny kernel per parameter,
+        646 per step for D-FINE-m.)"""
         grads, offs = [], []
-        for p, off in zip(self._params, self._grad_offsets):
+        for i in indices:
+            p = self._params[i]
             g = p.grad
             if g is not None:
                 if g.dtype != torch.float32 or not g.is_contiguous():
                     g = g.float().contiguous()
                 grads.append(g)
-                offs.append(off)
+                offs.append(self._grad_offsets[i])
                 p.grad = None
         if grads:
             # one HIP launch driven by a pointer table (torch._foreach_copy_ degrades to one DtoD memcpy
             # per tensor here: 646 launches per step for D-FINE-m)
-            self._live = (grads, self.hip.multi_copy_f32(grads, offs, self.flat_grad))
+            self._live.append((grads, self.hip.multi_copy_f32(grads, offs, self.flat_grad)))
+
+    def _reduce_bucket(self, b):
+        self._gather(b["params"])
+        b["done"] = True
+        if get_world_size() > 1:
+            # asynchronous on the communication stream: ordered after the copy above, overlaps what backward still runs
+            self._works.append(dist.all_reduce(self.flat_grad[b["lo"]:b["hi"]], async_op=True))
+
+    def _collect_grads(self):
+        """Single-shot path (no hooks) and flush of whatever the hooks did not see (parameters without a gradient this
+        step leave their bucket incomplete)."""
+        if not self.overlap:
+            self._gather(range(len(self._params)))
+            if get_world_size() > 1:
+                # one large collective over xGMI: 78 MB for D-FINE-m
+                dist.all_reduce(self.flat_grad)
+            return
+        for b in self._buckets:
+            if not b["done"]:
+                self._reduce_bucket(b)
+        for w in self._works:
+            w.wait()                         # the compute stream waits for the communication stream; the host does not block
+        self._works.clear()
+        for b in self._buckets:
+            b["ready"], b["done"] = 0, False
 
     def step(self):
         """all-reduce (if data parallel) -> norm -> per-group AdamW+EMA (also zeroes the grads)."""
         hip = self.hip
         world = get_world_size()
         self._collect_grads()
-        if world > 1:
-            # one large collective over xGMI instead of per-bucket calls: 78 MB for D-FINE-m
-            dist.all_reduce(self.flat_grad)
         grad_scale = 1.0 / world
         self.step_count += 1
         if self.clip_max_norm > 0:
@@ -165,3 +261,4 @@ class FusedAdamWEMA:
         kernels.bump_weight_epoch()          # cached packed conv weights are stale now
         # keep torch's scheduler bookkeeping consistent (it warns if optimizer.step was never called)
         self.optimizer._opt_called = True
+        self._live = self._live[-8:]         # sources of the copies queued this step; older ones have long been consumed

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "dfine_fdr_fwd": (c_int, [_P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_fdr_bwd": (c_int, [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_topk_anchors": (c_int, [_P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfine_postprocess": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_linear_wgrad_ws_floats": (_L, [_I, _I, _I]),
     "dfine_linear_wgrad_bf16": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dfine_ln_fused_fwd": (c_int, [_I, _P, _I, _P, _I, _P, _I, _P, _P, _F, _F, _P, _P, _P, _L, _I, _P]),
@@ -81,30 +82,54 @@ if _lib.dfine_abi_version() != ABI_VERSION:
 EXPORTED = tuple(_SIGNATURES)
 
 # ---- optional per-kernel timing (bench.py roofline leg): HIP events recorded on the launch
-# stream (torch's current stream) right around the launch of the named entry points.
-_TIMED = {}          # name -> list of (start_event, end_event)
+# stream (torch's current stream) right around the launch of the named entry points, together with the
+# algorithmic work (FLOPs or bytes) of the launch.
+_TIMED = {}          # name -> list of (start_event, end_event, work)
+_TIMING_ON = False   # bench.py switches this per step (`timing_active`) to sample a subset of the timed steps
 
 
-def enable_timing(names):
+def enable_timing(names=None):
+    """names: iterable of keys to record, or None = every instrumented launch."""
+    global _TIMING_ON
     _TIMED.clear()
-    for n in names:
-        _TIMED[n] = []
+    _TIMED["*"] = None if names is None else set(names)
+    _TIMING_ON = True
+
+
+def timing_active(flag):
+    global _TIMING_ON
+    _TIMING_ON = bool(flag) and "*" in _TIMED
 
 
 def disable_timing():
+    global _TIMING_ON
     _TIMED.clear()
+    _TIMING_ON = False
 
 
 def timing_summary():
-    """name -> (launches, mean_ms) after a device synchronize."""
+    """name -> (launches, mean_ms, total_ms, total_work) after a device synchronize."""
     torch.cuda.synchronize()
-    return {n: (len(ev), sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1))
-            for n, ev in _TIMED.items()}
+    out = {}
+    for n, ev in _TIMED.items():
+        if n == "*":
+            continue
+        tot = sum(a.elapsed_time(b) for a, b, _ in ev)
+        out[n] = (len(ev), tot / max(len(ev), 1), tot, sum(w for _, _, w in ev))
+    return out
 
 
 class _timed:
-    def __init__(self, name):
-        self.ev = _TIMED.get(name)
+    """`with _timed(key, work):` - no-op unless bench.py enabled timing for `key` and the current step is sampled."""
+    __slots__ = ("ev", "a", "work")
+
+    def __init__(self, name, work=0.0):
+        self.ev = None
+        if _TIMING_ON:
+            want = _TIMED.get("*")
+            if want is None or name in want:
+                self.ev = _TIMED.setdefault(name, [])
+                self.work = work
 
     def __enter__(self):
         if self.ev is not None:
@@ -115,7 +140,10 @@ class _timed:
         if self.ev is not None:
             b = torch.cuda.Event(enable_timing=True)
             b.record()
-            self.ev.append((self.a, b))
+            self.ev.append((self.a, b, self.work))
+
+
+timed = _timed
 _DTYPE = {torch.float32: 0, torch.bfloat16: 1}
 
 
@@ -187,6 +215,15 @@ def msda_backward(value, loc, weight, grad_out, shapes, points):
     return _finish_grad_value(gv, value.dtype), gl, gw
 
 
+def msda_algorithmic_bytes(batch, lq, heads=8, head_dim=32, points=12, elt=2, backward=False):
+    """per image and layer, forward = gathered value reads Lq*H*P*4 corners*hd*elt + offsets
+    Lq*H*P*2*elt + logits Lq*H*P*elt + reference boxes Lq*16 + output Lq*H*hd*elt; backward = the same gathered reads
+    again + an equal volume of grad_value read-modify-write (3 x the gathered bytes) + the small tensors twice."""
+    gathered = lq * heads * points * 4 * head_dim * elt
+    small = lq * heads * points * 2 * elt + lq * heads * points * elt + lq * 16 + lq * heads * head_dim * elt
+    return batch * ((3 * gathered + 2 * small) if backward else (gathered + small))
+
+
 def msda_fused_forward(value, ref, offsets, logits, shapes, points, offset_scale):
     B, L, H, D = value.shape
     Lq = ref.shape[1]
@@ -196,7 +233,7 @@ def msda_fused_forward(value, ref, offsets, logits, shapes, points, offset_scale
         logits = logits.to(value.dtype)
     out = torch.empty(B, Lq, H * D, device=value.device, dtype=value.dtype)
     hw, pts = _levels(shapes, points)
-    with _timed("dfine_msda_fused_fwd"):
+    with _timed("msda_fwd", msda_algorithmic_bytes(B, Lq, H, D, sum(points), value.element_size())):
         _check(_lib.dfine_msda_fused_fwd(_ptr(value), _ptr(ref), _ptr(offsets), _ptr(logits), _ptr(out),
                                          _dtype_code(value), B, L, H, D, Lq, len(shapes), hw, pts,
                                          float(offset_scale), _stream()), "dfine_msda_fused_fwd")
@@ -217,7 +254,7 @@ def msda_fused_backward(value, ref, offsets, logits, grad_out, shapes, points, o
     goff = torch.empty_like(offsets)
     glog = torch.empty_like(logits)
     hw, pts = _levels(shapes, points)
-    with _timed("dfine_msda_fused_bwd"):
+    with _timed("msda_bwd", msda_algorithmic_bytes(B, Lq, H, D, sum(points), value.element_size(), backward=True)):
         _check(_lib.dfine_msda_fused_bwd(_ptr(value), _ptr(ref), _ptr(offsets), _ptr(logits),
                                          _ptr(grad_out), _ptr(gv), _ptr(goff), _ptr(glog),
                                          _dtype_code(value), B, L, H, D, Lq, len(shapes), hw, pts,
@@ -462,7 +499,7 @@ def conv_forward_bf16(x, w2, cout, ks):
     """x [B, Cin, H, W] bf16 contiguous, w2 packed by conv_pack_weights -> y [B, cout, H, W] bf16."""
     B, cin, H, W = x.shape
     y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.bfloat16)
-    with _timed("dfine_conv_fwd_bf16"):
+    with _timed(f"conv{ks}x{ks}", 2.0 * B * H * W * cin * cout * ks * ks):
         _check(_lib.dfine_conv_fwd_bf16(_ptr(x), _ptr(w2), _ptr(y), B, cin, cout, H, W, ks, _stream()),
                "dfine_conv_fwd_bf16")
     return y
@@ -478,7 +515,7 @@ def conv_wgrad_bf16(x, dy, ks):
     cout = dy.shape[1]
     dw = torch.empty(cout, cin, ks, ks, device=x.device, dtype=torch.float32)
     ws = torch.empty(int(_lib.dfine_conv_wgrad_ws_floats(B, cin, cout, H, W, ks)), device=x.device, dtype=torch.float32)
-    with _timed("dfine_conv_wgrad_bf16"):
+    with _timed(f"conv{ks}x{ks}_wgrad", 2.0 * B * H * W * cin * cout * ks * ks):
         _check(_lib.dfine_conv_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ks, _stream()),
                "dfine_conv_wgrad_bf16")
     return dw
@@ -541,6 +578,23 @@ def topk_anchors(logits, k, with_scores=False):
     return (idx, sc) if with_scores else idx
 
 
+def postprocess(logits, boxes, k, height, width, to_round=True):
+    """logits [B, Q, C] f32/bf16, boxes [B, Q, 4] f32 cxcywh (normalised) -> labels [B, k] i64, query [B, k] i64,
+    boxes [B, k, 4] f32 absolute xyxy, scores [B, k] f32 - the k best (query, class) pairs per image, descending."""
+    B, Q, C = logits.shape
+    logits = logits.contiguous()
+    boxes = boxes.float().contiguous()
+    dev = logits.device
+    labels = torch.empty(B, k, device=dev, dtype=torch.int64)
+    query = torch.empty(B, k, device=dev, dtype=torch.int64)
+    out_boxes = torch.empty(B, k, 4, device=dev, dtype=torch.float32)
+    scores = torch.empty(B, k, device=dev, dtype=torch.float32)
+    _check(_lib.dfine_postprocess(_ptr(logits), _ptr(boxes), _ptr(labels), _ptr(query), _ptr(out_boxes), _ptr(scores),
+                                  _dtype_code(logits), B, Q, C, k, int(height), int(width), int(bool(to_round)),
+                                  _stream()), "dfine_postprocess")
+    return labels, query, out_boxes, scores
+
+
 # ------------------------------------------------------------------------------------- linear wgrad
 _LW_WS = {}
 
@@ -558,7 +612,7 @@ def linear_wgrad_bf16(x2d, dy2d, with_bias=False):
         _LW_WS[key] = ws
     dw = torch.empty(N, K, device=dev, dtype=torch.float32)
     db = torch.empty(N, device=dev, dtype=torch.float32) if with_bias else None
-    with _timed("dfine_linear_wgrad_bf16"):
+    with _timed("linear_wgrad", 2.0 * M * N * K):
         _check(_lib.dfine_linear_wgrad_bf16(_ptr(x2d), _ptr(dy2d), _ptr(dw), _ptr(db), _ptr(ws), M, N, K, _stream()),
                "dfine_linear_wgrad_bf16")
     return (dw, db) if with_bias else dw
@@ -583,7 +637,7 @@ def stem_conv(x, wp, cout, ks, stride, pad, out_hw):
     B, cin, H, W = x.shape
     ho, wo = out_hw
     y = torch.empty(B, cout, ho, wo, device=x.device, dtype=torch.bfloat16)
-    with _timed("dfine_stem_conv_bf16"):
+    with _timed("stem_conv", 2.0 * B * ho * wo * cin * cout * ks * ks):
         _check(_lib.dfine_stem_conv_bf16(_ptr(x), _ptr(wp), _ptr(y), B, cin, cout, H, W, ho, wo, ks, stride, pad,
                                          _stream()), "dfine_stem_conv_bf16")
     return y
@@ -592,8 +646,9 @@ def stem_conv(x, wp, cout, ks, stride, pad, out_hw):
 def stem_dgrad_s2(dy, wq, cin):
     B, cout, ho, wo = dy.shape
     dx = torch.empty(B, cin, 2 * ho, 2 * wo, device=dy.device, dtype=torch.bfloat16)
-    _check(_lib.dfine_stem_dgrad_s2_bf16(_ptr(dy), _ptr(wq), _ptr(dx), B, cin, cout, ho, wo, _stream()),
-           "dfine_stem_dgrad_s2_bf16")
+    with _timed("stem_conv", 2.0 * B * ho * wo * cin * cout * 9):
+        _check(_lib.dfine_stem_dgrad_s2_bf16(_ptr(dy), _ptr(wq), _ptr(dx), B, cin, cout, ho, wo, _stream()),
+               "dfine_stem_dgrad_s2_bf16")
     return dx
 
 
@@ -609,8 +664,9 @@ def stem_wgrad(x, dy, ks, stride, pad):
     if ws is None or ws.numel() < need:
         ws = _STEM_WS[key] = torch.empty(need, device=x.device, dtype=torch.float32)
     dw = torch.empty(cout, cin, ks, ks, device=x.device, dtype=torch.float32)
-    _check(_lib.dfine_stem_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ho, wo, ks, stride,
-                                      pad, _stream()), "dfine_stem_wgrad_bf16")
+    with _timed("stem_wgrad", 2.0 * B * ho * wo * cin * cout * ks * ks):
+        _check(_lib.dfine_stem_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ho, wo, ks, stride,
+                                          pad, _stream()), "dfine_stem_wgrad_bf16")
     return dw
 
 

@@ -366,7 +366,11 @@ def _packed_weights(weight, dgrad):
         return ent[2]
     w2 = _hip().conv_pack_weights(weight.detach().float().contiguous(), dgrad)
     if batchable:
+        global _PACK_TABLE
+        # a new or REPLACED entry (id() reuse after an earlier model was freed) invalidates the device pointer table:
+        # neither len() nor the data_ptr check of _pack_all_registered would notice a replaced key
         _PACK_REGISTRY[key] = [weakref.ref(weight), dgrad, w2, weight.data_ptr(), weight._version]
+        _PACK_TABLE = None
     return w2
 
 
@@ -420,7 +424,9 @@ def bf16_param(p):
             ent[2], ent[3] = p.data_ptr(), p._version
         return ent[1]
     c = p.detach().to(torch.bfloat16)
+    global _BF16_TABLE
     _BF16_REGISTRY[id(p)] = [weakref.ref(p), c, p.data_ptr(), p._version]
+    _BF16_TABLE = None                 # inserted or replaced entry: rebuild the device pointer table
     return c
 
 
@@ -488,7 +494,8 @@ class _DenseConv(torch.autograd.Function):
         if plan["fwd"]:
             y = hip.conv_forward_bf16(x, _packed_weights(weight, False), weight.shape[0], ks)
         else:
-            y = F.conv2d(x, bf16_param(weight), None, 1, ks // 2)
+            with hip.timed("miopen_conv", 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * weight.numel()):
+                y = F.conv2d(x, bf16_param(weight), None, 1, ks // 2)
         ctx.save_for_backward(x, weight)
         ctx.plan = plan
         return y
@@ -507,9 +514,10 @@ class _DenseConv(torch.autograd.Function):
         dx = dw = None
         aten_dx, aten_dw = need_dx and not plan["dgrad"], need_dw and not plan["wgrad"]
         if aten_dx or aten_dw:
-            res = torch.ops.aten.convolution_backward(
-                dy, x, bf16_param(weight), None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
-                [aten_dx, aten_dw, False])
+            with hip.timed("miopen_conv", 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * weight.numel() * (int(aten_dx) + int(aten_dw))):
+                res = torch.ops.aten.convolution_backward(
+                    dy, x, bf16_param(weight), None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
+                    [aten_dx, aten_dw, False])
             dx = res[0] if aten_dx else None
             dw = res[1].to(weight.dtype) if aten_dw else None
         if need_dx and plan["dgrad"]:
@@ -890,6 +898,15 @@ def topk_anchors(logits: torch.Tensor, k: int) -> torch.Tensor:
             and q <= 16384 and k <= min(q, 1024):
         return _hip().topk_anchors(logits, k)
     return torch.topk(logits.max(-1).values, k, dim=-1).indices
+
+
+def detection_topk(logits: torch.Tensor, boxes: torch.Tensor, k: int, height: int, width: int, to_round: bool = True):
+    """A18 post-processor core (ref export.py:61-100): the k best (query, class) pairs of every image by sigmoid score ->
+    (labels [B,k] i64, query index [B,k] i64, absolute xyxy boxes [B,k,4] f32, scores [B,k] f32), descending.
+    One HIP kernel (csrc/postproc.hip); Q*C <= 32768 and k <= 1024."""
+    if not logits.is_cuda:
+        return _backend_for_cpu("detection_topk")(logits, boxes, k, height, width, to_round)
+    return _hip().postprocess(logits, boxes, k, height, width, to_round)
 
 
 def topk_indices(score: torch.Tensor, k: int) -> torch.Tensor:

@@ -268,6 +268,20 @@ int dfine_topk_anchors(const void *logits, int64_t sb, int64_t sq, int64_t *out_
                        int dtype, int B, int Q, int C, int K, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * A18  Detection post-processor: sigmoid -> top-K over the Q*C (query, class) scores of every image ->
+ * label = idx % C, query = idx // C -> normalised cxcywh -> absolute xyxy (floor / ceil + clamp when
+ * to_round).  Replaces DFINEPostProcessor.forward (src/dl/export.py:61-100, box arithmetic :35-59) and
+ * the identical top-K block of Trainer.preds_postprocess (src/dl/train.py:262-277) and
+ * Torch_model._preds_postprocess (src/infer/torch_model.py:197-214).
+ *   logits [B, Q, C] dtype, boxes [B, Q, 4] f32 ->
+ *   labels [B, K] i64, query_idx [B, K] i64, out_boxes [B, K, 4] f32, scores [B, K] f32 (descending;
+ *   ties: larger logit, then lower flat index).  Q*C <= 32768, K <= min(Q*C, 1024).
+ */
+int dfine_postprocess(const void *logits, const float *boxes, int64_t *labels, int64_t *query_idx,
+                      float *out_boxes, float *scores, int dtype, int B, int Q, int C, int K, int height,
+                      int width, int to_round, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * A5/A6  Weight gradient of a token-stream nn.Linear: dw [N, K] f32 = dy [M, N]^T x [M, K] (bf16,
  * row-major; M = B*Lq rows), split over the M reduction (the autograd formula of F.linear used by
  * MLP / FFN / Gate / attention projections, src/d_fine/arch/dfine_decoder.py:33-46,214-271).

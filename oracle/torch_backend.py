@@ -80,6 +80,25 @@ def hungarian_assign(logits, boxes, tgt_labels, tgt_boxes, sizes, w_class, w_bbo
     return torch.from_numpy(cols), torch.from_numpy(cost_out)
 
 
+def detection_topk(logits, boxes, k, height, width, to_round=True):
+    """DFINEPostProcessor's focal branch restated (reference src/dl/export.py:35-59 box arithmetic, :61-84 top-k):
+    sigmoid -> topk over Q*C -> idx % C, idx // C -> gathered absolute xyxy boxes."""
+    B, Q, C = logits.shape
+    b = boxes.float().reshape(-1, 4)
+    xc, yc, bw, bh = b[:, 0] * width, b[:, 1] * height, b[:, 2] * width, b[:, 3] * height
+    x0, y0, x1, y1 = xc - bw / 2, yc - bh / 2, xc + bw / 2, yc + bh / 2
+    if to_round:
+        x0, y0 = torch.clamp(torch.floor(x0), min=1), torch.clamp(torch.floor(y0), min=1)
+        x1, y1 = torch.clamp(torch.ceil(x1), max=width - 1), torch.clamp(torch.ceil(y1), max=height - 1)
+    else:
+        x0, y0 = torch.clamp(x0, min=0), torch.clamp(y0, min=0)
+        x1, y1 = torch.clamp(x1, max=width), torch.clamp(y1, max=height)
+    abs_boxes = torch.stack([x0, y0, x1, y1], 1).view(B, Q, 4)
+    scores, idx = torch.topk(torch.sigmoid(logits.float()).flatten(1), k, dim=-1)
+    labels, qidx = idx % C, idx // C
+    return labels, qidx, abs_boxes.gather(1, qidx.unsqueeze(-1).expand(-1, -1, 4)), scores
+
+
 def install():
     """Route CPU tensors of the HIP-backed operators to this module (tests / cpu baseline)."""
     import sys

@@ -48,19 +48,46 @@ def make_images(batch, size, seed=123):
     return torch.from_numpy(np.random.default_rng(seed).random((batch, 3, size, size), np.float32))
 
 
-def make_targets(batch, num_classes, seed=7, max_t=6, min_t=1, device="cpu"):
-    """COCO-shaped synthetic labels: boxes stay inside the image (cx,cy in [.2,.8], w,h in [.05,.35])."""
+def box_masks(boxes, size):
+    """Instance masks of the segmentation config: ellipses inscribed in the GT boxes,
+    uint8 [T, size, size] (an ellipse, not the filled rectangle, so that the box-cropped losses see both classes)."""
+    ys = (np.arange(size, dtype=np.float32) + 0.5)[None, :, None] / size
+    xs = (np.arange(size, dtype=np.float32) + 0.5)[None, None, :] / size
+    b = np.asarray(boxes, dtype=np.float32)
+    cx, cy, w, h = (b[:, i][:, None, None] for i in range(4))
+    return ((((xs - cx) / (w / 2)) ** 2 + ((ys - cy) / (h / 2)) ** 2) <= 1.0).astype(np.uint8)
+
+
+def make_targets(batch, num_classes, seed=7, max_t=6, min_t=1, device="cpu", mask_size=None):
+    """COCO-shaped synthetic labels: boxes stay inside the image (cx,cy in [.2,.8], w,h in [.05,.35]).
+    `mask_size`: also emit `masks` u8 [T, mask_size, mask_size] (segmentation task)."""
     rng = np.random.default_rng(seed)
     out = []
     for _ in range(batch):
         n = int(rng.integers(min_t, max_t + 1))
         cxcy = rng.uniform(0.2, 0.8, (n, 2))
         wh = rng.uniform(0.05, 0.35, (n, 2))
-        out.append({
+        boxes = np.concatenate([cxcy, wh], 1).astype(np.float32)
+        t = {
             "labels": torch.from_numpy(rng.integers(0, num_classes, n)).long().to(device),
-            "boxes": torch.from_numpy(np.concatenate([cxcy, wh], 1).astype(np.float32)).to(device),
-        })
+            "boxes": torch.from_numpy(boxes).to(device),
+        }
+        if mask_size is not None:
+            t["masks"] = torch.from_numpy(box_masks(boxes, mask_size)).to(device)
+        out.append(t)
     return out
+
+
+def make_postprocess_case(seed, B=2, Q=300, C=80):
+    """Decoder outputs for the post-processor goldens: logits with exact ties (duplicated queries, a constant row)
+    and boxes that poke outside the image (exercises the floor/ceil clamps)."""
+    rng = np.random.default_rng(seed)
+    logits = rng.normal(-2.0, 2.0, (B, Q, C)).astype(np.float32)
+    logits[0, 5] = logits[0, 3]                      # tie between two queries
+    logits[B - 1, 7, :] = 0.25                       # tie inside one query
+    boxes = np.concatenate([rng.uniform(0.0, 1.0, (B, Q, 2)), rng.uniform(0.01, 0.6, (B, Q, 2))], -1).astype(np.float32)
+    orig = np.array([[480, 640], [1080, 1920], [333, 500], [640, 640]][:B], dtype=np.int64)
+    return logits, boxes, orig
 
 
 def make_msda_case(seed, B=2, Lq=16, H=8, D=4, shapes=((8, 8), (4, 4), (2, 2)), points=(3, 6, 3)):

@@ -32,6 +32,7 @@ def _worker(rank, world, port, out_dir):
     assert dist_utils.get_world_size() == world and dist_utils.get_rank() == rank
     assert dist_utils.all_gather_object({"r": rank}) == [{"r": 0}, {"r": 1}]
     assert dist_utils.broadcast_scalar(3.5 if rank == 0 else -1.0) == 3.5
+    assert dist_utils.host_all_reduce_sum([rank + 1, 2.0]) == [3.0, 4.0]
     red = dist_utils.reduce_dict({"a": torch.tensor(float(rank)), "b": torch.tensor(2.0)})
     assert red["a"].item() == 0.5 and red["b"].item() == 2.0
 

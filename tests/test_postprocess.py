@@ -1,0 +1,107 @@
+"""A18 post-processor (reference src/dl/export.py:61-100, src/dl/utils.py:673-712) against goldens generated from the
+reference: labels / query split are integer work -> bit-exact; boxes are exact fp32 (same operation order, integral after
+floor/ceil); scores within 1e-6.  CPU: the oracle restatement + the host box mapping.  GPU: the HIP kernel."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers
+
+G = helpers.GOLDEN_DIR
+CASES = ((0, {}), (1, dict(B=3, Q=40, C=7)))
+
+
+def _canon(labels, boxes, scores):
+    """torch.topk leaves the order of tied scores unspecified: sort (score desc, label, box) lexicographically."""
+    labels, boxes, scores = (np.asarray(a) for a in (labels, boxes, scores))
+    out = []
+    for b in range(labels.shape[0]):
+        key = np.lexsort((boxes[b][:, 3], boxes[b][:, 2], boxes[b][:, 1], boxes[b][:, 0], labels[b], -scores[b]))
+        out.append((labels[b][key], boxes[b][key], scores[b][key]))
+    return out
+
+
+def _check(got, g, prefix, k_expected):
+    labels, boxes, scores = got
+    assert labels.dtype == torch.int64 and boxes.dtype == torch.float32 and scores.dtype == torch.float32
+    assert labels.shape[1] == k_expected
+    a = _canon(labels.cpu().numpy(), boxes.cpu().numpy(), scores.cpu().numpy())
+    b = _canon(g[prefix + "/labels"], g[prefix + "/boxes"], g[prefix + "/scores"])
+    for (la, ba, sa), (lb, bb, sb) in zip(a, b):
+        np.testing.assert_allclose(sa, sb, rtol=0, atol=1e-6)
+        # scores 1 ulp apart may swap neighbours between two exp implementations: compare as multisets of rows
+        ra = sorted(map(tuple, np.concatenate([la[:, None].astype(np.float64), ba], 1).tolist()))
+        rb = sorted(map(tuple, np.concatenate([lb[:, None].astype(np.float64), bb], 1).tolist()))
+        assert ra == rb                                      # labels and boxes bit-exact
+        assert (np.diff(sa) <= 0).all()                      # descending
+
+
+@pytest.mark.parametrize("seed,kw", CASES)
+def test_oracle_postprocessor_matches_reference(oracle_backend, seed, kw):
+    from custom_d_fine_amd.dl.export import DFINEPostProcessor
+    g = np.load(f"{G}/postprocess.npz")
+    logits, boxes, _ = helpers.make_postprocess_case(seed, **kw)
+    pp = DFINEPostProcessor(logits.shape[-1], num_top_queries=300)
+    o = {"pred_logits": torch.tensor(logits), "pred_boxes": torch.tensor(boxes)}
+    for hh, ww in ((640, 640), (384, 512)):
+        _check(pp(o, hh, ww), g, f"s{seed}/{hh}x{ww}", min(300, logits.shape[1] * logits.shape[2]))
+
+
+@pytest.mark.parametrize("seed,kw", CASES)
+@pytest.mark.parametrize("keep_ratio", [False, True])
+def test_process_boxes_matches_reference(seed, kw, keep_ratio):
+    from custom_d_fine_amd.dl.postprocess import process_boxes
+    g = np.load(f"{G}/postprocess.npz")
+    _, boxes, orig = helpers.make_postprocess_case(seed, **kw)
+    got = process_boxes(torch.tensor(boxes), (640, 640), torch.tensor(orig), keep_ratio)
+    np.testing.assert_allclose(got.numpy(), g[f"s{seed}/process_boxes/keep{int(keep_ratio)}"], rtol=1e-6, atol=1e-4)
+
+
+def test_preds_postprocess_contract(oracle_backend):
+    from custom_d_fine_amd.dl.postprocess import preds_postprocess
+    logits, boxes, orig = helpers.make_postprocess_case(0)
+    res = preds_postprocess(torch.zeros(2, 3, 640, 640), {"pred_logits": torch.tensor(logits), "pred_boxes": torch.tensor(boxes)},
+                            torch.tensor(orig), 80, False, 0.5)
+    assert len(res) == 2
+    for r in res:
+        assert set(r) == {"labels", "boxes", "scores", "all_boxes", "all_scores", "all_labels"}
+        assert r["all_scores"].shape == (300,) and (r["scores"] >= 0.5).all() and len(r["scores"]) == int((r["all_scores"] >= 0.5).sum())
+        assert r["labels"].dtype == torch.int64 and r["labels"].max() < 80
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,kw", CASES)
+def test_hip_postprocessor_matches_reference(cuda, seed, kw):
+    from custom_d_fine_amd.dl.export import DFINEPostProcessor
+    g = np.load(f"{G}/postprocess.npz")
+    logits, boxes, _ = helpers.make_postprocess_case(seed, **kw)
+    pp = DFINEPostProcessor(logits.shape[-1], num_top_queries=300)
+    o = {"pred_logits": torch.tensor(logits, device=cuda), "pred_boxes": torch.tensor(boxes, device=cuda)}
+    for hh, ww in ((640, 640), (384, 512)):
+        _check(pp(o, hh, ww), g, f"s{seed}/{hh}x{ww}", min(300, logits.shape[1] * logits.shape[2]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_hip_postprocessor_full_size_vs_oracle(cuda, dtype):
+    """B = 32, Q = 300, C = 80 (the eval shape of BASELINE configs[2]); oracle = the torch restatement on the host."""
+    from custom_d_fine_amd import kernels
+    from oracle import torch_backend
+    gen = torch.Generator().manual_seed(5)
+    logits = (torch.randn(32, 300, 80, generator=gen) * 2 - 2).to(dtype)
+    boxes = torch.cat([torch.rand(32, 300, 2, generator=gen), torch.rand(32, 300, 2, generator=gen) * 0.5], -1)
+    labels, qidx, out_boxes, scores = kernels.detection_topk(logits.to(cuda), boxes.to(cuda), 300, 640, 640)
+    rl, rq, rb, rs = torch_backend.detection_topk(logits, boxes, 300, 640, 640)
+    assert (qidx < 300).all() and (labels < 80).all() and (qidx >= 0).all() and (labels >= 0).all()
+    np.testing.assert_allclose(scores.cpu().numpy(), rs.numpy(), atol=1e-6, rtol=0)
+    flat_got, flat_ref = (qidx * 80 + labels).cpu(), rq * 80 + rl
+    for b in range(32):
+        assert len(set(flat_got[b].tolist())) == 300
+        if dtype == torch.float32:                            # bf16 logits tie at the cut: any of the tied is valid
+            assert set(flat_got[b].tolist()) == set(flat_ref[b].tolist())
+    # every returned box is the exact conversion of the returned query's box
+    _, q_all, b_all, _ = torch_backend.detection_topk(torch.zeros(32, 300, 1), boxes, 300, 640, 640)   # all queries
+    table = torch.empty(32, 300, 4)
+    table.scatter_(1, q_all.unsqueeze(-1).expand(-1, -1, 4), b_all)
+    want = table.gather(1, qidx.cpu().unsqueeze(-1).expand(-1, -1, 4))
+    np.testing.assert_array_equal(out_boxes.cpu().numpy(), want.numpy())

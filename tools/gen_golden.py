@@ -16,12 +16,11 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from ref_import import import_reference  # noqa: E402
-from tests import helpers  # noqa: E402
+from tests import helpers  # noqa: E402  (before the reference import: that one re-binds `src`)
+from ref_import import import_reference_dl  # noqa: E402
 
-ref = import_reference()
+ref = import_reference_dl()
 OUT = os.path.join(ROOT, "tests", "golden")
-os.makedirs(OUT, exist_ok=True)
 
 
 def save(name, **arrays):
@@ -167,10 +166,135 @@ def gen_model(size, img, batch, name, train=True):
     save(name, **out)
 
 
+# ------------------------------------------------------------------ A18: post-processor
+def gen_postprocess():
+    out = {}
+    for seed, kw in ((0, {}), (1, dict(B=3, Q=40, C=7))):
+        logits, boxes, orig = helpers.make_postprocess_case(seed, **kw)
+        C = logits.shape[-1]
+        pp = ref.dl_export.DFINEPostProcessor(C, num_top_queries=300)
+        o = {"pred_logits": torch.tensor(logits), "pred_boxes": torch.tensor(boxes)}
+        for hh, ww in ((640, 640), (384, 512)):
+            labels, bx, scores = pp(o, hh, ww)
+            out[f"s{seed}/{hh}x{ww}/labels"] = labels.numpy()
+            out[f"s{seed}/{hh}x{ww}/boxes"] = bx.numpy()
+            out[f"s{seed}/{hh}x{ww}/scores"] = scores.numpy()
+        # Trainer.preds_postprocess = process_boxes (map to the original image) + the same top-k (train.py:240-332;
+        # train.py itself needs the whole training tool-chain to import, its box mapping lives in src/dl/utils.py)
+        for keep_ratio in (False, True):
+            pb = ref.dl_utils.process_boxes(torch.tensor(boxes), (640, 640), torch.tensor(orig), keep_ratio, "cpu")
+            out[f"s{seed}/process_boxes/keep{int(keep_ratio)}"] = pb.numpy()
+        out[f"s{seed}/orig_sizes"] = orig
+    save("postprocess.npz", **out)
+
+
+# ------------------------------------------------------------------ A10 / A15: mask decoder, mask losses, mask costs
+def _pool8(t):
+    """[B,Q,H,W] -> [B,Q,8,8] area means: a compact fingerprint of the mask maps."""
+    return torch.nn.functional.adaptive_avg_pool2d(t, 8)
+
+
+def gen_mask_units():
+    out = {}
+    # MaskDecoder on small maps (ref dfine_decoder.py:316-370)
+    torch.manual_seed(5)
+    md = ref.decoder.MaskDecoder([64, 64, 64], out_ch=64)
+    md.load_state_dict(helpers.seeded_state_dict(md.state_dict()))
+    g = torch.Generator().manual_seed(6)
+    feats = [torch.randn(2, 64, s, s, generator=g, requires_grad=True) for s in (20, 10, 5)]
+    y = md(feats)
+    go = torch.randn(y.shape, generator=g)
+    y.backward(go)
+    out["md/out"] = y.detach().numpy()
+    out["md/grad_out"] = go.numpy()
+    for i, f in enumerate(feats):
+        out[f"md/feat{i}"] = f.detach().numpy()
+        out[f"md/g_feat{i}"] = f.grad.numpy()
+    out["md/g_up_conv"] = md.up_conv.weight.grad.numpy()
+    out["md/g_lateral1"] = md.lateral[1].weight.grad.numpy()
+    out["md/g_gn0_w"] = md.bn[0].weight.grad.numpy()
+
+    # cropped BCE / Dice + target preparation (ref dfine_criterion.py:239-270,335-450,504-556)
+    crit = ref.dfine.build_loss("n", 80, 0.0, True)
+    targets = helpers.make_targets(2, 80, seed=9, mask_size=64)
+    pm = torch.randn(2, 12, 16, 16, generator=g, requires_grad=True)
+    indices = [(torch.tensor([1, 4, 7][:len(t["labels"])]), torch.arange(len(t["labels"]))[:3]) for t in targets]
+    losses = crit.loss_masks({"pred_masks": pm}, targets, indices, 1.0)
+    (losses["loss_mask_bce"] + 2 * losses["loss_mask_dice"]).backward()
+    out["loss/pred_masks"] = pm.detach().numpy()
+    out["loss/bce"] = losses["loss_mask_bce"].detach().numpy()
+    out["loss/dice"] = losses["loss_mask_dice"].detach().numpy()
+    out["loss/g_pred_masks"] = pm.grad.numpy()
+    for b, (i, j) in enumerate(indices):
+        out[f"loss/rows{b}"] = i.numpy()
+        out[f"loss/cols{b}"] = j.numpy()
+
+    # matcher with mask costs (ref matcher.py:19-71,175-237)
+    matcher = ref.matcher.HungarianMatcher(**ref.configs.models["n"]["matcher"])
+    logits, boxes, _ = helpers.make_matcher_case(3, B=2, Q=12, C=80, sizes=(3, 3))
+    captured = []
+    orig = ref.matcher.linear_sum_assignment
+
+    def spy(c):
+        captured.append(np.array(c, copy=True))
+        return orig(c)
+
+    ref.matcher.linear_sum_assignment = spy
+    res = matcher({"pred_logits": torch.tensor(logits), "pred_boxes": torch.tensor(boxes),
+                   "pred_masks": pm.detach()}, targets)
+    ref.matcher.linear_sum_assignment = orig
+    for b, ((i, j), c) in enumerate(zip(res["indices"], captured)):
+        out[f"match/rows{b}"] = i.numpy()
+        out[f"match/cols{b}"] = j.numpy()
+        out[f"match/cost{b}"] = c.astype(np.float32)
+    save("mask_units.npz", **out)
+
+
+def gen_mask_model():
+    """D-FINE-n + segmentation head, 320x320, bs 2 (the code path of BASELINE config #5 at a size the CPU reference
+    finishes in seconds): eval boxes/logits/mask fingerprints, all train losses incl. the mask terms, mask-path gradients."""
+    torch.manual_seed(0)
+    model = ref.dfine.build_model("n", 80, True, "cpu", img_size=[320, 320])
+    model.load_state_dict(helpers.seeded_state_dict(model.state_dict()))
+    x = helpers.make_images(2, 320)
+    out = {}
+    model.eval()
+    with torch.no_grad():
+        o = model(x)
+    out["eval/pred_logits"] = o["pred_logits"].numpy()
+    out["eval/pred_boxes"] = o["pred_boxes"].numpy()
+    out["eval/pred_masks_pool8"] = _pool8(o["pred_masks"]).numpy()
+    targets = helpers.make_targets(2, 80, mask_size=320)
+    crit = ref.dfine.build_loss("n", 80, 0.0, True)
+    model.train()
+    torch.manual_seed(11)
+    o = model(x, targets)
+    losses = crit(o, targets)
+    sum(losses.values()).backward()
+    for k, v in losses.items():
+        out[f"train/loss/{k}"] = v.detach().numpy()
+    for k in ("decoder.mask_decoder.up_conv.weight", "decoder.mask_decoder.lateral.0.weight",
+              "decoder.mask_head.layers.2.weight", "encoder.input_proj.0.conv.weight",
+              "decoder.dec_bbox_head.1.layers.2.weight"):
+        out[f"train/grad/{k}"] = dict(model.named_parameters())[k].grad.numpy()
+    save("model_n320_mask.npz", **out)
+
+
+GENERATORS = {
+    "lsap": gen_lsap, "msda": gen_msda, "matcher": gen_matcher, "criterion": gen_criterion,
+    "model_n320": lambda: gen_model("n", 320, 2, "model_n320.npz"),
+    "model_m640_eval": lambda: gen_model("m", 640, 1, "model_m640_eval.npz", train=False),
+    "model_s320": lambda: gen_model("s", 320, 2, "model_s320.npz"),
+    "postprocess": gen_postprocess, "mask_units": gen_mask_units, "model_n320_mask": gen_mask_model,
+}
+
 if __name__ == "__main__":
-    gen_lsap()
-    gen_msda()
-    gen_matcher()
-    gen_criterion()
-    gen_model("n", 320, 2, "model_n320.npz")
-    gen_model("m", 640, 1, "model_m640_eval.npz", train=False)
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=OUT, help="output directory (default tests/golden)")
+    ap.add_argument("only", nargs="*", help=f"subset of {sorted(GENERATORS)}")
+    a = ap.parse_args()
+    OUT = a.out
+    os.makedirs(OUT, exist_ok=True)
+    for name in (a.only or GENERATORS):
+        GENERATORS[name]()

@@ -37,11 +37,22 @@ def install_stubs():
         sys.modules["torchvision.ops.boxes"] = boxes
 
 
+def _bind_src_to_reference():
+    """Makes `src` mean /root/reference/src.  The repo root carries its own `src` alias package (a regular
+    package, so it would win over the reference's namespace package whenever the repo root is on sys.path, and
+    its meta-path finder would route `src.d_fine.*` to THIS build): drop both and pin `src.__path__`."""
+    for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+        del sys.modules[k]
+    sys.meta_path[:] = [f for f in sys.meta_path if type(f).__name__ != "_AliasFinder"]
+    pkg = types.ModuleType("src")
+    pkg.__path__ = [REF_ROOT + "/src"]
+    sys.modules["src"] = pkg
+
+
 def import_reference():
     """Returns the reference's `src.d_fine` package modules as a namespace."""
     install_stubs()
-    if REF_ROOT not in sys.path:
-        sys.path.insert(0, REF_ROOT)
+    _bind_src_to_reference()
     import importlib
 
     ns = types.SimpleNamespace()
@@ -53,4 +64,38 @@ def import_reference():
     ns.decoder = importlib.import_module("src.d_fine.arch.dfine_decoder")
     ns.encoder = importlib.import_module("src.d_fine.arch.hybrid_encoder")
     ns.backbone = importlib.import_module("src.d_fine.arch.hgnetv2")
+    for m in vars(ns).values():
+        assert m.__file__.startswith(REF_ROOT + "/"), f"{m.__name__} resolved to {m.__file__}, not the reference"
+    return ns
+
+
+_DL_ABSENT = ("hydra", "onnx", "onnxsim", "openvino", "tensorrt", "omegaconf", "onnxconverter_common", "wandb",
+              "cv2", "albumentations", "albumentations.core", "albumentations.core.transforms_interface",
+              "albumentations.pytorch", "faster_coco_eval", "faster_coco_eval.core", "matplotlib",
+              "matplotlib.pyplot", "torchmetrics", "torchmetrics.detection", "torchmetrics.detection.mean_ap")
+
+
+def import_reference_dl():
+    """`src.dl.export` / `src.dl.utils` of the reference (golden generator only).  Their module-level
+    imports of tool-chains this container lacks (hydra, onnx, TensorRT, OpenVINO, cv2, albumentations, wandb ...)
+    are satisfied by inert placeholder modules: none of the functions the generator calls
+    (`DFINEPostProcessor`, `process_boxes`) touches them."""
+    from unittest import mock
+    ns = import_reference()
+    for name in _DL_ABSENT:
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                m = mock.MagicMock(name=name)
+                m.__path__ = []
+                sys.modules[name] = m
+    tv = sys.modules["torchvision"]
+    if not hasattr(tv.ops, "nms"):
+        tv.ops.nms = None
+        tv.ops.box_iou = None
+    import importlib
+    ns.dl_utils = importlib.import_module("src.dl.utils")
+    ns.dl_export = importlib.import_module("src.dl.export")
+    assert ns.dl_export.__file__.startswith(REF_ROOT + "/") and ns.dl_utils.__file__.startswith(REF_ROOT + "/")
     return ns
