@@ -1,0 +1,315 @@
+// A2 (AIFI) / A3 / A5 / A6 - token-stream linear layers on the MFMA units:
+//     Y[M, N] = act(X[M, K] . W[N, K]^T + bias[N])            bf16 operands, fp32 accumulate, bf16 (or fp32) output
+// Reference call sites: nn.Linear inside MLP / FFN / Gate / attention projections / enc_output / score heads
+// (src/d_fine/arch/dfine_decoder.py:33-46,119-178,214-271,828-873, src/d_fine/arch/hybrid_encoder.py:243-290) - each an
+// ATen addmm (hipBLASLt) plus separate activation kernels.  M = B * Lq = 15 744 token rows (12 800 for AIFI, 268 800 for
+// the encoder-output heads), N, K <= 1024: small GEMMs whose cost is launch + one pass over X and Y, so the kernel is one
+// launch with the bias / ReLU / GELU / SiLU epilogue fused and nothing else around it.
+// The data gradient dX[M, K] = dY[M, N] . W[N, K] is the same kernel on a bf16 TRANSPOSED copy of the weight
+// (dfine_multi_cast_bf16_t refreshes all transposed shadows with one launch per optimizer step).
+//
+// Both operands are K-contiguous, so MFMA fragments are plain 16-byte LDS reads:
+//   block = 256 threads = 4 waves (2 x 2), tile 128 (n) x 128 (m) x 64 (k); wave = 64 x 64 = 4 x 4 MFMA 16x16x32 tiles.
+//   A operand = W rows (n), B operand = X rows (m)  ->  D lane l = Y[m = l & 15][n = 4 (l >> 4) .. + 3]: four consecutive
+//   output features per lane, one 8-byte store (the 4 lanes sharing an m write 32 contiguous bytes).
+//   LDS rows are 72 elements (144 B): the 16 rows of a fragment read fall into 16 different 16-byte bank slots.
+//   Register-staged double buffering, one barrier per 64-deep k step (the write of stage t + 2 is ordered behind the
+//   barrier of stage t + 1, which every wave reaches only after its MFMAs of stage t).
+//   XCD-aware block order: the n tiles of one m tile are consecutive workgroups of ONE XCD (X tile read from HBM once).
+#include "common.h"
+
+namespace dfine {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 g_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float g_f32x4;
+
+constexpr int kGemmThreads = 256;
+constexpr int kGBM = 128, kGBN = 128, kGBK = 64, kGPitch = 72;
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));      // exact GELU (nn.GELU default)
+    if (act == 3) return v / (1.f + __expf(-v));
+    return v;
+}
+
+// x [M, K] (ld = ldx), w [N, K] (ld = ldw) bf16; bias fp32 [N] or null; y [M, N] (ld = ldy) bf16 (OUT32 = 0) / fp32 (1).
+template <int ACT, int OUT32>
+__global__ __launch_bounds__(kGemmThreads) void linear_act_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,
+                                                                  const float *__restrict__ bias, void *__restrict__ yv,
+                                                                  int M, int N, int K, int ldx, int ldw, int ldy, int nt_n,
+                                                                  int nt_m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    uint16_t *sA = reinterpret_cast<uint16_t *>(lds);                       // [2][kGBN][kGPitch]  W rows
+    uint16_t *sB = sA + 2 * kGBN * kGPitch;                                 // [2][kGBM][kGPitch]  X rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tn = slot % nt_n, tm = (slot / nt_n) * 8 + xcd;
+    if (tm >= nt_m) return;
+    const int n0 = tn * kGBN, m0 = tm * kGBM;
+    const int wn = wave >> 1, wm = wave & 1;
+    const int g = lane >> 4, i16 = lane & 15;
+
+    g_f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = g_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging: 128 rows x 8 sixteen-byte chunks per operand = 1024 chunks / 256 threads = 4 per thread and operand
+    const int st_chunk = tid & 7, st_row = tid >> 3;                        // rows st_row + 32 j
+    const bool vec_x = (ldx & 7) == 0 && (K & 7) == 0, vec_w = (ldw & 7) == 0 && (K & 7) == 0;
+    uint4 pa[4], pb[4];
+    auto load_rows = [&](const uint16_t *base, int ld, int r0, int rmax, bool vec, int k0, uint4 (&dst)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + st_row + 32 * j, k = k0 + st_chunk * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r < rmax && k < K) {
+                const uint16_t *p = base + (int64_t)r * ld + k;
+                if (vec) v = *reinterpret_cast<const uint4 *>(p);          // K % 8 == 0: the chunk is entirely inside the row
+                else {                                                     // odd K (4, 20, 33 ...): element loads
+                    uint32_t q0 = 0u, q1 = 0u, q2 = 0u, q3 = 0u;
+                    if (k + 0 < K) q0 |= (uint32_t)p[0];
+                    if (k + 1 < K) q0 |= (uint32_t)p[1] << 16;
+                    if (k + 2 < K) q1 |= (uint32_t)p[2];
+                    if (k + 3 < K) q1 |= (uint32_t)p[3] << 16;
+                    if (k + 4 < K) q2 |= (uint32_t)p[4];
+                    if (k + 5 < K) q2 |= (uint32_t)p[5] << 16;
+                    if (k + 6 < K) q3 |= (uint32_t)p[6];
+                    if (k + 7 < K) q3 |= (uint32_t)p[7] << 16;
+                    v = make_uint4(q0, q1, q2, q3);
+                }
+            }
+            dst[j] = v;
+        }
+    };
+    auto fetch = [&](int k0) {
+        load_rows(w, ldw, n0, N, vec_w, k0, pa);
+        load_rows(x, ldx, m0, M, vec_x, k0, pb);
+    };
+    auto stash = [&](int buf) {
+        uint16_t *da = sA + buf * kGBN * kGPitch, *db = sB + buf * kGBM * kGPitch;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<uint4 *>(da + (st_row + 32 * j) * kGPitch + st_chunk * 8) = pa[j];
+            *reinterpret_cast<uint4 *>(db + (st_row + 32 * j) * kGPitch + st_chunk * 8) = pb[j];
+        }
+    };
+
+    const int nk = (K + kGBK - 1) / kGBK;
+    fetch(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        stash(buf);
+        __syncthreads();
+        if (kt + 1 < nk) fetch((kt + 1) * kGBK);                            // in flight during the MFMAs below
+        const uint16_t *la = sA + buf * kGBN * kGPitch + (wn * 64 + i16) * kGPitch + 8 * g;
+        const uint16_t *lb = sB + buf * kGBM * kGPitch + (wm * 64 + i16) * kGPitch + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < kGBK / 32; ++ks) {
+            g_bf16x8 af[4], bf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = __builtin_bit_cast(g_bf16x8, *reinterpret_cast<const uint4 *>(la + t * 16 * kGPitch + ks * 32));
+                bf[t] = __builtin_bit_cast(g_bf16x8, *reinterpret_cast<const uint4 *>(lb + t * 16 * kGPitch + ks * 32));
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: bias + activation, lane -> Y[m][n .. n + 3] ------------------------------------------------------
+    const bool vec_y = OUT32 ? (ldy & 3) == 0 : (ldy & 3) == 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int n = n0 + wn * 64 + a * 16 + 4 * g;
+        if (n >= N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < N) bv[r] = bias[n + r];
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int m = m0 + wm * 64 + b * 16 + i16;
+            if (m >= M) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = act_apply(acc[a][b][r] + bv[r], ACT);
+            if (OUT32) {
+                float *yp = reinterpret_cast<float *>(yv) + (int64_t)m * ldy + n;
+                if (vec_y && n + 3 < N) *reinterpret_cast<float4 *>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                else for (int r = 0; r < 4 && n + r < N; ++r) yp[r] = v[r];
+            } else {
+                uint16_t *yp = reinterpret_cast<uint16_t *>(yv) + (int64_t)m * ldy + n;
+                if (vec_y && n + 3 < N) {
+                    uint2 o;
+                    o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2 *>(yp) = o;
+                } else {
+                    for (int r = 0; r < 4 && n + r < N; ++r) yp[r] = f32_to_bf16(v[r]);
+                }
+            }
+        }
+    }
+}
+
+// fp32 [rows, cols] -> bf16 [cols, rows] (transposed shadow of a Linear weight), many tensors per launch.
+// table rows of 4 x int64 = {src ptr, dst ptr, rows, cols}; blockIdx.y = entry, 32 x 32 LDS tiles.
+__global__ __launch_bounds__(256) void multi_cast_bf16_t_kernel(const int64_t *__restrict__ table) {
+    __shared__ float tile[32][33];
+    const int64_t *e = table + (int64_t)blockIdx.y * 4;
+    const float *src = reinterpret_cast<const float *>(e[0]);
+    uint16_t *dst = reinterpret_cast<uint16_t *>(e[1]);
+    const int rows = (int)e[2], cols = (int)e[3];
+    const int tr = (rows + 31) / 32, tc = (cols + 31) / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                 // 32 x 8
+    for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+        const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + ty + 8 * j, c = c0 + tx;
+            tile[ty + 8 * j][tx] = (r < rows && c < cols) ? src[(int64_t)r * cols + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + ty + 8 * j, r = r0 + tx;
+            if (r < rows && c < cols) dst[(int64_t)c * rows + r] = f32_to_bf16(tile[tx][ty + 8 * j]);
+        }
+        __syncthreads();
+    }
+}
+
+// dpre = dy * act'(.) for the fused-epilogue activations, from the saved OUTPUT y for ReLU (y > 0) and from the saved
+// pre-activation z for GELU / SiLU.  bf16 in / out, 8 elements per thread.
+template <int ACT>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ ref,
+                                                      uint16_t *__restrict__ out, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 d = reinterpret_cast<const uint4 *>(dy)[i], r = reinterpret_cast<const uint4 *>(ref)[i];
+        const uint32_t dw[4] = {d.x, d.y, d.z, d.w}, rw[4] = {r.x, r.y, r.z, r.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float g0 = __uint_as_float(dw[j] << 16), g1 = __uint_as_float(dw[j] & 0xffff0000u);
+            const float z0 = __uint_as_float(rw[j] << 16), z1 = __uint_as_float(rw[j] & 0xffff0000u);
+            if (ACT == 1) { g0 = z0 > 0.f ? g0 : 0.f; g1 = z1 > 0.f ? g1 : 0.f; }
+            else if (ACT == 2) {
+                const float c = 0.70710678118654752440f, k = 0.39894228040143267794f;       // 1/sqrt(2), 1/sqrt(2 pi)
+                g0 *= 0.5f * (1.f + erff(z0 * c)) + z0 * k * __expf(-0.5f * z0 * z0);
+                g1 *= 0.5f * (1.f + erff(z1 * c)) + z1 * k * __expf(-0.5f * z1 * z1);
+            } else if (ACT == 3) {
+                const float s0 = 1.f / (1.f + __expf(-z0)), s1 = 1.f / (1.f + __expf(-z1));
+                g0 *= s0 * (1.f + z0 * (1.f - s0)); g1 *= s1 * (1.f + z1 * (1.f - s1));
+            }
+            o[j] = (uint32_t)f32_to_bf16(g0) | ((uint32_t)f32_to_bf16(g1) << 16);
+        }
+        reinterpret_cast<uint4 *>(out)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// y = act(z), bf16, 8 elements per thread (training-time GELU / SiLU: the pre-activation z is what backward needs)
+template <int ACT>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const uint16_t *__restrict__ z, uint16_t *__restrict__ y, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 d = reinterpret_cast<const uint4 *>(z)[i];
+        const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = (uint32_t)f32_to_bf16(act_apply(__uint_as_float(dw[j] << 16), ACT)) |
+                   ((uint32_t)f32_to_bf16(act_apply(__uint_as_float(dw[j] & 0xffff0000u), ACT)) << 16);
+        reinterpret_cast<uint4 *>(y)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+}  // namespace dfine
+
+using namespace dfine;
+
+extern "C" {
+
+int dfine_linear_act_fwd(const void *x, const void *w, const float *bias, void *y, int M, int N, int K, int ldx, int ldw,
+                         int ldy, int act, int out_f32, void *stream) {
+    if (M == 0 || N == 0) return DFINE_OK;
+    if (!x || !w || !y || M < 0 || N < 0 || K < 1 || ldx < K || ldw < K || ldy < N || act < 0 || act > 3) return DFINE_E_BADARG;
+    const int nt_n = (N + kGBN - 1) / kGBN, nt_m = (M + kGBM - 1) / kGBM;
+    const size_t ldsb = (size_t)2 * (kGBN + kGBM) * kGPitch * 2;            // 73 728 B
+    dim3 grid(8 * ((nt_m + 7) / 8) * nt_n);
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_set = false;       // once: not a stream operation, keep it out of graph capture
+#define DFINE_LA_ATTR(A, O)                                                                                              \
+    hipFuncSetAttribute(reinterpret_cast<const void *>(linear_act_kernel<A, O>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                        (int)ldsb)
+    if (!attr_set) {
+        hipError_t e = hipSuccess;
+        hipError_t r;
+        if ((r = DFINE_LA_ATTR(0, 0)) != hipSuccess) e = r;
+        if ((r = DFINE_LA_ATTR(1, 0)) != hipSuccess) e = r;
+        if ((r = DFINE_LA_ATTR(2, 0)) != hipSuccess) e = r;
+        if ((r = DFINE_LA_ATTR(3, 0)) != hipSuccess) e = r;
+        if ((r = DFINE_LA_ATTR(0, 1)) != hipSuccess) e = r;
+        if ((r = DFINE_LA_ATTR(1, 1)) != hipSuccess) e = r;
+        if ((r = DFINE_LA_ATTR(2, 1)) != hipSuccess) e = r;
+        if ((r = DFINE_LA_ATTR(3, 1)) != hipSuccess) e = r;
+        if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
+        attr_set = true;
+    }
+#undef DFINE_LA_ATTR
+#define DFINE_LA(A, O)                                                                                                   \
+    hipLaunchKernelGGL((linear_act_kernel<A, O>), grid, dim3(kGemmThreads), ldsb, st, (const uint16_t *)x, (const uint16_t *)w, \
+                       bias, y, M, N, K, ldx, ldw, ldy, nt_n, nt_m)
+#define DFINE_LA_O(A) { if (out_f32) DFINE_LA(A, 1); else DFINE_LA(A, 0); }
+    switch (act) {
+        case 0: DFINE_LA_O(0) break;
+        case 1: DFINE_LA_O(1) break;
+        case 2: DFINE_LA_O(2) break;
+        default: DFINE_LA_O(3) break;
+    }
+#undef DFINE_LA_O
+#undef DFINE_LA
+    return check_launch();
+}
+
+// table: device int64 [n_entries][4] = {src fp32 [rows, cols], dst bf16 [cols, rows], rows, cols}
+int dfine_multi_cast_bf16_t(const void *table, int n_entries, void *stream) {
+    if (n_entries == 0) return DFINE_OK;
+    if (!table || n_entries < 0) return DFINE_E_BADARG;
+    hipLaunchKernelGGL(multi_cast_bf16_t_kernel, dim3(64, n_entries), dim3(256), 0, (hipStream_t)stream, (const int64_t *)table);
+    return check_launch();
+}
+
+int dfine_act_fwd_bf16(const void *z, void *y, int64_t n, int act, void *stream) {
+    if (n == 0) return DFINE_OK;
+    if (!z || !y || n < 0 || (n & 7) || act < 1 || act > 3) return DFINE_E_BADARG;
+    const int64_t n8 = n / 8;
+    int blocks = (int)((n8 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (act == 1) hipLaunchKernelGGL(act_fwd_kernel<1>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)z, (uint16_t *)y, n8);
+    else if (act == 2) hipLaunchKernelGGL(act_fwd_kernel<2>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)z, (uint16_t *)y, n8);
+    else hipLaunchKernelGGL(act_fwd_kernel<3>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)z, (uint16_t *)y, n8);
+    return check_launch();
+}
+
+// out = dy * act'(ref): ref = saved output (act 1, ReLU) or saved pre-activation (act 2 GELU, 3 SiLU); bf16, n % 8 == 0
+int dfine_act_bwd_bf16(const void *dy, const void *ref, void *out, int64_t n, int act, void *stream) {
+    if (n == 0) return DFINE_OK;
+    if (!dy || !ref || !out || n < 0 || (n & 7) || act < 1 || act > 3) return DFINE_E_BADARG;
+    const int64_t n8 = n / 8;
+    int blocks = (int)((n8 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (act == 1) hipLaunchKernelGGL(act_bwd_kernel<1>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)dy, (const uint16_t *)ref, (uint16_t *)out, n8);
+    else if (act == 2) hipLaunchKernelGGL(act_bwd_kernel<2>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)dy, (const uint16_t *)ref, (uint16_t *)out, n8);
+    else hipLaunchKernelGGL(act_bwd_kernel<3>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)dy, (const uint16_t *)ref, (uint16_t *)out, n8);
+    return check_launch();
+}
+
+}  // extern "C"
