@@ -1,0 +1,452 @@
+// A2 (AIFI) / A6 - multi-head self-attention of the token streams, forward and backward, head_dim = 32.
+//
+// Reference: nn.MultiheadAttention inside TransformerEncoderLayer (src/d_fine/arch/hybrid_encoder.py:243-290, L = 400
+// tokens of the 20x20 map, no mask) and TransformerDecoderLayer.self_attn (src/d_fine/arch/dfine_decoder.py:200,233-255,
+// L = 300 + denoising queries <= 500, boolean [L, L] mask, True = blocked).  ATen runs it as in-projection GEMMs +
+// scaled_dot_product_attention (AOTriton attn_fwd / bwd_kernel_fuse on ROCm) + out-projection; the projections are the
+// linear_act kernels of gemm.hip, this file is softmax(Q K^T / sqrt(d) + mask) V and its gradient.
+//
+// Shapes are tiny for a 2.5 PFLOP/s chip (B * H * L^2 * d * 4 = 8 GFLOP per layer): the kernels are organised so that
+// NOTHING leaves registers between the two GEMMs of each direction, by choosing the MFMA orientation per product:
+//   forward / dQ ("S^T orientation", waves split the queries): S^T = K Q^T gives every lane ONE query column and 4 keys per
+//     16-key tile, i.e. exactly the key order in which gfx950's LDS transpose-read (ds_read_b64_tr_b16) delivers the V^T / K^T
+//     operand of the second product (rows 4g..4g+3 and 16+4g..16+4g+3 of a 32-key step) - the bf16-packed probabilities are
+//     the B operand of O^T = V^T P^T as they are.  Row max / sum = in-lane reduction + two cross-lane shuffles (lanes
+//     l, l+16, l+32, l+48 share a query).  Keys are streamed in blocks of 256 through LDS with an online softmax, so L is
+//     not limited by the register file.
+//   dK / dV ("S orientation", waves split the keys): S = Q K^T puts 4 query rows per 16-query tile in each lane = the
+//     q order of the transpose-read of dO^T / Q^T: P and dS are the B operands of dV^T = dO^T P and dK^T = Q^T dS as they are;
+//     each wave owns 128 keys (K, V fragments live in registers for the whole kernel) and walks the queries in chunks of 32.
+//   The softmax statistics are saved by the forward pass in the exp2 domain (lse2 = m + log2(sum)); delta = rowsum(dO * O) is
+//   produced by the dQ kernel, which runs first, and read by the dK/dV kernel.
+// Layout: q, k, v, o and the gradients are [B, L, H * 32] views with arbitrary row strides (the packed in-projection output is
+// consumed without copies); lse2, delta are [B, H, L] fp32.
+#include "common.h"
+
+namespace dfine {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 a_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float a_f32x4;
+typedef short a_tr4 __attribute__((ext_vector_type(4)));
+typedef short a_tr8 __attribute__((ext_vector_type(8)));
+
+constexpr int kAttnThreads = 256;
+constexpr int kHD = 32;                 // head dim
+constexpr int kKB = 256;                // keys per LDS block
+constexpr int kP40 = 40;                // row pitch (elements) of tiles read with 16-byte fragment loads: conflict-free
+constexpr int kP48 = 48;                // row pitch of tiles read with the transpose-read: the 8 rows of a 32-lane half hit disjoint banks
+
+__device__ __forceinline__ a_bf16x8 ld_frag(const uint16_t *p) { return __builtin_bit_cast(a_bf16x8, *reinterpret_cast<const uint4 *>(p)); }
+
+__device__ __forceinline__ a_bf16x8 tr_frag(const uint16_t *p, int pitch) {
+    const a_tr4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((a_tr4 __attribute__((address_space(3))) *)p);
+    const a_tr4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((a_tr4 __attribute__((address_space(3))) *)(p + 16 * pitch));
+    return __builtin_bit_cast(a_bf16x8, (a_tr8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
+
+__device__ __forceinline__ float xor_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16));
+    return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float xor_sum(float v) {
+    v += __shfl_xor(v, 16);
+    return v + __shfl_xor(v, 32);
+}
+
+// stage `rows` rows (32 bf16 each, global row stride ld) into an LDS tile with row pitch `pitch`; rows >= valid are zero
+__device__ __forceinline__ void stage_rows(uint16_t *dst, int pitch, const uint16_t *src, int64_t ld, int rows, int valid, int tid) {
+    for (int it = tid; it < rows * 4; it += kAttnThreads) {
+        const int r = it >> 2, c = (it & 3) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < valid) v = *reinterpret_cast<const uint4 *>(src + (int64_t)r * ld + c);
+        *reinterpret_cast<uint4 *>(dst + r * pitch + c) = v;
+    }
+}
+
+// mask value of 4 consecutive keys for one query: bit e set = blocked
+__device__ __forceinline__ uint32_t mask4(const uint8_t *mrow, int key, int L) {
+    uint32_t m = 0;
+    if (((L | key) & 3) == 0 && key + 3 < L) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(mrow + key);
+        m = ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) | ((w & 0xff000000u) ? 8u : 0u);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (key + e < L && mrow[key + e]) m |= 1u << e;
+    }
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward: block = (b, h, 64 * QT queries), wave = 16 queries per iteration
+template <int QT>
+__global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const uint16_t *__restrict__ q, const uint16_t *__restrict__ k,
+                                                                const uint16_t *__restrict__ v, uint16_t *__restrict__ o,
+                                                                float *__restrict__ lse2, const uint8_t *__restrict__ mask,
+                                                                int B, int L, int H, int ldq, int ldk, int ldv, int ldo,
+                                                                float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) uint16_t sK[kKB * kP40];
+    __shared__ __attribute__((aligned(16))) uint16_t sV[kKB * kP48];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
+    const int bh = blockIdx.x % (B * H), qblk = blockIdx.x / (B * H);        // blocks of one (b, h) share an XCD (L2 reuse of K, V)
+    const int b = bh / H, h = bh - b * H;
+    const uint16_t *qb = q + (int64_t)b * L * ldq + h * kHD;
+    const uint16_t *kb_ = k + (int64_t)b * L * ldk + h * kHD;
+    const uint16_t *vb = v + (int64_t)b * L * ldv + h * kHD;
+    const float NEG = -INFINITY;
+
+    int qrow[QT];
+    a_bf16x8 qf[QT];
+    float m_run[QT], l_run[QT];
+    a_f32x4 oacc[QT][2];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        qrow[t] = qblk * 64 * QT + t * 64 + wave * 16 + i16;
+        uint4 qv = make_uint4(0, 0, 0, 0);
+        if (qrow[t] < L) qv = *reinterpret_cast<const uint4 *>(qb + (int64_t)qrow[t] * ldq + 8 * g);
+        qf[t] = __builtin_bit_cast(a_bf16x8, qv);
+        m_run[t] = NEG; l_run[t] = 0.f;
+        oacc[t][0] = a_f32x4{0.f, 0.f, 0.f, 0.f}; oacc[t][1] = a_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int tr_off = (4 * g + (i16 >> 2)) * kP48 + 4 * (i16 & 3);
+
+    for (int k0 = 0; k0 < L; k0 += kKB) {
+        const int valid = min(kKB, L - k0);
+        __syncthreads();
+        stage_rows(sK, kP40, kb_ + (int64_t)k0 * ldk, ldk, kKB, valid, tid);
+        stage_rows(sV, kP48, vb + (int64_t)k0 * ldv, ldv, kKB, valid, tid);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            a_f32x4 s[kKB / 16];
+#pragma unroll
+            for (int kt = 0; kt < kKB / 16; ++kt)
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(sK + (kt * 16 + i16) * kP40 + 8 * g), qf[t],
+                                                                a_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const uint8_t *mrow = mask ? mask + (int64_t)min(qrow[t], L - 1) * L : nullptr;
+            float bmax = NEG;
+#pragma unroll
+            for (int kt = 0; kt < kKB / 16; ++kt) {
+                const int key = k0 + kt * 16 + 4 * g;
+                const uint32_t mb = mrow ? mask4(mrow, key, L) : 0u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = s[kt][r] * scale_log2e;
+                    if (key + r >= L || ((mb >> r) & 1u)) x = NEG;
+                    s[kt][r] = x;
+                    bmax = fmaxf(bmax, x);
+                }
+            }
+            bmax = xor_max(bmax);
+            const float m_new = fmaxf(m_run[t], bmax);
+            const float m_use = m_new == NEG ? 0.f : m_new;
+            const float alpha = exp2f(m_run[t] - m_use);                     // m_run = -inf -> 0
+            float psum = 0.f;
+            uint32_t pk[kKB / 16][2];
+#pragma unroll
+            for (int kt = 0; kt < kKB / 16; ++kt) {
+                const float p0 = exp2f(s[kt][0] - m_use), p1 = exp2f(s[kt][1] - m_use);
+                const float p2 = exp2f(s[kt][2] - m_use), p3 = exp2f(s[kt][3] - m_use);
+                psum += (p0 + p1) + (p2 + p3);
+                pk[kt][0] = pack2(p0, p1); pk[kt][1] = pack2(p2, p3);
+            }
+            psum = xor_sum(psum);
+            l_run[t] = l_run[t] * alpha + psum;
+            m_run[t] = m_new;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oacc[t][d][r] *= alpha;
+#pragma unroll
+            for (int ks = 0; ks < kKB / 32; ++ks) {
+                const a_bf16x8 pf = __builtin_bit_cast(a_bf16x8, make_uint4(pk[2 * ks][0], pk[2 * ks][1], pk[2 * ks + 1][0], pk[2 * ks + 1][1]));
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+                    oacc[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sV + ks * 32 * kP48 + tr_off + 16 * d, kP48), pf,
+                                                                         oacc[t][d], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        if (qrow[t] >= L) continue;
+        const float inv = l_run[t] > 0.f ? 1.f / l_run[t] : 0.f;
+        uint16_t *op = o + ((int64_t)b * L + qrow[t]) * ldo + h * kHD + 4 * g;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            uint2 w;
+            w.x = pack2(oacc[t][d][0] * inv, oacc[t][d][1] * inv);
+            w.y = pack2(oacc[t][d][2] * inv, oacc[t][d][3] * inv);
+            *reinterpret_cast<uint2 *>(op + 16 * d) = w;
+        }
+        if (g == 0 && lse2) lse2[((int64_t)b * H + h) * L + qrow[t]] = m_run[t] + log2f(l_run[t]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward, dQ (+ delta): same decomposition as the forward pass; P^T is recomputed from lse2
+template <int QT>
+__global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const uint16_t *__restrict__ q, const uint16_t *__restrict__ k,
+                                                                   const uint16_t *__restrict__ v, const uint16_t *__restrict__ o,
+                                                                   const uint16_t *__restrict__ dout, const float *__restrict__ lse2,
+                                                                   const uint8_t *__restrict__ mask, uint16_t *__restrict__ dq,
+                                                                   float *__restrict__ delta, int B, int L, int H, int ldq, int ldk,
+                                                                   int ldv, int ldo, int lddo, int lddq, float scale, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) uint16_t sK[kKB * kP48];          // 16-byte fragment reads AND transpose-reads
+    __shared__ __attribute__((aligned(16))) uint16_t sV[kKB * kP40];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
+    const int bh = blockIdx.x % (B * H), qblk = blockIdx.x / (B * H);
+    const int b = bh / H, h = bh - b * H;
+    const uint16_t *kb_ = k + (int64_t)b * L * ldk + h * kHD;
+    const uint16_t *vb = v + (int64_t)b * L * ldv + h * kHD;
+
+    int qrow[QT];
+    a_bf16x8 qf[QT], dof[QT];
+    float lse_q[QT], dl[QT];
+    a_f32x4 dacc[QT][2];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        qrow[t] = qblk * 64 * QT + t * 64 + wave * 16 + i16;
+        uint4 qv = make_uint4(0, 0, 0, 0), dv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
+        lse_q[t] = 0.f;
+        if (qrow[t] < L) {
+            qv = *reinterpret_cast<const uint4 *>(q + ((int64_t)b * L + qrow[t]) * ldq + h * kHD + 8 * g);
+            dv = *reinterpret_cast<const uint4 *>(dout + ((int64_t)b * L + qrow[t]) * lddo + h * kHD + 8 * g);
+            ov = *reinterpret_cast<const uint4 *>(o + ((int64_t)b * L + qrow[t]) * ldo + h * kHD + 8 * g);
+            lse_q[t] = lse2[((int64_t)b * H + h) * L + qrow[t]];
+        }
+        qf[t] = __builtin_bit_cast(a_bf16x8, qv);
+        dof[t] = __builtin_bit_cast(a_bf16x8, dv);
+        const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            part += __uint_as_float(dw[j] << 16) * __uint_as_float(ow[j] << 16) +
+                    __uint_as_float(dw[j] & 0xffff0000u) * __uint_as_float(ow[j] & 0xffff0000u);
+        dl[t] = xor_sum(part);
+        if (g == 0 && qrow[t] < L) delta[((int64_t)b * H + h) * L + qrow[t]] = dl[t];
+        dacc[t][0] = a_f32x4{0.f, 0.f, 0.f, 0.f}; dacc[t][1] = a_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int tr_off = (4 * g + (i16 >> 2)) * kP48 + 4 * (i16 & 3);
+
+    for (int k0 = 0; k0 < L; k0 += kKB) {
+        const int valid = min(kKB, L - k0);
+        __syncthreads();
+        stage_rows(sK, kP48, kb_ + (int64_t)k0 * ldk, ldk, kKB, valid, tid);
+        stage_rows(sV, kP40, vb + (int64_t)k0 * ldv, ldv, kKB, valid, tid);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const uint8_t *mrow = mask ? mask + (int64_t)min(qrow[t], L - 1) * L : nullptr;
+            uint32_t pk[kKB / 16][2];
+#pragma unroll
+            for (int kt = 0; kt < kKB / 16; ++kt) {
+                const a_f32x4 z = a_f32x4{0.f, 0.f, 0.f, 0.f};
+                const a_f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(sK + (kt * 16 + i16) * kP48 + 8 * g), qf[t], z, 0, 0, 0);
+                const a_f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(sV + (kt * 16 + i16) * kP40 + 8 * g), dof[t], z, 0, 0, 0);
+                const int key = k0 + kt * 16 + 4 * g;
+                const uint32_t mb = mrow ? mask4(mrow, key, L) : 0u;
+                float ds[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool dead = key + r >= L || ((mb >> r) & 1u);
+                    const float p = dead ? 0.f : exp2f(s[r] * scale_log2e - lse_q[t]);
+                    ds[r] = p * (dp[r] - dl[t]) * scale;
+                }
+                pk[kt][0] = pack2(ds[0], ds[1]); pk[kt][1] = pack2(ds[2], ds[3]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < kKB / 32; ++ks) {
+                const a_bf16x8 pf = __builtin_bit_cast(a_bf16x8, make_uint4(pk[2 * ks][0], pk[2 * ks][1], pk[2 * ks + 1][0], pk[2 * ks + 1][1]));
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+                    dacc[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sK + ks * 32 * kP48 + tr_off + 16 * d, kP48), pf,
+                                                                         dacc[t][d], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        if (qrow[t] >= L) continue;
+        uint16_t *op = dq + ((int64_t)b * L + qrow[t]) * lddq + h * kHD + 4 * g;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            uint2 w;
+            w.x = pack2(dacc[t][d][0], dacc[t][d][1]);
+            w.y = pack2(dacc[t][d][2], dacc[t][d][3]);
+            *reinterpret_cast<uint2 *>(op + 16 * d) = w;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward, dK and dV: block = (b, h, 512 keys), wave = 128 keys, queries in chunks of 32 through LDS (double buffered)
+__global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkdv_kernel(const uint16_t *__restrict__ q, const uint16_t *__restrict__ k,
+                                                                     const uint16_t *__restrict__ v, const uint16_t *__restrict__ dout,
+                                                                     const float *__restrict__ lse2, const float *__restrict__ delta,
+                                                                     const uint8_t *__restrict__ mask, uint16_t *__restrict__ dk,
+                                                                     uint16_t *__restrict__ dv, int B, int L, int H, int ldq, int ldk,
+                                                                     int ldv, int lddo, int lddk, int lddv, float scale,
+                                                                     float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) uint16_t sQ[2][32 * kP48];
+    __shared__ __attribute__((aligned(16))) uint16_t sDO[2][32 * kP48];
+    __shared__ float sL[2][32], sD[2][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
+    const int bh = blockIdx.x % (B * H), kblk = blockIdx.x / (B * H);
+    const int b = bh / H, h = bh - b * H;
+    const int kw0 = kblk * 512 + wave * 128;                                   // this wave's keys
+    const uint16_t *qb = q + (int64_t)b * L * ldq + h * kHD;
+    const uint16_t *dob = dout + (int64_t)b * L * lddo + h * kHD;
+
+    a_bf16x8 kf[8], vf[8];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+        const int key = kw0 + kt * 16 + i16;
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (key < L) {
+            kv = *reinterpret_cast<const uint4 *>(k + ((int64_t)b * L + key) * ldk + h * kHD + 8 * g);
+            vv = *reinterpret_cast<const uint4 *>(v + ((int64_t)b * L + key) * ldv + h * kHD + 8 * g);
+        }
+        kf[kt] = __builtin_bit_cast(a_bf16x8, kv);
+        vf[kt] = __builtin_bit_cast(a_bf16x8, vv);
+    }
+    a_f32x4 dka[2][8], dva[2][8];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) { dka[d][kt] = a_f32x4{0.f, 0.f, 0.f, 0.f}; dva[d][kt] = a_f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int tr_off = (4 * g + (i16 >> 2)) * kP48 + 4 * (i16 & 3);
+    const bool wave_live = kw0 < L;
+
+    auto stage = [&](int buf, int q0) {
+        const int valid = min(32, L - q0);
+        if (tid < 128) {
+            const int r = tid >> 2, c = (tid & 3) * 8;
+            uint4 a = make_uint4(0, 0, 0, 0);
+            if (r < valid) a = *reinterpret_cast<const uint4 *>(qb + (int64_t)(q0 + r) * ldq + c);
+            *reinterpret_cast<uint4 *>(&sQ[buf][r * kP48 + c]) = a;
+        } else {
+            const int t2 = tid - 128, r = t2 >> 2, c = (t2 & 3) * 8;
+            uint4 a = make_uint4(0, 0, 0, 0);
+            if (r < valid) a = *reinterpret_cast<const uint4 *>(dob + (int64_t)(q0 + r) * lddo + c);
+            *reinterpret_cast<uint4 *>(&sDO[buf][r * kP48 + c]) = a;
+        }
+        if (tid < 32) {
+            const bool ok = tid < valid;
+            sL[buf][tid] = ok ? lse2[((int64_t)b * H + h) * L + q0 + tid] : 0.f;
+            sD[buf][tid] = ok ? delta[((int64_t)b * H + h) * L + q0 + tid] : 0.f;
+        }
+    };
+
+    const int nchunk = (L + 31) / 32;
+    stage(0, 0);
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1, q0 = c * 32;
+        __syncthreads();                                                    // chunk c staged; every wave is done with chunk c - 1
+        if (c + 1 < nchunk) stage(buf ^ 1, q0 + 32);
+        if (!wave_live) continue;
+        const uint16_t *tq = sQ[buf], *tdo = sDO[buf];
+        uint32_t pp[8][2], dsp[8][2];                                       // bf16 pairs: [key tile][query tile] -> (r0 r1, r2 r3)
+        uint32_t pp2[8][2], dsp2[8][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const a_bf16x8 qa = ld_frag(tq + (qt * 16 + i16) * kP48 + 8 * g);
+            const a_bf16x8 da = ld_frag(tdo + (qt * 16 + i16) * kP48 + 8 * g);
+            float lq[4], dq_[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { lq[r] = sL[buf][qt * 16 + 4 * g + r]; dq_[r] = sD[buf][qt * 16 + 4 * g + r]; }
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) {
+                const a_f32x4 z = a_f32x4{0.f, 0.f, 0.f, 0.f};
+                const a_f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt], z, 0, 0, 0);    // S[q = 4g + r][key = i16]
+                const a_f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt], z, 0, 0, 0);
+                const int key = kw0 + kt * 16 + i16;
+                float p[4], ds[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qq = q0 + qt * 16 + 4 * g + r;
+                    bool dead = key >= L || qq >= L;
+                    if (!dead && mask) dead = mask[(int64_t)qq * L + key] != 0;
+                    p[r] = dead ? 0.f : exp2f(s[r] * scale_log2e - lq[r]);
+                    ds[r] = p[r] * (dp[r] - dq_[r]) * scale;
+                }
+                if (qt == 0) { pp[kt][0] = pack2(p[0], p[1]); pp[kt][1] = pack2(p[2], p[3]); dsp[kt][0] = pack2(ds[0], ds[1]); dsp[kt][1] = pack2(ds[2], ds[3]); }
+                else { pp2[kt][0] = pack2(p[0], p[1]); pp2[kt][1] = pack2(p[2], p[3]); dsp2[kt][0] = pack2(ds[0], ds[1]); dsp2[kt][1] = pack2(ds[2], ds[3]); }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const a_bf16x8 dot = tr_frag(tdo + tr_off + 16 * d, kP48);       // dO^T[d][q slots of g]
+            const a_bf16x8 qtf = tr_frag(tq + tr_off + 16 * d, kP48);        // Q^T
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) {
+                const a_bf16x8 pb = __builtin_bit_cast(a_bf16x8, make_uint4(pp[kt][0], pp[kt][1], pp2[kt][0], pp2[kt][1]));
+                const a_bf16x8 db = __builtin_bit_cast(a_bf16x8, make_uint4(dsp[kt][0], dsp[kt][1], dsp2[kt][0], dsp2[kt][1]));
+                dva[d][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pb, dva[d][kt], 0, 0, 0);
+                dka[d][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, db, dka[d][kt], 0, 0, 0);
+            }
+        }
+    }
+    if (!wave_live) return;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+        const int key = kw0 + kt * 16 + i16;
+        if (key >= L) continue;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            uint2 w;
+            w.x = pack2(dka[d][kt][0], dka[d][kt][1]); w.y = pack2(dka[d][kt][2], dka[d][kt][3]);
+            *reinterpret_cast<uint2 *>(dk + ((int64_t)b * L + key) * lddk + h * kHD + 16 * d + 4 * g) = w;
+            w.x = pack2(dva[d][kt][0], dva[d][kt][1]); w.y = pack2(dva[d][kt][2], dva[d][kt][3]);
+            *reinterpret_cast<uint2 *>(dv + ((int64_t)b * L + key) * lddv + h * kHD + 16 * d + 4 * g) = w;
+        }
+    }
+}
+
+}  // namespace dfine
+
+using namespace dfine;
+
+extern "C" {
+
+static bool attn_args_ok(int B, int L, int H, int hd, const int *lds_, int n) {
+    if (B < 1 || L < 1 || H < 1 || hd != kHD) return false;
+    for (int i = 0; i < n; ++i) if (lds_[i] < H * hd || (lds_[i] & 7)) return false;     // 16-byte aligned rows
+    return true;
+}
+
+int dfine_attn_fwd(const void *q, const void *k, const void *v, void *o, float *lse2, const uint8_t *mask, int B, int L, int H,
+                   int hd, int ldq, int ldk, int ldv, int ldo, float scale, void *stream) {
+    if (B == 0 || L == 0) return DFINE_OK;
+    const int lds_[4] = {ldq, ldk, ldv, ldo};
+    if (!q || !k || !v || !o || !attn_args_ok(B, L, H, hd, lds_, 4)) return DFINE_E_BADARG;
+    const float c = scale * 1.44269504088896340736f;
+    const int nq = (L + 63) / 64;
+    hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(B * H * nq), dim3(kAttnThreads), 0, (hipStream_t)stream, (const uint16_t *)q,
+                       (const uint16_t *)k, (const uint16_t *)v, (uint16_t *)o, lse2, mask, B, L, H, ldq, ldk, ldv, ldo, c);
+    return check_launch();
+}
+
+int dfine_attn_bwd(const void *q, const void *k, const void *v, const void *o, const void *dout, const float *lse2,
+                   const uint8_t *mask, void *dq, void *dk, void *dv, float *delta, int B, int L, int H, int hd, int ldq, int ldk,
+                   int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale, void *stream) {
+    if (B == 0 || L == 0) return DFINE_OK;
+    const int lds_[8] = {ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv};
+    if (!q || !k || !v || !o || !dout || !lse2 || !dq || !dk || !dv || !delta || !attn_args_ok(B, L, H, hd, lds_, 8))
+        return DFINE_E_BADARG;
+    const float c = scale * 1.44269504088896340736f;
+    hipStream_t st = (hipStream_t)stream;
+    const int nq = (L + 63) / 64;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<1>, dim3(B * H * nq), dim3(kAttnThreads), 0, st, (const uint16_t *)q, (const uint16_t *)k,
+                       (const uint16_t *)v, (const uint16_t *)o, (const uint16_t *)dout, lse2, mask, (uint16_t *)dq, delta, B, L, H,
+                       ldq, ldk, ldv, ldo, lddo, lddq, scale, c);
+    if (int e = check_launch()) return e;
+    const int nk = (L + 511) / 512;
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(B * H * nk), dim3(kAttnThreads), 0, st, (const uint16_t *)q, (const uint16_t *)k,
+                       (const uint16_t *)v, (const uint16_t *)dout, lse2, (const float *)delta, mask, (uint16_t *)dk, (uint16_t *)dv,
+                       B, L, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, c);
+    return check_launch();
+}
+
+}  // extern "C"

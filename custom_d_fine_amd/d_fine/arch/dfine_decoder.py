@@ -36,7 +36,7 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for layer in self.layers[:-1]:
-            x = self.act(kernels.linear(x, layer.weight, layer.bias))
+            x = kernels.linear(x, layer.weight, layer.bias, act=self.act)
         last = self.layers[-1]
         return kernels.linear(x, last.weight, last.bias)
 
@@ -154,7 +154,7 @@ class TransformerDecoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, tgt):
-        h = self.dropout3(self.activation(kernels.linear(tgt, self.linear1.weight, self.linear1.bias)))
+        h = self.dropout3(kernels.linear(tgt, self.linear1.weight, self.linear1.bias, act=self.activation))
         return kernels.linear(h, self.linear2.weight, self.linear2.bias)
 
     def forward(self, target, reference_points, value, spatial_shapes, attn_mask=None,

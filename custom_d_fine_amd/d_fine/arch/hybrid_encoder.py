@@ -206,7 +206,7 @@ class TransformerEncoderLayer(nn.Module):
         else:                                    # post-norm (the reference's configuration): residual + LN in one pass
             src = kernels.add_layer_norm(src, self.dropout1(attn), self.norm1)
         x = self.norm2(src) if self.normalize_before else src
-        x = kernels.linear(self.dropout(self.activation(kernels.linear(x, self.linear1.weight, self.linear1.bias))),
+        x = kernels.linear(self.dropout(kernels.linear(x, self.linear1.weight, self.linear1.bias, act=self.activation)),
                            self.linear2.weight, self.linear2.bias)
         if self.normalize_before:
             return src + self.dropout2(x)

@@ -56,6 +56,13 @@ _SIGNATURES = {
     "dfine_fdr_fwd": (c_int, [_P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_fdr_bwd": (c_int, [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_topk_anchors": (c_int, [_P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfine_linear_act_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_multi_cast_bf16_t": (c_int, [_P, _I, _P]),
+    "dfine_act_fwd_bf16": (c_int, [_P, _P, _L, _I, _P]),
+    "dfine_act_bwd_bf16": (c_int, [_P, _P, _P, _L, _I, _P]),
+    "dfine_attn_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "dfine_attn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
+                               _F, _P]),
     "dfine_postprocess": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_linear_wgrad_ws_floats": (_L, [_I, _I, _I]),
     "dfine_linear_wgrad_bf16": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -595,12 +602,79 @@ def postprocess(logits, boxes, k, height, width, to_round=True):
     return labels, query, out_boxes, scores
 
 
+# ------------------------------------------------------------------------------------- token-stream linears / attention
+ACT_CODE = {None: 0, "none": 0, "relu": 1, "gelu": 2, "silu": 3}
+
+
+def linear_act(x2d, w, bias=None, act=0, out_f32=False, out=None):
+    """x2d [M, K] bf16 (unit inner stride), w [N, K] bf16 (unit inner stride; row stride may exceed K: slices and
+    transposed shadows), bias fp32 [N] or None -> act(x2d @ w.T + bias) [M, N] bf16 (fp32 when out_f32)."""
+    M, K = x2d.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and x2d.stride(1) == 1 and w.stride(1) == 1
+    assert x2d.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    if out is None:
+        out = torch.empty(M, N, device=x2d.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.is_contiguous()
+    with _timed("linear", 2.0 * M * N * K):
+        _check(_lib.dfine_linear_act_fwd(_ptr(x2d), _ptr(w), _ptr(bias), _ptr(out), M, N, K, x2d.stride(0), w.stride(0),
+                                         out.stride(0), int(act), int(out.dtype == torch.float32), _stream()),
+               "dfine_linear_act_fwd")
+    return out
+
+
+def multi_cast_bf16_t(table, n_entries):
+    _check(_lib.dfine_multi_cast_bf16_t(_ptr(table), n_entries, _stream()), "dfine_multi_cast_bf16_t")
+
+
+def act_forward(z, act):
+    y = torch.empty_like(z)
+    _check(_lib.dfine_act_fwd_bf16(_ptr(z), _ptr(y), z.numel(), int(act), _stream()), "dfine_act_fwd_bf16")
+    return y
+
+
+def act_backward(dy, ref, act):
+    out = torch.empty_like(dy)
+    _check(_lib.dfine_act_bwd_bf16(_ptr(dy), _ptr(ref), _ptr(out), dy.numel(), int(act), _stream()), "dfine_act_bwd_bf16")
+    return out
+
+
+def _ld(t):
+    assert t.dim() == 3 and t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1), "need [B, L, C] rows with one stride"
+    return t.stride(1)
+
+
+def attn_forward(q, k, v, num_heads, mask=None):
+    """q, k, v [B, L, H * 32] bf16 views (e.g. column slices of the packed projection) -> o [B, L, H * 32] bf16, lse2 [B, H, L]."""
+    B, L, E = q.shape
+    hd = E // num_heads
+    o = torch.empty(B, L, E, device=q.device, dtype=torch.bfloat16)
+    lse2 = torch.empty(B, num_heads, L, device=q.device, dtype=torch.float32)
+    with _timed("attention", 4.0 * B * num_heads * L * L * hd):
+        _check(_lib.dfine_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse2), _ptr(mask), B, L, num_heads, hd, _ld(q),
+                                   _ld(k), _ld(v), E, float(hd) ** -0.5, _stream()), "dfine_attn_fwd")
+    return o, lse2
+
+
+def attn_backward(q, k, v, o, dout, lse2, num_heads, dq, dk, dv, mask=None):
+    """Writes dq, dk, dv ([B, L, H * 32] bf16 views, e.g. column slices of one packed gradient buffer)."""
+    B, L, E = q.shape
+    hd = E // num_heads
+    delta = torch.empty_like(lse2)
+    with _timed("attention", 10.0 * B * num_heads * L * L * hd):
+        _check(_lib.dfine_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(dout), _ptr(lse2), _ptr(mask), _ptr(dq), _ptr(dk),
+                                   _ptr(dv), _ptr(delta), B, L, num_heads, hd, _ld(q), _ld(k), _ld(v), _ld(o), _ld(dout),
+                                   _ld(dq), _ld(dk), _ld(dv), float(hd) ** -0.5, _stream()), "dfine_attn_bwd")
+
+
 # ------------------------------------------------------------------------------------- linear wgrad
 _LW_WS = {}
 
 
-def linear_wgrad_bf16(x2d, dy2d, with_bias=False):
-    """x2d [M, K], dy2d [M, N] bf16 contiguous -> dw [N, K] f32 = dy2d^T x2d (, db [N] f32 = column sums)."""
+def linear_wgrad_bf16(x2d, dy2d, with_bias=False, dw=None, db=None):
+    """x2d [M, K], dy2d [M, N] bf16 contiguous -> dw [N, K] f32 = dy2d^T x2d (, db [N] f32 = column sums); `dw` / `db`
+    may be given (contiguous row ranges of a larger gradient buffer)."""
     M, K = x2d.shape
     N = dy2d.shape[1]
     dev = x2d.device
@@ -610,8 +684,11 @@ def linear_wgrad_bf16(x2d, dy2d, with_bias=False):
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1 << 20), device=dev, dtype=torch.float32)
         _LW_WS[key] = ws
-    dw = torch.empty(N, K, device=dev, dtype=torch.float32)
-    db = torch.empty(N, device=dev, dtype=torch.float32) if with_bias else None
+    if dw is None:
+        dw = torch.empty(N, K, device=dev, dtype=torch.float32)
+    if with_bias and db is None:
+        db = torch.empty(N, device=dev, dtype=torch.float32)
+    assert dw.is_contiguous() and dw.dtype == torch.float32 and (db is None or db.is_contiguous())
     with _timed("linear_wgrad", 2.0 * M * N * K):
         _check(_lib.dfine_linear_wgrad_bf16(_ptr(x2d), _ptr(dy2d), _ptr(dw), _ptr(db), _ptr(ws), M, N, K, _stream()),
                "dfine_linear_wgrad_bf16")

@@ -430,6 +430,60 @@ def bf16_param(p):
     return c
 
 
+# Transposed bf16 shadows ([K, N] of an nn.Linear weight [N, K]): the B^T operand of the data-gradient GEMM
+# dX = dY . W (csrc/gemm.hip).  Same refresh protocol: one launch for all registered weights after an optimizer step.
+_BF16T_REGISTRY = {}       # id(param) -> [weakref(param), bf16 [K, N] copy, data_ptr, version]
+_BF16T_TABLE = None
+_BF16T_EPOCH = -1
+
+
+def _refresh_bf16_t(device):
+    global _BF16T_TABLE, _BF16T_EPOCH
+    import numpy as np
+    dead = [k for k, e in _BF16T_REGISTRY.items() if e[0]() is None]
+    for k in dead:
+        del _BF16T_REGISTRY[k]
+        _BF16T_TABLE = None
+    stale = _BF16T_TABLE is None
+    if not stale:
+        for e in _BF16T_REGISTRY.values():
+            if e[0]().data_ptr() != e[2]:
+                stale = True
+                break
+    if stale:
+        rows = []
+        for e in _BF16T_REGISTRY.values():
+            p = e[0]()
+            rows.append((p.data_ptr(), e[1].data_ptr(), p.shape[0], p.shape[1]))
+            e[2] = p.data_ptr()
+        from .d_fine.arch.utils import upload
+        _BF16T_TABLE = (upload(np.asarray(rows, dtype=np.int64), device), len(rows))
+    _hip().multi_cast_bf16_t(_BF16T_TABLE[0], _BF16T_TABLE[1])
+    for e in _BF16T_REGISTRY.values():
+        e[3] = e[0]()._version
+    _BF16T_EPOCH = _WEIGHT_EPOCH
+
+
+def bf16_param_t(p):
+    """bf16 TRANSPOSE [K, N] of a 2-d fp32 CUDA parameter [N, K], cached until the weights change."""
+    global _BF16T_TABLE
+    if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.dim() == 2) or (
+            _CAPTURE_POSSIBLE and torch.cuda.is_current_stream_capturing()):
+        return p.detach().t().to(torch.bfloat16).contiguous()
+    ent = _BF16T_REGISTRY.get(id(p))
+    if ent is not None and ent[0]() is p:
+        if _BF16T_EPOCH != _WEIGHT_EPOCH:
+            _refresh_bf16_t(p.device)
+        if ent[3] != p._version or ent[2] != p.data_ptr():       # changed in place by plain torch code
+            ent[1].copy_(p.detach().t())
+            ent[2], ent[3] = p.data_ptr(), p._version
+        return ent[1]
+    c = p.detach().t().to(torch.bfloat16).contiguous()
+    _BF16T_REGISTRY[id(p)] = [weakref.ref(p), c, p.data_ptr(), p._version]
+    _BF16T_TABLE = None
+    return c
+
+
 def _time_op(fn, reps=4):
     fn()
     torch.cuda.synchronize()
@@ -787,71 +841,158 @@ def gate_layer_norm(gate_logits, x1, x2, norm: nn.LayerNorm):
     return norm(g1 * x1 + g2 * x2)
 
 
-class _LinearSplitK(torch.autograd.Function):
-    """y = x W^T + b for x [B, L, K] with B*L >> N*K (every decoder / encoder linear: 15 744 rows
-    against <= 1024 x 1024 weights).  The weight gradient dW = dY^T X is a GEMM with a tiny output and
-    a 15 744-long reduction; as one `mm` hipBLASLt runs it on <= 16 workgroups (91 us whatever the
-    size - 57 calls, 5.2 ms per D-FINE-m step; torch.bmm split over the batch is 3x faster on the device
-    but costs 0.6 ms of HOST time per call in hipBLASLt's heuristics).  Here: the HIP split-K kernel
-    linear_wgrad_kernel (conv.hip).  Forward and dX stay hipBLASLt GEMMs [ATen plumbing]."""
+def _bf16_2d(x):
+    """[..., K] activation -> contiguous bf16 [M, K] (what the GEMM / weight-gradient kernels read)."""
+    xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+    return xb.reshape(-1, xb.shape[-1]).contiguous()
+
+
+def _f32_vec(b):
+    return None if b is None else (b.detach() if b.dtype == torch.float32 and b.is_contiguous() else b.detach().float().contiguous())
+
+
+class _LinearAct(torch.autograd.Function):
+    """y = act(x W^T + b) for the token streams of encoder / decoder, all three GEMMs on the HIP MFMA kernels:
+    forward and data gradient = linear_act_kernel (csrc/gemm.hip; the activation, the bias and - for the data gradient -
+    nothing else are fused in), weight + bias gradient = the split-K linear_wgrad_kernel (csrc/conv.hip).
+    `act`: 0 none, 1 relu, 2 gelu, 3 silu.  bf16 operands / fp32 accumulate (what bf16 autocast gives F.linear)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
-        xc = x if x.dtype == dt else x.to(dt)
-        if dt == torch.bfloat16:
-            wc = bf16_param(weight)
-            bc = None if bias is None else bf16_param(bias)
+    def forward(ctx, x, weight, bias, act):
+        hip = _hip()
+        x2d = _bf16_2d(x)
+        wb = bf16_param(weight)
+        b32 = _f32_vec(bias)
+        need_grad = any(ctx.needs_input_grad[:3])
+        ref = None
+        if act >= 2 and need_grad:          # GELU / SiLU: backward needs the pre-activation
+            ref = hip.linear_act(x2d, wb, b32, 0)
+            y = hip.act_forward(ref, act)
         else:
-            wc = weight if weight.dtype == dt else weight.to(dt)
-            bc = None if bias is None else (bias if bias.dtype == dt else bias.to(dt))
-        ctx.save_for_backward(xc, wc)
-        ctx.meta = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
-        # write into a fresh base tensor: F.linear on 3-d input returns a VIEW of its 2-d result, which
-        # autograd refuses to let callers modify in place (ReLU(inplace=True) in the MLP heads)
-        out = torch.empty(*xc.shape[:-1], wc.shape[0], device=xc.device, dtype=dt)
-        x2d = xc.reshape(-1, xc.shape[-1])
-        if bc is None:
-            torch.mm(x2d, wc.t(), out=out.view(-1, wc.shape[0]))
-        else:
-            torch.addmm(bc, x2d, wc.t(), out=out.view(-1, wc.shape[0]))
-        return out
+            y = hip.linear_act(x2d, wb, b32, act)
+            if act == 1:
+                ref = y
+        ctx.save_for_backward(x2d, weight, ref)
+        ctx.meta = (act, x.dtype, x.shape, bias is not None)
+        return y.view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        xc, wc = ctx.saved_tensors
-        xdt, wdt, bdt = ctx.meta
-        dy = dy if dy.dtype == xc.dtype else dy.to(xc.dtype)
+        hip = _hip()
+        x2d, weight, ref = ctx.saved_tensors
+        act, xdt, xshape, has_bias = ctx.meta
+        d2 = _bf16_2d(dy)
+        if act:
+            d2 = hip.act_backward(d2, ref, act)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.matmul(dy, wc)
-            dx = dx if dx.dtype == xdt else dx.to(xdt)
-        want_db = bdt is not None and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
-            if xc.dtype == torch.bfloat16:      # HIP split-K MFMA kernel on the row-major operands
-                res = _hip().linear_wgrad_bf16(xc.reshape(-1, xc.shape[-1]).contiguous(),
-                                               dy.reshape(-1, dy.shape[-1]).contiguous(), with_bias=want_db)
-                if want_db:                     # bias gradient comes out of the same kernel
-                    dw, db = res
-                    db = db if db.dtype == bdt else db.to(bdt)
-                    want_db = False
-                else:
-                    dw = res
-            else:
-                dw = torch.matmul(dy.reshape(-1, dy.shape[-1]).t(), xc.reshape(-1, xc.shape[-1]))
-            dw = dw if dw.dtype == wdt else dw.to(wdt)
-        if want_db:
-            db = dy.reshape(-1, dy.shape[-1]).sum(0, dtype=torch.float32)
-            db = db if db.dtype == bdt else db.to(bdt)
-        return dx, dw, db
+            dx = hip.linear_act(d2, bf16_param_t(weight), None, 0, out_f32=xdt == torch.float32).view(xshape)
+        want_db = has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_db:
+            res = hip.linear_wgrad_bf16(x2d, d2, with_bias=want_db)
+            dw, db = res if want_db else (res, None)
+            if dw.dtype != weight.dtype:
+                dw = dw.to(weight.dtype)
+        return dx, dw, db, None
 
 
-def linear(x, weight, bias=None):
-    """nn.Linear forward for the [B, L, K] activations of the decoder / encoder token streams."""
-    if x.is_cuda and x.dim() == 3 and x.shape[0] > 1 and x.shape[0] * x.shape[1] >= 4096 \
-            and _env("DFINE_SPLITK_LINEAR", "1") == "1" and torch.is_grad_enabled():
-        return _LinearSplitK.apply(x, weight, bias)
-    return F.linear(x, weight, bias)
+_ACT_CODES = {None: 0, "none": 0, "relu": 1, "gelu": 2, "silu": 3, "swish": 3}
+
+
+def _act_code(act):
+    if act is None or isinstance(act, str):
+        return _ACT_CODES.get(act.lower() if isinstance(act, str) else None)
+    if isinstance(act, nn.Identity):
+        return 0
+    if isinstance(act, nn.ReLU):
+        return 1
+    if isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none":
+        return 2
+    if isinstance(act, nn.SiLU):
+        return 3
+    return None
+
+
+def _hip_linear_ok(x, weight):
+    return (x.is_cuda and weight.dim() == 2 and weight.dtype in (torch.float32, torch.bfloat16)
+            and _env("DFINE_HIP_LINEAR", "1") == "1"
+            and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+                                               and x.dtype == torch.float32)))
+
+
+def linear(x, weight, bias=None, act=None):
+    """act(nn.Linear(x)) for [..., K] activations; `act`: None / "relu" / "gelu" / "silu" or the nn module.
+    CUDA under bf16 autocast (or bf16 inputs): HIP GEMM with the activation fused.  Otherwise (fp32 math, CPU) the ATen
+    composition."""
+    code = _act_code(act)
+    if code is not None and _hip_linear_ok(x, weight) and x.numel() > 0:
+        return _LinearAct.apply(x, weight, bias, code)
+    y = F.linear(x, weight, bias)
+    if act is None or code == 0:
+        return y
+    if isinstance(act, nn.Module):
+        return act(y)
+    return {1: F.relu, 2: F.gelu, 3: F.silu}[code](y)
+
+
+class _MHA(torch.autograd.Function):
+    """Packed multi-head self-attention block (q = k input `qk`, v input `value`), every piece a HIP kernel:
+    in-projections + out-projection = linear_act_kernel, softmax(QK^T / sqrt(d) + mask) V = attn_fwd_kernel, backward =
+    attn_bwd_dq / attn_bwd_dkdv + the same GEMM kernels + the split-K weight gradients written straight into one
+    [3E, E] gradient buffer (no slice / pad / cat kernels around the packed in_proj parameters)."""
+
+    @staticmethod
+    def forward(ctx, qk, value, in_w, in_b, out_w, out_b, num_heads, mask_u8):
+        hip = _hip()
+        B, L, E = qk.shape
+        qk2, v2 = _bf16_2d(qk), _bf16_2d(value)
+        wb = bf16_param(in_w)                                   # [3E, E]
+        b32 = _f32_vec(in_b)
+        qkp = hip.linear_act(qk2, wb[: 2 * E], b32[: 2 * E]).view(B, L, 2 * E)
+        vp = hip.linear_act(v2, wb[2 * E:], b32[2 * E:]).view(B, L, E)
+        o, lse2 = hip.attn_forward(qkp[..., :E], qkp[..., E:], vp, num_heads, mask_u8)
+        y = hip.linear_act(o.view(B * L, E), bf16_param(out_w), _f32_vec(out_b)).view(B, L, E)
+        ctx.save_for_backward(qk2, v2, qkp, vp, o, lse2, in_w, out_w, mask_u8)
+        ctx.meta = (num_heads, qk.dtype, value.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        hip = _hip()
+        qk2, v2, qkp, vp, o, lse2, in_w, out_w, mask_u8 = ctx.saved_tensors
+        num_heads, qdt, vdt = ctx.meta
+        B, L, E = o.shape
+        d2 = _bf16_2d(dy)
+        do = hip.linear_act(d2, bf16_param_t(out_w)).view(B, L, E)
+        d_out_w, d_out_b = hip.linear_wgrad_bf16(o.view(B * L, E), d2, with_bias=True)
+        dqk = torch.empty(B, L, 2 * E, device=o.device, dtype=torch.bfloat16)
+        dv = torch.empty(B, L, E, device=o.device, dtype=torch.bfloat16)
+        hip.attn_backward(qkp[..., :E], qkp[..., E:], vp, o, do, lse2, num_heads, dqk[..., :E], dqk[..., E:], dv, mask_u8)
+        wt = bf16_param_t(in_w)                                 # [E, 3E]
+        d_qk_in = hip.linear_act(dqk.view(B * L, 2 * E), wt[:, : 2 * E], out_f32=qdt == torch.float32).view(B, L, E)
+        d_v_in = hip.linear_act(dv.view(B * L, E), wt[:, 2 * E:], out_f32=vdt == torch.float32).view(B, L, E)
+        d_in_w = torch.empty(3 * E, E, device=o.device, dtype=torch.float32)
+        d_in_b = torch.empty(3 * E, device=o.device, dtype=torch.float32)
+        hip.linear_wgrad_bf16(qk2, dqk.view(B * L, 2 * E), with_bias=True, dw=d_in_w[: 2 * E], db=d_in_b[: 2 * E])
+        hip.linear_wgrad_bf16(v2, dv.view(B * L, E), with_bias=True, dw=d_in_w[2 * E:], db=d_in_b[2 * E:])
+        return d_qk_in, d_v_in, d_in_w, d_in_b, d_out_w, d_out_b, None, None
+
+
+def self_attention(qk, value, in_w, in_b, out_w, out_b, num_heads: int, attn_mask=None):
+    """Packed-QKV multi-head attention, q = k = `qk` (content+position), v = `value`;
+    boolean `attn_mask` [L, L], True = blocked (ref hybrid_encoder.py:243-290, dfine_decoder.py:200,233-255)."""
+    b, l, e = qk.shape
+    hd = e // num_heads
+    if (hd == 32 and e % 8 == 0 and in_b is not None and out_b is not None and _hip_linear_ok(qk, in_w)
+            and _env("DFINE_HIP_ATTN", "1") == "1" and (attn_mask is None or (attn_mask.dtype == torch.bool and attn_mask.shape == (l, l)))):
+        m8 = None if attn_mask is None else attn_mask.contiguous().view(torch.uint8)
+        return _MHA.apply(qk, value, in_w, in_b, out_w, out_b, num_heads, m8)
+    q, k = linear(qk, in_w[: 2 * e], in_b[: 2 * e]).chunk(2, dim=-1)
+    v = linear(value, in_w[2 * e:], in_b[2 * e:])
+    q, k, v = (t.reshape(b, l, num_heads, hd).transpose(1, 2) for t in (q, k, v))
+    mask = None if attn_mask is None else ~attn_mask
+    o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+    return linear(o.transpose(1, 2).reshape(b, l, e), out_w, out_b)
 
 
 # BatchNorm bookkeeping: nn.BatchNorm2d bumps `num_batches_tracked` (an int64 device scalar) every forward -
@@ -875,19 +1016,6 @@ def flush_bn_counters():
             for b, n in zip(bufs, counts):
                 b.add_(n)
         _BN_PENDING.clear()
-
-
-def self_attention(qk, value, in_w, in_b, out_w, out_b, num_heads: int, attn_mask=None):
-    """Packed-QKV multi-head attention, q = k = `qk` (content+position), v = `value`;
-    boolean `attn_mask` [L, L], True = blocked.  [ATen plumbing: GEMM + SDPA]"""
-    b, l, e = qk.shape
-    hd = e // num_heads
-    q, k = linear(qk, in_w[: 2 * e], in_b[: 2 * e]).chunk(2, dim=-1)
-    v = linear(value, in_w[2 * e:], in_b[2 * e:])
-    q, k, v = (t.reshape(b, l, num_heads, hd).transpose(1, 2) for t in (q, k, v))
-    mask = None if attn_mask is None else ~attn_mask
-    o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
-    return linear(o.transpose(1, 2).reshape(b, l, e), out_w, out_b)
 
 
 def topk_anchors(logits: torch.Tensor, k: int) -> torch.Tensor:

@@ -268,6 +268,39 @@ int dfine_topk_anchors(const void *logits, int64_t sb, int64_t sq, int64_t *out_
                        int dtype, int B, int Q, int C, int K, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * A2 / A3 / A5 / A6  Token-stream linear layers: y[M, N] = act(x[M, K] . w[N, K]^T + bias[N]), bf16
+ * operands (row strides ldx / ldw / ldy elements, unit inner stride), fp32 accumulate, bias fp32 or NULL,
+ * act: 0 none, 1 ReLU, 2 GELU (erf), 3 SiLU; out_f32 = 1 writes fp32.  Replaces F.linear + activation of
+ * MLP / FFN / Gate / in- and out-projections / enc_output / score and box heads
+ * (src/d_fine/arch/dfine_decoder.py:33-46,119-178,214-271,828-873; src/d_fine/arch/hybrid_encoder.py:243-290).
+ * The data gradient dX = dY . W is the same entry point on a transposed bf16 copy of the weight
+ * (dfine_multi_cast_bf16_t: table rows {src fp32 [rows, cols] ptr, dst bf16 [cols, rows] ptr, rows, cols},
+ * all shadows of a model in one launch); the weight / bias gradients are dfine_linear_wgrad_bf16.
+ * dfine_act_fwd_bf16 / dfine_act_bwd_bf16: y = act(z) and d_pre = dy * act'(ref) (ref = saved output for
+ * ReLU, saved pre-activation for GELU / SiLU), n % 8 == 0 elements.
+ */
+int dfine_linear_act_fwd(const void *x, const void *w, const float *bias, void *y, int M, int N, int K, int ldx,
+                         int ldw, int ldy, int act, int out_f32, void *stream);
+int dfine_multi_cast_bf16_t(const void *table, int n_entries, void *stream);
+int dfine_act_fwd_bf16(const void *z, void *y, int64_t n, int act, void *stream);
+int dfine_act_bwd_bf16(const void *dy, const void *ref, void *out, int64_t n, int act, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A2 / A6  Multi-head self-attention core, head_dim 32: o = softmax(q k^T * scale + mask) v per (batch,
+ * head).  q, k, v, o (and the gradients) are [B, L, H * 32] bf16 views with row strides ld* (elements,
+ * multiples of 8); mask uint8 [L, L] (non-zero = blocked) or NULL; lse2, delta fp32 [B, H, L] (softmax
+ * statistics in the exp2 domain / rowsum(dO * O), written by fwd / bwd).  Replaces the
+ * scaled_dot_product_attention inside nn.MultiheadAttention (src/d_fine/arch/hybrid_encoder.py:256,277,
+ * src/d_fine/arch/dfine_decoder.py:200,239).
+ */
+int dfine_attn_fwd(const void *q, const void *k, const void *v, void *o, float *lse2, const uint8_t *mask,
+                   int B, int L, int H, int hd, int ldq, int ldk, int ldv, int ldo, float scale, void *stream);
+int dfine_attn_bwd(const void *q, const void *k, const void *v, const void *o, const void *dout,
+                   const float *lse2, const uint8_t *mask, void *dq, void *dk, void *dv, float *delta, int B,
+                   int L, int H, int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk,
+                   int lddv, float scale, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * A18  Detection post-processor: sigmoid -> top-K over the Q*C (query, class) scores of every image ->
  * label = idx % C, query = idx // C -> normalised cxcywh -> absolute xyxy (floor / ceil + clamp when
  * to_round).  Replaces DFINEPostProcessor.forward (src/dl/export.py:61-100, box arithmetic :35-59) and
