@@ -24,7 +24,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 g_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float g_f32x4;
 
 constexpr int kGemmThreads = 256;
-constexpr int kGBM = 128, kGBN = 128, kGBK = 64, kGPitch = 72;
+constexpr int kGBN = 128, kGBK = 64, kGPitch = 72;
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == 1) return fmaxf(v, 0.f);
@@ -34,35 +34,37 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 }
 
 // x [M, K] (ld = ldx), w [N, K] (ld = ldw) bf16; bias fp32 [N] or null; y [M, N] (ld = ldy) bf16 (OUT32 = 0) / fp32 (1).
-template <int ACT, int OUT32>
+template <int ACT, int OUT32, int MT>                 // MT = 16-row m tiles per wave: block tile = 128 (n) x 32 MT (m)
 __global__ __launch_bounds__(kGemmThreads) void linear_act_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,
                                                                   const float *__restrict__ bias, void *__restrict__ yv,
                                                                   int M, int N, int K, int ldx, int ldw, int ldy, int nt_n,
                                                                   int nt_m) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     uint16_t *sA = reinterpret_cast<uint16_t *>(lds);                       // [2][kGBN][kGPitch]  W rows
-    uint16_t *sB = sA + 2 * kGBN * kGPitch;                                 // [2][kGBM][kGPitch]  X rows
+    constexpr int BM = 32 * MT;
+    uint16_t *sB = sA + 2 * kGBN * kGPitch;                                 // [2][BM][kGPitch]  X rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int tn = slot % nt_n, tm = (slot / nt_n) * 8 + xcd;
     if (tm >= nt_m) return;
-    const int n0 = tn * kGBN, m0 = tm * kGBM;
+    const int n0 = tn * kGBN, m0 = tm * BM;
     const int wn = wave >> 1, wm = wave & 1;
     const int g = lane >> 4, i16 = lane & 15;
 
-    g_f32x4 acc[4][4];
+    g_f32x4 acc[4][MT];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = g_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < MT; ++b) acc[a][b] = g_f32x4{0.f, 0.f, 0.f, 0.f};
 
     // staging: 128 rows x 8 sixteen-byte chunks per operand = 1024 chunks / 256 threads = 4 per thread and operand
     const int st_chunk = tid & 7, st_row = tid >> 3;                        // rows st_row + 32 j
     const bool vec_x = (ldx & 7) == 0 && (K & 7) == 0, vec_w = (ldw & 7) == 0 && (K & 7) == 0;
-    uint4 pa[4], pb[4];
-    auto load_rows = [&](const uint16_t *base, int ld, int r0, int rmax, bool vec, int k0, uint4 (&dst)[4]) {
+    uint4 pa[4], pb[MT];
+    auto load_rows = [&](const uint16_t *base, int ld, int r0, int rmax, bool vec, int k0, uint4 *dst, int nj) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            if (j >= nj) break;
             const int r = r0 + st_row + 32 * j, k = k0 + st_chunk * 8;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (r < rmax && k < K) {
@@ -85,16 +87,15 @@ __global__ __launch_bounds__(kGemmThreads) void linear_act_kernel(const uint16_t
         }
     };
     auto fetch = [&](int k0) {
-        load_rows(w, ldw, n0, N, vec_w, k0, pa);
-        load_rows(x, ldx, m0, M, vec_x, k0, pb);
+        load_rows(w, ldw, n0, N, vec_w, k0, pa, 4);
+        load_rows(x, ldx, m0, M, vec_x, k0, pb, MT);
     };
     auto stash = [&](int buf) {
-        uint16_t *da = sA + buf * kGBN * kGPitch, *db = sB + buf * kGBM * kGPitch;
+        uint16_t *da = sA + buf * kGBN * kGPitch, *db = sB + buf * BM * kGPitch;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            *reinterpret_cast<uint4 *>(da + (st_row + 32 * j) * kGPitch + st_chunk * 8) = pa[j];
-            *reinterpret_cast<uint4 *>(db + (st_row + 32 * j) * kGPitch + st_chunk * 8) = pb[j];
-        }
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4 *>(da + (st_row + 32 * j) * kGPitch + st_chunk * 8) = pa[j];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) *reinterpret_cast<uint4 *>(db + (st_row + 32 * j) * kGPitch + st_chunk * 8) = pb[j];
     };
 
     const int nk = (K + kGBK - 1) / kGBK;
@@ -105,19 +106,20 @@ __global__ __launch_bounds__(kGemmThreads) void linear_act_kernel(const uint16_t
         __syncthreads();
         if (kt + 1 < nk) fetch((kt + 1) * kGBK);                            // in flight during the MFMAs below
         const uint16_t *la = sA + buf * kGBN * kGPitch + (wn * 64 + i16) * kGPitch + 8 * g;
-        const uint16_t *lb = sB + buf * kGBM * kGPitch + (wm * 64 + i16) * kGPitch + 8 * g;
+        const uint16_t *lb = sB + buf * BM * kGPitch + (wm * 16 * MT + i16) * kGPitch + 8 * g;
 #pragma unroll
         for (int ks = 0; ks < kGBK / 32; ++ks) {
-            g_bf16x8 af[4], bf[4];
+            g_bf16x8 af[4], bf[MT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < 4; ++t)
                 af[t] = __builtin_bit_cast(g_bf16x8, *reinterpret_cast<const uint4 *>(la + t * 16 * kGPitch + ks * 32));
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
                 bf[t] = __builtin_bit_cast(g_bf16x8, *reinterpret_cast<const uint4 *>(lb + t * 16 * kGPitch + ks * 32));
-            }
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < MT; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
     }
@@ -134,8 +136,8 @@ __global__ __launch_bounds__(kGemmThreads) void linear_act_kernel(const uint16_t
             for (int r = 0; r < 4; ++r) if (n + r < N) bv[r] = bias[n + r];
         }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int m = m0 + wm * 64 + b * 16 + i16;
+        for (int b = 0; b < MT; ++b) {
+            const int m = m0 + wm * 16 * MT + b * 16 + i16;
             if (m >= M) continue;
             float v[4];
 #pragma unroll
@@ -239,33 +241,35 @@ int dfine_linear_act_fwd(const void *x, const void *w, const float *bias, void *
                          int ldy, int act, int out_f32, void *stream) {
     if (M == 0 || N == 0) return DFINE_OK;
     if (!x || !w || !y || M < 0 || N < 0 || K < 1 || ldx < K || ldw < K || ldy < N || act < 0 || act > 3) return DFINE_E_BADARG;
-    const int nt_n = (N + kGBN - 1) / kGBN, nt_m = (M + kGBM - 1) / kGBM;
-    const size_t ldsb = (size_t)2 * (kGBN + kGBM) * kGPitch * 2;            // 73 728 B
+    const int nt_n = (N + kGBN - 1) / kGBN;
+    // 128-row m tiles when they still give >= 2 workgroups per CU; 64-row tiles otherwise (the token streams have
+    // 12 800 - 15 744 rows: 100 - 123 tiles of 128 rows would leave half of the 256 CUs idle)
+    const int mt = ((int64_t)((M + 127) / 128) * nt_n >= 512) ? 4 : 2;
+    const int bm = 32 * mt;
+    const int nt_m = (M + bm - 1) / bm;
+    const size_t ldsb = (size_t)2 * (kGBN + bm) * kGPitch * 2;              // 73 728 B / 55 296 B
     dim3 grid(8 * ((nt_m + 7) / 8) * nt_n);
     hipStream_t st = (hipStream_t)stream;
     static bool attr_set = false;       // once: not a stream operation, keep it out of graph capture
-#define DFINE_LA_ATTR(A, O)                                                                                              \
-    hipFuncSetAttribute(reinterpret_cast<const void *>(linear_act_kernel<A, O>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                        (int)ldsb)
+#define DFINE_LA_ATTR(A, O, T)                                                                                           \
+    { hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void *>(linear_act_kernel<A, O, T>),                     \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (kGBN + 32 * T) * kGPitch * 2); \
+      if (r != hipSuccess) e = r; }
     if (!attr_set) {
         hipError_t e = hipSuccess;
-        hipError_t r;
-        if ((r = DFINE_LA_ATTR(0, 0)) != hipSuccess) e = r;
-        if ((r = DFINE_LA_ATTR(1, 0)) != hipSuccess) e = r;
-        if ((r = DFINE_LA_ATTR(2, 0)) != hipSuccess) e = r;
-        if ((r = DFINE_LA_ATTR(3, 0)) != hipSuccess) e = r;
-        if ((r = DFINE_LA_ATTR(0, 1)) != hipSuccess) e = r;
-        if ((r = DFINE_LA_ATTR(1, 1)) != hipSuccess) e = r;
-        if ((r = DFINE_LA_ATTR(2, 1)) != hipSuccess) e = r;
-        if ((r = DFINE_LA_ATTR(3, 1)) != hipSuccess) e = r;
+        DFINE_LA_ATTR(0, 0, 4) DFINE_LA_ATTR(1, 0, 4) DFINE_LA_ATTR(2, 0, 4) DFINE_LA_ATTR(3, 0, 4)
+        DFINE_LA_ATTR(0, 1, 4) DFINE_LA_ATTR(1, 1, 4) DFINE_LA_ATTR(2, 1, 4) DFINE_LA_ATTR(3, 1, 4)
+        DFINE_LA_ATTR(0, 0, 2) DFINE_LA_ATTR(1, 0, 2) DFINE_LA_ATTR(2, 0, 2) DFINE_LA_ATTR(3, 0, 2)
+        DFINE_LA_ATTR(0, 1, 2) DFINE_LA_ATTR(1, 1, 2) DFINE_LA_ATTR(2, 1, 2) DFINE_LA_ATTR(3, 1, 2)
         if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
         attr_set = true;
     }
 #undef DFINE_LA_ATTR
-#define DFINE_LA(A, O)                                                                                                   \
-    hipLaunchKernelGGL((linear_act_kernel<A, O>), grid, dim3(kGemmThreads), ldsb, st, (const uint16_t *)x, (const uint16_t *)w, \
+#define DFINE_LA(A, O, T)                                                                                                \
+    hipLaunchKernelGGL((linear_act_kernel<A, O, T>), grid, dim3(kGemmThreads), ldsb, st, (const uint16_t *)x, (const uint16_t *)w, \
                        bias, y, M, N, K, ldx, ldw, ldy, nt_n, nt_m)
-#define DFINE_LA_O(A) { if (out_f32) DFINE_LA(A, 1); else DFINE_LA(A, 0); }
+#define DFINE_LA_T(A, O) { if (mt == 4) DFINE_LA(A, O, 4); else DFINE_LA(A, O, 2); }
+#define DFINE_LA_O(A) { if (out_f32) DFINE_LA_T(A, 1) else DFINE_LA_T(A, 0) }
     switch (act) {
         case 0: DFINE_LA_O(0) break;
         case 1: DFINE_LA_O(1) break;
@@ -273,6 +277,7 @@ int dfine_linear_act_fwd(const void *x, const void *w, const float *bias, void *
         default: DFINE_LA_O(3) break;
     }
 #undef DFINE_LA_O
+#undef DFINE_LA_T
 #undef DFINE_LA
     return check_launch();
 }

@@ -611,15 +611,17 @@ def linear_act(x2d, w, bias=None, act=0, out_f32=False, out=None):
     transposed shadows), bias fp32 [N] or None -> act(x2d @ w.T + bias) [M, N] bf16 (fp32 when out_f32)."""
     M, K = x2d.shape
     N = w.shape[0]
-    assert w.shape[1] == K and x2d.stride(1) == 1 and w.stride(1) == 1
+    assert w.shape[1] == K and (K == 1 or (x2d.stride(1) == 1 and w.stride(1) == 1))     # size-1 dims carry arbitrary strides
     assert x2d.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    ldx = x2d.stride(0) if M > 1 else K
+    ldw = w.stride(0) if N > 1 else K
     if out is None:
         out = torch.empty(M, N, device=x2d.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.is_contiguous()
     with _timed("linear", 2.0 * M * N * K):
-        _check(_lib.dfine_linear_act_fwd(_ptr(x2d), _ptr(w), _ptr(bias), _ptr(out), M, N, K, x2d.stride(0), w.stride(0),
-                                         out.stride(0), int(act), int(out.dtype == torch.float32), _stream()),
+        _check(_lib.dfine_linear_act_fwd(_ptr(x2d), _ptr(w), _ptr(bias), _ptr(out), M, N, K, ldx, ldw,
+                                         out.stride(0) if M > 1 else N, int(act), int(out.dtype == torch.float32), _stream()),
                "dfine_linear_act_fwd")
     return out
 

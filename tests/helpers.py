@@ -44,6 +44,25 @@ def seeded_state_dict(state_dict):
     return out
 
 
+BACKBONE_ENCODER_GRAD_KEYS = (
+    "backbone.stem.stem1.conv.weight", "backbone.stem.stem3.conv.weight", "backbone.stages.0.blocks.0.layers.0.conv.weight",
+    "backbone.stages.1.blocks.0.aggregation.0.conv.weight", "backbone.stages.2.blocks.0.layers.1.conv2.conv.weight",
+    "backbone.stages.2.blocks.1.layers.0.conv1.conv.weight", "backbone.stages.3.blocks.0.aggregation.1.conv.weight",
+    "backbone.stages.2.blocks.0.layers.0.conv1.bn.weight", "encoder.input_proj.0.conv.weight",
+    "encoder.encoder.0.layers.0.self_attn.in_proj_weight", "encoder.encoder.0.layers.0.linear1.weight",
+    "encoder.fpn_blocks.0.cv1.conv.weight", "encoder.fpn_blocks.0.cv2.0.bottlenecks.0.conv1.conv.weight",
+    "encoder.pan_blocks.0.cv4.conv.weight")
+
+
+def compact_rows(t, rows=64):
+    """First `rows` rows of a tensor / array (golden fixtures keep a slice of the big weight gradients)."""
+    return t[:rows] if t.shape[0] > rows else t
+
+
+def make_cotangent(shape, seed):
+    return torch.from_numpy(np.random.default_rng(seed).normal(0, 1, tuple(shape)).astype(np.float32))
+
+
 def make_images(batch, size, seed=123):
     return torch.from_numpy(np.random.default_rng(seed).random((batch, 3, size, size), np.float32))
 

