@@ -351,9 +351,173 @@ __global__ __launch_bounds__(kConvThreads) void conv1x1_tr_kernel(const uint16_t
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 1x1 convolution, second generation: the same LDS transpose-read GEMM fed by asynchronous global -> LDS copies
+// (global_load_lds_dwordx4) into a ring of 3 stages, two of them in flight while the third is consumed - the first
+// generation (conv1x1_tr_kernel) was bound by the load -> LDS -> barrier latency of ONE register stage (MFMA 18 % busy,
+// HBM traffic already minimal: profiles/r01_conv1x1_tr_pmc.txt).
+//   stage  = 64 input channels: X [64 ch][128 px] (16 KiB) + W [64 NTN out ch][64 k] (8 NTN KiB), both copied by LDS-DMA.
+//            The DMA writes LDS lane-linearly (wave-uniform base + 16 B x lane), so the images are unpadded and the bank
+//            conflicts are removed on the SOURCE side: X row r keeps its 16-pixel segment jt at physical segment jt ^ (r & 7)
+//            (the 8 rows a 32-lane half transpose-reads then cover all 64 banks), W row n keeps its 16-byte k chunk kc at
+//            chunk kc ^ (n & 7) (2-way on the 16-row ds_read_b128).
+//   block  = 512 threads = 8 waves (4 over the output channels x 2 over the pixels), tile 128 px x 64 NTN channels,
+//            one workgroup per CU (72 / 96 KiB of LDS), two waves per SIMD.
+//   sync   = per stage ONE raw s_barrier behind a COUNTED s_waitcnt vmcnt(4): this wave's 4 copies of the stage being
+//            consumed have landed, the 4 of the next stage stay in flight across the barrier; the barrier also says every
+//            wave is done with the stage consumed before, whose slot the copies issued right after it overwrite.
+//   output = accumulators -> bf16 -> per-wave LDS transpose -> 16-byte stores of whole 128-byte pixel rows.
+constexpr int kG2Threads = 512, kG2Rows = 64;
+
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [lds_addr + 16 * lane].  Inline asm on purpose:
+// hipcc tracks the builtin form as an LDS write and puts `s_waitcnt vmcnt(0)` in front of the next ds_read, which drains
+// the ring every stage; the asm form is invisible to its counters, completion is waited for by hand (counted vmcnt +
+// barrier, see the kernel).  M0 carries the LDS address and is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void glds16(const uint16_t *gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+template <int NTN, int kG2Ring>        // kG2Ring LDS stages: 3 (two in flight) for deep layers, 2 for <= 128 input channels (2 workgroups per CU)
+__global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w2,
+                                                                  uint16_t *__restrict__ y, int Cin, int Cout, int NP, int KP,
+                                                                  int HW, int ptiles, int total_tiles, int nblk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int XB = kG2Rows * 256, WB = 64 * NTN * 128, SB = XB + WB;     // bytes per stage
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nb = slot % nblk, tile_id = (slot / nblk) * 8 + xcd;
+    if (tile_id >= total_tiles) return;
+    const int b = tile_id / ptiles, pt = tile_id - b * ptiles;
+    const int p0 = pt * kTrPix;
+    const int npix = min(kTrPix, HW - p0);
+    const uint16_t *xb = x + (int64_t)b * Cin * HW + p0;
+    const int n0 = nb * 64 * NTN;
+    const int wn = wave >> 1, wp = wave & 1;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int nstage = (KP + kG2Rows - 1) / kG2Rows;
+
+    // ---- per-lane source coordinates of this wave's LDS-DMA pieces (constant over the stages) ----
+    // X: 16 pieces of 4 rows; wave -> pieces 2 wave, 2 wave + 1.  W: 8 NTN pieces of 8 rows; wave -> NTN pieces.
+    int x_row[2], x_px[2], w_row[NTN], w_k[NTN];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 4 + (lane >> 4), pc = lane & 15;
+        const int px = (((pc >> 1) ^ (row & 7)) << 4) + ((pc & 1) << 3);
+        x_row[j] = row;
+        x_px[j] = px < npix ? px : 0;                  // columns past the plane: any valid data, never stored
+    }
+#pragma unroll
+    for (int j = 0; j < NTN; ++j) {
+        const int row = (wave * NTN + j) * 8 + (lane >> 3), pc = lane & 7;
+        w_row[j] = min(n0 + row, NP - 1);               // rows past the layer: any valid row, never stored
+        w_k[j] = ((pc ^ (row & 7)) << 3);
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    auto issue = [&](int s) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (s % kG2Ring) * SB);
+        const int c0 = s * kG2Rows;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ch = min(c0 + x_row[j], Cin - 1);  // channels past Cin meet zero weights (or a skipped slab)
+            glds16(xb + (int64_t)ch * HW + x_px[j], __builtin_amdgcn_readfirstlane(base + (wave * 2 + j) * 1024));
+        }
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) {
+            const int k = min(c0 + w_k[j], KP - 8);      // k chunks past KP belong to a slab that is skipped
+            glds16(w2 + (int64_t)w_row[j] * KP + k, __builtin_amdgcn_readfirstlane(base + XB + (wave * NTN + j) * 1024));
+        }
+    };
+
+    f32x4v acc[NTN][4];
+#pragma unroll
+    for (int t = 0; t < NTN; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    issue(0);
+    if (nstage > 1) issue(1);
+    for (int s = 0; s < nstage; ++s) {
+        if (s + 1 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NTN) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kG2Ring >= 3 && s + 2 < nstage) issue(s + 2);      // ring of 2: launched for <= 2 stages only, both issued above
+        const unsigned char *xs = lds + (s % kG2Ring) * SB, *ws = xs + XB;
+#pragma unroll
+        for (int slab = 0; slab < 2; ++slab) {
+            if (s * kG2Rows + slab * 32 >= KP) break;    // uniform
+            bf16x8 a[NTN];
+#pragma unroll
+            for (int t = 0; t < NTN; ++t) {
+                const int row = wn * 16 * NTN + t * 16 + i16;
+                a[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(ws + row * 128 + (((slab * 4 + g) ^ (row & 7)) << 4)));
+            }
+            const int r = slab * 32 + 4 * g + (i16 >> 2);
+            const unsigned char *xr = xs + r * 256 + ((i16 & 3) << 3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int seg = ((wp * 4 + j) ^ (r & 7)) << 5;
+                const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_v4s __attribute__((address_space(3))) *)(xr + seg));
+                const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_v4s __attribute__((address_space(3))) *)(xr + seg + 16 * 256));
+                typedef short tr_v8s __attribute__((ext_vector_type(8)));
+                const bf16x8 bf = __builtin_bit_cast(bf16x8, (tr_v8s)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int t = 0; t < NTN; ++t)
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], bf, acc[t][j], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: [n][px] bf16 tile of this wave through LDS, then whole 128-byte pixel rows with 16-byte stores ----
+    __builtin_amdgcn_s_barrier();                        // every wave is done reading the ring
+    uint16_t *ot = reinterpret_cast<uint16_t *>(lds) + wave * (16 * NTN * 72);          // [16 NTN rows][64 px], pitch 72
+#pragma unroll
+    for (int t = 0; t < NTN; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[(t * 16 + 4 * g + r) * 72 + j * 16 + i16] = f32_to_bf16(acc[t][j][r]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint16_t *yb = y + (int64_t)b * Cout * HW + p0 + wp * 64;
+#pragma unroll
+    for (int it = 0; it < 2 * NTN; ++it) {
+        const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+        const int n = n0 + wn * 16 * NTN + row;
+        if (n < Cout && wp * 64 + c8 < npix)
+            *reinterpret_cast<uint4 *>(yb + (int64_t)n * HW + c8) = *reinterpret_cast<const uint4 *>(ot + row * 72 + c8);
+    }
+}
+
 static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B, int Cin, int Cout, int NP, int KP, int HW,
                           hipStream_t st) {
     const int ptiles = (HW + kTrPix - 1) / kTrPix;
+    static const int v2_env = [] { const char *e = getenv("DFINE_CONV1X1_GLDS"); return e ? atoi(e) : 1; }();
+    if (v2_env && HW % 8 == 0 && KP >= 8 && Cin >= 1) {
+        // 128-channel tiles when the layer has them and they still fill the chip, 64-channel tiles otherwise
+        const bool wide2 = (NP % 128 == 0) && ((int64_t)B * ptiles * (NP / 128) >= 256);
+        const int nblk2 = wide2 ? NP / 128 : (NP + 63) / 64;
+        const int total2 = B * ptiles;
+        dim3 grid2(8 * ((total2 + 7) / 8) * nblk2);
+        const bool ring2 = KP <= 2 * kG2Rows;                  // <= 2 stages: both fit a 2-slot ring, half the LDS, 2 workgroups per CU
+        const size_t lds2 = (size_t)(ring2 ? 2 : 3) * (kG2Rows * 256 + 64 * (wide2 ? 2 : 1) * 128);
+        static bool attr2 = false;
+        if (!attr2) {
+            hipError_t e = hipSuccess, r;
+#define DFINE_G2_ATTR(N, R) if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<N, R>), hipFuncAttributeMaxDynamicSharedMemorySize, R * (16384 + 8192 * N))) != hipSuccess) e = r;
+            DFINE_G2_ATTR(1, 2) DFINE_G2_ATTR(1, 3) DFINE_G2_ATTR(2, 2) DFINE_G2_ATTR(2, 3)
+#undef DFINE_G2_ATTR
+            if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
+            attr2 = true;
+        }
+#define DFINE_G2(N, R) hipLaunchKernelGGL((conv1x1_glds_kernel<N, R>), grid2, dim3(kG2Threads), lds2, st, x, w2, y, Cin, Cout, NP, KP, HW, ptiles, total2, nblk2)
+        if (wide2) { if (ring2) DFINE_G2(2, 2); else DFINE_G2(2, 3); }
+        else { if (ring2) DFINE_G2(1, 2); else DFINE_G2(1, 3); }
+#undef DFINE_G2
+        return check_launch();
+    }
     const int vec = (HW % 8 == 0) ? 8 : (HW % 4 == 0 ? 4 : 2);
     static const int kc_env = [] { const char *e = getenv("DFINE_CONV_KC"); return e ? atoi(e) : 0; }();
     int kc = KP >= 128 ? 4 : (KP >= 64 ? 2 : 1);

@@ -214,29 +214,20 @@ def test_full_size_train_step_properties(cuda, monkeypatch):
         kernels.reload_env()
 
 
-@pytest.mark.parametrize("amp", [False, True])
-def test_backbone_encoder_m320_vs_reference(cuda, amp):
-    """HGNetv2 + HybridEncoder of D-FINE-m (every MFMA conv / stem / BN / depthwise / AIFI kernel, no discrete selection
-    in between) against the reference's fp32 features and parameter gradients.  fp32: 1e-3 of the feature scale,
-    gradient cosine 0.9999 (fixtures are fp16 slices).  bf16 autocast (the throughput path; these kernels only run there): feature cosine 0.999,
-    gradient cosine 0.99 and norm within 5 % per tensor.  (The full model is not a usable bf16 anchor: top-k query
-    selection and the matcher flip on bf16 noise - plain ATen bf16 autocast decorrelates the same gradients to ~0.5.)"""
+def test_backbone_encoder_m320_vs_reference(cuda):
+    """HGNetv2 + HybridEncoder of D-FINE-m in fp32 against the reference's features and parameter gradients
+    (3e-3 of the feature scale; gradient cosine 0.9999, norm 2e-3; fixtures are fp16 slices)."""
     g = np.load(f"{G}/backbone_encoder_m320.npz")
     m = dfine.build_model("m", 80, False, "cpu", img_size=[320, 320])
     m.load_state_dict(helpers.seeded_state_dict(m.state_dict()))
     m = m.to(cuda).train()
     x = helpers.make_images(2, 320).to(cuda)
-    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-        feats = m.encoder(m.backbone(x))
+    feats = m.encoder(m.backbone(x))
     loss = 0
     for i, f in enumerate(feats):
         ref = torch.tensor(g[f"feat{i}"].astype(np.float32))
         got = f.detach().float().cpu()[:1]
-        cos = torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item()
-        if amp:
-            assert cos > 0.999, (i, cos)
-        else:
-            assert (got - ref).abs().max() <= 3e-3 * ref.abs().max(), (i, (got - ref).abs().max().item())
+        assert (got - ref).abs().max() <= 3e-3 * ref.abs().max(), (i, (got - ref).abs().max().item())
         loss = loss + (f.float() * helpers.make_cotangent(f.shape, 50 + i).to(cuda)).sum()
     loss.backward()
     params = dict(m.named_parameters())
@@ -245,5 +236,53 @@ def test_backbone_encoder_m320_vs_reference(cuda, amp):
         got = helpers.compact_rows(params[k].grad.float().cpu())
         cos = torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item()
         ratio = (got.norm() / ref.norm()).item()
-        assert cos > (0.99 if amp else 0.9999), (k, cos)
-        assert abs(ratio - 1) < (0.05 if amp else 2e-3), (k, ratio)
+        assert cos > 0.9999, (k, cos)
+        assert abs(ratio - 1) < 2e-3, (k, ratio)
+
+
+def test_bf16_blocks_vs_fp32_blocks_m320(cuda):
+    """The bf16 (MFMA) path block by block.  End to end this network is not a usable bf16 anchor - with the seeded random
+    weights and batch statistics over 2 images, plain ATen bf16 autocast already decorrelates the encoder features to cosine
+    0.7-0.85 of the fp32 ones (and the full model adds top-k selection and the matcher) - so every backbone / encoder block
+    is run in bf16 autocast on the inputs it saw in the fp32 run above (itself pinned to the reference), and its output,
+    input gradient and parameter gradients are compared with the block's own fp32 results: cosine 0.998 / 0.99 / 0.99."""
+    import torch.nn as nn
+    m = dfine.build_model("m", 80, False, "cpu", img_size=[320, 320])
+    m.load_state_dict(helpers.seeded_state_dict(m.state_dict()))
+    m = m.to(cuda).train()
+    blocks = [("backbone.stem", m.backbone.stem)]
+    for si, st in enumerate(m.backbone.stages):
+        if hasattr(st, "downsample") and not isinstance(st.downsample, nn.Identity):
+            blocks.append((f"backbone.stages.{si}.downsample", st.downsample))
+        blocks += [(f"backbone.stages.{si}.blocks.{bi}", b) for bi, b in enumerate(st.blocks)]
+    enc = m.encoder
+    for name in ("input_proj", "lateral_convs", "fpn_blocks", "downsample_convs", "pan_blocks"):
+        blocks += [(f"encoder.{name}.{i}", b) for i, b in enumerate(getattr(enc, name))]
+    captured = {}
+    hooks = [b.register_forward_hook(lambda mod, inp, out, n=n: captured.__setitem__(n, (inp[0].detach(), out.detach())))
+             for n, b in blocks]
+    x = helpers.make_images(2, 320).to(cuda)
+    with torch.no_grad():
+        m.encoder(m.backbone(x))
+    for h in hooks:
+        h.remove()
+    assert len(captured) == len(blocks)
+    cos = lambda a, b: torch.nn.functional.cosine_similarity(a.float().flatten(), b.float().flatten(), dim=0).item()
+    worst = {}
+    for n, b in blocks:
+        xin, _ = captured[n]
+        res = []
+        for amp in (False, True):
+            xi = xin.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                y = b(xi)
+            go = helpers.make_cotangent(y.shape, 77).to(cuda)
+            b.zero_grad()
+            (y.float() * go).sum().backward()
+            res.append((y.detach(), xi.grad.detach(), {k: p.grad.detach().clone() for k, p in b.named_parameters() if p.grad is not None}))
+        (y0, gx0, gp0), (y1, gx1, gp1) = res
+        cy, cx = cos(y0, y1), cos(gx0, gx1)
+        cp = min((cos(gp0[k], gp1[k]) for k in gp0 if gp0[k].numel() > 16 and gp0[k].abs().max() > 0), default=1.0)
+        worst[n] = (cy, cx, cp)
+    bad = {n: v for n, v in worst.items() if v[0] < 0.998 or v[1] < 0.99 or v[2] < 0.99}
+    assert not bad, bad
