@@ -714,6 +714,132 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 1x1 weight gradient, second generation.  dW[n][c] = sum_{b, p} dY[b][n][p] X[b][c][p] is a GEMM with a 128-ish x 128-ish
+// output and a B*H*W-long reduction whose operands are each read ONCE: at 128 channels that is 64 FLOP per byte, and what
+// bounds it on this chip is the ~10 B/clk/CU global-load path (L2 hits included), not HBM or MFMA - the 64 x 64 tiles of
+// conv_wgrad_kernel<1> re-read both operands twice (32 FLOP per loaded byte -> 200 TFLOP/s measured).  Here a workgroup
+// owns a 128 x 128 (n, c) tile (64 accumulator registers per lane) for a range of 64-pixel chunks, both operands arrive by
+// LDS-DMA into a ring of 3 stages (same protocol as conv1x1_glds_kernel: counted vmcnt + one raw barrier per stage), rows are
+// 128-byte pixel runs whose 16-byte chunk kc sits at chunk kc ^ (row & 7), fragments are plain ds_read_b128.
+// Pixels past the plane and channels past the layer are fetched from a 16-byte page of zeros.
+__device__ uint4 g_zero_page = {0u, 0u, 0u, 0u};
+constexpr int kW2Threads = 256, kW2Ring = 3, kW2Px = 64;
+
+__global__ __launch_bounds__(kW2Threads) void conv_wgrad1_glds_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy,
+                                                                      float *__restrict__ part, int Cin, int Cout, int HW,
+                                                                      int chunks_per_image, int total_chunks, int chunks_per_split,
+                                                                      int nct, int NP16, int CP16, int npairs, int nsplits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int OPB = 128 * 128, SB = 2 * OPB;                             // bytes per operand tile / per stage
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int pair, split;
+    if ((nsplits & 7) == 0) {                                               // all tile pairs of a split on one XCD (L2 reuse)
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        pair = slot % npairs; split = (slot / npairs) * 8 + xcd;
+    } else {
+        pair = blockIdx.x % npairs; split = blockIdx.x / npairs;
+    }
+    if (split >= nsplits) return;
+    const int nt = pair / nct, ct = pair - nt * nct;
+    const int n0 = nt * 128, c0 = ct * 128;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int q0 = split * chunks_per_split, q1 = min(total_chunks, q0 + chunks_per_split);
+    const int nstage = q1 - q0;
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero_page);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+
+    // this wave's 4 + 4 LDS-DMA pieces per stage: piece = 8 rows x 128 B; lane -> (row, physical chunk)
+    int row_a[4], kc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + (lane >> 3);
+        row_a[j] = row;
+        kc[j] = ((lane & 7) ^ (row & 7)) << 3;                               // logical pixel offset of this lane's chunk
+    }
+    auto issue = [&](int s) {
+        const int q = q0 + s;
+        const int b = q / chunks_per_image, p0 = (q - b * chunks_per_image) * kW2Px;
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (s % kW2Ring) * SB);
+        const uint16_t *dyb = dy + (int64_t)b * Cout * HW + p0, *xb = x + (int64_t)b * Cin * HW + p0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool pin = p0 + kc[j] < HW;
+            const int n = n0 + row_a[j], c = c0 + row_a[j];
+            glds16((pin && n < Cout) ? dyb + (int64_t)n * HW + kc[j] : zero, __builtin_amdgcn_readfirstlane(base + (wave * 4 + j) * 1024));
+            glds16((pin && c < Cin) ? xb + (int64_t)c * HW + kc[j] : zero, __builtin_amdgcn_readfirstlane(base + OPB + (wave * 4 + j) * 1024));
+        }
+    };
+    f32x4v acc[2][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    if (nstage > 0) issue(0);
+    if (nstage > 1) issue(1);
+    for (int s = 0; s < nstage; ++s) {
+        if (s + 1 < nstage) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 2 < nstage) issue(s + 2);
+        const unsigned char *ta = lds + (s % kW2Ring) * SB, *tb = ta + OPB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2], bfr[8];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int row = wave * 32 + a * 16 + i16;
+                af[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(ta + row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4)));
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int row = b * 16 + i16;
+                bfr[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(tb + row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4)));
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 8; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    // partial sums: part[split][n][c]; lane holds c = i16 (+ 16 b), n = 4 g + r (+ 16 a + 32 wave)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const int c = c0 + b * 16 + i16;
+        if (c >= CP16) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wave * 32 + a * 16 + 4 * g + r;
+                if (n < NP16) part[((int64_t)split * NP16 + n) * CP16 + c] = acc[a][b][r];
+            }
+    }
+}
+
+static void wgrad1_plan(int B, int Cin, int Cout, int HW, int *splits, int *cps) {
+    const int cpi = (HW + kW2Px - 1) / kW2Px, total = B * cpi;
+    const int pairs = ((Cout + 127) / 128) * ((Cin + 127) / 128);
+    const int64_t bytes_per_split = (int64_t)((Cout + 15) / 16 * 16) * ((Cin + 15) / 16 * 16) * 4;
+    int cap = (int)(24000000 / bytes_per_split);                            // fp32 partials (written once, read once) below ~24 MB
+    if (cap < 8) cap = 8;
+    int sp = 256 / pairs;                                                   // one workgroup per CU (96 KiB of LDS), one round: the load path of EVERY CU is needed
+    if (sp < 1) sp = 1;
+    if (sp > cap) sp = cap;
+    if (sp > total) sp = total;
+    int c = (total + sp - 1) / sp;
+    int spl = (total + c - 1) / c;
+    if (spl >= 8 && (spl & 7)) {                                            // whole splits per XCD
+        for (int u = c; u <= c * 4 / 3 + 1; ++u) {
+            const int t = (total + u - 1) / u;
+            if (t >= 8 && (t & 7) == 0) { c = u; spl = t; break; }
+        }
+    }
+    *splits = spl; *cps = c;
+}
+
 // 64 outputs x 4 split lanes per block (a 128 x 128 layer has only 16 K outputs: one thread per output left 3/4 of
 // the chip idle while every thread walked its ~256 partials one after the other).
 // Blocks past the weight range (bias_blocks of them) sum the per-split bias partials part_b[split][NP16] -> db.
@@ -979,7 +1105,17 @@ int dfine_conv_fwd_bf16(const void *x, const void *w2, void *y, int B, int Cin, 
 // Weight gradient of the same convolution.  x [B,Cin,H,W], dy [B,Cout,H,W] bf16 -> dw [Cout,Cin,KS,KS]
 // f32 (overwritten).  ws: dfine_conv_wgrad_ws_floats(...) floats.  KS = 3 needs W % 8 == 0 and
 // W <= 160; KS = 1 needs (H*W) % 8 == 0.
+static bool wgrad1_v2(int KS, int HW) {
+    static const int env = [] { const char *e = getenv("DFINE_WGRAD1_GLDS"); return e ? atoi(e) : 1; }();
+    return env && KS == 1 && HW % 8 == 0;
+}
+
 int64_t dfine_conv_wgrad_ws_floats(int B, int Cin, int Cout, int H, int W, int KS) {
+    if (wgrad1_v2(KS, H * W)) {
+        int splits, cps;
+        wgrad1_plan(B, Cin, Cout, H * W, &splits, &cps);
+        return (int64_t)splits * ((Cout + 15) / 16 * 16) * ((Cin + 15) / 16 * 16);
+    }
     int h = H, w = W;
     if (KS == 1) { const int hw = H * W; w = 160; while (w > 8 && (hw % w || w % 8)) --w; h = hw / w; }
     int R, strips, splits, ups;
@@ -991,6 +1127,31 @@ int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, i
                           int W, int KS, void *stream) {
     if (B == 0) return DFINE_OK;
     if (!x || !dy || !dw || !ws || Cin < 1 || Cout < 1 || (KS != 1 && KS != 3)) return DFINE_E_BADARG;
+    if (wgrad1_v2(KS, H * W)) {
+        const int HW = H * W;
+        int splits, cps;
+        wgrad1_plan(B, Cin, Cout, HW, &splits, &cps);
+        const int cpi = (HW + kW2Px - 1) / kW2Px;
+        const int nnt = (Cout + 127) / 128, nct = (Cin + 127) / 128, npairs = nnt * nct;
+        const int np16 = (Cout + 15) / 16 * 16, cp16 = (Cin + 15) / 16 * 16;
+        hipStream_t st = (hipStream_t)stream;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad1_glds_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kW2Ring * 2 * 128 * 128);
+            if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
+            attr_set = true;
+        }
+        const int gsplits = (splits & 7) == 0 ? splits : splits;           // the XCD mapping pads inside the kernel
+        hipLaunchKernelGGL(conv_wgrad1_glds_kernel, dim3(((splits & 7) == 0 ? splits : gsplits) * npairs), dim3(kW2Threads),
+                           (size_t)kW2Ring * 2 * 128 * 128, st, (const uint16_t *)x, (const uint16_t *)dy, ws, Cin, Cout, HW, cpi,
+                           B * cpi, cps, nct, np16, cp16, npairs, splits);
+        if (int e = check_launch()) return e;
+        const int64_t total = (int64_t)Cout * Cin;
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((int)((total + 63) / 64)), dim3(256), 0, st, ws, dw, splits, Cout, Cin, 1,
+                           np16, cp16);
+        return check_launch();
+    }
     int h = H, w = W;
     if (KS == 1) {
         const int hw = H * W;
