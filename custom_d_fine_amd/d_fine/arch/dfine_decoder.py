@@ -495,6 +495,13 @@ class DFINETransformer(nn.Module):
             self._anchor_cache[key] = self._generate_anchors(spatial_shapes, device=device)
         return self._anchor_cache[key]
 
+    def _enc_output(self, t):
+        """enc_output = Linear + LayerNorm (ref dfine_decoder.py:615-621), both HIP kernels on the GPU."""
+        return kernels.layer_norm(kernels.linear_module(self.enc_output[0], t), self.enc_output[1])
+
+    def _enc_scores(self, t):
+        return kernels.linear_module(self.enc_score_head, t)
+
     def _get_decoder_input(self, memory, spatial_shapes, denoising_logits=None,
                            denoising_bbox_unact=None):
         anchors, valid = self._anchors_for(spatial_shapes, memory.device)
@@ -509,18 +516,18 @@ class DFINETransformer(nn.Module):
             # (dfine_decoder.py:842-853), but the backward no longer runs three GEMMs + a LayerNorm
             # over B*8400 mostly-zero gradient rows.
             with torch.no_grad():
-                scores_all = self.enc_score_head(self.enc_output(memory))
+                scores_all = self._enc_scores(self._enc_output(memory))
             ind = self._topk_indices(scores_all, self.num_queries)
 
             def take(t):
                 return t.gather(dim=1, index=ind.unsqueeze(-1).expand(-1, -1, t.shape[-1]))
 
-            top_mem = self.enc_output(take(memory))
-            top_logits = self.enc_score_head(top_mem)
+            top_mem = self._enc_output(take(memory))
+            top_logits = self._enc_scores(top_mem)
             top_anchor = take(anchors)
         else:
-            out_mem = self.enc_output(memory)
-            enc_logits = self.enc_score_head(out_mem)
+            out_mem = self._enc_output(memory)
+            enc_logits = self._enc_scores(out_mem)
             top_mem, top_logits, top_anchor = self._select_topk(out_mem, enc_logits, anchors,
                                                                 self.num_queries)
         box_unact = self.enc_bbox_head(top_mem) + top_anchor

@@ -832,6 +832,18 @@ def add_layer_norm(x, branch, norm: nn.LayerNorm, clamp: Optional[float] = None)
     return norm(z)
 
 
+def layer_norm(x, norm: nn.LayerNorm):
+    """Plain LayerNorm over the last dim (enc_output.norm, ref dfine_decoder.py:615-621); HIP on CUDA tensors."""
+    if _ln_fast(x, norm):
+        return _LNFused.apply(0, x, None, None, norm.weight, norm.bias, norm.eps, 0.0)
+    return norm(x)
+
+
+def linear_module(mod: nn.Linear, x, act=None):
+    """`mod(x)` (an nn.Linear kept for its state-dict keys) through the HIP GEMM."""
+    return linear(x, mod.weight, mod.bias, act=act)
+
+
 def gate_layer_norm(gate_logits, x1, x2, norm: nn.LayerNorm):
     """norm(sigmoid(g)[..., :D] * x1 + sigmoid(g)[..., D:] * x2), g = Gate.gate([x1, x2]) (ref dfine_decoder.py:258-271)."""
     if (_ln_fast(x1, norm) and x2.shape == x1.shape and gate_logits.shape[-1] == 2 * x1.shape[-1]
