@@ -369,6 +369,26 @@ __global__ __launch_bounds__(kConvThreads) void conv1x1_tr_kernel(const uint16_t
 //   output = accumulators -> bf16 -> per-wave LDS transpose -> 16-byte stores of whole 128-byte pixel rows.
 constexpr int kG2Threads = 512, kG2Rows = 64;
 
+// A [B, C, H, W] activation given as up to 8 tensors concatenated along C (each [B, C_k, H, W], contiguous): the 1x1
+// kernels read / write the parts in place instead of a torch.cat / split copy (HG_Block aggregation, RepNCSPELAN4.cv4,
+// FPN / PAN fusion inputs: src/d_fine/arch/hgnetv2.py:265-274, hybrid_encoder.py:196-206,460-486).
+struct ChanSegs {
+    const uint16_t *p[8];
+    int start[9];          // channel offsets, start[n] = C
+    int bs[8];             // batch stride of part k in channels (= its channel count, or more for a channel slice of a wider tensor)
+    int n;
+};
+
+// address of channel c, pixel offset `off` of image b
+__device__ __forceinline__ const uint16_t *seg_addr(const ChanSegs &sg, int b, int c, int HW) {
+    const uint16_t *sp = sg.p[0];
+    int s0 = 0, sc = sg.bs[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        if (k < sg.n && c >= sg.start[k]) { sp = sg.p[k]; s0 = sg.start[k]; sc = sg.bs[k]; }
+    return sp + ((int64_t)b * sc + (c - s0)) * HW;
+}
+
 // One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [lds_addr + 16 * lane].  Inline asm on purpose:
 // hipcc tracks the builtin form as an LDS write and puts `s_waitcnt vmcnt(0)` in front of the next ds_read, which drains
 // the ring every stage; the asm form is invisible to its counters, completion is waited for by hand (counted vmcnt +
@@ -382,8 +402,8 @@ __device__ __forceinline__ void glds16(const uint16_t *gsrc, unsigned lds_addr) 
 }
 
 template <int NTN, int kG2Ring>        // kG2Ring LDS stages: 3 (two in flight) for deep layers, 2 for <= 128 input channels (2 workgroups per CU)
-__global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w2,
-                                                                  uint16_t *__restrict__ y, int Cin, int Cout, int NP, int KP,
+__global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs xs_, const uint16_t *__restrict__ w2,
+                                                                  const ChanSegs ys_, int Cin, int Cout, int NP, int KP,
                                                                   int HW, int ptiles, int total_tiles, int nblk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int XB = kG2Rows * 256, WB = 64 * NTN * 128, SB = XB + WB;     // bytes per stage
@@ -395,7 +415,6 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const uint16_t
     const int b = tile_id / ptiles, pt = tile_id - b * ptiles;
     const int p0 = pt * kTrPix;
     const int npix = min(kTrPix, HW - p0);
-    const uint16_t *xb = x + (int64_t)b * Cin * HW + p0;
     const int n0 = nb * 64 * NTN;
     const int wn = wave >> 1, wp = wave & 1;
     const int g = lane >> 4, i16 = lane & 15;
@@ -424,7 +443,7 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const uint16_t
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int ch = min(c0 + x_row[j], Cin - 1);  // channels past Cin meet zero weights (or a skipped slab)
-            glds16(xb + (int64_t)ch * HW + x_px[j], __builtin_amdgcn_readfirstlane(base + (wave * 2 + j) * 1024));
+            glds16(seg_addr(xs_, b, ch, HW) + p0 + x_px[j], __builtin_amdgcn_readfirstlane(base + (wave * 2 + j) * 1024));
         }
 #pragma unroll
         for (int j = 0; j < NTN; ++j) {
@@ -481,18 +500,24 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const uint16_t
 #pragma unroll
             for (int r = 0; r < 4; ++r) ot[(t * 16 + 4 * g + r) * 72 + j * 16 + i16] = f32_to_bf16(acc[t][j][r]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    uint16_t *yb = y + (int64_t)b * Cout * HW + p0 + wp * 64;
 #pragma unroll
     for (int it = 0; it < 2 * NTN; ++it) {
         const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
         const int n = n0 + wn * 16 * NTN + row;
         if (n < Cout && wp * 64 + c8 < npix)
-            *reinterpret_cast<uint4 *>(yb + (int64_t)n * HW + c8) = *reinterpret_cast<const uint4 *>(ot + row * 72 + c8);
+            *reinterpret_cast<uint4 *>(const_cast<uint16_t *>(seg_addr(ys_, b, n, HW)) + p0 + wp * 64 + c8) =
+                *reinterpret_cast<const uint4 *>(ot + row * 72 + c8);
     }
 }
 
+static ChanSegs one_seg(const void *p, int C) {
+    ChanSegs sg{};
+    sg.p[0] = (const uint16_t *)p; sg.start[0] = 0; sg.start[1] = C; sg.bs[0] = C; sg.n = 1;
+    return sg;
+}
+
 static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B, int Cin, int Cout, int NP, int KP, int HW,
-                          hipStream_t st) {
+                          hipStream_t st, const ChanSegs *xsegs = nullptr, const ChanSegs *ysegs = nullptr) {
     const int ptiles = (HW + kTrPix - 1) / kTrPix;
     static const int v2_env = [] { const char *e = getenv("DFINE_CONV1X1_GLDS"); return e ? atoi(e) : 1; }();
     if (v2_env && HW % 8 == 0 && KP >= 8 && Cin >= 1) {
@@ -512,12 +537,14 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
             if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
             attr2 = true;
         }
-#define DFINE_G2(N, R) hipLaunchKernelGGL((conv1x1_glds_kernel<N, R>), grid2, dim3(kG2Threads), lds2, st, x, w2, y, Cin, Cout, NP, KP, HW, ptiles, total2, nblk2)
+        const ChanSegs xs_ = xsegs ? *xsegs : one_seg(x, Cin), ys_ = ysegs ? *ysegs : one_seg(y, Cout);
+#define DFINE_G2(N, R) hipLaunchKernelGGL((conv1x1_glds_kernel<N, R>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles, total2, nblk2)
         if (wide2) { if (ring2) DFINE_G2(2, 2); else DFINE_G2(2, 3); }
         else { if (ring2) DFINE_G2(1, 2); else DFINE_G2(1, 3); }
 #undef DFINE_G2
         return check_launch();
     }
+    if (xsegs || ysegs) return DFINE_E_BADARG;          // the first-generation kernel takes whole tensors only
     const int vec = (HW % 8 == 0) ? 8 : (HW % 4 == 0 ? 4 : 2);
     static const int kc_env = [] { const char *e = getenv("DFINE_CONV_KC"); return e ? atoi(e) : 0; }();
     int kc = KP >= 128 ? 4 : (KP >= 64 ? 2 : 1);
@@ -726,7 +753,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
 __device__ uint4 g_zero_page = {0u, 0u, 0u, 0u};
 constexpr int kW2Threads = 256, kW2Ring = 3, kW2Px = 64;
 
-__global__ __launch_bounds__(kW2Threads) void conv_wgrad1_glds_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy,
+__global__ __launch_bounds__(kW2Threads) void conv_wgrad1_glds_kernel(const ChanSegs xs_, const uint16_t *__restrict__ dy,
                                                                       float *__restrict__ part, int Cin, int Cout, int HW,
                                                                       int chunks_per_image, int total_chunks, int chunks_per_split,
                                                                       int nct, int NP16, int CP16, int npairs, int nsplits) {
@@ -762,13 +789,13 @@ __global__ __launch_bounds__(kW2Threads) void conv_wgrad1_glds_kernel(const uint
         const int q = q0 + s;
         const int b = q / chunks_per_image, p0 = (q - b * chunks_per_image) * kW2Px;
         const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (s % kW2Ring) * SB);
-        const uint16_t *dyb = dy + (int64_t)b * Cout * HW + p0, *xb = x + (int64_t)b * Cin * HW + p0;
+        const uint16_t *dyb = dy + (int64_t)b * Cout * HW + p0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool pin = p0 + kc[j] < HW;
             const int n = n0 + row_a[j], c = c0 + row_a[j];
             glds16((pin && n < Cout) ? dyb + (int64_t)n * HW + kc[j] : zero, __builtin_amdgcn_readfirstlane(base + (wave * 4 + j) * 1024));
-            glds16((pin && c < Cin) ? xb + (int64_t)c * HW + kc[j] : zero, __builtin_amdgcn_readfirstlane(base + OPB + (wave * 4 + j) * 1024));
+            glds16((pin && c < Cin) ? seg_addr(xs_, b, c, HW) + p0 + kc[j] : zero, __builtin_amdgcn_readfirstlane(base + OPB + (wave * 4 + j) * 1024));
         }
     };
     f32x4v acc[2][8];
@@ -1053,6 +1080,39 @@ static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B
 
 using namespace dfine;
 
+static int launch_wgrad1(const ChanSegs &xs_, const void *dy, float *dw, float *ws, int B, int Cin, int Cout, int HW, hipStream_t st) {
+    int splits, cps;
+    wgrad1_plan(B, Cin, Cout, HW, &splits, &cps);
+    const int cpi = (HW + kW2Px - 1) / kW2Px;
+    const int nnt = (Cout + 127) / 128, nct = (Cin + 127) / 128, npairs = nnt * nct;
+    const int np16 = (Cout + 15) / 16 * 16, cp16 = (Cin + 15) / 16 * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad1_glds_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kW2Ring * 2 * 128 * 128);
+        if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad1_glds_kernel, dim3(splits * npairs), dim3(kW2Threads), (size_t)kW2Ring * 2 * 128 * 128, st, xs_,
+                       (const uint16_t *)dy, ws, Cin, Cout, HW, cpi, B * cpi, cps, nct, np16, cp16, npairs, splits);
+    if (int e = check_launch()) return e;
+    const int64_t total = (int64_t)Cout * Cin;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((int)((total + 63) / 64)), dim3(256), 0, st, ws, dw, splits, Cout, Cin, 1,
+                       np16, cp16);
+    return check_launch();
+}
+
+static bool make_segs(ChanSegs *sg, const void *const *parts, const int *channels, const int *bstrides, int n, int C) {
+    if (!parts || !channels || n < 1 || n > 8) return false;
+    int c = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!parts[k] || channels[k] < 1 || (bstrides && bstrides[k] < channels[k])) return false;
+        sg->p[k] = (const uint16_t *)parts[k]; sg->start[k] = c; sg->bs[k] = bstrides ? bstrides[k] : channels[k]; c += channels[k];
+    }
+    sg->start[n] = c; sg->n = n;
+    return c == C;
+}
+
 extern "C" {
 
 int64_t dfine_conv_packed_elems(int Cout, int Cin, int KS, int dgrad) {
@@ -1127,31 +1187,7 @@ int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, i
                           int W, int KS, void *stream) {
     if (B == 0) return DFINE_OK;
     if (!x || !dy || !dw || !ws || Cin < 1 || Cout < 1 || (KS != 1 && KS != 3)) return DFINE_E_BADARG;
-    if (wgrad1_v2(KS, H * W)) {
-        const int HW = H * W;
-        int splits, cps;
-        wgrad1_plan(B, Cin, Cout, HW, &splits, &cps);
-        const int cpi = (HW + kW2Px - 1) / kW2Px;
-        const int nnt = (Cout + 127) / 128, nct = (Cin + 127) / 128, npairs = nnt * nct;
-        const int np16 = (Cout + 15) / 16 * 16, cp16 = (Cin + 15) / 16 * 16;
-        hipStream_t st = (hipStream_t)stream;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad1_glds_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, kW2Ring * 2 * 128 * 128);
-            if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
-            attr_set = true;
-        }
-        const int gsplits = (splits & 7) == 0 ? splits : splits;           // the XCD mapping pads inside the kernel
-        hipLaunchKernelGGL(conv_wgrad1_glds_kernel, dim3(((splits & 7) == 0 ? splits : gsplits) * npairs), dim3(kW2Threads),
-                           (size_t)kW2Ring * 2 * 128 * 128, st, (const uint16_t *)x, (const uint16_t *)dy, ws, Cin, Cout, HW, cpi,
-                           B * cpi, cps, nct, np16, cp16, npairs, splits);
-        if (int e = check_launch()) return e;
-        const int64_t total = (int64_t)Cout * Cin;
-        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((int)((total + 63) / 64)), dim3(256), 0, st, ws, dw, splits, Cout, Cin, 1,
-                           np16, cp16);
-        return check_launch();
-    }
+    if (wgrad1_v2(KS, H * W)) return launch_wgrad1(one_seg(x, Cin), dy, dw, ws, B, Cin, Cout, H * W, (hipStream_t)stream);
     int h = H, w = W;
     if (KS == 1) {
         const int hw = H * W;
@@ -1196,6 +1232,32 @@ int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, i
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, splits, Cout, Cin, KS * KS,
                        np16, cp16);
     return check_launch();
+}
+
+// 1x1 convolution whose input and / or output is a channel-wise concatenation kept as separate tensors: x_parts / y_parts are
+// HOST arrays of n device pointers (part k = [B, channels[k], H, W] bf16 with batch stride bstrides[k] * H * W elements - the
+// channel count, or more for a channel slice of a wider tensor; NULL = contiguous), sum(channels) = Cin / Cout.  (H*W) % 8 == 0.
+int dfine_conv1x1_seg_fwd_bf16(const void *const *x_parts, const int *x_channels, const int *x_bstrides, int n_x, const void *w2,
+                               void *const *y_parts, const int *y_channels, const int *y_bstrides, int n_y, int B, int Cin, int Cout,
+                               int H, int W, void *stream) {
+    if (B == 0) return DFINE_OK;
+    ChanSegs xs_, ys_;
+    if (!w2 || !make_segs(&xs_, x_parts, x_channels, x_bstrides, n_x, Cin) ||
+        !make_segs(&ys_, (const void *const *)y_parts, y_channels, y_bstrides, n_y, Cout))
+        return DFINE_E_BADARG;
+    if ((H * W) % 8 || Cin % 2) return DFINE_E_BADARG;
+    const int NP = (Cout + 15) / 16 * 16, KP = (Cin + 31) / 32 * 32;
+    return launch_conv1x1(nullptr, (const uint16_t *)w2, nullptr, B, Cin, Cout, NP, KP, H * W, (hipStream_t)stream, &xs_, &ys_);
+}
+
+// weight gradient of the same: dw [Cout, Cin] f32 (overwritten), ws: dfine_conv_wgrad_ws_floats(B, Cin, Cout, H, W, 1) floats
+int dfine_conv1x1_seg_wgrad_bf16(const void *const *x_parts, const int *x_channels, const int *x_bstrides, int n_x, const void *dy,
+                                 float *dw, float *ws,
+                                 int B, int Cin, int Cout, int H, int W, void *stream) {
+    if (B == 0) return DFINE_OK;
+    ChanSegs xs_;
+    if (!dy || !dw || !ws || !make_segs(&xs_, x_parts, x_channels, x_bstrides, n_x, Cin) || (H * W) % 8) return DFINE_E_BADARG;
+    return launch_wgrad1(xs_, dy, dw, ws, B, Cin, Cout, H * W, (hipStream_t)stream);
 }
 
 static void linear_wgrad_plan(int M, int N, int K, int *splits, int *rows) {

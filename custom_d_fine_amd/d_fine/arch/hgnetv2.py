@@ -50,7 +50,7 @@ class ConvBNAct(nn.Module):
     def forward(self, x, pad_br=False):
         """pad_br: the input stands for F.pad(x, (0, 1, 0, 1)) (StemBlock); the pad is applied inside."""
         if isinstance(self.conv, nn.Sequential):
-            x = self.conv[0](x)
+            x = self.conv[0](torch.cat(list(x), dim=1) if isinstance(x, (list, tuple)) else x)
             conv = self.conv[1]
         else:
             conv = self.conv
@@ -137,7 +137,7 @@ class HG_Block(nn.Module):
         feats = [x]
         for layer in self.layers:
             feats.append(layer(feats[-1]))
-        y = self.aggregation(torch.cat(feats, dim=1))
+        y = self.aggregation(feats)        # channel concat of all maps, read in place by the 1x1 aggregation conv
         return self.drop_path(y) + x if self.residual else y
 
 

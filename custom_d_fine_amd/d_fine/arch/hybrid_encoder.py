@@ -40,7 +40,7 @@ class ConvNormLayer_fuse(nn.Module):
 
     def forward(self, x):
         if hasattr(self, "conv_bn_fused"):
-            return self.act(self.conv_bn_fused(x))
+            return self.act(self.conv_bn_fused(torch.cat(list(x), dim=1) if isinstance(x, (list, tuple)) else x))
         if self._act_name is not None or isinstance(self.act, nn.Identity):
             return kernels.conv_bn_act(x, self.conv, self.norm, self._act_name, None)
         return self.act(kernels.conv_bn_act(x, self.conv, self.norm, None, None))
@@ -148,10 +148,10 @@ class RepNCSPELAN4(nn.Module):
         self.cv4 = ConvNormLayer_fuse(c3 + (2 * c4), c2, 1, 1, bias=bias, act=act)
 
     def forward(self, x):
-        parts = list(self.cv1(x).split((self.c, self.c), 1))
-        parts.append(self.cv2(parts[-1]))
-        parts.append(self.cv3(parts[-1]))
-        return self.cv4(torch.cat(parts, 1))
+        y1 = self.cv1(x)                                   # x may be a list: the FPN / PAN concat, read in place
+        y2 = self.cv2(y1[:, self.c:])
+        y3 = self.cv3(y2)
+        return self.cv4([y1, y2, y3])                      # cat(split(y1), y2, y3) without building it
 
 
 class MultiheadSelfAttention(nn.Module):
@@ -331,10 +331,10 @@ class HybridEncoder(nn.Module):
             top = self.lateral_convs[k](inner[0])
             inner[0] = top
             up = F.interpolate(top, scale_factor=2.0, mode="nearest")
-            inner.insert(0, self.fpn_blocks[k](torch.concat([up, proj[idx - 1]], dim=1)))
+            inner.insert(0, self.fpn_blocks[k]([up, proj[idx - 1]]))
 
         outs = [inner[0]]
         for idx in range(nlev - 1):
             down = self.downsample_convs[idx](outs[-1])
-            outs.append(self.pan_blocks[idx](torch.concat([down, inner[idx + 1]], dim=1)))
+            outs.append(self.pan_blocks[idx]([down, inner[idx + 1]]))
         return outs

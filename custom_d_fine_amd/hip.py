@@ -56,6 +56,8 @@ _SIGNATURES = {
     "dfine_fdr_fwd": (c_int, [_P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_fdr_bwd": (c_int, [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_topk_anchors": (c_int, [_P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfine_conv1x1_seg_fwd_bf16": (c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_conv1x1_seg_wgrad_bf16": (c_int, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfine_linear_act_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_multi_cast_bf16_t": (c_int, [_P, _I, _P]),
     "dfine_act_fwd_bf16": (c_int, [_P, _P, _L, _I, _P]),
@@ -510,6 +512,48 @@ def conv_forward_bf16(x, w2, cout, ks):
         _check(_lib.dfine_conv_fwd_bf16(_ptr(x), _ptr(w2), _ptr(y), B, cin, cout, H, W, ks, _stream()),
                "dfine_conv_fwd_bf16")
     return y
+
+
+def _seg_arrays(parts):
+    hw = parts[0].shape[2] * parts[0].shape[3]
+    ptrs = (c_void_p * len(parts))(*[t.data_ptr() for t in parts])
+    chans = (c_int * len(parts))(*[t.shape[1] for t in parts])
+    bstr = (c_int * len(parts))(*[(t.stride(0) // hw if t.shape[0] > 1 else t.shape[1]) for t in parts])
+    return ptrs, chans, bstr
+
+
+def is_channel_part(t):
+    """[B, C, H, W] bf16 that is contiguous or a channel slice of a contiguous tensor (planes dense, images equally spaced)."""
+    if t.dim() != 4 or t.dtype != torch.bfloat16:
+        return False
+    B, C, H, W = t.shape
+    hw = H * W
+    return (t.stride(3) == 1 or W == 1) and (t.stride(2) == W or H == 1) and (t.stride(1) == hw or C == 1) and (
+        B == 1 or (t.stride(0) % hw == 0 and t.stride(0) >= C * hw)) and t.data_ptr() % 16 == 0
+
+
+def conv1x1_seg_forward(x_parts, w2, y_parts):
+    """1x1 conv over the channel concatenation of `x_parts` ([B, C_k, H, W] bf16 contiguous) written into the channel
+    concatenation `y_parts` (preallocated), packed weights `w2` ([sum C_out] x [sum C_in])."""
+    B, _, H, W = x_parts[0].shape
+    cin, cout = sum(t.shape[1] for t in x_parts), sum(t.shape[1] for t in y_parts)
+    xp, xc, xb = _seg_arrays(x_parts)
+    yp, yc, yb = _seg_arrays(y_parts)
+    with _timed("conv1x1", 2.0 * B * H * W * cin * cout):
+        _check(_lib.dfine_conv1x1_seg_fwd_bf16(xp, xc, xb, len(x_parts), _ptr(w2), yp, yc, yb, len(y_parts), B, cin, cout, H, W,
+                                               _stream()), "dfine_conv1x1_seg_fwd_bf16")
+
+
+def conv1x1_seg_wgrad(x_parts, dy):
+    B, _, H, W = x_parts[0].shape
+    cin, cout = sum(t.shape[1] for t in x_parts), dy.shape[1]
+    dw = torch.empty(cout, cin, 1, 1, device=dy.device, dtype=torch.float32)
+    ws = torch.empty(int(_lib.dfine_conv_wgrad_ws_floats(B, cin, cout, H, W, 1)), device=dy.device, dtype=torch.float32)
+    xp, xc, xb = _seg_arrays(x_parts)
+    with _timed("conv1x1_wgrad", 2.0 * B * H * W * cin * cout):
+        _check(_lib.dfine_conv1x1_seg_wgrad_bf16(xp, xc, xb, len(x_parts), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W,
+                                                 _stream()), "dfine_conv1x1_seg_wgrad_bf16")
+    return dw
 
 
 def conv_wgrad_supported(H, W, ks):

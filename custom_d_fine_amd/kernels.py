@@ -505,7 +505,7 @@ def _conv_plan(x, weight):
     plan = _CONV_PLAN.get(key)
     if plan is not None:
         return plan
-    mode = _env("DFINE_CONV_TUNE", "1")
+    mode = _env("DFINE_CONV_TUNE", "hip")   # "hip" (default): HIP kernels only; "1": per-shape timing against MIOpen; "aten"
     if mode != "1":                      # "hip" / "aten": force one side (debugging, A/B runs)
         plan = {k: mode == "hip" for k in ("fwd", "dgrad", "wgrad")}
         plan["wgrad"] = plan["wgrad"] and hip.conv_wgrad_supported(H, W, ks)
@@ -579,6 +579,38 @@ class _DenseConv(torch.autograd.Function):
         if need_dw and plan["wgrad"]:
             dw = hip.conv_wgrad_bf16(x, dy, ks).to(weight.dtype)
         return dx, dw
+
+
+class _DenseConvSeg(torch.autograd.Function):
+    """1x1 convolution of torch.cat(xs, dim=1) that never builds the concatenation: the HIP kernels gather the input
+    channels from the parts (forward, weight gradient) and scatter the data gradient into one tensor per part
+    (csrc/conv.hip: ChanSegs)."""
+
+    @staticmethod
+    def forward(ctx, weight, *xs):
+        hip = _hip()
+        xs = tuple(x if hip.is_channel_part(x) else x.contiguous() for x in xs)     # channel slices are read in place
+        B, _, H, W = xs[0].shape
+        y = torch.empty(B, weight.shape[0], H, W, device=xs[0].device, dtype=torch.bfloat16)
+        hip.conv1x1_seg_forward(xs, _packed_weights(weight, False), (y,))
+        ctx.save_for_backward(weight, *xs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        hip = _hip()
+        weight, *xs = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dxs = [None] * len(xs)
+        need = ctx.needs_input_grad
+        if any(need[1:]):
+            outs = tuple(torch.empty(x.shape, device=x.device, dtype=x.dtype) for x in xs)
+            hip.conv1x1_seg_forward((dy,), _packed_weights(weight, True), outs)
+            dxs = [o if n else None for o, n in zip(outs, need[1:])]
+        dw = hip.conv1x1_seg_wgrad(xs, dy).to(weight.dtype) if need[0] else None
+        return (dw, *dxs)
 
 
 class _DenseConvMFMA(_DenseConv):
@@ -736,6 +768,19 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
     GPU: depthwise convs and the whole BN/act/affine tail are HIP kernels; dense convs are still
     MIOpen calls [ATen plumbing].  CPU tensors take the plain ATen composition below."""
     a = act.lower() if isinstance(act, str) else act
+    if (torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and not x.is_contiguous() and conv.kernel_size == (1, 1)
+            and x.dtype == torch.bfloat16 and _hip().is_channel_part(x)):
+        x = [x]                       # a channel slice of a wider map (RepNCSPELAN4 split): read in place, no .contiguous() copy
+    if isinstance(x, (list, tuple)):
+        # channel-wise concatenation kept as parts: the 1x1 MFMA kernels read them in place
+        xs = x
+        if (xs[0].is_cuda and not pad_br and _env("DFINE_HIP_UNITS", "1") == "1"
+                and _env("DFINE_SEG_CONV", "1") == "1" and a in (None, "relu", "silu", "swish")
+                and conv.kernel_size == (1, 1) and len(xs) <= 8 and (xs[0].shape[-1] * xs[0].shape[-2]) % 8 == 0
+                and all(t.shape[1] % 2 == 0 for t in xs) and _mfma_conv_ok(conv, xs[0])):
+            y = _DenseConvSeg.apply(conv.weight, *[t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16) for t in xs])
+            return _bn_tail(y, bn, a, act, lab)
+        x = torch.cat(list(xs), dim=1) if len(xs) > 1 else xs[0]
     if x.is_cuda and a in (None, "relu", "silu", "swish") and _env("DFINE_HIP_UNITS", "1") == "1":
         if _is_depthwise(conv):
             if torch.is_autocast_enabled() and x.dtype == torch.float32:
@@ -748,25 +793,33 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
                                 conv.stride[0], conv.padding[0], pad_br)
         else:
             y = conv(F.pad(x, (0, 1, 0, 1)) if pad_br else x)
-        if isinstance(bn, nn.BatchNorm2d) and bn.track_running_stats and bn.momentum is not None:
-            training = bn.training
-            if training:
-                if _BN_DEFER:
-                    ent = _BN_PENDING.get(id(bn))
-                    _BN_PENDING[id(bn)] = (bn.num_batches_tracked, 1 if ent is None else ent[1] + 1)
-                else:
-                    bn.num_batches_tracked.add_(1)
-            return _BNAct.apply(y, bn.weight, bn.bias, lab.scale if lab is not None else None,
-                                lab.bias if lab is not None else None, bn.running_mean, bn.running_var,
-                                a, training, bn.momentum, bn.eps)
-        if hasattr(bn, "running_var") and hasattr(bn, "affine") is False and hasattr(bn, "eps"):
-            # FrozenBatchNorm2d: buffers only, always "eval" statistics
-            return _BNAct.apply(y, bn.weight, bn.bias, lab.scale if lab is not None else None,
-                                lab.bias if lab is not None else None, bn.running_mean, bn.running_var,
-                                a, False, 0.0, bn.eps)
-        y = bn(y)
-    else:
-        y = bn(conv(F.pad(x, (0, 1, 0, 1)) if pad_br else x))
+        return _bn_tail(y, bn, a, act, lab)
+    y = bn(conv(F.pad(x, (0, 1, 0, 1)) if pad_br else x))
+    return _act_lab_torch(y, act, lab)
+
+
+def _bn_tail(y, bn, a, act, lab):
+    """BatchNorm (+ activation + learnable affine) of a conv output on the GPU: one fused HIP op (bnact.hip)."""
+    if isinstance(bn, nn.BatchNorm2d) and bn.track_running_stats and bn.momentum is not None:
+        training = bn.training
+        if training:
+            if _BN_DEFER:
+                ent = _BN_PENDING.get(id(bn))
+                _BN_PENDING[id(bn)] = (bn.num_batches_tracked, 1 if ent is None else ent[1] + 1)
+            else:
+                bn.num_batches_tracked.add_(1)
+        return _BNAct.apply(y, bn.weight, bn.bias, lab.scale if lab is not None else None,
+                            lab.bias if lab is not None else None, bn.running_mean, bn.running_var,
+                            a, training, bn.momentum, bn.eps)
+    if hasattr(bn, "running_var") and hasattr(bn, "affine") is False and hasattr(bn, "eps"):
+        # FrozenBatchNorm2d: buffers only, always "eval" statistics
+        return _BNAct.apply(y, bn.weight, bn.bias, lab.scale if lab is not None else None,
+                            lab.bias if lab is not None else None, bn.running_mean, bn.running_var,
+                            a, False, 0.0, bn.eps)
+    return _act_lab_torch(bn(y), act, lab)
+
+
+def _act_lab_torch(y, act, lab):
     if act is not None:
         a = act.lower()
         if a == "relu":
@@ -877,16 +930,19 @@ class _LinearAct(torch.autograd.Function):
         b32 = _f32_vec(bias)
         need_grad = any(ctx.needs_input_grad[:3])
         ref = None
+        n = weight.shape[0]
+        # the result is a fresh base tensor (not a view): callers may modify it in place (ReLU(inplace=True) in the heads)
+        y = torch.empty(*x.shape[:-1], n, device=x.device, dtype=torch.bfloat16)
         if act >= 2 and need_grad:          # GELU / SiLU: backward needs the pre-activation
-            ref = hip.linear_act(x2d, wb, b32, 0)
-            y = hip.act_forward(ref, act)
+            ref = hip.linear_act(x2d, wb, b32, 0, out=y.view(-1, n))
+            ref, y = y, hip.act_forward(y, act)
         else:
-            y = hip.linear_act(x2d, wb, b32, act)
+            hip.linear_act(x2d, wb, b32, act, out=y.view(-1, n))
             if act == 1:
                 ref = y
         ctx.save_for_backward(x2d, weight, ref)
         ctx.meta = (act, x.dtype, x.shape, bias is not None)
-        return y.view(*x.shape[:-1], weight.shape[0])
+        return y
 
     @staticmethod
     def backward(ctx, dy):
@@ -895,7 +951,7 @@ class _LinearAct(torch.autograd.Function):
         act, xdt, xshape, has_bias = ctx.meta
         d2 = _bf16_2d(dy)
         if act:
-            d2 = hip.act_backward(d2, ref, act)
+            d2 = hip.act_backward(d2, ref.view(-1, ref.shape[-1]), act)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = hip.linear_act(d2, bf16_param_t(weight), None, 0, out_f32=xdt == torch.float32).view(xshape)

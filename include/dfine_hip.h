@@ -268,6 +268,23 @@ int dfine_topk_anchors(const void *logits, int64_t sb, int64_t sq, int64_t *out_
                        int dtype, int B, int Q, int C, int K, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * A1 / A2  1x1 convolution over a channel-wise concatenation that is never materialised: the HG_Block
+ * aggregation conv (torch.cat of the block's maps, src/d_fine/arch/hgnetv2.py:265-274), RepNCSPELAN4.cv4
+ * and the FPN / PAN fusion inputs (src/d_fine/arch/hybrid_encoder.py:196-206,460-486).
+ * x_parts / y_parts: HOST arrays of n device pointers, part k = [B, channels[k], H, W] bf16 whose images are
+ * bstrides[k] * H * W elements apart (bstrides NULL: contiguous parts; larger: a channel slice of a wider
+ * tensor), sum(channels) = Cin / Cout; the forward entry point with a segmented OUTPUT and repacked weights
+ * (dfine_conv_pack_weights dgrad = 1, Cin / Cout exchanged) is the data gradient written straight into one
+ * tensor per concatenated input.  (H * W) % 8 == 0, at most 8 parts.
+ */
+int dfine_conv1x1_seg_fwd_bf16(const void *const *x_parts, const int *x_channels, const int *x_bstrides, int n_x,
+                               const void *w2, void *const *y_parts, const int *y_channels, const int *y_bstrides,
+                               int n_y, int B, int Cin, int Cout, int H, int W, void *stream);
+int dfine_conv1x1_seg_wgrad_bf16(const void *const *x_parts, const int *x_channels, const int *x_bstrides, int n_x,
+                                 const void *dy, float *dw, float *ws, int B, int Cin, int Cout, int H, int W,
+                                 void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * A2 / A3 / A5 / A6  Token-stream linear layers: y[M, N] = act(x[M, K] . w[N, K]^T + bias[N]), bf16
  * operands (row strides ldx / ldw / ldy elements, unit inner stride), fp32 accumulate, bias fp32 or NULL,
  * act: 0 none, 1 ReLU, 2 GELU (erf), 3 SiLU; out_f32 = 1 writes fp32.  Replaces F.linear + activation of

@@ -94,3 +94,29 @@ def test_packed_weight_caches_follow_weight_updates(cuda):
     finally:
         os.environ.pop("DFINE_CONV_TUNE", None)
         kernels.reload_env()
+
+
+@pytest.mark.parametrize("chans,Cout,H,W", [((128, 64, 64, 64), 256, 40, 40), ((96, 32, 32), 128, 80, 80), ((256, 256), 256, 20, 20),
+                                            ((48, 16, 16, 16, 16, 16, 16), 96, 16, 24)])
+def test_segmented_conv1x1_matches_cat_conv(cuda, chans, Cout, H, W):
+    """1x1 conv over torch.cat(parts) with the parts read in place (ChanSegs): forward, per-part data gradients and the
+    weight gradient vs fp32 torch on the concatenation; one part is a channel slice of a wider tensor."""
+    torch.manual_seed(sum(chans) + Cout)
+    B = 3
+    wide = torch.randn(B, chans[0] + 32, H, W, device=cuda).bfloat16()
+    parts = [wide[:, 32:]] + [torch.randn(B, c, H, W, device=cuda).bfloat16() for c in chans[1:]]
+    assert not parts[0].is_contiguous()
+    parts = [p.requires_grad_(True) for p in parts]
+    w = (torch.randn(Cout, sum(chans), 1, 1, device=cuda) / sum(chans) ** 0.5).requires_grad_(True)
+    y = kernels._DenseConvSeg.apply(w, *parts)
+    go = torch.randn_like(y)
+    y.backward(go)
+    pr = [p.detach().float().requires_grad_(True) for p in parts]
+    wr = w.detach().bfloat16().float().requires_grad_(True)
+    yr = F.conv2d(torch.cat(pr, 1), wr)
+    yr.backward(go.float())
+    assert (y.float() - yr).abs().max().item() < 1.5e-2 * yr.abs().max().item()
+    for p, r in zip(parts, pr):
+        assert p.grad.shape == r.grad.shape
+        assert (p.grad.float() - r.grad).abs().max().item() < 1.5e-2 * r.grad.abs().max().item()
+    assert (w.grad - wr.grad).abs().max().item() < 1.5e-2 * wr.grad.abs().max().item()
