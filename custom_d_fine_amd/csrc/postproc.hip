@@ -165,3 +165,87 @@ int dfine_postprocess(const void *logits, const float *boxes, int64_t *labels, i
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// (f1) Inference pre-processing on the device: uint8 HWC BGR image(s) -> [resize | letterbox] -> RGB CHW float / 255.
+// Reference: Torch_model._preprocess / _prepare_inputs (src/infer/torch_model.py:240-298) and letterbox (:378-418):
+// cv2.resize(INTER_LINEAR) [+ cv2.copyMakeBorder(114)] on the host, channel flip + transpose in numpy, H2D of the uint8
+// tensor, .float().div_(255) on the device.  Here the host only uploads the raw frame; one kernel does the rest.
+// The bilinear resize restates OpenCV's 8-bit path (imgproc/resize.cpp, not in /root/reference - a pip dependency): pixel
+// centres aligned (src = (dst + 0.5) * scale - 0.5), coefficients rounded to 11 fixed-point bits, horizontal pass in
+// int32, vertical pass (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2, so that the uint8 image the
+// network sees is the one cv2 would have produced.
+namespace dfine {
+
+__device__ __forceinline__ void resize_coef(int d, double scale, int ssize, int *s0, int *a0, int *a1) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    *s0 = s;
+    *a0 = (int)lrintf((1.f - f) * 2048.f);      // saturate_cast<short>: round to nearest (even), values within [0, 2048]
+    *a1 = (int)lrintf(f * 2048.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restrict__ src, T *__restrict__ dst, int B, int Hs, int Ws,
+                                                         int Ho, int Wo, int rh, int rw, int top, int left, float pad_value) {
+    const int64_t total = (int64_t)B * Ho * Wo;
+    const double sx = (double)Ws / rw, sy = (double)Hs / rh;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho), b = (int)(i / ((int64_t)Wo * Ho));
+        float out[3] = {pad_value, pad_value, pad_value};
+        const int rx = x - left, ry = y - top;
+        if (rx >= 0 && rx < rw && ry >= 0 && ry < rh) {
+            const uint8_t *img = src + (int64_t)b * Hs * Ws * 3;
+            if (rw == Ws && rh == Hs) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) out[c] = (float)img[((int64_t)ry * Ws + rx) * 3 + c];
+            } else {
+                int x0, ax0, ax1, y0, ay0, ay1;
+                resize_coef(rx, sx, Ws, &x0, &ax0, &ax1);
+                resize_coef(ry, sy, Hs, &y0, &ay0, &ay1);
+                const int x1 = min(x0 + 1, Ws - 1), y1 = min(y0 + 1, Hs - 1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int r0 = img[((int64_t)y0 * Ws + x0) * 3 + c] * ax0 + img[((int64_t)y0 * Ws + x1) * 3 + c] * ax1;
+                    const int r1 = img[((int64_t)y1 * Ws + x0) * 3 + c] * ax0 + img[((int64_t)y1 * Ws + x1) * 3 + c] * ax1;
+                    out[c] = (float)((((ay0 * (r0 >> 4)) >> 16) + ((ay1 * (r1 >> 4)) >> 16) + 2) >> 2);
+                }
+            }
+        }
+        const int64_t plane = (int64_t)Ho * Wo, o = (int64_t)b * 3 * plane + (int64_t)y * Wo + x;
+        store_f(dst + o, out[2] / 255.0f);              // BGR -> RGB
+        store_f(dst + o + plane, out[1] / 255.0f);
+        store_f(dst + o + 2 * plane, out[0] / 255.0f);
+    }
+}
+
+}  // namespace dfine
+
+extern "C" {
+
+// src uint8 [B, Hs, Ws, 3] (BGR, device) -> dst [B, 3, Ho, Wo] dtype (RGB / 255): the source is resized to (rh, rw) and placed at
+// (top, left) of the output, the rest is filled with pad_value / 255 (letterbox: 114).  Plain resize: rh = Ho, rw = Wo, top = left = 0.
+int dfine_preprocess_u8(const uint8_t *src, void *dst, int dtype, int B, int Hs, int Ws, int Ho, int Wo, int rh, int rw, int top,
+                        int left, int pad_value, void *stream) {
+    if (B == 0) return DFINE_OK;
+    if (!src || !dst || Hs < 1 || Ws < 1 || Ho < 1 || Wo < 1 || rh < 1 || rw < 1 || top < 0 || left < 0 || top + rh > Ho ||
+        left + rw > Wo)
+        return DFINE_E_BADARG;
+    const int64_t total = (int64_t)B * Ho * Wo;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DFINE_F32)
+        hipLaunchKernelGGL(dfine::preprocess_kernel<float>, dim3(blocks), dim3(256), 0, st, src, (float *)dst, B, Hs, Ws, Ho, Wo, rh, rw,
+                           top, left, (float)pad_value);
+    else if (dtype == DFINE_BF16)
+        hipLaunchKernelGGL(dfine::preprocess_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, src, (uint16_t *)dst, B, Hs, Ws, Ho, Wo,
+                           rh, rw, top, left, (float)pad_value);
+    else return DFINE_E_BADARG;
+    return dfine::check_launch();
+}
+
+}  // extern "C"

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "dfine_attn_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "dfine_attn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                                _F, _P]),
+    "dfine_preprocess_u8": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_postprocess": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_linear_wgrad_ws_floats": (_L, [_I, _I, _I]),
     "dfine_linear_wgrad_bf16": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -627,6 +628,15 @@ def topk_anchors(logits, k, with_scores=False):
     _check(_lib.dfine_topk_anchors(_ptr(logits), logits.stride(0), logits.stride(1), _ptr(idx), _ptr(sc),
                                    _dtype_code(logits), B, Q, C, k, _stream()), "dfine_topk_anchors")
     return (idx, sc) if with_scores else idx
+
+
+def preprocess_u8(frames, out_hw, resized_hw, top_left=(0, 0), pad_value=114, dtype=torch.float32):
+    """frames uint8 [B, Hs, Ws, 3] BGR (device) -> [B, 3, Ho, Wo] `dtype`, RGB / 255 (resize to `resized_hw`, placed at `top_left`)."""
+    B, Hs, Ws, _ = frames.shape
+    out = torch.empty(B, 3, out_hw[0], out_hw[1], device=frames.device, dtype=dtype)
+    _check(_lib.dfine_preprocess_u8(_ptr(frames), _ptr(out), _DTYPE[dtype], B, Hs, Ws, out_hw[0], out_hw[1], resized_hw[0],
+                                    resized_hw[1], top_left[0], top_left[1], int(pad_value), _stream()), "dfine_preprocess_u8")
+    return out
 
 
 def postprocess(logits, boxes, k, height, width, to_round=True):

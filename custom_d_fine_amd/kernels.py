@@ -1105,6 +1105,14 @@ def detection_topk(logits: torch.Tensor, boxes: torch.Tensor, k: int, height: in
     return _hip().postprocess(logits, boxes, k, height, width, to_round)
 
 
+def preprocess_frames(frames: torch.Tensor, out_hw, resized_hw, top_left=(0, 0), pad_value: int = 114, dtype=torch.float32):
+    """(f1) uint8 BGR frames [B, H, W, 3] -> network input [B, 3, Ho, Wo] (RGB / 255): bilinear resize to `resized_hw` with
+    OpenCV's 8-bit arithmetic, placed at `top_left`, padded with `pad_value` (ref torch_model.py:240-298,378-418).  One HIP kernel."""
+    if not frames.is_cuda:
+        return _backend_for_cpu("preprocess_frames")(frames, out_hw, resized_hw, top_left, pad_value, dtype)
+    return _hip().preprocess_u8(frames, out_hw, resized_hw, top_left, pad_value, dtype)
+
+
 def topk_indices(score: torch.Tensor, k: int) -> torch.Tensor:
     """Indices of the k largest entries per row, descending.  [ATen plumbing]"""
     return torch.topk(score, k, dim=-1).indices

@@ -332,6 +332,16 @@ int dfine_postprocess(const void *logits, const float *boxes, int64_t *labels, i
                       int width, int to_round, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * (f1) Inference pre-processing: uint8 [B, Hs, Ws, 3] BGR frames (device) -> [B, 3, Ho, Wo] dtype, RGB / 255.
+ * The source is bilinearly resized to (rh, rw) with OpenCV's 8-bit INTER_LINEAR arithmetic, placed at
+ * (top, left) and surrounded by pad_value (letterbox: 114); plain resize: rh = Ho, rw = Wo, top = left = 0.
+ * Replaces Torch_model._preprocess / _prepare_inputs + letterbox (src/infer/torch_model.py:240-298,378-418:
+ * cv2.resize + copyMakeBorder on the host, flip / transpose in numpy, .float().div_(255) on the device).
+ */
+int dfine_preprocess_u8(const uint8_t *src, void *dst, int dtype, int B, int Hs, int Ws, int Ho, int Wo, int rh,
+                        int rw, int top, int left, int pad_value, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * A5/A6  Weight gradient of a token-stream nn.Linear: dw [N, K] f32 = dy [M, N]^T x [M, K] (bf16,
  * row-major; M = B*Lq rows), split over the M reduction (the autograd formula of F.linear used by
  * MLP / FFN / Gate / attention projections, src/d_fine/arch/dfine_decoder.py:33-46,214-271).

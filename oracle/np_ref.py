@@ -237,3 +237,33 @@ def distance2bbox(points, distance, reg_scale):
     x2 = p[..., 0] + (np.float32(0.5) * rs + d[..., 2]) * (p[..., 2] / rs)
     y2 = p[..., 1] + (np.float32(0.5) * rs + d[..., 3]) * (p[..., 3] / rs)
     return np.stack([(x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1], -1)
+
+
+def resize_linear_u8(img, out_h, out_w):
+    """OpenCV's 8-bit bilinear resize restated (cv2.resize(..., INTER_LINEAR) on uint8, imgproc/resize.cpp of opencv-python -
+    a pip dependency of the reference, requirements.txt, not vendored in /root/reference and absent here: PARITY UNPINNED
+    against cv2 itself; call site: src/infer/torch_model.py:246-248,406).  img uint8 [H, W, C] -> uint8 [out_h, out_w, C].
+    Pixel centres aligned, 11-bit fixed-point coefficients, horizontal pass in int32, vertical pass
+    (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2."""
+    h, w = img.shape[:2]
+
+    def coef(n_out, n_in):
+        d = np.arange(n_out, dtype=np.float64)
+        f = ((d + 0.5) * (n_in / n_out) - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = f - s.astype(np.float32)
+        lo = s < 0
+        f[lo], s[lo] = 0.0, 0
+        hi = s >= n_in - 1
+        f[hi], s[hi] = 0.0, n_in - 1
+        a0 = np.rint((np.float32(1.0) - f) * np.float32(2048.0)).astype(np.int64)
+        a1 = np.rint(f * np.float32(2048.0)).astype(np.int64)
+        return s, np.minimum(s + 1, n_in - 1), a0, a1
+
+    x0, x1, ax0, ax1 = coef(out_w, w)
+    y0, y1, ay0, ay1 = coef(out_h, h)
+    src = img.astype(np.int64)
+    rows = src[:, x0] * ax0[None, :, None] + src[:, x1] * ax1[None, :, None]            # [H, out_w, C]
+    r0, r1 = rows[y0], rows[y1]
+    out = (((ay0[:, None, None] * (r0 >> 4)) >> 16) + ((ay1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)

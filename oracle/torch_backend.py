@@ -99,6 +99,18 @@ def detection_topk(logits, boxes, k, height, width, to_round=True):
     return labels, qidx, abs_boxes.gather(1, qidx.unsqueeze(-1).expand(-1, -1, 4)), scores
 
 
+def preprocess_frames(frames, out_hw, resized_hw, top_left=(0, 0), pad_value=114, dtype=torch.float32):
+    """Torch_model._preprocess restated on the host (reference src/infer/torch_model.py:240-298,378-418): resize with
+    np_ref.resize_linear_u8, constant border, BGR->RGB, HWC->CHW, /255."""
+    f = frames.cpu().numpy()
+    out = np.full((f.shape[0], out_hw[0], out_hw[1], 3), pad_value, dtype=np.uint8)
+    for i in range(f.shape[0]):
+        r = f[i] if tuple(resized_hw) == f[i].shape[:2] else np_ref.resize_linear_u8(f[i], resized_hw[0], resized_hw[1])
+        out[i, top_left[0]: top_left[0] + resized_hw[0], top_left[1]: top_left[1] + resized_hw[1]] = r
+    t = torch.from_numpy(out[..., ::-1].transpose(0, 3, 1, 2).copy())
+    return (t.float() / 255.0).to(dtype)
+
+
 def install():
     """Route CPU tensors of the HIP-backed operators to this module (tests / cpu baseline)."""
     import sys

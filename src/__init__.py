@@ -13,12 +13,14 @@ _ALIASES = {
     "src.d_fine": "custom_d_fine_amd.d_fine",
     "src.d_fine.arch": "custom_d_fine_amd.d_fine.arch",
     "src.dl": "custom_d_fine_amd.dl",
+    "src.infer": "custom_d_fine_amd.infer",
+    "src.infer.torch_model": "custom_d_fine_amd.infer.torch_model",
 }
 for _name in ("dfine", "configs", "matcher", "dfine_criterion", "dist_utils", "utils"):
     _ALIASES[f"src.d_fine.{_name}"] = f"custom_d_fine_amd.d_fine.{_name}"
 for _name in ("hgnetv2", "common", "hybrid_encoder", "dfine_decoder", "utils"):
     _ALIASES[f"src.d_fine.arch.{_name}"] = f"custom_d_fine_amd.d_fine.arch.{_name}"
-for _name in ("train", "export", "engine", "synthetic", "fused_optim"):
+for _name in ("train", "export", "engine", "synthetic", "fused_optim", "postprocess"):
     _ALIASES[f"src.dl.{_name}"] = f"custom_d_fine_amd.dl.{_name}"
 
 
@@ -42,7 +44,7 @@ class _AliasFinder:
                 pass
 
         return ModuleSpec(name, _Loader(), is_package=real.count(".") < 3 and not real.split(".")[-1] in
-                          ("dfine", "configs", "matcher", "dfine_criterion", "dist_utils", "utils", "train", "export"))
+                          ("dfine", "configs", "matcher", "dfine_criterion", "dist_utils", "utils", "train", "export", "torch_model"))
 
 
 sys.meta_path.insert(0, _AliasFinder())
