@@ -259,8 +259,12 @@ def test_bf16_blocks_vs_fp32_blocks_m320(cuda):
     for name in ("input_proj", "lateral_convs", "fpn_blocks", "downsample_convs", "pan_blocks"):
         blocks += [(f"encoder.{name}.{i}", b) for i, b in enumerate(getattr(enc, name))]
     captured = {}
-    hooks = [b.register_forward_hook(lambda mod, inp, out, n=n: captured.__setitem__(n, (inp[0].detach(), out.detach())))
-             for n, b in blocks]
+    def grab(n):
+        def hook(mod, inp, out):
+            x0 = inp[0]         # FPN / PAN blocks take the fusion inputs as a list (concatenation read in place)
+            captured[n] = ([t.detach() for t in x0] if isinstance(x0, (list, tuple)) else x0.detach(), out.detach())
+        return hook
+    hooks = [b.register_forward_hook(grab(n)) for n, b in blocks]
     x = helpers.make_images(2, 320).to(cuda)
     with torch.no_grad():
         m.encoder(m.backbone(x))
@@ -273,13 +277,17 @@ def test_bf16_blocks_vs_fp32_blocks_m320(cuda):
         xin, _ = captured[n]
         res = []
         for amp in (False, True):
-            xi = xin.clone().requires_grad_(True)
+            if isinstance(xin, list):
+                xi = [t.clone().requires_grad_(True) for t in xin]
+            else:
+                xi = xin.clone().requires_grad_(True)
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
                 y = b(xi)
             go = helpers.make_cotangent(y.shape, 77).to(cuda)
             b.zero_grad()
             (y.float() * go).sum().backward()
-            res.append((y.detach(), xi.grad.detach(), {k: p.grad.detach().clone() for k, p in b.named_parameters() if p.grad is not None}))
+            gx = torch.cat([t.grad.float().flatten() for t in xi]) if isinstance(xi, list) else xi.grad.detach()
+            res.append((y.detach(), gx, {k: p.grad.detach().clone() for k, p in b.named_parameters() if p.grad is not None}))
         (y0, gx0, gp0), (y1, gx1, gp1) = res
         cy, cx = cos(y0, y1), cos(gx0, gx1)
         cp = min((cos(gp0[k], gp1[k]) for k in gp0 if gp0[k].numel() > 16 and gp0[k].abs().max() > 0), default=1.0)
