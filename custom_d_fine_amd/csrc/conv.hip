@@ -379,7 +379,7 @@ struct ChanSegs {
     int n;
 };
 
-// address of channel c, pixel offset `off` of image b
+// address of channel c of image b (per-lane search: epilogues)
 __device__ __forceinline__ const uint16_t *seg_addr(const ChanSegs &sg, int b, int c, int HW) {
     const uint16_t *sp = sg.p[0];
     int s0 = 0, sc = sg.bs[0];
@@ -387,6 +387,39 @@ __device__ __forceinline__ const uint16_t *seg_addr(const ChanSegs &sg, int b, i
     for (int k = 1; k < 8; ++k)
         if (k < sg.n && c >= sg.start[k]) { sp = sg.p[k]; s0 = sg.start[k]; sc = sg.bs[k]; }
     return sp + ((int64_t)b * sc + (c - s0)) * HW;
+}
+
+// Part table held in registers: the kernel-argument copy would be re-read with scalar loads inside the stage loop, and those
+// share lgkmcnt with the LDS reads.
+struct SegRegs {
+    const uint16_t *p[8];
+    int start[8], bs[8], n;
+    __device__ __forceinline__ void load(const ChanSegs &sg) {
+        n = sg.n;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { p[k] = sg.p[k < sg.n ? k : 0]; start[k] = k < sg.n ? sg.start[k] : 0x7fffffff; bs[k] = sg.bs[k < sg.n ? k : 0]; }
+    }
+    // first channel `cu` (wave-uniform) of a run of rows inside one part -> address of row `row_in_run`
+    __device__ __forceinline__ const uint16_t *addr(int b, int cu, int row_in_run, int HW) const {
+        const uint16_t *sp = p[0];
+        int s0 = 0, sc = bs[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            if (cu >= start[k]) { sp = p[k]; s0 = start[k]; sc = bs[k]; }
+        return sp + ((int64_t)b * sc + (cu - s0) + row_in_run) * HW;
+    }
+};
+
+// the same for a WAVE-UNIFORM first channel `cu` of a run of rows that lies inside one part (part sizes are multiples of the
+// run length): the search runs on the scalar unit, the lanes only add their row offset - this sits in the LDS-DMA issue path
+// of every stage, where a per-lane search over 64-bit pointers cost 35 % of the kernel.
+__device__ __forceinline__ const uint16_t *seg_addr_uniform(const ChanSegs &sg, int b, int cu, int row_in_run, int HW) {
+    const uint16_t *sp = sg.p[0];
+    int s0 = 0, sc = sg.bs[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        if (k < sg.n && cu >= sg.start[k]) { sp = sg.p[k]; s0 = sg.start[k]; sc = sg.bs[k]; }
+    return sp + ((int64_t)b * sc + (cu - s0)) * HW + (int64_t)row_in_run * HW;
 }
 
 // One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [lds_addr + 16 * lane].  Inline asm on purpose:
@@ -401,31 +434,35 @@ __device__ __forceinline__ void glds16(const uint16_t *gsrc, unsigned lds_addr) 
                  : "memory");
 }
 
-template <int NTN, int kG2Ring>        // kG2Ring LDS stages: 3 (two in flight) for deep layers, 2 for <= 128 input channels (2 workgroups per CU)
+template <int NTN, int kG2Ring, int PXW, bool SEG>   // kG2Ring LDS stages (3: two in flight; 2 for <= 128 input channels); PXW 16-pixel
+                                                     // tiles per wave (4 / 8); SEG: input / output given as several parts
 __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs xs_, const uint16_t *__restrict__ w2,
                                                                   const ChanSegs ys_, int Cin, int Cout, int NP, int KP,
                                                                   int HW, int ptiles, int total_tiles, int nblk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int XB = kG2Rows * 256, WB = 64 * NTN * 128, SB = XB + WB;     // bytes per stage
+    constexpr int TP = 32 * PXW;                                             // pixels per workgroup (128 or 256)
+    constexpr int XPITCH = TP * 2;                                           // bytes per channel row
+    constexpr int XB = kG2Rows * XPITCH, WB = 64 * NTN * 128, SB = XB + WB;  // bytes per stage
+    constexpr int LPR = TP / 8, RPP = 64 / LPR, XPW = (kG2Rows / RPP) / 8;   // lanes per row, rows per piece, X pieces per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int nb = slot % nblk, tile_id = (slot / nblk) * 8 + xcd;
     if (tile_id >= total_tiles) return;
     const int b = tile_id / ptiles, pt = tile_id - b * ptiles;
-    const int p0 = pt * kTrPix;
-    const int npix = min(kTrPix, HW - p0);
+    const int p0 = pt * TP;
+    const int npix = min(TP, HW - p0);
     const int n0 = nb * 64 * NTN;
     const int wn = wave >> 1, wp = wave & 1;
     const int g = lane >> 4, i16 = lane & 15;
     const int nstage = (KP + kG2Rows - 1) / kG2Rows;
 
     // ---- per-lane source coordinates of this wave's LDS-DMA pieces (constant over the stages) ----
-    // X: 16 pieces of 4 rows; wave -> pieces 2 wave, 2 wave + 1.  W: 8 NTN pieces of 8 rows; wave -> NTN pieces.
-    int x_row[2], x_px[2], w_row[NTN], w_k[NTN];
+    // X: 64 / RPP pieces of RPP rows, XPW per wave.  W: 8 NTN pieces of 8 rows; wave -> NTN pieces.
+    int x_row[XPW], x_px[XPW], w_row[NTN], w_k[NTN];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = (wave * 2 + j) * 4 + (lane >> 4), pc = lane & 15;
+    for (int j = 0; j < XPW; ++j) {
+        const int row = (wave * XPW + j) * RPP + lane / LPR, pc = lane % LPR;
         const int px = (((pc >> 1) ^ (row & 7)) << 4) + ((pc & 1) << 3);
         x_row[j] = row;
         x_px[j] = px < npix ? px : 0;                  // columns past the plane: any valid data, never stored
@@ -437,13 +474,29 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
         w_k[j] = ((pc ^ (row & 7)) << 3);
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    // whole-tensor case: plain pointer arithmetic - the part table lives in the kernel-argument segment, and scalar loads from
+    // it inside the stage loop share lgkmcnt with the LDS reads (every wait for one drains the other)
+    const uint16_t *xflat = xs_.p[0] + (int64_t)b * xs_.bs[0] * HW + p0;
+    // several parts: a per-workgroup table in LDS, one 8-byte base address per group of 8 input channels (part sizes are
+    // multiples of 8), built once; the issue path then costs one ds_read_b64 per piece.  (Searching the part list there - per
+    // lane or on the scalar unit, from kernel arguments or registers - cost 2x of the whole kernel.)
+    const uint16_t **xtab = reinterpret_cast<const uint16_t **>(lds + kG2Ring * SB);
+    if (SEG) {
+        for (int gch = tid; gch * 8 < Cin; gch += kG2Threads) xtab[gch] = seg_addr(xs_, b, gch * 8, HW) + p0;
+        __syncthreads();
+    }
     auto issue = [&](int s) {
         const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (s % kG2Ring) * SB);
         const int c0 = s * kG2Rows;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ch = min(c0 + x_row[j], Cin - 1);  // channels past Cin meet zero weights (or a skipped slab)
-            glds16(seg_addr(xs_, b, ch, HW) + p0 + x_px[j], __builtin_amdgcn_readfirstlane(base + (wave * 2 + j) * 1024));
+        for (int j = 0; j < XPW; ++j) {
+            if (!SEG) {
+                const int ch = min(c0 + x_row[j], Cin - 1);
+                glds16(xflat + (int64_t)ch * HW + x_px[j], __builtin_amdgcn_readfirstlane(base + (wave * XPW + j) * 1024));
+                continue;
+            }
+            const int ch = min(c0 + x_row[j], Cin - 1);  // channels past Cin: any valid row - they meet zero weights or a skipped slab
+            glds16(xtab[ch >> 3] + (int64_t)(ch & 7) * HW + x_px[j], __builtin_amdgcn_readfirstlane(base + (wave * XPW + j) * 1024));
         }
 #pragma unroll
         for (int j = 0; j < NTN; ++j) {
@@ -452,16 +505,16 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
         }
     };
 
-    f32x4v acc[NTN][4];
+    f32x4v acc[NTN][PXW];
 #pragma unroll
     for (int t = 0; t < NTN; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < PXW; ++j) acc[t][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     issue(0);
     if (nstage > 1) issue(1);
     for (int s = 0; s < nstage; ++s) {
-        if (s + 1 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NTN) : "memory");
+        if (s + 1 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XPW + NTN) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (kG2Ring >= 3 && s + 2 < nstage) issue(s + 2);      // ring of 2: launched for <= 2 stages only, both issued above
@@ -476,12 +529,12 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
                 a[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(ws + row * 128 + (((slab * 4 + g) ^ (row & 7)) << 4)));
             }
             const int r = slab * 32 + 4 * g + (i16 >> 2);
-            const unsigned char *xr = xs + r * 256 + ((i16 & 3) << 3);
+            const unsigned char *xr = xs + r * XPITCH + ((i16 & 3) << 3);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int seg = ((wp * 4 + j) ^ (r & 7)) << 5;
+            for (int j = 0; j < PXW; ++j) {
+                const int seg = ((wp * PXW + j) ^ (r & 7)) << 5;
                 const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_v4s __attribute__((address_space(3))) *)(xr + seg));
-                const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_v4s __attribute__((address_space(3))) *)(xr + seg + 16 * 256));
+                const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_v4s __attribute__((address_space(3))) *)(xr + seg + 16 * XPITCH));
                 typedef short tr_v8s __attribute__((ext_vector_type(8)));
                 const bf16x8 bf = __builtin_bit_cast(bf16x8, (tr_v8s)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
@@ -492,21 +545,25 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
     }
     // ---- epilogue: [n][px] bf16 tile of this wave through LDS, then whole 128-byte pixel rows with 16-byte stores ----
     __builtin_amdgcn_s_barrier();                        // every wave is done reading the ring
-    uint16_t *ot = reinterpret_cast<uint16_t *>(lds) + wave * (16 * NTN * 72);          // [16 NTN rows][64 px], pitch 72
+    constexpr int OP = 16 * PXW + 8;                     // output tile pitch (elements)
+    uint16_t *ot = reinterpret_cast<uint16_t *>(lds) + wave * (16 * NTN * OP);          // [16 NTN rows][16 PXW px]
 #pragma unroll
     for (int t = 0; t < NTN; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < PXW; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ot[(t * 16 + 4 * g + r) * 72 + j * 16 + i16] = f32_to_bf16(acc[t][j][r]);
+            for (int r = 0; r < 4; ++r) ot[(t * 16 + 4 * g + r) * OP + j * 16 + i16] = f32_to_bf16(acc[t][j][r]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr int LPO = 2 * PXW, RPI = 64 / LPO;         // lanes per output row, rows per iteration
 #pragma unroll
-    for (int it = 0; it < 2 * NTN; ++it) {
-        const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+    for (int it = 0; it < 16 * NTN / RPI; ++it) {
+        const int row = it * RPI + lane / LPO, c8 = (lane % LPO) * 8;
         const int n = n0 + wn * 16 * NTN + row;
-        if (n < Cout && wp * 64 + c8 < npix)
-            *reinterpret_cast<uint4 *>(const_cast<uint16_t *>(seg_addr(ys_, b, n, HW)) + p0 + wp * 64 + c8) =
-                *reinterpret_cast<const uint4 *>(ot + row * 72 + c8);
+        if (n < Cout && wp * 16 * PXW + c8 < npix) {
+            uint16_t *yp = SEG ? const_cast<uint16_t *>(seg_addr(ys_, b, n, HW))
+                               : const_cast<uint16_t *>(ys_.p[0]) + ((int64_t)b * ys_.bs[0] + n) * HW;
+            *reinterpret_cast<uint4 *>(yp + p0 + wp * 16 * PXW + c8) = *reinterpret_cast<const uint4 *>(ot + row * OP + c8);
+        }
     }
 }
 
@@ -520,27 +577,41 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
                           hipStream_t st, const ChanSegs *xsegs = nullptr, const ChanSegs *ysegs = nullptr) {
     const int ptiles = (HW + kTrPix - 1) / kTrPix;
     static const int v2_env = [] { const char *e = getenv("DFINE_CONV1X1_GLDS"); return e ? atoi(e) : 1; }();
-    if (v2_env && HW % 8 == 0 && KP >= 8 && Cin >= 1) {
-        // 128-channel tiles when the layer has them and they still fill the chip, 64-channel tiles otherwise
-        const bool wide2 = (NP % 128 == 0) && ((int64_t)B * ptiles * (NP / 128) >= 256);
-        const int nblk2 = wide2 ? NP / 128 : (NP + 63) / 64;
-        const int total2 = B * ptiles;
-        dim3 grid2(8 * ((total2 + 7) / 8) * nblk2);
+    static const int px256_env = [] { const char *e = getenv("DFINE_CONV1X1_PX256"); return e ? atoi(e) : 1; }();
+    if (v2_env && HW % 8 == 0 && KP >= 8 && Cin >= 4 && Cin % 4 == 0) {
+        // The kernel is bound by the ~10 B/clk/CU load path, so the tile is as large as the layer can fill the chip with:
+        // 256 pixels x 128 channels (87 FLOP per loaded byte) for deep layers on big maps, 128 x 128 (64) / 128 x 64 otherwise.
         const bool ring2 = KP <= 2 * kG2Rows;                  // <= 2 stages: both fit a 2-slot ring, half the LDS, 2 workgroups per CU
-        const size_t lds2 = (size_t)(ring2 ? 2 : 3) * (kG2Rows * 256 + 64 * (wide2 ? 2 : 1) * 128);
+        const bool n128 = NP % 128 == 0;
+        const int pt256 = (HW + 255) / 256;
+        const bool px256 = px256_env && n128 && !ring2 && (HW % 256 == 0 || HW >= 1536) && (int64_t)B * pt256 * (NP / 128) >= 256;
+        const int tp = px256 ? 256 : kTrPix;
+        const int ptiles2 = (HW + tp - 1) / tp;
+        const bool wide2 = px256 || (n128 && ((int64_t)B * ptiles2 * (NP / 128) >= 256));
+        const int nblk2 = wide2 ? NP / 128 : (NP + 63) / 64;
+        const int total2 = B * ptiles2;
+        dim3 grid2(8 * ((total2 + 7) / 8) * nblk2);
+        const ChanSegs xs_ = xsegs ? *xsegs : one_seg(x, Cin), ys_ = ysegs ? *ysegs : one_seg(y, Cout);
+        const bool seg = xs_.n > 1 || ys_.n > 1;
+        if (seg && Cin > 4096) return DFINE_E_BADARG;
+        const size_t lds2 = (size_t)(ring2 ? 2 : 3) * (kG2Rows * tp * 2 + 64 * (wide2 ? 2 : 1) * 128) + (seg ? 4096 : 0);
         static bool attr2 = false;
         if (!attr2) {
             hipError_t e = hipSuccess, r;
-#define DFINE_G2_ATTR(N, R) if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<N, R>), hipFuncAttributeMaxDynamicSharedMemorySize, R * (16384 + 8192 * N))) != hipSuccess) e = r;
-            DFINE_G2_ATTR(1, 2) DFINE_G2_ATTR(1, 3) DFINE_G2_ATTR(2, 2) DFINE_G2_ATTR(2, 3)
+#define DFINE_G2_ATTR(N, R, P)                                                                                                                  \
+    if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<N, R, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize, R * (64 * 64 * P + 8192 * N))) != hipSuccess) e = r; \
+    if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<N, R, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize, R * (64 * 64 * P + 8192 * N) + 4096)) != hipSuccess) e = r;
+            DFINE_G2_ATTR(1, 2, 4) DFINE_G2_ATTR(1, 3, 4) DFINE_G2_ATTR(2, 2, 4) DFINE_G2_ATTR(2, 3, 4) DFINE_G2_ATTR(2, 3, 8)
 #undef DFINE_G2_ATTR
             if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
             attr2 = true;
         }
-        const ChanSegs xs_ = xsegs ? *xsegs : one_seg(x, Cin), ys_ = ysegs ? *ysegs : one_seg(y, Cout);
-#define DFINE_G2(N, R) hipLaunchKernelGGL((conv1x1_glds_kernel<N, R>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles, total2, nblk2)
-        if (wide2) { if (ring2) DFINE_G2(2, 2); else DFINE_G2(2, 3); }
-        else { if (ring2) DFINE_G2(1, 2); else DFINE_G2(1, 3); }
+#define DFINE_G2(N, R, P)                                                                                                                        \
+    { if (seg) hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, true>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2); \
+      else hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, false>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2); }
+        if (px256) DFINE_G2(2, 3, 8)
+        else if (wide2) { if (ring2) DFINE_G2(2, 2, 4) else DFINE_G2(2, 3, 4) }
+        else { if (ring2) DFINE_G2(1, 2, 4) else DFINE_G2(1, 3, 4) }
 #undef DFINE_G2
         return check_launch();
     }
@@ -753,6 +824,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
 __device__ uint4 g_zero_page = {0u, 0u, 0u, 0u};
 constexpr int kW2Threads = 256, kW2Ring = 3, kW2Px = 64;
 
+template <bool SEG>
 __global__ __launch_bounds__(kW2Threads) void conv_wgrad1_glds_kernel(const ChanSegs xs_, const uint16_t *__restrict__ dy,
                                                                       float *__restrict__ part, int Cin, int Cout, int HW,
                                                                       int chunks_per_image, int total_chunks, int chunks_per_split,
@@ -776,6 +848,23 @@ __global__ __launch_bounds__(kW2Threads) void conv_wgrad1_glds_kernel(const Chan
     const int nstage = q1 - q0;
     const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero_page);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    const uint16_t *xflat = xs_.p[0];
+    const uint16_t **xtab = reinterpret_cast<const uint16_t **>(lds + kW2Ring * SB);      // SEG: image-0 base per 8-channel group of this c tile
+    if (SEG) {
+        if (tid < 16) xtab[tid] = c0 + tid * 8 < Cin ? seg_addr(xs_, 0, c0 + tid * 8, HW) : nullptr;
+        __syncthreads();
+    }
+    // batch stride (in channels) of the part a channel group lives in: second table
+    int *xbs = reinterpret_cast<int *>(lds + kW2Ring * SB + 128);
+    if (SEG) {
+        if (tid < 16) {
+            int sc = xs_.bs[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) if (k < xs_.n && c0 + tid * 8 >= xs_.start[k]) sc = xs_.bs[k];
+            xbs[tid] = sc;
+        }
+        __syncthreads();
+    }
 
     // this wave's 4 + 4 LDS-DMA pieces per stage: piece = 8 rows x 128 B; lane -> (row, physical chunk)
     int row_a[4], kc[4];
@@ -795,7 +884,14 @@ __global__ __launch_bounds__(kW2Threads) void conv_wgrad1_glds_kernel(const Chan
             const bool pin = p0 + kc[j] < HW;
             const int n = n0 + row_a[j], c = c0 + row_a[j];
             glds16((pin && n < Cout) ? dyb + (int64_t)n * HW + kc[j] : zero, __builtin_amdgcn_readfirstlane(base + (wave * 4 + j) * 1024));
-            glds16((pin && c < Cin) ? seg_addr(xs_, b, c, HW) + p0 + kc[j] : zero, __builtin_amdgcn_readfirstlane(base + OPB + (wave * 4 + j) * 1024));
+            const uint16_t *xp;
+            if (SEG) {
+                const int gr = min(row_a[j] >> 3, 15);
+                xp = xtab[gr] + ((int64_t)b * xbs[gr] + (row_a[j] & 7)) * HW;
+            } else {
+                xp = xflat + ((int64_t)b * Cin + c) * HW;
+            }
+            glds16((pin && c < Cin) ? xp + p0 + kc[j] : zero, __builtin_amdgcn_readfirstlane(base + OPB + (wave * 4 + j) * 1024));
         }
     };
     f32x4v acc[2][8];
@@ -1088,13 +1184,19 @@ static int launch_wgrad1(const ChanSegs &xs_, const void *dy, float *dw, float *
     const int np16 = (Cout + 15) / 16 * 16, cp16 = (Cin + 15) / 16 * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad1_glds_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad1_glds_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kW2Ring * 2 * 128 * 128);
-        if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad1_glds_kernel<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, kW2Ring * 2 * 128 * 128 + 256);
+        if (e != hipSuccess || e2 != hipSuccess) { set_last_error(e != hipSuccess ? e : e2); return DFINE_E_LAUNCH; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv_wgrad1_glds_kernel, dim3(splits * npairs), dim3(kW2Threads), (size_t)kW2Ring * 2 * 128 * 128, st, xs_,
-                       (const uint16_t *)dy, ws, Cin, Cout, HW, cpi, B * cpi, cps, nct, np16, cp16, npairs, splits);
+    if (xs_.n > 1 || xs_.bs[0] != Cin)
+        hipLaunchKernelGGL(conv_wgrad1_glds_kernel<true>, dim3(splits * npairs), dim3(kW2Threads), (size_t)kW2Ring * 2 * 128 * 128 + 256, st, xs_,
+                           (const uint16_t *)dy, ws, Cin, Cout, HW, cpi, B * cpi, cps, nct, np16, cp16, npairs, splits);
+    else
+        hipLaunchKernelGGL(conv_wgrad1_glds_kernel<false>, dim3(splits * npairs), dim3(kW2Threads), (size_t)kW2Ring * 2 * 128 * 128, st, xs_,
+                           (const uint16_t *)dy, ws, Cin, Cout, HW, cpi, B * cpi, cps, nct, np16, cp16, npairs, splits);
     if (int e = check_launch()) return e;
     const int64_t total = (int64_t)Cout * Cin;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((int)((total + 63) / 64)), dim3(256), 0, st, ws, dw, splits, Cout, Cin, 1,

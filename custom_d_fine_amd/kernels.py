@@ -777,7 +777,7 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
         if (xs[0].is_cuda and not pad_br and _env("DFINE_HIP_UNITS", "1") == "1"
                 and _env("DFINE_SEG_CONV", "1") == "1" and a in (None, "relu", "silu", "swish")
                 and conv.kernel_size == (1, 1) and len(xs) <= 8 and (xs[0].shape[-1] * xs[0].shape[-2]) % 8 == 0
-                and all(t.shape[1] % 2 == 0 for t in xs) and _mfma_conv_ok(conv, xs[0])):
+                and all(t.shape[1] % 8 == 0 for t in xs) and _mfma_conv_ok(conv, xs[0])):
             y = _DenseConvSeg.apply(conv.weight, *[t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16) for t in xs])
             return _bn_tail(y, bn, a, act, lab)
         x = torch.cat(list(xs), dim=1) if len(xs) > 1 else xs[0]
