@@ -13,7 +13,8 @@ durations (HIP events around every step).  Extra objects:
   roofline          the dominant kernel FAMILY by device time: the dense-convolution implicit GEMMs of backbone + encoder
                     (forward, data gradient, weight gradient; MFMA roof).  achieved = algorithmic FLOPs of the timed
                     launches / their summed duration, both taken live with HIP events on the launch stream inside the
-                    timed region (every `--sample-every`-th step is instrumented, hip.py `_timed`).
+                    timed region (every `--sample-every`-th step - 2 of the default 50 - is instrumented, hip.py `_timed`: ~1 400 events
+                    cost such a step ~15 ms, so sampling keeps `value` within ~1 % of the un-instrumented rate).
   roofline_kernels  the same figures per kernel group (1x1 / 3x3 forward+dgrad, weight gradients, stem, token-stream
                     linear weight gradients) and the two deformable-attention kernels against the HBM roof
                     (algorithmic bytes of SURVEY.md 8(d); `traffic` = PMC HBM bytes from profiles/).
@@ -134,7 +135,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--mask", type=int, default=0, help="1: segmentation head (BASELINE configs[4])")
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-baseline steps (0 = skip)")
-    ap.add_argument("--sample-every", type=int, default=5, help="instrument every n-th timed step with HIP events (0 = none)")
+    ap.add_argument("--sample-every", type=int, default=25, help="instrument every n-th timed step with HIP events (0 = none)")
     ap.add_argument("--channels-last", type=int, default=0)
     args = ap.parse_args()
 
@@ -176,11 +177,14 @@ def main():
     hip.enable_timing(None)
     hip.timing_active(False)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    sampled_steps = set()
+    if args.sample_every > 0:
+        sampled_steps = {i for i in range(args.steps) if i % args.sample_every == args.sample_every - 1} or {args.steps - 1}
     fence()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
-        hip.timing_active(args.sample_every > 0 and i % args.sample_every == args.sample_every - 1)
+        hip.timing_active(i in sampled_steps)
         step(images, targets)
         marks[i + 1].record()
     hip.timing_active(False)
@@ -198,7 +202,7 @@ def main():
         max_t = max(len(t["labels"]) for t in targets)
         dn = 2 * max_t * max(100 // max_t, 1)
         lq = 300 + dn
-        sampled = sum(1 for i in range(args.steps) if args.sample_every > 0 and i % args.sample_every == args.sample_every - 1)
+        sampled = len(sampled_steps)
 
         def mfma_entry(keys, label):
             n = sum(timing[k][0] for k in keys if k in timing)
@@ -220,14 +224,14 @@ def main():
                     "algorithmic_bytes_per_launch": int(work / n), "launches_per_step": round(n / max(sampled, 1), 1),
                     "avg_launch_ms": round(mean_ms, 4), "ms_per_step": round(tot_ms / max(sampled, 1), 3)}
 
-        family = mfma_entry(MFMA_GROUPS, "dense-conv implicit GEMMs of backbone + encoder: conv1x1_tr / conv_igemm (fwd + dgrad), "
-                            "conv_wgrad<1|3>, stem_* (+ MIOpen launches where the plan still picks them)")
-        kernels_ = [mfma_entry(("conv1x1",), "conv1x1_tr_kernel fwd+dgrad"), mfma_entry(("conv3x3",), "conv_igemm_kernel<3> fwd+dgrad"),
-                    mfma_entry(("conv1x1_wgrad",), "conv_wgrad_kernel<1> + reduce"), mfma_entry(("conv3x3_wgrad",), "conv_wgrad_kernel<3> + reduce"),
+        family = mfma_entry(MFMA_GROUPS, "dense-conv implicit GEMMs of backbone + encoder: conv1x1_glds / conv_igemm<3> (fwd + dgrad), "
+                            "conv_wgrad1_glds / conv_wgrad<3> (+ reduce), stem_* (+ MIOpen: 3x3 weight gradient on 20x20 maps)")
+        kernels_ = [mfma_entry(("conv1x1",), "conv1x1_glds_kernel fwd+dgrad"), mfma_entry(("conv3x3",), "conv_igemm_kernel<3> fwd+dgrad"),
+                    mfma_entry(("conv1x1_wgrad",), "conv_wgrad1_glds_kernel + reduce"), mfma_entry(("conv3x3_wgrad",), "conv_wgrad_kernel<3> + reduce"),
                     mfma_entry(("stem_conv", "stem_wgrad"), "stem_conv / stem_dgrad_s2 / stem_wgrad"),
                     mfma_entry(("linear_wgrad",), "linear_wgrad_kernel (token-stream linears)"),
                     mfma_entry(("linear", "attention"), "linear_act / attention kernels (token streams)"),
-                    mfma_entry(("miopen_conv",), "MIOpen convolutions still dispatched by the per-shape plan"),
+                    mfma_entry(("miopen_conv",), "MIOpen convolutions (shapes the HIP weight-gradient kernel does not take)"),
                     hbm_entry("msda_fwd", "msda_fwd8_kernel (dfine_msda_fused_fwd)"),
                     hbm_entry("msda_bwd", "msda_bwd kernels incl. staging (dfine_msda_fused_bwd)")]
         line = {
