@@ -124,7 +124,20 @@ def _self_spawn(n):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+_GC_LOG = []
+
+
+def _gc_probe(phase, info, _t=[0.0]):
+    if phase == "start":
+        _t[0] = time.perf_counter()
+    elif info["generation"] >= 1:
+        _GC_LOG.append((info["generation"], round((time.perf_counter() - _t[0]) * 1e3, 1)))
+
+
 def main():
+    if os.environ.get("DFINE_BENCH_DUMP_STEPS") == "1":
+        import gc
+        gc.callbacks.append(_gc_probe)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -191,6 +204,9 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    if os.environ.get("DFINE_BENCH_DUMP_STEPS") == "1" and rank == 0:
+        print("gc collections (generation, ms):", _GC_LOG, file=sys.stderr)
+        print("per-step ms:", " ".join(f"{t:.1f}" for t in per_step), file=sys.stderr)
     timing = hip.timing_summary()
     hip.disable_timing()
     if world > 1:

@@ -1109,6 +1109,45 @@ __global__ __launch_bounds__(kConvThreads) void linear_wgrad_kernel(const uint16
     }
 }
 
+// Deferred split reduction of MANY weight gradients in one launch, accumulating into their final destination (the flat
+// gradient buffer of the fused optimizer): table rows of 8 x int64 = {partials ptr, dst ptr, splits, Cout, Cin, taps, NP16, CP16}
+// (a bias gradient is a row with Cin = taps = CP16 = 1); blockIdx.y = row, blockIdx.x strides over the row's outputs.
+// Replaces one conv_wgrad_reduce_kernel launch per layer (179 per D-FINE-m step) + the per-parameter gradient tensors.
+__global__ __launch_bounds__(256) void multi_wgrad_reduce_kernel(const int64_t *__restrict__ table) {
+    __shared__ float red[4][64];
+    const int64_t *e = table + (int64_t)blockIdx.y * 8;
+    const float *part = reinterpret_cast<const float *>(e[0]);
+    float *dst = reinterpret_cast<float *>(e[1]);
+    const int splits = (int)e[2], Cout = (int)e[3], Cin = (int)e[4], taps = (int)e[5], NP16 = (int)e[6], CP16 = (int)e[7];
+    const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t total = (int64_t)Cout * Cin * taps, stride = (int64_t)NP16 * CP16 * taps;
+    for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < total; i0 += (int64_t)gridDim.x * 64) {
+        const int64_t i = i0 + col;
+        float s0 = 0.f, s1 = 0.f;
+        if (i < total) {
+            const int t = (int)(i % taps);
+            const int c = (int)((i / taps) % Cin);
+            const int n = (int)(i / ((int64_t)taps * Cin));
+            const float *src = part + ((int64_t)n * CP16 + c) * taps + t;
+            int k = q;
+            // the small layers have the most splits (up to 512 x a few KB): keep 8 loads in flight per lane
+            for (; k + 28 < splits; k += 32) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(k + 4 * u) * stride];
+                s0 += (v[0] + v[2]) + (v[4] + v[6]);
+                s1 += (v[1] + v[3]) + (v[5] + v[7]);
+            }
+            for (; k + 4 < splits; k += 8) { s0 += src[(int64_t)k * stride]; s1 += src[(int64_t)(k + 4) * stride]; }
+            for (; k < splits; k += 4) s0 += src[(int64_t)k * stride];
+        }
+        red[q][col] = s0 + s1;
+        __syncthreads();
+        if (q == 0 && i < total) dst[i] += (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        __syncthreads();
+    }
+}
+
 static void wgrad_plan(int B, int Cin, int Cout, int H, int W, int KS, int *R, int *strips, int *splits, int *ups) {
     *R = 160 / W < 1 ? 1 : 160 / W;
     if (*R > H) *R = H;
@@ -1198,6 +1237,7 @@ static int launch_wgrad1(const ChanSegs &xs_, const void *dy, float *dw, float *
         hipLaunchKernelGGL(conv_wgrad1_glds_kernel<false>, dim3(splits * npairs), dim3(kW2Threads), (size_t)kW2Ring * 2 * 128 * 128, st, xs_,
                            (const uint16_t *)dy, ws, Cin, Cout, HW, cpi, B * cpi, cps, nct, np16, cp16, npairs, splits);
     if (int e = check_launch()) return e;
+    if (!dw) return DFINE_OK;                                // partials only: reduced later by dfine_multi_wgrad_reduce
     const int64_t total = (int64_t)Cout * Cin;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((int)((total + 63) / 64)), dim3(256), 0, st, ws, dw, splits, Cout, Cin, 1,
                        np16, cp16);
@@ -1288,7 +1328,7 @@ int64_t dfine_conv_wgrad_ws_floats(int B, int Cin, int Cout, int H, int W, int K
 int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, int B, int Cin, int Cout, int H,
                           int W, int KS, void *stream) {
     if (B == 0) return DFINE_OK;
-    if (!x || !dy || !dw || !ws || Cin < 1 || Cout < 1 || (KS != 1 && KS != 3)) return DFINE_E_BADARG;
+    if (!x || !dy || !ws || Cin < 1 || Cout < 1 || (KS != 1 && KS != 3)) return DFINE_E_BADARG;
     if (wgrad1_v2(KS, H * W)) return launch_wgrad1(one_seg(x, Cin), dy, dw, ws, B, Cin, Cout, H * W, (hipStream_t)stream);
     int h = H, w = W;
     if (KS == 1) {
@@ -1329,6 +1369,7 @@ int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, i
                            Cin, Cout, h, w, R, strips, B * strips, ups, nct64, np16, cp16, cs, npairs, splits);
     }
     if (int e = check_launch()) return e;
+    if (!dw) return DFINE_OK;                                // partials only
     const int64_t total = (int64_t)Cout * Cin * KS * KS;
     const int blocks = (int)((total + 63) / 64);
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, splits, Cout, Cin, KS * KS,
@@ -1358,7 +1399,7 @@ int dfine_conv1x1_seg_wgrad_bf16(const void *const *x_parts, const int *x_channe
                                  int B, int Cin, int Cout, int H, int W, void *stream) {
     if (B == 0) return DFINE_OK;
     ChanSegs xs_;
-    if (!dy || !dw || !ws || !make_segs(&xs_, x_parts, x_channels, x_bstrides, n_x, Cin) || (H * W) % 8) return DFINE_E_BADARG;
+    if (!dy || !ws || !make_segs(&xs_, x_parts, x_channels, x_bstrides, n_x, Cin) || (H * W) % 8) return DFINE_E_BADARG;
     return launch_wgrad1(xs_, dy, dw, ws, B, Cin, Cout, H * W, (hipStream_t)stream);
 }
 
@@ -1385,21 +1426,50 @@ int64_t dfine_linear_wgrad_ws_floats(int M, int N, int K) {
 int dfine_linear_wgrad_bf16(const void *x, const void *dy, float *dw, float *db, float *ws, int M, int N, int K,
                             void *stream) {
     if (M == 0) return DFINE_OK;
-    if (!x || !dy || !dw || !ws || M < 1 || N < 1 || K < 1) return DFINE_E_BADARG;
+    if (!x || !dy || !ws || M < 1 || N < 1 || K < 1) return DFINE_E_BADARG;
     int splits, rows;
     linear_wgrad_plan(M, N, K, &splits, &rows);
     const int nnt64 = (N + 63) / 64, nct64 = (K + 63) / 64;
     const int np16 = (N + 15) / 16 * 16, cp16 = (K + 15) / 16 * 16;
     hipStream_t st = (hipStream_t)stream;
-    float *part_b = db ? ws + (int64_t)splits * np16 * cp16 : nullptr;
+    float *part_b = (db || !dw) ? ws + (int64_t)splits * np16 * cp16 : nullptr;     // dw == NULL: partials (weights AND bias) only
     hipLaunchKernelGGL(linear_wgrad_kernel, dim3(nnt64 * nct64, splits), dim3(kConvThreads), 0, st, (const uint16_t *)x,
                        (const uint16_t *)dy, ws, part_b, M, N, K, rows, nct64, np16, cp16);
     if (int e = check_launch()) return e;
+    if (!dw) return DFINE_OK;
     const int64_t total = (int64_t)N * K;
     const int blocks = (int)((total + 63) / 64);
     const int bias_blocks = db ? (N + 63) / 64 : 0;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks + bias_blocks), dim3(256), 0, st, ws, dw, splits, N, K, 1, np16,
                        cp16, (const float *)part_b, db, blocks);
+    return check_launch();
+}
+
+// Number of splits (partial-sum slabs) the weight-gradient entry points above write into `ws` for these shapes.
+int dfine_conv_wgrad_splits(int B, int Cin, int Cout, int H, int W, int KS) {
+    if (wgrad1_v2(KS, H * W)) {
+        int splits, cps;
+        wgrad1_plan(B, Cin, Cout, H * W, &splits, &cps);
+        return splits;
+    }
+    int h = H, w = W;
+    if (KS == 1) { const int hw = H * W; w = 160; while (w > 8 && (hw % w || w % 8)) --w; h = hw / w; }
+    int R, strips, splits, ups;
+    wgrad_plan(B, Cin, Cout, h, w, KS, &R, &strips, &splits, &ups);
+    return splits;
+}
+
+int dfine_linear_wgrad_splits(int M, int N, int K) {
+    int splits, rows;
+    linear_wgrad_plan(M, N, K, &splits, &rows);
+    return splits;
+}
+
+// table: device int64 [n_entries][8] = {partials, dst (f32, ACCUMULATED into), splits, Cout, Cin, taps, NP16, CP16}
+int dfine_multi_wgrad_reduce(const void *table, int n_entries, void *stream) {
+    if (n_entries == 0) return DFINE_OK;
+    if (!table || n_entries < 0) return DFINE_E_BADARG;
+    hipLaunchKernelGGL(multi_wgrad_reduce_kernel, dim3(32, n_entries), dim3(256), 0, (hipStream_t)stream, (const int64_t *)table);
     return check_launch();
 }
 

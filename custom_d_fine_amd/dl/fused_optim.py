@@ -10,6 +10,7 @@ the per-group learning rates a scheduler may have updated - are read from the to
 `build_optimizer` returned, every step.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -141,6 +142,14 @@ class FusedAdamWEMA:
         if self.overlap:
             for i, p in enumerate(self._params):
                 p.register_post_accumulate_grad_hook(self._make_hook(index_of[i]))
+        # ---- deferred weight gradients: the conv / linear backward ops leave their split partial sums in a workspace and
+        # register them here; ONE launch per flush reduces all of them straight into the flat gradient buffer
+        self._bucket_of = index_of
+        self._deferred = []          # (param index, dst offset in flat_grad, workspace tensor, workspace offset, meta)
+        self._uses = {}              # param index -> deferred uses still to come in this backward
+        self.defer_wgrads = os.environ.get("DFINE_DEFER_WGRAD", "1") == "1"
+        for i, p in enumerate(self._params):
+            p._dfine_slot = (self, i)
 
     # -------------------------------------------------------------------------------------
     def broadcast_from_rank0(self):
@@ -177,6 +186,57 @@ class FusedAdamWEMA:
         for p in self._params:
             p.grad = None
 
+    def defer_wgrad(self, index, ws, meta, ws_offset=0, dst_offset=0):
+        """Called from a backward op instead of returning a gradient tensor for parameter `index`: `ws` holds per-split
+        partial sums (layout `meta` = (splits, Cout, Cin, taps, NP16, CP16)) of the gradient of the parameter's elements
+        [dst_offset, dst_offset + Cout * Cin * taps)."""
+        self._deferred.append((index, self._grad_offsets[index] + dst_offset, ws, ws_offset, meta))
+
+    def note_use(self, index):
+        """A forward op will deliver parameter `index`'s gradient through defer_wgrad (one call per use of the parameter)."""
+        self._uses[index] = self._uses.get(index, 0) + 1
+
+    def use_done(self, index):
+        n = self._uses.get(index, 0) - 1
+        self._uses[index] = n
+        if n <= 0:
+            self.param_ready(index)
+
+    def param_ready(self, index):
+        """The gradient of parameter `index` is complete (all its deferred pieces registered): bucket bookkeeping of the
+        overlapped all-reduce - what the post-accumulate-grad hook does for parameters that get a gradient tensor."""
+        if self.overlap and not self.accumulating:
+            b = self._buckets[self._bucket_of[index]]
+            b["ready"] += 1
+            if b["ready"] == len(b["params"]):
+                self._reduce_bucket(b)
+
+    def _flush_deferred(self, lo=None, hi=None):
+        import numpy as np
+        take = [d for d in self._deferred if lo is None or lo <= d[1] < hi]
+        if not take:
+            return
+        if lo is not None:
+            self._deferred = [d for d in self._deferred if not (lo <= d[1] < hi)]
+        else:
+            self._deferred = []
+        fg = self.flat_grad.data_ptr()
+        rows = [(ws.data_ptr() + 4 * wo, fg + 4 * off, m[0], m[1], m[2], m[3], m[4], m[5]) for _, off, ws, wo, m in take]
+        from ..d_fine.arch.utils import upload
+        if os.environ.get("DFINE_DEFER_DEBUG") == "1":
+            pb = sum(m[0] * m[4] * m[5] * m[3] * 4 for *_, m in take)
+            print(f"[deferred wgrads] {len(rows)} entries, {pb / 1e6:.1f} MB of partial sums, "
+                  f"max splits {max(m[0] for *_, m in take)}", flush=True)
+            import collections
+            agg = collections.Counter()
+            for *_, m in take:
+                agg[tuple(m[:4])] += m[0] * m[4] * m[5] * m[3] * 4
+            for k, v in agg.most_common(24):
+                print(f"    (splits, Cout, Cin, taps)={k}: {v / 1e6:.1f} MB", flush=True)
+        table = upload(np.asarray(rows, dtype=np.int64), self.flat_grad.device)
+        self.hip.multi_wgrad_reduce(table, len(rows))
+        self._live.append((take, table))
+
     def _make_hook(self, bi):
         b = self._buckets[bi]
         n = len(b["params"])
@@ -210,6 +270,7 @@ class FusedAdamWEMA:
 
     def _reduce_bucket(self, b):
         self._gather(b["params"])
+        self._flush_deferred(b["lo"], b["hi"])
         b["done"] = True
         if get_world_size() > 1:
             # asynchronous on the communication stream: ordered after the copy above, overlaps what backward still runs
@@ -220,6 +281,7 @@ class FusedAdamWEMA:
         step leave their bucket incomplete)."""
         if not self.overlap:
             self._gather(range(len(self._params)))
+            self._flush_deferred()
             if get_world_size() > 1:
                 # one large collective over xGMI: 78 MB for D-FINE-m
                 dist.all_reduce(self.flat_grad)
@@ -238,6 +300,7 @@ class FusedAdamWEMA:
         hip = self.hip
         world = get_world_size()
         self._collect_grads()
+        self._uses.clear()
         grad_scale = 1.0 / world
         self.step_count += 1
         if self.clip_max_norm > 0:
@@ -261,4 +324,4 @@ class FusedAdamWEMA:
         kernels.bump_weight_epoch()          # cached packed conv weights are stale now
         # keep torch's scheduler bookkeeping consistent (it warns if optimizer.step was never called)
         self.optimizer._opt_called = True
-        self._live = self._live[-8:]         # sources of the copies queued this step; older ones have long been consumed
+        self._live = self._live[-16:]        # sources of the copies / reductions queued this step; older ones have long been consumed

@@ -58,6 +58,9 @@ _SIGNATURES = {
     "dfine_topk_anchors": (c_int, [_P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfine_conv1x1_seg_fwd_bf16": (c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_conv1x1_seg_wgrad_bf16": (c_int, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfine_conv_wgrad_splits": (c_int, [_I, _I, _I, _I, _I, _I]),
+    "dfine_linear_wgrad_splits": (c_int, [_I, _I, _I]),
+    "dfine_multi_wgrad_reduce": (c_int, [_P, _I, _P]),
     "dfine_linear_act_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_multi_cast_bf16_t": (c_int, [_P, _I, _P]),
     "dfine_act_fwd_bf16": (c_int, [_P, _P, _L, _I, _P]),
@@ -545,15 +548,17 @@ def conv1x1_seg_forward(x_parts, w2, y_parts):
                                                _stream()), "dfine_conv1x1_seg_fwd_bf16")
 
 
-def conv1x1_seg_wgrad(x_parts, dy):
+def conv1x1_seg_wgrad(x_parts, dy, partials=False):
     B, _, H, W = x_parts[0].shape
     cin, cout = sum(t.shape[1] for t in x_parts), dy.shape[1]
-    dw = torch.empty(cout, cin, 1, 1, device=dy.device, dtype=torch.float32)
+    dw = None if partials else torch.empty(cout, cin, 1, 1, device=dy.device, dtype=torch.float32)
     ws = torch.empty(int(_lib.dfine_conv_wgrad_ws_floats(B, cin, cout, H, W, 1)), device=dy.device, dtype=torch.float32)
     xp, xc, xb = _seg_arrays(x_parts)
     with _timed("conv1x1_wgrad", 2.0 * B * H * W * cin * cout):
         _check(_lib.dfine_conv1x1_seg_wgrad_bf16(xp, xc, xb, len(x_parts), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W,
                                                  _stream()), "dfine_conv1x1_seg_wgrad_bf16")
+    if partials:
+        return ws, (int(_lib.dfine_conv_wgrad_splits(B, cin, cout, H, W, 1)), cout, cin, 1, _p16(cout), _p16(cin))
     return dw
 
 
@@ -561,16 +566,27 @@ def conv_wgrad_supported(H, W, ks):
     return (ks == 3 and W % 8 == 0 and W <= 160) or (ks == 1 and (H * W) % 8 == 0)
 
 
-def conv_wgrad_bf16(x, dy, ks):
-    """x [B,Cin,H,W], dy [B,Cout,H,W] bf16 contiguous -> dw [Cout,Cin,ks,ks] f32."""
+def _p16(n):
+    return (n + 15) // 16 * 16
+
+
+def conv_wgrad_bf16(x, dy, ks, partials=False):
+    """x [B,Cin,H,W], dy [B,Cout,H,W] bf16 contiguous -> dw [Cout,Cin,ks,ks] f32; partials=True: (ws, meta) for a deferred
+    dfine_multi_wgrad_reduce, meta = (splits, Cout, Cin, taps, NP16, CP16)."""
     B, cin, H, W = x.shape
     cout = dy.shape[1]
-    dw = torch.empty(cout, cin, ks, ks, device=x.device, dtype=torch.float32)
+    dw = None if partials else torch.empty(cout, cin, ks, ks, device=x.device, dtype=torch.float32)
     ws = torch.empty(int(_lib.dfine_conv_wgrad_ws_floats(B, cin, cout, H, W, ks)), device=x.device, dtype=torch.float32)
     with _timed(f"conv{ks}x{ks}_wgrad", 2.0 * B * H * W * cin * cout * ks * ks):
         _check(_lib.dfine_conv_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ks, _stream()),
                "dfine_conv_wgrad_bf16")
+    if partials:
+        return ws, (int(_lib.dfine_conv_wgrad_splits(B, cin, cout, H, W, ks)), cout, cin, ks * ks, _p16(cout), _p16(cin))
     return dw
+
+
+def multi_wgrad_reduce(table, n_entries):
+    _check(_lib.dfine_multi_wgrad_reduce(_ptr(table), n_entries, _stream()), "dfine_multi_wgrad_reduce")
 
 
 # ------------------------------------------------------------------------------------- FDR head
@@ -726,6 +742,19 @@ def attn_backward(q, k, v, o, dout, lse2, num_heads, dq, dk, dv, mask=None):
 
 # ------------------------------------------------------------------------------------- linear wgrad
 _LW_WS = {}
+
+
+def linear_wgrad_partials(x2d, dy2d):
+    """Partial sums only: (ws, weight meta, bias meta, bias offset in floats) for a deferred dfine_multi_wgrad_reduce."""
+    M, K = x2d.shape
+    N = dy2d.shape[1]
+    ws = torch.empty(int(_lib.dfine_linear_wgrad_ws_floats(M, N, K)), device=x2d.device, dtype=torch.float32)
+    with _timed("linear_wgrad", 2.0 * M * N * K):
+        _check(_lib.dfine_linear_wgrad_bf16(_ptr(x2d), _ptr(dy2d), None, None, _ptr(ws), M, N, K, _stream()),
+               "dfine_linear_wgrad_bf16")
+    splits = int(_lib.dfine_linear_wgrad_splits(M, N, K))
+    np16, cp16 = _p16(N), _p16(K)
+    return ws, (splits, N, K, 1, np16, cp16), (splits, N, 1, 1, np16, 1), splits * np16 * cp16
 
 
 def linear_wgrad_bf16(x2d, dy2d, with_bias=False, dw=None, db=None):

@@ -534,6 +534,19 @@ def _conv_plan(x, weight):
     return plan
 
 
+def _defer_slot(*params):
+    """(fused optimizer, [indices]) when every given parameter lives in a FusedAdamWEMA flat buffer that takes deferred weight
+    gradients (split partial sums reduced by ONE launch per step straight into the flat gradient buffer), else None."""
+    fused, idx = None, []
+    for p in params:
+        slot = getattr(p, "_dfine_slot", None)
+        if slot is None or not slot[0].defer_wgrads or (fused is not None and slot[0] is not fused) or p.dtype != torch.float32:
+            return None
+        fused = slot[0]
+        idx.append(slot[1])
+    return fused, idx
+
+
 class _DenseConv(torch.autograd.Function):
     """1x1 / 3x3 stride-1 dense convolution, NCHW bf16.  Each of forward / data gradient / weight
     gradient runs on the HIP implicit-GEMM MFMA kernels (conv.hip) or on MIOpen [ATen plumbing],
@@ -552,6 +565,9 @@ class _DenseConv(torch.autograd.Function):
                 y = F.conv2d(x, bf16_param(weight), None, 1, ks // 2)
         ctx.save_for_backward(x, weight)
         ctx.plan = plan
+        ctx.slot = _defer_slot(weight) if (plan["wgrad"] and ctx.needs_input_grad[1]) else None
+        if ctx.slot is not None:
+            ctx.slot[0].note_use(ctx.slot[1][0])
         return y
 
     @staticmethod
@@ -577,7 +593,13 @@ class _DenseConv(torch.autograd.Function):
         if need_dx and plan["dgrad"]:
             dx = hip.conv_forward_bf16(dy, _packed_weights(weight, True), weight.shape[1], ks)
         if need_dw and plan["wgrad"]:
-            dw = hip.conv_wgrad_bf16(x, dy, ks).to(weight.dtype)
+            slot = getattr(ctx, "slot", None)
+            if slot is not None:
+                ws, meta = hip.conv_wgrad_bf16(x, dy, ks, partials=True)
+                slot[0].defer_wgrad(slot[1][0], ws, meta)
+                slot[0].use_done(slot[1][0])
+            else:
+                dw = hip.conv_wgrad_bf16(x, dy, ks).to(weight.dtype)
         return dx, dw
 
 
@@ -594,6 +616,9 @@ class _DenseConvSeg(torch.autograd.Function):
         y = torch.empty(B, weight.shape[0], H, W, device=xs[0].device, dtype=torch.bfloat16)
         hip.conv1x1_seg_forward(xs, _packed_weights(weight, False), (y,))
         ctx.save_for_backward(weight, *xs)
+        ctx.slot = _defer_slot(weight) if ctx.needs_input_grad[0] else None
+        if ctx.slot is not None:
+            ctx.slot[0].note_use(ctx.slot[1][0])
         return y
 
     @staticmethod
@@ -609,7 +634,14 @@ class _DenseConvSeg(torch.autograd.Function):
             outs = tuple(torch.empty(x.shape, device=x.device, dtype=x.dtype) for x in xs)
             hip.conv1x1_seg_forward((dy,), _packed_weights(weight, True), outs)
             dxs = [o if n else None for o, n in zip(outs, need[1:])]
-        dw = hip.conv1x1_seg_wgrad(xs, dy).to(weight.dtype) if need[0] else None
+        dw = None
+        if need[0]:
+            if ctx.slot is not None:
+                ws, meta = hip.conv1x1_seg_wgrad(xs, dy, partials=True)
+                ctx.slot[0].defer_wgrad(ctx.slot[1][0], ws, meta)
+                ctx.slot[0].use_done(ctx.slot[1][0])
+            else:
+                dw = hip.conv1x1_seg_wgrad(xs, dy).to(weight.dtype)
         return (dw, *dxs)
 
 
@@ -942,6 +974,12 @@ class _LinearAct(torch.autograd.Function):
                 ref = y
         ctx.save_for_backward(x2d, weight, ref)
         ctx.meta = (act, x.dtype, x.shape, bias is not None)
+        ctx.slot = None
+        if ctx.needs_input_grad[1] and (bias is None or ctx.needs_input_grad[2]):
+            ctx.slot = _defer_slot(weight) if bias is None else _defer_slot(weight, bias)
+            if ctx.slot is not None:
+                for i in ctx.slot[1]:
+                    ctx.slot[0].note_use(i)
         return y
 
     @staticmethod
@@ -956,7 +994,15 @@ class _LinearAct(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = hip.linear_act(d2, bf16_param_t(weight), None, 0, out_f32=xdt == torch.float32).view(xshape)
         want_db = has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1] or want_db:
+        if ctx.slot is not None:
+            fused, idx = ctx.slot
+            ws, wmeta, bmeta, boff = hip.linear_wgrad_partials(x2d, d2)
+            fused.defer_wgrad(idx[0], ws, wmeta)
+            if has_bias:
+                fused.defer_wgrad(idx[1], ws, bmeta, ws_offset=boff)
+            for i in idx:
+                fused.use_done(i)
+        elif ctx.needs_input_grad[1] or want_db:
             res = hip.linear_wgrad_bf16(x2d, d2, with_bias=want_db)
             dw, db = res if want_db else (res, None)
             if dw.dtype != weight.dtype:
@@ -1022,6 +1068,10 @@ class _MHA(torch.autograd.Function):
         y = hip.linear_act(o.view(B * L, E), bf16_param(out_w), _f32_vec(out_b)).view(B, L, E)
         ctx.save_for_backward(qk2, v2, qkp, vp, o, lse2, in_w, out_w, mask_u8)
         ctx.meta = (num_heads, qk.dtype, value.dtype)
+        ctx.slot = _defer_slot(in_w, in_b, out_w, out_b) if all(ctx.needs_input_grad[2:6]) else None
+        if ctx.slot is not None:
+            for i in ctx.slot[1]:
+                ctx.slot[0].note_use(i)
         return y
 
     @staticmethod
@@ -1032,13 +1082,31 @@ class _MHA(torch.autograd.Function):
         B, L, E = o.shape
         d2 = _bf16_2d(dy)
         do = hip.linear_act(d2, bf16_param_t(out_w)).view(B, L, E)
-        d_out_w, d_out_b = hip.linear_wgrad_bf16(o.view(B * L, E), d2, with_bias=True)
+        slot = ctx.slot
+        d_out_w = d_out_b = None
+        if slot is not None:
+            fused, (i_w, i_b, o_w, o_b) = slot
+            ws, wmeta, bmeta, boff = hip.linear_wgrad_partials(o.view(B * L, E), d2)
+            fused.defer_wgrad(o_w, ws, wmeta)
+            fused.defer_wgrad(o_b, ws, bmeta, ws_offset=boff)
+        else:
+            d_out_w, d_out_b = hip.linear_wgrad_bf16(o.view(B * L, E), d2, with_bias=True)
         dqk = torch.empty(B, L, 2 * E, device=o.device, dtype=torch.bfloat16)
         dv = torch.empty(B, L, E, device=o.device, dtype=torch.bfloat16)
         hip.attn_backward(qkp[..., :E], qkp[..., E:], vp, o, do, lse2, num_heads, dqk[..., :E], dqk[..., E:], dv, mask_u8)
         wt = bf16_param_t(in_w)                                 # [E, 3E]
         d_qk_in = hip.linear_act(dqk.view(B * L, 2 * E), wt[:, : 2 * E], out_f32=qdt == torch.float32).view(B, L, E)
         d_v_in = hip.linear_act(dv.view(B * L, E), wt[:, 2 * E:], out_f32=vdt == torch.float32).view(B, L, E)
+        if slot is not None:
+            ws, wmeta, bmeta, boff = hip.linear_wgrad_partials(qk2, dqk.view(B * L, 2 * E))
+            fused.defer_wgrad(i_w, ws, wmeta)                                   # rows [0, 2E) of in_proj_weight
+            fused.defer_wgrad(i_b, ws, bmeta, ws_offset=boff)
+            ws, wmeta, bmeta, boff = hip.linear_wgrad_partials(v2, dv.view(B * L, E))
+            fused.defer_wgrad(i_w, ws, wmeta, dst_offset=2 * E * E)             # rows [2E, 3E)
+            fused.defer_wgrad(i_b, ws, bmeta, ws_offset=boff, dst_offset=2 * E)
+            for i in (i_w, i_b, o_w, o_b):
+                fused.use_done(i)
+            return d_qk_in, d_v_in, None, None, None, None, None, None
         d_in_w = torch.empty(3 * E, E, device=o.device, dtype=torch.float32)
         d_in_b = torch.empty(3 * E, device=o.device, dtype=torch.float32)
         hip.linear_wgrad_bf16(qk2, dqk.view(B * L, 2 * E), with_bias=True, dw=d_in_w[: 2 * E], db=d_in_b[: 2 * E])

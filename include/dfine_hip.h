@@ -285,6 +285,21 @@ int dfine_conv1x1_seg_wgrad_bf16(const void *const *x_parts, const int *x_channe
                                  void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * A16 / A17  Deferred weight-gradient reduction.  dfine_conv_wgrad_bf16, dfine_conv1x1_seg_wgrad_bf16 and
+ * dfine_linear_wgrad_bf16 called with dw == NULL leave their per-split partial sums in `ws`
+ * ([splits][NP16][CP16][taps] f32, NP16 / CP16 = Cout / Cin rounded up to 16; the linear entry point also leaves
+ * [splits][NP16] bias partials behind them); dfine_*_wgrad_splits report `splits`.  dfine_multi_wgrad_reduce sums
+ * the partials of many layers in ONE launch and ACCUMULATES into their destinations - the slots of the flat
+ * gradient buffer the fused optimizer / all-reduce work on (the per-parameter `.grad` tensors and the
+ * per-layer reductions of autograd's AccumulateGrad, src/dl/train.py:512-535, disappear).
+ *   table: device int64 [n_entries][8] = {partials ptr, dst ptr, splits, Cout, Cin, taps, NP16, CP16}
+ *   (bias gradient: Cin = taps = CP16 = 1).
+ */
+int dfine_conv_wgrad_splits(int B, int Cin, int Cout, int H, int W, int KS);
+int dfine_linear_wgrad_splits(int M, int N, int K);
+int dfine_multi_wgrad_reduce(const void *table, int n_entries, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * A2 / A3 / A5 / A6  Token-stream linear layers: y[M, N] = act(x[M, K] . w[N, K]^T + bias[N]), bf16
  * operands (row strides ldx / ldw / ldy elements, unit inner stride), fp32 accumulate, bias fp32 or NULL,
  * act: 0 none, 1 ReLU, 2 GELU (erf), 3 SiLU; out_f32 = 1 writes fp32.  Replaces F.linear + activation of
