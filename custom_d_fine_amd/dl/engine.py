@@ -6,6 +6,7 @@ backward, [unscale ->] clip_grad_norm_(max_norm) -> AdamW -> scheduler -> zero_g
 bf16 autocast needs no GradScaler (the reference's fp16 path does).
 """
 import math
+import os
 from copy import deepcopy
 
 import torch
@@ -165,6 +166,7 @@ class TrainStep:
         self.fused = fused_optimizer      # FusedAdamWEMA (GPU): clip + AdamW + EMA + zero_grad + all-reduce
         self.hip_graph, self.graph_after = hip_graph, graph_after
         self._graphed, self._calls, self._graph_shape = None, 0, None
+        self.gc_freeze_after = int(os.environ.get("DFINE_GC_FREEZE_AFTER", "3"))      # 0 = never
 
     def optimizer_step(self, step_scheduler=True):
         from .. import kernels
@@ -226,4 +228,13 @@ class TrainStep:
         self._micro += 1
         if self._micro % self.accum_steps == 0:
             self.optimizer_step()
+        if self._calls == self.gc_freeze_after:
+            # The model, the optimizer state, the cached launch tables ... are a few hundred thousand long-lived Python
+            # objects: every full (generation-2) garbage collection walks all of them - 50-150 ms of host pause, about
+            # once per 30-40 steps, during which the device queue of a ~50 ms step runs dry (measured: 1 step in ~35 took
+            # 145-210 ms, +3 ms on the mean).  Moving them to the permanent generation once the steady state is reached
+            # keeps later collections to the per-step garbage.
+            import gc
+            gc.collect()
+            gc.freeze()
         return loss.detach(), loss_dict
