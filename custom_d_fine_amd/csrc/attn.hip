@@ -44,7 +44,7 @@ __device__ __forceinline__ a_bf16x8 tr_frag(const uint16_t *p, int pitch) {
     return __builtin_bit_cast(a_bf16x8, (a_tr8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return pack_bf16x2(a, b); }
 
 __device__ __forceinline__ float xor_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 16));

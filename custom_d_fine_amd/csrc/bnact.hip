@@ -24,13 +24,14 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
 
 __device__ __forceinline__ float act_fwd(float z, int act) {
     if (act == ACT_RELU) return fmaxf(z, 0.f);
-    if (act == ACT_SILU) return z / (1.f + __expf(-z));
+    // v_rcp_f32 (1 ulp) instead of an IEEE division (~10 instructions): the SiLU passes are VALU-bound, not HBM-bound
+    if (act == ACT_SILU) return z * __builtin_amdgcn_rcpf(1.f + __expf(-z));
     return z;
 }
 __device__ __forceinline__ float act_grad(float z, int act) {
     if (act == ACT_RELU) return z > 0.f ? 1.f : 0.f;
     if (act == ACT_SILU) {
-        const float s = 1.f / (1.f + __expf(-z));
+        const float s = __builtin_amdgcn_rcpf(1.f + __expf(-z));
         return s * (1.f + z * (1.f - s));
     }
     return 1.f;
@@ -62,6 +63,25 @@ __device__ __forceinline__ void bf16x8_to_f32(const uint4 &r, float (&o)[8]) {
     o[4] = __uint_as_float(r.z << 16); o[5] = __uint_as_float(r.z & 0xffff0000u);
     o[6] = __uint_as_float(r.w << 16); o[7] = __uint_as_float(r.w & 0xffff0000u);
 }
+
+// Index arithmetic without per-vector divisions: a thread walks vectors v, v + step, v + 2*step, ...; the position
+// (q, r) = (v / d, v % d) is stepped with (sq, sr) = (step / d, step % d) computed once per kernel.  (An integer
+// division is ~25 VALU instructions, a 64-bit one several times that - more than the BN arithmetic of a 16-byte vector.)
+struct QR { uint32_t q, r; };
+__device__ __forceinline__ QR qr_init(uint32_t v, uint32_t d) { const uint32_t q = v / d; return {q, v - q * d}; }
+__device__ __forceinline__ QR qr_step(QR a, uint32_t sq, uint32_t sr, uint32_t d) {
+    a.q += sq; a.r += sr;
+    if (a.r >= d) { a.r -= d; ++a.q; }
+    return a;
+}
+// channel = plane % C stepped the same way (cq = (step / d) % C); `carry` = the plane advanced by one extra
+__device__ __forceinline__ uint32_t chan_step(uint32_t c, uint32_t cq, bool carry, uint32_t C) {
+    c += cq + (carry ? 1u : 0u);
+    if (c >= C) c -= C;
+    if (c >= C) c -= C;
+    return c;
+}
+
 constexpr int kRedUnroll = 4;      // independent 16-byte loads in flight per thread in the reductions
 
 // partial layout: [C][nchunk][NVAL]
@@ -75,16 +95,16 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const T *__restric
     if (sizeof(T) == 2 && (HW & 7) == 0) {
         const int nv = HW >> 3, total = (b1 - b0) * nv;            // (image, 8-vector) pairs of this chunk
         const uint16_t *xb = reinterpret_cast<const uint16_t *>(x);
+        const uint32_t sq = kBnThreads / nv, sr = kBnThreads % nv;
+        QR pos = qr_init(threadIdx.x, nv);                          // (image, vector) of i
         for (int i0 = threadIdx.x; i0 < total; i0 += kRedUnroll * kBnThreads) {
             uint4 r[kRedUnroll];
 #pragma unroll
             for (int j = 0; j < kRedUnroll; ++j) {
                 const int i = i0 + j * kBnThreads;
                 r[j] = make_uint4(0, 0, 0, 0);
-                if (i < total) {
-                    const int bi = i / nv, vi = i - bi * nv;
-                    r[j] = *reinterpret_cast<const uint4 *>(xb + ((int64_t)(b0 + bi) * C + c) * HW + vi * 8);
-                }
+                if (i < total) r[j] = *reinterpret_cast<const uint4 *>(xb + ((int64_t)(b0 + pos.q) * C + c) * HW + pos.r * 8);
+                pos = qr_step(pos, sq, sr, nv);
             }
 #pragma unroll
             for (int j = 0; j < kRedUnroll; ++j) {
@@ -186,9 +206,6 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_flat_kernel(const T *__re
     }
 }
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
-}
 
 // Finalize folded into the apply kernels (layers with C * nchunk <= kBnFuseMax): part == nullptr -> not fused.
 constexpr int kBnFuseMax = 8192;
@@ -207,13 +224,15 @@ struct BnFusedBwdFin {
     float *dgamma, *dbeta, *dlab, *coef;
 };
 
-// bf16, HW % 8 == 0: 16-byte vectors, two independent vectors per thread and iteration
+// bf16, HW % 8 == 0: 16-byte vectors, two independent vectors per thread and iteration (nvec < 2^31)
+template <int ACT_T>
 __global__ __launch_bounds__(kBnThreads) void bn_apply_flat8_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ y,
                                                                     const float *__restrict__ scale,
                                                                     const float *__restrict__ shift,
                                                                     const float *__restrict__ lab_s,
                                                                     const float *__restrict__ lab_b, int C, int HW,
-                                                                    int64_t nvec, int act, BnFusedFin fin) {
+                                                                    int64_t nvec, BnFusedFin fin) {
+    constexpr int act = ACT_T;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_sc = smem, *s_sh = smem + C;
     if (fin.part) {
@@ -247,16 +266,21 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_flat8_kernel(const uint16
     }
     const float ls = lab_s ? lab_s[0] : 1.f, lb = lab_b ? lab_b[0] : 0.f;
     __syncthreads();
-    const uint32_t nv = HW >> 3;
-    const int64_t stride = (int64_t)gridDim.x * kBnThreads;
-    for (int64_t v0 = (int64_t)blockIdx.x * kBnThreads + threadIdx.x; v0 < nvec; v0 += 2 * stride) {
-        const int64_t v1 = v0 + stride;
-        const bool has1 = v1 < nvec;
-        const uint4 r0 = *reinterpret_cast<const uint4 *>(x + v0 * 8);
+    const uint32_t nv = HW >> 3, n = (uint32_t)nvec;
+    const uint32_t stride = gridDim.x * kBnThreads;
+    const uint32_t sq = stride / nv, sr = stride % nv, cq = sq % C;
+    uint32_t v0 = blockIdx.x * kBnThreads + threadIdx.x;
+    QR p0 = qr_init(v0, nv);
+    uint32_t c0 = p0.q % C;
+    for (; v0 < n;) {
+        const uint32_t v1 = v0 + stride;
+        const QR p1 = qr_step(p0, sq, sr, nv);
+        const uint32_t c1 = chan_step(c0, cq, p1.q != p0.q + sq, C);
+        const bool has1 = v1 < n;
+        const uint4 r0 = *reinterpret_cast<const uint4 *>(x + (int64_t)v0 * 8);
         uint4 r1 = make_uint4(0, 0, 0, 0);
-        if (has1) r1 = *reinterpret_cast<const uint4 *>(x + v1 * 8);
-        auto apply = [&](const uint4 &r, int64_t v) {
-            const int c = (int)((v / nv) % C);
+        if (has1) r1 = *reinterpret_cast<const uint4 *>(x + (int64_t)v1 * 8);
+        auto apply = [&](const uint4 &r, int64_t v, uint32_t c) {
             const float sc = s_sc[c], sh = s_sh[c];
             float a[8];
             bf16x8_to_f32(r, a);
@@ -267,16 +291,21 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_flat8_kernel(const uint16
             o.z = pack_bf16x2(a[4], a[5]); o.w = pack_bf16x2(a[6], a[7]);
             *reinterpret_cast<uint4 *>(y + v * 8) = o;
         };
-        apply(r0, v0);
-        if (has1) apply(r1, v1);
+        apply(r0, v0, c0);
+        if (has1) apply(r1, v1, c1);
+        v0 = v1 + stride;
+        p0 = qr_step(p1, sq, sr, nv);
+        c0 = chan_step(c1, cq, p0.q != p1.q + sq, C);
     }
 }
 
+template <int ACT_T>
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_flat8_kernel(
     const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy, uint16_t *__restrict__ dx,
     const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ scale,
     const float *__restrict__ shift, const float *__restrict__ lab_s, const float *__restrict__ coef, int C, int HW,
-    int64_t nvec, int act, int train, BnFusedBwdFin fin) {
+    int64_t nvec, int train, BnFusedBwdFin fin) {
+    constexpr int act = ACT_T;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_mu = smem, *s_is = smem + C, *s_sc = smem + 2 * C, *s_sh = smem + 3 * C, *s_m0 = smem + 4 * C,
           *s_m1 = smem + 5 * C;
@@ -304,32 +333,42 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_flat8_kernel(
     }
     const float ls = lab_s ? lab_s[0] : 1.f;
     __syncthreads();
-    const uint32_t nv = HW >> 3;
-    const int64_t stride = (int64_t)gridDim.x * kBnThreads;
-    for (int64_t v0 = (int64_t)blockIdx.x * kBnThreads + threadIdx.x; v0 < nvec; v0 += 2 * stride) {
-        const int64_t v1 = v0 + stride;
-        const bool has1 = v1 < nvec;
-        const uint4 x0 = *reinterpret_cast<const uint4 *>(x + v0 * 8), g0 = *reinterpret_cast<const uint4 *>(dy + v0 * 8);
+    const uint32_t nv = HW >> 3, n = (uint32_t)nvec;
+    const uint32_t stride = gridDim.x * kBnThreads;
+    const uint32_t sq = stride / nv, sr = stride % nv, cq = sq % C;
+    uint32_t v0 = blockIdx.x * kBnThreads + threadIdx.x;
+    QR p0 = qr_init(v0, nv);
+    uint32_t c0 = p0.q % C;
+    for (; v0 < n;) {
+        const uint32_t v1 = v0 + stride;
+        const QR p1 = qr_step(p0, sq, sr, nv);
+        const uint32_t c1 = chan_step(c0, cq, p1.q != p0.q + sq, C);
+        const bool has1 = v1 < n;
+        const uint4 x0 = *reinterpret_cast<const uint4 *>(x + (int64_t)v0 * 8), g0 = *reinterpret_cast<const uint4 *>(dy + (int64_t)v0 * 8);
         uint4 x1 = make_uint4(0, 0, 0, 0), g1 = make_uint4(0, 0, 0, 0);
-        if (has1) { x1 = *reinterpret_cast<const uint4 *>(x + v1 * 8); g1 = *reinterpret_cast<const uint4 *>(dy + v1 * 8); }
-        auto apply = [&](const uint4 &rx, const uint4 &rg, int64_t v) {
-            const int c = (int)((v / nv) % C);
-            const float mu = s_mu[c], is = s_is[c], sc = s_sc[c], sh = s_sh[c], m0 = s_m0[c], m1 = s_m1[c];
+        if (has1) { x1 = *reinterpret_cast<const uint4 *>(x + (int64_t)v1 * 8); g1 = *reinterpret_cast<const uint4 *>(dy + (int64_t)v1 * 8); }
+        auto apply = [&](const uint4 &rx, const uint4 &rg, int64_t v, uint32_t c) {
+            const float is = s_is[c], sc = s_sc[c], sh = s_sh[c], m1 = s_m1[c];
+            // dx = sc * (dz - m0 - xhat * m1), xhat = x * is - mu * is:  dx = dz * sc + (x * k1 + k0)
+            const float k1 = -sc * is * m1, k0 = -sc * (s_m0[c] - s_mu[c] * is * m1);
+            const float lsc = ls * sc;
             float a[8], g[8], o[8];
             bf16x8_to_f32(rx, a); bf16x8_to_f32(rg, g);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float z = a[e] * sc + sh;
-                const float dz = g[e] * ls * act_grad(z, act);
-                o[e] = sc * (dz - m0 - ((a[e] - mu) * is) * m1);
+                o[e] = (g[e] * lsc) * act_grad(z, act) + (a[e] * k1 + k0);
             }
             uint4 w;
             w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
             w.z = pack_bf16x2(o[4], o[5]); w.w = pack_bf16x2(o[6], o[7]);
             *reinterpret_cast<uint4 *>(dx + v * 8) = w;
         };
-        apply(x0, g0, v0);
-        if (has1) apply(x1, g1, v1);
+        apply(x0, g0, v0, c0);
+        if (has1) apply(x1, g1, v1, c1);
+        v0 = v1 + stride;
+        p0 = qr_step(p1, sq, sr, nv);
+        c0 = chan_step(c1, cq, p0.q != p1.q + sq, C);
     }
 }
 
@@ -392,30 +431,36 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const T *__restric
 }
 
 // partials: [C][nchunk][4] = sum dz, sum dz*xhat, sum dy*act(z), sum dy
-template <typename T>
+// ACT_T: activation as a template parameter (no per-element branches); LAB: the two learnable-affine sums are wanted
+template <typename T, int ACT_T, bool LAB>
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(
     const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ part,
     const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ scale,
     const float *__restrict__ shift, const float *__restrict__ lab_s, int C, int HW, int B,
-    int imgs_per_chunk, int act) {
+    int imgs_per_chunk) {
+    constexpr int act = ACT_T;
     __shared__ float red[4 * kBnThreads / 64];
     const int c = blockIdx.x, chunk = blockIdx.y;
     const int b0 = chunk * imgs_per_chunk, b1 = min(B, b0 + imgs_per_chunk);
     const float mu = mean[c], is = invstd[c], sc = scale[c], sh = shift[c];
-    const float ls = lab_s ? lab_s[0] : 1.f;
+    const float ls = LAB ? lab_s[0] : 1.f;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     auto accum = [&](float xv, float g) {
         const float z = xv * sc + sh;
         const float dz = g * ls * act_grad(z, act);
         v[0] += dz;
-        v[1] += dz * ((xv - mu) * is);
-        v[2] += g * act_fwd(z, act);
-        v[3] += g;
+        v[1] += dz * ((xv - mu) * is);      // not x * is - mu * is: that cancels badly when |mean| >> std (fp32 parity)
+        if (LAB) {
+            v[2] += g * act_fwd(z, act);
+            v[3] += g;
+        }
     };
     if (sizeof(T) == 2 && (HW & 7) == 0) {
         const int nv = HW >> 3, total = (b1 - b0) * nv;
         const uint16_t *xb = reinterpret_cast<const uint16_t *>(x), *gb = reinterpret_cast<const uint16_t *>(dy);
-        constexpr int U = kRedUnroll / 2;                             // two streams -> 4 loads in flight
+        constexpr int U = kRedUnroll;                                 // two streams -> 8 loads in flight
+        const uint32_t sq = kBnThreads / nv, sr = kBnThreads % nv;
+        QR pos = qr_init(threadIdx.x, nv);                            // (image, vector) of i
         for (int i0 = threadIdx.x; i0 < total; i0 += U * kBnThreads) {
             uint4 rx[U], rg[U];
 #pragma unroll
@@ -423,11 +468,11 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(
                 const int i = i0 + j * kBnThreads;
                 rx[j] = make_uint4(0, 0, 0, 0); rg[j] = make_uint4(0, 0, 0, 0);
                 if (i < total) {
-                    const int bi = i / nv, vi = i - bi * nv;
-                    const int64_t off = ((int64_t)(b0 + bi) * C + c) * HW + vi * 8;
+                    const int64_t off = ((int64_t)(b0 + pos.q) * C + c) * HW + pos.r * 8;
                     rx[j] = *reinterpret_cast<const uint4 *>(xb + off);
                     rg[j] = *reinterpret_cast<const uint4 *>(gb + off);
                 }
+                pos = qr_step(pos, sq, sr, nv);
             }
 #pragma unroll
             for (int j = 0; j < U; ++j) {
@@ -605,7 +650,7 @@ __global__ __launch_bounds__(kBnOneThreads) void bn_one_fwd_kernel(const uint16_
     }
 }
 
-template <int VPT, int ACT>
+template <int VPT, int ACT, bool LAB>
 __global__ __launch_bounds__(kBnOneThreads) void bn_one_bwd_kernel(
     const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy, uint16_t *__restrict__ dx,
     const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ scale,
@@ -646,7 +691,7 @@ __global__ __launch_bounds__(kBnOneThreads) void bn_one_bwd_kernel(
         const float h0 = (a0 - mu) * is, h1 = (a1 - mu) * is;
         if (accumulate) {                                         // padded slots carry g = 0 and contribute nothing
             v[0] += d0 + d1; v[1] += d0 * h0 + d1 * h1;
-            v[2] += g0 * act_fwd(z0, act) + g1 * act_fwd(z1, act); v[3] += g0 + g1;
+            if (LAB) { v[2] += g0 * act_fwd(z0, act) + g1 * act_fwd(z1, act); v[3] += g0 + g1; }
         } else {
             o0 = sc * (d0 - m0 - h0 * m1); o1 = sc * (d1 - m0 - h1 * m1);
         }
@@ -688,7 +733,7 @@ __global__ __launch_bounds__(kBnOneThreads) void bn_one_bwd_kernel(
 // Same one-block-per-channel backward for planes whose x + dy do not fit the registers (B * HW up to 65 536): both
 // passes stream the channel from global memory - the second one re-reads what the block itself just pulled into
 // L2 - so it is still one launch without workspace or finalize, just not one read pass.
-template <int ACT>
+template <int ACT, bool LAB>
 __global__ __launch_bounds__(kBnOneThreads) void bn_one_bwd_stream_kernel(
     const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy, uint16_t *__restrict__ dx,
     const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ scale,
@@ -701,17 +746,37 @@ __global__ __launch_bounds__(kBnOneThreads) void bn_one_bwd_stream_kernel(
     const float mu = mean[c], is = invstd[c], sc = scale[c], sh = shift[c];
     const float ls = lab_s ? lab_s[0] : 1.f;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = threadIdx.x; i < nvec; i += kBnOneThreads) {
-        const int b = i / nvhw, r = i - b * nvhw;
-        const int64_t o = ((int64_t)b * C + c) * HW + r * 8;
-        float a[8], g[8];
-        bf16x8_to_f32(*reinterpret_cast<const uint4 *>(x + o), a);
-        bf16x8_to_f32(*reinterpret_cast<const uint4 *>(dy + o), g);
+    // both passes walk the channel in batches of kBatch vectors per thread with all loads of a batch in flight (one
+    // 1024-thread block per channel has no other latency hiding); positions are stepped, not divided
+    constexpr int kBatch = 4;
+    const uint32_t sq = kBnOneThreads / nvhw, sr = kBnOneThreads % nvhw;
+    auto offset = [&](QR p) -> int64_t { return ((int64_t)p.q * C + c) * HW + p.r * 8; };
+    {
+        QR pos = qr_init(threadIdx.x, nvhw);
+        for (int i0 = threadIdx.x; i0 < nvec; i0 += kBatch * kBnOneThreads) {
+            uint4 xr[kBatch], gr[kBatch];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float z = a[e] * sc + sh;
-            const float dz = g[e] * ls * act_grad(z, act);
-            v[0] += dz; v[1] += dz * ((a[e] - mu) * is); v[2] += g[e] * act_fwd(z, act); v[3] += g[e];
+            for (int k = 0; k < kBatch; ++k) {
+                xr[k] = make_uint4(0, 0, 0, 0); gr[k] = make_uint4(0, 0, 0, 0);
+                if (i0 + k * kBnOneThreads < nvec) {
+                    const int64_t o = offset(pos);
+                    xr[k] = *reinterpret_cast<const uint4 *>(x + o);
+                    gr[k] = *reinterpret_cast<const uint4 *>(dy + o);
+                }
+                pos = qr_step(pos, sq, sr, nvhw);
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                float a[8], g[8];
+                bf16x8_to_f32(xr[k], a); bf16x8_to_f32(gr[k], g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {                       // padded slots carry g = 0 and contribute nothing
+                    const float z = a[e] * sc + sh;
+                    const float dz = g[e] * ls * act_grad(z, act);
+                    v[0] += dz; v[1] += dz * ((a[e] - mu) * is);
+                    if (LAB) { v[2] += g[e] * act_fwd(z, act); v[3] += g[e]; }
+                }
+            }
         }
     }
     block_reduce_one<4>(v, red);
@@ -721,22 +786,38 @@ __global__ __launch_bounds__(kBnOneThreads) void bn_one_bwd_stream_kernel(
         if (dbeta) dbeta[c] = v[0];
         if (dlab) { unsafeAtomicAdd(dlab, v[2]); unsafeAtomicAdd(dlab + 1, v[3]); }   // zeroed by the caller
     }
-    for (int i = threadIdx.x; i < nvec; i += kBnOneThreads) {
-        const int b = i / nvhw, r = i - b * nvhw;
-        const int64_t o = ((int64_t)b * C + c) * HW + r * 8;
-        float a[8], g[8], w[8];
-        bf16x8_to_f32(*reinterpret_cast<const uint4 *>(x + o), a);
-        bf16x8_to_f32(*reinterpret_cast<const uint4 *>(dy + o), g);
+    const float k1 = -sc * is * m1, k0 = -sc * (m0 - mu * is * m1), lsc = ls * sc;    // dx = dz * sc + (x * k1 + k0)
+    {
+        QR pos = qr_init(threadIdx.x, nvhw);
+        for (int i0 = threadIdx.x; i0 < nvec; i0 += kBatch * kBnOneThreads) {
+            uint4 xr[kBatch], gr[kBatch];
+            int64_t off[kBatch];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float z = a[e] * sc + sh;
-            const float dz = g[e] * ls * act_grad(z, act);
-            w[e] = sc * (dz - m0 - ((a[e] - mu) * is) * m1);
+            for (int k = 0; k < kBatch; ++k) {
+                off[k] = -1;
+                if (i0 + k * kBnOneThreads < nvec) {
+                    off[k] = offset(pos);
+                    xr[k] = *reinterpret_cast<const uint4 *>(x + off[k]);
+                    gr[k] = *reinterpret_cast<const uint4 *>(dy + off[k]);
+                }
+                pos = qr_step(pos, sq, sr, nvhw);
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                if (off[k] < 0) continue;
+                float a[8], g[8], w[8];
+                bf16x8_to_f32(xr[k], a); bf16x8_to_f32(gr[k], g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float z = a[e] * sc + sh;
+                    w[e] = (g[e] * lsc) * act_grad(z, act) + (a[e] * k1 + k0);
+                }
+                uint4 ov;
+                ov.x = pack_bf16x2(w[0], w[1]); ov.y = pack_bf16x2(w[2], w[3]);
+                ov.z = pack_bf16x2(w[4], w[5]); ov.w = pack_bf16x2(w[6], w[7]);
+                *reinterpret_cast<uint4 *>(dx + off[k]) = ov;
+            }
         }
-        uint4 ov;
-        ov.x = pack_bf16x2(w[0], w[1]); ov.y = pack_bf16x2(w[2], w[3]);
-        ov.z = pack_bf16x2(w[4], w[5]); ov.w = pack_bf16x2(w[6], w[7]);
-        *reinterpret_cast<uint4 *>(dx + o) = ov;
     }
 }
 
@@ -791,7 +872,8 @@ int dfine_bn_act_fwd(const void *x, void *y, const float *gamma, const float *be
             hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(C, nchunk), dim3(kBnThreads), 0, st, (const float *)x, ws, C, HW, B, per);
         else
             hipLaunchKernelGGL(bn_stats_kernel<uint16_t>, dim3(C, nchunk), dim3(kBnThreads), 0, st, (const uint16_t *)x, ws, C, HW, B, per);
-        fuse_fin = dtype != DFINE_F32 && (HW & 7) == 0 && C <= 4096 && (int64_t)C * nchunk <= kBnFuseMax;
+        fuse_fin = dtype != DFINE_F32 && (HW & 7) == 0 && C <= 4096 && (int64_t)C * nchunk <= kBnFuseMax &&
+                   (int64_t)B * C * HW / 8 < (int64_t)1 << 31;       // = the conditions of the flat8 apply kernel below
         if (fuse_fin)
             ffin = BnFusedFin{ws, nchunk, (double)B * HW, gamma, beta, running_mean, running_var, save_mean, save_invstd,
                               scale, shift, momentum, eps};
@@ -807,12 +889,14 @@ int dfine_bn_act_fwd(const void *x, void *y, const float *gamma, const float *be
         int64_t nb = (nvec + kBnThreads * 4 - 1) / (kBnThreads * 4);
         if (nb > 4096) nb = 4096;
         const size_t sm = sizeof(float) * 2 * C;
-        if (dtype != DFINE_F32 && (HW & 7) == 0) {
+        if (dtype != DFINE_F32 && (HW & 7) == 0 && nvec / 2 < (int64_t)1 << 31) {
             const int64_t nvec8 = nvec / 2;
             int64_t nb8 = (nvec8 + kBnThreads * 4 - 1) / (kBnThreads * 4);
             if (nb8 > 4096) nb8 = 4096;
-            hipLaunchKernelGGL(bn_apply_flat8_kernel, dim3((unsigned)nb8), dim3(kBnThreads), sm, st, (const uint16_t *)x,
-                               (uint16_t *)y, scale, shift, lab_scale, lab_bias, C, HW, nvec8, act, ffin);
+#define DFINE_BNA8(A) hipLaunchKernelGGL(bn_apply_flat8_kernel<A>, dim3((unsigned)nb8), dim3(kBnThreads), sm, st, (const uint16_t *)x, \
+                                         (uint16_t *)y, scale, shift, lab_scale, lab_bias, C, HW, nvec8, ffin)
+            if (act == 0) DFINE_BNA8(0); else if (act == 1) DFINE_BNA8(1); else DFINE_BNA8(2);
+#undef DFINE_BNA8
             return check_launch();
         }
         if (dtype == DFINE_F32)
@@ -843,20 +927,25 @@ int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_
     // backward: only while x AND dy of the channel fit the 128-VGPR budget of a 1024-thread block (<= 2 vectors per
     // thread = B * HW <= 16 384: the 20x20 planes); the 8-vector instantiation spills ~260 registers
     if (training && bn_one_ok(dtype, B, HW, &vpt) && vpt <= 2) {
-#define DFINE_BN1B(V, A) hipLaunchKernelGGL((bn_one_bwd_kernel<V, A>), dim3(C), dim3(kBnOneThreads), 0, st, (const uint16_t *)x, \
-                                            (const uint16_t *)dy, (uint16_t *)dx, save_mean, save_invstd, scale, shift, lab_scale, \
-                                            dgamma, dbeta, dlab, C, HW, B, (double)B * HW)
-#define DFINE_BN1B_A(V) { if (act == 0) DFINE_BN1B(V, 0); else if (act == 1) DFINE_BN1B(V, 1); else DFINE_BN1B(V, 2); }
+#define DFINE_BN1B(V, A, LB) hipLaunchKernelGGL((bn_one_bwd_kernel<V, A, LB>), dim3(C), dim3(kBnOneThreads), 0, st, (const uint16_t *)x, \
+                                                (const uint16_t *)dy, (uint16_t *)dx, save_mean, save_invstd, scale, shift, lab_scale, \
+                                                dgamma, dbeta, dlab, C, HW, B, (double)B * HW)
+#define DFINE_BN1B_L(V, A) { if (lab_scale) DFINE_BN1B(V, A, true); else DFINE_BN1B(V, A, false); }
+#define DFINE_BN1B_A(V) { if (act == 0) DFINE_BN1B_L(V, 0) else if (act == 1) DFINE_BN1B_L(V, 1) else DFINE_BN1B_L(V, 2) }
         if (vpt == 1) DFINE_BN1B_A(1) else DFINE_BN1B_A(2)
+#undef DFINE_BN1B_L
 #undef DFINE_BN1B_A
 #undef DFINE_BN1B
         return check_launch();
     }
-    if (training && bn_one_ok(dtype, B, HW, &vpt)) {              // 3 .. 8 vectors per thread: streaming variant
-#define DFINE_BN1S(A) hipLaunchKernelGGL((bn_one_bwd_stream_kernel<A>), dim3(C), dim3(kBnOneThreads), 0, st, (const uint16_t *)x, \
-                                         (const uint16_t *)dy, (uint16_t *)dx, save_mean, save_invstd, scale, shift, lab_scale, \
-                                         dgamma, dbeta, dlab, C, HW, B, (double)B * HW)
-        if (act == 0) DFINE_BN1S(0); else if (act == 1) DFINE_BN1S(1); else DFINE_BN1S(2);
+    // 3 .. 8 vectors per thread: streaming variant (measured equal to the two-kernel path below for C < 256, one launch less)
+    if (training && bn_one_ok(dtype, B, HW, &vpt)) {
+#define DFINE_BN1S(A, LB) hipLaunchKernelGGL((bn_one_bwd_stream_kernel<A, LB>), dim3(C), dim3(kBnOneThreads), 0, st, (const uint16_t *)x, \
+                                             (const uint16_t *)dy, (uint16_t *)dx, save_mean, save_invstd, scale, shift, lab_scale, \
+                                             dgamma, dbeta, dlab, C, HW, B, (double)B * HW)
+#define DFINE_BN1S_L(A) { if (lab_scale) DFINE_BN1S(A, true); else DFINE_BN1S(A, false); }
+        if (act == 0) DFINE_BN1S_L(0) else if (act == 1) DFINE_BN1S_L(1) else DFINE_BN1S_L(2)
+#undef DFINE_BN1S_L
 #undef DFINE_BN1S
         return check_launch();
     }
@@ -864,14 +953,17 @@ int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_
     const int nchunk = chunks_for(B, C, HW, &per);
     float *coef = ws + (int64_t)C * nchunk * 4;
     // the reductions are needed for the parameter gradients in both modes
-    if (dtype == DFINE_F32)
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(C, nchunk), dim3(kBnThreads), 0, st, (const float *)x, (const float *)dy,
-                           ws, save_mean ? save_mean : scale, save_invstd ? save_invstd : scale, scale, shift, lab_scale, C, HW, B, per, act);
-    else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<uint16_t>, dim3(C, nchunk), dim3(kBnThreads), 0, st, (const uint16_t *)x,
-                           (const uint16_t *)dy, ws, save_mean ? save_mean : scale, save_invstd ? save_invstd : scale, scale, shift,
-                           lab_scale, C, HW, B, per, act);
-    const bool fuse_fin = dtype != DFINE_F32 && (HW & 7) == 0 && (HW & 3) == 0 && C <= 2048 && (int64_t)C * nchunk <= kBnFuseMax;
+#define DFINE_BNR(TT, A, LB) hipLaunchKernelGGL((bn_bwd_reduce_kernel<TT, A, LB>), dim3(C, nchunk), dim3(kBnThreads), 0, st, \
+                                                (const TT *)x, (const TT *)dy, ws, save_mean ? save_mean : scale,               \
+                                                save_invstd ? save_invstd : scale, scale, shift, lab_scale, C, HW, B, per)
+#define DFINE_BNR_A(TT, LB) { if (act == 0) DFINE_BNR(TT, 0, LB); else if (act == 1) DFINE_BNR(TT, 1, LB); else DFINE_BNR(TT, 2, LB); }
+    // without a learnable affine the two extra sums stay zero (the partial buffer slots are still written)
+    if (dtype == DFINE_F32) { if (lab_scale) DFINE_BNR_A(float, true) else DFINE_BNR_A(float, false) }
+    else { if (lab_scale) DFINE_BNR_A(uint16_t, true) else DFINE_BNR_A(uint16_t, false) }
+#undef DFINE_BNR_A
+#undef DFINE_BNR
+    const bool fuse_fin = dtype != DFINE_F32 && (HW & 7) == 0 && (HW & 3) == 0 && C <= 2048 && (int64_t)C * nchunk <= kBnFuseMax &&
+                          (int64_t)B * C * HW / 8 < (int64_t)1 << 31;
     BnFusedBwdFin bfin{};
     if (fuse_fin)
         bfin = BnFusedBwdFin{ws, nchunk, (double)B * HW, dgamma, dbeta, dlab, coef};
@@ -883,13 +975,15 @@ int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_
         int64_t nb = (nvec + kBnThreads * 4 - 1) / (kBnThreads * 4);
         if (nb > 4096) nb = 4096;
         const size_t sm = sizeof(float) * 6 * C;
-        if (dtype != DFINE_F32 && (HW & 7) == 0) {
+        if (dtype != DFINE_F32 && (HW & 7) == 0 && nvec / 2 < (int64_t)1 << 31) {
             const int64_t nvec8 = nvec / 2;
             int64_t nb8 = (nvec8 + kBnThreads * 4 - 1) / (kBnThreads * 4);
             if (nb8 > 4096) nb8 = 4096;
-            hipLaunchKernelGGL(bn_bwd_apply_flat8_kernel, dim3((unsigned)nb8), dim3(kBnThreads), sm, st, (const uint16_t *)x,
-                               (const uint16_t *)dy, (uint16_t *)dx, save_mean, save_invstd, scale, shift, lab_scale, coef, C, HW,
-                               nvec8, act, training, bfin);
+#define DFINE_BNB8(A) hipLaunchKernelGGL(bn_bwd_apply_flat8_kernel<A>, dim3((unsigned)nb8), dim3(kBnThreads), sm, st, (const uint16_t *)x, \
+                                         (const uint16_t *)dy, (uint16_t *)dx, save_mean, save_invstd, scale, shift, lab_scale, coef, \
+                                         C, HW, nvec8, training, bfin)
+            if (act == 0) DFINE_BNB8(0); else if (act == 1) DFINE_BNB8(1); else DFINE_BNB8(2);
+#undef DFINE_BNB8
             return check_launch();
         }
         if (dtype == DFINE_F32)

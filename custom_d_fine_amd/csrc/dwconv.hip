@@ -222,10 +222,10 @@ template <> struct DwVec<8> {
     }
     static __device__ __forceinline__ uint4 pack(const float (&o)[8]) {
         uint4 r;
-        r.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-        r.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
-        r.z = (uint32_t)f32_to_bf16(o[4]) | ((uint32_t)f32_to_bf16(o[5]) << 16);
-        r.w = (uint32_t)f32_to_bf16(o[6]) | ((uint32_t)f32_to_bf16(o[7]) << 16);
+        r.x = pack_bf16x2(o[0], o[1]);
+        r.y = pack_bf16x2(o[2], o[3]);
+        r.z = pack_bf16x2(o[4], o[5]);
+        r.w = pack_bf16x2(o[6], o[7]);
         return r;
     }
 };
@@ -237,8 +237,8 @@ template <> struct DwVec<4> {
     }
     static __device__ __forceinline__ uint2 pack(const float (&o)[4]) {
         uint2 r;
-        r.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-        r.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+        r.x = pack_bf16x2(o[0], o[1]);
+        r.y = pack_bf16x2(o[2], o[3]);
         return r;
     }
 };

@@ -29,7 +29,7 @@ constexpr int kGBN = 128, kGBK = 64, kGPitch = 72;
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == 1) return fmaxf(v, 0.f);
     if (act == 2) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));      // exact GELU (nn.GELU default)
-    if (act == 3) return v / (1.f + __expf(-v));
+    if (act == 3) return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
     return v;
 }
 
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(kGemmThreads) void linear_act_kernel(const uint16_t
                 uint16_t *yp = reinterpret_cast<uint16_t *>(yv) + (int64_t)m * ldy + n;
                 if (vec_y && n + 3 < N) {
                     uint2 o;
-                    o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
                     *reinterpret_cast<uint2 *>(yp) = o;
                 } else {
                     for (int r = 0; r < 4 && n + r < N; ++r) yp[r] = f32_to_bf16(v[r]);
@@ -207,10 +207,10 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const uint16_t *__restrict
                 g0 *= 0.5f * (1.f + erff(z0 * c)) + z0 * k * __expf(-0.5f * z0 * z0);
                 g1 *= 0.5f * (1.f + erff(z1 * c)) + z1 * k * __expf(-0.5f * z1 * z1);
             } else if (ACT == 3) {
-                const float s0 = 1.f / (1.f + __expf(-z0)), s1 = 1.f / (1.f + __expf(-z1));
+                const float s0 = __builtin_amdgcn_rcpf(1.f + __expf(-z0)), s1 = __builtin_amdgcn_rcpf(1.f + __expf(-z1));
                 g0 *= s0 * (1.f + z0 * (1.f - s0)); g1 *= s1 * (1.f + z1 * (1.f - s1));
             }
-            o[j] = (uint32_t)f32_to_bf16(g0) | ((uint32_t)f32_to_bf16(g1) << 16);
+            o[j] = pack_bf16x2(g0, g1);
         }
         reinterpret_cast<uint4 *>(out)[i] = make_uint4(o[0], o[1], o[2], o[3]);
     }
@@ -225,8 +225,7 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const uint16_t *__restrict
         uint32_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            o[j] = (uint32_t)f32_to_bf16(act_apply(__uint_as_float(dw[j] << 16), ACT)) |
-                   ((uint32_t)f32_to_bf16(act_apply(__uint_as_float(dw[j] & 0xffff0000u), ACT)) << 16);
+            o[j] = pack_bf16x2(act_apply(__uint_as_float(dw[j] << 16), ACT), act_apply(__uint_as_float(dw[j] & 0xffff0000u), ACT));
         reinterpret_cast<uint4 *>(y)[i] = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }

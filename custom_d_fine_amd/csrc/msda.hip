@@ -205,10 +205,10 @@ __global__ __launch_bounds__(kThreads) void msda_fwd8_kernel(
         }
     }
     uint4 o;
-    o.x = (uint32_t)f32_to_bf16(acc[0]) | ((uint32_t)f32_to_bf16(acc[1]) << 16);
-    o.y = (uint32_t)f32_to_bf16(acc[2]) | ((uint32_t)f32_to_bf16(acc[3]) << 16);
-    o.z = (uint32_t)f32_to_bf16(acc[4]) | ((uint32_t)f32_to_bf16(acc[5]) << 16);
-    o.w = (uint32_t)f32_to_bf16(acc[6]) | ((uint32_t)f32_to_bf16(acc[7]) << 16);
+    o.x = pack_bf16x2(acc[0], acc[1]);
+    o.y = pack_bf16x2(acc[2], acc[3]);
+    o.z = pack_bf16x2(acc[4], acc[5]);
+    o.w = pack_bf16x2(acc[6], acc[7]);
     *reinterpret_cast<uint4 *>(out + ((int64_t)gq * H + head) * D + c8) = o;
 }
 

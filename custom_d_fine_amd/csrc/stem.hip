@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kStemThreads) void stem_dgrad_s2_kernel(const uint1
     uint16_t *o = dx + ((int64_t)b * CIN * H + yi) * W + 2 * c;
 #pragma unroll
     for (int ci = 0; ci < CIN; ++ci)
-        *reinterpret_cast<uint32_t *>(o + (int64_t)ci * H * W) = (uint32_t)f32_to_bf16(a0[ci]) | ((uint32_t)f32_to_bf16(a1[ci]) << 16);
+        *reinterpret_cast<uint32_t *>(o + (int64_t)ci * H * W) = pack_bf16x2(a0[ci], a1[ci]);
 }
 
 // 8 bf16 elements x[xi0 + j*S], j = 0..7, of one plane row as a packed MFMA fragment (0 outside [0, W)).
@@ -343,10 +343,10 @@ __device__ __forceinline__ void unpack8(const uint4 &v, float (&o)[8]) {
 }
 __device__ __forceinline__ uint4 pack8(const float (&o)[8]) {
     uint4 r;
-    r.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-    r.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
-    r.z = (uint32_t)f32_to_bf16(o[4]) | ((uint32_t)f32_to_bf16(o[5]) << 16);
-    r.w = (uint32_t)f32_to_bf16(o[6]) | ((uint32_t)f32_to_bf16(o[7]) << 16);
+    r.x = pack_bf16x2(o[0], o[1]);
+    r.y = pack_bf16x2(o[2], o[3]);
+    r.z = pack_bf16x2(o[4], o[5]);
+    r.w = pack_bf16x2(o[6], o[7]);
     return r;
 }
 // row[-1 .. 8] of a plane row around column x0 (x0 % 8 == 0): e[0] = column x0-1, e[1..8] = x0..x0+7, e[9] = x0+8;
