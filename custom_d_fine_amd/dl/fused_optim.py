@@ -192,6 +192,13 @@ class FusedAdamWEMA:
         [dst_offset, dst_offset + Cout * Cin * taps)."""
         self._deferred.append((index, self._grad_offsets[index] + dst_offset, ws, ws_offset, meta))
 
+    def grad_offset(self, index):
+        return self._grad_offsets[index]
+
+    def grad_ptr(self, index):
+        """Device address of parameter `index`'s slot in the flat gradient buffer (for kernels that ADD into it)."""
+        return self.flat_grad.data_ptr() + 4 * self._grad_offsets[index]
+
     def note_use(self, index):
         """A forward op will deliver parameter `index`'s gradient through defer_wgrad (one call per use of the parameter)."""
         self._uses[index] = self._uses.get(index, 0) + 1
@@ -241,8 +248,10 @@ class FusedAdamWEMA:
         b = self._buckets[bi]
         n = len(b["params"])
 
-        def hook(_param):
-            if self.accumulating:
+        def hook(param):
+            # (the hook also fires, with .grad still None, for a parameter whose backward op returned no tensor because it
+            # delivered the gradient through defer_wgrad / straight into the flat buffer: those report through param_ready)
+            if self.accumulating or param.grad is None:
                 return
             b["ready"] += 1
             if b["ready"] == n:
@@ -289,6 +298,9 @@ class FusedAdamWEMA:
         for b in self._buckets:
             if not b["done"]:
                 self._reduce_bucket(b)
+        if self._deferred:
+            raise RuntimeError(f"{len(self._deferred)} deferred weight gradients were registered after their bucket had "
+                               "been reduced (bucket bookkeeping out of step with the backward ops)")
         for w in self._works:
             w.wait()                         # the compute stream waits for the communication stream; the host does not block
         self._works.clear()

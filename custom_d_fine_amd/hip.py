@@ -398,23 +398,28 @@ def bn_act_forward(x, gamma, beta, running_mean, running_var, lab_scale, lab_bia
     return y, stats
 
 
-def bn_act_backward(x, dy, stats, lab_scale, act, training, need_affine=True, need_lab=True):
+def bn_act_backward(x, dy, stats, lab_scale, act, training, need_affine=True, need_lab=True, dlab_ptr=None):
+    """-> (dx, dgamma, dbeta, dlab).  dgamma / dbeta are two separate tensors (autograd's AccumulateGrad takes ownership
+    of a whole tensor but has to copy a view: 2 x 133 small device copies per D-FINE-m step).  `dlab_ptr`: device address
+    of two adjacent floats the kernel ADDS the learnable-affine gradients to (the fused optimizer's flat gradient slots);
+    then no dlab tensor is made."""
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // max(B * C, 1)
     dev = x.device
     dx = torch.empty_like(x)
-    dparam = torch.empty(2, C, device=dev, dtype=torch.float32) if need_affine else None
-    dlab = torch.zeros(2, device=dev, dtype=torch.float32) if need_lab else None
+    dgamma = torch.empty(C, device=dev, dtype=torch.float32) if need_affine else None
+    dbeta = torch.empty(C, device=dev, dtype=torch.float32) if need_affine else None
+    dlab = torch.zeros(2, device=dev, dtype=torch.float32) if (need_lab and dlab_ptr is None) else None
     ws = _bn_workspace(dev, _bn_ws_need(B, C, HW))
     sp = stats.data_ptr()
     row = 4 * C
-    dpp = dparam.data_ptr() if need_affine else None
+    dl = dlab_ptr if (need_lab and dlab_ptr is not None) else _ptr(dlab)
     status = _lib.dfine_bn_act_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), sp, sp + row, sp + 2 * row, sp + 3 * row,
-                                   _ptr(lab_scale), dpp, (dpp + row) if need_affine else None, _ptr(dlab), ws.data_ptr(),
+                                   _ptr(lab_scale), _ptr(dgamma), _ptr(dbeta), dl, ws.data_ptr(),
                                    _DTYPE[x.dtype], B, C, HW, _ACT[act], 1 if training else 0, _stream())
     if status != 0:
         _check(status, "dfine_bn_act_bwd")
-    return dx, dparam, dlab
+    return dx, dgamma, dbeta, dlab
 
 
 # ------------------------------------------------------------------------------------- losses
@@ -870,12 +875,13 @@ def ln_fused_backward(mode, a, b, gate, weight, mean, rstd, dy, clampv, need_a, 
     da = torch.empty_like(a) if need_a else None
     db = torch.empty_like(b) if (need_b and b is not None) else None
     dg = torch.empty_like(gate) if (need_gate and gate is not None) else None
-    dwb = ws = None
+    dw = dbias = ws = None
     if need_affine:
-        dwb = torch.empty(2, D, device=a.device, dtype=torch.float32)
+        # two tensors, not two rows of one: AccumulateGrad adopts a whole tensor but copies a view
+        dw = torch.empty(D, device=a.device, dtype=torch.float32)
+        dbias = torch.empty(D, device=a.device, dtype=torch.float32)
         ws = torch.empty(int(_lib.dfine_ln_fused_bwd_ws_floats(rows, D)), device=a.device, dtype=torch.float32)
     _check(_lib.dfine_ln_fused_bwd(mode, _ptr(a), _dt(a), _ptr(b), _dt(b), _ptr(gate), _dt(gate), _ptr(weight), _ptr(mean),
-                                   _ptr(rstd), _ptr(dy), float(clampv), _ptr(da), _ptr(db), _ptr(dg),
-                                   _ptr(dwb[0]) if need_affine else None, _ptr(dwb[1]) if need_affine else None, _ptr(ws),
-                                   rows, D, _stream()), "dfine_ln_fused_bwd")
-    return da, db, dg, (dwb[0] if need_affine else None), (dwb[1] if need_affine else None)
+                                   _ptr(rstd), _ptr(dy), float(clampv), _ptr(da), _ptr(db), _ptr(dg), _ptr(dw), _ptr(dbias),
+                                   _ptr(ws), rows, D, _stream()), "dfine_ln_fused_bwd")
+    return da, db, dg, dw, dbias

@@ -255,6 +255,15 @@ class _BNAct(torch.autograd.Function):
                                          act, training, momentum, eps)
         ctx.save_for_backward(x, stats, lab_scale)
         ctx.cfg = (act, training, gamma is not None, lab_scale is not None)
+        # learnable affine: the backward kernel adds its two scalars straight into the fused optimizer's flat gradient
+        # buffer when scale and bias sit next to each other there (they do: consecutive parameters of one module)
+        ctx.slot = None
+        if lab_scale is not None and lab_bias is not None and ctx.needs_input_grad[3] and ctx.needs_input_grad[4]:
+            slot = _defer_slot(lab_scale, lab_bias)
+            if slot is not None and slot[0].grad_offset(slot[1][1]) == slot[0].grad_offset(slot[1][0]) + 1:
+                ctx.slot = slot
+                for i in slot[1]:
+                    slot[0].note_use(i)
         return y
 
     @staticmethod
@@ -264,11 +273,15 @@ class _BNAct(torch.autograd.Function):
         dy = dy.contiguous()
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
-        dx, dparam, dlab = _hip().bn_act_backward(x, dy, stats, lab_scale, act, training, has_affine, has_lab)
-        dg = dparam[0] if has_affine else None
-        db = dparam[1] if has_affine else None
-        dls = dlab[0:1] if has_lab else None
-        dlb = dlab[1:2] if has_lab else None
+        slot = ctx.slot
+        dlab_ptr = slot[0].grad_ptr(slot[1][0]) if slot is not None else None
+        dx, dg, db, dlab = _hip().bn_act_backward(x, dy, stats, lab_scale, act, training, has_affine, has_lab, dlab_ptr)
+        dls = dlb = None
+        if slot is not None:
+            for i in slot[1]:
+                slot[0].use_done(i)
+        elif has_lab:
+            dls, dlb = dlab[0:1], dlab[1:2]
         return dx, dg, db, dls, dlb, None, None, None, None, None, None
 
 

@@ -70,6 +70,29 @@ def _worker(rank, world, port, out_dir, overlap):
     assert torch.equal(fused.flat_grad, twin_fused.flat_grad), "bucketed and single-shot reductions differ"
     assert fused.flat_grad.abs().sum() > 0
     fused.flat_grad.zero_()
+    twin_fused.flat_grad.zero_()
+    # ---- the same comparison on a REAL backward (conv / linear weight gradients arrive through defer_wgrad, the learnable
+    # affine scalars straight in the flat buffer, the rest through autograd hooks): no parameter may lose its gradient to
+    # a bucket that was reduced too early.  Atomics make two backward passes differ in the last bits, hence tolerances.
+    for f, mdl in ((fused, model), (twin_fused, twin)):
+        torch.manual_seed(7 + rank)                     # same denoising noise for both
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = mdl(images, targets=targets)
+        with torch.autocast("cuda", enabled=False):
+            ld = crit(out, targets)
+        f.accumulating = False
+        crit.total(ld).backward()
+        f._collect_grads()
+        f._uses.clear()
+    torch.cuda.synchronize()
+    ga, gb = fused.flat_grad, twin_fused.flat_grad
+    assert torch.isfinite(ga).all() and torch.isfinite(gb).all()
+    for i, p in enumerate(fused._params):
+        o = fused.grad_offset(i)
+        za, zb = bool((ga[o:o + p.numel()] != 0).any()), bool((gb[o:o + p.numel()] != 0).any())
+        assert za == zb, f"parameter {i}: gradient present in one reduction mode only"
+    assert (ga - gb).norm() <= 0.05 * gb.norm(), ((ga - gb).norm().item(), gb.norm().item())
+    fused.flat_grad.zero_()
     del twin, twin_opt, twin_fused
 
     losses = []
