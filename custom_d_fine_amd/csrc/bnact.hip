@@ -565,6 +565,204 @@ static int chunks_for(int B, int C, int HW, int *imgs_per_chunk) {
     return (B + per - 1) / per;
 }
 
+// ---- RepVGG unit: act(BN_a(x1) + BN_b(x2)) [+ residual] as one op ----------------------------------------------------
+// Reference: VGGBlock.forward = act(conv1(x) + conv2(x)) with two ConvNormLayers (src/d_fine/arch/hybrid_encoder.py:106-156)
+// and CSPLayer's `bottlenecks(...) + conv2(x)` (hybrid_encoder.py:209-239): BN apply x2, add, activation, add = 11 passes
+// over the map in the forward and 13 in the backward (activation backward + two BN backwards).  Here: two statistics
+// passes + ONE apply pass (2R [+1R] + 1W), and in the backward ONE reduction pass (3R) + ONE apply pass (3R + 2W), both
+// branches sharing dz = dy * act'(z), z = BN_a(x1) + BN_b(x2).  bf16, H*W % 8 == 0, C * nchunk <= kBnFuseMax.
+struct Bn2Saved {                      // per-channel rows saved by the forward for the backward
+    float *mean, *invstd, *scale, *shift;
+};
+
+__device__ __forceinline__ void bn_fold_channel(const BnFusedFin &fin, int c, bool publish, float &sc, float &sh) {
+    double sm = 0.0, ss = 0.0;
+    for (int k = 0; k < fin.nchunk; ++k) {
+        sm += (double)fin.part[((int64_t)c * fin.nchunk + k) * 2];
+        ss += (double)fin.part[((int64_t)c * fin.nchunk + k) * 2 + 1];
+    }
+    const double mean = sm / fin.count;
+    double var = ss / fin.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)fin.eps));
+    const float g = fin.gamma ? fin.gamma[c] : 1.f, bt = fin.beta ? fin.beta[c] : 0.f;
+    sc = g * invstd; sh = bt - (float)mean * g * invstd;
+    if (publish) {
+        fin.mean_out[c] = (float)mean; fin.invstd_out[c] = invstd;
+        fin.scale_out[c] = sc; fin.shift_out[c] = sh;
+        if (fin.running_mean) {
+            const double unbiased = fin.count > 1.0 ? var * fin.count / (fin.count - 1.0) : var;
+            fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * (float)mean;
+            fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unbiased;
+        }
+    }
+}
+
+template <int ACT_T, bool RES>
+__global__ __launch_bounds__(kBnThreads) void bn2_apply_flat8_kernel(
+    const uint16_t *__restrict__ x1, const uint16_t *__restrict__ x2, const uint16_t *__restrict__ res,
+    uint16_t *__restrict__ y, int C, int HW, int64_t nvec, BnFusedFin fin1, BnFusedFin fin2) {
+    constexpr int act = ACT_T;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_a = smem, *s_b = smem + C, *s_sh = smem + 2 * C;
+    for (int c = threadIdx.x; c < C; c += kBnThreads) {
+        float sa, ha, sb, hb;
+        bn_fold_channel(fin1, c, blockIdx.x == 0, sa, ha);
+        bn_fold_channel(fin2, c, blockIdx.x == 0, sb, hb);
+        s_a[c] = sa; s_b[c] = sb; s_sh[c] = ha + hb;
+    }
+    __syncthreads();
+    const uint32_t nv = HW >> 3, n = (uint32_t)nvec;
+    const uint32_t stride = gridDim.x * kBnThreads;
+    const uint32_t sq = stride / nv, sr = stride % nv, cq = sq % C;
+    uint32_t v = blockIdx.x * kBnThreads + threadIdx.x;
+    QR pos = qr_init(v, nv);
+    uint32_t c = pos.q % C;
+    for (; v < n;) {
+        const uint4 r1 = *reinterpret_cast<const uint4 *>(x1 + (int64_t)v * 8);
+        const uint4 r2 = *reinterpret_cast<const uint4 *>(x2 + (int64_t)v * 8);
+        uint4 rr = make_uint4(0, 0, 0, 0);
+        if (RES) rr = *reinterpret_cast<const uint4 *>(res + (int64_t)v * 8);
+        const float sa = s_a[c], sb = s_b[c], sh = s_sh[c];
+        float a[8], b[8], r[8];
+        bf16x8_to_f32(r1, a); bf16x8_to_f32(r2, b); bf16x8_to_f32(rr, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[e] = act_fwd(a[e] * sa + (b[e] * sb + sh), act);
+            if (RES) a[e] += r[e];
+        }
+        uint4 o;
+        o.x = pack_bf16x2(a[0], a[1]); o.y = pack_bf16x2(a[2], a[3]);
+        o.z = pack_bf16x2(a[4], a[5]); o.w = pack_bf16x2(a[6], a[7]);
+        *reinterpret_cast<uint4 *>(y + (int64_t)v * 8) = o;
+        v += stride;
+        const QR nx = qr_step(pos, sq, sr, nv);
+        c = chan_step(c, cq, nx.q != pos.q + sq, C);
+        pos = nx;
+    }
+}
+
+// partials [C][nchunk][4] = sum dz, sum dz * xhat1, sum dz * xhat2, -
+template <int ACT_T>
+__global__ __launch_bounds__(kBnThreads) void bn2_bwd_reduce_kernel(
+    const uint16_t *__restrict__ x1, const uint16_t *__restrict__ x2, const uint16_t *__restrict__ dy,
+    float *__restrict__ part, Bn2Saved s1, Bn2Saved s2, int C, int HW, int B, int imgs_per_chunk) {
+    constexpr int act = ACT_T;
+    __shared__ float red[4 * kBnThreads / 64];
+    const int c = blockIdx.x, chunk = blockIdx.y;
+    const int b0 = chunk * imgs_per_chunk, b1 = min(B, b0 + imgs_per_chunk);
+    const float mu1 = s1.mean[c], is1 = s1.invstd[c], sa = s1.scale[c];
+    const float mu2 = s2.mean[c], is2 = s2.invstd[c], sb = s2.scale[c];
+    const float sh = s1.shift[c] + s2.shift[c];
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nv = HW >> 3, total = (b1 - b0) * nv;
+    const uint32_t sq = kBnThreads / nv, sr = kBnThreads % nv;
+    QR pos = qr_init(threadIdx.x, nv);
+    constexpr int U = 2;                                       // three streams -> 6 loads in flight
+    for (int i0 = threadIdx.x; i0 < total; i0 += U * kBnThreads) {
+        uint4 ra[U], rb[U], rg[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            ra[j] = make_uint4(0, 0, 0, 0); rb[j] = ra[j]; rg[j] = ra[j];
+            if (i0 + j * kBnThreads < total) {
+                const int64_t off = ((int64_t)(b0 + pos.q) * C + c) * HW + pos.r * 8;
+                ra[j] = *reinterpret_cast<const uint4 *>(x1 + off);
+                rb[j] = *reinterpret_cast<const uint4 *>(x2 + off);
+                rg[j] = *reinterpret_cast<const uint4 *>(dy + off);
+            }
+            pos = qr_step(pos, sq, sr, nv);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            float a[8], b[8], g[8];
+            bf16x8_to_f32(ra[j], a); bf16x8_to_f32(rb[j], b); bf16x8_to_f32(rg[j], g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {                            // padded slots carry g = 0 and contribute nothing
+                const float z = a[e] * sa + (b[e] * sb + sh);
+                const float dz = g[e] * act_grad(z, act);
+                v[0] += dz; v[1] += dz * ((a[e] - mu1) * is1); v[2] += dz * ((b[e] - mu2) * is2);
+            }
+        }
+    }
+    block_reduce<4>(v, red);
+    if (threadIdx.x == 0) {
+        float *o = part + ((int64_t)c * gridDim.y + chunk) * 4;
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = 0.f;
+    }
+}
+
+template <int ACT_T>
+__global__ __launch_bounds__(kBnThreads) void bn2_bwd_apply_flat8_kernel(
+    const uint16_t *__restrict__ x1, const uint16_t *__restrict__ x2, const uint16_t *__restrict__ dy,
+    uint16_t *__restrict__ dx1, uint16_t *__restrict__ dx2, Bn2Saved s1, Bn2Saved s2, const float *__restrict__ part,
+    int nchunk, double count, float *__restrict__ dgamma1, float *__restrict__ dbeta1, float *__restrict__ dgamma2,
+    float *__restrict__ dbeta2, int C, int HW, int64_t nvec) {
+    constexpr int act = ACT_T;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // per channel: z = x1 * sa + x2 * sb + sh;  dx1 = dz * sa + (x1 * k1a + k0a);  dx2 = dz * sb + (x2 * k1b + k0b)
+    float *s_sa = smem, *s_sb = smem + C, *s_sh = smem + 2 * C, *s_k1a = smem + 3 * C, *s_k0a = smem + 4 * C,
+          *s_k1b = smem + 5 * C, *s_k0b = smem + 6 * C;
+    for (int c = threadIdx.x; c < C; c += kBnThreads) {
+        double t0 = 0, t1 = 0, t2 = 0;
+        for (int k = 0; k < nchunk; ++k) {
+            const float *p = part + ((int64_t)c * nchunk + k) * 4;
+            t0 += p[0]; t1 += p[1]; t2 += p[2];
+        }
+        const float m0 = (float)(t0 / count), m1 = (float)(t1 / count), m2 = (float)(t2 / count);
+        const float sa = s1.scale[c], sb = s2.scale[c];
+        const float is1 = s1.invstd[c], mu1 = s1.mean[c], is2 = s2.invstd[c], mu2 = s2.mean[c];
+        s_sa[c] = sa; s_sb[c] = sb; s_sh[c] = s1.shift[c] + s2.shift[c];
+        s_k1a[c] = -sa * is1 * m1; s_k0a[c] = -sa * (m0 - mu1 * is1 * m1);
+        s_k1b[c] = -sb * is2 * m2; s_k0b[c] = -sb * (m0 - mu2 * is2 * m2);
+        if (blockIdx.x == 0) {
+            if (dgamma1) dgamma1[c] = (float)t1;
+            if (dbeta1) dbeta1[c] = (float)t0;
+            if (dgamma2) dgamma2[c] = (float)t2;
+            if (dbeta2) dbeta2[c] = (float)t0;
+        }
+    }
+    __syncthreads();
+    const uint32_t nv = HW >> 3, n = (uint32_t)nvec;
+    const uint32_t stride = gridDim.x * kBnThreads;
+    const uint32_t sq = stride / nv, sr = stride % nv, cq = sq % C;
+    uint32_t v = blockIdx.x * kBnThreads + threadIdx.x;
+    QR pos = qr_init(v, nv);
+    uint32_t c = pos.q % C;
+    for (; v < n;) {
+        const uint4 r1 = *reinterpret_cast<const uint4 *>(x1 + (int64_t)v * 8);
+        const uint4 r2 = *reinterpret_cast<const uint4 *>(x2 + (int64_t)v * 8);
+        const uint4 rg = *reinterpret_cast<const uint4 *>(dy + (int64_t)v * 8);
+        const float sa = s_sa[c], sb = s_sb[c], sh = s_sh[c];
+        const float k1a = s_k1a[c], k0a = s_k0a[c], k1b = s_k1b[c], k0b = s_k0b[c];
+        float a[8], b[8], g[8], oa[8], ob[8];
+        bf16x8_to_f32(r1, a); bf16x8_to_f32(r2, b); bf16x8_to_f32(rg, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float z = a[e] * sa + (b[e] * sb + sh);
+            const float dz = g[e] * act_grad(z, act);
+            oa[e] = dz * sa + (a[e] * k1a + k0a);
+            ob[e] = dz * sb + (b[e] * k1b + k0b);
+        }
+        uint4 wa, wb;
+        wa.x = pack_bf16x2(oa[0], oa[1]); wa.y = pack_bf16x2(oa[2], oa[3]);
+        wa.z = pack_bf16x2(oa[4], oa[5]); wa.w = pack_bf16x2(oa[6], oa[7]);
+        wb.x = pack_bf16x2(ob[0], ob[1]); wb.y = pack_bf16x2(ob[2], ob[3]);
+        wb.z = pack_bf16x2(ob[4], ob[5]); wb.w = pack_bf16x2(ob[6], ob[7]);
+        *reinterpret_cast<uint4 *>(dx1 + (int64_t)v * 8) = wa;
+        *reinterpret_cast<uint4 *>(dx2 + (int64_t)v * 8) = wb;
+        v += stride;
+        const QR nx = qr_step(pos, sq, sr, nv);
+        c = chan_step(c, cq, nx.q != pos.q + sq, C);
+        pos = nx;
+    }
+}
+
+static bool bn2_ok(int B, int C, int HW, int *nchunk, int *per) {
+    if (B < 1 || C < 1 || HW < 8 || (HW & 7) || C > 1024) return false;
+    *nchunk = chunks_for(B, C, HW, per);
+    return (int64_t)C * *nchunk <= kBnFuseMax && (int64_t)B * C * HW / 8 < (int64_t)1 << 31;
+}
+
 // ---- small planes: ONE block per channel holds the channel's B * HW <= 65 536 elements in registers ----------------
 // The 40x40 / 20x20 layers (about 100 of the 133 BN units of D-FINE-m) are launch-floor bound with the chunked
 // two / three-kernel scheme above (~20 us forward, ~28 us backward per unit for 3-13 MB of data).  Here a 1024-thread
@@ -1003,6 +1201,73 @@ int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<uint16_t>, grid, dim3(kBnThreads), 0, st, (const uint16_t *)x, (const uint16_t *)dy,
                            (uint16_t *)dx, save_mean, save_invstd, scale, shift, lab_scale, coef, C, HW, act, training);
+    return check_launch();
+}
+
+/* RepVGG unit  y = act(BN_a(x1) + BN_b(x2)) [+ residual]  (training mode, bf16): see the kernels above. */
+int dfine_bn2_supported(int B, int C, int HW) {
+    int nchunk, per;
+    return bn2_ok(B, C, HW, &nchunk, &per) ? 1 : 0;
+}
+
+int64_t dfine_bn2_ws_floats(int B, int C, int HW) {
+    int nchunk, per;
+    if (!bn2_ok(B, C, HW, &nchunk, &per)) return DFINE_E_BADARG;
+    return (int64_t)C * nchunk * 4;
+}
+
+int dfine_bn2_act_fwd(const void *x1, const void *x2, const void *residual, void *y, const float *gamma1, const float *beta1,
+                      float *running_mean1, float *running_var1, const float *gamma2, const float *beta2,
+                      float *running_mean2, float *running_var2, float *saved /* [8][C] */, float *ws, int B, int C, int HW,
+                      int act, float momentum1, float eps1, float momentum2, float eps2, void *stream) {
+    int nchunk, per;
+    if (!x1 || !x2 || !y || !saved || !ws || act < 0 || act > 2 || !bn2_ok(B, C, HW, &nchunk, &per)) return DFINE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    float *part1 = ws, *part2 = ws + (int64_t)C * nchunk * 2;
+    hipLaunchKernelGGL(bn_stats_kernel<uint16_t>, dim3(C, nchunk), dim3(kBnThreads), 0, st, (const uint16_t *)x1, part1, C, HW, B, per);
+    hipLaunchKernelGGL(bn_stats_kernel<uint16_t>, dim3(C, nchunk), dim3(kBnThreads), 0, st, (const uint16_t *)x2, part2, C, HW, B, per);
+    const double count = (double)B * HW;
+    BnFusedFin f1{part1, nchunk, count, gamma1, beta1, running_mean1, running_var1, saved, saved + C, saved + 2 * C, saved + 3 * C,
+                  momentum1, eps1};
+    BnFusedFin f2{part2, nchunk, count, gamma2, beta2, running_mean2, running_var2, saved + 4 * C, saved + 5 * C, saved + 6 * C,
+                  saved + 7 * C, momentum2, eps2};
+    const int64_t nvec8 = (int64_t)B * C * HW / 8;
+    int64_t nb = (nvec8 + kBnThreads * 2 - 1) / (kBnThreads * 2);
+    if (nb > 1024) nb = 1024;                  // every block folds the partial sums of all channels in its prologue
+    const size_t sm = sizeof(float) * 3 * C;
+#define DFINE_BN2A(A, R) hipLaunchKernelGGL((bn2_apply_flat8_kernel<A, R>), dim3((unsigned)nb), dim3(kBnThreads), sm, st,       \
+                                            (const uint16_t *)x1, (const uint16_t *)x2, (const uint16_t *)residual, (uint16_t *)y, \
+                                            C, HW, nvec8, f1, f2)
+#define DFINE_BN2A_R(A) { if (residual) DFINE_BN2A(A, true); else DFINE_BN2A(A, false); }
+    if (act == 0) DFINE_BN2A_R(0) else if (act == 1) DFINE_BN2A_R(1) else DFINE_BN2A_R(2)
+#undef DFINE_BN2A_R
+#undef DFINE_BN2A
+    return check_launch();
+}
+
+int dfine_bn2_act_bwd(const void *x1, const void *x2, const void *dy, void *dx1, void *dx2, const float *saved /* [8][C] */,
+                      float *dgamma1, float *dbeta1, float *dgamma2, float *dbeta2, float *ws, int B, int C, int HW, int act,
+                      void *stream) {
+    int nchunk, per;
+    if (!x1 || !x2 || !dy || !dx1 || !dx2 || !saved || !ws || act < 0 || act > 2 || !bn2_ok(B, C, HW, &nchunk, &per))
+        return DFINE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    float *sv = const_cast<float *>(saved);
+    const Bn2Saved s1{sv, sv + C, sv + 2 * C, sv + 3 * C}, s2{sv + 4 * C, sv + 5 * C, sv + 6 * C, sv + 7 * C};
+    const int64_t nvec8 = (int64_t)B * C * HW / 8;
+    int64_t nb = (nvec8 + kBnThreads * 2 - 1) / (kBnThreads * 2);
+    if (nb > 1024) nb = 1024;
+    const size_t sm = sizeof(float) * 7 * C;
+#define DFINE_BN2B(A)                                                                                                          \
+    {                                                                                                                          \
+        hipLaunchKernelGGL(bn2_bwd_reduce_kernel<A>, dim3(C, nchunk), dim3(kBnThreads), 0, st, (const uint16_t *)x1,           \
+                           (const uint16_t *)x2, (const uint16_t *)dy, ws, s1, s2, C, HW, B, per);                             \
+        hipLaunchKernelGGL(bn2_bwd_apply_flat8_kernel<A>, dim3((unsigned)nb), dim3(kBnThreads), sm, st, (const uint16_t *)x1,  \
+                           (const uint16_t *)x2, (const uint16_t *)dy, (uint16_t *)dx1, (uint16_t *)dx2, s1, s2, ws, nchunk,   \
+                           (double)B * HW, dgamma1, dbeta1, dgamma2, dbeta2, C, HW, nvec8);                                    \
+    }
+    if (act == 0) DFINE_BN2B(0) else if (act == 1) DFINE_BN2B(1) else DFINE_BN2B(2)
+#undef DFINE_BN2B
     return check_launch();
 }
 

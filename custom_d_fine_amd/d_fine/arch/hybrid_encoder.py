@@ -95,10 +95,17 @@ class VGGBlock(nn.Module):
         self.conv2 = ConvNormLayer(ch_in, ch_out, 1, 1, padding=0, act=None)
         self.act = nn.Identity() if act is None else act
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         if hasattr(self, "conv"):
-            return self.act(self.conv(x))
-        return self.act(self.conv1(x) + self.conv2(x))
+            y = self.act(self.conv(x))
+            return y if residual is None else y + residual
+        name = ("silu" if isinstance(self.act, nn.SiLU) else "relu" if isinstance(self.act, nn.ReLU)
+                else None if isinstance(self.act, nn.Identity) else False)
+        if name is not False:
+            # both branches, their BatchNorms, the add, the activation (and CSPLayer's residual) as one unit
+            return kernels.repvgg_unit(x, self.conv1.conv, self.conv1.norm, self.conv2.conv, self.conv2.norm, name, residual)
+        y = self.act(self.conv1(x) + self.conv2(x))
+        return y if residual is None else y + residual
 
     def get_equivalent_kernel_bias(self):
         k3, b3 = _fold_bn(self.conv1.conv, self.conv1.norm)
@@ -128,7 +135,13 @@ class CSPLayer(nn.Module):
                       if hidden != out_channels else nn.Identity())
 
     def forward(self, x):
-        return self.conv3(self.bottlenecks(self.conv1(x)) + self.conv2(x))
+        y, r = self.conv1(x), self.conv2(x)
+        blocks = list(self.bottlenecks)
+        if blocks and all(isinstance(b, VGGBlock) for b in blocks):
+            for b in blocks[:-1]:
+                y = b(y)
+            return self.conv3(blocks[-1](y, residual=r))       # the residual add rides in the last unit's apply pass
+        return self.conv3(self.bottlenecks(y) + r)
 
 
 class RepNCSPELAN4(nn.Module):

@@ -37,6 +37,10 @@ _SIGNATURES = {
     "dfine_dwconv_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_dwconv_bwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_bn_ws_floats": (_L, [_I, _I, _I]),
+    "dfine_bn2_supported": (c_int, [_I, _I, _I]),
+    "dfine_bn2_ws_floats": (_L, [_I, _I, _I]),
+    "dfine_bn2_act_fwd": (c_int, [_P] * 14 + [_I, _I, _I, _I, _F, _F, _F, _F, _P]),
+    "dfine_bn2_act_bwd": (c_int, [_P] * 11 + [_I, _I, _I, _I, _P]),
     "dfine_bn_act_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     "dfine_head_losses": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _P, _I,
                                    _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P,
@@ -420,6 +424,41 @@ def bn_act_backward(x, dy, stats, lab_scale, act, training, need_affine=True, ne
     if status != 0:
         _check(status, "dfine_bn_act_bwd")
     return dx, dgamma, dbeta, dlab
+
+
+def bn2_supported(x):
+    """Shape / dtype of a conv output the RepVGG-unit kernels take (bf16 NCHW, H*W % 8 == 0, moderate channel count)."""
+    if x.dtype != torch.bfloat16 or x.dim() != 4:
+        return False
+    B, C = x.shape[0], x.shape[1]
+    return bool(_lib.dfine_bn2_supported(B, C, x.numel() // max(B * C, 1)))
+
+
+def bn2_act_forward(x1, x2, residual, bn1, bn2, act):
+    """act(BN_1(x1) + BN_2(x2)) [+ residual] with batch statistics; bn = (gamma, beta, running_mean, running_var,
+    momentum, eps).  -> (y, saved [8, C])."""
+    B, C = x1.shape[0], x1.shape[1]
+    HW = x1.numel() // max(B * C, 1)
+    y = torch.empty_like(x1)
+    saved = torch.empty(8, C, device=x1.device, dtype=torch.float32)
+    ws = _bn_workspace(x1.device, int(_lib.dfine_bn2_ws_floats(B, C, HW)))
+    _check(_lib.dfine_bn2_act_fwd(_ptr(x1), _ptr(x2), _ptr(residual), _ptr(y), _ptr(bn1[0]), _ptr(bn1[1]), _ptr(bn1[2]),
+                                  _ptr(bn1[3]), _ptr(bn2[0]), _ptr(bn2[1]), _ptr(bn2[2]), _ptr(bn2[3]), _ptr(saved), _ptr(ws),
+                                  B, C, HW, _ACT[act], float(bn1[4]), float(bn1[5]), float(bn2[4]), float(bn2[5]), _stream()),
+           "dfine_bn2_act_fwd")
+    return y, saved
+
+
+def bn2_act_backward(x1, x2, dy, saved, act, need_affine=(True, True)):
+    B, C = x1.shape[0], x1.shape[1]
+    HW = x1.numel() // max(B * C, 1)
+    dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
+    dev = x1.device
+    g = [torch.empty(C, device=dev, dtype=torch.float32) if need_affine[i // 2] else None for i in range(4)]
+    ws = _bn_workspace(dev, int(_lib.dfine_bn2_ws_floats(B, C, HW)))
+    _check(_lib.dfine_bn2_act_bwd(_ptr(x1), _ptr(x2), _ptr(dy), _ptr(dx1), _ptr(dx2), _ptr(saved), _ptr(g[0]), _ptr(g[1]),
+                                  _ptr(g[2]), _ptr(g[3]), _ptr(ws), B, C, HW, _ACT[act], _stream()), "dfine_bn2_act_bwd")
+    return dx1, dx2, g[0], g[1], g[2], g[3]
 
 
 # ------------------------------------------------------------------------------------- losses

@@ -843,6 +843,65 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
     return _act_lab_torch(y, act, lab)
 
 
+class _BN2Act(torch.autograd.Function):
+    """act(BN_1(c1) + BN_2(c2)) [+ residual], batch statistics (HIP: bnact.hip, RepVGG unit)."""
+
+    @staticmethod
+    def forward(ctx, c1, c2, residual, g1, b1, rm1, rv1, g2, b2, rm2, rv2, act, mom1, eps1, mom2, eps2):
+        c1, c2 = c1.contiguous(), c2.contiguous()
+        res = None if residual is None else residual.contiguous()
+        y, saved = _hip().bn2_act_forward(c1, c2, res, (g1, b1, rm1, rv1, mom1, eps1), (g2, b2, rm2, rv2, mom2, eps2), act)
+        ctx.save_for_backward(c1, c2, saved)
+        ctx.cfg = (act, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        c1, c2, saved = ctx.saved_tensors
+        act, has_res = ctx.cfg
+        dy = dy.contiguous()
+        if dy.dtype != c1.dtype:
+            dy = dy.to(c1.dtype)
+        need = ctx.needs_input_grad
+        d1, d2, dg1, db1, dg2, db2 = _hip().bn2_act_backward(c1, c2, dy, saved, act, (need[3] or need[4], need[7] or need[8]))
+        return (d1, d2, dy if has_res else None, dg1, db1, None, None, dg2, db2, None, None, None, None, None, None, None)
+
+
+def _bn_trainable(bn):
+    return (isinstance(bn, nn.BatchNorm2d) and bn.training and bn.track_running_stats and bn.momentum is not None
+            and bn.affine)
+
+
+def repvgg_unit(x, conv1: nn.Conv2d, bn1, conv2: nn.Conv2d, bn2, act: Optional[str], residual=None):
+    """act(bn1(conv1(x)) + bn2(conv2(x))) [+ residual]: the RepVGG block of the hybrid encoder in training form (ref
+    hybrid_encoder.py:106-156) and CSPLayer's residual (hybrid_encoder.py:209-239).  On the GPU in bf16 training the two
+    BatchNorms, the add, the activation and the residual add are ONE apply pass (csrc/bnact.hip: dfine_bn2_act_*);
+    everything else composes the unit from conv_bn_act."""
+    a = act.lower() if isinstance(act, str) else act
+    if (x.is_cuda and a in (None, "relu", "silu", "swish") and _env("DFINE_HIP_UNITS", "1") == "1"
+            and _env("DFINE_BN2", "1") == "1" and _bn_trainable(bn1) and _bn_trainable(bn2)
+            and _mfma_conv_ok(conv1, x) and _mfma_conv_ok(conv2, x)):
+        xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+        c1 = _DenseConv.apply(xb, conv1.weight)
+        c2 = _DenseConv.apply(xb, conv2.weight)
+        if c1.shape == c2.shape and _hip().bn2_supported(c1) and (residual is None or (
+                residual.shape == c1.shape and residual.dtype == torch.bfloat16)):
+            for bn in (bn1, bn2):
+                if _BN_DEFER:
+                    ent = _BN_PENDING.get(id(bn))
+                    _BN_PENDING[id(bn)] = (bn.num_batches_tracked, 1 if ent is None else ent[1] + 1)
+                else:
+                    bn.num_batches_tracked.add_(1)
+            return _BN2Act.apply(c1, c2, residual, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
+                                 bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, a,
+                                 bn1.momentum, bn1.eps, bn2.momentum, bn2.eps)
+        y = _bn_tail(c1, bn1, None, None, None) + _bn_tail(c2, bn2, None, None, None)
+    else:
+        y = conv_bn_act(x, conv1, bn1, None, None) + conv_bn_act(x, conv2, bn2, None, None)
+    y = _act_lab_torch(y, act, None)
+    return y if residual is None else y + residual
+
+
 def _bn_tail(y, bn, a, act, lab):
     """BatchNorm (+ activation + learnable affine) of a conv output on the GPU: one fused HIP op (bnact.hip)."""
     if isinstance(bn, nn.BatchNorm2d) and bn.track_running_stats and bn.momentum is not None:

@@ -154,6 +154,25 @@ int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_
                      const float *lab_scale, float *dgamma, float *dbeta, float *dlab, float *ws,
                      int dtype, int B, int C, int HW, int act, int training, void *stream);
 
+/* RepVGG unit: y = act(BN_a(x1) + BN_b(x2)) [+ residual] in one op (training mode, bf16 NCHW, H*W % 8 == 0).
+ * Replaces VGGBlock.forward's two ConvNormLayer BatchNorms + add + activation and CSPLayer's residual add
+ * (src/d_fine/arch/hybrid_encoder.py:106-156, 209-239).  `saved` [8][C] f32 receives mean, invstd, scale, shift of BN_a
+ * then of BN_b; running statistics are updated like nn.BatchNorm2d (momentum, unbiased variance).
+ * act: DFINE_ACT_* as in dfine_bn_act_fwd.  ws: dfine_bn2_ws_floats() floats.  dfine_bn2_supported() != 0 tells whether
+ * the shape is handled (otherwise compose the unit from dfine_bn_act_fwd calls). */
+int dfine_bn2_supported(int B, int C, int HW);
+int64_t dfine_bn2_ws_floats(int B, int C, int HW);
+int dfine_bn2_act_fwd(const void *x1, const void *x2, const void *residual, void *y, const float *gamma1,
+                      const float *beta1, float *running_mean1, float *running_var1, const float *gamma2,
+                      const float *beta2, float *running_mean2, float *running_var2, float *saved, float *ws,
+                      int B, int C, int HW, int act, float momentum1, float eps1, float momentum2, float eps2,
+                      void *stream);
+/* Backward: dx1, dx2 (bf16) and the four parameter gradients [C] f32 (any of them may be NULL); the gradient of
+ * `residual` is dy itself. */
+int dfine_bn2_act_bwd(const void *x1, const void *x2, const void *dy, void *dx1, void *dx2, const float *saved,
+                      float *dgamma1, float *dbeta1, float *dgamma2, float *dbeta2, float *ws, int B, int C, int HW,
+                      int act, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * A13/A14  All set-criterion losses of ONE prediction head, values and gradients in one call.
  * Replaces DFINECriterion.loss_labels_vfl / loss_boxes / loss_local (+ unimodal_distribution_

@@ -129,3 +129,64 @@ def test_units_match_aten_composition_bf16(cuda):
                 out = g(x.to(cuda))
             assert out.dtype == dt
             assert (out.float().cpu() - ref).abs().max() < tol * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,C,H,W,act,with_res", [(4, 128, 40, 40, "silu", True), (2, 64, 80, 80, "silu", False),
+                                                   (3, 32, 20, 20, "relu", True), (2, 16, 24, 8, None, False)])
+def test_repvgg_unit_fused_vs_fp32_reference(cuda, B, C, H, W, act, with_res):
+    """act(BN(conv3x3(x)) + BN(conv1x1(x))) [+ residual] through the one-pass RepVGG kernels (dfine_bn2_act_*) against a
+    plain fp32 PyTorch composition on the same bf16-rounded input and weights; tolerance = bf16 storage of the conv outputs
+    (the two convolutions themselves are the MFMA kernels, checked separately in test_conv_mfma_gpu.py)."""
+    from custom_d_fine_amd.d_fine.arch.hybrid_encoder import VGGBlock
+    torch.manual_seed(C + H)
+    act_mod = {"silu": nn.SiLU(), "relu": nn.ReLU(), None: None}[act]
+    blk = VGGBlock(C, C, act=act_mod).to(cuda).train()
+    with torch.no_grad():
+        for bn in (blk.conv1.norm, blk.conv2.norm):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.5, 0.5)
+        for conv in (blk.conv1.conv, blk.conv2.conv):
+            conv.weight.copy_(conv.weight.bfloat16().float())
+    ref = VGGBlock(C, C, act=act_mod).to(cuda).train()
+    ref.load_state_dict(blk.state_dict())
+    x = torch.randn(B, C, H, W, device=cuda).bfloat16()
+    res = torch.randn(B, C, H, W, device=cuda).bfloat16() if with_res else None
+    go = torch.randn(B, C, H, W, device=cuda)
+
+    xg = x.clone().requires_grad_(True)
+    rg = None if res is None else res.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = blk(xg, residual=rg)
+    assert y.dtype == torch.bfloat16
+    y.float().mul(go).sum().backward()
+
+    # fp32 reference (plain modules, no autocast)
+    xr = x.float().requires_grad_(True)
+    rr = None if res is None else res.float().requires_grad_(True)
+    def stored(c):                    # the conv outputs live in bf16 (straight-through rounding keeps the graph fp32)
+        return c + (c.bfloat16().float() - c).detach()
+
+    z = ref.conv1.norm(stored(ref.conv1.conv(xr))) + ref.conv2.norm(stored(ref.conv2.conv(xr)))
+    yr = z if act_mod is None else act_mod(z)
+    if rr is not None:
+        yr = yr + rr
+    yr.mul(go).sum().backward()
+
+    def close(a, b, tol):
+        return (a.float() - b.float()).abs().max().item() <= tol * max(b.float().abs().max().item(), 1.0)
+
+    def close_l2(a, b, tol):          # gradients: ReLU masks flip where bf16 rounding moves z across 0, so compare in norm
+        return (a.float() - b.float()).norm().item() <= tol * b.float().norm().item()
+
+    assert close(y, yr, 2e-2)
+    assert close_l2(xg.grad, xr.grad, 3e-2)
+    if rg is not None:
+        assert close(rg.grad, rr.grad, 1e-2)
+    for name in ("conv1.norm.weight", "conv1.norm.bias", "conv2.norm.weight", "conv2.norm.bias",
+                 "conv1.conv.weight", "conv2.conv.weight"):
+        a, b = dict(blk.named_parameters())[name].grad, dict(ref.named_parameters())[name].grad
+        assert a is not None and close_l2(a, b, 3e-2), name
+    for name in ("conv1.norm.running_mean", "conv1.norm.running_var", "conv2.norm.running_mean", "conv2.norm.running_var"):
+        a, b = dict(blk.named_buffers())[name], dict(ref.named_buffers())[name]
+        assert close(a, b, 1e-2), name
+    assert int(blk.conv1.norm.num_batches_tracked) == 1 and int(blk.conv2.norm.num_batches_tracked) == 1
