@@ -62,7 +62,8 @@ __device__ __forceinline__ void ln_row_z(const LnArgs &p, int64_t row, int D, in
 template <int EPL>
 __global__ __launch_bounds__(kLnThreads) void ln_fused_fwd_kernel(LnArgs p, const float *__restrict__ weight,
                                                                  const float *__restrict__ bias, float eps,
-                                                                 float *__restrict__ y, float *__restrict__ mean_out,
+                                                                 float *__restrict__ y, uint16_t *__restrict__ y16,
+                                                                 float *__restrict__ mean_out,
                                                                  float *__restrict__ rstd_out, int64_t rows, int D) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float w[EPL], bt[EPL];
@@ -80,7 +81,11 @@ __global__ __launch_bounds__(kLnThreads) void ln_fused_fwd_kernel(LnArgs p, cons
         for (int e = 0; e < EPL; ++e) { const float d = z[e] - mean; v += d * d; }
         const float rstd = rsqrtf(wave_sum(v) / (float)D + eps);
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) y[row * D + lane * EPL + e] = (z[e] - mean) * rstd * w[e] + bt[e];
+        for (int e = 0; e < EPL; ++e) {
+            const float o = (z[e] - mean) * rstd * w[e] + bt[e];
+            y[row * D + lane * EPL + e] = o;
+            if (y16) y16[row * D + lane * EPL + e] = f32_to_bf16(o);     // the copy the following GEMMs read
+        }
         if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
     }
 }
@@ -205,15 +210,15 @@ static bool ln_args_ok(int mode, const void *a, const void *b, const void *gate,
     }
 
 int dfine_ln_fused_fwd(int mode, const void *a, int a_dt, const void *b, int b_dt, const void *gate, int g_dt,
-                       const float *weight, const float *bias, float eps, float clampv, float *y, float *mean,
-                       float *rstd, int64_t rows, int D, void *stream) {
+                       const float *weight, const float *bias, float eps, float clampv, float *y, void *y_bf16,
+                       float *mean, float *rstd, int64_t rows, int D, void *stream) {
     if (rows == 0) return DFINE_OK;
     if (!ln_args_ok(mode, a, b, gate, a_dt, b_dt, g_dt, D) || !weight || !y || !mean || !rstd || rows < 0) return DFINE_E_BADARG;
     LnArgs p{a, b, gate, a_dt, b_dt, g_dt, mode, clampv};
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     DFINE_LN_DISPATCH(D / 64, hipLaunchKernelGGL((ln_fused_fwd_kernel<E>), dim3((unsigned)blocks), dim3(kLnThreads), 0,
-                                                 (hipStream_t)stream, p, weight, bias, eps, y, mean, rstd, rows, D))
+                                                 (hipStream_t)stream, p, weight, bias, eps, y, (uint16_t *)y_bf16, mean, rstd, rows, D))
     return check_launch();
 }
 

@@ -343,7 +343,10 @@ class HybridEncoder(nn.Module):
             k = nlev - 1 - idx
             top = self.lateral_convs[k](inner[0])
             inner[0] = top
-            up = F.interpolate(top, scale_factor=2.0, mode="nearest")
+            # autocast would run the nearest-neighbour copy in fp32 (4x the bytes of the bf16 map it duplicates, plus a cast
+            # back for the fusion conv); a pure data movement has nothing to gain from fp32
+            with torch.autocast(top.device.type, enabled=False):
+                up = F.interpolate(top, scale_factor=2.0, mode="nearest")
             inner.insert(0, self.fpn_blocks[k]([up, proj[idx - 1]]))
 
         outs = [inner[0]]

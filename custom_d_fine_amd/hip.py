@@ -76,7 +76,7 @@ _SIGNATURES = {
     "dfine_postprocess": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_linear_wgrad_ws_floats": (_L, [_I, _I, _I]),
     "dfine_linear_wgrad_bf16": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "dfine_ln_fused_fwd": (c_int, [_I, _P, _I, _P, _I, _P, _I, _P, _P, _F, _F, _P, _P, _P, _L, _I, _P]),
+    "dfine_ln_fused_fwd": (c_int, [_I, _P, _I, _P, _I, _P, _I, _P, _P, _F, _F, _P, _P, _P, _P, _L, _I, _P]),
     "dfine_ln_fused_bwd": (c_int, [_I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "dfine_ln_fused_bwd_ws_floats": (_L, [_L, _I]),
     "dfine_stem_supported": (c_int, [_I, _I, _I, _I]),
@@ -895,17 +895,18 @@ def _dt(t):
     return 0 if t is None else _DTYPE[t.dtype]
 
 
-def ln_fused_forward(mode, a, b, gate, weight, bias, eps, clampv):
-    """a [.., D] (f32 / bf16), b same shape or None, gate [.., 2D] (mode 2) -> (y f32, mean, rstd)."""
+def ln_fused_forward(mode, a, b, gate, weight, bias, eps, clampv, with_bf16=False):
+    """a [.., D] (f32 / bf16), b same shape or None, gate [.., 2D] (mode 2) -> (y f32, mean, rstd[, y bf16 [rows, D]])."""
     D = a.shape[-1]
     rows = a.numel() // D
     y = torch.empty(a.shape, device=a.device, dtype=torch.float32)
+    y16 = torch.empty(rows, D, device=a.device, dtype=torch.bfloat16) if with_bf16 else None
     mean = torch.empty(rows, device=a.device, dtype=torch.float32)
     rstd = torch.empty(rows, device=a.device, dtype=torch.float32)
     _check(_lib.dfine_ln_fused_fwd(mode, _ptr(a), _dt(a), _ptr(b), _dt(b), _ptr(gate), _dt(gate), _ptr(weight), _ptr(bias),
-                                   float(eps), float(clampv), _ptr(y), _ptr(mean), _ptr(rstd), rows, D, _stream()),
+                                   float(eps), float(clampv), _ptr(y), _ptr(y16), _ptr(mean), _ptr(rstd), rows, D, _stream()),
            "dfine_ln_fused_fwd")
-    return y, mean, rstd
+    return (y, mean, rstd, y16) if with_bf16 else (y, mean, rstd)
 
 
 def ln_fused_backward(mode, a, b, gate, weight, mean, rstd, dy, clampv, need_a, need_b, need_gate, need_affine):

@@ -953,7 +953,13 @@ class _LNFused(torch.autograd.Function):
         a = a.contiguous()
         b = None if b is None else b.contiguous()
         gate = None if gate is None else gate.contiguous()
-        y, mean, rstd = _hip().ln_fused_forward(mode, a, b, gate, weight, bias, eps, clampv)
+        if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+            # the stream stays fp32 (residual path, as in the reference under autocast); the GEMMs that read it next take
+            # the bf16 copy written in the same pass (picked up by _bf16_2d) instead of casting it themselves
+            y, mean, rstd, y16 = _hip().ln_fused_forward(mode, a, b, gate, weight, bias, eps, clampv, with_bf16=True)
+            y._dfine_bf16 = (y._version, y16)
+        else:
+            y, mean, rstd = _hip().ln_fused_forward(mode, a, b, gate, weight, bias, eps, clampv)
         ctx.save_for_backward(a, b, gate, weight, mean, rstd)
         ctx.cfg = (mode, clampv, bias is not None)
         return y
@@ -1011,9 +1017,19 @@ def gate_layer_norm(gate_logits, x1, x2, norm: nn.LayerNorm):
 
 
 def _bf16_2d(x):
-    """[..., K] activation -> contiguous bf16 [M, K] (what the GEMM / weight-gradient kernels read)."""
-    xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
-    return xb.reshape(-1, xb.shape[-1]).contiguous()
+    """[..., K] activation -> contiguous bf16 [M, K] (what the GEMM / weight-gradient kernels read).
+    The cast of an fp32 tensor is remembered on the tensor (the decoder's fp32 token stream feeds several linears each -
+    score / box heads, value projection, FFN: 22 casts of the same few [B, Q, 256] tensors per step)."""
+    if x.dtype == torch.bfloat16:
+        return x.reshape(-1, x.shape[-1]).contiguous()
+    memo = getattr(x, "_dfine_bf16", None)
+    if memo is not None and memo[0] == x._version:
+        return memo[1]
+    xb = x.to(torch.bfloat16)
+    xb = xb.reshape(-1, xb.shape[-1]).contiguous()
+    if x.dtype == torch.float32 and x.is_contiguous():
+        x._dfine_bf16 = (x._version, xb)
+    return xb
 
 
 def _f32_vec(b):

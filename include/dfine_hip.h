@@ -423,14 +423,15 @@ int dfine_stem_pool_bwd(const void *x, const void *dy, void *dx, int64_t planes,
  *   mode 0: z = a + b (b may be NULL)   mode 1: z = clamp(a + b, -clampv, clampv)
  *   mode 2: z = sigmoid(gate[:, :D]) * a + sigmoid(gate[:, D:]) * b      (gate [rows, 2 D])
  *   y [rows, D] f32 = (z - mean) * rstd * weight + bias;  mean / rstd [rows] f32 are kept for the backward.
+ *   y_bf16 [rows, D] (may be NULL): the same values rounded to bf16, for the GEMMs that consume the stream next.
  *   a / b / gate: DFINE_F32 or DFINE_BF16 each (x_dt arguments), unit inner stride, row stride D (2 D for gate).
  *   D % 64 == 0, D <= 1024.  backward: dy f32; da / db / dgate in the inputs' storage types (NULL = not needed);
  *   dweight / dbias f32 [D] are overwritten (deterministic two-stage column sums through ws:
  *   dfine_ln_fused_bwd_ws_floats(rows, D) floats).
  */
 int dfine_ln_fused_fwd(int mode, const void *a, int a_dt, const void *b, int b_dt, const void *gate, int g_dt,
-                       const float *weight, const float *bias, float eps, float clampv, float *y, float *mean,
-                       float *rstd, int64_t rows, int D, void *stream);
+                       const float *weight, const float *bias, float eps, float clampv, float *y, void *y_bf16,
+                       float *mean, float *rstd, int64_t rows, int D, void *stream);
 int dfine_ln_fused_bwd(int mode, const void *a, int a_dt, const void *b, int b_dt, const void *gate, int g_dt,
                        const float *weight, const float *mean, const float *rstd, const float *dy, float clampv,
                        void *da, void *db, void *dgate, float *dweight, float *dbias, float *ws, int64_t rows,
