@@ -181,6 +181,22 @@ class FusedAdamWEMA:
                             self.flat_ema.data_ptr() <= t.data_ptr() < self.flat_ema.data_ptr() + self.flat_ema.numel() * 4):
                         t.copy_(src)
 
+    def state_dict(self):
+        """What a resumed run needs beyond the model / EMA state dicts: the Adam moments (they live only in the flat
+        buffers, `optimizer.state_dict()` stays empty) and the two step counters.  Layout = the flat parameter layout of
+        this model and parameter-group order, checked on load."""
+        return {"exp_avg": self.exp_avg.detach().clone(), "exp_avg_sq": self.exp_avg_sq.detach().clone(),
+                "step_count": int(self.step_count), "ema_iters": int(self.ema_iters),
+                "segments": [tuple(s) for s in self.segments]}
+
+    def load_state_dict(self, state):
+        if [tuple(s) for s in state["segments"]] != [tuple(s) for s in self.segments]:
+            raise ValueError("optimizer state was saved for a different parameter layout")
+        self.exp_avg.copy_(state["exp_avg"])
+        self.exp_avg_sq.copy_(state["exp_avg_sq"])
+        self.step_count = int(state["step_count"])
+        self.ema_iters = int(state["ema_iters"])
+
     def zero_grad(self):
         self.flat_grad.zero_()
         for p in self._params:

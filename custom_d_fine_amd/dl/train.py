@@ -27,7 +27,7 @@ DEFAULTS = {
         "use_ema": True, "ema_momentum": 0.9998, "base_lr": 1.5e-4, "backbone_lr": 2e-5,
         "betas": [0.9, 0.999], "weight_decay": 1.25e-4, "cycler_pct_start": 0.1, "use_scheduler": True,
         "label_smoothing": 0.0, "seed": 42, "ddp": {"enabled": False}, "path_to_save": "output/models/exp",
-        "pretrained_model_path": None,
+        "pretrained_model_path": None, "resume_path": None,
     },
 }
 
@@ -103,6 +103,9 @@ class Trainer:
                               clip_max_norm=t["clip_max_norm"], ema=self.ema, scheduler=sched,
                               accum_steps=t["b_accum_steps"], fused_optimizer=fused)
         self.path_to_save = Path(t["path_to_save"])
+        self.fused, self.scheduler, self.start_epoch = fused, sched, 1
+        if t.get("resume_path"):
+            self.load_resume_state(t["resume_path"])
 
     def save_model(self):
         """Weight-only checkpoints, EMA weights when enabled (reference train.py:476-503)."""
@@ -112,10 +115,37 @@ class Trainer:
         torch.save(m.state_dict(), self.path_to_save / "last.pt")
         torch.save(m.state_dict(), self.path_to_save / "model.pt")
 
+    def save_resume_state(self, epoch):
+        """`resume.pt`: everything a continued run needs - student and EMA weights, Adam moments and step counters (the
+        fused optimizer keeps them in flat buffers), scheduler position, epoch.  (The reference only writes weight-only
+        checkpoints, train.py:476-503, so an interrupted run restarts its schedule)"""
+        m = self.model.module if hasattr(self.model, "module") else self.model
+        state = {"epoch": epoch, "model": m.state_dict(),
+                 "ema": None if self.ema is None else self.ema.model.state_dict(),
+                 "optimizer": self.fused.state_dict() if self.fused is not None else self.optimizer.state_dict(),
+                 "fused": self.fused is not None,
+                 "scheduler": None if self.scheduler is None else self.scheduler.state_dict(),
+                 "iters": self.step.iters}
+        torch.save(state, self.path_to_save / "resume.pt")
+
+    def load_resume_state(self, path):
+        state = torch.load(path, map_location=self.device, weights_only=False)
+        m = self.model.module if hasattr(self.model, "module") else self.model
+        m.load_state_dict(state["model"])
+        if self.ema is not None and state["ema"] is not None:
+            self.ema.model.load_state_dict(state["ema"])
+        if state["fused"] != (self.fused is not None):
+            raise ValueError("resume.pt was written with a different optimizer path (fused HIP vs torch.optim)")
+        (self.fused if self.fused is not None else self.optimizer).load_state_dict(state["optimizer"])
+        if self.scheduler is not None and state["scheduler"] is not None:
+            self.scheduler.load_state_dict(state["scheduler"])
+        self.step.iters = state["iters"]
+        self.start_epoch = state["epoch"] + 1
+
     def train(self):
         t = self.cfg["train"]
         size = t["img_size"][0]
-        for epoch in range(1, t["epochs"] + 1):
+        for epoch in range(self.start_epoch, t["epochs"] + 1):
             t0, losses = time.time(), []
             for it in range(t["steps_per_epoch"]):
                 images, targets = make_batch(t["batch_size"], size, t["num_classes"],
@@ -128,6 +158,7 @@ class Trainer:
                 n = t["steps_per_epoch"] * t["batch_size"] * self.world
                 print(f"epoch {epoch}: loss {mean:.4f}, {n / (time.time() - t0):.1f} img/s", flush=True)
                 self.save_model()
+                self.save_resume_state(epoch)
             dist_utils.synchronize()
 
 

@@ -206,3 +206,26 @@ def test_go_indices_batchwide_equals_per_image_procedure():
             assert a.tolist() == [int(x) for x in c] and b.tolist() == [int(x) for x in d]
         again = crit._get_go_indices(lists[0], lists[1:])  # plain reference-style lists are accepted too
         assert np.array_equal(again.src, got.src) and np.array_equal(again.tgt, got.tgt)
+
+
+def test_trainer_plumbing_and_resume(oracle_backend, tmp_path):
+    """BASELINE config #1 shape (D-FINE-n, 320x320, bs 2, CPU): the trainer runs, writes last.pt / model.pt / resume.pt, and a
+    second trainer resumed from resume.pt carries on with the same weights, optimizer moments, scheduler position and epoch."""
+    from custom_d_fine_amd.dl import train as T
+    args = ["model_name=n", "train.device=cpu", "train.num_classes=3", "train.img_size=[320,320]", "train.batch_size=2",
+            "train.steps_per_epoch=2", "train.epochs=1", "train.amp_enabled=false", f"train.path_to_save={tmp_path}"]
+    tr = T.Trainer(T.load_config(args))
+    tr.train()
+    for f in ("last.pt", "model.pt", "resume.pt"):
+        assert (tmp_path / f).exists()
+    weights = torch.load(tmp_path / "model.pt", weights_only=True)
+    assert set(weights) == set(tr.ema.model.state_dict())
+    tr2 = T.Trainer(T.load_config(args + ["train.epochs=2", f"train.resume_path={tmp_path / 'resume.pt'}"]))
+    assert tr2.start_epoch == 2 and tr2.step.iters == tr.step.iters
+    for (k, a), b in zip(tr.model.state_dict().items(), tr2.model.state_dict().values()):
+        assert torch.equal(a, b), k
+    sa, sb = tr.optimizer.state_dict()["state"], tr2.optimizer.state_dict()["state"]
+    assert sa.keys() == sb.keys() and len(sa) > 100
+    k0 = next(iter(sa))
+    assert torch.equal(sa[k0]["exp_avg"], sb[k0]["exp_avg"]) and sa[k0]["step"] == sb[k0]["step"]
+    assert tr2.scheduler.last_epoch == tr.scheduler.last_epoch
