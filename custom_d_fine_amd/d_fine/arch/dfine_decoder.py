@@ -277,6 +277,8 @@ class TransformerDecoder(nn.Module):
                 query_pos_head, pre_bbox_head, integral, up, reg_scale, attn_mask=None,
                 memory_mask=None, return_queries: bool = False):
         value = self.value_op(memory, None, None, memory_mask, spatial_shapes)
+        if self.training and self.layer_scale == 1:
+            value = kernels.msda_share_value_grad(value)      # every layer gathers from this one tensor
         project = self.project if hasattr(self, "project") else weighting_function(
             self.reg_max, up, reg_scale)
 

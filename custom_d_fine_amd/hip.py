@@ -257,7 +257,18 @@ def msda_fused_forward(value, ref, offsets, logits, shapes, points, offset_scale
     return out
 
 
-def msda_fused_backward(value, ref, offsets, logits, grad_out, shapes, points, offset_scale):
+def msda_grad_value_buffer(value):
+    """Zero-filled fp32 accumulator for d(value) (the backward kernels add into it with atomics)."""
+    return torch.zeros(value.shape, device=value.device, dtype=torch.float32)
+
+
+def msda_finish_grad_value(gv32, dtype):
+    return _finish_grad_value(gv32, dtype)
+
+
+def msda_fused_backward(value, ref, offsets, logits, grad_out, shapes, points, offset_scale, gv_acc=None):
+    """gv_acc: a shared fp32 accumulator (msda_grad_value_buffer) several backward calls on the SAME value add into; then
+    the first return value is None and the caller finishes the buffer once (msda_finish_grad_value)."""
     B, L, H, D = value.shape
     Lq = ref.shape[1]
     off_dtype, log_dtype = offsets.dtype, logits.dtype
@@ -267,7 +278,7 @@ def msda_fused_backward(value, ref, offsets, logits, grad_out, shapes, points, o
         logits = logits.to(value.dtype)
     if grad_out.dtype != value.dtype:
         grad_out = grad_out.to(value.dtype)
-    gv = torch.zeros(B, L, H, D, device=value.device, dtype=torch.float32)
+    gv = torch.zeros(B, L, H, D, device=value.device, dtype=torch.float32) if gv_acc is None else gv_acc
     goff = torch.empty_like(offsets)
     glog = torch.empty_like(logits)
     hw, pts = _levels(shapes, points)
@@ -276,7 +287,7 @@ def msda_fused_backward(value, ref, offsets, logits, grad_out, shapes, points, o
                                          _ptr(grad_out), _ptr(gv), _ptr(goff), _ptr(glog),
                                          _dtype_code(value), B, L, H, D, Lq, len(shapes), hw, pts,
                                          float(offset_scale), _stream()), "dfine_msda_fused_bwd")
-    return _finish_grad_value(gv, value.dtype), goff.to(off_dtype), glog.to(log_dtype)
+    return (None if gv_acc is not None else _finish_grad_value(gv, value.dtype)), goff.to(off_dtype), glog.to(log_dtype)
 
 
 # ------------------------------------------------------------------------------------- matcher

@@ -71,10 +71,31 @@ def msda(value: torch.Tensor, spatial_shapes, sampling_locations: torch.Tensor,
     return _MSDA.apply(value, sampling_locations, attention_weights, shapes, points)
 
 
+class _ValueGradShare:
+    """All decoder layers gather from the same `value` (the encoder memory, split by heads once: ref
+    dfine_decoder.py:410-420,443): their backward kernels add d(value) into ONE fp32 accumulator that is zero-filled once
+    and rounded to the value dtype once, instead of a zero fill + cast per layer and three adds of the results by autograd.
+    Every forward use registers here; the backward call that brings the count back to zero returns the total, the others
+    return None.  A backward pass that skips some of the registered uses would lose their share, so the count is
+    per-graph: `begin()` (called where `value` is made) starts a fresh one."""
+
+    def __init__(self):
+        self.pending = 0
+        self.acc = None
+
+
+def msda_share_value_grad(value):
+    """Marks `value` as gathered by several msda_fused calls of one forward pass (the decoder calls it once per step)."""
+    if value.is_cuda and value.requires_grad and _env("DFINE_MSDA_SHARE", "1") == "1":
+        value._dfine_share = _ValueGradShare()
+    return value
+
+
 class _MSDAFused(torch.autograd.Function):
     @staticmethod
     def forward(ctx, value, ref, offsets, logits, shapes, points, offset_scale):
         hip = _hip()
+        share = getattr(value, "_dfine_share", None)
         value = value.contiguous()
         ref = ref.float().contiguous()
         offsets = offsets.contiguous()
@@ -82,14 +103,31 @@ class _MSDAFused(torch.autograd.Function):
         out = hip.msda_fused_forward(value, ref, offsets, logits, shapes, points, offset_scale)
         ctx.save_for_backward(value, ref, offsets, logits)
         ctx.cfg = (shapes, points, offset_scale)
+        ctx.share = share if (share is not None and ctx.needs_input_grad[0]) else None
+        if ctx.share is not None:
+            ctx.share.pending += 1
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
+        hip = _hip()
         value, ref, offsets, logits = ctx.saved_tensors
         shapes, points, offset_scale = ctx.cfg
-        gv, goff, glog = _hip().msda_fused_backward(
-            value, ref, offsets, logits, grad_out.contiguous(), shapes, points, offset_scale)
+        share = ctx.share
+        if share is not None and share.pending <= 0:      # a second backward through the same graph: plain path
+            share = None
+        if share is None:
+            gv, goff, glog = hip.msda_fused_backward(
+                value, ref, offsets, logits, grad_out.contiguous(), shapes, points, offset_scale)
+            return gv, None, goff, glog, None, None, None
+        if share.acc is None:
+            share.acc = hip.msda_grad_value_buffer(value)
+        _, goff, glog = hip.msda_fused_backward(value, ref, offsets, logits, grad_out.contiguous(), shapes, points,
+                                                offset_scale, gv_acc=share.acc)
+        share.pending -= 1
+        gv = None
+        if share.pending == 0:
+            gv, share.acc = hip.msda_finish_grad_value(share.acc, value.dtype), None
         return gv, None, goff, glog, None, None, None
 
 

@@ -140,3 +140,38 @@ def test_full_size_properties_bf16(cuda):
     loc, w = np_ref.msda_prologue(ref[:1].cpu().numpy(), off[:1].cpu().numpy(), lg[:1].cpu().numpy(), points, 0.5)
     want = np_ref.msda_forward(v1[:1].cpu().numpy(), shapes, loc, w, points)
     np.testing.assert_allclose(o[:1].detach().cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+
+
+def test_shared_value_gradient_accumulator(cuda):
+    """Several gathers from ONE value tensor (the decoder layers): with msda_share_value_grad their backward passes add into a
+    single fp32 accumulator and the total is returned once - the same gradient as the per-call path summed by autograd."""
+    torch.manual_seed(5)
+    B, Lq, H, D = 2, 40, 8, 32
+    shapes, points = ((10, 12), (5, 6), (3, 3)), (3, 6, 3)
+    L = 120 + 30 + 9
+    ref = torch.cat([torch.rand(B, Lq, 2, device=cuda), torch.rand(B, Lq, 2, device=cuda) * 0.5 + 0.02], -1)
+    offs = [torch.randn(B, Lq, H, 12, 2, device=cuda).bfloat16() for _ in range(3)]
+    lgs = [torch.randn(B, Lq, H, 12, device=cuda).bfloat16() for _ in range(3)]
+    gos = [torch.randn(B, Lq, H * D, device=cuda).bfloat16() for _ in range(3)]
+    base = torch.randn(B, L, H * D, device=cuda).bfloat16()
+
+    def run(shared):
+        mem = base.clone().requires_grad_(True)
+        value = mem.reshape(B, L, H, D)
+        if shared:
+            value = kernels.msda_share_value_grad(value)
+            assert hasattr(value, "_dfine_share")
+        outs = [kernels.msda_fused(value, shapes, ref, o, l, points, 0.5) for o, l in zip(offs, lgs)]
+        torch.autograd.backward(outs, gos)
+        return mem.grad.float()
+
+    plain, shared = run(False), run(True)
+    assert plain.abs().max() > 0
+    # one rounding of the fp32 total instead of three roundings + two bf16 adds: equal within bf16 resolution
+    assert (plain - shared).abs().max() <= 2e-2 * plain.abs().max()
+    # a subset of the uses never reports a total twice or loses the accumulator
+    mem = base.clone().requires_grad_(True)
+    value = kernels.msda_share_value_grad(mem.reshape(B, L, H, D))
+    o1 = kernels.msda_fused(value, shapes, ref, offs[0], lgs[0], points, 0.5)
+    o1.backward(gos[0])
+    assert mem.grad is not None and torch.isfinite(mem.grad.float()).all()
