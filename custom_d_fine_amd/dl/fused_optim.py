@@ -39,10 +39,12 @@ class FusedAdamWEMA:
     too, so EMA is a handful of streaming kernels instead of two launches per tensor.
     """
 
-    def __init__(self, model, optimizer, ema=None, clip_max_norm=0.1, overlap=None, bucket_mb=32):
+    def __init__(self, model, optimizer, ema=None, clip_max_norm=0.1, overlap=None, bucket_mb=16):
         """overlap: all-reduce gradient buckets during backward (default: on when world_size > 1; the
         DFINE_GRAD_OVERLAP environment variable overrides).  bucket_mb: xGMI is point-to-point (7 links x ~153 GB/s), a ring
-        all-reduce is per-link bound and its fixed latency is paid per call, so buckets are few and large."""
+        all-reduce is per-link bound and its fixed latency is paid per call, so buckets are few and large - but only the
+        LAST bucket (the first layers of the backbone, complete when backward ends) is exposed, so not too large either:
+        D-FINE-m's 78 MB make 8 buckets at 16 MB, the exposed one 7 MB (24 MB with 32 MB buckets)."""
         import os
         from .. import hip
         self.hip = hip
