@@ -438,7 +438,7 @@ template <int NTN, int kG2Ring, int PXW, bool SEG>   // kG2Ring LDS stages (3: t
                                                      // tiles per wave (4 / 8); SEG: input / output given as several parts
 __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs xs_, const uint16_t *__restrict__ w2,
                                                                   const ChanSegs ys_, int Cin, int Cout, int NP, int KP,
-                                                                  int HW, int ptiles, int total_tiles, int nblk) {
+                                                                  int HW, int ptiles, int total_tiles, int nblk, int accum) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int TP = 32 * PXW;                                             // pixels per workgroup (128 or 256)
     constexpr int XPITCH = TP * 2;                                           // bytes per channel row
@@ -562,7 +562,18 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
         if (n < Cout && wp * 16 * PXW + c8 < npix) {
             uint16_t *yp = SEG ? const_cast<uint16_t *>(seg_addr(ys_, b, n, HW))
                                : const_cast<uint16_t *>(ys_.p[0]) + ((int64_t)b * ys_.bs[0] + n) * HW;
-            *reinterpret_cast<uint4 *>(yp + p0 + wp * 16 * PXW + c8) = *reinterpret_cast<const uint4 *>(ot + row * OP + c8);
+            uint4 v = *reinterpret_cast<const uint4 *>(ot + row * OP + c8);
+            if (accum) {                                  // y += conv(x): bf16 + bf16 in fp32, one rounding (like a separate add)
+                const uint4 o = *reinterpret_cast<const uint4 *>(yp + p0 + wp * 16 * PXW + c8);
+                const uint32_t a[4] = {v.x, v.y, v.z, v.w}, c[4] = {o.x, o.y, o.z, o.w};
+                uint32_t r[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    r[k] = pack_bf16x2(__uint_as_float(a[k] << 16) + __uint_as_float(c[k] << 16),
+                                       __uint_as_float(a[k] & 0xffff0000u) + __uint_as_float(c[k] & 0xffff0000u));
+                v = make_uint4(r[0], r[1], r[2], r[3]);
+            }
+            *reinterpret_cast<uint4 *>(yp + p0 + wp * 16 * PXW + c8) = v;
         }
     }
 }
@@ -574,7 +585,7 @@ static ChanSegs one_seg(const void *p, int C) {
 }
 
 static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B, int Cin, int Cout, int NP, int KP, int HW,
-                          hipStream_t st, const ChanSegs *xsegs = nullptr, const ChanSegs *ysegs = nullptr) {
+                          hipStream_t st, const ChanSegs *xsegs = nullptr, const ChanSegs *ysegs = nullptr, int accum = 0) {
     const int ptiles = (HW + kTrPix - 1) / kTrPix;
     static const int v2_env = [] { const char *e = getenv("DFINE_CONV1X1_GLDS"); return e ? atoi(e) : 1; }();
     static const int px256_env = [] { const char *e = getenv("DFINE_CONV1X1_PX256"); return e ? atoi(e) : 1; }();
@@ -607,15 +618,15 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
             attr2 = true;
         }
 #define DFINE_G2(N, R, P)                                                                                                                        \
-    { if (seg) hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, true>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2); \
-      else hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, false>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2); }
+    { if (seg) hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, true>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum); \
+      else hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, false>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum); }
         if (px256) DFINE_G2(2, 3, 8)
         else if (wide2) { if (ring2) DFINE_G2(2, 2, 4) else DFINE_G2(2, 3, 4) }
         else { if (ring2) DFINE_G2(1, 2, 4) else DFINE_G2(1, 3, 4) }
 #undef DFINE_G2
         return check_launch();
     }
-    if (xsegs || ysegs) return DFINE_E_BADARG;          // the first-generation kernel takes whole tensors only
+    if (xsegs || ysegs || accum) return DFINE_E_BADARG;  // the first-generation kernel takes whole tensors only, no accumulation
     const int vec = (HW % 8 == 0) ? 8 : (HW % 4 == 0 ? 4 : 2);
     static const int kc_env = [] { const char *e = getenv("DFINE_CONV_KC"); return e ? atoi(e) : 0; }();
     int kc = KP >= 128 ? 4 : (KP >= 64 ? 2 : 1);
@@ -1302,6 +1313,17 @@ int dfine_conv_fwd_bf16(const void *x, const void *w2, void *y, int B, int Cin, 
     if (w % 2 || w > 160) return DFINE_E_BADARG;
     return launch_conv((const uint16_t *)x, (const uint16_t *)w2, (uint16_t *)y, B, Cin, Cout, NP, KP, h, w, KS,
                        (hipStream_t)stream);
+}
+
+// y[B, Cout, H*W] += conv1x1(x[B, Cin, H*W]) (bf16 accumulate-into: the second data gradient of a RepVGG unit adds onto
+// the first instead of a separate add pass).  DFINE_E_BADARG when the shape is outside the LDS-DMA kernel's range
+// (H*W % 8, Cin % 4): the caller then adds separately.
+int dfine_conv1x1_accum_bf16(const void *x, const void *w2, void *y, int B, int Cin, int Cout, int HW, void *stream) {
+    if (B == 0) return DFINE_OK;
+    if (!x || !w2 || !y || Cin < 1 || Cout < 1 || HW < 1 || Cin % 2) return DFINE_E_BADARG;
+    const int NP = (Cout + 15) / 16 * 16, KP = (Cin + 31) / 32 * 32;
+    return launch_conv1x1((const uint16_t *)x, (const uint16_t *)w2, (uint16_t *)y, B, Cin, Cout, NP, KP, HW,
+                          (hipStream_t)stream, nullptr, nullptr, 1);
 }
 
 // Weight gradient of the same convolution.  x [B,Cin,H,W], dy [B,Cout,H,W] bf16 -> dw [Cout,Cin,KS,KS]

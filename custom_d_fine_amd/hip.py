@@ -55,6 +55,7 @@ _SIGNATURES = {
     "dfine_conv_pack_weights": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "dfine_conv_pack_weights_multi": (c_int, [_P, _I, _P]),
     "dfine_conv_fwd_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_conv1x1_accum_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_conv_wgrad_ws_floats": (_L, [_I, _I, _I, _I, _I, _I]),
     "dfine_conv_wgrad_bf16": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_fdr_fwd": (c_int, [_P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -571,6 +572,17 @@ def conv_forward_bf16(x, w2, cout, ks):
         _check(_lib.dfine_conv_fwd_bf16(_ptr(x), _ptr(w2), _ptr(y), B, cin, cout, H, W, ks, _stream()),
                "dfine_conv_fwd_bf16")
     return y
+
+
+def conv1x1_accumulate(x, w2, y):
+    """y += conv1x1(x) (bf16, packed weights); False when the shape needs the separate-add fallback."""
+    B, cin, H, W = x.shape
+    with _timed("conv1x1", 2.0 * B * H * W * cin * y.shape[1]):
+        status = _lib.dfine_conv1x1_accum_bf16(_ptr(x), _ptr(w2), _ptr(y), B, cin, y.shape[1], H * W, _stream())
+    if status == -1:
+        return False
+    _check(status, "dfine_conv1x1_accum_bf16")
+    return True
 
 
 def _seg_arrays(parts):

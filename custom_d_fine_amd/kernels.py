@@ -654,6 +654,56 @@ class _DenseConv(torch.autograd.Function):
         return dx, dw
 
 
+class _DualConv(torch.autograd.Function):
+    """(conv_a(x), conv_b(x)) for a 3x3 and a 1x1 convolution of the same input (RepVGG unit): one op so that the backward
+    pass forms d(x) = dgrad_a(dc_a) + dgrad_b(dc_b) with the second data-gradient kernel accumulating onto the first
+    (dfine_conv1x1_accum_bf16) instead of autograd adding two maps."""
+
+    @staticmethod
+    def forward(ctx, x, wa, wb):
+        hip = _hip()
+        x = x.contiguous()
+        ca = hip.conv_forward_bf16(x, _packed_weights(wa, False), wa.shape[0], wa.shape[-1])
+        cb = hip.conv_forward_bf16(x, _packed_weights(wb, False), wb.shape[0], wb.shape[-1])
+        ctx.save_for_backward(x, wa, wb)
+        ctx.slots = []
+        for i, w in ((1, wa), (2, wb)):
+            slot = _defer_slot(w) if (ctx.needs_input_grad[i] and hip.conv_wgrad_supported(x.shape[2], x.shape[3], w.shape[-1])) else None
+            if slot is not None:
+                slot[0].note_use(slot[1][0])
+            ctx.slots.append(slot)
+        return ca, cb
+
+    @staticmethod
+    def backward(ctx, dca, dcb):
+        hip = _hip()
+        x, wa, wb = ctx.saved_tensors
+        dca = dca.contiguous() if dca.dtype == torch.bfloat16 else dca.to(torch.bfloat16).contiguous()
+        dcb = dcb.contiguous() if dcb.dtype == torch.bfloat16 else dcb.to(torch.bfloat16).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = hip.conv_forward_bf16(dca, _packed_weights(wa, True), wa.shape[1], wa.shape[-1])
+            if not hip.conv1x1_accumulate(dcb, _packed_weights(wb, True), dx):
+                dx = dx + hip.conv_forward_bf16(dcb, _packed_weights(wb, True), wb.shape[1], 1)
+        grads = []
+        for need, w, dy, slot in ((ctx.needs_input_grad[1], wa, dca, ctx.slots[0]), (ctx.needs_input_grad[2], wb, dcb, ctx.slots[1])):
+            g = None
+            if need:
+                ks = w.shape[-1]
+                if slot is not None:
+                    ws, meta = hip.conv_wgrad_bf16(x, dy, ks, partials=True)
+                    slot[0].defer_wgrad(slot[1][0], ws, meta)
+                    slot[0].use_done(slot[1][0])
+                elif hip.conv_wgrad_supported(x.shape[2], x.shape[3], ks):
+                    g = hip.conv_wgrad_bf16(x, dy, ks).to(w.dtype)
+                else:
+                    pad = ks // 2
+                    g = torch.ops.aten.convolution_backward(dy, x, bf16_param(w), None, [1, 1], [pad, pad], [1, 1], False,
+                                                            [0, 0], 1, [False, True, False])[1].to(w.dtype)
+            grads.append(g)
+        return dx, grads[0], grads[1]
+
+
 class _DenseConvSeg(torch.autograd.Function):
     """1x1 convolution of torch.cat(xs, dim=1) that never builds the concatenation: the HIP kernels gather the input
     channels from the parts (forward, weight gradient) and scatter the data gradient into one tensor per part
@@ -920,8 +970,12 @@ def repvgg_unit(x, conv1: nn.Conv2d, bn1, conv2: nn.Conv2d, bn2, act: Optional[s
             and _env("DFINE_BN2", "1") == "1" and _bn_trainable(bn1) and _bn_trainable(bn2)
             and _mfma_conv_ok(conv1, x) and _mfma_conv_ok(conv2, x)):
         xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
-        c1 = _DenseConv.apply(xb, conv1.weight)
-        c2 = _DenseConv.apply(xb, conv2.weight)
+        if (conv1.kernel_size == (3, 3) and conv2.kernel_size == (1, 1) and _env("DFINE_CONV_TUNE", "hip") == "hip"
+                and _env("DFINE_DUAL_CONV", "1") == "1"):
+            c1, c2 = _DualConv.apply(xb, conv1.weight, conv2.weight)
+        else:
+            c1 = _DenseConv.apply(xb, conv1.weight)
+            c2 = _DenseConv.apply(xb, conv2.weight)
         if c1.shape == c2.shape and _hip().bn2_supported(c1) and (residual is None or (
                 residual.shape == c1.shape and residual.dtype == torch.bfloat16)):
             for bn in (bn1, bn2):

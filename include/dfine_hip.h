@@ -253,6 +253,12 @@ int dfine_conv_pack_weights(const float *w, void *w2, int Cout, int Cin, int KS,
 int dfine_conv_pack_weights_multi(const void *table, int n_entries, void *stream);
 int dfine_conv_fwd_bf16(const void *x, const void *w2, void *y, int B, int Cin, int Cout, int H, int W,
                         int KS, void *stream);
+
+/* y += conv1x1(x) in bf16 (stride 1; same packed weights): the second data gradient of a RepVGG unit
+ * (conv3x3 and conv1x1 on the same input, src/d_fine/arch/hybrid_encoder.py:106-156) accumulates onto the first.
+ * DFINE_E_BADARG for shapes outside the LDS-DMA 1x1 kernel (H*W % 8 != 0, Cin % 4 != 0). */
+int dfine_conv1x1_accum_bf16(const void *x, const void *w2, void *y, int B, int Cin, int Cout, int HW,
+                             void *stream);
 /* Weight gradient of the same convolution: dw [Cout, Cin, KS, KS] f32 (overwritten) from x [B,Cin,H,W]
  * and dy [B,Cout,H,W] (bf16); ws = dfine_conv_wgrad_ws_floats(...) floats of scratch (split-K
  * partial sums).  KS = 3: W % 8 == 0 and W <= 160.  KS = 1: (H*W) % 8 == 0. */
