@@ -468,7 +468,7 @@ class DFINETransformer(nn.Module):
         for i in range(len(proj), self.num_levels):
             proj.append(apply(self.input_proj[i], feats[-1] if i == len(feats) else proj[-1]))
         shapes = [[f.shape[2], f.shape[3]] for f in proj]
-        memory = torch.concat([f.flatten(2).permute(0, 2, 1) for f in proj], 1)
+        memory = kernels.flatten_levels(proj)
         return memory, shapes
 
     def _generate_anchors(self, spatial_shapes=None, grid_size=0.05, dtype=torch.float32,

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "dfine_conv_packed_elems": (_L, [_I, _I, _I, _I]),
     "dfine_conv_pack_weights": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "dfine_conv_pack_weights_multi": (c_int, [_P, _I, _P]),
+    "dfine_maps_tokens_bf16": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_conv_fwd_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_conv1x1_accum_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_conv_wgrad_ws_floats": (_L, [_I, _I, _I, _I, _I, _I]),
@@ -572,6 +573,31 @@ def conv_forward_bf16(x, w2, cout, ks):
         _check(_lib.dfine_conv_fwd_bf16(_ptr(x), _ptr(w2), _ptr(y), B, cin, cout, H, W, ks, _stream()),
                "dfine_conv_fwd_bf16")
     return y
+
+
+def maps_to_tokens(maps):
+    """List of [B, C, H_l, W_l] bf16 contiguous maps -> tokens [B, sum(H_l W_l), C] (levels in list order)."""
+    B, C = maps[0].shape[0], maps[0].shape[1]
+    hws = [m.shape[2] * m.shape[3] for m in maps]
+    L = sum(hws)
+    tokens = torch.empty(B, L, C, device=maps[0].device, dtype=torch.bfloat16)
+    row = 0
+    for m, hw in zip(maps, hws):
+        _check(_lib.dfine_maps_tokens_bf16(_ptr(m), _ptr(tokens), B, C, hw, L, row, 1, _stream()), "dfine_maps_tokens_bf16")
+        row += hw
+    return tokens
+
+
+def tokens_to_maps(tokens, shapes):
+    """tokens [B, L, C] bf16 contiguous -> one contiguous [B, C, h, w] map per (h, w) in `shapes`."""
+    B, L, C = tokens.shape
+    out, row = [], 0
+    for h, w in shapes:
+        m = torch.empty(B, C, h, w, device=tokens.device, dtype=torch.bfloat16)
+        _check(_lib.dfine_maps_tokens_bf16(_ptr(m), _ptr(tokens), B, C, h * w, L, row, 0, _stream()), "dfine_maps_tokens_bf16")
+        out.append(m)
+        row += h * w
+    return out
 
 
 def conv1x1_accumulate(x, w2, y):

@@ -148,6 +148,35 @@ def msda_fused(value, spatial_shapes, ref_boxes, offsets, logits, num_points_lis
 
 
 # =============================================================================================
+# A3  encoder maps -> decoder token memory
+# =============================================================================================
+class _FlattenLevels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *maps):
+        maps = tuple(m.contiguous() for m in maps)
+        ctx.shapes = [(m.shape[2], m.shape[3]) for m in maps]
+        return _hip().maps_to_tokens(maps)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        if g.dtype != torch.bfloat16:
+            g = g.to(torch.bfloat16)
+        return tuple(_hip().tokens_to_maps(g, ctx.shapes))
+
+
+def flatten_levels(maps):
+    """concat([m.flatten(2).permute(0, 2, 1) for m in maps], 1): the decoder's memory [B, L, C] from the encoder's maps
+    (ref dfine_decoder.py:778-801).  GPU/bf16: tiled transposes (csrc/layout.hip); the backward hands every level a
+    contiguous gradient map instead of a strided view of d(memory)."""
+    if (maps[0].is_cuda and all(m.dtype == torch.bfloat16 and m.dim() == 4 for m in maps)
+            and maps[0].shape[1] % 8 == 0 and all((m.shape[2] * m.shape[3]) % 8 == 0 and m.shape[1] == maps[0].shape[1] for m in maps)
+            and _env("DFINE_HIP_UNITS", "1") == "1"):
+        return _FlattenLevels.apply(*maps)
+    return torch.concat([m.flatten(2).permute(0, 2, 1) for m in maps], 1)
+
+
+# =============================================================================================
 # A11/A12  matcher: cost matrix + linear sum assignment, all heads of a step in one launch
 # =============================================================================================
 def hungarian_assign(logits: torch.Tensor, boxes: torch.Tensor, tgt_labels: torch.Tensor,

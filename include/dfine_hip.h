@@ -444,6 +444,15 @@ int dfine_ln_fused_bwd(int mode, const void *a, int a_dt, const void *b, int b_d
                        int D, void *stream);
 int64_t dfine_ln_fused_bwd_ws_floats(int64_t rows, int D);
 
+/* ---------------------------------------------------------------------------------------------
+ * A3  Encoder maps <-> decoder token memory.  Replaces the flatten(2).permute(0, 2, 1) + concat of
+ * DFINETransformer._get_encoder_input (src/d_fine/arch/dfine_decoder.py:778-801) and its autograd backward.
+ *   map [B, C, HW] bf16 (NCHW level), tokens [B, L, C] bf16; the level occupies token rows [row0, row0 + HW).
+ *   to_tokens != 0: tokens <- map;  to_tokens == 0: map <- tokens (the gradient direction).  C % 8 == 0, HW % 8 == 0.
+ */
+int dfine_maps_tokens_bf16(const void *map, void *tokens, int B, int C, int HW, int L, int row0, int to_tokens,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

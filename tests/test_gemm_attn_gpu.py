@@ -156,3 +156,21 @@ def test_mha_block_matches_nn_multiheadattention(cuda):
     _close(y, yr, tol=2e-2, what="y")
     for name, a, b in zip(["d_qk", "d_v", "d_in_w", "d_in_b", "d_out_w", "d_out_b"], got, want):
         _close(a, b, tol=3e-2, what=name)
+
+
+@pytest.mark.parametrize("B,C,shapes", [(2, 256, ((80, 80), (40, 40), (20, 20))), (3, 64, ((6, 12), (5, 8))), (1, 8, ((2, 4),))])
+def test_flatten_levels_matches_permute_concat(cuda, B, C, shapes):
+    """Encoder maps -> decoder token memory (csrc/layout.hip) and its backward: bit-identical to
+    concat(flatten(2).permute(0, 2, 1)) and to the autograd gradient of that composition (pure data movement)."""
+    from custom_d_fine_amd import kernels
+    torch.manual_seed(C)
+    maps = [torch.randn(B, C, h, w, device=cuda).bfloat16().requires_grad_(True) for h, w in shapes]
+    ref_maps = [m.detach().clone().requires_grad_(True) for m in maps]
+    mem = kernels.flatten_levels(maps)
+    want = torch.concat([m.flatten(2).permute(0, 2, 1) for m in ref_maps], 1)
+    assert mem.shape == want.shape and torch.equal(mem, want)
+    go = torch.randn_like(want)
+    mem.backward(go)
+    want.backward(go)
+    for a, b in zip(maps, ref_maps):
+        assert a.grad.is_contiguous() and torch.equal(a.grad, b.grad)
