@@ -656,7 +656,10 @@ def conv1x1_seg_wgrad(x_parts, dy, partials=False):
 
 
 def conv_wgrad_supported(H, W, ks):
-    return (ks == 3 and W % 8 == 0 and W <= 160) or (ks == 1 and (H * W) % 8 == 0)
+    """3x3: rows are walked in 16-byte chunks, so the kernel wants W % 8 == 0; narrower maps (the 20x20 level) are run on
+    zero-padded copies of x and dy (conv_wgrad_bf16): zero columns of dy add nothing and zero columns of x are the
+    convolution's own padding."""
+    return (ks == 3 and W % 2 == 0 and (W + 7) // 8 * 8 <= 160) or (ks == 1 and (H * W) % 8 == 0)
 
 
 def _p16(n):
@@ -666,6 +669,10 @@ def _p16(n):
 def conv_wgrad_bf16(x, dy, ks, partials=False):
     """x [B,Cin,H,W], dy [B,Cout,H,W] bf16 contiguous -> dw [Cout,Cin,ks,ks] f32; partials=True: (ws, meta) for a deferred
     dfine_multi_wgrad_reduce, meta = (splits, Cout, Cin, taps, NP16, CP16)."""
+    if ks == 3 and x.shape[3] % 8:
+        padw = (x.shape[3] + 7) // 8 * 8 - x.shape[3]
+        x = torch.nn.functional.pad(x, (0, padw))
+        dy = torch.nn.functional.pad(dy, (0, padw))
     B, cin, H, W = x.shape
     cout = dy.shape[1]
     dw = None if partials else torch.empty(cout, cin, ks, ks, device=x.device, dtype=torch.float32)
