@@ -109,6 +109,27 @@ def weighting_function(reg_max, up, reg_scale, deploy=False):
     W = [-2b, -(s^(h-1))+1, ..., -(s^1)+1, 0, s^1-1, ..., s^(h-1)-1, 2b] with
     b = |up|*|reg_scale|, h = reg_max/2, s = (b+1)^(2/(reg_max-2)).
     """
+    # `up` / `reg_scale` are constants of the model (parameters with requires_grad=False): the table - ~80 one-element
+    # kernels - is rebuilt only when they change, not on every forward / criterion call
+    cacheable = (not deploy and torch.is_tensor(up) and torch.is_tensor(reg_scale) and not up.requires_grad
+                 and not reg_scale.requires_grad)
+    if cacheable:
+        key = (int(reg_max), up.data_ptr(), up._version, reg_scale.data_ptr(), reg_scale._version, up.dtype, str(up.device))
+        hit = _W_CACHE.get(key)
+        if hit is not None:
+            return hit
+    w = _weighting_function(reg_max, up, reg_scale, deploy)
+    if cacheable:
+        if len(_W_CACHE) > 16:
+            _W_CACHE.clear()
+        _W_CACHE[key] = w
+    return w
+
+
+_W_CACHE = {}
+
+
+def _weighting_function(reg_max, up, reg_scale, deploy):
     b1 = abs(up[0]) * abs(reg_scale)
     b2 = b1 * 2
     half = reg_max // 2
