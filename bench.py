@@ -39,7 +39,7 @@ import torch.distributed as dist  # noqa: E402
 LRS = {"n": (8e-4, 4e-4), "s": (2.5e-4, 6e-5), "m": (1.5e-4, 2e-5), "l": (1.6e-4, 1e-5), "x": (2e-4, 2e-6)}
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
-MFMA_GROUPS = ("conv1x1", "conv3x3", "conv1x1_wgrad", "conv3x3_wgrad", "stem_conv", "stem_wgrad", "miopen_conv")
+MFMA_GROUPS = ("conv1x1", "conv3x3", "conv1x1_wgrad", "conv3x3_wgrad", "wgrad_reduce", "stem_conv", "stem_wgrad", "miopen_conv")
 
 
 def build_step(model_name, img, device, amp_dtype, num_classes=80, channels_last=False, mask=False):
@@ -241,15 +241,16 @@ def main():
                     "avg_launch_ms": round(mean_ms, 4), "ms_per_step": round(tot_ms / max(sampled, 1), 3)}
 
         family = mfma_entry(MFMA_GROUPS, "dense-conv implicit GEMMs of backbone + encoder: conv1x1_glds / conv_igemm<3> (fwd + dgrad), "
-                            "conv_wgrad1_glds / conv_wgrad<3> (+ reduce), stem_* (+ MIOpen: 3x3 weight gradient on 20x20 maps)")
+                            "conv_wgrad1_glds / conv_wgrad<3> + the deferred split reduction, stem_*")
         kernels_ = [mfma_entry(("conv1x1",), "conv1x1_glds_kernel fwd+dgrad"), mfma_entry(("conv3x3",), "conv_igemm_kernel<3> fwd+dgrad"),
-                    mfma_entry(("conv1x1_wgrad",), "conv_wgrad1_glds_kernel + reduce"), mfma_entry(("conv3x3_wgrad",), "conv_wgrad_kernel<3> + reduce"),
+                    mfma_entry(("conv1x1_wgrad",), "conv_wgrad1_glds_kernel"), mfma_entry(("conv3x3_wgrad",), "conv_wgrad_kernel<3>"),
+                    mfma_entry(("wgrad_reduce",), "multi_wgrad_reduce_kernel (split partial sums of all conv / linear weight gradients)"),
                     mfma_entry(("stem_conv", "stem_wgrad"), "stem_conv / stem_dgrad_s2 / stem_wgrad"),
                     mfma_entry(("linear_wgrad",), "linear_wgrad_kernel (token-stream linears)"),
                     mfma_entry(("linear", "attention"), "linear_act / attention kernels (token streams)"),
                     mfma_entry(("miopen_conv",), "MIOpen convolutions (shapes the HIP weight-gradient kernel does not take)"),
                     hbm_entry("msda_fwd", "msda_fwd8_kernel (dfine_msda_fused_fwd)"),
-                    hbm_entry("msda_bwd", "msda_bwd kernels incl. staging (dfine_msda_fused_bwd)")]
+                    hbm_entry("msda_bwd", "msda_bwd_wide_kernel (dfine_msda_fused_bwd)")]
         line = {
             "metric": "images/sec train step D-FINE-m 640x640 bs=32 at 1/2/4/8 MI355X",
             "value": round(args.batch * world * args.steps / elapsed, 3),

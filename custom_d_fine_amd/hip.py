@@ -686,7 +686,8 @@ def conv_wgrad_bf16(x, dy, ks, partials=False):
 
 
 def multi_wgrad_reduce(table, n_entries):
-    _check(_lib.dfine_multi_wgrad_reduce(_ptr(table), n_entries, _stream()), "dfine_multi_wgrad_reduce")
+    with _timed("wgrad_reduce", 0.0):       # no FLOPs of its own: its time counts against the weight-gradient family
+        _check(_lib.dfine_multi_wgrad_reduce(_ptr(table), n_entries, _stream()), "dfine_multi_wgrad_reduce")
 
 
 # ------------------------------------------------------------------------------------- FDR head
