@@ -20,7 +20,7 @@ for _name in ("dfine", "configs", "matcher", "dfine_criterion", "dist_utils", "u
     _ALIASES[f"src.d_fine.{_name}"] = f"custom_d_fine_amd.d_fine.{_name}"
 for _name in ("hgnetv2", "common", "hybrid_encoder", "dfine_decoder", "utils"):
     _ALIASES[f"src.d_fine.arch.{_name}"] = f"custom_d_fine_amd.d_fine.arch.{_name}"
-for _name in ("train", "export", "engine", "synthetic", "fused_optim", "postprocess"):
+for _name in ("train", "export", "engine", "synthetic", "fused_optim", "postprocess", "validator"):
     _ALIASES[f"src.dl.{_name}"] = f"custom_d_fine_amd.dl.{_name}"
 
 

@@ -203,3 +203,42 @@ def criterion_targets_and_meta(B=2, dn=8, C=6, device="cpu"):
     pos = torch.tensor([0, 1, 4, 5])
     meta = {"dn_positive_idx": tuple(pos.clone() for _ in range(B)), "dn_num_group": 2, "dn_num_split": [dn, 0]}
     return targets, meta
+
+
+def make_validator_case(seed, n_images=12, n_classes=5):
+    """Ground truth / prediction lists in the Validator's format (absolute xyxy boxes): per image a few GT boxes;
+    predictions = jittered copies (some with a wrong label), duplicates of the same object, pure false positives and
+    misses; some images without GT and / or without predictions."""
+    import numpy as np
+    import torch
+    rng = np.random.default_rng(seed)
+    gt, preds = [], []
+    for i in range(n_images):
+        n = int(rng.integers(0, 6)) if i % 5 else 0
+        xy = rng.uniform(20, 400, (n, 2))
+        wh = rng.uniform(20, 160, (n, 2))
+        g_boxes = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        g_labels = rng.integers(0, n_classes, n)
+        p_boxes, p_labels, p_scores = [], [], []
+        for b, l in zip(g_boxes, g_labels):
+            r = rng.uniform()
+            if r < 0.15:
+                continue                                              # miss
+            jitter = rng.normal(0, 6 if r < 0.8 else 40, 4).astype(np.float32)
+            p_boxes.append(b + jitter)
+            p_labels.append(l if rng.uniform() < 0.8 else (l + 1) % n_classes)
+            p_scores.append(rng.uniform(0.3, 1.0))
+            if rng.uniform() < 0.25:                                  # duplicate detection of the same object
+                p_boxes.append(b + rng.normal(0, 3, 4).astype(np.float32))
+                p_labels.append(l)
+                p_scores.append(rng.uniform(0.3, 1.0))
+        for _ in range(int(rng.integers(0, 3)) if i % 7 else 0):      # pure false positives
+            q = rng.uniform(20, 400, 2)
+            p_boxes.append(np.concatenate([q, q + rng.uniform(20, 100, 2)]).astype(np.float32))
+            p_labels.append(int(rng.integers(0, n_classes)))
+            p_scores.append(rng.uniform(0.3, 1.0))
+        gt.append({"labels": torch.tensor(g_labels, dtype=torch.int64), "boxes": torch.tensor(g_boxes).reshape(-1, 4)})
+        preds.append({"labels": torch.tensor(p_labels, dtype=torch.int64),
+                      "boxes": torch.tensor(np.array(p_boxes, dtype=np.float32)).reshape(-1, 4),
+                      "scores": torch.tensor(p_scores, dtype=torch.float32)})
+    return gt, preds

@@ -1,0 +1,87 @@
+"""(f2) evaluation metrics: `custom_d_fine_amd.dl.validator.Validator` against goldens generated from the reference's
+`Validator` (tools/gen_golden.py::gen_validator, box path, compute_maps=False) and against the known-answer cases of the
+reference's own self-test (`src/dl/validator.py:727-800`, restated with boxes instead of masks)."""
+import numpy as np
+import pytest
+import torch
+
+from custom_d_fine_amd.dl.validator import Validator, coco_map
+from tests import helpers
+
+G = helpers.GOLDEN_DIR
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("thr", [0.5, 0.75])
+def test_box_metrics_match_reference(seed, thr):
+    g = np.load(f"{G}/validator.npz")
+    k = f"s{seed}_t{int(thr * 100)}"
+    gt, preds = helpers.make_validator_case(seed)
+    v = Validator(gt, preds, {i: f"c{i}" for i in range(5)}, conf_thresh=0.5, iou_thresh=thr, compute_maps=False)
+    m = v.compute_metrics(extended=True)
+    for name in ("TPs", "FPs", "FNs"):
+        assert m[name] == int(g[f"{k}/{name}"]), name                      # integer work: exact
+    for name in ("f1", "precision", "recall"):
+        assert abs(m[name] - float(g[f"{k}/{name}"])) < 1e-12, name
+    assert abs(m["iou"] - float(g[f"{k}/iou"])) < 1e-6
+    assert np.array_equal(v.conf_matrix, g[f"{k}/conf_matrix"])
+    assert sorted(v.class_to_idx) == g[f"{k}/classes"].tolist()
+    ext = m["extended_metrics"]
+    assert sorted(ext) == g[f"{k}/ext_keys"].tolist()
+    np.testing.assert_allclose([float(ext[x]) for x in sorted(ext)], g[f"{k}/ext_vals"], rtol=0, atol=1e-6)
+
+
+def _sample(boxes, labels, scores=None):
+    out = {"boxes": torch.tensor(boxes, dtype=torch.float32).reshape(-1, 4), "labels": torch.tensor(labels, dtype=torch.int64)}
+    if scores is not None:
+        out["scores"] = torch.tensor(scores, dtype=torch.float32)
+    return out
+
+
+def test_known_answer_cases_of_the_reference_self_test():
+    names = {0: "class_0", 1: "class_1"}
+    box = [1.0, 1.0, 3.0, 3.0]
+    # perfect match
+    m = Validator([_sample([box], [0])], [_sample([box], [0], [1.0])], names, compute_maps=False).compute_metrics()
+    assert m["precision"] == 1.0 and m["recall"] == 1.0 and abs(m["iou"] - 1.0) < 1e-6
+    # partial match above the threshold: 4x4 vs 4x3 -> IoU 0.75
+    m = Validator([_sample([[0, 0, 4, 4]], [0])], [_sample([[0, 0, 4, 3]], [0], [1.0])], names, compute_maps=False).compute_metrics()
+    assert m["precision"] == 1.0 and m["recall"] == 1.0 and abs(m["iou"] - 0.75) < 1e-6
+    # misclassification: FP for the predicted class, FN for the GT class
+    m = Validator([_sample([box], [0])], [_sample([box], [1], [1.0])], names, compute_maps=False).compute_metrics()
+    assert m["precision"] == 0.0 and m["recall"] == 0.0 and m["iou"] == 0.0 and m["FPs"] == 1 and m["FNs"] == 1
+    # pure false positive
+    m = Validator([_sample([], [])], [_sample([box], [0], [1.0])], names, compute_maps=False).compute_metrics()
+    assert m["precision"] == 0.0 and m["recall"] == 0.0 and m["FPs"] == 1 and m["FNs"] == 0
+    # nothing at all
+    m = Validator([_sample([], [])], [_sample([], [], [])], names, compute_maps=False).compute_metrics()
+    assert m["TPs"] == m["FPs"] == m["FNs"] == 0 and m["f1"] == 0
+
+
+def test_coco_map_properties():
+    """mAP restatement (unpinned against torchmetrics, absent here): 1.0 for perfect detections, invariant to extra low-score
+    false positives ranked after every true positive only in recall, lower with a misplaced box, -1 without ground truth."""
+    gt, _ = helpers.make_validator_case(4)
+    perfect = [{"boxes": g["boxes"].clone(), "labels": g["labels"].clone(), "scores": torch.full((len(g["labels"]),), 0.9)} for g in gt]
+    m = coco_map(gt, perfect)
+    assert abs(m["map"] - 1.0) < 1e-9 and abs(m["map_50"] - 1.0) < 1e-9
+    shifted = [{"boxes": p["boxes"] + 8.0, "labels": p["labels"], "scores": p["scores"]} for p in perfect]
+    m2 = coco_map(gt, shifted)
+    assert m2["map"] < m["map"] and m2["map_50"] <= 1.0
+    noisy = [{"boxes": torch.cat([p["boxes"], torch.tensor([[500.0, 500.0, 520.0, 520.0]])]),
+              "labels": torch.cat([p["labels"], torch.tensor([0])]), "scores": torch.cat([p["scores"], torch.tensor([0.05])])} for p in perfect]
+    assert abs(coco_map(gt, noisy)["map_50"] - 1.0) < 1e-9
+    assert coco_map([_sample([], [])], [_sample([[1, 1, 2, 2]], [0], [0.5])])["map"] == -1.0
+    full = Validator(gt, perfect, {i: f"c{i}" for i in range(5)}).compute_metrics()
+    assert abs(full["mAP_50_95"] - 1.0) < 1e-9 and full["f1"] == 1.0
+
+
+@pytest.mark.gpu
+def test_device_resident_boxes(cuda):
+    gt, preds = helpers.make_validator_case(2)
+    gt_d = [{k: v.to(cuda) for k, v in g.items()} for g in gt]
+    pr_d = [{k: v.to(cuda) for k, v in p.items()} for p in preds]
+    a = Validator(gt, preds, {i: f"c{i}" for i in range(5)}).compute_metrics()
+    b = Validator(gt_d, pr_d, {i: f"c{i}" for i in range(5)}).compute_metrics()
+    for k in a:
+        assert abs(float(a[k]) - float(b[k])) < 1e-6, k

@@ -304,12 +304,51 @@ def gen_backbone_encoder():
     save("backbone_encoder_m320.npz", **out)
 
 
+def gen_validator():
+    """Box metrics of the reference's `Validator` (src/dl/validator.py:295-451: greedy IoU matching, per-class TP / FP / FN /
+    IoU lists, confusion matrix) on seeded detection lists; `compute_maps=False` (torchmetrics / faster_coco_eval are not in
+    this container) and torchvision's `box_iou` supplied as the standard pairwise IoU."""
+    import importlib
+    import torchvision
+
+    def box_iou(a, b):
+        area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+        area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        lt = torch.max(a[:, None, :2], b[None, :, :2])
+        rb = torch.min(a[:, None, 2:], b[None, :, 2:])
+        wh = (rb - lt).clamp(min=0)
+        inter = wh[..., 0] * wh[..., 1]
+        return inter / (area_a[:, None] + area_b[None] - inter)
+
+    torchvision.ops.box_iou = box_iou
+    V = importlib.import_module("src.dl.validator")
+    assert V.__file__.startswith("/root/reference/")
+    out = {}
+    for seed in (1, 2, 3):
+        gt, preds = helpers.make_validator_case(seed)
+        for thr in (0.5, 0.75):
+            import copy
+            v = V.Validator(copy.deepcopy(gt), copy.deepcopy(preds), {i: f"c{i}" for i in range(5)}, conf_thresh=0.5,
+                            iou_thresh=thr, compute_maps=False)
+            m = v.compute_metrics(extended=True)
+            k = f"s{seed}_t{int(thr * 100)}"
+            for name in ("f1", "precision", "recall", "iou", "TPs", "FPs", "FNs"):
+                out[f"{k}/{name}"] = np.float64(m[name])
+            ext = m["extended_metrics"]
+            out[f"{k}/ext_keys"] = np.array(sorted(ext))
+            out[f"{k}/ext_vals"] = np.array([float(ext[x]) for x in sorted(ext)], dtype=np.float64)
+            out[f"{k}/conf_matrix"] = v.conf_matrix
+            out[f"{k}/classes"] = np.array(sorted(v.class_to_idx))
+    save("validator.npz", **out)
+
+
 GENERATORS = {
     "lsap": gen_lsap, "msda": gen_msda, "matcher": gen_matcher, "criterion": gen_criterion,
     "model_n320": lambda: gen_model("n", 320, 2, "model_n320.npz"),
     "model_m640_eval": lambda: gen_model("m", 640, 1, "model_m640_eval.npz", train=False),
     "model_s320": lambda: gen_model("s", 320, 2, "model_s320.npz"),
     "backbone_encoder": gen_backbone_encoder, "postprocess": gen_postprocess, "mask_units": gen_mask_units, "model_n320_mask": gen_mask_model,
+    "validator": gen_validator,
 }
 
 if __name__ == "__main__":
