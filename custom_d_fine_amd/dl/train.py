@@ -142,6 +142,36 @@ class Trainer:
         self.step.iters = state["iters"]
         self.start_epoch = state["epoch"] + 1
 
+    @torch.no_grad()
+    def evaluate(self, n_batches=2, conf_thresh=0.5, iou_thresh=0.5, keep_ratio=False):
+        """Evaluation pass of the (EMA) model on synthetic batches: forward -> `preds_postprocess` / `gt_postprocess`
+        (device-side top-K and box mapping) -> `Validator` metrics - the hand-off of the reference's
+        `Trainer.get_preds_and_gt` + `evaluate` (train.py:384-474)."""
+        from .postprocess import gt_postprocess, preds_postprocess
+        from .validator import Validator
+        t = self.cfg["train"]
+        model = self.ema.model if self.ema is not None else self.model
+        model = model.module if hasattr(model, "module") else model
+        was_training = model.training
+        model.eval()
+        size = t["img_size"][0]
+        all_preds, all_gt = [], []
+        amp = self.step.amp_dtype
+        for it in range(n_batches):
+            images, targets = make_batch(t["batch_size"], size, t["num_classes"], seed=t["seed"] + 777 + it, device=self.device)
+            orig = torch.tensor([[size, size]] * len(targets))
+            if amp is not None:
+                with torch.autocast(self.device.type, dtype=amp):
+                    out = model(images)
+            else:
+                out = model(images)
+            out = {k: v.float() for k, v in out.items() if k in ("pred_logits", "pred_boxes")}
+            all_preds += preds_postprocess(images, out, orig, t["num_classes"], keep_ratio, conf_thresh)
+            all_gt += gt_postprocess(images, targets, orig, keep_ratio)
+        model.train(was_training)
+        names = {i: str(i) for i in range(t["num_classes"])}
+        return Validator(all_gt, all_preds, names, conf_thresh=conf_thresh, iou_thresh=iou_thresh).compute_metrics()
+
     def train(self):
         t = self.cfg["train"]
         size = t["img_size"][0]

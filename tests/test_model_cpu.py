@@ -229,3 +229,7 @@ def test_trainer_plumbing_and_resume(oracle_backend, tmp_path):
     k0 = next(iter(sa))
     assert torch.equal(sa[k0]["exp_avg"], sb[k0]["exp_avg"]) and sa[k0]["step"] == sb[k0]["step"]
     assert tr2.scheduler.last_epoch == tr.scheduler.last_epoch
+    # evaluation hand-off: eval forward -> post-processing -> metrics (random weights: only the plumbing is checked)
+    m = tr.evaluate(n_batches=1, conf_thresh=0.01)
+    assert {"f1", "precision", "recall", "iou", "TPs", "FPs", "FNs", "mAP_50", "mAP_50_95"} <= set(m)
+    assert m["FNs"] + m["TPs"] > 0 and 0.0 <= m["precision"] <= 1.0 and m["mAP_50_95"] <= m["mAP_50"] + 1e-12
