@@ -31,7 +31,50 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
-__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
+// EPL consecutive elements of one lane: one 16-byte (fp32) / 8-byte (bf16) access per 4 elements when EPL % 4 == 0 (the
+// dtype branch is per row, wave-uniform), element-wise otherwise
+template <int EPL>
+__device__ __forceinline__ void ln_load_vec(const void *p, int dt, int64_t i, float (&o)[EPL]) {
+    if (EPL % 4 == 0) {
+        if (dt == DFINE_F32) {
+#pragma unroll
+            for (int e = 0; e < EPL; e += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p) + i + e);
+                o[e] = v.x; o[e + 1] = v.y; o[e + 2] = v.z; o[e + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; e += 4) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(p) + i + e);
+                o[e] = __uint_as_float(v.x << 16); o[e + 1] = __uint_as_float(v.x & 0xffff0000u);
+                o[e + 2] = __uint_as_float(v.y << 16); o[e + 3] = __uint_as_float(v.y & 0xffff0000u);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[e] = ln_load(p, dt, i + e);
+    }
+}
+template <int EPL>
+__device__ __forceinline__ void ln_store_vec(void *p, int dt, int64_t i, const float (&v)[EPL]) {
+    if (EPL % 4 == 0) {
+        if (dt == DFINE_F32) {
+#pragma unroll
+            for (int e = 0; e < EPL; e += 4)
+                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p) + i + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; e += 4)
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(p) + i + e) =
+                    make_uint2(pack_bf16x2(v[e], v[e + 1]), pack_bf16x2(v[e + 2], v[e + 3]));
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) ln_store(p, dt, i + e, v[e]);
+    }
+}
 
 struct LnArgs {
     const void *a, *b, *gate;
@@ -43,14 +86,22 @@ struct LnArgs {
 template <int EPL>
 __device__ __forceinline__ void ln_row_z(const LnArgs &p, int64_t row, int D, int lane, float (&z)[EPL], float (&av)[EPL],
                                          float (&bv)[EPL], float (&s1)[EPL], float (&s2)[EPL]) {
+    const int64_t base = row * D + lane * EPL;
+    ln_load_vec<EPL>(p.a, p.a_dt, base, av);
+    if (p.b) ln_load_vec<EPL>(p.b, p.b_dt, base, bv);
+    else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) bv[e] = 0.f;
+    }
+    if (p.mode == 2) {
+        ln_load_vec<EPL>(p.gate, p.g_dt, row * 2 * D + lane * EPL, s1);
+        ln_load_vec<EPL>(p.gate, p.g_dt, row * 2 * D + D + lane * EPL, s2);
+    }
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-        const int col = lane * EPL + e;
-        av[e] = ln_load(p.a, p.a_dt, row * D + col);
-        bv[e] = p.b ? ln_load(p.b, p.b_dt, row * D + col) : 0.f;
         if (p.mode == 2) {
-            s1[e] = sigmoidf(ln_load(p.gate, p.g_dt, row * 2 * D + col));
-            s2[e] = sigmoidf(ln_load(p.gate, p.g_dt, row * 2 * D + D + col));
+            s1[e] = sigmoidf(s1[e]);
+            s2[e] = sigmoidf(s2[e]);
             z[e] = s1[e] * av[e] + s2[e] * bv[e];
         } else {
             z[e] = av[e] + bv[e];
@@ -80,12 +131,11 @@ __global__ __launch_bounds__(kLnThreads) void ln_fused_fwd_kernel(LnArgs p, cons
 #pragma unroll
         for (int e = 0; e < EPL; ++e) { const float d = z[e] - mean; v += d * d; }
         const float rstd = rsqrtf(wave_sum(v) / (float)D + eps);
+        float o[EPL];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const float o = (z[e] - mean) * rstd * w[e] + bt[e];
-            y[row * D + lane * EPL + e] = o;
-            if (y16) y16[row * D + lane * EPL + e] = f32_to_bf16(o);     // the copy the following GEMMs read
-        }
+        for (int e = 0; e < EPL; ++e) o[e] = (z[e] - mean) * rstd * w[e] + bt[e];
+        ln_store_vec<EPL>(y, DFINE_F32, row * D + lane * EPL, o);
+        if (y16) ln_store_vec<EPL>(y16, DFINE_BF16, row * D + lane * EPL, o);     // the copy the following GEMMs read
         if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
     }
 }
@@ -107,9 +157,9 @@ __global__ __launch_bounds__(kLnThreads) void ln_fused_bwd_kernel(LnArgs p, cons
         ln_row_z<EPL>(p, row, D, lane, z, av, bv, s1, s2);
         const float mean = mean_in[row], rstd = rstd_in[row];
         float c1 = 0.f, c2 = 0.f;
+        ln_load_vec<EPL>(dy, DFINE_F32, row * D + lane * EPL, g);
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-            g[e] = dy[row * D + lane * EPL + e];
             xh[e] = (z[e] - mean) * rstd;
             gw_acc[e] += g[e] * xh[e];
             gb_acc[e] += g[e];
@@ -118,25 +168,31 @@ __global__ __launch_bounds__(kLnThreads) void ln_fused_bwd_kernel(LnArgs p, cons
         }
         c1 = wave_sum(c1) / (float)D;
         c2 = wave_sum(c2) / (float)D;
+        float dz[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-            const int col = lane * EPL + e;
-            float dz = rstd * (g[e] * w[e] - c1 - xh[e] * c2);
+            dz[e] = rstd * (g[e] * w[e] - c1 - xh[e] * c2);
             if (p.mode == 1) {                                    // clamp passes the gradient strictly inside the range
                 const float raw = av[e] + bv[e];
-                if (!(raw >= -p.clampv && raw <= p.clampv)) dz = 0.f;
+                if (!(raw >= -p.clampv && raw <= p.clampv)) dz[e] = 0.f;
             }
-            if (p.mode == 2) {
-                if (da) ln_store(da, p.a_dt, row * D + col, dz * s1[e]);
-                if (db) ln_store(db, p.b_dt, row * D + col, dz * s2[e]);
-                if (dgate) {
-                    ln_store(dgate, p.g_dt, row * 2 * D + col, dz * av[e] * s1[e] * (1.f - s1[e]));
-                    ln_store(dgate, p.g_dt, row * 2 * D + D + col, dz * bv[e] * s2[e] * (1.f - s2[e]));
-                }
-            } else {
-                if (da) ln_store(da, p.a_dt, row * D + col, dz);
-                if (db && p.b) ln_store(db, p.b_dt, row * D + col, dz);
+        }
+        const int64_t base = row * D + lane * EPL;
+        if (p.mode == 2) {
+            float t1[EPL], t2[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { t1[e] = dz[e] * s1[e]; t2[e] = dz[e] * s2[e]; }
+            if (da) ln_store_vec<EPL>(da, p.a_dt, base, t1);
+            if (db) ln_store_vec<EPL>(db, p.b_dt, base, t2);
+            if (dgate) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) { t1[e] *= av[e] * (1.f - s1[e]); t2[e] *= bv[e] * (1.f - s2[e]); }
+                ln_store_vec<EPL>(dgate, p.g_dt, row * 2 * D + lane * EPL, t1);
+                ln_store_vec<EPL>(dgate, p.g_dt, row * 2 * D + D + lane * EPL, t2);
             }
+        } else {
+            if (da) ln_store_vec<EPL>(da, p.a_dt, base, dz);
+            if (db && p.b) ln_store_vec<EPL>(db, p.b_dt, base, dz);
         }
     }
     // column sums over the block's rows: waves combine through LDS, the block writes ONE partial row; a second tiny
