@@ -121,14 +121,14 @@ __global__ __launch_bounds__(kLT) void vfl_kernel(const T *__restrict__ logits, 
                                                   float alpha, float gamma, float s_vfl,
                                                   T *__restrict__ grad, float *__restrict__ out) {
     __shared__ float red[kLT / 64];
-    const int64_t n = (int64_t)B * Q * C;
+    const uint32_t n = (uint32_t)B * Q * C;               // < 2^31 (checked by the entry point): 32-bit index arithmetic
     float acc = 0.f;
-    for (int64_t e = (int64_t)blockIdx.x * kLT + threadIdx.x; e < n; e += (int64_t)gridDim.x * kLT) {
-        const int64_t row = e / C;
+    for (uint32_t e = blockIdx.x * kLT + threadIdx.x; e < n; e += gridDim.x * kLT) {
+        const uint32_t row = e / (uint32_t)C;
         const int c = (int)(e - row * C);
-        const int64_t b = row / Q, q = row - b * Q;
-        const float x = load_f(logits + b * lv.sb + q * lv.sq + c);
-        const float p = 1.f / (1.f + __expf(-x));
+        const uint32_t b = row / (uint32_t)Q, q = row - b * Q;
+        const float x = load_f(logits + (int64_t)b * lv.sb + (int64_t)q * lv.sq + c);
+        const float p = __builtin_amdgcn_rcpf(1.f + __expf(-x));
         const int m = map[row];
         float t = 0.f, w;
         if (m >= 0 && labels[plan[2 * M + m]] == c) { t = iou[m]; w = t; }
@@ -320,6 +320,7 @@ int dfine_head_losses(
         hipLaunchKernelGGL(pair_box_kernel<float>, dim3((M_box + kLT - 1) / kLT), dim3(kLT), 0, st, boxes, bv, tgt_boxes,
                            box_plan, M_box, Q, iou_box, map_box, grad_l1, grad_giou, out + 1, 1, s_l1, s_giou);
     const int64_t n = (int64_t)B * Q * C;
+    if (n >= ((int64_t)1 << 31) - 2048 * kLT) return DFINE_E_BADARG;      // the kernels index the logits with 32 bits
     const int vb = (int)((n + kLT - 1) / kLT < 2048 ? (n + kLT - 1) / kLT : 2048);
     const View lv{l_sb, l_sq};
     if (dtype == DFINE_F32)
