@@ -255,6 +255,9 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const uint16_
                     ds[r] = p * (dp[r] - dl[t]) * scale;
                 }
                 pk[kt][0] = pack2(ds[0], ds[1]); pk[kt][1] = pack2(ds[2], ds[3]);
+                // keep the 16 key tiles in program order: with the one-instruction bf16 packing the scheduler otherwise
+                // hoists all fragment reads and MFMAs of the unrolled loop (332 registers, one wave per SIMD, 2x slower)
+                if (kt & 1) __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int ks = 0; ks < kKB / 32; ++ks) {
@@ -263,6 +266,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const uint16_
                 for (int d = 0; d < 2; ++d)
                     dacc[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sK + ks * 32 * kP48 + tr_off + 16 * d, kP48), pf,
                                                                          dacc[t][d], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }

@@ -24,12 +24,13 @@ __device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_floa
 // arithmetic it replaces costs ~6 VALU instructions per element, which matters: the element-wise kernels (BatchNorm,
 // activations, epilogues) run close to the VALU roofline, not only the HBM one.
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-    const f32x2_t v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+    // inline asm, not __builtin_convertvector to a __bf16 vector: the vector-typed conversion made the register allocator
+    // give attn_bwd_dq_kernel 332 VGPRs (one wave per SIMD, 2x slower) where this form needs 88
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return (uint16_t)(pack_bf16x2(f, f) & 0xffffu); }
 
 struct f32x4 { float x, y, z, w; };
 
