@@ -13,7 +13,7 @@ durations (HIP events around every step).  Extra objects:
   roofline          the dominant kernel FAMILY by device time: the dense-convolution implicit GEMMs of backbone + encoder
                     (forward, data gradient, weight gradient; MFMA roof).  achieved = algorithmic FLOPs of the timed
                     launches / their summed duration, both taken live with HIP events on the launch stream inside the
-                    timed region (every `--sample-every`-th step - 2 of the default 50 - is instrumented, hip.py `_timed`: ~1 400 events
+                    timed region (every `--sample-every`-th step - 1 of the default 50 - is instrumented, hip.py `_timed`: ~1 400 events
                     cost such a step ~15 ms, so sampling keeps `value` within ~1 % of the un-instrumented rate).
   roofline_kernels  the same figures per kernel group (1x1 / 3x3 forward+dgrad, weight gradients, stem, token-stream
                     linear weight gradients) and the two deformable-attention kernels against the HBM roof
@@ -148,7 +148,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--mask", type=int, default=0, help="1: segmentation head (BASELINE configs[4])")
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-baseline steps (0 = skip)")
-    ap.add_argument("--sample-every", type=int, default=25, help="instrument every n-th timed step with HIP events (0 = none)")
+    ap.add_argument("--sample-every", type=int, default=50,
+                    help="instrument every n-th timed step with HIP events around the kernel launches (0 = none); an instrumented "
+                         "step is ~15 ms slower, so the default samples one step of the 50")
     ap.add_argument("--channels-last", type=int, default=0)
     args = ap.parse_args()
 
