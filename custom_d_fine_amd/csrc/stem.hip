@@ -42,9 +42,12 @@ __global__ void stem_pack_kernel(const float *__restrict__ w, float *__restrict_
 // y[b][co][yo][xo] = sum_{ci,ky,kx} x[b][ci][yo*S+ky-pad][xo*S+kx-pad] * wp[(ci,ky,kx)][co]   (0 outside the plane)
 template <int CIN, int COUT, int KS, int S>
 __global__ __launch_bounds__(kStemThreads) void stem_conv_kernel(const uint16_t *__restrict__ x,
+                                                                 const uint16_t *__restrict__ x2, int CA,
                                                                  const float *__restrict__ wp,
                                                                  uint16_t *__restrict__ y, int H, int W, int Ho,
                                                                  int Wo, int pad) {
+    // x2 != nullptr: the input is the channel concatenation [x (CA channels) | x2 (CIN - CA)] read in place (StemBlock's
+    // torch.cat of the pooled stem1 map and the stem2 branch, ref hgnetv2.py:158-163)
     const int p = blockIdx.x * kStemThreads + threadIdx.x;
     const int b = blockIdx.y;
     if (p >= Ho * Wo) return;
@@ -52,7 +55,11 @@ __global__ __launch_bounds__(kStemThreads) void stem_conv_kernel(const uint16_t 
     float acc[COUT];
 #pragma unroll
     for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
-    const uint16_t *xb = x + (int64_t)b * CIN * H * W;
+    const int64_t HWi = (int64_t)H * W;
+    const uint16_t *xa_b = x + (int64_t)b * (x2 ? CA : CIN) * HWi;
+    const uint16_t *xb_b = x2 ? x2 + (int64_t)b * (CIN - CA) * HWi : nullptr;
+    auto chan = [&](int ci) -> const uint16_t * { return (x2 && ci >= CA) ? xb_b + (int64_t)(ci - CA) * HWi : xa_b + (int64_t)ci * HWi; };
+    const uint16_t *xb = xa_b;
     const int yi0 = yo * S - pad, xi0 = xo * S - pad;
     // tap offsets / validity do not depend on the channel; loads are unconditional (clamped address, value
     // zeroed afterwards) so that the KS*KS loads of a channel are all in flight before the first FMA
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(kStemThreads) void stem_conv_kernel(const uint16_t 
     for (int t = 0; t < KS * KS; ++t) raw[t] = xb[toff[t]];
     for (int ci = 0; ci < CIN; ++ci) {
         const float *wc = wp + ci * (KS * KS * COUT);           // wave-uniform -> scalar loads
-        const uint16_t *xn = xb + (int64_t)min(ci + 1, CIN - 1) * H * W;        // next channel's taps in flight
+        const uint16_t *xn = chan(min(ci + 1, CIN - 1));                        // next channel's taps in flight
 #pragma unroll
         for (int t = 0; t < KS * KS; ++t) nxt[t] = xn[toff[t]];
 #pragma unroll
@@ -96,8 +103,9 @@ __global__ __launch_bounds__(kStemThreads) void stem_conv_kernel(const uint16_t 
 template <int CIN, int COUT>
 __global__ __launch_bounds__(kStemThreads) void stem_dgrad_s2_kernel(const uint16_t *__restrict__ dy,
                                                                      const float *__restrict__ wq,
-                                                                     uint16_t *__restrict__ dx, int H, int W, int Ho,
-                                                                     int Wo) {
+                                                                     uint16_t *__restrict__ dx, uint16_t *__restrict__ dx2,
+                                                                     int CA, int H, int W, int Ho, int Wo) {
+    // dx2 != nullptr: channels [0, CA) of the gradient go to dx, [CA, CIN) to dx2 (one contiguous tensor per concatenated input)
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int yi = blockIdx.y, b = blockIdx.z;
     if (c >= Wo) return;
@@ -140,10 +148,14 @@ __global__ __launch_bounds__(kStemThreads) void stem_dgrad_s2_kernel(const uint1
         }
         r0 = n0; r1 = n1;
     }
-    uint16_t *o = dx + ((int64_t)b * CIN * H + yi) * W + 2 * c;
+    const int64_t HWi = (int64_t)H * W, rowoff = (int64_t)yi * W + 2 * c;
+    uint16_t *oa = dx + (int64_t)b * (dx2 ? CA : CIN) * HWi + rowoff;
+    uint16_t *ob = dx2 ? dx2 + (int64_t)b * (CIN - CA) * HWi + rowoff : nullptr;
 #pragma unroll
-    for (int ci = 0; ci < CIN; ++ci)
-        *reinterpret_cast<uint32_t *>(o + (int64_t)ci * H * W) = pack_bf16x2(a0[ci], a1[ci]);
+    for (int ci = 0; ci < CIN; ++ci) {
+        uint16_t *o = (dx2 && ci >= CA) ? ob + (int64_t)(ci - CA) * HWi : oa + (int64_t)ci * HWi;
+        *reinterpret_cast<uint32_t *>(o) = pack_bf16x2(a0[ci], a1[ci]);
+    }
 }
 
 // 8 bf16 elements x[xi0 + j*S], j = 0..7, of one plane row as a packed MFMA fragment (0 outside [0, W)).
@@ -185,6 +197,7 @@ __device__ __forceinline__ uint4 stem_row8(const uint16_t *rowp, int xi0, int W,
 constexpr int kStemNT = 4;          // 16-column tiles per worker
 template <int S>
 __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(const uint16_t *__restrict__ x,
+                                                                  const uint16_t *__restrict__ x2, int CA,
                                                                   const uint16_t *__restrict__ dy,
                                                                   float *__restrict__ part, int CIN, int COUT, int KS,
                                                                   int pad, int H, int W, int Ho, int Wo,
@@ -197,12 +210,14 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(const uint16_t
     const int ncols = CIN * KS * KS;
     const int kk = KS * KS;
     int col_off[kStemNT], col_ky[kStemNT], col_kx[kStemNT];
+    bool col_b[kStemNT];                                         // the column's channel lives in the second source
 #pragma unroll
     for (int t = 0; t < kStemNT; ++t) {
         const int n = (g * kStemNT + t) * 16 + (lane & 15);
         const bool ok = n < ncols;
         const int ci = ok ? n / kk : 0, tap = ok ? n - ci * kk : 0;
-        col_off[t] = ok ? ci * H * W : -1;
+        col_b[t] = x2 != nullptr && ci >= CA;
+        col_off[t] = ok ? (col_b[t] ? ci - CA : ci) * H * W : -1;
         col_ky[t] = tap / KS;
         col_kx[t] = tap - (tap / KS) * KS;
     }
@@ -224,13 +239,14 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(const uint16_t
             if (co < COUT) av = *reinterpret_cast<const uint4 *>(dy + (((int64_t)b * COUT + co) * Ho + yo) * Wo + xo0);
             a[mt] = __builtin_bit_cast(stem_bf16x8, av);
         }
-        const uint16_t *xb = x + (int64_t)b * CIN * H * W;
+        const uint16_t *xb_a = x + (int64_t)b * (x2 ? CA : CIN) * H * W;
+        const uint16_t *xb_b = x2 ? x2 + (int64_t)b * (CIN - CA) * H * W : xb_a;
 #pragma unroll
         for (int t = 0; t < kStemNT; ++t) {
             if ((g * kStemNT + t) * 16 >= ncols) break;          // uniform
             const int yi = yo * S + col_ky[t] - pad;
             const bool row_ok = col_off[t] >= 0 && (unsigned)yi < (unsigned)H;
-            const uint16_t *rowp = xb + (row_ok ? col_off[t] + yi * W : 0);
+            const uint16_t *rowp = (col_b[t] ? xb_b : xb_a) + (row_ok ? col_off[t] + yi * W : 0);
             const int xi0 = xo0 * S + col_kx[t] - pad;
             const uint4 bv = stem_row8<S>(rowp, xi0, W, row_ok);
             const stem_bf16x8 bf = __builtin_bit_cast(stem_bf16x8, bv);
@@ -420,10 +436,10 @@ __global__ void stem_pool_bwd8_kernel(const uint16_t *__restrict__ x, const uint
 struct StemCfg { int cin, cout, ks, s; };
 
 template <int CIN, int COUT, int KS, int S>
-static void launch_stem(const uint16_t *x, const float *wp, uint16_t *y, int B, int H, int W, int Ho, int Wo, int pad,
-                        hipStream_t st) {
+static void launch_stem(const uint16_t *x, const uint16_t *x2, int ca, const float *wp, uint16_t *y, int B, int H, int W,
+                        int Ho, int Wo, int pad, hipStream_t st) {
     dim3 grid((Ho * Wo + kStemThreads - 1) / kStemThreads, B);
-    hipLaunchKernelGGL((stem_conv_kernel<CIN, COUT, KS, S>), grid, dim3(kStemThreads), 0, st, x, wp, y, H, W, Ho, Wo, pad);
+    hipLaunchKernelGGL((stem_conv_kernel<CIN, COUT, KS, S>), grid, dim3(kStemThreads), 0, st, x, x2, ca, wp, y, H, W, Ho, Wo, pad);
 }
 
 }  // namespace dfine
@@ -452,16 +468,33 @@ int dfine_stem_pack_weights(const float *w, float *wp, int Cout, int Cin, int KS
 
 // Direct convolution y[B,Cout,Ho,Wo] = conv(x[B,Cin,H,W]) with zero fill outside the plane; wp from
 // dfine_stem_pack_weights(mode 0) - or mode 1 with Cin/Cout exchanged (stride-1 data gradient, pad' = KS-1-pad).
+static int stem_conv_impl(const void *x, const void *x2, int ca, const float *wp, void *y, int B, int Cin, int Cout, int H, int W,
+                          int Ho, int Wo, int KS, int stride, int pad, void *stream);
+
 int dfine_stem_conv_bf16(const void *x, const float *wp, void *y, int B, int Cin, int Cout, int H, int W, int Ho, int Wo,
                          int KS, int stride, int pad, void *stream) {
+    return stem_conv_impl(x, nullptr, Cin, wp, y, B, Cin, Cout, H, W, Ho, Wo, KS, stride, pad, stream);
+}
+
+// The same with the input given as two tensors that the reference concatenates along the channels first
+// (xa [B, Ca, H, W], xb [B, Cin - Ca, H, W]).
+int dfine_stem_conv2_bf16(const void *xa, const void *xb, int Ca, const float *wp, void *y, int B, int Cin, int Cout, int H,
+                          int W, int Ho, int Wo, int KS, int stride, int pad, void *stream) {
+    if (!xb || Ca < 1 || Ca >= Cin) return DFINE_E_BADARG;
+    return stem_conv_impl(xa, xb, Ca, wp, y, B, Cin, Cout, H, W, Ho, Wo, KS, stride, pad, stream);
+}
+
+static int stem_conv_impl(const void *x, const void *x2, int ca, const float *wp, void *y, int B, int Cin, int Cout, int H, int W,
+                          int Ho, int Wo, int KS, int stride, int pad, void *stream) {
     if (B == 0) return DFINE_OK;
     if (!x || !wp || !y || H < 1 || W < 1 || Ho < 1 || Wo < 1) return DFINE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const uint16_t *xs = (const uint16_t *)x;
+    const uint16_t *xs2 = (const uint16_t *)x2;
     uint16_t *ys = (uint16_t *)y;
 #define STEM_CASE(CI, CO, K, S_)                                                         \
     if (Cin == CI && Cout == CO && KS == K && stride == S_) {                            \
-        launch_stem<CI, CO, K, S_>(xs, wp, ys, B, H, W, Ho, Wo, pad, st);                \
+        launch_stem<CI, CO, K, S_>(xs, xs2, ca, wp, ys, B, H, W, Ho, Wo, pad, st);       \
         return check_launch();                                                           \
     }
     // B2 (D-FINE-m): 3->24, 24->12, 12->24, 48->24, 24->32 and the stride-1 data gradients (channels swapped)
@@ -478,8 +511,23 @@ int dfine_stem_conv_bf16(const void *x, const float *wp, void *y, int B, int Cin
 
 // Data gradient of a 3x3 / stride 2 / pad 1 layer: dy [B,Cout,Ho,Wo] -> dx [B,Cin,2*Ho,2*Wo]; wq from
 // dfine_stem_pack_weights(mode 2).
+static int stem_dgrad_impl(const void *dy, const float *wq, void *dx, void *dx2, int ca, int B, int Cin, int Cout, int Ho, int Wo,
+                           void *stream);
+
 int dfine_stem_dgrad_s2_bf16(const void *dy, const float *wq, void *dx, int B, int Cin, int Cout, int Ho, int Wo,
                              void *stream) {
+    return stem_dgrad_impl(dy, wq, dx, nullptr, Cin, B, Cin, Cout, Ho, Wo, stream);
+}
+
+// The same writing the gradient of a two-tensor input (dfine_stem_conv2_bf16) as two contiguous tensors.
+int dfine_stem_dgrad_s2_2_bf16(const void *dy, const float *wq, void *dxa, void *dxb, int Ca, int B, int Cin, int Cout, int Ho,
+                               int Wo, void *stream) {
+    if (!dxb || Ca < 1 || Ca >= Cin) return DFINE_E_BADARG;
+    return stem_dgrad_impl(dy, wq, dxa, dxb, Ca, B, Cin, Cout, Ho, Wo, stream);
+}
+
+static int stem_dgrad_impl(const void *dy, const float *wq, void *dx, void *dx2, int ca, int B, int Cin, int Cout, int Ho, int Wo,
+                           void *stream) {
     if (B == 0) return DFINE_OK;
     if (!dy || !wq || !dx || Ho < 1 || Wo < 1) return DFINE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -488,7 +536,7 @@ int dfine_stem_dgrad_s2_bf16(const void *dy, const float *wq, void *dx, int B, i
 #define STEM_DG(CI, CO)                                                                                         \
     if (Cin == CI && Cout == CO) {                                                                              \
         hipLaunchKernelGGL((stem_dgrad_s2_kernel<CI, CO>), grid, dim3(bt), 0, st, (const uint16_t *)dy, wq, \
-                           (uint16_t *)dx, 2 * Ho, 2 * Wo, Ho, Wo);                                             \
+                           (uint16_t *)dx, (uint16_t *)dx2, ca, 2 * Ho, 2 * Wo, Ho, Wo);                        \
         return check_launch();                                                                                  \
     }
     STEM_DG(48, 24) STEM_DG(32, 16) STEM_DG(64, 32)
@@ -516,8 +564,22 @@ int64_t dfine_stem_wgrad_ws_floats(int B, int Cin, int Cout, int KS, int Ho, int
 }
 
 // dw [Cout,Cin,KS,KS] f32 (overwritten).  Wo % 32 == 0, Cout <= 32.
+static int stem_wgrad_impl(const void *x, const void *x2, int ca, const void *dy, float *dw, float *ws, int B, int Cin, int Cout,
+                           int H, int W, int Ho, int Wo, int KS, int stride, int pad, void *stream);
+
 int dfine_stem_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, int B, int Cin, int Cout, int H, int W,
                           int Ho, int Wo, int KS, int stride, int pad, void *stream) {
+    return stem_wgrad_impl(x, nullptr, Cin, dy, dw, ws, B, Cin, Cout, H, W, Ho, Wo, KS, stride, pad, stream);
+}
+
+int dfine_stem_wgrad2_bf16(const void *xa, const void *xb, int Ca, const void *dy, float *dw, float *ws, int B, int Cin, int Cout,
+                           int H, int W, int Ho, int Wo, int KS, int stride, int pad, void *stream) {
+    if (!xb || Ca < 1 || Ca >= Cin) return DFINE_E_BADARG;
+    return stem_wgrad_impl(xa, xb, Ca, dy, dw, ws, B, Cin, Cout, H, W, Ho, Wo, KS, stride, pad, stream);
+}
+
+static int stem_wgrad_impl(const void *x, const void *x2, int ca, const void *dy, float *dw, float *ws, int B, int Cin, int Cout,
+                           int H, int W, int Ho, int Wo, int KS, int stride, int pad, void *stream) {
     if (B == 0) return DFINE_OK;
     if (!x || !dy || !dw || !ws || Cout > 32 || Cout < 1 || Cin < 1 || Wo % 32 || KS < 1 || KS > 3 || pad > 1 ||
         (stride != 1 && stride != 2) || W < 8 * stride)
@@ -528,10 +590,10 @@ int dfine_stem_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, i
     hipStream_t st = (hipStream_t)stream;
     if (stride == 1)
         hipLaunchKernelGGL(stem_wgrad_kernel<1>, dim3((workers + 3) / 4), dim3(kStemThreads), 0, st, (const uint16_t *)x,
-                           (const uint16_t *)dy, ws, Cin, Cout, KS, pad, H, W, Ho, Wo, ng, ns, B * Ho * (Wo / 32), steps);
+                           (const uint16_t *)x2, ca, (const uint16_t *)dy, ws, Cin, Cout, KS, pad, H, W, Ho, Wo, ng, ns, B * Ho * (Wo / 32), steps);
     else
         hipLaunchKernelGGL(stem_wgrad_kernel<2>, dim3((workers + 3) / 4), dim3(kStemThreads), 0, st, (const uint16_t *)x,
-                           (const uint16_t *)dy, ws, Cin, Cout, KS, pad, H, W, Ho, Wo, ng, ns, B * Ho * (Wo / 32), steps);
+                           (const uint16_t *)x2, ca, (const uint16_t *)dy, ws, Cin, Cout, KS, pad, H, W, Ho, Wo, ng, ns, B * Ho * (Wo / 32), steps);
     if (int e = check_launch()) return e;
     const int total = Cout * Cin * KS * KS;
     (void)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)total, st);

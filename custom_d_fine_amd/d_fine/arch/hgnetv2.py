@@ -88,8 +88,8 @@ class StemBlock(nn.Module):
         # the max-pool read zeros past the bottom / right edge (HIP stem kernels; ATen composition on CPU)
         x = self.stem1(x)
         branch = self.stem2b(self.stem2a(x, pad_br=True), pad_br=True)
-        x = torch.cat([kernels.stem_pool(x), branch], dim=1)
-        return self.stem4(self.stem3(x))
+        # the concatenation is never built on the GPU: stem3 reads both tensors in place (kernels._StemConv2)
+        return self.stem4(self.stem3([kernels.stem_pool(x), branch]))
 
 
 class EseModule(nn.Module):

@@ -87,6 +87,9 @@ _SIGNATURES = {
     "dfine_stem_dgrad_s2_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfine_stem_wgrad_ws_floats": (_L, [_I, _I, _I, _I, _I, _I]),
     "dfine_stem_wgrad_bf16": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_stem_conv2_bf16": (c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_stem_dgrad_s2_2_bf16": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_stem_wgrad2_bf16": (c_int, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_stem_pool_fwd": (c_int, [_P, _P, _L, _I, _I, _P]),
     "dfine_stem_pool_bwd": (c_int, [_P, _P, _P, _L, _I, _I, _P]),
     "dfine_bn_act_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -930,6 +933,44 @@ def stem_wgrad(x, dy, ks, stride, pad):
     with _timed("stem_wgrad", 2.0 * B * ho * wo * cin * cout * ks * ks):
         _check(_lib.dfine_stem_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ho, wo, ks, stride,
                                           pad, _stream()), "dfine_stem_wgrad_bf16")
+    return dw
+
+
+def stem_conv2(xa, xb, wp, cout, ks, stride, pad, out_hw):
+    """stem_conv of the channel concatenation [xa | xb] read in place."""
+    B, ca, H, W = xa.shape
+    cin = ca + xb.shape[1]
+    ho, wo = out_hw
+    y = torch.empty(B, cout, ho, wo, device=xa.device, dtype=torch.bfloat16)
+    with _timed("stem_conv", 2.0 * B * ho * wo * cin * cout * ks * ks):
+        _check(_lib.dfine_stem_conv2_bf16(_ptr(xa), _ptr(xb), ca, _ptr(wp), _ptr(y), B, cin, cout, H, W, ho, wo, ks, stride,
+                                          pad, _stream()), "dfine_stem_conv2_bf16")
+    return y
+
+
+def stem_dgrad_s2_2(dy, wq, ca, cb):
+    B, cout, ho, wo = dy.shape
+    dxa = torch.empty(B, ca, 2 * ho, 2 * wo, device=dy.device, dtype=torch.bfloat16)
+    dxb = torch.empty(B, cb, 2 * ho, 2 * wo, device=dy.device, dtype=torch.bfloat16)
+    with _timed("stem_conv", 2.0 * B * ho * wo * (ca + cb) * cout * 9):
+        _check(_lib.dfine_stem_dgrad_s2_2_bf16(_ptr(dy), _ptr(wq), _ptr(dxa), _ptr(dxb), ca, B, ca + cb, cout, ho, wo,
+                                               _stream()), "dfine_stem_dgrad_s2_2_bf16")
+    return dxa, dxb
+
+
+def stem_wgrad2(xa, xb, dy, ks, stride, pad):
+    B, ca, H, W = xa.shape
+    cin = ca + xb.shape[1]
+    _, cout, ho, wo = dy.shape
+    need = int(_lib.dfine_stem_wgrad_ws_floats(B, cin, cout, ks, ho, wo))
+    key = (xa.device.index, _stream())
+    ws = _STEM_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _STEM_WS[key] = torch.empty(need, device=xa.device, dtype=torch.float32)
+    dw = torch.empty(cout, cin, ks, ks, device=xa.device, dtype=torch.float32)
+    with _timed("stem_wgrad", 2.0 * B * ho * wo * cin * cout * ks * ks):
+        _check(_lib.dfine_stem_wgrad2_bf16(_ptr(xa), _ptr(xb), ca, _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ho, wo, ks,
+                                           stride, pad, _stream()), "dfine_stem_wgrad2_bf16")
     return dw
 
 

@@ -843,6 +843,40 @@ class _StemConv(torch.autograd.Function):
         return dx, dw, None, None, None
 
 
+class _StemConv2(torch.autograd.Function):
+    """3x3 / stride-2 stem convolution of torch.cat([xa, xb], 1) that never builds the concatenation (StemBlock: pooled stem1
+    map + stem2 branch -> stem3, ref hgnetv2.py:158-165): both tensors are read in place and the data gradient comes back as
+    two contiguous tensors (the concatenation costs a 630 MB copy forward and two 315 MB `.contiguous()` copies of the
+    sliced gradient backward at D-FINE-m / 640 / bs 32)."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, weight, pad):
+        hip = _hip()
+        xa, xb = xa.contiguous(), xb.contiguous()
+        cout, cin, ks, _ = weight.shape
+        H, W = xa.shape[2], xa.shape[3]
+        ho, wo = (H + 2 * pad - ks) // 2 + 1, (W + 2 * pad - ks) // 2 + 1
+        y = hip.stem_conv2(xa, xb, _packed_stem(weight, 0), cout, ks, 2, pad, (ho, wo))
+        ctx.save_for_backward(xa, xb, weight)
+        ctx.pad = pad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        hip = _hip()
+        xa, xb, weight = ctx.saved_tensors
+        ks = weight.shape[-1]
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dxa = dxb = dw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dxa, dxb = hip.stem_dgrad_s2_2(dy, _packed_stem(weight, 2), xa.shape[1], xb.shape[1])
+        if ctx.needs_input_grad[2]:
+            dw = hip.stem_wgrad2(xa, xb, dy, ks, 2, ctx.pad).to(weight.dtype)
+        return dxa, dxb, dw, None
+
+
 class _StemPool(torch.autograd.Function):
     """MaxPool2d(2, stride 1, ceil_mode) of F.pad(x, (0, 1, 0, 1)) without materialising the padded map."""
 
@@ -941,6 +975,14 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
                 and conv.kernel_size == (1, 1) and len(xs) <= 8 and (xs[0].shape[-1] * xs[0].shape[-2]) % 8 == 0
                 and all(t.shape[1] % 8 == 0 for t in xs) and _mfma_conv_ok(conv, xs[0])):
             y = _DenseConvSeg.apply(conv.weight, *[t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16) for t in xs])
+            return _bn_tail(y, bn, a, act, lab)
+        if (len(xs) == 2 and xs[0].is_cuda and not pad_br and a in (None, "relu", "silu", "swish") and _env("DFINE_HIP_UNITS", "1") == "1"
+                and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1)
+                and xs[0].shape[2:] == xs[1].shape[2:] and xs[0].shape[2] % 2 == 0 and xs[0].shape[3] % 2 == 0
+                and (conv.in_channels, conv.out_channels) in _STEM_DGRAD_S2 and xs[0].shape[1] + xs[1].shape[1] == conv.in_channels
+                and _stem_conv_ok(conv, xs[0], False)):
+            xa, xb = (t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16) for t in xs)
+            y = _StemConv2.apply(xa, xb, conv.weight, conv.padding[0])
             return _bn_tail(y, bn, a, act, lab)
         x = torch.cat(list(xs), dim=1) if len(xs) > 1 else xs[0]
     if x.is_cuda and a in (None, "relu", "silu", "swish") and _env("DFINE_HIP_UNITS", "1") == "1":

@@ -419,6 +419,15 @@ int dfine_stem_dgrad_s2_bf16(const void *dy, const float *wq, void *dx, int B, i
 int64_t dfine_stem_wgrad_ws_floats(int B, int Cin, int Cout, int KS, int Ho, int Wo);
 int dfine_stem_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, int B, int Cin, int Cout,
                           int H, int W, int Ho, int Wo, int KS, int stride, int pad, void *stream);
+/* The three stem operators with the input given as TWO tensors xa [B, Ca, H, W], xb [B, Cin - Ca, H, W] that the reference
+ * concatenates along the channels first (StemBlock.forward: torch.cat([pool(stem1), stem2b]) -> stem3, hgnetv2.py:158-165);
+ * the data gradient comes back as two contiguous tensors. */
+int dfine_stem_conv2_bf16(const void *xa, const void *xb, int Ca, const float *wp, void *y, int B, int Cin, int Cout,
+                          int H, int W, int Ho, int Wo, int KS, int stride, int pad, void *stream);
+int dfine_stem_dgrad_s2_2_bf16(const void *dy, const float *wq, void *dxa, void *dxb, int Ca, int B, int Cin, int Cout,
+                               int Ho, int Wo, void *stream);
+int dfine_stem_wgrad2_bf16(const void *xa, const void *xb, int Ca, const void *dy, float *dw, float *ws, int B, int Cin,
+                           int Cout, int H, int W, int Ho, int Wo, int KS, int stride, int pad, void *stream);
 int dfine_stem_pool_fwd(const void *x, void *y, int64_t planes, int H, int W, void *stream);
 int dfine_stem_pool_bwd(const void *x, const void *dy, void *dx, int64_t planes, int H, int W, void *stream);
 

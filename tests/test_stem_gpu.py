@@ -107,3 +107,26 @@ def test_stem_block_matches_aten_composition(cuda):
             continue
         c_hip, c_aten = cos(g_hip[n], g_ref[n]), cos(g_aten[n], g_ref[n])
         assert c_hip > 0.98 and c_hip > c_aten - 0.01, (n, c_hip, c_aten)
+
+
+@pytest.mark.parametrize("ca,cb,cout,hw", [(24, 24, 24, (64, 128)), (16, 16, 16, (40, 64)), (32, 32, 32, (64, 64))])
+def test_stem_conv_two_sources_matches_concatenated_input(cuda, ca, cb, cout, hw):
+    """stem3 reading [pooled stem1 | stem2 branch] in place (_StemConv2) is the single-tensor kernel on torch.cat of the two:
+    bit-identical forward (same arithmetic order), data gradient returned as two contiguous tensors, same weight gradient."""
+    from custom_d_fine_amd import kernels
+    torch.manual_seed(ca + cout)
+    H, W = hw
+    xa = torch.randn(3, ca, H, W, device=cuda).bfloat16().requires_grad_(True)
+    xb = torch.randn(3, cb, H, W, device=cuda).bfloat16().requires_grad_(True)
+    w = (torch.randn(cout, ca + cb, 3, 3, device=cuda) / ((ca + cb) * 9) ** 0.5).requires_grad_(True)
+    y = kernels._StemConv2.apply(xa, xb, w, 1)
+    go = torch.randn_like(y)
+    y.backward(go)
+    xc = torch.cat([xa.detach(), xb.detach()], 1).requires_grad_(True)
+    wr = w.detach().clone().requires_grad_(True)
+    yr = kernels._StemConv.apply(xc, wr, 2, 1, False)
+    yr.backward(go)
+    assert torch.equal(y, yr)
+    assert xa.grad.is_contiguous() and xb.grad.is_contiguous()
+    assert torch.equal(xa.grad, xc.grad[:, :ca]) and torch.equal(xb.grad, xc.grad[:, ca:])
+    assert _rel(w.grad, wr.grad) < 1e-6
