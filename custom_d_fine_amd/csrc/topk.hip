@@ -38,8 +38,23 @@ __global__ __launch_bounds__(kTkThreads) void topk_anchor_kernel(const T *__rest
         uint32_t k = 0u;
         if (q < Q) {
             const T *p = base + (int64_t)q * sq;
-            float m = load_f(p);
-            for (int c = 1; c < C; ++c) m = fmaxf(m, load_f(p + c));
+            float m;
+            if (sizeof(T) == 2 && (C & 7) == 0 && (sq & 7) == 0 && (sb & 7) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
+                // 16-byte loads: a lane walks its own row (rows are 2 C bytes apart), so the instruction count, not
+                // coalescing, is what can be saved - 8x fewer loads than element-wise
+                const uint4 *pv = reinterpret_cast<const uint4 *>(p);
+                m = -INFINITY;
+                for (int c = 0; c < C / 8; ++c) {
+                    const uint4 v = pv[c];
+                    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        m = fmaxf(m, fmaxf(__uint_as_float(u[j] << 16), __uint_as_float(u[j] & 0xffff0000u)));
+                }
+            } else {
+                m = load_f(p);
+                for (int c = 1; c < C; ++c) m = fmaxf(m, load_f(p + c));
+            }
             k = f2key(m);
             if (k == 0u) k = 1u;                // keep 0 for "no element"
         }
