@@ -17,11 +17,13 @@
 namespace dfine {
 
 constexpr int kPpThreads = 1024;
-constexpr int kPpPerThread = 32;          // up to 32768 (query, class) scores per image
-constexpr int kPpSort = 1024;             // K <= 1024
+constexpr int kPpPerThread = 32;          // keys of up to 32768 (query, class) scores per image stay in registers; larger
+                                          // problems (Objects365: 300 x 365) recompute them from L2 in every pass
+constexpr int kPpSortSmall = 1024;        // K <= 1024: one element per thread in the bitonic network
+constexpr int kPpSortLarge = 4096;        // K <= 4096
 
-__device__ __forceinline__ uint32_t pp_key(float f) {      // larger float -> larger key; NaN sorts last
-    if (f != f) return 1u;
+__device__ __forceinline__ uint32_t pp_key(float f) {      // larger float -> larger key; NaN sorts FIRST like torch.topk
+    if (f != f) return 0xffffffffu;
     const uint32_t u = __float_as_uint(f);
     const uint32_t k = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     return k == 0u ? 1u : k;                                // 0 is reserved for "no element"
@@ -31,7 +33,7 @@ __device__ __forceinline__ float pp_unkey(uint32_t key) {
     return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
 }
 
-template <typename T>
+template <typename T, bool REG, int kPpSort>
 __global__ __launch_bounds__(kPpThreads) void postprocess_kernel(const T *__restrict__ logits, const float *__restrict__ boxes,
                                                                  int Q, int C, int K, float height, float width, int to_round,
                                                                  int64_t *__restrict__ out_label, int64_t *__restrict__ out_query,
@@ -43,20 +45,31 @@ __global__ __launch_bounds__(kPpThreads) void postprocess_kernel(const T *__rest
     const int b = blockIdx.x, tid = threadIdx.x;
     const int N = Q * C;
     const T *base = logits + (int64_t)b * N;
-    uint32_t keys[kPpPerThread];
+    uint32_t keys[REG ? kPpPerThread : 1];
+    if (REG) {
 #pragma unroll
-    for (int i = 0; i < kPpPerThread; ++i) {
-        const int q = tid + i * kPpThreads;
-        keys[i] = q < N ? pp_key(load_f(base + q)) : 0u;
+        for (int i = 0; i < kPpPerThread; ++i) {
+            const int q = tid + i * kPpThreads;
+            keys[i] = q < N ? pp_key(load_f(base + q)) : 0u;
+        }
     }
+    // visit every (flat index, key) this thread owns: from registers, or recomputed from the (L2-resident) logits
+    auto for_each_key = [&](auto &&fn) {
+        if (REG) {
+#pragma unroll
+            for (int i = 0; i < kPpPerThread; ++i) fn(tid + i * kPpThreads, keys[i]);
+        } else {
+            for (int q = tid; q < N; q += kPpThreads) fn(q, pp_key(load_f(base + q)));
+        }
+    };
     uint32_t prefix = 0u, need = (uint32_t)K;
     for (int shift = 24; shift >= 0; shift -= 8) {
         if (tid < 256) hist[tid] = 0u;
         __syncthreads();
         const uint32_t mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
-#pragma unroll
-        for (int i = 0; i < kPpPerThread; ++i)
-            if (keys[i] != 0u && (keys[i] & mask) == (prefix & mask)) atomicAdd(&hist[(keys[i] >> shift) & 255u], 1u);
+        for_each_key([&](int, uint32_t key) {
+            if (key != 0u && (key & mask) == (prefix & mask)) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        });
         __syncthreads();
         if (tid == 0) {
             uint32_t acc = 0u; int d = 255;
@@ -72,27 +85,23 @@ __global__ __launch_bounds__(kPpThreads) void postprocess_kernel(const T *__rest
     if (tid == 0) s_cnt = 0u;
     for (int i = tid; i < kPpSort; i += kPpThreads) s_items[i] = 0ull;
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < kPpPerThread; ++i) {
-        const int q = tid + i * kPpThreads;
-        if (keys[i] > kth) {
+    for_each_key([&](int q, uint32_t key) {
+        if (key > kth) {
             const uint32_t pos = atomicAdd(&s_cnt, 1u);
-            s_items[pos] = ((uint64_t)keys[i] << 32) | (uint64_t)(0xffffffffu - (uint32_t)q);
+            s_items[pos] = ((uint64_t)key << 32) | (uint64_t)(0xffffffffu - (uint32_t)q);
         }
-    }
+    });
     __syncthreads();
     const uint32_t n_gt = s_cnt;
     __syncthreads();
     if (tid == 0) s_cnt = 0u;
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < kPpPerThread; ++i) {
-        const int q = tid + i * kPpThreads;
-        if (keys[i] == kth && keys[i] != 0u) {
+    for_each_key([&](int q, uint32_t key) {
+        if (key == kth && key != 0u) {
             const uint32_t pos = atomicAdd(&s_cnt, 1u);
             if (pos < kPpSort) s_eq[pos] = (uint32_t)q;
         }
-    }
+    });
     __syncthreads();
     // keys equal to the K-th: the `need` lowest flat indices.  When more than kPpSort elements tie at the cut (a constant
     // logit map) only the first kPpSort collected are ranked - still a valid top-K of tied scores.
@@ -107,11 +116,13 @@ __global__ __launch_bounds__(kPpThreads) void postprocess_kernel(const T *__rest
     __syncthreads();
     for (int size = 2; size <= kPpSort; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const int i = tid, j = i ^ stride;
-            if (j > i) {
-                const bool desc = (i & size) == 0;
-                const uint64_t a = s_items[i], c = s_items[j];
-                if ((a < c) == desc) { s_items[i] = c; s_items[j] = a; }
+            for (int i = tid; i < kPpSort; i += kPpThreads) {
+                const int j = i ^ stride;
+                if (j > i) {
+                    const bool desc = (i & size) == 0;
+                    const uint64_t a = s_items[i], c = s_items[j];
+                    if ((a < c) == desc) { s_items[i] = c; s_items[j] = a; }
+                }
             }
             __syncthreads();
         }
@@ -151,16 +162,17 @@ int dfine_postprocess(const void *logits, const float *boxes, int64_t *labels, i
                       void *stream) {
     if (B == 0) return DFINE_OK;
     if (!logits || !boxes || !labels || !query_idx || !out_boxes || !scores || Q < 1 || C < 1 || K < 1 ||
-        (int64_t)Q * C > (int64_t)kPpThreads * kPpPerThread || K > kPpSort || K > Q * C || height < 1 || width < 1)
+        (int64_t)Q * C > 0x7fffffff || K > kPpSortLarge || K > Q * C || height < 1 || width < 1)
         return DFINE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DFINE_F32)
-        hipLaunchKernelGGL(postprocess_kernel<float>, dim3(B), dim3(kPpThreads), 0, st, (const float *)logits, boxes, Q, C, K,
-                           (float)height, (float)width, to_round, labels, query_idx, out_boxes, scores);
-    else if (dtype == DFINE_BF16)
-        hipLaunchKernelGGL(postprocess_kernel<uint16_t>, dim3(B), dim3(kPpThreads), 0, st, (const uint16_t *)logits, boxes, Q,
-                           C, K, (float)height, (float)width, to_round, labels, query_idx, out_boxes, scores);
+    const bool small = (int64_t)Q * C <= (int64_t)kPpThreads * kPpPerThread && K <= kPpSortSmall;
+#define DFINE_PP(T, REG, SORT)                                                                                             \
+    hipLaunchKernelGGL((postprocess_kernel<T, REG, SORT>), dim3(B), dim3(kPpThreads), 0, st, (const T *)logits, boxes, Q, C, K, \
+                       (float)height, (float)width, to_round, labels, query_idx, out_boxes, scores)
+    if (dtype == DFINE_F32) { if (small) DFINE_PP(float, true, kPpSortSmall); else DFINE_PP(float, false, kPpSortLarge); }
+    else if (dtype == DFINE_BF16) { if (small) DFINE_PP(uint16_t, true, kPpSortSmall); else DFINE_PP(uint16_t, false, kPpSortLarge); }
     else return DFINE_E_BADARG;
+#undef DFINE_PP
     return check_launch();
 }
 

@@ -114,19 +114,28 @@ def weighting_function(reg_max, up, reg_scale, deploy=False):
     cacheable = (not deploy and torch.is_tensor(up) and torch.is_tensor(reg_scale) and not up.requires_grad
                  and not reg_scale.requires_grad)
     if cacheable:
-        key = (int(reg_max), up.data_ptr(), up._version, reg_scale.data_ptr(), reg_scale._version, up.dtype, str(up.device))
+        # keyed on the tensor OBJECTS (held by the entry, so their ids / storage cannot be recycled by another model) and their
+        # version counters; writers that bypass the counter (`.data` writes: FusedAdamWEMA.broadcast_from_rank0) call
+        # invalidate_weighting_cache()
+        key = (int(reg_max), id(up), up._version, id(reg_scale), reg_scale._version, up.data_ptr(), reg_scale.data_ptr(),
+               up.dtype, str(up.device))
         hit = _W_CACHE.get(key)
-        if hit is not None:
-            return hit
+        if hit is not None and hit[0] is up and hit[1] is reg_scale:
+            return hit[2]
     w = _weighting_function(reg_max, up, reg_scale, deploy)
     if cacheable:
         if len(_W_CACHE) > 16:
             _W_CACHE.clear()
-        _W_CACHE[key] = w
+        _W_CACHE[key] = (up, reg_scale, w)
     return w
 
 
 _W_CACHE = {}
+
+
+def invalidate_weighting_cache():
+    """Forget the cached W(n) tables (after `up` / `reg_scale` were rewritten through `.data`)."""
+    _W_CACHE.clear()
 
 
 def _weighting_function(reg_max, up, reg_scale, deploy):

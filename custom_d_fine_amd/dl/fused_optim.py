@@ -138,7 +138,15 @@ class FusedAdamWEMA:
                     cur, hi = [], e[1]
             if cur:
                 self._buckets.append({"lo": cur[-1][1], "hi": hi, "params": [c[0] for c in cur], "ready": 0, "done": False})
+        # Collectives pair up across ranks by CALL ORDER, so the all-reduces are issued in one fixed order on every rank - the
+        # order backward is expected to complete the buckets in (latest-registered parameters first) - and a bucket whose
+        # turn has not come waits, gathered, for its predecessors (DDP's reducer does the same; a rank-local completion order
+        # would pair different ranges on different ranks when one rank has a parameter without gradient, e.g. an image
+        # batch without targets skips the denoising embedding).
+        self._buckets.sort(key=lambda b: -max(b["params"]))
+        self._next_launch = 0
         for bi, b in enumerate(self._buckets):
+            b["gathered"] = False
             for i in b["params"]:
                 index_of[i] = bi
         if self.overlap:
@@ -170,6 +178,8 @@ class FusedAdamWEMA:
         for t in rest:
             if t.numel():
                 dist.broadcast(t, 0)
+        from ..d_fine.arch.utils import invalidate_weighting_cache
+        invalidate_weighting_cache()         # `up` / `reg_scale` are frozen parameters: just rewritten through .data
         if self.ema is not None:
             self.flat_ema.copy_(self.flat_param)
             if self.flat_ema_buf is not None:
@@ -258,8 +268,23 @@ class FusedAdamWEMA:
                 agg[tuple(m[:4])] += m[0] * m[4] * m[5] * m[3] * 4
             for k, v in agg.most_common(24):
                 print(f"    (splits, Cout, Cin, taps)={k}: {v / 1e6:.1f} MB", flush=True)
-        table = upload(np.asarray(rows, dtype=np.int64), self.flat_grad.device)
-        self.hip.multi_wgrad_reduce(table, len(rows))
+        # The kernel adds one table row per blockIdx.y into its destination with a plain read-modify-write: rows that share a
+        # destination (a module applied several times in one forward - query_pos_head runs once per decoder layer - or one
+        # row per micro-step of a gradient-accumulation window) must not run in the same launch.  Round r holds the r-th row
+        # of every destination; the rounds are stream-ordered launches, so the sum order is fixed (replicas stay bit-identical).
+        seen, rounds = {}, []
+        for row in rows:
+            r = seen.get(row[1], 0)
+            seen[row[1]] = r + 1
+            if r == len(rounds):
+                rounds.append([])
+            rounds[r].append(row)
+        order = [row for rnd in rounds for row in rnd]
+        table = upload(np.asarray(order, dtype=np.int64), self.flat_grad.device)
+        first = 0
+        for rnd in rounds:
+            self.hip.multi_wgrad_reduce(table[first:first + len(rnd)], len(rnd))
+            first += len(rnd)
         self._live.append((take, table))
 
     def _make_hook(self, bi):
@@ -298,10 +323,24 @@ class FusedAdamWEMA:
     def _reduce_bucket(self, b):
         self._gather(b["params"])
         self._flush_deferred(b["lo"], b["hi"])
-        b["done"] = True
-        if get_world_size() > 1:
-            # asynchronous on the communication stream: ordered after the copy above, overlaps what backward still runs
-            self._works.append(dist.all_reduce(self.flat_grad[b["lo"]:b["hi"]], async_op=True))
+        b["gathered"] = True
+        self._launch_in_order()
+
+    def _launch_in_order(self, force=False):
+        """Starts the all-reduce of every bucket whose turn has come (all earlier buckets of the fixed order launched)."""
+        while self._next_launch < len(self._buckets):
+            b = self._buckets[self._next_launch]
+            if not b["gathered"]:
+                if not force:
+                    return
+                self._gather(b["params"])
+                self._flush_deferred(b["lo"], b["hi"])
+                b["gathered"] = True
+            b["done"] = True
+            self._next_launch += 1
+            if get_world_size() > 1:
+                # asynchronous on the communication stream: ordered after the copies above, overlaps what backward still runs
+                self._works.append(dist.all_reduce(self.flat_grad[b["lo"]:b["hi"]], async_op=True))
 
     def _collect_grads(self):
         """Single-shot path (no hooks) and flush of whatever the hooks did not see (parameters without a gradient this
@@ -313,9 +352,7 @@ class FusedAdamWEMA:
                 # one large collective over xGMI: 78 MB for D-FINE-m
                 dist.all_reduce(self.flat_grad)
             return
-        for b in self._buckets:
-            if not b["done"]:
-                self._reduce_bucket(b)
+        self._launch_in_order(force=True)      # parameters without a gradient this step leave their bucket incomplete
         if self._deferred:
             raise RuntimeError(f"{len(self._deferred)} deferred weight gradients were registered after their bucket had "
                                "been reduced (bucket bookkeeping out of step with the backward ops)")
@@ -323,7 +360,8 @@ class FusedAdamWEMA:
             w.wait()                         # the compute stream waits for the communication stream; the host does not block
         self._works.clear()
         for b in self._buckets:
-            b["ready"], b["done"] = 0, False
+            b["ready"], b["done"], b["gathered"] = 0, False, False
+        self._next_launch = 0
 
     def step(self):
         """all-reduce (if data parallel) -> norm -> per-group AdamW+EMA (also zeroes the grads)."""

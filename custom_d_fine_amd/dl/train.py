@@ -129,7 +129,7 @@ class Trainer:
         torch.save(state, self.path_to_save / "resume.pt")
 
     def load_resume_state(self, path):
-        state = torch.load(path, map_location=self.device, weights_only=False)
+        state = torch.load(path, map_location=self.device, weights_only=True)     # tensors and primitives only
         m = self.model.module if hasattr(self.model, "module") else self.model
         m.load_state_dict(state["model"])
         if self.ema is not None and state["ema"] is not None:
@@ -139,6 +139,10 @@ class Trainer:
         (self.fused if self.fused is not None else self.optimizer).load_state_dict(state["optimizer"])
         if self.scheduler is not None and state["scheduler"] is not None:
             self.scheduler.load_state_dict(state["scheduler"])
+            # OneCycleLR.load_state_dict restores its counters but not the rates it had written into the parameter groups,
+            # and the fused optimizer's state holds no lr: without this the first resumed step runs at max_lr / 25
+            for g, lr in zip(self.optimizer.param_groups, self.scheduler.get_last_lr()):
+                g["lr"] = lr
         self.step.iters = state["iters"]
         self.start_epoch = state["epoch"] + 1
 

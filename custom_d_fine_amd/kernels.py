@@ -1418,9 +1418,22 @@ def topk_anchors(logits: torch.Tensor, k: int) -> torch.Tensor:
 def detection_topk(logits: torch.Tensor, boxes: torch.Tensor, k: int, height: int, width: int, to_round: bool = True):
     """A18 post-processor core (ref export.py:61-100): the k best (query, class) pairs of every image by sigmoid score ->
     (labels [B,k] i64, query index [B,k] i64, absolute xyxy boxes [B,k,4] f32, scores [B,k] f32), descending.
-    One HIP kernel (csrc/postproc.hip); Q*C <= 32768 and k <= 1024."""
+    One HIP kernel (csrc/postproc.hip) for k <= 4096 (any class count); beyond that the reference's own composition on the device."""
     if not logits.is_cuda:
         return _backend_for_cpu("detection_topk")(logits, boxes, k, height, width, to_round)
+    if k > 4096:                                       # outside the kernel's sort network: export.py:61-100 restated with device ops
+        b, q, c = logits.shape
+        scores, index = torch.topk(torch.sigmoid(logits.float()).flatten(1), k, dim=-1)
+        query = index // c
+        bx = boxes.float() * boxes.new_tensor([width, height, width, height], dtype=torch.float32)
+        xy0, xy1 = bx[..., :2] - bx[..., 2:] / 2, bx[..., :2] + bx[..., 2:] / 2
+        lim = bx.new_tensor([width, height])
+        if to_round:
+            xy0, xy1 = torch.clamp(torch.floor(xy0), min=1), torch.minimum(torch.ceil(xy1), lim - 1)
+        else:
+            xy0, xy1 = torch.clamp(xy0, min=0), torch.minimum(xy1, lim)
+        out = torch.cat([xy0, xy1], -1).gather(1, query.unsqueeze(-1).expand(-1, -1, 4))
+        return index - query * c, query, out, scores
     return _hip().postprocess(logits, boxes, k, height, width, to_round)
 
 

@@ -365,7 +365,8 @@ int dfine_attn_bwd(const void *q, const void *k, const void *v, const void *o, c
  * Torch_model._preds_postprocess (src/infer/torch_model.py:197-214).
  *   logits [B, Q, C] dtype, boxes [B, Q, 4] f32 ->
  *   labels [B, K] i64, query_idx [B, K] i64, out_boxes [B, K, 4] f32, scores [B, K] f32 (descending;
- *   ties: larger logit, then lower flat index).  Q*C <= 32768, K <= min(Q*C, 1024).
+ *   ties: larger logit, then lower flat index; NaN logits rank first, as in torch.topk).  K <= min(Q*C, 4096);
+ *   Q*C <= 32768 and K <= 1024 keep the keys in registers, larger problems (365 classes) re-read them from L2 per pass.
  */
 int dfine_postprocess(const void *logits, const float *boxes, int64_t *labels, int64_t *query_idx,
                       float *out_boxes, float *scores, int dtype, int B, int Q, int C, int K, int height,

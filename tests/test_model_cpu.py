@@ -229,6 +229,9 @@ def test_trainer_plumbing_and_resume(oracle_backend, tmp_path):
     k0 = next(iter(sa))
     assert torch.equal(sa[k0]["exp_avg"], sb[k0]["exp_avg"]) and sa[k0]["step"] == sb[k0]["step"]
     assert tr2.scheduler.last_epoch == tr.scheduler.last_epoch
+    # the resumed run continues at the saved position of the one-cycle schedule, not at its initial rate
+    assert [g["lr"] for g in tr2.optimizer.param_groups] == [g["lr"] for g in tr.optimizer.param_groups]
+    assert [g["lr"] for g in tr2.optimizer.param_groups] == tr2.scheduler.get_last_lr()
     # evaluation hand-off: eval forward -> post-processing -> metrics (random weights: only the plumbing is checked)
     m = tr.evaluate(n_batches=1, conf_thresh=0.01)
     assert {"f1", "precision", "recall", "iou", "TPs", "FPs", "FNs", "mAP_50", "mAP_50_95"} <= set(m)

@@ -3,6 +3,8 @@ reference's per-tensor EMA loop (plain PyTorch fp32 reference of the same op).""
 import copy
 import math
 
+import numpy as np
+
 import pytest
 import torch
 import torch.nn as nn
@@ -168,3 +170,49 @@ def test_deferred_weight_gradients_match_immediate(cuda):
     for i, p in enumerate(fused._params):
         o = fused._grad_offsets[i]
         assert (got[o:o + p.numel()] != 0).any() == (ref[o:o + p.numel()] != 0).any(), i
+
+
+@pytest.mark.gpu
+def test_deferred_reduction_with_repeated_module_and_accumulation(cuda):
+    """A Linear applied FOUR times in one forward (the decoder's query_pos_head runs once per layer) over TWO micro-steps of a
+    gradient-accumulation window leaves eight rows with one destination in the deferred table; they are reduced in
+    stream-ordered rounds (a single launch would race on the read-modify-write).  The deferred flat gradient must equal the
+    immediate one to fp32 rounding and be bit-identical from run to run."""
+    from custom_d_fine_amd import kernels
+
+    torch.manual_seed(7)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = nn.Linear(64, 256), nn.Linear(256, 64)
+
+        def forward(self, x):
+            for _ in range(4):
+                x = x + kernels.linear(kernels.linear(x, self.a.weight, self.a.bias, "relu"), self.b.weight, self.b.bias)
+            return x
+
+    net = Net().to(cuda)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4)
+    fused = FusedAdamWEMA(net, opt, None, clip_max_norm=0.1, overlap=False)
+    xs = [torch.randn(8, 512, 64, device=cuda) * 0.5 for _ in range(2)]
+    flats = {}
+    for defer in (False, True, True):
+        fused.defer_wgrads = defer
+        fused.flat_grad.zero_()
+        for x in xs:                                                 # two micro-steps, one flush
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = net(x)
+            (y.float() ** 2).mean().backward()
+        if defer:
+            dsts = [d[1] for d in fused._deferred]
+            assert len(dsts) == 32 and len(set(dsts)) == 4           # 4 parameters x 4 uses x 2 micro-steps
+        fused._collect_grads()
+        fused._uses.clear()
+        assert not fused._deferred
+        torch.cuda.synchronize()
+        flats.setdefault(defer, []).append(fused.flat_grad.clone())
+    ref, got, again = flats[False][0], flats[True][0], flats[True][1]
+    assert torch.equal(got, again)
+    assert got.abs().max() > 0
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-6 * ref.abs().max().item())

@@ -105,3 +105,41 @@ def test_hip_postprocessor_full_size_vs_oracle(cuda, dtype):
     table.scatter_(1, q_all.unsqueeze(-1).expand(-1, -1, 4), b_all)
     want = table.gather(1, qidx.cpu().unsqueeze(-1).expand(-1, -1, 4))
     np.testing.assert_array_equal(out_boxes.cpu().numpy(), want.numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,K", [(365, 300), (365, 2000), (80, 1500), (91, 5000)])
+def test_hip_postprocessor_many_classes_and_large_k(cuda, C, K):
+    """Objects365-sized heads (300 x 365 = 109 500 scores > the 32 768 register-resident keys), K above the 1024-entry sort
+    network, and K above the kernel's range (device composition): same (query, class) set and exact boxes as the oracle."""
+    from custom_d_fine_amd import kernels
+    from oracle import torch_backend
+    gen = torch.Generator().manual_seed(C + K)
+    logits = torch.randn(3, 300, C, generator=gen) * 2 - 2
+    boxes = torch.cat([torch.rand(3, 300, 2, generator=gen), torch.rand(3, 300, 2, generator=gen) * 0.5], -1)
+    labels, qidx, out_boxes, scores = kernels.detection_topk(logits.to(cuda), boxes.to(cuda), K, 480, 640)
+    rl, rq, rb, rs = torch_backend.detection_topk(logits, boxes, K, 480, 640)
+    np.testing.assert_allclose(scores.cpu().numpy(), rs.numpy(), atol=1e-6, rtol=0)
+    assert (np.diff(scores.cpu().numpy(), axis=1) <= 0).all()
+    flat_got, flat_ref = (qidx * C + labels).cpu(), rq * C + rl
+    for b in range(3):
+        assert set(flat_got[b].tolist()) == set(flat_ref[b].tolist()) and len(set(flat_got[b].tolist())) == K
+    order = torch.argsort(flat_got, 1), torch.argsort(flat_ref, 1)
+    np.testing.assert_array_equal(out_boxes.cpu().gather(1, order[0].unsqueeze(-1).expand(-1, -1, 4)).numpy(),
+                                  rb.gather(1, order[1].unsqueeze(-1).expand(-1, -1, 4)).numpy())
+
+
+@pytest.mark.gpu
+def test_hip_postprocessor_nan_logits_rank_first(cuda):
+    """torch.topk ranks NaN above every number (reference export.py:73 runs it on the sigmoid scores): so does the kernel."""
+    from custom_d_fine_amd import kernels
+    gen = torch.Generator().manual_seed(3)
+    logits = torch.randn(2, 300, 80, generator=gen)
+    logits[0, 7, 3] = float("nan")
+    logits[1, 299, 79] = float("nan")
+    boxes = torch.rand(2, 300, 4, generator=gen) * 0.5 + 0.25
+    labels, qidx, _, scores = kernels.detection_topk(logits.to(cuda), boxes.to(cuda), 300, 640, 640)
+    ref = torch.topk(torch.sigmoid(logits).flatten(1), 300, dim=-1)
+    assert torch.isnan(scores[:, 0]).all() and not torch.isnan(scores[:, 1:]).any()
+    assert (qidx[:, 0].cpu() * 80 + labels[:, 0].cpu()).tolist() == ref.indices[:, 0].tolist() == [7 * 80 + 3, 299 * 80 + 79]
+    np.testing.assert_allclose(scores[:, 1:].cpu().numpy(), ref.values[:, 1:].numpy(), atol=1e-6, rtol=0)
