@@ -303,7 +303,9 @@ class TransformerDecoder(nn.Module):
             if i == 0:
                 # classic sigmoid-space box head on the first layer seeds the FDR reference
                 pre_bboxes = F.sigmoid(pre_bbox_head(out) + inverse_sigmoid(ref_detach))
-                pre_scores = kernels.linear(out, score_head[0].weight, score_head[0].bias)
+                # (after deploy() the heads before eval_idx are nn.Identity placeholders: ref dfine_decoder.py:698-707)
+                pre_scores = kernels.linear(out, score_head[0].weight, score_head[0].bias) \
+                    if isinstance(score_head[0], nn.Linear) else score_head[0](out)
                 ref_initial = pre_bboxes.detach()
 
             # FDR: residual update of the edge distributions, decoded around the initial box

@@ -39,8 +39,10 @@ class ConvNormLayer_fuse(nn.Module):
         self.g, self.padding, self.bias = g, padding, bias
 
     def forward(self, x):
-        if hasattr(self, "conv_bn_fused"):
-            return self.act(self.conv_bn_fused(torch.cat(list(x), dim=1) if isinstance(x, (list, tuple)) else x))
+        if hasattr(self, "conv_bn_fused"):                 # deployed form: BN folded into the conv
+            if self._act_name is not None or isinstance(self.act, nn.Identity):
+                return kernels.conv_bias_act(x, self.conv_bn_fused, self._act_name)
+            return self.act(kernels.conv_bias_act(x, self.conv_bn_fused, None))
         if self._act_name is not None or isinstance(self.act, nn.Identity):
             return kernels.conv_bn_act(x, self.conv, self.norm, self._act_name, None)
         return self.act(kernels.conv_bn_act(x, self.conv, self.norm, None, None))
@@ -49,6 +51,8 @@ class ConvNormLayer_fuse(nn.Module):
         return _fold_bn(self.conv, self.norm)
 
     def convert_to_deploy(self):
+        if not hasattr(self, "conv"):
+            return                                          # already deployed (the reference raises here)
         if not hasattr(self, "conv_bn_fused"):
             self.conv_bn_fused = nn.Conv2d(self.ch_in, self.ch_out, self.kernel_size, self.stride,
                                            groups=self.g, padding=self.padding, bias=True)
@@ -96,11 +100,13 @@ class VGGBlock(nn.Module):
         self.act = nn.Identity() if act is None else act
 
     def forward(self, x, residual=None):
-        if hasattr(self, "conv"):
-            y = self.act(self.conv(x))
-            return y if residual is None else y + residual
         name = ("silu" if isinstance(self.act, nn.SiLU) else "relu" if isinstance(self.act, nn.ReLU)
                 else None if isinstance(self.act, nn.Identity) else False)
+        if hasattr(self, "conv"):                          # deployed form: one re-parameterised 3x3
+            if name is not False:
+                return kernels.conv_bias_act(x, self.conv, name, residual)
+            y = self.act(self.conv(x))
+            return y if residual is None else y + residual
         if name is not False:
             # both branches, their BatchNorms, the add, the activation (and CSPLayer's residual) as one unit
             return kernels.repvgg_unit(x, self.conv1.conv, self.conv1.norm, self.conv2.conv, self.conv2.norm, name, residual)
@@ -113,6 +119,8 @@ class VGGBlock(nn.Module):
         return k3 + F.pad(k1, [1, 1, 1, 1]), b3 + b1
 
     def convert_to_deploy(self):
+        if not hasattr(self, "conv1"):
+            return                                          # already deployed
         if not hasattr(self, "conv"):
             self.conv = nn.Conv2d(self.ch_in, self.ch_out, 3, 1, padding=1)
         k, b = self.get_equivalent_kernel_bias()

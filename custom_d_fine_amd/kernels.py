@@ -7,9 +7,9 @@ HIP-backed operators raise, unless a test harness has installed the oracle backe
 (`oracle.torch_backend.install()` - used only by tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg).
 
-Operators that are still composed from ATen calls (MIOpen convolutions, rocBLAS GEMMs, SDPA)
+Operators that are still composed from ATen calls (the fp32 math of configs[1], the mask head of configs[4])
 are marked "ATen plumbing" - they run the same code on CPU and GPU and are the next ones to be
-replaced by HIP kernels (DESIGN.md "kernel status").
+replaced by HIP kernels.
 """
 import os
 import weakref
@@ -628,9 +628,9 @@ def _defer_slot(*params):
 
 
 class _DenseConv(torch.autograd.Function):
-    """1x1 / 3x3 stride-1 dense convolution, NCHW bf16.  Each of forward / data gradient / weight
-    gradient runs on the HIP implicit-GEMM MFMA kernels (conv.hip) or on MIOpen [ATen plumbing],
-    whichever `_conv_plan` measured to be faster for the shape."""
+    """1x1 / 3x3 stride-1 dense convolution, NCHW bf16: forward / data gradient / weight gradient on the HIP implicit-GEMM
+    MFMA kernels (conv.hip).  (`DFINE_CONV_TUNE=1` restores the round-1 per-shape timing against MIOpen for comparison
+    runs, `DFINE_CONV_TUNE=aten` forces MIOpen.)"""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -938,11 +938,11 @@ def _stem_conv_ok(conv, x, pad_br):
     return False
 
 
-def _mfma_conv_ok(conv, x):
+def _mfma_conv_ok(conv, x, allow_bias=False):
     """Layers the implicit-GEMM kernels can serve (1x1 / 3x3, stride 1, 'same' padding, bf16 autocast)."""
     k = conv.kernel_size
     return (_env("DFINE_MFMA_CONV", "1") == "1" and conv.groups == 1 and k[0] == k[1] and k[0] in (1, 3)
-            and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.bias is None
+            and conv.stride == (1, 1) and conv.dilation == (1, 1) and (conv.bias is None or allow_bias)
             and isinstance(conv.padding, tuple) and conv.padding == (k[0] // 2, k[0] // 2)
             and conv.in_channels % 16 == 0 and conv.out_channels % 16 == 0 and x.dim() == 4
             and ((k[0] == 1 and (x.shape[-1] * x.shape[-2]) % 2 == 0)
@@ -950,10 +950,10 @@ def _mfma_conv_ok(conv, x):
             and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
 
 
-def _is_depthwise(conv):
+def _is_depthwise(conv, allow_bias=False):
     return (conv.groups > 1 and conv.groups == conv.in_channels == conv.out_channels
             and conv.kernel_size[0] == conv.kernel_size[1] <= 7 and conv.stride[0] == conv.stride[1]
-            and conv.padding[0] == conv.padding[1] and conv.dilation == (1, 1) and conv.bias is None
+            and conv.padding[0] == conv.padding[1] and conv.dilation == (1, 1) and (conv.bias is None or allow_bias)
             and isinstance(conv.padding, tuple))
 
 
@@ -961,8 +961,8 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
                 pad_br: bool = False):
     """conv(bias=False) -> BN (batch stats in training) -> {None, relu, silu} -> scalar affine; the
     building block of HGNetv2 and the HybridEncoder.
-    GPU: depthwise convs and the whole BN/act/affine tail are HIP kernels; dense convs are still
-    MIOpen calls [ATen plumbing].  CPU tensors take the plain ATen composition below."""
+    GPU (bf16 autocast): dense 1x1 / 3x3, depthwise and stem convolutions and the whole BN/act/affine tail are HIP kernels;
+    fp32 math and CPU tensors take the plain ATen composition below."""
     a = act.lower() if isinstance(act, str) else act
     if (torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and not x.is_contiguous() and conv.kernel_size == (1, 1)
             and x.dtype == torch.bfloat16 and _hip().is_channel_part(x)):
@@ -1000,6 +1000,33 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
         return _bn_tail(y, bn, a, act, lab)
     y = bn(conv(F.pad(x, (0, 1, 0, 1)) if pad_br else x))
     return _act_lab_torch(y, act, lab)
+
+
+_UNIT_BN = {}        # (device, channels) -> (ones, zeros): the identity BatchNorm a bias + activation pass is expressed with
+
+
+def conv_bias_act(x, conv: nn.Conv2d, act: Optional[str], residual=None):
+    """act(conv(x) + bias) [+ residual] for a convolution whose BatchNorm was folded away by `model.deploy()`
+    (ConvNormLayer_fuse.conv_bn_fused, the re-parameterised RepVGG 3x3: ref hybrid_encoder.py:47-79,123-156).
+    CUDA under bf16 autocast: the same MFMA implicit-GEMM kernels as the training form, then ONE pass of the fused
+    BatchNorm / activation kernel with unit statistics (scale 1, shift = bias).  Otherwise the ATen composition."""
+    a = act.lower() if isinstance(act, str) else act
+    if isinstance(x, (list, tuple)):
+        x = torch.cat(list(x), dim=1) if len(x) > 1 else x[0]
+    autocast16 = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+    dense = _mfma_conv_ok(conv, x, allow_bias=True)
+    if (x.is_cuda and a in (None, "relu", "silu", "swish") and _env("DFINE_HIP_UNITS", "1") == "1" and conv.bias is not None
+            and x.dim() == 4 and (dense or (autocast16 and _is_depthwise(conv, allow_bias=True)))):
+        c = conv.out_channels
+        unit = _UNIT_BN.get((x.device, c))
+        if unit is None:
+            unit = _UNIT_BN[(x.device, c)] = (torch.ones(c, device=x.device), torch.zeros(c, device=x.device))
+        xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+        y = _DenseConv.apply(xb, conv.weight) if dense else _DepthwiseConv.apply(xb, conv.weight, conv.stride[0], conv.padding[0])
+        y = _BNAct.apply(y, unit[0], conv.bias, None, None, unit[1], unit[0], a, False, 0.0, 0.0)
+        return y if residual is None else y + residual
+    y = _act_lab_torch(conv(x), act, None)
+    return y if residual is None else y + residual
 
 
 class _BN2Act(torch.autograd.Function):

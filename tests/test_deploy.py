@@ -1,0 +1,109 @@
+"""`model.deploy()` (reference dfine.py:43-48 -> conv-BN folding hybrid_encoder.py:47-79, RepVGG
+re-parameterisation :123-156, decoder pruning dfine_decoder.py:422-427,698-707) against goldens produced by the
+reference's own deploy() on the seeded models (tools/gen_golden.py::gen_deploy -> tests/golden/deploy.npz).
+CPU: module inventory, folded weights, eval outputs through the oracle backend.  GPU: fp32 eval outputs of D-FINE-n, and
+the deployed D-FINE-m encoder under bf16 autocast with every deployed convolution on the HIP kernels."""
+import numpy as np
+import pytest
+import torch
+
+from custom_d_fine_amd.d_fine import dfine
+from tests import helpers
+from tests.test_model_cpu import assert_same_query_set
+
+G = helpers.GOLDEN_DIR
+W_KEYS = ("encoder.fpn_blocks.0.cv2.0.bottlenecks.0.conv.weight", "encoder.fpn_blocks.0.cv2.0.bottlenecks.0.conv.bias",
+          "encoder.lateral_convs.0.conv_bn_fused.weight", "encoder.lateral_convs.0.conv_bn_fused.bias")
+
+
+def _deployed(size, device="cpu"):
+    m = dfine.build_model(size, 80, False, "cpu", img_size=[320, 320])
+    m.load_state_dict(helpers.seeded_state_dict(m.state_dict()))
+    return m.to(device).deploy()
+
+
+@pytest.mark.parametrize("size,tag", [("n", "n320"), ("m", "m320")])
+def test_deploy_inventory_and_folded_weights(size, tag):
+    g = np.load(f"{G}/deploy.npz")
+    m = _deployed(size)
+    assert not m.training
+    sd = m.state_dict()
+    assert sorted(sd.keys()) == g[f"{tag}/state_keys"].tolist()        # same modules folded / pruned, same key names
+    for k in W_KEYS:
+        np.testing.assert_allclose(helpers.compact_rows(sd[k].numpy()), g[f"{tag}/w/{k}"], rtol=1e-5, atol=1e-6)
+    # decoder pruning: heads past eval_idx are gone, earlier score heads / LQE layers are placeholders
+    dec = m.decoder
+    assert len(dec.decoder.layers) == dec.eval_idx + 1 if dec.eval_idx >= 0 else True
+    m.deploy()                                                        # idempotent on an already deployed model
+    assert sorted(m.state_dict().keys()) == g[f"{tag}/state_keys"].tolist()
+
+
+def test_deploy_eval_outputs_match_reference_n320(oracle_backend):
+    g = np.load(f"{G}/deploy.npz")
+    m = _deployed("n")
+    with torch.no_grad():
+        o = m(helpers.make_images(2, 320))
+    assert set(o) == {"pred_logits", "pred_boxes"}
+    assert_same_query_set(o["pred_logits"], o["pred_boxes"], torch.tensor(g["n320/pred_logits"]), torch.tensor(g["n320/pred_boxes"]))
+    # and deploy() does not change what the model computes (reference before / after within the same tolerance)
+    assert_same_query_set(o["pred_logits"], o["pred_boxes"], torch.tensor(g["n320/before_logits"]), torch.tensor(g["n320/before_boxes"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,tag", [("n", "n320"), ("m", "m320")])
+def test_deploy_eval_outputs_match_reference_gpu(cuda, size, tag):
+    g = np.load(f"{G}/deploy.npz")
+    m = _deployed(size, cuda)
+    with torch.no_grad():
+        o = m(helpers.make_images(2, 320).to(cuda))
+    assert_same_query_set(o["pred_logits"].cpu(), o["pred_boxes"].cpu(), torch.tensor(g[f"{tag}/pred_logits"]),
+                          torch.tensor(g[f"{tag}/pred_boxes"]))
+
+
+@pytest.mark.gpu
+def test_deployed_encoder_runs_on_hip_kernels_bf16(cuda, monkeypatch):
+    """D-FINE-m after deploy(), backbone + encoder under bf16 autocast: every folded convolution (1x1 conv_bn_fused, the
+    re-parameterised RepVGG 3x3, the depthwise SCDown) goes through the HIP kernels - no F.conv2d / nn.Conv2d.forward call in
+    the encoder - and the features agree with the reference's deployed fp32 features within bf16 storage error."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from custom_d_fine_amd import hip
+    g = np.load(f"{G}/deploy.npz")
+    m = _deployed("m", cuda)
+    calls = {"hip_dense": 0, "hip_dw": 0, "aten": 0}
+    real_dense, real_dw, real_conv2d = hip.conv_forward_bf16, hip.dwconv_forward, F.conv2d
+
+    def dense(*a, **k):
+        calls["hip_dense"] += 1
+        return real_dense(*a, **k)
+
+    def dw(*a, **k):
+        calls["hip_dw"] += 1
+        return real_dw(*a, **k)
+
+    def conv2d(*a, **k):
+        calls["aten"] += 1
+        return real_conv2d(*a, **k)
+
+    monkeypatch.setattr(hip, "conv_forward_bf16", dense)
+    monkeypatch.setattr(hip, "dwconv_forward", dw)
+    monkeypatch.setattr(F, "conv2d", conv2d)
+    monkeypatch.setattr(nn.Conv2d, "_conv_forward", lambda self, x, w, b: conv2d(x, w, b, self.stride, self.padding, self.dilation, self.groups))
+    x = helpers.make_images(2, 320).to(cuda)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        feats_b = m.backbone(x)
+        before = dict(calls)
+        feats = m.encoder(feats_b)
+    enc_calls = {k: calls[k] - before[k] for k in calls}
+    n_fused = sum(1 for mod in m.encoder.modules() if hasattr(mod, "conv_bn_fused"))
+    n_rep = sum(1 for mod in m.encoder.modules() if type(mod).__name__ == "VGGBlock")
+    assert n_fused > 10 and n_rep >= 4
+    assert enc_calls["aten"] == 0, enc_calls
+    assert enc_calls["hip_dense"] + enc_calls["hip_dw"] == n_fused + n_rep, (enc_calls, n_fused, n_rep)
+    assert enc_calls["hip_dw"] == 2                                   # the two SCDown depthwise convolutions
+    for i, f in enumerate(feats):
+        ref = torch.tensor(g[f"m320/feat{i}"].astype(np.float32))
+        got = f.float().cpu()[:1, ::2]
+        cos = torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item()
+        assert cos > 0.999, (i, cos)                                  # eval statistics: no batch-statistics amplification
+        assert (got - ref).abs().max() <= 4e-2 * ref.abs().max(), (i, (got - ref).abs().max().item(), ref.abs().max().item())

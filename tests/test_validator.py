@@ -11,12 +11,12 @@ from tests import helpers
 G = helpers.GOLDEN_DIR
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
-@pytest.mark.parametrize("thr", [0.5, 0.75])
-def test_box_metrics_match_reference(seed, thr):
+def _check_box_metrics(seed, thr, device):
     g = np.load(f"{G}/validator.npz")
     k = f"s{seed}_t{int(thr * 100)}"
     gt, preds = helpers.make_validator_case(seed)
+    gt = [{n: t.to(device) for n, t in d.items()} for d in gt]
+    preds = [{n: t.to(device) for n, t in d.items()} for d in preds]
     v = Validator(gt, preds, {i: f"c{i}" for i in range(5)}, conf_thresh=0.5, iou_thresh=thr, compute_maps=False)
     m = v.compute_metrics(extended=True)
     for name in ("TPs", "FPs", "FNs"):
@@ -29,6 +29,20 @@ def test_box_metrics_match_reference(seed, thr):
     ext = m["extended_metrics"]
     assert sorted(ext) == g[f"{k}/ext_keys"].tolist()
     np.testing.assert_allclose([float(ext[x]) for x in sorted(ext)], g[f"{k}/ext_vals"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("thr", [0.5, 0.75])
+def test_box_metrics_match_reference(seed, thr):
+    _check_box_metrics(seed, thr, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("thr", [0.5, 0.75])
+def test_box_metrics_match_reference_on_device(cuda, seed, thr):
+    """The same reference goldens with device-resident predictions / ground truth (the batched IoU pass runs on the GPU)."""
+    _check_box_metrics(seed, thr, cuda)
 
 
 def _sample(boxes, labels, scores=None):
@@ -74,6 +88,21 @@ def test_coco_map_properties():
     assert coco_map([_sample([], [])], [_sample([[1, 1, 2, 2]], [0], [0.5])])["map"] == -1.0
     full = Validator(gt, perfect, {i: f"c{i}" for i in range(5)}).compute_metrics()
     assert abs(full["mAP_50_95"] - 1.0) < 1e-9 and full["f1"] == 1.0
+
+
+def test_coco_map_hand_computed_case():
+    """COCO AP worked by hand (101-point interpolated precision, IoU 0.50:0.05:0.95).  One image, one class, two ground
+    truths A = [0,0,10,10], B = [20,20,30,30]; detections by score: d1 = A exactly (0.9), d2 = [100,100,110,110] (0.8, a
+    false positive), d3 = [20,20,30,28] (0.7: IoU with B = 80/100 = 0.8).
+      IoU thresholds 0.50 .. 0.80 (7 of them): TP, FP, TP -> precision at recall 0.5 is 1, at recall 1.0 is 2/3;
+        101-point AP = (51 * 1 + 50 * 2/3) / 101
+      IoU thresholds 0.85, 0.90, 0.95: TP, FP, FP -> recall stops at 0.5: AP = 51 / 101."""
+    gt = [_sample([[0, 0, 10, 10], [20, 20, 30, 30]], [0, 0])]
+    pr = [_sample([[0, 0, 10, 10], [100, 100, 110, 110], [20, 20, 30, 28]], [0, 0, 0], [0.9, 0.8, 0.7])]
+    m = coco_map(gt, pr)
+    ap_lo, ap_hi = (51 + 50 * 2 / 3) / 101, 51 / 101
+    assert abs(m["map_50"] - ap_lo) < 1e-9
+    assert abs(m["map"] - (7 * ap_lo + 3 * ap_hi) / 10) < 1e-9
 
 
 @pytest.mark.gpu

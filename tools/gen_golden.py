@@ -304,6 +304,40 @@ def gen_backbone_encoder():
     save("backbone_encoder_m320.npz", **out)
 
 
+def gen_deploy():
+    """`model.deploy()` of the reference (dfine.py:43-48: eval + convert_to_deploy of every module - conv-BN folding
+    hybrid_encoder.py:47-79, RepVGG re-parameterisation :123-156, decoder pruning dfine_decoder.py:422-427,698-707) on the
+    seeded D-FINE-n 320x320 model: eval outputs after deploy, the deployed module inventory, and - for D-FINE-m, whose
+    encoder carries every deployable unit type at MFMA-eligible channel counts - the encoder features after deploy."""
+    out = {}
+    for size, tag in (("n", "n320"), ("m", "m320")):
+        torch.manual_seed(0)
+        model = ref.dfine.build_model(size, 80, False, "cpu", img_size=[320, 320])
+        model.load_state_dict(helpers.seeded_state_dict(model.state_dict()))
+        x = helpers.make_images(2, 320)
+        model.eval()
+        with torch.no_grad():
+            before = model(x)
+        model.deploy()
+        with torch.no_grad():
+            feats = model.encoder(model.backbone(x))
+            o = model(x)
+        out[f"{tag}/pred_logits"] = o["pred_logits"].numpy()
+        out[f"{tag}/pred_boxes"] = o["pred_boxes"].numpy()
+        out[f"{tag}/before_logits"] = before["pred_logits"].numpy()          # eval outputs of the un-deployed model
+        out[f"{tag}/before_boxes"] = before["pred_boxes"].numpy()
+        if size == "m":
+            for i, f in enumerate(feats):
+                out[f"{tag}/feat{i}"] = f.numpy()[:1, ::2].astype(np.float16)   # image 0, every other channel
+        out[f"{tag}/state_keys"] = np.array(sorted(model.state_dict().keys()))
+        sd = model.state_dict()
+        for k in ("encoder.fpn_blocks.0.cv2.0.bottlenecks.0.conv.weight", "encoder.fpn_blocks.0.cv2.0.bottlenecks.0.conv.bias",
+                  "encoder.input_proj.0.conv_bn_fused.weight" if "encoder.input_proj.0.conv_bn_fused.weight" in sd else
+                  "encoder.lateral_convs.0.conv_bn_fused.weight", "encoder.lateral_convs.0.conv_bn_fused.bias"):
+            out[f"{tag}/w/{k}"] = helpers.compact_rows(sd[k].numpy())
+    save("deploy.npz", **out)
+
+
 def gen_validator():
     """Box metrics of the reference's `Validator` (src/dl/validator.py:295-451: greedy IoU matching, per-class TP / FP / FN /
     IoU lists, confusion matrix) on seeded detection lists; `compute_maps=False` (torchmetrics / faster_coco_eval are not in
@@ -348,7 +382,7 @@ GENERATORS = {
     "model_m640_eval": lambda: gen_model("m", 640, 1, "model_m640_eval.npz", train=False),
     "model_s320": lambda: gen_model("s", 320, 2, "model_s320.npz"),
     "backbone_encoder": gen_backbone_encoder, "postprocess": gen_postprocess, "mask_units": gen_mask_units, "model_n320_mask": gen_mask_model,
-    "validator": gen_validator,
+    "validator": gen_validator, "deploy": gen_deploy,
 }
 
 if __name__ == "__main__":
