@@ -316,6 +316,8 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
 // Backward, "wide" mapping: D lanes per task, one channel per lane.  The f32 atomics of one
 // (task, corner) then cover one contiguous 4*D-byte run (a single 128 B line for D = 32) instead of
 // four quarter-filled lines - the L2 atomic units are paced by line operations, not by bytes.
+typedef __attribute__((ext_vector_type(2))) _Float16 half2_t;
+
 template <typename T, int D, bool FUSED>
 __global__ __launch_bounds__(kThreads) void msda_bwd_wide_kernel(
     const T *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ weight,
@@ -400,6 +402,128 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_wide_kernel(
     }
 }
 
+// Backward, "pair" mapping: D / 2 lanes per task, TWO channels per lane, so that one 8-byte integer atomic carries both:
+// d(value) is accumulated in int32 fixed point (contribution * fx_scale, rounded to nearest), channel pair (2j, 2j+1) packed
+// as lo + hi * 2^32 in one int64 and added with global_atomic_add_x2.  Integer addition is exact and commutative - the
+// result does not depend on the order the atomics retire in (f32 atomics do) - and the carry of the signed low half into
+// the high half is undone exactly when the buffer is read back: lo = (int32)R, hi = (R - lo) >> 32.  The L2 atomic units
+// retire one LANE operation per clock per channel (tools/msda_acc_bench.py: f32 599 us, int32 482 us, this kernel: see
+// DESIGN.md), so two channels per lane-op is what halves the time; a (task, corner) still covers one 128-byte line.
+// AM 2: the same mapping with ONE packed f16 atomic per channel pair (global_atomic_pk_add_f16) into an f16 accumulator whose
+// power-of-two scale (fx_state) keeps the largest possible sum below 2^15: the atomic units retire one DWORD per clock per
+// channel (f32 608 us, int32 482 us, int64 pairs 548 us, packed 16-bit pairs 325 us at the bench shape), so halving the
+// dwords is what halves the time.  f16 carries 11 significant bits (bf16: 8, measured 1.9 % of max worst-case error and
+// addends below 1/256 of a running sum lost outright) and, scaled, 39 binary orders below the largest sum.
+template <typename T, int D, bool FUSED, int AM>
+__global__ __launch_bounds__(kThreads) void msda_bwd_pair_kernel(
+    const T *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ weight,
+    const float *__restrict__ ref, const T *__restrict__ offsets, const T *__restrict__ logits,
+    const T *__restrict__ grad_out, void *__restrict__ grad_value, float *__restrict__ grad_loc,
+    float *__restrict__ grad_weight, T *__restrict__ grad_offsets, T *__restrict__ grad_logits,
+    MsdaLevels lv, int L, int H, int Lq, int total_q, float offset_scale, const float *__restrict__ fx_scale_p) {
+    constexpr int LPT = D / 2;
+    constexpr int QPB = kThreads / LPT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int P = lv.n_points;
+    float *s_x = smem, *s_y = smem + QPB * P, *s_w = smem + 2 * QPB * P;
+    float *s_gx = smem + 3 * QPB * P, *s_gy = smem + 4 * QPB * P, *s_gw = smem + 5 * QPB * P;
+    float *s_dot = smem + 6 * QPB * P;
+
+    const int head = blockIdx.x % H;
+    const int q0 = (blockIdx.x / H) * QPB;
+    const int nq = min(QPB, total_q - q0);
+    stage_points<T, FUSED>(lv, loc, weight, ref, offsets, logits, offset_scale, head, H, q0, nq,
+                           total_q, s_x, s_y, s_w);
+    const float fx_scale = *fx_scale_p;
+    __syncthreads();
+
+    const int qi = threadIdx.x / LPT, c2 = (threadIdx.x % LPT) * 2;
+    if (qi < nq) {
+        const int gq = q0 + qi;
+        const int b = gq / Lq;
+        const int64_t stride = (int64_t)H * D;
+        const int64_t base = ((int64_t)b * L * H + head) * D + c2;
+        const T *vbase = value + base;
+        float *px = s_x + qi * P, *py = s_y + qi * P, *pw = s_w + qi * P;
+        float go0, go1;
+        if (sizeof(T) == 2) {
+            const uint32_t gg = *reinterpret_cast<const uint32_t *>(grad_out + ((int64_t)gq * H + head) * D + c2);
+            go0 = __uint_as_float(gg << 16); go1 = __uint_as_float(gg & 0xffff0000u);
+        } else {
+            const float2 gg = *reinterpret_cast<const float2 *>(grad_out + ((int64_t)gq * H + head) * D + c2);
+            go0 = gg.x; go1 = gg.y;
+        }
+        const float gs0 = go0 * fx_scale, gs1 = go1 * fx_scale;
+
+        float wmax = 0.f, winv = 1.f;
+        if (FUSED) {
+            wmax = pw[0];
+            for (int p = 1; p < P; ++p) wmax = fmaxf(wmax, pw[p]);
+            float s = 0.f;
+            for (int p = 0; p < P; ++p) s += __expf(pw[p] - wmax);
+            winv = 1.f / s;
+        }
+        float dot_acc = 0.f;
+        for (int p = 0; p < P; ++p) {
+            const Corner c = corners(px[p], py[p], lv.start[p], lv.h[p], lv.w[p]);
+            const float aw = FUSED ? __expf(pw[p] - wmax) * winv : pw[p];
+            float d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v0, v1;
+                if (sizeof(T) == 2) {
+                    const uint32_t vv = *reinterpret_cast<const uint32_t *>(vbase + c.row[k] * stride);
+                    v0 = __uint_as_float(vv << 16); v1 = __uint_as_float(vv & 0xffff0000u);
+                } else {
+                    const float2 vv = *reinterpret_cast<const float2 *>(vbase + c.row[k] * stride);
+                    v0 = vv.x; v1 = vv.y;
+                }
+                d[k] = (go0 * v0 + go1 * v1) * c.ok[k];
+                const float g = aw * c.bw[k];
+                if (g != 0.f) {
+                    if (AM == 3) {
+                        const long long lo = (long long)__float2int_rn(g * gs0), hi = (long long)__float2int_rn(g * gs1);
+                        long long *dst = reinterpret_cast<long long *>(reinterpret_cast<int *>(grad_value) + base + c.row[k] * stride);
+                        __hip_atomic_fetch_add(dst, lo + (hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        const half2_t v = {(_Float16)(g * gs0), (_Float16)(g * gs1)};
+                        _Float16 *dst = reinterpret_cast<_Float16 *>(grad_value) + base + c.row[k] * stride;
+                        __builtin_amdgcn_global_atomic_fadd_v2f16((half2_t __attribute__((address_space(1))) *)dst, v);
+                    }
+                }
+            }
+            float gw = c.wy0 * c.wx0 * d[0] + c.wy0 * c.wx1 * d[1] + c.wy1 * c.wx0 * d[2] + c.wy1 * c.wx1 * d[3];
+            float gx = (c.wy0 * (d[1] - d[0]) + c.wy1 * (d[3] - d[2])) * aw * (float)lv.w[p];
+            float gy = (c.wx0 * (d[2] - d[0]) + c.wx1 * (d[3] - d[1])) * aw * (float)lv.h[p];
+            gw = group_sum<LPT>(gw);
+            gx = group_sum<LPT>(gx);
+            gy = group_sum<LPT>(gy);
+            dot_acc += aw * gw;
+            if (c2 == 0) {
+                s_gx[qi * P + p] = gx; s_gy[qi * P + p] = gy; s_gw[qi * P + p] = gw;
+                if (FUSED) pw[p] = aw;
+            }
+        }
+        if (c2 == 0) s_dot[qi] = dot_acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nq * P; i += kThreads) {
+        const int qj = i / P, p = i - qj * P;
+        const int64_t task = (int64_t)(q0 + qj) * H + head;
+        if (FUSED) {
+            const float4 r = *reinterpret_cast<const float4 *>(ref + (int64_t)(q0 + qj) * 4);
+            const float sc = lv.inv_n[p] * offset_scale;
+            store_f(grad_offsets + (task * P + p) * 2, s_gx[i] * sc * r.z);
+            store_f(grad_offsets + (task * P + p) * 2 + 1, s_gy[i] * sc * r.w);
+            store_f(grad_logits + task * P + p, s_w[i] * (s_gw[i] - s_dot[qj]));
+        } else {
+            grad_loc[(task * P + p) * 2] = s_gx[i];
+            grad_loc[(task * P + p) * 2 + 1] = s_gy[i];
+            grad_weight[task * P + p] = s_gw[i];
+        }
+    }
+}
+
 __global__ void cast_f32_bf16_kernel(const float *__restrict__ src, uint16_t *__restrict__ dst, int64_t n) {
     int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int64_t step = (int64_t)gridDim.x * blockDim.x * 4;
@@ -408,6 +532,105 @@ __global__ void cast_f32_bf16_kernel(const float *__restrict__ src, uint16_t *__
         Vec4<uint16_t>::store(dst + i, {v.x, v.y, v.z, v.w});
     }
     if (i < n && i + 3 >= n) for (int64_t j = i; j < n; ++j) dst[j] = f32_to_bf16(src[j]);
+}
+
+// ---- scale state of the fixed-point d(value) accumulator ------------------------------------------------------------
+// fx_state (device, 4 words, zero-filled together with the accumulator): [0] f32 scale (fixed-point units per 1.0),
+// [1] f32 capacity = the largest |grad_out| the scale was sized for, [2] u32 bits of max |grad_out| of the current call,
+// [3] i32 right-shift the accumulator needs before the current call adds into it.
+// Bound: every (query, head) spreads softmax weights (sum 1) x bilinear weights (<= 1) over its corners, so one
+// accumulator word receives at most |grad_out| per query and call: |sum| <= hit_bound * capacity with hit_bound =
+// (calls sharing the accumulator) x Lq, kept below 2^30.  A later call with larger gradients than the first one (x 4 head
+// room) rescales the accumulator in place (rare: one extra pass over it).
+template <typename T>
+__global__ __launch_bounds__(256) void fx_gmax_kernel(const T *__restrict__ g, int64_t n, float *__restrict__ state) {
+    float m = 0.f;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i + 3 < n; i += (int64_t)gridDim.x * 1024) {
+        const f32x4 v = Vec4<T>::load(g + i);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(load_f(g + (n & ~(int64_t)3) + threadIdx.x)));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m == m) atomicMax(reinterpret_cast<unsigned *>(state) + 2, __float_as_uint(fminf(m, 1e30f)));   // non-negative floats order like their bits
+    }
+}
+
+__global__ void fx_update_kernel(float *__restrict__ state, float hit_bound, float limit_log2) {
+    unsigned *su = reinterpret_cast<unsigned *>(state);
+    int *si = reinterpret_cast<int *>(state);
+    float gmax = __uint_as_float(su[2]);
+    su[2] = 0u;
+    gmax = fmaxf(gmax, 1e-30f);
+    int shift = 0;
+    if (state[0] == 0.f) {
+        const float cap = exp2f(ceilf(log2f(gmax)) + 2.f);           // power of two >= 4 gmax: scales stay exact powers of two
+        state[1] = cap;
+        state[0] = exp2f(limit_log2) / (exp2f(ceilf(log2f(fmaxf(hit_bound, 1.f)))) * cap);
+    } else if (gmax > state[1]) {
+        shift = (int)ceilf(log2f(gmax / state[1])) + 1;
+        if (shift > 62) shift = 62;
+        state[1] *= exp2f((float)shift);
+        state[0] *= exp2f(-(float)shift);
+    }
+    si[3] = shift;
+}
+
+// acc holds channel pairs lo + hi * 2^32 (see msda_bwd_pair_kernel): shift both halves right with rounding
+__global__ __launch_bounds__(256) void fx_rescale_kernel(long long *__restrict__ acc, int64_t n, const float *__restrict__ state) {
+    const int shift = reinterpret_cast<const int *>(state)[3];
+    if (shift == 0) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const long long r = acc[i];
+        const long long lo = (long long)(int)(r & 0xffffffffll), hi = (r - lo) >> 32;
+        const long long half = 1ll << (shift - 1);
+        const long long lo2 = (lo + half) >> shift, hi2 = (hi + half) >> shift;
+        acc[i] = lo2 + hi2 * 4294967296ll;
+    }
+}
+
+__global__ __launch_bounds__(256) void fx_rescale_f16_kernel(half2_t *__restrict__ acc, int64_t n, const float *__restrict__ state) {
+    const int shift = reinterpret_cast<const int *>(state)[3];
+    if (shift == 0) return;
+    const _Float16 f = (_Float16)exp2f(-(float)min(shift, 24));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        half2_t v = acc[i];
+        v.x *= f; v.y *= f;
+        acc[i] = v;
+    }
+}
+
+template <typename T>
+__global__ void cast_f16acc_kernel(const _Float16 *__restrict__ src, T *__restrict__ dst, int64_t n, const float *__restrict__ state) {
+    const float inv = 1.f / state[0];
+    typedef __attribute__((ext_vector_type(4))) _Float16 half4_t;
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    for (; i + 3 < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        const half4_t v = *reinterpret_cast<const half4_t *>(src + i);
+        Vec4<T>::store(dst + i, {(float)v.x * inv, (float)v.y * inv, (float)v.z * inv, (float)v.w * inv});
+    }
+    if (i < n && i + 3 >= n) for (int64_t j = i; j < n; ++j) store_f(dst + j, (float)src[j] * inv);
+}
+
+template <typename T>
+__global__ void cast_fixed_kernel(const long long *__restrict__ src, T *__restrict__ dst, int64_t npairs, const float *__restrict__ state) {
+    const float inv = 1.f / state[0];
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < npairs; i += (int64_t)gridDim.x * blockDim.x * 2) {
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const long long r = i + k < npairs ? src[i + k] : 0ll;
+            const long long lo = (long long)(int)(r & 0xffffffffll), hi = (r - lo) >> 32;
+            o[2 * k] = (float)lo * inv; o[2 * k + 1] = (float)hi * inv;
+        }
+        if (i + 1 < npairs) Vec4<T>::store(dst + 2 * i, {o[0], o[1], o[2], o[3]});
+        else { store_f(dst + 2 * i, o[0]); store_f(dst + 2 * i + 1, o[1]); }
+    }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -468,10 +691,38 @@ static int launch_bwd(const void *value, const float *loc, const float *weight, 
                       const void *offsets, const void *logits, const void *grad_out,
                       float *grad_value, float *grad_loc, float *grad_weight, void *grad_offsets,
                       void *grad_logits, int B, int L, int H, int D, int Lq, const MsdaLevels &lv,
-                      float offset_scale, hipStream_t st) {
+                      float offset_scale, hipStream_t st, int acc_mode = 0, float *fx_state = nullptr, float hit_bound = 1.f) {
     const int total_q = B * Lq;
     if (total_q == 0) return DFINE_OK;
     static const int variant = [] { const char *e = getenv("DFINE_MSDA_BWD"); return e ? atoi(e) : 1; }();
+    if (acc_mode == 2 || acc_mode == 3) {
+        if (!(D == 32 || D == 16 || D == 64)) return DFINE_E_BADARG;
+        // scale bookkeeping of the scaled accumulator (see fx_update_kernel): three small launches in front of the gather
+        hipLaunchKernelGGL((fx_gmax_kernel<T>), dim3(256), dim3(256), 0, st, (const T *)grad_out, (int64_t)total_q * H * D, fx_state);
+        hipLaunchKernelGGL(fx_update_kernel, dim3(1), dim3(1), 0, st, fx_state, hit_bound, acc_mode == 3 ? 30.f : 15.f);
+        if (acc_mode == 3)
+            hipLaunchKernelGGL(fx_rescale_kernel, dim3(1024), dim3(256), 0, st, reinterpret_cast<long long *>(grad_value),
+                               (int64_t)B * L * H * D / 2, fx_state);
+        else
+            hipLaunchKernelGGL(fx_rescale_f16_kernel, dim3(1024), dim3(256), 0, st, reinterpret_cast<half2_t *>(grad_value),
+                               (int64_t)B * L * H * D / 2, fx_state);
+#define DFINE_BWDP(DD, AM)                                                                     \
+    {                                                                                          \
+        constexpr int QPB = kThreads / (DD / 2);                                               \
+        const int nblk = ((total_q + QPB - 1) / QPB) * H;                                      \
+        const size_t sm = sizeof(float) * (6 * QPB * lv.n_points + QPB);                       \
+        hipLaunchKernelGGL((msda_bwd_pair_kernel<T, DD, FUSED, AM>), dim3(nblk), dim3(kThreads), sm, st, \
+                           (const T *)value, loc, weight, ref, (const T *)offsets,             \
+                           (const T *)logits, (const T *)grad_out, (void *)grad_value, grad_loc, \
+                           grad_weight, (T *)grad_offsets, (T *)grad_logits, lv, L, H, Lq,     \
+                           total_q, offset_scale, (const float *)fx_state);                    \
+    }
+        if (acc_mode == 3) { if (D == 32) DFINE_BWDP(32, 3) else if (D == 16) DFINE_BWDP(16, 3) else DFINE_BWDP(64, 3) }
+        else { if (D == 32) DFINE_BWDP(32, 2) else if (D == 16) DFINE_BWDP(16, 2) else DFINE_BWDP(64, 2) }
+#undef DFINE_BWDP
+        return check_launch();
+    }
+    if (acc_mode != 0) return DFINE_E_BADARG;
     if (variant == 1 && (D == 32 || D == 16 || D == 64)) {
 #define DFINE_BWDW(DD)                                                                         \
     {                                                                                          \
@@ -579,6 +830,57 @@ int dfine_msda_fused_bwd(const void *value, const float *ref, const void *offset
         return launch_bwd<uint16_t, true>(value, nullptr, nullptr, ref, offsets, logits, grad_out, grad_value_f32,
                                           nullptr, nullptr, grad_offsets, grad_logits, B, L, H, D, Lq, lv, offset_scale, st);
     return DFINE_E_BADARG;
+}
+
+// acc_mode: 0 = grad_value_acc is f32 (hardware f32 atomics, as dfine_msda_fused_bwd); 2 = f16, one packed f16 atomic per
+// channel pair, power-of-two scale in fx_state; 3 = int32 fixed point, channel pairs packed in int64, integer atomics (exact,
+// order-independent).  Modes 2 and 3 are finished by dfine_cast_scaled_acc.
+int dfine_msda_fused_bwd_acc(const void *value, const float *ref, const void *offsets, const void *logits,
+                             const void *grad_out, void *grad_value_acc, void *grad_offsets,
+                             void *grad_logits, int dtype, int B, int L, int H, int D, int Lq, int n_levels,
+                             const int *level_hw, const int *level_points, float offset_scale, int acc_mode,
+                             float *fx_state, float hit_bound, void *stream) {
+    if (B == 0 || Lq == 0) return DFINE_OK;
+    if (!value || !ref || !offsets || !logits || !grad_out || !grad_value_acc || !grad_offsets ||
+        !grad_logits || B < 0 || Lq < 0 || H < 1 || (acc_mode != 0 && acc_mode != 2 && acc_mode != 3) ||
+        (acc_mode != 0 && (!fx_state || !(hit_bound >= 1.f))))
+        return DFINE_E_BADARG;
+    MsdaLevels lv;
+    if (int e = fill_levels(lv, L, n_levels, level_hw, level_points)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    float *acc = reinterpret_cast<float *>(grad_value_acc);
+    if (dtype == DFINE_F32)
+        return launch_bwd<float, true>(value, nullptr, nullptr, ref, offsets, logits, grad_out, acc,
+                                       nullptr, nullptr, grad_offsets, grad_logits, B, L, H, D, Lq, lv, offset_scale, st,
+                                       acc_mode, fx_state, hit_bound);
+    if (dtype == DFINE_BF16)
+        return launch_bwd<uint16_t, true>(value, nullptr, nullptr, ref, offsets, logits, grad_out, acc,
+                                          nullptr, nullptr, grad_offsets, grad_logits, B, L, H, D, Lq, lv, offset_scale, st,
+                                          acc_mode, fx_state, hit_bound);
+    return DFINE_E_BADARG;
+}
+
+int dfine_cast_scaled_acc(const void *src, void *dst, int acc_mode, int dtype, int64_t n, const float *fx_state, void *stream) {
+    if (n == 0) return DFINE_OK;
+    if (!src || !dst || !fx_state || n < 0 || (n & 1) || (dtype != DFINE_BF16 && dtype != DFINE_F32) || (acc_mode != 2 && acc_mode != 3))
+        return DFINE_E_BADARG;
+    const int threads = 256;
+    int64_t blocks = (n / 4 + threads - 1) / threads;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (acc_mode == 3) {
+        if (dtype == DFINE_BF16)
+            hipLaunchKernelGGL(cast_fixed_kernel<uint16_t>, dim3((unsigned)blocks), dim3(threads), 0, st, (const long long *)src, (uint16_t *)dst, n / 2, fx_state);
+        else
+            hipLaunchKernelGGL(cast_fixed_kernel<float>, dim3((unsigned)blocks), dim3(threads), 0, st, (const long long *)src, (float *)dst, n / 2, fx_state);
+    } else {
+        if (dtype == DFINE_BF16)
+            hipLaunchKernelGGL(cast_f16acc_kernel<uint16_t>, dim3((unsigned)blocks), dim3(threads), 0, st, (const _Float16 *)src, (uint16_t *)dst, n, fx_state);
+        else
+            hipLaunchKernelGGL(cast_f16acc_kernel<float>, dim3((unsigned)blocks), dim3(threads), 0, st, (const _Float16 *)src, (float *)dst, n, fx_state);
+    }
+    return check_launch();
 }
 
 int dfine_cast_f32_to_bf16(const float *src, void *dst, int64_t n, void *stream) {

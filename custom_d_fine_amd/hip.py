@@ -30,6 +30,8 @@ _SIGNATURES = {
     "dfine_msda_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "dfine_msda_fused_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
     "dfine_msda_fused_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
+    "dfine_msda_fused_bwd_acc": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _F, _P]),
+    "dfine_cast_scaled_acc": (c_int, [_P, _P, _I, _I, _L, _P, _P]),
     "dfine_cast_f32_to_bf16": (c_int, [_P, _P, _L, _P]),
     "dfine_match_ws_bytes": (_L, [_I, _I, _I, _I]),
     "dfine_match": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P]),
@@ -262,13 +264,38 @@ def msda_fused_forward(value, ref, offsets, logits, shapes, points, offset_scale
     return out
 
 
-def msda_grad_value_buffer(value):
-    """Zero-filled fp32 accumulator for d(value) (the backward kernels add into it with atomics)."""
+# How d(value) of the deformable attention is accumulated: 2 = scaled f16, one packed atomic per channel pair (default: half
+# the atomic dwords of f32), 3 = int32 fixed point in 64-bit integer atomics (exact, order-independent), 0 = f32 atomics.
+# Default (-1): 2 for a bf16 model (the result is rounded to bf16 anyway), 0 for fp32 math (the fixed-point form resolves
+# ~1e-5 of max |grad_out| under its worst-case overflow bound: fine for training, coarser than the f32 atomics' 1e-7).
+MSDA_ACC_MODE = int(os.environ.get("DFINE_MSDA_ACC", "-1"))
+
+
+def msda_grad_value_buffer(value, uses=1):
+    """Zero-filled accumulator for d(value) (the backward kernels add into it with atomics); `uses` = backward calls that
+    will share it.  Modes 2 / 3: a flat f16 / int32 tensor with 16 trailing bytes of scale state."""
+    n = value.numel()
+    mode = MSDA_ACC_MODE if MSDA_ACC_MODE >= 0 else (2 if value.dtype == torch.bfloat16 else 0)
+    if mode in (2, 3) and n % 2 == 0:
+        buf = (torch.zeros(n + 8, device=value.device, dtype=torch.float16) if mode == 2
+               else torch.zeros(n + 4, device=value.device, dtype=torch.int32))
+        buf._dfine_fx = (tuple(value.shape), max(int(uses), 1), n)
+        return buf
     return torch.zeros(value.shape, device=value.device, dtype=torch.float32)
 
 
-def msda_finish_grad_value(gv32, dtype):
-    return _finish_grad_value(gv32, dtype)
+_ACC_MODE_OF = {torch.float32: 0, torch.float16: 2, torch.int32: 3}
+
+
+def msda_finish_grad_value(acc, dtype):
+    mode = _ACC_MODE_OF[acc.dtype]
+    if mode == 0:
+        return _finish_grad_value(acc, dtype)
+    shape, _, n = acc._dfine_fx
+    out = torch.empty(shape, device=acc.device, dtype=dtype)
+    _check(_lib.dfine_cast_scaled_acc(_ptr(acc), _ptr(out), mode, _DTYPE[dtype], n, acc.data_ptr() + acc.element_size() * n,
+                                      _stream()), "dfine_cast_scaled_acc")
+    return out
 
 
 def msda_fused_backward(value, ref, offsets, logits, grad_out, shapes, points, offset_scale, gv_acc=None):
@@ -283,16 +310,21 @@ def msda_fused_backward(value, ref, offsets, logits, grad_out, shapes, points, o
         logits = logits.to(value.dtype)
     if grad_out.dtype != value.dtype:
         grad_out = grad_out.to(value.dtype)
-    gv = torch.zeros(B, L, H, D, device=value.device, dtype=torch.float32) if gv_acc is None else gv_acc
+    gv = msda_grad_value_buffer(value) if gv_acc is None else gv_acc
+    mode = _ACC_MODE_OF[gv.dtype]
+    fx_state, hit_bound = None, 1.0
+    if mode != 0:
+        fx_state = gv.data_ptr() + gv.element_size() * gv._dfine_fx[2]
+        hit_bound = float(gv._dfine_fx[1] * Lq)
     goff = torch.empty_like(offsets)
     glog = torch.empty_like(logits)
     hw, pts = _levels(shapes, points)
     with _timed("msda_bwd", msda_algorithmic_bytes(B, Lq, H, D, sum(points), value.element_size(), backward=True)):
-        _check(_lib.dfine_msda_fused_bwd(_ptr(value), _ptr(ref), _ptr(offsets), _ptr(logits),
-                                         _ptr(grad_out), _ptr(gv), _ptr(goff), _ptr(glog),
-                                         _dtype_code(value), B, L, H, D, Lq, len(shapes), hw, pts,
-                                         float(offset_scale), _stream()), "dfine_msda_fused_bwd")
-    return (None if gv_acc is not None else _finish_grad_value(gv, value.dtype)), goff.to(off_dtype), glog.to(log_dtype)
+        _check(_lib.dfine_msda_fused_bwd_acc(_ptr(value), _ptr(ref), _ptr(offsets), _ptr(logits),
+                                             _ptr(grad_out), _ptr(gv), _ptr(goff), _ptr(glog),
+                                             _dtype_code(value), B, L, H, D, Lq, len(shapes), hw, pts,
+                                             float(offset_scale), mode, fx_state, hit_bound, _stream()), "dfine_msda_fused_bwd_acc")
+    return (None if gv_acc is not None else msda_finish_grad_value(gv, value.dtype)), goff.to(off_dtype), glog.to(log_dtype)
 
 
 # ------------------------------------------------------------------------------------- matcher

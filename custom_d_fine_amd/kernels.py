@@ -121,7 +121,7 @@ class _MSDAFused(torch.autograd.Function):
                 value, ref, offsets, logits, grad_out.contiguous(), shapes, points, offset_scale)
             return gv, None, goff, glog, None, None, None
         if share.acc is None:
-            share.acc = hip.msda_grad_value_buffer(value)
+            share.acc = hip.msda_grad_value_buffer(value, uses=share.pending)
         _, goff, glog = hip.msda_fused_backward(value, ref, offsets, logits, grad_out.contiguous(), shapes, points,
                                                 offset_scale, gv_acc=share.acc)
         share.pending -= 1

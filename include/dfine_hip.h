@@ -82,6 +82,30 @@ int dfine_msda_fused_bwd(const void *value, const float *ref, const void *offset
                          int D, int Lq, int n_levels, const int *level_hw,
                          const int *level_points, float offset_scale, void *stream);
 
+/* The same backward with a choice of how d(value) is accumulated (grad_value_acc [B, L, H, D], zero-filled by the
+ * caller, shared by the decoder layers of one step):
+ *   acc_mode 0: f32 words, hardware f32 atomics (= dfine_msda_fused_bwd);
+ *   acc_mode 2: f16 words, ONE packed f16 atomic per channel pair (the L2 atomic units retire one dword per clock and
+ *               channel: half the dwords = half the time), contributions multiplied by a power-of-two scale that keeps the
+ *               largest possible sum below 2^15;
+ *   acc_mode 3: int32 fixed-point words, the channel pair (2j, 2j+1) packed as lo + hi * 2^32 in one int64 and added
+ *               with ONE integer atomic - exact and commutative (the sum does not depend on the order the atomics retire
+ *               in), 10 % faster than f32.
+ * Modes 2 / 3: fx_state = 4 device words zero-filled with the accumulator (scale, capacity, scratch); the call sizes the
+ * scale from max |grad_out| so that hit_bound (= calls sharing the accumulator x Lq: every query adds at most |grad_out|
+ * to one word) x capacity stays below the limit, and rescales the accumulator in place if a later call brings larger
+ * gradients.  Finish with dfine_cast_scaled_acc. */
+int dfine_msda_fused_bwd_acc(const void *value, const float *ref, const void *offsets,
+                             const void *logits, const void *grad_out, void *grad_value_acc,
+                             void *grad_offsets, void *grad_logits, int dtype, int B, int L, int H,
+                             int D, int Lq, int n_levels, const int *level_hw,
+                             const int *level_points, float offset_scale, int acc_mode,
+                             float *fx_state, float hit_bound, void *stream);
+
+/* dst[i] (f32 or bf16, n elements, n even) = word i of an acc_mode 2 / 3 accumulator / scale(fx_state). */
+int dfine_cast_scaled_acc(const void *src, void *dst, int acc_mode, int dtype, int64_t n,
+                          const float *fx_state, void *stream);
+
 /* f32 -> bf16 (round to nearest even) copy of n elements; used to hand the f32-accumulated
  * grad_value back in the model's compute dtype. */
 int dfine_cast_f32_to_bf16(const float *src, void *dst, int64_t n, void *stream);

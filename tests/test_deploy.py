@@ -99,7 +99,8 @@ def test_deployed_encoder_runs_on_hip_kernels_bf16(cuda, monkeypatch):
     n_rep = sum(1 for mod in m.encoder.modules() if type(mod).__name__ == "VGGBlock")
     assert n_fused > 10 and n_rep >= 4
     assert enc_calls["aten"] == 0, enc_calls
-    assert enc_calls["hip_dense"] + enc_calls["hip_dw"] == n_fused + n_rep, (enc_calls, n_fused, n_rep)
+    n_proj = len(m.encoder.input_proj)                               # conv + BN pairs the reference's deploy() leaves alone (eval BN)
+    assert enc_calls["hip_dense"] + enc_calls["hip_dw"] == n_fused + n_rep + n_proj, (enc_calls, n_fused, n_rep, n_proj)
     assert enc_calls["hip_dw"] == 2                                   # the two SCDown depthwise convolutions
     for i, f in enumerate(feats):
         ref = torch.tensor(g[f"m320/feat{i}"].astype(np.float32))

@@ -1,5 +1,7 @@
 """End-to-end parity on the GPU: D-FINE forward / train step through the HIP kernels vs the golden
 vectors generated from the reference (fp32, north_star tolerance 1e-3 on logits/boxes)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -297,13 +299,11 @@ def test_bf16_blocks_vs_fp32_blocks_m320(cuda):
     assert not bad, bad
 
 
-def test_bf16_hip_blocks_vs_aten_bf16_blocks_m320(cuda, monkeypatch):
-    """The tight anchor of the bf16 path: every backbone / encoder block under bf16 autocast on the HIP kernels against THE
-    SAME block under bf16 autocast composed from ATen ops (MIOpen convolutions, at::batch_norm, rocBLAS: `DFINE_HIP_UNITS=0`
-    and friends), on the inputs the block saw in the fp32 run.  Both round to bf16 at the same points (conv output, BN /
-    activation output), so what is left is accumulation order: output cosine >= 0.9999, input-gradient and every
-    parameter-gradient cosine >= 0.999 - a wrong tap, a dropped split of a weight-gradient kernel or a mis-scaled BN
-    statistic shows up as 0.9x here (the fp32 comparison above cannot see them below its 0.9 bound)."""
+def bf16_block_parity_table(cuda):
+    """Every backbone / encoder block of D-FINE-m (seeded weights, 2 images, 320x320) run three ways on the inputs it saw in the
+    fp32 forward: fp32, bf16 autocast on the HIP kernels, bf16 autocast composed from ATen ops (MIOpen convolutions,
+    at::batch_norm: `DFINE_HIP_UNITS=0` and friends).  -> {block: {"hip": (1-cos y, 1-cos dx, worst 1-cos dparam, its name),
+    "aten": (...)}} with the cosines taken against the fp32 results."""
     import torch.nn as nn
     from custom_d_fine_amd import kernels
     m = dfine.build_model("m", 80, False, "cpu", img_size=[320, 320])
@@ -331,39 +331,63 @@ def test_bf16_hip_blocks_vs_aten_bf16_blocks_m320(cuda, monkeypatch):
         h.remove()
     switches = ("DFINE_HIP_UNITS", "DFINE_MFMA_CONV", "DFINE_STEM", "DFINE_SEG_CONV", "DFINE_BN2", "DFINE_DUAL_CONV",
                 "DFINE_HIP_LINEAR", "DFINE_LN_FUSED", "DFINE_HIP_ATTN")
-    cos = lambda a, b: torch.nn.functional.cosine_similarity(a.float().flatten(), b.float().flatten(), dim=0).item()
+    saved = {s: os.environ.get(s) for s in switches}
 
-    def run(b, xin):
+    def run(b, xin, amp):
         xi = [t.clone().requires_grad_(True) for t in xin] if isinstance(xin, list) else xin.clone().requires_grad_(True)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
             y = b(xi)
         b.zero_grad()
         (y.float() * helpers.make_cotangent(y.shape, 77).to(cuda)).sum().backward()
         gx = torch.cat([t.grad.float().flatten() for t in xi]) if isinstance(xi, list) else xi.grad.detach()
         return y.detach(), gx, {k: p.grad.detach().clone() for k, p in b.named_parameters() if p.grad is not None}
 
+    results = {}
     try:
-        results = {}
-        for mode in ("hip", "aten"):
+        for mode in ("fp32", "hip", "aten"):
             for s in switches:
                 if mode == "aten":
-                    monkeypatch.setenv(s, "0")
+                    os.environ[s] = "0"
                 else:
-                    monkeypatch.delenv(s, raising=False)
+                    os.environ.pop(s, None)
             kernels.reload_env()
             for n, b in blocks:
-                results[(mode, n)] = run(b, captured[n])
+                results[(mode, n)] = run(b, captured[n], mode != "fp32")
     finally:
-        for s in switches:
-            monkeypatch.delenv(s, raising=False)
+        for s, v in saved.items():
+            if v is None:
+                os.environ.pop(s, None)
+            else:
+                os.environ[s] = v
         kernels.reload_env()
-    bad = {}
+    one_minus_cos = lambda a, b: 1.0 - torch.nn.functional.cosine_similarity(a.double().flatten(), b.double().flatten(), dim=0).item()
+    table = {}
     for n, _ in blocks:
-        (y0, gx0, gp0), (y1, gx1, gp1) = results[("hip", n)], results[("aten", n)]
-        assert gp0.keys() == gp1.keys(), n
-        cy, cx = cos(y0, y1), cos(gx0, gx1)
-        worst_k, cp = min(((k, cos(gp0[k], gp1[k])) for k in gp0 if gp0[k].numel() > 16 and gp1[k].abs().max() > 0),
-                          key=lambda t: t[1], default=("", 1.0))
-        if cy < 0.9999 or cx < 0.999 or cp < 0.999:
-            bad[n] = (round(cy, 5), round(cx, 5), worst_k, round(cp, 5))
+        y0, gx0, gp0 = results[("fp32", n)]
+        row = {}
+        for mode in ("hip", "aten"):
+            y1, gx1, gp1 = results[(mode, n)]
+            assert gp0.keys() == gp1.keys(), (n, mode)
+            wk, wp = max(((k, one_minus_cos(gp0[k], gp1[k])) for k in gp0 if gp0[k].numel() > 16 and gp0[k].abs().max() > 0),
+                         key=lambda t: t[1], default=("", 0.0))
+            row[mode] = (one_minus_cos(y0, y1), one_minus_cos(gx0, gx1), wp, wk)
+        table[n] = row
+    return table
+
+
+def test_bf16_hip_blocks_no_worse_than_aten_bf16_blocks_m320(cuda):
+    """The tight anchor of the bf16 path.  Two bf16 implementations of one block cannot be compared with each other at
+    cosine 0.999 - measured: the BatchNorm weight gradients (sums of dy * xhat with cancelling signs over batch statistics of
+    two images) of the HIP path and of the ATen bf16 composition differ by cosine 0.90-0.98 although both round to bf16 at the
+    same points.  What can be demanded is that the HIP path is AS CLOSE TO fp32 AS ATen's bf16 path: per block, the distance
+    1 - cos to the block's fp32 output / input gradient / worst parameter gradient may exceed ATen-bf16's by at most a factor
+    1.5 (+ 2e-4 absolute).  A wrong tap, a dropped weight-gradient split or a mis-scaled statistic moves the HIP distance by
+    orders of magnitude, ATen's not at all (the fp32 comparison above only bounds it by 0.1)."""
+    table = bf16_block_parity_table(cuda)
+    bad = {}
+    for n, row in table.items():
+        for qi, q in enumerate(("y", "dx", "dparam")):
+            h, a = row["hip"][qi], row["aten"][qi]
+            if h > 1.5 * a + 2e-4:
+                bad[(n, q)] = (round(h, 5), round(a, 5), row["hip"][3] if q == "dparam" else "")
     assert not bad, bad

@@ -175,3 +175,45 @@ def test_shared_value_gradient_accumulator(cuda):
     o1 = kernels.msda_fused(value, shapes, ref, offs[0], lgs[0], points, 0.5)
     o1.backward(gos[0])
     assert mem.grad is not None and torch.isfinite(mem.grad.float()).all()
+
+
+def test_value_gradient_accumulate_modes(cuda, monkeypatch):
+    """d(value) accumulation forms of dfine_msda_fused_bwd_acc at the bench shape (clustered denoising queries + uniform
+    ones): scaled f16 with one packed atomic per channel pair (the bf16 default) and int32 fixed point in 64-bit integer
+    atomics against the f32-atomic accumulator.  Two calls share each accumulator; the second brings 64x larger gradients,
+    which forces the in-place rescale of the scaled forms.  f16: 11 significant bits per running sum - 2e-3 of the largest
+    entry, below the bf16 rounding of the result; fixed point: exact sums of contributions rounded to 2^-30 of the overflow
+    bound, bit-identical from run to run (integer adds commute; f32 atomics do not)."""
+    from custom_d_fine_amd import hip
+    torch.manual_seed(1)
+    B, Lq, H, D, L = 8, 492, 8, 32, 8400
+    shapes, points = ((80, 80), (40, 40), (20, 20)), (3, 6, 3)
+    value = torch.randn(B, L, H, D, device=cuda).bfloat16()
+    gt = torch.cat([torch.rand(B, 7, 2, device=cuda) * 0.6 + 0.2, torch.rand(B, 7, 2, device=cuda) * 0.3 + 0.05], -1)
+    dn = (gt.repeat(1, 28, 1)[:, :192] + torch.randn(B, 192, 4, device=cuda) * 0.02).clamp(0.01, 0.99)
+    ref = torch.cat([dn, torch.cat([torch.rand(B, 300, 2, device=cuda), torch.rand(B, 300, 2, device=cuda) * 0.3 + 0.02], -1)], 1).contiguous()
+    off = (torch.randn(B, Lq, H, 12, 2, device=cuda) * 0.5).bfloat16()
+    lg = torch.randn(B, Lq, H, 12, device=cuda).bfloat16()
+    gos = [torch.randn(B, Lq, H * D, device=cuda).bfloat16(), (torch.randn(B, Lq, H * D, device=cuda) * 64).bfloat16()]
+
+    def run(mode):
+        monkeypatch.setattr(hip, "MSDA_ACC_MODE", mode)
+        acc = hip.msda_grad_value_buffer(value, uses=2)
+        small = []
+        for go in gos:
+            _, goff, glog = hip.msda_fused_backward(value, ref, off, lg, go, shapes, points, 0.5, gv_acc=acc)
+            small.append((goff.float(), glog.float()))
+        return hip.msda_finish_grad_value(acc, torch.float32), small
+
+    want, small0 = run(0)
+    top = want.abs().max().item()
+    f16, small2 = run(2)
+    assert (f16 - want).abs().max().item() <= 2e-3 * top
+    assert ((f16 - want).abs().sum() / want.abs().sum()).item() < 1e-3
+    fx, small3 = run(3)
+    assert (fx - want).abs().max().item() <= 2e-4 * top
+    fx2, _ = run(3)
+    assert torch.equal(fx, fx2)
+    for other in (small2, small3):                    # the per-point gradients do not depend on the accumulator form
+        for (a0, b0), (a1, b1) in zip(small0, other):
+            assert torch.equal(a0, a1) and torch.equal(b0, b1)
