@@ -517,16 +517,19 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
         if (s + 1 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XPW + NTN) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kG2Ring >= 3 && s + 2 < nstage) issue(s + 2);      // ring of 2: launched for <= 2 stages only, both issued above
         const unsigned char *xs = lds + (s % kG2Ring) * SB, *ws = xs + XB;
+        // Every fragment of the stage's two 32-channel slabs is requested BEFORE the first MFMA (the loop this replaces read
+        // one B fragment, waited for it, issued its NTN MFMAs, read the next: ~150 cycles of exposed LDS latency per fragment,
+        // 16 x per stage - the kernel ran at a fifth of its MFMA time, profiles/r03_conv1x1_schedule.txt); the copies of stage
+        // s + 2 are issued behind the reads, so their issue slots overlap the LDS latency instead of preceding it.
+        const bool two = s * kG2Rows + 32 < KP;               // uniform: the second slab exists (KP is a multiple of 32)
+        bf16x8 a[2][NTN], bq[2][PXW];
 #pragma unroll
         for (int slab = 0; slab < 2; ++slab) {
-            if (s * kG2Rows + slab * 32 >= KP) break;    // uniform
-            bf16x8 a[NTN];
 #pragma unroll
             for (int t = 0; t < NTN; ++t) {
                 const int row = wn * 16 * NTN + t * 16 + i16;
-                a[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(ws + row * 128 + (((slab * 4 + g) ^ (row & 7)) << 4)));
+                a[slab][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(ws + row * 128 + (((slab * 4 + g) ^ (row & 7)) << 4)));
             }
             const int r = slab * 32 + 4 * g + (i16 >> 2);
             const unsigned char *xr = xs + r * XPITCH + ((i16 & 3) << 3);
@@ -536,11 +539,21 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
                 const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_v4s __attribute__((address_space(3))) *)(xr + seg));
                 const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_v4s __attribute__((address_space(3))) *)(xr + seg + 16 * XPITCH));
                 typedef short tr_v8s __attribute__((ext_vector_type(8)));
-                const bf16x8 bf = __builtin_bit_cast(bf16x8, (tr_v8s)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                bq[slab][j] = __builtin_bit_cast(bf16x8, (tr_v8s)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+        }
+        if (kG2Ring >= 3 && s + 2 < nstage) issue(s + 2);      // ring of 2: launched for <= 2 stages only, both issued above
+#pragma unroll
+        for (int j = 0; j < PXW; ++j)
+#pragma unroll
+            for (int t = 0; t < NTN; ++t)
+                acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][t], bq[0][j], acc[t][j], 0, 0, 0);
+        if (two) {
+#pragma unroll
+            for (int j = 0; j < PXW; ++j)
 #pragma unroll
                 for (int t = 0; t < NTN; ++t)
-                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], bf, acc[t][j], 0, 0, 0);
-            }
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][t], bq[1][j], acc[t][j], 0, 0, 0);
         }
     }
     // ---- epilogue: [n][px] bf16 tile of this wave through LDS, then whole 128-byte pixel rows with 16-byte stores ----
@@ -917,26 +930,31 @@ __global__ __launch_bounds__(kW2Threads) void conv_wgrad1_glds_kernel(const Chan
         if (s + 1 < nstage) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (s + 2 < nstage) issue(s + 2);
         const unsigned char *ta = lds + (s % kW2Ring) * SB, *tb = ta + OPB;
+        // all 20 fragments of the stage's two 32-pixel K steps are requested first, the copies of stage s + 2 are issued behind
+        // them (their issue slots overlap the LDS latency), then 32 MFMAs run back to back - one wave per SIMD here, so nothing
+        // else would hide a read -> wait -> MFMA chain
+        bf16x8 af[2][2], bfr[2][8];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2], bfr[8];
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int row = wave * 32 + a * 16 + i16;
-                af[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(ta + row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4)));
+                af[ks][a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(ta + row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4)));
             }
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 const int row = b * 16 + i16;
-                bfr[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(tb + row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4)));
+                bfr[ks][b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(tb + row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4)));
             }
+        }
+        if (s + 2 < nstage) issue(s + 2);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 8; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
-        }
+                for (int b = 0; b < 8; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][a], bfr[ks][b], acc[a][b], 0, 0, 0);
     }
     // partial sums: part[split][n][c]; lane holds c = i16 (+ 16 b), n = 4 g + r (+ 16 a + 32 wave)
 #pragma unroll
