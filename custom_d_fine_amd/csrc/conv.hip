@@ -114,7 +114,7 @@ template <> __device__ __forceinline__ void unpack<2>(const uint32_t &v, uint16_
 // KC = number of 32-channel slabs staged per barrier pair: layers with many input channels are otherwise
 // bound by the (global load -> LDS -> barrier) latency of each 32-channel step, not by MFMA or HBM.
 template <int KS, int NTN, int VEC, int KC>
-__global__ __launch_bounds__(kConvThreads) void conv_igemm_kernel(
+__global__ __launch_bounds__(kConvThreads, 2) void conv_igemm_kernel(      // two workgroups per CU: at most 256 registers
     const uint16_t *__restrict__ x, const uint16_t *__restrict__ w2, uint16_t *__restrict__ y, int Cin,
     int Cout, int NP, int KP, int H, int W, int R, int strips) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -179,31 +179,41 @@ __global__ __launch_bounds__(kConvThreads) void conv_igemm_kernel(
         }
         __syncthreads();
         // ---- MFMA over the slabs and taps --------------------------------------------------------
+        // The weights of tap t + 1 are requested (L2 -> registers) before the MFMAs of tap t, and all pixel-tile fragments of a
+        // tap are read from LDS before its first MFMA: the loop this replaces went load A -> per pixel tile { ds_read ->
+        // s_waitcnt vmcnt(0) lgkmcnt(0) -> NTN MFMAs }, i.e. one exposed L2 round trip per tap and one exposed LDS round trip
+        // per NTN MFMAs.  Pixel tiles past the strip (the last strip of a 20 x 20 map) read pixel 0 and are never stored.
+        auto load_a = [&](int tap, int cs, bf16x8 (&a)[NTN]) {
+#pragma unroll
+            for (int t = 0; t < NTN; ++t) {
+                const int n = min(n_wave + t * 16 + (lane & 15), NP - 1);          // rows past the layer: a valid row, never stored
+                a[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(w2 + ((int64_t)tap * NP + n) * KP + cs + 8 * (lane >> 4)));
+            }
+        };
 #pragma unroll
         for (int slab = 0; slab < KC; ++slab) {
             const int cs = c0 + 32 * slab;
             if (KC > 1 && cs >= KP) break;
             const unsigned char *slds = lds + slab * npxl * 64;
+            bf16x8 a[NTN];
+            load_a(0, cs, a);
 #pragma unroll
             for (int tap = 0; tap < KS * KS; ++tap) {
                 const int toff = ((tap / KS) * WL + (tap % KS)) * 64;
-                bf16x8 a[NTN];
+                bf16x8 an[NTN];
+                if (tap + 1 < KS * KS) load_a(tap + 1, cs, an);
+                bf16x8 bf[kMaxPixTiles];
 #pragma unroll
-                for (int t = 0; t < NTN; ++t) {
-                    const int n = n_wave + t * 16 + (lane & 15);
-                    uint4 av = make_uint4(0, 0, 0, 0);
-                    if (n < NP) av = *reinterpret_cast<const uint4 *>(w2 + ((int64_t)tap * NP + n) * KP + cs + 8 * (lane >> 4));
-                    a[t] = __builtin_bit_cast(bf16x8, av);
-                }
+                for (int jt = 0; jt < kMaxPixTiles; ++jt)
+                    bf[jt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(slds + pl[jt] + toff));
 #pragma unroll
-                for (int jt = 0; jt < kMaxPixTiles; ++jt) {
-                    if (jt < ntile) {
-                        const uint4 bv = *reinterpret_cast<const uint4 *>(slds + pl[jt] + toff);
-                        const bf16x8 bf = __builtin_bit_cast(bf16x8, bv);
+                for (int jt = 0; jt < kMaxPixTiles; ++jt)
 #pragma unroll
-                        for (int t = 0; t < NTN; ++t)
-                            acc[t][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], bf, acc[t][jt], 0, 0, 0);
-                    }
+                    for (int t = 0; t < NTN; ++t)
+                        acc[t][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], bf[jt], acc[t][jt], 0, 0, 0);
+                if (tap + 1 < KS * KS) {
+#pragma unroll
+                    for (int t = 0; t < NTN; ++t) a[t] = an[t];
                 }
             }
         }
@@ -781,31 +791,33 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
             return av;
         };
         uint4 av = KS == 3 ? acur[0] : load_a(0);
-        for (int k0 = 0; k0 < tp; k0 += 32) {
-            uint4 an;
-            if (KS == 3) {                                        // select, no dynamic register indexing
-                const int ksn = (k0 >> 5) + 1;
-                an = make_uint4(0, 0, 0, 0);
-#pragma unroll
-                for (int q = 1; q < NKS; ++q) if (ksn == q) an = acur[q];
-            } else {
-                an = load_a(k0 + 32);                             // zero beyond the strip
-            }
-            const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+        // LDS fragments of K step k0 + 32 are requested before the MFMAs of step k0 (the loop this replaces read one channel
+        // tile's fragment, waited for it, issued its KS MFMAs - an exposed LDS round trip per 3 MFMAs).  Channel tiles past
+        // Cin hold zeros and output rows past Cout meet a zero dY fragment: no per-tile branches.
+        uint4 fc[2][4];
+        uint32_t fl[2][4], fr[2][4];
+        auto read_step = [&](int k0, uint4 (&c1)[4], uint32_t (&lw)[4], uint32_t (&rw)[4]) {
             const int px = k0 + 8 * (lane >> 4);
             const int pxc = px < tp ? px : 0;
             const int row = pxc / W, col = pxc - row * W;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
-                if (c_base + ct * 16 >= Cin || !wave_active) continue;       // uniform per wave
-                const int cc = ct * 16 + (lane & 15);
-                const uint16_t *e = xs + (cc * CS + row * PW + LPAD + col);
-                const uint4 c1 = *reinterpret_cast<const uint4 *>(e);
+                const uint16_t *e = xs + ((ct * 16 + (lane & 15)) * CS + row * PW + LPAD + col);
+                c1[ct] = *reinterpret_cast<const uint4 *>(e);
+                if (KS == 3) {
+                    lw[ct] = *reinterpret_cast<const uint32_t *>(e - 2);
+                    rw[ct] = *reinterpret_cast<const uint32_t *>(e + 8);
+                }
+            }
+        };
+        auto mfma_step = [&](const bf16x8 a, const uint4 (&c1v)[4], const uint32_t (&lwv)[4], const uint32_t (&rwv)[4]) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const uint4 c1 = c1v[ct];
                 if (KS == 1) {
                     acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, c1), acc[ct][0], 0, 0, 0);
                 } else {
-                    const uint32_t lw = *reinterpret_cast<const uint32_t *>(e - 2);
-                    const uint32_t rw = *reinterpret_cast<const uint32_t *>(e + 8);
+                    const uint32_t lw = lwv[ct], rw = rwv[ct];
                     uint4 b0, b2;
                     b0.x = (lw >> 16) | (c1.x << 16); b0.y = (c1.x >> 16) | (c1.y << 16);
                     b0.z = (c1.y >> 16) | (c1.z << 16); b0.w = (c1.z >> 16) | (c1.w << 16);
@@ -816,7 +828,34 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
                     acc[ct][KS - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, b2), acc[ct][KS - 1], 0, 0, 0);
                 }
             }
-            av = an;
+        };
+        read_step(0, fc[0], fl[0], fr[0]);
+        for (int k0 = 0; k0 < tp; k0 += 64) {                       // two K steps per trip: static register sets
+            uint4 an;
+            if (KS == 3) {                                        // select, no dynamic register indexing
+                const int ksn = (k0 >> 5) + 1;
+                an = make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int q = 1; q < NKS; ++q) if (ksn == q) an = acur[q];
+            } else {
+                an = load_a(k0 + 32);                             // zero beyond the strip
+            }
+            const bool second = k0 + 32 < tp;
+            if (second) read_step(k0 + 32, fc[1], fl[1], fr[1]);
+            mfma_step(__builtin_bit_cast(bf16x8, av), fc[0], fl[0], fr[0]);
+            if (!second) break;
+            uint4 an2;
+            if (KS == 3) {
+                const int ksn = (k0 >> 5) + 2;
+                an2 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int q = 2; q < NKS; ++q) if (ksn == q) an2 = acur[q];
+            } else {
+                an2 = load_a(k0 + 64);
+            }
+            if (k0 + 64 < tp) read_step(k0 + 64, fc[0], fl[0], fr[0]);
+            mfma_step(__builtin_bit_cast(bf16x8, an), fc[1], fl[1], fr[1]);
+            av = an2;
         }
         __syncthreads();
     }
