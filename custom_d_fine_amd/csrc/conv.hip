@@ -448,7 +448,8 @@ template <int NTN, int kG2Ring, int PXW, bool SEG>   // kG2Ring LDS stages (3: t
                                                      // tiles per wave (4 / 8); SEG: input / output given as several parts
 __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs xs_, const uint16_t *__restrict__ w2,
                                                                   const ChanSegs ys_, int Cin, int Cout, int NP, int KP,
-                                                                  int HW, int ptiles, int total_tiles, int nblk, int accum) {
+                                                                  int HW, int ptiles, int total_tiles, int nblk, int accum,
+                                                                  int64_t w_bstride /* elements between the images' weight sets: 0 = shared */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int TP = 32 * PXW;                                             // pixels per workgroup (128 or 256)
     constexpr int XPITCH = TP * 2;                                           // bytes per channel row
@@ -463,6 +464,7 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
     const int p0 = pt * TP;
     const int npix = min(TP, HW - p0);
     const int n0 = nb * 64 * NTN;
+    w2 += (int64_t)b * w_bstride;                       // per-image weights (the mask-logit einsum bqc,bchw->bqhw)
     const int wn = wave >> 1, wp = wave & 1;
     const int g = lane >> 4, i16 = lane & 15;
     const int nstage = (KP + kG2Rows - 1) / kG2Rows;
@@ -608,7 +610,8 @@ static ChanSegs one_seg(const void *p, int C) {
 }
 
 static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B, int Cin, int Cout, int NP, int KP, int HW,
-                          hipStream_t st, const ChanSegs *xsegs = nullptr, const ChanSegs *ysegs = nullptr, int accum = 0) {
+                          hipStream_t st, const ChanSegs *xsegs = nullptr, const ChanSegs *ysegs = nullptr, int accum = 0,
+                          int64_t w_bstride = 0) {
     const int ptiles = (HW + kTrPix - 1) / kTrPix;
     static const int v2_env = [] { const char *e = getenv("DFINE_CONV1X1_GLDS"); return e ? atoi(e) : 1; }();
     static const int px256_env = [] { const char *e = getenv("DFINE_CONV1X1_PX256"); return e ? atoi(e) : 1; }();
@@ -641,15 +644,15 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
             attr2 = true;
         }
 #define DFINE_G2(N, R, P)                                                                                                                        \
-    { if (seg) hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, true>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum); \
-      else hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, false>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum); }
+    { if (seg) hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, true>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum, w_bstride); \
+      else hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, false>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum, w_bstride); }
         if (px256) DFINE_G2(2, 3, 8)
         else if (wide2) { if (ring2) DFINE_G2(2, 2, 4) else DFINE_G2(2, 3, 4) }
         else { if (ring2) DFINE_G2(1, 2, 4) else DFINE_G2(1, 3, 4) }
 #undef DFINE_G2
         return check_launch();
     }
-    if (xsegs || ysegs || accum) return DFINE_E_BADARG;  // the first-generation kernel takes whole tensors only, no accumulation
+    if (xsegs || ysegs || accum || w_bstride) return DFINE_E_BADARG;  // the first-generation kernel takes whole tensors, shared weights, no accumulation
     const int vec = (HW % 8 == 0) ? 8 : (HW % 4 == 0 ? 4 : 2);
     static const int kc_env = [] { const char *e = getenv("DFINE_CONV_KC"); return e ? atoi(e) : 0; }();
     int kc = KP >= 128 ? 4 : (KP >= 64 ? 2 : 1);
@@ -1381,6 +1384,18 @@ int dfine_conv1x1_accum_bf16(const void *x, const void *w2, void *y, int B, int 
     const int NP = (Cout + 15) / 16 * 16, KP = (Cin + 31) / 32 * 32;
     return launch_conv1x1((const uint16_t *)x, (const uint16_t *)w2, (uint16_t *)y, B, Cin, Cout, NP, KP, HW,
                           (hipStream_t)stream, nullptr, nullptr, 1);
+}
+
+// y[b] = conv1x1(x[b], W_b) with ONE WEIGHT SET PER IMAGE: w2 [B][NP][KP] packed like dfine_conv_pack_weights(KS = 1) per
+// image (NP = Cout rounded up to 16, KP = Cin rounded up to 32, k in tr_slab_channel order).  The mask-logit contraction
+// einsum("bqc,bchw->bqhw") of the segmentation head (ref dfine_decoder.py:925-932: Cout = queries, Cin = mask_dim) and its
+// gradient with respect to the mask features (weights = the embeddings transposed).  (H*W) % 8 == 0, Cin % 4 == 0.
+int dfine_conv1x1_bw_bf16(const void *x, const void *w2, void *y, int B, int Cin, int Cout, int HW, void *stream) {
+    if (B == 0) return DFINE_OK;
+    if (!x || !w2 || !y || Cin < 4 || Cout < 1 || HW < 1 || Cin % 4 || HW % 8) return DFINE_E_BADARG;
+    const int NP = (Cout + 15) / 16 * 16, KP = (Cin + 31) / 32 * 32;
+    return launch_conv1x1((const uint16_t *)x, (const uint16_t *)w2, (uint16_t *)y, B, Cin, Cout, NP, KP, HW, (hipStream_t)stream,
+                          nullptr, nullptr, 0, (int64_t)NP * KP);
 }
 
 // Weight gradient of the same convolution.  x [B,Cin,H,W], dy [B,Cout,H,W] bf16 -> dw [Cout,Cin,KS,KS]

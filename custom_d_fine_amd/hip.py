@@ -76,6 +76,15 @@ _SIGNATURES = {
     "dfine_attn_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "dfine_attn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                                _F, _P]),
+    "dfine_groupnorm_ws_floats": (_L, [_I, _I, _I]),
+    "dfine_groupnorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "dfine_groupnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_bilinear_fwd": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_bilinear_bwd": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_mask_loss_sums": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfine_mask_loss_grad": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfine_mask_cost": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "dfine_conv1x1_bw_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_preprocess_u8": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_postprocess": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_linear_wgrad_ws_floats": (_L, [_I, _I, _I]),
@@ -1055,3 +1064,84 @@ def ln_fused_backward(mode, a, b, gate, weight, mean, rstd, dy, clampv, need_a, 
                                    _ptr(rstd), _ptr(dy), float(clampv), _ptr(da), _ptr(db), _ptr(dg), _ptr(dw), _ptr(dbias),
                                    _ptr(ws), rows, D, _stream()), "dfine_ln_fused_bwd")
     return da, db, dg, dw, dbias
+
+
+# ------------------------------------------------------------------------------------- segmentation head (A10 / A15)
+def groupnorm_forward(x, gamma, beta, groups, eps, relu):
+    """x [B, C, H, W] f32 / bf16 contiguous -> (y, stat [B, G, 2])."""
+    B, C = x.shape[:2]
+    hw = x.numel() // max(B * C, 1)
+    y = torch.empty_like(x)
+    stat = torch.empty(B, groups, 2, device=x.device, dtype=torch.float32)
+    ws = torch.empty(int(_lib.dfine_groupnorm_ws_floats(B, C, groups)), device=x.device, dtype=torch.float32)
+    _check(_lib.dfine_groupnorm_fwd(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(stat), _ptr(ws), _dtype_code(x), B, C, hw,
+                                    groups, float(eps), int(bool(relu)), _stream()), "dfine_groupnorm_fwd")
+    return y, stat
+
+
+def groupnorm_backward(x, dy, gamma, beta, stat, groups, relu):
+    """-> (dx, dgamma [C], dbeta [C])."""
+    B, C = x.shape[:2]
+    hw = x.numel() // max(B * C, 1)
+    dx = torch.empty_like(x)
+    part = torch.empty(B, C, 2, device=x.device, dtype=torch.float32)
+    ws = torch.empty(B * groups * 2, device=x.device, dtype=torch.float32)
+    _check(_lib.dfine_groupnorm_bwd(_ptr(x), _ptr(dy), _ptr(dx), _ptr(gamma), _ptr(beta), _ptr(stat), _ptr(part), _ptr(ws),
+                                    _dtype_code(x), B, C, hw, groups, int(bool(relu)), _stream()), "dfine_groupnorm_bwd")
+    s = part.sum(0)
+    return dx, s[:, 1].contiguous(), s[:, 0].contiguous()
+
+
+def bilinear_forward(x, out_hw, accumulate_into=None):
+    """x [..., Hi, Wi] contiguous -> [..., Ho, Wo] (align_corners=False); accumulate_into: a tensor of that shape to add onto."""
+    hi, wi = x.shape[-2:]
+    planes = x.numel() // max(hi * wi, 1)
+    y = accumulate_into if accumulate_into is not None else torch.empty(*x.shape[:-2], out_hw[0], out_hw[1], device=x.device, dtype=x.dtype)
+    _check(_lib.dfine_bilinear_fwd(_ptr(x), _ptr(y), _dtype_code(x), planes, hi, wi, out_hw[0], out_hw[1],
+                                   int(accumulate_into is not None), _stream()), "dfine_bilinear_fwd")
+    return y
+
+
+def bilinear_backward(dy, in_hw):
+    ho, wo = dy.shape[-2:]
+    planes = dy.numel() // max(ho * wo, 1)
+    dx = torch.empty(*dy.shape[:-2], in_hw[0], in_hw[1], device=dy.device, dtype=dy.dtype)
+    _check(_lib.dfine_bilinear_bwd(_ptr(dy), _ptr(dx), _dtype_code(dy), planes, in_hw[0], in_hw[1], ho, wo, _stream()),
+           "dfine_bilinear_bwd")
+    return dx
+
+
+def mask_loss_sums(pm, plan_b, plan_q, tgt, boxes):
+    B, Q, H, W = pm.shape
+    M = plan_b.numel()
+    sums = torch.empty(M, 4, device=pm.device, dtype=torch.float32)
+    _check(_lib.dfine_mask_loss_sums(_ptr(pm), _ptr(plan_b), _ptr(plan_q), _ptr(tgt), _ptr(boxes), _ptr(sums), _dtype_code(pm),
+                                     M, Q, H, W, _stream()), "dfine_mask_loss_sums")
+    return sums
+
+
+def mask_loss_grad(pm, plan_b, plan_q, tgt, boxes, coef):
+    B, Q, H, W = pm.shape
+    grad = torch.zeros_like(pm)
+    _check(_lib.dfine_mask_loss_grad(_ptr(pm), _ptr(plan_b), _ptr(plan_q), _ptr(tgt), _ptr(boxes), _ptr(coef), _ptr(grad),
+                                     _dtype_code(pm), plan_b.numel(), Q, H, W, _stream()), "dfine_mask_loss_grad")
+    return grad
+
+
+def mask_cost_sums(pm, gt, toff, q, tmax, alpha, gamma):
+    """pm [B, Qall, H, W] logits, gt [sumT, H, W] f32, toff int32 [B + 1] (device) -> (out [B, q, tmax, 2], qsum [B, q, 2])."""
+    B, qall, H, W = pm.shape
+    out = torch.zeros(B, q, tmax, 2, device=pm.device, dtype=torch.float32)
+    qsum = torch.empty(B, q, 2, device=pm.device, dtype=torch.float32)
+    _check(_lib.dfine_mask_cost(_ptr(pm), _ptr(gt), _ptr(toff), _ptr(out), _ptr(qsum), _dtype_code(pm), B, qall, q, H * W, tmax,
+                                float(alpha), float(gamma), _stream()), "dfine_mask_cost")
+    return out, qsum
+
+
+def conv1x1_batched_weights(x, w2, cout):
+    """x [B, Cin, H, W] bf16, w2 [B, NP, KP] packed per image -> y [B, cout, H, W] bf16."""
+    B, cin, H, W = x.shape
+    y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.bfloat16)
+    with _timed("conv1x1", 2.0 * B * H * W * cin * cout):
+        _check(_lib.dfine_conv1x1_bw_bf16(_ptr(x), _ptr(w2), _ptr(y), B, cin, cout, H * W, _stream()), "dfine_conv1x1_bw_bf16")
+    return y

@@ -382,6 +382,50 @@ int dfine_attn_bwd(const void *q, const void *k, const void *v, const void *o, c
                    int lddv, float scale, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * A10 / A15  Segmentation head (BASELINE configs[4]): the element-wise / reduction kernels of MaskDecoder
+ * (src/d_fine/arch/dfine_decoder.py:316-370), of the mask losses (src/d_fine/dfine_criterion.py:335-450,504-556) and of
+ * the matcher's mask costs (src/d_fine/matcher.py:19-71,175-237).  dtype: activations f32 or bf16; parameters, statistics
+ * and loss terms f32.  The dense contractions of the head run on the convolution entry points (dfine_conv_fwd_bf16,
+ * dfine_conv1x1_bw_bf16 for the per-image mask-logit einsum).
+ */
+/* y = [relu](GroupNorm_G(x) * gamma + beta), nn.GroupNorm(G, C) semantics (biased variance, eps inside the root).
+ * x, y [B, C, HW]; stat [B, G, 2] f32 out = (mean, rstd), kept for the backward; ws: dfine_groupnorm_ws_floats floats. */
+int64_t dfine_groupnorm_ws_floats(int B, int C, int G);
+int dfine_groupnorm_fwd(const void *x, void *y, const float *gamma, const float *beta, float *stat, float *ws,
+                        int dtype, int B, int C, int HW, int G, float eps, int relu, void *stream);
+/* dx [B, C, HW]; part [B, C, 2] f32 out = per-plane (sum dz, sum dz * xhat) with dz = dy [* relu'] - the caller sums
+ * them over B into d(beta) / d(gamma); ws: 2 * B * G floats. */
+int dfine_groupnorm_bwd(const void *x, const void *dy, void *dx, const float *gamma, const float *beta,
+                        const float *stat, float *part, float *ws, int dtype, int B, int C, int HW, int G, int relu,
+                        void *stream);
+/* y [planes, Ho, Wo] (+)= bilinear resize of x [planes, Hi, Wi], align_corners = False (F.interpolate(mode="bilinear"));
+ * accumulate = 1 adds onto y (MaskDecoder's upsample-sum of the lateral maps).  _bwd: the adjoint, as a gather. */
+int dfine_bilinear_fwd(const void *x, void *y, int dtype, int planes, int Hi, int Wi, int Ho, int Wo, int accumulate,
+                       void *stream);
+int dfine_bilinear_bwd(const void *dy, void *dx, int dtype, int planes, int Hi, int Wi, int Ho, int Wo, void *stream);
+/* Cropped BCE + Dice of M matched masks read in place from pm [B, Q, H, W] through (plan_b, plan_q) [M] i64;
+ * tgt [M, H, W] f32; boxes [M, 4] f32 (x1, y1, x2, y2 in mask pixels: pixel (x, y) counts iff x1 <= x < x2, y1 <= y < y2).
+ * sums [M, 4] f32 out = (BCE-with-logits, p * t, p, t) summed inside the box, p = sigmoid(logit). */
+int dfine_mask_loss_sums(const void *pm, const int64_t *plan_b, const int64_t *plan_q, const float *tgt,
+                         const float *boxes, float *sums, int dtype, int M, int Q, int H, int W, void *stream);
+/* grad [B, Q, H, W] dtype (zero-filled by the caller; the M matched planes are written): per pixel inside the box
+ * coef[m][0] * (p - t) + (coef[m][1] * t + coef[m][2]) * p * (1 - p), 0 outside.  coef [M, 3] f32 from the caller. */
+int dfine_mask_loss_grad(const void *pm, const int64_t *plan_b, const int64_t *plan_q, const float *tgt,
+                         const float *boxes, const float *coef, void *grad, int dtype, int M, int Q, int H, int W,
+                         void *stream);
+/* Pairwise mask-cost sums of the LAST Q of the Qall queries of every image against its targets: gt [sum T, HW] f32
+ * (concatenated over the batch), toff [B + 1] i32.  out [B, Q, Tmax, 2] f32 = (sum_p sigmoid(x) g, sum_p (pos - neg)(x) g)
+ * with the focal terms pos = alpha (1 - p)^gamma (-log(p + 1e-8)), neg = (1 - alpha) p^gamma (-log(1 - p + 1e-8));
+ * qsum [B, Q, 2] f32 = (sum_p sigmoid(x), sum_p neg(x)).  Entries t >= T_b of out are not written. */
+int dfine_mask_cost(const void *pm, const float *gt, const int *toff, float *out, float *qsum, int dtype, int B,
+                    int Qall, int Q, int HW, int Tmax, float alpha, float gamma, void *stream);
+/* y[b] = conv1x1(x[b], W_b), one weight set per image: w2 [B][NP][KP] bf16 in the dfine_conv_pack_weights(KS = 1) layout
+ * per image.  einsum("bqc,bchw->bqhw") of DFINETransformer._mask_logits_from_h (dfine_decoder.py:925-932) with
+ * Cout = queries, Cin = mask_dim, and its gradient w.r.t. the mask features (weights = embeddings transposed).
+ * (H*W) % 8 == 0, Cin % 4 == 0. */
+int dfine_conv1x1_bw_bf16(const void *x, const void *w2, void *y, int B, int Cin, int Cout, int HW, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * A18  Detection post-processor: sigmoid -> top-K over the Q*C (query, class) scores of every image ->
  * label = idx % C, query = idx // C -> normalised cxcywh -> absolute xyxy (floor / ceil + clamp when
  * to_round).  Replaces DFINEPostProcessor.forward (src/dl/export.py:61-100, box arithmetic :35-59) and
