@@ -154,11 +154,12 @@ __device__ __forceinline__ void bil_src(int d, float scale, int in_size, int *i0
 }
 
 template <typename T>
-__global__ __launch_bounds__(kMaskThreads) void bilinear_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, int Hi, int Wi, int Ho, int Wo,
-                                                                    float sy, float sx, int accumulate) {
+__global__ __launch_bounds__(kMaskThreads) void bilinear_fwd_kernel(const T *__restrict__ x, const T *base, T *y, int Hi, int Wi, int Ho, int Wo,
+                                                                    float sy, float sx) {
     const int plane = blockIdx.y;
     const T *p = x + (int64_t)plane * Hi * Wi;
     T *o = y + (int64_t)plane * Ho * Wo;
+    const T *ob = base ? base + (int64_t)plane * Ho * Wo : nullptr;
     for (int i = blockIdx.x * kMaskThreads + threadIdx.x; i < Ho * Wo; i += gridDim.x * kMaskThreads) {
         const int oy = i / Wo, ox = i - oy * Wo;
         int y0, y1, x0, x1; float fy, fx;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(kMaskThreads) void bilinear_fwd_kernel(const T *__r
         const float v00 = load_f(p + y0 * Wi + x0), v01 = load_f(p + y0 * Wi + x1);
         const float v10 = load_f(p + y1 * Wi + x0), v11 = load_f(p + y1 * Wi + x1);
         float v = (1.f - fy) * ((1.f - fx) * v00 + fx * v01) + fy * ((1.f - fx) * v10 + fx * v11);
-        if (accumulate) v += load_f(o + i);
+        if (ob) v += load_f(ob + i);
         store_f(o + i, v);
     }
 }
@@ -390,17 +391,17 @@ int dfine_groupnorm_bwd(const void *x, const void *dy, void *dx, const float *ga
     return check_launch();
 }
 
-// y [planes, Ho, Wo] (+)= bilinear(x [planes, Hi, Wi]), align_corners = False
-int dfine_bilinear_fwd(const void *x, void *y, int dtype, int planes, int Hi, int Wi, int Ho, int Wo, int accumulate, void *stream) {
+// y [planes, Ho, Wo] = [base +] bilinear(x [planes, Hi, Wi]), align_corners = False; base may be NULL or equal y
+int dfine_bilinear_fwd(const void *x, const void *base, void *y, int dtype, int planes, int Hi, int Wi, int Ho, int Wo, void *stream) {
     if (planes == 0) return DFINE_OK;
     if (!x || !y || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1) return DFINE_E_BADARG;
     const dim3 grid(plane_blocks(Ho * Wo, 2), planes);
     const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DFINE_F32)
-        hipLaunchKernelGGL(bilinear_fwd_kernel<float>, grid, dim3(kMaskThreads), 0, st, (const float *)x, (float *)y, Hi, Wi, Ho, Wo, sy, sx, accumulate);
+        hipLaunchKernelGGL(bilinear_fwd_kernel<float>, grid, dim3(kMaskThreads), 0, st, (const float *)x, (const float *)base, (float *)y, Hi, Wi, Ho, Wo, sy, sx);
     else if (dtype == DFINE_BF16)
-        hipLaunchKernelGGL(bilinear_fwd_kernel<uint16_t>, grid, dim3(kMaskThreads), 0, st, (const uint16_t *)x, (uint16_t *)y, Hi, Wi, Ho, Wo, sy, sx, accumulate);
+        hipLaunchKernelGGL(bilinear_fwd_kernel<uint16_t>, grid, dim3(kMaskThreads), 0, st, (const uint16_t *)x, (const uint16_t *)base, (uint16_t *)y, Hi, Wi, Ho, Wo, sy, sx);
     else return DFINE_E_BADARG;
     return check_launch();
 }

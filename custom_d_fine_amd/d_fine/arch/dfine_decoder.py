@@ -219,13 +219,15 @@ class MaskDecoder(nn.Module):
         init.kaiming_normal_(self.up_conv.weight, mode="fan_out", nonlinearity="relu")
 
     def forward(self, feats):
-        x = self.bn[0](self.lateral[0](feats[0]))
+        # every piece is a HIP operator on CUDA tensors (MFMA convolutions under bf16 autocast, GroupNorm [+ ReLU] and the
+        # bilinear upsample [+ sum] as one pass each: csrc/mask.hip) and the reference's ATen composition otherwise
+        x = kernels.group_norm_act(kernels.conv_plain(feats[0], self.lateral[0]), self.bn[0])
         size = x.shape[-2:]
         for lat, gn, f in zip(self.lateral[1:], self.bn[1:], feats[1:]):
-            x = x + F.interpolate(gn(lat(f)), size=size, mode="bilinear", align_corners=False)
-        x = self.act(self.fusion_norm(self.fusion_conv(x)))
-        x = F.interpolate(x, scale_factor=2.0, mode="bilinear", align_corners=False)
-        return self.act(self.bn1(self.up_conv(x)))
+            x = kernels.bilinear_resize(kernels.group_norm_act(kernels.conv_plain(f, lat), gn), size, base=x)
+        x = kernels.group_norm_act(kernels.conv_plain(x, self.fusion_conv), self.fusion_norm, relu=True)
+        x = kernels.bilinear_resize(x, (2 * x.shape[-2], 2 * x.shape[-1]))
+        return kernels.group_norm_act(kernels.conv_plain(x, self.up_conv), self.bn1, relu=True)
 
 
 class TransformerDecoder(nn.Module):
@@ -586,7 +588,7 @@ class DFINETransformer(nn.Module):
     def _mask_logits_from_h(self, h, mask_feat):
         emb = self.mask_head(h)
         emb = emb * (emb.shape[-1] ** -0.5)
-        return torch.einsum("bqc,bchw->bqhw", emb, mask_feat)
+        return kernels.mask_logits(emb, mask_feat)
 
     # ------------------------------------------------------------------ forward
     def forward(self, feats, targets=None):

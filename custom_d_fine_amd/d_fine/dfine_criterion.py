@@ -17,6 +17,7 @@ import torch.distributed
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import kernels
 from .arch.utils import upload, bbox2distance, box_cxcywh_to_xyxy, box_iou, generalized_box_iou, paired_iou_giou
 from .dist_utils import get_world_size, is_dist_available_and_initialized
 
@@ -265,8 +266,9 @@ class DFINECriterion(nn.Module):
             m = t.get("masks")
             if m is None or m.numel() == 0 or m.dim() != 3 or j.numel() == 0:
                 continue
-            sel = m[j.to(m.device)].unsqueeze(1).float().to(device)
-            sel = F.interpolate(sel, size=(out_h, out_w), mode="bilinear", align_corners=False)
+            sel = m[j.to(m.device)].float().to(device)
+            sel = kernels.bilinear_resize(sel.unsqueeze(1), (out_h, out_w)) if sel.is_cuda else \
+                F.interpolate(sel.unsqueeze(1), size=(out_h, out_w), mode="bilinear", align_corners=False)
             chunks.append(sel.squeeze(1).clamp_(0, 1))
         if not chunks:
             return torch.zeros(0, out_h, out_w, device=device, dtype=torch.float32), 0
@@ -336,12 +338,16 @@ class DFINECriterion(nn.Module):
         if p.count == 0:
             z = pm.sum() * 0
             return {"loss_mask_bce": z, "loss_mask_dice": z}
-        sel = pm[p.batch, p.src]
         tgt, valid = self._prepare_target_masks(targets, indices, hm, wm, device=pm.device)
         if valid == 0:
-            z = sel.sum() * 0
+            z = pm.sum() * 0
             return {"loss_mask_bce": z, "loss_mask_dice": z}
         boxes = self._prepare_target_boxes_for_masks(targets, indices, hm, wm, device=pm.device)
+        if pm.is_cuda and pm.dtype in (torch.float32, torch.bfloat16) and tgt.shape[0] == p.count:
+            # fused: the matched planes are read in place through the plan, both losses and their gradient in two passes
+            bce, dice = kernels.mask_losses(pm, p.batch, p.src, tgt, boxes)
+            return {"loss_mask_bce": bce, "loss_mask_dice": dice}
+        sel = pm[p.batch, p.src]
         if sel.shape[0] != tgt.shape[0]:
             raise AssertionError(f"Mismatch between number of selected predictions ({sel.shape[0]})"
                                  f"and target masks ({tgt.shape[0]})")

@@ -130,6 +130,9 @@ class HungarianMatcher(nn.Module):
         if pm.shape[1] != num_queries and pm.shape[1] > num_queries:
             pm = pm[:, pm.shape[1] - num_queries:]
         hm, wm = pm.shape[-2:]
+        if pm.is_cuda and pm.dtype in (torch.float32, torch.bfloat16) and all(
+                t.get("masks") is not None and len(t["masks"]) == len(t["boxes"]) for t in targets):
+            return self._mask_cost_hip(pm, targets, num_queries, tmax)
         extra = torch.zeros(pm.shape[0], num_queries, tmax, device=pm.device)
         for b, t in enumerate(targets):
             n = len(t["boxes"])
@@ -147,6 +150,39 @@ class HungarianMatcher(nn.Module):
                                                             alpha=self.alpha, gamma=self.gamma)
             extra[b, :, :n] = c
         return extra
+
+    def _mask_cost_hip(self, pm, targets, num_queries, tmax, eps=1e-6):
+        """The same costs from ONE pass over the mask logits per head (csrc/mask.hip: mask_cost_kernel accumulates, for every
+        (query, target) of an image, sum_p sigmoid(x) g and sum_p (pos - neg)(x) g plus the per-query sums) instead of four
+        [Q, HW] x [HW, T] matmuls on materialised sigmoid / focal maps per image."""
+        hm, wm = pm.shape[-2:]
+        sizes = [len(t["boxes"]) for t in targets]
+        key = (id(targets), hm, wm)
+        cache = getattr(self, "_gt_mask_cache", None)
+        if cache is None or cache[0] != key:           # the targets' masks at mask resolution: once per step, shared by all heads
+            chunks = []
+            for t in targets:
+                if len(t["boxes"]) == 0:
+                    continue
+                gt = t["masks"].float().to(pm.device)
+                if gt.shape[-2:] != (hm, wm):
+                    gt = kernels.bilinear_resize(gt.unsqueeze(1), (hm, wm)).squeeze(1)
+                chunks.append(gt)
+            gt_all = torch.cat(chunks) if chunks else torch.zeros(0, hm, wm, device=pm.device)
+            toff = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32), device=pm.device)
+            cache = self._gt_mask_cache = (key, gt_all.contiguous(), toff, gt_all.flatten(1).sum(1), targets)
+        _, gt_all, toff, gsum, _ = cache
+        out, qsum = kernels.mask_cost_sums(pm, gt_all, toff, num_queries, tmax, self.alpha, self.gamma)
+        tsum = torch.zeros(len(sizes), tmax, device=pm.device)
+        col = torch.arange(tmax, device=pm.device)[None, :]
+        valid = col < torch.as_tensor(sizes, device=pm.device)[:, None]
+        tsum[valid] = gsum
+        extra = torch.zeros(pm.shape[0], num_queries, tmax, device=pm.device)
+        if self.cost_mask_dice > 0:
+            extra = extra + self.cost_mask_dice * (1 - (2 * out[..., 0] + eps) / (qsum[:, :, None, 0] + tsum[:, None, :] + eps))
+        if self.cost_mask > 0:
+            extra = extra + self.cost_mask * (out[..., 1] + qsum[:, :, None, 1]) / float(hm * wm)
+        return extra * valid[:, None, :]
 
     # ------------------------------------------------------------------ batched entry point
     @torch.no_grad()

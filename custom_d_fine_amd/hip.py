@@ -79,7 +79,7 @@ _SIGNATURES = {
     "dfine_groupnorm_ws_floats": (_L, [_I, _I, _I]),
     "dfine_groupnorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "dfine_groupnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "dfine_bilinear_fwd": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_bilinear_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_bilinear_bwd": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_mask_loss_sums": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfine_mask_loss_grad": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -1092,13 +1092,13 @@ def groupnorm_backward(x, dy, gamma, beta, stat, groups, relu):
     return dx, s[:, 1].contiguous(), s[:, 0].contiguous()
 
 
-def bilinear_forward(x, out_hw, accumulate_into=None):
-    """x [..., Hi, Wi] contiguous -> [..., Ho, Wo] (align_corners=False); accumulate_into: a tensor of that shape to add onto."""
+def bilinear_forward(x, out_hw, base=None):
+    """x [..., Hi, Wi] contiguous -> [base +] resize to [..., Ho, Wo] (align_corners=False), a new tensor."""
     hi, wi = x.shape[-2:]
     planes = x.numel() // max(hi * wi, 1)
-    y = accumulate_into if accumulate_into is not None else torch.empty(*x.shape[:-2], out_hw[0], out_hw[1], device=x.device, dtype=x.dtype)
-    _check(_lib.dfine_bilinear_fwd(_ptr(x), _ptr(y), _dtype_code(x), planes, hi, wi, out_hw[0], out_hw[1],
-                                   int(accumulate_into is not None), _stream()), "dfine_bilinear_fwd")
+    y = torch.empty(*x.shape[:-2], out_hw[0], out_hw[1], device=x.device, dtype=x.dtype)
+    _check(_lib.dfine_bilinear_fwd(_ptr(x), _ptr(base), _ptr(y), _dtype_code(x), planes, hi, wi, out_hw[0], out_hw[1],
+                                   _stream()), "dfine_bilinear_fwd")
     return y
 
 

@@ -1475,3 +1475,219 @@ def preprocess_frames(frames: torch.Tensor, out_hw, resized_hw, top_left=(0, 0),
 def topk_indices(score: torch.Tensor, k: int) -> torch.Tensor:
     """Indices of the k largest entries per row, descending.  [ATen plumbing]"""
     return torch.topk(score, k, dim=-1).indices
+
+
+# =============================================================================================
+# A10 / A15  segmentation head: GroupNorm, bilinear resize, mask logits, mask losses, mask costs (csrc/mask.hip)
+# =============================================================================================
+def _mask_hip_ok(x):
+    return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and _env("DFINE_HIP_MASK", "1") == "1"
+
+
+class _GroupNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, relu):
+        x = x.contiguous()
+        g32, b32 = _f32_vec(gamma), _f32_vec(beta)
+        y, stat = _hip().groupnorm_forward(x, g32, b32, groups, eps, relu)
+        ctx.save_for_backward(x, g32, b32, stat)
+        ctx.cfg = (groups, relu, gamma.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g32, b32, stat = ctx.saved_tensors
+        groups, relu, pdt = ctx.cfg
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dx, dg, db = _hip().groupnorm_backward(x, dy, g32, b32, stat, groups, relu)
+        return dx, dg.to(pdt), db.to(pdt), None, None, None
+
+
+def group_norm_act(x, gn: nn.GroupNorm, relu: bool = False):
+    """[relu](gn(x)) - MaskDecoder's normalisation (ref dfine_decoder.py:316-370).  CUDA: one statistics pass + one apply pass
+    (csrc/mask.hip), in the dtype of x (under autocast ATen's group_norm would return fp32 maps: 2x the traffic of the
+    1/4-resolution maps for nothing the following bf16 convolution keeps)."""
+    if _mask_hip_ok(x) and x.dim() == 4 and gn.affine:
+        return _GroupNormAct.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, bool(relu))
+    y = gn(x)
+    return F.relu(y) if relu else y
+
+
+class _Bilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, base, out_hw):
+        x = x.contiguous()
+        if base is not None:
+            base = base.contiguous()
+            if base.dtype != x.dtype:
+                base = base.to(x.dtype)
+        ctx.in_hw = tuple(x.shape[-2:])
+        ctx.has_base = base is not None
+        return _hip().bilinear_forward(x, out_hw, base)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = _hip().bilinear_backward(dy, ctx.in_hw) if ctx.needs_input_grad[0] else None
+        return dx, (dy if ctx.has_base else None), None
+
+
+def bilinear_resize(x, size, base=None):
+    """[base +] F.interpolate(x, size=size, mode="bilinear", align_corners=False): forward and (gather) backward in one HIP
+    kernel each; `base` rides in the same pass (the upsample-sum of MaskDecoder's lateral maps)."""
+    size = (int(size[0]), int(size[1]))
+    if _mask_hip_ok(x) and x.dim() >= 3 and (base is None or base.shape[-2:] == size):
+        return _Bilinear.apply(x, base, size)
+    y = F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+    return y if base is None else base + y
+
+
+_SLAB_PERM = {}
+
+
+def _pack_rows_1x1(w, device):
+    """[B, N, K] float -> bf16 [B, NP, KP] in the k order the 1x1 MFMA kernels read (conv.hip: tr_slab_channel)."""
+    B, n, k = w.shape
+    NP, KP = (n + 15) // 16 * 16, (k + 31) // 32 * 32
+    perm = _SLAB_PERM.get((KP, device))
+    if perm is None:
+        idx = torch.arange(KP)
+        kk = idx % 32
+        g, e = kk // 8, kk % 8
+        ch = torch.where(e < 4, 4 * g + e, 16 + 4 * g + (e - 4))
+        perm = _SLAB_PERM[(KP, device)] = ((idx // 32) * 32 + ch).to(device)
+    out = torch.zeros(B, NP, KP, device=device, dtype=torch.bfloat16)
+    out[:, :n, :k] = w
+    return out[:, :, perm].contiguous()
+
+
+class _MaskLogits(torch.autograd.Function):
+    """einsum("bqc,bchw->bqhw") on the MFMA 1x1 kernel with one weight set per image (conv.hip: dfine_conv1x1_bw_bf16)."""
+
+    @staticmethod
+    def forward(ctx, emb, feat):
+        hip = _hip()
+        feat = feat.contiguous()
+        B, Q, C = emb.shape
+        y = hip.conv1x1_batched_weights(feat, _pack_rows_1x1(emb.detach(), emb.device), Q)
+        ctx.save_for_backward(emb, feat)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        hip = _hip()
+        emb, feat = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        B, Q, C = emb.shape
+        d_emb = d_feat = None
+        if ctx.needs_input_grad[1]:
+            d_feat = hip.conv1x1_batched_weights(dy, _pack_rows_1x1(emb.detach().transpose(1, 2), emb.device), C)
+        if ctx.needs_input_grad[0]:
+            d_emb = torch.stack([hip.conv_wgrad_bf16(feat[b:b + 1], dy[b:b + 1], 1).view(Q, C) for b in range(B)]).to(emb.dtype)
+        return d_emb, d_feat
+
+
+def mask_logits(emb, feat):
+    """emb [B, Q, C] (already scaled), feat [B, C, H, W] -> [B, Q, H, W] (ref dfine_decoder.py:925-932)."""
+    if (_mask_hip_ok(feat) and feat.dtype == torch.bfloat16 and emb.shape[1] % 4 == 0 and emb.shape[2] % 4 == 0
+            and (feat.shape[2] * feat.shape[3]) % 8 == 0 and _hip().conv_wgrad_supported(feat.shape[2], feat.shape[3], 1)):
+        return _MaskLogits.apply(emb, feat)
+    return torch.einsum("bqc,bchw->bqhw", emb.to(feat.dtype) if emb.dtype != feat.dtype else emb, feat)
+
+
+class _DenseConvWide(torch.autograd.Function):
+    """3x3 convolution of a map wider than the implicit-GEMM kernel's 160-pixel strips (the 240-wide 1/4-resolution maps of
+    the segmentation head at 960 x 960): two overlapping column halves through the same kernels, each half's own output
+    columns kept.  Forward / data gradient: halves with a 8-column apron; weight gradient: the sum of the halves' gradients with
+    the other half's output columns zeroed in dY."""
+
+    @staticmethod
+    def _halves(W):
+        half = W // 2
+        wl = (half + 8 + 7) // 8 * 8                   # left: columns [0, wl), right: columns [W - wl, W)
+        return half, wl
+
+    @staticmethod
+    def _run(hip, x, w2, cout):
+        B, _, H, W = x.shape
+        half, wl = _DenseConvWide._halves(W)
+        yl = hip.conv_forward_bf16(x[..., :wl].contiguous(), w2, cout, 3)
+        yr = hip.conv_forward_bf16(x[..., W - wl:].contiguous(), w2, cout, 3)
+        return torch.cat([yl[..., :half], yr[..., wl - (W - half):]], dim=-1)
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        hip = _hip()
+        x = x.contiguous()
+        ctx.save_for_backward(x, weight)
+        return _DenseConvWide._run(hip, x, _packed_weights(weight, False), weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        hip = _hip()
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous() if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16).contiguous()
+        W = x.shape[-1]
+        half, wl = _DenseConvWide._halves(W)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = _DenseConvWide._run(hip, dy, _packed_weights(weight, True), weight.shape[1])
+        if ctx.needs_input_grad[1]:
+            dyl = dy[..., :wl].clone()
+            dyl[..., half:] = 0
+            dyr = dy[..., W - wl:].clone()
+            dyr[..., :wl - (W - half)] = 0
+            dw = (hip.conv_wgrad_bf16(x[..., :wl].contiguous(), dyl, 3) + hip.conv_wgrad_bf16(x[..., W - wl:].contiguous(), dyr, 3)).to(weight.dtype)
+        return dx, dw
+
+
+def conv_plain(x, conv: nn.Conv2d):
+    """conv(x) for a bias-free 1x1 / 3x3 stride-1 convolution without normalisation behind it (MaskDecoder's lateral / fusion /
+    up convolutions): the MFMA kernels under bf16 autocast, ATen otherwise."""
+    if x.is_cuda and _env("DFINE_HIP_UNITS", "1") == "1":
+        if _mfma_conv_ok(conv, x):
+            return _DenseConv.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv.weight)
+        W = x.shape[-1]
+        if conv.kernel_size == (3, 3) and 160 < W <= 304 and W % 2 == 0:
+            probe = x[..., :_DenseConvWide._halves(W)[1]]          # the halves the wide form would run
+            if _mfma_conv_ok(conv, probe):
+                return _DenseConvWide.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv.weight)
+    return conv(x)
+
+
+class _MaskLosses(torch.autograd.Function):
+    """-> tensor[2] = (cropped BCE, cropped Dice) of the matched masks (ref dfine_criterion.py:335-450)."""
+
+    @staticmethod
+    def forward(ctx, pm, plan_b, plan_q, tgt, boxes, eps):
+        hip = _hip()
+        pm = pm.contiguous()
+        tgt, boxes = tgt.float().contiguous(), boxes.float().contiguous()
+        sums = hip.mask_loss_sums(pm, plan_b, plan_q, tgt, boxes)
+        area = ((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])).clamp(min=1.0)
+        num, den = 2.0 * sums[:, 1] + eps, sums[:, 2] + sums[:, 3] + eps
+        out = torch.stack([(sums[:, 0] / area).mean(), (1.0 - num / den).mean()])
+        ctx.save_for_backward(pm, plan_b, plan_q, tgt, boxes, area, num, den)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pm, plan_b, plan_q, tgt, boxes, area, num, den = ctx.saved_tensors
+        m = float(plan_b.numel())
+        coef = torch.stack([g[0] / (m * area), -2.0 * g[1] / (m * den), g[1] * num / (m * den * den)], dim=1).float().contiguous()
+        return _hip().mask_loss_grad(pm, plan_b, plan_q, tgt, boxes, coef), None, None, None, None, None
+
+
+def mask_losses(pm, plan_b, plan_q, tgt, boxes, eps=1e-6):
+    """pm [B, Q, H, W] mask logits, (plan_b, plan_q) [M] int64 matched (image, query), tgt [M, H, W] in [0, 1], boxes [M, 4]
+    in mask pixels -> (loss_mask_bce, loss_mask_dice); read in place (no gathered copy), gradient written in one pass."""
+    out = _MaskLosses.apply(pm, plan_b, plan_q, tgt, boxes, float(eps))
+    return out[0], out[1]
+
+
+def mask_cost_sums(pm, gt, toff, q, tmax, alpha, gamma):
+    return _hip().mask_cost_sums(pm.contiguous(), gt.float().contiguous(), toff, q, tmax, alpha, gamma)

@@ -398,9 +398,10 @@ int dfine_groupnorm_fwd(const void *x, void *y, const float *gamma, const float 
 int dfine_groupnorm_bwd(const void *x, const void *dy, void *dx, const float *gamma, const float *beta,
                         const float *stat, float *part, float *ws, int dtype, int B, int C, int HW, int G, int relu,
                         void *stream);
-/* y [planes, Ho, Wo] (+)= bilinear resize of x [planes, Hi, Wi], align_corners = False (F.interpolate(mode="bilinear"));
- * accumulate = 1 adds onto y (MaskDecoder's upsample-sum of the lateral maps).  _bwd: the adjoint, as a gather. */
-int dfine_bilinear_fwd(const void *x, void *y, int dtype, int planes, int Hi, int Wi, int Ho, int Wo, int accumulate,
+/* y [planes, Ho, Wo] = [base +] bilinear resize of x [planes, Hi, Wi], align_corners = False
+ * (F.interpolate(mode="bilinear")); base (NULL, or a map of the output shape, may alias y): MaskDecoder's upsample-sum of
+ * the lateral maps.  _bwd: the adjoint of the resize, as a gather. */
+int dfine_bilinear_fwd(const void *x, const void *base, void *y, int dtype, int planes, int Hi, int Wi, int Ho, int Wo,
                        void *stream);
 int dfine_bilinear_bwd(const void *dy, void *dx, int dtype, int planes, int Hi, int Wi, int Ho, int Wo, void *stream);
 /* Cropped BCE + Dice of M matched masks read in place from pm [B, Q, H, W] through (plan_b, plan_q) [M] i64;
