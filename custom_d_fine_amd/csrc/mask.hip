@@ -217,14 +217,15 @@ __device__ __forceinline__ bool box_has(const float4 b, int x, int y) {
 
 template <typename T>
 __global__ __launch_bounds__(kMaskThreads) void mask_loss_sums_kernel(const T *__restrict__ pm, const int64_t *__restrict__ plan_b,
-                                                                      const int64_t *__restrict__ plan_q, const float *__restrict__ tgt,
-                                                                      const float *__restrict__ boxes, float *__restrict__ sums, int Q, int H,
-                                                                      int W) {
+                                                                      const int64_t *__restrict__ plan_q, const int64_t *__restrict__ plan_t,
+                                                                      const float *__restrict__ tgt, const float *__restrict__ boxes,
+                                                                      float *__restrict__ sums, int Q, int H, int W) {
     __shared__ float red[8];
     const int m = blockIdx.x, HW = H * W;
     const T *p = pm + ((int64_t)plan_b[m] * Q + plan_q[m]) * HW;
-    const float *t = tgt + (int64_t)m * HW;
-    const float4 bx = *reinterpret_cast<const float4 *>(boxes + (int64_t)m * 4);
+    const int64_t row = plan_t ? plan_t[m] : m;           // row of tgt / boxes: the matched target, or m when they are gathered
+    const float *t = tgt + row * HW;
+    const float4 bx = *reinterpret_cast<const float4 *>(boxes + row * 4);
     // only the rows / columns the box can cover are visited
     const int y_lo = max((int)ceilf(bx.y), 0), y_hi = min((int)ceilf(bx.w), H);
     const int x_lo = max((int)ceilf(bx.x), 0), x_hi = min((int)ceilf(bx.z), W);
@@ -248,15 +249,16 @@ __global__ __launch_bounds__(kMaskThreads) void mask_loss_sums_kernel(const T *_
 // (g_bce / (M area_m), -g_dice 2 / (M den_m), g_dice (2 pt_m + eps) / (M den_m^2)) computed by the host wrapper from `sums`.
 template <typename T>
 __global__ __launch_bounds__(kMaskThreads) void mask_loss_grad_kernel(const T *__restrict__ pm, const int64_t *__restrict__ plan_b,
-                                                                      const int64_t *__restrict__ plan_q, const float *__restrict__ tgt,
-                                                                      const float *__restrict__ boxes, const float *__restrict__ coef,
-                                                                      T *__restrict__ grad, int Q, int H, int W) {
+                                                                      const int64_t *__restrict__ plan_q, const int64_t *__restrict__ plan_t,
+                                                                      const float *__restrict__ tgt, const float *__restrict__ boxes,
+                                                                      const float *__restrict__ coef, T *__restrict__ grad, int Q, int H, int W) {
     const int m = blockIdx.y, HW = H * W;
     const int64_t plane = ((int64_t)plan_b[m] * Q + plan_q[m]) * HW;
     const T *p = pm + plane;
     T *g_out = grad + plane;
-    const float *t = tgt + (int64_t)m * HW;
-    const float4 bx = *reinterpret_cast<const float4 *>(boxes + (int64_t)m * 4);
+    const int64_t row = plan_t ? plan_t[m] : m;
+    const float *t = tgt + row * HW;
+    const float4 bx = *reinterpret_cast<const float4 *>(boxes + row * 4);
     const float c_bce = coef[(int64_t)m * 3], c_pt = coef[(int64_t)m * 3 + 1], c_p = coef[(int64_t)m * 3 + 2];
     for (int i = blockIdx.x * kMaskThreads + threadIdx.x; i < HW; i += gridDim.x * kMaskThreads) {
         const int y = i / W, x = i - y * W;
@@ -277,6 +279,53 @@ __global__ __launch_bounds__(kMaskThreads) void mask_loss_grad_kernel(const T *_
 // block = 8 waves = 8 queries of one image; the targets' pixels go through LDS in chunks of kMcPix shared by the 8 queries.
 constexpr int kMcPix = 256, kMcT = 32;
 
+// one block of NG * 8 targets (compile-time count: the accumulators stay in registers, groups past the image's target
+// count cost nothing) against the wave's query over all pixels
+template <typename T, int NG>
+__device__ __forceinline__ void mask_cost_block(const T *__restrict__ p, const float *__restrict__ gt, float (*s_g)[kMcPix], int t_first,
+                                                int tn, int HW, float alpha, float gamma, bool first, float &s_sig, float &s_neg,
+                                                float *__restrict__ o2, bool live, int lane) {
+    float a_d[NG * 8], a_f[NG * 8];
+#pragma unroll
+    for (int t = 0; t < NG * 8; ++t) { a_d[t] = 0.f; a_f[t] = 0.f; }
+    for (int p0 = 0; p0 < HW; p0 += kMcPix) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < NG * 8 * kMcPix; i += 512) {
+            const int t = i / kMcPix, px = i - t * kMcPix;
+            s_g[t][px] = (t < tn && p0 + px < HW) ? gt[(int64_t)(t_first + t) * HW + p0 + px] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int k = 0; k < kMcPix / 64; ++k) {
+            const int px = k * 64 + lane;
+            if (p0 + px < HW) {
+                const float x = load_f(p + p0 + px);
+                // hardware exp / log (1 ulp-class relative error, averaged over the H * W terms of a cost sum): the accurate
+                // library forms made this kernel VALU-bound at 2.3 ms per head of config #5
+                const float pr = __builtin_amdgcn_rcpf(1.f + __expf(-x));
+                const float pg = gamma == 2.f ? pr * pr : __powf(pr, gamma);
+                const float qg = gamma == 2.f ? (1.f - pr) * (1.f - pr) : __powf(1.f - pr, gamma);
+                const float neg = (1.f - alpha) * pg * (-__logf(1.f - pr + 1e-8f));
+                const float pos = alpha * qg * (-__logf(pr + 1e-8f));
+                if (first) { s_sig += pr; s_neg += neg; }
+                const float pn = pos - neg;
+#pragma unroll
+                for (int t = 0; t < NG * 8; ++t) {
+                    const float g = s_g[t][px];
+                    a_d[t] += pr * g; a_f[t] += pn * g;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NG * 8; ++t) {
+        float d = a_d[t], f = a_f[t];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { d += __shfl_xor(d, o, 64); f += __shfl_xor(f, o, 64); }
+        if (lane == 0 && live && t < tn) { o2[t * 2] = d; o2[t * 2 + 1] = f; }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(512) void mask_cost_kernel(const T *__restrict__ pm, const float *__restrict__ gt, const int *__restrict__ toff,
                                                         float *__restrict__ out, float *__restrict__ qsum, int Qall, int Q, int HW, int Tmax,
@@ -289,47 +338,13 @@ __global__ __launch_bounds__(512) void mask_cost_kernel(const T *__restrict__ pm
     const T *p = pm + ((int64_t)b * Qall + (Qall - Q) + (live ? q : 0)) * HW;
     float s_sig = 0.f, s_neg = 0.f;
     for (int tb = 0; tb < max(nt, 1); tb += kMcT) {
-        const int tn = min(kMcT, nt - tb);
-        float a_d[kMcT], a_f[kMcT];
-#pragma unroll
-        for (int t = 0; t < kMcT; ++t) { a_d[t] = 0.f; a_f[t] = 0.f; }
-        for (int p0 = 0; p0 < HW; p0 += kMcPix) {
-            __syncthreads();
-            for (int i = threadIdx.x; i < kMcT * kMcPix; i += 512) {
-                const int t = i / kMcPix, px = i - t * kMcPix;
-                s_g[t][px] = (t < tn && p0 + px < HW) ? gt[(int64_t)(t0 + tb + t) * HW + p0 + px] : 0.f;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < kMcPix / 64; ++k) {
-                const int px = k * 64 + lane;
-                if (p0 + px < HW) {
-                    const float x = load_f(p + p0 + px);
-                    const float pr = 1.f / (1.f + expf(-x));           // accurate exp / log: these sums decide assignments
-                    const float pg = gamma == 2.f ? pr * pr : powf(pr, gamma);
-                    const float qg = gamma == 2.f ? (1.f - pr) * (1.f - pr) : powf(1.f - pr, gamma);
-                    const float neg = (1.f - alpha) * pg * (-logf(1.f - pr + 1e-8f));
-                    const float pos = alpha * qg * (-logf(pr + 1e-8f));
-                    if (tb == 0) { s_sig += pr; s_neg += neg; }
-                    const float pn = pos - neg;
-#pragma unroll
-                    for (int t = 0; t < kMcT; ++t) {
-                        const float g = s_g[t][px];
-                        a_d[t] += pr * g; a_f[t] += pn * g;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < kMcT; ++t) {
-            float d = a_d[t], f = a_f[t];
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) { d += __shfl_xor(d, o, 64); f += __shfl_xor(f, o, 64); }
-            if (lane == 0 && live && t < tn) {
-                float *o2 = out + (((int64_t)b * Q + q) * Tmax + tb + t) * 2;
-                o2[0] = d; o2[1] = f;
-            }
-        }
+        const int tn = max(min(kMcT, nt - tb), 0);
+        float *o2 = out + (((int64_t)b * Q + (live ? q : 0)) * Tmax + tb) * 2;
+        const int ng = (tn + 7) / 8;                                  // block-uniform
+        if (ng <= 1) mask_cost_block<T, 1>(p, gt, s_g, t0 + tb, tn, HW, alpha, gamma, tb == 0, s_sig, s_neg, o2, live, lane);
+        else if (ng == 2) mask_cost_block<T, 2>(p, gt, s_g, t0 + tb, tn, HW, alpha, gamma, tb == 0, s_sig, s_neg, o2, live, lane);
+        else if (ng == 3) mask_cost_block<T, 3>(p, gt, s_g, t0 + tb, tn, HW, alpha, gamma, tb == 0, s_sig, s_neg, o2, live, lane);
+        else mask_cost_block<T, 4>(p, gt, s_g, t0 + tb, tn, HW, alpha, gamma, tb == 0, s_sig, s_neg, o2, live, lane);
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { s_sig += __shfl_xor(s_sig, o, 64); s_neg += __shfl_xor(s_neg, o, 64); }
@@ -421,29 +436,29 @@ int dfine_bilinear_bwd(const void *dy, void *dx, int dtype, int planes, int Hi, 
     return check_launch();
 }
 
-int dfine_mask_loss_sums(const void *pm, const int64_t *plan_b, const int64_t *plan_q, const float *tgt, const float *boxes, float *sums,
-                         int dtype, int M, int Q, int H, int W, void *stream) {
+int dfine_mask_loss_sums(const void *pm, const int64_t *plan_b, const int64_t *plan_q, const int64_t *plan_t, const float *tgt,
+                         const float *boxes, float *sums, int dtype, int M, int Q, int H, int W, void *stream) {
     if (M == 0) return DFINE_OK;
     if (!pm || !plan_b || !plan_q || !tgt || !boxes || !sums || Q < 1 || H < 1 || W < 1) return DFINE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DFINE_F32)
-        hipLaunchKernelGGL(mask_loss_sums_kernel<float>, dim3(M), dim3(kMaskThreads), 0, st, (const float *)pm, plan_b, plan_q, tgt, boxes, sums, Q, H, W);
+        hipLaunchKernelGGL(mask_loss_sums_kernel<float>, dim3(M), dim3(kMaskThreads), 0, st, (const float *)pm, plan_b, plan_q, plan_t, tgt, boxes, sums, Q, H, W);
     else if (dtype == DFINE_BF16)
-        hipLaunchKernelGGL(mask_loss_sums_kernel<uint16_t>, dim3(M), dim3(kMaskThreads), 0, st, (const uint16_t *)pm, plan_b, plan_q, tgt, boxes, sums, Q, H, W);
+        hipLaunchKernelGGL(mask_loss_sums_kernel<uint16_t>, dim3(M), dim3(kMaskThreads), 0, st, (const uint16_t *)pm, plan_b, plan_q, plan_t, tgt, boxes, sums, Q, H, W);
     else return DFINE_E_BADARG;
     return check_launch();
 }
 
-int dfine_mask_loss_grad(const void *pm, const int64_t *plan_b, const int64_t *plan_q, const float *tgt, const float *boxes,
-                         const float *coef, void *grad, int dtype, int M, int Q, int H, int W, void *stream) {
+int dfine_mask_loss_grad(const void *pm, const int64_t *plan_b, const int64_t *plan_q, const int64_t *plan_t, const float *tgt,
+                         const float *boxes, const float *coef, void *grad, int dtype, int M, int Q, int H, int W, void *stream) {
     if (M == 0) return DFINE_OK;
     if (!pm || !plan_b || !plan_q || !tgt || !boxes || !coef || !grad || Q < 1 || H < 1 || W < 1) return DFINE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(plane_blocks(H * W, 4), M);
     if (dtype == DFINE_F32)
-        hipLaunchKernelGGL(mask_loss_grad_kernel<float>, grid, dim3(kMaskThreads), 0, st, (const float *)pm, plan_b, plan_q, tgt, boxes, coef, (float *)grad, Q, H, W);
+        hipLaunchKernelGGL(mask_loss_grad_kernel<float>, grid, dim3(kMaskThreads), 0, st, (const float *)pm, plan_b, plan_q, plan_t, tgt, boxes, coef, (float *)grad, Q, H, W);
     else if (dtype == DFINE_BF16)
-        hipLaunchKernelGGL(mask_loss_grad_kernel<uint16_t>, grid, dim3(kMaskThreads), 0, st, (const uint16_t *)pm, plan_b, plan_q, tgt, boxes, coef, (uint16_t *)grad, Q, H, W);
+        hipLaunchKernelGGL(mask_loss_grad_kernel<uint16_t>, grid, dim3(kMaskThreads), 0, st, (const uint16_t *)pm, plan_b, plan_q, plan_t, tgt, boxes, coef, (uint16_t *)grad, Q, H, W);
     else return DFINE_E_BADARG;
     return check_launch();
 }

@@ -338,15 +338,25 @@ class DFINECriterion(nn.Module):
         if p.count == 0:
             z = pm.sum() * 0
             return {"loss_mask_bce": z, "loss_mask_dice": z}
+        if (pm.is_cuda and pm.dtype in (torch.float32, torch.bfloat16) and hasattr(self.matcher, "gt_masks_at") and all(
+                t.get("masks") is not None and t["masks"].dim() == 3 and len(t["masks"]) == len(t["boxes"]) for t in targets)):
+            # fused: targets of the whole batch at mask resolution once per step (shared with the matcher); the matched
+            # prediction planes, target planes and boxes are read in place through the plan - no per-image host loop
+            gt_all, _, _ = self.matcher.gt_masks_at(targets, hm, wm, pm.device)
+            bkey = (id(targets), hm, wm)
+            if getattr(self, "_mask_box_cache", (None,))[0] != bkey:
+                b = self._targets_cat(targets)[1].float().to(pm.device)
+                cx, cy, w, h = b.unbind(1)
+                self._mask_box_cache = (bkey, torch.stack([
+                    ((cx - w / 2) * wm).clamp(0, wm - 1), ((cy - h / 2) * hm).clamp(0, hm - 1),
+                    ((cx + w / 2) * wm).clamp(1, wm), ((cy + h / 2) * hm).clamp(1, hm)], dim=1).contiguous(), targets)
+            bce, dice = kernels.mask_losses(pm, p.batch, p.src, gt_all, self._mask_box_cache[1], plan_t=p.tgt)
+            return {"loss_mask_bce": bce, "loss_mask_dice": dice}
         tgt, valid = self._prepare_target_masks(targets, indices, hm, wm, device=pm.device)
         if valid == 0:
             z = pm.sum() * 0
             return {"loss_mask_bce": z, "loss_mask_dice": z}
         boxes = self._prepare_target_boxes_for_masks(targets, indices, hm, wm, device=pm.device)
-        if pm.is_cuda and pm.dtype in (torch.float32, torch.bfloat16) and tgt.shape[0] == p.count:
-            # fused: the matched planes are read in place through the plan, both losses and their gradient in two passes
-            bce, dice = kernels.mask_losses(pm, p.batch, p.src, tgt, boxes)
-            return {"loss_mask_bce": bce, "loss_mask_dice": dice}
         sel = pm[p.batch, p.src]
         if sel.shape[0] != tgt.shape[0]:
             raise AssertionError(f"Mismatch between number of selected predictions ({sel.shape[0]})"
@@ -513,7 +523,7 @@ class DFINECriterion(nn.Module):
     # ------------------------------------------------------------------ fused GPU path
     def _fusable(self, outputs):
         """The HIP head-loss kernels cover the reference's default configuration."""
-        return (set(self.losses) <= {"vfl", "boxes", "local"} and self.boxes_weight_format is None
+        return (set(self.losses) <= {"vfl", "boxes", "local", "masks"} and self.boxes_weight_format is None
                 and self.reg_max == 32 and not outputs["enc_meta"]["class_agnostic"])
 
     def _fdr_constants(self, outputs):
@@ -541,6 +551,7 @@ class DFINECriterion(nn.Module):
         self._build_plans([indices, *cached, *cached_enc, indices_go] + ([indices_dn] if indices_dn is not None else []),
                           targets, dev)
         names, vecs = [], []
+        want_masks, extra = "masks" in self.losses, {}
 
         def run(head, suffix, cls_idx, box_idx, n_cls, n_box, local, is_dn=False, box_go_only=False):
             cls_plan = self._plan(cls_idx, targets, dev)
@@ -583,6 +594,11 @@ class DFINECriterion(nn.Module):
                     keys.append(("loss_ddf", 4))
             vecs.append(vec)
             names.append([(k + suffix, j) for k, j in keys])
+            if want_masks and head.get("pred_masks") is not None:
+                # the matched mask planes are read in place in the model's dtype (no fp32 copy of [B, Q, H/4, W/4] per head)
+                for k, v in self.loss_masks(head, targets, cls_idx, n_cls).items():
+                    if k in wd:
+                        extra[k + suffix] = torch.nan_to_num(v * wd[k], nan=0.0)
 
         run(outputs, "", indices, indices_go, num_boxes, num_boxes_go, True)
         for i, aux in enumerate(outputs["aux_outputs"]):
@@ -595,6 +611,11 @@ class DFINECriterion(nn.Module):
             dn_boxes = dn_boxes if dn_boxes > 0 else 1
             for i, aux in enumerate(outputs["dn_outputs"]):
                 run(aux, f"_dn_{i}", indices_dn, indices_dn, dn_boxes, dn_boxes, True, is_dn=True)
+            if want_masks and outputs.get("dn_pred_masks") is not None:
+                final = {"pred_masks": outputs["dn_pred_masks"], "pred_boxes": outputs["dn_outputs"][-1]["pred_boxes"]}
+                for k, v in self.loss_masks(final, targets, indices_dn, dn_boxes).items():
+                    if k in wd:
+                        extra[k + "_dn_final"] = torch.nan_to_num(v * wd[k], nan=0.0)
             if "dn_pre_outputs" in outputs:
                 run(outputs["dn_pre_outputs"], "_dn_pre", indices_dn, indices_dn, dn_boxes, dn_boxes, False,
                     is_dn=True)
@@ -605,6 +626,8 @@ class DFINECriterion(nn.Module):
         for h, keys in enumerate(names):
             for k, j in keys:
                 losses[k] = cells[h * 5 + j]
+        self.__dict__["_last_extra"] = list(extra.values())
+        losses.update(extra)
         return losses
 
     def total(self, loss_dict):
@@ -615,8 +638,9 @@ class DFINECriterion(nn.Module):
         # graph alive and free it (~1 ms of node destructors) in the middle of the next criterion call,
         # while the device idles
         self.__dict__["_last_table"] = None
+        extra = self.__dict__.pop("_last_extra", None) or []
         if t is not None and loss_dict and next(iter(loss_dict.values()))._base is t:
-            return t.sum()
+            return t.sum() + sum(extra) if extra else t.sum()
         return sum(loss_dict.values())
 
     def get_loss_meta_info(self, loss, outputs, targets, indices):

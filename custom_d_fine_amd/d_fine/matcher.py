@@ -151,27 +151,35 @@ class HungarianMatcher(nn.Module):
             extra[b, :, :n] = c
         return extra
 
+    def gt_masks_at(self, targets, hm, wm, device):
+        """The batch's target masks at mask resolution, concatenated [sum T, hm, wm] f32 (+ int32 offsets [B + 1] and the
+        per-mask pixel sums): prepared once per step and shared by the cost kernel of every head and by the criterion's mask
+        losses (the reference resizes them per image in every matcher call and every loss branch)."""
+        key = (id(targets), hm, wm, str(device))
+        cache = getattr(self, "_gt_mask_cache", None)
+        if cache is None or cache[0] != key:
+            sizes = [len(t["boxes"]) for t in targets]
+            chunks = []
+            for t in targets:
+                if len(t["boxes"]) == 0:
+                    continue
+                gt = t["masks"].float().to(device)
+                if gt.shape[-2:] != (hm, wm):
+                    gt = kernels.bilinear_resize(gt.unsqueeze(1), (hm, wm)).squeeze(1) if gt.is_cuda else \
+                        F.interpolate(gt.unsqueeze(1), size=(hm, wm), mode="bilinear", align_corners=False).squeeze(1)
+                chunks.append(gt)
+            gt_all = torch.cat(chunks) if chunks else torch.zeros(0, hm, wm, device=device)
+            toff = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32), device=device)
+            cache = self._gt_mask_cache = (key, gt_all.contiguous(), toff, gt_all.flatten(1).sum(1), targets)
+        return cache[1], cache[2], cache[3]
+
     def _mask_cost_hip(self, pm, targets, num_queries, tmax, eps=1e-6):
         """The same costs from ONE pass over the mask logits per head (csrc/mask.hip: mask_cost_kernel accumulates, for every
         (query, target) of an image, sum_p sigmoid(x) g and sum_p (pos - neg)(x) g plus the per-query sums) instead of four
         [Q, HW] x [HW, T] matmuls on materialised sigmoid / focal maps per image."""
         hm, wm = pm.shape[-2:]
         sizes = [len(t["boxes"]) for t in targets]
-        key = (id(targets), hm, wm)
-        cache = getattr(self, "_gt_mask_cache", None)
-        if cache is None or cache[0] != key:           # the targets' masks at mask resolution: once per step, shared by all heads
-            chunks = []
-            for t in targets:
-                if len(t["boxes"]) == 0:
-                    continue
-                gt = t["masks"].float().to(pm.device)
-                if gt.shape[-2:] != (hm, wm):
-                    gt = kernels.bilinear_resize(gt.unsqueeze(1), (hm, wm)).squeeze(1)
-                chunks.append(gt)
-            gt_all = torch.cat(chunks) if chunks else torch.zeros(0, hm, wm, device=pm.device)
-            toff = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32), device=pm.device)
-            cache = self._gt_mask_cache = (key, gt_all.contiguous(), toff, gt_all.flatten(1).sum(1), targets)
-        _, gt_all, toff, gsum, _ = cache
+        gt_all, toff, gsum = self.gt_masks_at(targets, hm, wm, pm.device)
         out, qsum = kernels.mask_cost_sums(pm, gt_all, toff, num_queries, tmax, self.alpha, self.gamma)
         tsum = torch.zeros(len(sizes), tmax, device=pm.device)
         col = torch.arange(tmax, device=pm.device)[None, :]

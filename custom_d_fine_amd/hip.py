@@ -81,8 +81,8 @@ _SIGNATURES = {
     "dfine_groupnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_bilinear_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_bilinear_bwd": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "dfine_mask_loss_sums": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "dfine_mask_loss_grad": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfine_mask_loss_sums": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfine_mask_loss_grad": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfine_mask_cost": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     "dfine_conv1x1_bw_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_preprocess_u8": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -1111,20 +1111,20 @@ def bilinear_backward(dy, in_hw):
     return dx
 
 
-def mask_loss_sums(pm, plan_b, plan_q, tgt, boxes):
+def mask_loss_sums(pm, plan_b, plan_q, plan_t, tgt, boxes):
     B, Q, H, W = pm.shape
     M = plan_b.numel()
     sums = torch.empty(M, 4, device=pm.device, dtype=torch.float32)
-    _check(_lib.dfine_mask_loss_sums(_ptr(pm), _ptr(plan_b), _ptr(plan_q), _ptr(tgt), _ptr(boxes), _ptr(sums), _dtype_code(pm),
-                                     M, Q, H, W, _stream()), "dfine_mask_loss_sums")
+    _check(_lib.dfine_mask_loss_sums(_ptr(pm), _ptr(plan_b), _ptr(plan_q), _ptr(plan_t), _ptr(tgt), _ptr(boxes), _ptr(sums),
+                                     _dtype_code(pm), M, Q, H, W, _stream()), "dfine_mask_loss_sums")
     return sums
 
 
-def mask_loss_grad(pm, plan_b, plan_q, tgt, boxes, coef):
+def mask_loss_grad(pm, plan_b, plan_q, plan_t, tgt, boxes, coef):
     B, Q, H, W = pm.shape
     grad = torch.zeros_like(pm)
-    _check(_lib.dfine_mask_loss_grad(_ptr(pm), _ptr(plan_b), _ptr(plan_q), _ptr(tgt), _ptr(boxes), _ptr(coef), _ptr(grad),
-                                     _dtype_code(pm), plan_b.numel(), Q, H, W, _stream()), "dfine_mask_loss_grad")
+    _check(_lib.dfine_mask_loss_grad(_ptr(pm), _ptr(plan_b), _ptr(plan_q), _ptr(plan_t), _ptr(tgt), _ptr(boxes), _ptr(coef),
+                                     _ptr(grad), _dtype_code(pm), plan_b.numel(), Q, H, W, _stream()), "dfine_mask_loss_grad")
     return grad
 
 

@@ -992,6 +992,10 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
             y = _DepthwiseConv.apply(x, conv.weight, conv.stride[0], conv.padding[0])
         elif not pad_br and _mfma_conv_ok(conv, x):
             y = _DenseConv.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv.weight)
+        elif (not pad_br and conv.kernel_size == (3, 3) and 160 < x.shape[-1] <= 304 and x.shape[-1] % 2 == 0
+              and _mfma_conv_ok(conv, x[..., :_DenseConvWide._halves(x.shape[-1])[1]])):
+            # maps wider than the kernel's 160-pixel strips (the 240-wide stage of D-FINE-l / x at 960 x 960): two column halves
+            y = _DenseConvWide.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv.weight)
         elif _stem_conv_ok(conv, x, pad_br):
             y = _StemConv.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv.weight,
                                 conv.stride[0], conv.padding[0], pad_br)
@@ -1663,29 +1667,31 @@ class _MaskLosses(torch.autograd.Function):
     """-> tensor[2] = (cropped BCE, cropped Dice) of the matched masks (ref dfine_criterion.py:335-450)."""
 
     @staticmethod
-    def forward(ctx, pm, plan_b, plan_q, tgt, boxes, eps):
+    def forward(ctx, pm, plan_b, plan_q, plan_t, tgt, boxes, eps):
         hip = _hip()
         pm = pm.contiguous()
         tgt, boxes = tgt.float().contiguous(), boxes.float().contiguous()
-        sums = hip.mask_loss_sums(pm, plan_b, plan_q, tgt, boxes)
-        area = ((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])).clamp(min=1.0)
+        sums = hip.mask_loss_sums(pm, plan_b, plan_q, plan_t, tgt, boxes)
+        bx = boxes if plan_t is None else boxes[plan_t]
+        area = ((bx[:, 2] - bx[:, 0]) * (bx[:, 3] - bx[:, 1])).clamp(min=1.0)
         num, den = 2.0 * sums[:, 1] + eps, sums[:, 2] + sums[:, 3] + eps
         out = torch.stack([(sums[:, 0] / area).mean(), (1.0 - num / den).mean()])
-        ctx.save_for_backward(pm, plan_b, plan_q, tgt, boxes, area, num, den)
+        ctx.save_for_backward(pm, plan_b, plan_q, plan_t, tgt, boxes, area, num, den)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        pm, plan_b, plan_q, tgt, boxes, area, num, den = ctx.saved_tensors
+        pm, plan_b, plan_q, plan_t, tgt, boxes, area, num, den = ctx.saved_tensors
         m = float(plan_b.numel())
         coef = torch.stack([g[0] / (m * area), -2.0 * g[1] / (m * den), g[1] * num / (m * den * den)], dim=1).float().contiguous()
-        return _hip().mask_loss_grad(pm, plan_b, plan_q, tgt, boxes, coef), None, None, None, None, None
+        return _hip().mask_loss_grad(pm, plan_b, plan_q, plan_t, tgt, boxes, coef), None, None, None, None, None, None
 
 
-def mask_losses(pm, plan_b, plan_q, tgt, boxes, eps=1e-6):
-    """pm [B, Q, H, W] mask logits, (plan_b, plan_q) [M] int64 matched (image, query), tgt [M, H, W] in [0, 1], boxes [M, 4]
-    in mask pixels -> (loss_mask_bce, loss_mask_dice); read in place (no gathered copy), gradient written in one pass."""
-    out = _MaskLosses.apply(pm, plan_b, plan_q, tgt, boxes, float(eps))
+def mask_losses(pm, plan_b, plan_q, tgt, boxes, eps=1e-6, plan_t=None):
+    """pm [B, Q, H, W] mask logits, (plan_b, plan_q) [M] int64 matched (image, query); tgt [rows, H, W] in [0, 1] and boxes
+    [rows, 4] in mask pixels, row of match m = plan_t[m] (targets of the whole batch, prepared once per step) or m
+    -> (loss_mask_bce, loss_mask_dice); read in place (no gathered copies), gradient written in one pass."""
+    out = _MaskLosses.apply(pm, plan_b, plan_q, plan_t, tgt, boxes, float(eps))
     return out[0], out[1]
 
 

@@ -405,15 +405,17 @@ int dfine_bilinear_fwd(const void *x, const void *base, void *y, int dtype, int 
                        void *stream);
 int dfine_bilinear_bwd(const void *dy, void *dx, int dtype, int planes, int Hi, int Wi, int Ho, int Wo, void *stream);
 /* Cropped BCE + Dice of M matched masks read in place from pm [B, Q, H, W] through (plan_b, plan_q) [M] i64;
- * tgt [M, H, W] f32; boxes [M, 4] f32 (x1, y1, x2, y2 in mask pixels: pixel (x, y) counts iff x1 <= x < x2, y1 <= y < y2).
+ * tgt [rows, H, W] f32 and boxes [rows, 4] f32 (x1, y1, x2, y2 in mask pixels: pixel (x, y) counts iff x1 <= x < x2,
+ * y1 <= y < y2), row of match m = plan_t[m] (the batch-concatenated target index) or m when plan_t is NULL.
  * sums [M, 4] f32 out = (BCE-with-logits, p * t, p, t) summed inside the box, p = sigmoid(logit). */
-int dfine_mask_loss_sums(const void *pm, const int64_t *plan_b, const int64_t *plan_q, const float *tgt,
-                         const float *boxes, float *sums, int dtype, int M, int Q, int H, int W, void *stream);
+int dfine_mask_loss_sums(const void *pm, const int64_t *plan_b, const int64_t *plan_q, const int64_t *plan_t,
+                         const float *tgt, const float *boxes, float *sums, int dtype, int M, int Q, int H, int W,
+                         void *stream);
 /* grad [B, Q, H, W] dtype (zero-filled by the caller; the M matched planes are written): per pixel inside the box
  * coef[m][0] * (p - t) + (coef[m][1] * t + coef[m][2]) * p * (1 - p), 0 outside.  coef [M, 3] f32 from the caller. */
-int dfine_mask_loss_grad(const void *pm, const int64_t *plan_b, const int64_t *plan_q, const float *tgt,
-                         const float *boxes, const float *coef, void *grad, int dtype, int M, int Q, int H, int W,
-                         void *stream);
+int dfine_mask_loss_grad(const void *pm, const int64_t *plan_b, const int64_t *plan_q, const int64_t *plan_t,
+                         const float *tgt, const float *boxes, const float *coef, void *grad, int dtype, int M, int Q,
+                         int H, int W, void *stream);
 /* Pairwise mask-cost sums of the LAST Q of the Qall queries of every image against its targets: gt [sum T, HW] f32
  * (concatenated over the batch), toff [B + 1] i32.  out [B, Q, Tmax, 2] f32 = (sum_p sigmoid(x) g, sum_p (pos - neg)(x) g)
  * with the focal terms pos = alpha (1 - p)^gamma (-log(p + 1e-8)), neg = (1 - alpha) p^gamma (-log(1 - p + 1e-8));

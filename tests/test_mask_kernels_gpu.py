@@ -122,6 +122,13 @@ def test_mask_losses_match_torch_composition(cuda, dtype):
     boxes[0] = torch.tensor([3.0, 5.0, 3.4, 5.2])                 # covers no pixel centre: area clamps to 1, sums are 0
     bce, dice = kernels.mask_losses(pm, pb, pq, tgt, boxes)
     (1.7 * bce + 0.6 * dice).backward()
+    # the same through a target-row indirection (targets of the whole batch prepared once, rows picked by the plan)
+    perm = torch.randperm(M, device=cuda)
+    inv = torch.argsort(perm)
+    pm2 = pm.detach().clone().requires_grad_(True)
+    bce2, dice2 = kernels.mask_losses(pm2, pb, pq, tgt[perm], boxes[perm], plan_t=inv)
+    (1.7 * bce2 + 0.6 * dice2).backward()
+    assert torch.equal(bce2, bce) and torch.equal(dice2, dice) and torch.equal(pm2.grad, pm.grad)
     pr = pm.detach().float().requires_grad_(True)
     sel = pr[pb, pq]
     rb, rd = DFINECriterion._cropped_bce_loss(sel, tgt, boxes), DFINECriterion._cropped_dice_loss(sel, tgt, boxes)

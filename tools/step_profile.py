@@ -5,7 +5,7 @@ import torch
 import bench
 from custom_d_fine_amd.dl.synthetic import make_batch
 
-FAMILIES = (("conv1x1", "conv1x1 fwd/dgrad"), ("conv_wgrad1_glds", "conv wgrad 1x1"), ("conv_wgrad_kernel<1>", "conv wgrad 1x1"),
+FAMILIES = (("gn_", "mask: groupnorm"), ("bilinear_", "mask: bilinear"), ("mask_", "mask: losses / costs"), ("conv1x1", "conv1x1 fwd/dgrad"), ("conv_wgrad1_glds", "conv wgrad 1x1"), ("conv_wgrad_kernel<1>", "conv wgrad 1x1"),
             ("conv_wgrad_kernel<3>", "conv wgrad 3x3"), ("conv_wgrad_reduce", "wgrad reduce"), ("conv_igemm", "conv3x3 fwd/dgrad"),
             ("dfine::bn_", "bn"), ("msda", "msda"), ("cast_f32_bf16", "msda"), ("linear_act", "linear_act"), ("act_", "linear_act"),
             ("linear_wgrad", "linear_wgrad"), ("attn_", "attention"), ("stem_", "stem"), ("dwconv", "dwconv"), ("ln_fused", "ln"),
@@ -13,8 +13,9 @@ FAMILIES = (("conv1x1", "conv1x1 fwd/dgrad"), ("conv_wgrad1_glds", "conv wgrad 1
             ("FillFunctor", "ATen fill"), ("copy", "ATen copy/cast"), ("Memcpy", "ATen copy/cast"), ("CUDAFunctor_add", "ATen add"),
             ("at::native", "ATen other"))
 dev = torch.device("cuda", 0)
-step = bench.build_step("m", 640, dev, torch.bfloat16)
-images, targets = make_batch(32, 640, seed=42, device=dev)
+MODEL, IMG, BATCH, MASK = os.environ.get("SP_MODEL", "m"), int(os.environ.get("SP_IMG", "640")), int(os.environ.get("SP_BATCH", "32")), os.environ.get("SP_MASK", "0") == "1"
+step = bench.build_step(MODEL, IMG, dev, torch.bfloat16, mask=MASK)
+images, targets = make_batch(BATCH, IMG, seed=42, device=dev, with_masks=MASK)
 for _ in range(4):
     step(images, targets)
 torch.cuda.synchronize()
@@ -28,7 +29,7 @@ for k in prof.key_averages():
     agg[fam] += k.device_time_total / 3e3
     cnt[fam] += k.count // 3
 tot = sum(agg.values())
-print(f"device time per step {tot:.2f} ms, {sum(cnt.values())} launches  (env: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("DFINE_")) + ")")
+print(f"D-FINE-{MODEL}{'+mask' if MASK else ''} {IMG}x{IMG} bs {BATCH}: device time per step {tot:.2f} ms, {sum(cnt.values())} launches  (env: " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("DFINE_")) + ")")
 for f, v in sorted(agg.items(), key=lambda kv: -kv[1]):
     print(f"  {f:22s} {v:7.2f} ms  {cnt[f]:5d} launches")
 if os.environ.get("STEP_PROFILE_TOP"):
