@@ -90,6 +90,16 @@ def pmc_traffic(kernel, batch, lq, dtype):
     return best
 
 
+def conv_pmc_traffic():
+    """Measured HBM bytes per launch of the family's reference kernel (conv1x1_glds_kernel on the 512 -> 512 @ 80x80 layer,
+    profiles/*_conv_pmc.json: FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes) next to its compulsory bytes, or None."""
+    best = None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+        if name.endswith("_conv_pmc.json"):
+            best = json.load(open(os.path.join(ROOT, "profiles", name)))
+    return best
+
+
 def cpu_baseline(model_name, img, steps):
     """The same train step on the host through the oracle backend (kind 'port')."""
     from oracle import torch_backend
@@ -226,13 +236,18 @@ def main():
         lq = 300 + dn
         sampled = len(sampled_steps)
 
-        def mfma_entry(keys, label):
+        def mfma_entry(keys, label, traffic=None):
             n = sum(timing[k][0] for k in keys if k in timing)
             ms = sum(timing[k][2] for k in keys if k in timing)
             fl = sum(timing[k][3] for k in keys if k in timing)
+            bound_ms = sum(timing[k][4] for k in keys if k in timing)
             tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             return {"kernel": label, "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
-                    "frac": round(tf / MFMA_BF16_PEAK_TFS, 4), "traffic": None,
+                    "frac": round(tf / MFMA_BF16_PEAK_TFS, 4), "traffic": traffic,
+                    # per-launch roofline: sum over the launches of max(FLOPs / 2.5 PFLOP/s, compulsory bytes / 8 TB/s) over
+                    # the measured time - most layers of this network are HBM-bound (a 128 -> 128 1x1 layer has 64 FLOP / B)
+                    "bound_ms_per_step": round(bound_ms / max(sampled, 1), 3),
+                    "bound_frac": round(bound_ms / ms, 4) if ms > 0 else 0.0,
                     "launches_per_step": round(n / max(sampled, 1), 1), "ms_per_step": round(ms / max(sampled, 1), 3),
                     "algorithmic_tflop_per_step": round(fl / max(sampled, 1) / 1e12, 3)}
 
@@ -247,7 +262,8 @@ def main():
                     "avg_launch_ms": round(mean_ms, 4), "ms_per_step": round(tot_ms / max(sampled, 1), 3)}
 
         family = mfma_entry(MFMA_GROUPS, "dense-conv implicit GEMMs of backbone + encoder: conv1x1_glds / conv_igemm<3> (fwd + dgrad), "
-                            "conv_wgrad1_glds / conv_wgrad<3> + the deferred split reduction, stem_*")
+                            "conv_wgrad1_glds / conv_wgrad<3> + the deferred split reduction, stem_*",
+                            traffic=conv_pmc_traffic())
         kernels_ = [mfma_entry(("conv1x1",), "conv1x1_glds_kernel fwd+dgrad"), mfma_entry(("conv3x3",), "conv_igemm_kernel<3> fwd+dgrad"),
                     mfma_entry(("conv1x1_wgrad",), "conv_wgrad1_glds_kernel"), mfma_entry(("conv3x3_wgrad",), "conv_wgrad_kernel<3>"),
                     mfma_entry(("wgrad_reduce",), "multi_wgrad_reduce_kernel (split partial sums of all conv / linear weight gradients)"),

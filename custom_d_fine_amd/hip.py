@@ -117,7 +117,8 @@ EXPORTED = tuple(_SIGNATURES)
 # ---- optional per-kernel timing (bench.py roofline leg): HIP events recorded on the launch
 # stream (torch's current stream) right around the launch of the named entry points, together with the
 # algorithmic work (FLOPs or bytes) of the launch.
-_TIMED = {}          # name -> list of (start_event, end_event, work)
+_TIMED = {}          # name -> list of (start_event, end_event, work, bound_seconds)
+MFMA_PEAK_FLOPS, HBM_PEAK_BYTES = 2.5e15, 8.0e12       # MI355X_MICROARCH.md: dense bf16 MFMA, HBM3E
 _TIMING_ON = False   # bench.py switches this per step (`timing_active`) to sample a subset of the timed steps
 
 
@@ -141,28 +142,31 @@ def disable_timing():
 
 
 def timing_summary():
-    """name -> (launches, mean_ms, total_ms, total_work) after a device synchronize."""
+    """name -> (launches, mean_ms, total_ms, total_work, bound_ms) after a device synchronize; bound_ms = sum over the launches
+    of max(FLOPs / MFMA peak, compulsory bytes / HBM peak) - the time a launch cannot go below on this chip."""
     torch.cuda.synchronize()
     out = {}
     for n, ev in _TIMED.items():
         if n == "*":
             continue
-        tot = sum(a.elapsed_time(b) for a, b, _ in ev)
-        out[n] = (len(ev), tot / max(len(ev), 1), tot, sum(w for _, _, w in ev))
+        tot = sum(e[0].elapsed_time(e[1]) for e in ev)
+        out[n] = (len(ev), tot / max(len(ev), 1), tot, sum(e[2] for e in ev), sum(e[3] for e in ev) * 1e3)
     return out
 
 
 class _timed:
     """`with _timed(key, work):` - no-op unless bench.py enabled timing for `key` and the current step is sampled."""
-    __slots__ = ("ev", "a", "work")
+    __slots__ = ("ev", "a", "work", "bound")
 
-    def __init__(self, name, work=0.0):
+    def __init__(self, name, work=0.0, io=0.0):
+        """work: algorithmic FLOPs (bytes for the HBM-bound keys); io: compulsory HBM bytes of an MFMA-keyed launch."""
         self.ev = None
         if _TIMING_ON:
             want = _TIMED.get("*")
             if want is None or name in want:
                 self.ev = _TIMED.setdefault(name, [])
                 self.work = work
+                self.bound = max(work / MFMA_PEAK_FLOPS, io / HBM_PEAK_BYTES) if io else 0.0
 
     def __enter__(self):
         if self.ev is not None:
@@ -173,7 +177,7 @@ class _timed:
         if self.ev is not None:
             b = torch.cuda.Event(enable_timing=True)
             b.record()
-            self.ev.append((self.a, b, self.work))
+            self.ev.append((self.a, b, self.work, self.bound))
 
 
 timed = _timed
@@ -613,7 +617,7 @@ def conv_forward_bf16(x, w2, cout, ks):
     """x [B, Cin, H, W] bf16 contiguous, w2 packed by conv_pack_weights -> y [B, cout, H, W] bf16."""
     B, cin, H, W = x.shape
     y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.bfloat16)
-    with _timed(f"conv{ks}x{ks}", 2.0 * B * H * W * cin * cout * ks * ks):
+    with _timed(f"conv{ks}x{ks}", 2.0 * B * H * W * cin * cout * ks * ks, io=2.0 * B * H * W * (cin + cout) + 2.0 * cin * cout * ks * ks):
         _check(_lib.dfine_conv_fwd_bf16(_ptr(x), _ptr(w2), _ptr(y), B, cin, cout, H, W, ks, _stream()),
                "dfine_conv_fwd_bf16")
     return y
@@ -647,7 +651,7 @@ def tokens_to_maps(tokens, shapes):
 def conv1x1_accumulate(x, w2, y):
     """y += conv1x1(x) (bf16, packed weights); False when the shape needs the separate-add fallback."""
     B, cin, H, W = x.shape
-    with _timed("conv1x1", 2.0 * B * H * W * cin * y.shape[1]):
+    with _timed("conv1x1", 2.0 * B * H * W * cin * y.shape[1], io=2.0 * B * H * W * (cin + y.shape[1]) + 2.0 * cin * y.shape[1]):
         status = _lib.dfine_conv1x1_accum_bf16(_ptr(x), _ptr(w2), _ptr(y), B, cin, y.shape[1], H * W, _stream())
     if status == -1:
         return False
@@ -680,7 +684,7 @@ def conv1x1_seg_forward(x_parts, w2, y_parts):
     cin, cout = sum(t.shape[1] for t in x_parts), sum(t.shape[1] for t in y_parts)
     xp, xc, xb = _seg_arrays(x_parts)
     yp, yc, yb = _seg_arrays(y_parts)
-    with _timed("conv1x1", 2.0 * B * H * W * cin * cout):
+    with _timed("conv1x1", 2.0 * B * H * W * cin * cout, io=2.0 * B * H * W * (cin + cout) + 2.0 * cin * cout):
         _check(_lib.dfine_conv1x1_seg_fwd_bf16(xp, xc, xb, len(x_parts), _ptr(w2), yp, yc, yb, len(y_parts), B, cin, cout, H, W,
                                                _stream()), "dfine_conv1x1_seg_fwd_bf16")
 
@@ -691,7 +695,7 @@ def conv1x1_seg_wgrad(x_parts, dy, partials=False):
     dw = None if partials else torch.empty(cout, cin, 1, 1, device=dy.device, dtype=torch.float32)
     ws = torch.empty(int(_lib.dfine_conv_wgrad_ws_floats(B, cin, cout, H, W, 1)), device=dy.device, dtype=torch.float32)
     xp, xc, xb = _seg_arrays(x_parts)
-    with _timed("conv1x1_wgrad", 2.0 * B * H * W * cin * cout):
+    with _timed("conv1x1_wgrad", 2.0 * B * H * W * cin * cout, io=2.0 * B * H * W * (cin + cout) + 4.0 * cin * cout):
         _check(_lib.dfine_conv1x1_seg_wgrad_bf16(xp, xc, xb, len(x_parts), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W,
                                                  _stream()), "dfine_conv1x1_seg_wgrad_bf16")
     if partials:
@@ -721,7 +725,7 @@ def conv_wgrad_bf16(x, dy, ks, partials=False):
     cout = dy.shape[1]
     dw = None if partials else torch.empty(cout, cin, ks, ks, device=x.device, dtype=torch.float32)
     ws = torch.empty(int(_lib.dfine_conv_wgrad_ws_floats(B, cin, cout, H, W, ks)), device=x.device, dtype=torch.float32)
-    with _timed(f"conv{ks}x{ks}_wgrad", 2.0 * B * H * W * cin * cout * ks * ks):
+    with _timed(f"conv{ks}x{ks}_wgrad", 2.0 * B * H * W * cin * cout * ks * ks, io=2.0 * B * H * W * (cin + cout) + 4.0 * cin * cout * ks * ks):
         _check(_lib.dfine_conv_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ks, _stream()),
                "dfine_conv_wgrad_bf16")
     if partials:
@@ -834,7 +838,7 @@ def linear_act(x2d, w, bias=None, act=0, out_f32=False, out=None):
         out = torch.empty(M, N, device=x2d.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.is_contiguous()
-    with _timed("linear", 2.0 * M * N * K):
+    with _timed("linear", 2.0 * M * N * K, io=2.0 * (M * K + N * K + M * N)):
         _check(_lib.dfine_linear_act_fwd(_ptr(x2d), _ptr(w), _ptr(bias), _ptr(out), M, N, K, ldx, ldw,
                                          out.stride(0) if M > 1 else N, int(act), int(out.dtype == torch.float32), _stream()),
                "dfine_linear_act_fwd")
@@ -868,7 +872,7 @@ def attn_forward(q, k, v, num_heads, mask=None):
     hd = E // num_heads
     o = torch.empty(B, L, E, device=q.device, dtype=torch.bfloat16)
     lse2 = torch.empty(B, num_heads, L, device=q.device, dtype=torch.float32)
-    with _timed("attention", 4.0 * B * num_heads * L * L * hd):
+    with _timed("attention", 4.0 * B * num_heads * L * L * hd, io=2.0 * 4 * B * num_heads * L * hd):
         _check(_lib.dfine_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse2), _ptr(mask), B, L, num_heads, hd, _ld(q),
                                    _ld(k), _ld(v), E, float(hd) ** -0.5, _stream()), "dfine_attn_fwd")
     return o, lse2
@@ -879,7 +883,7 @@ def attn_backward(q, k, v, o, dout, lse2, num_heads, dq, dk, dv, mask=None):
     B, L, E = q.shape
     hd = E // num_heads
     delta = torch.empty_like(lse2)
-    with _timed("attention", 10.0 * B * num_heads * L * L * hd):
+    with _timed("attention", 10.0 * B * num_heads * L * L * hd, io=2.0 * 8 * B * num_heads * L * hd):
         _check(_lib.dfine_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(dout), _ptr(lse2), _ptr(mask), _ptr(dq), _ptr(dk),
                                    _ptr(dv), _ptr(delta), B, L, num_heads, hd, _ld(q), _ld(k), _ld(v), _ld(o), _ld(dout),
                                    _ld(dq), _ld(dk), _ld(dv), float(hd) ** -0.5, _stream()), "dfine_attn_bwd")
@@ -894,7 +898,7 @@ def linear_wgrad_partials(x2d, dy2d):
     M, K = x2d.shape
     N = dy2d.shape[1]
     ws = torch.empty(int(_lib.dfine_linear_wgrad_ws_floats(M, N, K)), device=x2d.device, dtype=torch.float32)
-    with _timed("linear_wgrad", 2.0 * M * N * K):
+    with _timed("linear_wgrad", 2.0 * M * N * K, io=2.0 * M * (N + K) + 4.0 * N * K):
         _check(_lib.dfine_linear_wgrad_bf16(_ptr(x2d), _ptr(dy2d), None, None, _ptr(ws), M, N, K, _stream()),
                "dfine_linear_wgrad_bf16")
     splits = int(_lib.dfine_linear_wgrad_splits(M, N, K))
@@ -919,7 +923,7 @@ def linear_wgrad_bf16(x2d, dy2d, with_bias=False, dw=None, db=None):
     if with_bias and db is None:
         db = torch.empty(N, device=dev, dtype=torch.float32)
     assert dw.is_contiguous() and dw.dtype == torch.float32 and (db is None or db.is_contiguous())
-    with _timed("linear_wgrad", 2.0 * M * N * K):
+    with _timed("linear_wgrad", 2.0 * M * N * K, io=2.0 * M * (N + K) + 4.0 * N * K):
         _check(_lib.dfine_linear_wgrad_bf16(_ptr(x2d), _ptr(dy2d), _ptr(dw), _ptr(db), _ptr(ws), M, N, K, _stream()),
                "dfine_linear_wgrad_bf16")
     return (dw, db) if with_bias else dw
@@ -944,7 +948,7 @@ def stem_conv(x, wp, cout, ks, stride, pad, out_hw):
     B, cin, H, W = x.shape
     ho, wo = out_hw
     y = torch.empty(B, cout, ho, wo, device=x.device, dtype=torch.bfloat16)
-    with _timed("stem_conv", 2.0 * B * ho * wo * cin * cout * ks * ks):
+    with _timed("stem_conv", 2.0 * B * ho * wo * cin * cout * ks * ks, io=2.0 * B * (H * W * cin + ho * wo * cout)):
         _check(_lib.dfine_stem_conv_bf16(_ptr(x), _ptr(wp), _ptr(y), B, cin, cout, H, W, ho, wo, ks, stride, pad,
                                          _stream()), "dfine_stem_conv_bf16")
     return y
@@ -953,7 +957,7 @@ def stem_conv(x, wp, cout, ks, stride, pad, out_hw):
 def stem_dgrad_s2(dy, wq, cin):
     B, cout, ho, wo = dy.shape
     dx = torch.empty(B, cin, 2 * ho, 2 * wo, device=dy.device, dtype=torch.bfloat16)
-    with _timed("stem_conv", 2.0 * B * ho * wo * cin * cout * 9):
+    with _timed("stem_conv", 2.0 * B * ho * wo * cin * cout * 9, io=2.0 * B * ho * wo * (cout + 4 * cin)):
         _check(_lib.dfine_stem_dgrad_s2_bf16(_ptr(dy), _ptr(wq), _ptr(dx), B, cin, cout, ho, wo, _stream()),
                "dfine_stem_dgrad_s2_bf16")
     return dx
@@ -971,7 +975,7 @@ def stem_wgrad(x, dy, ks, stride, pad):
     if ws is None or ws.numel() < need:
         ws = _STEM_WS[key] = torch.empty(need, device=x.device, dtype=torch.float32)
     dw = torch.empty(cout, cin, ks, ks, device=x.device, dtype=torch.float32)
-    with _timed("stem_wgrad", 2.0 * B * ho * wo * cin * cout * ks * ks):
+    with _timed("stem_wgrad", 2.0 * B * ho * wo * cin * cout * ks * ks, io=2.0 * B * (H * W * cin + ho * wo * cout)):
         _check(_lib.dfine_stem_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ho, wo, ks, stride,
                                           pad, _stream()), "dfine_stem_wgrad_bf16")
     return dw
@@ -983,7 +987,7 @@ def stem_conv2(xa, xb, wp, cout, ks, stride, pad, out_hw):
     cin = ca + xb.shape[1]
     ho, wo = out_hw
     y = torch.empty(B, cout, ho, wo, device=xa.device, dtype=torch.bfloat16)
-    with _timed("stem_conv", 2.0 * B * ho * wo * cin * cout * ks * ks):
+    with _timed("stem_conv", 2.0 * B * ho * wo * cin * cout * ks * ks, io=2.0 * B * (H * W * cin + ho * wo * cout)):
         _check(_lib.dfine_stem_conv2_bf16(_ptr(xa), _ptr(xb), ca, _ptr(wp), _ptr(y), B, cin, cout, H, W, ho, wo, ks, stride,
                                           pad, _stream()), "dfine_stem_conv2_bf16")
     return y
@@ -993,7 +997,7 @@ def stem_dgrad_s2_2(dy, wq, ca, cb):
     B, cout, ho, wo = dy.shape
     dxa = torch.empty(B, ca, 2 * ho, 2 * wo, device=dy.device, dtype=torch.bfloat16)
     dxb = torch.empty(B, cb, 2 * ho, 2 * wo, device=dy.device, dtype=torch.bfloat16)
-    with _timed("stem_conv", 2.0 * B * ho * wo * (ca + cb) * cout * 9):
+    with _timed("stem_conv", 2.0 * B * ho * wo * (ca + cb) * cout * 9, io=2.0 * B * ho * wo * (cout + 4 * (ca + cb))):
         _check(_lib.dfine_stem_dgrad_s2_2_bf16(_ptr(dy), _ptr(wq), _ptr(dxa), _ptr(dxb), ca, B, ca + cb, cout, ho, wo,
                                                _stream()), "dfine_stem_dgrad_s2_2_bf16")
     return dxa, dxb
@@ -1009,7 +1013,7 @@ def stem_wgrad2(xa, xb, dy, ks, stride, pad):
     if ws is None or ws.numel() < need:
         ws = _STEM_WS[key] = torch.empty(need, device=xa.device, dtype=torch.float32)
     dw = torch.empty(cout, cin, ks, ks, device=xa.device, dtype=torch.float32)
-    with _timed("stem_wgrad", 2.0 * B * ho * wo * cin * cout * ks * ks):
+    with _timed("stem_wgrad", 2.0 * B * ho * wo * cin * cout * ks * ks, io=2.0 * B * (H * W * cin + ho * wo * cout)):
         _check(_lib.dfine_stem_wgrad2_bf16(_ptr(xa), _ptr(xb), ca, _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ho, wo, ks,
                                            stride, pad, _stream()), "dfine_stem_wgrad2_bf16")
     return dw
@@ -1142,6 +1146,6 @@ def conv1x1_batched_weights(x, w2, cout):
     """x [B, Cin, H, W] bf16, w2 [B, NP, KP] packed per image -> y [B, cout, H, W] bf16."""
     B, cin, H, W = x.shape
     y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.bfloat16)
-    with _timed("conv1x1", 2.0 * B * H * W * cin * cout):
+    with _timed("conv1x1", 2.0 * B * H * W * cin * cout, io=2.0 * B * H * W * (cin + cout) + 2.0 * cin * cout):
         _check(_lib.dfine_conv1x1_bw_bf16(_ptr(x), _ptr(w2), _ptr(y), B, cin, cout, H * W, _stream()), "dfine_conv1x1_bw_bf16")
     return y

@@ -61,7 +61,10 @@ class Torch_model:
     def __init__(self, model_name: str, model_path: str, n_outputs: int, input_width: int = 640, input_height: int = 640,
                  conf_thresh: float = 0.5, rect: bool = False, half: bool = False, keep_ratio: bool = False,
                  use_nms: bool = False, enable_mask_head: bool = False, binarize_masks: bool = True,
-                 mask_threshold: float = 0.5, device: str = None):
+                 mask_threshold: float = 0.5, device: str = None, hip_graph: bool = False):
+        """hip_graph: capture the network forward of every (batch, input size) it meets into a HIP graph and replay it -
+        one launch instead of ~1 000 host-issued kernel launches per call (the eager forward is host-bound: ~11 ms per call
+        from batch 1 to 16, profiles/r03_infer_table.txt).  The weights must not change afterwards (inference)."""
         self.input_size = (input_height, input_width)
         self.n_outputs, self.model_name, self.model_path = n_outputs, model_name, model_path
         self.rect, self.half, self.keep_ratio, self.use_nms = rect, half, keep_ratio, use_nms
@@ -70,6 +73,8 @@ class Torch_model:
         self.conf_threshs = [conf_thresh] * n_outputs if isinstance(conf_thresh, float) else list(conf_thresh)
         self.device = device or ("cuda" if torch.cuda.is_available() else "cpu")
         self._thr = None
+        self.hip_graph = bool(hip_graph) and str(self.device).startswith("cuda")
+        self._graphs = {}
         self._load_model()
         self._test_pred()
 
@@ -197,11 +202,51 @@ class Torch_model:
         return results
 
     @torch.no_grad()
-    def _predict(self, inputs):
+    def _forward(self, inputs):
         if self.half and inputs.is_cuda:
-            with torch.autocast("cuda", dtype=torch.bfloat16):
+            with torch.autocast("cuda", dtype=torch.bfloat16, cache_enabled=False):
                 return self.model(inputs)
         return self.model(inputs)
+
+    @torch.no_grad()
+    def _predict(self, inputs):
+        if not (self.hip_graph and inputs.is_cuda):
+            return self._forward(inputs)
+        key = tuple(inputs.shape)
+        ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._graphs[key] = self._capture(inputs)
+        if ent is False:                                   # capture failed for this shape: eager from now on
+            return self._forward(inputs)
+        static_in, graph, static_out = ent
+        static_in.copy_(inputs)
+        graph.replay()
+        return static_out
+
+    def _capture(self, inputs):
+        """Warm-up on a side stream (fills the anchor / packed-weight / constant caches), then one capture of the forward."""
+        from .. import kernels as K
+        static_in = inputs.clone()
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._forward(static_in)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            K._CAPTURE_POSSIBLE, K._CAPTURE_FROZEN_WEIGHTS = True, True
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._forward(static_in)
+            return static_in, graph, out
+        except Exception as e:                              # keep serving: eager path
+            import warnings
+            warnings.warn(f"Torch_model: HIP-graph capture failed for input {tuple(inputs.shape)} ({type(e).__name__}: {e}); running eagerly")
+            torch.cuda.synchronize()
+            return False
+        finally:
+            K._CAPTURE_FROZEN_WEIGHTS = False
 
     def _postprocess(self, preds, processed_sizes, original_sizes):
         output = self._preds_postprocess(preds, processed_sizes, original_sizes)

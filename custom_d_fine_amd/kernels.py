@@ -387,6 +387,8 @@ def bump_weight_epoch():
 
 
 _CAPTURE_POSSIBLE = False      # set by dl.engine.GraphedSegment: only then is the capture query worth a call per layer
+_CAPTURE_FROZEN_WEIGHTS = False   # set by infer.Torch_model while it captures: the weights never change again, so the cached
+                                  # packed / bf16 copies (filled by its eager warm-up) are served inside the capture
 
 
 # Every (weight, layout) pair the model has asked for is remembered; the first request after an optimizer step
@@ -428,7 +430,7 @@ def _pack_all_registered(device):
 
 
 def _packed_weights(weight, dgrad):
-    if _CAPTURE_POSSIBLE and torch.cuda.is_current_stream_capturing():
+    if _CAPTURE_POSSIBLE and not _CAPTURE_FROZEN_WEIGHTS and torch.cuda.is_current_stream_capturing():
         # inside a HIP-graph capture the pack launch itself must be recorded (the weights change
         # between replays), so never serve or fill the cache here
         return _hip().conv_pack_weights(weight.detach().float().contiguous(), dgrad)
@@ -493,7 +495,7 @@ def bf16_param(p):
     if p.dtype == torch.bfloat16:
         return p.detach()
     if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()) or (
-            _CAPTURE_POSSIBLE and torch.cuda.is_current_stream_capturing()):
+            _CAPTURE_POSSIBLE and not _CAPTURE_FROZEN_WEIGHTS and torch.cuda.is_current_stream_capturing()):
         return p.detach().to(torch.bfloat16)
     ent = _BF16_REGISTRY.get(id(p))
     if ent is not None and ent[0]() is p:
@@ -548,7 +550,7 @@ def bf16_param_t(p):
     """bf16 TRANSPOSE [K, N] of a 2-d fp32 CUDA parameter [N, K], cached until the weights change."""
     global _BF16T_TABLE
     if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.dim() == 2) or (
-            _CAPTURE_POSSIBLE and torch.cuda.is_current_stream_capturing()):
+            _CAPTURE_POSSIBLE and not _CAPTURE_FROZEN_WEIGHTS and torch.cuda.is_current_stream_capturing()):
         return p.detach().t().to(torch.bfloat16).contiguous()
     ent = _BF16T_REGISTRY.get(id(p))
     if ent is not None and ent[0]() is p:

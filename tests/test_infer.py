@@ -125,3 +125,27 @@ def test_torch_model_gpu_matches_cpu_oracle(cuda):
         ka = torch.cat([a["scores"][:, None].cpu(), a["labels"][:, None].float().cpu()], 1)[None]
         kb = torch.cat([b["scores"][:, None], b["labels"][:, None].float()], 1)[None]
         assert_same_query_set(ka, a["boxes"][None].cpu() / 360, kb, b["boxes"][None] / 360, tol=2e-3, min_frac=0.97)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("half", [False, True])
+def test_torch_model_hip_graph_replays_the_eager_forward(cuda, half):
+    """Torch_model(hip_graph=True): the network forward of every input shape is captured once and replayed - the results must
+    be the eager ones, call after call, for new frames, and for a second batch size (its own graph)."""
+    from custom_d_fine_amd.infer.torch_model import Torch_model
+    from tests import helpers
+    rng = np.random.default_rng(9)
+    torch.manual_seed(0)
+    e = Torch_model("n", None, 80, input_width=320, input_height=320, conf_thresh=0.0, device="cuda", half=half)
+    sd = helpers.seeded_state_dict(e.model.state_dict())
+    e.model.load_state_dict(sd)
+    g = Torch_model("n", None, 80, input_width=320, input_height=320, conf_thresh=0.0, device="cuda", half=half, hip_graph=True)
+    g.model.load_state_dict(sd)
+    g._graphs.clear()                                   # graphs of the constructor's test call were captured with other weights
+    for shape in ((2, 240, 360, 3), (2, 240, 360, 3), (240, 360, 3), (2, 240, 360, 3)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        want, got = e(img), g(img)
+        assert len(want) == len(got)
+        for a, b in zip(want, got):
+            assert torch.equal(a["labels"], b["labels"]) and torch.equal(a["boxes"], b["boxes"]) and torch.equal(a["scores"], b["scores"])
+    assert len(g._graphs) == 2 and all(v is not False for v in g._graphs.values())

@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="m")
 ap.add_argument("--images", type=int, default=256, help="images per (configuration, batch size) - the reference uses 512")
 ap.add_argument("--out", default=None)
+ap.add_argument("--graph", type=int, default=0, help="1: also measure Torch_model(hip_graph=True)")
 args = ap.parse_args()
 assert torch.cuda.is_available()
 rng = np.random.default_rng(0)
@@ -32,12 +33,13 @@ def emit(s):
 
 emit(f"Torch_model D-FINE-{args.model} 640x640, random-init weights, 80 classes, 1280x720 uint8 source frames, {args.images} images per cell, "
      f"one MI355X; reference column: README.md:159-171 (RTX 5070 Ti, Torch fp32)")
-emit(f"{'precision':10s} {'deploy':7s} {'bs':>3s} {'ms/batch':>9s} {'ms/img':>8s} {'img/s':>9s} {'ref img/s':>9s}  model-only ms/batch")
-for half in (False, True):
-    for deploy in (False, True):
-        tm = Torch_model(args.model, None, 80, 640, 640, half=half)
+emit(f"{'precision':10s} {'deploy':7s} {'graph':6s} {'bs':>3s} {'ms/batch':>9s} {'ms/img':>8s} {'img/s':>9s} {'ref img/s':>9s}  model-only ms/batch")
+for half, deploy, graph in [(h, d, g) for g in ((False, True) if args.graph else (False,)) for h in (False, True) for d in (False, True)]:
+    if True:
+        tm = Torch_model(args.model, None, 80, 640, 640, half=half, hip_graph=False)
         if deploy:
             tm.model.deploy()
+        tm.hip_graph = graph
         for bs in (1, 2, 4, 8, 16, 32):
             batch = frames[:bs] if bs > 1 else frames[0]
             for _ in range(10):
@@ -51,16 +53,15 @@ for half in (False, True):
             dt = (time.perf_counter() - t0) / n
             # network alone on a device-resident, pre-processed batch
             x, _, _ = tm._prepare_inputs(batch)
-            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=half):
-                for _ in range(3):
-                    tm.model(x)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(max(n // 2, 4)):
-                    tm.model(x)
-                torch.cuda.synchronize()
-                dm = (time.perf_counter() - t1) / max(n // 2, 4)
-            emit(f"{'bf16' if half else 'fp32':10s} {str(deploy):7s} {bs:3d} {dt * 1e3:9.2f} {dt * 1e3 / bs:8.3f} {bs / dt:9.1f} {REF[bs]:9.1f}  {dm * 1e3:8.2f}")
+            for _ in range(3):
+                tm._predict(x)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(max(n // 2, 4)):
+                tm._predict(x)
+            torch.cuda.synchronize()
+            dm = (time.perf_counter() - t1) / max(n // 2, 4)
+            emit(f"{'bf16' if half else 'fp32':10s} {str(deploy):7s} {str(graph):6s} {bs:3d} {dt * 1e3:9.2f} {dt * 1e3 / bs:8.3f} {bs / dt:9.1f} {REF[bs]:9.1f}  {dm * 1e3:8.2f}")
         del tm
         torch.cuda.empty_cache()
 if args.out:
