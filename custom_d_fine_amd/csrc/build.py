@@ -22,6 +22,7 @@ SOURCES = {
     "conv.hip": ["-munsafe-fp-atomics"],
     "stem.hip": ["-munsafe-fp-atomics"],
     "postproc.hip": ["-ffp-contract=off"],       # box arithmetic bit-identical to the reference's fp32 ops
+    "data.hip": ["-ffp-contract=off"],           # the same for the augmentation box transform
 }
 
 

@@ -28,6 +28,8 @@ DEFAULTS = {
         "betas": [0.9, 0.999], "weight_decay": 1.25e-4, "cycler_pct_start": 0.1, "use_scheduler": True,
         "label_smoothing": 0.0, "seed": 42, "ddp": {"enabled": False}, "path_to_save": "output/models/exp",
         "pretrained_model_path": None, "resume_path": None,
+        "data_path": None,           # a folder with images/ + labels/ (YOLO txt): dl/data_device.YoloTxtDataset; None = synthetic batches
+        "multiscale_prob": 0.0,      # the reference's train_collate_fn resize (dataset.py:667-694), on the device
     },
 }
 
@@ -90,6 +92,10 @@ class Trainer:
             fused.broadcast_from_rank0()
         elif self.distributed:
             self.model = wrap_data_parallel(self.model, self.device)
+        if t.get("data_path"):           # one epoch = one pass over this rank's shard of the folder
+            from . import data_device
+            self._dataset = data_device.YoloTxtDataset(t["data_path"], t["img_size"])
+            t["steps_per_epoch"] = max(len(self._dataset) // (t["batch_size"] * self.world), 1)
         sched = None
         if t["use_scheduler"]:
             sched = torch.optim.lr_scheduler.OneCycleLR(
@@ -176,20 +182,40 @@ class Trainer:
         names = {i: str(i) for i in range(t["num_classes"])}
         return Validator(all_gt, all_preds, names, conf_thresh=conf_thresh, iou_thresh=iou_thresh).compute_metrics()
 
-    def train(self):
+    def _batches(self, epoch):
+        """(images, targets) of one epoch: a YOLO-txt folder sharded over the ranks like the reference's DistributedSampler
+        (dataset.py:562-568: a per-epoch permutation, every world-th index from `rank`), or synthetic batches."""
+        import random
         t = self.cfg["train"]
         size = t["img_size"][0]
+        rng = random.Random(t["seed"] + 7919 * epoch)
+        if t.get("data_path"):
+            from . import data_device
+            if getattr(self, "_dataset", None) is None:
+                self._dataset = data_device.YoloTxtDataset(t["data_path"], t["img_size"])
+            order = list(range(len(self._dataset)))
+            rng.shuffle(order)
+            mine = order[self.rank::self.world]
+            for i in range(0, len(mine) - t["batch_size"] + 1, t["batch_size"]):
+                images, targets = self._dataset.batch(mine[i: i + t["batch_size"]], self.device)
+                if t.get("multiscale_prob", 0) and rng.random() < t["multiscale_prob"] and self.device.type == "cuda":
+                    images, targets = data_device.multiscale_collate(images, targets, rng.choice([-2, -1, 1, 2]) * 32)
+                yield images, targets
+            return
+        for it in range(t["steps_per_epoch"]):
+            yield make_batch(t["batch_size"], size, t["num_classes"], seed=t["seed"] + self.rank + 1000 * it, device=self.device,
+                             with_masks=self.cfg["task"] == "segment")
+
+    def train(self):
+        t = self.cfg["train"]
         for epoch in range(self.start_epoch, t["epochs"] + 1):
             t0, losses = time.time(), []
-            for it in range(t["steps_per_epoch"]):
-                images, targets = make_batch(t["batch_size"], size, t["num_classes"],
-                                             seed=t["seed"] + self.rank + 1000 * it, device=self.device,
-                                             with_masks=self.cfg["task"] == "segment")
+            for images, targets in self._batches(epoch):
                 loss, _ = self.step(images, targets)
                 losses.append(loss)
             mean = torch.stack(losses).mean().item()
             if self.rank == 0:
-                n = t["steps_per_epoch"] * t["batch_size"] * self.world
+                n = len(losses) * t["batch_size"] * self.world
                 print(f"epoch {epoch}: loss {mean:.4f}, {n / (time.time() - t0):.1f} img/s", flush=True)
                 self.save_model()
                 self.save_resume_state(epoch)

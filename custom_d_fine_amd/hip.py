@@ -85,6 +85,9 @@ _SIGNATURES = {
     "dfine_mask_loss_grad": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfine_mask_cost": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     "dfine_conv1x1_bw_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfine_mosaic_place_u8": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_warp_affine_u8": (c_int, [_P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    "dfine_affine_boxes": (c_int, [_P, _P, _P, _I, _P, _F, _F, _F, _F, _P]),
     "dfine_preprocess_u8": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_postprocess": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_linear_wgrad_ws_floats": (_L, [_I, _I, _I]),
@@ -1149,3 +1152,35 @@ def conv1x1_batched_weights(x, w2, cout):
     with _timed("conv1x1", 2.0 * B * H * W * cin * cout, io=2.0 * B * H * W * (cin + cout) + 2.0 * cin * cout):
         _check(_lib.dfine_conv1x1_bw_bf16(_ptr(x), _ptr(w2), _ptr(y), B, cin, cout, H * W, _stream()), "dfine_conv1x1_bw_bf16")
     return y
+
+
+# ------------------------------------------------------------------------------------- device data path (f3)
+def mosaic_place(src, canvas, resized_hw, region, crop_xy):
+    """src uint8 [Hs, Ws, 3], canvas uint8 [Hc, Wc, 3] (written in place): region (lx1, ly1, lx2, ly2) <- resize(src, resized_hw)
+    cropped from crop_xy = (sx1, sy1)."""
+    hs, ws = src.shape[:2]
+    hc, wc = canvas.shape[:2]
+    _check(_lib.dfine_mosaic_place_u8(_ptr(src), _ptr(canvas), hs, ws, int(resized_hw[0]), int(resized_hw[1]), hc, wc, int(region[0]),
+                                      int(region[1]), int(region[2]), int(region[3]), int(crop_xy[0]), int(crop_xy[1]), _stream()),
+           "dfine_mosaic_place_u8")
+
+
+def warp_affine(src, m2x3, out_hw, border=114):
+    """cv2.warpAffine(src uint8 [H, W, 3], M[:2], dsize=(out_w, out_h), borderValue=border) on the device."""
+    hs, ws = src.shape[:2]
+    dst = torch.empty(out_hw[0], out_hw[1], 3, device=src.device, dtype=torch.uint8)
+    m = (ctypes.c_double * 6)(*[float(v) for v in m2x3.reshape(-1)])
+    _check(_lib.dfine_warp_affine_u8(_ptr(src), _ptr(dst), hs, ws, out_hw[0], out_hw[1], m, int(border), _stream()), "dfine_warp_affine_u8")
+    return dst
+
+
+def affine_boxes(boxes, m2x3, scale, target_wh, area_thr):
+    """boxes f32 [N, 4] xyxy (device) -> (transformed + clipped boxes [N, 4], keep u8 [N])."""
+    boxes = boxes.float().contiguous()
+    n = boxes.shape[0]
+    out = torch.empty_like(boxes)
+    keep = torch.empty(n, device=boxes.device, dtype=torch.uint8)
+    m = (ctypes.c_float * 6)(*[float(v) for v in m2x3.reshape(-1)])
+    _check(_lib.dfine_affine_boxes(_ptr(boxes), _ptr(out), _ptr(keep), n, m, float(scale), float(target_wh[0]), float(target_wh[1]),
+                                   float(area_thr), _stream()), "dfine_affine_boxes")
+    return out, keep

@@ -444,6 +444,24 @@ int dfine_postprocess(const void *logits, const float *boxes, int64_t *labels, i
                       int width, int to_round, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * (f3) Device-side data path, geometric augmentation of training samples (reference: host OpenCV / numpy in
+ * CustomDataset._load_mosaic src/dl/dataset.py:258-377, random_affine / get_mosaic_coordinate src/dl/utils.py:325-414).
+ * Images are uint8 HWC on the device.
+ */
+/* canvas [Hc, Wc, 3] region [ly1, ly2) x [lx1, lx2) <- cv2.resize(src [Hs, Ws, 3], (rw, rh), INTER_LINEAR) cropped from
+ * (sx1, sy1): one mosaic quadrant (dataset.py:275-290). */
+int dfine_mosaic_place_u8(const uint8_t *src, uint8_t *canvas, int Hs, int Ws, int rh, int rw, int Hc, int Wc, int lx1,
+                          int ly1, int lx2, int ly2, int sx1, int sy1, void *stream);
+/* dst [Hd, Wd, 3] = cv2.warpAffine(src [Hs, Ws, 3], m (forward 2 x 3, HOST doubles), dsize, INTER_LINEAR, constant border)
+ * (utils.py:339-341); OpenCV's fixed-point arithmetic restated, parity unpinned (cv2 absent from the build image). */
+int dfine_warp_affine_u8(const uint8_t *src, uint8_t *dst, int Hs, int Ws, int Hd, int Wd, const double *m, int border,
+                         void *stream);
+/* boxes [N, 4] xyxy -> out [N, 4]: the four corners through m (2 x 3, HOST floats), min / max, clip to
+ * [0, target_w] x [0, target_h]; keep [N] u8 = box_candidates(box1 = boxes * scale, box2 = out, area_thr) (utils.py:343-377,283-295). */
+int dfine_affine_boxes(const float *boxes, float *out, uint8_t *keep, int N, const float *m, float scale, float target_w,
+                       float target_h, float area_thr, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * (f1) Inference pre-processing: uint8 [B, Hs, Ws, 3] BGR frames (device) -> [B, 3, Ho, Wo] dtype, RGB / 255.
  * The source is bilinearly resized to (rh, rw) with OpenCV's 8-bit INTER_LINEAR arithmetic, placed at
  * (top, left) and surrounded by pad_value (letterbox: 114); plain resize: rh = Ho, rw = Wo, top = left = 0.

@@ -267,3 +267,62 @@ def resize_linear_u8(img, out_h, out_w):
     r0, r1 = rows[y0], rows[y1]
     out = (((ay0[:, None, None] * (r0 >> 4)) >> 16) + ((ay1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
     return out.astype(np.uint8)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# (f3) augmentation geometry - restated from the reference's host code (src/dl/utils.py), which cannot be imported here
+# (it imports cv2 / albumentations at module level).
+def box_candidates(box1, box2, wh_thr=2, ar_thr=20, area_thr=0.1, eps=1e-16):
+    """Reference utils.py:283-295: box1 / box2 [4, n] before / after the augmentation."""
+    w1, h1 = box1[2] - box1[0], box1[3] - box1[1]
+    w2, h2 = box2[2] - box2[0], box2[3] - box2[1]
+    ar = np.maximum(w2 / (h2 + eps), h2 / (w2 + eps))
+    return (w2 > wh_thr) & (h2 > wh_thr) & (w2 * h2 / (w1 * h1 + eps) > area_thr) & (ar < ar_thr)
+
+
+def affine_boxes(boxes, M, scale, target_size, area_thr=0.1):
+    """Reference utils.py:343-377 (random_affine without polygons): boxes [n, 4] xyxy through the 3 x 3 matrix M by their four
+    corners, min / max, clip to [0, target_w] x [0, target_h] -> (new boxes [n, 4] f32, keep [n] bool)."""
+    n = len(boxes)
+    xy = np.ones((n * 4, 3), dtype=np.float32)
+    xy[:, :2] = boxes[:, [0, 1, 2, 3, 0, 3, 2, 1]].reshape(n * 4, 2)
+    xy = (xy @ np.asarray(M, dtype=np.float64).T)[:, :2].reshape(n, 8)
+    x, y = xy[:, [0, 2, 4, 6]], xy[:, [1, 3, 5, 7]]
+    new = np.stack([x.min(1), y.min(1), x.max(1), y.max(1)], axis=1)
+    new[:, [0, 2]] = new[:, [0, 2]].clip(0, target_size[0])
+    new[:, [1, 3]] = new[:, [1, 3]].clip(0, target_size[1])
+    keep = box_candidates(box1=boxes.T * scale, box2=new.T, area_thr=area_thr)
+    return new.astype(np.float32), keep
+
+
+def warp_affine_u8(src, M2x3, out_hw, border=114):
+    """cv2.warpAffine(src, M, dsize, flags=INTER_LINEAR, borderMode=BORDER_CONSTANT) restated (OpenCV imgwarp.cpp: inverse map
+    in AB_BITS = 10 fixed point, INTER_BITS = 5 sub-pixel positions, bilinear weights from the 2^15-scaled table whose rows are
+    normalised by adjusting their largest entry).  cv2 is not in the build image: parity with cv2 itself is UNPINNED; this
+    restatement is what the HIP kernel is checked against, next to size-independent properties."""
+    Hs, Ws = src.shape[:2]
+    Hd, Wd = out_hw
+    m = np.asarray(M2x3, dtype=np.float64).reshape(2, 3)
+    D = m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    i00, i01, i10, i11 = m[1, 1] * D, -m[0, 1] * D, -m[1, 0] * D, m[0, 0] * D
+    b1, b2 = -i00 * m[0, 2] - i01 * m[1, 2], -i10 * m[0, 2] - i11 * m[1, 2]
+    xs, ys = np.arange(Wd), np.arange(Hd)
+    adelta, bdelta = np.rint(i00 * xs * 1024).astype(np.int64), np.rint(i10 * xs * 1024).astype(np.int64)
+    X0 = np.rint((i01 * ys + b1) * 1024).astype(np.int64) + 16
+    Y0 = np.rint((i11 * ys + b2) * 1024).astype(np.int64) + 16
+    X, Y = (X0[:, None] + adelta[None, :]) >> 5, (Y0[:, None] + bdelta[None, :]) >> 5
+    sx, sy, fx, fy = X >> 5, Y >> 5, X & 31, Y & 31
+    wx1, wy1 = fx.astype(np.float32) / 32, fy.astype(np.float32) / 32
+    w = np.stack([(1 - wy1) * (1 - wx1), (1 - wy1) * wx1, wy1 * (1 - wx1), wy1 * wx1], -1).astype(np.float32)
+    wi = np.rint(w * np.float32(32768)).astype(np.int64)
+    diff = 32768 - wi.sum(-1)
+    kmax = wi.argmax(-1)
+    np.put_along_axis(wi, kmax[..., None], np.take_along_axis(wi, kmax[..., None], -1) + diff[..., None], -1)
+    out = np.zeros((Hd, Wd, 3), dtype=np.int64)
+    for k, (dx, dy) in enumerate(((0, 0), (1, 0), (0, 1), (1, 1))):
+        px, py = sx + dx, sy + dy
+        ok = (px >= 0) & (px < Ws) & (py >= 0) & (py < Hs)
+        v = np.where(ok[..., None], src[np.clip(py, 0, Hs - 1), np.clip(px, 0, Ws - 1)].astype(np.int64), border)
+        out += v * wi[..., k][..., None]
+    return np.clip((out + (1 << 14)) >> 15, 0, 255).astype(np.uint8)

@@ -236,3 +236,20 @@ def test_trainer_plumbing_and_resume(oracle_backend, tmp_path):
     m = tr.evaluate(n_batches=1, conf_thresh=0.01)
     assert {"f1", "precision", "recall", "iou", "TPs", "FPs", "FNs", "mAP_50", "mAP_50_95"} <= set(m)
     assert m["FNs"] + m["TPs"] > 0 and 0.0 <= m["precision"] <= 1.0 and m["mAP_50_95"] <= m["mAP_50"] + 1e-12
+
+
+def test_config1_yolo_folder_one_epoch_cpu(oracle_backend, tmp_path):
+    """BASELINE configs[0] as written: D-FINE-n 320x320, bs 2, ONE epoch over 16 synthetic YOLO-labelled images ON DISK
+    (images/*.png + labels/*.txt), CPU: 8 optimisation steps, finite decreasing-or-equal-order losses, checkpoints written."""
+    from custom_d_fine_amd.dl import data_device, train as T
+    root = data_device.write_synthetic_yolo_dataset(tmp_path / "ds", n_images=16, size=(200, 260), num_classes=3, seed=0)
+    cfg = T.load_config(["model_name=n", "train.device=cpu", "train.num_classes=3", "train.img_size=[320,320]", "train.batch_size=2",
+                         "train.epochs=1", "train.amp_enabled=false", f"train.data_path={root}", f"train.path_to_save={tmp_path / 'out'}"])
+    tr = T.Trainer(cfg)
+    assert cfg["train"]["steps_per_epoch"] == 8
+    batches = list(tr._batches(1))
+    assert len(batches) == 8 and all(im.shape == (2, 3, 320, 320) for im, _ in batches)
+    ids = sorted(int(t["orig_size"][0]) for _, tg in batches for t in tg)
+    assert len(ids) == 16
+    tr.train()
+    assert tr.step.iters == 8 and (tmp_path / "out" / "model.pt").exists()
