@@ -85,6 +85,12 @@ _SIGNATURES = {
     "dfine_mask_loss_grad": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfine_mask_cost": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     "dfine_conv1x1_bw_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfine_conv_f32_packed_elems": (_L, [_I, _I, _I, _I]),
+    "dfine_conv_f32_pack_weights": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "dfine_conv_f32_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_conv_f32_wgrad_splits": (c_int, [_I, _I, _I, _I, _I, _I]),
+    "dfine_conv_f32_wgrad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_upsample2_zero_f32": (c_int, [_P, _P, _L, _I, _I, _I, _I, _P]),
     "dfine_mosaic_place_u8": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_warp_affine_u8": (c_int, [_P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "dfine_affine_boxes": (c_int, [_P, _P, _P, _I, _P, _F, _F, _F, _F, _P]),
@@ -1184,3 +1190,41 @@ def affine_boxes(boxes, m2x3, scale, target_wh, area_thr):
     _check(_lib.dfine_affine_boxes(_ptr(boxes), _ptr(out), _ptr(keep), n, m, float(scale), float(target_wh[0]), float(target_wh[1]),
                                    float(area_thr), _stream()), "dfine_affine_boxes")
     return out, keep
+
+
+# ------------------------------------------------------------------------------------- fp32 convolutions (configs[1])
+def conv_f32_pack_weights(w, dgrad):
+    cout, cin, ks, _ = w.shape
+    w2 = torch.empty(int(_lib.dfine_conv_f32_packed_elems(cout, cin, ks, int(dgrad))), device=w.device, dtype=torch.float32)
+    _check(_lib.dfine_conv_f32_pack_weights(_ptr(w), _ptr(w2), cout, cin, ks, int(dgrad), _stream()), "dfine_conv_f32_pack_weights")
+    return w2
+
+
+def conv_f32_forward(x, w2, cout, ks, stride, pt, pl, out_hw):
+    B, cin, hi, wi = x.shape
+    y = torch.empty(B, cout, out_hw[0], out_hw[1], device=x.device, dtype=torch.float32)
+    _check(_lib.dfine_conv_f32_fwd(_ptr(x), _ptr(w2), _ptr(y), B, cin, cout, hi, wi, out_hw[0], out_hw[1], ks, stride, pt, pl, _stream()),
+           "dfine_conv_f32_fwd")
+    return y
+
+
+def conv_f32_wgrad(x, dy, ks, stride, pt, pl, partials=False):
+    """-> dw [Cout, Cin, ks, ks] f32, or (ws, meta) for the deferred reduction (meta = (splits, Cout, Cin, taps, NP16, CP16))."""
+    B, cin, hi, wi = x.shape
+    _, cout, ho, wo = dy.shape
+    splits = int(_lib.dfine_conv_f32_wgrad_splits(B, cin, cout, ho, wo, ks))
+    np16, cp16 = _p16(cout), _p16(cin)
+    ws = torch.empty(splits * np16 * cp16 * ks * ks, device=x.device, dtype=torch.float32)
+    _check(_lib.dfine_conv_f32_wgrad(_ptr(x), _ptr(dy), _ptr(ws), B, cin, cout, hi, wi, ho, wo, ks, stride, pt, pl, _stream()),
+           "dfine_conv_f32_wgrad")
+    if partials:
+        return ws, (splits, cout, cin, ks * ks, np16, cp16)
+    return ws.view(splits, np16, cp16, ks * ks).sum(0)[:cout, :cin].reshape(cout, cin, ks, ks).contiguous()
+
+
+def upsample2_zero(x, out_hw):
+    planes = x.numel() // (x.shape[-1] * x.shape[-2])
+    out = torch.empty(*x.shape[:-2], out_hw[0], out_hw[1], device=x.device, dtype=torch.float32)
+    _check(_lib.dfine_upsample2_zero_f32(_ptr(x), _ptr(out), planes, x.shape[-2], x.shape[-1], out_hw[0], out_hw[1], _stream()),
+           "dfine_upsample2_zero_f32")
+    return out

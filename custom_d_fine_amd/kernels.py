@@ -1001,6 +1001,8 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
         elif _stem_conv_ok(conv, x, pad_br):
             y = _StemConv.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv.weight,
                                 conv.stride[0], conv.padding[0], pad_br)
+        elif _f32_conv_ok(conv, x):
+            y = conv_f32(x, conv, pad_br)           # fp32 math (configs[1]): the f32-input MFMA kernels
         else:
             y = conv(F.pad(x, (0, 1, 0, 1)) if pad_br else x)
         return _bn_tail(y, bn, a, act, lab)
@@ -1699,3 +1701,70 @@ def mask_losses(pm, plan_b, plan_q, tgt, boxes, eps=1e-6, plan_t=None):
 
 def mask_cost_sums(pm, gt, toff, q, tmax, alpha, gamma):
     return _hip().mask_cost_sums(pm.contiguous(), gt.float().contiguous(), toff, q, tmax, alpha, gamma)
+
+
+# =============================================================================================
+# A1 / A2 in fp32 (configs[1]): dense convolutions on the f32-input matrix cores (csrc/conv_f32.hip)
+# =============================================================================================
+def _packed_f32(weight, dgrad):
+    key = (id(weight), "f32", dgrad)
+    tag = (_WEIGHT_EPOCH, weight._version, weight.data_ptr())
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] == tag and hit[2]() is weight:
+        return hit[1]
+    wp = _hip().conv_f32_pack_weights(weight.detach().float().contiguous(), dgrad)
+    _PACK_CACHE[key] = (tag, wp, weakref.ref(weight))
+    return wp
+
+
+class _DenseConvF32(torch.autograd.Function):
+    """conv2d(x, weight, stride, padding (pt, pl) top / left, output size `out_hw`) in exact fp32 on the MFMA units; the data
+    gradient is the same kernel on the transposed + flipped packing (stride 2: on the zero-upsampled gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pt, pl, out_hw):
+        hip = _hip()
+        x = x.contiguous()
+        ks = weight.shape[-1]
+        y = hip.conv_f32_forward(x, _packed_f32(weight, False), weight.shape[0], ks, stride, pt, pl, out_hw)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pt, pl)
+        ctx.slot = _defer_slot(weight) if ctx.needs_input_grad[1] else None
+        if ctx.slot is not None:
+            ctx.slot[0].note_use(ctx.slot[1][0])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        hip = _hip()
+        x, weight = ctx.saved_tensors
+        stride, pt, pl = ctx.cfg
+        ks = weight.shape[-1]
+        dy = dy.float().contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            src = dy if stride == 1 else hip.upsample2_zero(dy, (2 * dy.shape[2] - 1, 2 * dy.shape[3] - 1))
+            dx = hip.conv_f32_forward(src, _packed_f32(weight, True), weight.shape[1], ks, 1, ks - 1 - pt, ks - 1 - pl, tuple(x.shape[2:]))
+        if ctx.needs_input_grad[1]:
+            if ctx.slot is not None:
+                ws, meta = hip.conv_f32_wgrad(x, dy, ks, stride, pt, pl, partials=True)
+                ctx.slot[0].defer_wgrad(ctx.slot[1][0], ws, meta)
+                ctx.slot[0].use_done(ctx.slot[1][0])
+            else:
+                dw = hip.conv_f32_wgrad(x, dy, ks, stride, pt, pl).to(weight.dtype)
+        return dx, dw, None, None, None, None
+
+
+def _f32_conv_ok(conv, x):
+    k, s, p = conv.kernel_size, conv.stride, conv.padding
+    return (_env("DFINE_F32_CONV", "1") == "1" and x.dim() == 4 and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and conv.weight.dtype == torch.float32 and conv.groups == 1 and conv.bias is None and conv.dilation == (1, 1)
+            and k[0] == k[1] <= 3 and s[0] == s[1] <= 2 and isinstance(p, tuple) and p[0] == p[1] <= k[0] - 1)
+
+
+def conv_f32(x, conv: nn.Conv2d, pad_br: bool = False):
+    """conv(x) (or conv(F.pad(x, (0, 1, 0, 1))) for the stem's 2x2 convolutions) in fp32 on the HIP kernel."""
+    k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    hi, wi = x.shape[2] + int(pad_br), x.shape[3] + int(pad_br)
+    ho, wo = (hi + 2 * p - k) // s + 1, (wi + 2 * p - k) // s + 1
+    return _DenseConvF32.apply(x, conv.weight, s, p, p, (ho, wo))

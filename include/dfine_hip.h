@@ -382,6 +382,26 @@ int dfine_attn_bwd(const void *q, const void *k, const void *v, const void *o, c
                    int lddv, float scale, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * A1 / A2 in fp32 (BASELINE configs[1]): dense convolutions on the f32-input matrix cores (v_mfma_f32_16x16x4_f32, exact
+ * fp32 arithmetic) - the layers of dfine_conv_fwd_bf16 plus the HGNetv2 stem (3x3 stride 2, 2x2 on the bottom/right padded
+ * map: hgnetv2.py:115-166) when the model runs without autocast.  Kernel size 1..3, stride 1 / 2, padding (pt, pl) on the
+ * top / left, zeros outside the input.
+ */
+int64_t dfine_conv_f32_packed_elems(int Cout, int Cin, int KS, int dgrad);
+/* fp32 master [Cout, Cin, KS, KS] -> [KS*KS][NP][KP] fp32 (NP = rows rounded up to 64, KP = k rounded up to 16); dgrad = 1:
+ * rows = input channels, k = output channels, taps flipped (the data gradient is the forward kernel on this packing). */
+int dfine_conv_f32_pack_weights(const float *w, float *w2, int Cout, int Cin, int KS, int dgrad, void *stream);
+int dfine_conv_f32_fwd(const float *x, const float *w2, float *y, int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo,
+                       int KS, int S, int pt, int pl, void *stream);
+/* part [splits][NP16][CP16][KS*KS] f32 partial sums of the weight gradient (splits = dfine_conv_f32_wgrad_splits). */
+int dfine_conv_f32_wgrad_splits(int B, int Cin, int Cout, int Ho, int Wo, int KS);
+int dfine_conv_f32_wgrad(const float *x, const float *dy, float *part, int B, int Cin, int Cout, int Hi, int Wi, int Ho,
+                         int Wo, int KS, int S, int pt, int pl, void *stream);
+/* out [planes, Ho, Wo] = in [planes, H, W] with zeros inserted between the pixels (out[2y, 2x] = in[y, x]): the operand of
+ * the data gradient of a stride-2 convolution.  Ho >= 2 H - 1, Wo >= 2 W - 1. */
+int dfine_upsample2_zero_f32(const float *in, float *out, int64_t planes, int H, int W, int Ho, int Wo, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * A10 / A15  Segmentation head (BASELINE configs[4]): the element-wise / reduction kernels of MaskDecoder
  * (src/d_fine/arch/dfine_decoder.py:316-370), of the mask losses (src/d_fine/dfine_criterion.py:335-450,504-556) and of
  * the matcher's mask costs (src/d_fine/matcher.py:19-71,175-237).  dtype: activations f32 or bf16; parameters, statistics
