@@ -254,7 +254,7 @@ def main():
         def hbm_entry(key, label):
             if key not in timing or timing[key][2] <= 0:
                 return None
-            n, mean_ms, tot_ms, work = timing[key]
+            n, mean_ms, tot_ms, work = timing[key][:4]
             gbs = work / (tot_ms * 1e-3) / 1e9
             return {"kernel": label, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(key, args.batch, lq, args.dtype),
@@ -272,7 +272,7 @@ def main():
                     mfma_entry(("linear", "attention"), "linear_act / attention kernels (token streams)"),
                     mfma_entry(("miopen_conv",), "MIOpen convolutions (shapes the HIP weight-gradient kernel does not take)"),
                     hbm_entry("msda_fwd", "msda_fwd8_kernel (dfine_msda_fused_fwd)"),
-                    hbm_entry("msda_bwd", "msda_bwd_wide_kernel (dfine_msda_fused_bwd)")]
+                    hbm_entry("msda_bwd", "msda_bwd_pair_kernel (dfine_msda_fused_bwd_acc, packed-f16 accumulate)")]
         line = {
             "metric": "images/sec train step D-FINE-m 640x640 bs=32 at 1/2/4/8 MI355X",
             "value": round(args.batch * world * args.steps / elapsed, 3),

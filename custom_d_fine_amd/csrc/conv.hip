@@ -1184,16 +1184,26 @@ __global__ __launch_bounds__(kConvThreads) void linear_wgrad_kernel(const uint16
 // gradient buffer of the fused optimizer): table rows of 8 x int64 = {partials ptr, dst ptr, splits, Cout, Cin, taps, NP16, CP16}
 // (a bias gradient is a row with Cin = taps = CP16 = 1); blockIdx.y = row, blockIdx.x strides over the row's outputs.
 // Replaces one conv_wgrad_reduce_kernel launch per layer (179 per D-FINE-m step) + the per-parameter gradient tensors.
+// One block sums the partials of kWrGroups(splits) consecutive 64-element groups of one table row; the grid is
+// (largest group count of the launch, rows), blocks beyond a row's own count leave at once.  (A fixed 32 blocks per row
+// left the small layers - up to 512 splits of a few KB - as 128 waves walking chains of dependent rounds: 1.44 TB/s over
+// the step's 2.57 GB of partials.)
+__host__ __device__ static inline int wr_groups(int splits) { return splits >= 128 ? 1 : 128 / (splits < 1 ? 1 : splits); }
+
 __global__ __launch_bounds__(256) void multi_wgrad_reduce_kernel(const int64_t *__restrict__ table) {
     __shared__ float red[4][64];
     const int64_t *e = table + (int64_t)blockIdx.y * 8;
+    const int splits = (int)e[2], Cout = (int)e[3], Cin = (int)e[4], taps = (int)e[5], NP16 = (int)e[6], CP16 = (int)e[7];
+    const int64_t total = (int64_t)Cout * Cin * taps, stride = (int64_t)NP16 * CP16 * taps;
+    const int per = wr_groups(splits);
+    const int64_t first = (int64_t)blockIdx.x * per * 64;
+    if (first >= total) return;
     const float *part = reinterpret_cast<const float *>(e[0]);
     float *dst = reinterpret_cast<float *>(e[1]);
-    const int splits = (int)e[2], Cout = (int)e[3], Cin = (int)e[4], taps = (int)e[5], NP16 = (int)e[6], CP16 = (int)e[7];
     const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int64_t total = (int64_t)Cout * Cin * taps, stride = (int64_t)NP16 * CP16 * taps;
-    for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < total; i0 += (int64_t)gridDim.x * 64) {
-        const int64_t i = i0 + col;
+    for (int g = 0; g < per; ++g) {
+        const int64_t i = first + (int64_t)g * 64 + col;
+        if (first + (int64_t)g * 64 >= total) break;             // uniform over the block
         float s0 = 0.f, s1 = 0.f;
         if (i < total) {
             const int t = (int)(i % taps);
@@ -1201,8 +1211,7 @@ __global__ __launch_bounds__(256) void multi_wgrad_reduce_kernel(const int64_t *
             const int n = (int)(i / ((int64_t)taps * Cin));
             const float *src = part + ((int64_t)n * CP16 + c) * taps + t;
             int k = q;
-            // the small layers have the most splits (up to 512 x a few KB): keep 8 loads in flight per lane
-            for (; k + 28 < splits; k += 32) {
+            for (; k + 28 < splits; k += 32) {                    // 8 loads in flight per lane
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(k + 4 * u) * stride];
@@ -1559,11 +1568,17 @@ int dfine_linear_wgrad_splits(int M, int N, int K) {
     return splits;
 }
 
-// table: device int64 [n_entries][8] = {partials, dst (f32, ACCUMULATED into), splits, Cout, Cin, taps, NP16, CP16}
-int dfine_multi_wgrad_reduce(const void *table, int n_entries, void *stream) {
+// table: device int64 [n_entries][8] = {partials, dst (f32, ACCUMULATED into), splits, Cout, Cin, taps, NP16, CP16};
+// max_blocks = the largest dfine_multi_wgrad_reduce_blocks(splits, Cout * Cin * taps) of the rows
+int dfine_multi_wgrad_reduce_blocks(int splits, int64_t elems) {
+    const int64_t per = (int64_t)wr_groups(splits) * 64;
+    return (int)((elems + per - 1) / per);
+}
+
+int dfine_multi_wgrad_reduce(const void *table, int n_entries, int max_blocks, void *stream) {
     if (n_entries == 0) return DFINE_OK;
-    if (!table || n_entries < 0) return DFINE_E_BADARG;
-    hipLaunchKernelGGL(multi_wgrad_reduce_kernel, dim3(32, n_entries), dim3(256), 0, (hipStream_t)stream, (const int64_t *)table);
+    if (!table || n_entries < 0 || max_blocks < 1) return DFINE_E_BADARG;
+    hipLaunchKernelGGL(multi_wgrad_reduce_kernel, dim3(max_blocks, n_entries), dim3(256), 0, (hipStream_t)stream, (const int64_t *)table);
     return check_launch();
 }
 

@@ -246,6 +246,12 @@ class FusedAdamWEMA:
             if b["ready"] == len(b["params"]):
                 self._reduce_bucket(b)
 
+    def _reduce_blocks(self, splits, elems, _memo={}):
+        key = (splits, elems)
+        if key not in _memo:
+            _memo[key] = self.hip.multi_wgrad_reduce_blocks(splits, elems)
+        return _memo[key]
+
     def _flush_deferred(self, lo=None, hi=None):
         import numpy as np
         take = [d for d in self._deferred if lo is None or lo <= d[1] < hi]
@@ -283,7 +289,9 @@ class FusedAdamWEMA:
         table = upload(np.asarray(order, dtype=np.int64), self.flat_grad.device)
         first = 0
         for rnd in rounds:
-            self.hip.multi_wgrad_reduce(table[first:first + len(rnd)], len(rnd))
+            blocks = max(self._reduce_blocks(r[2], r[3] * r[4] * r[5]) for r in rnd)
+            io = sum(4.0 * r[2] * r[6] * r[7] * r[5] + 8.0 * r[3] * r[4] * r[5] for r in rnd)
+            self.hip.multi_wgrad_reduce(table[first:first + len(rnd)], len(rnd), blocks, io=io)
             first += len(rnd)
         self._live.append((take, table))
 

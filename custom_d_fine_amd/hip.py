@@ -68,7 +68,8 @@ _SIGNATURES = {
     "dfine_conv1x1_seg_wgrad_bf16": (c_int, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfine_conv_wgrad_splits": (c_int, [_I, _I, _I, _I, _I, _I]),
     "dfine_linear_wgrad_splits": (c_int, [_I, _I, _I]),
-    "dfine_multi_wgrad_reduce": (c_int, [_P, _I, _P]),
+    "dfine_multi_wgrad_reduce": (c_int, [_P, _I, _I, _P]),
+    "dfine_multi_wgrad_reduce_blocks": (c_int, [_I, c_int64]),
     "dfine_linear_act_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_multi_cast_bf16_t": (c_int, [_P, _I, _P]),
     "dfine_act_fwd_bf16": (c_int, [_P, _P, _L, _I, _P]),
@@ -742,9 +743,14 @@ def conv_wgrad_bf16(x, dy, ks, partials=False):
     return dw
 
 
-def multi_wgrad_reduce(table, n_entries):
-    with _timed("wgrad_reduce", 0.0):       # no FLOPs of its own: its time counts against the weight-gradient family
-        _check(_lib.dfine_multi_wgrad_reduce(_ptr(table), n_entries, _stream()), "dfine_multi_wgrad_reduce")
+def multi_wgrad_reduce_blocks(splits, elems):
+    return int(_lib.dfine_multi_wgrad_reduce_blocks(int(splits), int(elems)))
+
+
+def multi_wgrad_reduce(table, n_entries, max_blocks, io=0.0):
+    """io: bytes of partial sums + destinations the launch streams (its roofline is HBM; no FLOPs of its own)."""
+    with _timed("wgrad_reduce", 0.0, io=io):
+        _check(_lib.dfine_multi_wgrad_reduce(_ptr(table), n_entries, int(max_blocks), _stream()), "dfine_multi_wgrad_reduce")
 
 
 # ------------------------------------------------------------------------------------- FDR head

@@ -342,11 +342,13 @@ int dfine_conv1x1_seg_wgrad_bf16(const void *const *x_parts, const int *x_channe
  * gradient buffer the fused optimizer / all-reduce work on (the per-parameter `.grad` tensors and the
  * per-layer reductions of autograd's AccumulateGrad, src/dl/train.py:512-535, disappear).
  *   table: device int64 [n_entries][8] = {partials ptr, dst ptr, splits, Cout, Cin, taps, NP16, CP16}
- *   (bias gradient: Cin = taps = CP16 = 1).
+ *   (bias gradient: Cin = taps = CP16 = 1).  max_blocks: the largest dfine_multi_wgrad_reduce_blocks(splits,
+ *   Cout * Cin * taps) over the rows (the launch is max_blocks x n_entries workgroups).
  */
 int dfine_conv_wgrad_splits(int B, int Cin, int Cout, int H, int W, int KS);
 int dfine_linear_wgrad_splits(int M, int N, int K);
-int dfine_multi_wgrad_reduce(const void *table, int n_entries, void *stream);
+int dfine_multi_wgrad_reduce_blocks(int splits, int64_t elems);   /* blocks one row of the table needs */
+int dfine_multi_wgrad_reduce(const void *table, int n_entries, int max_blocks, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A2 / A3 / A5 / A6  Token-stream linear layers: y[M, N] = act(x[M, K] . w[N, K]^T + bias[N]), bf16
