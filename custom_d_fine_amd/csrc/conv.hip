@@ -113,6 +113,13 @@ template <> __device__ __forceinline__ void unpack<2>(const uint32_t &v, uint16_
 // y [B, Cout, H, W] bf16.  H*W, W describe the (possibly flattened, for 1x1) plane.
 // KC = number of 32-channel slabs staged per barrier pair: layers with many input channels are otherwise
 // bound by the (global load -> LDS -> barrier) latency of each 32-channel step, not by MFMA or HBM.
+// tools/probe/conv3x3_ablate.hip builds timing-only variants (1: no MFMAs, 2: no LDS fragment reads, 4: no staging of x,
+// 8: no weight loads).
+#ifndef DFINE_CONV3X3_ABLATE
+#define DFINE_CONV3X3_ABLATE 0
+#endif
+constexpr int kAbl3 = DFINE_CONV3X3_ABLATE;
+
 template <int KS, int NTN, int VEC, int KC>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_igemm_kernel(      // two workgroups per CU: at most 256 registers
     const uint16_t *__restrict__ x, const uint16_t *__restrict__ w2, uint16_t *__restrict__ y, int Cin,
@@ -129,7 +136,12 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_igemm_kernel(      // tw
     uint32_t *lds32 = reinterpret_cast<uint32_t *>(lds);
     for (int i = tid; i < npxl * 16 * KC; i += kConvThreads) lds32[i] = 0u;
 
-    // per column-tile LDS byte offset of this lane's pixel (tap (0,0)) + its 16-byte channel group
+    // LDS record of a pixel: 32 channels = 64 bytes = four 16-byte channel groups.  A B fragment is one ds_read_b128 per lane
+    // (lane = 16 * group + pixel of the tile), served in lane sets {0-3, 12-15, 20-27} ...: with the groups in order, pixels
+    // p and p + 4 of a set fall on the same banks (2-way conflicts on every fragment read - half of the LDS-active cycles,
+    // profiles/r02_conv3x3_pmc.txt - and this kernel keeps the LDS pipe half busy even without them).  Group g of pixel P is
+    // therefore stored in slot g ^ (2 if P & 4): any 16 consecutive pixels then read conflict-free, for every tap shift.
+    const int g16 = (lane >> 4) * 16;
     int pl[kMaxPixTiles];
     const int ntile = (TP + 15) / 16;
 #pragma unroll
@@ -137,7 +149,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_igemm_kernel(      // tw
         int q = jt * 16 + (lane & 15);
         if (q >= TP) q = 0;
         const int orow = q / W, ocol = q - orow * W;
-        pl[jt] = (orow * WL + ocol) * 64 + (lane >> 4) * 16;
+        pl[jt] = (orow * WL + ocol) * 64 + g16;        // byte offset of this lane's pixel (tap (0, 0)) and channel group, unswizzled
     }
     const int n_wave = blockIdx.y * 64 * NTN + wave * 16 * NTN;
     f32x4v acc[NTN][kMaxPixTiles];
@@ -151,9 +163,24 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_igemm_kernel(      // tw
     const uint16_t *xb = x + (int64_t)b * Cin * H * W;
     __syncthreads();
 
+    // Weights: a ring of three fragment sets per wave, filled two taps ahead ACROSS slabs and stages (the sequence of (stage,
+    // slab, tap) steps is known up front and does not depend on the staging).  One tap ahead left ~0.13 us of MFMAs to cover
+    // an L2 round trip per tap: with nothing else in the kernel the weight loads alone took 36 us of a 99 us launch on
+    // 128 -> 128 @ 80 x 80 (tools/probe/conv3x3_ablate.hip).
+    auto load_a = [&](int tap, int cs, bf16x8 (&a)[NTN]) {
+#pragma unroll
+        for (int t = 0; t < NTN; ++t) {
+            const int n = min(n_wave + t * 16 + (lane & 15), NP - 1);          // rows past the layer: a valid row, never stored
+            if (kAbl3 & 8) { a[t] = __builtin_bit_cast(bf16x8, make_uint4(n, tap, cs, lane)); continue; }
+            a[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(w2 + ((int64_t)tap * NP + n) * KP + cs + 8 * (lane >> 4)));
+        }
+    };
+    bf16x8 aw[3][NTN];
+    load_a(0, 0, aw[0]);
+    load_a(1, 0, aw[1]);
     for (int c0 = 0; c0 < KP; c0 += 32 * KC) {
         // ---- stage KC x [32 channels] x [strip + halo] slabs, each transposed to [pixel][channel] ----
-        for (int it = tid; it < 16 * nvec * KC; it += kConvThreads) {
+        for (int it = tid; it < 16 * nvec * KC && !(kAbl3 & 4); it += kConvThreads) {
             const int pair = it & 15, vs = it >> 4;
             const int slab = KC == 1 ? 0 : vs / nvec, v = KC == 1 ? vs : vs - slab * nvec;
             const int lr = v / nvec_row, xv = (v - lr * nvec_row) * VEC;
@@ -173,47 +200,55 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_igemm_kernel(      // tw
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) e1[i] = 0;
             }
-            uint32_t *dst = lds32 + slab * npxl * 16 + (lr * WL + xv + PAD) * 16 + pair;
+            const int P = lr * WL + xv + PAD;
+            uint32_t *dst = lds32 + slab * npxl * 16 + P * 16;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) dst[i * 16] = (uint32_t)e0[i] | ((uint32_t)e1[i] << 16);
+            for (int i = 0; i < VEC; ++i) dst[i * 16 + (pair ^ (((P + i) & 4) << 1))] = (uint32_t)e0[i] | ((uint32_t)e1[i] << 16);
         }
         __syncthreads();
         // ---- MFMA over the slabs and taps --------------------------------------------------------
-        // The weights of tap t + 1 are requested (L2 -> registers) before the MFMAs of tap t, and all pixel-tile fragments of a
-        // tap are read from LDS before its first MFMA: the loop this replaces went load A -> per pixel tile { ds_read ->
+        // All pixel-tile fragments of a tap are read from LDS before its first MFMA (and its weights were requested two taps
+        // earlier): the loop this replaces went load A -> per pixel tile { ds_read ->
         // s_waitcnt vmcnt(0) lgkmcnt(0) -> NTN MFMAs }, i.e. one exposed L2 round trip per tap and one exposed LDS round trip
         // per NTN MFMAs.  Pixel tiles past the strip (the last strip of a 20 x 20 map) read pixel 0 and are never stored.
-        auto load_a = [&](int tap, int cs, bf16x8 (&a)[NTN]) {
-#pragma unroll
-            for (int t = 0; t < NTN; ++t) {
-                const int n = min(n_wave + t * 16 + (lane & 15), NP - 1);          // rows past the layer: a valid row, never stored
-                a[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(w2 + ((int64_t)tap * NP + n) * KP + cs + 8 * (lane >> 4)));
-            }
-        };
 #pragma unroll
         for (int slab = 0; slab < KC; ++slab) {
             const int cs = c0 + 32 * slab;
             if (KC > 1 && cs >= KP) break;
             const unsigned char *slds = lds + slab * npxl * 64;
-            bf16x8 a[NTN];
-            load_a(0, cs, a);
+            // (the fragment addresses of all 9 taps x 10 tiles do not depend on the slab: left alone the compiler computes the
+            // 90 of them once, ahead of the loop, and spills)
+#pragma unroll
+            for (int jt = 0; jt < kMaxPixTiles; ++jt) asm volatile("" : "+v"(pl[jt]));
 #pragma unroll
             for (int tap = 0; tap < KS * KS; ++tap) {
                 const int toff = ((tap / KS) * WL + (tap % KS)) * 64;
-                bf16x8 an[NTN];
-                if (tap + 1 < KS * KS) load_a(tap + 1, cs, an);
+                static_assert((KS * KS) % 3 == 0, "ring positions repeat per slab");
+                bf16x8 (&a)[NTN] = aw[tap % 3];
+                if (tap + 2 < KS * KS) load_a(tap + 2, cs, aw[(tap + 2) % 3]);
+                else if (cs + 32 < KP) load_a(tap + 2 - KS * KS, cs + 32, aw[(tap + 2) % 3]);
                 bf16x8 bf[kMaxPixTiles];
 #pragma unroll
                 for (int jt = 0; jt < kMaxPixTiles; ++jt)
-                    bf[jt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(slds + pl[jt] + toff));
+                {
+                    const int A = pl[jt] + toff;           // bit 8 = bit 2 of the pixel index -> flips bit 5 (slot g ^ 2)
+                    if (kAbl3 & 2) { bf[jt] = __builtin_bit_cast(bf16x8, make_uint4(A, lane, tap, jt)); continue; }
+                    bf[jt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(slds + (A ^ ((A >> 3) & 32))));
+                }
+                // (pins the requests above the MFMAs: at this register pressure the scheduler otherwise sinks each weight load to
+                // just before its use and re-serialises the fragment reads, ds_read -> wait -> 2 MFMAs)
+                __builtin_amdgcn_sched_barrier(0);
+                if (kAbl3 & 1) {
 #pragma unroll
-                for (int jt = 0; jt < kMaxPixTiles; ++jt)
+                    for (int jt = 0; jt < kMaxPixTiles; ++jt) asm volatile("" ::"v"(bf[jt]));
 #pragma unroll
-                    for (int t = 0; t < NTN; ++t)
-                        acc[t][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], bf[jt], acc[t][jt], 0, 0, 0);
-                if (tap + 1 < KS * KS) {
+                    for (int t = 0; t < NTN; ++t) asm volatile("" ::"v"(a[t]));
+                } else {
 #pragma unroll
-                    for (int t = 0; t < NTN; ++t) a[t] = an[t];
+                    for (int jt = 0; jt < kMaxPixTiles; ++jt)
+#pragma unroll
+                        for (int t = 0; t < NTN; ++t)
+                            acc[t][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], bf[jt], acc[t][jt], 0, 0, 0);
                 }
             }
         }
@@ -236,6 +271,234 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_igemm_kernel(      // tw
                     }
                 }
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 forward / data gradient, second generation: wave-specialised and persistent.
+// conv_igemm_kernel alternates "stage x into LDS" and "MFMA over the staged slabs" inside a workgroup and relies on the CU's
+// second workgroup for overlap - but two workgroups launched together run the same phases at the same time, and the parts of
+// a launch simply add up (tools/probe/conv3x3_ablate.hip on 128 -> 128 @ 80 x 80: empty kernel 23 us, + staging 25, + weight
+// loads 23, + MFMAs 24 (= the matrix peak), + fragment reads 3 -> 98 us).  Here a workgroup is 4 MFMA waves + 4 loader waves
+// (wave w and w + 4 share a SIMD), two LDS buffers, one barrier per stage: the loaders fill buffer (g + 1) & 1 - global rows
+// -> registers -> [pixel][channel] records - while the MFMA waves work on buffer g & 1.  A workgroup walks a list of
+// (image, strip, output-channel block) units, so the loaders are already on the next unit's first stage while the MFMA waves
+// store the finished strip, and zero-filling / address set-up happen once per workgroup instead of once per strip.
+constexpr int kWsThreads = 512;
+// LDS row pitch in pixels: a multiple of 8, so that the slot swizzle (bit 2 of the pixel index) of a tap depends on its column
+// offset only and the loaders' eight writes of a vector have compile-time offsets
+__host__ __device__ static inline int ws_pitch(int W) { return (W + 2 + 7) & ~7; }
+
+// Address arithmetic is kept out of the inner loops on both sides: the first version of this kernel spent 5.4 vector
+// instructions per MFMA (rocprofv3: SQ_INSTS_VALU 23.5 M against 3.7 M MFMAs, VALU busy 38 us per SIMD next to 24 us of MFMA
+// in a 76 us launch - per fragment read an add, the swizzle's shift / and / xor and the slab base; per loader item three
+// integer divisions, 24 shift / and / or to pair the channels and 8 swizzled addresses).  Now a fragment read is ONE add of a
+// wave-uniform offset to a per-lane base prepared per (tile, column offset), and a loader item is a table entry (LDS offset,
+// global offset, row, channel - two registers) + 8 v_perm_b32 + 8 writes with immediate offsets.
+template <int NTN, int VEC, int KC>
+__global__ __launch_bounds__(kWsThreads) void conv3x3_ws_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w2,
+                                                               uint16_t *__restrict__ y, int Cin, int Cout, int NP, int KP, int H,
+                                                               int W, int R, int strips, int nblk, int units) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int KS = 3, PAD = 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int WL = ws_pitch(W), rows_l = R + 2 * PAD, npxl = rows_l * WL;
+    const int buf_bytes = KC * npxl * 64;
+    // XCD x (workgroup L runs on XCD L % 8) owns a contiguous range of units - neighbouring strips share halo rows through
+    // that XCD's L2 - and its workgroups take them round-robin, so strips in flight at the same time are neighbours.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+    const int upx = (units + 7) / 8;
+    const int u_end = min(units, (xcd + 1) * upx), first = xcd * upx + slot;
+    const int n_mine = first < u_end ? (u_end - first + wpx - 1) / wpx : 0;
+    uint32_t *lds32 = reinterpret_cast<uint32_t *>(lds);
+    for (int i = tid; i < buf_bytes / 2; i += kWsThreads) lds32[i] = 0u;      // both buffers; the halo columns stay zero
+    __syncthreads();
+    auto decode = [&](int k, int &b, int &r0, int &nb) {
+        const int u = first + k * wpx;
+        nb = u % nblk;
+        const int bs = u / nblk;
+        b = bs / strips;
+        r0 = (bs - b * strips) * R;
+    };
+
+    if (wave >= 4) {
+        // ---------------- loader waves: rows of x -> registers -> LDS records [pixel][32 channels] (slot g ^ 2 if pixel & 4) ----
+        const int lt = tid - 256;
+        const int nvec_row = W / VEC, nvec = rows_l * nvec_row;
+        const int items = 16 * nvec * KC;                        // <= kItems * 256 (launch_conv)
+        constexpr int kItems = VEC == 8 ? 8 : 12;
+        // item table (the same for every stage and unit): meta = LDS dword offset | channel in the stage << 16 | row << 24
+        int meta[kItems], goff[kItems];
+#pragma unroll
+        for (int j = 0; j < kItems; ++j) {
+            const int it = j * 256 + lt;
+            meta[j] = -1;
+            goff[j] = 0;
+            if (it >= items) continue;
+            const int pair = it & 15, vs = it >> 4;
+            const int slab = KC == 1 ? 0 : vs / nvec, v = KC == 1 ? vs : vs - slab * nvec;
+            const int lr = v / nvec_row, xv = (v - lr * nvec_row) * VEC;
+            const int P = lr * WL + xv + PAD;
+            // VEC = 8: P = 1 (mod 8), the slot flips of pixels P .. P + 7 are compile-time; VEC = 4: P = 1 or 5 (mod 8), and the
+            // pattern of P = 5 is that of P = 1 with every flip inverted - folded into the pair index of the base
+            const int pbase = (VEC == 4 && (P & 4)) ? (pair ^ 8) : pair;
+            meta[j] = (slab * npxl * 16 + P * 16 + pbase) | ((32 * slab + 2 * pair) << 16) | (lr << 24);
+            goff[j] = ((32 * slab + 2 * pair) * H + (lr - PAD)) * W + xv;
+        }
+        int g = 0;
+        for (int k = 0; k < n_mine; ++k) {
+            int b, r0, nb;
+            decode(k, b, r0, nb);
+            const uint16_t *xb = x + (int64_t)b * Cin * H * W + (int64_t)r0 * W;
+            for (int c0 = 0; c0 < KP; c0 += 32 * KC, ++g) {
+                uint32_t *buf = lds32 + (g & 1) * (buf_bytes / 4);
+                const uint16_t *xs = xb + (int64_t)c0 * H * W;
+                typename PixVec<VEC>::type v0[kItems], v1[kItems];
+#pragma unroll
+                for (int j = 0; j < kItems; ++j) {                 // every load of the stage is in flight before the first unpack
+                    v0[j] = typename PixVec<VEC>::type{};
+                    v1[j] = typename PixVec<VEC>::type{};
+                    if (meta[j] < 0 || (kAbl3 & 4)) continue;
+                    const int gy = r0 - PAD + (meta[j] >> 24), ca = c0 + ((meta[j] >> 16) & 0xff);
+                    if (gy < 0 || gy >= H) continue;             // rows outside the plane are written as zeros (the buffer is reused)
+                    if (ca < Cin) v0[j] = *reinterpret_cast<const typename PixVec<VEC>::type *>(xs + goff[j]);
+                    if (ca + 1 < Cin) v1[j] = *reinterpret_cast<const typename PixVec<VEC>::type *>(xs + goff[j] + H * W);
+                }
+#pragma unroll
+                for (int j = 0; j < kItems; ++j) {
+                    if (meta[j] < 0 || (kAbl3 & 16)) continue;
+                    // dword (pair ^ flip) of pixel P + i, flip = 8 where (1 + i) & 4, relative to the base's own flip: two bases, the
+                    // per-pixel part is an immediate offset
+                    uint32_t *dst0 = buf + (meta[j] & 0xffff), *dst1 = buf + ((meta[j] & 0xffff) ^ 8);
+                    const uint32_t *a0 = reinterpret_cast<const uint32_t *>(&v0[j]), *a1 = reinterpret_cast<const uint32_t *>(&v1[j]);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        const uint32_t pr = __builtin_amdgcn_perm(a1[i >> 1], a0[i >> 1], (i & 1) ? 0x07060302u : 0x05040100u);
+                        (((1 + i) & 4) ? dst1 : dst0)[i * 16] = pr;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        return;
+    }
+
+    // ---------------- MFMA waves: wave w -> output channels [16 NTN w, 16 NTN (w + 1)) of the unit's block ----------------
+    const int g16 = (lane >> 4) * 16, i16 = lane & 15;
+    int pre[kMaxPixTiles][KS];                                   // per pixel tile and column offset: record + swizzled slot, bytes
+#pragma unroll
+    for (int jt = 0; jt < kMaxPixTiles; ++jt) {
+        int q = jt * 16 + i16;
+        if (q >= R * W) q = 0;
+        const int orow = q / W, ocol = q - orow * W;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const int A = (orow * WL + ocol + kx) * 64 + g16;    // bit 8 = bit 2 of the pixel index -> flips bit 5 (slot g ^ 2)
+            pre[jt][kx] = A ^ ((A >> 3) & 32);
+        }
+    }
+    // weights: ring of three fragment sets, requested two taps ahead across slabs, stages and units
+    auto wptr = [&](int nb) { return w2 + (int64_t)(nb * 64 * NTN + wave * 16 * NTN + i16) * KP + 8 * (lane >> 4); };
+    auto load_a = [&](const uint16_t *wp, int tap, bf16x8 (&a)[NTN]) {
+#pragma unroll
+        for (int t = 0; t < NTN; ++t) {
+            if (kAbl3 & 8) { a[t] = __builtin_bit_cast(bf16x8, make_uint4(tap, t, lane, 1)); continue; }
+            a[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(wp + ((int64_t)tap * NP + t * 16) * KP));
+        }
+    };
+    bf16x8 aw[3][NTN];
+    if (n_mine > 0) {
+        int b, r0, nb;
+        decode(0, b, r0, nb);
+        load_a(wptr(nb), 0, aw[0]);
+        load_a(wptr(nb), 1, aw[1]);
+    }
+    __syncthreads();                                             // stage 0 of the first unit is in buffer 0
+    int g = 0;
+    for (int k = 0; k < n_mine; ++k) {
+        int b, r0, nb;
+        decode(k, b, r0, nb);
+        const uint16_t *wu = wptr(nb);
+        const uint16_t *wnext_unit = wu;                         // weights of the unit after this one (any valid address at the end)
+        if (k + 1 < n_mine) {
+            int b2, r2, nb2;
+            decode(k + 1, b2, r2, nb2);
+            wnext_unit = wptr(nb2);
+        }
+        f32x4v acc[NTN][kMaxPixTiles];
+#pragma unroll
+        for (int t = 0; t < NTN; ++t)
+#pragma unroll
+            for (int jt = 0; jt < kMaxPixTiles; ++jt) acc[t][jt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < KP; c0 += 32 * KC, ++g) {
+            const unsigned char *buf = lds + (g & 1) * buf_bytes;
+            // (Requesting the fragments of the next half-tap in the shadow of the current MFMAs - sched_group_barrier: 2 MFMAs, 1
+            // add, 1 ds_read, four reads in flight - changed nothing on the 128-channel blocks and cost 10 % on the 64-channel ones.)
+#pragma unroll
+            for (int slab = 0; slab < KC; ++slab) {
+                const int cs = c0 + 32 * slab;
+                if (KC > 1 && cs >= KP) break;
+                const uint16_t *wnext = cs + 32 < KP ? wu + cs + 32 : wnext_unit;
+#pragma unroll
+                for (int jt = 0; jt < kMaxPixTiles; ++jt)
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) asm volatile("" : "+v"(pre[jt][kx]));   // (keeps the 90 tap addresses from being formed ahead of the loop)
+#pragma unroll
+                for (int tap = 0; tap < KS * KS; ++tap) {
+                    const unsigned char *rowb = buf + slab * npxl * 64 + (tap / KS) * WL * 64;   // wave-uniform
+                    bf16x8 (&a)[NTN] = aw[tap % 3];
+                    if (tap + 2 < KS * KS) load_a(wu + cs, tap + 2, aw[(tap + 2) % 3]);
+                    else load_a(wnext, tap + 2 - KS * KS, aw[(tap + 2) % 3]);
+                    bf16x8 bf[kMaxPixTiles];
+#pragma unroll
+                    for (int jt = 0; jt < kMaxPixTiles; ++jt) {
+                        if (kAbl3 & 2) { bf[jt] = __builtin_bit_cast(bf16x8, make_uint4(pre[jt][0], lane, tap, jt)); continue; }
+                        bf[jt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(rowb + pre[jt][tap % KS]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);           // requests stay above the MFMAs
+                    if (kAbl3 & 1) {
+#pragma unroll
+                        for (int jt = 0; jt < kMaxPixTiles; ++jt) asm volatile("" ::"v"(bf[jt]));
+#pragma unroll
+                        for (int t = 0; t < NTN; ++t) asm volatile("" ::"v"(a[t]));
+                        continue;
+                    }
+#pragma unroll
+                    for (int jt = 0; jt < kMaxPixTiles; ++jt)
+#pragma unroll
+                        for (int t = 0; t < NTN; ++t)
+                            acc[t][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], bf[jt], acc[t][jt], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- store through this wave's own LDS tile [16 NTN channels][strip pixels]: a strip is whole rows, i.e. TP contiguous
+        // elements per output channel, written with VEC-element stores; the loaders are already filling the next unit's first stage
+        const int TP = min(R, H - r0) * W;
+        const int n_wave = nb * 64 * NTN + wave * 16 * NTN;
+        constexpr int OP = 16 * kMaxPixTiles + 8;
+        uint16_t *ot = reinterpret_cast<uint16_t *>(lds + 2 * buf_bytes) + wave * (16 * NTN * OP);
+#pragma unroll
+        for (int t = 0; t < NTN; ++t)
+#pragma unroll
+            for (int jt = 0; jt < kMaxPixTiles; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ot[(t * 16 + 4 * (lane >> 4) + r) * OP + jt * 16 + i16] = f32_to_bf16(acc[t][jt][r]);
+        uint16_t *yb = y + ((int64_t)b * Cout * H + r0) * W;
+        const int cpr = TP / VEC;                                // chunks per channel row (W is a multiple of VEC)
+        int row = lane / cpr, c = (lane - row * cpr) * VEC;      // 64 lanes walk the [16 NTN][cpr] chunk grid
+        const int drow = 64 / cpr, dc = (64 - drow * cpr) * VEC;
+        while (row < 16 * NTN) {
+            const int n = n_wave + row;
+            if (n < Cout)
+                *reinterpret_cast<typename PixVec<VEC>::type *>(yb + (int64_t)n * H * W + c) =
+                    *reinterpret_cast<const typename PixVec<VEC>::type *>(ot + row * OP + c);
+            row += drow;
+            c += dc;
+            if (c >= TP) { c -= TP; ++row; }
         }
     }
 }
@@ -444,6 +707,13 @@ __device__ __forceinline__ void glds16(const uint16_t *gsrc, unsigned lds_addr) 
                  : "memory");
 }
 
+// tools/probe/conv1x1_ablate.hip builds timing-only variants of the kernel with parts of the stage loop removed
+// (1: no MFMAs, 2: no LDS fragment reads, 4: no copies after the first two stages and no waiting for them).
+#ifndef DFINE_CONV1X1_ABLATE
+#define DFINE_CONV1X1_ABLATE 0
+#endif
+constexpr int kAbl = DFINE_CONV1X1_ABLATE;
+
 template <int NTN, int kG2Ring, int PXW, bool SEG>   // kG2Ring LDS stages (3: two in flight; 2 for <= 128 input channels); PXW 16-pixel
                                                      // tiles per wave (4 / 8); SEG: input / output given as several parts
 __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs xs_, const uint16_t *__restrict__ w2,
@@ -526,8 +796,10 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
     issue(0);
     if (nstage > 1) issue(1);
     for (int s = 0; s < nstage; ++s) {
-        if (s + 1 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XPW + NTN) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(kAbl & 4) || s < 2) {
+            if (s + 1 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XPW + NTN) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         const unsigned char *xs = lds + (s % kG2Ring) * SB, *ws = xs + XB;
         // Every fragment of the stage's two 32-channel slabs is requested BEFORE the first MFMA (the loop this replaces read
@@ -541,6 +813,7 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
 #pragma unroll
             for (int t = 0; t < NTN; ++t) {
                 const int row = wn * 16 * NTN + t * 16 + i16;
+                if (kAbl & 2) { a[slab][t] = __builtin_bit_cast(bf16x8, make_uint4(row, lane, s, t)); continue; }
                 a[slab][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(ws + row * 128 + (((slab * 4 + g) ^ (row & 7)) << 4)));
             }
             const int r = slab * 32 + 4 * g + (i16 >> 2);
@@ -548,13 +821,24 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
 #pragma unroll
             for (int j = 0; j < PXW; ++j) {
                 const int seg = ((wp * PXW + j) ^ (r & 7)) << 5;
+                if (kAbl & 2) { bq[slab][j] = __builtin_bit_cast(bf16x8, make_uint4(seg, lane, s, j)); continue; }
                 const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_v4s __attribute__((address_space(3))) *)(xr + seg));
                 const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_v4s __attribute__((address_space(3))) *)(xr + seg + 16 * XPITCH));
                 typedef short tr_v8s __attribute__((ext_vector_type(8)));
                 bq[slab][j] = __builtin_bit_cast(bf16x8, (tr_v8s)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
         }
-        if (kG2Ring >= 3 && s + 2 < nstage) issue(s + 2);      // ring of 2: launched for <= 2 stages only, both issued above
+        if (kG2Ring >= 3 && s + 2 < nstage && !(kAbl & 4)) issue(s + 2);      // ring of 2: launched for <= 2 stages only, both issued above
+        if (kAbl & 1) {                                        // fragments kept alive, no matrix work
+#pragma unroll
+            for (int slab = 0; slab < 2; ++slab) {
+#pragma unroll
+                for (int t = 0; t < NTN; ++t) asm volatile("" ::"v"(a[slab][t]));
+#pragma unroll
+                for (int j = 0; j < PXW; ++j) asm volatile("" ::"v"(bq[slab][j]));
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < PXW; ++j)
 #pragma unroll
@@ -1275,6 +1559,40 @@ static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B
     const int vec = (W % 8 == 0) ? 8 : (W % 4 == 0 ? 4 : 2);
     const int nblk64 = (NP + 63) / 64;
     const bool wide = (NP % 128 == 0) && ((int64_t)B * strips * (NP / 128) >= 512);
+    static const int ws_env = [] { const char *e = getenv("DFINE_CONV3X3_WS"); return e ? atoi(e) : 1; }();
+    const size_t ws_ep = (size_t)4 * 16 * (wide ? 2 : 1) * (16 * kMaxPixTiles + 8) * 2;
+    int kc_ws = kc > 2 ? 2 : kc;                               // two buffers: the stage overhead is already hidden
+    const size_t ws_slab = (size_t)(R + 2 * pad) * ws_pitch(W) * 64;
+    const int ws_items = 16 * (R + 2 * pad) * (W / vec) * kc_ws;
+    if (KS == 3 && ws_env && NP % 64 == 0 && vec >= 4 && 2 * ws_slab * kc_ws + ws_ep <= 160 * 1024 && ws_items <= (vec == 8 ? 8 : 12) * 256) {
+        // wave-specialised persistent kernel: 128-channel blocks when they fill the chip, 64-channel blocks otherwise
+        const int ntn = wide ? 2 : 1;
+        const int nblk = NP / (64 * ntn);
+        const int units = B * strips * nblk;
+        static const int cus = [] { hipDeviceProp_t p; return hipGetDeviceProperties(&p, 0) == hipSuccess ? p.multiProcessorCount : 256; }();
+        const int upx = (units + 7) / 8;
+        const int wpx = upx < cus / 8 ? upx : cus / 8;
+        static bool attr_ws = false;
+        if (!attr_ws) {
+            hipError_t e = hipSuccess, r;
+#define DFINE_WS_ATTR(N, V, K) \
+    if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_ws_kernel<N, V, K>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) e = r;
+            DFINE_WS_ATTR(1, 8, 1) DFINE_WS_ATTR(1, 8, 2) DFINE_WS_ATTR(2, 8, 1) DFINE_WS_ATTR(2, 8, 2)
+            DFINE_WS_ATTR(1, 4, 1) DFINE_WS_ATTR(1, 4, 2) DFINE_WS_ATTR(2, 4, 1) DFINE_WS_ATTR(2, 4, 2)
+#undef DFINE_WS_ATTR
+            if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
+            attr_ws = true;
+        }
+#define DFINE_WS(N, V, K) \
+    hipLaunchKernelGGL((conv3x3_ws_kernel<N, V, K>), dim3(8 * wpx), dim3(kWsThreads), 2 * ws_slab * kc_ws + ws_ep, st, x, w2, y, Cin, Cout, NP, KP, H, W, R, strips, nblk, units)
+#define DFINE_WS_K(N, V) { if (kc_ws == 2) DFINE_WS(N, V, 2); else DFINE_WS(N, V, 1); }
+#define DFINE_WS_V(N) { if (vec == 8) DFINE_WS_K(N, 8) else DFINE_WS_K(N, 4) }
+        if (ntn == 2) DFINE_WS_V(2) else DFINE_WS_V(1)
+#undef DFINE_WS_V
+#undef DFINE_WS_K
+#undef DFINE_WS
+        return check_launch();
+    }
     dim3 grid(B * strips, wide ? NP / 128 : nblk64);
 #define DFINE_CONV(KSS, NTNN, VECC, KCC)                                                                   \
     hipLaunchKernelGGL((conv_igemm_kernel<KSS, NTNN, VECC, KCC>), grid, dim3(kConvThreads), ldsb, st, x, w2, y, Cin, \
