@@ -52,14 +52,59 @@ def process_boxes(boxes: torch.Tensor, processed_size, orig_sizes, keep_ratio: b
     return torch.stack([x0, y0, x1, y1], dim=-1)
 
 
+def _resize(m: torch.Tensor, size) -> torch.Tensor:
+    """[N, h, w] -> [N, H, W], bilinear, align_corners=False: the HIP gather kernel on the device (csrc/mask.hip)."""
+    if m.is_cuda:
+        return kernels.bilinear_resize(m.unsqueeze(0).contiguous(), (int(size[0]), int(size[1])))[0]
+    return torch.nn.functional.interpolate(m.unsqueeze(0), size=(int(size[0]), int(size[1])), mode="bilinear", align_corners=False)[0]
+
+
+def process_masks(pred_masks: torch.Tensor, processed_size, orig_sizes, keep_ratio: bool) -> List[torch.Tensor]:
+    """[B, Q, Hm, Wm] (or [Q, Hm, Wm]) mask probabilities -> per image [Q, H0, W0] in [0, 1] in the ORIGINAL frame: resized to
+    the network input size, the letterbox padding cut off (keep_ratio), resized to the original size (reference:
+    src/dl/utils.py:715-769; fp32 throughout - the reference's evaluation loop detours through fp16 to save host memory)."""
+    single = pred_masks.dim() == 3
+    if single:
+        pred_masks = pred_masks.unsqueeze(0)
+    sizes = torch.as_tensor(orig_sizes).reshape(-1, 2).tolist()
+    if pred_masks.shape[1] == 0:
+        return [torch.zeros((0, int(sizes[0][0]), int(sizes[0][1])), device=pred_masks.device)]
+    proc_h, proc_w = int(processed_size[0]), int(processed_size[1])
+    out = []
+    for b in range(pred_masks.shape[0]):
+        h0, w0 = int(sizes[b][0]), int(sizes[b][1])
+        m = _resize(pred_masks[b].float(), (proc_h, proc_w))
+        if keep_ratio:
+            gain = min(proc_h / h0, proc_w / w0)
+            padw = round((proc_w - w0 * gain) / 2 - 0.1)
+            padh = round((proc_h - h0 * gain) / 2 - 0.1)
+            m = m[:, max(padh, 0): proc_h - max(padh, 0), max(padw, 0): proc_w - max(padw, 0)]
+        out.append(_resize(m, (h0, w0)).clamp_(0, 1))
+    return out
+
+
+def cleanup_masks(masks: torch.Tensor, boxes: torch.Tensor) -> torch.Tensor:
+    """Pixels outside the instance's box are cleared: x in [x1, x2), y in [y1, y2) on the integer pixel grid (utils.py:772-786)."""
+    _, h, w = masks.shape
+    ys = torch.arange(h, device=masks.device)[None, :, None]
+    xs = torch.arange(w, device=masks.device)[None, None, :]
+    x1, y1, x2, y2 = boxes.to(masks.device).T
+    inside = (xs >= x1[:, None, None]) & (xs < x2[:, None, None]) & (ys >= y1[:, None, None]) & (ys < y2[:, None, None])
+    return masks * inside.to(masks.dtype)
+
+
 def preds_postprocess(inputs: torch.Tensor, outputs: Dict[str, torch.Tensor], orig_sizes, num_labels: int,
                       keep_ratio: bool, conf_thresh: float, num_top_queries: int = 300,
                       use_focal_loss: bool = True) -> List[Dict[str, torch.Tensor]]:
     """List (batch) of {"labels", "boxes", "scores", "all_boxes", "all_scores", "all_labels"} with the reference's
     meaning (train.py:240-332): top-K (query, class) pairs by sigmoid score, boxes mapped to the original frame,
     `labels/boxes/scores` thresholded at conf_thresh, `all_*` unthresholded.  Everything stays on the device until the
-    final per-image split (the reference calls .cpu() six times per image)."""
+    final per-image split (the reference calls .cpu() six times per image).  With a mask head (`pred_masks` [B, Q, Hm, Wm]) the
+    kept queries' masks are mapped to the original frame, binarised with >= conf_thresh and cleared outside their boxes
+    (train.py:305-329); they STAY on the device as uint8 (the validator bit-packs them there - the reference moves them to the
+    host and RLE-encodes them)."""
     logits, boxes = outputs["pred_logits"], outputs["pred_boxes"]
+    pred_masks = outputs.get("pred_masks")
     B, Q, C = logits.shape
     if not use_focal_loss:
         raise NotImplementedError("softmax scoring is off the default path (configs.py: use_focal_loss=True)")
@@ -72,17 +117,31 @@ def preds_postprocess(inputs: torch.Tensor, outputs: Dict[str, torch.Tensor], or
     results = []
     for b in range(B):
         kb = keep_c[b]
-        results.append({"labels": labels_c[b][kb], "boxes": boxes_c[b][kb], "scores": scores_c[b][kb],
-                        "all_boxes": boxes_c[b], "all_scores": scores_c[b], "all_labels": labels_c[b]})
+        res = {"labels": labels_c[b][kb], "boxes": boxes_c[b][kb], "scores": scores_c[b][kb],
+               "all_boxes": boxes_c[b], "all_scores": scores_c[b], "all_labels": labels_c[b]}
+        if pred_masks is not None and int(kb.sum()) > 0:
+            osz = torch.as_tensor(orig_sizes)[b].reshape(1, 2)
+            probs = process_masks(pred_masks[b, qidx[b][keep[b]]].unsqueeze(0), inputs.shape[2:], osz, keep_ratio)[0]
+            res["masks"] = cleanup_masks((probs >= conf_thresh).to(torch.uint8), top_boxes[b][keep[b]])
+        results.append(res)
     return results
 
 
 def gt_postprocess(inputs: torch.Tensor, targets, orig_sizes, keep_ratio: bool):
-    """Ground truth in the same frame as `preds_postprocess` (reference train.py:334-365): {"labels", "boxes"} per image."""
+    """Ground truth in the same frame as `preds_postprocess` (reference train.py:334-378): {"labels", "boxes"[, "masks"]} per
+    image; masks (network-size rasters) are mapped to the original frame and re-thresholded at 0.5, uint8 on their device."""
     out = []
     for t, osz in zip(targets, torch.as_tensor(orig_sizes).tolist()):
         bx = t["boxes"]
         if bx.numel():
             bx = process_boxes(bx[None], inputs.shape[2:], [osz], keep_ratio, bx.device)[0]
-        out.append({"labels": t["labels"].cpu(), "boxes": bx.cpu()})
+        res = {"labels": t["labels"].cpu(), "boxes": bx.cpu()}
+        m = t.get("masks")
+        if m is not None:
+            if m.numel() > 0:
+                pm = process_masks(m.to(inputs.device, torch.float32).unsqueeze(0), inputs.shape[2:], [osz], keep_ratio)[0]
+                res["masks"] = (pm >= 0.5).to(torch.uint8)
+            else:
+                res["masks"] = torch.zeros((0, int(osz[0]), int(osz[1])), dtype=torch.uint8, device=inputs.device)
+        out.append(res)
     return out

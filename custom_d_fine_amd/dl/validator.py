@@ -10,9 +10,15 @@ Counterpart of the reference's `Validator` (`src/dl/validator.py:21-451`, box pa
   * the reference delegates mAP to torchmetrics + faster_coco_eval (absent here): `coco_map` below is a plain restatement of
     the COCO protocol (IoU 0.50:0.05:0.95, 101-point interpolated precision, at most 100 detections per image, all areas) -
     **parity unpinned** against torchmetrics itself.
+  * instance masks (`_compute_metrics_and_confusion_matrix_masks`, `:453-568`): when predictions AND ground truth carry masks
+    the matching runs on the pairwise MASK IoU instead of the box IoU (predictions of another resolution are resized to the
+    ground truth's with bilinear interpolation and re-thresholded at 0.5, float masks / `mask_probs` are binarised with
+    `> conf_thresh`); `mAP_50_mask` / `mAP_50_95_mask` follow the same protocol as the box mAP on the mask IoU.  Device-resident
+    masks are bit-packed and intersected with popcounts (`csrc/metrics.hip`, values bit-identical to the reference's fp32
+    matmul route); the pycocotools RLE round trip the reference uses to keep a validation set in host memory
+    (`src/dl/utils.py:1040-1160`) has no counterpart - masks stay on the device, one bit per pixel when packed.
 The pairwise IoUs of all images are computed in ONE batched pass on the device the boxes live on (padded [images, P, G]); the
-greedy matching - inherently sequential per image - runs on the host over the thresholded pairs.  Masks are out of scope here
-(`ignore_masks=True` semantics of the reference)."""
+greedy matching - inherently sequential per image - runs on the host over the thresholded pairs."""
 from collections import defaultdict
 from typing import Dict, List
 
@@ -46,6 +52,41 @@ def pairwise_iou_batched(pred_boxes: List[torch.Tensor], gt_boxes: List[torch.Te
     return [iou[i, :len(p), :len(g)] for i, (p, g) in enumerate(zip(pred_boxes, gt_boxes))]
 
 
+def _nhw(m):
+    if m.ndim == 4 and m.shape[1] == 1:
+        m = m[:, 0]
+    return m
+
+
+def binary_masks(sample, conf_thresh, keys=("masks", "mask_probs")):
+    """[N, H, W] masks of a sample as the reference binarises them (validator.py:203-253): uint8 as is, anything else
+    `> conf_thresh`; None when the sample has none."""
+    for k in keys:
+        m = sample.get(k)
+        if m is not None and hasattr(m, "numel") and m.numel() > 0:
+            m = _nhw(m)
+            return m if m.dtype in (torch.uint8, torch.bool) else (m > float(conf_thresh)).to(torch.uint8)
+    return None
+
+
+def pairwise_mask_iou(pm: torch.Tensor, gm: torch.Tensor, thresh: float = 0.5) -> np.ndarray:
+    """[Np, H, W] x [Ng, H, W] -> [Np, Ng] IoU (validator.py:283-293).  uint8 / bool masks count non-zero pixels, float masks
+    pixels `> thresh`.  On the device: bit-packed masks + popcounts (csrc/metrics.hip); host tensors take the reference's
+    composition."""
+    if pm.shape[0] == 0 or gm.shape[0] == 0:
+        return np.zeros((pm.shape[0], gm.shape[0]), dtype=np.float32)
+    if pm.is_cuda:
+        from .. import hip
+        return hip.mask_iou_bits(hip.mask_pack_bits(pm, thresh), hip.mask_pack_bits(gm.to(pm.device), thresh)).cpu().numpy()
+
+    def as01(m):
+        return (m != 0 if m.dtype in (torch.uint8, torch.bool) else m > thresh).to(torch.float32).flatten(1)
+    a, b = as01(pm), as01(gm)
+    inter = a @ b.T
+    union = a.sum(1, keepdim=True) + b.sum(1, keepdim=True).T - inter
+    return torch.where(union > 0, inter / union, torch.zeros_like(union)).numpy()
+
+
 class Validator:
     def __init__(self, gt: List[Dict[str, torch.Tensor]], preds: List[Dict[str, torch.Tensor]], label_to_name: Dict[int, str],
                  conf_thresh=0.5, iou_thresh=0.5, compute_maps=True) -> None:
@@ -59,9 +100,36 @@ class Validator:
         self.conf_matrix = None
         self.metrics_per_class = None
         self.class_to_idx = None
+        # masks take part when both sides carry them (validator.py:69-79)
+        self.use_masks = any(binary_masks(p, conf_thresh, ("masks",)) is not None for p in preds) and \
+            any(binary_masks(g, conf_thresh, ("masks",)) is not None for g in gt)
+        self._mask_ious = None
+
+    def mask_ious(self):
+        """Per image the [P, G] mask IoU matrix (predictions resized to the ground truth's resolution when they differ:
+        bilinear, align_corners=False, > 0.5 - validator.py:485-491)."""
+        if self._mask_ious is None:
+            out = []
+            for p, g in zip(self.preds, self.gt):
+                pm, gm = binary_masks(p, self.conf_thresh), binary_masks(g, self.conf_thresh, ("masks",))
+                n_p, n_g = len(p["labels"]), len(g["labels"])
+                if pm is None or gm is None or n_p == 0 or n_g == 0:
+                    out.append(np.zeros((n_p, n_g), dtype=np.float32))
+                    continue
+                if pm.shape[-2:] != gm.shape[-2:]:
+                    if pm.is_cuda:
+                        from .. import kernels
+                        r = kernels.bilinear_resize(pm.unsqueeze(0).float().contiguous(), tuple(gm.shape[-2:]))[0]
+                    else:
+                        r = torch.nn.functional.interpolate(pm.unsqueeze(1).float(), size=gm.shape[-2:], mode="bilinear",
+                                                            align_corners=False)[:, 0]
+                    pm = (r > 0.5).to(torch.uint8)
+                out.append(pairwise_mask_iou(pm, gm))
+            self._mask_ious = out
+        return self._mask_ious
 
     # ------------------------------------------------------------------------------------------------------------
-    def _match(self):
+    def _match(self, ignore_masks=False):
         per_class = defaultdict(lambda: {"TPs": 0, "FPs": 0, "FNs": 0, "IoUs": []})
         classes = set()
         pl = [p["labels"].cpu().numpy() for p in self.preds]
@@ -72,7 +140,10 @@ class Validator:
         idx = {c: i for i, c in enumerate(classes)}
         nc = len(classes)
         conf = np.zeros((nc + 1, nc + 1), dtype=int)
-        ious = pairwise_iou_batched([p["boxes"].reshape(-1, 4) for p in self.preds], [g["boxes"].reshape(-1, 4) for g in self.gt])
+        if self.use_masks and not ignore_masks:
+            ious = self.mask_ious()
+        else:
+            ious = pairwise_iou_batched([p["boxes"].reshape(-1, 4) for p in self.preds], [g["boxes"].reshape(-1, 4) for g in self.gt])
         for iou, plab, glab in zip(ious, pl, gl):
             n_p, n_g = len(plab), len(glab)
             used_p, used_g = np.zeros(n_p, bool), np.zeros(n_g, bool)
@@ -107,8 +178,8 @@ class Validator:
                 per_class[b]["IoUs"].append(0)
         return per_class, conf, idx
 
-    def compute_metrics(self, extended=False) -> Dict[str, float]:
-        self.metrics_per_class, self.conf_matrix, self.class_to_idx = self._match()
+    def compute_metrics(self, extended=False, ignore_masks=False) -> Dict[str, float]:
+        self.metrics_per_class, self.conf_matrix, self.class_to_idx = self._match(ignore_masks)
         tps = fps = fns = 0
         ious, ext = [], {}
         for key, v in self.metrics_per_class.items():
@@ -128,23 +199,28 @@ class Validator:
         if self.compute_maps:
             m = coco_map(self.gt, self.preds)
             out["mAP_50"], out["mAP_50_95"] = m["map_50"], m["map"]
+            if self.use_masks and not ignore_masks:            # validator.py:117-121 (segm mAP of the kept predictions' masks)
+                mm = coco_map(self.gt, self.preds, ious=self.mask_ious())
+                out["mAP_50_mask"], out["mAP_50_95_mask"] = mm["map_50"], mm["map"]
         if not extended:
             out.pop("extended_metrics", None)
         return out
 
 
-def coco_map(gt, preds, max_dets=100):
-    """COCO detection mAP (all areas): per class and IoU threshold t in 0.50:0.05:0.95 the detections of all images are sorted
+def coco_map(gt, preds, max_dets=100, ious=None):
+    """COCO detection mAP (all areas; `ious`: per image [P, G] IoU matrices of the thresholded predictions - the mask IoU of
+    the segmentation mAP - instead of the box IoU of the `all_*` / plain fields): per class and IoU threshold t in 0.50:0.05:0.95 the detections of all images are sorted
     by score, each is matched to the still-free ground truth of its image and class with the highest IoU >= t, precision is made
     monotonically non-increasing and sampled at 101 recall points; classes without ground truth are skipped."""
     thr = np.arange(0.5, 0.96, 0.05)
     rec_pts = np.linspace(0.0, 1.0, 101)
 
     def field(p, k):
-        return p.get(f"all_{k}", p[k])
+        return p[k] if ious is not None else p.get(f"all_{k}", p[k])
 
-    pb = [field(p, "boxes").reshape(-1, 4) for p in preds]
-    ious = pairwise_iou_batched(pb, [g["boxes"].reshape(-1, 4) for g in gt])
+    if ious is None:
+        pb = [field(p, "boxes").reshape(-1, 4) for p in preds]
+        ious = pairwise_iou_batched(pb, [g["boxes"].reshape(-1, 4) for g in gt])
     pl = [field(p, "labels").cpu().numpy() for p in preds]
     ps = [field(p, "scores").cpu().numpy() for p in preds]
     gl = [g["labels"].cpu().numpy() for g in gt]

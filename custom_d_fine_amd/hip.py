@@ -92,6 +92,9 @@ _SIGNATURES = {
     "dfine_conv_f32_wgrad_splits": (c_int, [_I, _I, _I, _I, _I, _I]),
     "dfine_conv_f32_wgrad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_upsample2_zero_f32": (c_int, [_P, _P, _L, _I, _I, _I, _I, _P]),
+    "dfine_mask_bits_words": (c_int64, [c_int64]),
+    "dfine_mask_pack_bits": (c_int, [_P, _I, _F, _I, c_int64, _P, _P]),
+    "dfine_mask_iou_bits": (c_int, [_P, _P, _I, _I, c_int64, _P, _P]),
     "dfine_mosaic_place_u8": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_warp_affine_u8": (c_int, [_P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "dfine_affine_boxes": (c_int, [_P, _P, _P, _I, _P, _F, _F, _F, _F, _P]),
@@ -1164,6 +1167,26 @@ def conv1x1_batched_weights(x, w2, cout):
     with _timed("conv1x1", 2.0 * B * H * W * cin * cout, io=2.0 * B * H * W * (cin + cout) + 2.0 * cin * cout):
         _check(_lib.dfine_conv1x1_bw_bf16(_ptr(x), _ptr(w2), _ptr(y), B, cin, cout, H * W, _stream()), "dfine_conv1x1_bw_bf16")
     return y
+
+
+# ------------------------------------------------------------------------------------- evaluation masks (f2)
+def mask_pack_bits(masks, thresh=0.5):
+    """masks [N, H, W] uint8 (bit = value != 0) / float32 / bfloat16 (bit = value > thresh), contiguous -> [N, words] int64
+    bit-packed masks (the layout is private to the library: only mask_iou_bits reads it)."""
+    n, hw = masks.shape[0], int(masks.shape[-2]) * int(masks.shape[-1])
+    dt = {torch.uint8: 0, torch.bool: 0, torch.float32: 1, torch.bfloat16: 2}[masks.dtype]
+    words = int(_lib.dfine_mask_bits_words(hw))
+    bits = torch.empty(n, words, device=masks.device, dtype=torch.int64)
+    _check(_lib.dfine_mask_pack_bits(_ptr(masks.contiguous()), dt, float(thresh), n, hw, _ptr(bits), _stream()), "dfine_mask_pack_bits")
+    return bits
+
+
+def mask_iou_bits(pred_bits, gt_bits):
+    """[Np, words], [Ng, words] packed masks of one image size -> [Np, Ng] float32 IoU."""
+    iou = torch.zeros(pred_bits.shape[0], gt_bits.shape[0], device=pred_bits.device, dtype=torch.float32)
+    _check(_lib.dfine_mask_iou_bits(_ptr(pred_bits), _ptr(gt_bits), pred_bits.shape[0], gt_bits.shape[0], pred_bits.shape[1],
+                                    _ptr(iou), _stream()), "dfine_mask_iou_bits")
+    return iou
 
 
 # ------------------------------------------------------------------------------------- device data path (f3)

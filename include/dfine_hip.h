@@ -574,6 +574,21 @@ int64_t dfine_ln_fused_bwd_ws_floats(int64_t rows, int D);
 int dfine_maps_tokens_bf16(const void *map, void *tokens, int B, int C, int HW, int L, int row0, int to_tokens,
                            void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * (f2)  Instance-mask IoU of the evaluation hand-off.  Replaces Validator._pairwise_mask_iou
+ * (src/dl/validator.py:283-293: uint8 masks -> fp32 matmul -> areas -> inter / union) and the pycocotools RLE round trip
+ * the reference stores validation masks through (src/dl/utils.py:1040-1160) with 1-bit-per-pixel device masks.
+ *   dfine_mask_bits_words(HW): uint64 words per packed mask.
+ *   dfine_mask_pack_bits: masks [N, HW]; dtype 0 = uint8 (bit = value != 0), 1 = f32, 2 = bf16 (bit = value > thresh, the
+ *     reference's `m > conf_thresh`); bits [N, words] uint64.  The bit order inside a 256-pixel chunk is private to the
+ *     library (the same permutation for every mask).
+ *   dfine_mask_iou_bits: iou [Np, Ng] f32 = |p & g| / |p | g| (0 where the union is empty), bit-identical to the reference's
+ *     fp32 route for H * W < 2^24.
+ */
+int64_t dfine_mask_bits_words(int64_t HW);
+int dfine_mask_pack_bits(const void *masks, int dtype, float thresh, int N, int64_t HW, void *bits, void *stream);
+int dfine_mask_iou_bits(const void *pred_bits, const void *gt_bits, int Np, int Ng, int64_t words, float *iou, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -242,3 +242,35 @@ def make_validator_case(seed, n_images=12, n_classes=5):
                       "boxes": torch.tensor(np.array(p_boxes, dtype=np.float32)).reshape(-1, 4),
                       "scores": torch.tensor(p_scores, dtype=torch.float32)})
     return gt, preds
+
+
+def make_validator_mask_case(seed, n_images=10, n_classes=4, hw=(96, 128), pred_hw=None, probs=False):
+    """`make_validator_case` with instance masks: ground truth = filled ellipses inside the boxes (uint8 [G, H, W]); predictions
+    = the jittered boxes' ellipses, `masks` either uint8 or float probabilities (soft edge, binarised by the validator with
+    > conf_thresh); `pred_hw` gives the predictions another resolution (the validator resizes them)."""
+    import numpy as np
+    import torch
+    gt, preds = make_validator_case(seed, n_images, n_classes)
+    H, W = hw
+    ph, pw = pred_hw or hw
+
+    def ellipses(boxes, h, w, soft, rng):
+        ys = torch.arange(h, dtype=torch.float32)[None, :, None] + 0.5
+        xs = torch.arange(w, dtype=torch.float32)[None, None, :] + 0.5
+        b = boxes.clone() * torch.tensor([w / 560.0, h / 560.0, w / 560.0, h / 560.0])
+        cx, cy = (b[:, 0] + b[:, 2])[:, None, None] / 2, (b[:, 1] + b[:, 3])[:, None, None] / 2
+        rx, ry = ((b[:, 2] - b[:, 0]) / 2).clamp(min=1.0)[:, None, None], ((b[:, 3] - b[:, 1]) / 2).clamp(min=1.0)[:, None, None]
+        d = ((xs - cx) / rx) ** 2 + ((ys - cy) / ry) ** 2
+        if soft:
+            return torch.sigmoid((1.0 - d) * 4.0 + torch.tensor(rng.normal(0, 0.3, d.shape), dtype=torch.float32))
+        return (d <= 1.0).to(torch.uint8)
+
+    rng = np.random.default_rng(seed + 100)
+    for g, p in zip(gt, preds):
+        g["masks"] = ellipses(g["boxes"], H, W, False, rng) if len(g["labels"]) else torch.zeros((0, H, W), dtype=torch.uint8)
+        if len(p["labels"]):
+            m = ellipses(p["boxes"], ph, pw, probs, rng)
+        else:
+            m = torch.zeros((0, ph, pw), dtype=torch.float32 if probs else torch.uint8)
+        p["masks"] = m                                          # float masks are binarised by the validator with > conf_thresh
+    return gt, preds

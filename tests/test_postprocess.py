@@ -143,3 +143,56 @@ def test_hip_postprocessor_nan_logits_rank_first(cuda):
     assert torch.isnan(scores[:, 0]).all() and not torch.isnan(scores[:, 1:]).any()
     assert (qidx[:, 0].cpu() * 80 + labels[:, 0].cpu()).tolist() == ref.indices[:, 0].tolist() == [7 * 80 + 3, 299 * 80 + 79]
     np.testing.assert_allclose(scores[:, 1:].cpu().numpy(), ref.values[:, 1:].numpy(), atol=1e-6, rtol=0)
+
+
+# ------------------------------------------------------------------------------------------------ masks of the hand-off
+def _check_process_masks(device):
+    from custom_d_fine_amd.dl.postprocess import cleanup_masks, process_masks
+    g = np.load(f"{G}/postprocess_masks.npz")
+    pm = torch.tensor(g["pred_masks"]).to(device)
+    orig = g["orig_sizes"]
+    for keep in (0, 1):
+        got = process_masks(pm, (80, 96), orig, bool(keep))
+        for b, m in enumerate(got):
+            want = g[f"process_masks/keep{keep}/{b}"].astype(np.float32)
+            assert m.shape == want.shape
+            assert np.abs(m.cpu().numpy() - want).max() <= 1e-3            # fixture stored as fp16
+            bits = np.unpackbits(g[f"process_masks/keep{keep}/{b}_bin"], axis=-1)[..., : m.shape[-1]].astype(bool)
+            flips = ((m.cpu().numpy() >= 0.5) != bits) & (np.abs(want - 0.5) > 2e-3)   # binarisation agrees away from the threshold
+            assert not flips.any()
+    mb = (process_masks(pm[:1], (80, 96), orig[:1], False)[0] >= 0.5).to(torch.uint8)
+    got = cleanup_masks(mb, torch.tensor(g["cleanup/boxes"]).to(device)).cpu().numpy()
+    want = np.unpackbits(g["cleanup/masks"], axis=-1)[..., : got.shape[-1]]
+    near = np.abs(process_masks(pm[:1], (80, 96), orig[:1], False)[0].cpu().numpy() - 0.5) <= 2e-3
+    assert ((got != want) & ~near).sum() == 0
+    assert got[4].sum() == 0 and got[1].sum() == mb[1].sum().item()        # empty box clears everything, full-frame box nothing
+
+
+def test_process_and_cleanup_masks_match_reference():
+    _check_process_masks("cpu")
+
+
+@pytest.mark.gpu
+def test_process_and_cleanup_masks_match_reference_on_device(cuda):
+    """The same goldens through the HIP bilinear kernel."""
+    _check_process_masks(cuda)
+
+
+def test_preds_postprocess_with_masks_contract(oracle_backend):
+    from custom_d_fine_amd.dl.postprocess import gt_postprocess, preds_postprocess
+    logits, boxes, orig = helpers.make_postprocess_case(0)
+    B, Q = logits.shape[:2]
+    torch.manual_seed(0)
+    out = {"pred_logits": torch.tensor(logits), "pred_boxes": torch.tensor(boxes), "pred_masks": torch.rand(B, Q, 40, 40)}
+    res = preds_postprocess(torch.zeros(B, 3, 160, 160), out, orig, logits.shape[-1], False, 0.5)
+    for r, osz in zip(res, orig):
+        if len(r["labels"]):
+            assert r["masks"].dtype == torch.uint8 and tuple(r["masks"].shape) == (len(r["labels"]), int(osz[0]), int(osz[1]))
+            x1, y1, x2, y2 = r["boxes"][0].tolist()
+            m = r["masks"][0]
+            assert m[: int(np.floor(y1))].sum() == 0 and m[:, : int(np.floor(x1))].sum() == 0    # nothing outside the box
+    tg = [{"labels": torch.tensor([1]), "boxes": torch.tensor([[0.5, 0.5, 0.4, 0.4]]), "masks": torch.ones(1, 160, 160)},
+          {"labels": torch.zeros(0, dtype=torch.int64), "boxes": torch.zeros(0, 4), "masks": torch.zeros(0, 160, 160)}]
+    gt = gt_postprocess(torch.zeros(2, 3, 160, 160), tg, orig[:2], False)
+    assert tuple(gt[0]["masks"].shape) == (1, int(orig[0][0]), int(orig[0][1])) and gt[0]["masks"].min() == 1
+    assert tuple(gt[1]["masks"].shape) == (0, int(orig[1][0]), int(orig[1][1]))

@@ -114,3 +114,82 @@ def test_device_resident_boxes(cuda):
     b = Validator(gt_d, pr_d, {i: f"c{i}" for i in range(5)}).compute_metrics()
     for k in a:
         assert abs(float(a[k]) - float(b[k])) < 1e-6, k
+
+
+# ------------------------------------------------------------------------------------------------ instance masks
+MASK_CASES = {"dense": {}, "probs": {"probs": True}, "resized": {"pred_hw": (48, 64)}, "resized_probs": {"pred_hw": (60, 80), "probs": True}}
+
+
+def _check_mask_metrics(name, seed, device):
+    g = np.load(f"{G}/validator_masks.npz")
+    k = f"{name}_s{seed}"
+    gt, preds = helpers.make_validator_mask_case(seed, **MASK_CASES[name])
+    gt = [{n: t.to(device) for n, t in d.items()} for d in gt]
+    preds = [{n: t.to(device) for n, t in d.items()} for d in preds]
+    v = Validator(gt, preds, {i: f"c{i}" for i in range(5)}, conf_thresh=0.5, iou_thresh=0.5, compute_maps=False)
+    assert v.use_masks
+    m = v.compute_metrics(extended=True)
+    for nm in ("TPs", "FPs", "FNs"):
+        assert m[nm] == int(g[f"{k}/{nm}"]), nm
+    for nm in ("f1", "precision", "recall"):
+        assert abs(m[nm] - float(g[f"{k}/{nm}"])) < 1e-12, nm
+    assert abs(m["iou"] - float(g[f"{k}/iou"])) < 1e-7
+    assert np.array_equal(v.conf_matrix, g[f"{k}/conf_matrix"])
+    ext = m["extended_metrics"]
+    assert sorted(ext) == g[f"{k}/ext_keys"].tolist()
+    np.testing.assert_allclose([float(ext[x]) for x in sorted(ext)], g[f"{k}/ext_vals"], rtol=0, atol=1e-7)
+    if name == "dense":                                    # the IoU matrices themselves: integer counts + one fp32 division
+        for i, iou in enumerate(v.mask_ious()):
+            assert np.array_equal(np.asarray(iou, dtype=np.float32), g[f"{k}/iou{i}"]), i
+    # box-only metrics of the same lists are still available (ignore_masks, validator.py:109-113)
+    mb = v.compute_metrics(ignore_masks=True)
+    assert mb["TPs"] + mb["FNs"] == m["TPs"] + m["FNs"]
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+@pytest.mark.parametrize("name", list(MASK_CASES))
+def test_mask_metrics_match_reference(name, seed):
+    _check_mask_metrics(name, seed, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2])
+@pytest.mark.parametrize("name", list(MASK_CASES))
+def test_mask_metrics_match_reference_on_device(cuda, name, seed):
+    """Device-resident masks: bit-packed (dfine_mask_pack_bits) and intersected with popcounts (dfine_mask_iou_bits), resized
+    with the HIP bilinear kernel - against the reference's goldens; the IoU matrices of the dense case bit for bit."""
+    _check_mask_metrics(name, seed, cuda)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("hw", [(64, 64), (37, 53), (640, 640), (5, 3)])
+def test_packed_mask_iou_matches_matmul_route(cuda, dtype, hw):
+    """Ragged sizes (H * W not a multiple of 4 / 256), empty masks, full masks, all storage types."""
+    from custom_d_fine_amd import hip
+    from custom_d_fine_amd.dl.validator import pairwise_mask_iou
+    torch.manual_seed(hw[0] * 7 + hw[1])
+    pm = torch.rand(7, *hw, device=cuda)
+    gm = torch.rand(5, *hw, device=cuda)
+    pm[0] = 0
+    pm[1] = 1
+    gm[0] = 0
+    gm[1] = 1
+    if dtype == torch.uint8:
+        a, b = (pm > 0.6).to(torch.uint8), (gm > 0.4).to(torch.uint8)
+    else:
+        a, b = pm.to(dtype), gm.to(dtype)
+    got = pairwise_mask_iou(a, b, 0.5)
+    want = pairwise_mask_iou(a.cpu().float() if dtype != torch.uint8 else a.cpu(), b.cpu().float() if dtype != torch.uint8 else b.cpu(), 0.5)
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+    assert got[0].max() == 0 and got[1, 1] == 1.0
+    assert hip.mask_pack_bits(a).shape == (7, 4 * ((hw[0] * hw[1] + 255) // 256))
+
+
+def test_mask_map_is_reported_and_bounded():
+    gt, preds = helpers.make_validator_mask_case(3)
+    m = Validator(gt, preds, {i: f"c{i}" for i in range(5)}, compute_maps=True).compute_metrics()
+    assert 0.0 <= m["mAP_50_95_mask"] <= m["mAP_50_mask"] <= 1.0
+    perfect = [{"labels": g["labels"], "boxes": g["boxes"], "masks": g["masks"], "scores": torch.ones(len(g["labels"]))} for g in gt]
+    mp = Validator(gt, perfect, {i: f"c{i}" for i in range(5)}, compute_maps=True).compute_metrics()
+    assert abs(mp["mAP_50_95_mask"] - 1.0) < 1e-9 and mp["FPs"] == 0 and mp["FNs"] == 0

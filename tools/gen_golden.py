@@ -186,6 +186,24 @@ def gen_postprocess():
             out[f"s{seed}/process_boxes/keep{int(keep_ratio)}"] = pb.numpy()
         out[f"s{seed}/orig_sizes"] = orig
     save("postprocess.npz", **out)
+    # mask side of the evaluation hand-off: process_masks (network-size probabilities -> original frame, letterbox padding
+    # removed) and cleanup_masks (pixels outside the box cleared), src/dl/utils.py:715-787
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    pm = torch.rand(2, 5, 20, 24, generator=g)
+    orig = torch.tensor([[60, 100], [150, 75]])
+    out["pred_masks"] = pm.numpy()
+    out["orig_sizes"] = orig.numpy()
+    for keep_ratio in (False, True):
+        ml = ref.dl_utils.process_masks(pm, (80, 96), orig, keep_ratio)
+        for b, m in enumerate(ml):
+            out[f"process_masks/keep{int(keep_ratio)}/{b}"] = m.numpy().astype(np.float16)
+            out[f"process_masks/keep{int(keep_ratio)}/{b}_bin"] = np.packbits((m >= 0.5).numpy(), axis=-1)
+    boxes = torch.tensor([[10.0, 5.0, 60.0, 50.0], [0.0, 0.0, 100.0, 60.0], [30.5, 20.2, 31.0, 50.7], [75.0, 50.0, 99.0, 59.0], [5.0, 5.0, 5.0, 5.0]])
+    mb = (ref.dl_utils.process_masks(pm[:1], (80, 96), orig[:1], False)[0] >= 0.5).to(torch.uint8)
+    out["cleanup/boxes"] = boxes.numpy()
+    out["cleanup/masks"] = np.packbits(ref.dl_utils.cleanup_masks(mb, boxes).numpy(), axis=-1)
+    save("postprocess_masks.npz", **out)
 
 
 # ------------------------------------------------------------------ A10 / A15: mask decoder, mask losses, mask costs
@@ -374,6 +392,30 @@ def gen_validator():
             out[f"{k}/conf_matrix"] = v.conf_matrix
             out[f"{k}/classes"] = np.array(sorted(v.class_to_idx))
     save("validator.npz", **out)
+    # instance masks: the matching runs on the pairwise mask IoU (validator.py:453-568); dense uint8 masks, float mask_probs
+    # (binarised with > conf_thresh) and predictions of another resolution (bilinear resize + > 0.5)
+    out = {}
+    for name, kw in (("dense", {}), ("probs", {"probs": True}), ("resized", {"pred_hw": (48, 64)}), ("resized_probs", {"pred_hw": (60, 80), "probs": True})):
+        for seed in (1, 2):
+            gt, preds = helpers.make_validator_mask_case(seed, **kw)
+            import copy
+            v = V.Validator(copy.deepcopy(gt), copy.deepcopy(preds), {i: f"c{i}" for i in range(5)}, conf_thresh=0.5,
+                            iou_thresh=0.5, compute_maps=False)
+            assert v.use_masks
+            m = v.compute_metrics(extended=True)
+            k = f"{name}_s{seed}"
+            for nm in ("f1", "precision", "recall", "iou", "TPs", "FPs", "FNs"):
+                out[f"{k}/{nm}"] = np.float64(m[nm])
+            ext = m["extended_metrics"]
+            out[f"{k}/ext_keys"] = np.array(sorted(ext))
+            out[f"{k}/ext_vals"] = np.array([float(ext[x]) for x in sorted(ext)], dtype=np.float64)
+            out[f"{k}/conf_matrix"] = v.conf_matrix
+            # the pairwise IoU matrices themselves (bit-exact target of the packed-mask kernels), dense same-size case only
+            if name == "dense":
+                for i, (p, g) in enumerate(zip(preds, gt)):
+                    out[f"{k}/iou{i}"] = v._pairwise_mask_iou(p["masks"], g["masks"]).numpy().astype(np.float32) \
+                        if len(p["labels"]) and len(g["labels"]) else np.zeros((len(p["labels"]), len(g["labels"])), np.float32)
+    save("validator_masks.npz", **out)
 
 
 GENERATORS = {
