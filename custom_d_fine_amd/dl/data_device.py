@@ -202,13 +202,26 @@ class YoloTxtDataset:
         boxes, _ = parse_yolo_label_file(lab) if lab.exists() else (np.zeros((0, 5), dtype=np.float32), [])
         return img, boxes
 
-    def batch(self, indices, device):
+    def batch(self, indices, device, mosaic_prob=0.0, rng=random):
+        """mosaic_prob: with that probability a sample becomes the 2 x 2 mosaic of itself and three other images of the folder,
+        randomly scaled / translated into the target frame (the reference's `_load_mosaic` + `random_affine`, dataset.py:258-345,
+        drawn per sample like dataset.py:386-392) - pixel work and box transform on the device (csrc/data.hip)."""
         device = torch.device(device)
         th, tw = self.img_size
         images, targets = [], []
         for i in indices:
             img, boxes = self._load(i)
             h0, w0 = img.shape[:2]
+            if device.type == "cuda" and mosaic_prob > 0 and rng.random() < mosaic_prob:
+                picks = [i] + [rng.randrange(len(self)) for _ in range(3)]
+                loaded = [(img, boxes)] + [self._load(j) for j in picks[1:]]
+                frames = [torch.from_numpy(np.ascontiguousarray(f[..., ::-1])).to(device) for f, _ in loaded]
+                canvas, cls, xyxy = mosaic_affine(frames, [b for _, b in loaded], (th, tw), rng)
+                images.append(kernels.preprocess_frames(canvas[None], (th, tw), (th, tw))[0])
+                scale = torch.tensor([tw, th, tw, th], dtype=torch.float32, device=device)
+                cxcywh = torch.cat([(xyxy[:, :2] + xyxy[:, 2:]) / 2, xyxy[:, 2:] - xyxy[:, :2]], 1) / scale
+                targets.append({"labels": cls, "boxes": cxcywh, "orig_size": torch.tensor([th, tw], dtype=torch.int64, device=device)})
+                continue
             if device.type == "cuda":
                 frame = torch.from_numpy(np.ascontiguousarray(img[..., ::-1])).to(device)[None]     # the kernel takes BGR frames
                 x = kernels.preprocess_frames(frame, (th, tw), (th, tw))[0]

@@ -30,6 +30,7 @@ DEFAULTS = {
         "pretrained_model_path": None, "resume_path": None,
         "data_path": None,           # a folder with images/ + labels/ (YOLO txt): dl/data_device.YoloTxtDataset; None = synthetic batches
         "multiscale_prob": 0.0,      # the reference's train_collate_fn resize (dataset.py:667-694), on the device
+        "mosaic_prob": 0.0,          # 2 x 2 mosaic + random affine per sample (dataset.py:258-345,386-392), on the device
     },
 }
 
@@ -197,7 +198,7 @@ class Trainer:
             rng.shuffle(order)
             mine = order[self.rank::self.world]
             for i in range(0, len(mine) - t["batch_size"] + 1, t["batch_size"]):
-                images, targets = self._dataset.batch(mine[i: i + t["batch_size"]], self.device)
+                images, targets = self._dataset.batch(mine[i: i + t["batch_size"]], self.device, t.get("mosaic_prob", 0.0), rng)
                 if t.get("multiscale_prob", 0) and rng.random() < t["multiscale_prob"] and self.device.type == "cuda":
                     images, targets = data_device.multiscale_collate(images, targets, rng.choice([-2, -1, 1, 2]) * 32)
                 yield images, targets

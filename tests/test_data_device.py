@@ -174,3 +174,26 @@ def test_mosaic_affine_end_to_end(cuda, tmp_path):
         px = img[(y0 + y1) // 2, (x0 + x1) // 2]
         hits += int(np.abs(px - np.array([60 + 60 * c, 200 - 50 * c, 90 + 40 * c])).max() <= 3)
     assert hits >= max(1, int(0.6 * sum((b[2] - b[0] >= 6) and (b[3] - b[1] >= 6) for b in boxes.cpu().numpy())))
+
+
+@pytest.mark.gpu
+def test_dataset_batch_with_mosaic(cuda, tmp_path):
+    """`batch(..., mosaic_prob=1)`: every sample is a 2 x 2 mosaic warped into the target frame - the batch contract holds
+    (images in [0, 1], boxes normalised cxcywh inside the frame), the draw is reproducible, and the plain path is untouched."""
+    root = D.write_synthetic_yolo_dataset(tmp_path / "ds", n_images=6, size=(120, 160), num_classes=3, seed=3)
+    ds = D.YoloTxtDataset(root, img_size=(128, 160))
+    im1, t1 = ds.batch([0, 1, 2], cuda, mosaic_prob=1.0, rng=random.Random(5))
+    im2, t2 = ds.batch([0, 1, 2], cuda, mosaic_prob=1.0, rng=random.Random(5))
+    assert im1.shape == (3, 3, 128, 160) and im1.dtype == torch.float32 and 0.0 <= im1.min() and im1.max() <= 1.0
+    assert torch.equal(im1, im2) and all(torch.equal(a["boxes"], b["boxes"]) for a, b in zip(t1, t2))
+    n = 0
+    for t in t1:
+        assert t["labels"].dtype == torch.int64 and t["boxes"].shape == (len(t["labels"]), 4) and t["orig_size"].tolist() == [128, 160]
+        if len(t["labels"]):
+            b = t["boxes"]
+            assert (b[:, 2:] > 0).all() and (b[:, :2] - b[:, 2:] / 2 >= -1e-6).all() and (b[:, :2] + b[:, 2:] / 2 <= 1 + 1e-6).all()
+            n += len(b)
+    assert n >= 1
+    plain, _ = ds.batch([0, 1, 2], cuda)
+    plain0, _ = ds.batch([0, 1, 2], cuda, mosaic_prob=0.0, rng=random.Random(5))
+    assert torch.equal(plain, plain0) and not torch.equal(plain, im1)
