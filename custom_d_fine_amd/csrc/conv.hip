@@ -973,7 +973,7 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
 // no row halo in LDS, 3 instead of 9 accumulator sets); the next unit's X slab is prefetched into registers
 // while the MFMAs of the current one run, and the dY fragment of the next K step is loaded one step ahead.
 template <int KS>
-__global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
+__global__ __launch_bounds__(kConvThreads, 2) void conv_wgrad_kernel(      // two workgroups per CU: at most 256 registers
     const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy, float *__restrict__ part, int Cin,
     int Cout, int H, int W, int R, int strips, int total_units, int units_per_split, int nct64, int NP16,
     int CP16, int CS /* LDS elements per channel: = 8 (mod 128) -> the 16 channel lanes of a b128 read hit 16 distinct 16-byte bank slots */,
@@ -1051,6 +1051,15 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
         }
     };
 
+    // LDS element offset of this lane's fragment per K step (the same for every unit; pixels past a short last strip meet a
+    // zero dY fragment, whatever finite values the slab still holds there)
+    int poff[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int px = min(ks * 32 + 8 * (lane >> 4), R * W - 8);
+        const int row = px / W, col = px - row * W;
+        poff[ks] = (lane & 15) * CS + row * PW + LPAD + col;
+    }
     const int u0 = split * units_per_split, u1 = min(total_units, u0 + units_per_split);
     if (u0 < u1) fetch_unit(u0);
     __syncthreads();
@@ -1077,34 +1086,34 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
             if (px < tp && n_lane < Cout) av = *reinterpret_cast<const uint4 *>(dyb + (int64_t)n_lane * H * W + px);
             return av;
         };
-        uint4 av = KS == 3 ? acur[0] : load_a(0);
-        // LDS fragments of K step k0 + 32 are requested before the MFMAs of step k0 (the loop this replaces read one channel
-        // tile's fragment, waited for it, issued its KS MFMAs - an exposed LDS round trip per 3 MFMAs).  Channel tiles past
-        // Cin hold zeros and output rows past Cout meet a zero dY fragment: no per-tile branches.
-        uint4 fc[2][4];
-        uint32_t fl[2][4], fr[2][4];
-        auto read_step = [&](int k0, uint4 (&c1)[4], uint32_t (&lw)[4], uint32_t (&rw)[4]) {
-            const int px = k0 + 8 * (lane >> 4);
-            const int pxc = px < tp ? px : 0;
-            const int row = pxc / W, col = pxc - row * W;
+        if (KS == 3) {
+            // 3x3: the strip is <= 160 pixels = NKS static K steps, two channel tiles per request group, the next group in
+            // flight during the MFMAs of the current one.  The +-1 column shifts are made from the aligned 16-byte fragment and
+            // one neighbouring dword each side with v_alignbit (8 per 3 MFMAs).  (Unaligned 16-byte LDS reads work on gfx950 but
+            // are served in many passes: the kernel ran 2.6 x SLOWER with them.  The dynamic K-step index of the loop this
+            // replaces cost register-select chains and a division per step: 7.9 vector instructions per MFMA.)
+            uint4 fc[2][2];
+            uint32_t fl[2][2], fr[2][2];
+            auto read3 = [&](int hs, uint4 (&c)[2], uint32_t (&l)[2], uint32_t (&r)[2]) {
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                const uint16_t *e = xs + ((ct * 16 + (lane & 15)) * CS + row * PW + LPAD + col);
-                c1[ct] = *reinterpret_cast<const uint4 *>(e);
-                if (KS == 3) {
-                    lw[ct] = *reinterpret_cast<const uint32_t *>(e - 2);
-                    rw[ct] = *reinterpret_cast<const uint32_t *>(e + 8);
+                for (int q = 0; q < 2; ++q) {
+                    const uint16_t *e = xs + ((2 * (hs & 1) + q) * 16 * CS + poff[hs >> 1]);
+                    c[q] = *reinterpret_cast<const uint4 *>(e);
+                    l[q] = *reinterpret_cast<const uint32_t *>(e - 2);
+                    r[q] = *reinterpret_cast<const uint32_t *>(e + 8);
                 }
-            }
-        };
-        auto mfma_step = [&](const bf16x8 a, const uint4 (&c1v)[4], const uint32_t (&lwv)[4], const uint32_t (&rwv)[4]) {
+            };
+            read3(0, fc[0], fl[0], fr[0]);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                const uint4 c1 = c1v[ct];
-                if (KS == 1) {
-                    acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, c1), acc[ct][0], 0, 0, 0);
-                } else {
-                    const uint32_t lw = lwv[ct], rw = rwv[ct];
+            for (int hs = 0; hs < 2 * NKS; ++hs) {
+                if ((hs >> 1) * 32 >= tp) break;
+                if (hs + 1 < 2 * NKS && ((hs + 1) >> 1) * 32 < tp) read3(hs + 1, fc[(hs + 1) & 1], fl[(hs + 1) & 1], fr[(hs + 1) & 1]);
+                const bf16x8 a = __builtin_bit_cast(bf16x8, acur[hs >> 1]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int ct = 2 * (hs & 1) + q;
+                    const uint4 c1 = fc[hs & 1][q];
+                    const uint32_t lw = fl[hs & 1][q], rw = fr[hs & 1][q];
                     uint4 b0, b2;
                     b0.x = (lw >> 16) | (c1.x << 16); b0.y = (c1.x >> 16) | (c1.y << 16);
                     b0.z = (c1.y >> 16) | (c1.z << 16); b0.w = (c1.z >> 16) | (c1.w << 16);
@@ -1115,33 +1124,34 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(
                     acc[ct][KS - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, b2), acc[ct][KS - 1], 0, 0, 0);
                 }
             }
+            __syncthreads();
+            continue;
+        }
+        uint4 av = load_a(0);
+        uint4 fc[2][4];
+        auto read_step = [&](int k0, uint4 (&c1)[4]) {
+            const int px = k0 + 8 * (lane >> 4);
+            const int pxc = px < tp ? px : 0;
+            const int row = pxc / W, col = pxc - row * W;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+                c1[ct] = *reinterpret_cast<const uint4 *>(xs + ((ct * 16 + (lane & 15)) * CS + row * PW + LPAD + col));
         };
-        read_step(0, fc[0], fl[0], fr[0]);
+        auto mfma_step = [&](const bf16x8 a, const uint4 (&c1v)[4]) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+                acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, c1v[ct]), acc[ct][0], 0, 0, 0);
+        };
+        read_step(0, fc[0]);
         for (int k0 = 0; k0 < tp; k0 += 64) {                       // two K steps per trip: static register sets
-            uint4 an;
-            if (KS == 3) {                                        // select, no dynamic register indexing
-                const int ksn = (k0 >> 5) + 1;
-                an = make_uint4(0, 0, 0, 0);
-#pragma unroll
-                for (int q = 1; q < NKS; ++q) if (ksn == q) an = acur[q];
-            } else {
-                an = load_a(k0 + 32);                             // zero beyond the strip
-            }
+            const uint4 an = load_a(k0 + 32);                       // zero beyond the strip
             const bool second = k0 + 32 < tp;
-            if (second) read_step(k0 + 32, fc[1], fl[1], fr[1]);
-            mfma_step(__builtin_bit_cast(bf16x8, av), fc[0], fl[0], fr[0]);
+            if (second) read_step(k0 + 32, fc[1]);
+            mfma_step(__builtin_bit_cast(bf16x8, av), fc[0]);
             if (!second) break;
-            uint4 an2;
-            if (KS == 3) {
-                const int ksn = (k0 >> 5) + 2;
-                an2 = make_uint4(0, 0, 0, 0);
-#pragma unroll
-                for (int q = 2; q < NKS; ++q) if (ksn == q) an2 = acur[q];
-            } else {
-                an2 = load_a(k0 + 64);
-            }
-            if (k0 + 64 < tp) read_step(k0 + 64, fc[0], fl[0], fr[0]);
-            mfma_step(__builtin_bit_cast(bf16x8, an), fc[1], fl[1], fr[1]);
+            const uint4 an2 = load_a(k0 + 64);
+            if (k0 + 64 < tp) read_step(k0 + 64, fc[0]);
+            mfma_step(__builtin_bit_cast(bf16x8, an), fc[1]);
             av = an2;
         }
         __syncthreads();
