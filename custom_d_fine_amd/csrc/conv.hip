@@ -1373,11 +1373,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__r
 // The reduction index is the ROW index of both operands, so MFMA fragments (8 consecutive m per lane) are
 // columns of the staged tiles: read from LDS with 16-bit loads (row pitch 66 elements -> the 4 row groups of
 // a wave hit different banks).  LDS-read bound at ~20 % of the MFMA rate, far above what 2 GFLOP needs.
-__global__ __launch_bounds__(kConvThreads) void linear_wgrad_kernel(const uint16_t *__restrict__ x,
-                                                                    const uint16_t *__restrict__ dy,
-                                                                    float *__restrict__ part, float *__restrict__ db,
-                                                                    int M, int N, int K, int rows_per_split, int nct64,
-                                                                    int NP16, int CP16) {
+__device__ __forceinline__ void linear_wgrad_body(const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy,
+                                                  float *__restrict__ part, float *__restrict__ db, int M, int N, int K,
+                                                  int rows_per_split, int nct64, int NP16, int CP16, int tile, int split) {
     // Both MFMA operands are COLUMNS of row-major tiles (the reduction index m is the row): gfx950's LDS
     // transpose-read delivers them - lane (column i, group g) gets rows 4g..4g+3 (first read) and 16+4g..16+4g+3
     // (second read) of its column; A and B use the same row order, and a sum over m does not care about it.
@@ -1388,9 +1386,9 @@ __global__ __launch_bounds__(kConvThreads) void linear_wgrad_kernel(const uint16
     typedef short tr4 __attribute__((ext_vector_type(4)));
     typedef short tr8 __attribute__((ext_vector_type(8)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nt64 = blockIdx.x / nct64, ct64 = blockIdx.x - nt64 * nct64;
+    const int nt64 = tile / nct64, ct64 = tile - nt64 * nct64;
     const int n0 = nt64 * 64, k0 = ct64 * 64;
-    const int m_begin = blockIdx.y * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+    const int m_begin = split * rows_per_split, m_end = min(M, m_begin + rows_per_split);
     f32x4v acc[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
@@ -1462,16 +1460,39 @@ __global__ __launch_bounds__(kConvThreads) void linear_wgrad_kernel(const uint16
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = n0 + wave * 16 + 4 * (lane >> 4) + r;
-            if (n < NP16) part[((int64_t)blockIdx.y * NP16 + n) * CP16 + c] = acc[ct][r];
+            if (n < NP16) part[((int64_t)split * NP16 + n) * CP16 + c] = acc[ct][r];
         }
     }
     if (want_db && wave_active && (lane & 15) == 0) {          // per-split partial: no zero-fill, no atomics
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = n0 + wave * 16 + 4 * (lane >> 4) + r;
-            if (n < NP16) db[(int64_t)blockIdx.y * NP16 + n] = acc_b[r];
+            if (n < NP16) db[(int64_t)split * NP16 + n] = acc_b[r];
         }
     }
+}
+
+__global__ __launch_bounds__(kConvThreads) void linear_wgrad_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy,
+                                                                    float *__restrict__ part, float *__restrict__ db, int M, int N,
+                                                                    int K, int rows_per_split, int nct64, int NP16, int CP16) {
+    linear_wgrad_body(x, dy, part, db, M, N, K, rows_per_split, nct64, NP16, CP16, blockIdx.x, blockIdx.y);
+}
+
+// Many linear weight gradients in ONE launch.  A token-stream weight gradient (M = 15 744 rows, 256 x 256 outputs) is ~1000
+// short workgroups of three or four dependent memory round trips each: 16 us on the device for 2 us of traffic, 78 times per
+// step.  The backward ops only REGISTER their (x, dY) pair; all pairs of a flush run as one grid = (largest problem, problems)
+// whose latency chains overlap.  table rows of 8 x int64 = {x, dy, ws, M, N, K, rows per split, splits}; ws as in
+// dfine_linear_wgrad_bf16 with dw == NULL (weight partials, then bias partials).
+__global__ __launch_bounds__(kConvThreads) void linear_wgrad_group_kernel(const int64_t *__restrict__ table) {
+    const int64_t *e = table + (int64_t)blockIdx.y * 8;
+    const int M = (int)e[3], N = (int)e[4], K = (int)e[5], rows = (int)e[6], splits = (int)e[7];
+    const int nnt64 = (N + 63) / 64, nct64 = (K + 63) / 64, ntiles = nnt64 * nct64;
+    if ((int)blockIdx.x >= ntiles * splits) return;
+    const int split = blockIdx.x / ntiles, tile = blockIdx.x - split * ntiles;
+    const int np16 = (N + 15) / 16 * 16, cp16 = (K + 15) / 16 * 16;
+    float *ws = reinterpret_cast<float *>(e[2]);
+    linear_wgrad_body(reinterpret_cast<const uint16_t *>(e[0]), reinterpret_cast<const uint16_t *>(e[1]), ws,
+                      ws + (int64_t)splits * np16 * cp16, M, N, K, rows, nct64, np16, cp16, tile, split);
 }
 
 // Deferred split reduction of MANY weight gradients in one launch, accumulating into their final destination (the flat
@@ -1894,6 +1915,24 @@ int dfine_linear_wgrad_splits(int M, int N, int K) {
     int splits, rows;
     linear_wgrad_plan(M, N, K, &splits, &rows);
     return splits;
+}
+
+// Fills one 8 x int64 table row of dfine_linear_wgrad_group for a problem and returns the workgroups it needs.
+int dfine_linear_wgrad_group_row(const void *x, const void *dy, float *ws, int M, int N, int K, int64_t *row) {
+    if (!x || !dy || !ws || !row || M < 1 || N < 1 || K < 1) return DFINE_E_BADARG;
+    int splits, rows;
+    linear_wgrad_plan(M, N, K, &splits, &rows);
+    row[0] = (int64_t)x; row[1] = (int64_t)dy; row[2] = (int64_t)ws; row[3] = M; row[4] = N; row[5] = K; row[6] = rows; row[7] = splits;
+    return ((N + 63) / 64) * ((K + 63) / 64) * splits;
+}
+
+// table: device int64 [n_problems][8] (rows from dfine_linear_wgrad_group_row); max_blocks = the largest row's workgroup count.
+int dfine_linear_wgrad_group(const void *table, int n_problems, int max_blocks, void *stream) {
+    if (n_problems == 0) return DFINE_OK;
+    if (!table || n_problems < 0 || max_blocks < 1) return DFINE_E_BADARG;
+    hipLaunchKernelGGL(linear_wgrad_group_kernel, dim3(max_blocks, n_problems), dim3(kConvThreads), 0, (hipStream_t)stream,
+                       (const int64_t *)table);
+    return check_launch();
 }
 
 // table: device int64 [n_entries][8] = {partials, dst (f32, ACCUMULATED into), splits, Cout, Cin, taps, NP16, CP16};

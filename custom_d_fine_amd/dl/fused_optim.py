@@ -254,6 +254,7 @@ class FusedAdamWEMA:
 
     def _flush_deferred(self, lo=None, hi=None):
         import numpy as np
+        self.hip.linear_wgrad_flush()               # registered linear weight-gradient GEMMs -> their partial sums (one launch)
         take = [d for d in self._deferred if lo is None or lo <= d[1] < hi]
         if not take:
             return

@@ -70,6 +70,8 @@ _SIGNATURES = {
     "dfine_linear_wgrad_splits": (c_int, [_I, _I, _I]),
     "dfine_multi_wgrad_reduce": (c_int, [_P, _I, _I, _P]),
     "dfine_multi_wgrad_reduce_blocks": (c_int, [_I, c_int64]),
+    "dfine_linear_wgrad_group_row": (c_int, [_P, _P, _P, _I, _I, _I, _P]),
+    "dfine_linear_wgrad_group": (c_int, [_P, _I, _I, _P]),
     "dfine_linear_act_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_multi_cast_bf16_t": (c_int, [_P, _I, _P]),
     "dfine_act_fwd_bf16": (c_int, [_P, _P, _L, _I, _P]),
@@ -911,17 +913,54 @@ def attn_backward(q, k, v, o, dout, lse2, num_heads, dq, dk, dv, mask=None):
 _LW_WS = {}
 
 
+_LW_GROUP = os.environ.get("DFINE_LINEAR_WGRAD_GROUP", "1") == "1"
+_LW_PENDING = []            # (x2d, dy2d, ws, M, N, K) registered since the last linear_wgrad_flush
+
+
 def linear_wgrad_partials(x2d, dy2d):
-    """Partial sums only: (ws, weight meta, bias meta, bias offset in floats) for a deferred dfine_multi_wgrad_reduce."""
+    """Partial sums only: (ws, weight meta, bias meta, bias offset in floats) for a deferred dfine_multi_wgrad_reduce.  The
+    GEMM itself is only REGISTERED here (the tensors are kept alive); `linear_wgrad_flush` - called by the fused optimizer in
+    front of every deferred reduction - runs all registered problems as one launch (dfine_linear_wgrad_group)."""
     M, K = x2d.shape
     N = dy2d.shape[1]
     ws = torch.empty(int(_lib.dfine_linear_wgrad_ws_floats(M, N, K)), device=x2d.device, dtype=torch.float32)
-    with _timed("linear_wgrad", 2.0 * M * N * K, io=2.0 * M * (N + K) + 4.0 * N * K):
-        _check(_lib.dfine_linear_wgrad_bf16(_ptr(x2d), _ptr(dy2d), None, None, _ptr(ws), M, N, K, _stream()),
-               "dfine_linear_wgrad_bf16")
+    if _LW_GROUP:
+        _LW_PENDING.append((x2d, dy2d, ws, M, N, K))
+    else:
+        with _timed("linear_wgrad", 2.0 * M * N * K, io=2.0 * M * (N + K) + 4.0 * N * K):
+            _check(_lib.dfine_linear_wgrad_bf16(_ptr(x2d), _ptr(dy2d), None, None, _ptr(ws), M, N, K, _stream()),
+                   "dfine_linear_wgrad_bf16")
     splits = int(_lib.dfine_linear_wgrad_splits(M, N, K))
     np16, cp16 = _p16(N), _p16(K)
     return ws, (splits, N, K, 1, np16, cp16), (splits, N, 1, 1, np16, 1), splits * np16 * cp16
+
+
+def linear_wgrad_flush():
+    """Runs the registered linear weight-gradient problems (partial sums into their `ws` buffers) in one launch."""
+    if not _LW_PENDING:
+        return
+    import numpy as np
+    from .d_fine.arch.utils import upload
+    pend = list(_LW_PENDING)
+    _LW_PENDING.clear()
+    table = np.empty((len(pend), 8), dtype=np.int64)
+    blocks, flops, io = 1, 0.0, 0.0
+    for i, (x2d, dy2d, ws, M, N, K) in enumerate(pend):
+        n = int(_lib.dfine_linear_wgrad_group_row(_ptr(x2d), _ptr(dy2d), _ptr(ws), M, N, K, table[i].ctypes.data))
+        if n < 0:
+            raise RuntimeError("dfine_linear_wgrad_group_row: bad arguments")
+        blocks = max(blocks, n)
+        flops += 2.0 * M * N * K
+        io += 2.0 * M * (N + K) + 4.0 * N * K
+    dev_table = upload(table, pend[0][0].device)
+    with _timed("linear_wgrad", flops, io=io):
+        _check(_lib.dfine_linear_wgrad_group(_ptr(dev_table), len(pend), blocks, _stream()), "dfine_linear_wgrad_group")
+    _LW_KEEP.append((pend, dev_table))          # inputs stay alive until the launch has run (stream order: dropped at the next flush)
+    while len(_LW_KEEP) > 2:
+        _LW_KEEP.pop(0)
+
+
+_LW_KEEP = []
 
 
 def linear_wgrad_bf16(x2d, dy2d, with_bias=False, dw=None, db=None):

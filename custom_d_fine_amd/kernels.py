@@ -371,7 +371,9 @@ def _env(name, default):
 
 
 def reload_env():
+    global _ROUTES
     _ENV.clear()
+    _ROUTES = [0]
     _CONV_PLAN.clear()
 
 # Packed bf16 copies of the conv weights (forward and data-gradient layouts) are rebuilt only when the
@@ -616,6 +618,14 @@ def _conv_plan(x, weight):
     return plan
 
 
+_FUSE_CONV_BN = os.environ.get("DFINE_FUSE_CONV_BN", "1") == "1"
+
+
+def _conv_plan_all_hip(x, weight):
+    plan = _conv_plan(x, weight)
+    return plan["fwd"] and plan["dgrad"] and plan["wgrad"]
+
+
 def _defer_slot(*params):
     """(fused optimizer, [indices]) when every given parameter lives in a FusedAdamWEMA flat buffer that takes deferred weight
     gradients (split partial sums reduced by ONE launch per step straight into the flat gradient buffer), else None."""
@@ -683,6 +693,65 @@ class _DenseConv(torch.autograd.Function):
             else:
                 dw = hip.conv_wgrad_bf16(x, dy, ks).to(weight.dtype)
         return dx, dw
+
+
+class _DenseConvBNAct(torch.autograd.Function):
+    """_DenseConv followed by _BNAct as ONE autograd node (the HIP-only plan): the same kernel calls in the same order, half
+    the `Function.apply` / backward-node dispatches for the ~250 conv + BatchNorm units of a step - the forward pass is
+    host-bound (tools/host_profile.py: ~44 ms of host work against 39 ms of device work per step)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, lab_scale, lab_bias, running_mean, running_var, act, training, momentum, eps):
+        hip = _hip()
+        x = x.contiguous()
+        ks = weight.shape[-1]
+        c = hip.conv_forward_bf16(x, _packed_weights(weight, False), weight.shape[0], ks)
+        y, stats = hip.bn_act_forward(c, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, training, momentum, eps)
+        ctx.save_for_backward(x, weight, c, stats, lab_scale)
+        ctx.cfg = (act, training, gamma is not None, lab_scale is not None)
+        need = ctx.needs_input_grad
+        ctx.wslot = _defer_slot(weight) if need[1] else None
+        if ctx.wslot is not None:
+            ctx.wslot[0].note_use(ctx.wslot[1][0])
+        ctx.slot = None
+        if lab_scale is not None and lab_bias is not None and need[4] and need[5]:
+            slot = _defer_slot(lab_scale, lab_bias)
+            if slot is not None and slot[0].grad_offset(slot[1][1]) == slot[0].grad_offset(slot[1][0]) + 1:
+                ctx.slot = slot
+                for i in slot[1]:
+                    slot[0].note_use(i)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        hip = _hip()
+        x, weight, c, stats, lab_scale = ctx.saved_tensors
+        act, training, has_affine, has_lab = ctx.cfg
+        dy = dy.contiguous()
+        if dy.dtype != c.dtype:
+            dy = dy.to(c.dtype)
+        slot = ctx.slot
+        dlab_ptr = slot[0].grad_ptr(slot[1][0]) if slot is not None else None
+        dc, dg, db, dlab = hip.bn_act_backward(c, dy, stats, lab_scale, act, training, has_affine, has_lab, dlab_ptr)
+        dls = dlb = None
+        if slot is not None:
+            for i in slot[1]:
+                slot[0].use_done(i)
+        elif has_lab:
+            dls, dlb = dlab[0:1], dlab[1:2]
+        ks = weight.shape[-1]
+        need = ctx.needs_input_grad
+        dx = hip.conv_forward_bf16(dc, _packed_weights(weight, True), weight.shape[1], ks) if need[0] else None
+        dw = None
+        if need[1]:
+            wslot = ctx.wslot
+            if wslot is not None:
+                ws, meta = hip.conv_wgrad_bf16(x, dc, ks, partials=True)
+                wslot[0].defer_wgrad(wslot[1][0], ws, meta)
+                wslot[0].use_done(wslot[1][0])
+            else:
+                dw = hip.conv_wgrad_bf16(x, dc, ks).to(weight.dtype)
+        return dx, dw, dg, db, dls, dlb, None, None, None, None, None, None
 
 
 class _DualConv(torch.autograd.Function):
@@ -959,6 +1028,9 @@ def _is_depthwise(conv, allow_bias=False):
             and isinstance(conv.padding, tuple))
 
 
+_ROUTES = [0]       # epoch token of the per-module route caches of conv_bn_act (replaced by reload_env)
+
+
 def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Optional[nn.Module],
                 pad_br: bool = False):
     """conv(bias=False) -> BN (batch stats in training) -> {None, relu, silu} -> scalar affine; the
@@ -988,20 +1060,57 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
             return _bn_tail(y, bn, a, act, lab)
         x = torch.cat(list(xs), dim=1) if len(xs) > 1 else xs[0]
     if x.is_cuda and a in (None, "relu", "silu", "swish") and _env("DFINE_HIP_UNITS", "1") == "1":
-        if _is_depthwise(conv):
-            if torch.is_autocast_enabled() and x.dtype == torch.float32:
+        # Which kernel serves this layer depends on the module and on the input's shape / type only: decided once per
+        # (module, input signature) - the predicates below cost ~10 us of attribute look-ups per call, 300 calls per step, and
+        # the forward pass is host-bound (tools/host_profile.py).
+        routes = conv.__dict__.get("_dfine_routes")
+        if routes is None or routes[0] is not _ROUTES:
+            routes = conv.__dict__["_dfine_routes"] = (_ROUTES, {})      # per module; a new epoch object after reload_env()
+        key = (x.shape, x.dtype, pad_br, x.requires_grad, torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None)
+        route = routes[1].get(key)
+        if route is None:
+            if _is_depthwise(conv):
+                route = 1
+            elif not pad_br and _mfma_conv_ok(conv, x):
+                route = 2
+            elif (not pad_br and conv.kernel_size == (3, 3) and 160 < x.shape[-1] <= 304 and x.shape[-1] % 2 == 0
+                  and _mfma_conv_ok(conv, x[..., :_DenseConvWide._halves(x.shape[-1])[1]])):
+                route = 3
+            elif _stem_conv_ok(conv, x, pad_br):
+                route = 4
+            elif _f32_conv_ok(conv, x):
+                route = 5
+            else:
+                route = 0
+            if len(routes[1]) > 64:
+                routes[1].clear()
+            routes[1][key] = route
+        if route == 1:
+            if x.dtype == torch.float32 and torch.is_autocast_enabled():
                 x = x.to(torch.get_autocast_dtype("cuda"))      # what autocast would do for F.conv2d
             y = _DepthwiseConv.apply(x, conv.weight, conv.stride[0], conv.padding[0])
-        elif not pad_br and _mfma_conv_ok(conv, x):
-            y = _DenseConv.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv.weight)
-        elif (not pad_br and conv.kernel_size == (3, 3) and 160 < x.shape[-1] <= 304 and x.shape[-1] % 2 == 0
-              and _mfma_conv_ok(conv, x[..., :_DenseConvWide._halves(x.shape[-1])[1]])):
+        elif route == 2:
+            xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+            if (_FUSE_CONV_BN and type(bn) is nn.BatchNorm2d and bn.track_running_stats and bn.momentum is not None
+                    and _conv_plan_all_hip(xb, conv.weight)):
+                training = bn.training
+                if training:
+                    if _BN_DEFER:
+                        ent = _BN_PENDING.get(id(bn))
+                        _BN_PENDING[id(bn)] = (bn.num_batches_tracked, 1 if ent is None else ent[1] + 1)
+                    else:
+                        bn.num_batches_tracked.add_(1)
+                return _DenseConvBNAct.apply(xb, conv.weight, bn.weight, bn.bias, lab.scale if lab is not None else None,
+                                             lab.bias if lab is not None else None, bn.running_mean, bn.running_var, a, training,
+                                             bn.momentum, bn.eps)
+            y = _DenseConv.apply(xb, conv.weight)
+        elif route == 3:
             # maps wider than the kernel's 160-pixel strips (the 240-wide stage of D-FINE-l / x at 960 x 960): two column halves
             y = _DenseConvWide.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv.weight)
-        elif _stem_conv_ok(conv, x, pad_br):
+        elif route == 4:
             y = _StemConv.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv.weight,
                                 conv.stride[0], conv.padding[0], pad_br)
-        elif _f32_conv_ok(conv, x):
+        elif route == 5:
             y = conv_f32(x, conv, pad_br)           # fp32 math (configs[1]): the f32-input MFMA kernels
         else:
             y = conv(F.pad(x, (0, 1, 0, 1)) if pad_br else x)

@@ -347,6 +347,12 @@ int dfine_conv1x1_seg_wgrad_bf16(const void *const *x_parts, const int *x_channe
  */
 int dfine_conv_wgrad_splits(int B, int Cin, int Cout, int H, int W, int KS);
 int dfine_linear_wgrad_splits(int M, int N, int K);
+/* Many linear weight gradients (partial sums only, as dfine_linear_wgrad_bf16 with dw == NULL) in one launch: the backward ops
+ * of the token-stream linears (arch/dfine_decoder.py:33-46,214-271, arch/hybrid_encoder.py:243-290) register their (x, dY)
+ * pairs, a flush runs them together.  dfine_linear_wgrad_group_row fills a host row of 8 int64 and returns its workgroup
+ * count; table = the rows on the device, max_blocks = the largest count. */
+int dfine_linear_wgrad_group_row(const void *x, const void *dy, float *ws, int M, int N, int K, int64_t *row);
+int dfine_linear_wgrad_group(const void *table, int n_problems, int max_blocks, void *stream);
 int dfine_multi_wgrad_reduce_blocks(int splits, int64_t elems);   /* blocks one row of the table needs */
 int dfine_multi_wgrad_reduce(const void *table, int n_entries, int max_blocks, void *stream);
 
