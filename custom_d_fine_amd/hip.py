@@ -207,11 +207,14 @@ def _check(status, what):
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
-    """Raw hipStream_t of torch's current stream (the private getter is ~20x cheaper than building a
-    torch.cuda.Stream object per launch; ~500 launches per step go through here)."""
+    """Raw hipStream_t of torch's current stream (the private getters are ~20x cheaper than building a
+    torch.cuda.Stream object per launch; ~1500 launches per step go through here)."""
     if _raw_stream is not None:
-        return _raw_stream(torch.cuda.current_device())
+        return _raw_stream(_raw_device() if _raw_device is not None else torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -632,6 +635,11 @@ def conv_forward_bf16(x, w2, cout, ks):
     """x [B, Cin, H, W] bf16 contiguous, w2 packed by conv_pack_weights -> y [B, cout, H, W] bf16."""
     B, cin, H, W = x.shape
     y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.bfloat16)
+    if not _TIMING_ON:                     # ~250 calls per step: no timing object, no FLOP arithmetic on the plain path
+        status = _lib.dfine_conv_fwd_bf16(x.data_ptr(), w2.data_ptr(), y.data_ptr(), B, cin, cout, H, W, ks, _stream())
+        if status != 0:
+            _check(status, "dfine_conv_fwd_bf16")
+        return y
     with _timed(f"conv{ks}x{ks}", 2.0 * B * H * W * cin * cout * ks * ks, io=2.0 * B * H * W * (cin + cout) + 2.0 * cin * cout * ks * ks):
         _check(_lib.dfine_conv_fwd_bf16(_ptr(x), _ptr(w2), _ptr(y), B, cin, cout, H, W, ks, _stream()),
                "dfine_conv_fwd_bf16")
@@ -858,6 +866,12 @@ def linear_act(x2d, w, bias=None, act=0, out_f32=False, out=None):
         out = torch.empty(M, N, device=x2d.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.is_contiguous()
+    if not _TIMING_ON:                     # ~160 calls per step
+        status = _lib.dfine_linear_act_fwd(x2d.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K, ldx, ldw,
+                                           out.stride(0) if M > 1 else N, int(act), int(out.dtype == torch.float32), _stream())
+        if status != 0:
+            _check(status, "dfine_linear_act_fwd")
+        return out
     with _timed("linear", 2.0 * M * N * K, io=2.0 * (M * K + N * K + M * N)):
         _check(_lib.dfine_linear_act_fwd(_ptr(x2d), _ptr(w), _ptr(bias), _ptr(out), M, N, K, ldx, ldw,
                                          out.stride(0) if M > 1 else N, int(act), int(out.dtype == torch.float32), _stream()),

@@ -31,9 +31,15 @@ def _backend_for_cpu(op: str):
     return getattr(_TEST_BACKEND, op)
 
 
+_HIP = None
+
+
 def _hip():
-    from . import hip  # raises loudly if libdfine_hip.so is missing / not loadable
-    return hip
+    global _HIP
+    if _HIP is None:                       # (a plain global: the import statement costs ~1 us per call, ~350 calls per forward pass)
+        from . import hip  # raises loudly if libdfine_hip.so is missing / not loadable
+        _HIP = hip
+    return _HIP
 
 
 # =============================================================================================
