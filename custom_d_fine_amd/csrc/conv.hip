@@ -1185,20 +1185,20 @@ __device__ uint4 g_zero_page = {0u, 0u, 0u, 0u};
 constexpr int kW2Threads = 256, kW2Ring = 3, kW2Px = 64;
 
 template <bool SEG>
-__global__ __launch_bounds__(kW2Threads) void conv_wgrad1_glds_kernel(const ChanSegs xs_, const uint16_t *__restrict__ dy,
-                                                                      float *__restrict__ part, int Cin, int Cout, int HW,
-                                                                      int chunks_per_image, int total_chunks, int chunks_per_split,
-                                                                      int nct, int NP16, int CP16, int npairs, int nsplits) {
+__device__ __forceinline__ void conv_wgrad1_glds_body(const ChanSegs &xs_, const uint16_t *__restrict__ dy, float *__restrict__ part,
+                                                      int Cin, int Cout, int HW, int chunks_per_image, int total_chunks,
+                                                      int chunks_per_split, int nct, int NP16, int CP16, int npairs, int nsplits,
+                                                      const int bx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int OPB = 128 * 128, SB = 2 * OPB;                             // bytes per operand tile / per stage
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int pair, split;
     if ((nsplits & 7) == 0) {                                               // all tile pairs of a split on one XCD (L2 reuse)
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int xcd = bx & 7, slot = bx >> 3;
         pair = slot % npairs; split = (slot / npairs) * 8 + xcd;
     } else {
-        pair = blockIdx.x % npairs; split = blockIdx.x / npairs;
+        pair = bx % npairs; split = bx / npairs;
     }
     if (split >= nsplits) return;
     const int nt = pair / nct, ct = pair - nt * nct;
@@ -1305,6 +1305,32 @@ __global__ __launch_bounds__(kW2Threads) void conv_wgrad1_glds_kernel(const Chan
                 if (n < NP16) part[((int64_t)split * NP16 + n) * CP16 + c] = acc[a][b][r];
             }
     }
+}
+
+template <bool SEG>
+__global__ __launch_bounds__(kW2Threads) void conv_wgrad1_glds_kernel(const ChanSegs xs_, const uint16_t *__restrict__ dy,
+                                                                      float *__restrict__ part, int Cin, int Cout, int HW,
+                                                                      int chunks_per_image, int total_chunks, int chunks_per_split,
+                                                                      int nct, int NP16, int CP16, int npairs, int nsplits) {
+    conv_wgrad1_glds_body<SEG>(xs_, dy, part, Cin, Cout, HW, chunks_per_image, total_chunks, chunks_per_split, nct, NP16, CP16, npairs,
+                               nsplits, blockIdx.x);
+}
+
+// Many 1x1 weight gradients (whole-tensor inputs) in ONE launch: grid = (largest problem, problems).  The small layers
+// (128 -> 128 @ 40x40: 256 workgroups of four 64-pixel stages) are ~23 us on the device each, 53 of them per step: a fixed
+// launch + ring-fill + drain cost per layer that one grid pays once.  table rows of 8 x int64 = {x, dy, ws, B, Cin, Cout,
+// HW, splits | chunks per split << 32}.
+__global__ __launch_bounds__(kW2Threads) void conv_wgrad1_group_kernel(const int64_t *__restrict__ table) {
+    const int64_t *e = table + (int64_t)blockIdx.y * 8;
+    const int B = (int)e[3], Cin = (int)e[4], Cout = (int)e[5], HW = (int)e[6];
+    const int splits = (int)(e[7] & 0xffffffff), cps = (int)(e[7] >> 32);
+    const int cpi = (HW + kW2Px - 1) / kW2Px;
+    const int nnt = (Cout + 127) / 128, nct = (Cin + 127) / 128, npairs = nnt * nct;
+    if ((int)blockIdx.x >= 8 * ((splits + 7) / 8) * npairs) return;
+    ChanSegs xs_;
+    xs_.p[0] = reinterpret_cast<const uint16_t *>(e[0]); xs_.start[0] = 0; xs_.start[1] = Cin; xs_.bs[0] = Cin; xs_.n = 1;
+    conv_wgrad1_glds_body<false>(xs_, reinterpret_cast<const uint16_t *>(e[1]), reinterpret_cast<float *>(e[2]), Cin, Cout, HW, cpi,
+                                 B * cpi, cps, nct, (Cout + 15) / 16 * 16, (Cin + 15) / 16 * 16, npairs, splits, blockIdx.x);
 }
 
 static void wgrad1_plan(int B, int Cin, int Cout, int HW, int *splits, int *cps) {
@@ -1924,6 +1950,31 @@ int dfine_linear_wgrad_group_row(const void *x, const void *dy, float *ws, int M
     linear_wgrad_plan(M, N, K, &splits, &rows);
     row[0] = (int64_t)x; row[1] = (int64_t)dy; row[2] = (int64_t)ws; row[3] = M; row[4] = N; row[5] = K; row[6] = rows; row[7] = splits;
     return ((N + 63) / 64) * ((K + 63) / 64) * splits;
+}
+
+// 1x1 weight gradients, grouped: row helper (returns the workgroup count, < 0 when this shape does not take the LDS-DMA kernel).
+int dfine_conv_wgrad1_group_row(const void *x, const void *dy, float *ws, int B, int Cin, int Cout, int HW, int64_t *row) {
+    if (!x || !dy || !ws || !row || B < 1 || Cin < 1 || Cout < 1 || !wgrad1_v2(1, HW)) return DFINE_E_BADARG;
+    int splits, cps;
+    wgrad1_plan(B, Cin, Cout, HW, &splits, &cps);
+    row[0] = (int64_t)x; row[1] = (int64_t)dy; row[2] = (int64_t)ws; row[3] = B; row[4] = Cin; row[5] = Cout; row[6] = HW;
+    row[7] = (int64_t)splits | ((int64_t)cps << 32);
+    return 8 * ((splits + 7) / 8) * ((Cout + 127) / 128) * ((Cin + 127) / 128);
+}
+
+int dfine_conv_wgrad1_group(const void *table, int n_problems, int max_blocks, void *stream) {
+    if (n_problems == 0) return DFINE_OK;
+    if (!table || n_problems < 0 || max_blocks < 1) return DFINE_E_BADARG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad1_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           kW2Ring * 2 * 128 * 128);
+        if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad1_group_kernel, dim3(max_blocks, n_problems), dim3(kW2Threads), (size_t)kW2Ring * 2 * 128 * 128,
+                       (hipStream_t)stream, (const int64_t *)table);
+    return check_launch();
 }
 
 // table: device int64 [n_problems][8] (rows from dfine_linear_wgrad_group_row); max_blocks = the largest row's workgroup count.

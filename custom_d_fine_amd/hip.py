@@ -72,6 +72,8 @@ _SIGNATURES = {
     "dfine_multi_wgrad_reduce_blocks": (c_int, [_I, c_int64]),
     "dfine_linear_wgrad_group_row": (c_int, [_P, _P, _P, _I, _I, _I, _P]),
     "dfine_linear_wgrad_group": (c_int, [_P, _I, _I, _P]),
+    "dfine_conv_wgrad1_group_row": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfine_conv_wgrad1_group": (c_int, [_P, _I, _I, _P]),
     "dfine_linear_act_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_multi_cast_bf16_t": (c_int, [_P, _I, _P]),
     "dfine_act_fwd_bf16": (c_int, [_P, _P, _L, _I, _P]),
@@ -748,6 +750,10 @@ def conv_wgrad_bf16(x, dy, ks, partials=False):
     cout = dy.shape[1]
     dw = None if partials else torch.empty(cout, cin, ks, ks, device=x.device, dtype=torch.float32)
     ws = torch.empty(int(_lib.dfine_conv_wgrad_ws_floats(B, cin, cout, H, W, ks)), device=x.device, dtype=torch.float32)
+    if partials and ks == 1 and _CW_GROUP and (H * W) % 8 == 0:
+        # registered only: every 1x1 weight gradient of a flush runs in one launch (linear_wgrad_flush -> dfine_conv_wgrad1_group)
+        _CW_PENDING.append((x, dy, ws, B, cin, cout, H * W))
+        return ws, (int(_lib.dfine_conv_wgrad_splits(B, cin, cout, H, W, ks)), cout, cin, 1, _p16(cout), _p16(cin))
     with _timed(f"conv{ks}x{ks}_wgrad", 2.0 * B * H * W * cin * cout * ks * ks, io=2.0 * B * H * W * (cin + cout) + 4.0 * cin * cout * ks * ks):
         _check(_lib.dfine_conv_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ks, _stream()),
                "dfine_conv_wgrad_bf16")
@@ -928,6 +934,8 @@ _LW_WS = {}
 
 
 _LW_GROUP = os.environ.get("DFINE_LINEAR_WGRAD_GROUP", "1") == "1"
+_CW_GROUP = os.environ.get("DFINE_CONV_WGRAD_GROUP", "1") == "1"
+_CW_PENDING = []            # (x, dy, ws, B, Cin, Cout, HW): 1x1 convolution weight gradients registered since the last flush
 _LW_PENDING = []            # (x2d, dy2d, ws, M, N, K) registered since the last linear_wgrad_flush
 
 
@@ -950,11 +958,30 @@ def linear_wgrad_partials(x2d, dy2d):
 
 
 def linear_wgrad_flush():
-    """Runs the registered linear weight-gradient problems (partial sums into their `ws` buffers) in one launch."""
-    if not _LW_PENDING:
-        return
+    """Runs the registered weight-gradient problems (token-stream linears, 1x1 convolutions: partial sums into their `ws`
+    buffers) in one launch per kind."""
     import numpy as np
     from .d_fine.arch.utils import upload
+    if _CW_PENDING:
+        pend = list(_CW_PENDING)
+        _CW_PENDING.clear()
+        table = np.empty((len(pend), 8), dtype=np.int64)
+        blocks, flops, io = 1, 0.0, 0.0
+        for i, (x, dy, ws, B, cin, cout, hw) in enumerate(pend):
+            n = int(_lib.dfine_conv_wgrad1_group_row(x.data_ptr(), dy.data_ptr(), ws.data_ptr(), B, cin, cout, hw, table[i].ctypes.data))
+            if n < 0:
+                raise RuntimeError("dfine_conv_wgrad1_group_row: bad arguments")
+            blocks = max(blocks, n)
+            flops += 2.0 * B * hw * cin * cout
+            io += 2.0 * B * hw * (cin + cout) + 4.0 * cin * cout
+        dev_table = upload(table, pend[0][0].device)
+        with _timed("conv1x1_wgrad", flops, io=io):
+            _check(_lib.dfine_conv_wgrad1_group(_ptr(dev_table), len(pend), blocks, _stream()), "dfine_conv_wgrad1_group")
+        _LW_KEEP.append((pend, dev_table))
+    if not _LW_PENDING:
+        while len(_LW_KEEP) > 4:
+            _LW_KEEP.pop(0)
+        return
     pend = list(_LW_PENDING)
     _LW_PENDING.clear()
     table = np.empty((len(pend), 8), dtype=np.int64)
@@ -969,8 +996,8 @@ def linear_wgrad_flush():
     dev_table = upload(table, pend[0][0].device)
     with _timed("linear_wgrad", flops, io=io):
         _check(_lib.dfine_linear_wgrad_group(_ptr(dev_table), len(pend), blocks, _stream()), "dfine_linear_wgrad_group")
-    _LW_KEEP.append((pend, dev_table))          # inputs stay alive until the launch has run (stream order: dropped at the next flush)
-    while len(_LW_KEEP) > 2:
+    _LW_KEEP.append((pend, dev_table))          # inputs stay alive until the launch has run (stream order: dropped a few flushes later)
+    while len(_LW_KEEP) > 4:
         _LW_KEEP.pop(0)
 
 
