@@ -96,6 +96,7 @@ _SIGNATURES = {
     "dfine_conv_f32_wgrad_splits": (c_int, [_I, _I, _I, _I, _I, _I]),
     "dfine_conv_f32_wgrad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_upsample2_zero_f32": (c_int, [_P, _P, _L, _I, _I, _I, _I, _P]),
+    "dfine_gemm_f32_nt": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, c_int64, c_int64, c_int64, _I, _I, _F, _I, _P]),
     "dfine_mask_bits_words": (c_int64, [c_int64]),
     "dfine_mask_pack_bits": (c_int, [_P, _I, _F, _I, c_int64, _P, _P]),
     "dfine_mask_iou_bits": (c_int, [_P, _P, _I, _I, c_int64, _P, _P]),
@@ -1247,6 +1248,50 @@ def conv1x1_batched_weights(x, w2, cout):
     with _timed("conv1x1", 2.0 * B * H * W * cin * cout, io=2.0 * B * H * W * (cin + cout) + 2.0 * cin * cout):
         _check(_lib.dfine_conv1x1_bw_bf16(_ptr(x), _ptr(w2), _ptr(y), B, cin, cout, H * W, _stream()), "dfine_conv1x1_bw_bf16")
     return y
+
+
+# ------------------------------------------------------------------------------------- fp32 GEMMs (config #2)
+def gemm_f32_nt(a, b, bias=None, alpha=1.0, act=0, splits=1, out=None):
+    """a [..., M, K], b [..., N, K] fp32 with unit inner stride (leading batch dims equal, or b 2-D = shared) ->
+    act(alpha * a @ b^T + bias) [..., M, N] fp32.  splits > 1 (2-D operands): [splits, M, N] partial products over K chunks."""
+    if a.stride(-1) != 1:          # (size-1 inner dimensions carry arbitrary strides)
+        a = a.contiguous()
+    if b.stride(-1) != 1:
+        b = b.contiguous()
+    assert a.dtype == torch.float32 and b.dtype == torch.float32
+    M, K = a.shape[-2], a.shape[-1]
+    N = b.shape[-2]
+    assert b.shape[-1] == K
+    if a.dim() == 2:
+        batch, sa, sb = 1, 0, 0
+        a3, b3 = a, b
+    else:
+        a3 = a.reshape(-1, M, K) if a.dim() != 3 else a
+        batch = a3.shape[0]
+        if a3.stride(-1) != 1 or (M > 1 and a3.stride(1) < K):
+            a3 = a3.contiguous()
+        sa = a3.stride(0) if batch > 1 else 0
+        if b.dim() == 2:
+            b3, sb = b, 0
+        else:
+            b3 = b.reshape(-1, N, K) if b.dim() != 3 else b
+            if b3.stride(-1) != 1:
+                b3 = b3.contiguous()
+            sb = b3.stride(0) if batch > 1 else 0
+    lda = a3.stride(-2) if M > 1 else K
+    ldb = b3.stride(-2) if N > 1 else K
+    chunk = K
+    if splits > 1:
+        assert a.dim() == 2 and bias is None and act == 0
+        chunk = ((K + splits - 1) // splits + 3) // 4 * 4
+        splits = (K + chunk - 1) // chunk
+    if out is None:
+        shape = (splits, M, N) if splits > 1 else (tuple(a.shape[:-2]) + (M, N))
+        out = torch.empty(shape, device=a.device, dtype=torch.float32)
+    with _timed("linear_f32", 2.0 * batch * M * N * K, io=4.0 * batch * (M * K + N * K + M * N)):
+        _check(_lib.dfine_gemm_f32_nt(a3.data_ptr(), b3.data_ptr(), _ptr(bias), out.data_ptr(), batch, M, N, K, lda, ldb, N, sa, sb,
+                                      M * N, splits, chunk, float(alpha), int(act), _stream()), "dfine_gemm_f32_nt")
+    return out
 
 
 # ------------------------------------------------------------------------------------- evaluation masks (f2)

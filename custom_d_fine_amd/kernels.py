@@ -1435,6 +1435,86 @@ def _hip_linear_ok(x, weight):
                                                and x.dtype == torch.float32)))
 
 
+class _LinearF32(torch.autograd.Function):
+    """fp32 nn.Linear (config #2, no autocast) on the f32-input MFMA GEMM (csrc/gemm_f32.hip): forward x W^T + b (ReLU fused),
+    data gradient dY (W^T)^T, weight gradient dY^T (x^T)^T as split partial products over the token rows."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        hip = _hip()
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        w = weight if weight.stride(-1) == 1 else weight.contiguous()
+        y = hip.gemm_f32_nt(x2, w, bias, act=1 if relu else 0)
+        ctx.save_for_backward(x2, w, y if relu else None)
+        ctx.cfg = (relu, bias is not None, x.shape)
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        hip = _hip()
+        x2, w, y = ctx.saved_tensors
+        relu, has_bias, xshape = ctx.cfg
+        N = w.shape[0]
+        d2 = dy.reshape(-1, N)
+        if relu:
+            d2 = d2 * (y > 0)
+        elif not d2.is_contiguous():
+            d2 = d2.contiguous()
+        need = ctx.needs_input_grad
+        dx = dw = db = None
+        if need[0]:
+            dx = hip.gemm_f32_nt(d2, w.t().contiguous()).view(xshape)
+        if need[1]:
+            M = x2.shape[0]
+            splits = max(1, min(64, M // 256))
+            part = hip.gemm_f32_nt(d2.t().contiguous(), x2.t().contiguous(), splits=splits)
+            dw = part.sum(0) if part.dim() == 3 else part
+        if has_bias and need[2]:
+            db = d2.sum(0)
+        return dx, dw, db, None
+
+
+class _BmmNTF32(torch.autograd.Function):
+    """alpha * a @ b^T for fp32 [Z, M, K] x [Z, N, K] (the two products of an attention head) on the same GEMM kernel."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        a, b = a.contiguous(), b.contiguous()
+        ctx.save_for_backward(a, b)
+        ctx.alpha = alpha
+        return _hip().gemm_f32_nt(a, b, alpha=alpha)
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        hip = _hip()
+        dc = dc.contiguous()
+        da = hip.gemm_f32_nt(dc, b.transpose(-1, -2).contiguous(), alpha=ctx.alpha) if ctx.needs_input_grad[0] else None
+        db = hip.gemm_f32_nt(dc.transpose(-1, -2).contiguous(), a.transpose(-1, -2).contiguous(), alpha=ctx.alpha) \
+            if ctx.needs_input_grad[1] else None
+        return da, db, None
+
+
+def _f32_gemm_ok(x, weight):
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2 and x.numel() > 0
+            and not torch.is_autocast_enabled() and _env("DFINE_F32_GEMM", "1") == "1")
+
+
+def attention_f32(q, k, v, allowed=None):
+    """softmax(q k^T / sqrt(d) [masked]) v for fp32 [B, H, L, d] tensors: both products on the f32 MFMA GEMM, the softmax an
+    ATen element-wise / reduction kernel (no rocBLAS, no SDPA library kernel).  `allowed`: bool [L, L], True = may attend."""
+    B, H, L, d = q.shape
+    s = _BmmNTF32.apply(q.reshape(B * H, L, d), k.reshape(B * H, -1, d), float(d) ** -0.5)
+    if allowed is not None:
+        s = s.masked_fill(~allowed, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    o = _BmmNTF32.apply(p, v.reshape(B * H, -1, d).transpose(-1, -2), 1.0)
+    return o.view(B, H, L, d)
+
+
 def linear(x, weight, bias=None, act=None):
     """act(nn.Linear(x)) for [..., K] activations; `act`: None / "relu" / "gelu" / "silu" or the nn module.
     CUDA under bf16 autocast (or bf16 inputs): HIP GEMM with the activation fused.  Otherwise (fp32 math, CPU) the ATen
@@ -1442,7 +1522,12 @@ def linear(x, weight, bias=None, act=None):
     code = _act_code(act)
     if code is not None and _hip_linear_ok(x, weight) and x.numel() > 0:
         return _LinearAct.apply(x, weight, bias, code)
-    y = F.linear(x, weight, bias)
+    if _f32_gemm_ok(x, weight):
+        y = _LinearF32.apply(x, weight, bias, code == 1)       # fp32 math (configs[1]): the f32-input MFMA GEMM, ReLU fused
+        if code == 1:
+            return y
+    else:
+        y = F.linear(x, weight, bias)
     if act is None or code == 0:
         return y
     if isinstance(act, nn.Module):
@@ -1528,7 +1613,10 @@ def self_attention(qk, value, in_w, in_b, out_w, out_b, num_heads: int, attn_mas
     v = linear(value, in_w[2 * e:], in_b[2 * e:])
     q, k, v = (t.reshape(b, l, num_heads, hd).transpose(1, 2) for t in (q, k, v))
     mask = None if attn_mask is None else ~attn_mask
-    o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+    if _f32_gemm_ok(q, in_w):
+        o = attention_f32(q, k, v, mask)
+    else:
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
     return linear(o.transpose(1, 2).reshape(b, l, e), out_w, out_b)
 
 

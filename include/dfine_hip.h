@@ -585,6 +585,18 @@ int dfine_maps_tokens_bf16(const void *map, void *tokens, int B, int C, int HW, 
                            void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * A2 / A5 / A6, fp32 (BASELINE config #2)  Token-stream GEMMs on the f32-input matrix cores.  Replaces the rocBLAS calls
+ * behind nn.Linear (arch/dfine_decoder.py:33-46,119-178,214-271,828-873, arch/hybrid_encoder.py:243-290) and the two batched
+ * products of F.scaled_dot_product_attention (hybrid_encoder.py:256,277, dfine_decoder.py:200,239) for fp32 tensors.
+ *   C[z][M, N] (row stride ldc, z stride sc) = act(alpha * A[b][M, K] . B[b][N, K]^T + bias[N]),  z = b * splits + split;
+ *   operands K-contiguous with row strides lda / ldb and batch strides sa / sb (elements; 0 = shared).  splits > 1 cuts K
+ *   into chunks of `chunk` (multiple of 4): every z writes its own partial product (weight gradients: reduction over token rows).
+ *   act: 0 none, 1 relu, 2 gelu (erf), 3 silu.
+ */
+int dfine_gemm_f32_nt(const float *A, const float *B, const float *bias, float *C, int batch, int M, int N, int K, int lda, int ldb,
+                      int ldc, int64_t sa, int64_t sb, int64_t sc, int splits, int chunk, float alpha, int act, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * (f2)  Instance-mask IoU of the evaluation hand-off.  Replaces Validator._pairwise_mask_iou
  * (src/dl/validator.py:283-293: uint8 masks -> fp32 matmul -> areas -> inter / union) and the pycocotools RLE round trip
  * the reference stores validation masks through (src/dl/utils.py:1040-1160) with 1-bit-per-pixel device masks.
