@@ -1466,36 +1466,43 @@ class _LinearF32(torch.autograd.Function):
         need = ctx.needs_input_grad
         dx = dw = db = None
         if need[0]:
-            dx = hip.gemm_f32_nt(d2, w.t().contiguous()).view(xshape)
+            dx = hip.gemm_f32(d2, w, b_kmajor=True).view(xshape)                 # dY [M, N] . W [N, K]: W read in place
         if need[1]:
             M = x2.shape[0]
             splits = max(1, min(64, M // 256))
-            part = hip.gemm_f32_nt(d2.t().contiguous(), x2.t().contiguous(), splits=splits)
+            part = hip.gemm_f32(d2, x2, a_kmajor=True, b_kmajor=True, splits=splits)   # dY^T x: both read in place, token rows = K
             dw = part.sum(0) if part.dim() == 3 else part
         if has_bias and need[2]:
             db = d2.sum(0)
         return dx, dw, db, None
 
 
-class _BmmNTF32(torch.autograd.Function):
-    """alpha * a @ b^T for fp32 [Z, M, K] x [Z, N, K] (the two products of an attention head) on the same GEMM kernel."""
+class _BmmF32(torch.autograd.Function):
+    """alpha * a @ b^T (b_kmajor False: b [Z, N, K]) or alpha * a @ b (b_kmajor True: b [Z, K, N]) for fp32 batches - the two
+    products of an attention head and their four gradients on the f32 GEMM kernel, every operand read in place."""
 
     @staticmethod
-    def forward(ctx, a, b, alpha):
+    def forward(ctx, a, b, alpha, b_kmajor):
         a, b = a.contiguous(), b.contiguous()
         ctx.save_for_backward(a, b)
-        ctx.alpha = alpha
-        return _hip().gemm_f32_nt(a, b, alpha=alpha)
+        ctx.cfg = (alpha, b_kmajor)
+        return _hip().gemm_f32(a, b, b_kmajor=b_kmajor, alpha=alpha)
 
     @staticmethod
     def backward(ctx, dc):
         a, b = ctx.saved_tensors
+        alpha, bkm = ctx.cfg
         hip = _hip()
         dc = dc.contiguous()
-        da = hip.gemm_f32_nt(dc, b.transpose(-1, -2).contiguous(), alpha=ctx.alpha) if ctx.needs_input_grad[0] else None
-        db = hip.gemm_f32_nt(dc.transpose(-1, -2).contiguous(), a.transpose(-1, -2).contiguous(), alpha=ctx.alpha) \
-            if ctx.needs_input_grad[1] else None
-        return da, db, None
+        da = db = None
+        if ctx.needs_input_grad[0]:          # dA [M, K] = dC [M, N] . B ([N, K]: K-major for this product) or . B^T ([K, N]: NT)
+            da = hip.gemm_f32(dc, b, b_kmajor=not bkm, alpha=alpha)
+        if ctx.needs_input_grad[1]:
+            if bkm:                          # B [K, N]: dB = A^T dC
+                db = hip.gemm_f32(a, dc, a_kmajor=True, b_kmajor=True, alpha=alpha)
+            else:                            # B [N, K]: dB = dC^T A
+                db = hip.gemm_f32(dc, a, a_kmajor=True, b_kmajor=True, alpha=alpha)
+        return da, db, None, None
 
 
 def _f32_gemm_ok(x, weight):
@@ -1507,11 +1514,11 @@ def attention_f32(q, k, v, allowed=None):
     """softmax(q k^T / sqrt(d) [masked]) v for fp32 [B, H, L, d] tensors: both products on the f32 MFMA GEMM, the softmax an
     ATen element-wise / reduction kernel (no rocBLAS, no SDPA library kernel).  `allowed`: bool [L, L], True = may attend."""
     B, H, L, d = q.shape
-    s = _BmmNTF32.apply(q.reshape(B * H, L, d), k.reshape(B * H, -1, d), float(d) ** -0.5)
+    s = _BmmF32.apply(q.reshape(B * H, L, d), k.reshape(B * H, -1, d), float(d) ** -0.5, False)
     if allowed is not None:
         s = s.masked_fill(~allowed, float("-inf"))
     p = torch.softmax(s, dim=-1)
-    o = _BmmNTF32.apply(p, v.reshape(B * H, -1, d).transpose(-1, -2), 1.0)
+    o = _BmmF32.apply(p, v.reshape(B * H, -1, d), 1.0, True)
     return o.view(B, H, L, d)
 
 
@@ -1929,7 +1936,10 @@ class _DenseConvF32(torch.autograd.Function):
         hip = _hip()
         x = x.contiguous()
         ks = weight.shape[-1]
-        y = hip.conv_f32_forward(x, _packed_f32(weight, False), weight.shape[0], ks, stride, pt, pl, out_hw)
+        if ks == 1 and stride == 1 and pt == 0 and pl == 0:
+            y = hip.conv1x1_f32(x, weight.view(weight.shape[0], weight.shape[1]))      # y[b] = W x[b]: the fp32 GEMM kernel
+        else:
+            y = hip.conv_f32_forward(x, _packed_f32(weight, False), weight.shape[0], ks, stride, pt, pl, out_hw)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pt, pl)
         ctx.slot = _defer_slot(weight) if ctx.needs_input_grad[1] else None
@@ -1945,7 +1955,9 @@ class _DenseConvF32(torch.autograd.Function):
         ks = weight.shape[-1]
         dy = dy.float().contiguous()
         dx = dw = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ks == 1 and stride == 1 and pt == 0 and pl == 0:
+            dx = hip.conv1x1_f32(dy, weight.view(weight.shape[0], weight.shape[1]).t().contiguous())      # dx[b] = W^T dy[b]
+        elif ctx.needs_input_grad[0]:
             src = dy if stride == 1 else hip.upsample2_zero(dy, (2 * dy.shape[2] - 1, 2 * dy.shape[3] - 1))
             dx = hip.conv_f32_forward(src, _packed_f32(weight, True), weight.shape[1], ks, 1, ks - 1 - pt, ks - 1 - pl, tuple(x.shape[2:]))
         if ctx.needs_input_grad[1]:

@@ -595,6 +595,14 @@ int dfine_maps_tokens_bf16(const void *map, void *tokens, int B, int C, int HW, 
  */
 int dfine_gemm_f32_nt(const float *A, const float *B, const float *bias, float *C, int batch, int M, int N, int K, int lda, int ldb,
                       int ldc, int64_t sa, int64_t sb, int64_t sc, int splits, int chunk, float alpha, int act, void *stream);
+/* B given K-major ([K, N], rows N-contiguous): C[z] = act(alpha * A[b] . B[b] + bias).  The fp32 1x1 convolution on NCHW maps
+ * (arch/hgnetv2.py:35-80, arch/hybrid_encoder.py:21-156): y[b] = W x[b], dx[b] = W^T dy[b], N = H * W. */
+int dfine_gemm_f32_nn(const float *A, const float *B, const float *bias, float *C, int batch, int M, int N, int K, int lda, int ldb,
+                      int ldc, int64_t sa, int64_t sb, int64_t sc, float alpha, int act, void *stream);
+/* General form: a_kmajor / b_kmajor != 0 - that operand is stored K-major ([K, M] / [K, N], rows contiguous in M / N): the
+ * products with a transposed first factor (linear weight gradient dY^T x, P^T dO, dS^T Q) without transposed copies. */
+int dfine_gemm_f32(int a_kmajor, int b_kmajor, const float *A, const float *B, const float *bias, float *C, int batch, int M, int N, int K,
+                   int lda, int ldb, int ldc, int64_t sa, int64_t sb, int64_t sc, int splits, int chunk, float alpha, int act, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (f2)  Instance-mask IoU of the evaluation hand-off.  Replaces Validator._pairwise_mask_iou

@@ -108,3 +108,20 @@ def test_fp32_train_step_launches_no_library_gemm(cuda):
            and "dfine::" not in n]
     assert not bad, bad
     assert any("gemm_f32_nt_kernel" in n for n in names) and any("conv_f32_kernel" in n for n in names)
+
+
+@pytest.mark.parametrize("akm,bkm", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("batch", [1, 5])
+def test_gemm_f32_operand_layouts(cuda, akm, bkm, batch):
+    """K-major operands ([K, M] / [K, N]) read in place: every transposition combination against fp64 matmul."""
+    torch.manual_seed(11)
+    M, N, K = 70, 45, 130
+    a = torch.randn(*((batch,) if batch > 1 else ()), *((K, M) if akm else (M, K)), device=cuda)
+    b = torch.randn(*((batch,) if batch > 1 else ()), *((K, N) if bkm else (N, K)), device=cuda)
+    got = hip.gemm_f32(a, b, a_kmajor=akm, b_kmajor=bkm, alpha=1.5)
+    ad = a.double().transpose(-1, -2) if akm else a.double()
+    bd = b.double() if bkm else b.double().transpose(-1, -2)
+    _close(got, 1.5 * (ad @ bd), 3e-6)
+    if batch == 1:
+        part = hip.gemm_f32(a, b, a_kmajor=akm, b_kmajor=bkm, splits=4)
+        _close(part.sum(0), ad @ bd, 3e-6)
