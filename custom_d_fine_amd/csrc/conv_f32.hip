@@ -50,6 +50,7 @@ __global__ __launch_bounds__(kF32Threads) void conv_f32_kernel(const float *__re
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int TAPS = KS * KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int g = lane >> 4, i16 = lane & 15;
     int u = blockIdx.x;
     const int ct = u % ctiles; u /= ctiles;
@@ -80,13 +81,19 @@ __global__ __launch_bounds__(kF32Threads) void conv_f32_kernel(const float *__re
     const int xelems = rows_l * WL;
     for (int c0 = 0; c0 < KP; c0 += kF32KC) {
         __syncthreads();
-        for (int i = tid; i < kF32KC * xelems; i += kF32Threads) {
-            const int c = i / xelems, rem = i - c * xelems;
-            const int ly = rem / WL, lx = rem - ly * WL;
-            const int iy = iy0 + ly, ix = ix0 + lx;
-            float v = 0.f;
-            if (c0 + c < Cin && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) v = xb[((int64_t)(c0 + c) * Hi + iy) * Wi + ix];
-            xs[i] = v;
+        // one wave per (channel, tile row): the row / channel split runs on the scalar unit, lanes walk the columns (an integer
+        // division pair per ELEMENT made this loop the kernel's bottleneck on the 3-channel stem: 935 us for 1.4 GFLOP)
+        const int kkn = (min(kF32KC, Cin - c0) + 3) >> 2;                  // 4-channel groups of this stage that hold data
+        for (int row = wv; row < 4 * kkn * rows_l; row += 4) {
+            const int c = row / rows_l, ly = row - c * rows_l;
+            const int iy = iy0 + ly;
+            const bool ok = c0 + c < Cin && iy >= 0 && iy < Hi;
+            const float *src = xb + ((int64_t)(c0 + c) * Hi + (ok ? iy : 0)) * Wi;
+            float *dst = xs + row * WL;
+            for (int lx = lane; lx < WL; lx += 64) {
+                const int ix = ix0 + lx;
+                dst[lx] = (ok && ix >= 0 && ix < Wi) ? src[ix] : 0.f;
+            }
         }
         for (int i = tid; i < TAPS * 64 * kF32KC; i += kF32Threads) {
             const int k = i % kF32KC, n = (i / kF32KC) % 64, tap = i / (kF32KC * 64);
@@ -98,6 +105,7 @@ __global__ __launch_bounds__(kF32Threads) void conv_f32_kernel(const float *__re
             const int toff = (tap / KS) * WL + (tap % KS);
 #pragma unroll
             for (int kk = 0; kk < kF32KC / 4; ++kk) {
+                if (kk >= kkn) break;                                      // uniform: channel groups past Cin (the stem: 3 channels)
                 const float a = ws[(tap * 64 + wave * 16 + i16) * WP + kk * 4 + g];
                 const float *xr = xs + (kk * 4 + g) * xelems + toff;
 #pragma unroll
@@ -130,6 +138,7 @@ __global__ __launch_bounds__(kF32Threads) void wgrad_f32_kernel(const float *__r
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int TAPS = KS * KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int g = lane >> 4, i16 = lane & 15;
     const int nt = blockIdx.x / nct, ctile = blockIdx.x - nt * nct;
     const int n0 = nt * 64, c0 = ctile * 16;
@@ -153,24 +162,27 @@ __global__ __launch_bounds__(kF32Threads) void wgrad_f32_kernel(const float *__r
         const float *xb = x + (int64_t)b * Cin * Hi * Wi;
         const float *dyb = dy + (int64_t)b * Cout * Ho * Wo;
         __syncthreads();
-        for (int i = tid; i < 16 * xelems; i += kF32Threads) {
-            const int c = i / xelems, rem = i - c * xelems;
-            const int ly = rem / WL, lx = rem - ly * WL;
-            const int iy = iy0 + ly, ix = ix0 + lx;
-            float v = 0.f;
-            if (c0 + c < Cin && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) v = xb[((int64_t)(c0 + c) * Hi + iy) * Wi + ix];
-            xs[i] = v;
+        for (int row = wv; row < 16 * rows_l; row += 4) {                  // (channel, tile row) per wave, lanes over the columns
+            const int c = row / rows_l, ly = row - c * rows_l;
+            const int iy = iy0 + ly;
+            const bool ok = c0 + c < Cin && iy >= 0 && iy < Hi;
+            const float *src = xb + ((int64_t)(c0 + c) * Hi + (ok ? iy : 0)) * Wi;
+            float *dst = xs + row * WL;
+            for (int lx = lane; lx < WL; lx += 64) {
+                const int ix = ix0 + lx;
+                dst[lx] = (ok && ix >= 0 && ix < Wi) ? src[ix] : 0.f;
+            }
         }
         const int TP4 = (TP + 3) & ~3;
-        for (int i = tid; i < 64 * TP4; i += kF32Threads) {
-            const int n = i / TP4, q = i - n * TP4;
-            float v = 0.f;
-            if (q < TP && n0 + n < Cout) {
-                const int oy = q / cols, ox = q - oy * cols;
-                v = dyb[((int64_t)(n0 + n) * Ho + r0 + oy) * Wo + x0 + ox];
-            }
-            ds[n * DP + q] = v;
+        for (int row = wv; row < 64 * rows; row += 4) {                    // (output channel, output row) per wave
+            const int n = row / rows, oy = row - n * rows;
+            const bool ok = n0 + n < Cout;
+            const float *src = dyb + ((int64_t)(ok ? n0 + n : 0) * Ho + r0 + oy) * Wo + x0;
+            float *dst = ds + n * DP + oy * cols;
+            for (int ox = lane; ox < cols; ox += 64) dst[ox] = ok ? src[ox] : 0.f;
         }
+        if (TP4 > TP)
+            for (int i = tid; i < 64 * (TP4 - TP); i += kF32Threads) ds[(i / (TP4 - TP)) * DP + TP + i % (TP4 - TP)] = 0.f;
         __syncthreads();
         for (int k0 = 0; k0 < TP4; k0 += 4) {
             const float a = ds[(wave * 16 + i16) * DP + k0 + g];           // A[n = i16][k = pixel k0 + g]
