@@ -760,6 +760,75 @@ class _DenseConvBNAct(torch.autograd.Function):
         return dx, dw, dg, db, dls, dlb, None, None, None, None, None, None
 
 
+class _InnerCtx:
+    """Stand-in for the autograd context of a convolution node run INSIDE another node (_ConvBNActAny)."""
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class _ConvBNActAny(torch.autograd.Function):
+    """Any convolution node of this module (depthwise, part-wise 1x1, stem ...) followed by _BNAct as ONE autograd node: the
+    inner node's forward / backward run as plain functions on a stand-in context.  Same kernels, one node dispatch less per
+    unit and direction (the forward pass is host-bound)."""
+
+    @staticmethod
+    def forward(ctx, inner, n, *args):
+        conv_args = args[:n]
+        gamma, beta, lab_scale, lab_bias, running_mean, running_var, act, training, momentum, eps = args[n:]
+        ictx = _InnerCtx()
+        ictx.needs_input_grad = ctx.needs_input_grad[2:2 + n]
+        c = inner.forward(ictx, *conv_args)
+        y, stats = _hip().bn_act_forward(c, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, training, momentum, eps)
+        ctx.save_for_backward(c, stats, lab_scale)
+        ctx.inner, ctx.ictx, ctx.n = inner, ictx, n
+        ctx.cfg = (act, training, gamma is not None, lab_scale is not None)
+        ctx.slot = None
+        need = ctx.needs_input_grad
+        if lab_scale is not None and lab_bias is not None and need[2 + n + 2] and need[2 + n + 3]:
+            slot = _defer_slot(lab_scale, lab_bias)
+            if slot is not None and slot[0].grad_offset(slot[1][1]) == slot[0].grad_offset(slot[1][0]) + 1:
+                ctx.slot = slot
+                for i in slot[1]:
+                    slot[0].note_use(i)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        c, stats, lab_scale = ctx.saved_tensors
+        act, training, has_affine, has_lab = ctx.cfg
+        dy = dy.contiguous()
+        if dy.dtype != c.dtype:
+            dy = dy.to(c.dtype)
+        slot = ctx.slot
+        dlab_ptr = slot[0].grad_ptr(slot[1][0]) if slot is not None else None
+        dc, dg, db, dlab = _hip().bn_act_backward(c, dy, stats, lab_scale, act, training, has_affine, has_lab, dlab_ptr)
+        dls = dlb = None
+        if slot is not None:
+            for i in slot[1]:
+                slot[0].use_done(i)
+        elif has_lab:
+            dls, dlb = dlab[0:1], dlab[1:2]
+        inner_grads = ctx.inner.backward(ctx.ictx, dc)
+        ctx.ictx = None
+        return (None, None) + tuple(inner_grads) + (dg, db, dls, dlb, None, None, None, None, None, None)
+
+
+def _bn_tail_fused(inner, conv_args, bn, a, lab):
+    """conv node + BatchNorm tail as one autograd node when the BatchNorm is a plain tracked nn.BatchNorm2d; None otherwise."""
+    if not (_FUSE_CONV_BN and type(bn) is nn.BatchNorm2d and bn.track_running_stats and bn.momentum is not None):
+        return None
+    training = bn.training
+    if training:
+        if _BN_DEFER:
+            ent = _BN_PENDING.get(id(bn))
+            _BN_PENDING[id(bn)] = (bn.num_batches_tracked, 1 if ent is None else ent[1] + 1)
+        else:
+            bn.num_batches_tracked.add_(1)
+    return _ConvBNActAny.apply(inner, len(conv_args), *conv_args, bn.weight, bn.bias, lab.scale if lab is not None else None,
+                               lab.bias if lab is not None else None, bn.running_mean, bn.running_var, a, training, bn.momentum, bn.eps)
+
+
 class _DualConv(torch.autograd.Function):
     """(conv_a(x), conv_b(x)) for a 3x3 and a 1x1 convolution of the same input (RepVGG unit): one op so that the backward
     pass forms d(x) = dgrad_a(dc_a) + dgrad_b(dc_b) with the second data-gradient kernel accumulating onto the first
@@ -1054,7 +1123,11 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
                 and _env("DFINE_SEG_CONV", "1") == "1" and a in (None, "relu", "silu", "swish")
                 and conv.kernel_size == (1, 1) and len(xs) <= 8 and (xs[0].shape[-1] * xs[0].shape[-2]) % 8 == 0
                 and all(t.shape[1] % 8 == 0 for t in xs) and _mfma_conv_ok(conv, xs[0])):
-            y = _DenseConvSeg.apply(conv.weight, *[t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16) for t in xs])
+            parts = [t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16) for t in xs]
+            y = _bn_tail_fused(_DenseConvSeg, (conv.weight, *parts), bn, a, lab)
+            if y is not None:
+                return y
+            y = _DenseConvSeg.apply(conv.weight, *parts)
             return _bn_tail(y, bn, a, act, lab)
         if (len(xs) == 2 and xs[0].is_cuda and not pad_br and a in (None, "relu", "silu", "swish") and _env("DFINE_HIP_UNITS", "1") == "1"
                 and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1)
@@ -1094,6 +1167,9 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
         if route == 1:
             if x.dtype == torch.float32 and torch.is_autocast_enabled():
                 x = x.to(torch.get_autocast_dtype("cuda"))      # what autocast would do for F.conv2d
+            y = _bn_tail_fused(_DepthwiseConv, (x, conv.weight, conv.stride[0], conv.padding[0]), bn, a, lab)
+            if y is not None:
+                return y
             y = _DepthwiseConv.apply(x, conv.weight, conv.stride[0], conv.padding[0])
         elif route == 2:
             xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
