@@ -1257,12 +1257,73 @@ def _bn_trainable(bn):
             and bn.affine)
 
 
+class _DualConvBN2Act(torch.autograd.Function):
+    """_DualConv followed by _BN2Act as ONE autograd node (the RepVGG unit of the encoder in training form)."""
+
+    @staticmethod
+    def forward(ctx, x, wa, wb, residual, g1, b1, rm1, rv1, g2, b2, rm2, rv2, act, mom1, eps1, mom2, eps2):
+        ictx = _InnerCtx()
+        ictx.needs_input_grad = ctx.needs_input_grad[:3]
+        c1, c2 = _DualConv.forward(ictx, x, wa, wb)
+        res = None if residual is None else residual.contiguous()
+        y, saved = _hip().bn2_act_forward(c1, c2, res, (g1, b1, rm1, rv1, mom1, eps1), (g2, b2, rm2, rv2, mom2, eps2), act)
+        ctx.save_for_backward(c1, c2, saved)
+        ctx.ictx = ictx
+        ctx.cfg = (act, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        c1, c2, saved = ctx.saved_tensors
+        act, has_res = ctx.cfg
+        dy = dy.contiguous()
+        if dy.dtype != c1.dtype:
+            dy = dy.to(c1.dtype)
+        need = ctx.needs_input_grad
+        d1, d2, dg1, db1, dg2, db2 = _hip().bn2_act_backward(c1, c2, dy, saved, act, (need[4] or need[5], need[8] or need[9]))
+        dx, dwa, dwb = _DualConv.backward(ctx.ictx, d1, d2)
+        ctx.ictx = None
+        return (dx, dwa, dwb, dy if has_res else None, dg1, db1, None, None, dg2, db2, None, None, None, None, None, None, None)
+
+
 def repvgg_unit(x, conv1: nn.Conv2d, bn1, conv2: nn.Conv2d, bn2, act: Optional[str], residual=None):
     """act(bn1(conv1(x)) + bn2(conv2(x))) [+ residual]: the RepVGG block of the hybrid encoder in training form (ref
     hybrid_encoder.py:106-156) and CSPLayer's residual (hybrid_encoder.py:209-239).  On the GPU in bf16 training the two
     BatchNorms, the add, the activation and the residual add are ONE apply pass (csrc/bnact.hip: dfine_bn2_act_*);
     everything else composes the unit from conv_bn_act."""
     a = act.lower() if isinstance(act, str) else act
+    if x.is_cuda and _FUSE_CONV_BN:
+        # the fully fused form (dual conv + two BatchNorms + add + activation [+ residual] as one node), decided once per
+        # (module, input signature, BatchNorm mode)
+        routes = conv1.__dict__.get("_dfine_rep_routes")
+        if routes is None or routes[0] is not _ROUTES:
+            routes = conv1.__dict__["_dfine_rep_routes"] = (_ROUTES, {})
+        key = (x.shape, x.dtype, a, bn1.training, bn2.training, None if residual is None else (residual.shape, residual.dtype),
+               torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None)
+        ok = routes[1].get(key)
+        if ok is None:
+            ok = bool(a in (None, "relu", "silu", "swish") and _env("DFINE_HIP_UNITS", "1") == "1" and _env("DFINE_BN2", "1") == "1"
+                      and _bn_trainable(bn1) and _bn_trainable(bn2) and type(bn1) is nn.BatchNorm2d and type(bn2) is nn.BatchNorm2d
+                      and _mfma_conv_ok(conv1, x) and _mfma_conv_ok(conv2, x)
+                      and conv1.kernel_size == (3, 3) and conv2.kernel_size == (1, 1) and conv1.out_channels == conv2.out_channels
+                      and _env("DFINE_CONV_TUNE", "hip") == "hip" and _env("DFINE_DUAL_CONV", "1") == "1"
+                      and _hip().bn2_supported(torch.empty(x.shape[0], conv1.out_channels, x.shape[2], x.shape[3], device="meta",
+                                                           dtype=torch.bfloat16))
+                      and (residual is None or (residual.shape == (x.shape[0], conv1.out_channels, x.shape[2], x.shape[3])
+                                                and residual.dtype == torch.bfloat16)))
+            if len(routes[1]) > 64:
+                routes[1].clear()
+            routes[1][key] = ok
+        if ok:
+            for bn in (bn1, bn2):
+                if _BN_DEFER:
+                    ent = _BN_PENDING.get(id(bn))
+                    _BN_PENDING[id(bn)] = (bn.num_batches_tracked, 1 if ent is None else ent[1] + 1)
+                else:
+                    bn.num_batches_tracked.add_(1)
+            return _DualConvBN2Act.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv1.weight, conv2.weight, residual,
+                                         bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn2.weight, bn2.bias,
+                                         bn2.running_mean, bn2.running_var, a, bn1.momentum, bn1.eps, bn2.momentum, bn2.eps)
     if (x.is_cuda and a in (None, "relu", "silu", "swish") and _env("DFINE_HIP_UNITS", "1") == "1"
             and _env("DFINE_BN2", "1") == "1" and _bn_trainable(bn1) and _bn_trainable(bn2)
             and _mfma_conv_ok(conv1, x) and _mfma_conv_ok(conv2, x)):
