@@ -20,6 +20,7 @@
 namespace dfine {
 
 constexpr int kBnThreads = 256;
+static int kBnGridCap() { static const int v = [] { const char *e = getenv("DFINE_BN_GRID"); return e ? atoi(e) : 512; }(); return v; }   // workgroups of the flat apply kernels: 512 fat ones amortise the per-workgroup parameter / finalize prologue (6.12 -> 5.90 ms per step; 256: 6.28)
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
 
 __device__ __forceinline__ float act_fwd(float z, int act) {
@@ -1085,12 +1086,12 @@ int dfine_bn_act_fwd(const void *x, void *y, const float *gamma, const float *be
     if ((HW & 3) == 0 && C <= 4096) {
         const int64_t nvec = (int64_t)B * C * HW / 4;
         int64_t nb = (nvec + kBnThreads * 4 - 1) / (kBnThreads * 4);
-        if (nb > 4096) nb = 4096;
+        if (nb > kBnGridCap()) nb = kBnGridCap();
         const size_t sm = sizeof(float) * 2 * C;
         if (dtype != DFINE_F32 && (HW & 7) == 0 && nvec / 2 < (int64_t)1 << 31) {
             const int64_t nvec8 = nvec / 2;
             int64_t nb8 = (nvec8 + kBnThreads * 4 - 1) / (kBnThreads * 4);
-            if (nb8 > 4096) nb8 = 4096;
+            if (nb8 > kBnGridCap()) nb8 = kBnGridCap();
 #define DFINE_BNA8(A) hipLaunchKernelGGL(bn_apply_flat8_kernel<A>, dim3((unsigned)nb8), dim3(kBnThreads), sm, st, (const uint16_t *)x, \
                                          (uint16_t *)y, scale, shift, lab_scale, lab_bias, C, HW, nvec8, ffin)
             if (act == 0) DFINE_BNA8(0); else if (act == 1) DFINE_BNA8(1); else DFINE_BNA8(2);
@@ -1171,12 +1172,12 @@ int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_
     if ((HW & 3) == 0 && C <= 2048) {
         const int64_t nvec = (int64_t)B * C * HW / 4;
         int64_t nb = (nvec + kBnThreads * 4 - 1) / (kBnThreads * 4);
-        if (nb > 4096) nb = 4096;
+        if (nb > kBnGridCap()) nb = kBnGridCap();
         const size_t sm = sizeof(float) * 6 * C;
         if (dtype != DFINE_F32 && (HW & 7) == 0 && nvec / 2 < (int64_t)1 << 31) {
             const int64_t nvec8 = nvec / 2;
             int64_t nb8 = (nvec8 + kBnThreads * 4 - 1) / (kBnThreads * 4);
-            if (nb8 > 4096) nb8 = 4096;
+            if (nb8 > kBnGridCap()) nb8 = kBnGridCap();
 #define DFINE_BNB8(A) hipLaunchKernelGGL(bn_bwd_apply_flat8_kernel<A>, dim3((unsigned)nb8), dim3(kBnThreads), sm, st, (const uint16_t *)x, \
                                          (const uint16_t *)dy, (uint16_t *)dx, save_mean, save_invstd, scale, shift, lab_scale, coef, \
                                          C, HW, nvec8, training, bfin)
