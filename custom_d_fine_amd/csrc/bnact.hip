@@ -20,7 +20,14 @@
 namespace dfine {
 
 constexpr int kBnThreads = 256;
-static int kBnGridCap() { static const int v = [] { const char *e = getenv("DFINE_BN_GRID"); return e ? atoi(e) : 512; }(); return v; }   // workgroups of the flat apply kernels: 512 fat ones amortise the per-workgroup parameter / finalize prologue (6.12 -> 5.90 ms per step; 256: 6.28)
+// Workgroups of the flat apply kernels: few fat ones amortise the per-workgroup parameter / finalize prologue on the maps of
+// the 640 x 640 models (D-FINE-m: 6.12 -> 5.90 ms per step with 512 instead of 4096; 256: 6.28); the > 64 MB maps of the 960 x 960
+// models want the full grid (D-FINE-x + masks: 112.7 -> 109.8 ms per step).  DFINE_BN_GRID overrides.
+static int bn_grid_cap(int64_t nvec8) {
+    static const int env = [] { const char *e = getenv("DFINE_BN_GRID"); return e ? atoi(e) : 0; }();
+    if (env > 0) return env;
+    return nvec8 <= ((int64_t)1 << 22) ? 512 : 4096;
+}
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
 
 __device__ __forceinline__ float act_fwd(float z, int act) {
@@ -1086,12 +1093,12 @@ int dfine_bn_act_fwd(const void *x, void *y, const float *gamma, const float *be
     if ((HW & 3) == 0 && C <= 4096) {
         const int64_t nvec = (int64_t)B * C * HW / 4;
         int64_t nb = (nvec + kBnThreads * 4 - 1) / (kBnThreads * 4);
-        if (nb > kBnGridCap()) nb = kBnGridCap();
+        if (nb > bn_grid_cap(nvec / 2)) nb = bn_grid_cap(nvec / 2);
         const size_t sm = sizeof(float) * 2 * C;
         if (dtype != DFINE_F32 && (HW & 7) == 0 && nvec / 2 < (int64_t)1 << 31) {
             const int64_t nvec8 = nvec / 2;
             int64_t nb8 = (nvec8 + kBnThreads * 4 - 1) / (kBnThreads * 4);
-            if (nb8 > kBnGridCap()) nb8 = kBnGridCap();
+            if (nb8 > bn_grid_cap(nvec8)) nb8 = bn_grid_cap(nvec8);
 #define DFINE_BNA8(A) hipLaunchKernelGGL(bn_apply_flat8_kernel<A>, dim3((unsigned)nb8), dim3(kBnThreads), sm, st, (const uint16_t *)x, \
                                          (uint16_t *)y, scale, shift, lab_scale, lab_bias, C, HW, nvec8, ffin)
             if (act == 0) DFINE_BNA8(0); else if (act == 1) DFINE_BNA8(1); else DFINE_BNA8(2);
@@ -1172,12 +1179,12 @@ int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_
     if ((HW & 3) == 0 && C <= 2048) {
         const int64_t nvec = (int64_t)B * C * HW / 4;
         int64_t nb = (nvec + kBnThreads * 4 - 1) / (kBnThreads * 4);
-        if (nb > kBnGridCap()) nb = kBnGridCap();
+        if (nb > bn_grid_cap(nvec / 2)) nb = bn_grid_cap(nvec / 2);
         const size_t sm = sizeof(float) * 6 * C;
         if (dtype != DFINE_F32 && (HW & 7) == 0 && nvec / 2 < (int64_t)1 << 31) {
             const int64_t nvec8 = nvec / 2;
             int64_t nb8 = (nvec8 + kBnThreads * 4 - 1) / (kBnThreads * 4);
-            if (nb8 > kBnGridCap()) nb8 = kBnGridCap();
+            if (nb8 > bn_grid_cap(nvec8)) nb8 = bn_grid_cap(nvec8);
 #define DFINE_BNB8(A) hipLaunchKernelGGL(bn_bwd_apply_flat8_kernel<A>, dim3((unsigned)nb8), dim3(kBnThreads), sm, st, (const uint16_t *)x, \
                                          (const uint16_t *)dy, (uint16_t *)dx, save_mean, save_invstd, scale, shift, lab_scale, coef, \
                                          C, HW, nvec8, training, bfin)
