@@ -763,8 +763,12 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
     // multiples of 8), built once; the issue path then costs one ds_read_b64 per piece.  (Searching the part list there - per
     // lane or on the scalar unit, from kernel arguments or registers - cost 2x of the whole kernel.)
     const uint16_t **xtab = reinterpret_cast<const uint16_t **>(lds + kG2Ring * SB);
+    // ... and one per output row of this workgroup for the store loop (a per-lane search of the part list there was ~100
+    // vector instructions per 16-byte store, ~800 per wave and tile after the last MFMA)
+    uint16_t **ytab = reinterpret_cast<uint16_t **>(lds + kG2Ring * SB + 4096);
     if (SEG) {
         for (int gch = tid; gch * 8 < Cin; gch += kG2Threads) xtab[gch] = seg_addr(xs_, b, gch * 8, HW) + p0;
+        if (tid < 64 * NTN) ytab[tid] = const_cast<uint16_t *>(seg_addr(ys_, b, min(n0 + tid, Cout - 1), HW));
         __syncthreads();
     }
     auto issue = [&](int s) {
@@ -869,7 +873,7 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
         const int row = it * RPI + lane / LPO, c8 = (lane % LPO) * 8;
         const int n = n0 + wn * 16 * NTN + row;
         if (n < Cout && wp * 16 * PXW + c8 < npix) {
-            uint16_t *yp = SEG ? const_cast<uint16_t *>(seg_addr(ys_, b, n, HW))
+            uint16_t *yp = SEG ? ytab[wn * 16 * NTN + row]
                                : const_cast<uint16_t *>(ys_.p[0]) + ((int64_t)b * ys_.bs[0] + n) * HW;
             uint4 v = *reinterpret_cast<const uint4 *>(ot + row * OP + c8);
             if (accum) {                                  // y += conv(x): bf16 + bf16 in fp32, one rounding (like a separate add)
@@ -915,13 +919,13 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
         const ChanSegs xs_ = xsegs ? *xsegs : one_seg(x, Cin), ys_ = ysegs ? *ysegs : one_seg(y, Cout);
         const bool seg = xs_.n > 1 || ys_.n > 1;
         if (seg && Cin > 4096) return DFINE_E_BADARG;
-        const size_t lds2 = (size_t)(ring2 ? 2 : 3) * (kG2Rows * tp * 2 + 64 * (wide2 ? 2 : 1) * 128) + (seg ? 4096 : 0);
+        const size_t lds2 = (size_t)(ring2 ? 2 : 3) * (kG2Rows * tp * 2 + 64 * (wide2 ? 2 : 1) * 128) + (seg ? 5120 : 0);
         static bool attr2 = false;
         if (!attr2) {
             hipError_t e = hipSuccess, r;
 #define DFINE_G2_ATTR(N, R, P)                                                                                                                  \
     if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<N, R, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize, R * (64 * 64 * P + 8192 * N))) != hipSuccess) e = r; \
-    if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<N, R, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize, R * (64 * 64 * P + 8192 * N) + 4096)) != hipSuccess) e = r;
+    if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<N, R, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize, R * (64 * 64 * P + 8192 * N) + 5120)) != hipSuccess) e = r;
             DFINE_G2_ATTR(1, 2, 4) DFINE_G2_ATTR(1, 3, 4) DFINE_G2_ATTR(2, 2, 4) DFINE_G2_ATTR(2, 3, 4) DFINE_G2_ATTR(2, 3, 8)
 #undef DFINE_G2_ATTR
             if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }

@@ -161,6 +161,174 @@ __global__ __launch_bounds__(kGemmThreads) void linear_act_kernel(const uint16_t
     }
 }
 
+// Second generation for K % 64 == 0 and 16-byte aligned rows (every projection / FFN / head-trunk layer of the token
+// streams): the same tile product fed by asynchronous global -> LDS copies into a ring, like conv1x1_glds_kernel.  The
+// register-staged kernel above has ONE k step of loads in flight per workgroup and exposes a full L2 / HBM round trip per
+// 64-deep step (16 - 32 MFMAs of work): 0.2 PFLOP/s on 15 744 x 1024 x 256, 168 us on 268 800 x 256 x 256.
+//   stage  = 64 k: W rows [128][64] + X rows [64 MT][64], 8-row x 128-byte pieces copied by LDS-DMA; row r keeps its
+//            16-byte k chunk c at chunk c ^ (r & 7) (the copy writes LDS lane-linearly, so the swizzle is applied on the
+//            SOURCE side; the 16 lanes of one ds_read_b128 group then hit 16 different bank slots).
+//   ring   = R stages (4 for MT 2: a whole K = 256 row block is in flight at once; 3 for MT 1 / 4), counted vmcnt + ONE
+//            barrier per stage; the copies of stage s + R - 1 are issued behind the fragment reads of stage s.
+//   block  = 512 threads = 8 waves (2 over n x 4 over m), tile 128 (n) x 64 MT (m), wave = 64 (n) x 16 MT (m).
+constexpr int kLRThreads = 512;
+
+__device__ __forceinline__ void lr_glds16(const uint16_t *gsrc, unsigned lds_addr) {      // see glds16 in conv.hip
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+template <int ACT, int OUT32, int MT, int R>
+__global__ __launch_bounds__(kLRThreads) void linear_ring_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,
+                                                                 const float *__restrict__ bias, void *__restrict__ yv,
+                                                                 int M, int N, int K, int ldx, int ldw, int ldy, int nt_n,
+                                                                 int nt_m, int total_v) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int BM = 64 * MT, ROWS = kGBN + BM, SB = ROWS * 128, PPW = ROWS / 64;   // 8-row pieces per wave and stage
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wm = wave & 3;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int G = gridDim.x;                                               // a multiple of 8: a workgroup stays on its XCD
+    const int nk = K / kGBK;
+
+    // virtual tile index v -> (tn, tm): the n tiles of one m tile are consecutive slots of ONE XCD (v & 7)
+    auto decode = [&](int v, int &n0, int &m0) -> bool {
+        const int xcd = v & 7, slot = v >> 3;
+        const int tn = slot % nt_n, tm = (slot / nt_n) * 8 + xcd;
+        n0 = tn * kGBN; m0 = tm * BM;
+        return tm < nt_m;
+    };
+    auto next_valid = [&](int v) {
+        int n0, m0;
+        while (v < total_v && !decode(v, n0, m0)) v += G;
+        return v;
+    };
+
+    // ---- copy side: a flat stream of stages over this workgroup's tiles; the ring keeps filling across tile boundaries, so
+    // the loads of the next tile are in flight during the last MFMAs and the stores of the current one ----
+    // LDS image of a stage: row r keeps its 16-byte k chunk c at chunk c ^ f(r).  X rows: f = r & 7.  W rows: the MFMA "row" i
+    // of A tile a is W row 16 (i >> 2) + 4 a + (i & 3) of the wave's 64 (below), f = 2 ((r >> 4) & 3) + ((r >> 1) & 1): the 16
+    // lanes of one ds_read_b128 group then hit 16 different bank slots in both regions.
+    const int prow = lane >> 3, pc = lane & 7;
+    int iv = next_valid(blockIdx.x), is_ = 0, qi = 0;
+    const uint16_t *src[PPW];
+    auto set_src = [&]() {
+        int n0, m0;
+        decode(iv, n0, m0);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int row = (wave * PPW + j) * 8 + prow;
+            if (row < kGBN) src[j] = w + (int64_t)min(n0 + row, N - 1) * ldw + ((pc ^ (2 * ((row >> 4) & 3) + ((row >> 1) & 1))) << 3);
+            else src[j] = x + (int64_t)min(m0 + row - kGBN, M - 1) * ldx + ((pc ^ (row & 7)) << 3);   // rows past the matrix: any
+        }                                                                                            // valid row, never stored
+    };
+    if (iv < total_v) set_src();
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds + wave * PPW * 1024;
+    auto issue_next = [&]() {
+        if (iv >= total_v) return;
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (qi % R) * SB);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) lr_glds16(src[j] + is_ * kGBK, __builtin_amdgcn_readfirstlane(base + j * 1024));
+        ++qi;
+        if (++is_ == nk) {
+            is_ = 0;
+            iv = next_valid(iv + G);
+            if (iv < total_v) set_src();
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < R - 1; ++s) issue_next();
+
+    // A tile a, MFMA row i16 -> W row 16 (i16 >> 2) + 4 a + (i16 & 3): lane (i16, g) then ends up with the 16 CONSECUTIVE
+    // output features 16 g .. 16 g + 15 of token row i16 (a = 0 .. 3, r = 0 .. 3) - 32-byte pieces of whole 128-byte rows
+    const int ar = wn * 64 + 16 * (i16 >> 2) + (i16 & 3), fa = 2 * (i16 >> 2) + ((i16 >> 1) & 1);
+    const int arow = ar * 128, brow = (kGBN + wm * 16 * MT + i16) * 128;
+    const int sa0 = (g ^ fa) << 4, sa1 = ((4 + g) ^ fa) << 4;
+    const int sb0 = (g ^ (i16 & 7)) << 4, sb1 = ((4 + g) ^ (i16 & 7)) << 4;
+
+    int q = 0;
+    for (int cv = next_valid(blockIdx.x); cv < total_v; cv = next_valid(cv + G)) {
+        g_f32x4 acc[4][MT];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) acc[a][b] = g_f32x4{0.f, 0.f, 0.f, 0.f};
+        int n0, m0;
+        decode(cv, n0, m0);
+        const int n = n0 + wn * 64 + 16 * g;
+        // the bias is fetched HERE: a load in the epilogue would be waited for with the copies of the next tile in front of it
+        float bv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bv[e] = (bias && n + e < N) ? bias[n + e] : 0.f;
+        for (int s = 0; s < nk; ++s, ++q) {
+            // loads return in order: "at most (younger copies) outstanding" means this stage has landed (stores of the
+            // previous tile may still be counted - the wait is then longer than needed, never shorter)
+            const int ahead = qi - q - 1;
+            if (R >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const unsigned char *st = lds + (q % R) * SB;
+            g_bf16x8 af[2][4], bf[2][MT];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[0][t] = __builtin_bit_cast(g_bf16x8, *reinterpret_cast<const uint4 *>(st + arow + t * 512 + sa0));
+                af[1][t] = __builtin_bit_cast(g_bf16x8, *reinterpret_cast<const uint4 *>(st + arow + t * 512 + sa1));
+            }
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                bf[0][t] = __builtin_bit_cast(g_bf16x8, *reinterpret_cast<const uint4 *>(st + brow + t * 2048 + sb0));
+                bf[1][t] = __builtin_bit_cast(g_bf16x8, *reinterpret_cast<const uint4 *>(st + brow + t * 2048 + sb1));
+            }
+            issue_next();                                // into the slot of stage q - 1: every wave is past it (the barrier above)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int b = 0; b < MT; ++b)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[h][a], bf[h][b], acc[a][b], 0, 0, 0);
+        }
+
+        // ---- epilogue: bias + activation; lane -> Y[m][n .. n + 15] ----
+        if (n >= N) continue;
+        const bool full = n + 15 < N;
+#pragma unroll
+        for (int b = 0; b < MT; ++b) {
+            const int m = m0 + wm * 16 * MT + b * 16 + i16;
+            if (m >= M) continue;
+            float v[16];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * a + r] = act_apply(acc[a][b][r] + bv[4 * a + r], ACT);
+            if (OUT32) {
+                float *yp = reinterpret_cast<float *>(yv) + (int64_t)m * ldy + n;
+                if (full && (ldy & 3) == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) reinterpret_cast<float4 *>(yp)[e] = make_float4(v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]);
+                } else {
+                    for (int e = 0; e < 16 && n + e < N; ++e) yp[e] = v[e];
+                }
+            } else {
+                uint16_t *yp = reinterpret_cast<uint16_t *>(yv) + (int64_t)m * ldy + n;
+                if (full && (ldy & 7) == 0) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        reinterpret_cast<uint4 *>(yp)[e] = make_uint4(pack_bf16x2(v[8 * e], v[8 * e + 1]), pack_bf16x2(v[8 * e + 2], v[8 * e + 3]),
+                                                                      pack_bf16x2(v[8 * e + 4], v[8 * e + 5]), pack_bf16x2(v[8 * e + 6], v[8 * e + 7]));
+                } else {
+                    for (int e = 0; e < 16 && n + e < N; ++e) yp[e] = f32_to_bf16(v[e]);
+                }
+            }
+        }
+    }
+}
+
 // fp32 [rows, cols] -> bf16 [cols, rows] (transposed shadow of a Linear weight), many tensors per launch.
 // table rows of 4 x int64 = {src ptr, dst ptr, rows, cols}; blockIdx.y = entry, 32 x 32 LDS tiles.
 __global__ __launch_bounds__(256) void multi_cast_bf16_t_kernel(const int64_t *__restrict__ table) {
@@ -241,6 +409,51 @@ int dfine_linear_act_fwd(const void *x, const void *w, const float *bias, void *
     if (M == 0 || N == 0) return DFINE_OK;
     if (!x || !w || !y || M < 0 || N < 0 || K < 1 || ldx < K || ldw < K || ldy < N || act < 0 || act > 3) return DFINE_E_BADARG;
     const int nt_n = (N + kGBN - 1) / kGBN;
+    hipStream_t st = (hipStream_t)stream;
+    static const int ring_env = [] { const char *e = getenv("DFINE_LINEAR_RING"); return e ? atoi(e) : -1; }();   // 0 off, 1/2/4 forces MT
+    if (ring_env != 0 && (K % kGBK) == 0 && (ldx & 7) == 0 && (ldw & 7) == 0 && (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0) {
+        // m tile: 256 rows once that still gives >= 4 rounds of workgroups (the 268 800-row encoder streams), 64 rows when
+        // 128-row tiles would leave CUs idle, 128 otherwise
+        const int64_t t128 = (int64_t)((M + 127) / 128) * nt_n;
+        int mt = t128 >= 900 ? 4 : t128 >= 200 ? 2 : 1;
+        if (ring_env > 0) mt = ring_env;
+        const int bm = 64 * mt, nt_m = (M + bm - 1) / bm, ring = mt == 2 ? 4 : 3;
+        const size_t ldsb = (size_t)ring * (kGBN + bm) * 128;
+        const int total_v = 8 * ((nt_m + 7) / 8) * nt_n;
+        static const int cus = [] { int d = 0, c = 0; hipGetDevice(&d); hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d); return c > 0 ? c : 256; }();
+        const int resident = (cus & ~7) * (mt == 1 ? 2 : 1);                // workgroups that fit the chip at once (LDS bound)
+        dim3 grid(total_v < resident ? total_v : resident);
+        static bool ring_attr = false;
+#define DFINE_LR_ATTR(A, O, T, RR)                                                                                        \
+    { hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void *>(linear_ring_kernel<A, O, T, RR>),                \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, RR * (kGBN + 64 * T) * 128);        \
+      if (r != hipSuccess) e = r; }
+#define DFINE_LR_ATTR_A(O, T, RR) DFINE_LR_ATTR(0, O, T, RR) DFINE_LR_ATTR(1, O, T, RR) DFINE_LR_ATTR(2, O, T, RR) DFINE_LR_ATTR(3, O, T, RR)
+        if (!ring_attr) {
+            hipError_t e = hipSuccess;
+            DFINE_LR_ATTR_A(0, 1, 3) DFINE_LR_ATTR_A(1, 1, 3) DFINE_LR_ATTR_A(0, 2, 4) DFINE_LR_ATTR_A(1, 2, 4)
+            DFINE_LR_ATTR_A(0, 4, 3) DFINE_LR_ATTR_A(1, 4, 3)
+            if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
+            ring_attr = true;
+        }
+#undef DFINE_LR_ATTR_A
+#undef DFINE_LR_ATTR
+#define DFINE_LR(A, O, T, RR)                                                                                             \
+    hipLaunchKernelGGL((linear_ring_kernel<A, O, T, RR>), grid, dim3(kLRThreads), ldsb, st, (const uint16_t *)x,          \
+                       (const uint16_t *)w, bias, y, M, N, K, ldx, ldw, ldy, nt_n, nt_m, total_v)
+#define DFINE_LR_T(A, O) { if (mt == 4) DFINE_LR(A, O, 4, 3); else if (mt == 2) DFINE_LR(A, O, 2, 4); else DFINE_LR(A, O, 1, 3); }
+#define DFINE_LR_O(A) { if (out_f32) DFINE_LR_T(A, 1) else DFINE_LR_T(A, 0) }
+        switch (act) {
+            case 0: DFINE_LR_O(0) break;
+            case 1: DFINE_LR_O(1) break;
+            case 2: DFINE_LR_O(2) break;
+            default: DFINE_LR_O(3) break;
+        }
+#undef DFINE_LR_O
+#undef DFINE_LR_T
+#undef DFINE_LR
+        return check_launch();
+    }
     // 128-row m tiles when they still give >= 2 workgroups per CU; 64-row tiles otherwise (the token streams have
     // 12 800 - 15 744 rows: 100 - 123 tiles of 128 rows would leave half of the 256 CUs idle)
     const int mt = ((int64_t)((M + 127) / 128) * nt_n >= 512) ? 4 : 2;
@@ -248,7 +461,6 @@ int dfine_linear_act_fwd(const void *x, const void *w, const float *bias, void *
     const int nt_m = (M + bm - 1) / bm;
     const size_t ldsb = (size_t)2 * (kGBN + bm) * kGPitch * 2;              // 73 728 B / 55 296 B
     dim3 grid(8 * ((nt_m + 7) / 8) * nt_n);
-    hipStream_t st = (hipStream_t)stream;
     static bool attr_set = false;       // once: not a stream operation, keep it out of graph capture
 #define DFINE_LA_ATTR(A, O, T)                                                                                           \
     { hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void *>(linear_act_kernel<A, O, T>),                     \
