@@ -299,7 +299,7 @@ __host__ __device__ static inline int ws_pitch(int W) { return (W + 2 + 7) & ~7;
 template <int NTN, int VEC, int KC>
 __global__ __launch_bounds__(kWsThreads) void conv3x3_ws_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w2,
                                                                uint16_t *__restrict__ y, int Cin, int Cout, int NP, int KP, int H,
-                                                               int W, int R, int strips, int nblk, int units) {
+                                                               int W, int R, int strips, int nblk, int units, int accum) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int KS = 3, PAD = 1;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -493,9 +493,20 @@ __global__ __launch_bounds__(kWsThreads) void conv3x3_ws_kernel(const uint16_t *
         const int drow = 64 / cpr, dc = (64 - drow * cpr) * VEC;
         while (row < 16 * NTN) {
             const int n = n_wave + row;
-            if (n < Cout)
-                *reinterpret_cast<typename PixVec<VEC>::type *>(yb + (int64_t)n * H * W + c) =
-                    *reinterpret_cast<const typename PixVec<VEC>::type *>(ot + row * OP + c);
+            if (n < Cout) {
+                typename PixVec<VEC>::type v = *reinterpret_cast<const typename PixVec<VEC>::type *>(ot + row * OP + c);
+                typename PixVec<VEC>::type *dst = reinterpret_cast<typename PixVec<VEC>::type *>(yb + (int64_t)n * H * W + c);
+                if (accum) {                                     // y += conv(x): bf16 + bf16 in fp32, one rounding (like a separate add)
+                    const typename PixVec<VEC>::type o = *dst;
+                    const uint32_t *a2 = reinterpret_cast<const uint32_t *>(&v), *c2 = reinterpret_cast<const uint32_t *>(&o);
+                    uint32_t *r2 = reinterpret_cast<uint32_t *>(&v);
+#pragma unroll
+                    for (int e = 0; e < VEC / 2; ++e)
+                        r2[e] = pack_bf16x2(__uint_as_float(a2[e] << 16) + __uint_as_float(c2[e] << 16),
+                                            __uint_as_float(a2[e] & 0xffff0000u) + __uint_as_float(c2[e] & 0xffff0000u));
+                }
+                *dst = v;
+            }
             row += drow;
             c += dc;
             if (c >= TP) { c -= TP; ++row; }
@@ -891,6 +902,12 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
     }
 }
 
+// shapes the LDS-DMA kernel takes (the others run on conv1x1_tr_kernel: whole tensors, no accumulation)
+static bool conv1x1_glds_ok(int Cin, int KP, int HW) {
+    static const int v2_env = [] { const char *e = getenv("DFINE_CONV1X1_GLDS"); return e ? atoi(e) : 1; }();
+    return v2_env && HW % 8 == 0 && KP >= 8 && Cin >= 4 && Cin % 4 == 0;
+}
+
 static ChanSegs one_seg(const void *p, int C) {
     ChanSegs sg{};
     sg.p[0] = (const uint16_t *)p; sg.start[0] = 0; sg.start[1] = C; sg.bs[0] = C; sg.n = 1;
@@ -901,9 +918,8 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
                           hipStream_t st, const ChanSegs *xsegs = nullptr, const ChanSegs *ysegs = nullptr, int accum = 0,
                           int64_t w_bstride = 0) {
     const int ptiles = (HW + kTrPix - 1) / kTrPix;
-    static const int v2_env = [] { const char *e = getenv("DFINE_CONV1X1_GLDS"); return e ? atoi(e) : 1; }();
     static const int px256_env = [] { const char *e = getenv("DFINE_CONV1X1_PX256"); return e ? atoi(e) : 1; }();
-    if (v2_env && HW % 8 == 0 && KP >= 8 && Cin >= 4 && Cin % 4 == 0) {
+    if (conv1x1_glds_ok(Cin, KP, HW)) {
         // The kernel is bound by the ~10 B/clk/CU load path, so the tile is as large as the layer can fill the chip with:
         // 256 pixels x 128 channels (87 FLOP per loaded byte) for deep layers on big maps, 128 x 128 (64) / 128 x 64 otherwise.
         const bool ring2 = KP <= 2 * kG2Rows;                  // <= 2 stages: both fit a 2-slot ring, half the LDS, 2 workgroups per CU
@@ -1602,8 +1618,29 @@ static void wgrad_plan(int B, int Cin, int Cout, int H, int W, int KS, int *R, i
     }
 }
 
+// the wave-specialised 3x3 kernel's shape range (the others run on conv_igemm_kernel: no accumulation)
+static bool conv3x3_ws_ok(int B, int NP, int KP, int H, int W) {
+    if (W < 1 || W > 160 || H < 1) return false;
+    int R = 160 / W;
+    if (R > H) R = H;
+    const int strips = (H + R - 1) / R;
+    const size_t slab_bytes = (size_t)(R + 2) * (W + 2) * 64;
+    static const int kc_env = [] { const char *e = getenv("DFINE_CONV_KC"); return e ? atoi(e) : 0; }();
+    int kc = KP >= 256 ? 4 : (KP >= 64 ? 2 : 1);
+    if (kc_env) kc = kc_env;
+    while (kc > 1 && (slab_bytes * kc > 65536 || KP < 32 * kc)) kc >>= 1;
+    const int vec = (W % 8 == 0) ? 8 : (W % 4 == 0 ? 4 : 2);
+    const bool wide = (NP % 128 == 0) && ((int64_t)B * strips * (NP / 128) >= 512);
+    static const int ws_env = [] { const char *e = getenv("DFINE_CONV3X3_WS"); return e ? atoi(e) : 1; }();
+    const size_t ws_ep = (size_t)4 * 16 * (wide ? 2 : 1) * (16 * kMaxPixTiles + 8) * 2;
+    const int kc_ws = kc > 2 ? 2 : kc;
+    const size_t ws_slab = (size_t)(R + 2) * ws_pitch(W) * 64;
+    const int ws_items = 16 * (R + 2) * (W / vec) * kc_ws;
+    return ws_env && NP % 64 == 0 && vec >= 4 && 2 * ws_slab * kc_ws + ws_ep <= 160 * 1024 && ws_items <= (vec == 8 ? 8 : 12) * 256;
+}
+
 static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B, int Cin, int Cout, int NP, int KP,
-                       int H, int W, int KS, hipStream_t st) {
+                       int H, int W, int KS, hipStream_t st, int accum = 0) {
     // strip height: as many rows as fit in 160 pixels
     int R = 160 / W;
     if (R < 1) return DFINE_E_BADARG;
@@ -1620,12 +1657,10 @@ static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B
     const int vec = (W % 8 == 0) ? 8 : (W % 4 == 0 ? 4 : 2);
     const int nblk64 = (NP + 63) / 64;
     const bool wide = (NP % 128 == 0) && ((int64_t)B * strips * (NP / 128) >= 512);
-    static const int ws_env = [] { const char *e = getenv("DFINE_CONV3X3_WS"); return e ? atoi(e) : 1; }();
     const size_t ws_ep = (size_t)4 * 16 * (wide ? 2 : 1) * (16 * kMaxPixTiles + 8) * 2;
     int kc_ws = kc > 2 ? 2 : kc;                               // two buffers: the stage overhead is already hidden
     const size_t ws_slab = (size_t)(R + 2 * pad) * ws_pitch(W) * 64;
-    const int ws_items = 16 * (R + 2 * pad) * (W / vec) * kc_ws;
-    if (KS == 3 && ws_env && NP % 64 == 0 && vec >= 4 && 2 * ws_slab * kc_ws + ws_ep <= 160 * 1024 && ws_items <= (vec == 8 ? 8 : 12) * 256) {
+    if (KS == 3 && conv3x3_ws_ok(B, NP, KP, H, W)) {
         // wave-specialised persistent kernel: 128-channel blocks when they fill the chip, 64-channel blocks otherwise
         const int ntn = wide ? 2 : 1;
         const int nblk = NP / (64 * ntn);
@@ -1645,7 +1680,7 @@ static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B
             attr_ws = true;
         }
 #define DFINE_WS(N, V, K) \
-    hipLaunchKernelGGL((conv3x3_ws_kernel<N, V, K>), dim3(8 * wpx), dim3(kWsThreads), 2 * ws_slab * kc_ws + ws_ep, st, x, w2, y, Cin, Cout, NP, KP, H, W, R, strips, nblk, units)
+    hipLaunchKernelGGL((conv3x3_ws_kernel<N, V, K>), dim3(8 * wpx), dim3(kWsThreads), 2 * ws_slab * kc_ws + ws_ep, st, x, w2, y, Cin, Cout, NP, KP, H, W, R, strips, nblk, units, accum)
 #define DFINE_WS_K(N, V) { if (kc_ws == 2) DFINE_WS(N, V, 2); else DFINE_WS(N, V, 1); }
 #define DFINE_WS_V(N) { if (vec == 8) DFINE_WS_K(N, 8) else DFINE_WS_K(N, 4) }
         if (ntn == 2) DFINE_WS_V(2) else DFINE_WS_V(1)
@@ -1654,6 +1689,7 @@ static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B
 #undef DFINE_WS
         return check_launch();
     }
+    if (accum) return DFINE_E_BADARG;                // conv_igemm_kernel: plain stores only
     dim3 grid(B * strips, wide ? NP / 128 : nblk64);
 #define DFINE_CONV(KSS, NTNN, VECC, KCC)                                                                   \
     hipLaunchKernelGGL((conv_igemm_kernel<KSS, NTNN, VECC, KCC>), grid, dim3(kConvThreads), ldsb, st, x, w2, y, Cin, \
@@ -1761,6 +1797,29 @@ int dfine_conv_fwd_bf16(const void *x, const void *w2, void *y, int B, int Cin, 
     if (w % 2 || w > 160) return DFINE_E_BADARG;
     return launch_conv((const uint16_t *)x, (const uint16_t *)w2, (uint16_t *)y, B, Cin, Cout, NP, KP, h, w, KS,
                        (hipStream_t)stream);
+}
+
+// y += conv(x): a data gradient added onto the one already in y - the sum autograd forms for a map with two consumers
+// (HG_Block: layer i output -> layer i + 1 and the aggregation, ref hgnetv2.py:265-274) without the element-wise add pass.
+// Only on the shapes dfine_conv_epilogue_supported() accepts (the LDS-DMA 1x1 kernel / the wave-specialised 3x3 kernel);
+// DFINE_E_BADARG otherwise, the caller then adds separately.
+int dfine_conv_epilogue_supported(int B, int Cin, int Cout, int H, int W, int KS) {
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || Cin % 2) return 0;
+    const int NP = (Cout + 15) / 16 * 16, KP = (Cin + 31) / 32 * 32;
+    if (KS == 1) return conv1x1_glds_ok(Cin, KP, H * W) ? 1 : 0;
+    if (KS == 3) return (W % 2 == 0 && conv3x3_ws_ok(B, NP, KP, H, W)) ? 1 : 0;
+    return 0;
+}
+
+int dfine_conv_accum_bf16(const void *x, const void *w2, void *y, int B, int Cin, int Cout, int H, int W, int KS, void *stream) {
+    if (B == 0) return DFINE_OK;
+    if (!x || !w2 || !y || !dfine_conv_epilogue_supported(B, Cin, Cout, H, W, KS)) return DFINE_E_BADARG;
+    const int NP = (Cout + 15) / 16 * 16, KP = (Cin + 31) / 32 * 32;
+    if (KS == 1)
+        return launch_conv1x1((const uint16_t *)x, (const uint16_t *)w2, (uint16_t *)y, B, Cin, Cout, NP, KP, H * W,
+                              (hipStream_t)stream, nullptr, nullptr, 1);
+    return launch_conv((const uint16_t *)x, (const uint16_t *)w2, (uint16_t *)y, B, Cin, Cout, NP, KP, H, W, KS,
+                       (hipStream_t)stream, 1);
 }
 
 // y[B, Cout, H*W] += conv1x1(x[B, Cin, H*W]) (bf16 accumulate-into: the second data gradient of a RepVGG unit adds onto

@@ -47,15 +47,16 @@ class ConvBNAct(nn.Module):
         self.act = nn.ReLU() if use_act else nn.Identity()
         self.lab = LearnableAffineBlock() if (use_act and use_lab) else nn.Identity()
 
-    def forward(self, x, pad_br=False):
-        """pad_br: the input stands for F.pad(x, (0, 1, 0, 1)) (StemBlock); the pad is applied inside."""
+    def forward(self, x, pad_br=False, fanin=None, fans=None):
+        """pad_br: the input stands for F.pad(x, (0, 1, 0, 1)) (StemBlock); the pad is applied inside.
+        fanin / fans: gradient hand-offs of HG_Block (kernels.GradFanIn)."""
         if isinstance(self.conv, nn.Sequential):
             x = self.conv[0](torch.cat(list(x), dim=1) if isinstance(x, (list, tuple)) else x)
             conv = self.conv[1]
         else:
             conv = self.conv
         lab = self.lab if isinstance(self.lab, LearnableAffineBlock) else None
-        return kernels.conv_bn_act(x, conv, self.bn, "relu" if self.use_act else None, lab, pad_br=pad_br)
+        return kernels.conv_bn_act(x, conv, self.bn, "relu" if self.use_act else None, lab, pad_br=pad_br, fanin=fanin, fans=fans)
 
 
 class LightConvBNAct(nn.Module):
@@ -67,8 +68,8 @@ class LightConvBNAct(nn.Module):
         self.conv2 = ConvBNAct(out_chs, out_chs, kernel_size, groups=out_chs, use_act=True,
                                use_lab=use_lab)
 
-    def forward(self, x):
-        return self.conv2(self.conv1(x))
+    def forward(self, x, fanin=None):
+        return self.conv2(self.conv1(x, fanin=fanin))
 
 
 class StemBlock(nn.Module):
@@ -135,9 +136,17 @@ class HG_Block(nn.Module):
 
     def forward(self, x):
         feats = [x]
-        for layer in self.layers:
-            feats.append(layer(feats[-1]))
-        y = self.aggregation(feats)        # channel concat of all maps, read in place by the 1x1 aggregation conv
+        if kernels.grad_fanin_enabled(x):
+            # every map but the last has two consumers (the next layer and the aggregation): their data gradients meet in
+            # the next layer's convolution epilogue instead of an element-wise add (kernels.GradFanIn)
+            fans = [kernels.GradFanIn() for _ in self.layers]
+            for layer, fan in zip(self.layers, fans):
+                feats.append(layer(feats[-1], fanin=fan))
+            y = self.aggregation[1](self.aggregation[0](feats, fans=fans + [None]))
+        else:
+            for layer in self.layers:
+                feats.append(layer(feats[-1]))
+            y = self.aggregation(feats)    # channel concat of all maps, read in place by the 1x1 aggregation conv
         return self.drop_path(y) + x if self.residual else y
 
 

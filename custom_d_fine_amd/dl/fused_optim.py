@@ -314,6 +314,7 @@ class FusedAdamWEMA:
         """Moves the listed parameters' gradients into their flat slots with one multi-tensor copy and drops them.
         (Keeping `.grad` as persistent views instead makes autograd ADD into them - one tiny kernel per parameter,
         646 per step for D-FINE-m.)"""
+        self.hip.side_join()                 # gradient tensors produced on the side stream (depthwise / stem weight gradients)
         grads, offs = [], []
         for i in indices:
             p = self._params[i]

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "dfine_maps_tokens_bf16": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_conv_fwd_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_conv1x1_accum_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfine_conv_epilogue_supported": (c_int, [_I, _I, _I, _I, _I, _I]),
+    "dfine_conv_accum_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_conv_wgrad_ws_floats": (_L, [_I, _I, _I, _I, _I, _I]),
     "dfine_conv_wgrad_bf16": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_fdr_fwd": (c_int, [_P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -423,11 +425,22 @@ def dwconv_forward(x, w, stride, pad):
     return y
 
 
-def dwconv_backward(x, w, dy, stride, pad, need_dx=True, need_dw=True):
+def dwconv_backward(x, w, dy, stride, pad, need_dx=True, need_dw=True, side_dw=False):
+    """side_dw: the weight gradient is launched on the side stream (see _side_fork); the caller guarantees that its only
+    consumer runs behind side_join() (the fused optimizer's gradient gather)."""
     B, C, H, W = x.shape
     K = w.shape[-1]
     dx = torch.empty_like(x) if need_dx else None
     dw = torch.zeros(w.shape, device=x.device, dtype=torch.float32) if need_dw else None
+    if side_dw and need_dw and _side_ok():
+        st = _side_fork(x.device)
+        _check(_lib.dfine_dwconv_bwd(_ptr(x), _ptr(w), _ptr(dy), None, _ptr(dw), _dtype_code(x), B, C, H, W, K, stride, pad,
+                                     st.cuda_stream), "dfine_dwconv_bwd")
+        _SIDE_LIVE.append((x, w, dy))         # (not dw: autograd only takes ownership of a gradient nobody else references - it would CLONE it, on the main stream)
+        if need_dx:
+            _check(_lib.dfine_dwconv_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), None, _dtype_code(x), B, C, H, W, K, stride, pad,
+                                         _stream()), "dfine_dwconv_bwd")
+        return dx, dw
     with _timed("dfine_dwconv_bwd"):
         _check(_lib.dfine_dwconv_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _dtype_code(x), B, C, H, W,
                                      K, stride, pad, _stream()), "dfine_dwconv_bwd")
@@ -484,6 +497,27 @@ def bn_act_forward(x, gamma, beta, running_mean, running_var, lab_scale, lab_bia
         stats[0].copy_(running_mean)
         torch.rsqrt(running_var + eps, out=stats[1])
     return y, stats
+
+
+_EPI_OK = {}
+
+
+def conv_epilogue_supported(B, cin, cout, H, W, ks):
+    """Does the forward kernel for this shape have the accumulate epilogue (dfine_conv_epilogue_supported)?"""
+    key = (B, cin, cout, H, W, ks)
+    ok = _EPI_OK.get(key)
+    if ok is None:
+        ok = _EPI_OK[key] = bool(_lib.dfine_conv_epilogue_supported(B, cin, cout, H, W, ks))
+    return ok
+
+
+def conv_accumulate_bf16(x, w2, y, ks):
+    """y += conv(x) (bf16, in place): dfine_conv_accum_bf16, shapes of conv_epilogue_supported only."""
+    B, cin, H, W = x.shape
+    status = _lib.dfine_conv_accum_bf16(x.data_ptr(), w2.data_ptr(), y.data_ptr(), B, cin, y.shape[1], H, W, ks, _stream())
+    if status != 0:
+        _check(status, "dfine_conv_accum_bf16")
+    return y
 
 
 def bn_act_backward(x, dy, stats, lab_scale, act, training, need_affine=True, need_lab=True, dlab_ptr=None):
@@ -723,12 +757,53 @@ def conv1x1_seg_wgrad(x_parts, dy, partials=False):
     dw = None if partials else torch.empty(cout, cin, 1, 1, device=dy.device, dtype=torch.float32)
     ws = torch.empty(int(_lib.dfine_conv_wgrad_ws_floats(B, cin, cout, H, W, 1)), device=dy.device, dtype=torch.float32)
     xp, xc, xb = _seg_arrays(x_parts)
+    if partials and _side_ok():
+        st = _side_fork(dy.device)
+        _check(_lib.dfine_conv1x1_seg_wgrad_bf16(xp, xc, xb, len(x_parts), _ptr(dy), None, _ptr(ws), B, cin, cout, H, W,
+                                                 st.cuda_stream), "dfine_conv1x1_seg_wgrad_bf16")
+        _SIDE_LIVE.append((x_parts, dy, ws))
+        return ws, (int(_lib.dfine_conv_wgrad_splits(B, cin, cout, H, W, 1)), cout, cin, 1, _p16(cout), _p16(cin))
     with _timed("conv1x1_wgrad", 2.0 * B * H * W * cin * cout, io=2.0 * B * H * W * (cin + cout) + 4.0 * cin * cout):
         _check(_lib.dfine_conv1x1_seg_wgrad_bf16(xp, xc, xb, len(x_parts), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W,
                                                  _stream()), "dfine_conv1x1_seg_wgrad_bf16")
     if partials:
         return ws, (int(_lib.dfine_conv_wgrad_splits(B, cin, cout, H, W, 1)), cout, cin, 1, _p16(cout), _p16(cin))
     return dw
+
+
+# ---- weight gradients on a second HIP stream ---------------------------------------------------------------------------
+# In backward a convolution's weight gradient depends on nothing after it and nothing depends on it until the optimizer's
+# flush, while the chain  BatchNorm backward -> data gradient -> next unit's BatchNorm backward ...  is a sequence of short,
+# latency-bound launches that leave most of the chip idle.  The deferred weight-gradient launches (partial sums, reduced at
+# the flush) therefore go to a side stream forked from the current one and joined at the flush: they fill the idle CUs
+# under the chain.  Inputs stay referenced until the join (the caching allocator only knows the stream a block was
+# allocated on).  DFINE_WGRAD_STREAM=0: everything on the current stream.
+WGRAD_STREAM = os.environ.get("DFINE_WGRAD_STREAM", "1") == "1"
+_SIDE = {}
+_SIDE_LIVE = []
+_SIDE_GROUP_AT = int(os.environ.get("DFINE_WGRAD_GROUP_AT", "12"))     # registered problems that trigger an early grouped launch
+
+
+def _side_ok():
+    return WGRAD_STREAM and not _TIMING_ON and not torch.cuda.is_current_stream_capturing()
+
+
+def _side_fork(dev):
+    """-> raw handle of the side stream, made to wait for everything enqueued on the current stream so far."""
+    st = _SIDE.get(dev.index)
+    if st is None:
+        st = _SIDE[dev.index] = torch.cuda.Stream(device=dev)
+    st.wait_stream(torch.cuda.current_stream(dev))
+    return st
+
+
+def side_join():
+    """The current stream waits for the side stream's launches (called before their results are consumed)."""
+    if _SIDE_LIVE:
+        cur = torch.cuda.current_stream()
+        for st in _SIDE.values():
+            cur.wait_stream(st)
+        _SIDE_LIVE.clear()
 
 
 def conv_wgrad_supported(H, W, ks):
@@ -756,7 +831,14 @@ def conv_wgrad_bf16(x, dy, ks, partials=False):
     if partials and ks == 1 and _CW_GROUP and (H * W) % 8 == 0:
         # registered only: every 1x1 weight gradient of a flush runs in one launch (linear_wgrad_flush -> dfine_conv_wgrad1_group)
         _CW_PENDING.append((x, dy, ws, B, cin, cout, H * W))
+        if len(_CW_PENDING) >= _SIDE_GROUP_AT and _side_ok():
+            _flush_conv_group(True)          # ... or in a few, on the side stream while backward goes on
         return ws, (int(_lib.dfine_conv_wgrad_splits(B, cin, cout, H, W, ks)), cout, cin, 1, _p16(cout), _p16(cin))
+    if partials and _side_ok():
+        st = _side_fork(x.device)
+        _check(_lib.dfine_conv_wgrad_bf16(_ptr(x), _ptr(dy), None, _ptr(ws), B, cin, cout, H, W, ks, st.cuda_stream), "dfine_conv_wgrad_bf16")
+        _SIDE_LIVE.append((x, dy, ws))
+        return ws, (int(_lib.dfine_conv_wgrad_splits(B, cin, cout, H, W, ks)), cout, cin, ks * ks, _p16(cout), _p16(cin))
     with _timed(f"conv{ks}x{ks}_wgrad", 2.0 * B * H * W * cin * cout * ks * ks, io=2.0 * B * H * W * (cin + cout) + 4.0 * cin * cout * ks * ks):
         _check(_lib.dfine_conv_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ks, _stream()),
                "dfine_conv_wgrad_bf16")
@@ -951,6 +1033,8 @@ def linear_wgrad_partials(x2d, dy2d):
     ws = torch.empty(int(_lib.dfine_linear_wgrad_ws_floats(M, N, K)), device=x2d.device, dtype=torch.float32)
     if _LW_GROUP:
         _LW_PENDING.append((x2d, dy2d, ws, M, N, K))
+        if len(_LW_PENDING) >= 2 * _SIDE_GROUP_AT and _side_ok():
+            _flush_linear_group(True)
     else:
         with _timed("linear_wgrad", 2.0 * M * N * K, io=2.0 * M * (N + K) + 4.0 * N * K):
             _check(_lib.dfine_linear_wgrad_bf16(_ptr(x2d), _ptr(dy2d), None, None, _ptr(ws), M, N, K, _stream()),
@@ -960,31 +1044,34 @@ def linear_wgrad_partials(x2d, dy2d):
     return ws, (splits, N, K, 1, np16, cp16), (splits, N, 1, 1, np16, 1), splits * np16 * cp16
 
 
-def linear_wgrad_flush():
-    """Runs the registered weight-gradient problems (token-stream linears, 1x1 convolutions: partial sums into their `ws`
-    buffers) in one launch per kind."""
+def _flush_conv_group(side=False):
     import numpy as np
     from .d_fine.arch.utils import upload
-    if _CW_PENDING:
-        pend = list(_CW_PENDING)
-        _CW_PENDING.clear()
-        table = np.empty((len(pend), 8), dtype=np.int64)
-        blocks, flops, io = 1, 0.0, 0.0
-        for i, (x, dy, ws, B, cin, cout, hw) in enumerate(pend):
-            n = int(_lib.dfine_conv_wgrad1_group_row(x.data_ptr(), dy.data_ptr(), ws.data_ptr(), B, cin, cout, hw, table[i].ctypes.data))
-            if n < 0:
-                raise RuntimeError("dfine_conv_wgrad1_group_row: bad arguments")
-            blocks = max(blocks, n)
-            flops += 2.0 * B * hw * cin * cout
-            io += 2.0 * B * hw * (cin + cout) + 4.0 * cin * cout
-        dev_table = upload(table, pend[0][0].device)
-        with _timed("conv1x1_wgrad", flops, io=io):
-            _check(_lib.dfine_conv_wgrad1_group(_ptr(dev_table), len(pend), blocks, _stream()), "dfine_conv_wgrad1_group")
-        _LW_KEEP.append((pend, dev_table))
-    if not _LW_PENDING:
-        while len(_LW_KEEP) > 4:
-            _LW_KEEP.pop(0)
+    pend = list(_CW_PENDING)
+    _CW_PENDING.clear()
+    table = np.empty((len(pend), 8), dtype=np.int64)
+    blocks, flops, io = 1, 0.0, 0.0
+    for i, (x, dy, ws, B, cin, cout, hw) in enumerate(pend):
+        n = int(_lib.dfine_conv_wgrad1_group_row(x.data_ptr(), dy.data_ptr(), ws.data_ptr(), B, cin, cout, hw, table[i].ctypes.data))
+        if n < 0:
+            raise RuntimeError("dfine_conv_wgrad1_group_row: bad arguments")
+        blocks = max(blocks, n)
+        flops += 2.0 * B * hw * cin * cout
+        io += 2.0 * B * hw * (cin + cout) + 4.0 * cin * cout
+    dev_table = upload(table, pend[0][0].device)
+    if side:
+        st = _side_fork(pend[0][0].device)         # (forked after the table's copy was enqueued)
+        _check(_lib.dfine_conv_wgrad1_group(_ptr(dev_table), len(pend), blocks, st.cuda_stream), "dfine_conv_wgrad1_group")
+        _SIDE_LIVE.append((pend, dev_table))
         return
+    with _timed("conv1x1_wgrad", flops, io=io):
+        _check(_lib.dfine_conv_wgrad1_group(_ptr(dev_table), len(pend), blocks, _stream()), "dfine_conv_wgrad1_group")
+    _LW_KEEP.append((pend, dev_table))
+
+
+def _flush_linear_group(side=False):
+    import numpy as np
+    from .d_fine.arch.utils import upload
     pend = list(_LW_PENDING)
     _LW_PENDING.clear()
     table = np.empty((len(pend), 8), dtype=np.int64)
@@ -997,11 +1084,27 @@ def linear_wgrad_flush():
         flops += 2.0 * M * N * K
         io += 2.0 * M * (N + K) + 4.0 * N * K
     dev_table = upload(table, pend[0][0].device)
+    if side:
+        st = _side_fork(pend[0][0].device)
+        _check(_lib.dfine_linear_wgrad_group(_ptr(dev_table), len(pend), blocks, st.cuda_stream), "dfine_linear_wgrad_group")
+        _SIDE_LIVE.append((pend, dev_table))
+        return
     with _timed("linear_wgrad", flops, io=io):
         _check(_lib.dfine_linear_wgrad_group(_ptr(dev_table), len(pend), blocks, _stream()), "dfine_linear_wgrad_group")
     _LW_KEEP.append((pend, dev_table))          # inputs stay alive until the launch has run (stream order: dropped a few flushes later)
+
+
+def linear_wgrad_flush():
+    """Runs the registered weight-gradient problems (token-stream linears, 1x1 convolutions: partial sums into their `ws`
+    buffers) in one launch per kind, then joins the side stream: afterwards every partial sum registered so far is ordered
+    before whatever the current stream runs next."""
+    if _CW_PENDING:
+        _flush_conv_group()
+    if _LW_PENDING:
+        _flush_linear_group()
     while len(_LW_KEEP) > 4:
         _LW_KEEP.pop(0)
+    side_join()
 
 
 _LW_KEEP = []
@@ -1067,15 +1170,23 @@ def stem_dgrad_s2(dy, wq, cin):
 _STEM_WS = {}
 
 
-def stem_wgrad(x, dy, ks, stride, pad):
+def stem_wgrad(x, dy, ks, stride, pad, side=False):
+    """side: launched on the side stream (see dwconv_backward)."""
     B, cin, H, W = x.shape
     _, cout, ho, wo = dy.shape
     need = int(_lib.dfine_stem_wgrad_ws_floats(B, cin, cout, ks, ho, wo))
-    key = (x.device.index, _stream())
+    side = side and _side_ok()
+    st = _side_fork(x.device) if side else None
+    key = (x.device.index, st.cuda_stream if side else _stream())
     ws = _STEM_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = _STEM_WS[key] = torch.empty(need, device=x.device, dtype=torch.float32)
     dw = torch.empty(cout, cin, ks, ks, device=x.device, dtype=torch.float32)
+    if side:
+        _check(_lib.dfine_stem_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ho, wo, ks, stride,
+                                          pad, st.cuda_stream), "dfine_stem_wgrad_bf16")
+        _SIDE_LIVE.append((x, dy))
+        return dw
     with _timed("stem_wgrad", 2.0 * B * ho * wo * cin * cout * ks * ks, io=2.0 * B * (H * W * cin + ho * wo * cout)):
         _check(_lib.dfine_stem_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ho, wo, ks, stride,
                                           pad, _stream()), "dfine_stem_wgrad_bf16")
@@ -1104,16 +1215,23 @@ def stem_dgrad_s2_2(dy, wq, ca, cb):
     return dxa, dxb
 
 
-def stem_wgrad2(xa, xb, dy, ks, stride, pad):
+def stem_wgrad2(xa, xb, dy, ks, stride, pad, side=False):
     B, ca, H, W = xa.shape
     cin = ca + xb.shape[1]
     _, cout, ho, wo = dy.shape
     need = int(_lib.dfine_stem_wgrad_ws_floats(B, cin, cout, ks, ho, wo))
-    key = (xa.device.index, _stream())
+    side = side and _side_ok()
+    st = _side_fork(xa.device) if side else None
+    key = (xa.device.index, st.cuda_stream if side else _stream())
     ws = _STEM_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = _STEM_WS[key] = torch.empty(need, device=xa.device, dtype=torch.float32)
     dw = torch.empty(cout, cin, ks, ks, device=xa.device, dtype=torch.float32)
+    if side:
+        _check(_lib.dfine_stem_wgrad2_bf16(_ptr(xa), _ptr(xb), ca, _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ho, wo, ks,
+                                           stride, pad, st.cuda_stream), "dfine_stem_wgrad2_bf16")
+        _SIDE_LIVE.append((xa, xb, dy))
+        return dw
     with _timed("stem_wgrad", 2.0 * B * ho * wo * cin * cout * ks * ks, io=2.0 * B * (H * W * cin + ho * wo * cout)):
         _check(_lib.dfine_stem_wgrad2_bf16(_ptr(xa), _ptr(xb), ca, _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ho, wo, ks,
                                            stride, pad, _stream()), "dfine_stem_wgrad2_bf16")

@@ -295,6 +295,14 @@ def head_losses(logits, boxes, corners, ref, teacher_corners, teacher_logits, cl
 # =============================================================================================
 # A1/A2  conv -> BatchNorm -> activation -> learnable affine units of backbone and encoder
 # =============================================================================================
+def _side_wgrad_ok(weight):
+    """May this parameter's gradient TENSOR be produced on the side stream (hip._side_fork)?  Only when its sole consumer is the
+    fused optimizer's gather (which joins the side stream first): the parameter is managed by it, fp32 (no cast kernel on
+    the main stream) and has no gradient yet (autograd then just stores the tensor instead of adding to it)."""
+    slot = getattr(weight, "_dfine_slot", None)
+    return slot is not None and slot[0].defer_wgrads and weight.dtype == torch.float32 and weight.grad is None
+
+
 class _DepthwiseConv(torch.autograd.Function):
     """Depthwise k x k conv, NCHW (HIP: dwconv.hip).  Weights stay fp32 master parameters."""
 
@@ -313,7 +321,7 @@ class _DepthwiseConv(torch.autograd.Function):
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
         dx, dw = _hip().dwconv_backward(x, weight.detach().float().contiguous(), dy, stride, pad,
-                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1], side_dw=_side_wgrad_ok(weight))
         return dx, (dw.to(weight.dtype) if dw is not None else None), None, None
 
 
@@ -701,16 +709,48 @@ class _DenseConv(torch.autograd.Function):
         return dx, dw
 
 
+class GradFanIn:
+    """Hand-off of a data gradient between the two consumers of one map inside a block (HG_Block: layer i output ->
+    layer i + 1 and the aggregation conv, ref hgnetv2.py:265-274).  The reference lets autograd add the two gradients (one
+    element-wise pass, 2 reads + 1 write of the map).  Here the consumer that runs its backward FIRST (the aggregation: every
+    layer's gradient depends on it) parks its gradient in `buf` and reports None to autograd; the consumer that runs LATER adds
+    its own data gradient onto the parked one in its convolution's epilogue (dfine_conv_accum_bf16) and returns the sum.
+    `armed` is set in the forward pass by the later consumer when it will be able to do that, `parking` by the earlier one
+    (whose forward runs after it) when it will park - only then does the later consumer expect a parked gradient."""
+    __slots__ = ("armed", "parking", "buf")
+
+    def __init__(self):
+        self.armed, self.parking, self.buf = False, False, None
+
+    def take(self):
+        buf, self.buf = self.buf, None
+        if buf is None:
+            raise RuntimeError("GradFanIn: the parked gradient is missing (backward order violated)")
+        return buf
+
+
+def grad_fanin_enabled(x):
+    return (_env("DFINE_GRAD_FANIN", "1") == "1" and torch.is_tensor(x) and x.is_cuda and torch.is_grad_enabled()
+            and _env("DFINE_HIP_UNITS", "1") == "1")
+
+
 class _DenseConvBNAct(torch.autograd.Function):
     """_DenseConv followed by _BNAct as ONE autograd node (the HIP-only plan): the same kernel calls in the same order, half
     the `Function.apply` / backward-node dispatches for the ~250 conv + BatchNorm units of a step - the forward pass is
     host-bound (tools/host_profile.py: ~44 ms of host work against 39 ms of device work per step)."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, lab_scale, lab_bias, running_mean, running_var, act, training, momentum, eps):
+    def forward(ctx, x, weight, gamma, beta, lab_scale, lab_bias, running_mean, running_var, act, training, momentum, eps,
+                fanin=None):
         hip = _hip()
         x = x.contiguous()
         ks = weight.shape[-1]
+        B, cin, H, W = x.shape
+        ctx.fanin = None
+        if (fanin is not None and ctx.needs_input_grad[0] and x.dtype == torch.bfloat16
+                and hip.conv_epilogue_supported(B, weight.shape[0], cin, H, W, ks)):      # (the data gradient: channels exchanged)
+            fanin.armed = True
+            ctx.fanin = fanin
         c = hip.conv_forward_bf16(x, _packed_weights(weight, False), weight.shape[0], ks)
         y, stats = hip.bn_act_forward(c, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, training, momentum, eps)
         ctx.save_for_backward(x, weight, c, stats, lab_scale)
@@ -747,7 +787,13 @@ class _DenseConvBNAct(torch.autograd.Function):
             dls, dlb = dlab[0:1], dlab[1:2]
         ks = weight.shape[-1]
         need = ctx.needs_input_grad
-        dx = hip.conv_forward_bf16(dc, _packed_weights(weight, True), weight.shape[1], ks) if need[0] else None
+        dx = None
+        if need[0]:
+            if ctx.fanin is not None and ctx.fanin.parking:    # the other consumer's gradient is parked: add onto it in the epilogue
+                dx = hip.conv_accumulate_bf16(dc, _packed_weights(weight, True), ctx.fanin.take(), ks)
+                ctx.fanin = None
+            else:
+                dx = hip.conv_forward_bf16(dc, _packed_weights(weight, True), weight.shape[1], ks)
         dw = None
         if need[1]:
             wslot = ctx.wslot
@@ -757,7 +803,7 @@ class _DenseConvBNAct(torch.autograd.Function):
                 wslot[0].use_done(wslot[1][0])
             else:
                 dw = hip.conv_wgrad_bf16(x, dc, ks).to(weight.dtype)
-        return dx, dw, dg, db, dls, dlb, None, None, None, None, None, None
+        return dx, dw, dg, db, dls, dlb, None, None, None, None, None, None, None
 
 
 class _InnerCtx:
@@ -885,8 +931,16 @@ class _DenseConvSeg(torch.autograd.Function):
     (csrc/conv.hip: ChanSegs)."""
 
     @staticmethod
-    def forward(ctx, weight, *xs):
+    def forward(ctx, weight, fans, *xs):
+        """fans: None, or one GradFanIn / None per part - armed ones receive that part's data gradient in backward (the part's
+        other consumer then returns the sum), see GradFanIn."""
         hip = _hip()
+        ctx.fans = None
+        if fans is not None:
+            for i, f in enumerate(fans):
+                if f is not None and f.armed and ctx.needs_input_grad[2 + i] and xs[i].dtype == torch.bfloat16:
+                    f.parking = True
+                    ctx.fans = fans
         xs = tuple(x if hip.is_channel_part(x) else x.contiguous() for x in xs)     # channel slices are read in place
         B, _, H, W = xs[0].shape
         y = torch.empty(B, weight.shape[0], H, W, device=xs[0].device, dtype=torch.bfloat16)
@@ -906,10 +960,16 @@ class _DenseConvSeg(torch.autograd.Function):
             dy = dy.to(torch.bfloat16)
         dxs = [None] * len(xs)
         need = ctx.needs_input_grad
-        if any(need[1:]):
+        if any(need[2:]):
             outs = tuple(torch.empty(x.shape, device=x.device, dtype=x.dtype) for x in xs)
             hip.conv1x1_seg_forward((dy,), _packed_weights(weight, True), outs)
-            dxs = [o if n else None for o, n in zip(outs, need[1:])]
+            dxs = [o if n else None for o, n in zip(outs, need[2:])]
+            fans = ctx.fans
+            if fans is not None:
+                for i, f in enumerate(fans):
+                    if f is not None and f.parking and dxs[i] is not None:
+                        f.buf, dxs[i] = dxs[i], None        # parked for the part's other consumer (GradFanIn)
+                ctx.fans = None
         dw = None
         if need[0]:
             if ctx.slot is not None:
@@ -918,7 +978,7 @@ class _DenseConvSeg(torch.autograd.Function):
                 ctx.slot[0].use_done(ctx.slot[1][0])
             else:
                 dw = hip.conv1x1_seg_wgrad(xs, dy).to(weight.dtype)
-        return (dw, *dxs)
+        return (dw, None, *dxs)
 
 
 class _DenseConvMFMA(_DenseConv):
@@ -985,7 +1045,7 @@ class _StemConv(torch.autograd.Function):
             else:
                 dx = hip.stem_dgrad_s2(dy, _packed_stem(weight, 2), cin)
         if ctx.needs_input_grad[1]:
-            dw = hip.stem_wgrad(x, dy, ks, stride, pad).to(weight.dtype)
+            dw = hip.stem_wgrad(x, dy, ks, stride, pad, side=_side_wgrad_ok(weight)).to(weight.dtype)
         return dx, dw, None, None, None
 
 
@@ -1019,7 +1079,7 @@ class _StemConv2(torch.autograd.Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dxa, dxb = hip.stem_dgrad_s2_2(dy, _packed_stem(weight, 2), xa.shape[1], xb.shape[1])
         if ctx.needs_input_grad[2]:
-            dw = hip.stem_wgrad2(xa, xb, dy, ks, 2, ctx.pad).to(weight.dtype)
+            dw = hip.stem_wgrad2(xa, xb, dy, ks, 2, ctx.pad, side=_side_wgrad_ok(weight)).to(weight.dtype)
         return dxa, dxb, dw, None
 
 
@@ -1107,9 +1167,11 @@ _ROUTES = [0]       # epoch token of the per-module route caches of conv_bn_act 
 
 
 def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Optional[nn.Module],
-                pad_br: bool = False):
+                pad_br: bool = False, fanin=None, fans=None):
     """conv(bias=False) -> BN (batch stats in training) -> {None, relu, silu} -> scalar affine; the
     building block of HGNetv2 and the HybridEncoder.
+    fanin / fans: GradFanIn hand-offs of the data gradient (fanin: this unit is the LATER consumer of x in backward; fans: one
+    per part of a list input, this unit being the EARLIER one) - only honoured by the fused HIP units, ignored elsewhere.
     GPU (bf16 autocast): dense 1x1 / 3x3, depthwise and stem convolutions and the whole BN/act/affine tail are HIP kernels;
     fp32 math and CPU tensors take the plain ATen composition below."""
     a = act.lower() if isinstance(act, str) else act
@@ -1124,10 +1186,10 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
                 and conv.kernel_size == (1, 1) and len(xs) <= 8 and (xs[0].shape[-1] * xs[0].shape[-2]) % 8 == 0
                 and all(t.shape[1] % 8 == 0 for t in xs) and _mfma_conv_ok(conv, xs[0])):
             parts = [t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16) for t in xs]
-            y = _bn_tail_fused(_DenseConvSeg, (conv.weight, *parts), bn, a, lab)
+            y = _bn_tail_fused(_DenseConvSeg, (conv.weight, fans, *parts), bn, a, lab)
             if y is not None:
                 return y
-            y = _DenseConvSeg.apply(conv.weight, *parts)
+            y = _DenseConvSeg.apply(conv.weight, fans, *parts)
             return _bn_tail(y, bn, a, act, lab)
         if (len(xs) == 2 and xs[0].is_cuda and not pad_br and a in (None, "relu", "silu", "swish") and _env("DFINE_HIP_UNITS", "1") == "1"
                 and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1)
@@ -1184,7 +1246,7 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
                         bn.num_batches_tracked.add_(1)
                 return _DenseConvBNAct.apply(xb, conv.weight, bn.weight, bn.bias, lab.scale if lab is not None else None,
                                              lab.bias if lab is not None else None, bn.running_mean, bn.running_var, a, training,
-                                             bn.momentum, bn.eps)
+                                             bn.momentum, bn.eps, fanin if xb is x else None)
             y = _DenseConv.apply(xb, conv.weight)
         elif route == 3:
             # maps wider than the kernel's 160-pixel strips (the 240-wide stage of D-FINE-l / x at 960 x 960): two column halves

@@ -283,6 +283,15 @@ int dfine_conv_fwd_bf16(const void *x, const void *w2, void *y, int B, int Cin, 
  * DFINE_E_BADARG for shapes outside the LDS-DMA 1x1 kernel (H*W % 8 != 0, Cin % 4 != 0). */
 int dfine_conv1x1_accum_bf16(const void *x, const void *w2, void *y, int B, int Cin, int Cout, int HW,
                              void *stream);
+
+/* y += conv(x) with the packed weights of dfine_conv_fwd_bf16 (1x1 or 3x3, stride 1): a data gradient added onto the one
+ * already in y - the sum autograd forms for a map with two consumers (HG_Block: layer i output -> layer i + 1 and the
+ * aggregation, src/d_fine/arch/hgnetv2.py:265-274) - in the convolution's epilogue instead of an element-wise add pass.
+ * dfine_conv_epilogue_supported() != 0 says whether the shape is served (1x1 on the LDS-DMA kernel, 3x3 on the
+ * wave-specialised kernel); DFINE_E_BADARG otherwise. */
+int dfine_conv_epilogue_supported(int B, int Cin, int Cout, int H, int W, int KS);
+int dfine_conv_accum_bf16(const void *x, const void *w2, void *y, int B, int Cin, int Cout, int H, int W, int KS,
+                          void *stream);
 /* Weight gradient of the same convolution: dw [Cout, Cin, KS, KS] f32 (overwritten) from x [B,Cin,H,W]
  * and dy [B,Cout,H,W] (bf16); ws = dfine_conv_wgrad_ws_floats(...) floats of scratch (split-K
  * partial sums).  KS = 3: W % 8 == 0 and W <= 160.  KS = 1: (H*W) % 8 == 0. */

@@ -108,7 +108,7 @@ def test_segmented_conv1x1_matches_cat_conv(cuda, chans, Cout, H, W):
     assert not parts[0].is_contiguous()
     parts = [p.requires_grad_(True) for p in parts]
     w = (torch.randn(Cout, sum(chans), 1, 1, device=cuda) / sum(chans) ** 0.5).requires_grad_(True)
-    y = kernels._DenseConvSeg.apply(w, *parts)
+    y = kernels._DenseConvSeg.apply(w, None, *parts)
     go = torch.randn_like(y)
     y.backward(go)
     pr = [p.detach().float().requires_grad_(True) for p in parts]

@@ -173,6 +173,62 @@ def test_deferred_weight_gradients_match_immediate(cuda):
 
 
 @pytest.mark.gpu
+def test_side_stream_weight_gradients_match_single_stream(cuda, monkeypatch):
+    """The deferred conv weight gradients (3x3, channel-segment 1x1, the grouped launches) and the depthwise / stem
+    weight-gradient tensors run on a second HIP stream, joined in front of the optimizer's gather / reduction
+    (hip._side_fork / side_join): the flat gradient must equal the single-stream one (same kernels; what differs run to run
+    are activation gradients that went through atomics), over several steps so that a missing join would show."""
+    from custom_d_fine_amd import hip
+    from custom_d_fine_amd.d_fine.dfine import build_model
+
+    torch.manual_seed(4)
+    model = build_model("m", 5, False, cuda, img_size=[320, 320]).train()
+    for m in model.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.momentum = 0.0
+
+    class BE(nn.Module):
+        def __init__(self, full):
+            super().__init__()
+            self.backbone, self.encoder = full.backbone, full.encoder
+
+        def forward(self, x):
+            return self.encoder(self.backbone(x))
+
+    net = BE(model)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4)
+    fused = FusedAdamWEMA(net, opt, None, clip_max_norm=0.1, overlap=False)
+    x = torch.randn(4, 3, 320, 320, device=cuda)
+    cot, flats = None, {}
+    for side in (False, True, False, True):
+        monkeypatch.setattr(hip, "WGRAD_STREAM", side)
+        fused.flat_grad.zero_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            feats = net(x)
+        if cot is None:
+            cot = [torch.randn_like(f, dtype=torch.float32) / f.shape[1] for f in feats]
+        sum((f.float() * c).sum() for f, c in zip(feats, cot)).backward()
+        if side:
+            assert hip._SIDE_LIVE, "nothing was launched on the side stream"
+        fused._collect_grads()
+        fused._uses.clear()
+        assert not hip._SIDE_LIVE and not fused._deferred
+        for p in net.parameters():
+            p.grad = None
+        torch.cuda.synchronize()
+        flats.setdefault(side, []).append(fused.flat_grad.clone())
+    ref, ref2 = flats[False]
+    noise = (ref - ref2).abs().max().item()
+    tol = max(10 * noise, 2e-3 * ref.abs().max().item())
+    for got in flats[True]:
+        assert torch.isfinite(got).all() and got.abs().sum() > 0
+        assert (got - ref).abs().max().item() <= tol, ((got - ref).abs().max().item(), noise)
+        for i, p in enumerate(fused._params):
+            o = fused._grad_offsets[i]
+            assert (got[o:o + p.numel()] != 0).any() == (ref[o:o + p.numel()] != 0).any(), i
+
+
+@pytest.mark.gpu
 def test_deferred_reduction_with_repeated_module_and_accumulation(cuda):
     """A Linear applied FOUR times in one forward (the decoder's query_pos_head runs once per layer) over TWO micro-steps of a
     gradient-accumulation window leaves eight rows with one destination in the deferred table; they are reduced in
