@@ -730,7 +730,8 @@ template <int NTN, int kG2Ring, int PXW, bool SEG>   // kG2Ring LDS stages (3: t
 __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs xs_, const uint16_t *__restrict__ w2,
                                                                   const ChanSegs ys_, int Cin, int Cout, int NP, int KP,
                                                                   int HW, int ptiles, int total_tiles, int nblk, int accum,
-                                                                  int64_t w_bstride /* elements between the images' weight sets: 0 = shared */) {
+                                                                  int64_t w_bstride /* elements between the images' weight sets: 0 = shared */,
+                                                                  int ximg /* tiles over the pixels of ALL images (B * HW), see below */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int TP = 32 * PXW;                                             // pixels per workgroup (128 or 256)
     constexpr int XPITCH = TP * 2;                                           // bytes per channel row
@@ -741,9 +742,14 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int nb = slot % nblk, tile_id = (slot / nblk) * 8 + xcd;
     if (tile_id >= total_tiles) return;
-    const int b = tile_id / ptiles, pt = tile_id - b * ptiles;
-    const int p0 = pt * TP;
-    const int npix = min(TP, HW - p0);
+    // Pixel tiles: per image (ptiles of them, the last one partly empty: 400-pixel planes fill 78 % of four 128-pixel tiles),
+    // or - ximg, whole tensors only - over the B * HW pixels of the batch: an 8-pixel chunk (one LDS-DMA piece, one 16-byte
+    // store) never straddles two images (HW % 8 == 0), so a lane just carries its own image / pixel base.  `ptiles` then
+    // holds the number of images.
+    const int b = ximg ? 0 : tile_id / ptiles, pt = ximg ? tile_id : tile_id - b * ptiles;
+    const int p0 = ximg ? 0 : pt * TP;
+    const int64_t g0 = (int64_t)pt * TP, gtot = (int64_t)ptiles * HW;             // ximg: first pixel of the tile in the batch
+    const int npix = ximg ? (int)min((int64_t)TP, gtot - g0) : min(TP, HW - p0);
     const int n0 = nb * 64 * NTN;
     w2 += (int64_t)b * w_bstride;                       // per-image weights (the mask-logit einsum bqc,bchw->bqhw)
     const int wn = wave >> 1, wp = wave & 1;
@@ -753,12 +759,20 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
     // ---- per-lane source coordinates of this wave's LDS-DMA pieces (constant over the stages) ----
     // X: 64 / RPP pieces of RPP rows, XPW per wave.  W: 8 NTN pieces of 8 rows; wave -> NTN pieces.
     int x_row[XPW], x_px[XPW], w_row[NTN], w_k[NTN];
+    const uint16_t *x_src[XPW];                        // whole-tensor case: this lane's channel-0 address of piece j
 #pragma unroll
     for (int j = 0; j < XPW; ++j) {
         const int row = (wave * XPW + j) * RPP + lane / LPR, pc = lane % LPR;
         const int px = (((pc >> 1) ^ (row & 7)) << 4) + ((pc & 1) << 3);
         x_row[j] = row;
         x_px[j] = px < npix ? px : 0;                  // columns past the plane: any valid data, never stored
+        if (ximg) {
+            const int64_t gp = g0 + x_px[j];
+            const int bi = (int)(gp / HW);
+            x_src[j] = xs_.p[0] + ((int64_t)bi * xs_.bs[0]) * HW + (gp - (int64_t)bi * HW);
+        } else {
+            x_src[j] = xs_.p[0] + (int64_t)b * xs_.bs[0] * HW + p0 + x_px[j];
+        }
     }
 #pragma unroll
     for (int j = 0; j < NTN; ++j) {
@@ -769,7 +783,6 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
     // whole-tensor case: plain pointer arithmetic - the part table lives in the kernel-argument segment, and scalar loads from
     // it inside the stage loop share lgkmcnt with the LDS reads (every wait for one drains the other)
-    const uint16_t *xflat = xs_.p[0] + (int64_t)b * xs_.bs[0] * HW + p0;
     // several parts: a per-workgroup table in LDS, one 8-byte base address per group of 8 input channels (part sizes are
     // multiples of 8), built once; the issue path then costs one ds_read_b64 per piece.  (Searching the part list there - per
     // lane or on the scalar unit, from kernel arguments or registers - cost 2x of the whole kernel.)
@@ -789,7 +802,7 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
         for (int j = 0; j < XPW; ++j) {
             if (!SEG) {
                 const int ch = min(c0 + x_row[j], Cin - 1);
-                glds16(xflat + (int64_t)ch * HW + x_px[j], __builtin_amdgcn_readfirstlane(base + (wave * XPW + j) * 1024));
+                glds16(x_src[j] + (int64_t)ch * HW, __builtin_amdgcn_readfirstlane(base + (wave * XPW + j) * 1024));
                 continue;
             }
             const int ch = min(c0 + x_row[j], Cin - 1);  // channels past Cin: any valid row - they meet zero weights or a skipped slab
@@ -879,16 +892,23 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
             for (int r = 0; r < 4; ++r) ot[(t * 16 + 4 * g + r) * OP + j * 16 + i16] = f32_to_bf16(acc[t][j][r]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     constexpr int LPO = 2 * PXW, RPI = 64 / LPO;         // lanes per output row, rows per iteration
+    const int c8l = wp * 16 * PXW + (lane % LPO) * 8;    // this lane's 8-pixel chunk of the tile (the same for every row)
+    int64_t ylane = (int64_t)b * ys_.bs[0] * HW + p0 + c8l;      // whole-tensor case: element offset of channel 0 of that chunk
+    if (ximg) {
+        const int64_t gp = g0 + (c8l < npix ? c8l : 0);
+        const int bi = (int)(gp / HW);
+        ylane = ((int64_t)bi * ys_.bs[0]) * HW + (gp - (int64_t)bi * HW);
+    }
 #pragma unroll
     for (int it = 0; it < 16 * NTN / RPI; ++it) {
         const int row = it * RPI + lane / LPO, c8 = (lane % LPO) * 8;
         const int n = n0 + wn * 16 * NTN + row;
         if (n < Cout && wp * 16 * PXW + c8 < npix) {
-            uint16_t *yp = SEG ? ytab[wn * 16 * NTN + row]
-                               : const_cast<uint16_t *>(ys_.p[0]) + ((int64_t)b * ys_.bs[0] + n) * HW;
+            uint16_t *yp = SEG ? ytab[wn * 16 * NTN + row] + p0 + wp * 16 * PXW + c8
+                               : const_cast<uint16_t *>(ys_.p[0]) + ylane + (int64_t)n * HW;
             uint4 v = *reinterpret_cast<const uint4 *>(ot + row * OP + c8);
             if (accum) {                                  // y += conv(x): bf16 + bf16 in fp32, one rounding (like a separate add)
-                const uint4 o = *reinterpret_cast<const uint4 *>(yp + p0 + wp * 16 * PXW + c8);
+                const uint4 o = *reinterpret_cast<const uint4 *>(yp);
                 const uint32_t a[4] = {v.x, v.y, v.z, v.w}, c[4] = {o.x, o.y, o.z, o.w};
                 uint32_t r[4];
 #pragma unroll
@@ -897,7 +917,7 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
                                        __uint_as_float(a[k] & 0xffff0000u) + __uint_as_float(c[k] & 0xffff0000u));
                 v = make_uint4(r[0], r[1], r[2], r[3]);
             }
-            *reinterpret_cast<uint4 *>(yp + p0 + wp * 16 * PXW + c8) = v;
+            *reinterpret_cast<uint4 *>(yp) = v;
         }
     }
 }
@@ -924,16 +944,22 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
         // 256 pixels x 128 channels (87 FLOP per loaded byte) for deep layers on big maps, 128 x 128 (64) / 128 x 64 otherwise.
         const bool ring2 = KP <= 2 * kG2Rows;                  // <= 2 stages: both fit a 2-slot ring, half the LDS, 2 workgroups per CU
         const bool n128 = NP % 128 == 0;
-        const int pt256 = (HW + 255) / 256;
-        const bool px256 = px256_env && n128 && !ring2 && (HW % 256 == 0 || HW >= 1536) && (int64_t)B * pt256 * (NP / 128) >= 256;
-        const int tp = px256 ? 256 : kTrPix;
-        const int ptiles2 = (HW + tp - 1) / tp;
-        const bool wide2 = px256 || (n128 && ((int64_t)B * ptiles2 * (NP / 128) >= 256));
-        const int nblk2 = wide2 ? NP / 128 : (NP + 63) / 64;
-        const int total2 = B * ptiles2;
-        dim3 grid2(8 * ((total2 + 7) / 8) * nblk2);
         const ChanSegs xs_ = xsegs ? *xsegs : one_seg(x, Cin), ys_ = ysegs ? *ysegs : one_seg(y, Cout);
         const bool seg = xs_.n > 1 || ys_.n > 1;
+        // whole tensors with shared weights: pixel tiles over the B * HW pixels of the batch whenever per-image tiles would
+        // leave the last one partly empty (20 x 20 planes: 400 pixels = 3.1 tiles of 128; 40 x 40: 6.25 tiles of 256)
+        static const int ximg_env = [] { const char *e = getenv("DFINE_CONV1X1_XIMG"); return e ? atoi(e) : 1; }();
+        const bool xok = ximg_env && !seg && !w_bstride;
+        const int64_t gpix = (int64_t)B * HW;
+        const int64_t t256 = xok ? (gpix + 255) / 256 : (int64_t)B * ((HW + 255) / 256);
+        const bool px256 = px256_env && n128 && !ring2 && (xok || HW % 256 == 0 || HW >= 1536) && t256 * (NP / 128) >= 256;
+        const int tp = px256 ? 256 : kTrPix;
+        const bool ximg = xok && HW % tp != 0;
+        const int ptiles2 = ximg ? B : (HW + tp - 1) / tp;     // (ximg: the kernel wants the image count here)
+        const int total2 = ximg ? (int)((gpix + tp - 1) / tp) : B * ptiles2;
+        const bool wide2 = px256 || (n128 && ((int64_t)total2 * (NP / 128) >= 256));
+        const int nblk2 = wide2 ? NP / 128 : (NP + 63) / 64;
+        dim3 grid2(8 * ((total2 + 7) / 8) * nblk2);
         if (seg && Cin > 4096) return DFINE_E_BADARG;
         const size_t lds2 = (size_t)(ring2 ? 2 : 3) * (kG2Rows * tp * 2 + 64 * (wide2 ? 2 : 1) * 128) + (seg ? 5120 : 0);
         static bool attr2 = false;
@@ -948,8 +974,8 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
             attr2 = true;
         }
 #define DFINE_G2(N, R, P)                                                                                                                        \
-    { if (seg) hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, true>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum, w_bstride); \
-      else hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, false>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum, w_bstride); }
+    { if (seg) hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, true>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum, w_bstride, ximg ? 1 : 0); \
+      else hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, false>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum, w_bstride, ximg ? 1 : 0); }
         if (px256) DFINE_G2(2, 3, 8)
         else if (wide2) { if (ring2) DFINE_G2(2, 2, 4) else DFINE_G2(2, 3, 4) }
         else { if (ring2) DFINE_G2(1, 2, 4) else DFINE_G2(1, 3, 4) }

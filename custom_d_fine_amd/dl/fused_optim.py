@@ -158,6 +158,8 @@ class FusedAdamWEMA:
         self._deferred = []          # (param index, dst offset in flat_grad, workspace tensor, workspace offset, meta)
         self._uses = {}              # param index -> deferred uses still to come in this backward
         self.defer_wgrads = os.environ.get("DFINE_DEFER_WGRAD", "1") == "1"
+        # deferred entries that trigger an early reduction on the side stream (0: only the flush in front of the step)
+        self._early_at = int(os.environ.get("DFINE_EARLY_REDUCE", "24")) or (1 << 30)
         for i, p in enumerate(self._params):
             p._dfine_slot = (self, i)
 
@@ -219,6 +221,10 @@ class FusedAdamWEMA:
         partial sums (layout `meta` = (splits, Cout, Cin, taps, NP16, CP16)) of the gradient of the parameter's elements
         [dst_offset, dst_offset + Cout * Cin * taps)."""
         self._deferred.append((index, self._grad_offsets[index] + dst_offset, ws, ws_offset, meta))
+        if len(self._deferred) >= self._early_at and self.hip.side_stream_ok():
+            # the reduction of what is registered so far runs on the side stream under the rest of backward instead of in the
+            # serial tail in front of the optimizer step
+            self._flush_deferred(side=True)
 
     def grad_offset(self, index):
         return self._grad_offsets[index]
@@ -252,9 +258,11 @@ class FusedAdamWEMA:
             _memo[key] = self.hip.multi_wgrad_reduce_blocks(splits, elems)
         return _memo[key]
 
-    def _flush_deferred(self, lo=None, hi=None):
+    def _flush_deferred(self, lo=None, hi=None, side=False):
+        """side: grouped launches and reduction on the side stream (hip._side_fork), nothing joined - a later flush does."""
         import numpy as np
-        self.hip.linear_wgrad_flush()               # registered linear weight-gradient GEMMs -> their partial sums (one launch)
+        # registered weight-gradient GEMMs -> their partial sums (one launch per kind); joins the side stream unless side
+        self.hip.linear_wgrad_flush(side=side)
         take = [d for d in self._deferred if lo is None or lo <= d[1] < hi]
         if not take:
             return
@@ -292,7 +300,7 @@ class FusedAdamWEMA:
         for rnd in rounds:
             blocks = max(self._reduce_blocks(r[2], r[3] * r[4] * r[5]) for r in rnd)
             io = sum(4.0 * r[2] * r[6] * r[7] * r[5] + 8.0 * r[3] * r[4] * r[5] for r in rnd)
-            self.hip.multi_wgrad_reduce(table[first:first + len(rnd)], len(rnd), blocks, io=io)
+            self.hip.multi_wgrad_reduce(table[first:first + len(rnd)], len(rnd), blocks, io=io, side=side)
             first += len(rnd)
         self._live.append((take, table))
 

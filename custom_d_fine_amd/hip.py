@@ -788,6 +788,10 @@ def _side_ok():
     return WGRAD_STREAM and not _TIMING_ON and not torch.cuda.is_current_stream_capturing()
 
 
+def side_stream_ok():
+    return _side_ok()
+
+
 def _side_fork(dev):
     """-> raw handle of the side stream, made to wait for everything enqueued on the current stream so far."""
     st = _SIDE.get(dev.index)
@@ -851,8 +855,14 @@ def multi_wgrad_reduce_blocks(splits, elems):
     return int(_lib.dfine_multi_wgrad_reduce_blocks(int(splits), int(elems)))
 
 
-def multi_wgrad_reduce(table, n_entries, max_blocks, io=0.0):
-    """io: bytes of partial sums + destinations the launch streams (its roofline is HBM; no FLOPs of its own)."""
+def multi_wgrad_reduce(table, n_entries, max_blocks, io=0.0, side=False):
+    """io: bytes of partial sums + destinations the launch streams (its roofline is HBM; no FLOPs of its own).
+    side: on the side stream, behind the weight-gradient launches already queued there."""
+    if side and _side_ok():
+        st = _side_fork(table.device)             # (forked after the table's upload was enqueued on the current stream)
+        _check(_lib.dfine_multi_wgrad_reduce(_ptr(table), n_entries, int(max_blocks), st.cuda_stream), "dfine_multi_wgrad_reduce")
+        _SIDE_LIVE.append((table,))
+        return
     with _timed("wgrad_reduce", 0.0, io=io):
         _check(_lib.dfine_multi_wgrad_reduce(_ptr(table), n_entries, int(max_blocks), _stream()), "dfine_multi_wgrad_reduce")
 
@@ -1094,17 +1104,20 @@ def _flush_linear_group(side=False):
     _LW_KEEP.append((pend, dev_table))          # inputs stay alive until the launch has run (stream order: dropped a few flushes later)
 
 
-def linear_wgrad_flush():
+def linear_wgrad_flush(side=False):
     """Runs the registered weight-gradient problems (token-stream linears, 1x1 convolutions: partial sums into their `ws`
     buffers) in one launch per kind, then joins the side stream: afterwards every partial sum registered so far is ordered
-    before whatever the current stream runs next."""
+    before whatever the current stream runs next.  side: the launches go to the side stream and nothing is joined (the
+    caller continues there: an early reduction under the rest of backward)."""
+    side = side and _side_ok()
     if _CW_PENDING:
-        _flush_conv_group()
+        _flush_conv_group(side)
     if _LW_PENDING:
-        _flush_linear_group()
+        _flush_linear_group(side)
     while len(_LW_KEEP) > 4:
         _LW_KEEP.pop(0)
-    side_join()
+    if not side:
+        side_join()
 
 
 _LW_KEEP = []

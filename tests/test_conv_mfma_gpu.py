@@ -13,7 +13,7 @@ CASES = [  # B, Cin, Cout, H, W, KS
     (2, 64, 48, 13, 22, 3), (2, 128, 128, 40, 40, 1), (2, 160, 48, 160, 160, 1), (2, 352, 192, 80, 80, 1),
     (3, 48, 96, 20, 20, 1), (1, 1792, 768, 20, 20, 1), (2, 256, 128, 30, 30, 1), (2, 128, 256, 7, 10, 1),
     (2, 512, 512, 80, 80, 1), (2, 768, 256, 40, 40, 1), (1, 1536, 256, 20, 20, 1), (2, 96, 48, 8, 8, 1), (2, 160, 80, 24, 24, 1),
-    (33, 128, 128, 8, 16, 1),
+    (33, 128, 128, 8, 16, 1), (5, 768, 1536, 20, 20, 1), (3, 1280, 384, 40, 40, 1), (7, 256, 256, 20, 20, 1), (9, 64, 96, 12, 10, 1),
 ]
 
 
