@@ -1,0 +1,48 @@
+"""A/B timing of one switch inside ONE process: the train step alternates between the two settings in blocks of a few steps
+(ABAB...), so box-to-box and minute-to-minute drift (+-1 ms between two bench.py runs on these boxes) cancels.  GPU box:
+    python tools/ab_step.py hip.WGRAD_STREAM            # module attribute toggled False / True
+    python tools/ab_step.py env:DFINE_GRAD_FANIN        # environment switch "0" / "1" + kernels.reload_env()
+    AB_BLOCKS=12 AB_STEPS=8 python tools/ab_step.py ..."""
+import os, sys, time, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from custom_d_fine_amd import hip, kernels
+from custom_d_fine_amd.dl.synthetic import make_batch
+
+what = sys.argv[1]
+blocks, steps = int(os.environ.get("AB_BLOCKS", "10")), int(os.environ.get("AB_STEPS", "8"))
+dev = torch.device("cuda", 0)
+step = bench.build_step(os.environ.get("SP_MODEL", "m"), int(os.environ.get("SP_IMG", "640")), dev, torch.bfloat16)
+images, targets = make_batch(int(os.environ.get("SP_BATCH", "32")), int(os.environ.get("SP_IMG", "640")), seed=42, device=dev)
+
+
+def setting(on):
+    if what.startswith("env:"):
+        os.environ[what[4:]] = "1" if on else "0"
+        kernels.reload_env()
+    else:
+        mod, attr = what.split(".")
+        setattr({"hip": hip, "kernels": kernels}[mod], attr, bool(on))
+
+
+for on in (False, True):
+    setting(on)
+    for _ in range(4):
+        step(images, targets)
+torch.cuda.synchronize()
+times = {False: [], True: []}
+for blk in range(2 * blocks):
+    on = bool(blk & 1)
+    setting(on)
+    step(images, targets)                       # one untimed step after the switch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(images, targets)
+    torch.cuda.synchronize()
+    times[on].append((time.perf_counter() - t0) * 1e3 / steps)
+for on in (False, True):
+    v = times[on]
+    print(f"{what} = {int(on)}: median {statistics.median(v):.3f} ms/step  mean {statistics.fmean(v):.3f}  min {min(v):.3f}  ({len(v)} blocks of {steps} steps)")
+print(f"difference of the medians (1 - 0): {statistics.median(times[True]) - statistics.median(times[False]):+.3f} ms")
