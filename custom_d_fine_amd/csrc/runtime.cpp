@@ -11,4 +11,31 @@ void set_last_error(hipError_t e) { g_last_error = hipGetErrorString(e); }
 extern "C" {
 int dfine_abi_version(void) { return 1; }
 const char *dfine_last_error(void) { return dfine::g_last_error.c_str(); }
+
+// Stream `to` waits for everything enqueued on stream `from` so far (fork / join of the side stream that carries the weight
+// gradients): one event record + one stream wait, ~2 us of host time against ~15 us for the same through torch.cuda.Stream
+// objects, 80 times per step.  Events come from a ring: a stream wait refers to the record that preceded it, so an event can
+// be recorded again as soon as its wait has been ENQUEUED.
+int dfine_stream_fork(void *from, void *to) {
+    constexpr int kRing = 64;
+    static hipEvent_t ring[kRing];
+    static int next = -1;
+    if (next < 0) {
+        for (int i = 0; i < kRing; ++i)
+            if (hipError_t e = hipEventCreateWithFlags(&ring[i], hipEventDisableTiming); e != hipSuccess) {
+                dfine::set_last_error(e);
+                return DFINE_E_LAUNCH;
+            }
+        next = 0;
+    }
+    hipEvent_t ev = ring[next];
+    next = (next + 1) % kRing;
+    hipError_t e = hipEventRecord(ev, (hipStream_t)from);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)to, ev, 0);
+    if (e != hipSuccess) {
+        dfine::set_last_error(e);
+        return DFINE_E_LAUNCH;
+    }
+    return DFINE_OK;
+}
 }

@@ -354,7 +354,7 @@ class HybridEncoder(nn.Module):
             # autocast would run the nearest-neighbour copy in fp32 (4x the bytes of the bf16 map it duplicates, plus a cast
             # back for the fusion conv); a pure data movement has nothing to gain from fp32
             with torch.autocast(top.device.type, enabled=False):
-                up = F.interpolate(top, scale_factor=2.0, mode="nearest")
+                up = kernels.upsample2_nearest(top)
             inner.insert(0, self.fpn_blocks[k]([up, proj[idx - 1]]))
 
         outs = [inner[0]]

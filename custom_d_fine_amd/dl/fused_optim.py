@@ -158,8 +158,9 @@ class FusedAdamWEMA:
         self._deferred = []          # (param index, dst offset in flat_grad, workspace tensor, workspace offset, meta)
         self._uses = {}              # param index -> deferred uses still to come in this backward
         self.defer_wgrads = os.environ.get("DFINE_DEFER_WGRAD", "1") == "1"
-        # deferred entries that trigger an early reduction on the side stream (0: only the flush in front of the step)
-        self._early_at = int(os.environ.get("DFINE_EARLY_REDUCE", "24")) or (1 << 30)
+        # deferred entries that trigger an early reduction on the side stream (0 = off, the default: no gain on the device side
+        # - the tail reduction is 0.7 ms - and each early flush costs ~0.2 ms of host time in a step that is host-bound again)
+        self._early_at = int(os.environ.get("DFINE_EARLY_REDUCE", "0")) or (1 << 30)
         for i, p in enumerate(self._params):
             p._dfine_slot = (self, i)
 

@@ -57,8 +57,10 @@ _SIGNATURES = {
     "dfine_conv_pack_weights": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "dfine_conv_pack_weights_multi": (c_int, [_P, _I, _P]),
     "dfine_maps_tokens_bf16": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_upsample2_nearest_bf16": (c_int, [_P, _P, c_int64, _I, _I, _I, _P]),
     "dfine_conv_fwd_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_conv1x1_accum_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfine_stream_fork": (c_int, [_P, _P]),
     "dfine_conv_epilogue_supported": (c_int, [_I, _I, _I, _I, _I, _I]),
     "dfine_conv_accum_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_conv_wgrad_ws_floats": (_L, [_I, _I, _I, _I, _I, _I]),
@@ -698,6 +700,19 @@ def maps_to_tokens(maps):
     return tokens
 
 
+def upsample2_nearest(x, backward=False):
+    """x [B, C, H, W] bf16 contiguous -> [B, C, 2H, 2W] (nearest); backward=True: x is the [B, C, 2H, 2W] gradient, returns
+    the [B, C, H, W] sums of its 2 x 2 blocks."""
+    B, C, H, W = x.shape
+    if backward:
+        out = torch.empty(B, C, H // 2, W // 2, device=x.device, dtype=x.dtype)
+        _check(_lib.dfine_upsample2_nearest_bf16(_ptr(out), _ptr(x), B * C, H // 2, W // 2, 1, _stream()), "dfine_upsample2_nearest_bf16")
+        return out
+    out = torch.empty(B, C, 2 * H, 2 * W, device=x.device, dtype=x.dtype)
+    _check(_lib.dfine_upsample2_nearest_bf16(_ptr(x), _ptr(out), B * C, H, W, 0, _stream()), "dfine_upsample2_nearest_bf16")
+    return out
+
+
 def tokens_to_maps(tokens, shapes):
     """tokens [B, L, C] bf16 contiguous -> one contiguous [B, C, h, w] map per (h, w) in `shapes`."""
     B, L, C = tokens.shape
@@ -792,21 +807,32 @@ def side_stream_ok():
     return _side_ok()
 
 
+class _SideStream:
+    """The side stream of one device: the torch object (for `with torch.cuda.stream(...)`) and its raw handle."""
+    __slots__ = ("stream", "cuda_stream")
+
+    def __init__(self, dev):
+        self.stream = torch.cuda.Stream(device=dev)
+        self.cuda_stream = self.stream.cuda_stream
+
+
 def _side_fork(dev):
-    """-> raw handle of the side stream, made to wait for everything enqueued on the current stream so far."""
+    """-> the side stream (`.cuda_stream` = raw handle), made to wait for everything enqueued on the current stream so far."""
     st = _SIDE.get(dev.index)
     if st is None:
-        st = _SIDE[dev.index] = torch.cuda.Stream(device=dev)
-    st.wait_stream(torch.cuda.current_stream(dev))
+        st = _SIDE[dev.index] = _SideStream(dev)
+    if _lib.dfine_stream_fork(_stream(), st.cuda_stream) != 0:
+        _check(-2, "dfine_stream_fork")
     return st
 
 
 def side_join():
     """The current stream waits for the side stream's launches (called before their results are consumed)."""
     if _SIDE_LIVE:
-        cur = torch.cuda.current_stream()
+        cur = _stream()
         for st in _SIDE.values():
-            cur.wait_stream(st)
+            if _lib.dfine_stream_fork(st.cuda_stream, cur) != 0:
+                _check(-2, "dfine_stream_fork")
         _SIDE_LIVE.clear()
 
 
@@ -824,10 +850,20 @@ def _p16(n):
 def conv_wgrad_bf16(x, dy, ks, partials=False):
     """x [B,Cin,H,W], dy [B,Cout,H,W] bf16 contiguous -> dw [Cout,Cin,ks,ks] f32; partials=True: (ws, meta) for a deferred
     dfine_multi_wgrad_reduce, meta = (splits, Cout, Cin, taps, NP16, CP16)."""
+    st = None
     if ks == 3 and x.shape[3] % 8:
         padw = (x.shape[3] + 7) // 8 * 8 - x.shape[3]
-        x = torch.nn.functional.pad(x, (0, padw))
-        dy = torch.nn.functional.pad(dy, (0, padw))
+        if partials and _side_ok():
+            # the zero-padded copies are part of the weight-gradient work: made on the side stream too (their blocks belong to
+            # its allocator pool and stay referenced until the join)
+            st = _side_fork(x.device)
+            with torch.cuda.stream(st.stream):
+                xp, dyp = torch.nn.functional.pad(x, (0, padw)), torch.nn.functional.pad(dy, (0, padw))
+            _SIDE_LIVE.append((x, dy))
+            x, dy = xp, dyp
+        else:
+            x = torch.nn.functional.pad(x, (0, padw))
+            dy = torch.nn.functional.pad(dy, (0, padw))
     B, cin, H, W = x.shape
     cout = dy.shape[1]
     dw = None if partials else torch.empty(cout, cin, ks, ks, device=x.device, dtype=torch.float32)
@@ -839,7 +875,8 @@ def conv_wgrad_bf16(x, dy, ks, partials=False):
             _flush_conv_group(True)          # ... or in a few, on the side stream while backward goes on
         return ws, (int(_lib.dfine_conv_wgrad_splits(B, cin, cout, H, W, ks)), cout, cin, 1, _p16(cout), _p16(cin))
     if partials and _side_ok():
-        st = _side_fork(x.device)
+        if st is None:
+            st = _side_fork(x.device)
         _check(_lib.dfine_conv_wgrad_bf16(_ptr(x), _ptr(dy), None, _ptr(ws), B, cin, cout, H, W, ks, st.cuda_stream), "dfine_conv_wgrad_bf16")
         _SIDE_LIVE.append((x, dy, ws))
         return ws, (int(_lib.dfine_conv_wgrad_splits(B, cin, cout, H, W, ks)), cout, cin, ks * ks, _p16(cout), _p16(cin))

@@ -156,6 +156,25 @@ def msda_fused(value, spatial_shapes, ref_boxes, offsets, logits, num_points_lis
 # =============================================================================================
 # A3  encoder maps -> decoder token memory
 # =============================================================================================
+class _Upsample2Nearest(torch.autograd.Function):
+    """F.interpolate(x, scale_factor=2, mode="nearest") of a bf16 NCHW map (FPN top-down path): one data-movement pass each way
+    (csrc/layout.hip) instead of ATen's gather kernels (78 / 73 us for the 40x40 -> 80x80 map of D-FINE-m bs 32)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _hip().upsample2_nearest(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _hip().upsample2_nearest(dy.contiguous(), backward=True)
+
+
+def upsample2_nearest(x):
+    if x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[-1] % 8 == 0 and _env("DFINE_HIP_UNITS", "1") == "1":
+        return _Upsample2Nearest.apply(x)
+    return F.interpolate(x, scale_factor=2.0, mode="nearest")
+
+
 class _FlattenLevels(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *maps):

@@ -37,6 +37,11 @@ int dfine_abi_version(void);
 /* Text of the last HIP runtime error seen by this library on the calling thread ("" if none). */
 const char *dfine_last_error(void);
 
+/* Stream `to` waits for everything enqueued on stream `from` so far (hipEventRecord + hipStreamWaitEvent on an internal event
+ * ring): fork / join of the second stream that runs the weight-gradient launches of a backward pass next to the data-gradient
+ * chain (the reference runs both on one stream through autograd: torch.Tensor.backward in src/dl/train.py:575). */
+int dfine_stream_fork(void *from, void *to);
+
 /* ---------------------------------------------------------------------------------------------
  * A7  Multi-scale deformable attention gather.
  * Replaces deformable_attention_core_func_v2 (src/d_fine/arch/utils.py:191-264): per level
@@ -592,6 +597,11 @@ int64_t dfine_ln_fused_bwd_ws_floats(int64_t rows, int D);
  */
 int dfine_maps_tokens_bf16(const void *map, void *tokens, int B, int C, int HW, int L, int row0, int to_tokens,
                            void *stream);
+
+/* Nearest-neighbour 2x upsampling of the FPN top-down path, `F.interpolate(feat_heigh, scale_factor=2.0, mode="nearest")`
+ * (src/d_fine/arch/hybrid_encoder.py:472), and its backward: x [planes, H, W], y [planes, 2H, 2W], bf16, W % 8 == 0.
+ * backward = 0: y := upsample(x); backward = 1: x := sum of the 2 x 2 blocks of y (the gradient with respect to x). */
+int dfine_upsample2_nearest_bf16(void *x, void *y, int64_t planes, int H, int W, int backward, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A2 / A5 / A6, fp32 (BASELINE config #2)  Token-stream GEMMs on the f32-input matrix cores.  Replaces the rocBLAS calls

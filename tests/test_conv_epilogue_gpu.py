@@ -65,3 +65,22 @@ def test_hg_block_gradient_fanin_matches_autograd_sum(cuda, monkeypatch):
         assert torch.equal(res[0][0], res[1][0])                     # the input gradient: same kernels, same bf16 additions
         for a, b in zip(res[0][1:], res[1][1:]):                     # (parameter gradients: reductions with atomics in the BN tail)
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(a.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 20, 24), (3, 256, 40, 40), (1, 8, 5, 8)])
+def test_nearest_upsample_2x_matches_interpolate(cuda, shape):
+    """FPN top-down upsampling (ref hybrid_encoder.py:472): forward bit-exact (pure copy), backward = fp32 sum of the 2 x 2
+    block rounded once to bf16 (ATen's bf16 backward accumulates in fp32 as well)."""
+    import torch.nn.functional as F
+    torch.manual_seed(1)
+    x = torch.randn(shape, device=cuda).bfloat16().requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    y = kernels.upsample2_nearest(x)
+    yr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    assert torch.equal(y, yr)
+    go = torch.randn_like(yr)
+    y.backward(go)
+    yr.backward(go)
+    want = go.float().view(shape[0], shape[1], shape[2], 2, shape[3], 2).sum((3, 5)).bfloat16()
+    assert torch.equal(x.grad, want)
+    assert (x.grad.float() - xr.grad.float()).abs().max() <= 2 ** -7 * xr.grad.float().abs().max()
