@@ -74,54 +74,73 @@ __global__ __launch_bounds__(kTThreads) void tokens_to_maps_kernel(const uint16_
 }
 
 // ---- nearest-neighbour 2x upsampling of the FPN top-down path (ref hybrid_encoder.py:472 F.interpolate(scale_factor=2,
-// mode="nearest")) and its backward (sum of the 2 x 2 block): pure data movement, one thread per 8 input pixels - a 16-byte
-// load, four 16-byte stores (two output rows x 16 pixels) forward; four 16-byte loads, one 16-byte store backward.
+// mode="nearest")) and its backward (sum of the 2 x 2 block): pure data movement, one thread per 8 (or 4) input pixels - one
+// vector load and four vector stores (two output rows x 16 pixels) forward, four loads and one store backward.
+template <int V> struct UpVec;
+template <> struct UpVec<8> { typedef uint4 type; };
+template <> struct UpVec<4> { typedef uint2 type; };
+
+template <int V>   // V input pixels per thread: 8 (16-byte vectors) or 4 (W % 8 != 0: the 20-wide level)
 __global__ __launch_bounds__(256) void upsample2_nearest_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ y,
-                                                                int64_t nvec, int W8 /* W / 8 */, int H) {
+                                                                int64_t nvec, int WV /* W / V */, int H) {
+    typedef typename UpVec<V>::type vec_t;
     for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
-        const int64_t row = v / W8;                      // plane * H + h
-        const int wv = (int)(v - row * W8);
-        const uint4 a = *reinterpret_cast<const uint4 *>(x + v * 8);
-        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
-        uint32_t d[8];
+        const int64_t row = v / WV;                      // plane * H + h
+        const int wv = (int)(v - row * WV);
+        const vec_t a = *reinterpret_cast<const vec_t *>(x + v * V);
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&a);
+        uint32_t d[V];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < V / 2; ++k) {
             d[2 * k] = (w[k] & 0xffffu) | (w[k] << 16);             // pixel 2k twice
             d[2 * k + 1] = (w[k] >> 16) | (w[k] & 0xffff0000u);     // pixel 2k + 1 twice
         }
-        const uint4 lo = make_uint4(d[0], d[1], d[2], d[3]), hi = make_uint4(d[4], d[5], d[6], d[7]);
         const int64_t plane = row / H;
         const int h = (int)(row - plane * H);
-        uint16_t *o = y + ((plane * 2 * H + 2 * h) * (int64_t)W8 * 2 + 2 * wv) * 8;      // output row length 16 W8
-        const int64_t pitch = (int64_t)W8 * 16;
-        *reinterpret_cast<uint4 *>(o) = lo;
-        *reinterpret_cast<uint4 *>(o + 8) = hi;
-        *reinterpret_cast<uint4 *>(o + pitch) = lo;
-        *reinterpret_cast<uint4 *>(o + pitch + 8) = hi;
+        const int64_t pitch = (int64_t)WV * 2 * V;                  // output row length
+        uint16_t *o = y + (plane * 2 * H + 2 * h) * pitch + (int64_t)wv * 2 * V;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                vec_t ov;
+                uint32_t *op = reinterpret_cast<uint32_t *>(&ov);
+#pragma unroll
+                for (int k = 0; k < V / 2; ++k) op[k] = d[half * (V / 2) + k];
+                *reinterpret_cast<vec_t *>(o + r * pitch + half * V) = ov;
+            }
     }
 }
 
+template <int V>
 __global__ __launch_bounds__(256) void upsample2_nearest_bwd_kernel(const uint16_t *__restrict__ dy, uint16_t *__restrict__ dx,
-                                                                    int64_t nvec, int W8, int H) {
+                                                                    int64_t nvec, int WV, int H) {
+    typedef typename UpVec<V>::type vec_t;
     for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
-        const int64_t row = v / W8;
-        const int wv = (int)(v - row * W8);
+        const int64_t row = v / WV;
+        const int wv = (int)(v - row * WV);
         const int64_t plane = row / H;
         const int h = (int)(row - plane * H);
-        const uint16_t *g = dy + ((plane * 2 * H + 2 * h) * (int64_t)W8 * 2 + 2 * wv) * 8;
-        const int64_t pitch = (int64_t)W8 * 16;
-        const uint4 r0a = *reinterpret_cast<const uint4 *>(g), r0b = *reinterpret_cast<const uint4 *>(g + 8);
-        const uint4 r1a = *reinterpret_cast<const uint4 *>(g + pitch), r1b = *reinterpret_cast<const uint4 *>(g + pitch + 8);
-        const uint32_t t0[8] = {r0a.x, r0a.y, r0a.z, r0a.w, r0b.x, r0b.y, r0b.z, r0b.w};
-        const uint32_t t1[8] = {r1a.x, r1a.y, r1a.z, r1a.w, r1b.x, r1b.y, r1b.z, r1b.w};
-        float s[8];
+        const int64_t pitch = (int64_t)WV * 2 * V;
+        const uint16_t *g = dy + (plane * 2 * H + 2 * h) * pitch + (int64_t)wv * 2 * V;
+        float s[V];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)                       // dword k of a row = output pixels 2k, 2k + 1 = the block of input pixel k
-            s[k] = (__uint_as_float(t0[k] << 16) + __uint_as_float(t0[k] & 0xffff0000u)) +
-                   (__uint_as_float(t1[k] << 16) + __uint_as_float(t1[k] & 0xffff0000u));
-        uint4 o;
-        o.x = pack_bf16x2(s[0], s[1]); o.y = pack_bf16x2(s[2], s[3]); o.z = pack_bf16x2(s[4], s[5]); o.w = pack_bf16x2(s[6], s[7]);
-        *reinterpret_cast<uint4 *>(dx + v * 8) = o;
+        for (int k = 0; k < V; ++k) s[k] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const vec_t t = *reinterpret_cast<const vec_t *>(g + r * pitch + half * V);
+                const uint32_t *tp = reinterpret_cast<const uint32_t *>(&t);
+#pragma unroll
+                for (int k = 0; k < V / 2; ++k)      // dword k of this half = output pixels of input pixel half * V / 2 + k
+                    s[half * (V / 2) + k] += __uint_as_float(tp[k] << 16) + __uint_as_float(tp[k] & 0xffff0000u);
+            }
+        vec_t o;
+        uint32_t *op = reinterpret_cast<uint32_t *>(&o);
+#pragma unroll
+        for (int k = 0; k < V / 2; ++k) op[k] = pack_bf16x2(s[2 * k], s[2 * k + 1]);
+        *reinterpret_cast<vec_t *>(dx + v * V) = o;
     }
 }
 
@@ -145,20 +164,23 @@ int dfine_maps_tokens_bf16(const void *map, void *tokens, int B, int C, int HW, 
     return check_launch();
 }
 
-// y [planes, 2H, 2W] = nearest-neighbour 2x upsampling of x [planes, H, W] (bf16, W % 8 == 0); backward = 0: forward,
+// y [planes, 2H, 2W] = nearest-neighbour 2x upsampling of x [planes, H, W] (bf16, W % 4 == 0); backward = 0: forward,
 // 1: x := sum over the 2 x 2 blocks of y (the gradient).
 int dfine_upsample2_nearest_bf16(void *x, void *y, int64_t planes, int H, int W, int backward, void *stream) {
     if (planes == 0 || H == 0 || W == 0) return DFINE_OK;
-    if (!x || !y || planes < 0 || H < 1 || W < 8 || (W & 7)) return DFINE_E_BADARG;
-    const int64_t nvec = planes * H * (W / 8);
+    if (!x || !y || planes < 0 || H < 1 || W < 4 || (W & 3)) return DFINE_E_BADARG;
+    const int V = (W & 7) ? 4 : 8;
+    const int64_t nvec = planes * H * (W / V);
     int64_t blocks = (nvec + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    if (backward)
-        hipLaunchKernelGGL(upsample2_nearest_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                           (const uint16_t *)y, (uint16_t *)x, nvec, W / 8, H);
-    else
-        hipLaunchKernelGGL(upsample2_nearest_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)x,
-                           (uint16_t *)y, nvec, W / 8, H);
+    hipStream_t st = (hipStream_t)stream;
+    if (backward) {
+        if (V == 8) hipLaunchKernelGGL(upsample2_nearest_bwd_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, (const uint16_t *)y, (uint16_t *)x, nvec, W / 8, H);
+        else hipLaunchKernelGGL(upsample2_nearest_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, (const uint16_t *)y, (uint16_t *)x, nvec, W / 4, H);
+    } else {
+        if (V == 8) hipLaunchKernelGGL(upsample2_nearest_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, (const uint16_t *)x, (uint16_t *)y, nvec, W / 8, H);
+        else hipLaunchKernelGGL(upsample2_nearest_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, (const uint16_t *)x, (uint16_t *)y, nvec, W / 4, H);
+    }
     return check_launch();
 }
 

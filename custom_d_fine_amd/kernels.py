@@ -170,7 +170,7 @@ class _Upsample2Nearest(torch.autograd.Function):
 
 
 def upsample2_nearest(x):
-    if x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[-1] % 8 == 0 and _env("DFINE_HIP_UNITS", "1") == "1":
+    if x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[-1] % 4 == 0 and _env("DFINE_HIP_UNITS", "1") == "1":
         return _Upsample2Nearest.apply(x)
     return F.interpolate(x, scale_factor=2.0, mode="nearest")
 

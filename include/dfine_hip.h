@@ -599,7 +599,7 @@ int dfine_maps_tokens_bf16(const void *map, void *tokens, int B, int C, int HW, 
                            void *stream);
 
 /* Nearest-neighbour 2x upsampling of the FPN top-down path, `F.interpolate(feat_heigh, scale_factor=2.0, mode="nearest")`
- * (src/d_fine/arch/hybrid_encoder.py:472), and its backward: x [planes, H, W], y [planes, 2H, 2W], bf16, W % 8 == 0.
+ * (src/d_fine/arch/hybrid_encoder.py:472), and its backward: x [planes, H, W], y [planes, 2H, 2W], bf16, W % 4 == 0.
  * backward = 0: y := upsample(x); backward = 1: x := sum of the 2 x 2 blocks of y (the gradient with respect to x). */
 int dfine_upsample2_nearest_bf16(void *x, void *y, int64_t planes, int H, int W, int backward, void *stream);
 

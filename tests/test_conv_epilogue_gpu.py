@@ -67,7 +67,7 @@ def test_hg_block_gradient_fanin_matches_autograd_sum(cuda, monkeypatch):
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(a.abs().max()))
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 20, 24), (3, 256, 40, 40), (1, 8, 5, 8)])
+@pytest.mark.parametrize("shape", [(2, 16, 20, 24), (3, 256, 40, 40), (1, 8, 5, 8), (2, 256, 20, 20), (1, 4, 3, 12)])
 def test_nearest_upsample_2x_matches_interpolate(cuda, shape):
     """FPN top-down upsampling (ref hybrid_encoder.py:472): forward bit-exact (pure copy), backward = fp32 sum of the 2 x 2
     block rounded once to bf16 (ATen's bf16 backward accumulates in fp32 as well)."""

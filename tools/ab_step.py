@@ -2,6 +2,7 @@
 (ABAB...), so box-to-box and minute-to-minute drift (+-1 ms between two bench.py runs on these boxes) cancels.  GPU box:
     python tools/ab_step.py hip.WGRAD_STREAM            # module attribute toggled False / True
     python tools/ab_step.py env:DFINE_GRAD_FANIN        # environment switch "0" / "1" + kernels.reload_env()
+    python tools/ab_step.py hip._SIDE_GROUP_AT=12,48    # module attribute set to the first / second value
     AB_BLOCKS=12 AB_STEPS=8 python tools/ab_step.py ..."""
 import os, sys, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,6 +22,11 @@ def setting(on):
     if what.startswith("env:"):
         os.environ[what[4:]] = "1" if on else "0"
         kernels.reload_env()
+    elif "=" in what:                                  # hip._SIDE_GROUP_AT=12,48 : arm 0 -> 12, arm 1 -> 48
+        name, vals = what.split("=")
+        mod, attr = name.split(".")
+        a, b = vals.split(",")
+        setattr({"hip": hip, "kernels": kernels}[mod], attr, type(getattr({"hip": hip, "kernels": kernels}[mod], attr))(b if on else a))
     else:
         mod, attr = what.split(".")
         setattr({"hip": hip, "kernels": kernels}[mod], attr, bool(on))
