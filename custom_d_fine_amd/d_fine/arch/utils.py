@@ -322,7 +322,7 @@ def get_contrastive_denoising_training_group(
         box = torch.where(box < 0, -box, box)
         box_unact = inverse_sigmoid(box)
 
-    logits = class_embed(cls)
+    logits = kernels.embedding(class_embed, cls) if isinstance(class_embed, nn.Embedding) else class_embed(cls)
 
     n = total + num_queries
     mask = torch.zeros([n, n], dtype=torch.bool, device=device)

@@ -156,6 +156,42 @@ def msda_fused(value, spatial_shapes, ref_boxes, offsets, logits, num_points_lis
 # =============================================================================================
 # A3  encoder maps -> decoder token memory
 # =============================================================================================
+class _EmbeddingSideGrad(torch.autograd.Function):
+    """nn.Embedding lookup whose weight gradient (ATen's sort-based embedding_dense_backward: 0.17 ms for the denoising class
+    embedding of a D-FINE-m step, and nothing in backward waits for it) runs on the side stream next to the decoder's backward
+    chain (hip._side_fork; joined by the fused optimizer's gather like the other gradient tensors produced there)."""
+
+    @staticmethod
+    def forward(ctx, weight, idx, padding_idx):
+        ctx.save_for_backward(idx)
+        ctx.cfg = (weight.shape[0], padding_idx, weight)
+        return F.embedding(idx, weight, padding_idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        hip = _hip()
+        (idx,) = ctx.saved_tensors
+        n, padding_idx, weight = ctx.cfg
+        ctx.cfg = None
+        pad = -1 if padding_idx is None else padding_idx
+        g = g.contiguous()
+        if _side_wgrad_ok(weight) and hip.side_stream_ok():
+            st = hip._side_fork(g.device)
+            with torch.cuda.stream(st.stream):
+                dw = torch.ops.aten.embedding_dense_backward(g, idx, n, pad, False)
+            hip._SIDE_LIVE.append((g, idx))
+            return dw, None, None
+        return torch.ops.aten.embedding_dense_backward(g, idx, n, pad, False), None, None
+
+
+def embedding(mod: nn.Embedding, idx):
+    """mod(idx) for a plain nn.Embedding; on the GPU training path the weight gradient leaves the backward chain."""
+    if (idx.is_cuda and mod.weight.requires_grad and torch.is_grad_enabled() and mod.max_norm is None and not mod.sparse
+            and not mod.scale_grad_by_freq and _env("DFINE_HIP_UNITS", "1") == "1"):
+        return _EmbeddingSideGrad.apply(mod.weight, idx, mod.padding_idx)
+    return mod(idx)
+
+
 class _Upsample2Nearest(torch.autograd.Function):
     """F.interpolate(x, scale_factor=2, mode="nearest") of a bf16 NCHW map (FPN top-down path): one data-movement pass each way
     (csrc/layout.hip) instead of ATen's gather kernels (78 / 73 us for the 40x40 -> 80x80 map of D-FINE-m bs 32)."""
