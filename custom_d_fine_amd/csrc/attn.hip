@@ -285,8 +285,12 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const uint16_
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// backward, dK and dV: block = (b, h, 512 keys), wave = 128 keys, queries in chunks of 32 through LDS (double buffered)
-__global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkdv_kernel(const uint16_t *__restrict__ q, const uint16_t *__restrict__ k,
+// backward, dK and dV: block = (b, h, 512 keys) = NW waves of 16 KT keys each, queries in chunks of 32 through LDS (double
+// buffered).  <8, 4>: 128 keys per wave, 256 threads - ONE wave per SIMD for the decoder's 492 tokens (B H = 256 blocks on 256
+// CUs): latency-bound, and slowed down further by whatever shares the chip (143 us alone, 268 us next to the side stream's
+// weight-gradient kernels).  <4, 8>: 64 keys per wave, 512 threads, two waves per SIMD and half the accumulators per wave.
+template <int KT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const uint16_t *__restrict__ q, const uint16_t *__restrict__ k,
                                                                      const uint16_t *__restrict__ v, const uint16_t *__restrict__ dout,
                                                                      const float *__restrict__ lse2, const float *__restrict__ delta,
                                                                      const uint8_t *__restrict__ mask, uint16_t *__restrict__ dk,
@@ -299,13 +303,13 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkdv_kernel(const uint1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
     const int bh = blockIdx.x % (B * H), kblk = blockIdx.x / (B * H);
     const int b = bh / H, h = bh - b * H;
-    const int kw0 = kblk * 512 + wave * 128;                                   // this wave's keys
+    const int kw0 = kblk * 512 + wave * 16 * KT;                               // this wave's keys
     const uint16_t *qb = q + (int64_t)b * L * ldq + h * kHD;
     const uint16_t *dob = dout + (int64_t)b * L * lddo + h * kHD;
 
-    a_bf16x8 kf[8], vf[8];
+    a_bf16x8 kf[KT], vf[KT];
 #pragma unroll
-    for (int kt = 0; kt < 8; ++kt) {
+    for (int kt = 0; kt < KT; ++kt) {
         const int key = kw0 + kt * 16 + i16;
         uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
         if (key < L) {
@@ -315,11 +319,11 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkdv_kernel(const uint1
         kf[kt] = __builtin_bit_cast(a_bf16x8, kv);
         vf[kt] = __builtin_bit_cast(a_bf16x8, vv);
     }
-    a_f32x4 dka[2][8], dva[2][8];
+    a_f32x4 dka[2][KT], dva[2][KT];
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) { dka[d][kt] = a_f32x4{0.f, 0.f, 0.f, 0.f}; dva[d][kt] = a_f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int kt = 0; kt < KT; ++kt) { dka[d][kt] = a_f32x4{0.f, 0.f, 0.f, 0.f}; dva[d][kt] = a_f32x4{0.f, 0.f, 0.f, 0.f}; }
     const int tr_off = (4 * g + (i16 >> 2)) * kP48 + 4 * (i16 & 3);
     const bool wave_live = kw0 < L;
 
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkdv_kernel(const uint1
             uint4 a = make_uint4(0, 0, 0, 0);
             if (r < valid) a = *reinterpret_cast<const uint4 *>(qb + (int64_t)(q0 + r) * ldq + c);
             *reinterpret_cast<uint4 *>(&sQ[buf][r * kP48 + c]) = a;
-        } else {
+        } else if (tid < 256) {
             const int t2 = tid - 128, r = t2 >> 2, c = (t2 & 3) * 8;
             uint4 a = make_uint4(0, 0, 0, 0);
             if (r < valid) a = *reinterpret_cast<const uint4 *>(dob + (int64_t)(q0 + r) * lddo + c);
@@ -351,8 +355,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkdv_kernel(const uint1
         if (c + 1 < nchunk) stage(buf ^ 1, q0 + 32);
         if (!wave_live) continue;
         const uint16_t *tq = sQ[buf], *tdo = sDO[buf];
-        uint32_t pp[8][2], dsp[8][2];                                       // bf16 pairs: [key tile][query tile] -> (r0 r1, r2 r3)
-        uint32_t pp2[8][2], dsp2[8][2];
+        uint32_t pp[KT][2], dsp[KT][2];                                       // bf16 pairs: [key tile][query tile] -> (r0 r1, r2 r3)
+        uint32_t pp2[KT][2], dsp2[KT][2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             const a_bf16x8 qa = ld_frag(tq + (qt * 16 + i16) * kP48 + 8 * g);
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkdv_kernel(const uint1
 #pragma unroll
             for (int r = 0; r < 4; ++r) { lq[r] = sL[buf][qt * 16 + 4 * g + r]; dq_[r] = sD[buf][qt * 16 + 4 * g + r]; }
 #pragma unroll
-            for (int kt = 0; kt < 8; ++kt) {
+            for (int kt = 0; kt < KT; ++kt) {
                 const a_f32x4 z = a_f32x4{0.f, 0.f, 0.f, 0.f};
                 const a_f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt], z, 0, 0, 0);    // S[q = 4g + r][key = i16]
                 const a_f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt], z, 0, 0, 0);
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkdv_kernel(const uint1
             const a_bf16x8 dot = tr_frag(tdo + tr_off + 16 * d, kP48);       // dO^T[d][q slots of g]
             const a_bf16x8 qtf = tr_frag(tq + tr_off + 16 * d, kP48);        // Q^T
 #pragma unroll
-            for (int kt = 0; kt < 8; ++kt) {
+            for (int kt = 0; kt < KT; ++kt) {
                 const a_bf16x8 pb = __builtin_bit_cast(a_bf16x8, make_uint4(pp[kt][0], pp[kt][1], pp2[kt][0], pp2[kt][1]));
                 const a_bf16x8 db = __builtin_bit_cast(a_bf16x8, make_uint4(dsp[kt][0], dsp[kt][1], dsp2[kt][0], dsp2[kt][1]));
                 dva[d][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pb, dva[d][kt], 0, 0, 0);
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkdv_kernel(const uint1
     }
     if (!wave_live) return;
 #pragma unroll
-    for (int kt = 0; kt < 8; ++kt) {
+    for (int kt = 0; kt < KT; ++kt) {
         const int key = kw0 + kt * 16 + i16;
         if (key >= L) continue;
 #pragma unroll
@@ -447,9 +451,15 @@ int dfine_attn_bwd(const void *q, const void *k, const void *v, const void *o, c
                        ldq, ldk, ldv, ldo, lddo, lddq, scale, c);
     if (int e = check_launch()) return e;
     const int nk = (L + 511) / 512;
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(B * H * nk), dim3(kAttnThreads), 0, st, (const uint16_t *)q, (const uint16_t *)k,
-                       (const uint16_t *)v, (const uint16_t *)dout, lse2, (const float *)delta, mask, (uint16_t *)dk, (uint16_t *)dv,
-                       B, L, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, c);
+    static const int kt4 = [] { const char *e = getenv("DFINE_ATTN_DKDV_KT4"); return e ? atoi(e) : 1; }();
+    if (kt4)
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<4, 8>), dim3(B * H * nk), dim3(512), 0, st, (const uint16_t *)q, (const uint16_t *)k,
+                           (const uint16_t *)v, (const uint16_t *)dout, lse2, (const float *)delta, mask, (uint16_t *)dk, (uint16_t *)dv,
+                           B, L, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, c);
+    else
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<8, 4>), dim3(B * H * nk), dim3(256), 0, st, (const uint16_t *)q, (const uint16_t *)k,
+                           (const uint16_t *)v, (const uint16_t *)dout, lse2, (const float *)delta, mask, (uint16_t *)dk, (uint16_t *)dv,
+                           B, L, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, c);
     return check_launch();
 }
 
