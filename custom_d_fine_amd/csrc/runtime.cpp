@@ -17,9 +17,13 @@ const char *dfine_last_error(void) { return dfine::g_last_error.c_str(); }
 // objects, 80 times per step.  Events come from a ring: a stream wait refers to the record that preceded it, so an event can
 // be recorded again as soon as its wait has been ENQUEUED.
 int dfine_stream_fork(void *from, void *to) {
-    constexpr int kRing = 64;
-    static hipEvent_t ring[kRing];
-    static int next = -1;
+    constexpr int kRing = 64, kDevices = 16;             // one ring per device: an event belongs to the device it was made on
+    static hipEvent_t rings[kDevices][kRing];
+    static int nexts[kDevices] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDevices) return DFINE_E_BADARG;
+    hipEvent_t *ring = rings[dev];
+    int &next = nexts[dev];
     if (next < 0) {
         for (int i = 0; i < kRing; ++i)
             if (hipError_t e = hipEventCreateWithFlags(&ring[i], hipEventDisableTiming); e != hipSuccess) {

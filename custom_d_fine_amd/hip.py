@@ -796,6 +796,7 @@ def conv1x1_seg_wgrad(x_parts, dy, partials=False):
 WGRAD_STREAM = os.environ.get("DFINE_WGRAD_STREAM", "1") == "1"
 _SIDE = {}
 _SIDE_LIVE = []
+_SIDE_PRIORITY = int(os.environ.get("DFINE_SIDE_PRIORITY", "0"))       # stream priority of the side stream (torch: lower number = higher priority)
 _SIDE_GROUP_AT = int(os.environ.get("DFINE_WGRAD_GROUP_AT", "32"))     # registered problems that trigger an early grouped launch (12 / 48 / never: +0.13 / 0 / +0.4 ms per step)
 
 
@@ -812,7 +813,7 @@ class _SideStream:
     __slots__ = ("stream", "cuda_stream")
 
     def __init__(self, dev):
-        self.stream = torch.cuda.Stream(device=dev)
+        self.stream = torch.cuda.Stream(device=dev, priority=_SIDE_PRIORITY)
         self.cuda_stream = self.stream.cuda_stream
 
 

@@ -18,7 +18,20 @@ step = bench.build_step(os.environ.get("SP_MODEL", "m"), int(os.environ.get("SP_
 images, targets = make_batch(int(os.environ.get("SP_BATCH", "32")), int(os.environ.get("SP_IMG", "640")), seed=42, device=dev)
 
 
+_HI = torch.cuda.Stream(device=dev, priority=-1)
+_CTX = [None]
+
+
 def setting(on):
+    if what == "main_high_priority":                   # the whole step on a high-priority stream (the side stream stays normal)
+        torch.cuda.synchronize()
+        if _CTX[0] is not None:
+            _CTX[0].__exit__(None, None, None)
+            _CTX[0] = None
+        if on:
+            _CTX[0] = torch.cuda.stream(_HI)
+            _CTX[0].__enter__()
+        return
     if what.startswith("env:"):
         os.environ[what[4:]] = "1" if on else "0"
         kernels.reload_env()
@@ -27,6 +40,9 @@ def setting(on):
         mod, attr = name.split(".")
         a, b = vals.split(",")
         setattr({"hip": hip, "kernels": kernels}[mod], attr, type(getattr({"hip": hip, "kernels": kernels}[mod], attr))(b if on else a))
+        if attr == "_SIDE_PRIORITY":                   # the side stream is made again with the new priority
+            torch.cuda.synchronize()
+            hip._SIDE.clear()
     else:
         mod, attr = what.split(".")
         setattr({"hip": hip, "kernels": kernels}[mod], attr, bool(on))
