@@ -39,12 +39,14 @@ class FusedAdamWEMA:
     too, so EMA is a handful of streaming kernels instead of two launches per tensor.
     """
 
-    def __init__(self, model, optimizer, ema=None, clip_max_norm=0.1, overlap=None, bucket_mb=16):
+    def __init__(self, model, optimizer, ema=None, clip_max_norm=0.1, overlap=None, bucket_mb=40):
         """overlap: all-reduce gradient buckets during backward (default: on when world_size > 1; the
         DFINE_GRAD_OVERLAP environment variable overrides).  bucket_mb: xGMI is point-to-point (7 links x ~153 GB/s), a ring
         all-reduce is per-link bound and its fixed latency is paid per call, so buckets are few and large - but only the
-        LAST bucket (the first layers of the backbone, complete when backward ends) is exposed, so not too large either:
-        D-FINE-m's 78 MB make 8 buckets at 16 MB, the exposed one 7 MB (24 MB with 32 MB buckets)."""
+        LAST bucket (the first layers of the backbone, complete when backward ends) is exposed, so not too large either.
+        Every bucket boundary also joins the side stream and runs the bucket's deferred reductions in the middle of backward:
+        measured on a one-rank RCCL group (tools/probe/ddp_mode_timing.py) the mode itself costs +1.06 ms per step with
+        16 MB buckets (8 for D-FINE-m's 78 MB), +0.33 ms with 40 MB (5).  DFINE_BUCKET_MB overrides."""
         import os
         from .. import hip
         self.hip = hip
@@ -122,6 +124,7 @@ class FusedAdamWEMA:
             self.overlap = env == "1"
         self.accumulating = False            # TrainStep sets it on all but the last micro-step of an accumulation window
         self._buckets, self._works = [], []
+        bucket_mb = float(os.environ.get("DFINE_BUCKET_MB", bucket_mb))
         cap = max(int(bucket_mb * (1 << 20) // 4), 1)
         pidx = 0
         index_of = {}
