@@ -318,7 +318,8 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
 // four quarter-filled lines - the L2 atomic units are paced by line operations, not by bytes.
 typedef __attribute__((ext_vector_type(2))) _Float16 half2_t;
 
-template <typename T, int D, bool FUSED>
+// MERGE: contributions to one value row are summed in registers first (see msda_bwd_pair_kernel).
+template <typename T, int D, bool FUSED, bool MERGE>
 __global__ __launch_bounds__(kThreads) void msda_bwd_wide_kernel(
     const T *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ weight,
     const float *__restrict__ ref, const T *__restrict__ offsets, const T *__restrict__ logits,
@@ -359,6 +360,10 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_wide_kernel(
             for (int p = 0; p < P; ++p) s += __expf(pw[p] - wmax);
             winv = 1.f / s;
         }
+        float *gvbase0 = grad_value + (int64_t)head * D + ch;      // (row 0 of image 0); a pending row is kept as b * L + row
+        const int brow = b * L;
+        int prow[4] = {-1, -1, -1, -1};
+        float pa[4] = {0.f, 0.f, 0.f, 0.f};
         float dot_acc = 0.f;
         for (int p = 0; p < P; ++p) {
             const Corner c = corners(px[p], py[p], lv.start[p], lv.h[p], lv.w[p]);
@@ -368,7 +373,38 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_wide_kernel(
             for (int k = 0; k < 4; ++k) {
                 d[k] = go * load_f(vbase + c.row[k] * stride) * c.ok[k];
                 const float g = aw * c.bw[k];
-                if (g != 0.f) unsafeAtomicAdd(gvbase + c.row[k] * stride, g * go);
+                if (g != 0.f) {
+                    if (!MERGE) {
+                        unsafeAtomicAdd(gvbase + c.row[k] * stride, g * go);
+                    } else {
+                        const int grow = brow + (int)c.row[k];
+                        if (grow == prow[k]) {
+                            pa[k] += g * go;
+                        } else {
+                            if (prow[k] >= 0) unsafeAtomicAdd(gvbase0 + (int64_t)prow[k] * stride, pa[k]);
+                            prow[k] = grow; pa[k] = g * go;
+                        }
+                    }
+                }
+            }
+            if (MERGE && (p + 1 == P || lv.start[p + 1] != lv.start[p])) {      // end of a level (uniform): merge over the wave, flush
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int r = prow[k];
+                    float a = pa[k];
+#pragma unroll
+                    for (int o = LPT; o < 64; o <<= 1) {
+                        const int r1 = __shfl_xor(r, o, 64);
+                        const float a1 = __shfl_xor(a, o, 64);
+                        const bool partner = (int)((threadIdx.x ^ o) / LPT) < nq;
+                        if (partner && r >= 0 && r1 == r) {
+                            if (threadIdx.x & o) r = -1;
+                            else a += a1;
+                        }
+                    }
+                    if (r >= 0) unsafeAtomicAdd(gvbase0 + (int64_t)r * stride, a);
+                    prow[k] = -1;
+                }
             }
             float gw = c.wy0 * c.wx0 * d[0] + c.wy0 * c.wx1 * d[1] + c.wy1 * c.wx0 * d[2] + c.wy1 * c.wx1 * d[3];
             float gx = (c.wy0 * (d[1] - d[0]) + c.wy1 * (d[3] - d[2])) * aw * (float)lv.w[p];
@@ -414,7 +450,14 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_wide_kernel(
 // channel (f32 608 us, int32 482 us, int64 pairs 548 us, packed 16-bit pairs 325 us at the bench shape), so halving the
 // dwords is what halves the time.  f16 carries 11 significant bits (bf16: 8, measured 1.9 % of max worst-case error and
 // addends below 1/256 of a running sum lost outright) and, scaled, 39 binary orders below the largest sum.
-template <typename T, int D, bool FUSED, int AM>
+// MERGE: contributions that meet in one value row are summed in registers before they reach the atomic units - over the
+// consecutive points of a level inside a lane (a pending (row, sum) pair per corner, flushed when the row changes) and, at
+// the end of every level, over the tasks of the wave (butterfly over lane ^ LPT, ^ 2 LPT, ...: the lower task takes the sum,
+// the upper one drops out).  In training a fifth of the queries are the PADDING entries of the denoising groups: zero boxes
+// whose 12 points all sit on pixel (0, 0) of their level, consecutive in the query order - 12 x 4 atomics of a wave on three
+// hot rows become three.  Every contribution is still added exactly once; sums are formed in fp32 before the f16 / integer
+// conversion.
+template <typename T, int D, bool FUSED, int AM, bool MERGE>
 __global__ __launch_bounds__(kThreads) void msda_bwd_pair_kernel(
     const T *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ weight,
     const float *__restrict__ ref, const T *__restrict__ offsets, const T *__restrict__ logits,
@@ -463,6 +506,23 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_pair_kernel(
             for (int p = 0; p < P; ++p) s += __expf(pw[p] - wmax);
             winv = 1.f / s;
         }
+        // element offset of (row 0, this head, this channel pair) of image 0; a pending row is kept as b * L + row
+        const int64_t base0 = (int64_t)head * D + c2;
+        const int brow = b * L;
+        auto add_pair = [&](int grow, float a0, float a1) {
+            const int64_t e = base0 + (int64_t)grow * stride;
+            if (AM == 3) {
+                const long long lo = (long long)__float2int_rn(a0), hi = (long long)__float2int_rn(a1);
+                long long *dst = reinterpret_cast<long long *>(reinterpret_cast<int *>(grad_value) + e);
+                __hip_atomic_fetch_add(dst, lo + (hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const half2_t v = {(_Float16)a0, (_Float16)a1};
+                _Float16 *dst = reinterpret_cast<_Float16 *>(grad_value) + e;
+                __builtin_amdgcn_global_atomic_fadd_v2f16((half2_t __attribute__((address_space(1))) *)dst, v);
+            }
+        };
+        int prow[4] = {-1, -1, -1, -1};
+        float pa0[4] = {0.f, 0.f, 0.f, 0.f}, pa1[4] = {0.f, 0.f, 0.f, 0.f};
         float dot_acc = 0.f;
         for (int p = 0; p < P; ++p) {
             const Corner c = corners(px[p], py[p], lv.start[p], lv.h[p], lv.w[p]);
@@ -481,15 +541,34 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_pair_kernel(
                 d[k] = (go0 * v0 + go1 * v1) * c.ok[k];
                 const float g = aw * c.bw[k];
                 if (g != 0.f) {
-                    if (AM == 3) {
-                        const long long lo = (long long)__float2int_rn(g * gs0), hi = (long long)__float2int_rn(g * gs1);
-                        long long *dst = reinterpret_cast<long long *>(reinterpret_cast<int *>(grad_value) + base + c.row[k] * stride);
-                        __hip_atomic_fetch_add(dst, lo + (hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int grow = brow + (int)c.row[k];
+                    if (!MERGE) {
+                        add_pair(grow, g * gs0, g * gs1);
+                    } else if (grow == prow[k]) {
+                        pa0[k] += g * gs0; pa1[k] += g * gs1;
                     } else {
-                        const half2_t v = {(_Float16)(g * gs0), (_Float16)(g * gs1)};
-                        _Float16 *dst = reinterpret_cast<_Float16 *>(grad_value) + base + c.row[k] * stride;
-                        __builtin_amdgcn_global_atomic_fadd_v2f16((half2_t __attribute__((address_space(1))) *)dst, v);
+                        if (prow[k] >= 0) add_pair(prow[k], pa0[k], pa1[k]);
+                        prow[k] = grow; pa0[k] = g * gs0; pa1[k] = g * gs1;
                     }
+                }
+            }
+            if (MERGE && (p + 1 == P || lv.start[p + 1] != lv.start[p])) {      // end of a level (uniform): merge over the wave, flush
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int r = prow[k];
+                    float a0 = pa0[k], a1 = pa1[k];
+#pragma unroll
+                    for (int o = LPT; o < 64; o <<= 1) {
+                        const int r1 = __shfl_xor(r, o, 64);
+                        const float b0 = __shfl_xor(a0, o, 64), b1 = __shfl_xor(a1, o, 64);
+                        const bool partner = (int)((threadIdx.x ^ o) / LPT) < nq;    // lanes of tasks past the last query hold nothing
+                        if (partner && r >= 0 && r1 == r) {
+                            if (threadIdx.x & o) r = -1;
+                            else { a0 += b0; a1 += b1; }
+                        }
+                    }
+                    if (r >= 0) add_pair(r, a0, a1);
+                    prow[k] = -1;
                 }
             }
             float gw = c.wy0 * c.wx0 * d[0] + c.wy0 * c.wx1 * d[1] + c.wy1 * c.wx0 * d[2] + c.wy1 * c.wx1 * d[3];
@@ -695,6 +774,9 @@ static int launch_bwd(const void *value, const float *loc, const float *weight, 
     const int total_q = B * Lq;
     if (total_q == 0) return DFINE_OK;
     static const int variant = [] { const char *e = getenv("DFINE_MSDA_BWD"); return e ? atoi(e) : 1; }();
+    // DFINE_MSDA_MERGE=0: every contribution as its own atomic (A/B switch of the in-register merge, see the kernels)
+    static const int merge_env = [] { const char *e = getenv("DFINE_MSDA_MERGE"); return e ? atoi(e) : 1; }();
+    const bool merge = merge_env && (int64_t)B * L < (int64_t)1 << 31;
     if (acc_mode == 2 || acc_mode == 3) {
         if (!(D == 32 || D == 16 || D == 64)) return DFINE_E_BADARG;
         // scale bookkeeping of the scaled accumulator (see fx_update_kernel): three small launches in front of the gather
@@ -711,11 +793,18 @@ static int launch_bwd(const void *value, const float *loc, const float *weight, 
         constexpr int QPB = kThreads / (DD / 2);                                               \
         const int nblk = ((total_q + QPB - 1) / QPB) * H;                                      \
         const size_t sm = sizeof(float) * (6 * QPB * lv.n_points + QPB);                       \
-        hipLaunchKernelGGL((msda_bwd_pair_kernel<T, DD, FUSED, AM>), dim3(nblk), dim3(kThreads), sm, st, \
-                           (const T *)value, loc, weight, ref, (const T *)offsets,             \
-                           (const T *)logits, (const T *)grad_out, (void *)grad_value, grad_loc, \
-                           grad_weight, (T *)grad_offsets, (T *)grad_logits, lv, L, H, Lq,     \
-                           total_q, offset_scale, (const float *)fx_state);                    \
+        if (merge)                                                                             \
+            hipLaunchKernelGGL((msda_bwd_pair_kernel<T, DD, FUSED, AM, true>), dim3(nblk), dim3(kThreads), sm, st, \
+                               (const T *)value, loc, weight, ref, (const T *)offsets,         \
+                               (const T *)logits, (const T *)grad_out, (void *)grad_value, grad_loc, \
+                               grad_weight, (T *)grad_offsets, (T *)grad_logits, lv, L, H, Lq, \
+                               total_q, offset_scale, (const float *)fx_state);                \
+        else                                                                                   \
+            hipLaunchKernelGGL((msda_bwd_pair_kernel<T, DD, FUSED, AM, false>), dim3(nblk), dim3(kThreads), sm, st, \
+                               (const T *)value, loc, weight, ref, (const T *)offsets,         \
+                               (const T *)logits, (const T *)grad_out, (void *)grad_value, grad_loc, \
+                               grad_weight, (T *)grad_offsets, (T *)grad_logits, lv, L, H, Lq, \
+                               total_q, offset_scale, (const float *)fx_state);                \
     }
         if (acc_mode == 3) { if (D == 32) DFINE_BWDP(32, 3) else if (D == 16) DFINE_BWDP(16, 3) else DFINE_BWDP(64, 3) }
         else { if (D == 32) DFINE_BWDP(32, 2) else if (D == 16) DFINE_BWDP(16, 2) else DFINE_BWDP(64, 2) }
@@ -729,11 +818,18 @@ static int launch_bwd(const void *value, const float *loc, const float *weight, 
         constexpr int QPB = kThreads / DD;                                                     \
         const int nblk = ((total_q + QPB - 1) / QPB) * H;                                      \
         const size_t sm = sizeof(float) * (6 * QPB * lv.n_points + QPB);                       \
-        hipLaunchKernelGGL((msda_bwd_wide_kernel<T, DD, FUSED>), dim3(nblk), dim3(kThreads), sm, st, \
-                           (const T *)value, loc, weight, ref, (const T *)offsets,             \
-                           (const T *)logits, (const T *)grad_out, grad_value, grad_loc,       \
-                           grad_weight, (T *)grad_offsets, (T *)grad_logits, lv, L, H, Lq,     \
-                           total_q, offset_scale);                                             \
+        if (merge)                                                                             \
+            hipLaunchKernelGGL((msda_bwd_wide_kernel<T, DD, FUSED, true>), dim3(nblk), dim3(kThreads), sm, st, \
+                               (const T *)value, loc, weight, ref, (const T *)offsets,         \
+                               (const T *)logits, (const T *)grad_out, grad_value, grad_loc,   \
+                               grad_weight, (T *)grad_offsets, (T *)grad_logits, lv, L, H, Lq, \
+                               total_q, offset_scale);                                         \
+        else                                                                                   \
+            hipLaunchKernelGGL((msda_bwd_wide_kernel<T, DD, FUSED, false>), dim3(nblk), dim3(kThreads), sm, st, \
+                               (const T *)value, loc, weight, ref, (const T *)offsets,         \
+                               (const T *)logits, (const T *)grad_out, grad_value, grad_loc,   \
+                               grad_weight, (T *)grad_offsets, (T *)grad_logits, lv, L, H, Lq, \
+                               total_q, offset_scale);                                         \
     }
         if (D == 32) DFINE_BWDW(32) else if (D == 16) DFINE_BWDW(16) else DFINE_BWDW(64)
 #undef DFINE_BWDW

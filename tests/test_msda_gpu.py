@@ -191,6 +191,9 @@ def test_value_gradient_accumulate_modes(cuda, monkeypatch):
     value = torch.randn(B, L, H, D, device=cuda).bfloat16()
     gt = torch.cat([torch.rand(B, 7, 2, device=cuda) * 0.6 + 0.2, torch.rand(B, 7, 2, device=cuda) * 0.3 + 0.05], -1)
     dn = (gt.repeat(1, 28, 1)[:, :192] + torch.randn(B, 192, 4, device=cuda) * 0.02).clamp(0.01, 0.99)
+    dn = dn.view(B, 12, 16, 4).clone()
+    dn[:, :, 11:] = 1e-5                    # padding entries of the denoising groups: zero boxes, every point on pixel (0, 0)
+    dn = dn.view(B, 192, 4)
     ref = torch.cat([dn, torch.cat([torch.rand(B, 300, 2, device=cuda), torch.rand(B, 300, 2, device=cuda) * 0.3 + 0.02], -1)], 1).contiguous()
     off = (torch.randn(B, Lq, H, 12, 2, device=cuda) * 0.5).bfloat16()
     lg = torch.randn(B, Lq, H, 12, device=cuda).bfloat16()
@@ -218,3 +221,32 @@ def test_value_gradient_accumulate_modes(cuda, monkeypatch):
         for (a0, b0), (a1, b1) in zip(small0, other): # (two lane mappings: fp32 sums in another order, bf16 results 1 ulp apart)
             assert (a0 - a1).abs().max() <= 1e-2 * a0.abs().max() and (b0 - b1).abs().max() <= 1e-2 * b0.abs().max()
     assert torch.equal(small3[0][0], run(3)[1][0][0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("D,H,B,Lq", [(32, 8, 1, 23), (16, 4, 2, 45), (64, 2, 2, 7), (32, 3, 3, 41)])
+def test_backward_with_coinciding_rows(cuda, dtype, D, H, B, Lq):
+    """The backward kernels sum contributions that meet in one value row in registers before the atomic (over the points of a
+    level inside a task, over the tasks of a wave at the end of a level).  Rows that coincide on purpose: runs of consecutive
+    queries with all points on pixel (0, 0) of every level (the padding entries of the denoising groups), runs that continue
+    across an image boundary (same row index, different image: must NOT merge), identical neighbours at other pixels, a last
+    workgroup that is only partly filled, row 0 of image 0 with B = 1."""
+    value, loc, w, go, shapes, points = helpers.make_msda_case(7 * D + Lq, B=B, Lq=Lq, H=H, D=D)
+    loc[:, Lq // 2:, :, :, :] = 1e-5                         # second half of every image: everything on the corner pixel
+    loc[:, 3:7] = loc[:, 3:4]                                # four identical neighbours somewhere else
+    q1 = min(8, Lq - 1)
+    loc[:, q1, :, :, :] = loc[:, q1, :, :1, :]               # one query whose points all coincide
+    if B > 1:
+        loc[1, :2] = 1e-5                                    # the run of image 0 continues into image 1
+    if dtype == torch.bfloat16:
+        value = torch.tensor(value).bfloat16().float().numpy()
+        go = torch.tensor(go).bfloat16().float().numpy()
+    out, gv, gl, gw = _run(value, loc, w, go, shapes, points, cuda, dtype)
+    rv, rl, rw = np_ref.msda_backward(value, shapes, loc, w, points, go)
+    if dtype == torch.float32:
+        np.testing.assert_allclose(gv, rv, rtol=1e-4, atol=2e-5 * max(1.0, np.abs(rv).max()))
+        np.testing.assert_allclose(gw, rw, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(gl, rl, rtol=1e-4, atol=3e-4)
+    else:       # f16 accumulator + bf16 result: hot rows collect B-independent sums of ~Lq / 2 * P addends
+        assert np.abs(gv - rv).max() <= 1e-2 * np.abs(rv).max()
+        assert np.abs(gw - rw).max() <= 2e-2 * max(1.0, np.abs(rw).max())

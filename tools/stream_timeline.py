@@ -1,0 +1,75 @@
+"""Per-stream device timeline of one steady-state train step (torch.profiler chrome trace): busy time of every HIP stream, the
+union, the idle time of the main chain, and a 1-ms histogram of the occupancy of the two streams - where the step is bound by
+the device chain, where by the host (the main stream idles while the host is still enqueueing) and where the side stream
+(weight gradients) is the longer one.   GPU box only:   python tools/stream_timeline.py [--ms 1.0]"""
+import argparse, json, os, sys, tempfile, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+import bench
+from custom_d_fine_amd.dl.synthetic import make_batch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--ms", type=float, default=1.0)
+ap.add_argument("--warmup", type=int, default=5)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+step = bench.build_step("m", 640, dev, torch.bfloat16)
+images, targets = make_batch(32, 640, seed=42, device=dev)
+for _ in range(a.warmup):
+    step(images, targets)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    step(images, targets)
+    torch.cuda.synchronize()
+path = os.path.join(tempfile.mkdtemp(), "trace.json")
+prof.export_chrome_trace(path)
+ev = [e for e in json.load(open(path))["traceEvents"]
+      if e.get("ph") == "X" and e.get("cat") in ("kernel", "gpu_memcpy", "gpu_memset")]
+ev.sort(key=lambda e: e["ts"])
+t0 = ev[0]["ts"]
+t1 = max(e["ts"] + e["dur"] for e in ev)
+streams = collections.defaultdict(list)
+for e in ev:
+    streams[e["args"].get("stream", -1)].append((e["ts"] - t0, e["ts"] - t0 + e["dur"], e["name"]))
+
+
+def union(iv):
+    tot, end = 0.0, -1.0
+    for s, e, _ in sorted(iv):
+        if e > end:
+            tot += e - max(s, end)
+            end = e
+    return tot
+
+
+order = sorted(streams, key=lambda s: -union(streams[s]))
+main = order[0]
+print(f"device span of the step {(t1 - t0) / 1e3:.2f} ms, union busy {union([x for s in streams.values() for x in s]) / 1e3:.2f} ms")
+for s in order:
+    iv = streams[s]
+    print(f"  stream {s}: {len(iv):5d} events, busy {union(iv) / 1e3:7.2f} ms, first {iv[0][0] / 1e3:6.2f} ms, last {max(e for _, e, _ in iv) / 1e3:6.2f} ms")
+nb = int((t1 - t0) / 1e3 / a.ms) + 1
+occ = {s: [0.0] * nb for s in order[:3]}
+for s in order[:3]:
+    for b, e, _ in streams[s]:
+        i = int(b / 1e3 / a.ms)
+        while b < e and i < nb:
+            hi = min(e, (i + 1) * a.ms * 1e3)
+            occ[s][i] += hi - b
+            b, i = hi, i + 1
+print(f"\noccupancy per {a.ms} ms bin (percent busy): bin start | " + " | ".join(f"stream {s}" for s in order[:3]) + " | longest kernel of the main stream in the bin")
+for i in range(nb):
+    lo, hi = i * a.ms * 1e3, (i + 1) * a.ms * 1e3
+    names = [(e - b, n) for b, e, n in streams[main] if b < hi and e > lo]
+    top = max(names)[1][:60] if names else "-"
+    print(f"{i * a.ms:6.1f} | " + " | ".join(f"{100 * occ[s][i] / (a.ms * 1e3):5.0f}" for s in order[:3]) + f" | {top}")
+# idle windows of the main stream (> 20 us) and what the host was doing
+gaps, end = [], 0.0
+for b, e, n in sorted(streams[main]):
+    if b - end > 20 and end > 0:
+        gaps.append((b - end, end, n))
+    end = max(end, e)
+print(f"\nmain stream idle windows > 20 us: {len(gaps)} totalling {sum(g[0] for g in gaps) / 1e3:.2f} ms")
+for g in sorted(gaps, reverse=True)[:25]:
+    print(f"  {g[0]:8.1f} us at t = {g[1] / 1e3:6.2f} ms, before {g[2][:80]}")
