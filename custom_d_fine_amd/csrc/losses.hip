@@ -270,7 +270,39 @@ __global__ __launch_bounds__(kLT) void fgl_kernel(const T *__restrict__ pred, Vi
     if (threadIdx.x == 0) unsafeAtomicAdd(out, s);
 }
 
+// Backward of the fused head losses: the closed-form gradients of the forward pass scaled by the upstream gradient g[5] of
+// the (vfl, l1, giou, fgl, ddf) vector, in place and in ONE launch (the torch composition was 5 multiplies, 2 adds and the
+// 0-d casts: ~8 launches per head, 11 heads, in the host-bound stretch between the matcher sync and the decoder's backward):
+//   grad_logits *= g[0];   grad_l1 = grad_l1 * g[1] + grad_giou * g[2];   grad_fgl = grad_fgl * g[3] + grad_ddf * g[4]
+template <typename T>
+__global__ __launch_bounds__(256) void head_grads_scale_kernel(const float *__restrict__ g, T *__restrict__ gl, int64_t nl,
+                                                               float *__restrict__ gb, const float *__restrict__ gg, int64_t nb,
+                                                               T *__restrict__ gf, const T *__restrict__ gd, int64_t nc) {
+    const float g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], g4 = g[4];
+    const int64_t step = (int64_t)gridDim.x * 256, t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (int64_t i = t * 4; i + 3 < nl; i += step * 4) {
+        const f32x4 v = Vec4<T>::load(gl + i);
+        Vec4<T>::store(gl + i, {v.x * g0, v.y * g0, v.z * g0, v.w * g0});
+    }
+    for (int64_t i = (nl & ~(int64_t)3) + t; i < nl; i += step) store_f(gl + i, load_f(gl + i) * g0);
+    for (int64_t i = t; i < nb; i += step) gb[i] = gb[i] * g1 + gg[i] * g2;
+    if (gd) {
+        for (int64_t i = t * 4; i + 3 < nc; i += step * 4) {
+            const f32x4 a = Vec4<T>::load(gf + i), b = Vec4<T>::load(gd + i);
+            Vec4<T>::store(gf + i, {a.x * g3 + b.x * g4, a.y * g3 + b.y * g4, a.z * g3 + b.z * g4, a.w * g3 + b.w * g4});
+        }
+        for (int64_t i = (nc & ~(int64_t)3) + t; i < nc; i += step) store_f(gf + i, load_f(gf + i) * g3 + load_f(gd + i) * g4);
+    } else {
+        for (int64_t i = t * 4; i + 3 < nc; i += step * 4) {
+            const f32x4 a = Vec4<T>::load(gf + i);
+            Vec4<T>::store(gf + i, {a.x * g3, a.y * g3, a.z * g3, a.w * g3});
+        }
+        for (int64_t i = (nc & ~(int64_t)3) + t; i < nc; i += step) store_f(gf + i, load_f(gf + i) * g3);
+    }
+}
+
 }  // namespace dfine
+
 
 using namespace dfine;
 
@@ -364,6 +396,25 @@ int dfine_head_losses(
                                    s_fgl, (uint16_t *)grad_corners_fgl, out + 3);
         }
     }
+    return check_launch();
+}
+
+int dfine_head_grads_scale(const float *g, void *grad_logits, int64_t n_logits, float *grad_l1, const float *grad_giou,
+                           int64_t n_box, void *grad_corners_fgl, const void *grad_corners_ddf, int64_t n_corners, int dtype,
+                           void *stream) {
+    if (!g || !grad_logits || !grad_l1 || !grad_giou || n_logits < 0 || n_box < 0 || n_corners < 0 ||
+        (n_corners > 0 && !grad_corners_fgl) || (dtype != DFINE_F32 && dtype != DFINE_BF16))
+        return DFINE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t work = (n_logits + n_corners) / 4 + n_box;
+    if (work == 0 && n_logits == 0 && n_corners == 0) return DFINE_OK;
+    const int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (work + 255) / 256));
+    if (dtype == DFINE_F32)
+        hipLaunchKernelGGL(head_grads_scale_kernel<float>, dim3(grid), dim3(256), 0, st, g, (float *)grad_logits, n_logits,
+                           grad_l1, grad_giou, n_box, (float *)grad_corners_fgl, (const float *)grad_corners_ddf, n_corners);
+    else
+        hipLaunchKernelGGL(head_grads_scale_kernel<uint16_t>, dim3(grid), dim3(256), 0, st, g, (uint16_t *)grad_logits, n_logits,
+                           grad_l1, grad_giou, n_box, (uint16_t *)grad_corners_fgl, (const uint16_t *)grad_corners_ddf, n_corners);
     return check_launch();
 }
 

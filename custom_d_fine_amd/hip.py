@@ -47,6 +47,7 @@ _SIGNATURES = {
     "dfine_head_losses": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _P, _I,
                                    _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P,
                                    _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfine_head_grads_scale": (c_int, [_P, _P, _L, _P, _P, _L, _P, _P, _L, _I, _P]),
     "dfine_grad_sqnorm": (c_int, [_P, _L, _F, _P, _P]),
     "dfine_grad_sqnorm_ws_floats": (_L, []),
     "dfine_adamw_ema_step": (c_int, [_P, _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _I, _F, _F, _F, _P]),
@@ -628,6 +629,13 @@ def head_losses(logits, boxes, corners, ref, teacher_corners, teacher_logits, cl
         _ptr(scratch_f[m_cls + m_box:]), _ptr(out), _dtype_code(logits), B, Q, C, _stream()),
         "dfine_head_losses")
     return out, g_logits, g_box[0], g_box[1], g_fgl, g_ddf
+
+
+def head_grads_scale(g, g_logits, g_l1, g_giou, g_fgl, g_ddf):
+    """In-place backward scaling of the gradients head_losses left behind (dfine_head_grads_scale): g = d / d out[5]."""
+    _check(_lib.dfine_head_grads_scale(
+        _ptr(g), _ptr(g_logits), g_logits.numel(), _ptr(g_l1), _ptr(g_giou), g_l1.numel(), _ptr(g_fgl), _ptr(g_ddf),
+        0 if g_fgl is None else g_fgl.numel(), _dtype_code(g_logits), _stream()), "dfine_head_grads_scale")
 
 
 # ------------------------------------------------------------------------------------- optimizer

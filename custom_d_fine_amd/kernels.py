@@ -293,6 +293,9 @@ def fdr_decode(corners, ref_boxes, wtable, reg_scale):
 # =============================================================================================
 # A13/A14  set-criterion losses of one prediction head (values + gradients in one launch group)
 # =============================================================================================
+HEAD_GRADS_FUSED = True       # backward of the fused head losses as one in-place launch (tools/ab_step.py kernels.HEAD_GRADS_FUSED)
+
+
 class _HeadLosses(torch.autograd.Function):
     """-> tensor[5] = (vfl, l1, giou, fgl, ddf), already weighted and normalised.  The kernels
     compute the closed-form gradients in the forward pass; backward only scales them."""
@@ -322,6 +325,11 @@ class _HeadLosses(torch.autograd.Function):
     def backward(ctx, g):
         g_logits, g_l1, g_giou, g_fgl, g_ddf = ctx.grads
         ctx.grads = None
+        if (HEAD_GRADS_FUSED and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and ctx.dtypes[0] == torch.float32
+                and (g_fgl is None or ctx.dtypes[1] == g_fgl.dtype)):
+            # one in-place launch instead of ~8 element-wise ones per head (the saved gradients are used once)
+            _hip().head_grads_scale(g, g_logits, g_l1, g_giou, g_fgl, g_ddf)
+            return g_logits, g_l1, g_fgl, None, None, None, None, None, None, None, None
         d_logits = g_logits * g[0].to(g_logits.dtype)
         d_boxes = g_l1 * g[1] + g_giou * g[2]
         d_corners = None

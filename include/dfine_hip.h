@@ -234,6 +234,16 @@ int dfine_head_losses(
     int *map_cls, int *map_box, float *wrow, float *out, int dtype, int B, int Q, int C,
     void *stream);
 
+/* Backward of dfine_head_losses (reference: autograd through loss_labels_vfl / loss_boxes / loss_local,
+ * src/d_fine/dfine_criterion.py:92-237): scales the gradients the forward call left behind by the upstream gradient
+ * g[5] (device, f32) of its `out` vector, in place, one launch:
+ *   grad_logits[n_logits] (dtype) *= g[0];   grad_l1[n_box] = grad_l1 * g[1] + grad_giou * g[2];
+ *   grad_corners_fgl[n_corners] (dtype) = grad_corners_fgl * g[3] + grad_corners_ddf * g[4]   (ddf NULL: the first term;
+ *   n_corners 0: a head without the local losses). */
+int dfine_head_grads_scale(const float *g, void *grad_logits, int64_t n_logits, float *grad_l1,
+                           const float *grad_giou, int64_t n_box, void *grad_corners_fgl,
+                           const void *grad_corners_ddf, int64_t n_corners, int dtype, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * A16  Optimizer step on flat fp32 buffers (parameters are views into them).
  * Replaces clip_grad_norm_ + AdamW.step + zero_grad + ModelEMA.update

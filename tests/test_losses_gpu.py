@@ -80,3 +80,27 @@ def test_fused_equals_torch_composition_on_strided_views(cuda):
     assert torch.allclose(g_fused[0], wide_logits.grad, rtol=1e-3, atol=1e-6)
     assert torch.allclose(g_fused[1], wide_corners.grad, rtol=1e-3, atol=1e-6)
     assert (g_fused[0][:, :16] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_ddf,with_corners", [(True, True), (False, True), (False, False)])
+def test_head_grads_scale_matches_torch_composition(cuda, dtype, with_ddf, with_corners):
+    """dfine_head_grads_scale (the one-launch backward of the fused head losses) against the element-wise composition it
+    replaces; sizes that are not multiples of the 4-element vectors."""
+    from custom_d_fine_amd import hip
+    torch.manual_seed(3)
+    g = torch.randn(5, device=cuda)
+    nl, nb, nc = 2 * 37 * 7 + 1, 2 * 37 * 4, 2 * 37 * 132 + 3
+    gl = torch.randn(nl, device=cuda).to(dtype)
+    l1, gi = torch.randn(nb, device=cuda), torch.randn(nb, device=cuda)
+    gf = torch.randn(nc, device=cuda).to(dtype) if with_corners else None
+    gd = torch.randn(nc, device=cuda).to(dtype) if with_ddf else None
+    want_l = gl.float() * g[0]
+    want_b = l1 * g[1] + gi * g[2]
+    want_c = None if gf is None else gf.float() * g[3] + (gd.float() * g[4] if gd is not None else 0)
+    hip.head_grads_scale(g, gl, l1, gi, gf, gd)
+    tol = 1e-6 if dtype == torch.float32 else 8e-3
+    assert (gl.float() - want_l).abs().max() <= tol * want_l.abs().max()
+    assert (l1 - want_b).abs().max() <= 1e-6 * want_b.abs().max()
+    if gf is not None:
+        assert (gf.float() - want_c).abs().max() <= tol * want_c.abs().max()
