@@ -139,6 +139,26 @@ if _lib.dfine_abi_version() != ABI_VERSION:
 
 EXPORTED = tuple(_SIGNATURES)
 
+
+class _PureQueries:
+    """Memoized front of the library's size / split-count / capability queries (pure functions of a few integers that the
+    launch wrappers ask for on every call: ~400 ctypes round trips per train step)."""
+
+    def __getattr__(self, name):
+        fn, cache = getattr(_lib, name), {}
+
+        def call(*args):
+            r = cache.get(args)
+            if r is None:
+                r = cache[args] = fn(*args)
+            return r
+
+        setattr(self, name, call)
+        return call
+
+
+_PURE = _PureQueries()
+
 # ---- optional per-kernel timing (bench.py roofline leg): HIP events recorded on the launch
 # stream (torch's current stream) right around the launch of the named entry points, together with the
 # algorithmic work (FLOPs or bytes) of the launch.
@@ -552,7 +572,7 @@ def bn2_supported(x):
     if x.dtype != torch.bfloat16 or x.dim() != 4:
         return False
     B, C = x.shape[0], x.shape[1]
-    return bool(_lib.dfine_bn2_supported(B, C, x.numel() // max(B * C, 1)))
+    return bool(_PURE.dfine_bn2_supported(B, C, x.numel() // max(B * C, 1)))
 
 
 def bn2_act_forward(x1, x2, residual, bn1, bn2, act):
@@ -562,7 +582,7 @@ def bn2_act_forward(x1, x2, residual, bn1, bn2, act):
     HW = x1.numel() // max(B * C, 1)
     y = torch.empty_like(x1)
     saved = torch.empty(8, C, device=x1.device, dtype=torch.float32)
-    ws = _bn_workspace(x1.device, int(_lib.dfine_bn2_ws_floats(B, C, HW)))
+    ws = _bn_workspace(x1.device, int(_PURE.dfine_bn2_ws_floats(B, C, HW)))
     _check(_lib.dfine_bn2_act_fwd(_ptr(x1), _ptr(x2), _ptr(residual), _ptr(y), _ptr(bn1[0]), _ptr(bn1[1]), _ptr(bn1[2]),
                                   _ptr(bn1[3]), _ptr(bn2[0]), _ptr(bn2[1]), _ptr(bn2[2]), _ptr(bn2[3]), _ptr(saved), _ptr(ws),
                                   B, C, HW, _ACT[act], float(bn1[4]), float(bn1[5]), float(bn2[4]), float(bn2[5]), _stream()),
@@ -576,7 +596,7 @@ def bn2_act_backward(x1, x2, dy, saved, act, need_affine=(True, True)):
     dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
     dev = x1.device
     g = [torch.empty(C, device=dev, dtype=torch.float32) if need_affine[i // 2] else None for i in range(4)]
-    ws = _bn_workspace(dev, int(_lib.dfine_bn2_ws_floats(B, C, HW)))
+    ws = _bn_workspace(dev, int(_PURE.dfine_bn2_ws_floats(B, C, HW)))
     _check(_lib.dfine_bn2_act_bwd(_ptr(x1), _ptr(x2), _ptr(dy), _ptr(dx1), _ptr(dx2), _ptr(saved), _ptr(g[0]), _ptr(g[1]),
                                   _ptr(g[2]), _ptr(g[3]), _ptr(ws), B, C, HW, _ACT[act], _stream()), "dfine_bn2_act_bwd")
     return dx1, dx2, g[0], g[1], g[2], g[3]
@@ -778,19 +798,19 @@ def conv1x1_seg_wgrad(x_parts, dy, partials=False):
     B, _, H, W = x_parts[0].shape
     cin, cout = sum(t.shape[1] for t in x_parts), dy.shape[1]
     dw = None if partials else torch.empty(cout, cin, 1, 1, device=dy.device, dtype=torch.float32)
-    ws = torch.empty(int(_lib.dfine_conv_wgrad_ws_floats(B, cin, cout, H, W, 1)), device=dy.device, dtype=torch.float32)
+    ws = torch.empty(int(_PURE.dfine_conv_wgrad_ws_floats(B, cin, cout, H, W, 1)), device=dy.device, dtype=torch.float32)
     xp, xc, xb = _seg_arrays(x_parts)
     if partials and _side_ok():
         st = _side_fork(dy.device)
         _check(_lib.dfine_conv1x1_seg_wgrad_bf16(xp, xc, xb, len(x_parts), _ptr(dy), None, _ptr(ws), B, cin, cout, H, W,
                                                  st.cuda_stream), "dfine_conv1x1_seg_wgrad_bf16")
         _SIDE_LIVE.append((x_parts, dy, ws))
-        return ws, (int(_lib.dfine_conv_wgrad_splits(B, cin, cout, H, W, 1)), cout, cin, 1, _p16(cout), _p16(cin))
+        return ws, (int(_PURE.dfine_conv_wgrad_splits(B, cin, cout, H, W, 1)), cout, cin, 1, _p16(cout), _p16(cin))
     with _timed("conv1x1_wgrad", 2.0 * B * H * W * cin * cout, io=2.0 * B * H * W * (cin + cout) + 4.0 * cin * cout):
         _check(_lib.dfine_conv1x1_seg_wgrad_bf16(xp, xc, xb, len(x_parts), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W,
                                                  _stream()), "dfine_conv1x1_seg_wgrad_bf16")
     if partials:
-        return ws, (int(_lib.dfine_conv_wgrad_splits(B, cin, cout, H, W, 1)), cout, cin, 1, _p16(cout), _p16(cin))
+        return ws, (int(_PURE.dfine_conv_wgrad_splits(B, cin, cout, H, W, 1)), cout, cin, 1, _p16(cout), _p16(cin))
     return dw
 
 
@@ -876,29 +896,29 @@ def conv_wgrad_bf16(x, dy, ks, partials=False):
     B, cin, H, W = x.shape
     cout = dy.shape[1]
     dw = None if partials else torch.empty(cout, cin, ks, ks, device=x.device, dtype=torch.float32)
-    ws = torch.empty(int(_lib.dfine_conv_wgrad_ws_floats(B, cin, cout, H, W, ks)), device=x.device, dtype=torch.float32)
+    ws = torch.empty(int(_PURE.dfine_conv_wgrad_ws_floats(B, cin, cout, H, W, ks)), device=x.device, dtype=torch.float32)
     if partials and ks == 1 and _CW_GROUP and (H * W) % 8 == 0:
         # registered only: every 1x1 weight gradient of a flush runs in one launch (linear_wgrad_flush -> dfine_conv_wgrad1_group)
         _CW_PENDING.append((x, dy, ws, B, cin, cout, H * W))
         if len(_CW_PENDING) >= _SIDE_GROUP_AT and _side_ok():
             _flush_conv_group(True)          # ... or in a few, on the side stream while backward goes on
-        return ws, (int(_lib.dfine_conv_wgrad_splits(B, cin, cout, H, W, ks)), cout, cin, 1, _p16(cout), _p16(cin))
+        return ws, (int(_PURE.dfine_conv_wgrad_splits(B, cin, cout, H, W, ks)), cout, cin, 1, _p16(cout), _p16(cin))
     if partials and _side_ok():
         if st is None:
             st = _side_fork(x.device)
         _check(_lib.dfine_conv_wgrad_bf16(_ptr(x), _ptr(dy), None, _ptr(ws), B, cin, cout, H, W, ks, st.cuda_stream), "dfine_conv_wgrad_bf16")
         _SIDE_LIVE.append((x, dy, ws))
-        return ws, (int(_lib.dfine_conv_wgrad_splits(B, cin, cout, H, W, ks)), cout, cin, ks * ks, _p16(cout), _p16(cin))
+        return ws, (int(_PURE.dfine_conv_wgrad_splits(B, cin, cout, H, W, ks)), cout, cin, ks * ks, _p16(cout), _p16(cin))
     with _timed(f"conv{ks}x{ks}_wgrad", 2.0 * B * H * W * cin * cout * ks * ks, io=2.0 * B * H * W * (cin + cout) + 4.0 * cin * cout * ks * ks):
         _check(_lib.dfine_conv_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ks, _stream()),
                "dfine_conv_wgrad_bf16")
     if partials:
-        return ws, (int(_lib.dfine_conv_wgrad_splits(B, cin, cout, H, W, ks)), cout, cin, ks * ks, _p16(cout), _p16(cin))
+        return ws, (int(_PURE.dfine_conv_wgrad_splits(B, cin, cout, H, W, ks)), cout, cin, ks * ks, _p16(cout), _p16(cin))
     return dw
 
 
 def multi_wgrad_reduce_blocks(splits, elems):
-    return int(_lib.dfine_multi_wgrad_reduce_blocks(int(splits), int(elems)))
+    return int(_PURE.dfine_multi_wgrad_reduce_blocks(int(splits), int(elems)))
 
 
 def multi_wgrad_reduce(table, n_entries, max_blocks, io=0.0, side=False):
@@ -1086,7 +1106,7 @@ def linear_wgrad_partials(x2d, dy2d):
     front of every deferred reduction - runs all registered problems as one launch (dfine_linear_wgrad_group)."""
     M, K = x2d.shape
     N = dy2d.shape[1]
-    ws = torch.empty(int(_lib.dfine_linear_wgrad_ws_floats(M, N, K)), device=x2d.device, dtype=torch.float32)
+    ws = torch.empty(int(_PURE.dfine_linear_wgrad_ws_floats(M, N, K)), device=x2d.device, dtype=torch.float32)
     if _LW_GROUP:
         _LW_PENDING.append((x2d, dy2d, ws, M, N, K))
         if len(_LW_PENDING) >= 2 * _SIDE_GROUP_AT and _side_ok():
@@ -1095,7 +1115,7 @@ def linear_wgrad_partials(x2d, dy2d):
         with _timed("linear_wgrad", 2.0 * M * N * K, io=2.0 * M * (N + K) + 4.0 * N * K):
             _check(_lib.dfine_linear_wgrad_bf16(_ptr(x2d), _ptr(dy2d), None, None, _ptr(ws), M, N, K, _stream()),
                    "dfine_linear_wgrad_bf16")
-    splits = int(_lib.dfine_linear_wgrad_splits(M, N, K))
+    splits = int(_PURE.dfine_linear_wgrad_splits(M, N, K))
     np16, cp16 = _p16(N), _p16(K)
     return ws, (splits, N, K, 1, np16, cp16), (splits, N, 1, 1, np16, 1), splits * np16 * cp16
 
@@ -1175,7 +1195,7 @@ def linear_wgrad_bf16(x2d, dy2d, with_bias=False, dw=None, db=None):
     M, K = x2d.shape
     N = dy2d.shape[1]
     dev = x2d.device
-    need = int(_lib.dfine_linear_wgrad_ws_floats(M, N, K))
+    need = int(_PURE.dfine_linear_wgrad_ws_floats(M, N, K))
     key = (dev.index, _stream())
     ws = _LW_WS.get(key)
     if ws is None or ws.numel() < need:
@@ -1194,7 +1214,7 @@ def linear_wgrad_bf16(x2d, dy2d, with_bias=False, dw=None, db=None):
 
 # ------------------------------------------------------------------------------------- HGNetv2 stem
 def stem_supported(cin, cout, ks, stride):
-    return bool(_lib.dfine_stem_supported(cin, cout, ks, stride))
+    return bool(_PURE.dfine_stem_supported(cin, cout, ks, stride))
 
 
 def stem_pack_weights(weight_f32, mode):
@@ -1233,7 +1253,7 @@ def stem_wgrad(x, dy, ks, stride, pad, side=False):
     """side: launched on the side stream (see dwconv_backward)."""
     B, cin, H, W = x.shape
     _, cout, ho, wo = dy.shape
-    need = int(_lib.dfine_stem_wgrad_ws_floats(B, cin, cout, ks, ho, wo))
+    need = int(_PURE.dfine_stem_wgrad_ws_floats(B, cin, cout, ks, ho, wo))
     side = side and _side_ok()
     st = _side_fork(x.device) if side else None
     key = (x.device.index, st.cuda_stream if side else _stream())
@@ -1278,7 +1298,7 @@ def stem_wgrad2(xa, xb, dy, ks, stride, pad, side=False):
     B, ca, H, W = xa.shape
     cin = ca + xb.shape[1]
     _, cout, ho, wo = dy.shape
-    need = int(_lib.dfine_stem_wgrad_ws_floats(B, cin, cout, ks, ho, wo))
+    need = int(_PURE.dfine_stem_wgrad_ws_floats(B, cin, cout, ks, ho, wo))
     side = side and _side_ok()
     st = _side_fork(xa.device) if side else None
     key = (xa.device.index, st.cuda_stream if side else _stream())
@@ -1341,7 +1361,7 @@ def ln_fused_backward(mode, a, b, gate, weight, mean, rstd, dy, clampv, need_a, 
         # two tensors, not two rows of one: AccumulateGrad adopts a whole tensor but copies a view
         dw = torch.empty(D, device=a.device, dtype=torch.float32)
         dbias = torch.empty(D, device=a.device, dtype=torch.float32)
-        ws = torch.empty(int(_lib.dfine_ln_fused_bwd_ws_floats(rows, D)), device=a.device, dtype=torch.float32)
+        ws = torch.empty(int(_PURE.dfine_ln_fused_bwd_ws_floats(rows, D)), device=a.device, dtype=torch.float32)
     _check(_lib.dfine_ln_fused_bwd(mode, _ptr(a), _dt(a), _ptr(b), _dt(b), _ptr(gate), _dt(gate), _ptr(weight), _ptr(mean),
                                    _ptr(rstd), _ptr(dy), float(clampv), _ptr(da), _ptr(db), _ptr(dg), _ptr(dw), _ptr(dbias),
                                    _ptr(ws), rows, D, _stream()), "dfine_ln_fused_bwd")
@@ -1355,7 +1375,7 @@ def groupnorm_forward(x, gamma, beta, groups, eps, relu):
     hw = x.numel() // max(B * C, 1)
     y = torch.empty_like(x)
     stat = torch.empty(B, groups, 2, device=x.device, dtype=torch.float32)
-    ws = torch.empty(int(_lib.dfine_groupnorm_ws_floats(B, C, groups)), device=x.device, dtype=torch.float32)
+    ws = torch.empty(int(_PURE.dfine_groupnorm_ws_floats(B, C, groups)), device=x.device, dtype=torch.float32)
     _check(_lib.dfine_groupnorm_fwd(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(stat), _ptr(ws), _dtype_code(x), B, C, hw,
                                     groups, float(eps), int(bool(relu)), _stream()), "dfine_groupnorm_fwd")
     return y, stat
