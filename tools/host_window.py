@@ -59,3 +59,13 @@ for e in top:
     if e.time_range.start - end > 60:
         print(f"  t = {(end - lo) / 1e3:6.2f} ms  {e.time_range.start - end:8.1f} us  before {e.name[:80]}")
     end = max(end, e.time_range.end)
+
+print("\ndevice kernels inside the window by name (count, total us):")
+dagg = collections.defaultdict(lambda: [0, 0.0])
+for e in gpu:
+    if e.time_range.start >= lo and e.time_range.start < first_bwd.time_range.start:
+        dagg[e.name[:110]][0] += 1
+        dagg[e.name[:110]][1] += e.time_range.end - e.time_range.start
+print(f"  {sum(v[0] for v in dagg.values())} launches")
+for k, (n, t) in sorted(dagg.items(), key=lambda kv: -kv[1][0])[:60]:
+    print(f"  {n:4d} x {t:9.1f} us  {k}")
