@@ -272,3 +272,47 @@ def test_deferred_reduction_with_repeated_module_and_accumulation(cuda):
     assert torch.equal(got, again)
     assert got.abs().max() > 0
     np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-6 * ref.abs().max().item())
+
+
+def test_bucket_all_reduces_start_in_one_fixed_order(cuda, monkeypatch):
+    """RCCL pairs collectives by call order: every rank must issue the bucket all-reduces over the same flat-gradient ranges
+    in the same order, whatever order its gradients arrive in and even when a parameter gets no gradient on this rank only
+    (a batch without targets skips the denoising branch).  A recorder stands in for the collective; the world is told to have
+    two ranks."""
+    from custom_d_fine_amd.dl import fused_optim as fo
+
+    torch.manual_seed(2)
+    net = nn.Sequential(*[nn.Linear(64, 64) for _ in range(6)]).to(cuda)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    monkeypatch.setattr(fo, "get_world_size", lambda: 2)
+    calls = []
+
+    class _Work:
+        def wait(self):
+            pass
+
+    def fake_all_reduce(t, async_op=False):
+        calls.append((t.data_ptr(), t.numel()))
+        return _Work()
+
+    monkeypatch.setattr(fo.dist, "all_reduce", fake_all_reduce)
+    fused = FusedAdamWEMA(net, opt, None, clip_max_norm=0.1, overlap=True, bucket_mb=64 * 65 * 4 * 2 / 2 ** 20)   # two layers per bucket
+    assert len(fused._buckets) >= 3
+    x = torch.randn(8, 64, device=cuda)
+
+    def run(skip):
+        calls.clear()
+        h = x
+        for i, layer in enumerate(net):
+            if i != skip:
+                h = layer(h)
+        h.sum().backward()
+        fused._collect_grads()
+        for p in net.parameters():
+            p.grad = None
+        return list(calls)
+
+    full = run(None)
+    assert len(full) == len(fused._buckets) and len(set(full)) == len(full)
+    for skip in (0, 2, 5):                     # a layer of the last / a middle / the first bucket gets no gradient
+        assert run(skip) == full
