@@ -41,14 +41,23 @@ struct View {            // [B, Q, inner] tensor view with unit inner stride
 
 // ---------------------------------------------------------------------------------------------
 // plan: int64 [3, M] = (image, query, target row).  boxes cxcywh.
+// One launch for both matchings of a head: blocks [0, nb_cls) walk the classification plan (IoU + map only), the others the
+// box plan (IoU, map, L1 / GIoU sums and gradients).  map[b * Q + q] = pair index + 1; 0 = unmatched (zero-filled).
 template <typename T>
 __global__ __launch_bounds__(kLT) void pair_box_kernel(
     const T *__restrict__ boxes, View bv, const float *__restrict__ tgt_boxes,
-    const int64_t *__restrict__ plan, int M, int Q, float *__restrict__ iou_out,
-    int *__restrict__ map, float *__restrict__ grad_l1, float *__restrict__ grad_giou,
-    float *__restrict__ out /* [0]+=l1 sum, [1]+=(1-giou) sum */, int with_loss, float s_l1, float s_giou) {
+    const int64_t *__restrict__ cls_plan, int M_cls, float *__restrict__ iou_cls, int *__restrict__ map_cls, int nb_cls,
+    const int64_t *__restrict__ box_plan, int M_box, float *__restrict__ iou_box, int *__restrict__ map_box, int Q,
+    float *__restrict__ grad_l1, float *__restrict__ grad_giou,
+    float *__restrict__ out /* [0]+=l1 sum, [1]+=(1-giou) sum */, float s_l1, float s_giou) {
     __shared__ float red[kLT / 64];
-    const int m = blockIdx.x * kLT + threadIdx.x;
+    const bool is_cls = (int)blockIdx.x < nb_cls;                       // uniform per block
+    const int64_t *__restrict__ plan = is_cls ? cls_plan : box_plan;
+    const int M = is_cls ? M_cls : M_box;
+    float *__restrict__ iou_out = is_cls ? iou_cls : iou_box;
+    int *__restrict__ map = is_cls ? map_cls : map_box;
+    const int with_loss = is_cls ? 0 : 1;
+    const int m = ((int)blockIdx.x - (is_cls ? 0 : nb_cls)) * kLT + threadIdx.x;
     float l1 = 0.f, lg = 0.f;
     if (m < M) {
         const int64_t b = plan[m], q = plan[M + m], t = plan[2 * M + m];
@@ -71,7 +80,7 @@ __global__ __launch_bounds__(kLT) void pair_box_kernel(
         const float hull = cw * ch;
         const float giou = iou - (hull - uni) / hull;
         if (iou_out) iou_out[m] = iou;
-        if (map) map[b * Q + q] = m;
+        if (map) map[b * Q + q] = m + 1;
         if (with_loss) {
             const float d0 = cx - tb.x, d1 = cy - tb.y, d2 = w - tb.z, d3 = h - tb.w;
             l1 = fabsf(d0) + fabsf(d1) + fabsf(d2) + fabsf(d3);
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(kLT) void vfl_kernel(const T *__restrict__ logits, 
         const uint32_t b = row / (uint32_t)Q, q = row - b * Q;
         const float x = load_f(logits + (int64_t)b * lv.sb + (int64_t)q * lv.sq + c);
         const float p = __builtin_amdgcn_rcpf(1.f + __expf(-x));
-        const int m = map[row];
+        const int m = map[row] - 1;
         float t = 0.f, w;
         if (m >= 0 && labels[plan[2 * M + m]] == c) { t = iou[m]; w = t; }
         else w = alpha * (gamma == 2.f ? p * p : __powf(p, gamma));
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(kLT) void row_weight_kernel(const T *__restrict__ t
                                                          int C, float *__restrict__ wrow) {
     const int row = blockIdx.x * kLT + threadIdx.x;
     if (row >= B * Q) return;
-    const int m = map[row];
+    const int m = map[row] - 1;
     if (m >= 0) { wrow[row] = iou[m]; return; }
     const int b = row / Q, q = row - b * Q;
     const T *p = tlogits + (int64_t)b * tv.sb + (int64_t)q * tv.sq;
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(kLT) void ddf_kernel(const T *__restrict__ pred, Vi
 #pragma unroll
         for (int j = 0; j < NB; ++j) { ps += __expf(pl[j] - pm); ts += __expf(tl[j] - tm); }
         const float plz = pm + __logf(ps), tlz = tm + __logf(ts);
-        const bool pos = map[row] >= 0;
+        const bool pos = map[row] > 0;
         const float coef = (pos ? c_pos : c_neg) * wrow[row];
         float kl = 0.f;
         T *gp = grad + ((int64_t)row * 4 + edge) * NB;
@@ -328,29 +337,32 @@ int dfine_head_losses(
     if ((M_cls > 0 && (!cls_plan || !iou_cls)) || (M_box > 0 && (!box_plan || !iou_box))) return DFINE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const size_t esz = dtype == DFINE_F32 ? 4 : 2;
-    // the host wrapper lays [out(8) | grad_l1 | grad_giou] and [map_cls | map_box] out back to back: two fills
-    // instead of five (each fill is its own queue packet, ~14 heads per step)
+    // the host wrapper lays [out(8) | grad_l1 | grad_giou | map_cls | map_box | (pad to 16 B) grad_corners_fgl] out back to back:
+    // ONE fill instead of six (each fill is its own queue packet, 11 heads per step, all in the host-paced stretch after the
+    // matcher sync); other layouts get their fills one by one
     const size_t nq = (size_t)B * Q;
-    if (grad_l1 == out + 8 && grad_giou == grad_l1 + nq * 4) {
-        (void)hipMemsetAsync(out, 0, sizeof(float) * (8 + nq * 8), st);
+    const size_t fgl_bytes = corners ? esz * nq * 4 * 33 : 0;
+    char *const o8 = reinterpret_cast<char *>(out);
+    const size_t maps_end = 32 + nq * 40;
+    const bool packed = reinterpret_cast<char *>(grad_l1) == o8 + 32 && grad_giou == grad_l1 + nq * 4 &&
+                        reinterpret_cast<char *>(map_cls) == o8 + 32 + nq * 32 && map_box == map_cls + nq &&
+                        (!corners || reinterpret_cast<char *>(grad_corners_fgl) == o8 + (maps_end + 15) / 16 * 16);
+    if (packed) {
+        (void)hipMemsetAsync(out, 0, corners ? (maps_end + 15) / 16 * 16 + fgl_bytes : maps_end, st);
     } else {
         (void)hipMemsetAsync(out, 0, 5 * sizeof(float), st);
         (void)hipMemsetAsync(grad_l1, 0, sizeof(float) * nq * 4, st);
         (void)hipMemsetAsync(grad_giou, 0, sizeof(float) * nq * 4, st);
-    }
-    if (map_box == map_cls + nq) {
-        (void)hipMemsetAsync(map_cls, 0xFF, sizeof(int) * nq * 2, st);
-    } else {
-        (void)hipMemsetAsync(map_cls, 0xFF, sizeof(int) * nq, st);
-        (void)hipMemsetAsync(map_box, 0xFF, sizeof(int) * nq, st);
+        (void)hipMemsetAsync(map_cls, 0, sizeof(int) * nq, st);
+        (void)hipMemsetAsync(map_box, 0, sizeof(int) * nq, st);
+        if (corners) (void)hipMemsetAsync(grad_corners_fgl, 0, fgl_bytes, st);
     }
     const View bv{b_sb, b_sq};
-    if (M_cls > 0)   // IoU of the classification matching (VFL soft labels)
-        hipLaunchKernelGGL(pair_box_kernel<float>, dim3((M_cls + kLT - 1) / kLT), dim3(kLT), 0, st, boxes, bv, tgt_boxes,
-                           cls_plan, M_cls, Q, iou_cls, map_cls, nullptr, nullptr, nullptr, 0, 0.f, 0.f);
-    if (M_box > 0)   // L1 / GIoU of the box matching (+ IoU weights of FGL / DDF)
-        hipLaunchKernelGGL(pair_box_kernel<float>, dim3((M_box + kLT - 1) / kLT), dim3(kLT), 0, st, boxes, bv, tgt_boxes,
-                           box_plan, M_box, Q, iou_box, map_box, grad_l1, grad_giou, out + 1, 1, s_l1, s_giou);
+    if (M_cls > 0 || M_box > 0) {   // IoU of the classification matching (VFL soft labels); L1 / GIoU of the box matching (+ IoU weights of FGL / DDF)
+        const int nb_cls = (M_cls + kLT - 1) / kLT, nb_box = (M_box + kLT - 1) / kLT;
+        hipLaunchKernelGGL(pair_box_kernel<float>, dim3(nb_cls + nb_box), dim3(kLT), 0, st, boxes, bv, tgt_boxes, cls_plan, M_cls,
+                           iou_cls, map_cls, nb_cls, box_plan, M_box, iou_box, map_box, Q, grad_l1, grad_giou, out + 1, s_l1, s_giou);
+    }
     const int64_t n = (int64_t)B * Q * C;
     if (n >= ((int64_t)1 << 31) - 2048 * kLT) return DFINE_E_BADARG;      // the kernels index the logits with 32 bits
     const int vb = (int)((n + kLT - 1) / kLT < 2048 ? (n + kLT - 1) / kLT : 2048);
@@ -381,7 +393,6 @@ int dfine_head_losses(
                                    temp, ddf_c_pos, ddf_c_neg, (uint16_t *)grad_corners_ddf, out + 4);
             }
         }
-        (void)hipMemsetAsync(grad_corners_fgl, 0, esz * (size_t)B * Q * 4 * 33, st);
         if (M_box > 0) {
             FglTable tab;
             for (int j = 0; j <= reg_max; ++j) tab.w[j] = wtable[j];

@@ -620,16 +620,22 @@ def head_losses(logits, boxes, corners, ref, teacher_corners, teacher_logits, cl
     dev = logits.device
     dt = logits.dtype
     m_cls, m_box = int(cls_plan.shape[1]), int(box_plan.shape[1])
-    zbuf = torch.empty(8 + 2 * B * Q * 4, device=dev, dtype=torch.float32)   # [out | grad_l1 | grad_giou]: one fill
+    # [out(8 f32) | grad_l1 | grad_giou | map_cls | map_box | pad to 16 B | grad_corners_fgl]: everything the call wants
+    # zeroed, back to back in one allocation - the library clears it with ONE fill (see dfine_head_losses)
+    nq = B * Q
+    maps_end = 32 + nq * 40
+    fgl_off = (maps_end + 15) // 16 * 16
+    nb = corners.shape[-1] if corners is not None else 0
+    zbytes = torch.empty(fgl_off + nq * nb * dt.itemsize, device=dev, dtype=torch.uint8)
+    zbuf = zbytes[:32 + nq * 32].view(torch.float32)
     out = zbuf[:5]
     g_box = zbuf[8:].view(2, B, Q, 4)
+    scratch_i = zbytes[32 + nq * 32: maps_end].view(torch.int32).view(2, nq)
     g_logits = torch.empty(B, Q, C, device=dev, dtype=dt)
     scratch_f = torch.empty(m_cls + m_box + B * Q, device=dev, dtype=torch.float32)
-    scratch_i = torch.empty(2, B * Q, device=dev, dtype=torch.int32)
     g_fgl = g_ddf = None
     if corners is not None:
-        nb = corners.shape[-1]
-        g_fgl = torch.empty(B, Q, nb, device=dev, dtype=dt)
+        g_fgl = zbytes[fgl_off:].view(dt).view(B, Q, nb)
         if teacher_corners is not None:
             g_ddf = torch.empty(B, Q, nb, device=dev, dtype=dt)
     lp, lsb, lsq = _view3(logits)

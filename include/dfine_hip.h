@@ -221,6 +221,9 @@ int dfine_bn2_act_bwd(const void *x1, const void *x2, const void *dy, void *dx1,
  *   outputs: out[5] = {vfl, l1, giou, fgl, ddf} (scaled);  grad_logits [B,Q,C] dtype;
  *   grad_l1, grad_giou [B,Q,4] f32;  grad_corners_fgl, grad_corners_ddf [B,Q,4*33] dtype.
  *   scratch: iou_cls [M_cls], iou_box [M_box] f32; map_cls, map_box [B*Q] i32; wrow [B*Q] f32.
+ *   The call zero-fills out, grad_l1, grad_giou, map_cls, map_box and grad_corners_fgl itself; when the caller lays them out
+ *   back to back - [out (8 floats) | grad_l1 | grad_giou | map_cls | map_box | pad to 16 bytes | grad_corners_fgl] - that is
+ *   ONE fill instead of six.
  */
 int dfine_head_losses(
     const void *logits, int64_t l_sb, int64_t l_sq, const float *boxes, int64_t b_sb, int64_t b_sq,
