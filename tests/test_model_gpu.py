@@ -347,9 +347,12 @@ def bf16_block_parity_table(cuda):
 
     results = {}
     try:
-        for mode in ("fp32", "hip", "aten"):
+        # ATen's bf16 composition is not reproducible from run to run (atomically accumulated MIOpen / at::batch_norm
+        # gradients: the worst BatchNorm weight gradient of one block moved between 6.2e-2 and 7.8e-2 over a dozen runs while the
+        # HIP path returned 8.32e-2 every time): its distance is taken as the largest of three runs
+        for mode in ("fp32", "hip", "aten", "aten2", "aten3"):
             for s in switches:
-                if mode == "aten":
+                if mode.startswith("aten"):
                     os.environ[s] = "0"
                 else:
                     os.environ.pop(s, None)
@@ -368,12 +371,14 @@ def bf16_block_parity_table(cuda):
     for n, _ in blocks:
         y0, gx0, gp0 = results[("fp32", n)]
         row = {}
-        for mode in ("hip", "aten"):
+        for mode in ("hip", "aten", "aten2", "aten3"):
             y1, gx1, gp1 = results[(mode, n)]
             assert gp0.keys() == gp1.keys(), (n, mode)
             wk, wp = max(((k, one_minus_cos(gp0[k], gp1[k])) for k in gp0 if gp0[k].numel() > 16 and gp0[k].abs().max() > 0),
                          key=lambda t: t[1], default=("", 0.0))
             row[mode] = (one_minus_cos(y0, y1), one_minus_cos(gx0, gx1), wp, wk)
+        reps = [row.pop("aten2"), row.pop("aten3"), row["aten"]]
+        row["aten"] = (max(r[0] for r in reps), max(r[1] for r in reps), max(r[2] for r in reps), row["aten"][3])
         table[n] = row
     return table
 
