@@ -356,6 +356,8 @@ __global__ __launch_bounds__(256) void multi_cast_bf16_t_kernel(const int64_t *_
     }
 }
 
+constexpr float kPosClamp = 10.f;       // act 4: the decoder's clamp of the query position embedding (ref dfine_decoder.py:466)
+
 // dpre = dy * act'(.) for the fused-epilogue activations, from the saved OUTPUT y for ReLU (y > 0) and from the saved
 // pre-activation z for GELU / SiLU.  bf16 in / out, 8 elements per thread.
 template <int ACT>
@@ -370,7 +372,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const uint16_t *__restrict
             float g0 = __uint_as_float(dw[j] << 16), g1 = __uint_as_float(dw[j] & 0xffff0000u);
             const float z0 = __uint_as_float(rw[j] << 16), z1 = __uint_as_float(rw[j] & 0xffff0000u);
             if (ACT == 1) { g0 = z0 > 0.f ? g0 : 0.f; g1 = z1 > 0.f ? g1 : 0.f; }
-            else if (ACT == 2) {
+            else if (ACT == 4) {                        // clamp(z, -10, 10): the gradient passes where -10 <= z <= 10 (ATen's rule)
+                g0 = (z0 >= -kPosClamp && z0 <= kPosClamp) ? g0 : 0.f; g1 = (z1 >= -kPosClamp && z1 <= kPosClamp) ? g1 : 0.f;
+            } else if (ACT == 2) {
                 const float c = 0.70710678118654752440f, k = 0.39894228040143267794f;       // 1/sqrt(2), 1/sqrt(2 pi)
                 g0 *= 0.5f * (1.f + erff(z0 * c)) + z0 * k * __expf(-0.5f * z0 * z0);
                 g1 *= 0.5f * (1.f + erff(z1 * c)) + z1 * k * __expf(-0.5f * z1 * z1);
@@ -392,8 +396,11 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const uint16_t *__restrict
         const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
         uint32_t o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            o[j] = pack_bf16x2(act_apply(__uint_as_float(dw[j] << 16), ACT), act_apply(__uint_as_float(dw[j] & 0xffff0000u), ACT));
+        for (int j = 0; j < 4; ++j) {
+            const float z0 = __uint_as_float(dw[j] << 16), z1 = __uint_as_float(dw[j] & 0xffff0000u);
+            if (ACT == 4) o[j] = pack_bf16x2(fminf(fmaxf(z0, -kPosClamp), kPosClamp), fminf(fmaxf(z1, -kPosClamp), kPosClamp));
+            else o[j] = pack_bf16x2(act_apply(z0, ACT), act_apply(z1, ACT));
+        }
         reinterpret_cast<uint4 *>(y)[i] = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
@@ -503,28 +510,30 @@ int dfine_multi_cast_bf16_t(const void *table, int n_entries, void *stream) {
 
 int dfine_act_fwd_bf16(const void *z, void *y, int64_t n, int act, void *stream) {
     if (n == 0) return DFINE_OK;
-    if (!z || !y || n < 0 || (n & 7) || act < 1 || act > 3) return DFINE_E_BADARG;
+    if (!z || !y || n < 0 || (n & 7) || act < 1 || act > 4) return DFINE_E_BADARG;
     const int64_t n8 = n / 8;
     int blocks = (int)((n8 + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
     if (act == 1) hipLaunchKernelGGL(act_fwd_kernel<1>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)z, (uint16_t *)y, n8);
     else if (act == 2) hipLaunchKernelGGL(act_fwd_kernel<2>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)z, (uint16_t *)y, n8);
-    else hipLaunchKernelGGL(act_fwd_kernel<3>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)z, (uint16_t *)y, n8);
+    else if (act == 3) hipLaunchKernelGGL(act_fwd_kernel<3>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)z, (uint16_t *)y, n8);
+    else hipLaunchKernelGGL(act_fwd_kernel<4>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)z, (uint16_t *)y, n8);
     return check_launch();
 }
 
 // out = dy * act'(ref): ref = saved output (act 1, ReLU) or saved pre-activation (act 2 GELU, 3 SiLU); bf16, n % 8 == 0
 int dfine_act_bwd_bf16(const void *dy, const void *ref, void *out, int64_t n, int act, void *stream) {
     if (n == 0) return DFINE_OK;
-    if (!dy || !ref || !out || n < 0 || (n & 7) || act < 1 || act > 3) return DFINE_E_BADARG;
+    if (!dy || !ref || !out || n < 0 || (n & 7) || act < 1 || act > 4) return DFINE_E_BADARG;
     const int64_t n8 = n / 8;
     int blocks = (int)((n8 + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
     if (act == 1) hipLaunchKernelGGL(act_bwd_kernel<1>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)dy, (const uint16_t *)ref, (uint16_t *)out, n8);
     else if (act == 2) hipLaunchKernelGGL(act_bwd_kernel<2>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)dy, (const uint16_t *)ref, (uint16_t *)out, n8);
-    else hipLaunchKernelGGL(act_bwd_kernel<3>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)dy, (const uint16_t *)ref, (uint16_t *)out, n8);
+    else if (act == 3) hipLaunchKernelGGL(act_bwd_kernel<3>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)dy, (const uint16_t *)ref, (uint16_t *)out, n8);
+    else hipLaunchKernelGGL(act_bwd_kernel<4>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)dy, (const uint16_t *)ref, (uint16_t *)out, n8);
     return check_launch();
 }
 

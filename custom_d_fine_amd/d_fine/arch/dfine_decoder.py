@@ -291,7 +291,7 @@ class TransformerDecoder(nn.Module):
         out_detach = prev_corners = 0
 
         for i, layer in enumerate(self.layers):
-            pos = query_pos_head(ref_detach).clamp(min=-10, max=10)
+            pos = kernels.clamp_pos(query_pos_head(ref_detach))          # .clamp(min=-10, max=10)
             if i >= self.eval_idx + 1 and self.layer_scale > 1:  # "wide" layers (dead at scale 1)
                 pos = F.interpolate(pos, scale_factor=self.layer_scale)
                 value = self.value_op(memory, None, pos.shape[-1], memory_mask, spatial_shapes)

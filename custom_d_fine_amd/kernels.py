@@ -1673,6 +1673,30 @@ class _LinearAct(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _ClampPos(torch.autograd.Function):
+    """clamp(x, -10, 10) of the decoder's query position embedding (ref dfine_decoder.py:466) as one launch each way: ATen's
+    ClampBackward1 is two compares, a logical and a multiply - 4 launches per decoder layer in the host-paced stretch of the
+    step."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return _hip().act_forward(x, 4)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return _hip().act_backward(dy.contiguous() if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16).contiguous(), x, 4)
+
+
+def clamp_pos(x):
+    """x.clamp(min=-10, max=10); bf16 CUDA tensors on the HIP element-wise kernels."""
+    if x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.numel() % 8 == 0 and x.numel() > 0 \
+            and torch.is_grad_enabled() and x.requires_grad:
+        return _ClampPos.apply(x)
+    return x.clamp(min=-10, max=10)
+
+
 _ACT_CODES = {None: 0, "none": 0, "relu": 1, "gelu": 2, "silu": 3, "swish": 3}
 
 

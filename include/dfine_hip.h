@@ -397,7 +397,9 @@ int dfine_multi_wgrad_reduce(const void *table, int n_entries, int max_blocks, v
  * (dfine_multi_cast_bf16_t: table rows {src fp32 [rows, cols] ptr, dst bf16 [cols, rows] ptr, rows, cols},
  * all shadows of a model in one launch); the weight / bias gradients are dfine_linear_wgrad_bf16.
  * dfine_act_fwd_bf16 / dfine_act_bwd_bf16: y = act(z) and d_pre = dy * act'(ref) (ref = saved output for
- * ReLU, saved pre-activation for GELU / SiLU), n % 8 == 0 elements.
+ * ReLU, saved pre-activation for GELU / SiLU), n % 8 == 0 elements.  These two also take act 4 = clamp(z, -10, 10), the
+ * clamp of the decoder's query position embedding (src/d_fine/arch/dfine_decoder.py:466; ref = saved input, the gradient
+ * passes where -10 <= z <= 10).
  */
 int dfine_linear_act_fwd(const void *x, const void *w, const float *bias, void *y, int M, int N, int K, int ldx,
                          int ldw, int ldy, int act, int out_f32, void *stream);

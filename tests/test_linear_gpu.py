@@ -44,3 +44,21 @@ def test_linear_function_matches_f_linear(cuda):
         F.linear(x, lin.weight, lin.bias).backward(go)
     for a, b in zip(g, (x.grad, lin.weight.grad, lin.bias.grad)):
         assert torch.allclose(a, b, rtol=2e-2, atol=2e-2 * b.abs().max().item())
+
+
+def test_clamp_pos_matches_aten_clamp(cuda):
+    """kernels.clamp_pos (the decoder's clamp of the query position embedding, one launch each way) against x.clamp(-10, 10)
+    and ATen's ClampBackward1: values beyond, inside and exactly on the bounds."""
+    from custom_d_fine_amd import kernels
+    torch.manual_seed(0)
+    x = (torch.randn(4, 123, 256, device=cuda) * 8).bfloat16()
+    x.view(-1)[:6] = torch.tensor([10.0, -10.0, 10.0625, -10.0625, 9.9375, -9.9375], device=cuda).bfloat16()
+    g = torch.randn(4, 123, 256, device=cuda).bfloat16()
+    a = x.clone().requires_grad_(True)
+    b = x.clone().requires_grad_(True)
+    ya, yb = kernels.clamp_pos(a), b.clamp(min=-10, max=10)
+    assert torch.equal(ya, yb)
+    ya.backward(g)
+    yb.backward(g)
+    assert torch.equal(a.grad, b.grad)
+    assert (a.grad.view(-1)[:2] == g.view(-1)[:2]).all() and (a.grad.view(-1)[2:4] == 0).all()
