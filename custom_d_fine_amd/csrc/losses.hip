@@ -7,13 +7,12 @@
 // weighting_function (src/d_fine/arch/utils.py:145-188,267-354) and box_iou /
 // generalized_box_iou (src/d_fine/arch/utils.py:12-51).  The reference issues ~20 small ATen
 // kernels per loss term, 48 terms per step for D-FINE-m - the criterion is host-bound (28 ms of
-// launch overhead per step on MI355X).  Here one head costs 3-6 launches:
-//   pair_box_kernel   per matched (image, query, target): IoU, GIoU, L1 (+ gradients wrt the
-//                     predicted box) and the (image,query) -> pair map
-//   vfl_kernel        varifocal loss over all B*Q*C logits
-//   row_weight_kernel per (image, query): sigmoid(max_c teacher_logit)   [DDF weights]
-//   ddf_kernel        T^2 * KL(softmax(teacher/T) || softmax(pred/T)) over all B*Q*4 edge rows
-//   fgl_kernel        fine-grained localisation CE on the matched rows, targets derived in-kernel
+// launch overhead per step on MI355X).  Here one head costs one fill and two launches:
+//   pair_box_kernel     per matched (image, query, target) of both matchings: IoU, GIoU, L1 (+ gradients wrt the predicted
+//                       box) and the (image, query) -> pair maps
+//   head_phase2_kernel  block roles: varifocal loss over all B*Q*C logits | T^2 * KL(softmax(teacher/T) || softmax(pred/T))
+//                       over all B*Q*4 edge rows, weighted per (image, query) by the pair's IoU or sigmoid(max_c teacher_logit)
+//                       [DDF] | fine-grained localisation CE on the matched rows, targets derived in-kernel [FGL]
 // Inputs may be strided views (batch / query strides) of fp32 or bf16 tensors; math is fp32.
 // Loss sums are accumulated with one atomic per block into out[] (zeroed by the entry point).
 #include "common.h"
@@ -121,18 +120,18 @@ __global__ __launch_bounds__(kLT) void pair_box_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// (the three loss bodies below are the block roles of head_phase2_kernel: `blk` of `nblk` blocks of kLT threads)
 template <typename T>
-__global__ __launch_bounds__(kLT) void vfl_kernel(const T *__restrict__ logits, View lv,
-                                                  const int *__restrict__ map,
-                                                  const int64_t *__restrict__ plan, int M,
-                                                  const int64_t *__restrict__ labels,
-                                                  const float *__restrict__ iou, int B, int Q, int C,
-                                                  float alpha, float gamma, float s_vfl,
-                                                  T *__restrict__ grad, float *__restrict__ out) {
-    __shared__ float red[kLT / 64];
+__device__ __forceinline__ void vfl_body(int blk, int nblk, float *red, const T *__restrict__ logits, View lv,
+                                         const int *__restrict__ map,
+                                         const int64_t *__restrict__ plan, int M,
+                                         const int64_t *__restrict__ labels,
+                                         const float *__restrict__ iou, int B, int Q, int C,
+                                         float alpha, float gamma, float s_vfl,
+                                         T *__restrict__ grad, float *__restrict__ out) {
     const uint32_t n = (uint32_t)B * Q * C;               // < 2^31 (checked by the entry point): 32-bit index arithmetic
     float acc = 0.f;
-    for (uint32_t e = blockIdx.x * kLT + threadIdx.x; e < n; e += gridDim.x * kLT) {
+    for (uint32_t e = (uint32_t)blk * kLT + threadIdx.x; e < n; e += (uint32_t)nblk * kLT) {
         const uint32_t row = e / (uint32_t)C;
         const int c = (int)(e - row * C);
         const uint32_t b = row / (uint32_t)Q, q = row - b * Q;
@@ -151,34 +150,27 @@ __global__ __launch_bounds__(kLT) void vfl_kernel(const T *__restrict__ logits, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// w[b,q] = matched ? iou : sigmoid(max_c teacher_logits)
+// w[b,q] = matched ? iou : sigmoid(max_c teacher_logits)   (computed by each of the row's four edge threads)
 template <typename T>
-__global__ __launch_bounds__(kLT) void row_weight_kernel(const T *__restrict__ tlogits, View tv,
-                                                         const int *__restrict__ map,
-                                                         const float *__restrict__ iou, int B, int Q,
-                                                         int C, float *__restrict__ wrow) {
-    const int row = blockIdx.x * kLT + threadIdx.x;
-    if (row >= B * Q) return;
-    const int m = map[row] - 1;
-    if (m >= 0) { wrow[row] = iou[m]; return; }
-    const int b = row / Q, q = row - b * Q;
+__device__ __forceinline__ float row_weight(const T *__restrict__ tlogits, View tv, int m /* pair index or -1 */,
+                                            const float *__restrict__ iou, int b, int q, int C) {
+    if (m >= 0) return iou[m];
     const T *p = tlogits + (int64_t)b * tv.sb + (int64_t)q * tv.sq;
     float mx = load_f(p);
     for (int c = 1; c < C; ++c) mx = fmaxf(mx, load_f(p + c));
-    wrow[row] = 1.f / (1.f + __expf(-mx));
+    return 1.f / (1.f + __expf(-mx));
 }
 
 // one thread per (b, q, edge) row of NB bins
 template <typename T, int NB>
-__global__ __launch_bounds__(kLT) void ddf_kernel(const T *__restrict__ pred, View pv,
-                                                  const T *__restrict__ teacher, View tv,
-                                                  const int *__restrict__ map,
-                                                  const float *__restrict__ wrow, int B, int Q,
-                                                  float temp, float c_pos, float c_neg,
-                                                  T *__restrict__ grad /* [B,Q,4*NB] */,
-                                                  float *__restrict__ out) {
-    __shared__ float red[kLT / 64];
-    const int r = blockIdx.x * kLT + threadIdx.x;
+__device__ __forceinline__ void ddf_body(int blk, float *red, const T *__restrict__ pred, View pv,
+                                         const T *__restrict__ teacher, View tv,
+                                         const int *__restrict__ map, const T *__restrict__ tlogits, View tlv,
+                                         const float *__restrict__ iou, int B, int Q, int C,
+                                         float temp, float c_pos, float c_neg,
+                                         T *__restrict__ grad /* [B,Q,4*NB] */,
+                                         float *__restrict__ out) {
+    const int r = blk * kLT + threadIdx.x;
     float loss = 0.f;
     if (r < B * Q * 4) {
         const int row = r >> 2, edge = r & 3;
@@ -196,8 +188,9 @@ __global__ __launch_bounds__(kLT) void ddf_kernel(const T *__restrict__ pred, Vi
 #pragma unroll
         for (int j = 0; j < NB; ++j) { ps += __expf(pl[j] - pm); ts += __expf(tl[j] - tm); }
         const float plz = pm + __logf(ps), tlz = tm + __logf(ts);
-        const bool pos = map[row] > 0;
-        const float coef = (pos ? c_pos : c_neg) * wrow[row];
+        const int mrow = map[row] - 1;
+        const bool pos = mrow >= 0;
+        const float coef = (pos ? c_pos : c_neg) * row_weight(tlogits, tlv, mrow, iou, b, q, C);
         float kl = 0.f;
         T *gp = grad + ((int64_t)row * 4 + edge) * NB;
 #pragma unroll
@@ -217,15 +210,14 @@ struct FglTable { float w[64]; int reg_max; float reg_scale; };
 
 // one thread per (pair, edge); ADDS its gradient onto grad (written by ddf_kernel or zeroed)
 template <typename T, int NB>
-__global__ __launch_bounds__(kLT) void fgl_kernel(const T *__restrict__ pred, View pv,
-                                                  const float *__restrict__ ref, View rv,
-                                                  const float *__restrict__ tgt_boxes,
-                                                  const int64_t *__restrict__ plan, int M, int Q,
-                                                  const float *__restrict__ iou, FglTable tab,
-                                                  float s_fgl, T *__restrict__ grad,
-                                                  float *__restrict__ out) {
-    __shared__ float red[kLT / 64];
-    const int r = blockIdx.x * kLT + threadIdx.x;
+__device__ __forceinline__ void fgl_body(int blk, float *red, const T *__restrict__ pred, View pv,
+                                         const float *__restrict__ ref, View rv,
+                                         const float *__restrict__ tgt_boxes,
+                                         const int64_t *__restrict__ plan, int M, int Q,
+                                         const float *__restrict__ iou, const FglTable &tab,
+                                         float s_fgl, T *__restrict__ grad,
+                                         float *__restrict__ out) {
+    const int r = blk * kLT + threadIdx.x;
     float loss = 0.f;
     if (r < M * 4) {
         const int m = r >> 2, edge = r & 3;
@@ -277,6 +269,34 @@ __global__ __launch_bounds__(kLT) void fgl_kernel(const T *__restrict__ pred, Vi
     }
     const float s = block_sum(loss, red);
     if (threadIdx.x == 0) unsafeAtomicAdd(out, s);
+}
+
+// Second phase of a head (after pair_box_kernel): varifocal loss, DDF and FGL are independent of each other - ONE launch whose
+// blocks take the three roles (they were 3-4 launches of 8-30 us each, back to back on one stream).
+template <typename T>
+struct Phase2 {
+    const T *logits; View lv; const int *map_cls; const int64_t *cls_plan; int M_cls; const int64_t *labels; const float *iou_cls;
+    float alpha, gamma, s_vfl; T *grad_logits;
+    const T *corners; View pv; const T *teacher; View tcv; const int *map_box; const T *tlogits; View tlv; const float *iou_box;
+    float temp, c_pos, c_neg; T *grad_ddf;
+    const float *ref; View rv; const float *tgt_boxes; const int64_t *box_plan; int M_box; float s_fgl; T *grad_fgl;
+    float *out; int B, Q, C, nb_vfl, nb_ddf;
+    FglTable tab;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kLT) void head_phase2_kernel(const Phase2<T> a) {
+    __shared__ float red[kLT / 64];
+    const int blk = blockIdx.x;
+    if (blk < a.nb_vfl)
+        vfl_body<T>(blk, a.nb_vfl, red, a.logits, a.lv, a.map_cls, a.cls_plan, a.M_cls, a.labels, a.iou_cls, a.B, a.Q, a.C, a.alpha,
+                    a.gamma, a.s_vfl, a.grad_logits, a.out);
+    else if (blk < a.nb_vfl + a.nb_ddf)
+        ddf_body<T, 33>(blk - a.nb_vfl, red, a.corners, a.pv, a.teacher, a.tcv, a.map_box, a.tlogits, a.tlv, a.iou_box, a.B, a.Q, a.C,
+                        a.temp, a.c_pos, a.c_neg, a.grad_ddf, a.out + 4);
+    else
+        fgl_body<T, 33>(blk - a.nb_vfl - a.nb_ddf, red, a.corners, a.pv, a.ref, a.rv, a.tgt_boxes, a.box_plan, a.M_box, a.Q, a.iou_box,
+                        a.tab, a.s_fgl, a.grad_fgl, a.out + 3);
 }
 
 // Backward of the fused head losses: the closed-form gradients of the forward pass scaled by the upstream gradient g[5] of
@@ -366,47 +386,29 @@ int dfine_head_losses(
     const int64_t n = (int64_t)B * Q * C;
     if (n >= ((int64_t)1 << 31) - 2048 * kLT) return DFINE_E_BADARG;      // the kernels index the logits with 32 bits
     const int vb = (int)((n + kLT - 1) / kLT < 2048 ? (n + kLT - 1) / kLT : 2048);
-    const View lv{l_sb, l_sq};
-    if (dtype == DFINE_F32)
-        hipLaunchKernelGGL(vfl_kernel<float>, dim3(vb), dim3(kLT), 0, st, (const float *)logits, lv, map_cls, cls_plan, M_cls,
-                           tgt_labels, iou_cls, B, Q, C, alpha, gamma, s_vfl, (float *)grad_logits, out);
-    else
-        hipLaunchKernelGGL(vfl_kernel<uint16_t>, dim3(vb), dim3(kLT), 0, st, (const uint16_t *)logits, lv, map_cls, cls_plan,
-                           M_cls, tgt_labels, iou_cls, B, Q, C, alpha, gamma, s_vfl, (uint16_t *)grad_logits, out);
-    if (corners) {
-        const View pv{c_sb, c_sq};
-        const int rows = B * Q * 4;
-        if (teacher_corners) {
-            if (!teacher_logits || !wrow || !grad_corners_ddf) return DFINE_E_BADARG;
-            const View tcv{tc_sb, tc_sq}, tlv{tl_sb, tl_sq};
-            if (dtype == DFINE_F32) {
-                hipLaunchKernelGGL(row_weight_kernel<float>, dim3((B * Q + kLT - 1) / kLT), dim3(kLT), 0, st,
-                                   (const float *)teacher_logits, tlv, map_box, iou_box, B, Q, C, wrow);
-                hipLaunchKernelGGL((ddf_kernel<float, 33>), dim3((rows + kLT - 1) / kLT), dim3(kLT), 0, st, (const float *)corners,
-                                   pv, (const float *)teacher_corners, tcv, map_box, wrow, B, Q, temp, ddf_c_pos, ddf_c_neg,
-                                   (float *)grad_corners_ddf, out + 4);
-            } else {
-                hipLaunchKernelGGL(row_weight_kernel<uint16_t>, dim3((B * Q + kLT - 1) / kLT), dim3(kLT), 0, st,
-                                   (const uint16_t *)teacher_logits, tlv, map_box, iou_box, B, Q, C, wrow);
-                hipLaunchKernelGGL((ddf_kernel<uint16_t, 33>), dim3((rows + kLT - 1) / kLT), dim3(kLT), 0, st,
-                                   (const uint16_t *)corners, pv, (const uint16_t *)teacher_corners, tcv, map_box, wrow, B, Q,
-                                   temp, ddf_c_pos, ddf_c_neg, (uint16_t *)grad_corners_ddf, out + 4);
-            }
+    if (corners && teacher_corners && (!teacher_logits || !grad_corners_ddf)) return DFINE_E_BADARG;
+    const int nb_ddf = corners && teacher_corners ? (B * Q * 4 + kLT - 1) / kLT : 0;
+    const int nb_fgl = corners && M_box > 0 ? (M_box * 4 + kLT - 1) / kLT : 0;
+    auto launch = [&](auto tag) {
+        using T = decltype(tag);
+        Phase2<T> a{};
+        a.logits = (const T *)logits; a.lv = View{l_sb, l_sq}; a.map_cls = map_cls; a.cls_plan = cls_plan; a.M_cls = M_cls;
+        a.labels = tgt_labels; a.iou_cls = iou_cls; a.alpha = alpha; a.gamma = gamma; a.s_vfl = s_vfl; a.grad_logits = (T *)grad_logits;
+        a.corners = (const T *)corners; a.pv = View{c_sb, c_sq}; a.teacher = (const T *)teacher_corners; a.tcv = View{tc_sb, tc_sq};
+        a.map_box = map_box; a.tlogits = (const T *)teacher_logits; a.tlv = View{tl_sb, tl_sq}; a.iou_box = iou_box;
+        a.temp = temp; a.c_pos = ddf_c_pos; a.c_neg = ddf_c_neg; a.grad_ddf = (T *)grad_corners_ddf;
+        a.ref = ref; a.rv = View{r_sb, r_sq}; a.tgt_boxes = tgt_boxes; a.box_plan = box_plan; a.M_box = M_box; a.s_fgl = s_fgl;
+        a.grad_fgl = (T *)grad_corners_fgl;
+        a.out = out; a.B = B; a.Q = Q; a.C = C; a.nb_vfl = vb; a.nb_ddf = nb_ddf;
+        if (nb_fgl) {
+            for (int j = 0; j <= reg_max; ++j) a.tab.w[j] = wtable[j];
+            a.tab.reg_max = reg_max; a.tab.reg_scale = reg_scale;
         }
-        if (M_box > 0) {
-            FglTable tab;
-            for (int j = 0; j <= reg_max; ++j) tab.w[j] = wtable[j];
-            tab.reg_max = reg_max; tab.reg_scale = reg_scale;
-            const View rv{r_sb, r_sq};
-            if (dtype == DFINE_F32)
-                hipLaunchKernelGGL((fgl_kernel<float, 33>), dim3((M_box * 4 + kLT - 1) / kLT), dim3(kLT), 0, st, (const float *)corners,
-                                   pv, ref, rv, tgt_boxes, box_plan, M_box, Q, iou_box, tab, s_fgl, (float *)grad_corners_fgl, out + 3);
-            else
-                hipLaunchKernelGGL((fgl_kernel<uint16_t, 33>), dim3((M_box * 4 + kLT - 1) / kLT), dim3(kLT), 0, st,
-                                   (const uint16_t *)corners, pv, ref, rv, tgt_boxes, box_plan, M_box, Q, iou_box, tab,
-                                   s_fgl, (uint16_t *)grad_corners_fgl, out + 3);
-        }
-    }
+        hipLaunchKernelGGL(head_phase2_kernel<T>, dim3(vb + nb_ddf + nb_fgl), dim3(kLT), 0, st, a);
+    };
+    if (dtype == DFINE_F32) launch(float{});
+    else launch(uint16_t{});
+    (void)wrow;          // (the DDF row weights are computed in place by the edge threads; the scratch argument stays in the ABI)
     return check_launch();
 }
 
