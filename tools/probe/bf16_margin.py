@@ -1,3 +1,6 @@
+"""How close the per-block bf16 criterion of tests/test_model_gpu.py::test_bf16_hip_blocks_no_worse_than_aten_bf16_blocks_m320 comes
+to its limit, four repetitions: the largest h / (1.5 a + 2e-4) over blocks and quantities (h = HIP-bf16 distance to fp32, a = ATen-bf16's,
+now the largest of three ATen runs).  The HIP side repeats exactly, ATen's moves by 20 % from run to run.  GPU box."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
