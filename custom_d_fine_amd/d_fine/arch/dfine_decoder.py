@@ -513,25 +513,28 @@ class DFINETransformer(nn.Module):
         anchors, valid = self._anchors_for(spatial_shapes, memory.device)
         if memory.shape[0] > 1:
             anchors = anchors.expand(memory.shape[0], -1, -1)
-        memory = valid.to(memory.dtype) * memory
+        keep = valid.to(memory.dtype)                       # [1, sum(HW), 1]: 0 for anchors outside (0.01, 0.99)
         if self.training and torch.is_grad_enabled():
             # Query selection only needs the scores of all anchors to pick indices; every op on this
             # path (Linear, LayerNorm, score head) is row-wise and gradients only flow through the
             # selected rows.  So: score all sum(HW) rows WITHOUT autograd, then recompute the 300
             # selected rows with autograd.  Same values and gradients as the reference
             # (dfine_decoder.py:842-853), but the backward no longer runs three GEMMs + a LayerNorm
-            # over B*8400 mostly-zero gradient rows.
+            # over B*8400 mostly-zero gradient rows.  The validity mask is applied to the whole memory for the
+            # scoring pass only (no autograd) and to the 300 gathered rows on the differentiable path: the same
+            # products, without a full-size multiply (and its saved operand) in the backward.
             with torch.no_grad():
-                scores_all = self._enc_scores(self._enc_output(memory))
+                scores_all = self._enc_scores(self._enc_output(keep * memory))
             ind = self._topk_indices(scores_all, self.num_queries)
 
             def take(t):
                 return t.gather(dim=1, index=ind.unsqueeze(-1).expand(-1, -1, t.shape[-1]))
 
-            top_mem = self._enc_output(take(memory))
+            top_mem = self._enc_output(take(memory) * take(keep.expand(memory.shape[0], -1, -1)))
             top_logits = self._enc_scores(top_mem)
             top_anchor = take(anchors)
         else:
+            memory = keep * memory
             out_mem = self._enc_output(memory)
             enc_logits = self._enc_scores(out_mem)
             top_mem, top_logits, top_anchor = self._select_topk(out_mem, enc_logits, anchors,
