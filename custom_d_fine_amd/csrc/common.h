@@ -18,6 +18,20 @@ inline int check_launch() {
     return DFINE_OK;
 }
 
+// Zero fill as a KERNEL launch, not hipMemsetAsync: a memset recorded into a HIP graph (the captured backward segment of
+// dl/engine.py) came back with garbage in the filled range from the second replay on (stem weight gradients of 1e12 .. 1e35,
+// tests/test_graph_gpu.py) - kernel nodes replay faithfully.  `bytes` must be a multiple of 4, `p` 4-byte aligned.
+static __global__ __launch_bounds__(256) void zero_fill_kernel(uint32_t *__restrict__ p, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+inline void zero_fill_async(void *p, size_t bytes, hipStream_t st) {
+    const size_t words = bytes >> 2;
+    if (!words) return;
+    size_t blocks = (words + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t *)p, words);
+}
+
 // ---- bf16 <-> f32 (round to nearest even), raw 16-bit storage ------------------------------
 __device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // gfx950 converts with round-to-nearest-even in hardware (v_cvt_pk_bf16_f32, two floats per instruction); the bit

@@ -368,14 +368,14 @@ int dfine_head_losses(
                         reinterpret_cast<char *>(map_cls) == o8 + 32 + nq * 32 && map_box == map_cls + nq &&
                         (!corners || reinterpret_cast<char *>(grad_corners_fgl) == o8 + (maps_end + 15) / 16 * 16);
     if (packed) {
-        (void)hipMemsetAsync(out, 0, corners ? (maps_end + 15) / 16 * 16 + fgl_bytes : maps_end, st);
+        zero_fill_async(out, corners ? (maps_end + 15) / 16 * 16 + fgl_bytes : maps_end, st);
     } else {
-        (void)hipMemsetAsync(out, 0, 5 * sizeof(float), st);
-        (void)hipMemsetAsync(grad_l1, 0, sizeof(float) * nq * 4, st);
-        (void)hipMemsetAsync(grad_giou, 0, sizeof(float) * nq * 4, st);
-        (void)hipMemsetAsync(map_cls, 0, sizeof(int) * nq, st);
-        (void)hipMemsetAsync(map_box, 0, sizeof(int) * nq, st);
-        if (corners) (void)hipMemsetAsync(grad_corners_fgl, 0, fgl_bytes, st);
+        zero_fill_async(out, 5 * sizeof(float), st);
+        zero_fill_async(grad_l1, sizeof(float) * nq * 4, st);
+        zero_fill_async(grad_giou, sizeof(float) * nq * 4, st);
+        zero_fill_async(map_cls, sizeof(int) * nq, st);
+        zero_fill_async(map_box, sizeof(int) * nq, st);
+        if (corners) zero_fill_async(grad_corners_fgl, fgl_bytes, st);
     }
     const View bv{b_sb, b_sq};
     if (M_cls > 0 || M_box > 0) {   // IoU of the classification matching (VFL soft labels); L1 / GIoU of the box matching (+ IoU weights of FGL / DDF)

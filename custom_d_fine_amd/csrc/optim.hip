@@ -107,17 +107,24 @@ __global__ __launch_bounds__(256) void ema_kernel(float *__restrict__ ema, const
 // element chunk, one block per entry.
 struct CopyEntry { const float *src; int64_t dst_off; int64_t n; };
 
+template <bool ADD>
 __global__ __launch_bounds__(256) void multi_copy_kernel(const CopyEntry *__restrict__ table, float *__restrict__ dst) {
     const CopyEntry e = table[blockIdx.x];
     float *d = dst + e.dst_off;
     const bool aligned = (((uintptr_t)e.src | (uintptr_t)d) & 15) == 0;
     if (aligned) {
         const int64_t n4 = e.n >> 2;
-        for (int64_t i = threadIdx.x; i < n4; i += 256)
-            reinterpret_cast<float4 *>(d)[i] = reinterpret_cast<const float4 *>(e.src)[i];
-        for (int64_t i = (n4 << 2) + threadIdx.x; i < e.n; i += 256) d[i] = e.src[i];
+        for (int64_t i = threadIdx.x; i < n4; i += 256) {
+            float4 v = reinterpret_cast<const float4 *>(e.src)[i];
+            if (ADD) {
+                const float4 o = reinterpret_cast<float4 *>(d)[i];
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            reinterpret_cast<float4 *>(d)[i] = v;
+        }
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < e.n; i += 256) d[i] = ADD ? d[i] + e.src[i] : e.src[i];
     } else {
-        for (int64_t i = threadIdx.x; i < e.n; i += 256) d[i] = e.src[i];
+        for (int64_t i = threadIdx.x; i < e.n; i += 256) d[i] = ADD ? d[i] + e.src[i] : e.src[i];
     }
 }
 
@@ -175,7 +182,16 @@ int dfine_adamw_ema_step(float *param, float *grad, float *exp_avg, float *exp_a
 int dfine_multi_copy_f32(const void *table, int n_entries, float *dst, void *stream) {
     if (n_entries == 0) return DFINE_OK;
     if (!table || !dst || n_entries < 0) return DFINE_E_BADARG;
-    hipLaunchKernelGGL(multi_copy_kernel, dim3(n_entries), dim3(256), 0, (hipStream_t)stream, (const CopyEntry *)table, dst);
+    hipLaunchKernelGGL(multi_copy_kernel<false>, dim3(n_entries), dim3(256), 0, (hipStream_t)stream, (const CopyEntry *)table, dst);
+    return check_launch();
+}
+
+// Same table; dst[dst_offset + i] += src[i].  Records of one launch must not overlap in dst (one block per record, plain
+// read-modify-write).
+int dfine_multi_add_f32(const void *table, int n_entries, float *dst, void *stream) {
+    if (n_entries == 0) return DFINE_OK;
+    if (!table || !dst || n_entries < 0) return DFINE_E_BADARG;
+    hipLaunchKernelGGL(multi_copy_kernel<true>, dim3(n_entries), dim3(256), 0, (hipStream_t)stream, (const CopyEntry *)table, dst);
     return check_launch();
 }
 

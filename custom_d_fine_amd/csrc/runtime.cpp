@@ -42,4 +42,18 @@ int dfine_stream_fork(void *from, void *to) {
     }
     return DFINE_OK;
 }
+
+// Host -> device copy of a small table on `stream` from memory the CALLER keeps pinned, alive and unchanged.  Used for the
+// pointer tables of launches recorded inside a HIP-graph capture: the copy becomes a memcpy node that re-reads `src` at
+// every replay.  (torch's own pinned-memory copies tag the host block with an event for its caching host allocator; an
+// event recorded on a capturing stream cannot be queried afterwards - hipErrorCapturedEvent on the next pin_memory().)
+int dfine_upload(void *dst, const void *src, int64_t bytes, void *stream) {
+    if (bytes == 0) return DFINE_OK;
+    if (!dst || !src || bytes < 0) return DFINE_E_BADARG;
+    if (hipError_t e = hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream); e != hipSuccess) {
+        dfine::set_last_error(e);
+        return DFINE_E_LAUNCH;
+    }
+    return DFINE_OK;
+}
 }

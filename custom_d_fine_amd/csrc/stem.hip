@@ -596,7 +596,7 @@ static int stem_wgrad_impl(const void *x, const void *x2, int ca, const void *dy
                            (const uint16_t *)x2, ca, (const uint16_t *)dy, ws, Cin, Cout, KS, pad, H, W, Ho, Wo, ng, ns, B * Ho * (Wo / 32), steps);
     if (int e = check_launch()) return e;
     const int total = Cout * Cin * KS * KS;
-    (void)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)total, st);
+    zero_fill_async(dw, sizeof(float) * (size_t)total, st);
     const int colblocks = (total + 63) / 64;
     int chunks = 1024 / colblocks;                       // ~1024 blocks whatever the weight size
     if (chunks < 1) chunks = 1;

@@ -235,12 +235,20 @@ def set_denoising_generator(gen):
     _NOISE_GENERATOR = gen
 
 
+CAPTURE_KEEP = None      # a hip.CaptureArena while dl.engine.GraphedSegment captures: pinned staging of the uploads recorded in the graph
+
+
 def upload(array, device):
     """Host numpy array / CPU tensor -> device without stalling the host: pinned staging + async copy for
-    CUDA devices (a pageable-memory copy waits for the device queue to drain), plain conversion on CPU."""
+    CUDA devices (a pageable-memory copy waits for the device queue to drain), plain conversion on CPU.
+    Inside a HIP-graph capture the copy becomes a memcpy node that re-reads the host buffer at every replay: it is staged
+    in the capturing segment's own pinned arena (CAPTURE_KEEP), alive and unchanged for the graph's lifetime, and copied
+    by the library (torch's pinned copies record an allocator event on the capturing stream)."""
     t = torch.from_numpy(array) if isinstance(array, np.ndarray) else array
     if torch.device(device).type != "cuda":
         return t.to(device)
+    if CAPTURE_KEEP is not None:
+        return CAPTURE_KEEP.upload(t, device)
     return t.pin_memory().to(device, non_blocking=True)
 
 

@@ -70,55 +70,209 @@ class _BackboneEncoder(nn.Module):
         return tuple(self.encoder(self.backbone(x)))
 
 
+class _DualCapture:
+    """Backward capture as a chain of graph PAIRS: pair k = (main_k, side_k); main_k holds what the backward pass launches
+    on its own stream (BatchNorm backward -> data gradient -> ...), side_k what it launches on the side stream during the
+    same stretch (weight gradients).  Replay: main_0, [event] side_0 || main_1, [event] side_1 || main_2 ... join.  Every
+    launch of side_k reads results of main_j, j <= k, only (it was issued after them), so the one event per pair orders it.
+    Why not fork the side stream INTO one capture: the runtime then executes the branches without any overlap (measured,
+    tools/graph_probe8.py: 17.2 ms with or without the side stream inside the graph, against 15.9 ms for the eager launch
+    sequence; DEBUG_HIP_FORCE_GRAPH_QUEUES 1 / 2 / 8 change nothing)."""
+
+    def __init__(self, cap_stream, side, pool, every):
+        self.cap_stream, self.side, self.pool, self.every = cap_stream, side, pool, max(int(every), 1)
+        self.side_pool = torch.cuda.graph_pool_handle()      # two captures that are open at the same time cannot share a pool
+        self.pairs, self.n, self.cur = [], 0, None
+
+    def begin(self):
+        gm, gs = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.stream(self.cap_stream):
+            gm.capture_begin(pool=self.pool, capture_error_mode="relaxed")
+        with torch.cuda.stream(self.side.stream):
+            gs.capture_begin(pool=self.side_pool, capture_error_mode="relaxed")
+        self.cur = [gm, gs, 0]
+
+    def end(self):
+        import warnings
+        gm, gs, n = self.cur
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                  # "The CUDA Graph is empty": a pair without side-stream launches
+            with torch.cuda.stream(self.side.stream):
+                gs.capture_end()
+            with torch.cuda.stream(self.cap_stream):
+                gm.capture_end()
+        self.pairs.append((gm, gs if n else None))
+        self.cur = None
+
+    def side_launch(self):
+        if self.cur[2] >= self.every:           # this launch opens the next pair
+            self.end()
+            self.begin()
+        self.cur[2] += 1
+
+
 class GraphedSegment:
-    """A module with static shapes whose forward and backward are each captured ONCE into a HIP graph and
-    replayed afterwards (two launches instead of thousands of host-side kernel launches).
+    """A module with static shapes (backbone + encoder) whose training forward and backward are each captured ONCE into a HIP
+    graph and replayed afterwards: two graph launches (~0.1 ms of host time each, measured: tools/graph_probe7.py) instead
+    of ~1 000 kernel launches issued from ~700 Python autograd nodes (~16 ms of host time per step for D-FINE-m - the step
+    was host-paced).  The device-side work is the eager path's, launch for launch:
 
-    Hand-rolled equivalent of torch.cuda.make_graphed_callables - which segfaults on torch 2.10.0+rocm7.0
-    even for a two-layer MLP (tools/graph_probe2.py), while explicit torch.cuda.graph capture with
-    torch.autograd.grad inside works (tools/graph_probe3.py).  Inputs are copied into static buffers,
-    outputs / parameter gradients are returned as the graph's static tensors."""
+    * the parameters are views of the fused optimizer's flat buffer (fixed addresses); their packed / bf16 copies are the
+      registered shadows of `kernels`, refreshed with one launch per kind in front of every forward replay;
+    * the backward graph ends with the segment's gradients IN the flat gradient buffer: the deferred weight-gradient
+      partial sums are reduced there by the same grouped launches as in the eager step (dfine_conv_wgrad1_group,
+      dfine_linear_wgrad_group, dfine_multi_wgrad_reduce), gradient tensors (BatchNorm affine, depthwise, stem ...) are added
+      by one dfine_multi_add_f32 launch - no autograd leaf of the model takes part in a replay;
+    * the weight-gradient launches keep their side stream: the backward pass is recorded as a chain of graph pairs
+      (_DualCapture: what goes to the main stream / to the side stream during a stretch of 5 weight-gradient launches),
+      replayed pair by pair on the two streams (`DFINE_GRAPH_SIDE=fork`: the side stream forked into ONE capture - the
+      runtime then runs the branches without overlap; `DFINE_GRAPH_SIDE=0`: one stream);
+    * BatchNorm running statistics are updated by the recorded kernels; the `num_batches_tracked` counters by the same
+      deferred bookkeeping as in the eager step.
 
-    def __init__(self, module, sample_inputs, amp_dtype=None, warmup=2):
-        from .. import kernels
-        kernels._CAPTURE_POSSIBLE = True
-        self.module = module
-        self.params = [p for p in module.parameters() if p.requires_grad]
-        self.amp_dtype = amp_dtype
-        self.static_in = [t.detach().clone().requires_grad_(t.requires_grad) for t in sample_inputs]
-        self.grad_in_idx = [i for i, t in enumerate(self.static_in) if t.requires_grad]
+    The capture runs the module on ALIASES of the parameters (detached views made on the capture stream): autograd ties a
+    leaf's gradient accumulator to the stream it was created on, and an accumulator left over from an eager step (default
+    stream, kept alive by any graph the caller still holds) makes the engine synchronise the capturing stream with the
+    legacy stream - a crash on this stack (tools/graph_probe6.py).  `torch.cuda.make_graphed_callables` segfaults here even
+    for a two-layer MLP (tools/graph_probe2.py)."""
+
+    def __init__(self, module, sample_inputs, amp_dtype=None, fused=None, warmup=1):
+        from .. import hip, kernels
+        from ..d_fine.arch import utils as arch_utils
+        if fused is None:
+            raise RuntimeError("GraphedSegment delivers its gradients into FusedAdamWEMA's flat gradient buffer")
+        self.module, self.fused, self.amp_dtype = module, fused, amp_dtype
+        self.hip, self.kernels = hip, kernels
+        dev = sample_inputs[0].device
+        self.device = dev
+        self.static_in = [t.detach().clone() for t in sample_inputs]
+        self._keep, self._pinned = [], hip.CaptureArena()
+        self.side = os.environ.get("DFINE_GRAPH_SIDE", "dual")           # "dual" | "fork" | "0"
+        if not hip.WGRAD_STREAM:
+            self.side = "0"
+
+        cap_stream = torch.cuda.Stream(device=dev)
+        cap_stream.wait_stream(torch.cuda.current_stream(dev))
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        with torch.cuda.stream(cap_stream):
+            aliases = []
+            for _, p in named:
+                a = p.detach().requires_grad_(True)
+                slot = getattr(p, "_dfine_slot", None)
+                if slot is not None:
+                    a._dfine_slot = slot
+                aliases.append(a)
+        alias_map = {n: a for (n, _), a in zip(named, aliases)}
+        self._aliases = aliases
+        self.param_index = [getattr(p, "_dfine_slot", (None, None))[1] for _, p in named]
+        if any(i is None for i in self.param_index) or any(getattr(p, "_dfine_slot")[0] is not fused for _, p in named):
+            raise RuntimeError("every trainable parameter of a graphed segment must live in the fused optimizer's flat buffers")
 
         def run():
             with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None, cache_enabled=False):
-                return tuple(module(*self.static_in))
+                return tuple(torch.func.functional_call(module, alias_map, tuple(self.static_in)))
 
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                outs = run()
-                torch.autograd.grad(outs, [self.static_in[i] for i in self.grad_in_idx] + self.params,
-                                    [torch.ones_like(o) for o in outs], allow_unused=True)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+        def deliver(grads):
+            """Segment gradients -> flat gradient buffer (recorded at the end of the backward capture)."""
+            hip.linear_wgrad_flush()                    # grouped weight-gradient launches of what is registered; joins the side stream
+            real = [(g, fused.grad_offset(i)) for g, i in zip(grads, self.param_index) if g is not None]
+            for g, _ in real:
+                if g.dtype != torch.float32:
+                    raise RuntimeError("graphed segment: parameter gradients are expected in fp32")
+            if real:
+                self._keep.append(hip.multi_copy_f32([g.contiguous() for g, _ in real], [o for _, o in real], fused.flat_grad, add=True))
+            fused._flush_deferred()                     # the deferred partial sums of the segment, reduced into flat_grad
 
-        self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.fwd_graph):
-            self.static_out = run()
-        self.static_gout = [torch.zeros_like(o) for o in self.static_out]
-        with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool()):
-            self.static_grads = torch.autograd.grad(
-                self.static_out, [self.static_in[i] for i in self.grad_in_idx] + self.params,
-                self.static_gout, allow_unused=True)
+        if fused._deferred or hip._CW_PENDING or hip._LW_PENDING:
+            raise RuntimeError("GraphedSegment must be built between steps (weight gradients of a running backward are pending)")
+        was_accumulating = fused.accumulating
+        fused.accumulating = True                       # no bucket bookkeeping from the warm-up / capture runs
+        snap_grad = fused.flat_grad.clone()
+        snap_buf = None if fused.flat_buf is None else fused.flat_buf.clone()
+        snap_bn = dict(kernels._BN_PENDING)
+        flags = (kernels._CAPTURE_POSSIBLE, kernels._CAPTURE_SHADOWS, hip.CAPTURE_SIDE, arch_utils.CAPTURE_KEEP)
+        self.bwd_pairs = None
+        try:
+            # ---- eager warm-up on the capture stream: fills the shadow registries for the aliases, sizes the workspaces
+            with torch.cuda.stream(cap_stream):
+                for _ in range(max(warmup, 1)):
+                    outs = run()
+                    grads = torch.autograd.grad(outs, aliases, [torch.ones_like(o) for o in outs], allow_unused=True)
+                    deliver(grads)
+                    del outs, grads
+            cap_stream.synchronize()
+            fused.flat_grad.copy_(snap_grad)
+            if snap_buf is not None:
+                fused.flat_buf.copy_(snap_buf)
+            kernels._BN_PENDING.clear()
+            kernels._BN_PENDING.update(snap_bn)
+            fused._uses.clear()
+            self._keep.clear()
+            torch.cuda.synchronize(dev)
+
+            kernels._CAPTURE_POSSIBLE, kernels._CAPTURE_SHADOWS = True, True
+            hip.CAPTURE_SIDE = self.side == "fork"
+            arch_utils.CAPTURE_KEEP = self._pinned
+            kernels.refresh_weight_shadows(dev)
+            torch.cuda.synchronize(dev)
+            self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.fwd_graph, stream=cap_stream, capture_error_mode="relaxed"):
+                self.static_out = run()
+                hip.side_join()
+            self._bn_counters = [(k, v[0]) for k, v in kernels._BN_PENDING.items() if snap_bn.get(k, (None, 0))[1] != v[1]]
+            kernels._BN_PENDING.clear()
+            kernels._BN_PENDING.update(snap_bn)
+            self.static_gout = [torch.zeros_like(o) for o in self.static_out]
+            if self.side == "dual":
+                # the backward pass proper as a chain of (main, side) graph pairs, then the delivery of the gradients as one graph
+                dual = _DualCapture(cap_stream, hip.side_stream(dev), self.fwd_graph.pool(),
+                                    os.environ.get("DFINE_GRAPH_CHUNK", "5"))
+                torch.cuda.synchronize(dev)
+                hip.CAPTURE_DUAL = dual
+                try:
+                    with torch.cuda.stream(cap_stream):
+                        dual.begin()
+                        grads = torch.autograd.grad(self.static_out, aliases, self.static_gout, allow_unused=True)
+                        dual.end()
+                finally:
+                    hip.CAPTURE_DUAL = None
+                self.bwd_pairs = dual.pairs
+                self._keep.append(list(hip._SIDE_LIVE))       # inputs of the side graphs: referenced until every capture is done
+                hip._SIDE_LIVE.clear()
+                with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(), stream=cap_stream, capture_error_mode="relaxed"):
+                    deliver(grads)
+            else:
+                with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(), stream=cap_stream, capture_error_mode="relaxed"):
+                    grads = torch.autograd.grad(self.static_out, aliases, self.static_gout, allow_unused=True)
+                    deliver(grads)
+            self._static_grads = grads
+            fused._uses.clear()
+            # scratch buffers the recorded launches point into live in module-level tables keyed by stream / shape: held here
+            # so that a later, larger request cannot free them under the graph
+            self._keep.append([list(d.values()) for d in (hip._BN_WS, hip._LW_WS, hip._STEM_WS)])
+            self._keep.append(list(fused._live))
+        finally:
+            kernels._CAPTURE_POSSIBLE, kernels._CAPTURE_SHADOWS, hip.CAPTURE_SIDE, arch_utils.CAPTURE_KEEP = flags
+            hip.CAPTURE_DUAL = None
+            fused.accumulating = was_accumulating
+        self._token = torch.zeros((), device=dev, requires_grad=True)     # makes autograd call _Replay.backward
         seg = self
 
         class _Replay(torch.autograd.Function):
             @staticmethod
-            def forward(ctx, *args):           # args = inputs + params (params only to hook autograd up)
-                for dst, src in zip(seg.static_in, args[:len(seg.static_in)]):
+            def forward(ctx, token, *args):
+                for dst, src in zip(seg.static_in, args):
                     if dst.data_ptr() != src.data_ptr():
                         dst.copy_(src)
+                kernels.refresh_weight_shadows(seg.device)
                 seg.fwd_graph.replay()
+                if kernels._BN_DEFER:
+                    pend = kernels._BN_PENDING
+                    for key, buf in seg._bn_counters:
+                        ent = pend.get(key)
+                        pend[key] = (buf, 1 if ent is None else ent[1] + 1)
+                else:
+                    torch._foreach_add_([b for _, b in seg._bn_counters], 1)
                 return tuple(o.detach() for o in seg.static_out)
 
             @staticmethod
@@ -128,31 +282,39 @@ class GraphedSegment:
                         dst.zero_()
                     elif dst.data_ptr() != src.data_ptr():
                         dst.copy_(src)
+                if seg.bwd_pairs is not None:
+                    cur, st = hip._stream(), hip.side_stream(seg.device)
+                    serial = os.environ.get("DFINE_GRAPH_SERIAL") == "1"        # debugging: no overlap between the two streams
+                    for gm, gs in seg.bwd_pairs:
+                        gm.replay()
+                        if gs is not None:
+                            hip.stream_wait(cur, st.cuda_stream)
+                            with torch.cuda.stream(st.stream):
+                                gs.replay()
+                            if serial:
+                                hip.stream_wait(st.cuda_stream, cur)
+                    hip.stream_wait(st.cuda_stream, cur)
                 seg.bwd_graph.replay()
-                grads = [None] * len(seg.static_in)
-                it = iter(seg.static_grads)
-                for i in seg.grad_in_idx:
-                    grads[i] = next(it)
-                return tuple(grads) + tuple(g.detach() if g is not None else None for g in it)
+                f = seg.fused
+                if f.overlap and not f.accumulating:            # bucket bookkeeping of the overlapped all-reduce
+                    for i in seg.param_index:
+                        f.param_ready(i)
+                return (None,) * (1 + len(seg.static_in))
 
         self._fn = _Replay
 
     def __call__(self, *inputs):
-        return self._fn.apply(*inputs, *self.params)
+        return self._fn.apply(self._token, *inputs)
 
 
 class TrainStep:
     """fwd (autocast) -> criterion (fp32) -> bwd -> clip -> AdamW -> [scheduler] -> EMA.
 
-    `hip_graph=True` (GPU): backbone + encoder - static shapes, ~70 % of the step's kernel launches
-    (conv / BN / depthwise units, forward and backward) - are captured once into HIP graphs
-    and replayed, which removes their host-side launch cost; the
+    `hip_graph=True` (GPU, fused optimizer): backbone + encoder - static shapes, ~70 % of the step's kernel launches
+    (conv / BN / depthwise units, forward and backward) - are captured once per input shape into HIP graphs
+    (GraphedSegment) and replayed, which removes their host-side launch cost (the step was host-paced); the
     decoder (query count depends on the batch's targets) and the criterion (one D2H copy of the
-    assignment) stay eager.
-    Measured on MI355X / ROCm 7.2 (D-FINE-m, bs 32, phases synchronised): forward 25.6 -> 24.5 ms but
-    backward 52.5 -> 57.9 ms, i.e. no net gain: the step is bound by device-side kernel boundaries
-    (~1.5 us x ~6000 launches, the same for eager and graph launches on this stack), not by host launch
-    cost - so the default is OFF and the way forward is fewer, fatter kernels."""
+    assignment) stay eager.  A step instrumented with per-launch HIP events (bench.py's roofline sample) runs eagerly."""
 
     def __init__(self, model, criterion, optimizer, *, amp_dtype=None, clip_max_norm=0.1,
                  ema=None, scheduler=None, accum_steps=1, fused_optimizer=None, hip_graph=False,
@@ -165,7 +327,7 @@ class TrainStep:
         self._params = [p for p in model.parameters() if p.requires_grad]
         self.fused = fused_optimizer      # FusedAdamWEMA (GPU): clip + AdamW + EMA + zero_grad + all-reduce
         self.hip_graph, self.graph_after = hip_graph, graph_after
-        self._graphed, self._calls, self._graph_shape = None, 0, None
+        self._graphs, self._calls = {}, 0
         self.gc_freeze_after = int(os.environ.get("DFINE_GC_FREEZE_AFTER", "3"))      # 0 = never
 
     def optimizer_step(self, step_scheduler=True):
@@ -191,20 +353,22 @@ class TrainStep:
 
     def _forward(self, images, targets):
         model = self.model
-        use_graph = (self.hip_graph and images.is_cuda and not isinstance(model, DDP)
-                     and hasattr(model, "backbone") and self._calls >= self.graph_after)
+        use_graph = (self.hip_graph and images.is_cuda and self.fused is not None and not isinstance(model, DDP)
+                     and hasattr(model, "backbone") and self._calls > self.graph_after and torch.is_grad_enabled())
+        if use_graph:
+            from .. import hip
+            use_graph = not hip._TIMING_ON       # per-launch HIP events only exist for eager launches
         if not use_graph:
             return model(images, targets=targets)
-        if self._graphed is None or self._graph_shape != tuple(images.shape):
-            # Capture on the FIRST call, before any eager .backward(): an AccumulateGrad node created on
-            # the default stream by an earlier eager backward makes the later capture segfault on this
-            # torch/ROCm build (tools/graph_probe6.py).  GraphedSegment's own warm-up iterations (side
-            # stream, torch.autograd.grad) run the conv autotuner / MIOpen find eagerly first.
+        key = (tuple(images.shape), images.dtype)
+        seg = self._graphs.get(key)
+        if seg is None:
+            if len(self._graphs) >= int(os.environ.get("DFINE_GRAPH_SHAPES", "4")):      # multiscale training: a few input sizes
+                self._graphs.pop(next(iter(self._graphs)))
             be = _BackboneEncoder(model.backbone, model.encoder)
-            self._graphed = GraphedSegment(be, (images,), amp_dtype=self.amp_dtype)
-            self._graph_shape = tuple(images.shape)
+            seg = self._graphs[key] = GraphedSegment(be, (images,), amp_dtype=self.amp_dtype, fused=self.fused)
         with torch.autocast("cuda", enabled=False):
-            feats = self._graphed(images)
+            feats = seg(images)
         return model.decoder(list(feats), targets)
 
     def __call__(self, images, targets):
@@ -214,7 +378,7 @@ class TrainStep:
             from .. import kernels
             kernels.defer_bn_counters(True)      # one multi-tensor add per step instead of 133 scalar adds
         if self.amp_dtype is not None:
-            with torch.autocast(dev_type, dtype=self.amp_dtype, cache_enabled=not self.hip_graph):
+            with torch.autocast(dev_type, dtype=self.amp_dtype):
                 outputs = self._forward(images, targets)
         else:
             outputs = self._forward(images, targets)

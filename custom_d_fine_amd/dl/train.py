@@ -67,6 +67,24 @@ def load_config(argv):
     return cfg
 
 
+def shard_batches(n, rank, world, batch_size, seed):
+    """Index lists of one rank's batches for one epoch over a dataset of `n` samples: torch's DistributedSampler with
+    shuffle and drop_last=False (ref dataset.py:562-568) followed by a DataLoader that keeps the short last batch - a
+    permutation seeded by `seed` (the same on every rank), wrapped around to world * ceil(n / world) entries, rank r takes
+    entries r, r + world, ...  Every rank gets ceil(ceil(n / world) / batch_size) batches."""
+    import random
+    if n <= 0:
+        return []
+    order = list(range(n))
+    random.Random(seed).shuffle(order)
+    per_rank = -(-n // world)
+    total = per_rank * world
+    while len(order) < total:
+        order += order[: total - len(order)]
+    mine = order[rank:total:world]
+    return [mine[i: i + batch_size] for i in range(0, per_rank, batch_size)]
+
+
 class Trainer:
     def __init__(self, cfg):
         t = cfg["train"]
@@ -96,7 +114,7 @@ class Trainer:
         if t.get("data_path"):           # one epoch = one pass over this rank's shard of the folder
             from . import data_device
             self._dataset = data_device.YoloTxtDataset(t["data_path"], t["img_size"])
-            t["steps_per_epoch"] = max(len(self._dataset) // (t["batch_size"] * self.world), 1)
+            t["steps_per_epoch"] = len(shard_batches(len(self._dataset), self.rank, self.world, t["batch_size"], 0))
         sched = None
         if t["use_scheduler"]:
             sched = torch.optim.lr_scheduler.OneCycleLR(
@@ -185,22 +203,23 @@ class Trainer:
 
     def _batches(self, epoch):
         """(images, targets) of one epoch: a YOLO-txt folder sharded over the ranks like the reference's DistributedSampler
-        (dataset.py:562-568: a per-epoch permutation, every world-th index from `rank`), or synthetic batches."""
+        (dataset.py:562-568: a per-epoch permutation shared by the ranks, padded by wrap-around to a multiple of the world
+        size, every world-th index from `rank`; the loader keeps the short last batch), or synthetic batches.  Every rank
+        yields the same number of batches (the fused optimizer all-reduces every step)."""
         import random
         t = self.cfg["train"]
         size = t["img_size"][0]
-        rng = random.Random(t["seed"] + 7919 * epoch)
         if t.get("data_path"):
             from . import data_device
             if getattr(self, "_dataset", None) is None:
                 self._dataset = data_device.YoloTxtDataset(t["data_path"], t["img_size"])
-            order = list(range(len(self._dataset)))
-            rng.shuffle(order)
-            mine = order[self.rank::self.world]
-            for i in range(0, len(mine) - t["batch_size"] + 1, t["batch_size"]):
-                images, targets = self._dataset.batch(mine[i: i + t["batch_size"]], self.device, t.get("mosaic_prob", 0.0), rng)
-                if t.get("multiscale_prob", 0) and rng.random() < t["multiscale_prob"] and self.device.type == "cuda":
-                    images, targets = data_device.multiscale_collate(images, targets, rng.choice([-2, -1, 1, 2]) * 32)
+            # two streams: the permutation is shared by the ranks; mosaic partners, affine draws and the multiscale offset are
+            # this rank's own (the reference's loader workers draw independently per rank)
+            aug = random.Random((t["seed"], epoch, self.rank).__repr__())
+            for idx in shard_batches(len(self._dataset), self.rank, self.world, t["batch_size"], t["seed"] + 7919 * epoch):
+                images, targets = self._dataset.batch(idx, self.device, t.get("mosaic_prob", 0.0), aug)
+                if t.get("multiscale_prob", 0) and aug.random() < t["multiscale_prob"] and self.device.type == "cuda":
+                    images, targets = data_device.multiscale_collate(images, targets, aug.choice([-2, -1, 1, 2]) * 32)
                 yield images, targets
             return
         for it in range(t["steps_per_epoch"]):

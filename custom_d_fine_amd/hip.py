@@ -53,6 +53,7 @@ _SIGNATURES = {
     "dfine_adamw_ema_step": (c_int, [_P, _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _I, _F, _F, _F, _P]),
     "dfine_ema_update": (c_int, [_P, _P, _L, _F, _P]),
     "dfine_multi_copy_f32": (c_int, [_P, _I, _P, _P]),
+    "dfine_multi_add_f32": (c_int, [_P, _I, _P, _P]),
     "dfine_multi_cast_bf16": (c_int, [_P, _I, _P]),
     "dfine_conv_packed_elems": (_L, [_I, _I, _I, _I]),
     "dfine_conv_pack_weights": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
@@ -62,6 +63,7 @@ _SIGNATURES = {
     "dfine_conv_fwd_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_conv1x1_accum_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_stream_fork": (c_int, [_P, _P]),
+    "dfine_upload": (c_int, [_P, _P, _L, _P]),
     "dfine_conv_epilogue_supported": (c_int, [_I, _I, _I, _I, _I, _I]),
     "dfine_conv_accum_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_conv_wgrad_ws_floats": (_L, [_I, _I, _I, _I, _I, _I]),
@@ -246,6 +248,28 @@ def _stream():
     if _raw_stream is not None:
         return _raw_stream(_raw_device() if _raw_device is not None else torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+class CaptureArena:
+    """Pinned host memory a capturing segment owns: staging for the table uploads recorded in its graphs (dfine_upload)."""
+
+    def __init__(self, nbytes=8 << 20):
+        self.buf = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self.off = 0
+
+    def upload(self, t, device):
+        """CPU tensor -> device tensor through a slice of the arena, on the current stream."""
+        t = t.contiguous()
+        n = t.numel() * t.element_size()
+        off = (self.off + 63) // 64 * 64
+        if off + n > self.buf.numel():
+            raise RuntimeError("capture arena exhausted (table uploads recorded in a HIP graph)")
+        self.off = off + n
+        host = self.buf[off:off + n].view(t.dtype).view(t.shape)
+        host.copy_(t)
+        dst = torch.empty(t.shape, dtype=t.dtype, device=device)
+        _check(_lib.dfine_upload(dst.data_ptr(), host.data_ptr(), n, _stream()), "dfine_upload")
+        return dst
 
 
 def _ptr(t):
@@ -834,8 +858,17 @@ _SIDE_PRIORITY = int(os.environ.get("DFINE_SIDE_PRIORITY", "0"))       # stream 
 _SIDE_GROUP_AT = int(os.environ.get("DFINE_WGRAD_GROUP_AT", "32"))     # registered problems that trigger an early grouped launch (12 / 48 / never: +0.13 / 0 / +0.4 ms per step)
 
 
+CAPTURE_SIDE = False      # set by dl.engine.GraphedSegment while it captures: the side stream is forked into the capture (and joined
+                          # before the capture ends), so the weight-gradient launches keep their second stream inside the graph
+
+
+CAPTURE_DUAL = None       # set by dl.engine.GraphedSegment while it captures a backward pass as a CHAIN of graph pairs: the side
+                          # stream records its own graphs next to the main stream's (no event between two captures); the object's
+                          # side_launch() is told about every side-stream launch and decides where one pair ends and the next begins
+
+
 def _side_ok():
-    return WGRAD_STREAM and not _TIMING_ON and not torch.cuda.is_current_stream_capturing()
+    return WGRAD_STREAM and not _TIMING_ON and (CAPTURE_SIDE or CAPTURE_DUAL is not None or not torch.cuda.is_current_stream_capturing())
 
 
 def side_stream_ok():
@@ -856,13 +889,32 @@ def _side_fork(dev):
     st = _SIDE.get(dev.index)
     if st is None:
         st = _SIDE[dev.index] = _SideStream(dev)
+    if CAPTURE_DUAL is not None:
+        CAPTURE_DUAL.side_launch()       # the replay orders the pair: main graph, event, side graph (dl/engine.py)
+        return st
     if _lib.dfine_stream_fork(_stream(), st.cuda_stream) != 0:
         _check(-2, "dfine_stream_fork")
     return st
 
 
+def side_stream(dev):
+    """The side stream object of a device (made on first use), without any ordering."""
+    st = _SIDE.get(dev.index)
+    if st is None:
+        st = _SIDE[dev.index] = _SideStream(dev)
+    return st
+
+
+def stream_wait(src, dst):
+    """Raw stream `dst` waits for everything enqueued on raw stream `src` so far."""
+    if _lib.dfine_stream_fork(src, dst) != 0:
+        _check(-2, "dfine_stream_fork")
+
+
 def side_join():
     """The current stream waits for the side stream's launches (called before their results are consumed)."""
+    if CAPTURE_DUAL is not None:
+        return                           # the replay joins once, after the last pair; the inputs stay referenced until then
     if _SIDE_LIVE:
         cur = _stream()
         for st in _SIDE.values():
@@ -874,8 +926,9 @@ def side_join():
 def conv_wgrad_supported(H, W, ks):
     """3x3: rows are walked in 16-byte chunks, so the kernel wants W % 8 == 0; narrower maps (the 20x20 level) are run on
     zero-padded copies of x and dy (conv_wgrad_bf16): zero columns of dy add nothing and zero columns of x are the
-    convolution's own padding."""
-    return (ks == 3 and W % 2 == 0 and (W + 7) // 8 * 8 <= 160) or (ks == 1 and (H * W) % 8 == 0)
+    convolution's own padding.  1x1: the pixels of a plane are walked in 16-byte chunks; planes with H * W % 8 != 0 (the
+    10x10 level of a 320 x 320 input) run on copies padded to the next multiple of 8 pixels."""
+    return (ks == 3 and W % 2 == 0 and (W + 7) // 8 * 8 <= 160) or ks == 1
 
 
 def _p16(n):
@@ -886,7 +939,13 @@ def conv_wgrad_bf16(x, dy, ks, partials=False):
     """x [B,Cin,H,W], dy [B,Cout,H,W] bf16 contiguous -> dw [Cout,Cin,ks,ks] f32; partials=True: (ws, meta) for a deferred
     dfine_multi_wgrad_reduce, meta = (splits, Cout, Cin, taps, NP16, CP16)."""
     st = None
-    if ks == 3 and x.shape[3] % 8:
+    need_pad = ks == 3 and x.shape[3] % 8
+    if ks == 1 and (x.shape[2] * x.shape[3]) % 8:
+        # a 1x1 weight gradient is a sum over pixels: the planes as rows of hw pixels, zero-padded below like the 3x3 case
+        hw = x.shape[2] * x.shape[3]
+        x, dy = x.reshape(x.shape[0], x.shape[1], 1, hw), dy.reshape(dy.shape[0], dy.shape[1], 1, hw)
+        need_pad = True
+    if need_pad:
         padw = (x.shape[3] + 7) // 8 * 8 - x.shape[3]
         if partials and _side_ok():
             # the zero-padded copies are part of the weight-gradient work: made on the side stream too (their blocks belong to
@@ -963,8 +1022,8 @@ def fdr_backward(corners, ref, wtable, reg_scale, g_boxes, g_stat, idx, k=4):
     return g
 
 
-def multi_copy_f32(srcs, dst_offsets, dst_flat, chunk=1 << 16):
-    """Copies the fp32 tensors `srcs` to dst_flat[dst_offsets[i] : +numel] with one launch."""
+def multi_copy_f32(srcs, dst_offsets, dst_flat, chunk=1 << 16, add=False):
+    """Copies (add: adds) the fp32 tensors `srcs` to dst_flat[dst_offsets[i] : +numel] with one launch."""
     import numpy as np
     rows = []
     for t, off in zip(srcs, dst_offsets):
@@ -973,8 +1032,10 @@ def multi_copy_f32(srcs, dst_offsets, dst_flat, chunk=1 << 16):
             rows.append((p + 4 * c0, off + c0, min(chunk, n - c0)))
     if not rows:
         return
-    table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dst_flat.device, non_blocking=True)
-    _check(_lib.dfine_multi_copy_f32(_ptr(table), len(rows), _ptr(dst_flat), _stream()), "dfine_multi_copy_f32")
+    from .d_fine.arch.utils import upload
+    table = upload(np.asarray(rows, dtype=np.int64), dst_flat.device)
+    fn = _lib.dfine_multi_add_f32 if add else _lib.dfine_multi_copy_f32
+    _check(fn(_ptr(table), len(rows), _ptr(dst_flat), _stream()), "dfine_multi_add_f32" if add else "dfine_multi_copy_f32")
     return table      # keep alive until the stream has consumed it
 
 

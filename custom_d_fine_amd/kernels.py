@@ -468,6 +468,32 @@ def bump_weight_epoch():
 _CAPTURE_POSSIBLE = False      # set by dl.engine.GraphedSegment: only then is the capture query worth a call per layer
 _CAPTURE_FROZEN_WEIGHTS = False   # set by infer.Torch_model while it captures: the weights never change again, so the cached
                                   # packed / bf16 copies (filled by its eager warm-up) are served inside the capture
+_CAPTURE_SHADOWS = False          # set by dl.engine.GraphedSegment while it captures a TRAINING segment: the registered packed /
+                                  # bf16 copies live at fixed addresses and the segment refreshes all of them (one launch per kind,
+                                  # `refresh_weight_shadows`) in front of every replay, so they are served inside the capture too
+
+
+def _recording_packs():
+    """True inside a HIP-graph capture whose replays see changed weights that nobody refreshes outside the graph: the pack /
+    cast launch itself must then be recorded, and the caches neither served nor filled."""
+    return (_CAPTURE_POSSIBLE and not _CAPTURE_FROZEN_WEIGHTS and not _CAPTURE_SHADOWS
+            and torch.cuda.is_current_stream_capturing())
+
+
+def _capturing_training_segment():
+    return _CAPTURE_SHADOWS and torch.cuda.is_current_stream_capturing()
+
+
+def refresh_weight_shadows(device):
+    """Brings every registered packed / bf16 / transposed-bf16 weight copy up to date with the master weights (at most one
+    launch per kind, nothing when no optimizer step happened since the last refresh).  The eager path does this lazily on
+    the first request after a step; a captured segment (dl.engine.GraphedSegment) calls it in front of every replay."""
+    if _PACK_REGISTRY and _PACK_BATCH_EPOCH != _WEIGHT_EPOCH:
+        _pack_all_registered(device)
+    if _BF16_REGISTRY and _BF16_EPOCH != _WEIGHT_EPOCH:
+        _refresh_bf16_params(device)
+    if _BF16T_REGISTRY and _BF16T_EPOCH != _WEIGHT_EPOCH:
+        _refresh_bf16_t(device)
 
 
 # Every (weight, layout) pair the model has asked for is remembered; the first request after an optimizer step
@@ -509,7 +535,7 @@ def _pack_all_registered(device):
 
 
 def _packed_weights(weight, dgrad):
-    if _CAPTURE_POSSIBLE and not _CAPTURE_FROZEN_WEIGHTS and torch.cuda.is_current_stream_capturing():
+    if _recording_packs():
         # inside a HIP-graph capture the pack launch itself must be recorded (the weights change
         # between replays), so never serve or fill the cache here
         return _hip().conv_pack_weights(weight.detach().float().contiguous(), dgrad)
@@ -518,15 +544,19 @@ def _packed_weights(weight, dgrad):
     batchable = weight.dtype == torch.float32 and weight.is_contiguous()
     if ent is not None and ent[0]() is weight and batchable:
         if _PACK_BATCH_EPOCH != _WEIGHT_EPOCH:
+            if _capturing_training_segment():
+                raise RuntimeError("packed weights are stale inside a segment capture (refresh_weight_shadows was not called)")
             _pack_all_registered(weight.device)
         if ent[4] == weight._version and ent[3] == weight.data_ptr():
             return ent[2]
+        if _capturing_training_segment():
+            return _hip().conv_pack_weights(weight.detach().float().contiguous(), dgrad)     # recorded, cache untouched
         # updated in place by torch since the batch pack (plain optimizers): repack this one
         ent[2].copy_(_hip().conv_pack_weights(weight.detach(), dgrad))
         ent[3], ent[4] = weight.data_ptr(), weight._version
         return ent[2]
     w2 = _hip().conv_pack_weights(weight.detach().float().contiguous(), dgrad)
-    if batchable:
+    if batchable and not _capturing_training_segment():       # (a copy made inside a capture lives in the graph's pool)
         global _PACK_TABLE
         # a new or REPLACED entry (id() reuse after an earlier model was freed) invalidates the device pointer table:
         # neither len() nor the data_ptr check of _pack_all_registered would notice a replaced key
@@ -573,17 +603,23 @@ def bf16_param(p):
     """bf16 copy of an fp32 CUDA parameter, cached until the weights change."""
     if p.dtype == torch.bfloat16:
         return p.detach()
-    if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()) or (
-            _CAPTURE_POSSIBLE and not _CAPTURE_FROZEN_WEIGHTS and torch.cuda.is_current_stream_capturing()):
+    if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()) or _recording_packs():
         return p.detach().to(torch.bfloat16)
     ent = _BF16_REGISTRY.get(id(p))
     if ent is not None and ent[0]() is p:
+        seg = _capturing_training_segment()
         if _BF16_EPOCH != _WEIGHT_EPOCH:
+            if seg:
+                raise RuntimeError("bf16 weight shadows are stale inside a segment capture (refresh_weight_shadows was not called)")
             _refresh_bf16_params(p.device)
         if ent[3] != p._version or ent[2] != p.data_ptr():       # changed in place by plain torch code
+            if seg:
+                return p.detach().to(torch.bfloat16)
             ent[1].copy_(p.detach())
             ent[2], ent[3] = p.data_ptr(), p._version
         return ent[1]
+    if _capturing_training_segment():
+        return p.detach().to(torch.bfloat16)                    # recorded in the graph, cache untouched
     c = p.detach().to(torch.bfloat16)
     global _BF16_TABLE
     _BF16_REGISTRY[id(p)] = [weakref.ref(p), c, p.data_ptr(), p._version]
@@ -628,17 +664,23 @@ def _refresh_bf16_t(device):
 def bf16_param_t(p):
     """bf16 TRANSPOSE [K, N] of a 2-d fp32 CUDA parameter [N, K], cached until the weights change."""
     global _BF16T_TABLE
-    if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.dim() == 2) or (
-            _CAPTURE_POSSIBLE and not _CAPTURE_FROZEN_WEIGHTS and torch.cuda.is_current_stream_capturing()):
+    if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.dim() == 2) or _recording_packs():
         return p.detach().t().to(torch.bfloat16).contiguous()
     ent = _BF16T_REGISTRY.get(id(p))
     if ent is not None and ent[0]() is p:
+        seg = _capturing_training_segment()
         if _BF16T_EPOCH != _WEIGHT_EPOCH:
+            if seg:
+                raise RuntimeError("bf16 weight shadows are stale inside a segment capture (refresh_weight_shadows was not called)")
             _refresh_bf16_t(p.device)
         if ent[3] != p._version or ent[2] != p.data_ptr():       # changed in place by plain torch code
+            if seg:
+                return p.detach().t().to(torch.bfloat16).contiguous()
             ent[1].copy_(p.detach().t())
             ent[2], ent[3] = p.data_ptr(), p._version
         return ent[1]
+    if _capturing_training_segment():
+        return p.detach().t().to(torch.bfloat16).contiguous()    # recorded in the graph, cache untouched
     c = p.detach().t().to(torch.bfloat16).contiguous()
     _BF16T_REGISTRY[id(p)] = [weakref.ref(p), c, p.data_ptr(), p._version]
     _BF16T_TABLE = None
@@ -1064,6 +1106,8 @@ _STEM_DGRAD_S2 = {(48, 24), (32, 16), (64, 32)}      # (Cin, Cout) of the instan
 
 
 def _packed_stem(weight, mode):
+    if _CAPTURE_POSSIBLE and not _CAPTURE_FROZEN_WEIGHTS and torch.cuda.is_current_stream_capturing():
+        return _hip().stem_pack_weights(weight.detach().float().contiguous(), mode)     # recorded: the weights change between replays
     key = (id(weight), "stem", mode)
     tag = (_WEIGHT_EPOCH, weight._version, weight.data_ptr())
     hit = _PACK_CACHE.get(key)
@@ -2203,6 +2247,8 @@ def mask_cost_sums(pm, gt, toff, q, tmax, alpha, gamma):
 # A1 / A2 in fp32 (configs[1]): dense convolutions on the f32-input matrix cores (csrc/conv_f32.hip)
 # =============================================================================================
 def _packed_f32(weight, dgrad):
+    if _CAPTURE_POSSIBLE and not _CAPTURE_FROZEN_WEIGHTS and torch.cuda.is_current_stream_capturing():
+        return _hip().conv_f32_pack_weights(weight.detach().float().contiguous(), dgrad)
     key = (id(weight), "f32", dgrad)
     tag = (_WEIGHT_EPOCH, weight._version, weight.data_ptr())
     hit = _PACK_CACHE.get(key)

@@ -41,6 +41,11 @@ const char *dfine_last_error(void);
  * ring): fork / join of the second stream that runs the weight-gradient launches of a backward pass next to the data-gradient
  * chain (the reference runs both on one stream through autograd: torch.Tensor.backward in src/dl/train.py:575). */
 int dfine_stream_fork(void *from, void *to);
+/* hipMemcpyAsync(dst, src, bytes, HostToDevice, stream) from memory the caller keeps pinned, alive and unchanged: the pointer
+ * tables of launches recorded inside a HIP-graph capture of the backward pass (custom_d_fine_amd/dl/engine.py; the reference
+ * launches the same work eagerly from torch.Tensor.backward, src/dl/train.py:575).  The copy becomes a memcpy node that
+ * re-reads `src` at every replay. */
+int dfine_upload(void *dst, const void *src, int64_t bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A7  Multi-scale deformable attention gather.
@@ -272,6 +277,11 @@ int dfine_ema_update(float *ema, const float *src, int64_t n, float momentum, vo
  * table = DEVICE array of n_entries records {const float *src; int64_t dst_offset; int64_t count}
  * (24 bytes each, one block per record; split large tensors into <= 64 K element records). */
 int dfine_multi_copy_f32(const void *table, int n_entries, float *dst, void *stream);
+/* Same records, dst[dst_offset + i] += src[i]: the gradient tensors a captured backward segment (HIP graph of backbone +
+ * encoder, custom_d_fine_amd/dl/engine.py) leaves are ADDED to the flat gradient buffer inside the graph - what
+ * AccumulateGrad does per parameter in src/dl/train.py:570-575 (`loss.backward()`), also across the micro-steps of a
+ * gradient-accumulation window.  Records of one launch must not overlap in dst. */
+int dfine_multi_add_f32(const void *table, int n_entries, float *dst, void *stream);
 /* bf16 shadow copies of the fp32 master weights (what autocast's per-call casts of nn.Linear / nn.Conv2d weights
  * produce, the modules of src/d_fine/arch under torch.autocast in src/dl/train.py:524-531) refreshed once per optimizer step:
  * device table of {const float *src; bf16 *dst; int64 n} records. */

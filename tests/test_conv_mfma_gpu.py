@@ -36,7 +36,7 @@ def test_conv_fwd_and_dgrad(cuda, B, Cin, Cout, H, W, KS):
     assert (y.float() - yr).abs().max().item() < 1.5e-2 * scale
     gscale = xr.grad.abs().max().item()
     assert (xg.grad.float() - xr.grad).abs().max().item() < 1.5e-2 * gscale
-    # weight gradient (MFMA split-K kernel, or MIOpen when W % 8 != 0)
+    # weight gradient (MFMA split-K kernel; zero-padded copies when W % 8 != 0 (3x3) / H * W % 8 != 0 (1x1))
     wr = wb.clone().requires_grad_(True)
     F.conv2d(x.float(), wr, padding=KS // 2).backward(go.float())
     wscale = wr.grad.abs().max().item()

@@ -197,3 +197,43 @@ def test_dataset_batch_with_mosaic(cuda, tmp_path):
     plain, _ = ds.batch([0, 1, 2], cuda)
     plain0, _ = ds.batch([0, 1, 2], cuda, mosaic_prob=0.0, rng=random.Random(5))
     assert torch.equal(plain, plain0) and not torch.equal(plain, im1)
+
+
+@pytest.mark.parametrize("n,world,bs", [(31, 2, 8), (47, 4, 4), (15, 2, 8), (1, 4, 8), (64, 8, 8), (100, 3, 7)])
+def test_shard_batches_same_count_on_every_rank(n, world, bs):
+    """The ranks of a data-parallel run must yield the same number of batches (every step all-reduces); sharding follows
+    torch's DistributedSampler(shuffle=True, drop_last=False): one shared permutation, wrapped around to a multiple of the
+    world size, strided by rank (ref dataset.py:562-568); the loader keeps the short last batch."""
+    from custom_d_fine_amd.dl.train import shard_batches
+    from torch.utils.data import DistributedSampler
+    per_rank = [shard_batches(n, r, world, bs, seed=5) for r in range(world)]
+    counts = {len(b) for b in per_rank}
+    assert len(counts) == 1 and counts.pop() == -(-(-(-n // world)) // bs) >= 1
+    assert all(len(b) > 0 for batches in per_rank for b in batches)
+    flat = [[i for b in batches for i in b] for batches in per_rank]
+    assert len({len(f) for f in flat}) == 1
+    assert set(i for f in flat for i in f) == set(range(n))               # every sample is seen
+    # same structure as the reference's sampler: per-rank sample count and the multiset of indices over all ranks
+    ref = [list(DistributedSampler(range(n), num_replicas=world, rank=r, shuffle=True, drop_last=False, seed=0)) for r in range(world)]
+    assert [len(f) for f in flat] == [len(f) for f in ref]
+    import collections
+    assert sorted(collections.Counter(i for f in flat for i in f).values()) == sorted(collections.Counter(i for f in ref for i in f).values())
+    assert shard_batches(0, 0, world, bs, 1) == []
+
+
+def test_trainer_epoch_schedule_matches_batches(tmp_path):
+    """steps_per_epoch (the OneCycleLR length) is the number of batches a rank really runs, also when the folder does not
+    divide by world * batch size."""
+    from PIL import Image
+    from custom_d_fine_amd.dl import train as T
+    (tmp_path / "images").mkdir(); (tmp_path / "labels").mkdir()
+    rs = np.random.RandomState(0)
+    for i in range(7):
+        Image.fromarray(rs.randint(0, 255, (40, 48, 3), dtype=np.uint8)).save(tmp_path / "images" / f"{i}.png")
+        (tmp_path / "labels" / f"{i}.txt").write_text("0 0.5 0.5 0.2 0.2\n")
+    from custom_d_fine_amd.dl.data_device import YoloTxtDataset
+    n = len(YoloTxtDataset(str(tmp_path), [64, 64]))
+    assert n == 7
+    for world in (1, 2, 4):
+        for rank in range(world):
+            assert len(T.shard_batches(n, rank, world, 2, 3)) == -(-(-(-n // world)) // 2)

@@ -3,6 +3,7 @@
     python tools/ab_step.py hip.WGRAD_STREAM            # module attribute toggled False / True
     python tools/ab_step.py env:DFINE_GRAD_FANIN        # environment switch "0" / "1" + kernels.reload_env()
     python tools/ab_step.py hip._SIDE_GROUP_AT=12,48    # module attribute set to the first / second value
+    python tools/ab_step.py step.hip_graph              # eager / HIP-graph replay of backbone + encoder
     AB_BLOCKS=12 AB_STEPS=8 python tools/ab_step.py ..."""
 import os, sys, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,6 +32,9 @@ def setting(on):
         if on:
             _CTX[0] = torch.cuda.stream(_HI)
             _CTX[0].__enter__()
+        return
+    if what == "step.hip_graph":                       # backbone + encoder through the captured HIP graphs (dl/engine.GraphedSegment)
+        step.hip_graph = bool(on)
         return
     if what.startswith("env:"):
         os.environ[what[4:]] = "1" if on else "0"

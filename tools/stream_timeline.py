@@ -12,9 +12,11 @@ from custom_d_fine_amd.dl.synthetic import make_batch
 ap = argparse.ArgumentParser()
 ap.add_argument("--ms", type=float, default=1.0)
 ap.add_argument("--warmup", type=int, default=5)
+ap.add_argument("--graph", type=int, default=0, help="1: backbone + encoder through the captured HIP graphs")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 step = bench.build_step("m", 640, dev, torch.bfloat16)
+step.hip_graph = bool(a.graph)
 images, targets = make_batch(32, 640, seed=42, device=dev)
 for _ in range(a.warmup):
     step(images, targets)
