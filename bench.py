@@ -67,7 +67,7 @@ def build_step(model_name, img, device, amp_dtype, num_classes=80, channels_last
                                                 pct_start=0.1, cycle_momentum=False)
     return TrainStep(model, criterion, opt, amp_dtype=amp_dtype, clip_max_norm=0.1, ema=ema,
                      scheduler=sched, fused_optimizer=fused,
-                     hip_graph=device.type == "cuda" and os.environ.get("DFINE_HIPGRAPH", "0") == "1")
+                     hip_graph=device.type == "cuda" and fused is not None and os.environ.get("DFINE_HIPGRAPH", "1") == "1")
 
 
 def msda_algorithmic_bytes(batch, lq, heads=8, head_dim=32, points=12, elt=2, backward=False):

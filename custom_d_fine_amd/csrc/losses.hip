@@ -48,18 +48,21 @@ __global__ __launch_bounds__(kLT) void pair_box_kernel(
     const int64_t *__restrict__ cls_plan, int M_cls, float *__restrict__ iou_cls, int *__restrict__ map_cls, int nb_cls,
     const int64_t *__restrict__ box_plan, int M_box, float *__restrict__ iou_box, int *__restrict__ map_box, int Q,
     float *__restrict__ grad_l1, float *__restrict__ grad_giou,
-    float *__restrict__ out /* [0]+=l1 sum, [1]+=(1-giou) sum */, float s_l1, float s_giou) {
+    float *__restrict__ out /* [0]+=l1 sum, [1]+=(1-giou) sum */, float s_l1, float s_giou,
+    const float *__restrict__ dev_scales, const int *__restrict__ dev_m_box) {
     __shared__ float red[kLT / 64];
+    if (dev_scales) { s_l1 = dev_scales[1]; s_giou = dev_scales[2]; }   // normalisers computed on the device (csrc/plans.hip)
     const bool is_cls = (int)blockIdx.x < nb_cls;                       // uniform per block
     const int64_t *__restrict__ plan = is_cls ? cls_plan : box_plan;
-    const int M = is_cls ? M_cls : M_box;
+    const int M = is_cls ? M_cls : M_box;                               // row stride of the plan
+    const int count = (!is_cls && dev_m_box) ? *dev_m_box : M;          // valid entries (the GO plan's length lives on the device)
     float *__restrict__ iou_out = is_cls ? iou_cls : iou_box;
     int *__restrict__ map = is_cls ? map_cls : map_box;
     const int with_loss = is_cls ? 0 : 1;
     const int m = ((int)blockIdx.x - (is_cls ? 0 : nb_cls)) * kLT + threadIdx.x;
     float l1 = 0.f, lg = 0.f;
-    if (m < M) {
-        const int64_t b = plan[m], q = plan[M + m], t = plan[2 * M + m];
+    if (m < count) {
+        const int64_t b = plan[m], q = plan[M + m], t = plan[2 * (int64_t)M + m];
         const T *sp = boxes + b * bv.sb + q * bv.sq;
         const float cx = load_f(sp), cy = load_f(sp + 1), w = load_f(sp + 2), h = load_f(sp + 3);
         const float4 tb = *reinterpret_cast<const float4 *>(tgt_boxes + t * 4);
@@ -213,15 +216,15 @@ template <typename T, int NB>
 __device__ __forceinline__ void fgl_body(int blk, float *red, const T *__restrict__ pred, View pv,
                                          const float *__restrict__ ref, View rv,
                                          const float *__restrict__ tgt_boxes,
-                                         const int64_t *__restrict__ plan, int M, int Q,
+                                         const int64_t *__restrict__ plan, int M, int count, int Q,
                                          const float *__restrict__ iou, const FglTable &tab,
                                          float s_fgl, T *__restrict__ grad,
                                          float *__restrict__ out) {
     const int r = blk * kLT + threadIdx.x;
     float loss = 0.f;
-    if (r < M * 4) {
+    if (r < count * 4) {
         const int m = r >> 2, edge = r & 3;
-        const int64_t b = plan[m], q = plan[M + m], t = plan[2 * M + m];
+        const int64_t b = plan[m], q = plan[M + m], t = plan[2 * (int64_t)M + m];
         const float *rp = ref + b * rv.sb + q * rv.sq;
         const float px = rp[0], py = rp[1], pw = rp[2], ph = rp[3];
         const float4 tb = *reinterpret_cast<const float4 *>(tgt_boxes + t * 4);
@@ -281,6 +284,7 @@ struct Phase2 {
     float temp, c_pos, c_neg; T *grad_ddf;
     const float *ref; View rv; const float *tgt_boxes; const int64_t *box_plan; int M_box; float s_fgl; T *grad_fgl;
     float *out; int B, Q, C, nb_vfl, nb_ddf;
+    const float *dev_scales; const int *dev_m_box;        // device-resident normalisers / box-plan length (or null)
     FglTable tab;
 };
 
@@ -288,15 +292,16 @@ template <typename T>
 __global__ __launch_bounds__(kLT) void head_phase2_kernel(const Phase2<T> a) {
     __shared__ float red[kLT / 64];
     const int blk = blockIdx.x;
+    const float *ds = a.dev_scales;
     if (blk < a.nb_vfl)
         vfl_body<T>(blk, a.nb_vfl, red, a.logits, a.lv, a.map_cls, a.cls_plan, a.M_cls, a.labels, a.iou_cls, a.B, a.Q, a.C, a.alpha,
-                    a.gamma, a.s_vfl, a.grad_logits, a.out);
+                    a.gamma, ds ? ds[0] : a.s_vfl, a.grad_logits, a.out);
     else if (blk < a.nb_vfl + a.nb_ddf)
         ddf_body<T, 33>(blk - a.nb_vfl, red, a.corners, a.pv, a.teacher, a.tcv, a.map_box, a.tlogits, a.tlv, a.iou_box, a.B, a.Q, a.C,
-                        a.temp, a.c_pos, a.c_neg, a.grad_ddf, a.out + 4);
+                        a.temp, ds ? ds[4] : a.c_pos, ds ? ds[5] : a.c_neg, a.grad_ddf, a.out + 4);
     else
-        fgl_body<T, 33>(blk - a.nb_vfl - a.nb_ddf, red, a.corners, a.pv, a.ref, a.rv, a.tgt_boxes, a.box_plan, a.M_box, a.Q, a.iou_box,
-                        a.tab, a.s_fgl, a.grad_fgl, a.out + 3);
+        fgl_body<T, 33>(blk - a.nb_vfl - a.nb_ddf, red, a.corners, a.pv, a.ref, a.rv, a.tgt_boxes, a.box_plan, a.M_box,
+                        a.dev_m_box ? *a.dev_m_box : a.M_box, a.Q, a.iou_box, a.tab, ds ? ds[3] : a.s_fgl, a.grad_fgl, a.out + 3);
 }
 
 // Backward of the fused head losses: the closed-form gradients of the forward pass scaled by the upstream gradient g[5] of
@@ -335,6 +340,18 @@ __global__ __launch_bounds__(256) void head_grads_scale_kernel(const float *__re
 
 using namespace dfine;
 
+static int head_losses_impl(
+    const void *logits, int64_t l_sb, int64_t l_sq, const float *boxes, int64_t b_sb, int64_t b_sq,
+    const void *corners, int64_t c_sb, int64_t c_sq, const float *ref, int64_t r_sb, int64_t r_sq,
+    const void *teacher_corners, int64_t tc_sb, int64_t tc_sq, const void *teacher_logits,
+    int64_t tl_sb, int64_t tl_sq, const int64_t *cls_plan, int M_cls, const int64_t *box_plan,
+    int M_box, const int64_t *tgt_labels, const float *tgt_boxes, const float *wtable, int reg_max,
+    float reg_scale, float alpha, float gamma, float temp, float s_vfl, float s_l1, float s_giou,
+    float s_fgl, float ddf_c_pos, float ddf_c_neg,
+    void *grad_logits, float *grad_l1, float *grad_giou, void *grad_corners_fgl,
+    void *grad_corners_ddf, float *iou_cls, float *iou_box, int *map_cls, int *map_box, float *wrow,
+    float *out, int dtype, int B, int Q, int C, const float *dev_scales, const int *dev_m_box, void *stream);
+
 extern "C" {
 
 // out[5] = {vfl, l1, giou, fgl, ddf} sums (zeroed here).  See include/dfine_hip.h.
@@ -349,6 +366,47 @@ int dfine_head_losses(
     void *grad_logits, float *grad_l1, float *grad_giou, void *grad_corners_fgl,
     void *grad_corners_ddf, float *iou_cls, float *iou_box, int *map_cls, int *map_box, float *wrow,
     float *out, int dtype, int B, int Q, int C, void *stream) {
+    return head_losses_impl(logits, l_sb, l_sq, boxes, b_sb, b_sq, corners, c_sb, c_sq, ref, r_sb, r_sq, teacher_corners, tc_sb, tc_sq,
+                            teacher_logits, tl_sb, tl_sq, cls_plan, M_cls, box_plan, M_box, tgt_labels, tgt_boxes, wtable, reg_max,
+                            reg_scale, alpha, gamma, temp, s_vfl, s_l1, s_giou, s_fgl, ddf_c_pos, ddf_c_neg, grad_logits, grad_l1,
+                            grad_giou, grad_corners_fgl, grad_corners_ddf, iou_cls, iou_box, map_cls, map_box, wrow, out, dtype, B, Q,
+                            C, nullptr, nullptr, stream);
+}
+
+// The same launch group with the six scalar factors (s_vfl, s_l1, s_giou, s_fgl, ddf_c_pos, ddf_c_neg) read from DEVICE memory
+// (`scales`, written by dfine_criterion_scales) and, when `box_count` is given, the number of valid entries of the box plan
+// read from device memory too (M_box is then the plan's row stride / capacity).
+int dfine_head_losses_dev(
+    const void *logits, int64_t l_sb, int64_t l_sq, const float *boxes, int64_t b_sb, int64_t b_sq,
+    const void *corners, int64_t c_sb, int64_t c_sq, const float *ref, int64_t r_sb, int64_t r_sq,
+    const void *teacher_corners, int64_t tc_sb, int64_t tc_sq, const void *teacher_logits,
+    int64_t tl_sb, int64_t tl_sq, const int64_t *cls_plan, int M_cls, const int64_t *box_plan,
+    int M_box, const int64_t *tgt_labels, const float *tgt_boxes, const float *wtable, int reg_max,
+    float reg_scale, float alpha, float gamma, float temp, const float *scales, const int *box_count,
+    void *grad_logits, float *grad_l1, float *grad_giou, void *grad_corners_fgl,
+    void *grad_corners_ddf, float *iou_cls, float *iou_box, int *map_cls, int *map_box, float *wrow,
+    float *out, int dtype, int B, int Q, int C, void *stream) {
+    if (!scales) return DFINE_E_BADARG;
+    return head_losses_impl(logits, l_sb, l_sq, boxes, b_sb, b_sq, corners, c_sb, c_sq, ref, r_sb, r_sq, teacher_corners, tc_sb, tc_sq,
+                            teacher_logits, tl_sb, tl_sq, cls_plan, M_cls, box_plan, M_box, tgt_labels, tgt_boxes, wtable, reg_max,
+                            reg_scale, alpha, gamma, temp, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, grad_logits, grad_l1, grad_giou,
+                            grad_corners_fgl, grad_corners_ddf, iou_cls, iou_box, map_cls, map_box, wrow, out, dtype, B, Q, C, scales,
+                            box_count, stream);
+}
+
+}  // extern "C"
+
+static int head_losses_impl(
+    const void *logits, int64_t l_sb, int64_t l_sq, const float *boxes, int64_t b_sb, int64_t b_sq,
+    const void *corners, int64_t c_sb, int64_t c_sq, const float *ref, int64_t r_sb, int64_t r_sq,
+    const void *teacher_corners, int64_t tc_sb, int64_t tc_sq, const void *teacher_logits,
+    int64_t tl_sb, int64_t tl_sq, const int64_t *cls_plan, int M_cls, const int64_t *box_plan,
+    int M_box, const int64_t *tgt_labels, const float *tgt_boxes, const float *wtable, int reg_max,
+    float reg_scale, float alpha, float gamma, float temp, float s_vfl, float s_l1, float s_giou,
+    float s_fgl, float ddf_c_pos, float ddf_c_neg,
+    void *grad_logits, float *grad_l1, float *grad_giou, void *grad_corners_fgl,
+    void *grad_corners_ddf, float *iou_cls, float *iou_box, int *map_cls, int *map_box, float *wrow,
+    float *out, int dtype, int B, int Q, int C, const float *dev_scales, const int *dev_m_box, void *stream) {
     if (!logits || !boxes || !out || !tgt_boxes || !tgt_labels || !grad_logits || !grad_l1 || !grad_giou ||
         !map_cls || !map_box || B < 1 || Q < 1 || C < 1)
         return DFINE_E_BADARG;
@@ -381,7 +439,8 @@ int dfine_head_losses(
     if (M_cls > 0 || M_box > 0) {   // IoU of the classification matching (VFL soft labels); L1 / GIoU of the box matching (+ IoU weights of FGL / DDF)
         const int nb_cls = (M_cls + kLT - 1) / kLT, nb_box = (M_box + kLT - 1) / kLT;
         hipLaunchKernelGGL(pair_box_kernel<float>, dim3(nb_cls + nb_box), dim3(kLT), 0, st, boxes, bv, tgt_boxes, cls_plan, M_cls,
-                           iou_cls, map_cls, nb_cls, box_plan, M_box, iou_box, map_box, Q, grad_l1, grad_giou, out + 1, s_l1, s_giou);
+                           iou_cls, map_cls, nb_cls, box_plan, M_box, iou_box, map_box, Q, grad_l1, grad_giou, out + 1, s_l1, s_giou,
+                           dev_scales, dev_m_box);
     }
     const int64_t n = (int64_t)B * Q * C;
     if (n >= ((int64_t)1 << 31) - 2048 * kLT) return DFINE_E_BADARG;      // the kernels index the logits with 32 bits
@@ -400,6 +459,7 @@ int dfine_head_losses(
         a.ref = ref; a.rv = View{r_sb, r_sq}; a.tgt_boxes = tgt_boxes; a.box_plan = box_plan; a.M_box = M_box; a.s_fgl = s_fgl;
         a.grad_fgl = (T *)grad_corners_fgl;
         a.out = out; a.B = B; a.Q = Q; a.C = C; a.nb_vfl = vb; a.nb_ddf = nb_ddf;
+        a.dev_scales = dev_scales; a.dev_m_box = dev_m_box;
         if (nb_fgl) {
             for (int j = 0; j <= reg_max; ++j) a.tab.w[j] = wtable[j];
             a.tab.reg_max = reg_max; a.tab.reg_scale = reg_scale;
@@ -411,6 +471,8 @@ int dfine_head_losses(
     (void)wrow;          // (the DDF row weights are computed in place by the edge threads; the scratch argument stays in the ABI)
     return check_launch();
 }
+
+extern "C" {
 
 int dfine_head_grads_scale(const float *g, void *grad_logits, int64_t n_logits, float *grad_l1, const float *grad_giou,
                            int64_t n_box, void *grad_corners_fgl, const void *grad_corners_ddf, int64_t n_corners, int dtype,

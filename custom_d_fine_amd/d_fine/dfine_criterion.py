@@ -22,6 +22,11 @@ from .arch.utils import upload, bbox2distance, box_cxcywh_to_xyxy, box_iou, gene
 from .dist_utils import get_world_size, is_dist_available_and_initialized
 
 
+import os
+
+_DEVICE_PLANS = [os.environ.get("DFINE_DEVICE_PLANS", "1") == "1"]      # a list: tools / tests flip it in place
+
+
 def _as_matching(indices):
     from .matcher import Matching
     return indices if isinstance(indices, Matching) else Matching.from_pairs(indices)
@@ -37,6 +42,7 @@ class _Plan:
             packed = upload(self.pack(m, offsets), device)
         self.packed = packed
         self.count = int(m.src.size)
+        self.count_dev = None                # (a plan built from host indices: its length is a host number)
         self.indices = indices
 
     # rows of the packed plan (only the torch-composition path reads them)
@@ -56,6 +62,27 @@ class _Plan:
     def pack(m, offsets):
         offs = np.asarray(offsets[:-1], dtype=np.int64)
         return np.stack([m.img, m.src, m.tgt + (offs[m.img] if m.img.size else m.img)])
+
+
+class _DevPlan:
+    """A gather plan that was built on the device (csrc/plans.hip): int64 [3, capacity] rows (image, query, target row);
+    `count` is the host's knowledge of its length (exact for a head's own matching: every target is matched; the
+    capacity for the GO union, whose true length lives in `count_dev`)."""
+
+    def __init__(self, packed, count, count_dev=None):
+        self.packed, self.count, self.count_dev = packed, int(count), count_dev
+
+    @property
+    def batch(self):
+        return self.packed[0]
+
+    @property
+    def src(self):
+        return self.packed[1]
+
+    @property
+    def tgt(self):
+        return self.packed[2]
 
 
 class DFINECriterion(nn.Module):
@@ -95,6 +122,8 @@ class DFINECriterion(nn.Module):
         return self._tgt[1], self._tgt[2], self._tgt[3]
 
     def _plan(self, indices, targets, device) -> _Plan:
+        if isinstance(indices, (_DevPlan, _Plan)):
+            return indices
         key = id(indices)
         if key not in self._plans:
             self._plans[key] = _Plan(indices, self._targets_cat(targets)[2], device)
@@ -441,6 +470,12 @@ class DFINECriterion(nn.Module):
         self._clear_cache()
         self._tgt = None
         indices_dn = None
+        if fused and _DEVICE_PLANS[0] and hasattr(self.matcher, "match_heads_device"):
+            # no host <-> device synchronisation: the matching stays on the device, the gather plans, the GO union and the
+            # normalisers that depend on its size are built there (csrc/plans.hip)
+            dev_match = self.matcher.match_heads_device(heads, targets)
+            if dev_match is not None:
+                return self._forward_fused_device(outputs, targets, heads, *dev_match)
         if hasattr(self.matcher, "match_heads_async"):
             finish = self.matcher.match_heads_async(heads, targets)
             # host / launch work that does not need the assignment runs while the device computes it
@@ -622,6 +657,113 @@ class DFINECriterion(nn.Module):
         table = torch.nan_to_num(torch.stack(vecs), nan=0.0)      # [heads, 5]
         self.__dict__["_last_table"] = table      # plain attribute: nn.Module.__setattr__ is not needed here
         cells = table.view(-1).unbind(0)                            # one op instead of ~60 selects
+        losses = {}
+        for h, keys in enumerate(names):
+            for k, j in keys:
+                losses[k] = cells[h * 5 + j]
+        self.__dict__["_last_extra"] = list(extra.values())
+        losses.update(extra)
+        return losses
+
+    def _forward_fused_device(self, outputs, targets, heads, cols, tgt_offset, sizes):
+        """The fused head losses with every index set and every size-dependent scalar produced on the device: same launches as
+        `_forward_fused`, fed with device-built plans (`_DevPlan`) and a device-resident table of the scalar factors."""
+        from .. import hip, kernels
+        from .dist_utils import host_all_reduce_sum
+        dev = outputs["pred_logits"].device
+        labels, tboxes, _ = self._targets_cat(targets)
+        labels = labels.to(torch.int64)
+        tboxes = tboxes.float().contiguous()
+        wd = self.weight_dict
+        wtable, reg_scale = self._fdr_constants(outputs)
+        want_vfl, want_box, want_local = ("vfl" in self.losses, "boxes" in self.losses, "local" in self.losses)
+        want_masks, extra = "masks" in self.losses, {}
+        world = get_world_size()
+        T = int(sum(sizes))
+        q_main = outputs["pred_logits"].shape[1]
+        head_plans, go_packed, go_count, go_f = hip.criterion_plans(cols, tgt_offset, sizes, q_main, want_float_count=world > 1)
+        go_sum = None
+        if world > 1:
+            torch.distributed.all_reduce(go_f)        # tiny device collective on the stream (the reference: all_reduce + .item())
+            go_sum = go_f
+        tot = host_all_reduce_sum([float(T)])
+        num_boxes = max(float(np.float32(tot[0]) / np.float32(world)), 1.0)
+        n_aux = len(outputs["aux_outputs"])
+        plans = [_DevPlan(head_plans[k], T) for k in range(len(heads))]
+        go = _DevPlan(go_packed, go_packed.shape[1], go_count)
+        indices_dn = dn_plan = None
+        dn_boxes = 1
+        if "dn_outputs" in outputs:
+            indices_dn = self.get_cdn_matched_indices(outputs["dn_meta"], targets)
+            self._build_plans([indices_dn], targets, dev)
+            dn_plan = self._plan(indices_dn, targets, dev)
+            dn_boxes = num_boxes * outputs["dn_meta"]["dn_num_group"]
+            dn_boxes = dn_boxes if dn_boxes > 0 else 1
+
+        # ---- pass 1: the launches of the step and the host-known part of their scalar factors
+        runs = []
+
+        def add(head, suffix, cls_plan, box_plan, n_cls, n_box, local, is_dn=False):
+            b, q = head["pred_logits"].shape[:2]
+            corners = head.get("pred_corners") if (local and want_local) else None
+            teacher = head.get("teacher_corners") if corners is not None else None
+            if teacher is not None and (teacher is corners or (teacher.data_ptr() == corners.data_ptr() and teacher.shape == corners.shape)):
+                teacher = None          # the teacher itself: KL == 0 (ref dfine_criterion.py:197-198)
+            uses_go = box_plan is go
+            row = (wd["loss_vfl"] / n_cls if want_vfl else 0.0, 1.0 if uses_go else 0.0, float(n_box),
+                   wd["loss_bbox"] if want_box else 0.0, wd["loss_giou"] if want_box else 0.0, wd["loss_fgl"],
+                   wd.get("loss_ddf", 0.0), 1.0 if teacher is not None else 0.0, 1.0 if is_dn else 0.0, 4.0 * (b * q),
+                   4.0 * box_plan.count, 8.0 / b)
+            runs.append((head, suffix, cls_plan, box_plan, corners, teacher, n_cls, row))
+
+        add(outputs, "", plans[0], go, num_boxes, 1.0, True)
+        for i, aux in enumerate(outputs["aux_outputs"]):
+            add(aux, f"_aux_{i}", plans[1 + i], go, num_boxes, 1.0, True)
+        add(outputs["pre_outputs"], "_pre", plans[n_aux + 1], go, num_boxes, 1.0, False)
+        for i, aux in enumerate(outputs["enc_aux_outputs"]):
+            add(aux, f"_enc_{i}", plans[n_aux + 2 + i], go, num_boxes, 1.0, False)
+        if dn_plan is not None:
+            for i, aux in enumerate(outputs["dn_outputs"]):
+                add(aux, f"_dn_{i}", dn_plan, dn_plan, dn_boxes, dn_boxes, True, is_dn=True)
+            if "dn_pre_outputs" in outputs:
+                add(outputs["dn_pre_outputs"], "_dn_pre", dn_plan, dn_plan, dn_boxes, dn_boxes, False, is_dn=True)
+        params = upload(np.asarray([r[-1] for r in runs], dtype=np.float64), dev)
+        scales = hip.criterion_scales(params, go_count, go_sum, world)
+
+        # ---- pass 2: the head-loss launches
+        names, vecs = [], []
+        for r, (head, suffix, cls_plan, box_plan, corners, teacher, n_cls, _) in enumerate(runs):
+            cfg = {"wtable": wtable, "reg_max": self.reg_max, "reg_scale": reg_scale, "alpha": self.alpha, "gamma": self.gamma,
+                   "temp": 5.0, "s_vfl": 0.0, "s_l1": 0.0, "s_giou": 0.0, "s_fgl": 0.0, "c_pos": 0.0, "c_neg": 0.0,
+                   "scales_dev": scales[r], "box_count_dev": box_plan.count_dev}
+            vec = kernels.head_losses(
+                head["pred_logits"], head["pred_boxes"], corners,
+                head["ref_points"].detach() if corners is not None else None, teacher,
+                head.get("teacher_logits") if teacher is not None else None, cls_plan.packed,
+                box_plan.packed, labels, tboxes, cfg)
+            keys = []
+            if want_vfl:
+                keys.append(("loss_vfl", 0))
+            if want_box:
+                keys += [("loss_bbox", 1), ("loss_giou", 2)]
+            if corners is not None:
+                keys.append(("loss_fgl", 3))
+                if "teacher_corners" in head:
+                    keys.append(("loss_ddf", 4))
+            vecs.append(vec)
+            names.append([(k + suffix, j) for k, j in keys])
+            if want_masks and head.get("pred_masks") is not None:
+                for k, v in self.loss_masks(head, targets, cls_plan, n_cls).items():
+                    if k in wd:
+                        extra[k + suffix] = torch.nan_to_num(v * wd[k], nan=0.0)
+        if dn_plan is not None and want_masks and outputs.get("dn_pred_masks") is not None:
+            final = {"pred_masks": outputs["dn_pred_masks"], "pred_boxes": outputs["dn_outputs"][-1]["pred_boxes"]}
+            for k, v in self.loss_masks(final, targets, dn_plan, dn_boxes).items():
+                if k in wd:
+                    extra[k + "_dn_final"] = torch.nan_to_num(v * wd[k], nan=0.0)
+        table = torch.nan_to_num(torch.stack(vecs), nan=0.0)      # [heads, 5]
+        self.__dict__["_last_table"] = table
+        cells = table.view(-1).unbind(0)
         losses = {}
         for h, keys in enumerate(names):
             for k, j in keys:

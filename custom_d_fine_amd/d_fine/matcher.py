@@ -237,6 +237,33 @@ class HungarianMatcher(nn.Module):
         return finish
 
     @torch.no_grad()
+    def match_heads_device(self, heads: List[Dict[str, torch.Tensor]], targets):
+        """The matching of every head left ON THE DEVICE: (cols int32 [K, T], tgt_offset int32 [B + 1], sizes) - `cols[k, t]`
+        is the query assigned to target row t by head k - for the criterion's device-side bookkeeping (csrc/plans.hip), or
+        None when that path does not apply (CPU tensors, no targets, an image with more targets than queries)."""
+        sizes = [len(t["boxes"]) for t in targets]
+        tmax = max(sizes) if sizes else 0
+        first = heads[0]["pred_logits"]
+        if tmax == 0 or not first.is_cuda:
+            return None
+        from .. import hip
+        if not hip.criterion_plans_supported(len(heads), tmax, first.shape[1]):
+            return None
+        logits = torch.stack([h["pred_logits"] for h in heads]).float()
+        boxes = torch.stack([h["pred_boxes"] for h in heads]).float()
+        tgt_ids = torch.cat([t["labels"] for t in targets])
+        tgt_box = torch.cat([t["boxes"] for t in targets]).float()
+        extra = None
+        per_head = [self._mask_cost(h, targets, logits.shape[2], tmax) for h in heads]
+        if any(e is not None for e in per_head):
+            extra = torch.stack([e if e is not None else torch.zeros_like(
+                next(x for x in per_head if x is not None)) for e in per_head])
+        cols, _ = kernels.hungarian_assign(
+            logits, boxes, tgt_ids, tgt_box, sizes, float(self.cost_class), float(self.cost_bbox),
+            float(self.cost_giou), float(self.alpha), float(self.gamma), self.use_focal_loss, extra)
+        return cols, cols._dfine_tgt_offset, sizes
+
+    @torch.no_grad()
     def forward(self, outputs: Dict[str, torch.Tensor], targets, return_topk=False):
         if return_topk:
             return {"indices_o2m": self.get_top_k_matches(outputs, targets, k=return_topk)}

@@ -192,6 +192,10 @@ class GraphedSegment:
         snap_bn = dict(kernels._BN_PENDING)
         flags = (kernels._CAPTURE_POSSIBLE, kernels._CAPTURE_SHADOWS, hip.CAPTURE_SIDE, arch_utils.CAPTURE_KEEP)
         self.bwd_pairs = None
+        group_at = hip._SIDE_GROUP_AT
+        # grouped weight-gradient launches every few registrations: a replay has no host cost per launch (the eager step
+        # groups 32 to save ~25 us of host time each), and small groups keep the side stream's work evenly spread
+        hip._SIDE_GROUP_AT = int(os.environ.get("DFINE_GRAPH_GROUP_AT", "8"))
         try:
             # ---- eager warm-up on the capture stream: fills the shadow registries for the aliases, sizes the workspaces
             with torch.cuda.stream(cap_stream):
@@ -233,6 +237,7 @@ class GraphedSegment:
                     with torch.cuda.stream(cap_stream):
                         dual.begin()
                         grads = torch.autograd.grad(self.static_out, aliases, self.static_gout, allow_unused=True)
+                        hip.linear_wgrad_flush(side=True)      # what is still registered: grouped launches on the side stream
                         dual.end()
                 finally:
                     hip.CAPTURE_DUAL = None
@@ -254,6 +259,7 @@ class GraphedSegment:
         finally:
             kernels._CAPTURE_POSSIBLE, kernels._CAPTURE_SHADOWS, hip.CAPTURE_SIDE, arch_utils.CAPTURE_KEEP = flags
             hip.CAPTURE_DUAL = None
+            hip._SIDE_GROUP_AT = group_at
             fused.accumulating = was_accumulating
         self._token = torch.zeros((), device=dev, requires_grad=True)     # makes autograd call _Replay.backward
         seg = self
@@ -273,7 +279,10 @@ class GraphedSegment:
                         pend[key] = (buf, 1 if ent is None else ent[1] + 1)
                 else:
                     torch._foreach_add_([b for _, b in seg._bn_counters], 1)
-                return tuple(o.detach() for o in seg.static_out)
+                outs = tuple(o.detach() for o in seg.static_out)
+                for o, buf in zip(outs, seg.static_gout):
+                    o._dfine_grad_buf = buf          # consumers that can (kernels.flatten_levels) write the gradient there
+                return outs
 
             @staticmethod
             def backward(ctx, *gouts):

@@ -126,7 +126,8 @@ class Trainer:
             amp = torch.bfloat16 if t["amp_dtype"] == "bf16" else torch.float16
         self.step = TrainStep(self.model, self.loss_fn, self.optimizer, amp_dtype=amp,
                               clip_max_norm=t["clip_max_norm"], ema=self.ema, scheduler=sched,
-                              accum_steps=t["b_accum_steps"], fused_optimizer=fused)
+                              accum_steps=t["b_accum_steps"], fused_optimizer=fused,
+                              hip_graph=fused is not None and os.environ.get("DFINE_HIPGRAPH", "1") == "1")
         self.path_to_save = Path(t["path_to_save"])
         self.fused, self.scheduler, self.start_epoch = fused, sched, 1
         if t.get("resume_path"):

@@ -47,6 +47,13 @@ _SIGNATURES = {
     "dfine_head_losses": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _P, _I,
                                    _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P,
                                    _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfine_head_losses_dev": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _P, _I,
+                                       _P, _P, _P, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                       _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfine_criterion_plans_supported": (c_int, [_I, _I, _I]),
+    "dfine_criterion_plans_ws_ints": (_L, [_I, _I, _I]),
+    "dfine_criterion_plans": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "dfine_criterion_scales": (c_int, [_P, _I, _P, _P, _I, _P, _P]),
     "dfine_head_grads_scale": (c_int, [_P, _P, _L, _P, _P, _L, _P, _P, _L, _I, _P]),
     "dfine_grad_sqnorm": (c_int, [_P, _L, _F, _P, _P]),
     "dfine_grad_sqnorm_ws_floats": (_L, []),
@@ -440,6 +447,7 @@ def hungarian_assign(logits, boxes, tgt_labels, tgt_boxes, sizes, w_class, w_bbo
                             _ptr(tgt_offset), _ptr(extra), _ptr(cost), c_void_p(0), _ptr(cols),
                             K, B, Q, C, tmax, T, float(w_class), float(w_bbox), float(w_giou),
                             float(alpha), float(gamma), _stream()), "dfine_match")
+    cols._dfine_tgt_offset = tgt_offset          # (the criterion's device-side plan builder reads the same offsets)
     return cols, cost.permute(0, 1, 3, 2)
 
 
@@ -637,7 +645,7 @@ def _view3(t):
 
 def head_losses(logits, boxes, corners, ref, teacher_corners, teacher_logits, cls_plan, box_plan,
                 tgt_labels, tgt_boxes, wtable, reg_max, reg_scale, alpha, gamma, temp, s_vfl, s_l1,
-                s_giou, s_fgl, c_pos, c_neg):
+                s_giou, s_fgl, c_pos, c_neg, scales_dev=None, box_count_dev=None):
     """One launch group for all losses of a head.  Returns (out[5], grad_logits, grad_l1, grad_giou,
     grad_corners_fgl, grad_corners_ddf) - see dfine_head_losses in include/dfine_hip.h."""
     B, Q, C = logits.shape
@@ -669,6 +677,17 @@ def head_losses(logits, boxes, corners, ref, teacher_corners, teacher_logits, cl
     tcp, tcsb, tcsq = _view3(teacher_corners)
     tlp, tlsb, tlsq = _view3(teacher_logits)
     wt = (c_float * len(wtable))(*wtable) if wtable is not None else None
+    if scales_dev is not None:
+        # the six scalar factors (and the length of the box plan) stay on the device: no host value depends on the matching
+        _check(_lib.dfine_head_losses_dev(
+            lp, lsb, lsq, bp, bsb, bsq, cp, csb, csq, rp, rsb, rsq, tcp, tcsb, tcsq, tlp, tlsb, tlsq,
+            _ptr(cls_plan), m_cls, _ptr(box_plan), m_box, _ptr(tgt_labels), _ptr(tgt_boxes), wt,
+            int(reg_max), float(reg_scale), float(alpha), float(gamma), float(temp), _ptr(scales_dev), _ptr(box_count_dev),
+            _ptr(g_logits), _ptr(g_box[0]), _ptr(g_box[1]), _ptr(g_fgl), _ptr(g_ddf), _ptr(scratch_f[:m_cls]),
+            _ptr(scratch_f[m_cls:m_cls + m_box]), _ptr(scratch_i[0]), _ptr(scratch_i[1]),
+            _ptr(scratch_f[m_cls + m_box:]), _ptr(out), _dtype_code(logits), B, Q, C, _stream()),
+            "dfine_head_losses_dev")
+        return out, g_logits, g_box[0], g_box[1], g_fgl, g_ddf
     _check(_lib.dfine_head_losses(
         lp, lsb, lsq, bp, bsb, bsq, cp, csb, csq, rp, rsb, rsq, tcp, tcsb, tcsq, tlp, tlsb, tlsq,
         _ptr(cls_plan), m_cls, _ptr(box_plan), m_box, _ptr(tgt_labels), _ptr(tgt_boxes), wt,
@@ -686,6 +705,37 @@ def head_grads_scale(g, g_logits, g_l1, g_giou, g_fgl, g_ddf):
     _check(_lib.dfine_head_grads_scale(
         _ptr(g), _ptr(g_logits), g_logits.numel(), _ptr(g_l1), _ptr(g_giou), g_l1.numel(), _ptr(g_fgl), _ptr(g_ddf),
         0 if g_fgl is None else g_fgl.numel(), _dtype_code(g_logits), _stream()), "dfine_head_grads_scale")
+
+
+def criterion_plans_supported(K, tmax, Q):
+    return bool(_PURE.dfine_criterion_plans_supported(int(K), int(tmax), int(Q)))
+
+
+def criterion_plans(cols, tgt_offset, sizes, Q, want_float_count=False):
+    """cols int32 [K, T] (device; every target matched), tgt_offset int32 [B + 1] (device), sizes = targets per image (host)
+    -> (head_plans int64 [K, 3, T], go_plan int64 [3, K * T], go_count int32 [1], go_count_f float [1] or None): the
+    criterion's gather plans and the GO union built on the device (csrc/plans.hip), no host synchronisation."""
+    K, T = cols.shape
+    B = len(sizes)
+    dev = cols.device
+    cap = K * T
+    head_plans = torch.empty(K, 3, T, device=dev, dtype=torch.int64)
+    go_plan = torch.empty(3, cap, device=dev, dtype=torch.int64)
+    go_count = torch.empty(1, device=dev, dtype=torch.int32)
+    go_f = torch.empty(1, device=dev, dtype=torch.float32) if want_float_count else None
+    ws = torch.empty(int(_PURE.dfine_criterion_plans_ws_ints(K, T, B)), device=dev, dtype=torch.int32)
+    _check(_lib.dfine_criterion_plans(_ptr(cols), _ptr(tgt_offset), K, T, B, int(Q), int(max(sizes)), _ptr(head_plans),
+                                      _ptr(go_plan), cap, _ptr(go_count), _ptr(go_f), _ptr(ws), _stream()), "dfine_criterion_plans")
+    return head_plans, go_plan, go_count, go_f
+
+
+def criterion_scales(params, go_count, go_sum, world):
+    """params: device float64 [R, 12] (see dfine_criterion_scales) -> scales float32 [R, 6] on the device."""
+    R = params.shape[0]
+    scales = torch.empty(R, 6, device=params.device, dtype=torch.float32)
+    _check(_lib.dfine_criterion_scales(_ptr(params), R, _ptr(go_count), _ptr(go_sum), int(world), _ptr(scales), _stream()),
+           "dfine_criterion_scales")
+    return scales
 
 
 # ------------------------------------------------------------------------------------- optimizer
@@ -771,12 +821,15 @@ def upsample2_nearest(x, backward=False):
     return out
 
 
-def tokens_to_maps(tokens, shapes):
-    """tokens [B, L, C] bf16 contiguous -> one contiguous [B, C, h, w] map per (h, w) in `shapes`."""
+def tokens_to_maps(tokens, shapes, outs=None):
+    """tokens [B, L, C] bf16 contiguous -> one contiguous [B, C, h, w] map per (h, w) in `shapes`; `outs`: optional
+    preallocated maps (entries may be None) to write into."""
     B, L, C = tokens.shape
     out, row = [], 0
-    for h, w in shapes:
-        m = torch.empty(B, C, h, w, device=tokens.device, dtype=torch.bfloat16)
+    for i, (h, w) in enumerate(shapes):
+        m = outs[i] if outs is not None else None
+        if m is None or m.shape != (B, C, h, w) or m.dtype != torch.bfloat16 or not m.is_contiguous():
+            m = torch.empty(B, C, h, w, device=tokens.device, dtype=torch.bfloat16)
         _check(_lib.dfine_maps_tokens_bf16(_ptr(m), _ptr(tokens), B, C, h * w, L, row, 0, _stream()), "dfine_maps_tokens_bf16")
         out.append(m)
         row += h * w

@@ -213,9 +213,10 @@ def upsample2_nearest(x):
 
 class _FlattenLevels(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, *maps):
+    def forward(ctx, bufs, *maps):
         maps = tuple(m.contiguous() for m in maps)
         ctx.shapes = [(m.shape[2], m.shape[3]) for m in maps]
+        ctx.bufs = bufs
         return _hip().maps_to_tokens(maps)
 
     @staticmethod
@@ -223,7 +224,7 @@ class _FlattenLevels(torch.autograd.Function):
         g = g.contiguous()
         if g.dtype != torch.bfloat16:
             g = g.to(torch.bfloat16)
-        return tuple(_hip().tokens_to_maps(g, ctx.shapes))
+        return (None,) + tuple(_hip().tokens_to_maps(g, ctx.shapes, outs=ctx.bufs))
 
 
 def flatten_levels(maps):
@@ -233,7 +234,10 @@ def flatten_levels(maps):
     if (maps[0].is_cuda and all(m.dtype == torch.bfloat16 and m.dim() == 4 for m in maps)
             and maps[0].shape[1] % 8 == 0 and all((m.shape[2] * m.shape[3]) % 8 == 0 and m.shape[1] == maps[0].shape[1] for m in maps)
             and _env("DFINE_HIP_UNITS", "1") == "1"):
-        return _FlattenLevels.apply(*maps)
+        # a map that came out of a captured segment (dl.engine.GraphedSegment) carries the static buffer its gradient is
+        # expected in: the backward pass writes there directly instead of into a fresh map that is copied afterwards
+        bufs = tuple(getattr(m, "_dfine_grad_buf", None) for m in maps)
+        return _FlattenLevels.apply(bufs if any(b is not None for b in bufs) else None, *maps)
     return torch.concat([m.flatten(2).permute(0, 2, 1) for m in maps], 1)
 
 
@@ -316,7 +320,7 @@ class _HeadLosses(torch.autograd.Function):
             logits, boxes, corners_k, None if ref is None else ref.float(), tc, tl, cls_plan,
             box_plan, tgt_labels, tgt_boxes, cfg["wtable"], cfg["reg_max"], cfg["reg_scale"],
             cfg["alpha"], cfg["gamma"], cfg["temp"], cfg["s_vfl"], cfg["s_l1"], cfg["s_giou"],
-            cfg["s_fgl"], cfg["c_pos"], cfg["c_neg"])
+            cfg["s_fgl"], cfg["c_pos"], cfg["c_neg"], scales_dev=cfg.get("scales_dev"), box_count_dev=cfg.get("box_count_dev"))
         ctx.grads = (g_logits, g_l1, g_giou, g_fgl, g_ddf)
         ctx.dtypes = (boxes.dtype, None if corners is None else corners.dtype)
         return out

@@ -252,6 +252,47 @@ int dfine_head_grads_scale(const float *g, void *grad_logits, int64_t n_logits, 
                            const float *grad_giou, int64_t n_box, void *grad_corners_fgl,
                            const void *grad_corners_ddf, int64_t n_corners, int dtype, void *stream);
 
+/* The launch group of dfine_head_losses with its six scalar factors (s_vfl, s_l1, s_giou, s_fgl, ddf_c_pos, ddf_c_neg) read from
+ * DEVICE memory (`scales`, one row of dfine_criterion_scales' table) and - when `box_count` is not NULL - the number of valid
+ * entries of the box plan read from device memory as well (M_box is then the row stride / capacity of the [3, M_box] plan).
+ * Lets the criterion run without the host round trip of the matching (src/d_fine/dfine_criterion.py:619-652). */
+int dfine_head_losses_dev(
+    const void *logits, int64_t l_sb, int64_t l_sq, const float *boxes, int64_t b_sb, int64_t b_sq,
+    const void *corners, int64_t c_sb, int64_t c_sq, const float *ref, int64_t r_sb, int64_t r_sq,
+    const void *teacher_corners, int64_t tc_sb, int64_t tc_sq, const void *teacher_logits,
+    int64_t tl_sb, int64_t tl_sq, const int64_t *cls_plan, int M_cls, const int64_t *box_plan,
+    int M_box, const int64_t *tgt_labels, const float *tgt_boxes, const float *wtable, int reg_max,
+    float reg_scale, float alpha, float gamma, float temp, const float *scales, const int *box_count,
+    void *grad_logits, float *grad_l1, float *grad_giou, void *grad_corners_fgl,
+    void *grad_corners_ddf, float *iou_cls, float *iou_box, int *map_cls, int *map_box, float *wrow,
+    float *out, int dtype, int B, int Q, int C, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A13  Index bookkeeping of the criterion on the device (csrc/plans.hip): replaces the host side of
+ * DFINECriterion.forward between the matcher and the loss terms - the per-head (batch, query, target) index lists
+ * (_get_src_permutation_idx, src/d_fine/dfine_criterion.py:558-562), the GO union of all matchings (_get_go_indices, :570-591:
+ * torch.unique(dim=0, return_counts=True) + torch.argsort(counts, descending=True) on the CPU + first pair per query) and
+ * num_boxes_go (:634-641) - so that the train step has no host <-> device synchronisation.
+ *   cols        int32 [K, T]   query assigned to target row t by head k (dfine_match / dfine_lsap), every entry >= 0
+ *   tgt_offset  int32 [B + 1]  first target row of every image
+ *   head_plans  int64 [K, 3, T] out: (image, query, target row) of head k, in target order
+ *   go_plan     int64 [3, cap] out: the GO union, image-major, within an image in the reference's order; cap >= K * T
+ *   go_count    int32 [1] out: its length;  go_count_f float [1] out or NULL: the same as a float (operand of a collective)
+ *   ws          int32 [dfine_criterion_plans_ws_ints(K, T, B)] scratch
+ * dfine_criterion_plans_supported: K * tmax <= 4096, Q <= 4096, tmax <= Q (every target matched). */
+int dfine_criterion_plans_supported(int K, int tmax, int Q);
+int64_t dfine_criterion_plans_ws_ints(int K, int T, int B);
+int dfine_criterion_plans(const int *cols, const int *tgt_offset, int K, int T, int B, int Q, int tmax, int64_t *head_plans,
+                          int64_t *go_plan, int cap, int *go_count, float *go_count_f, int *ws, void *stream);
+/* The scalar factors of R head-loss launches from the GO size (the Python arithmetic of src/d_fine/dfine_criterion.py:
+ * 639-652 normalisers, :213-235 DDF balance, in double / the float32 clamp division of the reference):
+ *   params double [R, 12] = (s_vfl, box normaliser is num_boxes_go (1) or params[2] (0), n_box, w_bbox, w_giou, w_fgl, w_ddf,
+ *                            has teacher, is denoising head, 4 * B * Q, 4 * matched pairs of a denoising head, 8 / B)
+ *   go_sum float [1] or NULL: GO size summed over the ranks (world > 1);  scales float [R, 6] out. */
+int dfine_criterion_scales(const double *params, int R, const int *go_count, const float *go_sum, int world, float *scales,
+                           void *stream);
+
+
 /* ---------------------------------------------------------------------------------------------
  * A16  Optimizer step on flat fp32 buffers (parameters are views into them).
  * Replaces clip_grad_norm_ + AdamW.step + zero_grad + ModelEMA.update

@@ -326,3 +326,133 @@ def warp_affine_u8(src, M2x3, out_hw, border=114):
         v = np.where(ok[..., None], src[np.clip(py, 0, Hs - 1), np.clip(px, 0, Ws - 1)].astype(np.int64), border)
         out += v * wi[..., k][..., None]
     return np.clip((out + (1 << 14)) >> 15, 0, 255).astype(np.uint8)
+
+
+# =============================================================================================
+# torch.argsort(counts, descending=True) on the CPU - the tie order of the GO-index vote (ref dfine_criterion.py:570-591 calls
+# it per image on the multiplicities of the (query, target) pairs).  ATen's CPU sort (aten/src/ATen/native/cpu/SortingKernel.cpp,
+# torch==2.9.0 pinned by requirements.txt:33; same code in the container's 2.10.0) runs std::sort over a composite
+# (value, index) iterator with the comparator "lhs.value > rhs.value": libstdc++'s introsort - median-of-three quicksort down
+# to runs of 16, heapsort past 2 * floor(log2 n) levels, one final insertion sort.  Unstable, but deterministic: restated here
+# step by step (bits/stl_algo.h, bits/stl_heap.h) so that the device kernel (csrc/plans.hip) can be pinned against it and it
+# against torch itself (tests/test_plans.py).
+# =============================================================================================
+def aten_argsort_desc(counts):
+    v = [int(c) for c in counts]
+    ix = list(range(len(v)))
+
+    def comp(a, b):                     # KeyValueCompDesc on positions
+        return v[a] > v[b]
+
+    def swap(a, b):
+        v[a], v[b] = v[b], v[a]
+        ix[a], ix[b] = ix[b], ix[a]
+
+    def unguarded_linear_insert(last):
+        val, vi = v[last], ix[last]
+        nxt = last - 1
+        while val > v[nxt]:
+            v[last], ix[last] = v[nxt], ix[nxt]
+            last = nxt
+            nxt -= 1
+        v[last], ix[last] = val, vi
+
+    def insertion_sort(first, last):
+        if first == last:
+            return
+        for i in range(first + 1, last):
+            if comp(i, first):
+                val, vi = v[i], ix[i]
+                v[first + 1:i + 1] = v[first:i]
+                ix[first + 1:i + 1] = ix[first:i]
+                v[first], ix[first] = val, vi
+            else:
+                unguarded_linear_insert(i)
+
+    def push_heap(first, hole, top, val, vi):
+        parent = (hole - 1) // 2
+        while hole > top and v[first + parent] > val:
+            v[first + hole], ix[first + hole] = v[first + parent], ix[first + parent]
+            hole = parent
+            parent = (hole - 1) // 2
+        v[first + hole], ix[first + hole] = val, vi
+
+    def adjust_heap(first, hole, length, val, vi):
+        top = hole
+        child = hole
+        while child < (length - 1) // 2:
+            child = 2 * (child + 1)
+            if comp(first + child, first + child - 1):
+                child -= 1
+            v[first + hole], ix[first + hole] = v[first + child], ix[first + child]
+            hole = child
+        if (length & 1) == 0 and child == (length - 2) // 2:
+            child = 2 * (child + 1)
+            v[first + hole], ix[first + hole] = v[first + child - 1], ix[first + child - 1]
+            hole = child - 1
+        push_heap(first, hole, top, val, vi)
+
+    def heap_sort(first, last):         # std::__partial_sort(first, last, last): make_heap + sort_heap
+        length = last - first
+        if length >= 2:
+            parent = (length - 2) // 2
+            while True:
+                adjust_heap(first, parent, length, v[first + parent], ix[first + parent])
+                if parent == 0:
+                    break
+                parent -= 1
+        while last - first > 1:
+            last -= 1
+            val, vi = v[last], ix[last]
+            v[last], ix[last] = v[first], ix[first]
+            adjust_heap(first, 0, last - first, val, vi)
+
+    def move_median_to_first(result, a, b, c):
+        if comp(a, b):
+            if comp(b, c):
+                swap(result, b)
+            elif comp(a, c):
+                swap(result, c)
+            else:
+                swap(result, a)
+        elif comp(a, c):
+            swap(result, a)
+        elif comp(b, c):
+            swap(result, c)
+        else:
+            swap(result, b)
+
+    def unguarded_partition(first, last, pivot):
+        while True:
+            while comp(first, pivot):
+                first += 1
+            last -= 1
+            while comp(pivot, last):
+                last -= 1
+            if not first < last:
+                return first
+            swap(first, last)
+            first += 1
+
+    def introsort_loop(first, last, depth):
+        while last - first > 16:
+            if depth == 0:
+                heap_sort(first, last)
+                return
+            depth -= 1
+            mid = first + (last - first) // 2
+            move_median_to_first(first, first + 1, mid, last - 1)
+            cut = unguarded_partition(first + 1, last, first)
+            introsort_loop(cut, last, depth)
+            last = cut
+
+    n = len(v)
+    if n:
+        introsort_loop(0, n, 2 * (n.bit_length() - 1))
+        if n > 16:
+            insertion_sort(0, 16)
+            for i in range(16, n):
+                unguarded_linear_insert(i)
+        else:
+            insertion_sort(0, n)
+    return np.asarray(ix, dtype=np.int64)
