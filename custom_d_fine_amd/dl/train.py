@@ -117,8 +117,11 @@ class Trainer:
             t["steps_per_epoch"] = len(shard_batches(len(self._dataset), self.rank, self.world, t["batch_size"], 0))
         sched = None
         if t["use_scheduler"]:
+            max_lr = t["base_lr"] * 2
+            if cfg["model_name"] in ("l", "x") or mask:       # per-group maxima for the big models (ref train.py:203-214)
+                max_lr = [t["backbone_lr"] * 2, t["backbone_lr"] * 2, t["base_lr"] * 2, t["base_lr"] * 2]
             sched = torch.optim.lr_scheduler.OneCycleLR(
-                self.optimizer, max_lr=t["base_lr"] * 2, epochs=t["epochs"],
+                self.optimizer, max_lr=max_lr, epochs=t["epochs"],
                 steps_per_epoch=max(t["steps_per_epoch"] // max(t["b_accum_steps"], 1), 1),
                 pct_start=t["cycler_pct_start"], cycle_momentum=False)
         amp = None

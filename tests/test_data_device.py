@@ -237,3 +237,48 @@ def test_trainer_epoch_schedule_matches_batches(tmp_path):
     for world in (1, 2, 4):
         for rank in range(world):
             assert len(T.shard_batches(n, rank, world, 2, 3)) == -(-(-(-n // world)) // 2)
+
+
+# ---- goldens from the reference's own functions (tests/golden/data_device.npz, tools/gen_golden.py::gen_data_device):
+# `random_affine` with its matrix draw pinned, `box_candidates`, `get_mosaic_coordinate` (src/dl/utils.py:283-414)
+def _golden():
+    from tests import helpers
+    return np.load(f"{helpers.GOLDEN_DIR}/data_device.npz")
+
+
+def test_oracle_box_candidates_and_mosaic_coordinates_match_reference():
+    g = _golden()
+    assert np.array_equal(np_ref.box_candidates(g["cand/box1"], g["cand/box2"], area_thr=0.1), g["cand/keep"])
+    for idx, xc, yc, w, h, *want in g["mosaic/rows"].tolist():
+        big, small = D.get_mosaic_coordinate(idx, xc, yc, w, h, 640, 640)
+        assert list(big) + list(small) == want
+
+
+def test_oracle_affine_boxes_match_reference_random_affine():
+    g = _golden()
+    for c in range(int(g["n_affine"])):
+        tin, tout = g[f"affine{c}/targets_in"], g[f"affine{c}/targets_out"]
+        new, keep = np_ref.affine_boxes(tin[:, 1:5], g[f"affine{c}/M"], float(g[f"affine{c}/scale"]), tuple(g[f"affine{c}/target_size"]))
+        assert int(keep.sum()) == len(tout) and 0 < len(tout) < len(tin)
+        np.testing.assert_allclose(new[keep], tout[:, 1:5], rtol=0, atol=1e-4)
+        assert np.array_equal(tin[keep, 0], tout[:, 0])
+
+
+@pytest.mark.gpu
+def test_affine_boxes_kernel_matches_reference_random_affine(cuda):
+    from custom_d_fine_amd import hip
+    g = _golden()
+    for c in range(int(g["n_affine"])):
+        tin, tout = g[f"affine{c}/targets_in"], g[f"affine{c}/targets_out"]
+        M, s, size = g[f"affine{c}/M"], float(g[f"affine{c}/scale"]), tuple(int(v) for v in g[f"affine{c}/target_size"])
+        got, keep = hip.affine_boxes(torch.from_numpy(tin[:, 1:5].copy()).to(cuda), M[:2], s, size, 0.1)
+        keep = keep.cpu().numpy().astype(bool)
+        want_new, want_keep = np_ref.affine_boxes(tin[:, 1:5], M, s, size)
+        # boxes on the filter's decision boundaries aside (fp32 kernel against the reference's float64 matrix product), the
+        # kept set and the kept boxes are the reference's
+        w, h = want_new[:, 2] - want_new[:, 0], want_new[:, 3] - want_new[:, 1]
+        sure = (np.abs(w - 2) > 0.01) & (np.abs(h - 2) > 0.01)
+        assert np.array_equal(keep[sure], want_keep[sure])
+        both = keep & want_keep
+        np.testing.assert_allclose(got.cpu().numpy()[both], want_new[both], rtol=0, atol=2e-3)
+        assert abs(int(keep.sum()) - len(tout)) <= int((~sure).sum())

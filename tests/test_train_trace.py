@@ -1,0 +1,95 @@
+"""The train loop across iterations - lr schedule x gradient clip x AdamW parameter groups x EMA decay - against a trace of
+the reference's loop (tests/golden/train_trace.npz: src/dl/train.py:512-535,550-586,52-73,203-221 restated around the imported
+reference builders by tools/gen_golden.py::gen_train_trace).  D-FINE-n 320 x 320, bs 2, fp32, 3 iterations.
+CPU: `TrainStep` through the oracle backend and torch's own AdamW - tight.  GPU: the same `TrainStep` on the HIP kernels with
+the fused flat-buffer optimizer - to the accuracy fp32 kernels of a different summation order allow (Adam turns a sign flip of
+a ~0 gradient into a +-lr update)."""
+import numpy as np
+import pytest
+import torch
+
+from custom_d_fine_amd.d_fine import dfine
+from custom_d_fine_amd.d_fine.arch import utils as U
+from custom_d_fine_amd.dl.engine import ModelEMA, TrainStep
+from tests import helpers
+
+G = np.load(f"{helpers.GOLDEN_DIR}/train_trace.npz")
+
+
+def _run(device, fused_opt):
+    base_lr, backbone_lr = float(G["base_lr"]), float(G["backbone_lr"])
+    torch.manual_seed(0)
+    model = dfine.build_model("n", 80, False, "cpu", img_size=[320, 320])
+    model.load_state_dict(helpers.seeded_state_dict(model.state_dict()))
+    model = model.to(device).train()
+    crit = dfine.build_loss("n", 80, 0.0, False)
+    ema = ModelEMA(model, 0.9998)
+    opt = dfine.build_optimizer(model, lr=base_lr, backbone_lr=backbone_lr, betas=(0.9, 0.999), weight_decay=1.25e-4, base_lr=base_lr)
+    fused = None
+    if fused_opt:
+        from custom_d_fine_amd.dl.fused_optim import FusedAdamWEMA
+        fused = FusedAdamWEMA(model, opt, ema, clip_max_norm=0.1)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=base_lr * 2, epochs=1, steps_per_epoch=8, pct_start=0.1, cycle_momentum=False)
+    step = TrainStep(model, crit, opt, amp_dtype=None, clip_max_norm=0.1, ema=ema, scheduler=sched, fused_optimizer=fused)
+    rec = []
+    for it in range(int(G["iters"])):
+        lrs = [g["lr"] for g in opt.param_groups]
+        images = helpers.make_images(2, 320, seed=500 + it).to(device)
+        targets = helpers.make_targets(2, 80, device=device)
+        if device.type == "cpu":
+            torch.manual_seed(11 + it)                   # the CPU path draws the denoising noise from the global generator
+        else:
+            U.set_denoising_generator(torch.Generator().manual_seed(11 + it))
+        loss, loss_dict = step(images, targets)
+        U.set_denoising_generator(None)
+        rec.append((lrs, loss.item(), {k: v.item() for k, v in loss_dict.items()}))
+    return model, ema, rec
+
+
+def _check(model, ema, rec, loss_tol0, loss_tol, delta_cos):
+    """loss_tol0: every loss term of the first iteration (identical weights) and the TOTAL of every iteration; loss_tol: the
+    single terms of the later iterations - after an AdamW update two correct runs differ by a +-lr step on every weight whose
+    near-zero gradient changed sign, which is enough to move a query across the matcher's decision for one target: a term
+    like loss_fgl_aux_0 (0.6 of a total of 2 016) then moves by several per cent while the total agrees to 2e-6."""
+    for it, (lrs, loss, losses) in enumerate(rec):
+        tol = loss_tol0 if it == 0 else loss_tol
+        assert lrs == pytest.approx(G[f"it{it}/lr"].tolist(), rel=1e-12), it            # schedule: exact
+        want = {k.split("/", 2)[2]: float(G[k]) for k in G.files if k.startswith(f"it{it}/losses/")}
+        assert set(losses) == set(want)
+        assert loss == pytest.approx(float(G[f"it{it}/loss"]), rel=loss_tol0), (it, loss)
+        for k, v in want.items():
+            assert losses[k] == pytest.approx(v, rel=tol, abs=tol), (it, k)
+    sd, esd = model.state_dict(), ema.model.state_dict()
+    init = helpers.seeded_state_dict(sd)
+    for key in [k for k in G.files if k.startswith("final/") and k != "final/num_batches_tracked"]:
+        name = key.split("/", 1)[1]
+        want, got, w0 = torch.tensor(G[key]), sd[name].detach().cpu().float(), init[name].float()
+        dw, dg = (want - w0).flatten(), (got - w0).flatten()
+        cos = torch.nn.functional.cosine_similarity(dw, dg, dim=0).item()
+        assert cos >= delta_cos, (name, cos)
+        assert abs(dw.norm().item() / dg.norm().item() - 1) < 0.05, name                  # same step length (3 updates of ~lr each)
+    for key in [k for k in G.files if k.startswith("final_ema/")]:
+        # momentum = 0.9998 (1 - exp(-i / 2000)) is ~5e-4 in the first iterations: the EMA copy follows the student closely
+        name = key.split("/", 1)[1]
+        want, got, w0 = torch.tensor(G[key]), esd[name].detach().cpu().float(), init[name].float()
+        if "running_" in name:
+            assert torch.allclose(got, want, rtol=2e-3, atol=1e-5), name
+            continue
+        dw, dg = (want - w0).flatten(), (got - w0).flatten()
+        assert torch.nn.functional.cosine_similarity(dw, dg, dim=0).item() >= delta_cos, name
+        assert abs(dw.norm().item() / dg.norm().item() - 1) < 0.05, name
+        student = sd[name].detach().cpu().float()
+        m = float(G[f"it{int(G['iters']) - 1}/ema_momentum"])
+        assert (got - student).abs().max().item() <= 4 * m * (student - w0).abs().max().item() + 1e-7, name   # EMA ~ student this early
+    assert int(sd["backbone.stem.stem1.bn.num_batches_tracked"].item()) == int(G["final/num_batches_tracked"])
+
+
+def test_train_trace_cpu(oracle_backend):
+    model, ema, rec = _run(torch.device("cpu"), fused_opt=False)
+    _check(model, ema, rec, loss_tol0=1e-4, loss_tol=0.15, delta_cos=0.995)
+
+
+@pytest.mark.gpu
+def test_train_trace_gpu(cuda):
+    model, ema, rec = _run(cuda, fused_opt=True)
+    _check(model, ema, rec, loss_tol0=2e-3, loss_tol=0.15, delta_cos=0.97)

@@ -418,13 +418,147 @@ def gen_validator():
     save("validator_masks.npz", **out)
 
 
+# ------------------------------------------------------------------ (f3) augmentation box path: random_affine / box_candidates / mosaic coordinates
+def gen_data_device():
+    """The box side of the reference's mosaic + affine augmentation (src/dl/utils.py:283-414), image warps excluded (cv2 is not
+    in the container): `random_affine` itself with its matrix draw pinned (get_transform_matrix patched to return the given
+    matrix) and cv2.warpAffine inert, `box_candidates` and `get_mosaic_coordinate` called directly."""
+    U = ref.dl_utils
+    rs = np.random.RandomState(7)
+    out = {}
+    n_cases = 6
+    for c in range(n_cases):
+        tw, th = [(640, 640), (320, 320), (640, 480)][c % 3]
+        a, sc = np.radians(rs.uniform(-10, 10)), rs.uniform(0.5, 1.5)
+        if c == 0:
+            a, sc = 0.0, 0.5
+        shx, shy = np.tan(np.radians(rs.uniform(-2, 2))), np.tan(np.radians(rs.uniform(-2, 2)))
+        tx, ty = rs.uniform(0.4, 0.6) * tw, rs.uniform(0.4, 0.6) * th
+        R = np.array([[sc * np.cos(a), sc * np.sin(a), 0], [-sc * np.sin(a), sc * np.cos(a), 0], [0, 0, 1.0]])
+        S = np.array([[1, shx, 0], [shy, 1, 0], [0, 0, 1.0]])
+        T = np.array([[1, 0, tx], [0, 1, ty], [0, 0, 1.0]])
+        C = np.array([[1, 0, -tw], [0, 1, -th], [0, 0, 1.0]])           # canvas of 2 x target: centre (tw, th)
+        M = T @ S @ R @ C
+        n = 120
+        xy = rs.uniform(0, 2 * np.array([tw, th]) - 10, (n, 2))
+        wh = rs.uniform(1, 0.6 * np.array([tw, th]), (n, 2))
+        x2y2 = np.minimum(xy + wh, 2 * np.array([tw, th]))
+        targets = np.concatenate([rs.randint(0, 5, (n, 1)), xy, x2y2], 1).astype(np.float32)
+        orig = U.get_transform_matrix
+        U.get_transform_matrix = lambda *a_, **k_: (M, sc)
+        try:
+            img = np.zeros((2 * th, 2 * tw, 3), np.uint8)
+            _, t_aff, _ = U.random_affine(img, targets.copy(), None, (tw, th), 10.0, 0.1, (0.5, 1.5), 2.0)
+        finally:
+            U.get_transform_matrix = orig
+        out[f"affine{c}/M"] = M
+        out[f"affine{c}/scale"] = np.float64(sc)
+        out[f"affine{c}/target_size"] = np.array([tw, th])
+        out[f"affine{c}/targets_in"] = targets
+        out[f"affine{c}/targets_out"] = np.asarray(t_aff, dtype=np.float32)
+    out["n_affine"] = np.int64(n_cases)
+    b1 = rs.uniform(0, 600, (4, 300)).astype(np.float32)
+    b1[2:] += b1[:2]
+    b2 = b1 * rs.uniform(0.0, 1.3, (1, 300)).astype(np.float32) + rs.uniform(-3, 3, (4, 300)).astype(np.float32)
+    out["cand/box1"], out["cand/box2"] = b1, b2
+    out["cand/keep"] = U.box_candidates(b1, b2, area_thr=0.1)
+    rows = []
+    for idx in range(4):
+        for xc, yc, w, h in ((700, 500, 640, 480), (400, 390, 640, 480), (960, 960, 300, 700), (330, 610, 1000, 200), (640, 640, 640, 640)):
+            (x1, y1, x2, y2), small = U.get_mosaic_coordinate(None, idx, xc, yc, w, h, 640, 640)
+            rows.append([idx, xc, yc, w, h, x1, y1, x2, y2, *small])
+    out["mosaic/rows"] = np.asarray(rows, dtype=np.int64)
+    save("data_device.npz", **out)
+
+
+# ------------------------------------------------------------------ A16: parameter-group membership of build_optimizer, all sizes
+def gen_param_groups():
+    out = {}
+    for size, mask in (("n", False), ("s", False), ("m", False), ("l", False), ("x", False), ("x", True)):
+        model = ref.dfine.build_model(size, 80, mask, "cpu", img_size=[640, 640])
+        opt = ref.dfine.build_optimizer(model, lr=1.5e-4, backbone_lr=2e-5, betas=(0.9, 0.999), weight_decay=1.25e-4, base_lr=1.5e-4)
+        gid = {}
+        for g, grp in enumerate(opt.param_groups):
+            for p in grp["params"]:
+                gid[id(p)] = g
+        names = [n for n, _ in model.named_parameters()]
+        groups = [gid[id(p)] for _, p in model.named_parameters()]
+        tag = size + ("_mask" if mask else "")
+        out[f"{tag}/names"] = np.array(names)
+        out[f"{tag}/group"] = np.asarray(groups, dtype=np.int8)
+        out[f"{tag}/requires_grad"] = np.asarray([p.requires_grad for _, p in model.named_parameters()])
+        out[f"{tag}/lr"] = np.asarray([grp["lr"] for grp in opt.param_groups], dtype=np.float64)
+        out[f"{tag}/weight_decay"] = np.asarray([grp["weight_decay"] for grp in opt.param_groups], dtype=np.float64)
+    save("param_groups.npz", **out)
+
+
+# ------------------------------------------------------------------ the train loop: lr schedule x clip x AdamW groups x EMA across iterations
+def gen_train_trace():
+    """Three iterations of the reference's loop (src/dl/train.py:512-535 optimizer_step, :550-586 the step, :52-73 ModelEMA,
+    :203-221 OneCycleLR) RESTATED here around the imported build_model / build_loss / build_optimizer - `src.dl.train`
+    itself cannot be imported (hydra, wandb, cv2 ... are not in the container).  fp32, no AMP, D-FINE-n 320 x 320, bs 2."""
+    import math
+    from copy import deepcopy
+    base_lr, backbone_lr, iters = 8e-4, 4e-4, 3
+    torch.manual_seed(0)
+    model = ref.dfine.build_model("n", 80, False, "cpu", img_size=[320, 320])
+    model.load_state_dict(helpers.seeded_state_dict(model.state_dict()))
+    crit = ref.dfine.build_loss("n", 80, 0.0, False)
+    opt = ref.dfine.build_optimizer(model, lr=base_lr, backbone_lr=backbone_lr, betas=(0.9, 0.999), weight_decay=1.25e-4, base_lr=base_lr)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=base_lr * 2, epochs=1, steps_per_epoch=8, pct_start=0.1, cycle_momentum=False)
+    ema = deepcopy(model).eval()
+    for p in ema.parameters():
+        p.requires_grad_(False)
+    ema_momentum = 0.9998
+    watch = ("backbone.stem.stem1.conv.weight", "encoder.input_proj.0.conv.weight", "decoder.enc_score_head.bias",
+             "decoder.dec_bbox_head.1.layers.2.weight", "backbone.stages.0.blocks.0.layers.0.bn.weight")
+    ema_watch = watch + ("backbone.stem.stem1.bn.running_mean", "backbone.stem.stem1.bn.running_var")
+    out = {"iters": np.int64(iters), "base_lr": np.float64(base_lr), "backbone_lr": np.float64(backbone_lr)}
+    model.train()
+    crit.train()
+    for it in range(iters):
+        x = helpers.make_images(2, 320, seed=500 + it)
+        targets = helpers.make_targets(2, 80)
+        out[f"it{it}/lr"] = np.asarray([g["lr"] for g in opt.param_groups], dtype=np.float64)
+        torch.manual_seed(11 + it)                      # CDN noise of this iteration (CPU generator)
+        o = model(x, targets=targets)
+        loss_dict = crit(o, targets)
+        loss = sum(loss_dict.values()) / 1
+        loss.backward()
+        norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+        opt.step()
+        sched.step()
+        opt.zero_grad()
+        momentum = ema_momentum * (1 - math.exp(-(it + 1) / 2000))
+        student = model.state_dict()
+        with torch.no_grad():
+            for name, param in ema.state_dict().items():
+                if param.dtype.is_floating_point:
+                    param *= momentum
+                    param += (1.0 - momentum) * student[name].detach()
+        out[f"it{it}/loss"] = np.float64(loss.item())
+        out[f"it{it}/grad_norm"] = np.float64(float(norm))
+        out[f"it{it}/ema_momentum"] = np.float64(momentum)
+        for k, v in loss_dict.items():
+            out[f"it{it}/losses/{k}"] = np.float64(v.item())
+    sd, esd = model.state_dict(), ema.state_dict()
+    for k in watch:
+        out[f"final/{k}"] = sd[k].numpy()
+    for k in ema_watch:
+        out[f"final_ema/{k}"] = esd[k].numpy()
+    out["final/num_batches_tracked"] = np.int64(sd["backbone.stem.stem1.bn.num_batches_tracked"].item())
+    save("train_trace.npz", **out)
+
+
 GENERATORS = {
     "lsap": gen_lsap, "msda": gen_msda, "matcher": gen_matcher, "criterion": gen_criterion,
     "model_n320": lambda: gen_model("n", 320, 2, "model_n320.npz"),
     "model_m640_eval": lambda: gen_model("m", 640, 1, "model_m640_eval.npz", train=False),
+    "model_m640_eval_b3": lambda: gen_model("m", 640, 3, "model_m640_eval_b3.npz", train=False),
     "model_s320": lambda: gen_model("s", 320, 2, "model_s320.npz"),
     "backbone_encoder": gen_backbone_encoder, "postprocess": gen_postprocess, "mask_units": gen_mask_units, "model_n320_mask": gen_mask_model,
     "validator": gen_validator, "deploy": gen_deploy,
+    "data_device": gen_data_device, "param_groups": gen_param_groups, "train_trace": gen_train_trace,
 }
 
 if __name__ == "__main__":

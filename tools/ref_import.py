@@ -89,6 +89,8 @@ def import_reference_dl():
             except Exception:
                 m = mock.MagicMock(name=name)
                 m.__path__ = []
+                import importlib.machinery
+                m.__spec__ = importlib.machinery.ModuleSpec(name, None)      # torch._dynamo probes find_spec("onnx") when an optimizer is built
                 sys.modules[name] = m
     tv = sys.modules["torchvision"]
     if not hasattr(tv.ops, "nms"):
