@@ -430,17 +430,24 @@ def bf16_decoder_parity_table(cuda):
     hooks.append(dec.decoder.register_forward_pre_hook(pre("decoder.stack"), with_kwargs=True))
     orig_gdi = dec._get_decoder_input
 
+    orig_eo = dec._enc_output
+    memory_seen = {}
+
     def spy_gdi(memory, spatial_shapes, dn_logits=None, dn_boxes=None):
-        captured["query_selection"] = ((memory.detach(), spatial_shapes, None if dn_logits is None else dn_logits.detach(),
-                                        None if dn_boxes is None else dn_boxes.detach()), {})
+        memory_seen["memory"], memory_seen["shapes"] = memory.detach(), spatial_shapes
         return orig_gdi(memory, spatial_shapes, dn_logits, dn_boxes)
-    dec._get_decoder_input = spy_gdi
+
+    def spy_eo(t):
+        if torch.is_grad_enabled():          # the differentiable call: the 300 selected (masked) rows
+            captured["query_heads"] = ((t.detach(),), {})
+        return orig_eo(t)
+    dec._get_decoder_input, dec._enc_output = spy_gdi, spy_eo
     U.set_denoising_generator(torch.Generator().manual_seed(11))
     try:
         m(helpers.make_images(2, 320).to(cuda), targets)
     finally:
         U.set_denoising_generator(None)
-        dec._get_decoder_input = orig_gdi
+        dec._get_decoder_input, dec._enc_output = orig_gdi, orig_eo
         for h in hooks:
             h.remove()
 
@@ -451,10 +458,11 @@ def bf16_decoder_parity_table(cuda):
         args, kwargs = captured[name]
         args = tuple(a.clone().requires_grad_(True) if (torch.is_tensor(a) and a.is_floating_point()) else a for a in args)
         dec.zero_grad()
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            if name == "query_selection":
-                content, box_unact, enc_boxes, enc_logits = orig_gdi(*args)
-                outs = [enc_boxes[0], enc_logits[0]]          # (content / box_unact are detached copies of the same rows)
+        # (cache_enabled=False: ATen's F.linear under autocast would reuse a bf16 weight copy that a no-grad call made)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp, cache_enabled=False):
+            if name == "query_heads":
+                top_mem = orig_eo(args[0])
+                outs = [top_mem, dec._enc_scores(top_mem), dec.enc_bbox_head(top_mem)]
             elif name == "decoder.stack":
                 res = dec.decoder(*args, **kwargs)
                 outs = [res[0], res[1], res[2], res[4], res[5]]     # boxes, logits, corners of every layer + the pre heads
@@ -469,7 +477,7 @@ def bf16_decoder_parity_table(cuda):
 
     switches = ("DFINE_HIP_LINEAR", "DFINE_LN_FUSED", "DFINE_HIP_ATTN")
     saved = {s: os.environ.get(s) for s in switches}
-    results = {}
+    results, topk = {}, {}
     try:
         for mode in ("fp32", "hip", "aten", "aten2", "aten3"):
             for s in switches:
@@ -480,6 +488,10 @@ def bf16_decoder_parity_table(cuda):
             kernels.reload_env()
             for name in captured:
                 results[(mode, name)] = run(name, mode != "fp32")
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode != "fp32", cache_enabled=False):
+                mem = memory_seen["memory"]
+                _, valid = dec._anchors_for(memory_seen["shapes"], mem.device)
+                topk[mode] = dec._topk_indices(dec._enc_scores(dec._enc_output(valid.to(mem.dtype) * mem)), dec.num_queries)
     finally:
         for s, v in saved.items():
             if v is None:
@@ -501,6 +513,11 @@ def bf16_decoder_parity_table(cuda):
         reps = [row.pop("aten2"), row.pop("aten3"), row["aten"]]
         row["aten"] = (max(r[0] for r in reps), max(r[1] for r in reps), max(r[2] for r in reps), row["aten"][3])
         table[name] = row
+
+    def overlap(a, b):
+        return min(len(set(x.tolist()) & set(y.tolist())) / len(x) for x, y in zip(a, b))
+    table["query_topk"] = {"hip": overlap(topk["hip"], topk["fp32"]),
+                           "aten": max(overlap(topk[m_], topk["fp32"]) for m_ in ("aten", "aten2", "aten3"))}
     return table
 
 
@@ -510,7 +527,10 @@ def test_bf16_hip_decoder_blocks_no_worse_than_aten_bf16_m320(cuda):
     (1 - cos to fp32 at most 1.5 x ATen's + 2e-4; same criterion as the backbone / encoder blocks above), and close in absolute
     terms (output 1 - cos < 2e-3: a token-stream block has no batch statistics to amplify bf16 rounding)."""
     table = bf16_decoder_parity_table(cuda)
-    assert {"query_selection", "decoder.stack", "decoder.layers.0", "decoder.layers.3"} <= set(table)
+    assert {"query_heads", "query_topk", "decoder.stack", "decoder.layers.0", "decoder.layers.3"} <= set(table)
+    sel = table.pop("query_topk")
+    # the bf16 selection shares as many of its 300 queries with the fp32 selection as ATen's bf16 selection does (- 2 %)
+    assert sel["hip"] >= sel["aten"] - 0.02 and sel["hip"] > 0.5, sel
     bad = {}
     for n, row in table.items():
         for qi, q in enumerate(("y", "dx", "dparam")):

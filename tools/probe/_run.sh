@@ -1,3 +1,2 @@
 mkdir -p gpurun_out/r04
-STEP_PROFILE_TOP=60 timeout 600 python tools/step_profile.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > gpurun_out/r04/step_profile.txt
-head -90 gpurun_out/r04/step_profile.txt
+timeout 1500 python -m pytest tests/test_model_gpu.py -q -x -k "decoder_blocks" 2>&1 | grep -v "^$" | grep "Error\|^E  \|passed\|failed\|FAILED" | head -30 | cut -c1-900 > gpurun_out/r04/test_model.txt; cat gpurun_out/r04/test_model.txt
