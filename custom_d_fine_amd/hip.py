@@ -1187,10 +1187,25 @@ def _ld(t):
     return t.stride(1)
 
 
+def _pad_heads(t, num_heads, hd):
+    """[B, L, H * hd] -> [B, L, H * 32] with every head zero-padded to 32 channels (head dims 8 / 16 / 24 run on the head-dim-32
+    kernels: zero channels add nothing to q k^T, and the extra output channels of v are dropped)."""
+    B, L, _ = t.shape
+    return torch.nn.functional.pad(t.reshape(B, L, num_heads, hd), (0, 32 - hd)).reshape(B, L, num_heads * 32)
+
+
 def attn_forward(q, k, v, num_heads, mask=None):
-    """q, k, v [B, L, H * 32] bf16 views (e.g. column slices of the packed projection) -> o [B, L, H * 32] bf16, lse2 [B, H, L]."""
+    """q, k, v [B, L, H * hd] bf16 views (e.g. column slices of the packed projection), hd = 32 (or 8 / 16 / 24: padded copies)
+    -> o [B, L, H * hd] bf16, lse2 [B, H, L]."""
     B, L, E = q.shape
     hd = E // num_heads
+    if hd != 32:
+        qp, kp, vp = (_pad_heads(t, num_heads, hd) for t in (q, k, v))
+        o = torch.empty(B, L, num_heads * 32, device=q.device, dtype=torch.bfloat16)
+        lse2 = torch.empty(B, num_heads, L, device=q.device, dtype=torch.float32)
+        _check(_lib.dfine_attn_fwd(_ptr(qp), _ptr(kp), _ptr(vp), _ptr(o), _ptr(lse2), _ptr(mask), B, L, num_heads, 32, _ld(qp),
+                                   _ld(kp), _ld(vp), num_heads * 32, float(hd) ** -0.5, _stream()), "dfine_attn_fwd")
+        return o.reshape(B, L, num_heads, 32)[..., :hd].reshape(B, L, E), lse2
     o = torch.empty(B, L, E, device=q.device, dtype=torch.bfloat16)
     lse2 = torch.empty(B, num_heads, L, device=q.device, dtype=torch.float32)
     with _timed("attention", 4.0 * B * num_heads * L * L * hd, io=2.0 * 4 * B * num_heads * L * hd):
@@ -1204,6 +1219,15 @@ def attn_backward(q, k, v, o, dout, lse2, num_heads, dq, dk, dv, mask=None):
     B, L, E = q.shape
     hd = E // num_heads
     delta = torch.empty_like(lse2)
+    if hd != 32:
+        qp, kp, vp, op, dop = (_pad_heads(t, num_heads, hd) for t in (q, k, v, o, dout))
+        g = torch.empty(3, B, L, num_heads * 32, device=q.device, dtype=torch.bfloat16)
+        _check(_lib.dfine_attn_bwd(_ptr(qp), _ptr(kp), _ptr(vp), _ptr(op), _ptr(dop), _ptr(lse2), _ptr(mask), _ptr(g[0]), _ptr(g[1]),
+                                   _ptr(g[2]), _ptr(delta), B, L, num_heads, 32, _ld(qp), _ld(kp), _ld(vp), _ld(op), _ld(dop),
+                                   _ld(g[0]), _ld(g[1]), _ld(g[2]), float(hd) ** -0.5, _stream()), "dfine_attn_bwd")
+        for dst, src in zip((dq, dk, dv), g):
+            dst.copy_(src.reshape(B, L, num_heads, 32)[..., :hd].reshape(B, L, E))
+        return
     with _timed("attention", 10.0 * B * num_heads * L * L * hd, io=2.0 * 8 * B * num_heads * L * hd):
         _check(_lib.dfine_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(dout), _ptr(lse2), _ptr(mask), _ptr(dq), _ptr(dk),
                                    _ptr(dv), _ptr(delta), B, L, num_heads, hd, _ld(q), _ld(k), _ld(v), _ld(o), _ld(dout),
@@ -1369,8 +1393,16 @@ def stem_dgrad_s2(dy, wq, cin):
 _STEM_WS = {}
 
 
+def _stem_pad32(dy):
+    """The weight-gradient kernel walks the output rows in steps of 32 pixels: rows of another width run on a zero-padded
+    copy of dy (zero gradients add nothing; the kernel bounds-checks its reads of x)."""
+    wo = dy.shape[3]
+    return dy if wo % 32 == 0 else torch.nn.functional.pad(dy, (0, 32 - wo % 32))
+
+
 def stem_wgrad(x, dy, ks, stride, pad, side=False):
     """side: launched on the side stream (see dwconv_backward)."""
+    dy = _stem_pad32(dy)
     B, cin, H, W = x.shape
     _, cout, ho, wo = dy.shape
     need = int(_PURE.dfine_stem_wgrad_ws_floats(B, cin, cout, ks, ho, wo))
@@ -1415,6 +1447,7 @@ def stem_dgrad_s2_2(dy, wq, ca, cb):
 
 
 def stem_wgrad2(xa, xb, dy, ks, stride, pad, side=False):
+    dy = _stem_pad32(dy)
     B, ca, H, W = xa.shape
     cin = ca + xb.shape[1]
     _, cout, ho, wo = dy.shape

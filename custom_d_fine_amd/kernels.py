@@ -34,6 +34,19 @@ def _backend_for_cpu(op: str):
 _HIP = None
 
 
+def _library_fallback(what):
+    """A CUDA tensor under bf16 autocast reached an operator form the build has no kernel for.  The product does not drop to a
+    library (MIOpen / hipBLASLt / the SDPA kernels) silently: it raises, unless DFINE_ALLOW_LIBRARY=1 asks for the ATen
+    composition (comparison runs, shapes outside the reference's configurations)."""
+    if _env("DFINE_ALLOW_LIBRARY", "0") != "1":
+        raise RuntimeError(f"custom_d_fine_amd: no HIP kernel for {what} (bf16 autocast on the GPU); "
+                           "set DFINE_ALLOW_LIBRARY=1 to run the ATen / library composition instead")
+
+
+def _bf16_autocast():
+    return torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+
+
 def _hip():
     global _HIP
     if _HIP is None:                       # (a plain global: the import statement costs ~1 us per call, ~350 calls per forward pass)
@@ -806,7 +819,9 @@ class _DenseConv(torch.autograd.Function):
             dx = res[0] if aten_dx else None
             dw = res[1].to(weight.dtype) if aten_dw else None
         if need_dx and plan["dgrad"]:
-            dx = hip.conv_forward_bf16(dy, _packed_weights(weight, True), weight.shape[1], ks)
+            w2 = (hip.conv_pack_weights(weight.detach().float().contiguous(), True) if getattr(ctx, "direct", False)
+                  else _packed_weights(weight, True))
+            dx = hip.conv_forward_bf16(dy, w2, weight.shape[1], ks)
         if need_dw and plan["wgrad"]:
             slot = getattr(ctx, "slot", None)
             if slot is not None:
@@ -1102,7 +1117,34 @@ class _DenseConvMFMA(_DenseConv):
                                   weight.shape[0], ks)
         ctx.save_for_backward(x, weight)
         ctx.plan = {"fwd": True, "dgrad": True, "wgrad": hip.conv_wgrad_supported(x.shape[2], x.shape[3], ks)}
+        ctx.direct = True            # the weight may be a temporary (channel-padded copy): packed per call, never registered
         return y
+
+
+def _pad16_conv_ok(conv, x):
+    """Dense 1x1 / 3x3 stride-1 'same' convolutions whose channel counts are NOT multiples of 16 (the 21 / 43-channel units of
+    D-FINE-n's encoder, expansion 0.34): served by the MFMA kernels on zero-padded channels."""
+    k = conv.kernel_size
+    return (_env("DFINE_MFMA_CONV", "1") == "1" and conv.groups == 1 and k[0] == k[1] and k[0] in (1, 3)
+            and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.bias is None
+            and isinstance(conv.padding, tuple) and conv.padding == (k[0] // 2, k[0] // 2)
+            and (conv.in_channels % 16 != 0 or conv.out_channels % 16 != 0) and x.dim() == 4
+            and ((k[0] == 1 and (x.shape[-1] * x.shape[-2]) % 2 == 0)
+                 or (k[0] == 3 and x.shape[-1] % 2 == 0 and x.shape[-1] <= 160))
+            and _bf16_autocast())
+
+
+def _dense_conv_pad16(x, weight):
+    """conv(x) with input / output channels zero-padded to multiples of 16 around the MFMA kernels (zero input channels and
+    zero weight rows add nothing; the extra output channels are dropped).  The padding / slicing ops carry the gradients."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    cin_p, cout_p = (cin + 15) // 16 * 16, (cout + 15) // 16 * 16
+    xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+    if cin_p != cin:
+        xb = F.pad(xb, (0, 0, 0, 0, 0, cin_p - cin))
+    w = weight if (cin_p, cout_p) == (cin, cout) else F.pad(weight, (0, 0, 0, 0, 0, cin_p - cin, 0, cout_p - cout))
+    y = _DenseConvMFMA.apply(xb, w)
+    return y if cout_p == cout else y[:, :cout].contiguous()
 
 
 # ---- HGNetv2 stem: direct small-channel convolutions + pad-fused max-pool (csrc/stem.hip) ------------
@@ -1245,8 +1287,7 @@ def _stem_conv_ok(conv, x, pad_br):
         if ks == 2:
             return False
         wo = (W + 2 * pad - ks) // st + 1
-    if wo % 32:
-        return False                                    # MFMA weight-gradient kernel: 32-pixel K steps
+    # (the MFMA weight-gradient kernel walks 32-pixel K steps: narrower rows run on zero-padded copies of dy, hip.stem_wgrad)
     if st == 1:
         return hip.stem_supported(cout, cin, ks, 1)     # data gradient = same kernel, channels swapped
     if st == 2:
@@ -1332,6 +1373,8 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
                 route = 4
             elif _f32_conv_ok(conv, x):
                 route = 5
+            elif not pad_br and _pad16_conv_ok(conv, x):
+                route = 6
             else:
                 route = 0
             if len(routes[1]) > 64:
@@ -1367,7 +1410,11 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
                                 conv.stride[0], conv.padding[0], pad_br)
         elif route == 5:
             y = conv_f32(x, conv, pad_br)           # fp32 math (configs[1]): the f32-input MFMA kernels
+        elif route == 6:
+            y = _dense_conv_pad16(x, conv.weight)
         else:
+            if _bf16_autocast():
+                _library_fallback(f"{conv} on an input of shape {tuple(x.shape)}")
             y = conv(F.pad(x, (0, 1, 0, 1)) if pad_br else x)
         return _bn_tail(y, bn, a, act, lab)
     y = bn(conv(F.pad(x, (0, 1, 0, 1)) if pad_br else x))
@@ -1868,6 +1915,8 @@ def linear(x, weight, bias=None, act=None):
         if code == 1:
             return y
     else:
+        if x.is_cuda and x.numel() > 0 and _bf16_autocast() and _env("DFINE_HIP_LINEAR", "1") == "1":
+            _library_fallback(f"linear {tuple(weight.shape)} on {x.dtype} activations {tuple(x.shape)}")
         y = F.linear(x, weight, bias)
     if act is None or code == 0:
         return y
@@ -1946,7 +1995,7 @@ def self_attention(qk, value, in_w, in_b, out_w, out_b, num_heads: int, attn_mas
     boolean `attn_mask` [L, L], True = blocked (ref hybrid_encoder.py:243-290, dfine_decoder.py:200,233-255)."""
     b, l, e = qk.shape
     hd = e // num_heads
-    if (hd == 32 and e % 8 == 0 and in_b is not None and out_b is not None and _hip_linear_ok(qk, in_w)
+    if (hd in (8, 16, 24, 32) and e % 8 == 0 and in_b is not None and out_b is not None and _hip_linear_ok(qk, in_w)
             and _env("DFINE_HIP_ATTN", "1") == "1" and (attn_mask is None or (attn_mask.dtype == torch.bool and attn_mask.shape == (l, l)))):
         m8 = None if attn_mask is None else attn_mask.contiguous().view(torch.uint8)
         return _MHA.apply(qk, value, in_w, in_b, out_w, out_b, num_heads, m8)
@@ -1956,7 +2005,14 @@ def self_attention(qk, value, in_w, in_b, out_w, out_b, num_heads: int, attn_mas
     mask = None if attn_mask is None else ~attn_mask
     if _f32_gemm_ok(q, in_w):
         o = attention_f32(q, k, v, mask)
+    elif q.is_cuda and _bf16_autocast() and _env("DFINE_HIP_ATTN", "1") == "1" and _env("DFINE_F32_GEMM", "1") == "1":
+        # head dims the bf16 attention kernels do not take (48: the AIFI layer of D-FINE-x): both products on the f32-input
+        # MFMA GEMM (csrc/gemm_f32.hip) - the build's own kernels, a fraction of a millisecond for the one layer concerned
+        with torch.autocast("cuda", enabled=False):
+            o = attention_f32(q.float(), k.float(), v.float(), mask).to(q.dtype)
     else:
+        if q.is_cuda and _bf16_autocast() and _env("DFINE_HIP_ATTN", "1") == "1":
+            _library_fallback(f"self-attention with head dim {hd} (kernels: 8 / 16 / 24 / 32)")
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
     return linear(o.transpose(1, 2).reshape(b, l, e), out_w, out_b)
 
@@ -2208,6 +2264,8 @@ def conv_plain(x, conv: nn.Conv2d):
             probe = x[..., :_DenseConvWide._halves(W)[1]]          # the halves the wide form would run
             if _mfma_conv_ok(conv, probe):
                 return _DenseConvWide.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv.weight)
+        if _bf16_autocast():
+            _library_fallback(f"{conv} on an input of shape {tuple(x.shape)}")
     return conv(x)
 
 

@@ -83,6 +83,7 @@ def test_stem_block_matches_aten_composition(cuda):
 
     def run(flag, amp):
         os.environ["DFINE_STEM"] = flag
+        os.environ["DFINE_ALLOW_LIBRARY"] = "1" if flag == "0" else "0"      # the ATen / MIOpen composition is the comparison run
         kernels.reload_env()
         blk.zero_grad()
         for m in blk.modules():
@@ -99,6 +100,7 @@ def test_stem_block_matches_aten_composition(cuda):
         y_ref, g_ref = run("0", False)
     finally:
         os.environ.pop("DFINE_STEM", None)
+        os.environ.pop("DFINE_ALLOW_LIBRARY", None)
         kernels.reload_env()
     cos = lambda a, b: torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
     assert _rel(y_hip, y_ref) < max(3e-2, 1.5 * _rel(y_aten, y_ref))
