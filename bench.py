@@ -97,29 +97,44 @@ def conv_pmc_traffic():
     for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
         if name.endswith("_conv_pmc.json"):
             best = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if isinstance(best, dict):
+                # a committed counter pass of an earlier run on another box, not a measurement of THIS run
+                best = dict(best, source=f"profiles/{name}", measured_in_run=False)
     return best
 
 
 def cpu_baseline(model_name, img, steps):
-    """The same train step on the host through the oracle backend (kind 'port')."""
+    """The same train step on the host through the oracle backend (kind 'port'), as BASELINE.md section 3 asks: fp32, bs 2,
+    one intra-op thread per PHYSICAL core, 1 warm-up + `steps` timed steps, median."""
     from oracle import torch_backend
     from custom_d_fine_amd.dl.synthetic import make_batch
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        cores = os.cpu_count()
+    before = torch.get_num_threads()
+    torch.set_num_threads(int(cores))
     torch_backend.install()
     try:
         bs = 2
         step = build_step(model_name, img, torch.device("cpu"), None)
         images, targets = make_batch(bs, img, seed=42)
         step(images, targets)  # warm-up (allocator, thread pools)
-        t0 = time.perf_counter()
+        times = []
         for _ in range(steps):
+            t0 = time.perf_counter()
             step(images, targets)
-        dt = time.perf_counter() - t0
+            times.append(time.perf_counter() - t0)
     finally:
         torch_backend.uninstall()
-    return {"value": round(bs * steps / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(),
+        torch.set_num_threads(before)
+    med = statistics.median(times)
+    return {"value": round(bs / med, 4), "unit": "images/sec", "cores": int(cores),
             "kind": "port",
-            "sample": f"D-FINE-{model_name} {img}x{img} bs={bs} fp32 full train step, 1 warm-up + {steps} timed steps "
-                      f"({dt:.1f} s) through oracle/torch_backend.py on {os.cpu_count()} logical host CPUs"}
+            "sample": f"D-FINE-{model_name} {img}x{img} bs={bs} fp32 full train step, 1 warm-up + {steps} timed steps (median "
+                      f"{med:.2f} s, total {sum(times):.1f} s) through oracle/torch_backend.py, {cores} intra-op threads = physical "
+                      f"cores of {os.cpu_count()} logical host CPUs"}
 
 
 def _self_spawn(n):
@@ -157,7 +172,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--mask", type=int, default=0, help="1: segmentation head (BASELINE configs[4])")
-    ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-baseline steps (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (0 = skip)")
     ap.add_argument("--sample-every", type=int, default=50,
                     help="instrument every n-th timed step with HIP events around the kernel launches (0 = none); an instrumented "
                          "step is ~15 ms slower, so the default samples one step of the 50")
@@ -225,10 +240,13 @@ def main():
         print("per-step ms:", " ".join(f"{t:.1f}" for t in per_step), file=sys.stderr)
     timing = hip.timing_summary()
     hip.disable_timing()
+    per_rank = [elapsed]
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        mine = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [e.item() for e in every]          # the ranks' own clocks: the line reports the slowest
+        elapsed = max(per_rank)
 
     if rank == 0:
         max_t = max(len(t["labels"]) for t in targets)
@@ -287,7 +305,9 @@ def main():
                                    "(fwd + Hungarian matcher/criterion + bwd + clip + AdamW + EMA), COCO-80 synthetic labels",
                        "global_batch": args.batch * world, "queries": lq, "parallelism": f"dp{world}",
                        "collective": f"RCCL all-reduce over {world} ranks" if world > 1 else "none",
-                       "instrumented_steps": sampled},
+                       "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
+                       "ranks_seen": world, "per_rank_ms_per_step": [round(e / args.steps * 1e3, 3) for e in per_rank],
+                       "hip_graph": bool(getattr(step, "hip_graph", False)), "instrumented_steps": sampled},
             "roofline": family,
             "roofline_kernels": [k for k in kernels_ if k is not None and k.get("launches_per_step", 0) > 0],
         }

@@ -372,7 +372,7 @@ class DFINECriterion(nn.Module):
             # fused: targets of the whole batch at mask resolution once per step (shared with the matcher); the matched
             # prediction planes, target planes and boxes are read in place through the plan - no per-image host loop
             gt_all, _, _ = self.matcher.gt_masks_at(targets, hm, wm, pm.device)
-            bkey = (id(targets), hm, wm)
+            bkey = (id(targets), hm, wm, tuple((t["boxes"].data_ptr(), t["boxes"]._version, len(t["boxes"])) for t in targets))
             if getattr(self, "_mask_box_cache", (None,))[0] != bkey:
                 b = self._targets_cat(targets)[1].float().to(pm.device)
                 cx, cy, w, h = b.unbind(1)

@@ -155,7 +155,9 @@ class HungarianMatcher(nn.Module):
         """The batch's target masks at mask resolution, concatenated [sum T, hm, wm] f32 (+ int32 offsets [B + 1] and the
         per-mask pixel sums): prepared once per step and shared by the cost kernel of every head and by the criterion's mask
         losses (the reference resizes them per image in every matcher call and every loss branch)."""
-        key = (id(targets), hm, wm, str(device))
+        # (identity of the list AND a fingerprint of its contents: a caller may refill or edit the same list object)
+        key = (id(targets), hm, wm, str(device), tuple((t["masks"].data_ptr(), t["masks"]._version, len(t["boxes"]))
+                                                        if t.get("masks") is not None else (0, 0, len(t["boxes"])) for t in targets))
         cache = getattr(self, "_gt_mask_cache", None)
         if cache is None or cache[0] != key:
             sizes = [len(t["boxes"]) for t in targets]

@@ -74,6 +74,7 @@ class Torch_model:
         self.device = device or ("cuda" if torch.cuda.is_available() else "cpu")
         self._thr = None
         self.hip_graph = bool(hip_graph) and str(self.device).startswith("cuda")
+        self.max_graphs = 8                              # captured input shapes kept (least recently used dropped)
         self._graphs = {}
         self._load_model()
         self._test_pred()
@@ -213,20 +214,27 @@ class Torch_model:
         if not (self.hip_graph and inputs.is_cuda):
             return self._forward(inputs)
         key = tuple(inputs.shape)
-        ent = self._graphs.get(key)
+        ent = self._graphs.pop(key, None)
         if ent is None:
-            ent = self._graphs[key] = self._capture(inputs)
+            # one captured graph (static input, outputs, private memory pool) per input shape: with `rect` inputs or varying
+            # batch sizes the shapes are unbounded, so only the most recently used few are kept
+            while len(self._graphs) >= self.max_graphs:
+                self._graphs.pop(next(iter(self._graphs)))
+            ent = self._capture(inputs)
+        self._graphs[key] = ent                            # (re-inserted: most recently used last)
         if ent is False:                                   # capture failed for this shape: eager from now on
             return self._forward(inputs)
         static_in, graph, static_out = ent
         static_in.copy_(inputs)
         graph.replay()
-        return static_out
+        # the graph's output tensors are overwritten by the next replay: hand out copies
+        return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in static_out.items()} if isinstance(static_out, dict) else static_out
 
     def _capture(self, inputs):
         """Warm-up on a side stream (fills the anchor / packed-weight / constant caches), then one capture of the forward."""
         from .. import kernels as K
         static_in = inputs.clone()
+        flags = (K._CAPTURE_POSSIBLE, K._CAPTURE_FROZEN_WEIGHTS)
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -246,7 +254,7 @@ class Torch_model:
             torch.cuda.synchronize()
             return False
         finally:
-            K._CAPTURE_FROZEN_WEIGHTS = False
+            K._CAPTURE_POSSIBLE, K._CAPTURE_FROZEN_WEIGHTS = flags
 
     def _postprocess(self, preds, processed_sizes, original_sizes):
         output = self._preds_postprocess(preds, processed_sizes, original_sizes)

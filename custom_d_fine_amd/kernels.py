@@ -704,53 +704,19 @@ def bf16_param_t(p):
     return c
 
 
-def _time_op(fn, reps=4):
-    fn()
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) / reps
-
-
 def _conv_plan(x, weight):
-    """{'fwd','dgrad','wgrad'} -> True when the HIP kernel is the faster one for this shape."""
-    hip = _hip()
-    B, cin, H, W = x.shape
-    cout, _, ks, _ = weight.shape
-    key = (B, cin, cout, H, W, ks)
+    """{'fwd','dgrad','wgrad'}: the HIP kernels serve every dense 1x1 / 3x3 stride-1 convolution `_mfma_conv_ok` lets through
+    (weight gradients of narrow planes on zero-padded copies, hip.conv_wgrad_bf16).  The per-shape timing against MIOpen of
+    rounds 1-3 lives in tools/conv_survey.py; the product has one route."""
+    H, W = x.shape[2], x.shape[3]
+    ks = weight.shape[-1]
+    key = (H, W, ks)
     plan = _CONV_PLAN.get(key)
-    if plan is not None:
-        return plan
-    mode = _env("DFINE_CONV_TUNE", "hip")   # "hip" (default): HIP kernels only; "1": per-shape timing against MIOpen; "aten"
-    if mode != "1":                      # "hip" / "aten": force one side (debugging, A/B runs)
-        plan = {k: mode == "hip" for k in ("fwd", "dgrad", "wgrad")}
-        plan["wgrad"] = plan["wgrad"] and hip.conv_wgrad_supported(H, W, ks)
-        _CONV_PLAN[key] = plan
-        return plan
-    pad = ks // 2
-    with torch.no_grad():
-        xs = torch.randn(x.shape, device=x.device, dtype=torch.bfloat16)
-        dy = torch.randn(B, cout, H, W, device=x.device, dtype=torch.bfloat16)
-        w32 = weight.detach().float().contiguous()
-        wb = w32.to(torch.bfloat16)
-
-        def aten_bwd(mask):
-            return torch.ops.aten.convolution_backward(dy, xs, wb, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1, mask)
-
-        w2f, w2d = hip.conv_pack_weights(w32, False), hip.conv_pack_weights(w32, True)   # cached per step
-        plan = {
-            "fwd": _time_op(lambda: hip.conv_forward_bf16(xs, w2f, cout, ks))
-            < _time_op(lambda: F.conv2d(xs, w32.to(torch.bfloat16), None, 1, pad)),
-            "dgrad": _time_op(lambda: hip.conv_forward_bf16(dy, w2d, cin, ks))
-            < _time_op(lambda: aten_bwd([True, False, False])),
-            "wgrad": hip.conv_wgrad_supported(H, W, ks)
-            and _time_op(lambda: hip.conv_wgrad_bf16(xs, dy, ks)) < _time_op(lambda: aten_bwd([False, True, False])[1].float()),
-        }
-    _CONV_PLAN[key] = plan
+    if plan is None:
+        ok = _hip().conv_wgrad_supported(H, W, ks)
+        if not ok:
+            raise RuntimeError(f"custom_d_fine_amd: no HIP weight-gradient kernel for a {ks}x{ks} convolution on {H}x{W} maps")
+        plan = _CONV_PLAN[key] = {"fwd": True, "dgrad": True, "wgrad": True}
     return plan
 
 
@@ -758,8 +724,8 @@ _FUSE_CONV_BN = os.environ.get("DFINE_FUSE_CONV_BN", "1") == "1"
 
 
 def _conv_plan_all_hip(x, weight):
-    plan = _conv_plan(x, weight)
-    return plan["fwd"] and plan["dgrad"] and plan["wgrad"]
+    _conv_plan(x, weight)
+    return True
 
 
 def _defer_slot(*params):
@@ -777,23 +743,17 @@ def _defer_slot(*params):
 
 class _DenseConv(torch.autograd.Function):
     """1x1 / 3x3 stride-1 dense convolution, NCHW bf16: forward / data gradient / weight gradient on the HIP implicit-GEMM
-    MFMA kernels (conv.hip).  (`DFINE_CONV_TUNE=1` restores the round-1 per-shape timing against MIOpen for comparison
-    runs, `DFINE_CONV_TUNE=aten` forces MIOpen.)"""
+    MFMA kernels (conv.hip)."""
 
     @staticmethod
     def forward(ctx, x, weight):
         hip = _hip()
         x = x.contiguous()
-        plan = _conv_plan(x, weight)
+        _conv_plan(x, weight)
         ks = weight.shape[-1]
-        if plan["fwd"]:
-            y = hip.conv_forward_bf16(x, _packed_weights(weight, False), weight.shape[0], ks)
-        else:
-            with hip.timed("miopen_conv", 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * weight.numel()):
-                y = F.conv2d(x, bf16_param(weight), None, 1, ks // 2)
+        y = hip.conv_forward_bf16(x, _packed_weights(weight, False), weight.shape[0], ks)
         ctx.save_for_backward(x, weight)
-        ctx.plan = plan
-        ctx.slot = _defer_slot(weight) if (plan["wgrad"] and ctx.needs_input_grad[1]) else None
+        ctx.slot = _defer_slot(weight) if ctx.needs_input_grad[1] else None
         if ctx.slot is not None:
             ctx.slot[0].note_use(ctx.slot[1][0])
         return y
@@ -802,27 +762,17 @@ class _DenseConv(torch.autograd.Function):
     def backward(ctx, dy):
         hip = _hip()
         x, weight = ctx.saved_tensors
-        plan = ctx.plan
         dy = dy.contiguous()
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         ks = weight.shape[-1]
-        pad = ks // 2
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dx = dw = None
-        aten_dx, aten_dw = need_dx and not plan["dgrad"], need_dw and not plan["wgrad"]
-        if aten_dx or aten_dw:
-            with hip.timed("miopen_conv", 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * weight.numel() * (int(aten_dx) + int(aten_dw))):
-                res = torch.ops.aten.convolution_backward(
-                    dy, x, bf16_param(weight), None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
-                    [aten_dx, aten_dw, False])
-            dx = res[0] if aten_dx else None
-            dw = res[1].to(weight.dtype) if aten_dw else None
-        if need_dx and plan["dgrad"]:
+        if need_dx:
             w2 = (hip.conv_pack_weights(weight.detach().float().contiguous(), True) if getattr(ctx, "direct", False)
                   else _packed_weights(weight, True))
             dx = hip.conv_forward_bf16(dy, w2, weight.shape[1], ks)
-        if need_dw and plan["wgrad"]:
+        if need_dw:
             slot = getattr(ctx, "slot", None)
             if slot is not None:
                 ws, meta = hip.conv_wgrad_bf16(x, dy, ks, partials=True)
@@ -1039,12 +989,8 @@ class _DualConv(torch.autograd.Function):
                     ws, meta = hip.conv_wgrad_bf16(x, dy, ks, partials=True)
                     slot[0].defer_wgrad(slot[1][0], ws, meta)
                     slot[0].use_done(slot[1][0])
-                elif hip.conv_wgrad_supported(x.shape[2], x.shape[3], ks):
-                    g = hip.conv_wgrad_bf16(x, dy, ks).to(w.dtype)
                 else:
-                    pad = ks // 2
-                    g = torch.ops.aten.convolution_backward(dy, x, bf16_param(w), None, [1, 1], [pad, pad], [1, 1], False,
-                                                            [0, 0], 1, [False, True, False])[1].to(w.dtype)
+                    g = hip.conv_wgrad_bf16(x, dy, ks).to(w.dtype)
             grads.append(g)
         return dx, grads[0], grads[1]
 
@@ -1116,7 +1062,6 @@ class _DenseConvMFMA(_DenseConv):
         y = hip.conv_forward_bf16(x, hip.conv_pack_weights(weight.detach().float().contiguous(), False),
                                   weight.shape[0], ks)
         ctx.save_for_backward(x, weight)
-        ctx.plan = {"fwd": True, "dgrad": True, "wgrad": hip.conv_wgrad_supported(x.shape[2], x.shape[3], ks)}
         ctx.direct = True            # the weight may be a temporary (channel-padded copy): packed per call, never registered
         return y
 
@@ -1526,7 +1471,7 @@ def repvgg_unit(x, conv1: nn.Conv2d, bn1, conv2: nn.Conv2d, bn2, act: Optional[s
                       and _bn_trainable(bn1) and _bn_trainable(bn2) and type(bn1) is nn.BatchNorm2d and type(bn2) is nn.BatchNorm2d
                       and _mfma_conv_ok(conv1, x) and _mfma_conv_ok(conv2, x)
                       and conv1.kernel_size == (3, 3) and conv2.kernel_size == (1, 1) and conv1.out_channels == conv2.out_channels
-                      and _env("DFINE_CONV_TUNE", "hip") == "hip" and _env("DFINE_DUAL_CONV", "1") == "1"
+                      and _env("DFINE_DUAL_CONV", "1") == "1"
                       and _hip().bn2_supported(torch.empty(x.shape[0], conv1.out_channels, x.shape[2], x.shape[3], device="meta",
                                                            dtype=torch.bfloat16))
                       and (residual is None or (residual.shape == (x.shape[0], conv1.out_channels, x.shape[2], x.shape[3])
@@ -1548,8 +1493,7 @@ def repvgg_unit(x, conv1: nn.Conv2d, bn1, conv2: nn.Conv2d, bn2, act: Optional[s
             and _env("DFINE_BN2", "1") == "1" and _bn_trainable(bn1) and _bn_trainable(bn2)
             and _mfma_conv_ok(conv1, x) and _mfma_conv_ok(conv2, x)):
         xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
-        if (conv1.kernel_size == (3, 3) and conv2.kernel_size == (1, 1) and _env("DFINE_CONV_TUNE", "hip") == "hip"
-                and _env("DFINE_DUAL_CONV", "1") == "1"):
+        if conv1.kernel_size == (3, 3) and conv2.kernel_size == (1, 1) and _env("DFINE_DUAL_CONV", "1") == "1":
             c1, c2 = _DualConv.apply(xb, conv1.weight, conv2.weight)
         else:
             c1 = _DenseConv.apply(xb, conv1.weight)

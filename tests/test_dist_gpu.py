@@ -21,19 +21,23 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, overlap):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), DFINE_CONV_TUNE="hip")      # no per-shape timing runs in the test
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
-    dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
+def _worker(rank, world, port, out_dir, overlap, graph=False, backend="gloo"):
+    local = rank if backend == "nccl" else 0           # RCCL: one device per rank; gloo: both ranks share the box's single GPU
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if backend == "nccl":
+        dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
     from custom_d_fine_amd.d_fine import dfine
     from custom_d_fine_amd.dl.engine import ModelEMA, TrainStep
     from custom_d_fine_amd.dl.fused_optim import FusedAdamWEMA
     from custom_d_fine_amd.dl.synthetic import make_batch
 
     torch.manual_seed(100 + rank)                      # different initial weights: rank 0's must win
-    model = dfine.build_model("n", 5, False, "cuda:0", img_size=[320, 320]).train()
+    model = dfine.build_model("n", 5, False, str(dev), img_size=[320, 320]).train()
     crit = dfine.build_loss("n", 5, 0.0, False)
     ema = ModelEMA(model, 0.9998)
     model.backbone.stem.stem1.conv.weight.requires_grad_(False)     # a frozen parameter (the l / x configs freeze the stem)
@@ -44,11 +48,11 @@ def _worker(rank, world, port, out_dir, overlap):
     # every rank now holds rank 0's WHOLE state (frozen parameters, integer buffers and the EMA copy included)
     for name, sd in (("model", model.state_dict()), ("ema", ema.model.state_dict())):
         for k, v in sd.items():
-            mine = v.detach().cpu().contiguous()
+            mine = v.detach().contiguous() if backend == "nccl" else v.detach().cpu().contiguous()
             both = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(both, mine)
-            assert torch.equal(both[0], both[1]), f"{name}.{k} differs between the ranks after broadcast_from_rank0"
-    step = TrainStep(model, crit, opt, amp_dtype=torch.bfloat16, clip_max_norm=0.1, ema=ema, fused_optimizer=fused)
+            assert all(torch.equal(both[0], b) for b in both[1:]), f"{name}.{k} differs between the ranks after broadcast_from_rank0"
+    step = TrainStep(model, crit, opt, amp_dtype=torch.bfloat16, clip_max_norm=0.1, ema=ema, fused_optimizer=fused, hip_graph=graph)
     images, targets = make_batch(2, 320, num_classes=5, seed=42 + rank, device=dev)      # different data per rank
     # ---- the bucketed all-reduce launched from backward hooks vs the single-shot all-reduce after backward, on gradients
     # that are deterministic functions of (rank, parameter): the reduced flat buffers must be bit-identical (the sum over
@@ -96,14 +100,16 @@ def _worker(rank, world, port, out_dir, overlap):
     del twin, twin_opt, twin_fused
 
     losses = []
-    for _ in range(2):
+    for _ in range(3 if graph else 2):
         loss, loss_dict = step(images, targets)
         losses.append(loss.item())
     torch.cuda.synchronize()
-    flat = fused.flat_param.detach().cpu()
+    assert not graph or step._graphs, "the captured backbone + encoder segment did not run"
+    flat = fused.flat_param.detach() if backend == "nccl" else fused.flat_param.detach().cpu()
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
-    assert torch.equal(gathered[0], gathered[1]), "ranks diverged: the averaged-gradient step must keep them identical"
+    flat = flat.cpu()
+    assert all(torch.equal(gathered[0], g) for g in gathered[1:]), "ranks diverged: the averaged-gradient step must keep them identical"
     assert all(torch.isfinite(torch.tensor(l)) for l in losses)
     torch.save({"losses": losses, "n_losses": len(loss_dict), "checksum": flat.double().sum().item(), "flat": flat},
                os.path.join(out_dir, f"rank{rank}_{int(overlap)}.pt"))
@@ -111,11 +117,24 @@ def _worker(rank, world, port, out_dir, overlap):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_two_rank_fused_train_step_shared_gpu(cuda, tmp_path, overlap):
+@pytest.mark.parametrize("overlap,graph", [(True, False), (False, False), (True, True)])
+def test_two_rank_fused_train_step_shared_gpu(cuda, tmp_path, overlap, graph):
+    """graph: backbone + encoder through the captured HIP graphs (the bench's default mode) - the segment's gradients reach the
+    flat buffer inside the graph, the buckets are reported after its replay, the GO count is all-reduced on the device."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), overlap), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), overlap, graph), nprocs=world, join=True)
     r0, r1 = torch.load(tmp_path / f"rank0_{int(overlap)}.pt"), torch.load(tmp_path / f"rank1_{int(overlap)}.pt")
     assert r0["checksum"] == r1["checksum"] and r0["n_losses"] == r1["n_losses"]
     assert torch.equal(r0["flat"], r1["flat"])
     assert r0["losses"] != r1["losses"]                # different data per rank
+
+
+def test_rccl_all_devices_fused_train_step(tmp_path):
+    """The same step over RCCL with one rank per visible GPU (what `bench.py --gpus N` runs).  Needs at least two devices:
+    skipped on the single-GPU test boxes - no multi-rank RCCL run exists for this build yet."""
+    world = torch.cuda.device_count()
+    if world < 2:
+        pytest.skip("one GPU visible: RCCL needs one device per rank")
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True, True, "nccl"), nprocs=world, join=True)
+    runs = [torch.load(tmp_path / f"rank{r}_1.pt") for r in range(world)]
+    assert all(torch.equal(runs[0]["flat"], r["flat"]) for r in runs[1:])

@@ -3,6 +3,7 @@ import os, sys, time, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn as nn, torch.nn.functional as F
 os.environ["DFINE_MFMA_CONV"] = "0"   # let every dense conv go through nn.Conv2d so the hook sees it
+os.environ["DFINE_ALLOW_LIBRARY"] = "1"   # (the product raises instead of dropping to MIOpen; this tool measures MIOpen)
 from custom_d_fine_amd.d_fine import dfine
 
 dev = torch.device("cuda", 0)
