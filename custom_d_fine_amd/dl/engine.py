@@ -196,6 +196,11 @@ class GraphedSegment:
         # grouped weight-gradient launches every few registrations: a replay has no host cost per launch (the eager step
         # groups 32 to save ~25 us of host time each), and small groups keep the side stream's work evenly spread
         hip._SIDE_GROUP_AT = int(os.environ.get("DFINE_GRAPH_GROUP_AT", "8"))
+        # (DFINE_GRAPH_EARLY_REDUCE=n: the partial sums of every n registered weight gradients reduced on the side stream while
+        # backward goes on - measured 33.17 / 33.24 against 33.12 / 33.27 ms per step without: the side stream is the one that
+        # finishes last, moving the reduction there gains nothing; off)
+        early_at = fused._early_at
+        fused._early_at = int(os.environ.get("DFINE_GRAPH_EARLY_REDUCE", "0")) or (1 << 30)
         try:
             # ---- eager warm-up on the capture stream: fills the shadow registries for the aliases, sizes the workspaces
             with torch.cuda.stream(cap_stream):
@@ -260,6 +265,7 @@ class GraphedSegment:
             kernels._CAPTURE_POSSIBLE, kernels._CAPTURE_SHADOWS, hip.CAPTURE_SIDE, arch_utils.CAPTURE_KEEP = flags
             hip.CAPTURE_DUAL = None
             hip._SIDE_GROUP_AT = group_at
+            fused._early_at = early_at
             fused.accumulating = was_accumulating
         self._token = torch.zeros((), device=dev, requires_grad=True)     # makes autograd call _Replay.backward
         seg = self
@@ -344,6 +350,10 @@ class TrainStep:
         kernels.flush_bn_counters()
         if self.fused is not None:
             self.fused.step()
+            if self.hip_graph and self._graphs:
+                # the packed / bf16 weight copies the captured forward reads: refreshed right behind the optimizer's kernels
+                # instead of at the start of the next step (the device would wait ~0.1 ms for the host to get there)
+                kernels.refresh_weight_shadows(self.fused.flat_param.device)
             if step_scheduler and self.scheduler is not None:
                 self.scheduler.step()
             self.iters += 1

@@ -375,6 +375,9 @@ def head_losses(logits, boxes, corners, ref, teacher_corners, teacher_logits, cl
 # =============================================================================================
 # A1/A2  conv -> BatchNorm -> activation -> learnable affine units of backbone and encoder
 # =============================================================================================
+_STEM_WGRAD_SIDE = os.environ.get("DFINE_STEM_WGRAD_SIDE", "1") == "1"
+
+
 def _side_wgrad_ok(weight):
     """May this parameter's gradient TENSOR be produced on the side stream (hip._side_fork)?  Only when its sole consumer is the
     fused optimizer's gather (which joins the side stream first): the parameter is managed by it, fp32 (no cast kernel on
@@ -1143,7 +1146,7 @@ class _StemConv(torch.autograd.Function):
             else:
                 dx = hip.stem_dgrad_s2(dy, _packed_stem(weight, 2), cin)
         if ctx.needs_input_grad[1]:
-            dw = hip.stem_wgrad(x, dy, ks, stride, pad, side=_side_wgrad_ok(weight)).to(weight.dtype)
+            dw = hip.stem_wgrad(x, dy, ks, stride, pad, side=_STEM_WGRAD_SIDE and _side_wgrad_ok(weight)).to(weight.dtype)
         return dx, dw, None, None, None
 
 
@@ -1177,7 +1180,7 @@ class _StemConv2(torch.autograd.Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dxa, dxb = hip.stem_dgrad_s2_2(dy, _packed_stem(weight, 2), xa.shape[1], xb.shape[1])
         if ctx.needs_input_grad[2]:
-            dw = hip.stem_wgrad2(xa, xb, dy, ks, 2, ctx.pad, side=_side_wgrad_ok(weight)).to(weight.dtype)
+            dw = hip.stem_wgrad2(xa, xb, dy, ks, 2, ctx.pad, side=_STEM_WGRAD_SIDE and _side_wgrad_ok(weight)).to(weight.dtype)
         return dxa, dxb, dw, None
 
 

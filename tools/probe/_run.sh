@@ -1,2 +1,3 @@
-mkdir -p gpurun_out/r04
-timeout 2400 python -m pytest tests/test_stem_gpu.py tests/test_train_trace.py tests/test_model_gpu.py tests/test_no_library_gpu.py -m gpu -q -n 2 2>&1 | grep -v "^$" | grep "Error\|^E  \|passed\|failed\|FAILED" | head -30 | cut -c1-1200 > gpurun_out/r04/test_all.txt; cat gpurun_out/r04/test_all.txt
+for cfg in "DFINE_STEM_WGRAD_SIDE=1" "DFINE_STEM_WGRAD_SIDE=0" "DFINE_STEM_WGRAD_SIDE=1" "DFINE_STEM_WGRAD_SIDE=0"; do
+echo "== $cfg"; env $cfg timeout 600 python bench.py --steps 60 --warmup 10 --cpu-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['median_ms_per_step'])"
+done
