@@ -1,3 +1,1 @@
-for cfg in "DFINE_STEM_WGRAD_SIDE=1" "DFINE_STEM_WGRAD_SIDE=0" "DFINE_STEM_WGRAD_SIDE=1" "DFINE_STEM_WGRAD_SIDE=0"; do
-echo "== $cfg"; env $cfg timeout 600 python bench.py --steps 60 --warmup 10 --cpu-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['median_ms_per_step'])"
-done
+DFINE_HIPGRAPH=0 timeout 600 python tools/step_aten_sites.py add add_ mul copy_ to cat clone contiguous _to_copy sum 2>&1 | grep -v -i "warn\|amdgpu" | head -50
