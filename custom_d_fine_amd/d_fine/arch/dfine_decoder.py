@@ -312,9 +312,11 @@ class TransformerDecoder(nn.Module):
 
             # FDR: residual update of the edge distributions, decoded around the initial box
             pred_corners = bbox_head[i](out + out_detach) + prev_corners
-            fused = pred_corners.is_cuda and self.reg_max == 32 and isinstance(self.lqe_layers[i], LQE) \
-                and self.lqe_layers[i].k == 4
-            if fused:   # Integral + distance2bbox + LQE statistics in one HIP kernel
+            # Integral + distance2bbox (+ the LQE statistics) in one HIP kernel; after deploy() the layers in front of eval_idx
+            # carry an nn.Identity in place of their LQE (ref dfine_decoder.py:422-427) and only take the boxes
+            fused_box = pred_corners.is_cuda and self.reg_max == 32
+            fused = fused_box and isinstance(self.lqe_layers[i], LQE) and self.lqe_layers[i].k == 4
+            if fused_box:
                 wtable, rs = self._fdr_constants(project, reg_scale)
                 box, stat = kernels.fdr_decode(pred_corners, ref_initial, wtable, rs)
             else:

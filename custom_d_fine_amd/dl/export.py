@@ -83,3 +83,34 @@ def export_artifact(model, num_classes, img_size, path):
     torch.save({"state_dict": model.state_dict(), "num_classes": num_classes, "img_size": list(img_size),
                 "postprocessor": {"num_top_queries": 300, "use_focal_loss": True}}, path)
     return path
+
+
+def main(argv=None):
+    """`python -m custom_d_fine_amd.dl.export [key=value ...]` (alias `python -m src.dl.export`): the reference's export entry
+    point (src/dl/export.py:278-334) for this stack - loads `<train.path_to_save>/model.pt`, deploys the model and writes
+    `<train.path_to_save>/model.pt2`, a `torch.export` ExportedProgram of model + post-processor whose launches go through
+    libdfine_hip.so (dl/export_program.py), next to the self-describing weight artefact `model_hip.pt`.  Keys: the train
+    config's (`model_name`, `task`, `train.img_size`, `train.num_classes` or `train.label_to_name`, `train.path_to_save`) and
+    `export.half` (bf16 autocast, default true), `export.max_batch_size` (the exported batch size, default 1)."""
+    import sys
+    from .train import load_config
+    from .export_program import export_program
+    cfg = load_config(sys.argv[1:] if argv is None else argv)
+    t = cfg["train"]
+    ex = cfg.get("export", {}) or {}
+    if not torch.cuda.is_available():
+        raise SystemExit("export traces the HIP-backed forward and needs the MI355X")
+    if "label_to_name" not in t:
+        t["label_to_name"] = {i: str(i) for i in range(t["num_classes"])}
+    model = prepare_model(cfg, "cuda")
+    n_cls = len(t["label_to_name"])
+    out = Path(t["path_to_save"])
+    export_artifact(model, n_cls, t["img_size"], out / "model_hip.pt")
+    path, ep = export_program(model, n_cls, t["img_size"], out / "model.pt2", batch=int(ex.get("max_batch_size", 1)),
+                              half=bool(ex.get("half", True)))
+    print(f"exported {path} ({path.stat().st_size >> 20} MiB)")
+    return path
+
+
+if __name__ == "__main__":
+    main()
