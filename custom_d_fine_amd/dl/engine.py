@@ -147,6 +147,7 @@ class GraphedSegment:
         self.device = dev
         self.static_in = [t.detach().clone() for t in sample_inputs]
         self._keep, self._pinned = [], hip.CaptureArena()
+        self.preflush = os.environ.get("DFINE_GRAPH_PREFLUSH", "1") == "1"
         self.side = os.environ.get("DFINE_GRAPH_SIDE", "dual")           # "dual" | "fork" | "0"
         if not hip.WGRAD_STREAM:
             self.side = "0"
@@ -297,6 +298,12 @@ class GraphedSegment:
                         dst.zero_()
                     elif dst.data_ptr() != src.data_ptr():
                         dst.copy_(src)
+                f = seg.fused
+                if seg.preflush and not f.accumulating and hip.side_stream_ok():
+                    # what the decoder's backward has registered so far - grouped weight-gradient launches still pending, partial
+                    # sums to reduce - goes to the side stream now, under the segment's backward, instead of running serially
+                    # in front of the optimizer step (joined by the optimizer's gather like every side-stream launch)
+                    f._flush_deferred(side=True)
                 if seg.bwd_pairs is not None:
                     cur, st = hip._stream(), hip.side_stream(seg.device)
                     serial = os.environ.get("DFINE_GRAPH_SERIAL") == "1"        # debugging: no overlap between the two streams
