@@ -198,6 +198,8 @@ class FusedAdamWEMA:
                 dist.broadcast(t, 0)
         from ..d_fine.arch.utils import invalidate_weighting_cache
         invalidate_weighting_cache()         # `up` / `reg_scale` are frozen parameters: just rewritten through .data
+        from .. import kernels
+        kernels.bump_weight_epoch()          # ... and the cached packed / bf16 weight copies are stale
         if self.ema is not None:
             self.flat_ema.copy_(self.flat_param)
             if self.flat_ema_buf is not None:

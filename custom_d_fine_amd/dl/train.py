@@ -174,6 +174,8 @@ class Trainer:
                 g["lr"] = lr
         self.step.iters = state["iters"]
         self.start_epoch = state["epoch"] + 1
+        from .. import kernels
+        kernels.bump_weight_epoch()          # the weights changed under the cached packed / bf16 copies (and under a captured segment)
 
     @torch.no_grad()
     def evaluate(self, n_batches=2, conf_thresh=0.5, iou_thresh=0.5, keep_ratio=False):
