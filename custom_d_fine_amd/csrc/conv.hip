@@ -1379,13 +1379,17 @@ __global__ __launch_bounds__(kW2Threads) void conv_wgrad1_group_kernel(const int
                                  B * cpi, cps, nct, (Cout + 15) / 16 * 16, (Cin + 15) / 16 * 16, npairs, splits, blockIdx.x);
 }
 
-static void wgrad1_plan(int B, int Cin, int Cout, int HW, int *splits, int *cps) {
+// wg_target: workgroups the problem should occupy - 256 (one per CU, one round: the load path of EVERY CU is needed) when it is
+// launched on its own; a problem of a GROUPED launch (dfine_conv_wgrad1_group: 8 - 32 problems side by side) fills the chip
+// with far fewer, and every split it does not use is a slab of fp32 partial sums that is not written and not read again by
+// the deferred reduction (2.7 GB per D-FINE-m step with 256: the 27 128 x 128 layers alone 354 MB in 200 splits each)
+static void wgrad1_plan(int B, int Cin, int Cout, int HW, int *splits, int *cps, int wg_target = 256) {
     const int cpi = (HW + kW2Px - 1) / kW2Px, total = B * cpi;
     const int pairs = ((Cout + 127) / 128) * ((Cin + 127) / 128);
     const int64_t bytes_per_split = (int64_t)((Cout + 15) / 16 * 16) * ((Cin + 15) / 16 * 16) * 4;
     int cap = (int)(24000000 / bytes_per_split);                            // fp32 partials (written once, read once) below ~24 MB
     if (cap < 8) cap = 8;
-    int sp = 256 / pairs;                                                   // one workgroup per CU (96 KiB of LDS), one round: the load path of EVERY CU is needed
+    int sp = wg_target / pairs;
     if (sp < 1) sp = 1;
     if (sp > cap) sp = cap;
     if (sp > total) sp = total;
@@ -2042,10 +2046,28 @@ int dfine_linear_wgrad_group_row(const void *x, const void *dy, float *ws, int M
 }
 
 // 1x1 weight gradients, grouped: row helper (returns the workgroup count, < 0 when this shape does not take the LDS-DMA kernel).
+static int wgrad1_group_target() {
+    // measured (D-FINE-m step, ms median): 256 -> 33.29 / 33.41, 128 -> 33.37, 64 -> 33.51 / 33.58, 32 -> 33.91: the kernels gain more
+    // from the parallelism of many splits than the step loses to their partial sums (2.7 -> 1.6 GB at 64) - the default keeps 256
+    static const int t = [] { const char *e = getenv("DFINE_WGRAD1_GROUP_WGS"); const int v = e ? atoi(e) : 256; return v < 8 ? 8 : v; }();
+    return t;
+}
+
+// Splits (partial-sum slabs) and workspace floats of a problem of the GROUPED 1x1 weight-gradient launch.
+int dfine_conv_wgrad1_group_splits(int B, int Cin, int Cout, int HW) {
+    int splits, cps;
+    wgrad1_plan(B, Cin, Cout, HW, &splits, &cps, wgrad1_group_target());
+    return splits;
+}
+
+int64_t dfine_conv_wgrad1_group_ws_floats(int B, int Cin, int Cout, int HW) {
+    return (int64_t)dfine_conv_wgrad1_group_splits(B, Cin, Cout, HW) * ((Cout + 15) / 16 * 16) * ((Cin + 15) / 16 * 16);
+}
+
 int dfine_conv_wgrad1_group_row(const void *x, const void *dy, float *ws, int B, int Cin, int Cout, int HW, int64_t *row) {
     if (!x || !dy || !ws || !row || B < 1 || Cin < 1 || Cout < 1 || !wgrad1_v2(1, HW)) return DFINE_E_BADARG;
     int splits, cps;
-    wgrad1_plan(B, Cin, Cout, HW, &splits, &cps);
+    wgrad1_plan(B, Cin, Cout, HW, &splits, &cps, wgrad1_group_target());
     row[0] = (int64_t)x; row[1] = (int64_t)dy; row[2] = (int64_t)ws; row[3] = B; row[4] = Cin; row[5] = Cout; row[6] = HW;
     row[7] = (int64_t)splits | ((int64_t)cps << 32);
     return 8 * ((splits + 7) / 8) * ((Cout + 127) / 128) * ((Cin + 127) / 128);

@@ -86,6 +86,8 @@ _SIGNATURES = {
     "dfine_multi_wgrad_reduce_blocks": (c_int, [_I, c_int64]),
     "dfine_linear_wgrad_group_row": (c_int, [_P, _P, _P, _I, _I, _I, _P]),
     "dfine_linear_wgrad_group": (c_int, [_P, _I, _I, _P]),
+    "dfine_conv_wgrad1_group_splits": (c_int, [_I, _I, _I, _I]),
+    "dfine_conv_wgrad1_group_ws_floats": (_L, [_I, _I, _I, _I]),
     "dfine_conv_wgrad1_group_row": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_conv_wgrad1_group": (c_int, [_P, _I, _I, _P]),
     "dfine_linear_act_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -1014,13 +1016,15 @@ def conv_wgrad_bf16(x, dy, ks, partials=False):
     B, cin, H, W = x.shape
     cout = dy.shape[1]
     dw = None if partials else torch.empty(cout, cin, ks, ks, device=x.device, dtype=torch.float32)
-    ws = torch.empty(int(_PURE.dfine_conv_wgrad_ws_floats(B, cin, cout, H, W, ks)), device=x.device, dtype=torch.float32)
     if partials and ks == 1 and _CW_GROUP and (H * W) % 8 == 0:
-        # registered only: every 1x1 weight gradient of a flush runs in one launch (linear_wgrad_flush -> dfine_conv_wgrad1_group)
+        # registered only: every 1x1 weight gradient of a flush runs in one launch (linear_wgrad_flush -> dfine_conv_wgrad1_group);
+        # a problem of a grouped launch is cut into fewer splits than a stand-alone one (dfine_conv_wgrad1_group_splits)
+        ws = torch.empty(int(_PURE.dfine_conv_wgrad1_group_ws_floats(B, cin, cout, H * W)), device=x.device, dtype=torch.float32)
         _CW_PENDING.append((x, dy, ws, B, cin, cout, H * W))
         if len(_CW_PENDING) >= _SIDE_GROUP_AT and _side_ok():
             _flush_conv_group(True)          # ... or in a few, on the side stream while backward goes on
-        return ws, (int(_PURE.dfine_conv_wgrad_splits(B, cin, cout, H, W, ks)), cout, cin, 1, _p16(cout), _p16(cin))
+        return ws, (int(_PURE.dfine_conv_wgrad1_group_splits(B, cin, cout, H * W)), cout, cin, 1, _p16(cout), _p16(cin))
+    ws = torch.empty(int(_PURE.dfine_conv_wgrad_ws_floats(B, cin, cout, H, W, ks)), device=x.device, dtype=torch.float32)
     if partials and _side_ok():
         if st is None:
             st = _side_fork(x.device)

@@ -433,6 +433,10 @@ int dfine_linear_wgrad_group_row(const void *x, const void *dy, float *ws, int M
 int dfine_linear_wgrad_group(const void *table, int n_problems, int max_blocks, void *stream);
 /* The same for the 1x1 convolution weight gradients with whole-tensor inputs (partial sums as dfine_conv_wgrad_bf16 with
  * dw == NULL, KS = 1, H * W % 8 == 0): arch/hgnetv2.py:35-80, arch/hybrid_encoder.py:21-156. */
+/* Splits / workspace floats of ONE problem of the grouped launch (fewer splits than a stand-alone launch of the same shape:
+ * the group fills the chip, and unused splits are partial sums that are neither written nor reduced). */
+int dfine_conv_wgrad1_group_splits(int B, int Cin, int Cout, int HW);
+int64_t dfine_conv_wgrad1_group_ws_floats(int B, int Cin, int Cout, int HW);
 int dfine_conv_wgrad1_group_row(const void *x, const void *dy, float *ws, int B, int Cin, int Cout, int HW, int64_t *row);
 int dfine_conv_wgrad1_group(const void *table, int n_problems, int max_blocks, void *stream);
 int dfine_multi_wgrad_reduce_blocks(int splits, int64_t elems);   /* blocks one row of the table needs */
