@@ -48,7 +48,8 @@ opt = dfine.build_optimizer(model, lr=8e-4, backbone_lr=4e-4, betas=(0.9, 0.999)
 fused = fused_optim.FusedAdamWEMA(model, opt, ema, clip_max_norm=0.1, bucket_mb=2)
 assert fused.overlap and len(fused._buckets) > 4
 fused.broadcast_from_rank0()
-step = TrainStep(model, crit, opt, amp_dtype=torch.bfloat16, clip_max_norm=0.1, ema=ema, fused_optimizer=fused)
+GRAPH = os.environ.get("RCCL_PROBE_GRAPH", "1") == "1"          # the bench's default mode: captured backbone + encoder segment
+step = TrainStep(model, crit, opt, amp_dtype=torch.bfloat16, clip_max_norm=0.1, ema=ema, fused_optimizer=fused, hip_graph=GRAPH)
 images, targets = make_batch(4, 320, num_classes=5, seed=42, device=dev)
 before = fused.flat_param.clone()
 losses = []
@@ -59,7 +60,8 @@ torch.cuda.synchronize()
 assert all(l == l and abs(l) < 1e6 for l in losses), losses
 assert (fused.flat_param - before).abs().max() > 0
 assert torch.isfinite(fused.flat_param).all()
-print("backend", dist.get_backend(), "| collectives issued:", calls, "| losses", [round(l, 3) for l in losses])
+assert not GRAPH or step._graphs, "the graph-replay path did not run"
+print("backend", dist.get_backend(), "| graph replay", GRAPH, "| collectives issued:", calls, "| losses", [round(l, 3) for l in losses])
 dist.barrier()
 dist.destroy_process_group()
 print("rccl one-rank smoke ok")
