@@ -493,6 +493,354 @@ __global__ __launch_bounds__(kDwThreads) void dwconv_s2_wgrad_vec_kernel(const u
     }
 }
 
+// ---- 3x3 / stride 2 / pad 1, bf16, STREAMING form (no LDS) -----------------------------------------------------------------
+// The strip kernels above move 1.7 - 2.9 TB/s stand-alone (tools/dwconv_bench.py): every block loads one small tile, waits, computes,
+// stores - one tile's latency per block and ~10 KB per block of traffic.  Here a lane owns one 16-byte column vector of a plane
+// (8 input columns = 4 outputs) and walks DOWN the rows with the previous input row kept in registers, a wave holds 64 / (W / 8)
+// whole planes side by side, the column halo comes from the neighbouring lane (one DPP-style shuffle per row), and the loads of
+// several output rows are issued before the first is consumed: a stream with constant bytes in flight instead of load-wait-compute
+// tiles.  Rows are cut into chunks (blockIdx.y) for parallelism: one halo row re-read per chunk.
+constexpr int kDwRowsAhead = 4;
+
+__device__ __forceinline__ void dw_unpack9(const uint4 &r, uint32_t left_pair, bool first, float (&o)[9]) {
+    // o[0] = column 8 v - 1 (the last element of the left neighbour's vector, zero at the plane edge), o[1..8] = own 8 columns
+    o[0] = first ? 0.f : __uint_as_float(left_pair & 0xffff0000u);
+    o[1] = __uint_as_float(r.x << 16); o[2] = __uint_as_float(r.x & 0xffff0000u);
+    o[3] = __uint_as_float(r.y << 16); o[4] = __uint_as_float(r.y & 0xffff0000u);
+    o[5] = __uint_as_float(r.z << 16); o[6] = __uint_as_float(r.z & 0xffff0000u);
+    o[7] = __uint_as_float(r.w << 16); o[8] = __uint_as_float(r.w & 0xffff0000u);
+}
+
+// forward: y[oy][4 v + e] = sum_{ky, kx} w[ky][kx] x[2 oy + ky - 1][8 v + 2 e + kx - 1]
+__global__ __launch_bounds__(kDwThreads) void dwconv_s2_fwd_stream_kernel(const uint16_t *__restrict__ x, const float *__restrict__ w,
+                                                                         uint16_t *__restrict__ y, int C, int H, int W, int planes,
+                                                                         int rows_per_chunk) {
+    const int lane = threadIdx.x & 63, wv = blockIdx.x * (kDwThreads / 64) + (threadIdx.x >> 6);
+    const int nv = W / 8, ppw = 64 / nv;
+    const int pl = lane / nv, v = lane - pl * nv;
+    const int plane = wv * ppw + pl;
+    const bool live = pl < ppw && plane < planes;
+    const int OH = H / 2, OW = W / 2;
+    const int oy0 = blockIdx.y * rows_per_chunk, oy1 = min(OH, oy0 + rows_per_chunk);
+    const int c = live ? plane % C : 0;
+    float wk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
+    const uint16_t *xp = x + (int64_t)(live ? plane : 0) * H * W + v * 8;
+    uint16_t *yp = y + (int64_t)(live ? plane : 0) * OH * OW + v * 4;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    auto ld = [&](int row) { return (live && row >= 0) ? *reinterpret_cast<const uint4 *>(xp + (int64_t)row * W) : zero4; };
+    uint4 rp = ld(2 * oy0 - 1);
+    for (int oy = oy0; oy < oy1; oy += kDwRowsAhead) {
+        uint4 ra[kDwRowsAhead], rb[kDwRowsAhead];
+#pragma unroll
+        for (int u = 0; u < kDwRowsAhead; ++u) {
+            const bool ok = oy + u < oy1;
+            ra[u] = ok ? ld(2 * (oy + u)) : zero4;
+            rb[u] = ok ? ld(2 * (oy + u) + 1) : zero4;
+        }
+#pragma unroll
+        for (int u = 0; u < kDwRowsAhead; ++u) {
+            if (oy + u >= oy1) break;                              // uniform
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            const uint4 rows[3] = {rp, ra[u], rb[u]};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const uint32_t lp = __shfl_up(rows[ky].w, 1, 64);
+                float in[9];
+                dw_unpack9(rows[ky], lp, v == 0, in);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(wk[ky * 3 + kx], in[2 * e + kx], acc[e]);
+            }
+            if (live) *reinterpret_cast<uint2 *>(yp + (int64_t)(oy + u) * OW) = DwVec<4>::pack(acc);
+            rp = rb[u];
+        }
+    }
+}
+
+// data gradient: a lane owns 4 dy columns = 8 dx columns; dy row oy feeds dx rows 2 oy (ky = 1), 2 oy - 1 (ky = 0) and 2 oy + 1 (ky = 2)
+__global__ __launch_bounds__(kDwThreads) void dwconv_s2_dgrad_stream_kernel(const uint16_t *__restrict__ dy, const float *__restrict__ w,
+                                                                           uint16_t *__restrict__ dx, int C, int H, int W, int planes,
+                                                                           int rows_per_chunk) {
+    const int lane = threadIdx.x & 63, wv = blockIdx.x * (kDwThreads / 64) + (threadIdx.x >> 6);
+    const int nv = W / 8, ppw = 64 / nv;
+    const int pl = lane / nv, v = lane - pl * nv;
+    const int plane = wv * ppw + pl;
+    const bool live = pl < ppw && plane < planes;
+    const int OH = H / 2, OW = W / 2;
+    const int oy0 = blockIdx.y * rows_per_chunk, oy1 = min(OH, oy0 + rows_per_chunk);
+    const int c = live ? plane % C : 0;
+    float wk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
+    const uint16_t *gp = dy + (int64_t)(live ? plane : 0) * OH * OW + v * 4;
+    uint16_t *dxp = dx + (int64_t)(live ? plane : 0) * H * W + v * 8;
+    const uint2 zero2 = make_uint2(0, 0);
+    auto ld = [&](int row) { return (live && row < OH) ? *reinterpret_cast<const uint2 *>(gp + (int64_t)row * OW) : zero2; };
+    auto unpack5 = [&](const uint2 &r, float (&g)[5]) {
+        const uint32_t right = __shfl_down(r.x, 1, 64);           // the right neighbour's first dy column
+        g[0] = __uint_as_float(r.x << 16); g[1] = __uint_as_float(r.x & 0xffff0000u);
+        g[2] = __uint_as_float(r.y << 16); g[3] = __uint_as_float(r.y & 0xffff0000u);
+        g[4] = (v == nv - 1) ? 0.f : __uint_as_float(right << 16);
+    };
+    auto row_terms = [&](const float (&g)[5], int ky, float (&acc)[8]) {
+        const float w0 = wk[ky * 3], w1 = wk[ky * 3 + 1], w2 = wk[ky * 3 + 2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[2 * j] = fmaf(w1, g[j], acc[2 * j]);                                   // x = 2c     : kx = 1
+            acc[2 * j + 1] = fmaf(w0, g[j + 1], fmaf(w2, g[j], acc[2 * j + 1]));       // x = 2c + 1 : kx = 0 (c + 1), kx = 2 (c)
+        }
+    };
+    float gc[5], gn[5];
+    { const uint2 r = ld(oy0); unpack5(r, gc); }
+    for (int oy = oy0; oy < oy1; oy += kDwRowsAhead) {
+        uint2 rn[kDwRowsAhead];
+#pragma unroll
+        for (int u = 0; u < kDwRowsAhead; ++u) rn[u] = (oy + u < oy1) ? ld(oy + u + 1) : zero2;     // (row OH reads as zeros)
+#pragma unroll
+        for (int u = 0; u < kDwRowsAhead; ++u) {
+            if (oy + u >= oy1) break;                              // uniform
+            unpack5(rn[u], gn);
+            float even[8], odd[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { even[e] = 0.f; odd[e] = 0.f; }
+            row_terms(gc, 1, even);                                // dx row 2 oy
+            row_terms(gc, 2, odd);                                 // dx row 2 oy + 1: ky = 2 from dy row oy ...
+            row_terms(gn, 0, odd);                                 // ... and ky = 0 from dy row oy + 1
+            if (live) {
+                *reinterpret_cast<uint4 *>(dxp + (int64_t)(2 * (oy + u)) * W) = DwVec<8>::pack(even);
+                *reinterpret_cast<uint4 *>(dxp + (int64_t)(2 * (oy + u) + 1) * W) = DwVec<8>::pack(odd);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) gc[i] = gn[i];
+        }
+    }
+}
+
+// weight gradient: a wave owns 64 / (W / 8) channels, walks the planes of its image chunk row by row, 9 sums per lane; at the end
+// the lanes of a channel are added through LDS and go to dw with one atomic per (channel, tap, block)
+__global__ __launch_bounds__(kDwThreads) void dwconv_s2_wgrad_stream_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy,
+                                                                           float *__restrict__ dw, int B, int C, int H, int W,
+                                                                           int imgs_per_block, int rows_per_chunk) {
+    __shared__ float red[kDwThreads][9 + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wv = blockIdx.x * (kDwThreads / 64) + wave;
+    const int nv = W / 8, ppw = 64 / nv;
+    const int pl = lane / nv, v = lane - pl * nv;
+    const int c = wv * ppw + pl;
+    const bool live = pl < ppw && c < C;
+    const int OH = H / 2, OW = W / 2;
+    const int b0 = blockIdx.y * imgs_per_block, b1 = min(B, b0 + imgs_per_block);
+    const int oy0 = blockIdx.z * rows_per_chunk, oy1 = min(OH, oy0 + rows_per_chunk);
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    float acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const int64_t plane = (int64_t)b * C + (live ? c : 0);
+        const uint16_t *xp = x + plane * H * W + v * 8;
+        const uint16_t *gp = dy + plane * OH * OW + v * 4;
+        auto ld = [&](int row) { return (live && row >= 0) ? *reinterpret_cast<const uint4 *>(xp + (int64_t)row * W) : zero4; };
+        uint4 rp = ld(2 * oy0 - 1);
+        for (int oy = oy0; oy < oy1; oy += kDwRowsAhead) {
+            uint4 ra[kDwRowsAhead], rb[kDwRowsAhead];
+            uint2 rg[kDwRowsAhead];
+#pragma unroll
+            for (int u = 0; u < kDwRowsAhead; ++u) {
+                const bool ok = oy + u < oy1;
+                ra[u] = ok ? ld(2 * (oy + u)) : zero4;
+                rb[u] = ok ? ld(2 * (oy + u) + 1) : zero4;
+                rg[u] = (ok && live) ? *reinterpret_cast<const uint2 *>(gp + (int64_t)(oy + u) * OW) : make_uint2(0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < kDwRowsAhead; ++u) {
+                if (oy + u >= oy1) break;                          // uniform
+                float g[4];
+                DwVec<4>::unpack(rg[u], g);
+                const uint4 rows[3] = {rp, ra[u], rb[u]};
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const uint32_t lp = __shfl_up(rows[ky].w, 1, 64);
+                    float in[9];
+                    dw_unpack9(rows[ky], lp, v == 0, in);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float a = acc[ky * 3 + kx];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a = fmaf(g[e], in[2 * e + kx], a);
+                        acc[ky * 3 + kx] = a;
+                    }
+                }
+                rp = rb[u];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) red[threadIdx.x][i] = acc[i];
+    __syncthreads();
+    // thread t < 4 waves x ppw channels x 9 taps: sum of the nv lanes of that channel
+    const int per_wave = ppw * 9;
+    for (int t = threadIdx.x; t < (kDwThreads / 64) * per_wave; t += kDwThreads) {
+        const int w_ = t / per_wave, r_ = t - w_ * per_wave, p_ = r_ / 9, i_ = r_ - p_ * 9;
+        const int cc = (blockIdx.x * (kDwThreads / 64) + w_) * ppw + p_;
+        if (cc >= C) continue;
+        float sum = 0.f;
+        for (int l = 0; l < nv; ++l) sum += red[w_ * 64 + p_ * nv + l][i_];
+        unsafeAtomicAdd(dw + cc * 9 + i_, sum);
+    }
+}
+
+// ---- stride 1 "same" layers (LightConvBNAct 5x5; 3x3), bf16, STREAMING form ------------------------------------------------
+// Same scheme: a lane owns one VW-column vector of a plane and walks down the rows with a K-row window of fp32 values in registers
+// (each input row is converted once), the P halo columns each side come from the neighbouring lanes' edge words.
+template <int VW> struct DwRaw;
+template <> struct DwRaw<8> {
+    typedef uint4 T;
+    static __device__ __forceinline__ T zero() { return make_uint4(0, 0, 0, 0); }
+    static __device__ __forceinline__ uint32_t first(const T &r) { return r.x; }
+    static __device__ __forceinline__ uint32_t last(const T &r) { return r.w; }
+};
+template <> struct DwRaw<4> {
+    typedef uint2 T;
+    static __device__ __forceinline__ T zero() { return make_uint2(0, 0); }
+    static __device__ __forceinline__ uint32_t first(const T &r) { return r.x; }
+    static __device__ __forceinline__ uint32_t last(const T &r) { return r.y; }
+};
+
+// o[j] = column VW v - 2 + j, j = 0 .. VW + 3 (two halo columns each side, zero outside the plane)
+template <int VW>
+__device__ __forceinline__ void dw_unpack_halo(const typename DwRaw<VW>::T &r, bool first, bool last, float (&o)[VW + 4]) {
+    const uint32_t lw = __shfl_up(DwRaw<VW>::last(r), 1, 64), rw = __shfl_down(DwRaw<VW>::first(r), 1, 64);
+    o[0] = first ? 0.f : __uint_as_float(lw << 16);
+    o[1] = first ? 0.f : __uint_as_float(lw & 0xffff0000u);
+    float c[VW];
+    DwVec<VW>::unpack(r, c);
+#pragma unroll
+    for (int e = 0; e < VW; ++e) o[2 + e] = c[e];
+    o[VW + 2] = last ? 0.f : __uint_as_float(rw << 16);
+    o[VW + 3] = last ? 0.f : __uint_as_float(rw & 0xffff0000u);
+}
+
+template <int K, int VW, bool FLIP>
+__global__ __launch_bounds__(kDwThreads) void dwconv_s1_stream_kernel(const uint16_t *__restrict__ x, const float *__restrict__ w,
+                                                                     uint16_t *__restrict__ y, int C, int H, int W, int planes,
+                                                                     int rows_per_chunk) {
+    constexpr int P = K / 2;
+    typedef typename DwRaw<VW>::T Raw;
+    const int lane = threadIdx.x & 63, wv = blockIdx.x * (kDwThreads / 64) + (threadIdx.x >> 6);
+    const int nv = W / VW, ppw = 64 / nv;
+    const int pl = lane / nv, v = lane - pl * nv;
+    const int plane = wv * ppw + pl;
+    const bool live = pl < ppw && plane < planes;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(H, r0 + rows_per_chunk);
+    const int c = live ? plane % C : 0;
+    float wk[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) wk[i] = w[c * K * K + (FLIP ? K * K - 1 - i : i)];
+    const uint16_t *xp = x + (int64_t)(live ? plane : 0) * H * W + v * VW;
+    uint16_t *yp = y + (int64_t)(live ? plane : 0) * H * W + v * VW;
+    auto ld = [&](int row) { return (live && row >= 0 && row < H) ? *reinterpret_cast<const Raw *>(xp + (int64_t)row * W) : DwRaw<VW>::zero(); };
+    const bool first = v == 0, last = v == nv - 1;
+    float win[K][VW + 4];                                          // rows r - P .. r + P of the current output row r
+#pragma unroll
+    for (int k = 0; k < K - 1; ++k) { const Raw t = ld(r0 - P + k); dw_unpack_halo<VW>(t, first, last, win[k + 1]); }
+    for (int r = r0; r < r1; r += kDwRowsAhead) {
+        Raw nx[kDwRowsAhead];
+#pragma unroll
+        for (int u = 0; u < kDwRowsAhead; ++u) nx[u] = (r + u < r1) ? ld(r + u + P) : DwRaw<VW>::zero();
+#pragma unroll
+        for (int u = 0; u < kDwRowsAhead; ++u) {
+            if (r + u >= r1) break;                                // uniform
+#pragma unroll
+            for (int k = 0; k < K - 1; ++k)
+#pragma unroll
+                for (int j = 0; j < VW + 4; ++j) win[k][j] = win[k + 1][j];
+            dw_unpack_halo<VW>(nx[u], first, last, win[K - 1]);
+            float acc[VW];
+#pragma unroll
+            for (int e = 0; e < VW; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) acc[e] = fmaf(wk[ky * K + kx], win[ky][e + kx + 2 - P], acc[e]);
+            if (live) *reinterpret_cast<Raw *>(yp + (int64_t)(r + u) * W) = DwVec<VW>::pack(acc);
+        }
+    }
+}
+
+template <int K, int VW>
+__global__ __launch_bounds__(kDwThreads) void dwconv_wgrad_s1_stream_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy,
+                                                                           float *__restrict__ dw, int B, int C, int H, int W,
+                                                                           int imgs_per_block, int rows_per_chunk) {
+    constexpr int P = K / 2, KK = K * K;
+    typedef typename DwRaw<VW>::T Raw;
+    __shared__ float red[kDwThreads][KK + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wv = blockIdx.x * (kDwThreads / 64) + wave;
+    const int nv = W / VW, ppw = 64 / nv;
+    const int pl = lane / nv, v = lane - pl * nv;
+    const int c = wv * ppw + pl;
+    const bool live = pl < ppw && c < C;
+    const int b0 = blockIdx.y * imgs_per_block, b1 = min(B, b0 + imgs_per_block);
+    const int r0 = blockIdx.z * rows_per_chunk, r1 = min(H, r0 + rows_per_chunk);
+    const bool first = v == 0, last = v == nv - 1;
+    float acc[KK];
+#pragma unroll
+    for (int i = 0; i < KK; ++i) acc[i] = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const int64_t plane = (int64_t)b * C + (live ? c : 0);
+        const uint16_t *xp = x + plane * H * W + v * VW;
+        const uint16_t *gp = dy + plane * H * W + v * VW;
+        auto ld = [&](int row) { return (live && row >= 0 && row < H) ? *reinterpret_cast<const Raw *>(xp + (int64_t)row * W) : DwRaw<VW>::zero(); };
+        float win[K][VW + 4];
+#pragma unroll
+        for (int k = 0; k < K - 1; ++k) { const Raw t = ld(r0 - P + k); dw_unpack_halo<VW>(t, first, last, win[k + 1]); }
+        for (int r = r0; r < r1; r += kDwRowsAhead) {
+            Raw nx[kDwRowsAhead], ng[kDwRowsAhead];
+#pragma unroll
+            for (int u = 0; u < kDwRowsAhead; ++u) {
+                const bool ok = r + u < r1;
+                nx[u] = ok ? ld(r + u + P) : DwRaw<VW>::zero();
+                ng[u] = (ok && live) ? *reinterpret_cast<const Raw *>(gp + (int64_t)(r + u) * W) : DwRaw<VW>::zero();
+            }
+#pragma unroll
+            for (int u = 0; u < kDwRowsAhead; ++u) {
+                if (r + u >= r1) break;                            // uniform
+#pragma unroll
+                for (int k = 0; k < K - 1; ++k)
+#pragma unroll
+                    for (int j = 0; j < VW + 4; ++j) win[k][j] = win[k + 1][j];
+                dw_unpack_halo<VW>(nx[u], first, last, win[K - 1]);
+                float g[VW];
+                DwVec<VW>::unpack(ng[u], g);
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {
+                        float a = acc[ky * K + kx];
+#pragma unroll
+                        for (int e = 0; e < VW; ++e) a = fmaf(g[e], win[ky][e + kx + 2 - P], a);
+                        acc[ky * K + kx] = a;
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < KK; ++i) red[threadIdx.x][i] = acc[i];
+    __syncthreads();
+    const int per_wave = ppw * KK;
+    for (int t = threadIdx.x; t < (kDwThreads / 64) * per_wave; t += kDwThreads) {
+        const int w_ = t / per_wave, r_ = t - w_ * per_wave, p_ = r_ / KK, i_ = r_ - p_ * KK;
+        const int cc = (blockIdx.x * (kDwThreads / 64) + w_) * ppw + p_;
+        if (cc >= C) continue;
+        float sum = 0.f;
+        for (int l = 0; l < nv; ++l) sum += red[w_ * 64 + p_ * nv + l][i_];
+        unsafeAtomicAdd(dw + cc * KK + i_, sum);
+    }
+}
+
 static bool dw_s2_ok(int dtype, int H, int W, int K, int stride, int pad) {
     return dtype == DFINE_BF16 && stride == 2 && K == 3 && pad == 1 && H % 2 == 0 && W % 8 == 0 && W <= 320;
 }
@@ -515,6 +863,13 @@ static int pick_rows(int rows_total, int row_len_lds, int K, int S, bool fwd) {
     return tr > rows_total ? rows_total : tr;
 }
 
+// output rows per chunk of the streaming kernels: whole multiples of the rows-ahead depth, enough chunks for ~2048+ waves
+static int dw_stream_rows(int OH, int waves) {
+    int rpc = OH;
+    while (rpc > 2 * kDwRowsAhead && (int64_t)waves * ((OH + rpc - 1) / rpc) < 4096) rpc = (rpc + 1) / 2;
+    return (rpc + kDwRowsAhead - 1) / kDwRowsAhead * kDwRowsAhead;
+}
+
 }  // namespace dfine
 
 using namespace dfine;
@@ -529,6 +884,19 @@ int dfine_dwconv_fwd(const void *x, const float *w, void *y, int dtype, int B, i
     if (OH < 1 || OW < 1) return DFINE_E_BADARG;
     hipStream_t st0 = (hipStream_t)stream;
     int vw = 0;
+    static const int stream_env = [] { const char *e = getenv("DFINE_DW_STREAM"); return e ? atoi(e) : 1; }();
+    if (stream_env && dw_vec_ok(dtype, H, W, K, stride, pad, &vw) && W / vw <= 64) {
+        const int nv = W / vw, ppw = 64 / nv, planes = B * C;
+        const int waves = (planes + ppw - 1) / ppw;
+        const int rpc = dw_stream_rows(H, waves);
+        const dim3 gs((waves + 3) / 4, (H + rpc - 1) / rpc);
+#define DFINE_DWS(KK, VV) hipLaunchKernelGGL((dwconv_s1_stream_kernel<KK, VV, false>), gs, dim3(kDwThreads), 0, st0, \
+                                             (const uint16_t *)x, w, (uint16_t *)y, C, H, W, planes, rpc)
+        if (K == 5) { if (vw == 8) DFINE_DWS(5, 8); else DFINE_DWS(5, 4); }
+        else { if (vw == 8) DFINE_DWS(3, 8); else DFINE_DWS(3, 4); }
+#undef DFINE_DWS
+        return check_launch();
+    }
     if (dw_vec_ok(dtype, H, W, K, stride, pad, &vw)) {
         // rows per block: as many as 256 threads cover with one strip each
         int TRv = kDwThreads / (W / vw);
@@ -540,6 +908,14 @@ int dfine_dwconv_fwd(const void *x, const float *w, void *y, int dtype, int B, i
         if (K == 5) { if (vw == 8) DFINE_DWV(5, 8); else DFINE_DWV(5, 4); }
         else { if (vw == 8) DFINE_DWV(3, 8); else DFINE_DWV(3, 4); }
 #undef DFINE_DWV
+        return check_launch();
+    }
+    if (stream_env && dw_s2_ok(dtype, H, W, K, stride, pad)) {
+        const int nv = W / 8, ppw = 64 / nv, planes = B * C;
+        const int waves = (planes + ppw - 1) / ppw;
+        const int rpc = dw_stream_rows(OH, waves);
+        hipLaunchKernelGGL(dwconv_s2_fwd_stream_kernel, dim3((waves + 3) / 4, (OH + rpc - 1) / rpc), dim3(kDwThreads), 0, st0,
+                           (const uint16_t *)x, w, (uint16_t *)y, C, H, W, planes, rpc);
         return check_launch();
     }
     if (dw_s2_ok(dtype, H, W, K, stride, pad)) {
@@ -580,7 +956,19 @@ int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, fl
     hipStream_t st = (hipStream_t)stream;
     int vw = 0;
     const bool vec = dw_vec_ok(dtype, H, W, K, stride, pad, &vw);
-    if (dx && vec) {
+    static const int stream_env = [] { const char *e = getenv("DFINE_DW_STREAM"); return e ? atoi(e) : 1; }();
+    if (dx && vec && stream_env && W / vw <= 64) {
+        const int nv = W / vw, ppw = 64 / nv, planes = B * C;
+        const int waves = (planes + ppw - 1) / ppw;
+        const int rpc = dw_stream_rows(H, waves);
+        const dim3 gs((waves + 3) / 4, (H + rpc - 1) / rpc);
+#define DFINE_DWS(KK, VV) hipLaunchKernelGGL((dwconv_s1_stream_kernel<KK, VV, true>), gs, dim3(kDwThreads), 0, st, \
+                                             (const uint16_t *)dy, w, (uint16_t *)dx, C, H, W, planes, rpc)
+        if (K == 5) { if (vw == 8) DFINE_DWS(5, 8); else DFINE_DWS(5, 4); }
+        else { if (vw == 8) DFINE_DWS(3, 8); else DFINE_DWS(3, 4); }
+#undef DFINE_DWS
+        if (int e = check_launch()) return e;
+    } else if (dx && vec) {
         int TRv = kDwThreads / (W / vw);
         if (TRv > H) TRv = H;
         const size_t smv = sizeof(float) * (size_t)(TRv + K - 1) * (W + 8);
@@ -590,6 +978,13 @@ int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, fl
         if (K == 5) { if (vw == 8) DFINE_DWV(5, 8); else DFINE_DWV(5, 4); }
         else { if (vw == 8) DFINE_DWV(3, 8); else DFINE_DWV(3, 4); }
 #undef DFINE_DWV
+        if (int e = check_launch()) return e;
+    } else if (dx && stream_env && dw_s2_ok(dtype, H, W, K, stride, pad)) {
+        const int nv = W / 8, ppw = 64 / nv, planes = B * C;
+        const int waves = (planes + ppw - 1) / ppw;
+        const int rpc = dw_stream_rows(OH, waves);
+        hipLaunchKernelGGL(dwconv_s2_dgrad_stream_kernel, dim3((waves + 3) / 4, (OH + rpc - 1) / rpc), dim3(kDwThreads), 0, st,
+                           (const uint16_t *)dy, w, (uint16_t *)dx, C, H, W, planes, rpc);
         if (int e = check_launch()) return e;
     } else if (dx && dw_s2_ok(dtype, H, W, K, stride, pad)) {
         int TRd = kDwThreads / (W / 8);
@@ -625,6 +1020,23 @@ int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, fl
         int per = 1;
         while ((int64_t)C * ((B + per - 1) / per) > 4096 && per < B) per *= 2;
         dim3 grid(C, (B + per - 1) / per);
+        if (vec && stream_env && W / vw <= 64) {
+            const int nv = W / vw, ppw = 64 / nv;
+            const int cwaves = (C + ppw - 1) / ppw, cblocks = (cwaves + 3) / 4;
+            int perb = B;
+            while (perb > 1 && (int64_t)cblocks * 4 * ((B + perb - 1) / perb) < 2048) perb = (perb + 1) / 2;
+            const int bchunks = (B + perb - 1) / perb;
+            int rpc = H;
+            while (rpc > 2 * kDwRowsAhead && (int64_t)cblocks * 4 * bchunks * ((H + rpc - 1) / rpc) < 2048) rpc = (rpc + 1) / 2;
+            rpc = (rpc + kDwRowsAhead - 1) / kDwRowsAhead * kDwRowsAhead;
+            const dim3 gw(cblocks, bchunks, (H + rpc - 1) / rpc);
+#define DFINE_WGS(KK, VV) hipLaunchKernelGGL((dwconv_wgrad_s1_stream_kernel<KK, VV>), gw, dim3(kDwThreads), 0, st, \
+                                             (const uint16_t *)x, (const uint16_t *)dy, dw_f32, B, C, H, W, perb, rpc)
+            if (K == 5) { if (vw == 8) DFINE_WGS(5, 8); else DFINE_WGS(5, 4); }
+            else { if (vw == 8) DFINE_WGS(3, 8); else DFINE_WGS(3, 4); }
+#undef DFINE_WGS
+            return check_launch();
+        }
         if (vec) {
             // ~1024 blocks: several images per block amortise the K*K-value block reduction + atomics
             int perv = (int)(((int64_t)B * C + 1023) / 1024);
@@ -639,6 +1051,20 @@ int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, fl
             if (K == 5) { if (vw == 8) DFINE_WGV(5, 8); else DFINE_WGV(5, 4); }
             else { if (vw == 8) DFINE_WGV(3, 8); else DFINE_WGV(3, 4); }
 #undef DFINE_WGV
+            return check_launch();
+        }
+        if (stream_env && dw_s2_ok(dtype, H, W, K, stride, pad)) {
+            const int nv = W / 8, ppw = 64 / nv;
+            const int cwaves = (C + ppw - 1) / ppw, cblocks = (cwaves + 3) / 4;
+            // ~2048 waves: images first (no halo rows), then row chunks
+            int per = B;
+            while (per > 1 && (int64_t)cblocks * 4 * ((B + per - 1) / per) < 2048) per = (per + 1) / 2;
+            const int bchunks = (B + per - 1) / per;
+            int rpc = OH;
+            while (rpc > 2 * kDwRowsAhead && (int64_t)cblocks * 4 * bchunks * ((OH + rpc - 1) / rpc) < 2048) rpc = (rpc + 1) / 2;
+            rpc = (rpc + kDwRowsAhead - 1) / kDwRowsAhead * kDwRowsAhead;
+            hipLaunchKernelGGL(dwconv_s2_wgrad_stream_kernel, dim3(cblocks, bchunks, (OH + rpc - 1) / rpc), dim3(kDwThreads), 0, st,
+                               (const uint16_t *)x, (const uint16_t *)dy, dw_f32, B, C, H, W, per, rpc);
             return check_launch();
         }
         if (dw_s2_ok(dtype, H, W, K, stride, pad)) {

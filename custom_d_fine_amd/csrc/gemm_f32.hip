@@ -125,6 +125,154 @@ __global__ __launch_bounds__(kGfThreads) void gemm_f32_nt_kernel(const float *__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Second generation for the large products (1x1 convolutions of config #2 and their weight gradients: M, N >= 128).
+// The 64 x 64 kernel above tops out at ~80 TFLOP/s (half of the 157 TFLOP/s f32 matrix rate): 16 MFMAs of 32 cycles per wave
+// between two barriers do not cover the stage's loads, LDS writes and barrier.  Here a workgroup owns a 128 x 128 tile, a wave a
+// 64 x 64 quadrant as 2 x 2 v_mfma_f32_32x32x2_f32 tiles (64 accumulator registers): 32 MFMAs of 64 cycles per wave and stage,
+// four times the matrix work per barrier, and an operand register feeds two MFMAs.
+//   v_mfma_f32_32x32x2_f32: A lane (row l % 32, k l / 32), B lane (column l % 32, k l / 32), D register v of lane l = row
+//   8 (v / 4) + 4 (l / 32) + v % 4 of column l % 32.
+//   The 16 k of a stage are dealt to the lane halves in runs of four (half h of group q takes k = 8 q + 4 h .. + 3 - a sum over
+//   k does not care about the order as long as both operands agree), so a row-major operand is read from LDS with ONE
+//   ds_read_b128 per four MFMAs (rows padded to 20 floats: the 16 rows of a quarter wave fall on the 16 distinct 16-byte bank
+//   slots); a K-major operand is read element-wise (consecutive lanes = consecutive columns).
+typedef __attribute__((ext_vector_type(16))) float gf_f32x16;
+constexpr int kGbBM = 128, kGbBN = 128, kGbPitch = 20, kGbPitchK = 132, kGbOp = 128 * kGbPitch;
+
+template <bool AKM, bool BKM>
+__global__ __launch_bounds__(kGfThreads, 2) void gemm_f32_big_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                                    const float *__restrict__ bias, float *__restrict__ C, int M,
+                                                                    int N, int K, int lda, int ldb, int ldc, int64_t sa, int64_t sb,
+                                                                    int64_t sc, int splits, int chunk, float alpha, int act, int nt_n,
+                                                                    int ntiles, int tiles_per_xcd) {
+    __shared__ __attribute__((aligned(16))) float sA[2][kGbOp];
+    __shared__ __attribute__((aligned(16))) float sB[2][kGbOp];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware tile order (workgroup L runs on XCD L % 8): every XCD owns a contiguous run of tiles, the tiles of one
+    // column block (the same columns of B with every row block of A) next to each other in it
+    const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= ntiles) return;
+    const int nt_m = ntiles / nt_n;
+    const int tn = tile / nt_m, tm = tile - tn * nt_m;
+    const int z = blockIdx.y, zb = z / splits, zs = z - zb * splits;
+    const int m0 = tm * kGbBM, n0 = tn * kGbBN;
+    const int kbeg = zs * chunk, kend = min(K, kbeg + chunk);
+    const float *Az = A + zb * sa, *Bz = B + zb * sb;
+    float *Cz = C + (int64_t)z * sc;
+    const bool vec_a = (lda & 3) == 0 && ((size_t)Az & 15) == 0 && (AKM || (kbeg & 3) == 0);
+    const bool vec_b = (ldb & 3) == 0 && ((size_t)Bz & 15) == 0 && (BKM || (kbeg & 3) == 0);
+    // staging, row-major operand: rows tid / 4 and + 64, floats 4 (tid % 4) .. + 3 of the stage;
+    // K-major operand: k rows tid / 32 and + 8 of the stage, columns 4 (tid % 32) .. + 3 of the tile
+    const int lr = tid >> 2, lq = (tid & 3) * 4;
+    const int kr = tid >> 5, nq = (tid & 31) * 4;
+    auto load_rm = [&](const float *base, int ld, int row, int rmax, int k, bool vec) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < rmax && k < kend) {
+            const float *p = base + (int64_t)row * ld + k;
+            if (vec && k + 3 < kend) v = *reinterpret_cast<const float4 *>(p);
+            else {
+                v.x = p[0];
+                if (k + 1 < kend) v.y = p[1];
+                if (k + 2 < kend) v.z = p[2];
+                if (k + 3 < kend) v.w = p[3];
+            }
+        }
+        return v;
+    };
+    auto load_km = [&](const float *base, int ld, int c0, int cmax, int k, bool vec) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int n = c0 + nq;
+        if (k < kend && n < cmax) {
+            const float *p = base + (int64_t)k * ld + n;
+            if (vec && n + 3 < cmax) v = *reinterpret_cast<const float4 *>(p);
+            else {
+                v.x = p[0];
+                if (n + 1 < cmax) v.y = p[1];
+                if (n + 2 < cmax) v.z = p[2];
+                if (n + 3 < cmax) v.w = p[3];
+            }
+        }
+        return v;
+    };
+    float4 pa[2], pb[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            pa[j] = AKM ? load_km(Az, lda, m0, M, k0 + kr + 8 * j, vec_a) : load_rm(Az, lda, m0 + lr + 64 * j, M, k0 + lq, vec_a);
+            pb[j] = BKM ? load_km(Bz, ldb, n0, N, k0 + kr + 8 * j, vec_b) : load_rm(Bz, ldb, n0 + lr + 64 * j, N, k0 + lq, vec_b);
+        }
+    };
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    gf_f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+    const int nk = (kend - kbeg + 15) / 16;
+    fetch(kbeg);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (AKM) *reinterpret_cast<float4 *>(&sA[buf][(kr + 8 * j) * kGbPitchK + nq]) = pa[j];
+            else *reinterpret_cast<float4 *>(&sA[buf][(lr + 64 * j) * kGbPitch + lq]) = pa[j];
+            if (BKM) *reinterpret_cast<float4 *>(&sB[buf][(kr + 8 * j) * kGbPitchK + nq]) = pb[j];
+            else *reinterpret_cast<float4 *>(&sB[buf][(lr + 64 * j) * kGbPitch + lq]) = pb[j];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) fetch(kbeg + (kt + 1) * 16);                // in flight during the MFMAs below
+        const float *la = AKM ? &sA[buf][(4 * h) * kGbPitchK + wm * 64 + r] : &sA[buf][(wm * 64 + r) * kGbPitch + 4 * h];
+        const float *lb = BKM ? &sB[buf][(4 * h) * kGbPitchK + wn * 64 + r] : &sB[buf][(wn * 64 + r) * kGbPitch + 4 * h];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float av[2][4], bv[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (AKM) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) av[t][i] = la[(8 * q + i) * kGbPitchK + 32 * t];
+                } else {
+                    const float4 v = *reinterpret_cast<const float4 *>(la + 32 * t * kGbPitch + 8 * q);
+                    av[t][0] = v.x; av[t][1] = v.y; av[t][2] = v.z; av[t][3] = v.w;
+                }
+                if (BKM) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bv[t][i] = lb[(8 * q + i) * kGbPitchK + 32 * t];
+                } else {
+                    const float4 v = *reinterpret_cast<const float4 *>(lb + 32 * t * kGbPitch + 8 * q);
+                    bv[t][0] = v.x; bv[t][1] = v.y; bv[t][2] = v.z; bv[t][3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][i], bv[0][i], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][i], bv[1][i], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][i], bv[0][i], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][i], bv[1][i], acc[1][1], 0, 0, 0);
+            }
+        }
+        // (the write of stage kt + 2 into this buffer is ordered behind the barrier of stage kt + 1)
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + wn * 64 + b * 32 + r;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = m0 + wm * 64 + a * 32 + 8 * (v >> 2) + 4 * h + (v & 3);
+                if (m < M) Cz[(int64_t)m * ldc + n] = gf_act(alpha * acc[a][b][v] + bv, act);
+            }
+        }
+    }
+}
+
 }  // namespace dfine
 
 using namespace dfine;
@@ -141,10 +289,25 @@ static int gemm_f32_launch(int akm, int bkm, const float *A, const float *B, con
     if (!A || !B || !C || batch < 0 || M < 0 || N < 0 || K < 1 || lda < 1 || ldb < 1 || ldc < N || splits < 1 || act < 0 || act > 3 ||
         (splits > 1 && (chunk < 4 || (chunk & 3) || (int64_t)chunk * (splits - 1) >= K)) || (int64_t)batch * splits > 65535)
         return DFINE_E_BADARG;
-    const int nt_n = (N + kGfBN - 1) / kGfBN, nt_m = (M + kGfBM - 1) / kGfBM;
-    const dim3 grid(nt_n * nt_m, batch * splits);
     const int ch = splits > 1 ? chunk : K;
     hipStream_t st = (hipStream_t)stream;
+    // large products: 128 x 128 tiles when they still make at least ~one workgroup per CU (DFINE_GEMM_F32_BIG=0: never)
+    static const int big_env = [] { const char *e = getenv("DFINE_GEMM_F32_BIG"); return e ? atoi(e) : 1; }();
+    const int bt_n = (N + kGbBN - 1) / kGbBN, bt_m = (M + kGbBM - 1) / kGbBM;
+    if (big_env && M >= 96 && N >= 96 && (int64_t)bt_n * bt_m * batch * splits >= 224) {
+        const int ntiles = bt_n * bt_m, per = (ntiles + 7) / 8;
+        const dim3 gridb(8 * per, batch * splits);
+#define DFINE_GB(AK, BK) hipLaunchKernelGGL((gemm_f32_big_kernel<AK, BK>), gridb, dim3(kGfThreads), 0, st, A, B, bias, C, M, N, K, lda, ldb, \
+                                            ldc, sa, sb, sc, splits, ch, alpha, act, bt_n, ntiles, per)
+        if (akm && bkm) DFINE_GB(true, true);
+        else if (akm) DFINE_GB(true, false);
+        else if (bkm) DFINE_GB(false, true);
+        else DFINE_GB(false, false);
+#undef DFINE_GB
+        return check_launch();
+    }
+    const int nt_n = (N + kGfBN - 1) / kGfBN, nt_m = (M + kGfBM - 1) / kGfBM;
+    const dim3 grid(nt_n * nt_m, batch * splits);
 #define DFINE_GF(AK, BK) hipLaunchKernelGGL((gemm_f32_nt_kernel<AK, BK>), grid, dim3(kGfThreads), 0, st, A, B, bias, C, M, N, K, lda, ldb, ldc, \
                                             sa, sb, sc, splits, ch, alpha, act, nt_n)
     if (akm && bkm) DFINE_GF(true, true);

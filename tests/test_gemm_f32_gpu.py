@@ -125,3 +125,32 @@ def test_gemm_f32_operand_layouts(cuda, akm, bkm, batch):
     if batch == 1:
         part = hip.gemm_f32(a, b, a_kmajor=akm, b_kmajor=bkm, splits=4)
         _close(part.sum(0), ad @ bd, 3e-6)
+
+
+@pytest.mark.parametrize("akm,bkm", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K,batch", [(130, 200, 37, 30), (256, 384, 64, 4), (97, 1601, 130, 2), (512, 400, 515, 16)])
+def test_gemm_f32_large_tile_kernel(cuda, akm, bkm, M, N, K, batch):
+    """Shapes that take the 128 x 128-tile kernel (gemm_f32_big_kernel: M, N >= 96 and >= 224 workgroups): edge tiles in both
+    directions, K tails that are not multiples of 4 / 16, every operand layout, batches, against the fp64 product."""
+    torch.manual_seed(M + N + K)
+    a = torch.randn(batch, *((K, M) if akm else (M, K)), device=cuda)
+    b = torch.randn(batch, *((K, N) if bkm else (N, K)), device=cuda)
+    bias = torch.randn(N, device=cuda)
+    got = hip.gemm_f32(a, b, a_kmajor=akm, b_kmajor=bkm, bias=bias, alpha=0.75, act=1)
+    ad = a.double().transpose(-1, -2) if akm else a.double()
+    bd = b.double() if bkm else b.double().transpose(-1, -2)
+    _close(got, torch.relu(0.75 * (ad @ bd) + bias.double()), 3e-6)
+
+
+def test_gemm_f32_large_tile_splits_and_shared_operand(cuda):
+    """K-split partial products (weight-gradient form) and a 2-D second operand shared by the batch on the large-tile kernel."""
+    torch.manual_seed(21)
+    dy, x = torch.randn(16, 256, 1600, device=cuda), torch.randn(16, 384, 1600, device=cuda)
+    part = hip.gemm_f32_nt(dy, x, splits=3)                               # [16 * 3, 256, 384]
+    assert part.shape == (48, 256, 384)
+    _close(part.view(16, 3, 256, 384).sum(1), dy.double() @ x.double().transpose(1, 2), 3e-6)
+    w = torch.randn(640, 256, device=cuda)
+    y = hip.conv1x1_f32(dy.view(16, 256, 40, 40), w)                     # shared row-major A, K-major B per image
+    _close(y.view(16, 640, 1600), w.double() @ dy.double(), 3e-6)
+    tok = torch.randn(134400 // 8, 256, device=cuda)
+    _close(hip.gemm_f32_nt(tok, w), tok.double() @ w.double().t(), 3e-6)

@@ -75,3 +75,12 @@ for b, e, n in sorted(streams[main]):
 print(f"\nmain stream idle windows > 20 us: {len(gaps)} totalling {sum(g[0] for g in gaps) / 1e3:.2f} ms")
 for g in sorted(gaps, reverse=True)[:25]:
     print(f"  {g[0]:8.1f} us at t = {g[1] / 1e3:6.2f} ms, before {g[2][:80]}")
+# what the other streams run while the main stream sits in its longest idle window (the tail the step waits for)
+if gaps and len(order) > 1:
+    g = max(gaps)
+    lo, hi = g[1], g[1] + g[0]
+    print(f"\nother streams during the longest main idle window ({lo / 1e3:.2f} - {hi / 1e3:.2f} ms):")
+    for s in order[1:3]:
+        for b, e, n in sorted(streams[s]):
+            if b < hi and e > lo:
+                print(f"  stream {s} {b / 1e3:7.3f} + {e - b:7.1f} us  {n[:100]}")
