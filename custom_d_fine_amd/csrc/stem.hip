@@ -98,6 +98,214 @@ __global__ __launch_bounds__(kStemThreads) void stem_conv_kernel(const uint16_t 
     for (int co = 0; co < COUT; ++co) yb[(int64_t)co * Ho * Wo] = f32_to_bf16(acc[co]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The stride-1 stem layers (2x2: stem2a / stem2b and their data gradients; 1x1: stem4) on the matrix cores.
+// stem_conv_kernel is bound by unpacked fp32 FMAs and 2-byte loads (the 24 -> 12 layer: 7.5 GFLOP and 235 MB in 141 us = 53
+// TFLOP/s, 1.7 TB/s).  The MFMA operands want 8 consecutive K values per lane, and K = (tap, input channel) is strided by a whole
+// plane in NCHW - so the input patch of a tile goes through LDS CHANNELS-LAST: 16-byte global loads along a row (8 pixels of one
+// channel), eight 2-byte LDS writes to patch[row][col][channel], and then one aligned ds_read_b128 gives a lane the 8 channels of
+// its pixel and tap.  GEMM view per tile: M = output pixels (16 per MFMA), N = output channels (16 / 32), K = taps x channel
+// groups of 8 (v_mfma_f32_16x16x32_bf16: A lane (pixel l % 16, K chunk l / 16), B lane (channel l % 16, K chunk l / 16), D lane
+// holds pixels 4 (l / 16) + i of channel l % 16: four consecutive pixels = one 8-byte store).
+// Workgroups are persistent: the next tile's global loads are issued into registers before the MFMAs of the current one
+// and written to LDS after them - loads stay in flight through the compute phase instead of load - wait - compute per tile.
+// Weights: the fp32 [(ci, ky, kx)][co] array of dfine_stem_pack_weights (modes 0 / 1) is rounded to bf16 B fragments once per
+// workgroup (like every other convolution under bf16 autocast: bf16 weights, fp32 accumulation).
+typedef uint32_t stem_u32x4_u __attribute__((ext_vector_type(4), aligned(2)));
+constexpr int kSmRows = 8, kSmCols = 64;
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL load (vmcnt(0)), which
+// would end the next tile's prefetch at each barrier
+__device__ __forceinline__ void stem_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int CIN, int COUT, int KS>
+__global__ __launch_bounds__(kStemThreads) void stem_mfma_s1_kernel(const uint16_t *__restrict__ x, const float *__restrict__ wp,
+                                                                    uint16_t *__restrict__ y, int H, int W, int Ho, int Wo, int pad,
+                                                                    int tiles_x, int tiles_y, int total_tiles) {
+    constexpr int CP = (CIN + 7) / 8 * 8, NCG = CP / 8, NCHUNK = KS * KS * NCG, KSTEPS = (NCHUNK + 3) / 4, NT = (COUT + 15) / 16;
+    constexpr int PR = kSmRows + KS - 1, PC = kSmCols + KS - 1;
+    // 16 bytes of padding after every 8 pixels of a patch row: the 8-pixel vectors of neighbouring lanes then start 25 (not 24) 16-byte
+    // slots apart and the eight ds_write_b128 of a staging item spread over all banks (24 = 8 mod 16 put 8 lanes on 2 slots)
+    constexpr int RP = PC * CP + (PC + 7) / 8 * 8;
+    // staging item = (8 pixels of a row) x (8 channels): 8 coalesced 16-byte loads (one per channel), an 8 x 8 transpose of bf16
+    // in registers (32 v_perm_b32), 8 ds_write_b128 (one pixel's 8 channels each).  [Writing the patch element by element
+    // - 56 ds_write_b16 per thread and tile - made the kernel LDS-bound: SQ_LDS_BANK_CONFLICT was 84 % of the LDS-active cycles.]
+    constexpr int NV = PR * NCG * (kSmCols / 8), NPF = (NV + kStemThreads - 1) / kStemThreads;
+    constexpr int NH = PR * CIN * (KS - 1), NPH = (NH + kStemThreads - 1) / kStemThreads;
+    extern __shared__ __attribute__((aligned(16))) uint16_t patch[];          // [PR][PC][CP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (CP != CIN && KS > 1) {                                                 // halo column: its pad channels are never written - no NaN bits there
+        for (int i = tid; i < PR * RP; i += kStemThreads) patch[i] = 0;
+        __syncthreads();
+    }
+    // B fragments: channel co = nt * 16 + lane % 16, K chunk q = 4 ks + lane / 16 -> (tap, channel group)
+    uint4 wreg[KSTEPS][NT];
+    int koff[KSTEPS];
+    bool kval[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int q = 4 * ks + (lane >> 4);
+        const bool qv = q < NCHUNK;
+        const int tap = qv ? q / NCG : 0, cig = qv ? q - tap * NCG : 0;
+        const int ky = tap / KS, kx = tap - ky * KS;
+        kval[ks] = qv;
+        const int qx = (lane & 15) + kx;                            // pixel of the lane inside its 16-pixel group, plus the tap's column
+        koff[ks] = ky * RP + qx * CP + (qx >> 3) * 8 + cig * 8;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = nt * 16 + (lane & 15);
+            float wv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ci = cig * 8 + j;
+                wv[j] = (qv && co < COUT && ci < CIN) ? wp[((ci * KS + ky) * KS + kx) * COUT + co] : 0.f;
+            }
+            wreg[ks][nt] = make_uint4(pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3]), pack_bf16x2(wv[4], wv[5]),
+                                      pack_bf16x2(wv[6], wv[7]));
+        }
+    }
+    uint4 pf[NPF][8];
+    uint16_t ph[NPH > 0 ? NPH : 1];
+    // what a thread stages is the same for every tile: offsets relative to the tile origin, computed once
+    int rel[NPF], lo[NPF], rr[NPF], vv[NPF], cg[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+        const int i = tid + j * kStemThreads;
+        const int v = i % (kSmCols / 8), rc = i / (kSmCols / 8), r = rc % PR, g = (i < NV) ? rc / PR : 0;
+        rel[j] = (g * 8 * H + r) * W + 8 * v;                       // channel g * 8 (+ c * H * W for the c-th of the group)
+        lo[j] = r * RP + 8 * v * CP + v * 8 + g * 8;
+        rr[j] = (i < NV) ? r : -(1 << 20);                          // (an item past the patch fails every row test)
+        vv[j] = 8 * v;
+        cg[j] = g * 8;
+    }
+    int hrel[NPH > 0 ? NPH : 1], hlo[NPH > 0 ? NPH : 1], hrr[NPH > 0 ? NPH : 1], hk[NPH > 0 ? NPH : 1];
+#pragma unroll
+    for (int j = 0; j < NPH; ++j) {
+        const int i = tid + j * kStemThreads;
+        const int k = i % (KS - 1 > 0 ? KS - 1 : 1), rc = i / (KS - 1 > 0 ? KS - 1 : 1), r = rc % PR, ci = (i < NH) ? rc / PR : 0;
+        hrel[j] = (ci * H + r) * W + kSmCols + k;
+        hlo[j] = r * RP + (kSmCols + k) * CP + ((kSmCols + k) >> 3) * 8 + ci;
+        hrr[j] = (i < NH) ? r : -(1 << 20);
+        hk[j] = kSmCols + k;
+    }
+    const int HW = H * W;
+    auto coords = [&](int t, int &b, int &y0, int &x0) {
+        b = t / (tiles_y * tiles_x);
+        const int r = t - b * (tiles_y * tiles_x);
+        const int ty = r / tiles_x;
+        y0 = ty * kSmRows; x0 = (r - ty * tiles_x) * kSmCols;
+    };
+    auto fetch = [&](int t) {
+        int b, y0, x0;
+        coords(t, b, y0, x0);
+        const int gy0 = y0 - pad, gx0 = x0 - pad;
+        const uint16_t *base = x + (int64_t)b * CIN * H * W + (int64_t)gy0 * W + gx0;     // dereferenced at valid positions only
+        const bool cols_in = gx0 >= 0 && gx0 + kSmCols <= W;       // uniform: every 8-pixel vector of the tile lies inside the rows
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const bool row_ok = (unsigned)(gy0 + rr[j]) < (unsigned)H;
+            const uint16_t *src = base + rel[j];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                pf[j][c] = make_uint4(0, 0, 0, 0);
+                if (row_ok && (CP == CIN || cg[j] + c < CIN)) {
+                    if (cols_in) {
+                        const stem_u32x4_u t4 = *reinterpret_cast<const stem_u32x4_u *>(src + c * HW);
+                        pf[j][c] = make_uint4(t4.x, t4.y, t4.z, t4.w);
+                    } else {
+                        const int gx = gx0 + vv[j];
+                        uint16_t e[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) e[k] = (gx + k >= 0 && gx + k < W) ? src[c * HW + k] : (uint16_t)0;
+                        pf[j][c] = make_uint4(e[0] | ((uint32_t)e[1] << 16), e[2] | ((uint32_t)e[3] << 16), e[4] | ((uint32_t)e[5] << 16),
+                                              e[6] | ((uint32_t)e[7] << 16));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NPH; ++j) {
+            ph[j] = 0;
+            if ((unsigned)(gy0 + hrr[j]) < (unsigned)H && (unsigned)(gx0 + hk[j]) < (unsigned)W) ph[j] = base[hrel[j]];
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            if (rr[j] >= 0) {
+                uint16_t *d = patch + lo[j];
+                const uint32_t(*w)[4] = reinterpret_cast<const uint32_t(*)[4]>(&pf[j][0]);      // w[channel][pixel pair]
+#pragma unroll
+                for (int pix = 0; pix < 8; ++pix) {
+                    const uint32_t sel = (pix & 1) ? 0x07060302u : 0x05040100u;                  // (b.half << 16) | a.half of perm(b, a)
+                    const int dw = pix >> 1;
+                    uint4 o;
+                    o.x = __builtin_amdgcn_perm(w[1][dw], w[0][dw], sel);
+                    o.y = __builtin_amdgcn_perm(w[3][dw], w[2][dw], sel);
+                    o.z = __builtin_amdgcn_perm(w[5][dw], w[4][dw], sel);
+                    o.w = __builtin_amdgcn_perm(w[7][dw], w[6][dw], sel);
+                    *reinterpret_cast<uint4 *>(d + pix * CP) = o;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NPH; ++j)
+            if (hrr[j] >= 0) patch[hlo[j]] = ph[j];
+    };
+    // per-lane parts of the MFMA phase: A fragment row of the lane inside a 16-pixel group, output offset of its 4 pixels
+    int orel[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) orel[nt] = (nt * 16 + (lane & 15)) * Ho * Wo + 4 * (lane >> 4);
+    const bool wo4 = (Wo & 3) == 0;
+    int t = blockIdx.x;
+    if (t < total_tiles) fetch(t);
+    for (; t < total_tiles; t += gridDim.x) {
+        commit();
+        stem_lds_barrier();
+        const int tn = t + gridDim.x;
+        if (tn < total_tiles) fetch(tn);                           // in flight during the MFMAs below
+        int b, y0, x0;
+        coords(t, b, y0, x0);
+        uint16_t *yb = y + (int64_t)b * COUT * Ho * Wo;
+#pragma unroll
+        for (int gi = 0; gi < 8; ++gi) {
+            const int g = wave * 8 + gi;
+            const int tr = g / (kSmCols / 16), c16 = g % (kSmCols / 16);      // wave-uniform
+            stem_f32x4 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = stem_f32x4{0.f, 0.f, 0.f, 0.f};
+            const uint16_t *pp = patch + tr * RP + c16 * (16 * CP + 16);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                uint4 av = make_uint4(0, 0, 0, 0);
+                if (kval[ks]) av = *reinterpret_cast<const uint4 *>(pp + koff[ks]);
+                const stem_bf16x8 a = __builtin_bit_cast(stem_bf16x8, av);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(stem_bf16x8, wreg[ks][nt]), acc[nt], 0, 0, 0);
+            }
+            const int gy = y0 + tr, gxb = x0 + c16 * 16;           // uniform
+            if (gy < Ho) {
+                uint16_t *og = yb + (int64_t)gy * Wo + gxb;
+                const int gx = gxb + 4 * (lane >> 4);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (nt * 16 + (lane & 15) >= COUT) continue;
+                    uint16_t *o = og + orel[nt];
+                    if (wo4 && gx + 3 < Wo) {
+                        *reinterpret_cast<uint2 *>(o) = make_uint2(pack_bf16x2(acc[nt][0], acc[nt][1]), pack_bf16x2(acc[nt][2], acc[nt][3]));
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (gx + i < Wo) o[i] = f32_to_bf16(acc[nt][i]);
+                    }
+                }
+            }
+        }
+        stem_lds_barrier();                                         // every wave is done with the patch before it is overwritten
+    }
+}
+
 // dx[b][ci][yi][xi] of a 3x3 / stride 2 / pad 1 convolution; dy [B, COUT, Ho, Wo], H = 2*Ho, W = 2*Wo.
 // wq[((co*3+ky)*3+kx)][ci].  thread = (row yi, pixel pair 2c / 2c+1).
 template <int CIN, int COUT>
@@ -161,8 +369,6 @@ __global__ __launch_bounds__(kStemThreads) void stem_dgrad_s2_kernel(const uint1
 // 8 bf16 elements x[xi0 + j*S], j = 0..7, of one plane row as a packed MFMA fragment (0 outside [0, W)).
 // One (S = 1) or two (S = 2) 16-byte loads from a start clamped into the row - 2-byte aligned, the hardware
 // runs in unaligned-access mode - then a shift by the clamp distance (|d| <= 1 element: pad <= 1, KS <= 3).
-typedef uint32_t stem_u32x4_u __attribute__((ext_vector_type(4), aligned(2)));
-
 template <int S>
 __device__ __forceinline__ uint4 stem_row8(const uint16_t *rowp, int xi0, int W, bool row_ok) {
     constexpr int SPAN = 8 * S;
@@ -492,6 +698,28 @@ static int stem_conv_impl(const void *x, const void *x2, int ca, const float *wp
     const uint16_t *xs = (const uint16_t *)x;
     const uint16_t *xs2 = (const uint16_t *)x2;
     uint16_t *ys = (uint16_t *)y;
+    // stride-1 layers of a single input tensor: matrix-core kernel (DFINE_STEM_MFMA=0: the direct kernel)
+    static const int mfma_env = [] { const char *e = getenv("DFINE_STEM_MFMA"); return e ? atoi(e) : 1; }();
+#define STEM_MFMA_CASE(CI, CO, K)                                                                                                   \
+    if (mfma_env && !xs2 && stride == 1 && Cin == CI && Cout == CO && KS == K) {                                                       \
+        constexpr int cp = (CI + 7) / 8 * 8;                                                                                        \
+        const size_t lds = (size_t)(kSmRows + K - 1) * ((kSmCols + K - 1) * cp + (kSmCols + K - 1 + 7) / 8 * 8) * 2;                                                  \
+        const int tx = (Wo + kSmCols - 1) / kSmCols, ty = (Ho + kSmRows - 1) / kSmRows, total = B * tx * ty;                        \
+        static int per_cu = 0;                                                                                                      \
+        if (!per_cu) {                                                                                                              \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stem_mfma_s1_kernel<CI, CO, K>, kStemThreads, lds) != hipSuccess || per_cu < 1) \
+                per_cu = 1;                                                                                                         \
+        }                                                                                                                           \
+        const int resident = per_cu * 256;                       /* persistent workgroups: exactly one resident set (no second, thin round) */ \
+        const int blocks = total < resident ? total : resident;                                                                     \
+        hipLaunchKernelGGL((stem_mfma_s1_kernel<CI, CO, K>), dim3(blocks), dim3(kStemThreads), lds, st, xs, wp, ys, H, W, Ho, Wo, pad, \
+                           tx, ty, total);                                                                                          \
+        return check_launch();                                                                                                      \
+    }
+    // (the 2x2 layers; the 1x1 layer stem4 measured slower than the direct kernel: 62 vs 57 us and 30 vs 26 us)
+    STEM_MFMA_CASE(24, 12, 2) STEM_MFMA_CASE(12, 24, 2) STEM_MFMA_CASE(16, 8, 2) STEM_MFMA_CASE(8, 16, 2)
+    STEM_MFMA_CASE(32, 16, 2) STEM_MFMA_CASE(16, 32, 2)
+#undef STEM_MFMA_CASE
 #define STEM_CASE(CI, CO, K, S_)                                                         \
     if (Cin == CI && Cout == CO && KS == K && stride == S_) {                            \
         launch_stem<CI, CO, K, S_>(xs, xs2, ca, wp, ys, B, H, W, Ho, Wo, pad, st);       \
