@@ -141,7 +141,10 @@ def test_graphed_train_steps_track_eager_steps(cuda):
     assert (g_e - g_g).abs().max().item() <= max(4 * (g_e - g_e2).abs().max().item(), 1e-6 * g_e.abs().max().item())
     le, lg = res[False][0], res[True][0]
     assert abs(le[0] - lg[0]) <= 2e-3 * abs(le[0]), (le, lg)
-    assert max(abs(a - b) / abs(a) for a, b in zip(le, lg)) < 2e-2, (le, lg)
+    # later steps: the trajectory amplifies the atomics' rounding noise of step 1 - two EAGER runs of this loop differ by up to 3 %
+    # in the loss of step 5 (measured: 32.56 / 33.53 / 32.70 over three runs) - so only the eager runs' own spread is demanded
+    spread = max(abs(a - b) / abs(a) for a, b in zip(le, res["again"][0]))
+    assert max(abs(a - b) / abs(a) for a, b in zip(le, lg)) < max(3 * spread, 5e-2), (le, lg, spread)
     assert res[False][3] == res[True][3] and set(res[True][3]) == {5}
     pe, pg = res[False][1], res[True][1]
     cos = torch.nn.functional.cosine_similarity(pe - pe.mean(), pg - pg.mean(), dim=0).item()
