@@ -433,32 +433,97 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(const uint16_t
     const int wsteps = Wo / 32;
     const int kg = lane >> 4;
     const int s0 = split * steps_per_split, s1 = min(total_steps, s0 + steps_per_split);
-    for (int step = s0; step < s1; ++step) {
-        const int b = step / (Ho * wsteps);
-        const int r = step - b * (Ho * wsteps);
-        const int yo = r / wsteps, xo0 = (r - yo * wsteps) * 32 + 8 * kg;
-        stem_bf16x8 a[2];
+    // Software pipeline: the loads of step s + 1 (two dy fragments, one or two 16-byte pieces of x per column tile) are issued
+    // before the MFMAs of step s.  [Issued and consumed in the same step, every wave sat out a full memory latency per 8 MFMAs:
+    // SQ_WAIT_ANY was 74 % of the wave cycles of the 48 -> 24 layer, 360 us for 17 GFLOP and 354 MB.]  The step's position
+    // (image, row, 32-pixel column block) is advanced, not divided.
+    // x fragments: ALIGNED 16-byte loads of the 8 (stride 1) / 16 (stride 2) input pixels under the lane's 8 output pixels plus, for
+    // a tap that sits one column left / right of them, one 2-byte load of the neighbouring element; the fragment is assembled
+    // with shifts.  (Loading the shifted window directly - 16 bytes at a 2-byte-aligned address - works in the hardware's
+    // unaligned mode but at a fraction of the load rate: the 48 -> 24 layer issues 1.8 GB of such loads.)
+    struct Stage {
+        uint4 a[2];
+        uint4 raw[kStemNT][S];
+        uint16_t e[kStemNT];
+        bool ok[kStemNT];
+    };
+    int coff[kStemNT];                                           // tap column relative to the aligned window: -1, 0, +1
+#pragma unroll
+    for (int t = 0; t < kStemNT; ++t) coff[t] = col_kx[t] - pad;
+    int pb = s0 / (Ho * wsteps), pr = s0 - pb * (Ho * wsteps), pyo = pr / wsteps, pxw = (pr - pyo * wsteps) * 32;
+    auto issue = [&](Stage &st) {
+        const int xo0 = pxw + 8 * kg;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int co = mt * 16 + (lane & 15);
-            uint4 av = make_uint4(0, 0, 0, 0);
-            if (co < COUT) av = *reinterpret_cast<const uint4 *>(dy + (((int64_t)b * COUT + co) * Ho + yo) * Wo + xo0);
-            a[mt] = __builtin_bit_cast(stem_bf16x8, av);
+            st.a[mt] = make_uint4(0, 0, 0, 0);
+            if (co < COUT) st.a[mt] = *reinterpret_cast<const uint4 *>(dy + (((int64_t)pb * COUT + co) * Ho + pyo) * Wo + xo0);
         }
-        const uint16_t *xb_a = x + (int64_t)b * (x2 ? CA : CIN) * H * W;
-        const uint16_t *xb_b = x2 ? x2 + (int64_t)b * (CIN - CA) * H * W : xb_a;
+        const uint16_t *xb_a = x + (int64_t)pb * (x2 ? CA : CIN) * H * W;
+        const uint16_t *xb_b = x2 ? x2 + (int64_t)pb * (CIN - CA) * H * W : xb_a;
+        // multiple of 8 elements: 16-byte aligned when W % 8 == 0 (any other width still works, at the unaligned rate); past the row only
+        // under zero-padded dy columns (hip._stem_pad32), where the values do not matter: clamped into the row
+        const int base = min(xo0 * S, W - 8 * S);
 #pragma unroll
         for (int t = 0; t < kStemNT; ++t) {
             if ((g * kStemNT + t) * 16 >= ncols) break;          // uniform
-            const int yi = yo * S + col_ky[t] - pad;
+            const int yi = pyo * S + col_ky[t] - pad;
             const bool row_ok = col_off[t] >= 0 && (unsigned)yi < (unsigned)H;
             const uint16_t *rowp = (col_b[t] ? xb_b : xb_a) + (row_ok ? col_off[t] + yi * W : 0);
-            const int xi0 = xo0 * S + col_kx[t] - pad;
-            const uint4 bv = stem_row8<S>(rowp, xi0, W, row_ok);
-            const stem_bf16x8 bf = __builtin_bit_cast(stem_bf16x8, bv);
-            acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bf, acc[t][0], 0, 0, 0);
-            if (COUT > 16) acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bf, acc[t][1], 0, 0, 0);
+            st.ok[t] = row_ok;
+            const stem_u32x4_u r0 = *reinterpret_cast<const stem_u32x4_u *>(rowp + base);
+            st.raw[t][0] = make_uint4(r0.x, r0.y, r0.z, r0.w);
+            if (S == 2) {
+                const stem_u32x4_u r1 = *reinterpret_cast<const stem_u32x4_u *>(rowp + base + 8);
+                st.raw[t][S - 1] = make_uint4(r1.x, r1.y, r1.z, r1.w);
+            }
+            st.e[t] = 0;
+            if (coff[t] < 0) { if (base > 0) st.e[t] = rowp[base - 1]; }
+            else if (S == 1 && coff[t] > 0) { if (base + 8 < W) st.e[t] = rowp[base + 8]; }
         }
+        pxw += 32;                                               // next step
+        if (pxw >= Wo) { pxw = 0; if (++pyo == Ho) { pyo = 0; ++pb; } }
+    };
+    auto consume = [&](const Stage &st) {
+        const stem_bf16x8 a0 = __builtin_bit_cast(stem_bf16x8, st.a[0]), a1 = __builtin_bit_cast(stem_bf16x8, st.a[1]);
+#pragma unroll
+        for (int t = 0; t < kStemNT; ++t) {
+            if ((g * kStemNT + t) * 16 >= ncols) break;          // uniform
+            const int d = coff[t];
+            const uint32_t e = st.e[t];
+            uint4 r;
+            if (S == 1) {
+                const uint4 v = st.raw[t][0];
+                if (d == 0) r = v;
+                else if (d < 0) { r.x = (v.x << 16) | e; r.y = (v.y << 16) | (v.x >> 16); r.z = (v.z << 16) | (v.y >> 16); r.w = (v.w << 16) | (v.z >> 16); }
+                else { r.x = (v.x >> 16) | (v.y << 16); r.y = (v.y >> 16) | (v.z << 16); r.z = (v.z >> 16) | (v.w << 16); r.w = (v.w >> 16) | (e << 16); }
+            } else {
+                const uint4 p = st.raw[t][0], q = st.raw[t][S - 1];
+                if (d == 0) {          // elements 0, 2, .. 14: low half of every dword
+                    r.x = (p.x & 0xffffu) | (p.y << 16); r.y = (p.z & 0xffffu) | (p.w << 16);
+                    r.z = (q.x & 0xffffu) | (q.y << 16); r.w = (q.z & 0xffffu) | (q.w << 16);
+                } else if (d > 0) {    // elements 1, 3, .. 15: high half of every dword
+                    r.x = (p.x >> 16) | (p.y & 0xffff0000u); r.y = (p.z >> 16) | (p.w & 0xffff0000u);
+                    r.z = (q.x >> 16) | (q.y & 0xffff0000u); r.w = (q.z >> 16) | (q.w & 0xffff0000u);
+                } else {               // elements -1, 1, .. 13: the element left of the window, then the high halves of dwords 0 .. 6
+                    r.x = e | (p.x & 0xffff0000u);           r.y = (p.y >> 16) | (p.z & 0xffff0000u);
+                    r.z = (p.w >> 16) | (q.x & 0xffff0000u); r.w = (q.y >> 16) | (q.z & 0xffff0000u);
+                }
+            }
+            if (!st.ok[t]) r = make_uint4(0, 0, 0, 0);
+            const stem_bf16x8 bf = __builtin_bit_cast(stem_bf16x8, r);
+            acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bf, acc[t][0], 0, 0, 0);
+            if (COUT > 16) acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf, acc[t][1], 0, 0, 0);
+        }
+    };
+    Stage stA, stB;
+    if (s0 < s1) issue(stA);
+    for (int step = s0; step < s1; step += 2) {
+        if (step + 1 < s1) issue(stB);
+        consume(stA);
+        if (step + 1 >= s1) break;
+        if (step + 2 < s1) issue(stA);
+        consume(stB);
     }
 #pragma unroll
     for (int t = 0; t < kStemNT; ++t) {
