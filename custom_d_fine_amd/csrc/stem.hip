@@ -98,6 +98,82 @@ __global__ __launch_bounds__(kStemThreads) void stem_conv_kernel(const uint16_t 
     for (int co = 0; co < COUT; ++co) yb[(int64_t)co * Ho * Wo] = f32_to_bf16(acc[co]);
 }
 
+// 3x3 / stride 2 / pad 1 layers (stem1, stem3) with 16-byte loads and packed FMAs: a thread owns FOUR consecutive output pixels
+// of a row = 9 input columns per kernel row: one aligned 16-byte load (columns 2 xo .. 2 xo + 7) plus the element left of
+// them, instead of nine 2-byte loads per pixel, and its accumulators are float pairs (v_pk_fma_f32, weight broadcast from a
+// scalar).  stem_conv_kernel is bound by unpacked FMAs and 2-byte loads: 247 us for the 17 GFLOP of the 48 -> 24 layer.
+typedef float stem_f32x2 __attribute__((ext_vector_type(2)));
+template <int CIN, int COUT>
+__global__ __launch_bounds__(kStemThreads) void stem_conv_s2_vec_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ x2,
+                                                                        int CA, const float *__restrict__ wp, uint16_t *__restrict__ y,
+                                                                        int H, int W, int Ho, int Wo) {
+    const int q = blockIdx.x * kStemThreads + threadIdx.x;         // quad of output pixels
+    const int b = blockIdx.y;
+    const int wq = Wo >> 2;
+    if (q >= Ho * wq) return;
+    const int yo = q / wq, xo = (q - yo * wq) * 4;
+    stem_f32x2 acc[COUT][2];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) { acc[co][0] = stem_f32x2{0.f, 0.f}; acc[co][1] = stem_f32x2{0.f, 0.f}; }
+    const int64_t HWi = (int64_t)H * W;
+    const uint16_t *xa_b = x + (int64_t)b * (x2 ? CA : CIN) * HWi;
+    const uint16_t *xb_b = x2 ? x2 + (int64_t)b * (CIN - CA) * HWi : nullptr;
+    auto chan = [&](int ci) -> const uint16_t * { return (x2 && ci >= CA) ? xb_b + (int64_t)(ci - CA) * HWi : xa_b + (int64_t)ci * HWi; };
+    int roff[3];
+    bool rok[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yi = 2 * yo + ky - 1;
+        rok[ky] = (unsigned)yi < (unsigned)H;
+        roff[ky] = (rok[ky] ? yi : 0) * W + 2 * xo;              // 2 xo is a multiple of 8: 16-byte aligned (W % 8 == 0)
+    }
+    const bool left = xo > 0;
+    uint4 cur[3], nxt[3];
+    uint16_t curl[3], nxtl[3];
+    {
+        const uint16_t *c0 = chan(0);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) { cur[ky] = *reinterpret_cast<const uint4 *>(c0 + roff[ky]); curl[ky] = left ? c0[roff[ky] - 1] : (uint16_t)0; }
+    }
+    for (int ci = 0; ci < CIN; ++ci) {
+        const float *wc = wp + ci * (9 * COUT);                  // wave-uniform -> scalar loads
+        const uint16_t *cn = chan(min(ci + 1, CIN - 1));         // next channel's rows in flight
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) { nxt[ky] = *reinterpret_cast<const uint4 *>(cn + roff[ky]); nxtl[ky] = left ? cn[roff[ky] - 1] : (uint16_t)0; }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            float v[9];                                          // columns 2 xo - 1 .. 2 xo + 7
+            const uint4 r = cur[ky];
+            v[0] = bf16_to_f32(curl[ky]);
+            v[1] = __uint_as_float(r.x << 16); v[2] = __uint_as_float(r.x & 0xffff0000u);
+            v[3] = __uint_as_float(r.y << 16); v[4] = __uint_as_float(r.y & 0xffff0000u);
+            v[5] = __uint_as_float(r.z << 16); v[6] = __uint_as_float(r.z & 0xffff0000u);
+            v[7] = __uint_as_float(r.w << 16); v[8] = __uint_as_float(r.w & 0xffff0000u);
+            if (!rok[ky]) {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) v[j] = 0.f;
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const stem_f32x2 p0 = {v[kx], v[2 + kx]}, p1 = {v[4 + kx], v[6 + kx]};      // output pixels (0, 1) and (2, 3)
+                const float *wk = wc + (ky * 3 + kx) * COUT;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) {
+                    const stem_f32x2 w2 = {wk[co], wk[co]};
+                    acc[co][0] = __builtin_elementwise_fma(p0, w2, acc[co][0]);
+                    acc[co][1] = __builtin_elementwise_fma(p1, w2, acc[co][1]);
+                }
+            }
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) { cur[ky] = nxt[ky]; curl[ky] = nxtl[ky]; }
+    }
+    uint16_t *yb = y + (int64_t)b * COUT * Ho * Wo + (int64_t)yo * Wo + xo;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co)
+        *reinterpret_cast<uint2 *>(yb + (int64_t)co * Ho * Wo) = make_uint2(pack_bf16x2(acc[co][0].x, acc[co][0].y), pack_bf16x2(acc[co][1].x, acc[co][1].y));
+}
+
 // ---------------------------------------------------------------------------------------------
 // The stride-1 stem layers (2x2: stem2a / stem2b and their data gradients; 1x1: stem4) on the matrix cores.
 // stem_conv_kernel is bound by unpacked fp32 FMAs and 2-byte loads (the 24 -> 12 layer: 7.5 GFLOP and 235 MB in 141 us = 53
@@ -785,6 +861,18 @@ static int stem_conv_impl(const void *x, const void *x2, int ca, const float *wp
     STEM_MFMA_CASE(24, 12, 2) STEM_MFMA_CASE(12, 24, 2) STEM_MFMA_CASE(16, 8, 2) STEM_MFMA_CASE(8, 16, 2)
     STEM_MFMA_CASE(32, 16, 2) STEM_MFMA_CASE(16, 32, 2)
 #undef STEM_MFMA_CASE
+    // 3x3 / stride 2 / pad 1 on whole 16-byte vectors (DFINE_STEM_VEC=0: the direct kernel)
+    static const int vec_env = [] { const char *e = getenv("DFINE_STEM_VEC"); return e ? atoi(e) : 1; }();
+#define STEM_VEC_CASE(CI, CO)                                                                                                       \
+    if (vec_env && KS == 3 && stride == 2 && pad == 1 && Cin == CI && Cout == CO && W % 8 == 0 && Wo % 4 == 0 && W == 2 * Wo && H == 2 * Ho) { \
+        dim3 gridv((Ho * (Wo / 4) + kStemThreads - 1) / kStemThreads, B);                                                           \
+        hipLaunchKernelGGL((stem_conv_s2_vec_kernel<CI, CO>), gridv, dim3(kStemThreads), 0, st, xs, xs2, ca, wp, ys, H, W, Ho, Wo);   \
+        return check_launch();                                                                                                      \
+    }
+    // (stem1 only: 86 -> 65 us.  The 48 -> 24 layer measured SLOWER in this form - 351 vs 247 us: 3 200 long-running waves of 140
+    // registers, and the packed FMAs with a scalar weight operand did not issue faster than the unpacked ones)
+    STEM_VEC_CASE(3, 24) STEM_VEC_CASE(3, 16) STEM_VEC_CASE(3, 32)
+#undef STEM_VEC_CASE
 #define STEM_CASE(CI, CO, K, S_)                                                         \
     if (Cin == CI && Cout == CO && KS == K && stride == S_) {                            \
         launch_stem<CI, CO, K, S_>(xs, xs2, ca, wp, ys, B, H, W, Ho, Wo, pad, st);       \
