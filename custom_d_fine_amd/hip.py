@@ -70,6 +70,8 @@ _SIGNATURES = {
     "dfine_conv_fwd_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_conv1x1_accum_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_stream_fork": (c_int, [_P, _P]),
+    "dfine_stream_create": (c_int, [c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "dfine_stream_destroy": (c_int, [_P]),
     "dfine_upload": (c_int, [_P, _P, _L, _P]),
     "dfine_conv_epilogue_supported": (c_int, [_I, _I, _I, _I, _I, _I]),
     "dfine_conv_accum_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -935,7 +937,14 @@ class _SideStream:
     __slots__ = ("stream", "cuda_stream")
 
     def __init__(self, dev):
-        self.stream = torch.cuda.Stream(device=dev, priority=_SIDE_PRIORITY)
+        if _SIDE_PRIORITY > 0:
+            # lower than the default stream: torch.cuda.Stream has no such level, the library creates it (kept for the process)
+            raw = ctypes.c_void_p()
+            with torch.cuda.device(dev):
+                _check(_lib.dfine_stream_create(_SIDE_PRIORITY, ctypes.byref(raw)), "dfine_stream_create")
+            self.stream = torch.cuda.ExternalStream(raw.value, device=dev)
+        else:
+            self.stream = torch.cuda.Stream(device=dev, priority=_SIDE_PRIORITY)
         self.cuda_stream = self.stream.cuda_stream
 
 

@@ -41,6 +41,10 @@ const char *dfine_last_error(void);
  * ring): fork / join of the second stream that runs the weight-gradient launches of a backward pass next to the data-gradient
  * chain (the reference runs both on one stream through autograd: torch.Tensor.backward in src/dl/train.py:575). */
 int dfine_stream_fork(void *from, void *to);
+/* A non-blocking stream of `priority` (clamped to the device's range: -1 high, 0 normal, 1 low on gfx950; torch.cuda.Stream only
+ * offers 0 / -1) on the current device, for the low-priority weight-gradient side stream; destroyed by dfine_stream_destroy. */
+int dfine_stream_create(int priority, void **out);
+int dfine_stream_destroy(void *stream);
 /* hipMemcpyAsync(dst, src, bytes, HostToDevice, stream) from memory the caller keeps pinned, alive and unchanged: the pointer
  * tables of launches recorded inside a HIP-graph capture of the backward pass (custom_d_fine_amd/dl/engine.py; the reference
  * launches the same work eagerly from torch.Tensor.backward, src/dl/train.py:575).  The copy becomes a memcpy node that
