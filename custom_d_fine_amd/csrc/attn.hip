@@ -12,7 +12,7 @@
 //     16-key tile, i.e. exactly the key order in which gfx950's LDS transpose-read (ds_read_b64_tr_b16) delivers the V^T / K^T
 //     operand of the second product (rows 4g..4g+3 and 16+4g..16+4g+3 of a 32-key step) - the bf16-packed probabilities are
 //     the B operand of O^T = V^T P^T as they are.  Row max / sum = in-lane reduction + two cross-lane shuffles (lanes
-//     l, l+16, l+32, l+48 share a query).  Keys are streamed in blocks of 256 through LDS with an online softmax, so L is
+//     l, l+16, l+32, l+48 share a query).  Keys are streamed in blocks of kKB = 64 through LDS with an online softmax, so L is
 //     not limited by the register file.
 //   dK / dV ("S orientation", waves split the keys): S = Q K^T puts 4 query rows per 16-query tile in each lane = the
 //     q order of the transpose-read of dO^T / Q^T: P and dS are the B operands of dV^T = dO^T P and dK^T = Q^T dS as they are;
@@ -32,7 +32,8 @@ typedef short a_tr8 __attribute__((ext_vector_type(8)));
 
 constexpr int kAttnThreads = 256;
 constexpr int kHD = 32;                 // head dim
-constexpr int kKB = 256;                // keys per LDS block
+constexpr int kKB = 64;                 // keys per LDS block (256 -> 128 -> 64: forward 99.7 -> 68.2 -> 62.8 us at B 32, L 492, masked: less LDS and
+                                        // fewer score registers per workgroup = more workgroups per CU to cover each other's load - compute phases)
 constexpr int kP40 = 40;                // row pitch (elements) of tiles read with 16-byte fragment loads: conflict-free
 constexpr int kP48 = 48;                // row pitch of tiles read with the transpose-read: the 8 rows of a 32-lane half hit disjoint banks
 
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const uint16_t *
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
     const int bh = blockIdx.x % (B * H), kblk = blockIdx.x / (B * H);
     const int b = bh / H, h = bh - b * H;
-    const int kw0 = kblk * 512 + wave * 16 * KT;                               // this wave's keys
+    const int kw0 = kblk * (NW * 16 * KT) + wave * 16 * KT;                    // this wave's keys
     const uint16_t *qb = q + (int64_t)b * L * ldq + h * kHD;
     const uint16_t *dob = dout + (int64_t)b * L * lddo + h * kHD;
 
@@ -450,16 +451,16 @@ int dfine_attn_bwd(const void *q, const void *k, const void *v, const void *o, c
                        (const uint16_t *)v, (const uint16_t *)o, (const uint16_t *)dout, lse2, mask, (uint16_t *)dq, delta, B, L, H,
                        ldq, ldk, ldv, ldo, lddo, lddq, scale, c);
     if (int e = check_launch()) return e;
-    const int nk = (L + 511) / 512;
-    static const int kt4 = [] { const char *e = getenv("DFINE_ATTN_DKDV_KT4"); return e ? atoi(e) : 1; }();
-    if (kt4)
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<4, 8>), dim3(B * H * nk), dim3(512), 0, st, (const uint16_t *)q, (const uint16_t *)k,
-                           (const uint16_t *)v, (const uint16_t *)dout, lse2, (const float *)delta, mask, (uint16_t *)dk, (uint16_t *)dv,
-                           B, L, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, c);
-    else
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<8, 4>), dim3(B * H * nk), dim3(256), 0, st, (const uint16_t *)q, (const uint16_t *)k,
-                           (const uint16_t *)v, (const uint16_t *)dout, lse2, (const float *)delta, mask, (uint16_t *)dk, (uint16_t *)dv,
-                           B, L, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, c);
+    // keys per workgroup: 512 (<4, 8>, <8, 4>), 256 (<2, 8>), 128 (<2, 4>): fewer keys = more workgroups for the same L
+    static const int var = [] { const char *e = getenv("DFINE_ATTN_DKDV"); return e ? atoi(e) : 48; }();
+#define DFINE_DKDV(KT_, NW_)                                                                                                           \
+    { const int nk = (L + 16 * KT_ * NW_ - 1) / (16 * KT_ * NW_);                                                                      \
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<KT_, NW_>), dim3(B * H * nk), dim3(64 * NW_), 0, st, (const uint16_t *)q, (const uint16_t *)k, \
+                         (const uint16_t *)v, (const uint16_t *)dout, lse2, (const float *)delta, mask, (uint16_t *)dk, (uint16_t *)dv, \
+                         B, L, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, c); }
+    if (var == 48) DFINE_DKDV(4, 8) else if (var == 84) DFINE_DKDV(8, 4) else if (var == 28) DFINE_DKDV(2, 8) else if (var == 14) DFINE_DKDV(1, 4)
+    else if (var == 24) DFINE_DKDV(2, 4) else DFINE_DKDV(4, 8)
+#undef DFINE_DKDV
     return check_launch();
 }
 
