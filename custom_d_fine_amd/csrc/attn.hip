@@ -290,11 +290,13 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const uint16_
 // buffered).  <8, 4>: 128 keys per wave, 256 threads - ONE wave per SIMD for the decoder's 492 tokens (B H = 256 blocks on 256
 // CUs): latency-bound, and slowed down further by whatever shares the chip (143 us alone, 268 us next to the side stream's
 // weight-gradient kernels).  <4, 8>: 64 keys per wave, 512 threads, two waves per SIMD and half the accumulators per wave.
-template <int KT, int NW>
+// MM: mask form - 0 none, 1 byte mask [L, L], 2 transposed bit mask (compile-time: the unmasked encoder layer pays nothing for it)
+template <int KT, int NW, int MM>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const uint16_t *__restrict__ q, const uint16_t *__restrict__ k,
                                                                      const uint16_t *__restrict__ v, const uint16_t *__restrict__ dout,
                                                                      const float *__restrict__ lse2, const float *__restrict__ delta,
-                                                                     const uint8_t *__restrict__ mask, uint16_t *__restrict__ dk,
+                                                                     const uint8_t *__restrict__ mask, const uint32_t *__restrict__ mbits,
+                                                                     uint16_t *__restrict__ dk,
                                                                      uint16_t *__restrict__ dv, int B, int L, int H, int ldq, int ldk,
                                                                      int ldv, int lddo, int lddk, int lddv, float scale,
                                                                      float scale_log2e) {
@@ -328,33 +330,67 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const uint16_t *
     const int tr_off = (4 * g + (i16 >> 2)) * kP48 + 4 * (i16 & 3);
     const bool wave_live = kw0 < L;
 
-    auto stage = [&](int buf, int q0) {
+    // staging of the next 32-query chunk in two halves: the global loads are issued BEFORE the chunk's MFMAs, the LDS writes come
+    // after them.  (Load and LDS write in one go made every staging thread sit out the memory latency in front of its compute,
+    // once per chunk - with one workgroup per CU nothing else covers it.)
+    uint4 st_a = make_uint4(0, 0, 0, 0);
+    float st_l = 0.f, st_d = 0.f;
+    // mask of a chunk as ONE word per key tile: mbits[key][chunk] holds the 32 queries of the chunk (dfine_attn_mask_bits: the
+    // transposed, bit-packed mask).  The byte mask costs 32 single-byte loads per lane and chunk: 98 us masked against 44 us
+    // unmasked at the decoder's shape.
+    const int W32 = (L + 31) >> 5;
+    uint32_t mw[KT], mwn[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) { mw[kt] = 0u; mwn[kt] = 0u; }
+    auto mask_load = [&](int chunk) {
+        if (MM != 2) return;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int key = kw0 + kt * 16 + i16;
+            mwn[kt] = key < L ? mbits[(int64_t)key * W32 + chunk] : 0u;
+        }
+    };
+    auto stage_load = [&](int q0) {
         const int valid = min(32, L - q0);
+        mask_load(q0 >> 5);
+        st_a = make_uint4(0, 0, 0, 0);
         if (tid < 128) {
             const int r = tid >> 2, c = (tid & 3) * 8;
-            uint4 a = make_uint4(0, 0, 0, 0);
-            if (r < valid) a = *reinterpret_cast<const uint4 *>(qb + (int64_t)(q0 + r) * ldq + c);
-            *reinterpret_cast<uint4 *>(&sQ[buf][r * kP48 + c]) = a;
+            if (r < valid) st_a = *reinterpret_cast<const uint4 *>(qb + (int64_t)(q0 + r) * ldq + c);
         } else if (tid < 256) {
             const int t2 = tid - 128, r = t2 >> 2, c = (t2 & 3) * 8;
-            uint4 a = make_uint4(0, 0, 0, 0);
-            if (r < valid) a = *reinterpret_cast<const uint4 *>(dob + (int64_t)(q0 + r) * lddo + c);
-            *reinterpret_cast<uint4 *>(&sDO[buf][r * kP48 + c]) = a;
+            if (r < valid) st_a = *reinterpret_cast<const uint4 *>(dob + (int64_t)(q0 + r) * lddo + c);
         }
         if (tid < 32) {
             const bool ok = tid < valid;
-            sL[buf][tid] = ok ? lse2[((int64_t)b * H + h) * L + q0 + tid] : 0.f;
-            sD[buf][tid] = ok ? delta[((int64_t)b * H + h) * L + q0 + tid] : 0.f;
+            st_l = ok ? lse2[((int64_t)b * H + h) * L + q0 + tid] : 0.f;
+            st_d = ok ? delta[((int64_t)b * H + h) * L + q0 + tid] : 0.f;
         }
+    };
+    auto stage_store = [&](int buf) {
+        if (tid < 128) {
+            const int r = tid >> 2, c = (tid & 3) * 8;
+            *reinterpret_cast<uint4 *>(&sQ[buf][r * kP48 + c]) = st_a;
+        } else if (tid < 256) {
+            const int t2 = tid - 128, r = t2 >> 2, c = (t2 & 3) * 8;
+            *reinterpret_cast<uint4 *>(&sDO[buf][r * kP48 + c]) = st_a;
+        }
+        if (tid < 32) { sL[buf][tid] = st_l; sD[buf][tid] = st_d; }
     };
 
     const int nchunk = (L + 31) / 32;
-    stage(0, 0);
+    stage_load(0);
+    stage_store(0);
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1, q0 = c * 32;
         __syncthreads();                                                    // chunk c staged; every wave is done with chunk c - 1
-        if (c + 1 < nchunk) stage(buf ^ 1, q0 + 32);
-        if (!wave_live) continue;
+        const bool more = c + 1 < nchunk;
+        if (MM == 2) {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) mw[kt] = mwn[kt];
+        }
+        if (more) stage_load(q0 + 32);
+        if (!wave_live) { if (more) stage_store(buf ^ 1); continue; }
         const uint16_t *tq = sQ[buf], *tdo = sDO[buf];
         uint32_t pp[KT][2], dsp[KT][2];                                       // bf16 pairs: [key tile][query tile] -> (r0 r1, r2 r3)
         uint32_t pp2[KT][2], dsp2[KT][2];
@@ -376,7 +412,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const uint16_t *
                 for (int r = 0; r < 4; ++r) {
                     const int qq = q0 + qt * 16 + 4 * g + r;
                     bool dead = key >= L || qq >= L;
-                    if (!dead && mask) dead = mask[(int64_t)qq * L + key] != 0;
+                    if (MM == 2) dead = dead || ((mw[kt] >> (qt * 16 + 4 * g + r)) & 1u);
+                    else if (MM == 1 && !dead) dead = mask[(int64_t)qq * L + key] != 0;
                     p[r] = dead ? 0.f : exp2f(s[r] * scale_log2e - lq[r]);
                     ds[r] = p[r] * (dp[r] - dq_[r]) * scale;
                 }
@@ -396,6 +433,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const uint16_t *
                 dka[d][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, db, dka[d][kt], 0, 0, 0);
             }
         }
+        if (more) stage_store(buf ^ 1);
     }
     if (!wave_live) return;
 #pragma unroll
@@ -411,6 +449,19 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const uint16_t *
             *reinterpret_cast<uint2 *>(dv + ((int64_t)b * L + key) * lddv + h * kHD + 16 * d + 4 * g) = w;
         }
     }
+}
+
+// bits[key][w] bit j = mask[32 w + j][key] != 0 (queries past L: 0)
+__global__ void attn_mask_bits_kernel(const uint8_t *__restrict__ mask, uint32_t *__restrict__ bits, int L, int W32) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L * W32) return;
+    const int w = i / L, key = i - w * L;                        // consecutive threads = consecutive keys: coalesced byte reads
+    uint32_t word = 0u;
+    for (int j = 0; j < 32; ++j) {
+        const int qq = 32 * w + j;
+        if (qq < L && mask[(int64_t)qq * L + key]) word |= 1u << j;
+    }
+    bits[(int64_t)key * W32 + w] = word;
 }
 
 }  // namespace dfine
@@ -437,9 +488,20 @@ int dfine_attn_fwd(const void *q, const void *k, const void *v, void *o, float *
     return check_launch();
 }
 
+// mask [L, L] uint8 -> the transposed bit mask of dfine_attn_bwd: bits [L][(L + 31) / 32] uint32, bit j of bits[key][w] = mask[32 w + j][key]
+int64_t dfine_attn_mask_bits_words(int L) { return (int64_t)L * ((L + 31) / 32); }
+
+int dfine_attn_mask_bits(const uint8_t *mask, int L, uint32_t *bits, void *stream) {
+    if (L == 0) return DFINE_OK;
+    if (!mask || !bits || L < 0) return DFINE_E_BADARG;
+    const int W32 = (L + 31) / 32, n = L * W32;
+    hipLaunchKernelGGL(attn_mask_bits_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, mask, bits, L, W32);
+    return check_launch();
+}
+
 int dfine_attn_bwd(const void *q, const void *k, const void *v, const void *o, const void *dout, const float *lse2,
-                   const uint8_t *mask, void *dq, void *dk, void *dv, float *delta, int B, int L, int H, int hd, int ldq, int ldk,
-                   int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale, void *stream) {
+                   const uint8_t *mask, const uint32_t *mask_bits, void *dq, void *dk, void *dv, float *delta, int B, int L, int H,
+                   int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale, void *stream) {
     if (B == 0 || L == 0) return DFINE_OK;
     const int lds_[8] = {ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv};
     if (!q || !k || !v || !o || !dout || !lse2 || !dq || !dk || !dv || !delta || !attn_args_ok(B, L, H, hd, lds_, 8))
@@ -453,13 +515,14 @@ int dfine_attn_bwd(const void *q, const void *k, const void *v, const void *o, c
     if (int e = check_launch()) return e;
     // keys per workgroup: 512 (<4, 8>, <8, 4>), 256 (<2, 8>), 128 (<2, 4>): fewer keys = more workgroups for the same L
     static const int var = [] { const char *e = getenv("DFINE_ATTN_DKDV"); return e ? atoi(e) : 48; }();
-#define DFINE_DKDV(KT_, NW_)                                                                                                           \
+#define DFINE_DKDV_M(KT_, NW_, MM_)                                                                                                    \
     { const int nk = (L + 16 * KT_ * NW_ - 1) / (16 * KT_ * NW_);                                                                      \
-      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<KT_, NW_>), dim3(B * H * nk), dim3(64 * NW_), 0, st, (const uint16_t *)q, (const uint16_t *)k, \
-                         (const uint16_t *)v, (const uint16_t *)dout, lse2, (const float *)delta, mask, (uint16_t *)dk, (uint16_t *)dv, \
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<KT_, NW_, MM_>), dim3(B * H * nk), dim3(64 * NW_), 0, st, (const uint16_t *)q, (const uint16_t *)k, \
+                         (const uint16_t *)v, (const uint16_t *)dout, lse2, (const float *)delta, mask, mask_bits, (uint16_t *)dk, (uint16_t *)dv, \
                          B, L, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, c); }
-    if (var == 48) DFINE_DKDV(4, 8) else if (var == 84) DFINE_DKDV(8, 4) else if (var == 28) DFINE_DKDV(2, 8) else if (var == 14) DFINE_DKDV(1, 4)
-    else if (var == 24) DFINE_DKDV(2, 4) else DFINE_DKDV(4, 8)
+#define DFINE_DKDV(KT_, NW_) { if (!mask) DFINE_DKDV_M(KT_, NW_, 0) else if (mask_bits) DFINE_DKDV_M(KT_, NW_, 2) else DFINE_DKDV_M(KT_, NW_, 1) }
+    if (var == 84) DFINE_DKDV(8, 4) else if (var == 28) DFINE_DKDV(2, 8) else DFINE_DKDV(4, 8)
+#undef DFINE_DKDV_M
 #undef DFINE_DKDV
     return check_launch();
 }

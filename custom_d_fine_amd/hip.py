@@ -97,8 +97,10 @@ _SIGNATURES = {
     "dfine_act_fwd_bf16": (c_int, [_P, _P, _L, _I, _P]),
     "dfine_act_bwd_bf16": (c_int, [_P, _P, _P, _L, _I, _P]),
     "dfine_attn_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
-    "dfine_attn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
+    "dfine_attn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                                _F, _P]),
+    "dfine_attn_mask_bits_words": (_L, [_I]),
+    "dfine_attn_mask_bits": (c_int, [_P, _I, _P, _P]),
     "dfine_groupnorm_ws_floats": (_L, [_I, _I, _I]),
     "dfine_groupnorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "dfine_groupnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -1227,22 +1229,38 @@ def attn_forward(q, k, v, num_heads, mask=None):
     return o, lse2
 
 
+_MASK_BITS = [None, None]          # (key of the last mask, its transposed bit mask): the decoder's layers share one mask per step
+
+
+def _mask_bits(mask):
+    """Transposed bit-packed form of a [L, L] uint8 mask for the dK / dV kernel (dfine_attn_mask_bits), remade when the mask
+    tensor or its contents change."""
+    key = (mask.data_ptr(), mask._version, mask.shape[0], mask.device.index)
+    if _MASK_BITS[0] != key:
+        L = mask.shape[0]
+        bits = torch.empty(int(_lib.dfine_attn_mask_bits_words(L)), device=mask.device, dtype=torch.int32)
+        _check(_lib.dfine_attn_mask_bits(_ptr(mask), L, _ptr(bits), _stream()), "dfine_attn_mask_bits")
+        _MASK_BITS[0], _MASK_BITS[1] = key, (bits, mask)       # (the mask is kept alive with its key)
+    return _MASK_BITS[1][0]
+
+
 def attn_backward(q, k, v, o, dout, lse2, num_heads, dq, dk, dv, mask=None):
     """Writes dq, dk, dv ([B, L, H * 32] bf16 views, e.g. column slices of one packed gradient buffer)."""
     B, L, E = q.shape
     hd = E // num_heads
     delta = torch.empty_like(lse2)
+    mbits = None if mask is None else _mask_bits(mask)
     if hd != 32:
         qp, kp, vp, op, dop = (_pad_heads(t, num_heads, hd) for t in (q, k, v, o, dout))
         g = torch.empty(3, B, L, num_heads * 32, device=q.device, dtype=torch.bfloat16)
-        _check(_lib.dfine_attn_bwd(_ptr(qp), _ptr(kp), _ptr(vp), _ptr(op), _ptr(dop), _ptr(lse2), _ptr(mask), _ptr(g[0]), _ptr(g[1]),
+        _check(_lib.dfine_attn_bwd(_ptr(qp), _ptr(kp), _ptr(vp), _ptr(op), _ptr(dop), _ptr(lse2), _ptr(mask), _ptr(mbits), _ptr(g[0]), _ptr(g[1]),
                                    _ptr(g[2]), _ptr(delta), B, L, num_heads, 32, _ld(qp), _ld(kp), _ld(vp), _ld(op), _ld(dop),
                                    _ld(g[0]), _ld(g[1]), _ld(g[2]), float(hd) ** -0.5, _stream()), "dfine_attn_bwd")
         for dst, src in zip((dq, dk, dv), g):
             dst.copy_(src.reshape(B, L, num_heads, 32)[..., :hd].reshape(B, L, E))
         return
     with _timed("attention", 10.0 * B * num_heads * L * L * hd, io=2.0 * 8 * B * num_heads * L * hd):
-        _check(_lib.dfine_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(dout), _ptr(lse2), _ptr(mask), _ptr(dq), _ptr(dk),
+        _check(_lib.dfine_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(dout), _ptr(lse2), _ptr(mask), _ptr(mbits), _ptr(dq), _ptr(dk),
                                    _ptr(dv), _ptr(delta), B, L, num_heads, hd, _ld(q), _ld(k), _ld(v), _ld(o), _ld(dout),
                                    _ld(dq), _ld(dk), _ld(dv), float(hd) ** -0.5, _stream()), "dfine_attn_bwd")
 

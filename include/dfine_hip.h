@@ -476,10 +476,15 @@ int dfine_act_bwd_bf16(const void *dy, const void *ref, void *out, int64_t n, in
  */
 int dfine_attn_fwd(const void *q, const void *k, const void *v, void *o, float *lse2, const uint8_t *mask,
                    int B, int L, int H, int hd, int ldq, int ldk, int ldv, int ldo, float scale, void *stream);
+/* mask_bits (optional, with mask): the transposed bit-packed mask made by dfine_attn_mask_bits - dfine_attn_mask_bits_words(L)
+ * uint32 words, bit j of word [key][w] = mask[32 w + j][key] - which gives the dK / dV kernel the 32 queries of a chunk in one
+ * load per key instead of 32 byte loads (98 -> see profiles: the byte mask doubled that kernel's time). */
+int64_t dfine_attn_mask_bits_words(int L);
+int dfine_attn_mask_bits(const uint8_t *mask, int L, uint32_t *bits, void *stream);
 int dfine_attn_bwd(const void *q, const void *k, const void *v, const void *o, const void *dout,
-                   const float *lse2, const uint8_t *mask, void *dq, void *dk, void *dv, float *delta, int B,
-                   int L, int H, int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk,
-                   int lddv, float scale, void *stream);
+                   const float *lse2, const uint8_t *mask, const uint32_t *mask_bits, void *dq, void *dk, void *dv,
+                   float *delta, int B, int L, int H, int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq,
+                   int lddk, int lddv, float scale, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A1 / A2 in fp32 (BASELINE configs[1]): dense convolutions on the f32-input matrix cores (v_mfma_f32_16x16x4_f32, exact

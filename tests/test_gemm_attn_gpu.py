@@ -174,3 +174,27 @@ def test_flatten_levels_matches_permute_concat(cuda, B, C, shapes):
     want.backward(go)
     for a, b in zip(maps, ref_maps):
         assert a.grad.is_contiguous() and torch.equal(a.grad, b.grad)
+
+
+def test_attention_backward_bit_mask_equals_byte_mask(cuda, monkeypatch):
+    """The dK / dV kernel's two mask forms (transposed bit-packed words made by dfine_attn_mask_bits, the byte mask itself) give
+    the same gradients bit for bit; L not a multiple of 32 and a mask with fully blocked rows / columns included."""
+    from custom_d_fine_amd import hip
+    torch.manual_seed(9)
+    B, H, L, E = 3, 8, 77, 256
+    q, k, v, do = (torch.randn(B, L, E, device=cuda).bfloat16() for _ in range(4))
+    m = torch.rand(L, L, device=cuda) < 0.3
+    m[5, :] = True
+    m[:, 11] = True
+    m[5, 5] = False
+    m8 = m.view(torch.uint8)
+    o, lse2 = hip.attn_forward(q, k, v, H, m8)
+    out = {}
+    for form in ("bits", "bytes"):
+        if form == "bytes":
+            monkeypatch.setattr(hip, "_mask_bits", lambda mask: None)
+        dq, dk, dv = (torch.full_like(q, float("nan")) for _ in range(3))
+        hip.attn_backward(q, k, v, o, do, lse2, H, dq, dk, dv, m8)
+        out[form] = (dq, dk, dv)
+    for a, b in zip(out["bits"], out["bytes"]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
