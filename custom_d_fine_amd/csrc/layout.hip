@@ -144,6 +144,41 @@ __global__ __launch_bounds__(256) void upsample2_nearest_bwd_kernel(const uint16
     }
 }
 
+// Weight gradient of an embedding lookup with FEW rows and MANY lookups (the denoising class embedding: 81 x 256 weights, B * dn =
+// 6 272 lookups per step): dw[c][:] = sum over the lookups i with idx[i] == c of g[i][:].  One workgroup per (weight row, 256-column
+// block) walks the index list (25 KB, L2) and adds the matching rows in order - deterministic, no sort, no atomics.  ATen's
+// embedding_dense_backward sorts the indices first (rocPRIM radix sort + segmented sum_and_scatter: 170-370 us for this problem).
+template <typename IT>
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const float *__restrict__ g, const IT *__restrict__ idx,
+                                                            float *__restrict__ dw, int64_t n, int D, int padding_idx) {
+    __shared__ int hits[256];
+    __shared__ int nhit;
+    const int c = blockIdx.x, col = blockIdx.y * 256 + threadIdx.x;
+    float acc = 0.f;
+    for (int64_t i0 = 0; i0 < n; i0 += 256) {
+        // the 256 lookups of this round that hit row c, compacted in order
+        if (threadIdx.x == 0) nhit = 0;
+        __syncthreads();
+        const int64_t i = i0 + threadIdx.x;
+        const bool hit = i < n && (int64_t)idx[i] == c && c != padding_idx;
+        const unsigned long long m = __ballot(hit);
+        __shared__ int wbase[4];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) wbase[wave] = __popcll(m);
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += wbase[w];
+        if (hit) hits[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)(i - i0);
+        if (threadIdx.x == 0) nhit = wbase[0] + wbase[1] + wbase[2] + wbase[3];
+        __syncthreads();
+        const int nh = nhit;
+        if (col < D)
+            for (int h = 0; h < nh; ++h) acc += g[(i0 + hits[h]) * D + col];
+        __syncthreads();
+    }
+    if (col < D) dw[(int64_t)c * D + col] = acc;
+}
+
 }  // namespace dfine
 
 using namespace dfine;
@@ -181,6 +216,20 @@ int dfine_upsample2_nearest_bf16(void *x, void *y, int64_t planes, int H, int W,
         if (V == 8) hipLaunchKernelGGL(upsample2_nearest_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, (const uint16_t *)x, (uint16_t *)y, nvec, W / 8, H);
         else hipLaunchKernelGGL(upsample2_nearest_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, (const uint16_t *)x, (uint16_t *)y, nvec, W / 4, H);
     }
+    return check_launch();
+}
+
+// dw [rows, D] f32 (overwritten) = gradient of F.embedding(idx, weight [rows, D]) given g [n, D] f32 and idx [n] int32 / int64 (idx_bits; lookups of
+// padding_idx, or -1 for none, contribute nothing).  Meant for small tables (rows <= a few hundred).
+int dfine_embedding_bwd(const float *g, const void *idx, int idx_bits, float *dw, int64_t n, int rows, int D, int padding_idx,
+                        void *stream) {
+    if (rows == 0 || D == 0) return DFINE_OK;
+    if (!dw || rows < 0 || D < 0 || n < 0 || (n > 0 && (!g || !idx)) || (idx_bits != 32 && idx_bits != 64)) return DFINE_E_BADARG;
+    const dim3 grid(rows, (D + 255) / 256);
+    if (idx_bits == 64)
+        hipLaunchKernelGGL(embedding_bwd_kernel<int64_t>, grid, dim3(256), 0, (hipStream_t)stream, g, (const int64_t *)idx, dw, n, D, padding_idx);
+    else
+        hipLaunchKernelGGL(embedding_bwd_kernel<int32_t>, grid, dim3(256), 0, (hipStream_t)stream, g, (const int32_t *)idx, dw, n, D, padding_idx);
     return check_launch();
 }
 

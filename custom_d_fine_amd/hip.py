@@ -67,6 +67,7 @@ _SIGNATURES = {
     "dfine_conv_pack_weights_multi": (c_int, [_P, _I, _P]),
     "dfine_maps_tokens_bf16": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_upsample2_nearest_bf16": (c_int, [_P, _P, c_int64, _I, _I, _I, _P]),
+    "dfine_embedding_bwd": (c_int, [_P, _P, _I, _P, c_int64, _I, _I, _I, _P]),
     "dfine_conv_fwd_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_conv1x1_accum_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_stream_fork": (c_int, [_P, _P]),
@@ -812,6 +813,19 @@ def maps_to_tokens(maps):
         _check(_lib.dfine_maps_tokens_bf16(_ptr(m), _ptr(tokens), B, C, hw, L, row, 1, _stream()), "dfine_maps_tokens_bf16")
         row += hw
     return tokens
+
+
+def embedding_backward(g, idx, rows, padding_idx=-1, stream=None):
+    """g [.., D] f32, idx [..] int32 / int64 -> dw [rows, D] f32 = gradient of F.embedding(idx, weight) (small tables: dfine_embedding_bwd)."""
+    D = g.shape[-1]
+    g = g.reshape(-1, D)
+    if g.dtype != torch.float32 or not g.is_contiguous():
+        g = g.float().contiguous()
+    idx = idx.reshape(-1).contiguous()
+    dw = torch.empty(rows, D, device=g.device, dtype=torch.float32)
+    _check(_lib.dfine_embedding_bwd(_ptr(g), _ptr(idx), 32 if idx.dtype == torch.int32 else 64, _ptr(dw), g.shape[0], rows, D, int(padding_idx),
+                                    _stream() if stream is None else stream), "dfine_embedding_bwd")
+    return dw
 
 
 def upsample2_nearest(x, backward=False):

@@ -682,6 +682,12 @@ int dfine_maps_tokens_bf16(const void *map, void *tokens, int B, int C, int HW, 
  * backward = 0: y := upsample(x); backward = 1: x := sum of the 2 x 2 blocks of y (the gradient with respect to x). */
 int dfine_upsample2_nearest_bf16(void *x, void *y, int64_t planes, int H, int W, int backward, void *stream);
 
+/* Weight gradient of a small embedding table (A4: denoising_class_embed, src/d_fine/arch/utils.py:357-467 looks it up for every
+ * denoising query; ATen's embedding_dense_backward sorts the lookups first): dw [rows, D] f32 (overwritten) = sum of the rows of
+ * g [n, D] f32 whose idx [n] (int32 / int64: idx_bits = 32 / 64) names that row; padding_idx (-1: none) contributes nothing.  Deterministic (lookup order). */
+int dfine_embedding_bwd(const float *g, const void *idx, int idx_bits, float *dw, int64_t n, int rows, int D, int padding_idx,
+                        void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * A2 / A5 / A6, fp32 (BASELINE config #2)  Token-stream GEMMs on the f32-input matrix cores.  Replaces the rocBLAS calls
  * behind nn.Linear (arch/dfine_decoder.py:33-46,119-178,214-271,828-873, arch/hybrid_encoder.py:243-290) and the two batched

@@ -62,3 +62,23 @@ def test_clamp_pos_matches_aten_clamp(cuda):
     yb.backward(g)
     assert torch.equal(a.grad, b.grad)
     assert (a.grad.view(-1)[:2] == g.view(-1)[:2]).all() and (a.grad.view(-1)[2:4] == 0).all()
+
+
+@pytest.mark.parametrize("n,rows,D,pad", [(6272, 81, 256, -1), (1000, 5, 100, 2), (3, 81, 256, -1), (0, 7, 64, -1), (513, 300, 300, 0)])
+def test_embedding_backward_scan_kernel(cuda, n, rows, D, pad):
+    """dfine_embedding_bwd (one scan kernel per small table, lookup order, no atomics) against ATen's embedding_dense_backward
+    and against the autograd path of kernels.embedding (the denoising class embedding of the decoder)."""
+    from custom_d_fine_amd import hip, kernels
+    torch.manual_seed(n + rows)
+    idx = torch.randint(0, rows, (n,), device=cuda)
+    g = torch.randn(n, D, device=cuda)
+    got = hip.embedding_backward(g, idx, rows, pad)
+    assert torch.equal(got, hip.embedding_backward(g, idx.int(), rows, pad))          # 32-bit indices: the same kernel, the same order
+    want = torch.ops.aten.embedding_dense_backward(g, idx, rows, pad, False) if n else torch.zeros(rows, D, device=cuda)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5 * max(1.0, float(want.abs().max())))
+    if n and pad < 0:
+        emb = torch.nn.Embedding(rows, D).to(cuda)
+        out = kernels.embedding(emb, idx.view(1, -1))
+        out.backward(g.view(1, n, D))
+        torch.cuda.synchronize()
+        assert torch.allclose(emb.weight.grad, want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
