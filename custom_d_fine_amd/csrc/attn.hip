@@ -521,7 +521,8 @@ int dfine_attn_bwd(const void *q, const void *k, const void *v, const void *o, c
                          (const uint16_t *)v, (const uint16_t *)dout, lse2, (const float *)delta, mask, mask_bits, (uint16_t *)dk, (uint16_t *)dv, \
                          B, L, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, c); }
 #define DFINE_DKDV(KT_, NW_) { if (!mask) DFINE_DKDV_M(KT_, NW_, 0) else if (mask_bits) DFINE_DKDV_M(KT_, NW_, 2) else DFINE_DKDV_M(KT_, NW_, 1) }
-    if (var == 84) DFINE_DKDV(8, 4) else if (var == 28) DFINE_DKDV(2, 8) else DFINE_DKDV(4, 8)
+    if (var == 84) DFINE_DKDV(8, 4) else if (var == 28) DFINE_DKDV(2, 8) else if (var == 44) DFINE_DKDV(4, 4) else if (var == 24) DFINE_DKDV(2, 4)
+    else DFINE_DKDV(4, 8)
 #undef DFINE_DKDV_M
 #undef DFINE_DKDV
     return check_launch();
