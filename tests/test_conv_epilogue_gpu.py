@@ -84,3 +84,29 @@ def test_nearest_upsample_2x_matches_interpolate(cuda, shape):
     want = go.float().view(shape[0], shape[1], shape[2], 2, shape[3], 2).sum((3, 5)).bfloat16()
     assert torch.equal(x.grad, want)
     assert (x.grad.float() - xr.grad.float()).abs().max() <= 2 ** -7 * xr.grad.float().abs().max()
+
+
+def test_multi_pack_equals_single_pack(cuda):
+    """dfine_conv_pack_weights_multi (all layers in one launch; the data-gradient packing as 32 x 32 tile transposes through LDS)
+    against the element-wise single-layer kernel, bit for bit: 1x1 and 3x3, forward and data-gradient forms, channel counts
+    that are not multiples of the tile."""
+    from custom_d_fine_amd import hip
+    torch.manual_seed(0)
+    shapes = [(512, 384, 1), (128, 96, 3), (43, 21, 3), (80, 256, 1), (24, 48, 3), (1536, 768, 1)]
+    rows, outs, keep = [], [], []
+    for cout, cin, ks in shapes:
+        w = torch.randn(cout, cin, ks, ks, device=cuda)
+        keep.append(w)
+        for dgrad in (False, True):
+            co, ci = (cin, cout) if dgrad else (cout, cin)
+            n = hip.conv_packed_elems(cout, cin, ks, dgrad)
+            dst = torch.full((n,), -1, device=cuda, dtype=torch.bfloat16)
+            NP, KP = (co + 15) // 16 * 16, (ci + 31) // 32 * 32
+            assert n == ks * ks * NP * KP
+            rows.append([w.data_ptr(), dst.data_ptr(), cout, cin, ks, NP, KP, int(dgrad)])
+            outs.append((dst, hip.conv_pack_weights(w, dgrad)))
+    table = torch.tensor(rows, dtype=torch.int64, device=cuda)
+    hip.conv_pack_weights_multi(table, len(rows))
+    torch.cuda.synchronize()
+    for got, want in outs:
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
