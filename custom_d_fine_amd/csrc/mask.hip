@@ -288,18 +288,42 @@ __device__ __forceinline__ void mask_cost_block(const T *__restrict__ p, const f
     float a_d[NG * 8], a_f[NG * 8];
 #pragma unroll
     for (int t = 0; t < NG * 8; ++t) { a_d[t] = 0.f; a_f[t] = 0.f; }
-    for (int p0 = 0; p0 < HW; p0 += kMcPix) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < NG * 8 * kMcPix; i += 512) {
+    // software pipeline over the 256-pixel chunks: the next chunk's target pixels (staged through LDS for the 8 queries of the
+    // block) and this wave's 4 x 64 logits are loaded into registers BEFORE the current chunk's arithmetic.  (Loaded and consumed
+    // in the same chunk, the 225 chunks of a 240 x 240 mask were 225 memory round trips in a row: 1.8 ms per launch, config #5.)
+    constexpr int NGF = NG * 8 * kMcPix / 512;                     // staged target values per thread and chunk
+    float gpf[NGF];
+    T ppf[kMcPix / 64], pcur[kMcPix / 64];
+    auto fetch = [&](int p0) {
+#pragma unroll
+        for (int j = 0; j < NGF; ++j) {
+            const int i = threadIdx.x + 512 * j;
             const int t = i / kMcPix, px = i - t * kMcPix;
-            s_g[t][px] = (t < tn && p0 + px < HW) ? gt[(int64_t)(t_first + t) * HW + p0 + px] : 0.f;
+            gpf[j] = (t < tn && p0 + px < HW) ? gt[(int64_t)(t_first + t) * HW + p0 + px] : 0.f;
         }
+#pragma unroll
+        for (int k = 0; k < kMcPix / 64; ++k) {
+            const int px = p0 + k * 64 + lane;
+            ppf[k] = px < HW ? p[px] : T(0);
+        }
+    };
+    fetch(0);
+    for (int p0 = 0; p0 < HW; p0 += kMcPix) {
+        __syncthreads();                                           // every wave is done with the previous chunk's targets
+#pragma unroll
+        for (int j = 0; j < NGF; ++j) {
+            const int i = threadIdx.x + 512 * j;
+            s_g[i / kMcPix][i % kMcPix] = gpf[j];
+        }
+#pragma unroll
+        for (int k = 0; k < kMcPix / 64; ++k) pcur[k] = ppf[k];
         __syncthreads();
-#pragma unroll 1
+        if (p0 + kMcPix < HW) fetch(p0 + kMcPix);                  // in flight during the arithmetic below
+#pragma unroll
         for (int k = 0; k < kMcPix / 64; ++k) {
             const int px = k * 64 + lane;
             if (p0 + px < HW) {
-                const float x = load_f(p + p0 + px);
+                const float x = load_f(&pcur[k]);
                 // hardware exp / log (1 ulp-class relative error, averaged over the H * W terms of a cost sum): the accurate
                 // library forms made this kernel VALU-bound at 2.3 ms per head of config #5
                 const float pr = __builtin_amdgcn_rcpf(1.f + __expf(-x));
