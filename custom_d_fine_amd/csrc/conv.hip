@@ -150,7 +150,7 @@ constexpr int kAbl3 = DFINE_CONV3X3_ABLATE;
 template <int KS, int NTN, int VEC, int KC>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_igemm_kernel(      // two workgroups per CU: at most 256 registers
     const uint16_t *__restrict__ x, const uint16_t *__restrict__ w2, uint16_t *__restrict__ y, int Cin,
-    int Cout, int NP, int KP, int H, int W, int R, int strips) {
+    int Cout, int NP, int KP, int H, int W, int R, int strips, int accum) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int PAD = KS / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -294,7 +294,11 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_igemm_kernel(      // tw
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int n = n_wave + t * 16 + 4 * (lane >> 4) + r;
-                        if (n < Cout) yb[(int64_t)n * H * W + q] = f32_to_bf16(acc[t][jt][r]);
+                        if (n < Cout) {                           // accum: y += conv(x), bf16 + bf16 in fp32, one rounding (like a separate add)
+                            uint16_t *o = yb + (int64_t)n * H * W + q;
+                            const uint16_t c = f32_to_bf16(acc[t][jt][r]);       // the convolution's own bf16 result first, as a separate add would see it
+                            *o = accum ? f32_to_bf16(bf16_to_f32(c) + bf16_to_f32(*o)) : c;
+                        }
                     }
                 }
             }
@@ -1786,11 +1790,10 @@ static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B
 #undef DFINE_WS
         return check_launch();
     }
-    if (accum) return DFINE_E_BADARG;                // conv_igemm_kernel: plain stores only
     dim3 grid(B * strips, wide ? NP / 128 : nblk64);
 #define DFINE_CONV(KSS, NTNN, VECC, KCC)                                                                   \
     hipLaunchKernelGGL((conv_igemm_kernel<KSS, NTNN, VECC, KCC>), grid, dim3(kConvThreads), ldsb, st, x, w2, y, Cin, \
-                       Cout, NP, KP, H, W, R, strips)
+                       Cout, NP, KP, H, W, R, strips, accum)
 #define DFINE_CONV_K(KSS, NTNN, VECC)                                                                 \
     { if (kc == 4) DFINE_CONV(KSS, NTNN, VECC, 4); else if (kc == 2) DFINE_CONV(KSS, NTNN, VECC, 2); else DFINE_CONV(KSS, NTNN, VECC, 1); }
 #define DFINE_CONV_V(KSS, NTNN)                                                                       \
@@ -1904,7 +1907,9 @@ int dfine_conv_epilogue_supported(int B, int Cin, int Cout, int H, int W, int KS
     if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || Cin % 2) return 0;
     const int NP = (Cout + 15) / 16 * 16, KP = (Cin + 31) / 32 * 32;
     if (KS == 1) return conv1x1_glds_ok(Cin, KP, H * W) ? 1 : 0;
-    if (KS == 3) return (W % 2 == 0 && conv3x3_ws_ok(B, NP, KP, H, W)) ? 1 : 0;
+    // (3x3: the wave-specialised kernel, or - output channels not a multiple of 64: stage 1 of the backbone - the first-generation
+    // kernel, whose per-element store reads the old value first)
+    if (KS == 3) return (W % 2 == 0 && W <= 160) ? 1 : 0;
     return 0;
 }
 
