@@ -1549,7 +1549,8 @@ def _bn_tail(y, bn, a, act, lab):
         return _BNAct.apply(y, bn.weight, bn.bias, lab.scale if lab is not None else None,
                             lab.bias if lab is not None else None, bn.running_mean, bn.running_var,
                             a, training, bn.momentum, bn.eps)
-    if hasattr(bn, "running_var") and hasattr(bn, "affine") is False and hasattr(bn, "eps"):
+    if (not isinstance(bn, nn.modules.batchnorm._BatchNorm) and torch.is_tensor(getattr(bn, "running_var", None))
+            and torch.is_tensor(getattr(bn, "weight", None)) and hasattr(bn, "eps")):
         # FrozenBatchNorm2d: buffers only, always "eval" statistics
         return _BNAct.apply(y, bn.weight, bn.bias, lab.scale if lab is not None else None,
                             lab.bias if lab is not None else None, bn.running_mean, bn.running_var,
