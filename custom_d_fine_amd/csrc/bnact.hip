@@ -1158,22 +1158,25 @@ int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_
     int per;
     const int nchunk = chunks_for(B, C, HW, &per);
     float *coef = ws + (int64_t)C * nchunk * 4;
-    // the reductions are needed for the parameter gradients in both modes
+    // the reductions are needed for the parameter gradients in both modes - and for nothing else in eval mode: a frozen unit
+    // (FrozenBatchNorm2d of the D-FINE-l / x backbone: statistics and affine are buffers) skips the pass over x and dy
+    const bool need_sums = training || dgamma || dbeta || dlab;
 #define DFINE_BNR(TT, A, LB) hipLaunchKernelGGL((bn_bwd_reduce_kernel<TT, A, LB>), dim3(C, nchunk), dim3(kBnThreads), 0, st, \
                                                 (const TT *)x, (const TT *)dy, ws, save_mean ? save_mean : scale,               \
                                                 save_invstd ? save_invstd : scale, scale, shift, lab_scale, C, HW, B, per)
 #define DFINE_BNR_A(TT, LB) { if (act == 0) DFINE_BNR(TT, 0, LB); else if (act == 1) DFINE_BNR(TT, 1, LB); else DFINE_BNR(TT, 2, LB); }
     // without a learnable affine the two extra sums stay zero (the partial buffer slots are still written)
-    if (dtype == DFINE_F32) { if (lab_scale) DFINE_BNR_A(float, true) else DFINE_BNR_A(float, false) }
+    if (!need_sums) {}
+    else if (dtype == DFINE_F32) { if (lab_scale) DFINE_BNR_A(float, true) else DFINE_BNR_A(float, false) }
     else { if (lab_scale) DFINE_BNR_A(uint16_t, true) else DFINE_BNR_A(uint16_t, false) }
 #undef DFINE_BNR_A
 #undef DFINE_BNR
-    const bool fuse_fin = dtype != DFINE_F32 && (HW & 7) == 0 && (HW & 3) == 0 && C <= 2048 && (int64_t)C * nchunk <= kBnFuseMax &&
+    const bool fuse_fin = need_sums && dtype != DFINE_F32 && (HW & 7) == 0 && (HW & 3) == 0 && C <= 2048 && (int64_t)C * nchunk <= kBnFuseMax &&
                           (int64_t)B * C * HW / 8 < (int64_t)1 << 31;
     BnFusedBwdFin bfin{};
     if (fuse_fin)
         bfin = BnFusedBwdFin{ws, nchunk, (double)B * HW, dgamma, dbeta, dlab, coef};
-    else
+    else if (need_sums)
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, ws, nchunk, C, (double)B * HW,
                            dgamma, dbeta, dlab, coef);
     if ((HW & 3) == 0 && C <= 2048) {

@@ -435,7 +435,10 @@ class _BNAct(torch.autograd.Function):
         y, stats = _hip().bn_act_forward(x, gamma, beta, running_mean, running_var, lab_scale, lab_bias,
                                          act, training, momentum, eps)
         ctx.save_for_backward(x, stats, lab_scale)
-        ctx.cfg = (act, training, gamma is not None, lab_scale is not None)
+        # (parameter gradients only where a parameter wants one: the frozen units of the D-FINE-l / x backbone carry buffers, and an
+        # eval-mode backward without them skips the reduction pass over x and dy altogether)
+        ctx.cfg = (act, training, gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]),
+                   lab_scale is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]))
         # learnable affine: the backward kernel adds its two scalars straight into the fused optimizer's flat gradient
         # buffer when scale and bias sit next to each other there (they do: consecutive parameters of one module)
         ctx.slot = None

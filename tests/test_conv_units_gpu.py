@@ -190,3 +190,42 @@ def test_repvgg_unit_fused_vs_fp32_reference(cuda, B, C, H, W, act, with_res):
         a, b = dict(blk.named_buffers())[name], dict(ref.named_buffers())[name]
         assert close(a, b, 1e-2), name
     assert int(blk.conv1.norm.num_batches_tracked) == 1 and int(blk.conv2.norm.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("lab", [False, True])
+def test_frozen_batchnorm_unit_takes_hip_tail(cuda, lab):
+    """ConvBNAct with a FrozenBatchNorm2d (backbone of D-FINE-l / x: statistics and affine are buffers) under bf16 autocast: the
+    fused HIP tail in eval mode - no ATen mul / add passes - against the same module on the CPU in fp32, forward and input
+    gradient; the buffers receive no gradient and stay untouched."""
+    from custom_d_fine_amd.d_fine.arch.common import FrozenBatchNorm2d, freeze_batch_norm2d
+    torch.manual_seed(3)
+    unit = ConvBNAct(32, 64, 1, use_act=True, use_lab=lab)
+    with torch.no_grad():
+        unit.bn.weight.uniform_(0.5, 1.5); unit.bn.bias.normal_(0, 0.3)
+        unit.bn.running_mean.normal_(0, 0.2); unit.bn.running_var.uniform_(0.5, 1.5)
+    state = {k: v.clone() for k, v in unit.bn.state_dict().items() if k != "num_batches_tracked"}
+    freeze_batch_norm2d(unit)
+    assert isinstance(unit.bn, FrozenBatchNorm2d)
+    unit.bn.load_state_dict(state)
+    unit.train()
+    x = torch.randn(4, 32, 40, 40)
+    go = torch.randn(4, 64, 40, 40)
+    xr = x.clone().requires_grad_(True)
+    yr = unit(xr)
+    yr.backward(go)
+    g = unit.to(cuda)
+    xg = x.to(cuda).requires_grad_(True)
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = g(xg)
+        y.backward(go.to(cuda).to(y.dtype))
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    assert any("bn_apply" in n or "bn_one" in n for n in names), names
+    assert not any("bn_bwd_reduce" in n for n in names), "a frozen unit's backward needs no reduction pass"
+    assert (y.float().cpu() - yr).abs().max() <= 3e-2 * yr.abs().max()
+    # (a ReLU whose bf16 pre-activation lands on the other side of zero flips single elements: the gradient is compared in norm)
+    assert (xg.grad.cpu() - xr.grad).norm() <= 6e-2 * xr.grad.norm()
+    for k, v in state.items():
+        assert torch.equal(g.bn.state_dict()[k].cpu(), v)
