@@ -223,7 +223,8 @@ def test_frozen_batchnorm_unit_takes_hip_tail(cuda, lab):
         torch.cuda.synchronize()
     names = [e.key for e in prof.key_averages()]
     assert any("bn_apply" in n or "bn_one" in n for n in names), names
-    assert not any("bn_bwd_reduce" in n for n in names), "a frozen unit's backward needs no reduction pass"
+    if not lab:                                                  # (the learnable affine of a unit still wants its two sums)
+        assert not any("bn_bwd_reduce" in n for n in names), "a frozen unit's backward needs no reduction pass"
     assert (y.float().cpu() - yr).abs().max() <= 3e-2 * yr.abs().max()
     # (a ReLU whose bf16 pre-activation lands on the other side of zero flips single elements: the gradient is compared in norm)
     assert (xg.grad.cpu() - xr.grad).norm() <= 6e-2 * xr.grad.norm()
