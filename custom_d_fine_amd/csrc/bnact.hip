@@ -179,13 +179,17 @@ __global__ void bn_finalize_kernel(const float *__restrict__ part, int nchunk, i
 // eval / frozen statistics: scale/shift from running stats
 __global__ void bn_fold_kernel(int C, const float *__restrict__ gamma, const float *__restrict__ beta,
                                const float *__restrict__ running_mean, const float *__restrict__ running_var,
-                               float eps, float *__restrict__ scale_out, float *__restrict__ shift_out) {
+                               float eps, float *__restrict__ scale_out, float *__restrict__ shift_out,
+                               float *__restrict__ mean_out, float *__restrict__ invstd_out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const float invstd = rsqrtf(running_var[c] + eps);
     const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
     scale_out[c] = g * invstd;
     shift_out[c] = bt - running_mean[c] * g * invstd;
+    // what the eval-mode backward takes as save_mean / save_invstd (the host composed them with three ATen launches per unit)
+    if (mean_out) mean_out[c] = running_mean[c];
+    if (invstd_out) invstd_out[c] = invstd;
 }
 
 // Flat variant for planes whose size is a multiple of 4: grid-stride over all 4-vectors of the tensor,
@@ -1088,7 +1092,8 @@ int dfine_bn_act_fwd(const void *x, void *y, const float *gamma, const float *be
                                running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
     } else {
         if (!running_mean || !running_var) return DFINE_E_BADARG;
-        hipLaunchKernelGGL(bn_fold_kernel, dim3(cb), dim3(128), 0, st, C, gamma, beta, running_mean, running_var, eps, scale, shift);
+        hipLaunchKernelGGL(bn_fold_kernel, dim3(cb), dim3(128), 0, st, C, gamma, beta, running_mean, running_var, eps, scale, shift,
+                           save_mean, save_invstd);
     }
     if ((HW & 3) == 0 && C <= 4096) {
         const int64_t nvec = (int64_t)B * C * HW / 4;

@@ -555,10 +555,7 @@ def bn_act_forward(x, gamma, beta, running_mean, running_var, lab_scale, lab_bia
                                    1 if training else 0, float(momentum), float(eps), _stream())
     if status != 0:
         _check(status, "dfine_bn_act_fwd")
-    if not training:
-        stats[0].copy_(running_mean)
-        torch.rsqrt(running_var + eps, out=stats[1])
-    return y, stats
+    return y, stats                # (eval mode: rows 0 / 1 hold the running mean and rsqrt(running_var + eps), written by the kernel)
 
 
 _EPI_OK = {}

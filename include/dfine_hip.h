@@ -179,7 +179,8 @@ int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, fl
  *   save_mean/save_invstd/scale/shift [C] f32 outputs (scale/shift: folded per-channel affine, also
  *   needed by the backward); ws: dfine_bn_ws_floats(B,C,HW) floats.
  *   bwd: dgamma/dbeta [C] f32 (may be NULL); dlab [2] f32 ZERO-FILLED (d lab_scale, d lab_bias) or
- *   NULL; in eval mode pass the running mean and rsqrt(running_var + eps) as save_mean/save_invstd.
+ *   NULL; in eval mode pass the running mean and rsqrt(running_var + eps) as save_mean/save_invstd (the eval-mode forward
+ *   writes exactly those into its save_mean / save_invstd outputs when they are given).
  */
 int64_t dfine_bn_ws_floats(int B, int C, int HW);
 int dfine_bn_act_fwd(const void *x, void *y, const float *gamma, const float *beta,
