@@ -965,6 +965,10 @@ static int stem_wgrad_impl(const void *x, const void *x2, int ca, const void *dy
     if (!x || !dy || !dw || !ws || Cout > 32 || Cout < 1 || Cin < 1 || Wo % 32 || KS < 1 || KS > 3 || pad > 1 ||
         (stride != 1 && stride != 2) || W < 8 * stride)
         return DFINE_E_BADARG;
+    // one 8-output lane group reads ONE clamped x window (base = min(xo0 * S, W - 8 * S)) and shifts by kx - pad in {-1, 0, 1}:
+    // a row width that is not a multiple of 8 * stride would pair the last partly valid group with shifted columns, and
+    // KS = 3 without padding needs a shift of +2 - both would be silently wrong weight gradients, so they are refused.
+    if (W % (8 * stride) != 0 || KS - 1 - pad > 1) return DFINE_E_BADARG;
     int ng, ns, steps;
     stem_wgrad_plan(B, Cin, KS, Ho, Wo, &ng, &ns, &steps);
     const int workers = ng * ns;

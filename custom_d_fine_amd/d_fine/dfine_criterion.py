@@ -111,8 +111,8 @@ class DFINECriterion(nn.Module):
 
     def _targets_cat(self, targets):
         """(labels [T], boxes [T,4], per-image offsets) of the batch, concatenated once."""
-        key = id(targets)
-        if self._tgt is None or self._tgt[0] != key:
+        key = targets           # the list itself: the cache keeps it alive, so its identity cannot be recycled by another list
+        if self._tgt is None or self._tgt[0] is not key:
             sizes = [len(t["labels"]) for t in targets]
             offs = [0]
             for n in sizes:
@@ -498,7 +498,17 @@ class DFINECriterion(nn.Module):
         # the reference's two scalar all-reduces (dfine_criterion.py:639-652) folded into one 2-float host-side collective
         from .dist_utils import host_all_reduce_sum
         world = get_world_size()
-        tot = host_all_reduce_sum([float(indices_go.src.size), float(sum(len(t["labels"]) for t in targets))])
+        n_tgt = float(sum(len(t["labels"]) for t in targets))
+        if world > 1 and fused and _DEVICE_PLANS[0] and hasattr(self.matcher, "match_heads_device"):
+            # Another rank of this step may be on the device-plan path (it is chosen per rank from the rank's OWN batch: no
+            # targets, too many pairs for the plan kernel ...).  Every rank must issue the SAME collectives in the same order
+            # or they pair up with the wrong partner (a gradient bucket's all-reduce): one 1-float device all-reduce of the
+            # GO count, then one 1-float host all-reduce of the target count - exactly `_forward_fused_device`'s sequence.
+            go_f = torch.full((1,), float(indices_go.src.size), device=device, dtype=torch.float32)
+            torch.distributed.all_reduce(go_f)
+            tot = [float(go_f.item()), host_all_reduce_sum([n_tgt])[0]]
+        else:
+            tot = host_all_reduce_sum([float(indices_go.src.size), n_tgt])
         # fp32 division like the reference's torch.clamp(t / world, min=1).item()
         num_boxes_go = max(float(np.float32(tot[0]) / np.float32(world)), 1.0)
         num_boxes = max(float(np.float32(tot[1]) / np.float32(world)), 1.0)

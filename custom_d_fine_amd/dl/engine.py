@@ -190,6 +190,9 @@ class GraphedSegment:
         fused.accumulating = True                       # no bucket bookkeeping from the warm-up / capture runs
         snap_grad = fused.flat_grad.clone()
         snap_buf = None if fused.flat_buf is None else fused.flat_buf.clone()
+        # the warm-up is a real training-mode forward: BatchNorm running statistics / counters that do not live in the
+        # optimizer's flat buffer (no EMA -> no flat_buf; integer counters never do) are rolled back module by module
+        snap_mod = [(b, b.clone()) for b in module.buffers() if fused.flat_buf is None or not b.dtype.is_floating_point]
         snap_bn = dict(kernels._BN_PENDING)
         flags = (kernels._CAPTURE_POSSIBLE, kernels._CAPTURE_SHADOWS, hip.CAPTURE_SIDE, arch_utils.CAPTURE_KEEP)
         self.bwd_pairs = None
@@ -214,6 +217,8 @@ class GraphedSegment:
             fused.flat_grad.copy_(snap_grad)
             if snap_buf is not None:
                 fused.flat_buf.copy_(snap_buf)
+            for b, c in snap_mod:
+                b.copy_(c)
             kernels._BN_PENDING.clear()
             kernels._BN_PENDING.update(snap_bn)
             fused._uses.clear()
@@ -328,6 +333,16 @@ class GraphedSegment:
     def __call__(self, *inputs):
         return self._fn.apply(self._token, *inputs)
 
+    def release(self):
+        """Drops the graphs and every buffer they pinned.  The segment and its `_Replay` closure reference each other, and
+        `gc.freeze()` may have moved them to the permanent generation: an evicted segment would otherwise keep its graph
+        memory pool for the life of the process."""
+        self._fn = None
+        self.fwd_graph = self.bwd_graph = self.bwd_pairs = None
+        self.static_in = self.static_out = self.static_gout = self._static_grads = None
+        self._keep = []
+        self._aliases = []
+
 
 class TrainStep:
     """fwd (autocast) -> criterion (fp32) -> bwd -> clip -> AdamW -> [scheduler] -> EMA.
@@ -387,10 +402,13 @@ class TrainStep:
         if not use_graph:
             return model(images, targets=targets)
         key = (tuple(images.shape), images.dtype)
-        seg = self._graphs.get(key)
-        if seg is None:
-            if len(self._graphs) >= int(os.environ.get("DFINE_GRAPH_SHAPES", "4")):      # multiscale training: a few input sizes
-                self._graphs.pop(next(iter(self._graphs)))
+        seg = self._graphs.pop(key, None)
+        if seg is not None:
+            self._graphs[key] = seg              # most recently used last: the eviction below is true LRU
+        else:
+            # multiscale training draws from 5 input sizes (base, +-32, +-64: reference dataset.py:667-694)
+            if len(self._graphs) >= int(os.environ.get("DFINE_GRAPH_SHAPES", "5")):
+                self._graphs.pop(next(iter(self._graphs))).release()
             be = _BackboneEncoder(model.backbone, model.encoder)
             seg = self._graphs[key] = GraphedSegment(be, (images,), amp_dtype=self.amp_dtype, fused=self.fused)
         with torch.autocast("cuda", enabled=False):

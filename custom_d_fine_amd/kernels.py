@@ -1255,7 +1255,10 @@ def _stem_conv_ok(conv, x, pad_br):
         if ks == 2:
             return False
         wo = (W + 2 * pad - ks) // st + 1
-    # (the MFMA weight-gradient kernel walks 32-pixel K steps: narrower rows run on zero-padded copies of dy, hip.stem_wgrad)
+    # (the MFMA weight-gradient kernel walks 32-pixel K steps: narrower rows run on zero-padded copies of dy, hip.stem_wgrad;
+    # its 8-output lane groups read one clamped x window each, which is only right when no group is partly valid)
+    if wo % 8 != 0 or W % (8 * st) != 0 or ks - 1 - pad > 1:
+        return False
     if st == 1:
         return hip.stem_supported(cout, cin, ks, 1)     # data gradient = same kernel, channels swapped
     if st == 2:

@@ -138,3 +138,65 @@ def test_rccl_all_devices_fused_train_step(tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True, True, "nccl"), nprocs=world, join=True)
     runs = [torch.load(tmp_path / f"rank{r}_1.pt") for r in range(world)]
     assert all(torch.equal(runs[0]["flat"], r["flat"]) for r in runs[1:])
+
+
+def _worker_empty_rank(rank, world, port, out_dir, graph):
+    """Rank 1's batch has NO targets: its criterion takes the host bookkeeping path while rank 0 builds its plans on the
+    device.  Both must issue the same collectives (a mismatch pairs the GO-count all-reduce with a gradient bucket's)."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    import datetime
+    dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    from custom_d_fine_amd.d_fine import dfine
+    from custom_d_fine_amd.dl.engine import ModelEMA, TrainStep
+    from custom_d_fine_amd.dl.fused_optim import FusedAdamWEMA
+    from custom_d_fine_amd.dl.synthetic import make_batch
+
+    torch.manual_seed(100)
+    model = dfine.build_model("n", 5, False, str(dev), img_size=[320, 320]).train()
+    crit = dfine.build_loss("n", 5, 0.0, False)
+    ema = ModelEMA(model, 0.9998)
+    opt = dfine.build_optimizer(model, lr=8e-4, backbone_lr=4e-4, betas=(0.9, 0.999), weight_decay=1.25e-4, base_lr=8e-4)
+    fused = FusedAdamWEMA(model, opt, ema, clip_max_norm=0.1, overlap=True, bucket_mb=2)
+    fused.broadcast_from_rank0()
+    step = TrainStep(model, crit, opt, amp_dtype=torch.bfloat16, clip_max_norm=0.1, ema=ema, fused_optimizer=fused, hip_graph=graph)
+    images, targets = make_batch(2, 320, num_classes=5, seed=42 + rank, device=dev)
+    if rank == 1:
+        targets = [{**t, "labels": t["labels"][:0], "boxes": t["boxes"][:0]} for t in targets]
+    losses = []
+    for _ in range(3):
+        loss, loss_dict = step(images, targets)
+        losses.append(loss.item())
+    torch.cuda.synchronize()
+    flat = fused.flat_param.detach().cpu()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert all(torch.equal(gathered[0], g) for g in gathered[1:]), "ranks diverged"
+    assert all(torch.isfinite(torch.tensor(l)) for l in losses)
+    torch.save({"losses": losses, "flat": flat}, os.path.join(out_dir, f"empty_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _spawn_bounded(fn, args, world, seconds):
+    """mp.spawn with a wall-clock bound: a collective mismatch shows up as a hang, which must fail the test, not the box."""
+    import time
+    ctx = mp.spawn(fn, args=args, nprocs=world, join=False)
+    t0 = time.time()
+    while not ctx.join(timeout=5):
+        if time.time() - t0 > seconds:
+            for p in ctx.processes:
+                if p.is_alive():
+                    p.kill()
+            pytest.fail(f"ranks did not finish within {seconds} s (mismatched collectives hang)")
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_ranks_one_without_targets(cuda, tmp_path, graph):
+    """the device-plan / host-plan choice is per rank; the collectives must not depend on it."""
+    world = 2
+    _spawn_bounded(_worker_empty_rank, (world, _free_port(), str(tmp_path), graph), world, 420)
+    r0, r1 = torch.load(tmp_path / "empty_rank0.pt"), torch.load(tmp_path / "empty_rank1.pt")
+    assert torch.equal(r0["flat"], r1["flat"])
