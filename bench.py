@@ -103,6 +103,17 @@ def conv_pmc_traffic():
     return best
 
 
+def profile_roofline():
+    """The family's fraction recomputed from the committed rocprofv3 --kernel-trace --stats summary of this command
+    (profiles/rNN_roofline_from_profile.json, written by tools/roofline_from_stats.py from rNN_bench_kernel_stats.csv): kernel
+    time of the family in the GRAPH-REPLAY two-stream mode that produces `value`.  Not a measurement of this run."""
+    best = None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+        if name.endswith("_roofline_from_profile.json"):
+            best = dict(json.load(open(os.path.join(ROOT, "profiles", name))), source=f"profiles/{name}", measured_in_run=False)
+    return best
+
+
 def cpu_baseline(model_name, img, steps):
     """The same train step on the host through the oracle backend (kind 'port'), as BASELINE.md section 3 asks: fp32, bs 2,
     one intra-op thread per PHYSICAL core, 1 warm-up + `steps` timed steps, median."""
@@ -217,7 +228,9 @@ def main():
     import gc
     gc.collect()
     gc.freeze()                  # the long-lived heap (model, optimizer, caches) stays out of the cyclic collector's walks
-    hip.enable_timing(None)
+    # events only around the launches the line reports: every event pair costs the host ~5 us, and a sampled step that is
+    # host-paced overlaps its two streams less than the un-instrumented steps do
+    hip.enable_timing(MFMA_GROUPS + ("linear_wgrad", "linear", "attention", "msda_fwd", "msda_bwd"))
     hip.timing_active(False)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     sampled_steps = set()
@@ -234,6 +247,13 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    if sampled_steps:
+        # one more step, OUTSIDE the timed region, with everything on one stream: the same kernels without a neighbour
+        # (records under "iso:<key>"; `roofline` itself is the two-stream sample taken inside the timed region)
+        hip.timing_active(True, isolated=True)
+        step(images, targets)
+        hip.timing_active(False)
+        torch.cuda.synchronize()
     if rank == 0:
         if os.environ.get("DFINE_BENCH_DUMP_STEPS") == "1":
             print("gc collections (generation, ms):", _GC_LOG, file=sys.stderr)
@@ -254,14 +274,20 @@ def main():
         lq = 300 + dn
         sampled = len(sampled_steps)
 
-        def mfma_entry(keys, label, traffic=None):
+        def mfma_entry(keys, label, traffic=None, iso=False):
+            if iso:
+                keys = tuple("iso:" + k for k in keys)
             n = sum(timing[k][0] for k in keys if k in timing)
             ms = sum(timing[k][2] for k in keys if k in timing)
             fl = sum(timing[k][3] for k in keys if k in timing)
             bound_ms = sum(timing[k][4] for k in keys if k in timing)
             tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            sampled = 1 if iso else len(sampled_steps)
             return {"kernel": label, "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
                     "frac": round(tf / MFMA_BF16_PEAK_TFS, 4), "traffic": traffic,
+                    "mode": "isolated: one eager step after the timed region, every launch on one stream" if iso else
+                            "concurrent: eager step(s) inside the timed region on the two streams of the timed mode (weight gradients "
+                            "beside the data-gradient chain), HIP events on the stream each launch goes to",
                     # per-launch roofline: sum over the launches of max(FLOPs / 2.5 PFLOP/s, compulsory bytes / 8 TB/s) over
                     # the measured time - most layers of this network are HBM-bound (a 128 -> 128 1x1 layer has 64 FLOP / B)
                     "bound_ms_per_step": round(bound_ms / max(sampled, 1), 3),
@@ -279,9 +305,12 @@ def main():
                     "algorithmic_bytes_per_launch": int(work / n), "launches_per_step": round(n / max(sampled, 1), 1),
                     "avg_launch_ms": round(mean_ms, 4), "ms_per_step": round(tot_ms / max(sampled, 1), 3)}
 
-        family = mfma_entry(MFMA_GROUPS, "dense-conv implicit GEMMs of backbone + encoder: conv1x1_glds / conv_igemm<3> (fwd + dgrad), "
-                            "conv_wgrad1_glds / conv_wgrad<3> + the deferred split reduction, stem_*",
-                            traffic=conv_pmc_traffic())
+        fam_label = ("dense-conv implicit GEMMs of backbone + encoder: conv1x1_glds / conv3x3_ws / conv_igemm<3> (fwd + dgrad), "
+                     "conv_wgrad1_glds / conv_wgrad3 + the deferred split reduction, stem_*")
+        family = mfma_entry(MFMA_GROUPS, fam_label, traffic=conv_pmc_traffic())
+        family["isolated"] = {k: v for k, v in mfma_entry(MFMA_GROUPS, fam_label, iso=True).items()
+                              if k in ("achieved", "frac", "mode", "bound_frac", "ms_per_step", "launches_per_step")}
+        family["profile"] = profile_roofline()
         kernels_ = [mfma_entry(("conv1x1",), "conv1x1_glds_kernel fwd+dgrad"), mfma_entry(("conv3x3",), "conv_igemm_kernel<3> fwd+dgrad"),
                     mfma_entry(("conv1x1_wgrad",), "conv_wgrad1_glds_kernel"), mfma_entry(("conv3x3_wgrad",), "conv_wgrad_kernel<3>"),
                     mfma_entry(("wgrad_reduce",), "multi_wgrad_reduce_kernel (split partial sums of all conv / linear weight gradients)"),

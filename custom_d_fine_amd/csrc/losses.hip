@@ -407,9 +407,11 @@ static int head_losses_impl(
     void *grad_logits, float *grad_l1, float *grad_giou, void *grad_corners_fgl,
     void *grad_corners_ddf, float *iou_cls, float *iou_box, int *map_cls, int *map_box, float *wrow,
     float *out, int dtype, int B, int Q, int C, const float *dev_scales, const int *dev_m_box, void *stream) {
-    if (!logits || !boxes || !out || !tgt_boxes || !tgt_labels || !grad_logits || !grad_l1 || !grad_giou ||
+    if (!logits || !boxes || !out || !grad_logits || !grad_l1 || !grad_giou ||
         !map_cls || !map_box || B < 1 || Q < 1 || C < 1)
         return DFINE_E_BADARG;
+    // a batch without targets has empty (null) target tensors and empty plans: every query is background
+    if ((!tgt_boxes || !tgt_labels) && (M_cls > 0 || M_box > 0)) return DFINE_E_BADARG;
     if (dtype != DFINE_F32 && dtype != DFINE_BF16) return DFINE_E_BADARG;
     if (corners && (reg_max != 32 || !ref || !wtable || !grad_corners_fgl)) return DFINE_E_BADARG;
     if ((M_cls > 0 && (!cls_plan || !iou_cls)) || (M_box > 0 && (!box_plan || !iou_box))) return DFINE_E_BADARG;

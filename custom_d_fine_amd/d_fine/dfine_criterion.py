@@ -623,11 +623,16 @@ class DFINECriterion(nn.Module):
                    "s_l1": wd["loss_bbox"] / n_box if want_box else 0.0,
                    "s_giou": wd["loss_giou"] / n_box if want_box else 0.0,
                    "s_fgl": wd["loss_fgl"] / n_box, "c_pos": c_pos, "c_neg": c_neg}
-            vec = kernels.head_losses(
-                head["pred_logits"], head["pred_boxes"], corners,
-                head["ref_points"].detach() if corners is not None else None, teacher,
-                head.get("teacher_logits") if teacher is not None else None, cls_plan.packed,
-                box_plan.packed, labels, tboxes, cfg)
+            if q == 0:
+                # denoising heads of a batch without targets ([B, 0, C]): the reference's terms are means / sums over nothing,
+                # NaN -> 0 by its nan_to_num (dfine_criterion.py:776) - the keys exist, the values are zero
+                vec = torch.zeros(5, device=dev, dtype=torch.float32)
+            else:
+                vec = kernels.head_losses(
+                    head["pred_logits"], head["pred_boxes"], corners,
+                    head["ref_points"].detach() if corners is not None else None, teacher,
+                    head.get("teacher_logits") if teacher is not None else None, cls_plan.packed,
+                    box_plan.packed, labels, tboxes, cfg)
             keys = []
             if want_vfl:
                 keys.append(("loss_vfl", 0))
@@ -639,7 +644,7 @@ class DFINECriterion(nn.Module):
                     keys.append(("loss_ddf", 4))
             vecs.append(vec)
             names.append([(k + suffix, j) for k, j in keys])
-            if want_masks and head.get("pred_masks") is not None:
+            if want_masks and head.get("pred_masks") is not None and q > 0:
                 # the matched mask planes are read in place in the model's dtype (no fp32 copy of [B, Q, H/4, W/4] per head)
                 for k, v in self.loss_masks(head, targets, cls_idx, n_cls).items():
                     if k in wd:
@@ -820,6 +825,9 @@ class DFINECriterion(nn.Module):
         from .matcher import Matching
         pos, groups = dn_meta["dn_positive_idx"], dn_meta["dn_num_group"]
         counts = np.asarray([len(t["labels"]) for t in targets], dtype=np.int64)
+        if pos is None:                 # a batch without targets: the reference's meta carries None (arch/utils.py:371-374)
+            assert int(counts.sum()) == 0
+            pos = []
         for i, n in enumerate(counts):
             assert n == 0 or len(pos[i]) == n * groups
         flat = dn_meta.get("dn_positive_flat")

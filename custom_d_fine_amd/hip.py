@@ -181,6 +181,9 @@ _PURE = _PureQueries()
 _TIMED = {}          # name -> list of (start_event, end_event, work, bound_seconds)
 MFMA_PEAK_FLOPS, HBM_PEAK_BYTES = 2.5e15, 8.0e12       # MI355X_MICROARCH.md: dense bf16 MFMA, HBM3E
 _TIMING_ON = False   # bench.py switches this per step (`timing_active`) to sample a subset of the timed steps
+_TIMING_ISOLATED = False   # True: the sampled step runs everything on ONE stream (no weight gradients beside the chain) and its
+                           # records go under "iso:<key>"; False: the step keeps its two streams and side-stream launches are
+                           # bracketed by events on the side stream - the mode the un-instrumented steps run in
 
 
 def enable_timing(names=None):
@@ -191,15 +194,16 @@ def enable_timing(names=None):
     _TIMING_ON = True
 
 
-def timing_active(flag):
-    global _TIMING_ON
+def timing_active(flag, isolated=False):
+    global _TIMING_ON, _TIMING_ISOLATED
     _TIMING_ON = bool(flag) and "*" in _TIMED
+    _TIMING_ISOLATED = bool(isolated) and _TIMING_ON
 
 
 def disable_timing():
-    global _TIMING_ON
+    global _TIMING_ON, _TIMING_ISOLATED
     _TIMED.clear()
-    _TIMING_ON = False
+    _TIMING_ON = _TIMING_ISOLATED = False
 
 
 def timing_summary():
@@ -217,27 +221,29 @@ def timing_summary():
 
 class _timed:
     """`with _timed(key, work):` - no-op unless bench.py enabled timing for `key` and the current step is sampled."""
-    __slots__ = ("ev", "a", "work", "bound")
+    __slots__ = ("ev", "a", "work", "bound", "stream")
 
-    def __init__(self, name, work=0.0, io=0.0):
-        """work: algorithmic FLOPs (bytes for the HBM-bound keys); io: compulsory HBM bytes of an MFMA-keyed launch."""
+    def __init__(self, name, work=0.0, io=0.0, stream=None):
+        """work: algorithmic FLOPs (bytes for the HBM-bound keys); io: compulsory HBM bytes of an MFMA-keyed launch;
+        stream: the torch stream the launch goes to when that is not the current one (side-stream weight gradients)."""
         self.ev = None
         if _TIMING_ON:
             want = _TIMED.get("*")
             if want is None or name in want:
-                self.ev = _TIMED.setdefault(name, [])
+                self.ev = _TIMED.setdefault("iso:" + name if _TIMING_ISOLATED else name, [])
                 self.work = work
                 self.bound = max(work / MFMA_PEAK_FLOPS, io / HBM_PEAK_BYTES) if io else 0.0
+                self.stream = stream
 
     def __enter__(self):
         if self.ev is not None:
             self.a = torch.cuda.Event(enable_timing=True)
-            self.a.record()
+            self.a.record(self.stream) if self.stream is not None else self.a.record()
 
     def __exit__(self, *exc):
         if self.ev is not None:
             b = torch.cuda.Event(enable_timing=True)
-            b.record()
+            b.record(self.stream) if self.stream is not None else b.record()
             self.ev.append((self.a, b, self.work, self.bound))
 
 
@@ -902,8 +908,9 @@ def conv1x1_seg_wgrad(x_parts, dy, partials=False):
     xp, xc, xb = _seg_arrays(x_parts)
     if partials and _side_ok():
         st = _side_fork(dy.device)
-        _check(_lib.dfine_conv1x1_seg_wgrad_bf16(xp, xc, xb, len(x_parts), _ptr(dy), None, _ptr(ws), B, cin, cout, H, W,
-                                                 st.cuda_stream), "dfine_conv1x1_seg_wgrad_bf16")
+        with _timed("conv1x1_wgrad", 2.0 * B * H * W * cin * cout, io=2.0 * B * H * W * (cin + cout) + 4.0 * cin * cout, stream=st.stream):
+            _check(_lib.dfine_conv1x1_seg_wgrad_bf16(xp, xc, xb, len(x_parts), _ptr(dy), None, _ptr(ws), B, cin, cout, H, W,
+                                                     st.cuda_stream), "dfine_conv1x1_seg_wgrad_bf16")
         _SIDE_LIVE.append((x_parts, dy, ws))
         return ws, (int(_PURE.dfine_conv_wgrad_splits(B, cin, cout, H, W, 1)), cout, cin, 1, _p16(cout), _p16(cin))
     with _timed("conv1x1_wgrad", 2.0 * B * H * W * cin * cout, io=2.0 * B * H * W * (cin + cout) + 4.0 * cin * cout):
@@ -938,7 +945,7 @@ CAPTURE_DUAL = None       # set by dl.engine.GraphedSegment while it captures a 
 
 
 def _side_ok():
-    return WGRAD_STREAM and not _TIMING_ON and (CAPTURE_SIDE or CAPTURE_DUAL is not None or not torch.cuda.is_current_stream_capturing())
+    return WGRAD_STREAM and not _TIMING_ISOLATED and (CAPTURE_SIDE or CAPTURE_DUAL is not None or not torch.cuda.is_current_stream_capturing())
 
 
 def side_stream_ok():
@@ -1050,7 +1057,9 @@ def conv_wgrad_bf16(x, dy, ks, partials=False):
     if partials and _side_ok():
         if st is None:
             st = _side_fork(x.device)
-        _check(_lib.dfine_conv_wgrad_bf16(_ptr(x), _ptr(dy), None, _ptr(ws), B, cin, cout, H, W, ks, st.cuda_stream), "dfine_conv_wgrad_bf16")
+        with _timed(f"conv{ks}x{ks}_wgrad", 2.0 * B * H * W * cin * cout * ks * ks,
+                    io=2.0 * B * H * W * (cin + cout) + 4.0 * cin * cout * ks * ks, stream=st.stream):
+            _check(_lib.dfine_conv_wgrad_bf16(_ptr(x), _ptr(dy), None, _ptr(ws), B, cin, cout, H, W, ks, st.cuda_stream), "dfine_conv_wgrad_bf16")
         _SIDE_LIVE.append((x, dy, ws))
         return ws, (int(_PURE.dfine_conv_wgrad_splits(B, cin, cout, H, W, ks)), cout, cin, ks * ks, _p16(cout), _p16(cin))
     with _timed(f"conv{ks}x{ks}_wgrad", 2.0 * B * H * W * cin * cout * ks * ks, io=2.0 * B * H * W * (cin + cout) + 4.0 * cin * cout * ks * ks):
@@ -1070,7 +1079,8 @@ def multi_wgrad_reduce(table, n_entries, max_blocks, io=0.0, side=False):
     side: on the side stream, behind the weight-gradient launches already queued there."""
     if side and _side_ok():
         st = _side_fork(table.device)             # (forked after the table's upload was enqueued on the current stream)
-        _check(_lib.dfine_multi_wgrad_reduce(_ptr(table), n_entries, int(max_blocks), st.cuda_stream), "dfine_multi_wgrad_reduce")
+        with _timed("wgrad_reduce", 0.0, io=io, stream=st.stream):
+            _check(_lib.dfine_multi_wgrad_reduce(_ptr(table), n_entries, int(max_blocks), st.cuda_stream), "dfine_multi_wgrad_reduce")
         _SIDE_LIVE.append((table,))
         return
     with _timed("wgrad_reduce", 0.0, io=io):
@@ -1323,7 +1333,8 @@ def _flush_conv_group(side=False):
     dev_table = upload(table, pend[0][0].device)
     if side:
         st = _side_fork(pend[0][0].device)         # (forked after the table's copy was enqueued)
-        _check(_lib.dfine_conv_wgrad1_group(_ptr(dev_table), len(pend), blocks, st.cuda_stream), "dfine_conv_wgrad1_group")
+        with _timed("conv1x1_wgrad", flops, io=io, stream=st.stream):
+            _check(_lib.dfine_conv_wgrad1_group(_ptr(dev_table), len(pend), blocks, st.cuda_stream), "dfine_conv_wgrad1_group")
         _SIDE_LIVE.append((pend, dev_table))
         return
     with _timed("conv1x1_wgrad", flops, io=io):
@@ -1348,7 +1359,8 @@ def _flush_linear_group(side=False):
     dev_table = upload(table, pend[0][0].device)
     if side:
         st = _side_fork(pend[0][0].device)
-        _check(_lib.dfine_linear_wgrad_group(_ptr(dev_table), len(pend), blocks, st.cuda_stream), "dfine_linear_wgrad_group")
+        with _timed("linear_wgrad", flops, io=io, stream=st.stream):
+            _check(_lib.dfine_linear_wgrad_group(_ptr(dev_table), len(pend), blocks, st.cuda_stream), "dfine_linear_wgrad_group")
         _SIDE_LIVE.append((pend, dev_table))
         return
     with _timed("linear_wgrad", flops, io=io):
@@ -1456,8 +1468,9 @@ def stem_wgrad(x, dy, ks, stride, pad, side=False):
         ws = _STEM_WS[key] = torch.empty(need, device=x.device, dtype=torch.float32)
     dw = torch.empty(cout, cin, ks, ks, device=x.device, dtype=torch.float32)
     if side:
-        _check(_lib.dfine_stem_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ho, wo, ks, stride,
-                                          pad, st.cuda_stream), "dfine_stem_wgrad_bf16")
+        with _timed("stem_wgrad", 2.0 * B * ho * wo * cin * cout * ks * ks, io=2.0 * B * (H * W * cin + ho * wo * cout), stream=st.stream):
+            _check(_lib.dfine_stem_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ho, wo, ks, stride,
+                                              pad, st.cuda_stream), "dfine_stem_wgrad_bf16")
         _SIDE_LIVE.append((x, dy))
         return dw
     with _timed("stem_wgrad", 2.0 * B * ho * wo * cin * cout * ks * ks, io=2.0 * B * (H * W * cin + ho * wo * cout)):
@@ -1502,8 +1515,9 @@ def stem_wgrad2(xa, xb, dy, ks, stride, pad, side=False):
         ws = _STEM_WS[key] = torch.empty(need, device=xa.device, dtype=torch.float32)
     dw = torch.empty(cout, cin, ks, ks, device=xa.device, dtype=torch.float32)
     if side:
-        _check(_lib.dfine_stem_wgrad2_bf16(_ptr(xa), _ptr(xb), ca, _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ho, wo, ks,
-                                           stride, pad, st.cuda_stream), "dfine_stem_wgrad2_bf16")
+        with _timed("stem_wgrad", 2.0 * B * ho * wo * cin * cout * ks * ks, io=2.0 * B * (H * W * cin + ho * wo * cout), stream=st.stream):
+            _check(_lib.dfine_stem_wgrad2_bf16(_ptr(xa), _ptr(xb), ca, _ptr(dy), _ptr(dw), _ptr(ws), B, cin, cout, H, W, ho, wo, ks,
+                                               stride, pad, st.cuda_stream), "dfine_stem_wgrad2_bf16")
         _SIDE_LIVE.append((xa, xb, dy))
         return dw
     with _timed("stem_wgrad", 2.0 * B * ho * wo * cin * cout * ks * ks, io=2.0 * B * (H * W * cin + ho * wo * cout)):
