@@ -11,12 +11,18 @@ Rank 0 prints ONE JSON line (contract in the task statement).  `value` = images 
 steps (barrier + device synchronize on both sides, max over ranks); `median_ms_per_step` = median of the K per-step
 durations (HIP events around every step).  Extra objects:
   roofline          the dominant kernel FAMILY by device time: the dense-convolution implicit GEMMs of backbone + encoder
-                    (forward, data gradient, weight gradient; MFMA roof).  achieved = algorithmic FLOPs of the timed
-                    launches / their summed duration, both taken live with HIP events on the launch stream inside the
-                    timed region (every `--sample-every`-th step - 1 of the default 50 - is instrumented, hip.py `_timed`: ~1 400 events
-                    cost such a step ~15 ms, so sampling keeps `value` within ~1 % of the un-instrumented rate).
+                    (forward, data gradient, weight gradient, stem; MFMA roof).  achieved = algorithmic FLOPs of the family's
+                    launches (2 B HW Cin Cout KS^2 each, counted by hip.py `_timed` in the instrumented eager step) / the
+                    family's kernel time per step IN THE TIMED MODE - graph replay of backbone + encoder with the weight
+                    gradients on a second stream -, taken from the device timestamps of every kernel of `--trace-steps` more
+                    steps run right after the timed region under torch.profiler's in-process tracer (HIP events cannot
+                    bracket kernels launched from a graph replay).  Sub-objects: `events` = the same sum from HIP events
+                    around every launch of ONE eager step inside the timed region (two streams; `--sample-every`), `isolated`
+                    = one eager step with everything on one stream (no neighbour kernels), `profile` = the figure
+                    recomputed from the committed rocprofv3 --kernel-trace --stats summary of this command
+                    (tools/roofline_from_stats.py; same kernel-name patterns, KERNEL_GROUPS).
   roofline_kernels  the same figures per kernel group (1x1 / 3x3 forward+dgrad, weight gradients, stem, token-stream
-                    linear weight gradients) and the two deformable-attention kernels against the HBM roof
+                    linears / attention) and the two deformable-attention kernels against the HBM roof
                     (algorithmic bytes of SURVEY.md 8(d); `traffic` = PMC HBM bytes from profiles/).
   cpu_baseline      the same train step through the CPU oracle backend ("port") on the host cores, D-FINE-m 640x640 at
                     bs=2, bounded to a few steps.
@@ -40,6 +46,54 @@ LRS = {"n": (8e-4, 4e-4), "s": (2.5e-4, 6e-5), "m": (1.5e-4, 2e-5), "l": (1.6e-4
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 MFMA_GROUPS = ("conv1x1", "conv3x3", "conv1x1_wgrad", "conv3x3_wgrad", "wgrad_reduce", "stem_conv", "stem_wgrad", "miopen_conv")
+
+
+# kernel-name patterns of the groups the line reports (shared with tools/roofline_from_stats.py, which applies them to a
+# rocprofv3 --kernel-trace --stats summary of this command)
+KERNEL_GROUPS = (
+    ("conv1x1", r"dfine::conv1x1_(glds|tr|ring)_kernel"),
+    ("conv3x3", r"dfine::(conv_igemm_kernel<3|conv3x3_ws_kernel)"),
+    ("conv1x1_wgrad", r"dfine::(conv_wgrad1_glds_kernel|conv_wgrad1_group_kernel|conv_wgrad_kernel<1>)"),
+    ("conv3x3_wgrad", r"dfine::(conv_wgrad_kernel<3>|conv_wgrad3_)"),
+    ("stem", r"dfine::stem_(conv|mfma|dgrad|wgrad)"),
+    ("wgrad_reduce", r"dfine::(multi_wgrad_reduce_kernel|conv_wgrad_reduce_kernel)"),
+    ("linear_wgrad", r"dfine::linear_wgrad"),
+    ("linear+attention", r"dfine::(linear_(act|ring)_kernel|attn_)"),
+    ("msda_fwd", r"dfine::msda_fwd"),
+    ("msda_bwd", r"dfine::msda_bwd"),
+    ("batchnorm", r"dfine::bn2?_"),
+    ("depthwise", r"dfine::dwconv_"),
+    ("aten", r"at::native::"),
+)
+FAMILY_GROUPS = ("conv1x1", "conv3x3", "conv1x1_wgrad", "conv3x3_wgrad", "stem", "wgrad_reduce")
+# event keys (hip.py `_timed`) -> traced kernel group
+EVENT_TO_GROUP = {"conv1x1": "conv1x1", "conv3x3": "conv3x3", "conv1x1_wgrad": "conv1x1_wgrad", "conv3x3_wgrad": "conv3x3_wgrad",
+                  "wgrad_reduce": "wgrad_reduce", "stem_conv": "stem", "stem_wgrad": "stem", "linear_wgrad": "linear_wgrad",
+                  "linear": "linear+attention", "attention": "linear+attention", "msda_fwd": "msda_fwd", "msda_bwd": "msda_bwd"}
+
+
+def traced_groups(step, images, targets, n_steps=3):
+    """Kernel time per group and step in the TIMED mode (graph replay of backbone + encoder, weight gradients on the second
+    stream): device timestamps of every kernel of `n_steps` more steps, collected in-process through torch.profiler (roctracer
+    activity records - kernels launched from graph replays are traced like any other; HIP events cannot bracket them).
+    -> {group: (ms per step, launches per step)} + {"*": total kernel ms per step}, or None when the tracer is unavailable."""
+    import re
+    try:
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+            for _ in range(n_steps):
+                step(images, targets)
+            torch.cuda.synchronize()
+        rows = [(k.key, k.device_time_total / 1e3, k.count) for k in prof.key_averages() if k.device_time_total > 0]
+    except Exception as e:                                   # noqa: BLE001 - the line is still valid without this object
+        print(f"torch.profiler trace failed: {e!r}", file=sys.stderr)
+        return None
+    out = {}
+    for name, pat in KERNEL_GROUPS:
+        rx = re.compile(pat)
+        sel = [r for r in rows if rx.search(r[0])]
+        out[name] = (sum(r[1] for r in sel) / n_steps, sum(r[2] for r in sel) / n_steps)
+    out["*"] = (sum(r[1] for r in rows) / n_steps, sum(r[2] for r in rows) / n_steps)
+    return out
 
 
 def build_step(model_name, img, device, amp_dtype, num_classes=80, channels_last=False, mask=False):
@@ -188,6 +242,9 @@ def main():
                     help="instrument every n-th timed step with HIP events around the kernel launches (0 = none); an instrumented "
                          "step is ~15 ms slower, so the default samples one step of the 50")
     ap.add_argument("--channels-last", type=int, default=0)
+    ap.add_argument("--trace-steps", type=int, default=3,
+                    help="steps run AFTER the timed region under torch.profiler's kernel tracer (0 = none): per-kernel device time in "
+                         "the timed (graph-replay, two-stream) mode, the source of `roofline.achieved`")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -254,6 +311,15 @@ def main():
         step(images, targets)
         hip.timing_active(False)
         torch.cuda.synchronize()
+    traced = None
+    if sampled_steps and args.trace_steps > 0:
+        # ... and a few more in the timed mode under the in-process kernel tracer (every rank runs the steps, rank 0 traces)
+        if rank == 0:
+            traced = traced_groups(step, images, targets, args.trace_steps)
+        else:
+            for _ in range(args.trace_steps):
+                step(images, targets)
+        torch.cuda.synchronize()
     if rank == 0:
         if os.environ.get("DFINE_BENCH_DUMP_STEPS") == "1":
             print("gc collections (generation, ms):", _GC_LOG, file=sys.stderr)
@@ -274,49 +340,74 @@ def main():
         lq = 300 + dn
         sampled = len(sampled_steps)
 
-        def mfma_entry(keys, label, traffic=None, iso=False):
-            if iso:
-                keys = tuple("iso:" + k for k in keys)
-            n = sum(timing[k][0] for k in keys if k in timing)
-            ms = sum(timing[k][2] for k in keys if k in timing)
-            fl = sum(timing[k][3] for k in keys if k in timing)
-            bound_ms = sum(timing[k][4] for k in keys if k in timing)
-            tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            sampled = 1 if iso else len(sampled_steps)
-            return {"kernel": label, "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
-                    "frac": round(tf / MFMA_BF16_PEAK_TFS, 4), "traffic": traffic,
-                    "mode": "isolated: one eager step after the timed region, every launch on one stream" if iso else
-                            "concurrent: eager step(s) inside the timed region on the two streams of the timed mode (weight gradients "
-                            "beside the data-gradient chain), HIP events on the stream each launch goes to",
-                    # per-launch roofline: sum over the launches of max(FLOPs / 2.5 PFLOP/s, compulsory bytes / 8 TB/s) over
-                    # the measured time - most layers of this network are HBM-bound (a 128 -> 128 1x1 layer has 64 FLOP / B)
-                    "bound_ms_per_step": round(bound_ms / max(sampled, 1), 3),
-                    "bound_frac": round(bound_ms / ms, 4) if ms > 0 else 0.0,
-                    "launches_per_step": round(n / max(sampled, 1), 1), "ms_per_step": round(ms / max(sampled, 1), 3),
-                    "algorithmic_tflop_per_step": round(fl / max(sampled, 1) / 1e12, 3)}
+        MODES = {"traced": "timed mode: graph replay of backbone + encoder, weight gradients on the second stream; device timestamps of "
+                           f"every kernel of {args.trace_steps} steps run right after the timed region, collected in-process through "
+                           "torch.profiler (roctracer)",
+                 "events": "eager step inside the timed region on the same two streams, HIP events on the stream each launch goes to",
+                 "isolated": "one eager step after the timed region with every launch on ONE stream (no neighbour kernel), HIP events"}
+
+        def event_sums(keys, iso):
+            keys = tuple("iso:" + k for k in keys) if iso else keys
+            per = 1 if iso else max(len(sampled_steps), 1)
+            have = [timing[k] for k in keys if k in timing]
+            # launches, ms, work (FLOPs or bytes), bound ms - per step
+            return tuple(sum(t[i] for t in have) / per for i in (0, 2, 3, 4))
+
+        def mfma_entry(keys, label, traffic=None):
+            n, ms_ev, fl, bound_ms = event_sums(keys, False)
+            _, ms_iso, _, _ = event_sums(keys, True)
+            groups = sorted({EVENT_TO_GROUP[k] for k in keys if k in EVENT_TO_GROUP})
+            ms_tr = sum(traced[g][0] for g in groups) if traced else 0.0
+            n_tr = sum(traced[g][1] for g in groups) if traced else 0.0
+            ms, mode = (ms_tr, "traced") if ms_tr > 0 else (ms_ev, "events")
+
+            def tf(t_ms):
+                return fl / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
+
+            ent = {"kernel": label, "bound": "mfma", "achieved": round(tf(ms), 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
+                   "frac": round(tf(ms) / MFMA_BF16_PEAK_TFS, 4), "traffic": traffic, "mode": MODES[mode],
+                   # per-launch roofline: sum over the launches of max(FLOPs / 2.5 PFLOP/s, compulsory bytes / 8 TB/s) over
+                   # the measured time - most layers of this network are HBM-bound (a 128 -> 128 1x1 layer has 64 FLOP / B)
+                   "bound_ms_per_step": round(bound_ms, 3), "bound_frac": round(bound_ms / ms, 4) if ms > 0 else 0.0,
+                   "launches_per_step": round(n_tr if mode == "traced" else n, 1), "ms_per_step": round(ms, 3),
+                   "algorithmic_tflop_per_step": round(fl / 1e12, 3),
+                   "events": {"mode": MODES["events"], "ms_per_step": round(ms_ev, 3), "frac": round(tf(ms_ev) / MFMA_BF16_PEAK_TFS, 4),
+                              "launches_per_step": round(n, 1)},
+                   "isolated": {"mode": MODES["isolated"], "ms_per_step": round(ms_iso, 3),
+                                "frac": round(tf(ms_iso) / MFMA_BF16_PEAK_TFS, 4),
+                                "bound_frac": round(bound_ms / ms_iso, 4) if ms_iso > 0 else 0.0}}
+            return ent
 
         def hbm_entry(key, label):
             if key not in timing or timing[key][2] <= 0:
                 return None
-            n, mean_ms, tot_ms, work = timing[key][:4]
-            gbs = work / (tot_ms * 1e-3) / 1e9
+            n, ms_ev, work, _ = event_sums((key,), False)
+            per_launch = work / n
+            g = EVENT_TO_GROUP[key]
+            ms_tr, n_tr = traced[g] if traced else (0.0, 0.0)
+            avg_ev = ms_ev / n
+            avg, mode = (ms_tr / n_tr, "traced") if ms_tr > 0 and n_tr > 0 else (avg_ev, "events")
+            gbs = per_launch / (avg * 1e-3) / 1e9
             return {"kernel": label, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(key, args.batch, lq, args.dtype),
-                    "algorithmic_bytes_per_launch": int(work / n), "launches_per_step": round(n / max(sampled, 1), 1),
-                    "avg_launch_ms": round(mean_ms, 4), "ms_per_step": round(tot_ms / max(sampled, 1), 3)}
+                    "mode": MODES[mode], "algorithmic_bytes_per_launch": int(per_launch),
+                    "launches_per_step": round(n_tr if mode == "traced" else n, 1), "avg_launch_ms": round(avg, 4),
+                    "ms_per_step": round(avg * (n_tr if mode == "traced" else n), 3), "events_avg_launch_ms": round(avg_ev, 4)}
 
         fam_label = ("dense-conv implicit GEMMs of backbone + encoder: conv1x1_glds / conv3x3_ws / conv_igemm<3> (fwd + dgrad), "
                      "conv_wgrad1_glds / conv_wgrad3 + the deferred split reduction, stem_*")
         family = mfma_entry(MFMA_GROUPS, fam_label, traffic=conv_pmc_traffic())
-        family["isolated"] = {k: v for k, v in mfma_entry(MFMA_GROUPS, fam_label, iso=True).items()
-                              if k in ("achieved", "frac", "mode", "bound_frac", "ms_per_step", "launches_per_step")}
         family["profile"] = profile_roofline()
-        kernels_ = [mfma_entry(("conv1x1",), "conv1x1_glds_kernel fwd+dgrad"), mfma_entry(("conv3x3",), "conv_igemm_kernel<3> fwd+dgrad"),
-                    mfma_entry(("conv1x1_wgrad",), "conv_wgrad1_glds_kernel"), mfma_entry(("conv3x3_wgrad",), "conv_wgrad_kernel<3>"),
+        if traced:
+            family["traced_kernel_ms_per_step"] = {g: round(v[0], 3) for g, v in traced.items()}
+        kernels_ = [mfma_entry(("conv1x1",), "conv1x1_glds_kernel fwd+dgrad"),
+                    mfma_entry(("conv3x3",), "conv3x3_ws_kernel / conv_igemm_kernel<3> fwd+dgrad"),
+                    mfma_entry(("conv1x1_wgrad",), "conv_wgrad1_glds_kernel / conv_wgrad1_group_kernel"),
+                    mfma_entry(("conv3x3_wgrad",), "3x3 weight gradient (conv_wgrad_kernel<3> / conv_wgrad3_*)"),
                     mfma_entry(("wgrad_reduce",), "multi_wgrad_reduce_kernel (split partial sums of all conv / linear weight gradients)"),
-                    mfma_entry(("stem_conv", "stem_wgrad"), "stem_conv / stem_dgrad_s2 / stem_wgrad"),
+                    mfma_entry(("stem_conv", "stem_wgrad"), "stem_conv / stem_mfma / stem_dgrad_s2 / stem_wgrad"),
                     mfma_entry(("linear_wgrad",), "linear_wgrad_kernel (token-stream linears)"),
-                    mfma_entry(("linear", "attention"), "linear_act / attention kernels (token streams)"),
+                    mfma_entry(("linear", "attention"), "linear_act / linear_ring / attention kernels (token streams)"),
                     mfma_entry(("miopen_conv",), "MIOpen convolutions (shapes the HIP weight-gradient kernel does not take)"),
                     hbm_entry("msda_fwd", "msda_fwd8_kernel (dfine_msda_fused_fwd)"),
                     hbm_entry("msda_bwd", "msda_bwd_pair_kernel (dfine_msda_fused_bwd_acc, packed-f16 accumulate)")]

@@ -14,23 +14,12 @@ import json
 import re
 import sys
 
-PEAK_TFS = 2500.0
-GROUPS = [
-    ("conv1x1", r"dfine::conv1x1_(glds|tr|ring)_kernel"),
-    ("conv3x3", r"dfine::(conv_igemm_kernel<3|conv3x3_ws_kernel)"),
-    ("conv1x1_wgrad", r"dfine::(conv_wgrad1_glds_kernel|conv_wgrad1_group_kernel|conv_wgrad_kernel<1>)"),
-    ("conv3x3_wgrad", r"dfine::(conv_wgrad_kernel<3>|conv_wgrad3_)"),
-    ("stem", r"dfine::stem_(conv|mfma|dgrad|wgrad)"),
-    ("wgrad_reduce", r"dfine::(multi_wgrad_reduce_kernel|conv_wgrad_reduce_kernel)"),
-]
-OTHER = [
-    ("batchnorm", r"dfine::bn2?_"),
-    ("depthwise", r"dfine::dwconv_"),
-    ("linear+attention", r"dfine::(linear_(act|ring)_kernel|attn_)"),
-    ("linear_wgrad", r"dfine::linear_wgrad"),
-    ("msda", r"dfine::msda_"),
-    ("aten", r"at::native::"),
-]
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import FAMILY_GROUPS, KERNEL_GROUPS, MFMA_BF16_PEAK_TFS as PEAK_TFS  # noqa: E402  (the SAME name patterns the bench line uses)
+
+GROUPS = [(n, p) for n, p in KERNEL_GROUPS if n in FAMILY_GROUPS]
+OTHER = [(n, p) for n, p in KERNEL_GROUPS if n not in FAMILY_GROUPS]
 
 
 def main(stats_csv, bench_json):
