@@ -33,6 +33,10 @@ namespace dfine {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
 
+// csrc/wgrad3.hip: the row-streaming 3x3 weight gradient (W % 8 == 0, W <= 160); 0 splits = shape not taken
+int wgrad3_rows_splits(int B, int Cin, int Cout, int H, int W);
+int wgrad3_rows_launch(const void *x, const void *dy, float *part, int B, int Cin, int Cout, int H, int W, hipStream_t st);
+
 constexpr int kConvThreads = 256;
 constexpr int kMaxPixTiles = 10;     // 160 pixels per strip
 
@@ -1961,6 +1965,10 @@ int64_t dfine_conv_wgrad_ws_floats(int B, int Cin, int Cout, int H, int W, int K
         wgrad1_plan(B, Cin, Cout, H * W, &splits, &cps);
         return (int64_t)splits * ((Cout + 15) / 16 * 16) * ((Cin + 15) / 16 * 16);
     }
+    if (KS == 3) {
+        const int s3 = wgrad3_rows_splits(B, Cin, Cout, H, W);
+        if (s3 > 0) return (int64_t)s3 * ((Cout + 15) / 16 * 16) * ((Cin + 15) / 16 * 16) * 9;
+    }
     int h = H, w = W;
     if (KS == 1) { const int hw = H * W; w = 160; while (w > 8 && (hw % w || w % 8)) --w; h = hw / w; }
     int R, strips, splits, ups;
@@ -1973,6 +1981,17 @@ int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, i
     if (B == 0) return DFINE_OK;
     if (!x || !dy || !ws || Cin < 1 || Cout < 1 || (KS != 1 && KS != 3)) return DFINE_E_BADARG;
     if (wgrad1_v2(KS, H * W)) return launch_wgrad1(one_seg(x, Cin), dy, dw, ws, B, Cin, Cout, H * W, (hipStream_t)stream);
+    if (KS == 3) {
+        const int s3 = wgrad3_rows_splits(B, Cin, Cout, H, W);
+        if (s3 > 0) {
+            if (int e = wgrad3_rows_launch(x, dy, ws, B, Cin, Cout, H, W, (hipStream_t)stream)) return e;
+            if (!dw) return DFINE_OK;                            // partials only
+            const int64_t total = (int64_t)Cout * Cin * 9;
+            hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((int)((total + 63) / 64)), dim3(256), 0, (hipStream_t)stream, ws, dw, s3,
+                               Cout, Cin, 9, (Cout + 15) / 16 * 16, (Cin + 15) / 16 * 16);
+            return check_launch();
+        }
+    }
     int h = H, w = W;
     if (KS == 1) {
         const int hw = H * W;
@@ -2094,6 +2113,10 @@ int dfine_conv_wgrad_splits(int B, int Cin, int Cout, int H, int W, int KS) {
         int splits, cps;
         wgrad1_plan(B, Cin, Cout, H * W, &splits, &cps);
         return splits;
+    }
+    if (KS == 3) {
+        const int s3 = wgrad3_rows_splits(B, Cin, Cout, H, W);
+        if (s3 > 0) return s3;
     }
     int h = H, w = W;
     if (KS == 1) { const int hw = H * W; w = 160; while (w > 8 && (hw % w || w % 8)) --w; h = hw / w; }

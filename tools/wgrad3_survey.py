@@ -46,9 +46,9 @@ for (xs, cout), n in seen.items():
         for _ in range(5):
             orig(x, dy, 3, partials=True)
         torch.cuda.synchronize()
-    evs = [e for e in prof.events() if "conv_wgrad_kernel" in e.name]
+    evs = [e for e in prof.events() if "conv_wgrad_kernel" in e.name or "conv_wgrad3_" in e.name]
     kus = sum(e.device_time for e in evs) / max(1, len(evs))
-    others = sorted({e.name[:50] for e in prof.events() if e.device_time > 0 and "conv_wgrad_kernel" not in e.name})
+    others = sorted({e.name[:50] for e in prof.events() if e.device_time > 0 and "conv_wgrad_kernel" not in e.name and "conv_wgrad3_" not in e.name})
     print(f"   kernel alone {kus:7.1f} us ({len(evs)} launches); other device work: {others}")
     us = kus
     fl = 2.0 * xs[0] * xs[2] * xs[3] * xs[1] * cout * 9
