@@ -70,6 +70,24 @@ class _BackboneEncoder(nn.Module):
         return tuple(self.encoder(self.backbone(x)))
 
 
+class _Backbone(nn.Module):
+    def __init__(self, backbone):
+        super().__init__()
+        self.backbone = backbone
+
+    def forward(self, x):
+        return tuple(self.backbone(x))
+
+
+class _Encoder(nn.Module):
+    def __init__(self, encoder):
+        super().__init__()
+        self.encoder = encoder
+
+    def forward(self, *feats):
+        return tuple(self.encoder(list(feats)))
+
+
 class _DualCapture:
     """Backward capture as a chain of graph PAIRS: pair k = (main_k, side_k); main_k holds what the backward pass launches
     on its own stream (BatchNorm backward -> data gradient -> ...), side_k what it launches on the side stream during the
@@ -136,7 +154,13 @@ class GraphedSegment:
     legacy stream - a crash on this stack (tools/graph_probe6.py).  `torch.cuda.make_graphed_callables` segfaults here even
     for a two-layer MLP (tools/graph_probe2.py)."""
 
-    def __init__(self, module, sample_inputs, amp_dtype=None, fused=None, warmup=1):
+    def __init__(self, module, sample_inputs, amp_dtype=None, fused=None, warmup=1, input_grads=False, clone_inputs=True,
+                 defer_backward=False):
+        """input_grads: the segment is not the first one of the model - its backward also produces the gradients of its
+        (floating-point) inputs, static tensors too (`static_gin`).  clone_inputs=False: the inputs ARE static tensors already (the
+        outputs of the segment in front: no copy per replay).  defer_backward: only the forward is captured here; the caller
+        finishes with `capture_backward(static_gout)` once it can say where the output gradients will be written (the
+        `static_gin` of the segment behind), so that no gradient map is copied between two segments."""
         from .. import hip, kernels
         from ..d_fine.arch import utils as arch_utils
         if fused is None:
@@ -145,7 +169,9 @@ class GraphedSegment:
         self.hip, self.kernels = hip, kernels
         dev = sample_inputs[0].device
         self.device = dev
-        self.static_in = [t.detach().clone() for t in sample_inputs]
+        self.input_grads = input_grads
+        self.static_in = [t.detach().clone() if clone_inputs else t.detach() for t in sample_inputs]
+        self.static_gin = None
         self._keep, self._pinned = [], hip.CaptureArena()
         self.preflush = os.environ.get("DFINE_GRAPH_PREFLUSH", "1") == "1"
         self.side = os.environ.get("DFINE_GRAPH_SIDE", "dual")           # "dual" | "fork" | "0"
@@ -163,6 +189,10 @@ class GraphedSegment:
                 if slot is not None:
                     a._dfine_slot = slot
                 aliases.append(a)
+            if input_grads:                          # leaves made on the capture stream, like the parameter aliases
+                self.static_in = [t.requires_grad_(True) if t.dtype.is_floating_point else t for t in self.static_in]
+        self._gin_of = [i for i, t in enumerate(self.static_in) if input_grads and t.dtype.is_floating_point]
+        wrt_inputs = [self.static_in[i] for i in self._gin_of]
         alias_map = {n: a for (n, _), a in zip(named, aliases)}
         self._aliases = aliases
         self.param_index = [getattr(p, "_dfine_slot", (None, None))[1] for _, p in named]
@@ -210,8 +240,8 @@ class GraphedSegment:
             with torch.cuda.stream(cap_stream):
                 for _ in range(max(warmup, 1)):
                     outs = run()
-                    grads = torch.autograd.grad(outs, aliases, [torch.ones_like(o) for o in outs], allow_unused=True)
-                    deliver(grads)
+                    grads = torch.autograd.grad(outs, aliases + wrt_inputs, [torch.ones_like(o) for o in outs], allow_unused=True)
+                    deliver(grads[:len(aliases)])
                     del outs, grads
             cap_stream.synchronize()
             fused.flat_grad.copy_(snap_grad)
@@ -237,42 +267,76 @@ class GraphedSegment:
             self._bn_counters = [(k, v[0]) for k, v in kernels._BN_PENDING.items() if snap_bn.get(k, (None, 0))[1] != v[1]]
             kernels._BN_PENDING.clear()
             kernels._BN_PENDING.update(snap_bn)
-            self.static_gout = [torch.zeros_like(o) for o in self.static_out]
-            if self.side == "dual":
-                # the backward pass proper as a chain of (main, side) graph pairs, then the delivery of the gradients as one graph
-                dual = _DualCapture(cap_stream, hip.side_stream(dev), self.fwd_graph.pool(),
-                                    os.environ.get("DFINE_GRAPH_CHUNK", "5"))
-                torch.cuda.synchronize(dev)
-                hip.CAPTURE_DUAL = dual
-                try:
-                    with torch.cuda.stream(cap_stream):
-                        dual.begin()
-                        grads = torch.autograd.grad(self.static_out, aliases, self.static_gout, allow_unused=True)
-                        hip.linear_wgrad_flush(side=True)      # what is still registered: grouped launches on the side stream
-                        dual.end()
-                finally:
-                    hip.CAPTURE_DUAL = None
-                self.bwd_pairs = dual.pairs
-                self._keep.append(list(hip._SIDE_LIVE))       # inputs of the side graphs: referenced until every capture is done
-                hip._SIDE_LIVE.clear()
-                with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(), stream=cap_stream, capture_error_mode="relaxed"):
-                    deliver(grads)
-            else:
-                with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(), stream=cap_stream, capture_error_mode="relaxed"):
-                    grads = torch.autograd.grad(self.static_out, aliases, self.static_gout, allow_unused=True)
-                    deliver(grads)
-            self._static_grads = grads
-            fused._uses.clear()
-            # scratch buffers the recorded launches point into live in module-level tables keyed by stream / shape: held here
-            # so that a later, larger request cannot free them under the graph
-            self._keep.append([list(d.values()) for d in (hip._BN_WS, hip._LW_WS, hip._STEM_WS)])
-            self._keep.append(list(fused._live))
         finally:
             kernels._CAPTURE_POSSIBLE, kernels._CAPTURE_SHADOWS, hip.CAPTURE_SIDE, arch_utils.CAPTURE_KEEP = flags
-            hip.CAPTURE_DUAL = None
             hip._SIDE_GROUP_AT = group_at
             fused._early_at = early_at
             fused.accumulating = was_accumulating
+
+        def capture_backward(static_gout=None):
+            """Second half of the construction: the backward pass as a chain of (main, side) graph pairs + the delivery graph.
+            static_gout: the tensors the output gradients arrive in (default: own zero-filled buffers)."""
+            flags_b = (kernels._CAPTURE_POSSIBLE, kernels._CAPTURE_SHADOWS, hip.CAPTURE_SIDE, arch_utils.CAPTURE_KEEP)
+            group_at_b, early_at_b, was_acc = hip._SIDE_GROUP_AT, fused._early_at, fused.accumulating
+            hip._SIDE_GROUP_AT = int(os.environ.get("DFINE_GRAPH_GROUP_AT", "8"))
+            fused._early_at = int(os.environ.get("DFINE_GRAPH_EARLY_REDUCE", "0")) or (1 << 30)
+            fused.accumulating = True
+            if fused._deferred or hip._CW_PENDING or hip._LW_PENDING:
+                raise RuntimeError("GraphedSegment.capture_backward: weight gradients of another backward are pending")
+            try:
+                kernels._CAPTURE_POSSIBLE, kernels._CAPTURE_SHADOWS = True, True
+                hip.CAPTURE_SIDE = self.side == "fork"
+                arch_utils.CAPTURE_KEEP = self._pinned
+                self.static_gout = list(static_gout) if static_gout is not None else [torch.zeros_like(o) for o in self.static_out]
+                for o, g in zip(self.static_out, self.static_gout):
+                    if g.shape != o.shape or g.dtype != o.dtype or not g.is_contiguous():
+                        raise RuntimeError("static_gout must match the segment's outputs (shape, dtype, contiguous)")
+                torch.cuda.synchronize(dev)
+                if self.side == "dual":
+                    # the backward pass proper as a chain of (main, side) graph pairs, then the delivery of the gradients as one graph
+                    dual = _DualCapture(cap_stream, hip.side_stream(dev), self.fwd_graph.pool(),
+                                        os.environ.get("DFINE_GRAPH_CHUNK", "5"))
+                    torch.cuda.synchronize(dev)
+                    hip.CAPTURE_DUAL = dual
+                    try:
+                        with torch.cuda.stream(cap_stream):
+                            dual.begin()
+                            grads = torch.autograd.grad(self.static_out, aliases + wrt_inputs, self.static_gout, allow_unused=True)
+                            hip.linear_wgrad_flush(side=True)      # what is still registered: grouped launches on the side stream
+                            dual.end()
+                    finally:
+                        hip.CAPTURE_DUAL = None
+                    self.bwd_pairs = dual.pairs
+                    self._keep.append(list(hip._SIDE_LIVE))       # inputs of the side graphs: referenced until every capture is done
+                    hip._SIDE_LIVE.clear()
+                    with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(), stream=cap_stream, capture_error_mode="relaxed"):
+                        deliver(grads[:len(aliases)])
+                else:
+                    with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(), stream=cap_stream, capture_error_mode="relaxed"):
+                        grads = torch.autograd.grad(self.static_out, aliases + wrt_inputs, self.static_gout, allow_unused=True)
+                        deliver(grads[:len(aliases)])
+                self._static_grads = grads
+                if self._gin_of:
+                    gin = [None] * len(self.static_in)
+                    for i, g in zip(self._gin_of, grads[len(aliases):]):
+                        if g is None:
+                            raise RuntimeError("graphed segment: an input that requires a gradient got none")
+                        gin[i] = g.contiguous()
+                    self.static_gin = gin
+                fused._uses.clear()
+                # scratch buffers the recorded launches point into live in module-level tables keyed by stream / shape: held
+                # here so that a later, larger request cannot free them under the graph
+                self._keep.append([list(d.values()) for d in (hip._BN_WS, hip._LW_WS, hip._STEM_WS)])
+                self._keep.append(list(fused._live))
+            finally:
+                kernels._CAPTURE_POSSIBLE, kernels._CAPTURE_SHADOWS, hip.CAPTURE_SIDE, arch_utils.CAPTURE_KEEP = flags_b
+                hip.CAPTURE_DUAL = None
+                hip._SIDE_GROUP_AT, fused._early_at, fused.accumulating = group_at_b, early_at_b, was_acc
+            self.capture_backward = None
+
+        self.capture_backward = capture_backward
+        if not defer_backward:
+            capture_backward()
         self._token = torch.zeros((), device=dev, requires_grad=True)     # makes autograd call _Replay.backward
         seg = self
 
@@ -323,10 +387,12 @@ class GraphedSegment:
                     hip.stream_wait(st.cuda_stream, cur)
                 seg.bwd_graph.replay()
                 f = seg.fused
-                if f.overlap and not f.accumulating:            # bucket bookkeeping of the overlapped all-reduce
-                    for i in seg.param_index:
-                        f.param_ready(i)
-                return (None,) * (1 + len(seg.static_in))
+                if f.overlap and not f.accumulating:            # bucket bookkeeping of the overlapped all-reduce: this segment's
+                    for i in seg.param_index:                   # gradients are in the flat buffer - its buckets' all-reduces start
+                        f.param_ready(i)                        # here, under the backward replay of the segment in front
+                if seg.static_gin is None:
+                    return (None,) * (1 + len(seg.static_in))
+                return (None,) + tuple(None if g is None else g.detach() for g in seg.static_gin)
 
         self._fn = _Replay
 
@@ -339,9 +405,25 @@ class GraphedSegment:
         memory pool for the life of the process."""
         self._fn = None
         self.fwd_graph = self.bwd_graph = self.bwd_pairs = None
-        self.static_in = self.static_out = self.static_gout = self._static_grads = None
+        self.static_in = self.static_out = self.static_gout = self._static_grads = self.static_gin = None
         self._keep = []
         self._aliases = []
+
+
+class _SegmentChain:
+    """Graphed segments applied one after the other (backbone, encoder)."""
+
+    def __init__(self, segments):
+        self.segments = segments
+
+    def __call__(self, *inputs):
+        for seg in self.segments:
+            inputs = seg(*inputs)
+        return inputs
+
+    def release(self):
+        for seg in self.segments:
+            seg.release()
 
 
 class TrainStep:
@@ -409,8 +491,24 @@ class TrainStep:
             # multiscale training draws from 5 input sizes (base, +-32, +-64: reference dataset.py:667-694)
             if len(self._graphs) >= int(os.environ.get("DFINE_GRAPH_SHAPES", "5")):
                 self._graphs.pop(next(iter(self._graphs))).release()
-            be = _BackboneEncoder(model.backbone, model.encoder)
-            seg = self._graphs[key] = GraphedSegment(be, (images,), amp_dtype=self.amp_dtype, fused=self.fused)
+            # (single rank: one segment - the split costs ~0.1 ms per step, 31.52 vs 31.38 ms, and buys nothing without an all-reduce)
+            split = os.environ.get("DFINE_GRAPH_SPLIT")
+            if (split == "1") if split is not None else bool(self.fused.overlap):
+                # TWO segments, encoder | backbone: the encoder's gradients are delivered to the flat buffer (and its buckets'
+                # all-reduces started, data-parallel runs) when ITS backward replay ends, i.e. under the backbone's backward -
+                # one segment delivered 55 of the 78 MB of D-FINE-m only after the whole backward.  The encoder reads the
+                # backbone's static outputs in place and writes their gradients where the backbone's backward graph reads
+                # them: no map is copied between the two.
+                bb = GraphedSegment(_Backbone(model.backbone), (images,), amp_dtype=self.amp_dtype, fused=self.fused,
+                                    defer_backward=True)
+                enc = GraphedSegment(_Encoder(model.encoder), tuple(bb.static_out), amp_dtype=self.amp_dtype, fused=self.fused,
+                                     input_grads=True, clone_inputs=False)
+                bb.capture_backward(static_gout=enc.static_gin)
+                seg = _SegmentChain([bb, enc])
+            else:
+                seg = GraphedSegment(_BackboneEncoder(model.backbone, model.encoder), (images,), amp_dtype=self.amp_dtype,
+                                     fused=self.fused)
+            self._graphs[key] = seg
         with torch.autocast("cuda", enabled=False):
             feats = seg(images)
         return model.decoder(list(feats), targets)

@@ -171,3 +171,58 @@ def test_graphed_steps_with_gradient_accumulation(cuda):
     rel = _rel(a, b)
     assert torch.isfinite(b).all() and rel < 2e-2, rel
     assert abs(a.norm().item() / b.norm().item() - 1) < 1e-2
+
+
+def test_encoder_buckets_start_before_backbone_backward(cuda):
+    """Graph mode, data-parallel bookkeeping on (overlap=True): backbone and encoder are separate graphed segments, so the encoder's
+    gradient buckets are complete - gathered, their deferred partial sums reduced, their all-reduce started - BEFORE the backbone's
+    backward graphs are replayed (one segment delivered everything at the very end of backward).  Reference: DistributedDataParallel's
+    overlapped bucket all-reduce, /root/reference/src/dl/train.py:171-176."""
+    from custom_d_fine_amd.d_fine import dfine
+    from custom_d_fine_amd.dl.engine import ModelEMA, TrainStep
+    from custom_d_fine_amd.dl.fused_optim import FusedAdamWEMA
+    torch.manual_seed(0)
+    model = dfine.build_model("n", 5, False, str(cuda), img_size=[320, 320]).train()
+    crit = dfine.build_loss("n", 5, 0.0, False)
+    ema = ModelEMA(model, 0.9998)
+    opt = dfine.build_optimizer(model, lr=8e-4, backbone_lr=4e-4, betas=(0.9, 0.999), weight_decay=1.25e-4, base_lr=8e-4)
+    fused = FusedAdamWEMA(model, opt, ema, clip_max_norm=0.1, overlap=True, bucket_mb=2)
+    step = TrainStep(model, crit, opt, amp_dtype=torch.bfloat16, clip_max_norm=0.1, ema=ema, fused_optimizer=fused, hip_graph=True)
+    images, targets = make_batch(2, 320, num_classes=5, seed=3, device=cuda)
+    for _ in range(2):
+        step(images, targets)
+    assert step._graphs
+    chain = next(iter(step._graphs.values()))
+    bb, enc = chain.segments
+    log = []
+
+    class _Spy:
+        def __init__(self, g):
+            self.g = g
+
+        def replay(self):
+            log.append("backbone_backward")
+            self.g.replay()
+    gm, gs = bb.bwd_pairs[0]
+    bb.bwd_pairs[0] = (_Spy(gm), gs)
+    owner = {}
+    for name, p in model.named_parameters():
+        slot = getattr(p, "_dfine_slot", None)
+        if slot is not None:
+            owner[fused._bucket_of[slot[1]]] = owner.get(fused._bucket_of[slot[1]], set()) | {name.split(".")[0]}
+    orig = fused._reduce_bucket
+
+    def spy(b):
+        log.append(("bucket", tuple(sorted(owner[fused._buckets.index(b)]))))
+        orig(b)
+    fused._reduce_bucket = spy
+    loss, _ = step(images, targets)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss)
+    first_bb = log.index("backbone_backward")
+    before = [e[1] for e in log[:first_bb] if e != "backbone_backward"]
+    assert any(o == ("encoder",) for o in before), log          # encoder buckets reduced under the backbone's backward
+    assert any(o == ("decoder",) for o in before), log
+    assert not any("backbone" in o for o in before), log
+    after = [e[1] for e in log[first_bb:] if e != "backbone_backward"]
+    assert any("backbone" in o for o in after), log
