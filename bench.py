@@ -242,11 +242,18 @@ def main():
                     help="instrument every n-th timed step with HIP events around the kernel launches (0 = none); an instrumented "
                          "step is ~15 ms slower, so the default samples one step of the 50")
     ap.add_argument("--channels-last", type=int, default=0)
+    ap.add_argument("--dry", action="store_true",
+                    help="launcher check: spawn the ranks (capped at the visible devices), initialise the RCCL process group, run one "
+                         "all-reduce + barrier, print one JSON line and stop (no model, no timing)")
     ap.add_argument("--trace-steps", type=int, default=3,
                     help="steps run AFTER the timed region under torch.profiler's kernel tracer (0 = none): per-kernel device time in "
                          "the timed (graph-replay, two-stream) mode, the source of `roofline.achieved`")
     args = ap.parse_args()
 
+    if args.dry and "WORLD_SIZE" not in os.environ:
+        args.gpus = max(1, min(args.gpus, torch.cuda.device_count()))
+        sys.argv = [a for a in sys.argv if not a.startswith("--gpus")]          # ("--gpus N" as two tokens: drop the value too)
+        sys.argv = [a for i, a in enumerate(sys.argv) if not (i > 0 and sys.argv[i - 1] == "--gpus")] + ["--gpus", str(args.gpus)]
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _self_spawn(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -263,6 +270,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", init_method="env://", device_id=device)
 
+    if args.dry:
+        t = torch.ones(1, device=device)
+        if world > 1:
+            dist.all_reduce(t)
+            dist.barrier()
+        torch.cuda.synchronize()
+        if rank == 0:
+            print(json.dumps({"dry": True, "n_gpus": world, "all_reduce_of_ones": t.item(), "devices_visible": torch.cuda.device_count(),
+                              "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     from custom_d_fine_amd import hip
     from custom_d_fine_amd.dl.synthetic import make_batch
     torch.manual_seed(42)        # identical initial weights on every rank; the per-rank stream is the DATA (seed 42 + rank)
@@ -274,7 +293,7 @@ def main():
 
     # W untimed warm-up steps (at least two: the second builds the batched weight-pack / bf16-shadow tables)
     for _ in range(max(args.warmup, 2)):
-        step(images, targets)
+        step(images, list(targets))
 
     def fence():
         torch.cuda.synchronize()
@@ -298,7 +317,9 @@ def main():
     marks[0].record()
     for i in range(args.steps):
         hip.timing_active(i in sampled_steps)
-        step(images, targets)
+        # a NEW target list per step, as a data loader hands over: the per-batch caches of matcher / criterion (target masks at
+        # mask resolution, concatenated labels / boxes) are keyed on the list and must be rebuilt every step like in training
+        step(images, list(targets))
         marks[i + 1].record()
     hip.timing_active(False)
     fence()

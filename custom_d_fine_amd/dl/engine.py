@@ -170,6 +170,7 @@ class GraphedSegment:
         dev = sample_inputs[0].device
         self.device = dev
         self.input_grads = input_grads
+        self.done_before = ()        # top-level modules whose backward is over when this segment's starts (set by the caller)
         self.static_in = [t.detach().clone() if clone_inputs else t.detach() for t in sample_inputs]
         self.static_gin = None
         self._keep, self._pinned = [], hip.CaptureArena()
@@ -368,6 +369,8 @@ class GraphedSegment:
                     elif dst.data_ptr() != src.data_ptr():
                         dst.copy_(src)
                 f = seg.fused
+                if seg.done_before:
+                    f.module_backward_done(seg.done_before)     # e.g. the decoder's buckets, whatever parameter got no gradient
                 if seg.preflush and not f.accumulating and hip.side_stream_ok():
                     # what the decoder's backward has registered so far - grouped weight-gradient launches still pending, partial
                     # sums to reduce - goes to the side stream now, under the segment's backward, instead of running serially
@@ -504,10 +507,12 @@ class TrainStep:
                 enc = GraphedSegment(_Encoder(model.encoder), tuple(bb.static_out), amp_dtype=self.amp_dtype, fused=self.fused,
                                      input_grads=True, clone_inputs=False)
                 bb.capture_backward(static_gout=enc.static_gin)
+                enc.done_before, bb.done_before = ("decoder",), ("decoder", "encoder")
                 seg = _SegmentChain([bb, enc])
             else:
                 seg = GraphedSegment(_BackboneEncoder(model.backbone, model.encoder), (images,), amp_dtype=self.amp_dtype,
                                      fused=self.fused)
+                seg.done_before = ("decoder",)
             self._graphs[key] = seg
         with torch.autocast("cuda", enabled=False):
             feats = seg(images)

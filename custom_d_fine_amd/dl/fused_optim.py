@@ -149,16 +149,23 @@ class FusedAdamWEMA:
                 # with the captured backward segment (dl/engine.GraphedSegment) those only arrive when its last graph has run
                 boundary = j + 1 < len(rev) and rev[j + 1][3] != e[3]
                 if hi - e[1] >= cap or boundary:
-                    self._buckets.append({"lo": e[1], "hi": hi, "params": [c[0] for c in cur], "ready": 0, "done": False})
+                    self._buckets.append({"lo": e[1], "hi": hi, "params": [c[0] for c in cur], "ready": 0, "done": False,
+                                          "owner": e[3]})
                     cur, hi = [], e[1]
             if cur:
-                self._buckets.append({"lo": cur[-1][1], "hi": hi, "params": [c[0] for c in cur], "ready": 0, "done": False})
+                self._buckets.append({"lo": cur[-1][1], "hi": hi, "params": [c[0] for c in cur], "ready": 0, "done": False,
+                                      "owner": cur[-1][3]})
         # Collectives pair up across ranks by CALL ORDER, so the all-reduces are issued in one fixed order on every rank - the
         # order backward is expected to complete the buckets in (latest-registered parameters first) - and a bucket whose
         # turn has not come waits, gathered, for its predecessors (DDP's reducer does the same; a rank-local completion order
         # would pair different ranges on different ranks when one rank has a parameter without gradient, e.g. an image
         # batch without targets skips the denoising embedding).
-        self._buckets.sort(key=lambda b: -max(b["params"]))
+        # The order: by top-level module in the order their BACKWARD passes end (decoder, encoder, backbone - the reverse of the
+        # forward; `named_parameters()` lists them in attribute order, which says nothing about execution), inside a module the
+        # latest-registered parameters first.  (Until round 5 the key was the parameter index alone: the encoder's buckets came
+        # first and the decoder's - complete long before - waited behind them.)
+        order = {m: i for i, m in enumerate(getattr(model, "_dfine_backward_order", ("decoder", "encoder", "backbone")))}
+        self._buckets.sort(key=lambda b: (order.get(b["owner"], -1), -max(b["params"])))
         self._next_launch = 0
         for bi, b in enumerate(self._buckets):
             b["gathered"] = False
@@ -266,8 +273,22 @@ class FusedAdamWEMA:
         overlapped all-reduce - what the post-accumulate-grad hook does for parameters that get a gradient tensor."""
         if self.overlap and not self.accumulating:
             b = self._buckets[self._bucket_of[index]]
+            if b["gathered"]:
+                raise RuntimeError("a gradient was registered for a bucket that was already handed to the all-reduce")
             b["ready"] += 1
             if b["ready"] == len(b["params"]):
+                self._reduce_bucket(b)
+
+    def module_backward_done(self, owners):
+        """The backward passes of the top-level modules `owners` are over: their buckets that are still incomplete - a parameter
+        that gets NO gradient in this step (an unused head, the denoising embedding of a batch without targets) never reports -
+        are handed to the all-reduce as they are (missing gradients are zeros in the flat buffer).  Without this, one such
+        parameter keeps its bucket, and every bucket behind it in the fixed launch order, until the end of backward.  Called by
+        the graphed segments (dl/engine.py) at the start of their backward replay: deterministic, the same on every rank."""
+        if not self.overlap or self.accumulating:
+            return
+        for b in self._buckets:
+            if b["owner"] in owners and not b["gathered"]:
                 self._reduce_bucket(b)
 
     def _reduce_blocks(self, splits, elems, _memo={}):
@@ -331,6 +352,9 @@ class FusedAdamWEMA:
             # delivered the gradient through defer_wgrad / straight into the flat buffer: those report through param_ready)
             if self.accumulating or param.grad is None:
                 return
+            if b["gathered"]:
+                raise RuntimeError("a gradient arrived for a bucket that was already handed to the all-reduce "
+                                   "(module_backward_done called too early?)")
             b["ready"] += 1
             if b["ready"] == n:
                 self._reduce_bucket(b)

@@ -194,7 +194,7 @@ def test_encoder_buckets_start_before_backbone_backward(cuda):
     assert step._graphs
     chain = next(iter(step._graphs.values()))
     bb, enc = chain.segments
-    log = []
+    log, state = [], []
 
     class _Spy:
         def __init__(self, g):
@@ -202,27 +202,16 @@ def test_encoder_buckets_start_before_backbone_backward(cuda):
 
         def replay(self):
             log.append("backbone_backward")
+            state.extend((b["owner"], b["done"]) for b in fused._buckets)     # done = its all-reduce has been started
             self.g.replay()
     gm, gs = bb.bwd_pairs[0]
     bb.bwd_pairs[0] = (_Spy(gm), gs)
-    owner = {}
-    for name, p in model.named_parameters():
-        slot = getattr(p, "_dfine_slot", None)
-        if slot is not None:
-            owner[fused._bucket_of[slot[1]]] = owner.get(fused._bucket_of[slot[1]], set()) | {name.split(".")[0]}
-    orig = fused._reduce_bucket
-
-    def spy(b):
-        log.append(("bucket", tuple(sorted(owner[fused._buckets.index(b)]))))
-        orig(b)
-    fused._reduce_bucket = spy
     loss, _ = step(images, targets)
     torch.cuda.synchronize()
     assert torch.isfinite(loss)
-    first_bb = log.index("backbone_backward")
-    before = [e[1] for e in log[:first_bb] if e != "backbone_backward"]
-    assert any(o == ("encoder",) for o in before), log          # encoder buckets reduced under the backbone's backward
-    assert any(o == ("decoder",) for o in before), log
-    assert not any("backbone" in o for o in before), log
-    after = [e[1] for e in log[first_bb:] if e != "backbone_backward"]
-    assert any("backbone" in o for o in after), log
+    assert log == ["backbone_backward"] and state
+    owners = [o for o, _ in state]
+    # launch order = the order the modules' backward passes end in
+    assert owners == sorted(owners, key=("decoder", "encoder", "backbone").index), owners
+    assert all(done for o, done in state if o in ("decoder", "encoder")), state     # ... even with parameters that got no gradient
+    assert not any(done for o, done in state if o == "backbone"), state

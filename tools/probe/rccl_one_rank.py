@@ -53,9 +53,40 @@ step = TrainStep(model, crit, opt, amp_dtype=torch.bfloat16, clip_max_norm=0.1, 
 images, targets = make_batch(4, 320, num_classes=5, seed=42, device=dev)
 before = fused.flat_param.clone()
 losses = []
-for _ in range(4):
+order = []
+for it in range(4):
+    if GRAPH and it == 3 and step._graphs:
+        # last step: where do the all-reduces fall relative to the backbone's backward replay?
+        chain = next(iter(step._graphs.values()))
+        if hasattr(chain, "segments"):
+            bb = chain.segments[0]
+            gm, gs = bb.bwd_pairs[0]
+
+            class _Spy:
+                def replay(self_):
+                    order.append("backbone backward replay starts")
+                    if os.environ.get("RCCL_PROBE_DEBUG") == "1":
+                        names = {id(p): n for n, p in model.named_parameters()}
+                        for bi, b in enumerate(fused._buckets):
+                            own = sorted({names[id(fused._params[i])].split(".")[0] for i in b["params"]})
+                            print(f"  bucket {bi}: {own} params {len(b['params'])} ready {b['ready']} gathered {b['gathered']} done {b['done']} "
+                                  f"MB {(b['hi'] - b['lo']) * 4 / 1e6:.2f}", flush=True)
+                        print("  next_launch", fused._next_launch, flush=True)
+                    gm.replay()
+            bb.bwd_pairs[0] = (_Spy(), gs)
+            _ar2 = dist.all_reduce
+
+            def all_reduce2(t, *a, **k):
+                if t.numel() > 1024:
+                    order.append(f"all_reduce of {t.numel() * 4 / 1e6:.2f} MB")
+                return _ar2(t, *a, **k)
+            dist.all_reduce = all_reduce2
     loss, _ = step(images, targets)
     losses.append(float(loss))
+if order:
+    print("order of the last step:", order)
+    first = order.index("backbone backward replay starts")
+    assert first > 0, "no gradient bucket was all-reduced before the backbone's backward started"
 torch.cuda.synchronize()
 assert all(l == l and abs(l) < 1e6 for l in losses), losses
 assert (fused.flat_param - before).abs().max() > 0
