@@ -154,10 +154,10 @@ def test_graphed_train_steps_track_eager_steps(cuda):
 def test_graphed_steps_with_gradient_accumulation(cuda):
     """Two micro-steps per optimizer step: the backward graph ADDS into the flat gradient buffer."""
     out = {}
-    for graph in (False, True):
+    for graph in (False, "again", True):
         torch.manual_seed(0)
         step = bench.build_step("n", 320, cuda, torch.bfloat16)
-        step.hip_graph, step.accum_steps = graph, 2
+        step.hip_graph, step.accum_steps = graph is True, 2
         batches = [make_batch(2, 320, seed=s, device=cuda) for s in (1, 2)]
         seen = []
         _spy_grads(step, seen)
@@ -168,8 +168,8 @@ def test_graphed_steps_with_gradient_accumulation(cuda):
         out[graph] = seen
     assert len(out[True]) == len(out[False]) == 2
     a, b = out[False][0], out[True][0]
-    rel = _rel(a, b)
-    assert torch.isfinite(b).all() and rel < 2e-2, rel
+    rel, noise = _rel(a, b), _rel(a, out["again"][0])        # (two EAGER runs differ by the decoder's atomics: usually < 1 %, seen > 2 %)
+    assert torch.isfinite(b).all() and rel < max(2e-2, 3 * noise), (rel, noise)
     assert abs(a.norm().item() / b.norm().item() - 1) < 1e-2
 
 
