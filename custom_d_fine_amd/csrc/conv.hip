@@ -821,10 +821,12 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
     // several parts: a per-workgroup table in LDS, one 8-byte base address per group of 8 input channels (part sizes are
     // multiples of 8), built once; the issue path then costs one ds_read_b64 per piece.  (Searching the part list there - per
     // lane or on the scalar unit, from kernel arguments or registers - cost 2x of the whole kernel.)
-    const uint16_t **xtab = reinterpret_cast<const uint16_t **>(lds + kG2Ring * SB);
+    // (the tables sit behind the ring AND behind the epilogue's staging tiles, which are larger than a 2-slot ring for NTN = 4)
+    constexpr int kTabOff = kG2Ring * SB > 8 * 16 * NTN * (16 * PXW + 8) * 2 ? kG2Ring * SB : 8 * 16 * NTN * (16 * PXW + 8) * 2;
+    const uint16_t **xtab = reinterpret_cast<const uint16_t **>(lds + kTabOff);
     // ... and one per output row of this workgroup for the store loop (a per-lane search of the part list there was ~100
     // vector instructions per 16-byte store, ~800 per wave and tile after the last MFMA)
-    uint16_t **ytab = reinterpret_cast<uint16_t **>(lds + kG2Ring * SB + 4096);
+    uint16_t **ytab = reinterpret_cast<uint16_t **>(lds + kTabOff + 4096);
     if (SEG) {
         for (int gch = tid; gch * 8 < Cin; gch += kG2Threads) xtab[gch] = seg_addr(xs_, b, gch * 8, HW) + p0;
         if (tid < 64 * NTN) ytab[tid] = const_cast<uint16_t *>(seg_addr(ys_, b, min(n0 + tid, Cout - 1), HW));
@@ -856,9 +858,50 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
 #pragma unroll
         for (int j = 0; j < PXW; ++j) acc[t][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
+    // NTN = 4 (256 output channels x 256 pixels per workgroup: 128 FLOP per loaded byte instead of 85): the stage is 64 KiB, so
+    // the ring has TWO slots and is streamed - stage s + 1 is issued behind the barrier of stage s into the slot stage s - 1 has
+    // just released - and the fragments are read one 32-channel slab at a time (128 accumulator + 48 fragment registers).
+    // Measured (tools/conv1x1_bench.py, forward): 512 -> 512 @80x80 202 -> 158 us (679 TFLOP/s), @40x40 53.5 -> 42.2,
+    // 768 -> 256 @80x80 144 -> 124, 384 -> 768 @40x40 60 -> 52.6; 26 layer shapes 1364 -> 1259 us.  One stage (64 KiB per CU) in
+    // flight is what LDS allows here and it does not cover the load latency (a stage takes ~7 600 cycles for 2 048 cycles of
+    // MFMA work); the early / late issue split of csrc/wgrad3.hip needs a third slot (late waves would wait for loads they
+    // have just issued: measured 172 us) and the split of the stage into two 32-channel halves with four slots is the open step.
+    constexpr bool kStream2 = NTN == 4;
+
     issue(0);
-    if (nstage > 1) issue(1);
+    if (!kStream2 && nstage > 1) issue(1);
     for (int s = 0; s < nstage; ++s) {
+        if (kStream2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const unsigned char *xs2 = lds + (s & 1) * SB, *ws2 = xs2 + XB;
+            if (s + 1 < nstage) issue(s + 1);
+            const int nslab = s * kG2Rows + 32 < KP ? 2 : 1;
+            for (int slab = 0; slab < nslab; ++slab) {
+                bf16x8 a1[NTN], b1[PXW];
+#pragma unroll
+                for (int t = 0; t < NTN; ++t) {
+                    const int row = wn * 16 * NTN + t * 16 + i16;
+                    a1[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(ws2 + row * 128 + (((slab * 4 + g) ^ (row & 7)) << 4)));
+                }
+                const int r = slab * 32 + 4 * g + (i16 >> 2);
+                const unsigned char *xr = xs2 + r * XPITCH + ((i16 & 3) << 3);
+#pragma unroll
+                for (int j = 0; j < PXW; ++j) {
+                    const int seg = ((wp * PXW + j) ^ (r & 7)) << 5;
+                    const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_v4s __attribute__((address_space(3))) *)(xr + seg));
+                    const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_v4s __attribute__((address_space(3))) *)(xr + seg + 16 * XPITCH));
+                    typedef short tr_v8s __attribute__((ext_vector_type(8)));
+                    b1[j] = __builtin_bit_cast(bf16x8, (tr_v8s)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int j = 0; j < PXW; ++j)
+#pragma unroll
+                    for (int t = 0; t < NTN; ++t)
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[t], b1[j], acc[t][j], 0, 0, 0);
+            }
+            continue;
+        }
         if (!(kAbl & 4) || s < 2) {
             if (s + 1 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XPW + NTN) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -993,10 +1036,14 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
         const int ptiles2 = ximg ? B : (HW + tp - 1) / tp;     // (ximg: the kernel wants the image count here)
         const int total2 = ximg ? (int)((gpix + tp - 1) / tp) : B * ptiles2;
         const bool wide2 = px256 || (n128 && ((int64_t)total2 * (NP / 128) >= 256));
-        const int nblk2 = wide2 ? NP / 128 : (NP + 63) / 64;
+        // 256 output channels per workgroup (NTN = 4) where the layer still fills the chip with such tiles
+        static const int n256_env = [] { const char *e = getenv("DFINE_CONV1X1_N256"); return e ? atoi(e) : 1; }();
+        const bool n256 = n256_env && px256 && NP % 256 == 0 && (int64_t)total2 * (NP / 256) >= 200;
+        const int nblk2 = n256 ? NP / 256 : wide2 ? NP / 128 : (NP + 63) / 64;
         dim3 grid2(8 * ((total2 + 7) / 8) * nblk2);
         if (seg && Cin > 4096) return DFINE_E_BADARG;
-        const size_t lds2 = (size_t)(ring2 ? 2 : 3) * (kG2Rows * tp * 2 + 64 * (wide2 ? 2 : 1) * 128) + (seg ? 5120 : 0);
+        const size_t lds2 = n256 ? (size_t)8 * 64 * 136 * 2 + (seg ? 6144 : 0)
+                                 : (size_t)(ring2 ? 2 : 3) * (kG2Rows * tp * 2 + 64 * (wide2 ? 2 : 1) * 128) + (seg ? 5120 : 0);
         static bool attr2 = false;
         if (!attr2) {
             hipError_t e = hipSuccess, r;
@@ -1005,13 +1052,16 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
     if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<N, R, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize, R * (64 * 64 * P + 8192 * N) + 5120)) != hipSuccess) e = r;
             DFINE_G2_ATTR(1, 2, 4) DFINE_G2_ATTR(1, 3, 4) DFINE_G2_ATTR(2, 2, 4) DFINE_G2_ATTR(2, 3, 4) DFINE_G2_ATTR(2, 3, 8)
 #undef DFINE_G2_ATTR
+            if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<4, 2, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 136 * 2)) != hipSuccess) e = r;
+            if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<4, 2, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 136 * 2 + 6144)) != hipSuccess) e = r;
             if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
             attr2 = true;
         }
 #define DFINE_G2(N, R, P)                                                                                                                        \
     { if (seg) hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, true>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum, w_bstride, ximg ? 1 : 0); \
       else hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, false>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum, w_bstride, ximg ? 1 : 0); }
-        if (px256) DFINE_G2(2, 3, 8)
+        if (n256) DFINE_G2(4, 2, 8)
+        else if (px256) DFINE_G2(2, 3, 8)
         else if (wide2) { if (ring2) DFINE_G2(2, 2, 4) else DFINE_G2(2, 3, 4) }
         else { if (ring2) DFINE_G2(1, 2, 4) else DFINE_G2(1, 3, 4) }
 #undef DFINE_G2
