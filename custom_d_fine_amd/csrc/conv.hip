@@ -865,7 +865,11 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
     // 768 -> 256 @80x80 144 -> 124, 384 -> 768 @40x40 60 -> 52.6; 26 layer shapes 1364 -> 1259 us.  One stage (64 KiB per CU) in
     // flight is what LDS allows here and it does not cover the load latency (a stage takes ~7 600 cycles for 2 048 cycles of
     // MFMA work); the early / late issue split of csrc/wgrad3.hip needs a third slot (late waves would wait for loads they
-    // have just issued: measured 172 us) and the split of the stage into two 32-channel halves with four slots is the open step.
+    // have just issued: measured 172 us).  Also measured and dropped: 32-channel HALF stages of 32 KiB in a ring of four slots,
+    // three in flight, with the early / late split (W rows of 64 B, chunk kc of row r at kc ^ ((r >> 2) & 3)): 167.6 us, 26 shapes
+    // 1311 us - more bytes in flight do not help, so the stage time is not exposed load latency: MFMA (2 048 cycles per SIMD and
+    // stage), LDS-DMA issue (~1 900) and fragment reads (~770) run one after the other inside a wave, and the barrier per
+    // stage keeps the two waves of a SIMD in phase.
     constexpr bool kStream2 = NTN == 4;
 
     issue(0);
