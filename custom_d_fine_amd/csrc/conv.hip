@@ -870,7 +870,7 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
     // 1311 us - more bytes in flight do not help, so the stage time is not exposed load latency: MFMA (2 048 cycles per SIMD and
     // stage), LDS-DMA issue (~1 900) and fragment reads (~770) run one after the other inside a wave, and the barrier per
     // stage keeps the two waves of a SIMD in phase.
-    constexpr bool kStream2 = NTN == 4;
+    const bool kStream2 = kG2Ring == 2 && (NTN == 4 || nstage > 2);     // (2-slot ring with more than two stages: streamed)
 
     issue(0);
     if (!kStream2 && nstage > 1) issue(1);
@@ -1024,25 +1024,38 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
     if (conv1x1_glds_ok(Cin, KP, HW)) {
         // The kernel is bound by the ~10 B/clk/CU load path, so the tile is as large as the layer can fill the chip with:
         // 256 pixels x 128 channels (87 FLOP per loaded byte) for deep layers on big maps, 128 x 128 (64) / 128 x 64 otherwise.
-        const bool ring2 = KP <= 2 * kG2Rows;                  // <= 2 stages: both fit a 2-slot ring, half the LDS, 2 workgroups per CU
+        // Three tile regimes (tools/conv1x1_bench.py, 26 layer shapes of D-FINE-m, forward: 1364 us with the round-4 choice ->
+        // 1193-1259 with either new one alone; per layer the better of the two):
+        //  * <= 2 stages (K <= 128): 2-slot ring, both stages issued up front, 2 workgroups per CU (as before);
+        //  * deep K (>= 512) and output channels a multiple of 256 with enough such tiles: 256 channels x 256 pixels (NTN = 4),
+        //    2-slot ring of 64 KiB stages, streamed - 128 FLOP per loaded byte;
+        //  * everything else: 128 (64) channels x 128 pixels with the 2-slot ring STREAMED (64 KiB of LDS: two workgroups = 16
+        //    waves per CU, which cover each other's load -> MFMA -> store phases; the round-4 choice for these layers was one
+        //    256-pixel workgroup per CU on a 3-slot ring: 1280 -> 384 @40x40 86 -> 70 us, 1792 -> 768 @20x20 68 -> 54, 192 -> 384
+        //    @80x80 71 -> 57, 896 -> 384 @40x40 59 -> 49).
+        const bool classic2 = KP <= 2 * kG2Rows;
         const bool n128 = NP % 128 == 0;
         const ChanSegs xs_ = xsegs ? *xsegs : one_seg(x, Cin), ys_ = ysegs ? *ysegs : one_seg(y, Cout);
         const bool seg = xs_.n > 1 || ys_.n > 1;
         // whole tensors with shared weights: pixel tiles over the B * HW pixels of the batch whenever per-image tiles would
         // leave the last one partly empty (20 x 20 planes: 400 pixels = 3.1 tiles of 128; 40 x 40: 6.25 tiles of 256)
         static const int ximg_env = [] { const char *e = getenv("DFINE_CONV1X1_XIMG"); return e ? atoi(e) : 1; }();
+        static const int n256_env = [] { const char *e = getenv("DFINE_CONV1X1_N256"); return e ? atoi(e) : 1; }();
+        static const int small_env = [] { const char *e = getenv("DFINE_CONV1X1_SMALL"); return e ? atoi(e) : 1; }();
         const bool xok = ximg_env && !seg && !w_bstride;
         const int64_t gpix = (int64_t)B * HW;
         const int64_t t256 = xok ? (gpix + 255) / 256 : (int64_t)B * ((HW + 255) / 256);
-        const bool px256 = px256_env && n128 && !ring2 && (xok || HW % 256 == 0 || HW >= 1536) && t256 * (NP / 128) >= 256;
+        const bool px256c = px256_env && n128 && !classic2 && (xok || HW % 256 == 0 || HW >= 1536) && t256 * (NP / 128) >= 256;
+        const int64_t blk256 = t256 * (NP / 256);
+        const bool n256 = n256_env && px256c && NP % 256 == 0 && KP >= 512 && blk256 >= 200 && !(blk256 > 256 && blk256 < 384);
+        const bool small = small_env && !n256 && !classic2;
+        const bool ring2 = classic2 || small;
+        const bool px256 = n256 || (px256c && !small);
         const int tp = px256 ? 256 : kTrPix;
         const bool ximg = xok && HW % tp != 0;
         const int ptiles2 = ximg ? B : (HW + tp - 1) / tp;     // (ximg: the kernel wants the image count here)
         const int total2 = ximg ? (int)((gpix + tp - 1) / tp) : B * ptiles2;
         const bool wide2 = px256 || (n128 && ((int64_t)total2 * (NP / 128) >= 256));
-        // 256 output channels per workgroup (NTN = 4) where the layer still fills the chip with such tiles
-        static const int n256_env = [] { const char *e = getenv("DFINE_CONV1X1_N256"); return e ? atoi(e) : 1; }();
-        const bool n256 = n256_env && px256 && NP % 256 == 0 && (int64_t)total2 * (NP / 256) >= 200;
         const int nblk2 = n256 ? NP / 256 : wide2 ? NP / 128 : (NP + 63) / 64;
         dim3 grid2(8 * ((total2 + 7) / 8) * nblk2);
         if (seg && Cin > 4096) return DFINE_E_BADARG;
