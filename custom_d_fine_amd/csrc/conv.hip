@@ -1481,6 +1481,113 @@ __global__ __launch_bounds__(kW2Threads) void conv_wgrad1_group_kernel(const int
                                  B * cpi, cps, nct, (Cout + 15) / 16 * 16, (Cin + 15) / 16 * 16, npairs, splits, blockIdx.x);
 }
 
+// The same for layers with <= 128 channels on both sides (53 of the 1x1 weight gradients of a D-FINE-m step): 64 x 64 (n, c) tiles.
+// With ONE 128 x 128 tile per layer the only parallelism is the split of the pixels, and every split is a 64 KiB slab of partial
+// sums: 256 workgroups = 16.8 MB written and read again for a 26 MB layer (40 x 40), three 64-pixel stages per workgroup - the
+// grouped launches ran at 57 TFLOP/s, 5 x their HBM time.  Four tiles x 64 splits are the same 256 workgroups with a quarter of
+// the partial sums and four times the pixels per workgroup; the operands are read twice (L2: the four tiles of a split sit on
+// one XCD), a stage is 16 KiB, three workgroups fit a CU.
+__device__ __forceinline__ void conv_wgrad1_t64_body(const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy, float *__restrict__ part,
+                                                     int Cin, int Cout, int HW, int chunks_per_image, int total_chunks,
+                                                     int chunks_per_split, int nct, int NP16, int CP16, int npairs, int nsplits, const int bx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int OPB = 64 * 128, SB = 2 * OPB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int pair, split;
+    if ((nsplits & 7) == 0) {
+        const int xcd = bx & 7, slot = bx >> 3;
+        pair = slot % npairs; split = (slot / npairs) * 8 + xcd;
+    } else {
+        pair = bx % npairs; split = bx / npairs;
+    }
+    if (split >= nsplits) return;
+    const int nt = pair / nct, ct = pair - nt * nct;
+    const int n0 = nt * 64, c0 = ct * 64;
+    const int g = lane >> 4, i16 = lane & 15, wn = wave >> 1, wc = wave & 1;
+    const int q0 = split * chunks_per_split, q1 = min(total_chunks, q0 + chunks_per_split);
+    const int nstage = q1 - q0;
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero_page);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    int row_a[2], kc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 8 + (lane >> 3);
+        row_a[j] = row;
+        kc[j] = ((lane & 7) ^ (row & 7)) << 3;
+    }
+    auto issue = [&](int s) {
+        const int q = q0 + s;
+        const int b = q / chunks_per_image, p0 = (q - b * chunks_per_image) * kW2Px;
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (s % kW2Ring) * SB);
+        const uint16_t *dyb = dy + (int64_t)b * Cout * HW + p0, *xb = x + (int64_t)b * Cin * HW + p0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool pin = p0 + kc[j] < HW;
+            const int n = n0 + row_a[j], c = c0 + row_a[j];
+            glds16((pin && n < Cout) ? dyb + (int64_t)n * HW + kc[j] : zero, __builtin_amdgcn_readfirstlane(base + (wave * 2 + j) * 1024));
+            glds16((pin && c < Cin) ? xb + (int64_t)c * HW + kc[j] : zero, __builtin_amdgcn_readfirstlane(base + OPB + (wave * 2 + j) * 1024));
+        }
+    };
+    f32x4v acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    if (nstage > 0) issue(0);
+    if (nstage > 1) issue(1);
+    for (int s = 0; s < nstage; ++s) {
+        if (s + 1 < nstage) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned char *ta = lds + (s % kW2Ring) * SB, *tb = ta + OPB;
+        bf16x8 af[2][2], bfr[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int row = wn * 32 + a * 16 + i16;
+                af[ks][a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(ta + row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4)));
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int row = wc * 32 + b * 16 + i16;
+                bfr[ks][b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(tb + row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4)));
+            }
+        }
+        if (s + 2 < nstage) issue(s + 2);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][a], bfr[ks][b], acc[a][b], 0, 0, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int c = c0 + wc * 32 + b * 16 + i16;
+        if (c >= CP16) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 32 + a * 16 + 4 * g + r;
+                if (n < NP16) part[((int64_t)split * NP16 + n) * CP16 + c] = acc[a][b][r];
+            }
+    }
+}
+
+__global__ __launch_bounds__(kW2Threads) void conv_wgrad1_group64_kernel(const int64_t *__restrict__ table) {
+    const int64_t *e = table + (int64_t)blockIdx.y * 8;
+    const int B = (int)e[3], Cin = (int)e[4], Cout = (int)e[5], HW = (int)e[6];
+    const int splits = (int)(e[7] & 0xffffffff), cps = (int)(e[7] >> 32);
+    const int cpi = (HW + kW2Px - 1) / kW2Px;
+    const int nnt = (Cout + 63) / 64, nct = (Cin + 63) / 64, npairs = nnt * nct;
+    if ((int)blockIdx.x >= 8 * ((splits + 7) / 8) * npairs) return;
+    conv_wgrad1_t64_body(reinterpret_cast<const uint16_t *>(e[0]), reinterpret_cast<const uint16_t *>(e[1]), reinterpret_cast<float *>(e[2]),
+                         Cin, Cout, HW, cpi, B * cpi, cps, nct, (Cout + 15) / 16 * 16, (Cin + 15) / 16 * 16, npairs, splits, blockIdx.x);
+}
+
 // wg_target: workgroups the problem should occupy - 256 (one per CU, one round: the load path of EVERY CU is needed) when it is
 // launched on its own; a problem of a GROUPED launch (dfine_conv_wgrad1_group: 8 - 32 problems side by side) fills the chip
 // with far fewer, and every split it does not use is a slab of fp32 partial sums that is not written and not read again by
@@ -2215,10 +2322,39 @@ static int wgrad1_group_target() {
     return t;
 }
 
+// Tile class of a problem of the grouped launch: 64 (dfine_conv_wgrad1_group64: layers with <= 128 channels on both sides) or
+// 128 (dfine_conv_wgrad1_group).  The rows of one launch must all be of the launch's class.
+int dfine_conv_wgrad1_group_tile(int Cin, int Cout) {
+    // OFF by default: in the D-FINE-m step the 64-tile launches take the family from 3.27 to 2.92 ms of kernel time (and the deferred
+    // reduction from 0.59 to 0.54), but the step got 0.1 ms SLOWER (30.56 / 30.63 -> 30.65 .. 30.79 ms, six runs in one call): three
+    // of these small workgroups fit a CU and crowd the main stream's 1024-thread BatchNorm workgroups out of it.  DFINE_WGRAD1_T64=1.
+    static const int on = [] { const char *e = getenv("DFINE_WGRAD1_T64"); return e ? atoi(e) : 0; }();
+    return on && Cin <= 128 && Cout <= 128 ? 64 : 128;
+}
+
+static void wgrad1_group_plan(int B, int Cin, int Cout, int HW, int *splits, int *cps) {
+    if (dfine_conv_wgrad1_group_tile(Cin, Cout) == 128) { wgrad1_plan(B, Cin, Cout, HW, splits, cps, wgrad1_group_target()); return; }
+    static const int target = [] { const char *e = getenv("DFINE_WGRAD1_T64_WGS"); const int v = e ? atoi(e) : 256; return v < 8 ? 8 : v; }();
+    const int cpi = (HW + kW2Px - 1) / kW2Px, total = B * cpi;
+    const int pairs = ((Cout + 63) / 64) * ((Cin + 63) / 64);
+    int sp = target / pairs;
+    if (sp < 1) sp = 1;
+    if (sp > total) sp = total;
+    int c = (total + sp - 1) / sp;
+    int spl = (total + c - 1) / c;
+    if (spl >= 8 && (spl & 7)) {                                            // whole splits per XCD
+        for (int u = c; u <= c * 4 / 3 + 1; ++u) {
+            const int t = (total + u - 1) / u;
+            if (t >= 8 && (t & 7) == 0) { c = u; spl = t; break; }
+        }
+    }
+    *splits = spl; *cps = c;
+}
+
 // Splits (partial-sum slabs) and workspace floats of a problem of the GROUPED 1x1 weight-gradient launch.
 int dfine_conv_wgrad1_group_splits(int B, int Cin, int Cout, int HW) {
     int splits, cps;
-    wgrad1_plan(B, Cin, Cout, HW, &splits, &cps, wgrad1_group_target());
+    wgrad1_group_plan(B, Cin, Cout, HW, &splits, &cps);
     return splits;
 }
 
@@ -2229,10 +2365,11 @@ int64_t dfine_conv_wgrad1_group_ws_floats(int B, int Cin, int Cout, int HW) {
 int dfine_conv_wgrad1_group_row(const void *x, const void *dy, float *ws, int B, int Cin, int Cout, int HW, int64_t *row) {
     if (!x || !dy || !ws || !row || B < 1 || Cin < 1 || Cout < 1 || !wgrad1_v2(1, HW)) return DFINE_E_BADARG;
     int splits, cps;
-    wgrad1_plan(B, Cin, Cout, HW, &splits, &cps, wgrad1_group_target());
+    const int tile = dfine_conv_wgrad1_group_tile(Cin, Cout);
+    wgrad1_group_plan(B, Cin, Cout, HW, &splits, &cps);
     row[0] = (int64_t)x; row[1] = (int64_t)dy; row[2] = (int64_t)ws; row[3] = B; row[4] = Cin; row[5] = Cout; row[6] = HW;
     row[7] = (int64_t)splits | ((int64_t)cps << 32);
-    return 8 * ((splits + 7) / 8) * ((Cout + 127) / 128) * ((Cin + 127) / 128);
+    return 8 * ((splits + 7) / 8) * ((Cout + tile - 1) / tile) * ((Cin + tile - 1) / tile);
 }
 
 int dfine_conv_wgrad1_group(const void *table, int n_problems, int max_blocks, void *stream) {
@@ -2251,6 +2388,14 @@ int dfine_conv_wgrad1_group(const void *table, int n_problems, int max_blocks, v
 }
 
 // table: device int64 [n_problems][8] (rows from dfine_linear_wgrad_group_row); max_blocks = the largest row's workgroup count.
+int dfine_conv_wgrad1_group64(const void *table, int n_problems, int max_blocks, void *stream) {
+    if (n_problems == 0) return DFINE_OK;
+    if (!table || n_problems < 0 || max_blocks < 1) return DFINE_E_BADARG;
+    hipLaunchKernelGGL(conv_wgrad1_group64_kernel, dim3(max_blocks, n_problems), dim3(kW2Threads), (size_t)kW2Ring * 2 * 64 * 128,
+                       (hipStream_t)stream, (const int64_t *)table);
+    return check_launch();
+}
+
 int dfine_linear_wgrad_group(const void *table, int n_problems, int max_blocks, void *stream) {
     if (n_problems == 0) return DFINE_OK;
     if (!table || n_problems < 0 || max_blocks < 1) return DFINE_E_BADARG;

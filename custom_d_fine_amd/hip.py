@@ -93,6 +93,8 @@ _SIGNATURES = {
     "dfine_conv_wgrad1_group_ws_floats": (_L, [_I, _I, _I, _I]),
     "dfine_conv_wgrad1_group_row": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_conv_wgrad1_group": (c_int, [_P, _I, _I, _P]),
+    "dfine_conv_wgrad1_group_tile": (c_int, [_I, _I]),
+    "dfine_conv_wgrad1_group64": (c_int, [_P, _I, _I, _P]),
     "dfine_linear_act_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_multi_cast_bf16_t": (c_int, [_P, _I, _P]),
     "dfine_act_fwd_bf16": (c_int, [_P, _P, _L, _I, _P]),
@@ -1317,29 +1319,36 @@ def linear_wgrad_partials(x2d, dy2d):
 
 
 def _flush_conv_group(side=False):
+    """The registered 1x1 weight gradients as grouped launches: one for the layers with <= 128 channels on both sides (64 x 64
+    tiles, dfine_conv_wgrad1_group64), one for the others (128 x 128 tiles)."""
     import numpy as np
     from .d_fine.arch.utils import upload
-    pend = list(_CW_PENDING)
+    pend_all = list(_CW_PENDING)
     _CW_PENDING.clear()
-    table = np.empty((len(pend), 8), dtype=np.int64)
-    blocks, flops, io = 1, 0.0, 0.0
-    for i, (x, dy, ws, B, cin, cout, hw) in enumerate(pend):
-        n = int(_lib.dfine_conv_wgrad1_group_row(x.data_ptr(), dy.data_ptr(), ws.data_ptr(), B, cin, cout, hw, table[i].ctypes.data))
-        if n < 0:
-            raise RuntimeError("dfine_conv_wgrad1_group_row: bad arguments")
-        blocks = max(blocks, n)
-        flops += 2.0 * B * hw * cin * cout
-        io += 2.0 * B * hw * (cin + cout) + 4.0 * cin * cout
-    dev_table = upload(table, pend[0][0].device)
-    if side:
-        st = _side_fork(pend[0][0].device)         # (forked after the table's copy was enqueued)
-        with _timed("conv1x1_wgrad", flops, io=io, stream=st.stream):
-            _check(_lib.dfine_conv_wgrad1_group(_ptr(dev_table), len(pend), blocks, st.cuda_stream), "dfine_conv_wgrad1_group")
-        _SIDE_LIVE.append((pend, dev_table))
-        return
-    with _timed("conv1x1_wgrad", flops, io=io):
-        _check(_lib.dfine_conv_wgrad1_group(_ptr(dev_table), len(pend), blocks, _stream()), "dfine_conv_wgrad1_group")
-    _LW_KEEP.append((pend, dev_table))
+    for tile, launch, what in ((64, _lib.dfine_conv_wgrad1_group64, "dfine_conv_wgrad1_group64"),
+                               (128, _lib.dfine_conv_wgrad1_group, "dfine_conv_wgrad1_group")):
+        pend = [p for p in pend_all if int(_PURE.dfine_conv_wgrad1_group_tile(p[4], p[5])) == tile]
+        if not pend:
+            continue
+        table = np.empty((len(pend), 8), dtype=np.int64)
+        blocks, flops, io = 1, 0.0, 0.0
+        for i, (x, dy, ws, B, cin, cout, hw) in enumerate(pend):
+            n = int(_lib.dfine_conv_wgrad1_group_row(x.data_ptr(), dy.data_ptr(), ws.data_ptr(), B, cin, cout, hw, table[i].ctypes.data))
+            if n < 0:
+                raise RuntimeError("dfine_conv_wgrad1_group_row: bad arguments")
+            blocks = max(blocks, n)
+            flops += 2.0 * B * hw * cin * cout
+            io += 2.0 * B * hw * (cin + cout) + 4.0 * cin * cout
+        dev_table = upload(table, pend[0][0].device)
+        if side:
+            st = _side_fork(pend[0][0].device)         # (forked after the table's copy was enqueued)
+            with _timed("conv1x1_wgrad", flops, io=io, stream=st.stream):
+                _check(launch(_ptr(dev_table), len(pend), blocks, st.cuda_stream), what)
+            _SIDE_LIVE.append((pend, dev_table))
+            continue
+        with _timed("conv1x1_wgrad", flops, io=io):
+            _check(launch(_ptr(dev_table), len(pend), blocks, _stream()), what)
+        _LW_KEEP.append((pend, dev_table))
 
 
 def _flush_linear_group(side=False):

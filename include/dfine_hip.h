@@ -444,6 +444,11 @@ int dfine_conv_wgrad1_group_splits(int B, int Cin, int Cout, int HW);
 int64_t dfine_conv_wgrad1_group_ws_floats(int B, int Cin, int Cout, int HW);
 int dfine_conv_wgrad1_group_row(const void *x, const void *dy, float *ws, int B, int Cin, int Cout, int HW, int64_t *row);
 int dfine_conv_wgrad1_group(const void *table, int n_problems, int max_blocks, void *stream);
+/* Tile class of a problem (64: both channel counts <= 128, launched by dfine_conv_wgrad1_group64 on 64 x 64 (n, c) tiles - a
+ * quarter of the partial-sum slabs for the same number of workgroups; 128: dfine_conv_wgrad1_group).  All rows of one launch
+ * must be of the launch's class; rows come from dfine_conv_wgrad1_group_row either way. */
+int dfine_conv_wgrad1_group_tile(int Cin, int Cout);
+int dfine_conv_wgrad1_group64(const void *table, int n_problems, int max_blocks, void *stream);
 int dfine_multi_wgrad_reduce_blocks(int splits, int64_t elems);   /* blocks one row of the table needs */
 int dfine_multi_wgrad_reduce(const void *table, int n_entries, int max_blocks, void *stream);
 
