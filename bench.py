@@ -52,7 +52,7 @@ MFMA_GROUPS = ("conv1x1", "conv3x3", "conv1x1_wgrad", "conv3x3_wgrad", "wgrad_re
 # rocprofv3 --kernel-trace --stats summary of this command)
 KERNEL_GROUPS = (
     ("conv1x1", r"dfine::conv1x1_(glds|tr|ring)_kernel"),
-    ("conv3x3", r"dfine::(conv_igemm_kernel<3|conv3x3_ws_kernel)"),
+    ("conv3x3", r"dfine::(conv_igemm_kernel<3|conv3x3_ws_kernel|conv3x3_rows32_kernel)"),
     ("conv1x1_wgrad", r"dfine::(conv_wgrad1_glds_kernel|conv_wgrad1_group_kernel|conv_wgrad_kernel<1>)"),
     ("conv3x3_wgrad", r"dfine::(conv_wgrad_kernel<3>|conv_wgrad3_)"),
     ("stem", r"dfine::stem_(conv|mfma|dgrad|wgrad)"),

@@ -37,6 +37,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4v;
 int wgrad3_rows_splits(int B, int Cin, int Cout, int H, int W);
 int wgrad3_rows_launch(const void *x, const void *dy, float *part, int B, int Cin, int Cout, int H, int W, hipStream_t st);
 
+// csrc/conv3s.hip: row-streaming 3x3 forward / data gradient for <= 32 channels on both sides
+bool conv3x3_rows32_ok(int NP, int KP, int H, int W);
+int conv3x3_rows32_launch(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B, int Cin, int Cout, int NP, int KP, int H, int W,
+                          int accum, hipStream_t st);
+
 constexpr int kConvThreads = 256;
 constexpr int kMaxPixTiles = 10;     // 160 pixels per strip
 
@@ -1920,6 +1925,7 @@ static bool conv3x3_ws_ok(int B, int NP, int KP, int H, int W) {
 
 static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B, int Cin, int Cout, int NP, int KP,
                        int H, int W, int KS, hipStream_t st, int accum = 0) {
+    if (KS == 3 && conv3x3_rows32_ok(NP, KP, H, W)) return conv3x3_rows32_launch(x, w2, y, B, Cin, Cout, NP, KP, H, W, accum, st);
     // strip height: as many rows as fit in 160 pixels
     int R = 160 / W;
     if (R < 1) return DFINE_E_BADARG;

@@ -14,6 +14,8 @@ CASES = [  # B, Cin, Cout, H, W, KS
     (3, 48, 96, 20, 20, 1), (1, 1792, 768, 20, 20, 1), (2, 256, 128, 30, 30, 1), (2, 128, 256, 7, 10, 1),
     (2, 512, 512, 80, 80, 1), (2, 768, 256, 40, 40, 1), (1, 1536, 256, 20, 20, 1), (2, 96, 48, 8, 8, 1), (2, 160, 80, 24, 24, 1),
     (33, 128, 128, 8, 16, 1), (5, 768, 1536, 20, 20, 1), (3, 1280, 384, 40, 40, 1), (7, 256, 256, 20, 20, 1), (9, 64, 96, 12, 10, 1),
+    # <= 32 channels on both sides, W % 16 == 0: the row-streaming kernel of csrc/conv3s.hip (rows per workgroup, remainders, one row)
+    (2, 32, 32, 160, 160, 3), (3, 16, 32, 9, 48, 3), (2, 32, 16, 33, 64, 3), (1, 16, 16, 1, 32, 3), (5, 32, 32, 17, 144, 3),
 ]
 
 
