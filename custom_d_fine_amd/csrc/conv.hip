@@ -27,6 +27,7 @@
 //   MFMA   = v_mfma_f32_16x16x32_bf16: A lane l -> W2[n = l&15][c = 8*(l>>4)..+7],
 //            B lane l -> X_lds[pixel = l&15][c = 8*(l>>4)..+7], D lane l -> Y[n = 4*(l>>4)+reg][pixel = l&15].
 #include "common.h"
+#include "epi_bn.h"
 
 namespace dfine {
 
@@ -765,13 +766,19 @@ __device__ __forceinline__ void glds16(const uint16_t *gsrc, unsigned lds_addr) 
 #endif
 constexpr int kAbl = DFINE_CONV1X1_ABLATE;
 
-template <int NTN, int kG2Ring, int PXW, bool SEG>   // kG2Ring LDS stages (3: two in flight; 2 for <= 128 input channels); PXW 16-pixel
-                                                     // tiles per wave (4 / 8); SEG: input / output given as several parts
+// kernel argument of the BatchNorm-sum epilogue (epi_bn.h): nothing at all in the plain instantiations
+template <bool EPI> struct EpiArg { DfineConvEpilogue e; };
+template <> struct EpiArg<false> {};
+
+template <int NTN, int kG2Ring, int PXW, bool SEG, bool EPI = false>   // kG2Ring LDS stages (3: two in flight; 2 for <= 128 input channels); PXW 16-pixel
+                                                     // tiles per wave (4 / 8); SEG: input / output given as several parts; EPI: BatchNorm
+                                                     // sums of the stored values in the store loop
 __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs xs_, const uint16_t *__restrict__ w2,
                                                                   const ChanSegs ys_, int Cin, int Cout, int NP, int KP,
                                                                   int HW, int ptiles, int total_tiles, int nblk, int accum,
                                                                   int64_t w_bstride /* elements between the images' weight sets: 0 = shared */,
-                                                                  int ximg /* tiles over the pixels of ALL images (B * HW), see below */) {
+                                                                  int ximg /* tiles over the pixels of ALL images (B * HW), see below */,
+                                                                  const EpiArg<EPI> epa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int TP = 32 * PXW;                                             // pixels per workgroup (128 or 256)
     constexpr int XPITCH = TP * 2;                                           // bytes per channel row
@@ -986,25 +993,78 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
         const int bi = (int)(gp / HW);
         ylane = ((int64_t)bi * ys_.bs[0]) * HW + (gp - (int64_t)bi * HW);
     }
+    if constexpr (!EPI) {
 #pragma unroll
-    for (int it = 0; it < 16 * NTN / RPI; ++it) {
-        const int row = it * RPI + lane / LPO, c8 = (lane % LPO) * 8;
-        const int n = n0 + wn * 16 * NTN + row;
-        if (n < Cout && wp * 16 * PXW + c8 < npix) {
-            uint16_t *yp = SEG ? ytab[wn * 16 * NTN + row] + p0 + wp * 16 * PXW + c8
-                               : const_cast<uint16_t *>(ys_.p[0]) + ylane + (int64_t)n * HW;
-            uint4 v = *reinterpret_cast<const uint4 *>(ot + row * OP + c8);
-            if (accum) {                                  // y += conv(x): bf16 + bf16 in fp32, one rounding (like a separate add)
-                const uint4 o = *reinterpret_cast<const uint4 *>(yp);
-                const uint32_t a[4] = {v.x, v.y, v.z, v.w}, c[4] = {o.x, o.y, o.z, o.w};
-                uint32_t r[4];
+        for (int it = 0; it < 16 * NTN / RPI; ++it) {
+            const int row = it * RPI + lane / LPO, c8 = (lane % LPO) * 8;
+            const int n = n0 + wn * 16 * NTN + row;
+            if (n < Cout && wp * 16 * PXW + c8 < npix) {
+                uint16_t *yp = SEG ? ytab[wn * 16 * NTN + row] + p0 + wp * 16 * PXW + c8
+                                   : const_cast<uint16_t *>(ys_.p[0]) + ylane + (int64_t)n * HW;
+                uint4 v = *reinterpret_cast<const uint4 *>(ot + row * OP + c8);
+                if (accum) {                                  // y += conv(x): bf16 + bf16 in fp32, one rounding (like a separate add)
+                    const uint4 o = *reinterpret_cast<const uint4 *>(yp);
+                    const uint32_t a[4] = {v.x, v.y, v.z, v.w}, c[4] = {o.x, o.y, o.z, o.w};
+                    uint32_t r[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    r[k] = pack_bf16x2(__uint_as_float(a[k] << 16) + __uint_as_float(c[k] << 16),
-                                       __uint_as_float(a[k] & 0xffff0000u) + __uint_as_float(c[k] & 0xffff0000u));
-                v = make_uint4(r[0], r[1], r[2], r[3]);
+                    for (int k = 0; k < 4; ++k)
+                        r[k] = pack_bf16x2(__uint_as_float(a[k] << 16) + __uint_as_float(c[k] << 16),
+                                           __uint_as_float(a[k] & 0xffff0000u) + __uint_as_float(c[k] & 0xffff0000u));
+                    v = make_uint4(r[0], r[1], r[2], r[3]);
+                }
+                *reinterpret_cast<uint4 *>(yp) = v;
             }
-            *reinterpret_cast<uint4 *>(yp) = v;
+        }
+        return;
+    } else {
+        // Every global load of a batch of rows (the old values of an accumulating store, the BatchNorm input of the epilogue sums) is
+        // issued before the batch's first store: loads do not move above stores they might alias, and a load -> add -> store chain
+        // per row left the wave waiting out one memory round trip per row (up to 16 in a row).
+        const DfineConvEpilogue &ep = epa.e;
+        constexpr int NIT = 16 * NTN / RPI, EB = NIT < 4 ? NIT : 4;
+        const int c8 = (lane % LPO) * 8;
+        const bool col_ok = wp * 16 * PXW + c8 < npix;
+        const uint16_t *bnx = reinterpret_cast<const uint16_t *>(ep.bn_x);
+#pragma unroll
+        for (int it0 = 0; it0 < NIT; it0 += EB) {
+            uint16_t *yp[EB];
+            uint4 old[EB], xin[EB];
+#pragma unroll
+            for (int k = 0; k < EB; ++k) {
+                const int row = (it0 + k) * RPI + lane / LPO;
+                const int n = n0 + wn * 16 * NTN + row;
+                const bool live = n < Cout && col_ok;
+                yp[k] = SEG ? ytab[wn * 16 * NTN + row] + p0 + wp * 16 * PXW + c8
+                            : const_cast<uint16_t *>(ys_.p[0]) + ylane + (int64_t)n * HW;
+                old[k] = make_uint4(0, 0, 0, 0); xin[k] = make_uint4(0, 0, 0, 0);
+                if (accum && live) old[k] = *reinterpret_cast<const uint4 *>(yp[k]);
+                if (ep.mode == 2 && live) xin[k] = *reinterpret_cast<const uint4 *>(bnx + (yp[k] - ys_.p[0]));
+            }
+#pragma unroll
+            for (int k = 0; k < EB; ++k) {
+                const int row = (it0 + k) * RPI + lane / LPO;
+                const int n = n0 + wn * 16 * NTN + row;
+                const bool live = n < Cout && col_ok;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (live) {
+                    v = *reinterpret_cast<const uint4 *>(ot + row * OP + c8);
+                    if (accum) {                              // y += conv(x): bf16 + bf16 in fp32, one rounding (like a separate add)
+                        const uint32_t a[4] = {v.x, v.y, v.z, v.w}, c[4] = {old[k].x, old[k].y, old[k].z, old[k].w};
+                        uint32_t r[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            r[q] = pack_bf16x2(__uint_as_float(a[q] << 16) + __uint_as_float(c[q] << 16),
+                                               __uint_as_float(a[q] & 0xffff0000u) + __uint_as_float(c[q] & 0xffff0000u));
+                        v = make_uint4(r[0], r[1], r[2], r[3]);
+                    }
+                    *reinterpret_cast<uint4 *>(yp[k]) = v;
+                }
+                if (ep.mode) {                                // (uniform) BatchNorm sums of the values just stored: one slot per
+                    float s4[4] = {0.f, 0.f, 0.f, 0.f};       // (channel, workgroup half); one output part only (launch_conv1x1)
+                    if (live) epi_bn_terms(ep, n, v, xin[k], s4);
+                    epi_bn_write<LPO>(ep, n, tile_id * 2 + wp, s4, n < Cout);
+                }
+            }
         }
     }
 }
@@ -1021,47 +1081,72 @@ static ChanSegs one_seg(const void *p, int C) {
     return sg;
 }
 
+// one-shot epilogue request (dfine_conv_epilogue_once): per host thread, consumed by the next convolution launch
+static thread_local DfineConvEpilogue g_epi_req;
+static thread_local bool g_epi_set = false;
+bool take_conv_epilogue(DfineConvEpilogue *out) {
+    if (!g_epi_set) return false;
+    *out = g_epi_req;
+    g_epi_set = false;
+    return true;
+}
+
+// tile choice of the LDS-DMA 1x1 kernel for one layer
+struct C1Cfg { bool n256, px256, wide2, ring2, ximg; int tp, ptiles2, total2, nblk2; };
+static C1Cfg conv1x1_cfg(int B, int NP, int KP, int HW, bool seg, bool per_image_weights) {
+    static const int px256_env = [] { const char *e = getenv("DFINE_CONV1X1_PX256"); return e ? atoi(e) : 1; }();
+    // The kernel is bound by the ~10 B/clk/CU load path, so the tile is as large as the layer can fill the chip with:
+    // 256 pixels x 128 channels (87 FLOP per loaded byte) for deep layers on big maps, 128 x 128 (64) / 128 x 64 otherwise.
+    // Three tile regimes (tools/conv1x1_bench.py, 26 layer shapes of D-FINE-m, forward: 1364 us with the round-4 choice ->
+    // 1193-1259 with either new one alone; per layer the better of the two):
+    //  * <= 2 stages (K <= 128): 2-slot ring, both stages issued up front, 2 workgroups per CU (as before);
+    //  * deep K (>= 512) and output channels a multiple of 256 with enough such tiles: 256 channels x 256 pixels (NTN = 4),
+    //    2-slot ring of 64 KiB stages, streamed - 128 FLOP per loaded byte;
+    //  * everything else: 128 (64) channels x 128 pixels with the 2-slot ring STREAMED (64 KiB of LDS: two workgroups = 16
+    //    waves per CU, which cover each other's load -> MFMA -> store phases; the round-4 choice for these layers was one
+    //    256-pixel workgroup per CU on a 3-slot ring: 1280 -> 384 @40x40 86 -> 70 us, 1792 -> 768 @20x20 68 -> 54, 192 -> 384
+    //    @80x80 71 -> 57, 896 -> 384 @40x40 59 -> 49).
+    C1Cfg c;
+    const bool classic2 = KP <= 2 * kG2Rows;
+    const bool n128 = NP % 128 == 0;
+    // whole tensors with shared weights: pixel tiles over the B * HW pixels of the batch whenever per-image tiles would
+    // leave the last one partly empty (20 x 20 planes: 400 pixels = 3.1 tiles of 128; 40 x 40: 6.25 tiles of 256)
+    static const int ximg_env = [] { const char *e = getenv("DFINE_CONV1X1_XIMG"); return e ? atoi(e) : 1; }();
+    static const int n256_env = [] { const char *e = getenv("DFINE_CONV1X1_N256"); return e ? atoi(e) : 1; }();
+    static const int small_env = [] { const char *e = getenv("DFINE_CONV1X1_SMALL"); return e ? atoi(e) : 1; }();
+    const bool xok = ximg_env && !seg && !per_image_weights;
+    const int64_t gpix = (int64_t)B * HW;
+    const int64_t t256 = xok ? (gpix + 255) / 256 : (int64_t)B * ((HW + 255) / 256);
+    const bool px256c = px256_env && n128 && !classic2 && (xok || HW % 256 == 0 || HW >= 1536) && t256 * (NP / 128) >= 256;
+    const int64_t blk256 = t256 * (NP / 256);
+    c.n256 = n256_env && px256c && NP % 256 == 0 && KP >= 512 && blk256 >= 200 && !(blk256 > 256 && blk256 < 384);
+    const bool small = small_env && !c.n256 && !classic2;
+    c.ring2 = classic2 || small;
+    c.px256 = c.n256 || (px256c && !small);
+    c.tp = c.px256 ? 256 : kTrPix;
+    c.ximg = xok && HW % c.tp != 0;
+    c.ptiles2 = c.ximg ? B : (HW + c.tp - 1) / c.tp;     // (ximg: the kernel wants the image count here)
+    c.total2 = c.ximg ? (int)((gpix + c.tp - 1) / c.tp) : B * c.ptiles2;
+    c.wide2 = c.px256 || (n128 && ((int64_t)c.total2 * (NP / 128) >= 256));
+    c.nblk2 = c.n256 ? NP / 256 : c.wide2 ? NP / 128 : (NP + 63) / 64;
+    return c;
+}
+
 static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B, int Cin, int Cout, int NP, int KP, int HW,
                           hipStream_t st, const ChanSegs *xsegs = nullptr, const ChanSegs *ysegs = nullptr, int accum = 0,
                           int64_t w_bstride = 0) {
     const int ptiles = (HW + kTrPix - 1) / kTrPix;
-    static const int px256_env = [] { const char *e = getenv("DFINE_CONV1X1_PX256"); return e ? atoi(e) : 1; }();
+    DfineConvEpilogue epv{};
+    const bool has_ep = take_conv_epilogue(&epv);
     if (conv1x1_glds_ok(Cin, KP, HW)) {
-        // The kernel is bound by the ~10 B/clk/CU load path, so the tile is as large as the layer can fill the chip with:
-        // 256 pixels x 128 channels (87 FLOP per loaded byte) for deep layers on big maps, 128 x 128 (64) / 128 x 64 otherwise.
-        // Three tile regimes (tools/conv1x1_bench.py, 26 layer shapes of D-FINE-m, forward: 1364 us with the round-4 choice ->
-        // 1193-1259 with either new one alone; per layer the better of the two):
-        //  * <= 2 stages (K <= 128): 2-slot ring, both stages issued up front, 2 workgroups per CU (as before);
-        //  * deep K (>= 512) and output channels a multiple of 256 with enough such tiles: 256 channels x 256 pixels (NTN = 4),
-        //    2-slot ring of 64 KiB stages, streamed - 128 FLOP per loaded byte;
-        //  * everything else: 128 (64) channels x 128 pixels with the 2-slot ring STREAMED (64 KiB of LDS: two workgroups = 16
-        //    waves per CU, which cover each other's load -> MFMA -> store phases; the round-4 choice for these layers was one
-        //    256-pixel workgroup per CU on a 3-slot ring: 1280 -> 384 @40x40 86 -> 70 us, 1792 -> 768 @20x20 68 -> 54, 192 -> 384
-        //    @80x80 71 -> 57, 896 -> 384 @40x40 59 -> 49).
-        const bool classic2 = KP <= 2 * kG2Rows;
-        const bool n128 = NP % 128 == 0;
         const ChanSegs xs_ = xsegs ? *xsegs : one_seg(x, Cin), ys_ = ysegs ? *ysegs : one_seg(y, Cout);
         const bool seg = xs_.n > 1 || ys_.n > 1;
-        // whole tensors with shared weights: pixel tiles over the B * HW pixels of the batch whenever per-image tiles would
-        // leave the last one partly empty (20 x 20 planes: 400 pixels = 3.1 tiles of 128; 40 x 40: 6.25 tiles of 256)
-        static const int ximg_env = [] { const char *e = getenv("DFINE_CONV1X1_XIMG"); return e ? atoi(e) : 1; }();
-        static const int n256_env = [] { const char *e = getenv("DFINE_CONV1X1_N256"); return e ? atoi(e) : 1; }();
-        static const int small_env = [] { const char *e = getenv("DFINE_CONV1X1_SMALL"); return e ? atoi(e) : 1; }();
-        const bool xok = ximg_env && !seg && !w_bstride;
-        const int64_t gpix = (int64_t)B * HW;
-        const int64_t t256 = xok ? (gpix + 255) / 256 : (int64_t)B * ((HW + 255) / 256);
-        const bool px256c = px256_env && n128 && !classic2 && (xok || HW % 256 == 0 || HW >= 1536) && t256 * (NP / 128) >= 256;
-        const int64_t blk256 = t256 * (NP / 256);
-        const bool n256 = n256_env && px256c && NP % 256 == 0 && KP >= 512 && blk256 >= 200 && !(blk256 > 256 && blk256 < 384);
-        const bool small = small_env && !n256 && !classic2;
-        const bool ring2 = classic2 || small;
-        const bool px256 = n256 || (px256c && !small);
-        const int tp = px256 ? 256 : kTrPix;
-        const bool ximg = xok && HW % tp != 0;
-        const int ptiles2 = ximg ? B : (HW + tp - 1) / tp;     // (ximg: the kernel wants the image count here)
-        const int total2 = ximg ? (int)((gpix + tp - 1) / tp) : B * ptiles2;
-        const bool wide2 = px256 || (n128 && ((int64_t)total2 * (NP / 128) >= 256));
-        const int nblk2 = n256 ? NP / 256 : wide2 ? NP / 128 : (NP + 63) / 64;
+        const C1Cfg cf = conv1x1_cfg(B, NP, KP, HW, seg, w_bstride != 0);
+        const bool n256 = cf.n256, px256 = cf.px256, wide2 = cf.wide2, ring2 = cf.ring2, ximg = cf.ximg;
+        const int tp = cf.tp, ptiles2 = cf.ptiles2, total2 = cf.total2, nblk2 = cf.nblk2;
+        if (has_ep && (ys_.n != 1 || ys_.bs[0] != Cout || w_bstride || !epv.part || epv.nchunk != 2 * total2 || epv.cout != Cout ||
+                       (epv.mode != 1 && epv.mode != 2) || (epv.mode == 2 && (!epv.bn_x || !epv.mean || !epv.invstd || !epv.scale || !epv.shift))))
+            return DFINE_E_BADARG;
         dim3 grid2(8 * ((total2 + 7) / 8) * nblk2);
         if (seg && Cin > 4096) return DFINE_E_BADARG;
         const size_t lds2 = n256 ? (size_t)8 * 64 * 136 * 2 + (seg ? 6144 : 0)
@@ -1069,27 +1154,35 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
         static bool attr2 = false;
         if (!attr2) {
             hipError_t e = hipSuccess, r;
-#define DFINE_G2_ATTR(N, R, P)                                                                                                                  \
-    if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<N, R, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize, R * (64 * 64 * P + 8192 * N))) != hipSuccess) e = r; \
-    if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<N, R, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize, R * (64 * 64 * P + 8192 * N) + 5120)) != hipSuccess) e = r;
+#define DFINE_G2_ATTR1(N, R, P, S, E, BYTES) \
+    if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<N, R, P, S, E>), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES)) != hipSuccess) e = r;
+#define DFINE_G2_ATTR(N, R, P) \
+    DFINE_G2_ATTR1(N, R, P, false, false, R * (64 * 64 * P + 8192 * N)) DFINE_G2_ATTR1(N, R, P, true, false, R * (64 * 64 * P + 8192 * N) + 5120) \
+    DFINE_G2_ATTR1(N, R, P, false, true, R * (64 * 64 * P + 8192 * N)) DFINE_G2_ATTR1(N, R, P, true, true, R * (64 * 64 * P + 8192 * N) + 5120)
             DFINE_G2_ATTR(1, 2, 4) DFINE_G2_ATTR(1, 3, 4) DFINE_G2_ATTR(2, 2, 4) DFINE_G2_ATTR(2, 3, 4) DFINE_G2_ATTR(2, 3, 8)
 #undef DFINE_G2_ATTR
-            if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<4, 2, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 136 * 2)) != hipSuccess) e = r;
-            if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<4, 2, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 136 * 2 + 6144)) != hipSuccess) e = r;
+            DFINE_G2_ATTR1(4, 2, 8, false, false, 8 * 64 * 136 * 2) DFINE_G2_ATTR1(4, 2, 8, true, false, 8 * 64 * 136 * 2 + 6144)
+            DFINE_G2_ATTR1(4, 2, 8, false, true, 8 * 64 * 136 * 2) DFINE_G2_ATTR1(4, 2, 8, true, true, 8 * 64 * 136 * 2 + 6144)
+#undef DFINE_G2_ATTR1
             if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
             attr2 = true;
         }
-#define DFINE_G2(N, R, P)                                                                                                                        \
-    { if (seg) hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, true>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum, w_bstride, ximg ? 1 : 0); \
-      else hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, false>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum, w_bstride, ximg ? 1 : 0); }
+#define DFINE_G2L(N, R, P, S, E, ARG) \
+    hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, S, E>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum, w_bstride, ximg ? 1 : 0, ARG)
+#define DFINE_G2(N, R, P)                                                                                            \
+    { if (has_ep) { if (seg) DFINE_G2L(N, R, P, true, true, epa1); else DFINE_G2L(N, R, P, false, true, epa1); }     \
+      else { if (seg) DFINE_G2L(N, R, P, true, false, epa0); else DFINE_G2L(N, R, P, false, false, epa0); } }
+        const EpiArg<true> epa1{epv};
+        const EpiArg<false> epa0{};
         if (n256) DFINE_G2(4, 2, 8)
         else if (px256) DFINE_G2(2, 3, 8)
         else if (wide2) { if (ring2) DFINE_G2(2, 2, 4) else DFINE_G2(2, 3, 4) }
         else { if (ring2) DFINE_G2(1, 2, 4) else DFINE_G2(1, 3, 4) }
 #undef DFINE_G2
+#undef DFINE_G2L
         return check_launch();
     }
-    if (xsegs || ysegs || accum || w_bstride) return DFINE_E_BADARG;  // the first-generation kernel takes whole tensors, shared weights, no accumulation
+    if (xsegs || ysegs || accum || w_bstride || has_ep) return DFINE_E_BADARG;  // the first-generation kernel takes whole tensors, shared weights, no accumulation, no epilogue sums
     const int vec = (HW % 8 == 0) ? 8 : (HW % 4 == 0 ? 4 : 2);
     static const int kc_env = [] { const char *e = getenv("DFINE_CONV_KC"); return e ? atoi(e) : 0; }();
     int kc = KP >= 128 ? 4 : (KP >= 64 ? 2 : 1);
@@ -1925,6 +2018,9 @@ static bool conv3x3_ws_ok(int B, int NP, int KP, int H, int W) {
 
 static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B, int Cin, int Cout, int NP, int KP,
                        int H, int W, int KS, hipStream_t st, int accum = 0) {
+    DfineConvEpilogue epv{};
+    const bool has_ep = take_conv_epilogue(&epv);
+    if (has_ep) return DFINE_E_BADARG;                 // (the 3x3 kernels have no BatchNorm-sum epilogue: dfine_conv_epilogue_chunks says 0)
     if (KS == 3 && conv3x3_rows32_ok(NP, KP, H, W)) return conv3x3_rows32_launch(x, w2, y, B, Cin, Cout, NP, KP, H, W, accum, st);
     // strip height: as many rows as fit in 160 pixels
     int R = 160 / W;
@@ -2095,6 +2191,24 @@ int dfine_conv_epilogue_supported(int B, int Cin, int Cout, int H, int W, int KS
     // kernel, whose per-element store reads the old value first)
     if (KS == 3) return (W % 2 == 0 && W <= 160) ? 1 : 0;
     return 0;
+}
+
+// BatchNorm sums in the store epilogue (DfineConvEpilogue, epi_bn.h): slots per channel the kernel serving this call writes
+// (0: no such epilogue for the shape).  n_x_parts > 1: the part-wise 1x1 convolution (dfine_conv1x1_seg_fwd_bf16).
+int dfine_conv_epilogue_chunks(int B, int Cin, int Cout, int H, int W, int KS, int n_x_parts) {
+    static const int on = [] { const char *e = getenv("DFINE_CONV_EPI_BN"); return e ? atoi(e) : 1; }();
+    if (!on || B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || Cin % 2 || KS != 1) return 0;
+    const int NP = (Cout + 15) / 16 * 16, KP = (Cin + 31) / 32 * 32, HW = H * W;
+    if (!conv1x1_glds_ok(Cin, KP, HW)) return 0;
+    return 2 * conv1x1_cfg(B, NP, KP, HW, n_x_parts > 1, false).total2;
+}
+
+int dfine_conv_epilogue_once(const DfineConvEpilogue *ep) {
+    if (!ep) { g_epi_set = false; return DFINE_OK; }
+    if ((ep->mode != 1 && ep->mode != 2) || !ep->part || ep->nchunk < 1) return DFINE_E_BADARG;
+    g_epi_req = *ep;
+    g_epi_set = true;
+    return DFINE_OK;
 }
 
 int dfine_conv_accum_bf16(const void *x, const void *w2, void *y, int B, int Cin, int Cout, int H, int W, int KS, void *stream) {

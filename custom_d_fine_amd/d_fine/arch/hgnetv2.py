@@ -47,16 +47,18 @@ class ConvBNAct(nn.Module):
         self.act = nn.ReLU() if use_act else nn.Identity()
         self.lab = LearnableAffineBlock() if (use_act and use_lab) else nn.Identity()
 
-    def forward(self, x, pad_br=False, fanin=None, fans=None):
+    def forward(self, x, pad_br=False, fanin=None, fans=None, fanout=None, bnsrc=None):
         """pad_br: the input stands for F.pad(x, (0, 1, 0, 1)) (StemBlock); the pad is applied inside.
-        fanin / fans: gradient hand-offs of HG_Block (kernels.GradFanIn)."""
+        fanin / fans: gradient hand-offs of HG_Block (kernels.GradFanIn); fanout / bnsrc: hand-offs of the BatchNorm-backward
+        sums between this unit and the consumer of its output / the producer of its input (kernels.BNLink)."""
         if isinstance(self.conv, nn.Sequential):
             x = self.conv[0](torch.cat(list(x), dim=1) if isinstance(x, (list, tuple)) else x)
             conv = self.conv[1]
         else:
             conv = self.conv
         lab = self.lab if isinstance(self.lab, LearnableAffineBlock) else None
-        return kernels.conv_bn_act(x, conv, self.bn, "relu" if self.use_act else None, lab, pad_br=pad_br, fanin=fanin, fans=fans)
+        return kernels.conv_bn_act(x, conv, self.bn, "relu" if self.use_act else None, lab, pad_br=pad_br, fanin=fanin, fans=fans,
+                                   fanout=fanout, bnsrc=bnsrc)
 
 
 class LightConvBNAct(nn.Module):
@@ -68,8 +70,8 @@ class LightConvBNAct(nn.Module):
         self.conv2 = ConvBNAct(out_chs, out_chs, kernel_size, groups=out_chs, use_act=True,
                                use_lab=use_lab)
 
-    def forward(self, x, fanin=None):
-        return self.conv2(self.conv1(x, fanin=fanin))
+    def forward(self, x, fanin=None, fanout=None):
+        return self.conv2(self.conv1(x, fanin=fanin), fanout=fanout)
 
 
 class StemBlock(nn.Module):
@@ -139,10 +141,16 @@ class HG_Block(nn.Module):
         if kernels.grad_fanin_enabled(x):
             # every map but the last has two consumers (the next layer and the aggregation): their data gradients meet in
             # the next layer's convolution epilogue instead of an element-wise add (kernels.GradFanIn)
+            # ... and that epilogue then holds the complete gradient of the map: it also adds up the sums the BatchNorm
+            # backward of the layer that produced the map starts with (kernels.BNLink; fans[j + 1] = the map layer j writes)
             fans = [kernels.GradFanIn() for _ in self.layers]
-            for layer, fan in zip(self.layers, fans):
-                feats.append(layer(feats[-1], fanin=fan))
-            y = self.aggregation[1](self.aggregation[0](feats, fans=fans + [None]))
+            for j, (layer, fan) in enumerate(zip(self.layers, fans)):
+                feats.append(layer(feats[-1], fanin=fan, fanout=fans[j + 1] if j + 1 < len(fans) else None))
+            if isinstance(self.aggregation[1], ConvBNAct):       # squeeze -> excitation: one consumer
+                link = kernels.BNLink()
+                y = self.aggregation[1](self.aggregation[0](feats, fans=fans + [None], fanout=link), bnsrc=link)
+            else:
+                y = self.aggregation[1](self.aggregation[0](feats, fans=fans + [None]))
         else:
             for layer in self.layers:
                 feats.append(layer(feats[-1]))

@@ -44,6 +44,10 @@ _SIGNATURES = {
     "dfine_bn2_act_fwd": (c_int, [_P] * 14 + [_I, _I, _I, _I, _F, _F, _F, _F, _P]),
     "dfine_bn2_act_bwd": (c_int, [_P] * 11 + [_I, _I, _I, _I, _P]),
     "dfine_bn_act_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "dfine_bn_act_fwd_part": (c_int, [_P] * 13 + [_I, _P, _I, _I, _I, _I, _F, _F, _P]),
+    "dfine_bn_act_bwd_part": (c_int, [_P] * 12 + [_I, _P, _I, _I, _I, _I, _P]),
+    "dfine_conv_epilogue_chunks": (c_int, [_I, _I, _I, _I, _I, _I, _I]),
+    "dfine_conv_epilogue_once": (c_int, [_P]),
     "dfine_head_losses": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _P, _I,
                                    _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P,
                                    _P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -545,15 +549,27 @@ def _bn_ws_need(B, C, HW):
 
 
 def bn_act_forward(x, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, training,
-                   momentum, eps):
+                   momentum, eps, part=None):
     """x [B, C, H, W] contiguous.  Returns (y, saved) where saved feeds bn_act_backward.
     (133 calls per train step: pointers of the four `stats` rows are computed, not sliced, and the HIP-event timing
-    wrapper is skipped unless a bench asked for it.)"""
+    wrapper is skipped unless a bench asked for it.)
+    part: [nchunk, C, 2] partial (sum, sum of squares) of x from the producing convolution's epilogue (arm_conv_stats) -
+    training mode only; the statistics pass over x is skipped."""
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // max(B * C, 1)
     dev = x.device
     y = torch.empty_like(x)
     stats = torch.empty(4, C, device=dev, dtype=torch.float32)     # mean, invstd, scale, shift
+    if part is not None:
+        sp, row = stats.data_ptr(), 4 * C
+        ws = _bn_workspace(dev, 4 * 8192 + 2 * C)
+        status = _lib.dfine_bn_act_fwd_part(x.data_ptr(), y.data_ptr(), _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                            _ptr(running_var), _ptr(lab_scale), _ptr(lab_bias), sp, sp + row, sp + 2 * row,
+                                            sp + 3 * row, part.data_ptr(), part.shape[0], ws.data_ptr(), B, C, HW, _ACT[act],
+                                            float(momentum), float(eps), _stream())
+        if status != 0:
+            _check(status, "dfine_bn_act_fwd_part")
+        return y, stats
     ws = _bn_workspace(dev, _bn_ws_need(B, C, HW))
     sp = stats.data_ptr()
     row = 4 * C
@@ -564,6 +580,50 @@ def bn_act_forward(x, gamma, beta, running_mean, running_var, lab_scale, lab_bia
     if status != 0:
         _check(status, "dfine_bn_act_fwd")
     return y, stats                # (eval mode: rows 0 / 1 hold the running mean and rsqrt(running_var + eps), written by the kernel)
+
+
+class _ConvEpilogue(ctypes.Structure):
+    """DfineConvEpilogue (include/dfine_hip.h)."""
+    _fields_ = [("mode", c_int), ("nchunk", c_int), ("act", c_int), ("cout", c_int), ("part", c_void_p),
+                ("bn_x", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
+                ("lab_scale", c_void_p)]
+
+
+_EPI_CHUNKS = {}
+
+
+def conv_epilogue_chunks(B, cin, cout, H, W, ks, n_x_parts=1):
+    """Partial-sum slots per output channel the convolution kernel for this call writes when a BatchNorm-sum epilogue is
+    armed (dfine_conv_epilogue_chunks); 0 = that kernel has none."""
+    key = (B, cin, cout, H, W, ks, n_x_parts)
+    n = _EPI_CHUNKS.get(key)
+    if n is None:
+        n = _EPI_CHUNKS[key] = int(_lib.dfine_conv_epilogue_chunks(B, cin, cout, H, W, ks, n_x_parts))
+    return n
+
+
+def arm_conv_stats(cout, nchunk, device):
+    """Arm the NEXT convolution launch of this thread to add up (sum, sum of squares) of its stored outputs per channel
+    (DfineConvEpilogue mode 1).  -> part [nchunk, cout, 2] f32 for bn_act_forward(part=...)."""
+    part = torch.empty(nchunk, cout, 2, device=device, dtype=torch.float32)
+    ep = _ConvEpilogue(1, nchunk, 0, cout, part.data_ptr(), None, None, None, None, None, None)
+    _check(_lib.dfine_conv_epilogue_once(ctypes.byref(ep)), "dfine_conv_epilogue_once")
+    return part
+
+
+def arm_conv_bn_bwd(cout, nchunk, bn_x, stats, lab_scale, act):
+    """Arm the NEXT convolution launch (a data gradient whose stored values are the dy of a BatchNorm with input `bn_x` and
+    saved `stats` [4, C]) to add up that BatchNorm's backward sums (DfineConvEpilogue mode 2).  -> part [nchunk, cout, 4]."""
+    part = torch.empty(nchunk, cout, 4, device=bn_x.device, dtype=torch.float32)
+    sp, row = stats.data_ptr(), 4 * cout
+    ep = _ConvEpilogue(2, nchunk, _ACT[act], cout, part.data_ptr(), bn_x.data_ptr(), sp, sp + row, sp + 2 * row, sp + 3 * row,
+                       _ptr(lab_scale))
+    _check(_lib.dfine_conv_epilogue_once(ctypes.byref(ep)), "dfine_conv_epilogue_once")
+    return part
+
+
+def disarm_conv_epilogue():
+    _lib.dfine_conv_epilogue_once(None)
 
 
 _EPI_OK = {}
@@ -587,7 +647,7 @@ def conv_accumulate_bf16(x, w2, y, ks):
     return y
 
 
-def bn_act_backward(x, dy, stats, lab_scale, act, training, need_affine=True, need_lab=True, dlab_ptr=None):
+def bn_act_backward(x, dy, stats, lab_scale, act, training, need_affine=True, need_lab=True, dlab_ptr=None, part=None):
     """-> (dx, dgamma, dbeta, dlab).  dgamma / dbeta are two separate tensors (autograd's AccumulateGrad takes ownership
     of a whole tensor but has to copy a view: 2 x 133 small device copies per D-FINE-m step).  `dlab_ptr`: device address
     of two adjacent floats the kernel ADDS the learnable-affine gradients to (the fused optimizer's flat gradient slots);
@@ -603,6 +663,14 @@ def bn_act_backward(x, dy, stats, lab_scale, act, training, need_affine=True, ne
     sp = stats.data_ptr()
     row = 4 * C
     dl = dlab_ptr if (need_lab and dlab_ptr is not None) else _ptr(dlab)
+    if part is not None:       # [nchunk, C, 4] sums from the epilogue of the data gradient that produced dy (arm_conv_bn_bwd)
+        ws = _bn_workspace(dev, 4 * 8192 + 2 * C)
+        status = _lib.dfine_bn_act_bwd_part(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), sp, sp + row, sp + 2 * row, sp + 3 * row,
+                                            _ptr(lab_scale), _ptr(dgamma), _ptr(dbeta), dl, part.data_ptr(), part.shape[0],
+                                            ws.data_ptr(), B, C, HW, _ACT[act], _stream())
+        if status != 0:
+            _check(status, "dfine_bn_act_bwd_part")
+        return dx, dgamma, dbeta, dlab
     status = _lib.dfine_bn_act_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), sp, sp + row, sp + 2 * row, sp + 3 * row,
                                    _ptr(lab_scale), _ptr(dgamma), _ptr(dbeta), dl, ws.data_ptr(),
                                    _DTYPE[x.dtype], B, C, HW, _ACT[act], 1 if training else 0, _stream())

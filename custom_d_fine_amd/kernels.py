@@ -814,16 +814,65 @@ class GradFanIn:
     its own data gradient onto the parked one in its convolution's epilogue (dfine_conv_accum_bf16) and returns the sum.
     `armed` is set in the forward pass by the later consumer when it will be able to do that, `parking` by the earlier one
     (whose forward runs after it) when it will park - only then does the later consumer expect a parked gradient."""
-    __slots__ = ("armed", "parking", "buf")
+    __slots__ = ("armed", "parking", "buf", "bn", "part")
 
     def __init__(self):
         self.armed, self.parking, self.buf = False, False, None
+        self.bn, self.part = None, None         # BNLink role (below): the map's producer is a BatchNorm unit
 
     def take(self):
         buf, self.buf = self.buf, None
         if buf is None:
             raise RuntimeError("GradFanIn: the parked gradient is missing (backward order violated)")
         return buf
+
+
+class BNLink:
+    """Hand-off of the BatchNorm-backward sums between a conv + BatchNorm unit (the PRODUCER of a map) and the convolution
+    that forms the map's complete gradient in backward (its only CONSUMER, or - GradFanIn - the later of its two consumers,
+    which adds the parked gradient in its epilogue).  The reference's BatchNorm backward reads dy and its input once for
+    sum(dz), sum(dz * xhat) before it can form dx (ATen batch_norm_backward behind hgnetv2.py:75-80); here the consumer's
+    data-gradient kernel adds those sums up while it stores dy (DfineConvEpilogue mode 2, csrc/epi_bn.h).  Forward: the
+    producer leaves `bn` = (BatchNorm input, saved statistics, lab scale, activation); backward: the consumer arms its
+    data-gradient launch with it and leaves `part`, which the producer's BatchNorm backward takes in place of its reduction pass."""
+    __slots__ = ("bn", "part")
+
+    def __init__(self):
+        self.bn, self.part = None, None
+
+
+_BN_LINK_MIN = 16384      # B * H * W up to this: the BatchNorm backward is ONE launch with the channel in registers (bn_one_bwd)
+_BN_STATS_MIN = 65536     # ... and the forward ONE launch with one read (bn_one_fwd): nothing to save by statistics from the convolution
+
+
+def _bn_link_register(link, c, stats, lab_scale, act, training):
+    """Producer side, forward: may the consumer's epilogue take over this unit's backward reduction?"""
+    if (link is None or not training or c.dtype != torch.bfloat16 or _env("DFINE_BN_LINK", "0") != "1"):
+        return None
+    B, C, H, W = c.shape
+    if (H * W) % 8 or C > 2048 or B * H * W <= _BN_LINK_MIN:
+        return None
+    link.bn, link.part = (c, stats, lab_scale, act), None
+    return link
+
+
+def _bn_link_take(link):
+    """Producer side, backward: the sums the consumer left (None: it could not)."""
+    if link is None:
+        return None
+    part, link.part, link.bn = link.part, None, None
+    return part
+
+
+def _bn_link_arm(link, B, cin, cout, H, W, ks):
+    """Consumer side, backward, right before the data-gradient launch (cout -> cin channels) whose stored values are the
+    complete gradient of the linked map."""
+    if link is None or link.bn is None:
+        return
+    hip = _hip()
+    nchunk = hip.conv_epilogue_chunks(B, cout, cin, H, W, ks)
+    if nchunk > 0 and link.bn[0].shape[1] == cin:
+        link.part = hip.arm_conv_bn_bwd(cin, nchunk, *link.bn)
 
 
 def grad_fanin_enabled(x):
@@ -838,18 +887,29 @@ class _DenseConvBNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, lab_scale, lab_bias, running_mean, running_var, act, training, momentum, eps,
-                fanin=None):
+                fanin=None, fanout=None, bnsrc=None):
+        """fanin: GradFanIn of x (this unit is its later consumer); fanout: BNLink / GradFanIn of the output (this unit is its
+        producer); bnsrc: BNLink of x when this unit is its ONLY consumer."""
         hip = _hip()
         x = x.contiguous()
         ks = weight.shape[-1]
         B, cin, H, W = x.shape
+        cout = weight.shape[0]
         ctx.fanin = None
         if (fanin is not None and ctx.needs_input_grad[0] and x.dtype == torch.bfloat16
-                and hip.conv_epilogue_supported(B, weight.shape[0], cin, H, W, ks)):      # (the data gradient: channels exchanged)
+                and hip.conv_epilogue_supported(B, cout, cin, H, W, ks)):      # (the data gradient: channels exchanged)
             fanin.armed = True
             ctx.fanin = fanin
-        c = hip.conv_forward_bf16(x, _packed_weights(weight, False), weight.shape[0], ks)
-        y, stats = hip.bn_act_forward(c, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, training, momentum, eps)
+        ctx.bnsrc = bnsrc if ctx.needs_input_grad[0] else None
+        part = None
+        if training and B * H * W > _BN_STATS_MIN and (H * W) % 8 == 0 and cout <= 4096 and _env("DFINE_BN_LINK", "0") == "1":
+            nchunk = hip.conv_epilogue_chunks(B, cin, cout, H, W, ks)
+            if nchunk > 0:                                # the convolution adds up the batch statistics while it stores c
+                part = hip.arm_conv_stats(cout, nchunk, x.device)
+        c = hip.conv_forward_bf16(x, _packed_weights(weight, False), cout, ks)
+        y, stats = hip.bn_act_forward(c, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, training, momentum, eps,
+                                      part=part)
+        ctx.fanout = _bn_link_register(fanout, c, stats, lab_scale, act, training)
         ctx.save_for_backward(x, weight, c, stats, lab_scale)
         ctx.cfg = (act, training, gamma is not None, lab_scale is not None)
         need = ctx.needs_input_grad
@@ -875,7 +935,9 @@ class _DenseConvBNAct(torch.autograd.Function):
             dy = dy.to(c.dtype)
         slot = ctx.slot
         dlab_ptr = slot[0].grad_ptr(slot[1][0]) if slot is not None else None
-        dc, dg, db, dlab = hip.bn_act_backward(c, dy, stats, lab_scale, act, training, has_affine, has_lab, dlab_ptr)
+        dc, dg, db, dlab = hip.bn_act_backward(c, dy, stats, lab_scale, act, training, has_affine, has_lab, dlab_ptr,
+                                               part=_bn_link_take(ctx.fanout))
+        ctx.fanout = None
         dls = dlb = None
         if slot is not None:
             for i in slot[1]:
@@ -886,11 +948,15 @@ class _DenseConvBNAct(torch.autograd.Function):
         need = ctx.needs_input_grad
         dx = None
         if need[0]:
+            B, cin, H, W = x.shape
             if ctx.fanin is not None and ctx.fanin.parking:    # the other consumer's gradient is parked: add onto it in the epilogue
+                _bn_link_arm(ctx.fanin, B, cin, weight.shape[0], H, W, ks)     # ... which then holds the map's complete gradient
                 dx = hip.conv_accumulate_bf16(dc, _packed_weights(weight, True), ctx.fanin.take(), ks)
                 ctx.fanin = None
             else:
+                _bn_link_arm(ctx.bnsrc, B, cin, weight.shape[0], H, W, ks)
                 dx = hip.conv_forward_bf16(dc, _packed_weights(weight, True), weight.shape[1], ks)
+            ctx.bnsrc = None
         dw = None
         if need[1]:
             wslot = ctx.wslot
@@ -900,7 +966,7 @@ class _DenseConvBNAct(torch.autograd.Function):
                 wslot[0].use_done(wslot[1][0])
             else:
                 dw = hip.conv_wgrad_bf16(x, dc, ks).to(weight.dtype)
-        return dx, dw, dg, db, dls, dlb, None, None, None, None, None, None, None
+        return dx, dw, dg, db, dls, dlb, None, None, None, None, None, None, None, None, None
 
 
 class _InnerCtx:
@@ -918,11 +984,22 @@ class _ConvBNActAny(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inner, n, *args):
         conv_args = args[:n]
-        gamma, beta, lab_scale, lab_bias, running_mean, running_var, act, training, momentum, eps = args[n:]
+        gamma, beta, lab_scale, lab_bias, running_mean, running_var, act, training, momentum, eps, fanout = args[n:]
         ictx = _InnerCtx()
         ictx.needs_input_grad = ctx.needs_input_grad[2:2 + n]
+        part = None
+        if inner is _DenseConvSeg and training and _env("DFINE_BN_LINK", "0") == "1":
+            xs = conv_args[2:]                            # the part-wise 1x1 convolution adds up the batch statistics itself
+            B, _, H, W = xs[0].shape
+            cout, hip = conv_args[0].shape[0], _hip()
+            if B * H * W > _BN_STATS_MIN and (H * W) % 8 == 0 and cout <= 4096:
+                nchunk = hip.conv_epilogue_chunks(B, sum(t.shape[1] for t in xs), cout, H, W, 1, len(xs))
+                if nchunk > 0:
+                    part = hip.arm_conv_stats(cout, nchunk, xs[0].device)
         c = inner.forward(ictx, *conv_args)
-        y, stats = _hip().bn_act_forward(c, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, training, momentum, eps)
+        y, stats = _hip().bn_act_forward(c, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, training, momentum, eps,
+                                         part=part)
+        ctx.fanout = _bn_link_register(fanout, c, stats, lab_scale, act, training)
         ctx.save_for_backward(c, stats, lab_scale)
         ctx.inner, ctx.ictx, ctx.n = inner, ictx, n
         ctx.cfg = (act, training, gamma is not None, lab_scale is not None)
@@ -945,7 +1022,9 @@ class _ConvBNActAny(torch.autograd.Function):
             dy = dy.to(c.dtype)
         slot = ctx.slot
         dlab_ptr = slot[0].grad_ptr(slot[1][0]) if slot is not None else None
-        dc, dg, db, dlab = _hip().bn_act_backward(c, dy, stats, lab_scale, act, training, has_affine, has_lab, dlab_ptr)
+        dc, dg, db, dlab = _hip().bn_act_backward(c, dy, stats, lab_scale, act, training, has_affine, has_lab, dlab_ptr,
+                                                  part=_bn_link_take(ctx.fanout))
+        ctx.fanout = None
         dls = dlb = None
         if slot is not None:
             for i in slot[1]:
@@ -954,10 +1033,10 @@ class _ConvBNActAny(torch.autograd.Function):
             dls, dlb = dlab[0:1], dlab[1:2]
         inner_grads = ctx.inner.backward(ctx.ictx, dc)
         ctx.ictx = None
-        return (None, None) + tuple(inner_grads) + (dg, db, dls, dlb, None, None, None, None, None, None)
+        return (None, None) + tuple(inner_grads) + (dg, db, dls, dlb, None, None, None, None, None, None, None)
 
 
-def _bn_tail_fused(inner, conv_args, bn, a, lab):
+def _bn_tail_fused(inner, conv_args, bn, a, lab, fanout=None):
     """conv node + BatchNorm tail as one autograd node when the BatchNorm is a plain tracked nn.BatchNorm2d; None otherwise."""
     if not (_FUSE_CONV_BN and type(bn) is nn.BatchNorm2d and bn.track_running_stats and bn.momentum is not None):
         return None
@@ -969,7 +1048,8 @@ def _bn_tail_fused(inner, conv_args, bn, a, lab):
         else:
             bn.num_batches_tracked.add_(1)
     return _ConvBNActAny.apply(inner, len(conv_args), *conv_args, bn.weight, bn.bias, lab.scale if lab is not None else None,
-                               lab.bias if lab is not None else None, bn.running_mean, bn.running_var, a, training, bn.momentum, bn.eps)
+                               lab.bias if lab is not None else None, bn.running_mean, bn.running_var, a, training, bn.momentum, bn.eps,
+                               fanout)
 
 
 class _DualConv(torch.autograd.Function):
@@ -1290,11 +1370,13 @@ _ROUTES = [0]       # epoch token of the per-module route caches of conv_bn_act 
 
 
 def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Optional[nn.Module],
-                pad_br: bool = False, fanin=None, fans=None):
+                pad_br: bool = False, fanin=None, fans=None, fanout=None, bnsrc=None):
     """conv(bias=False) -> BN (batch stats in training) -> {None, relu, silu} -> scalar affine; the
     building block of HGNetv2 and the HybridEncoder.
     fanin / fans: GradFanIn hand-offs of the data gradient (fanin: this unit is the LATER consumer of x in backward; fans: one
     per part of a list input, this unit being the EARLIER one) - only honoured by the fused HIP units, ignored elsewhere.
+    fanout / bnsrc: BNLink hand-offs of the BatchNorm-backward sums (fanout: of this unit's output; bnsrc: of x, this unit
+    being its only consumer) - likewise.
     GPU (bf16 autocast): dense 1x1 / 3x3, depthwise and stem convolutions and the whole BN/act/affine tail are HIP kernels;
     fp32 math and CPU tensors take the plain ATen composition below."""
     a = act.lower() if isinstance(act, str) else act
@@ -1309,7 +1391,7 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
                 and conv.kernel_size == (1, 1) and len(xs) <= 8 and (xs[0].shape[-1] * xs[0].shape[-2]) % 8 == 0
                 and all(t.shape[1] % 8 == 0 for t in xs) and _mfma_conv_ok(conv, xs[0])):
             parts = [t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16) for t in xs]
-            y = _bn_tail_fused(_DenseConvSeg, (conv.weight, fans, *parts), bn, a, lab)
+            y = _bn_tail_fused(_DenseConvSeg, (conv.weight, fans, *parts), bn, a, lab, fanout=fanout)
             if y is not None:
                 return y
             y = _DenseConvSeg.apply(conv.weight, fans, *parts)
@@ -1354,7 +1436,7 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
         if route == 1:
             if x.dtype == torch.float32 and torch.is_autocast_enabled():
                 x = x.to(torch.get_autocast_dtype("cuda"))      # what autocast would do for F.conv2d
-            y = _bn_tail_fused(_DepthwiseConv, (x, conv.weight, conv.stride[0], conv.padding[0]), bn, a, lab)
+            y = _bn_tail_fused(_DepthwiseConv, (x, conv.weight, conv.stride[0], conv.padding[0]), bn, a, lab, fanout=fanout)
             if y is not None:
                 return y
             y = _DepthwiseConv.apply(x, conv.weight, conv.stride[0], conv.padding[0])
@@ -1371,7 +1453,7 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
                         bn.num_batches_tracked.add_(1)
                 return _DenseConvBNAct.apply(xb, conv.weight, bn.weight, bn.bias, lab.scale if lab is not None else None,
                                              lab.bias if lab is not None else None, bn.running_mean, bn.running_var, a, training,
-                                             bn.momentum, bn.eps, fanin if xb is x else None)
+                                             bn.momentum, bn.eps, fanin if xb is x else None, fanout, bnsrc if xb is x else None)
             y = _DenseConv.apply(xb, conv.weight)
         elif route == 3:
             # maps wider than the kernel's 160-pixel strips (the 240-wide stage of D-FINE-l / x at 960 x 960): two column halves
