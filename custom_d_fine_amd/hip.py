@@ -1531,8 +1531,33 @@ def _stem_pad32(dy):
     return dy if wo % 32 == 0 else torch.nn.functional.pad(dy, (0, 32 - wo % 32))
 
 
+# measured (bench.py --steps 100, alternating, three pairs): 30.39 -> 30.25 ms per step - but the stem's weight-gradient kernels then
+# overlap the main stream's stem kernels and both run longer (family kernel time 16.5 -> 17.2 ms: the roofline fraction of the
+# timed mode drops 0.123 -> 0.118).  Off by default: 0.4 % of throughput is below what a single bench run resolves.
+_STEM_TAIL = os.environ.get("DFINE_STEM_TAIL", "0") == "1"
+
+
+def backward_tail_begins():
+    """Called when the backward pass reaches the stem, its last stretch.  The stem's weight gradients are the end of the side
+    stream's work and each can only start once the main stream has produced its dy, so whatever else is still queued for the
+    side stream must not sit behind them: the registered grouped weight gradients (1x1 convolutions, token-stream linears) are
+    launched NOW, under the stem's data gradients; and a captured backward (dl/engine.py: chain of (main, side) graph pairs, a
+    side graph starts when its main graph has ended) closes a pair at every side launch from here on instead of every fifth,
+    so that a stem weight gradient waits for one stem layer of main-stream work, not for the rest of the pass."""
+    if not _STEM_TAIL or not _side_ok():
+        return
+    if _CW_PENDING:
+        _flush_conv_group(True)
+    if _LW_PENDING:
+        _flush_linear_group(True)
+    if CAPTURE_DUAL is not None:
+        CAPTURE_DUAL.every = 1
+
+
 def stem_wgrad(x, dy, ks, stride, pad, side=False):
     """side: launched on the side stream (see dwconv_backward)."""
+    if side:
+        backward_tail_begins()
     dy = _stem_pad32(dy)
     B, cin, H, W = x.shape
     _, cout, ho, wo = dy.shape
@@ -1585,6 +1610,8 @@ def stem_wgrad2(xa, xb, dy, ks, stride, pad, side=False):
     _, cout, ho, wo = dy.shape
     need = int(_PURE.dfine_stem_wgrad_ws_floats(B, cin, cout, ks, ho, wo))
     side = side and _side_ok()
+    if side:
+        backward_tail_begins()
     st = _side_fork(xa.device) if side else None
     key = (xa.device.index, st.cuda_stream if side else _stream())
     ws = _STEM_WS.get(key)
