@@ -765,6 +765,13 @@ __device__ __forceinline__ void glds16(const uint16_t *gsrc, unsigned lds_addr) 
 #define DFINE_CONV1X1_ABLATE 0
 #endif
 constexpr int kAbl = DFINE_CONV1X1_ABLATE;
+// -DDFINE_CONV1X1_SPREAD=1: the streamed schedule issues the copies of stage s + 1 one piece behind every other MFMA group of
+// stage s instead of all of them behind the barrier.  Measured (tools/conv1x1_bench.py, 26 shapes): 1161 -> 1218 us, 512 -> 512
+// @80x80 158.6 -> 162.4: the copies queueing at the CU's address path in front of the first MFMA are not what the stage waits for.
+#ifndef DFINE_CONV1X1_SPREAD
+#define DFINE_CONV1X1_SPREAD 0
+#endif
+constexpr bool kIssueSpread = DFINE_CONV1X1_SPREAD != 0;
 
 // kernel argument of the BatchNorm-sum epilogue (epi_bn.h): nothing at all in the plain instantiations
 template <bool EPI> struct EpiArg { DfineConvEpilogue e; };
@@ -864,6 +871,22 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
         }
     };
 
+    // piece j (0 .. XPW + NTN - 1) of stage s alone: the streamed schedule spreads a stage's copies over the MFMA groups of the
+    // stage in front (kIssueSpread below)
+    auto issue_piece = [&](int s, int j) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (s % kG2Ring) * SB);
+        const int c0 = s * kG2Rows;
+        if (j < XPW) {
+            const int ch = min(c0 + x_row[j], Cin - 1);
+            if (!SEG) glds16(x_src[j] + (int64_t)ch * HW, __builtin_amdgcn_readfirstlane(base + (wave * XPW + j) * 1024));
+            else glds16(xtab[ch >> 3] + (int64_t)(ch & 7) * HW + x_px[j], __builtin_amdgcn_readfirstlane(base + (wave * XPW + j) * 1024));
+        } else {
+            const int jw = j - XPW;
+            const int k = min(c0 + w_k[jw], KP - 8);
+            glds16(w2 + (int64_t)w_row[jw] * KP + k, __builtin_amdgcn_readfirstlane(base + XB + (wave * NTN + jw) * 1024));
+        }
+    };
+
     f32x4v acc[NTN][PXW];
 #pragma unroll
     for (int t = 0; t < NTN; ++t)
@@ -891,9 +914,15 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             const unsigned char *xs2 = lds + (s & 1) * SB, *ws2 = xs2 + XB;
-            if (s + 1 < nstage) issue(s + 1);
+            // (kIssueSpread, off: the copies of stage s + 1 spread over the MFMA groups of the stage, order pinned by sched_barrier)
+            const bool more = s + 1 < nstage;
+            constexpr int kPieces = XPW + NTN, kGroups = 2 * PXW, kEvery = kGroups / kPieces > 0 ? kGroups / kPieces : 1;
+            if (more && !kIssueSpread) issue(s + 1);
             const int nslab = s * kG2Rows + 32 < KP ? 2 : 1;
-            for (int slab = 0; slab < nslab; ++slab) {
+            if (more && kIssueSpread && nslab == 1) issue(s + 1);        // (a one-slab stage has half the groups: up front)
+#pragma unroll
+            for (int slab = 0; slab < 2; ++slab) {
+                if (slab >= nslab) break;
                 bf16x8 a1[NTN], b1[PXW];
 #pragma unroll
                 for (int t = 0; t < NTN; ++t) {
@@ -911,10 +940,19 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
                     b1[j] = __builtin_bit_cast(bf16x8, (tr_v8s)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                 }
 #pragma unroll
-                for (int j = 0; j < PXW; ++j)
+                for (int j = 0; j < PXW; ++j) {
 #pragma unroll
                     for (int t = 0; t < NTN; ++t)
                         acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[t], b1[j], acc[t][j], 0, 0, 0);
+                    if (kIssueSpread && nslab == 2) {
+                        const int grp = slab * PXW + j;                    // MFMA group of the stage: 0 .. 2 PXW - 1
+                        if (grp % kEvery == kEvery - 1 && grp / kEvery < kPieces) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (more) issue_piece(s + 1, grp / kEvery);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
             }
             continue;
         }

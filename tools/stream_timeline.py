@@ -84,3 +84,16 @@ if gaps and len(order) > 1:
         for b, e, n in sorted(streams[s]):
             if b < hi and e > lo:
                 print(f"  stream {s} {b / 1e3:7.3f} + {e - b:7.1f} us  {n[:100]}")
+
+if os.environ.get("TIMELINE_MAIN_TOP"):
+    # where the MAIN stream's time goes (it is the step's critical path: 96-100 % busy), by kernel and by phase (forward graph =
+    # before the first side-stream launch minus the decoder / criterion, which starts at the first kernel of the matcher)
+    import re
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for b, e, n in streams[main]:
+        k = re.sub(r"\(.*", "", n)[:90]
+        agg[k][0] += e - b
+        agg[k][1] += 1
+    print(f"\nmain stream by kernel (top {os.environ['TIMELINE_MAIN_TOP']}):")
+    for k, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(os.environ["TIMELINE_MAIN_TOP"])]:
+        print(f"{t / 1e3:7.3f} ms {c:4d} x  {k}")
