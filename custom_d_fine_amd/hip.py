@@ -12,7 +12,7 @@ from ctypes import c_float, c_int, c_int64, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdfine_hip.so")
+LIB_PATH = os.environ.get("DFINE_HIP_LIB") or os.path.join(_HERE, "csrc", "libdfine_hip.so")     # (override: A/B of two builds on one box)
 ABI_VERSION = 1
 
 if not os.path.exists(LIB_PATH):
