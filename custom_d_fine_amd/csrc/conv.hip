@@ -911,11 +911,11 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
     if (!kStream2 && nstage > 1) issue(1);
     for (int s = 0; s < nstage; ++s) {
         if (kStream2) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(kAbl & 4) || s < 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             const unsigned char *xs2 = lds + (s & 1) * SB, *ws2 = xs2 + XB;
             // (kIssueSpread, off: the copies of stage s + 1 spread over the MFMA groups of the stage, order pinned by sched_barrier)
-            const bool more = s + 1 < nstage;
+            const bool more = s + 1 < nstage && !((kAbl & 4) && s >= 1);
             constexpr int kPieces = XPW + NTN, kGroups = 2 * PXW, kEvery = kGroups / kPieces > 0 ? kGroups / kPieces : 1;
             if (more && !kIssueSpread) issue(s + 1);
             const int nslab = s * kG2Rows + 32 < KP ? 2 : 1;
@@ -927,6 +927,7 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
 #pragma unroll
                 for (int t = 0; t < NTN; ++t) {
                     const int row = wn * 16 * NTN + t * 16 + i16;
+                    if (kAbl & 2) { a1[t] = __builtin_bit_cast(bf16x8, make_uint4(row, lane, s, t)); continue; }
                     a1[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(ws2 + row * 128 + (((slab * 4 + g) ^ (row & 7)) << 4)));
                 }
                 const int r = slab * 32 + 4 * g + (i16 >> 2);
@@ -934,10 +935,18 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
 #pragma unroll
                 for (int j = 0; j < PXW; ++j) {
                     const int seg = ((wp * PXW + j) ^ (r & 7)) << 5;
+                    if (kAbl & 2) { b1[j] = __builtin_bit_cast(bf16x8, make_uint4(seg, lane, s, j)); continue; }
                     const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_v4s __attribute__((address_space(3))) *)(xr + seg));
                     const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_v4s __attribute__((address_space(3))) *)(xr + seg + 16 * XPITCH));
                     typedef short tr_v8s __attribute__((ext_vector_type(8)));
                     b1[j] = __builtin_bit_cast(bf16x8, (tr_v8s)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+                if (kAbl & 1) {                                   // fragments kept alive, no matrix work
+#pragma unroll
+                    for (int t = 0; t < NTN; ++t) asm volatile("" ::"v"(a1[t]));
+#pragma unroll
+                    for (int j = 0; j < PXW; ++j) asm volatile("" ::"v"(b1[j]));
+                    continue;
                 }
 #pragma unroll
                 for (int j = 0; j < PXW; ++j) {
