@@ -69,8 +69,13 @@ __device__ __forceinline__ void stage_rows(uint16_t *dst, int pitch, const uint1
 // mask value of 4 consecutive keys for one query: bit e set = blocked
 __device__ __forceinline__ uint32_t mask4(const uint8_t *mrow, int key, int L) {
     uint32_t m = 0;
-    if (((L | key) & 3) == 0 && key + 3 < L) {
-        const uint32_t w = *reinterpret_cast<const uint32_t *>(mrow + key);
+    if (key + 8 <= L) {
+        // 4 mask bytes at ANY alignment (rows of L bytes: L = 300 + denoising queries is a multiple of 4 only for every other
+        // target count): two aligned words and a funnel shift.  (The byte-wise path below costs 4 loads and 4 branches per
+        // 4 keys: forward 61 -> 104 us at L = 498.)  key + 8 <= L keeps the second word inside the row.
+        const uintptr_t a = reinterpret_cast<uintptr_t>(mrow + key);
+        const uint32_t *wp = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+        const uint32_t w = __funnelshift_r(wp[0], wp[1], (uint32_t)(a & 3) * 8u);
         m = ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) | ((w & 0xff000000u) ? 8u : 0u);
     } else {
 #pragma unroll

@@ -1362,6 +1362,7 @@ _LW_WS = {}
 
 _LW_GROUP = os.environ.get("DFINE_LINEAR_WGRAD_GROUP", "1") == "1"
 _CW_GROUP = os.environ.get("DFINE_CONV_WGRAD_GROUP", "1") == "1"
+_LW_GROUP_AT = int(os.environ.get("DFINE_LW_GROUP_AT", "0"))     # registered linears that trigger a grouped side-stream launch (0: twice the conv threshold)
 _CW_PENDING = []            # (x, dy, ws, B, Cin, Cout, HW): 1x1 convolution weight gradients registered since the last flush
 _LW_PENDING = []            # (x2d, dy2d, ws, M, N, K) registered since the last linear_wgrad_flush
 
@@ -1375,7 +1376,7 @@ def linear_wgrad_partials(x2d, dy2d):
     ws = torch.empty(int(_PURE.dfine_linear_wgrad_ws_floats(M, N, K)), device=x2d.device, dtype=torch.float32)
     if _LW_GROUP:
         _LW_PENDING.append((x2d, dy2d, ws, M, N, K))
-        if len(_LW_PENDING) >= 2 * _SIDE_GROUP_AT and _side_ok():
+        if len(_LW_PENDING) >= (_LW_GROUP_AT or 2 * _SIDE_GROUP_AT) and _side_ok():
             _flush_linear_group(True)
     else:
         with _timed("linear_wgrad", 2.0 * M * N * K, io=2.0 * M * (N + K) + 4.0 * N * K):

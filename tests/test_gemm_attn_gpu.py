@@ -90,7 +90,7 @@ def _attn_ref(q, k, v, mask, H):
     return o.transpose(1, 2).reshape(B, L, E)
 
 
-@pytest.mark.parametrize("B,L,masked", [(2, 496, True), (3, 400, False), (2, 77, True), (1, 900, False), (2, 300, True), (1, 1030, True)])
+@pytest.mark.parametrize("B,L,masked", [(2, 496, True), (3, 400, False), (2, 77, True), (1, 900, False), (2, 300, True), (1, 1030, True), (2, 498, True)])
 def test_attention_forward_backward(cuda, B, L, masked):
     from custom_d_fine_amd import hip
     H, E = 8, 256

@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--ms", type=float, default=1.0)
 ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--graph", type=int, default=0, help="1: backbone + encoder through the captured HIP graphs")
+ap.add_argument("--cuda-only", type=int, default=0, help="1: device activities only (the CPU-side tracer slows the host: the eager decoder stretch then looks host-bound)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 step = bench.build_step("m", 640, dev, torch.bfloat16)
@@ -21,14 +22,21 @@ images, targets = make_batch(32, 640, seed=42, device=dev)
 for _ in range(a.warmup):
     step(images, targets)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CUDA] if a.cuda_only else [ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step(images, targets)
+    if a.cuda_only:                  # three steps without a sync in between: the middle one runs with the host already ahead, as in steady state
+        step(images, targets)
+        step(images, targets)
     torch.cuda.synchronize()
 path = os.path.join(tempfile.mkdtemp(), "trace.json")
 prof.export_chrome_trace(path)
 ev = [e for e in json.load(open(path))["traceEvents"]
       if e.get("ph") == "X" and e.get("cat") in ("kernel", "gpu_memcpy", "gpu_memset")]
 ev.sort(key=lambda e: e["ts"])
+if a.cuda_only:
+    marks = [e["ts"] for e in ev if "stem_conv_s2_vec" in e["name"]]          # the first convolution of a step's forward pass
+    if len(marks) >= 3:
+        ev = [e for e in ev if marks[1] <= e["ts"] < marks[2]]
 t0 = ev[0]["ts"]
 t1 = max(e["ts"] + e["dur"] for e in ev)
 streams = collections.defaultdict(list)
@@ -97,3 +105,40 @@ if os.environ.get("TIMELINE_MAIN_TOP"):
     print(f"\nmain stream by kernel (top {os.environ['TIMELINE_MAIN_TOP']}):")
     for k, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(os.environ["TIMELINE_MAIN_TOP"])]:
         print(f"{t / 1e3:7.3f} ms {c:4d} x  {k}")
+
+if os.environ.get("TIMELINE_WINDOW"):
+    # kernels of the main stream inside a time window "a,b" (ms from the step's first kernel): e.g. the decoder + criterion stretch
+    wa, wb = (float(v) * 1e3 for v in os.environ["TIMELINE_WINDOW"].split(","))
+    import re
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    busy = 0.0
+    for b, e, n in streams[main]:
+        if b >= wa and e <= wb:
+            k = re.sub(r"\(.*", "", n)[:100]
+            agg[k][0] += e - b
+            agg[k][1] += 1
+            busy += e - b
+    print(f"\nmain stream inside {wa / 1e3:.1f} .. {wb / 1e3:.1f} ms: busy {busy / 1e3:.2f} ms, {sum(c for _, c in agg.values())} launches")
+    for k, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("TIMELINE_WINDOW_TOP", "40"))]:
+        print(f"{t / 1e3:7.3f} ms {c:4d} x  {k}")
+
+if os.environ.get("TIMELINE_AROUND"):
+    # every launch whose name contains the pattern, with the launches in front of it on ALL streams that overlap it
+    pat = os.environ["TIMELINE_AROUND"]
+    allev = sorted(((b, e, n, s) for s, iv in streams.items() for b, e, n in iv))
+    for b, e, n, s in allev:
+        if pat in n:
+            print(f"\n{n[:70]}  stream {s}  start {b / 1e3:8.3f} ms  dur {e - b:7.1f} us")
+            for b2, e2, n2, s2 in allev:
+                if (b2, e2, n2, s2) != (b, e, n, s) and b2 < e and e2 > b:
+                    print(f"      overlaps: stream {s2} {b2 / 1e3:8.3f} + {e2 - b2:7.1f} us  {n2[:80]}")
+
+if os.environ.get("TIMELINE_LONGEST"):
+    # the longest launches of the main stream with what ran beside them (pathological sharing shows up here: a latency-bound
+    # kernel of 256 fat workgroups behind a grouped weight-gradient launch that holds every CU)
+    allev = sorted(((b, e, n, s) for s, iv in streams.items() for b, e, n in iv))
+    for b, e, n in sorted(streams[main], key=lambda x: x[0] - x[1])[:int(os.environ["TIMELINE_LONGEST"])]:
+        print(f"\n{e - b:7.1f} us at {b / 1e3:7.3f} ms  {n[:90]}")
+        for b2, e2, n2, s2 in allev:
+            if s2 != main and b2 < e and e2 > b:
+                print(f"      beside: stream {s2} {b2 / 1e3:8.3f} + {e2 - b2:7.1f} us  {n2[:80]}")
