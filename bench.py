@@ -55,7 +55,7 @@ KERNEL_GROUPS = (
     ("conv3x3", r"dfine::(conv_igemm_kernel<3|conv3x3_ws_kernel|conv3x3_rows32_kernel)"),
     ("conv1x1_wgrad", r"dfine::(conv_wgrad1_glds_kernel|conv_wgrad1_group_kernel|conv_wgrad_kernel<1>)"),
     ("conv3x3_wgrad", r"dfine::(conv_wgrad_kernel<3>|conv_wgrad3_)"),
-    ("stem", r"dfine::stem_(conv|mfma|dgrad|wgrad)"),
+    ("stem", r"dfine::(stem_(conv|mfma|dgrad|wgrad)|stem3_(fwd|bwd)_rows)"),
     ("wgrad_reduce", r"dfine::(multi_wgrad_reduce_kernel|conv_wgrad_reduce_kernel)"),
     ("linear_wgrad", r"dfine::linear_wgrad"),
     ("linear+attention", r"dfine::(linear_(act|ring)_kernel|attn_)"),

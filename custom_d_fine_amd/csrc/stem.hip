@@ -21,6 +21,12 @@
 namespace dfine {
 
 constexpr int kStemThreads = 256;
+
+// stem3.hip: the 3x3 / stride-2 layer over a two-tensor input on the matrix cores (DFINE_E_BADARG = shape not served)
+int stem3_fwd_rows(const uint16_t *xa, const uint16_t *xb, int Ca, const float *wp, uint16_t *y, int B, int Cin, int Cout, int H, int W,
+                   int Ho, int Wo, hipStream_t st);
+int stem3_bwd_rows(const uint16_t *dy, const float *wq, uint16_t *dxa, uint16_t *dxb, int Ca, int B, int Cin, int Cout, int Ho, int Wo,
+                   hipStream_t st);
 typedef __attribute__((ext_vector_type(8))) __bf16 stem_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float stem_f32x4;
 
@@ -836,6 +842,10 @@ static int stem_conv_impl(const void *x, const void *x2, int ca, const float *wp
     if (B == 0) return DFINE_OK;
     if (!x || !wp || !y || H < 1 || W < 1 || Ho < 1 || Wo < 1) return DFINE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    if (x2 && KS == 3 && stride == 2 && pad == 1) {      // stem3 on the matrix cores, streaming rows (stem3.hip); other shapes fall through
+        const int r = stem3_fwd_rows((const uint16_t *)x, (const uint16_t *)x2, ca, wp, (uint16_t *)y, B, Cin, Cout, H, W, Ho, Wo, st);
+        if (r != DFINE_E_BADARG) return r;
+    }
     const uint16_t *xs = (const uint16_t *)x;
     const uint16_t *xs2 = (const uint16_t *)x2;
     uint16_t *ys = (uint16_t *)y;
@@ -912,6 +922,10 @@ static int stem_dgrad_impl(const void *dy, const float *wq, void *dx, void *dx2,
     if (B == 0) return DFINE_OK;
     if (!dy || !wq || !dx || Ho < 1 || Wo < 1) return DFINE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    if (dx2) {
+        const int r = stem3_bwd_rows((const uint16_t *)dy, wq, (uint16_t *)dx, (uint16_t *)dx2, ca, B, Cin, Cout, Ho, Wo, st);
+        if (r != DFINE_E_BADARG) return r;
+    }
     const int bt = Wo >= kStemThreads ? kStemThreads : (Wo + 63) / 64 * 64;       // e.g. Wo = 160 -> 192 threads
     dim3 grid((Wo + bt - 1) / bt, 2 * Ho, B);
 #define STEM_DG(CI, CO)                                                                                         \

@@ -130,5 +130,35 @@ def test_stem_conv_two_sources_matches_concatenated_input(cuda, ca, cb, cout, hw
     yr.backward(go)
     assert torch.equal(y, yr)
     assert xa.grad.is_contiguous() and xb.grad.is_contiguous()
-    assert torch.equal(xa.grad, xc.grad[:, :ca]) and torch.equal(xb.grad, xc.grad[:, ca:])
+    # the two-tensor data gradient runs on the matrix cores with bf16-rounded weights (csrc/stem3.hip), the single-tensor one
+    # on fp32 FMAs: equal to bf16 rounding of the result, not bit for bit
+    tol = 2 ** -6 * xc.grad.float().abs().max()
+    assert (xa.grad.float() - xc.grad[:, :ca].float()).abs().max() <= tol
+    assert (xb.grad.float() - xc.grad[:, ca:].float()).abs().max() <= tol
     assert _rel(w.grad, wr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("ch,cout,B,hw", [(24, 24, 2, (32, 320)), (24, 24, 1, (320, 320)), (16, 16, 2, (24, 160)), (32, 32, 2, (20, 480)),
+                                          (24, 24, 3, (6, 160))])
+def test_stem3_row_streaming_kernels_vs_fp32_reference(cuda, ch, cout, B, hw):
+    """csrc/stem3.hip (forward: output widths that are multiples of 80; data gradient: multiples of 16) against fp32 conv2d /
+    conv_transpose2d on the same bf16 inputs with the weights rounded to bf16 (what the kernels multiply with); results are
+    rounded to bf16 once: 2^-7 of the largest magnitude.  Includes image borders, band borders and the 80-column block seams."""
+    import torch.nn.functional as F
+    from custom_d_fine_amd import hip
+    torch.manual_seed(ch + hw[1])
+    H, W = hw
+    xa = torch.randn(B, ch, H, W, device=cuda).bfloat16()
+    xb = torch.randn(B, ch, H, W, device=cuda).bfloat16()
+    w = torch.randn(cout, 2 * ch, 3, 3, device=cuda) / (2 * ch * 9) ** 0.5
+    wr = w.bfloat16().float()
+    y = hip.stem_conv2(xa, xb, hip.stem_pack_weights(w, 0), cout, 3, 2, 1, (H // 2, W // 2))
+    yr = F.conv2d(torch.cat([xa, xb], 1).float(), wr, stride=2, padding=1)
+    assert y.shape == yr.shape
+    assert (y.float() - yr).abs().max() <= 2 ** -7 * yr.abs().max()
+    go = torch.randn(B, cout, H // 2, W // 2, device=cuda).bfloat16()
+    dxa, dxb = hip.stem_dgrad_s2_2(go, hip.stem_pack_weights(w, 2), ch, ch)
+    dr = F.conv_transpose2d(go.float(), wr, stride=2, padding=1, output_padding=1)
+    assert dxa.shape == xa.shape and dxb.shape == xb.shape
+    tol = 2 ** -7 * dr.abs().max()
+    assert (dxa.float() - dr[:, :ch]).abs().max() <= tol and (dxb.float() - dr[:, ch:]).abs().max() <= tol

@@ -8,7 +8,7 @@ from custom_d_fine_amd.dl.synthetic import make_batch
 FAMILIES = (("gn_", "mask: groupnorm"), ("bilinear_", "mask: bilinear"), ("mask_", "mask: losses / costs"), ("conv1x1", "conv1x1 fwd/dgrad"), ("conv_wgrad1_glds", "conv wgrad 1x1"), ("conv_wgrad1_group", "conv wgrad 1x1"), ("conv_wgrad_kernel<1>", "conv wgrad 1x1"),
             ("conv_wgrad_kernel<3>", "conv wgrad 3x3"), ("conv_wgrad_reduce", "wgrad reduce"), ("conv_igemm", "conv3x3 fwd/dgrad"), ("conv3x3_ws", "conv3x3 fwd/dgrad"), ("conv3x3_rows32", "conv3x3 fwd/dgrad"), ("conv_wgrad3_rows", "conv wgrad 3x3"), ("multi_wgrad_reduce", "wgrad reduce"), ("fx_", "msda"), ("cast_f16acc", "msda"),
             ("dfine::bn_", "bn"), ("msda", "msda"), ("cast_f32_bf16", "msda"), ("linear_act", "linear_act"), ("linear_ring", "linear_act"), ("act_", "linear_act"),
-            ("linear_wgrad", "linear_wgrad"), ("attn_", "attention"), ("stem_", "stem"), ("dwconv", "dwconv"), ("ln_fused", "ln"),
+            ("linear_wgrad", "linear_wgrad"), ("attn_", "attention"), ("stem_", "stem"), ("stem3_", "stem"), ("dwconv", "dwconv"), ("ln_fused", "ln"),
             ("dfine::", "HIP other"), ("Cijk", "hipBLASLt"), ("igemm", "MIOpen"), ("batched_transpose", "MIOpen"), ("CatArray", "ATen cat"),
             ("FillFunctor", "ATen fill"), ("copy", "ATen copy/cast"), ("Memcpy", "ATen copy/cast"), ("CUDAFunctor_add", "ATen add"),
             ("at::native", "ATen other"))
