@@ -28,6 +28,10 @@ typedef __attribute__((ext_vector_type(4))) float s3_f32x4;
 
 constexpr int kS3Threads = 256;
 constexpr int kS3OutCols = 80;               // output columns per workgroup (forward)
+#ifndef DFINE_S3_PAD
+#define DFINE_S3_PAD 16
+#endif
+constexpr int kS3Pad = DFINE_S3_PAD;
 
 // 8 x 8 transpose of 8 channel rows (16 bytes = 8 pixels each) into 8 pixel vectors of 8 channels
 __device__ __forceinline__ void s3_transpose8(const uint4 (&pf)[8], uint4 (&o)[8]) {
@@ -55,7 +59,10 @@ __global__ __launch_bounds__(kS3Threads) void stem3_fwd_rows_kernel(const S3FwdA
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int K32 = CIN / 32, K16 = (CIN % 32) / 16, NT = (COUT + 15) / 16, CG = CIN / 8, CH = CIN / 2;
     constexpr int RB = CIN * 2;                                        // bytes per pixel record
-    constexpr int IW = 2 * kS3OutCols, REC = IW + 1, SLOT = REC * RB;  // record 0 = the column left of the block
+    // record 0 = the column left of the block.  16 bytes of padding behind every 8 records: the staging writes of a wave go to the
+    // same pixel of DIFFERENT 8-pixel chunks, 8 records = 768 bytes apart - an even number of 16-byte units, i.e. the same banks
+    constexpr int IW = 2 * kS3OutCols, REC = IW + 1, SLOT = REC * RB + (REC / 8 + 1) * kS3Pad;
+    auto recoff = [](int rec) -> int { return rec * RB + (rec >> 3) * kS3Pad; };
     constexpr int NCHUNK = IW / 8 + 1;                                 // 8-pixel chunks per row, chunk 0 = the halo's
     constexpr int OP = 24;                                             // output staging pitch (elements)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
@@ -75,15 +82,16 @@ __global__ __launch_bounds__(kS3Threads) void stem3_fwd_rows_kernel(const S3FwdA
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int co = nt * 16 + i16;
+            const int co = nt * 16 + i16, coc = co < COUT ? co : COUT - 1;      // (clamped loads + select: no divergent branches)
+            const bool cok = co < COUT;
 #pragma unroll
             for (int s = 0; s < K32; ++s) {
                 uint32_t p[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int ci = s * 32 + 8 * g + 2 * e;
-                    const float w0 = co < COUT ? a.wp[(ci * 9 + t) * COUT + co] : 0.f, w1 = co < COUT ? a.wp[((ci + 1) * 9 + t) * COUT + co] : 0.f;
-                    p[e] = pack_bf16x2(w0, w1);
+                    const float w0 = a.wp[(ci * 9 + t) * COUT + coc], w1 = a.wp[((ci + 1) * 9 + t) * COUT + coc];
+                    p[e] = cok ? pack_bf16x2(w0, w1) : 0u;
                 }
                 aw[t][s][nt] = make_uint4(p[0], p[1], p[2], p[3]);
             }
@@ -93,8 +101,8 @@ __global__ __launch_bounds__(kS3Threads) void stem3_fwd_rows_kernel(const S3FwdA
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int ci = K32 * 32 + s * 16 + 4 * g + 2 * e;
-                    const float w0 = co < COUT ? a.wp[(ci * 9 + t) * COUT + co] : 0.f, w1 = co < COUT ? a.wp[((ci + 1) * 9 + t) * COUT + co] : 0.f;
-                    p[e] = pack_bf16x2(w0, w1);
+                    const float w0 = a.wp[(ci * 9 + t) * COUT + coc], w1 = a.wp[((ci + 1) * 9 + t) * COUT + coc];
+                    p[e] = cok ? pack_bf16x2(w0, w1) : 0u;
                 }
                 at[t][s][nt] = make_uint2(p[0], p[1]);
             }
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(kS3Threads) void stem3_fwd_rows_kernel(const S3FwdA
                 *reinterpret_cast<uint4 *>(d) = o[7];                  // record 0 = column c0 - 1 (only the last pixel of the chunk is kept)
             } else {
 #pragma unroll
-                for (int pix = 0; pix < 8; ++pix) *reinterpret_cast<uint4 *>(d + (1 + (chunk - 1) * 8 + pix) * RB) = o[pix];
+                for (int pix = 0; pix < 8; ++pix) *reinterpret_cast<uint4 *>(d + recoff(1 + (chunk - 1) * 8 + pix)) = o[pix];
             }
         }
     };
@@ -154,12 +162,13 @@ __global__ __launch_bounds__(kS3Threads) void stem3_fwd_rows_kernel(const S3FwdA
             s3_f32x4 acc[NT], acc2[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { acc[nt] = s3_f32x4{0.f, 0.f, 0.f, 0.f}; acc2[nt] = s3_f32x4{0.f, 0.f, 0.f, 0.f}; }
-            const int rec = 2 * (t * 16 + i16) * RB;
+            const int rec0 = 2 * (t * 16 + i16);
+            const int roff[3] = {recoff(rec0), recoff(rec0 + 1), recoff(rec0 + 2)};
 #pragma unroll
             for (int kr = 0; kr < 3; ++kr)
 #pragma unroll
                 for (int kc = 0; kc < 3; ++kc) {
-                    const unsigned char *p = rows[kr] + rec + kc * RB;
+                    const unsigned char *p = rows[kr] + roff[kc];
 #pragma unroll
                     for (int s = 0; s < K32; ++s) {
                         const s3_bf16x8 bv = __builtin_bit_cast(s3_bf16x8, *reinterpret_cast<const uint4 *>(p + s * 64 + g * 16));
@@ -223,9 +232,9 @@ __global__ __launch_bounds__(kS3Threads) void stem3_bwd_rows_kernel(const S3BwdA
             uint32_t p[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int co = 8 * g + 2 * e;
-                const float w0 = co < COUT ? a.wq[(co * 9 + t) * CIN + ci] : 0.f, w1 = co + 1 < COUT ? a.wq[((co + 1) * 9 + t) * CIN + ci] : 0.f;
-                p[e] = pack_bf16x2(w0, w1);
+                const int co = 8 * g + 2 * e, c0c = co < COUT ? co : COUT - 1, c1c = co + 1 < COUT ? co + 1 : COUT - 1;
+                const float w0 = a.wq[(c0c * 9 + t) * CIN + ci], w1 = a.wq[(c1c * 9 + t) * CIN + ci];
+                p[e] = pack_bf16x2(co < COUT ? w0 : 0.f, co + 1 < COUT ? w1 : 0.f);
             }
             aw[t][nt] = make_uint4(p[0], p[1], p[2], p[3]);
         }
@@ -319,13 +328,14 @@ static int stem3_fwd_launch(const uint16_t *xa, const uint16_t *xb, const float 
     S3FwdArgs a;
     a.xa = xa; a.xb = xb; a.wp = wp; a.y = y; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
     a.cblocks = Wo / kS3OutCols;
-    int bands = (512 + B * a.cblocks - 1) / (B * a.cblocks);           // ~512 workgroups: two per CU
+    static const int wgs = [] { const char *e = getenv("DFINE_STEM3_WGS"); return e ? atoi(e) : 512; }();
+    int bands = (wgs + B * a.cblocks - 1) / (B * a.cblocks);           // ~512 workgroups: two per CU
     if (bands > (Ho + 7) / 8) bands = (Ho + 7) / 8;                    // at least 8 output rows each (one halo row pair per band)
     if (bands < 1) bands = 1;
     a.rpb = (Ho + bands - 1) / bands;
     a.bands = (Ho + a.rpb - 1) / a.rpb;
     constexpr int NT = (COUT + 15) / 16;
-    const size_t ldsb = (size_t)4 * (2 * kS3OutCols + 1) * CIN * 2 + 4 * 16 * NT * 24 * 2;
+    const size_t ldsb = (size_t)4 * ((2 * kS3OutCols + 1) * CIN * 2 + ((2 * kS3OutCols + 1) / 8 + 1) * kS3Pad) + 4 * 16 * NT * 24 * 2;
     static bool attr_set = false;                     // once: not a stream operation, keep it out of graph capture
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stem3_fwd_rows_kernel<CIN, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -350,7 +360,8 @@ template <int CIN, int COUT>
 static int stem3_bwd_launch(const uint16_t *dy, const float *wq, uint16_t *dxa, uint16_t *dxb, int B, int Ho, int Wo, hipStream_t st) {
     S3BwdArgs a;
     a.dy = dy; a.wq = wq; a.dxa = dxa; a.dxb = dxb; a.Ho = Ho; a.Wo = Wo;
-    int bands = (512 + B - 1) / B;
+    static const int wgs = [] { const char *e = getenv("DFINE_STEM3_WGS"); return e ? atoi(e) : 512; }();
+    int bands = (wgs + B - 1) / B;
     if (bands > (Ho + 7) / 8) bands = (Ho + 7) / 8;
     if (bands < 1) bands = 1;
     a.rpb = (Ho + bands - 1) / bands;
