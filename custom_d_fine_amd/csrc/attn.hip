@@ -90,10 +90,12 @@ template <int QT>
 __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const uint16_t *__restrict__ q, const uint16_t *__restrict__ k,
                                                                 const uint16_t *__restrict__ v, uint16_t *__restrict__ o,
                                                                 float *__restrict__ lse2, const uint8_t *__restrict__ mask,
+                                                                const uint8_t *__restrict__ msum,
                                                                 int B, int L, int H, int ldq, int ldk, int ldv, int ldo,
                                                                 float scale_log2e) {
     __shared__ __attribute__((aligned(16))) uint16_t sK[kKB * kP40];
     __shared__ __attribute__((aligned(16))) uint16_t sV[kKB * kP48];
+    const int nk64 = (L + 63) >> 6, nq16 = (L + 15) >> 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
     const int bh = blockIdx.x % (B * H), qblk = blockIdx.x / (B * H);        // blocks of one (b, h) share an XCD (L2 reuse of K, V)
     const int b = bh / H, h = bh - b * H;
@@ -119,18 +121,41 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const uint16_t *
 
     for (int k0 = 0; k0 < L; k0 += kKB) {
         const int valid = min(kKB, L - k0);
+        // mask summary (attn_mask_summary_kernel): a (16 queries x 64 keys) tile is free (0), mixed (1) or blocked (2).  A blocked
+        // tile changes nothing (every p is 0): skipped - by the whole workgroup (no staging) when all its query tiles are
+        // blocked, else by the wave; a free tile runs without the mask loads.  The denoising mask of the decoder
+        // (dfine_decoder.py:200, arch/utils.py:442-455) is block-structured: ~25 % of the tiles are blocked, ~60 % free.
+        int code[QT];
+        if (msum) {
+            bool all_blocked = true;
+#pragma unroll
+            for (int w = 0; w < 4 * QT; ++w) {
+                const int q16 = qblk * 4 * QT + w;
+                all_blocked = all_blocked && (q16 >= nq16 || msum[q16 * nk64 + (k0 >> 6)] == 2);
+            }
+            if (all_blocked) continue;                                   // uniform over the workgroup
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const int q16 = qblk * 4 * QT + t * 4 + wave;
+                code[t] = q16 >= nq16 ? 2 : msum[q16 * nk64 + (k0 >> 6)];
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < QT; ++t) code[t] = mask ? 1 : 0;
+        }
         __syncthreads();
         stage_rows(sK, kP40, kb_ + (int64_t)k0 * ldk, ldk, kKB, valid, tid);
         stage_rows(sV, kP48, vb + (int64_t)k0 * ldv, ldv, kKB, valid, tid);
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
+            if (code[t] == 2) continue;                                  // (wave-uniform)
             a_f32x4 s[kKB / 16];
 #pragma unroll
             for (int kt = 0; kt < kKB / 16; ++kt)
                 s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(sK + (kt * 16 + i16) * kP40 + 8 * g), qf[t],
                                                                 a_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            const uint8_t *mrow = mask ? mask + (int64_t)min(qrow[t], L - 1) * L : nullptr;
+            const uint8_t *mrow = code[t] == 1 ? mask + (int64_t)min(qrow[t], L - 1) * L : nullptr;
             float bmax = NEG;
 #pragma unroll
             for (int kt = 0; kt < kKB / 16; ++kt) {
@@ -196,7 +221,8 @@ template <int QT>
 __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const uint16_t *__restrict__ q, const uint16_t *__restrict__ k,
                                                                    const uint16_t *__restrict__ v, const uint16_t *__restrict__ o,
                                                                    const uint16_t *__restrict__ dout, const float *__restrict__ lse2,
-                                                                   const uint8_t *__restrict__ mask, uint16_t *__restrict__ dq,
+                                                                   const uint8_t *__restrict__ mask, const uint8_t *__restrict__ msum,
+                                                                   uint16_t *__restrict__ dq,
                                                                    float *__restrict__ delta, int B, int L, int H, int ldq, int ldk,
                                                                    int ldv, int ldo, int lddo, int lddq, float scale, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) uint16_t sK[kKB * kP48];          // 16-byte fragment reads AND transpose-reads
@@ -236,15 +262,35 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const uint16_
     }
     const int tr_off = (4 * g + (i16 >> 2)) * kP48 + 4 * (i16 & 3);
 
+    const int nk64 = (L + 63) >> 6, nq16 = (L + 15) >> 4;
     for (int k0 = 0; k0 < L; k0 += kKB) {
         const int valid = min(kKB, L - k0);
+        int code[QT];                                                    // mask summary of the tile: see attn_fwd_kernel (a blocked tile adds 0 to dQ)
+        if (msum) {
+            bool all_blocked = true;
+#pragma unroll
+            for (int w = 0; w < 4 * QT; ++w) {
+                const int q16 = qblk * 4 * QT + w;
+                all_blocked = all_blocked && (q16 >= nq16 || msum[q16 * nk64 + (k0 >> 6)] == 2);
+            }
+            if (all_blocked) continue;
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const int q16 = qblk * 4 * QT + t * 4 + wave;
+                code[t] = q16 >= nq16 ? 2 : msum[q16 * nk64 + (k0 >> 6)];
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < QT; ++t) code[t] = mask ? 1 : 0;
+        }
         __syncthreads();
         stage_rows(sK, kP48, kb_ + (int64_t)k0 * ldk, ldk, kKB, valid, tid);
         stage_rows(sV, kP40, vb + (int64_t)k0 * ldv, ldv, kKB, valid, tid);
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            const uint8_t *mrow = mask ? mask + (int64_t)min(qrow[t], L - 1) * L : nullptr;
+            if (code[t] == 2) continue;
+            const uint8_t *mrow = code[t] == 1 ? mask + (int64_t)min(qrow[t], L - 1) * L : nullptr;
             uint32_t pk[kKB / 16][2];
 #pragma unroll
             for (int kt = 0; kt < kKB / 16; ++kt) {
@@ -301,6 +347,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const uint16_t *
                                                                      const uint16_t *__restrict__ v, const uint16_t *__restrict__ dout,
                                                                      const float *__restrict__ lse2, const float *__restrict__ delta,
                                                                      const uint8_t *__restrict__ mask, const uint32_t *__restrict__ mbits,
+                                                                     const uint8_t *__restrict__ msumT /* [64-key group][32-query chunk] */,
                                                                      uint16_t *__restrict__ dk,
                                                                      uint16_t *__restrict__ dv, int B, int L, int H, int ldq, int ldk,
                                                                      int ldv, int lddo, int lddk, int lddv, float scale,
@@ -347,8 +394,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const uint16_t *
     uint32_t mw[KT], mwn[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) { mw[kt] = 0u; mwn[kt] = 0u; }
+    int code_next = 1, code = 1;                                          // tile summary of the staged / the current chunk
     auto mask_load = [&](int chunk) {
         if (MM != 2) return;
+        if (KT == 4 && msumT && kw0 < L) code_next = msumT[(kw0 >> 6) * ((L + 31) >> 5) + chunk];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             const int key = kw0 + kt * 16 + i16;
@@ -393,9 +442,17 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const uint16_t *
         if (MM == 2) {
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) mw[kt] = mwn[kt];
+            code = code_next;
         }
         if (more) stage_load(q0 + 32);
         if (!wave_live) { if (more) stage_store(buf ^ 1); continue; }
+        if (KT == 4 && msumT && MM == 2) {                                // this wave's 64 keys x the chunk's 32 queries: blocked -> adds nothing
+            if (code == 2) { if (more) stage_store(buf ^ 1); continue; }  // (the summary byte came with the chunk's mask words)
+            if (code == 0 && MM == 2) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) mw[kt] = 0u;
+            }
+        }
         const uint16_t *tq = sQ[buf], *tdo = sDO[buf];
         uint32_t pp[KT][2], dsp[KT][2];                                       // bf16 pairs: [key tile][query tile] -> (r0 r1, r2 r3)
         uint32_t pp2[KT][2], dsp2[KT][2];
@@ -469,6 +526,34 @@ __global__ void attn_mask_bits_kernel(const uint8_t *__restrict__ mask, uint32_t
     bits[(int64_t)key * W32 + w] = word;
 }
 
+// Tile summaries of a [L, L] mask: A[q16][k64] for the forward / dQ kernels (16 queries x 64 keys), T[k64][q32] for the dK / dV
+// kernel (64 keys x 32 queries): 0 = nothing blocked, 2 = everything blocked (positions past L do not count), 1 = mixed.
+__global__ __launch_bounds__(64) void attn_mask_summary_kernel(const uint8_t *__restrict__ mask, uint8_t *__restrict__ sumA,
+                                                               uint8_t *__restrict__ sumT, int L) {
+    const int nq16 = (L + 15) >> 4, nk64 = (L + 63) >> 6, nq32 = (L + 31) >> 5;
+    const int i = blockIdx.x, lane = threadIdx.x;                  // one wave per tile, lane = key column of the tile
+    int qa, qb, ka;
+    uint8_t *dst;
+    if (i < nq16 * nk64) {
+        const int q16 = i / nk64, k64 = i - q16 * nk64;
+        qa = q16 * 16; qb = qa + 16; ka = k64 * 64; dst = sumA + i;
+    } else {
+        const int j = i - nq16 * nk64, k64 = j / nq32, q32 = j - k64 * nq32;
+        qa = q32 * 32; qb = qa + 32; ka = k64 * 64; dst = sumT + j;
+    }
+    qb = min(qb, L);
+    bool any_blocked = false, any_free = false;
+    const int k = ka + lane;
+    if (k < L)
+        for (int q = qa; q < qb; ++q) {
+            const bool bl = mask[(int64_t)q * L + k] != 0;
+            any_blocked = any_blocked || bl;
+            any_free = any_free || !bl;
+        }
+    const bool ab = __any(any_blocked), af = __any(any_free);
+    if (lane == 0) *dst = af ? (ab ? 1 : 0) : 2;
+}
+
 }  // namespace dfine
 
 using namespace dfine;
@@ -481,15 +566,39 @@ static bool attn_args_ok(int B, int L, int H, int hd, const int *lds_, int n) {
     return true;
 }
 
+static size_t mask_summary_t_offset(int L) { return (size_t)(((L + 15) >> 4) * ((L + 63) >> 6) + 15) / 16 * 16; }
+
+int64_t dfine_attn_mask_summary_bytes(int L) { return (int64_t)mask_summary_t_offset(L) + ((L + 63) >> 6) * ((L + 31) >> 5); }
+
+// sum: dfine_attn_mask_summary_bytes(L) bytes - the tile summaries of `mask` for dfine_attn_fwd_ms / dfine_attn_bwd_ms
+int dfine_attn_mask_summary(const uint8_t *mask, int L, uint8_t *sum, void *stream) {
+    if (L == 0) return DFINE_OK;
+    if (!mask || !sum || L < 0) return DFINE_E_BADARG;
+    const int n = ((L + 15) >> 4) * ((L + 63) >> 6) + ((L + 63) >> 6) * ((L + 31) >> 5);
+    hipLaunchKernelGGL(attn_mask_summary_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, mask, sum,
+                       sum + mask_summary_t_offset(L), L);
+    return check_launch();
+}
+
+int dfine_attn_fwd_ms(const void *q, const void *k, const void *v, void *o, float *lse2, const uint8_t *mask, const uint8_t *mask_summary,
+                      int B, int L, int H, int hd, int ldq, int ldk, int ldv, int ldo, float scale, void *stream);
+
 int dfine_attn_fwd(const void *q, const void *k, const void *v, void *o, float *lse2, const uint8_t *mask, int B, int L, int H,
                    int hd, int ldq, int ldk, int ldv, int ldo, float scale, void *stream) {
+    return dfine_attn_fwd_ms(q, k, v, o, lse2, mask, nullptr, B, L, H, hd, ldq, ldk, ldv, ldo, scale, stream);
+}
+
+// mask_summary (optional, with mask): dfine_attn_mask_summary of the same mask - blocked tiles are skipped, free ones run unmasked
+int dfine_attn_fwd_ms(const void *q, const void *k, const void *v, void *o, float *lse2, const uint8_t *mask, const uint8_t *mask_summary,
+                      int B, int L, int H, int hd, int ldq, int ldk, int ldv, int ldo, float scale, void *stream) {
     if (B == 0 || L == 0) return DFINE_OK;
+    const uint8_t *msum = mask ? mask_summary : nullptr;
     const int lds_[4] = {ldq, ldk, ldv, ldo};
     if (!q || !k || !v || !o || !attn_args_ok(B, L, H, hd, lds_, 4)) return DFINE_E_BADARG;
     const float c = scale * 1.44269504088896340736f;
     const int nq = (L + 63) / 64;
     hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(B * H * nq), dim3(kAttnThreads), 0, (hipStream_t)stream, (const uint16_t *)q,
-                       (const uint16_t *)k, (const uint16_t *)v, (uint16_t *)o, lse2, mask, B, L, H, ldq, ldk, ldv, ldo, c);
+                       (const uint16_t *)k, (const uint16_t *)v, (uint16_t *)o, lse2, mask, msum, B, L, H, ldq, ldk, ldv, ldo, c);
     return check_launch();
 }
 
@@ -504,10 +613,25 @@ int dfine_attn_mask_bits(const uint8_t *mask, int L, uint32_t *bits, void *strea
     return check_launch();
 }
 
+int dfine_attn_bwd_ms(const void *q, const void *k, const void *v, const void *o, const void *dout, const float *lse2,
+                      const uint8_t *mask, const uint32_t *mask_bits, const uint8_t *mask_summary, void *dq, void *dk, void *dv, float *delta,
+                      int B, int L, int H, int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale,
+                      void *stream);
+
 int dfine_attn_bwd(const void *q, const void *k, const void *v, const void *o, const void *dout, const float *lse2,
                    const uint8_t *mask, const uint32_t *mask_bits, void *dq, void *dk, void *dv, float *delta, int B, int L, int H,
                    int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale, void *stream) {
+    return dfine_attn_bwd_ms(q, k, v, o, dout, lse2, mask, mask_bits, nullptr, dq, dk, dv, delta, B, L, H, hd, ldq, ldk, ldv, ldo, lddo,
+                             lddq, lddk, lddv, scale, stream);
+}
+
+int dfine_attn_bwd_ms(const void *q, const void *k, const void *v, const void *o, const void *dout, const float *lse2,
+                      const uint8_t *mask, const uint32_t *mask_bits, const uint8_t *mask_summary, void *dq, void *dk, void *dv, float *delta,
+                      int B, int L, int H, int hd, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale,
+                      void *stream) {
     if (B == 0 || L == 0) return DFINE_OK;
+    const uint8_t *msum = mask ? mask_summary : nullptr;
+    const uint8_t *msumT = (msum && mask_bits) ? msum + mask_summary_t_offset(L) : nullptr;
     const int lds_[8] = {ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv};
     if (!q || !k || !v || !o || !dout || !lse2 || !dq || !dk || !dv || !delta || !attn_args_ok(B, L, H, hd, lds_, 8))
         return DFINE_E_BADARG;
@@ -515,7 +639,7 @@ int dfine_attn_bwd(const void *q, const void *k, const void *v, const void *o, c
     hipStream_t st = (hipStream_t)stream;
     const int nq = (L + 63) / 64;
     hipLaunchKernelGGL(attn_bwd_dq_kernel<1>, dim3(B * H * nq), dim3(kAttnThreads), 0, st, (const uint16_t *)q, (const uint16_t *)k,
-                       (const uint16_t *)v, (const uint16_t *)o, (const uint16_t *)dout, lse2, mask, (uint16_t *)dq, delta, B, L, H,
+                       (const uint16_t *)v, (const uint16_t *)o, (const uint16_t *)dout, lse2, mask, msum, (uint16_t *)dq, delta, B, L, H,
                        ldq, ldk, ldv, ldo, lddo, lddq, scale, c);
     if (int e = check_launch()) return e;
     // keys per workgroup: 512 (<4, 8>, <8, 4>), 256 (<2, 8>), 128 (<2, 4>): fewer keys = more workgroups for the same L
@@ -523,7 +647,7 @@ int dfine_attn_bwd(const void *q, const void *k, const void *v, const void *o, c
 #define DFINE_DKDV_M(KT_, NW_, MM_)                                                                                                    \
     { const int nk = (L + 16 * KT_ * NW_ - 1) / (16 * KT_ * NW_);                                                                      \
       hipLaunchKernelGGL((attn_bwd_dkdv_kernel<KT_, NW_, MM_>), dim3(B * H * nk), dim3(64 * NW_), 0, st, (const uint16_t *)q, (const uint16_t *)k, \
-                         (const uint16_t *)v, (const uint16_t *)dout, lse2, (const float *)delta, mask, mask_bits, (uint16_t *)dk, (uint16_t *)dv, \
+                         (const uint16_t *)v, (const uint16_t *)dout, lse2, (const float *)delta, mask, mask_bits, msumT, (uint16_t *)dk, (uint16_t *)dv, \
                          B, L, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, c); }
 #define DFINE_DKDV(KT_, NW_) { if (!mask) DFINE_DKDV_M(KT_, NW_, 0) else if (mask_bits) DFINE_DKDV_M(KT_, NW_, 2) else DFINE_DKDV_M(KT_, NW_, 1) }
     if (var == 84) DFINE_DKDV(8, 4) else if (var == 28) DFINE_DKDV(2, 8) else if (var == 44) DFINE_DKDV(4, 4) else if (var == 24) DFINE_DKDV(2, 4)

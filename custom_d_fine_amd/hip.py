@@ -106,6 +106,10 @@ _SIGNATURES = {
     "dfine_attn_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "dfine_attn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                                _F, _P]),
+    "dfine_attn_mask_summary_bytes": (_L, [_I]),
+    "dfine_attn_mask_summary": (c_int, [_P, _I, _P, _P]),
+    "dfine_attn_fwd_ms": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "dfine_attn_bwd_ms": (c_int, [_P] * 13 + [_I] * 12 + [_F, _P]),
     "dfine_attn_mask_bits_words": (_L, [_I]),
     "dfine_attn_mask_bits": (c_int, [_P, _I, _P, _P]),
     "dfine_groupnorm_ws_floats": (_L, [_I, _I, _I]),
@@ -1305,18 +1309,19 @@ def attn_forward(q, k, v, num_heads, mask=None):
     -> o [B, L, H * hd] bf16, lse2 [B, H, L]."""
     B, L, E = q.shape
     hd = E // num_heads
+    msum = None if mask is None else _mask_forms(mask)[1]
     if hd != 32:
         qp, kp, vp = (_pad_heads(t, num_heads, hd) for t in (q, k, v))
         o = torch.empty(B, L, num_heads * 32, device=q.device, dtype=torch.bfloat16)
         lse2 = torch.empty(B, num_heads, L, device=q.device, dtype=torch.float32)
-        _check(_lib.dfine_attn_fwd(_ptr(qp), _ptr(kp), _ptr(vp), _ptr(o), _ptr(lse2), _ptr(mask), B, L, num_heads, 32, _ld(qp),
-                                   _ld(kp), _ld(vp), num_heads * 32, float(hd) ** -0.5, _stream()), "dfine_attn_fwd")
+        _check(_lib.dfine_attn_fwd_ms(_ptr(qp), _ptr(kp), _ptr(vp), _ptr(o), _ptr(lse2), _ptr(mask), _ptr(msum), B, L, num_heads, 32, _ld(qp),
+                                      _ld(kp), _ld(vp), num_heads * 32, float(hd) ** -0.5, _stream()), "dfine_attn_fwd_ms")
         return o.reshape(B, L, num_heads, 32)[..., :hd].reshape(B, L, E), lse2
     o = torch.empty(B, L, E, device=q.device, dtype=torch.bfloat16)
     lse2 = torch.empty(B, num_heads, L, device=q.device, dtype=torch.float32)
     with _timed("attention", 4.0 * B * num_heads * L * L * hd, io=2.0 * 4 * B * num_heads * L * hd):
-        _check(_lib.dfine_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse2), _ptr(mask), B, L, num_heads, hd, _ld(q),
-                                   _ld(k), _ld(v), E, float(hd) ** -0.5, _stream()), "dfine_attn_fwd")
+        _check(_lib.dfine_attn_fwd_ms(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse2), _ptr(mask), _ptr(msum), B, L, num_heads, hd, _ld(q),
+                                      _ld(k), _ld(v), E, float(hd) ** -0.5, _stream()), "dfine_attn_fwd_ms")
     return o, lse2
 
 
@@ -1326,13 +1331,26 @@ _MASK_BITS = [None, None]          # (key of the last mask, its transposed bit m
 def _mask_bits(mask):
     """Transposed bit-packed form of a [L, L] uint8 mask for the dK / dV kernel (dfine_attn_mask_bits), remade when the mask
     tensor or its contents change."""
+    return _mask_forms(mask)[0]
+
+
+_MASK_SUMMARY = os.environ.get("DFINE_ATTN_MASK_SUMMARY", "1") == "1"
+
+
+def _mask_forms(mask):
+    """(transposed bit mask, tile summaries) of a [L, L] uint8 mask, remade when the mask tensor or its contents change: the
+    decoder's layers share one mask per step.  The summaries (dfine_attn_mask_summary) let the kernels skip blocked tiles."""
     key = (mask.data_ptr(), mask._version, mask.shape[0], mask.device.index)
     if _MASK_BITS[0] != key:
         L = mask.shape[0]
         bits = torch.empty(int(_lib.dfine_attn_mask_bits_words(L)), device=mask.device, dtype=torch.int32)
         _check(_lib.dfine_attn_mask_bits(_ptr(mask), L, _ptr(bits), _stream()), "dfine_attn_mask_bits")
-        _MASK_BITS[0], _MASK_BITS[1] = key, (bits, mask)       # (the mask is kept alive with its key)
-    return _MASK_BITS[1][0]
+        msum = None
+        if _MASK_SUMMARY:
+            msum = torch.empty(int(_lib.dfine_attn_mask_summary_bytes(L)), device=mask.device, dtype=torch.uint8)
+            _check(_lib.dfine_attn_mask_summary(_ptr(mask), L, _ptr(msum), _stream()), "dfine_attn_mask_summary")
+        _MASK_BITS[0], _MASK_BITS[1] = key, (bits, msum, mask)       # (the mask is kept alive with its key)
+    return _MASK_BITS[1][0], _MASK_BITS[1][1]
 
 
 def attn_backward(q, k, v, o, dout, lse2, num_heads, dq, dk, dv, mask=None):
@@ -1340,20 +1358,20 @@ def attn_backward(q, k, v, o, dout, lse2, num_heads, dq, dk, dv, mask=None):
     B, L, E = q.shape
     hd = E // num_heads
     delta = torch.empty_like(lse2)
-    mbits = None if mask is None else _mask_bits(mask)
+    mbits, msum = (None, None) if mask is None else _mask_forms(mask)
     if hd != 32:
         qp, kp, vp, op, dop = (_pad_heads(t, num_heads, hd) for t in (q, k, v, o, dout))
         g = torch.empty(3, B, L, num_heads * 32, device=q.device, dtype=torch.bfloat16)
-        _check(_lib.dfine_attn_bwd(_ptr(qp), _ptr(kp), _ptr(vp), _ptr(op), _ptr(dop), _ptr(lse2), _ptr(mask), _ptr(mbits), _ptr(g[0]), _ptr(g[1]),
-                                   _ptr(g[2]), _ptr(delta), B, L, num_heads, 32, _ld(qp), _ld(kp), _ld(vp), _ld(op), _ld(dop),
-                                   _ld(g[0]), _ld(g[1]), _ld(g[2]), float(hd) ** -0.5, _stream()), "dfine_attn_bwd")
+        _check(_lib.dfine_attn_bwd_ms(_ptr(qp), _ptr(kp), _ptr(vp), _ptr(op), _ptr(dop), _ptr(lse2), _ptr(mask), _ptr(mbits), _ptr(msum), _ptr(g[0]),
+                                      _ptr(g[1]), _ptr(g[2]), _ptr(delta), B, L, num_heads, 32, _ld(qp), _ld(kp), _ld(vp), _ld(op), _ld(dop),
+                                      _ld(g[0]), _ld(g[1]), _ld(g[2]), float(hd) ** -0.5, _stream()), "dfine_attn_bwd_ms")
         for dst, src in zip((dq, dk, dv), g):
             dst.copy_(src.reshape(B, L, num_heads, 32)[..., :hd].reshape(B, L, E))
         return
     with _timed("attention", 10.0 * B * num_heads * L * L * hd, io=2.0 * 8 * B * num_heads * L * hd):
-        _check(_lib.dfine_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(dout), _ptr(lse2), _ptr(mask), _ptr(mbits), _ptr(dq), _ptr(dk),
-                                   _ptr(dv), _ptr(delta), B, L, num_heads, hd, _ld(q), _ld(k), _ld(v), _ld(o), _ld(dout),
-                                   _ld(dq), _ld(dk), _ld(dv), float(hd) ** -0.5, _stream()), "dfine_attn_bwd")
+        _check(_lib.dfine_attn_bwd_ms(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(dout), _ptr(lse2), _ptr(mask), _ptr(mbits), _ptr(msum), _ptr(dq),
+                                      _ptr(dk), _ptr(dv), _ptr(delta), B, L, num_heads, hd, _ld(q), _ld(k), _ld(v), _ld(o), _ld(dout),
+                                      _ld(dq), _ld(dk), _ld(dv), float(hd) ** -0.5, _stream()), "dfine_attn_bwd_ms")
 
 
 # ------------------------------------------------------------------------------------- linear wgrad

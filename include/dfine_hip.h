@@ -522,6 +522,18 @@ int dfine_attn_fwd(const void *q, const void *k, const void *v, void *o, float *
 /* mask_bits (optional, with mask): the transposed bit-packed mask made by dfine_attn_mask_bits - dfine_attn_mask_bits_words(L)
  * uint32 words, bit j of word [key][w] = mask[32 w + j][key] - which gives the dK / dV kernel the 32 queries of a chunk in one
  * load per key instead of 32 byte loads (98 -> see profiles: the byte mask doubled that kernel's time). */
+/* Tile summaries of the mask (free / mixed / blocked per 16 queries x 64 keys and per 64 keys x 32 queries): with them
+ * (dfine_attn_fwd_ms / dfine_attn_bwd_ms) blocked tiles are skipped and free tiles run without the mask loads - the decoder's
+ * denoising mask (src/d_fine/arch/utils.py:442-455) is block-structured.  Results are bit-identical to the plain entry points. */
+int64_t dfine_attn_mask_summary_bytes(int L);
+int dfine_attn_mask_summary(const uint8_t *mask, int L, uint8_t *sum, void *stream);
+int dfine_attn_fwd_ms(const void *q, const void *k, const void *v, void *o, float *lse2, const uint8_t *mask,
+                      const uint8_t *mask_summary, int B, int L, int H, int hd, int ldq, int ldk, int ldv, int ldo,
+                      float scale, void *stream);
+int dfine_attn_bwd_ms(const void *q, const void *k, const void *v, const void *o, const void *dout, const float *lse2,
+                      const uint8_t *mask, const uint32_t *mask_bits, const uint8_t *mask_summary, void *dq, void *dk,
+                      void *dv, float *delta, int B, int L, int H, int hd, int ldq, int ldk, int ldv, int ldo, int lddo,
+                      int lddq, int lddk, int lddv, float scale, void *stream);
 int64_t dfine_attn_mask_bits_words(int L);
 int dfine_attn_mask_bits(const uint8_t *mask, int L, uint32_t *bits, void *stream);
 int dfine_attn_bwd(const void *q, const void *k, const void *v, const void *o, const void *dout,

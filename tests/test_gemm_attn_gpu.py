@@ -198,3 +198,42 @@ def test_attention_backward_bit_mask_equals_byte_mask(cuda, monkeypatch):
         out[form] = (dq, dk, dv)
     for a, b in zip(out["bits"], out["bytes"]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("L,maxT,groups", [(480, 15, 6), (498, 9, 11), (340, 20, 1)])
+def test_attention_mask_tile_summaries_are_exact(cuda, monkeypatch, L, maxT, groups):
+    """The decoder's denoising mask (ref arch/utils.py:442-455: matching queries do not see the denoising ones, a denoising
+    group sees itself and the matching queries) through the tile summaries (blocked tiles skipped, free tiles unmasked) must
+    give bit-identical results to the plain masked kernels: a blocked tile only ever adds zeros."""
+    from custom_d_fine_amd import hip
+    dn = 2 * maxT * groups
+    assert L == 300 + dn
+    mask = torch.zeros(L, L, dtype=torch.bool, device=cuda)
+    mask[dn:, :dn] = True
+    for i in range(groups):
+        a, b = 2 * maxT * i, 2 * maxT * (i + 1)
+        mask[a:b, :a] = True
+        mask[a:b, b:dn] = True
+    m8 = mask.view(torch.uint8).contiguous()
+    B, H, E = 2, 8, 256
+    g = torch.Generator(device=cuda).manual_seed(L)
+    qkv = torch.randn(B, L, 3 * E, device=cuda, generator=g).bfloat16()
+    q, k, v = qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:]
+    do = torch.randn(B, L, E, device=cuda, generator=g).bfloat16()
+
+    def run(summary):
+        monkeypatch.setattr(hip, "_MASK_SUMMARY", summary)
+        hip._MASK_BITS[0] = None
+        o, lse2 = hip.attn_forward(q, k, v, H, m8)
+        d = torch.zeros_like(qkv)
+        hip.attn_backward(q, k, v, o, do, lse2, H, d[..., :E], d[..., E:2 * E], d[..., 2 * E:], m8)
+        return o, lse2, d
+
+    o0, l0, d0 = run(False)
+    o1, l1, d1 = run(True)
+    hip._MASK_BITS[0] = None
+    assert torch.equal(o0, o1) and torch.equal(l0, l1) and torch.equal(d0, d1)
+    # and against fp32 softmax attention
+    qh, kh, vh = (t.reshape(B, L, H, 32).transpose(1, 2).float() for t in (q, k, v))
+    ref = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh, attn_mask=~mask).transpose(1, 2).reshape(B, L, E)
+    assert (o1.float() - ref).abs().max() <= 2 ** -6 * ref.abs().max()

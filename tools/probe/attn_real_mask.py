@@ -15,7 +15,9 @@ for maxT, groups in ((15, 6), (9, 11), (0, 0)):
             a, b = 2 * maxT * i, 2 * maxT * (i + 1)
             mask[a:b, :a] = True
             mask[a:b, b:dn] = True
-    for name, m in (("real", mask), ("random", (torch.rand(L, L, device=dev) < 0.3).fill_diagonal_(False)), ("none", None)):
+    for name, m in (("real", mask), ("real-nosum", mask), ("random", (torch.rand(L, L, device=dev) < 0.3).fill_diagonal_(False)), ("none", None)):
+        hip._MASK_SUMMARY = name != "real-nosum"
+        hip._MASK_BITS[0] = None
         m8 = None if m is None else m.view(torch.uint8).contiguous()
         qkv = torch.randn(B, L, 3 * E, device=dev).bfloat16()
         q, k, v = qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:]
@@ -29,4 +31,4 @@ for maxT, groups in ((15, 6), (9, 11), (0, 0)):
             for _ in range(5): hip.attn_forward(q, k, v, H, m8); f()
             torch.cuda.synchronize()
         row = {k_.key.split("<")[0].split("::")[-1]: k_.device_time_total / 5 for k_ in prof.key_averages() if "attn" in k_.key}
-        print(f"L {L} mask {name:6s}: " + "  ".join(f"{a} {b:7.1f} us" for a, b in sorted(row.items())))
+        print(f"L {L} mask {name:10s}: " + "  ".join(f"{a} {b:7.1f} us" for a, b in sorted(row.items())))
