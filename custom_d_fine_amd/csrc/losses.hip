@@ -15,6 +15,8 @@
 //                       [DDF] | fine-grained localisation CE on the matched rows, targets derived in-kernel [FGL]
 // Inputs may be strided views (batch / query strides) of fp32 or bf16 tensors; math is fp32.
 // Loss sums are accumulated with one atomic per block into out[] (zeroed by the entry point).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace dfine {
@@ -154,13 +156,18 @@ __device__ __forceinline__ void vfl_body(int blk, int nblk, float *red, const T 
 
 // ---------------------------------------------------------------------------------------------
 // w[b,q] = matched ? iou : sigmoid(max_c teacher_logits)   (computed by each of the row's four edge threads)
+// `edge`: the caller is one of FOUR adjacent lanes working on the row (its four box edges): each scans a quarter of the class
+// logits and two cross-lane maxima finish the job (every lane scanning all C logits of its row made the teacher-logit reads -
+// 80 strided 2-byte loads per thread - the longest part of head_phase2_kernel)
 template <typename T>
 __device__ __forceinline__ float row_weight(const T *__restrict__ tlogits, View tv, int m /* pair index or -1 */,
-                                            const float *__restrict__ iou, int b, int q, int C) {
-    if (m >= 0) return iou[m];
+                                            const float *__restrict__ iou, int b, int q, int C, int edge) {
+    if (m >= 0) return iou[m];                             // (uniform over the row's four lanes)
     const T *p = tlogits + (int64_t)b * tv.sb + (int64_t)q * tv.sq;
-    float mx = load_f(p);
-    for (int c = 1; c < C; ++c) mx = fmaxf(mx, load_f(p + c));
+    float mx = -INFINITY;
+    for (int c = edge; c < C; c += 4) mx = fmaxf(mx, load_f(p + c));
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
     return 1.f / (1.f + __expf(-mx));
 }
 
@@ -193,7 +200,7 @@ __device__ __forceinline__ void ddf_body(int blk, float *red, const T *__restric
         const float plz = pm + __logf(ps), tlz = tm + __logf(ts);
         const int mrow = map[row] - 1;
         const bool pos = mrow >= 0;
-        const float coef = (pos ? c_pos : c_neg) * row_weight(tlogits, tlv, mrow, iou, b, q, C);
+        const float coef = (pos ? c_pos : c_neg) * row_weight(tlogits, tlv, mrow, iou, b, q, C, edge);
         float kl = 0.f;
         T *gp = grad + ((int64_t)row * 4 + edge) * NB;
 #pragma unroll
@@ -446,7 +453,10 @@ static int head_losses_impl(
     }
     const int64_t n = (int64_t)B * Q * C;
     if (n >= ((int64_t)1 << 31) - 2048 * kLT) return DFINE_E_BADARG;      // the kernels index the logits with 32 bits
-    const int vb = (int)((n + kLT - 1) / kLT < 2048 ? (n + kLT - 1) / kLT : 2048);
+    // (every block ends with ONE atomic onto the same loss scalar, and same-address atomics retire one after the other at L2:
+    // 2 048 blocks made that tail the longest part of the launch)
+    static const int vb_cap = [] { const char *e = getenv("DFINE_VFL_BLOCKS"); return e ? atoi(e) : 512; }();
+    const int vb = (int)((n + kLT - 1) / kLT < vb_cap ? (n + kLT - 1) / kLT : vb_cap);
     if (corners && teacher_corners && (!teacher_logits || !grad_corners_ddf)) return DFINE_E_BADARG;
     const int nb_ddf = corners && teacher_corners ? (B * Q * 4 + kLT - 1) / kLT : 0;
     const int nb_fgl = corners && M_box > 0 ? (M_box * 4 + kLT - 1) / kLT : 0;
