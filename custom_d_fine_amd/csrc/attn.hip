@@ -36,6 +36,9 @@ constexpr int kKB = 64;                 // keys per LDS block (256 -> 128 -> 64:
                                         // fewer score registers per workgroup = more workgroups per CU to cover each other's load - compute phases)
 constexpr int kP40 = 40;                // row pitch (elements) of tiles read with 16-byte fragment loads: conflict-free
 constexpr int kP48 = 48;                // row pitch of tiles read with the transpose-read: the 8 rows of a 32-lane half hit disjoint banks
+// Head dims up to 64 (DS = 2 slabs of 32 dims; 48 = the AIFI layer of D-FINE-x, src/d_fine/configs.py:182, runs zero-padded to 64):
+// rows of 64 elements, pitches 72 (an odd number of 16-byte units) / 80 (40 dwords: rows 0 .. 7 start in banks 0, 40, 16, 56, 32, 8, 48, 24)
+template <int DS> struct Pitch { static constexpr int frag = DS == 1 ? kP40 : 72, tr = DS == 1 ? kP48 : 80; };
 
 __device__ __forceinline__ a_bf16x8 ld_frag(const uint16_t *p) { return __builtin_bit_cast(a_bf16x8, *reinterpret_cast<const uint4 *>(p)); }
 
@@ -57,9 +60,10 @@ __device__ __forceinline__ float xor_sum(float v) {
 }
 
 // stage `rows` rows (32 bf16 each, global row stride ld) into an LDS tile with row pitch `pitch`; rows >= valid are zero
+template <int DS = 1>
 __device__ __forceinline__ void stage_rows(uint16_t *dst, int pitch, const uint16_t *src, int64_t ld, int rows, int valid, int tid) {
-    for (int it = tid; it < rows * 4; it += kAttnThreads) {
-        const int r = it >> 2, c = (it & 3) * 8;
+    for (int it = tid; it < rows * 4 * DS; it += kAttnThreads) {
+        const int r = it / (4 * DS), c = (it % (4 * DS)) * 8;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (r < valid) v = *reinterpret_cast<const uint4 *>(src + (int64_t)r * ld + c);
         *reinterpret_cast<uint4 *>(dst + r * pitch + c) = v;
@@ -86,38 +90,43 @@ __device__ __forceinline__ uint32_t mask4(const uint8_t *mrow, int key, int L) {
 
 // ------------------------------------------------------------------------------------------------------------------
 // forward: block = (b, h, 64 * QT queries), wave = 16 queries per iteration
-template <int QT>
+template <int QT, int DS = 1>
 __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const uint16_t *__restrict__ q, const uint16_t *__restrict__ k,
                                                                 const uint16_t *__restrict__ v, uint16_t *__restrict__ o,
                                                                 float *__restrict__ lse2, const uint8_t *__restrict__ mask,
                                                                 const uint8_t *__restrict__ msum,
                                                                 int B, int L, int H, int ldq, int ldk, int ldv, int ldo,
                                                                 float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) uint16_t sK[kKB * kP40];
-    __shared__ __attribute__((aligned(16))) uint16_t sV[kKB * kP48];
+    constexpr int PF = Pitch<DS>::frag, PT = Pitch<DS>::tr, HD = 32 * DS;
+    __shared__ __attribute__((aligned(16))) uint16_t sK[kKB * PF];
+    __shared__ __attribute__((aligned(16))) uint16_t sV[kKB * PT];
     const int nk64 = (L + 63) >> 6, nq16 = (L + 15) >> 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
     const int bh = blockIdx.x % (B * H), qblk = blockIdx.x / (B * H);        // blocks of one (b, h) share an XCD (L2 reuse of K, V)
     const int b = bh / H, h = bh - b * H;
-    const uint16_t *qb = q + (int64_t)b * L * ldq + h * kHD;
-    const uint16_t *kb_ = k + (int64_t)b * L * ldk + h * kHD;
-    const uint16_t *vb = v + (int64_t)b * L * ldv + h * kHD;
+    const uint16_t *qb = q + (int64_t)b * L * ldq + h * HD;
+    const uint16_t *kb_ = k + (int64_t)b * L * ldk + h * HD;
+    const uint16_t *vb = v + (int64_t)b * L * ldv + h * HD;
     const float NEG = -INFINITY;
 
     int qrow[QT];
-    a_bf16x8 qf[QT];
+    a_bf16x8 qf[QT][DS];
     float m_run[QT], l_run[QT];
-    a_f32x4 oacc[QT][2];
+    a_f32x4 oacc[QT][2 * DS];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         qrow[t] = qblk * 64 * QT + t * 64 + wave * 16 + i16;
-        uint4 qv = make_uint4(0, 0, 0, 0);
-        if (qrow[t] < L) qv = *reinterpret_cast<const uint4 *>(qb + (int64_t)qrow[t] * ldq + 8 * g);
-        qf[t] = __builtin_bit_cast(a_bf16x8, qv);
+#pragma unroll
+        for (int sl = 0; sl < DS; ++sl) {
+            uint4 qv = make_uint4(0, 0, 0, 0);
+            if (qrow[t] < L) qv = *reinterpret_cast<const uint4 *>(qb + (int64_t)qrow[t] * ldq + 32 * sl + 8 * g);
+            qf[t][sl] = __builtin_bit_cast(a_bf16x8, qv);
+        }
         m_run[t] = NEG; l_run[t] = 0.f;
-        oacc[t][0] = a_f32x4{0.f, 0.f, 0.f, 0.f}; oacc[t][1] = a_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 2 * DS; ++d) oacc[t][d] = a_f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int tr_off = (4 * g + (i16 >> 2)) * kP48 + 4 * (i16 & 3);
+    const int tr_off = (4 * g + (i16 >> 2)) * PT + 4 * (i16 & 3);
 
     for (int k0 = 0; k0 < L; k0 += kKB) {
         const int valid = min(kKB, L - k0);
@@ -144,17 +153,20 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const uint16_t *
             for (int t = 0; t < QT; ++t) code[t] = mask ? 1 : 0;
         }
         __syncthreads();
-        stage_rows(sK, kP40, kb_ + (int64_t)k0 * ldk, ldk, kKB, valid, tid);
-        stage_rows(sV, kP48, vb + (int64_t)k0 * ldv, ldv, kKB, valid, tid);
+        stage_rows<DS>(sK, PF, kb_ + (int64_t)k0 * ldk, ldk, kKB, valid, tid);
+        stage_rows<DS>(sV, PT, vb + (int64_t)k0 * ldv, ldv, kKB, valid, tid);
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             if (code[t] == 2) continue;                                  // (wave-uniform)
             a_f32x4 s[kKB / 16];
 #pragma unroll
-            for (int kt = 0; kt < kKB / 16; ++kt)
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(sK + (kt * 16 + i16) * kP40 + 8 * g), qf[t],
-                                                                a_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            for (int kt = 0; kt < kKB / 16; ++kt) {
+                s[kt] = a_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < DS; ++sl)
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(sK + (kt * 16 + i16) * PF + 32 * sl + 8 * g), qf[t][sl], s[kt], 0, 0, 0);
+            }
             const uint8_t *mrow = code[t] == 1 ? mask + (int64_t)min(qrow[t], L - 1) * L : nullptr;
             float bmax = NEG;
 #pragma unroll
@@ -186,15 +198,15 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const uint16_t *
             l_run[t] = l_run[t] * alpha + psum;
             m_run[t] = m_new;
 #pragma unroll
-            for (int d = 0; d < 2; ++d)
+            for (int d = 0; d < 2 * DS; ++d)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) oacc[t][d][r] *= alpha;
 #pragma unroll
             for (int ks = 0; ks < kKB / 32; ++ks) {
                 const a_bf16x8 pf = __builtin_bit_cast(a_bf16x8, make_uint4(pk[2 * ks][0], pk[2 * ks][1], pk[2 * ks + 1][0], pk[2 * ks + 1][1]));
 #pragma unroll
-                for (int d = 0; d < 2; ++d)
-                    oacc[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sV + ks * 32 * kP48 + tr_off + 16 * d, kP48), pf,
+                for (int d = 0; d < 2 * DS; ++d)
+                    oacc[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sV + ks * 32 * PT + tr_off + 16 * d, PT), pf,
                                                                          oacc[t][d], 0, 0, 0);
             }
         }
@@ -203,9 +215,9 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const uint16_t *
     for (int t = 0; t < QT; ++t) {
         if (qrow[t] >= L) continue;
         const float inv = l_run[t] > 0.f ? 1.f / l_run[t] : 0.f;
-        uint16_t *op = o + ((int64_t)b * L + qrow[t]) * ldo + h * kHD + 4 * g;
+        uint16_t *op = o + ((int64_t)b * L + qrow[t]) * ldo + h * HD + 4 * g;
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
+        for (int d = 0; d < 2 * DS; ++d) {
             uint2 w;
             w.x = pack2(oacc[t][d][0] * inv, oacc[t][d][1] * inv);
             w.y = pack2(oacc[t][d][2] * inv, oacc[t][d][3] * inv);
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const uint16_t *
 
 // ------------------------------------------------------------------------------------------------------------------
 // backward, dQ (+ delta): same decomposition as the forward pass; P^T is recomputed from lse2
-template <int QT>
+template <int QT, int DS = 1>
 __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const uint16_t *__restrict__ q, const uint16_t *__restrict__ k,
                                                                    const uint16_t *__restrict__ v, const uint16_t *__restrict__ o,
                                                                    const uint16_t *__restrict__ dout, const float *__restrict__ lse2,
@@ -225,42 +237,46 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const uint16_
                                                                    uint16_t *__restrict__ dq,
                                                                    float *__restrict__ delta, int B, int L, int H, int ldq, int ldk,
                                                                    int ldv, int ldo, int lddo, int lddq, float scale, float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) uint16_t sK[kKB * kP48];          // 16-byte fragment reads AND transpose-reads
-    __shared__ __attribute__((aligned(16))) uint16_t sV[kKB * kP40];
+    constexpr int PF = Pitch<DS>::frag, PT = Pitch<DS>::tr, HD = 32 * DS;
+    __shared__ __attribute__((aligned(16))) uint16_t sK[kKB * PT];            // 16-byte fragment reads AND transpose-reads
+    __shared__ __attribute__((aligned(16))) uint16_t sV[kKB * PF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
     const int bh = blockIdx.x % (B * H), qblk = blockIdx.x / (B * H);
     const int b = bh / H, h = bh - b * H;
-    const uint16_t *kb_ = k + (int64_t)b * L * ldk + h * kHD;
-    const uint16_t *vb = v + (int64_t)b * L * ldv + h * kHD;
+    const uint16_t *kb_ = k + (int64_t)b * L * ldk + h * HD;
+    const uint16_t *vb = v + (int64_t)b * L * ldv + h * HD;
 
     int qrow[QT];
-    a_bf16x8 qf[QT], dof[QT];
+    a_bf16x8 qf[QT][DS], dof[QT][DS];
     float lse_q[QT], dl[QT];
-    a_f32x4 dacc[QT][2];
+    a_f32x4 dacc[QT][2 * DS];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         qrow[t] = qblk * 64 * QT + t * 64 + wave * 16 + i16;
-        uint4 qv = make_uint4(0, 0, 0, 0), dv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
-        lse_q[t] = 0.f;
-        if (qrow[t] < L) {
-            qv = *reinterpret_cast<const uint4 *>(q + ((int64_t)b * L + qrow[t]) * ldq + h * kHD + 8 * g);
-            dv = *reinterpret_cast<const uint4 *>(dout + ((int64_t)b * L + qrow[t]) * lddo + h * kHD + 8 * g);
-            ov = *reinterpret_cast<const uint4 *>(o + ((int64_t)b * L + qrow[t]) * ldo + h * kHD + 8 * g);
-            lse_q[t] = lse2[((int64_t)b * H + h) * L + qrow[t]];
-        }
-        qf[t] = __builtin_bit_cast(a_bf16x8, qv);
-        dof[t] = __builtin_bit_cast(a_bf16x8, dv);
-        const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
+        lse_q[t] = qrow[t] < L ? lse2[((int64_t)b * H + h) * L + qrow[t]] : 0.f;
         float part = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            part += __uint_as_float(dw[j] << 16) * __uint_as_float(ow[j] << 16) +
-                    __uint_as_float(dw[j] & 0xffff0000u) * __uint_as_float(ow[j] & 0xffff0000u);
+        for (int sl = 0; sl < DS; ++sl) {
+            uint4 qv = make_uint4(0, 0, 0, 0), dv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
+            if (qrow[t] < L) {
+                qv = *reinterpret_cast<const uint4 *>(q + ((int64_t)b * L + qrow[t]) * ldq + h * HD + 32 * sl + 8 * g);
+                dv = *reinterpret_cast<const uint4 *>(dout + ((int64_t)b * L + qrow[t]) * lddo + h * HD + 32 * sl + 8 * g);
+                ov = *reinterpret_cast<const uint4 *>(o + ((int64_t)b * L + qrow[t]) * ldo + h * HD + 32 * sl + 8 * g);
+            }
+            qf[t][sl] = __builtin_bit_cast(a_bf16x8, qv);
+            dof[t][sl] = __builtin_bit_cast(a_bf16x8, dv);
+            const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                part += __uint_as_float(dw[jj] << 16) * __uint_as_float(ow[jj] << 16) +
+                        __uint_as_float(dw[jj] & 0xffff0000u) * __uint_as_float(ow[jj] & 0xffff0000u);
+        }
         dl[t] = xor_sum(part);
         if (g == 0 && qrow[t] < L) delta[((int64_t)b * H + h) * L + qrow[t]] = dl[t];
-        dacc[t][0] = a_f32x4{0.f, 0.f, 0.f, 0.f}; dacc[t][1] = a_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 2 * DS; ++d) dacc[t][d] = a_f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int tr_off = (4 * g + (i16 >> 2)) * kP48 + 4 * (i16 & 3);
+    const int tr_off = (4 * g + (i16 >> 2)) * PT + 4 * (i16 & 3);
 
     const int nk64 = (L + 63) >> 6, nq16 = (L + 15) >> 4;
     for (int k0 = 0; k0 < L; k0 += kKB) {
@@ -284,8 +300,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const uint16_
             for (int t = 0; t < QT; ++t) code[t] = mask ? 1 : 0;
         }
         __syncthreads();
-        stage_rows(sK, kP48, kb_ + (int64_t)k0 * ldk, ldk, kKB, valid, tid);
-        stage_rows(sV, kP40, vb + (int64_t)k0 * ldv, ldv, kKB, valid, tid);
+        stage_rows<DS>(sK, PT, kb_ + (int64_t)k0 * ldk, ldk, kKB, valid, tid);
+        stage_rows<DS>(sV, PF, vb + (int64_t)k0 * ldv, ldv, kKB, valid, tid);
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
@@ -294,9 +310,12 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const uint16_
             uint32_t pk[kKB / 16][2];
 #pragma unroll
             for (int kt = 0; kt < kKB / 16; ++kt) {
-                const a_f32x4 z = a_f32x4{0.f, 0.f, 0.f, 0.f};
-                const a_f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(sK + (kt * 16 + i16) * kP48 + 8 * g), qf[t], z, 0, 0, 0);
-                const a_f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(sV + (kt * 16 + i16) * kP40 + 8 * g), dof[t], z, 0, 0, 0);
+                a_f32x4 s = a_f32x4{0.f, 0.f, 0.f, 0.f}, dp = a_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < DS; ++sl) {
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(sK + (kt * 16 + i16) * PT + 32 * sl + 8 * g), qf[t][sl], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(sV + (kt * 16 + i16) * PF + 32 * sl + 8 * g), dof[t][sl], dp, 0, 0, 0);
+                }
                 const int key = k0 + kt * 16 + 4 * g;
                 const uint32_t mb = mrow ? mask4(mrow, key, L) : 0u;
                 float ds[4];
@@ -315,8 +334,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const uint16_
             for (int ks = 0; ks < kKB / 32; ++ks) {
                 const a_bf16x8 pf = __builtin_bit_cast(a_bf16x8, make_uint4(pk[2 * ks][0], pk[2 * ks][1], pk[2 * ks + 1][0], pk[2 * ks + 1][1]));
 #pragma unroll
-                for (int d = 0; d < 2; ++d)
-                    dacc[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sK + ks * 32 * kP48 + tr_off + 16 * d, kP48), pf,
+                for (int d = 0; d < 2 * DS; ++d)
+                    dacc[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sK + ks * 32 * PT + tr_off + 16 * d, PT), pf,
                                                                          dacc[t][d], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -325,9 +344,9 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const uint16_
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         if (qrow[t] >= L) continue;
-        uint16_t *op = dq + ((int64_t)b * L + qrow[t]) * lddq + h * kHD + 4 * g;
+        uint16_t *op = dq + ((int64_t)b * L + qrow[t]) * lddq + h * HD + 4 * g;
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
+        for (int d = 0; d < 2 * DS; ++d) {
             uint2 w;
             w.x = pack2(dacc[t][d][0], dacc[t][d][1]);
             w.y = pack2(dacc[t][d][2], dacc[t][d][3]);
@@ -342,7 +361,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const uint16_
 // CUs): latency-bound, and slowed down further by whatever shares the chip (143 us alone, 268 us next to the side stream's
 // weight-gradient kernels).  <4, 8>: 64 keys per wave, 512 threads, two waves per SIMD and half the accumulators per wave.
 // MM: mask form - 0 none, 1 byte mask [L, L], 2 transposed bit mask (compile-time: the unmasked encoder layer pays nothing for it)
-template <int KT, int NW, int MM>
+template <int KT, int NW, int MM, int DS = 1>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const uint16_t *__restrict__ q, const uint16_t *__restrict__ k,
                                                                      const uint16_t *__restrict__ v, const uint16_t *__restrict__ dout,
                                                                      const float *__restrict__ lse2, const float *__restrict__ delta,
@@ -352,34 +371,37 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const uint16_t *
                                                                      uint16_t *__restrict__ dv, int B, int L, int H, int ldq, int ldk,
                                                                      int ldv, int lddo, int lddk, int lddv, float scale,
                                                                      float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) uint16_t sQ[2][32 * kP48];
-    __shared__ __attribute__((aligned(16))) uint16_t sDO[2][32 * kP48];
+    constexpr int PT = Pitch<DS>::tr, HD = 32 * DS;
+    __shared__ __attribute__((aligned(16))) uint16_t sQ[2][32 * PT];
+    __shared__ __attribute__((aligned(16))) uint16_t sDO[2][32 * PT];
     __shared__ float sL[2][32], sD[2][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
     const int bh = blockIdx.x % (B * H), kblk = blockIdx.x / (B * H);
     const int b = bh / H, h = bh - b * H;
     const int kw0 = kblk * (NW * 16 * KT) + wave * 16 * KT;                    // this wave's keys
-    const uint16_t *qb = q + (int64_t)b * L * ldq + h * kHD;
-    const uint16_t *dob = dout + (int64_t)b * L * lddo + h * kHD;
+    const uint16_t *qb = q + (int64_t)b * L * ldq + h * HD;
+    const uint16_t *dob = dout + (int64_t)b * L * lddo + h * HD;
 
-    a_bf16x8 kf[KT], vf[KT];
+    a_bf16x8 kf[KT][DS], vf[KT][DS];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        const int key = kw0 + kt * 16 + i16;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (key < L) {
-            kv = *reinterpret_cast<const uint4 *>(k + ((int64_t)b * L + key) * ldk + h * kHD + 8 * g);
-            vv = *reinterpret_cast<const uint4 *>(v + ((int64_t)b * L + key) * ldv + h * kHD + 8 * g);
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int sl = 0; sl < DS; ++sl) {
+            const int key = kw0 + kt * 16 + i16;
+            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+            if (key < L) {
+                kv = *reinterpret_cast<const uint4 *>(k + ((int64_t)b * L + key) * ldk + h * HD + 32 * sl + 8 * g);
+                vv = *reinterpret_cast<const uint4 *>(v + ((int64_t)b * L + key) * ldv + h * HD + 32 * sl + 8 * g);
+            }
+            kf[kt][sl] = __builtin_bit_cast(a_bf16x8, kv);
+            vf[kt][sl] = __builtin_bit_cast(a_bf16x8, vv);
         }
-        kf[kt] = __builtin_bit_cast(a_bf16x8, kv);
-        vf[kt] = __builtin_bit_cast(a_bf16x8, vv);
-    }
-    a_f32x4 dka[2][KT], dva[2][KT];
+    a_f32x4 dka[2 * DS][KT], dva[2 * DS][KT];
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int d = 0; d < 2 * DS; ++d)
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) { dka[d][kt] = a_f32x4{0.f, 0.f, 0.f, 0.f}; dva[d][kt] = a_f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const int tr_off = (4 * g + (i16 >> 2)) * kP48 + 4 * (i16 & 3);
+    const int tr_off = (4 * g + (i16 >> 2)) * PT + 4 * (i16 & 3);
     const bool wave_live = kw0 < L;
 
     // staging of the next 32-query chunk in two halves: the global loads are issued BEFORE the chunk's MFMAs, the LDS writes come
@@ -408,11 +430,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const uint16_t *
         const int valid = min(32, L - q0);
         mask_load(q0 >> 5);
         st_a = make_uint4(0, 0, 0, 0);
-        if (tid < 128) {
-            const int r = tid >> 2, c = (tid & 3) * 8;
+        if (tid < 128 * DS) {
+            const int r = tid / (4 * DS), c = (tid % (4 * DS)) * 8;
             if (r < valid) st_a = *reinterpret_cast<const uint4 *>(qb + (int64_t)(q0 + r) * ldq + c);
-        } else if (tid < 256) {
-            const int t2 = tid - 128, r = t2 >> 2, c = (t2 & 3) * 8;
+        } else if (tid < 256 * DS) {
+            const int t2 = tid - 128 * DS, r = t2 / (4 * DS), c = (t2 % (4 * DS)) * 8;
             if (r < valid) st_a = *reinterpret_cast<const uint4 *>(dob + (int64_t)(q0 + r) * lddo + c);
         }
         if (tid < 32) {
@@ -422,12 +444,12 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const uint16_t *
         }
     };
     auto stage_store = [&](int buf) {
-        if (tid < 128) {
-            const int r = tid >> 2, c = (tid & 3) * 8;
-            *reinterpret_cast<uint4 *>(&sQ[buf][r * kP48 + c]) = st_a;
-        } else if (tid < 256) {
-            const int t2 = tid - 128, r = t2 >> 2, c = (t2 & 3) * 8;
-            *reinterpret_cast<uint4 *>(&sDO[buf][r * kP48 + c]) = st_a;
+        if (tid < 128 * DS) {
+            const int r = tid / (4 * DS), c = (tid % (4 * DS)) * 8;
+            *reinterpret_cast<uint4 *>(&sQ[buf][r * PT + c]) = st_a;
+        } else if (tid < 256 * DS) {
+            const int t2 = tid - 128 * DS, r = t2 / (4 * DS), c = (t2 % (4 * DS)) * 8;
+            *reinterpret_cast<uint4 *>(&sDO[buf][r * PT + c]) = st_a;
         }
         if (tid < 32) { sL[buf][tid] = st_l; sD[buf][tid] = st_d; }
     };
@@ -458,16 +480,23 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const uint16_t *
         uint32_t pp2[KT][2], dsp2[KT][2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            const a_bf16x8 qa = ld_frag(tq + (qt * 16 + i16) * kP48 + 8 * g);
-            const a_bf16x8 da = ld_frag(tdo + (qt * 16 + i16) * kP48 + 8 * g);
+            a_bf16x8 qa[DS], da[DS];
+#pragma unroll
+            for (int sl = 0; sl < DS; ++sl) {
+                qa[sl] = ld_frag(tq + (qt * 16 + i16) * PT + 32 * sl + 8 * g);
+                da[sl] = ld_frag(tdo + (qt * 16 + i16) * PT + 32 * sl + 8 * g);
+            }
             float lq[4], dq_[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { lq[r] = sL[buf][qt * 16 + 4 * g + r]; dq_[r] = sD[buf][qt * 16 + 4 * g + r]; }
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
-                const a_f32x4 z = a_f32x4{0.f, 0.f, 0.f, 0.f};
-                const a_f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt], z, 0, 0, 0);    // S[q = 4g + r][key = i16]
-                const a_f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt], z, 0, 0, 0);
+                a_f32x4 s = a_f32x4{0.f, 0.f, 0.f, 0.f}, dp = a_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < DS; ++sl) {
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[sl], kf[kt][sl], s, 0, 0, 0);    // S[q = 4g + r][key = i16]
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[sl], vf[kt][sl], dp, 0, 0, 0);
+                }
                 const int key = kw0 + kt * 16 + i16;
                 float p[4], ds[4];
 #pragma unroll
@@ -484,9 +513,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const uint16_t *
             }
         }
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            const a_bf16x8 dot = tr_frag(tdo + tr_off + 16 * d, kP48);       // dO^T[d][q slots of g]
-            const a_bf16x8 qtf = tr_frag(tq + tr_off + 16 * d, kP48);        // Q^T
+        for (int d = 0; d < 2 * DS; ++d) {
+            const a_bf16x8 dot = tr_frag(tdo + tr_off + 16 * d, PT);         // dO^T[d][q slots of g]
+            const a_bf16x8 qtf = tr_frag(tq + tr_off + 16 * d, PT);          // Q^T
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
                 const a_bf16x8 pb = __builtin_bit_cast(a_bf16x8, make_uint4(pp[kt][0], pp[kt][1], pp2[kt][0], pp2[kt][1]));
@@ -503,12 +532,12 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const uint16_t *
         const int key = kw0 + kt * 16 + i16;
         if (key >= L) continue;
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
+        for (int d = 0; d < 2 * DS; ++d) {
             uint2 w;
             w.x = pack2(dka[d][kt][0], dka[d][kt][1]); w.y = pack2(dka[d][kt][2], dka[d][kt][3]);
-            *reinterpret_cast<uint2 *>(dk + ((int64_t)b * L + key) * lddk + h * kHD + 16 * d + 4 * g) = w;
+            *reinterpret_cast<uint2 *>(dk + ((int64_t)b * L + key) * lddk + h * HD + 16 * d + 4 * g) = w;
             w.x = pack2(dva[d][kt][0], dva[d][kt][1]); w.y = pack2(dva[d][kt][2], dva[d][kt][3]);
-            *reinterpret_cast<uint2 *>(dv + ((int64_t)b * L + key) * lddv + h * kHD + 16 * d + 4 * g) = w;
+            *reinterpret_cast<uint2 *>(dv + ((int64_t)b * L + key) * lddv + h * HD + 16 * d + 4 * g) = w;
         }
     }
 }
@@ -561,7 +590,7 @@ using namespace dfine;
 extern "C" {
 
 static bool attn_args_ok(int B, int L, int H, int hd, const int *lds_, int n) {
-    if (B < 1 || L < 1 || H < 1 || hd != kHD) return false;
+    if (B < 1 || L < 1 || H < 1 || (hd != kHD && hd != 2 * kHD)) return false;      // 32, or 64 (two slabs; 48 runs zero-padded to 64)
     for (int i = 0; i < n; ++i) if (lds_[i] < H * hd || (lds_[i] & 7)) return false;     // 16-byte aligned rows
     return true;
 }
@@ -597,8 +626,12 @@ int dfine_attn_fwd_ms(const void *q, const void *k, const void *v, void *o, floa
     if (!q || !k || !v || !o || !attn_args_ok(B, L, H, hd, lds_, 4)) return DFINE_E_BADARG;
     const float c = scale * 1.44269504088896340736f;
     const int nq = (L + 63) / 64;
-    hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(B * H * nq), dim3(kAttnThreads), 0, (hipStream_t)stream, (const uint16_t *)q,
-                       (const uint16_t *)k, (const uint16_t *)v, (uint16_t *)o, lse2, mask, msum, B, L, H, ldq, ldk, ldv, ldo, c);
+    if (hd == kHD)
+        hipLaunchKernelGGL((attn_fwd_kernel<1, 1>), dim3(B * H * nq), dim3(kAttnThreads), 0, (hipStream_t)stream, (const uint16_t *)q,
+                           (const uint16_t *)k, (const uint16_t *)v, (uint16_t *)o, lse2, mask, msum, B, L, H, ldq, ldk, ldv, ldo, c);
+    else
+        hipLaunchKernelGGL((attn_fwd_kernel<1, 2>), dim3(B * H * nq), dim3(kAttnThreads), 0, (hipStream_t)stream, (const uint16_t *)q,
+                           (const uint16_t *)k, (const uint16_t *)v, (uint16_t *)o, lse2, mask, msum, B, L, H, ldq, ldk, ldv, ldo, c);
     return check_launch();
 }
 
@@ -638,10 +671,24 @@ int dfine_attn_bwd_ms(const void *q, const void *k, const void *v, const void *o
     const float c = scale * 1.44269504088896340736f;
     hipStream_t st = (hipStream_t)stream;
     const int nq = (L + 63) / 64;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<1>, dim3(B * H * nq), dim3(kAttnThreads), 0, st, (const uint16_t *)q, (const uint16_t *)k,
-                       (const uint16_t *)v, (const uint16_t *)o, (const uint16_t *)dout, lse2, mask, msum, (uint16_t *)dq, delta, B, L, H,
-                       ldq, ldk, ldv, ldo, lddo, lddq, scale, c);
+    if (hd == kHD)
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<1, 1>), dim3(B * H * nq), dim3(kAttnThreads), 0, st, (const uint16_t *)q, (const uint16_t *)k,
+                           (const uint16_t *)v, (const uint16_t *)o, (const uint16_t *)dout, lse2, mask, msum, (uint16_t *)dq, delta, B, L, H,
+                           ldq, ldk, ldv, ldo, lddo, lddq, scale, c);
+    else
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<1, 2>), dim3(B * H * nq), dim3(kAttnThreads), 0, st, (const uint16_t *)q, (const uint16_t *)k,
+                           (const uint16_t *)v, (const uint16_t *)o, (const uint16_t *)dout, lse2, mask, msum, (uint16_t *)dq, delta, B, L, H,
+                           ldq, ldk, ldv, ldo, lddo, lddq, scale, c);
     if (int e = check_launch()) return e;
+    if (hd != kHD) {                                   // two slabs: 8 waves (the staging of a chunk needs 512 threads) of 32 keys each - with 64 keys
+        const int nk = (L + 255) / 256;                // per wave the accumulators spill (169 registers)
+#define DFINE_DKDV64(MM_) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<2, 8, MM_, 2>), dim3(B * H * nk), dim3(512), 0, st, (const uint16_t *)q, (const uint16_t *)k, \
+                             (const uint16_t *)v, (const uint16_t *)dout, lse2, (const float *)delta, mask, mask_bits, msumT, (uint16_t *)dk, (uint16_t *)dv, \
+                             B, L, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, c)
+        if (!mask) DFINE_DKDV64(0); else if (mask_bits) DFINE_DKDV64(2); else DFINE_DKDV64(1);
+#undef DFINE_DKDV64
+        return check_launch();
+    }
     // keys per workgroup: 512 (<4, 8>, <8, 4>), 256 (<2, 8>), 128 (<2, 4>): fewer keys = more workgroups for the same L
     static const int var = [] { const char *e = getenv("DFINE_ATTN_DKDV"); return e ? atoi(e) : 48; }();
 #define DFINE_DKDV_M(KT_, NW_, MM_)                                                                                                    \

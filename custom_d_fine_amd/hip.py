@@ -1297,11 +1297,18 @@ def _ld(t):
     return t.stride(1)
 
 
+def _attn_hd(hd):
+    """Head dim the kernels run a head of `hd` channels on: 32 or 64 (zero-padded copies otherwise)."""
+    return 32 if hd <= 32 else 64
+
+
 def _pad_heads(t, num_heads, hd):
-    """[B, L, H * hd] -> [B, L, H * 32] with every head zero-padded to 32 channels (head dims 8 / 16 / 24 run on the head-dim-32
-    kernels: zero channels add nothing to q k^T, and the extra output channels of v are dropped)."""
+    """[B, L, H * hd] -> [B, L, H * P], P = 32 or 64, with every head zero-padded to P channels (head dims 8 / 16 / 24 run on the
+    head-dim-32 kernels, 40 / 48 / 56 - the AIFI layer of D-FINE-x has 48 - on the head-dim-64 ones: zero channels add nothing to
+    q k^T, and the extra output channels of v are dropped)."""
     B, L, _ = t.shape
-    return torch.nn.functional.pad(t.reshape(B, L, num_heads, hd), (0, 32 - hd)).reshape(B, L, num_heads * 32)
+    P = _attn_hd(hd)
+    return torch.nn.functional.pad(t.reshape(B, L, num_heads, hd), (0, P - hd)).reshape(B, L, num_heads * P)
 
 
 def attn_forward(q, k, v, num_heads, mask=None):
@@ -1310,13 +1317,14 @@ def attn_forward(q, k, v, num_heads, mask=None):
     B, L, E = q.shape
     hd = E // num_heads
     msum = None if mask is None else _mask_forms(mask)[1]
-    if hd != 32:
+    if hd not in (32, 64):
+        P = _attn_hd(hd)
         qp, kp, vp = (_pad_heads(t, num_heads, hd) for t in (q, k, v))
-        o = torch.empty(B, L, num_heads * 32, device=q.device, dtype=torch.bfloat16)
+        o = torch.empty(B, L, num_heads * P, device=q.device, dtype=torch.bfloat16)
         lse2 = torch.empty(B, num_heads, L, device=q.device, dtype=torch.float32)
-        _check(_lib.dfine_attn_fwd_ms(_ptr(qp), _ptr(kp), _ptr(vp), _ptr(o), _ptr(lse2), _ptr(mask), _ptr(msum), B, L, num_heads, 32, _ld(qp),
-                                      _ld(kp), _ld(vp), num_heads * 32, float(hd) ** -0.5, _stream()), "dfine_attn_fwd_ms")
-        return o.reshape(B, L, num_heads, 32)[..., :hd].reshape(B, L, E), lse2
+        _check(_lib.dfine_attn_fwd_ms(_ptr(qp), _ptr(kp), _ptr(vp), _ptr(o), _ptr(lse2), _ptr(mask), _ptr(msum), B, L, num_heads, P, _ld(qp),
+                                      _ld(kp), _ld(vp), num_heads * P, float(hd) ** -0.5, _stream()), "dfine_attn_fwd_ms")
+        return o.reshape(B, L, num_heads, P)[..., :hd].reshape(B, L, E), lse2
     o = torch.empty(B, L, E, device=q.device, dtype=torch.bfloat16)
     lse2 = torch.empty(B, num_heads, L, device=q.device, dtype=torch.float32)
     with _timed("attention", 4.0 * B * num_heads * L * L * hd, io=2.0 * 4 * B * num_heads * L * hd):
@@ -1359,14 +1367,15 @@ def attn_backward(q, k, v, o, dout, lse2, num_heads, dq, dk, dv, mask=None):
     hd = E // num_heads
     delta = torch.empty_like(lse2)
     mbits, msum = (None, None) if mask is None else _mask_forms(mask)
-    if hd != 32:
+    if hd not in (32, 64):
+        P = _attn_hd(hd)
         qp, kp, vp, op, dop = (_pad_heads(t, num_heads, hd) for t in (q, k, v, o, dout))
-        g = torch.empty(3, B, L, num_heads * 32, device=q.device, dtype=torch.bfloat16)
+        g = torch.empty(3, B, L, num_heads * P, device=q.device, dtype=torch.bfloat16)
         _check(_lib.dfine_attn_bwd_ms(_ptr(qp), _ptr(kp), _ptr(vp), _ptr(op), _ptr(dop), _ptr(lse2), _ptr(mask), _ptr(mbits), _ptr(msum), _ptr(g[0]),
-                                      _ptr(g[1]), _ptr(g[2]), _ptr(delta), B, L, num_heads, 32, _ld(qp), _ld(kp), _ld(vp), _ld(op), _ld(dop),
+                                      _ptr(g[1]), _ptr(g[2]), _ptr(delta), B, L, num_heads, P, _ld(qp), _ld(kp), _ld(vp), _ld(op), _ld(dop),
                                       _ld(g[0]), _ld(g[1]), _ld(g[2]), float(hd) ** -0.5, _stream()), "dfine_attn_bwd_ms")
         for dst, src in zip((dq, dk, dv), g):
-            dst.copy_(src.reshape(B, L, num_heads, 32)[..., :hd].reshape(B, L, E))
+            dst.copy_(src.reshape(B, L, num_heads, P)[..., :hd].reshape(B, L, E))
         return
     with _timed("attention", 10.0 * B * num_heads * L * L * hd, io=2.0 * 8 * B * num_heads * L * hd):
         _check(_lib.dfine_attn_bwd_ms(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(dout), _ptr(lse2), _ptr(mask), _ptr(mbits), _ptr(msum), _ptr(dq),

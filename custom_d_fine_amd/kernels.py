@@ -2048,7 +2048,7 @@ def self_attention(qk, value, in_w, in_b, out_w, out_b, num_heads: int, attn_mas
     boolean `attn_mask` [L, L], True = blocked (ref hybrid_encoder.py:243-290, dfine_decoder.py:200,233-255)."""
     b, l, e = qk.shape
     hd = e // num_heads
-    if (hd in (8, 16, 24, 32) and e % 8 == 0 and in_b is not None and out_b is not None and _hip_linear_ok(qk, in_w)
+    if (hd in (8, 16, 24, 32, 40, 48, 56, 64) and e % 8 == 0 and in_b is not None and out_b is not None and _hip_linear_ok(qk, in_w)
             and _env("DFINE_HIP_ATTN", "1") == "1" and (attn_mask is None or (attn_mask.dtype == torch.bool and attn_mask.shape == (l, l)))):
         m8 = None if attn_mask is None else attn_mask.contiguous().view(torch.uint8)
         return _MHA.apply(qk, value, in_w, in_b, out_w, out_b, num_heads, m8)
@@ -2065,7 +2065,7 @@ def self_attention(qk, value, in_w, in_b, out_w, out_b, num_heads: int, attn_mas
             o = attention_f32(q.float(), k.float(), v.float(), mask).to(q.dtype)
     else:
         if q.is_cuda and _bf16_autocast() and _env("DFINE_HIP_ATTN", "1") == "1":
-            _library_fallback(f"self-attention with head dim {hd} (kernels: 8 / 16 / 24 / 32)")
+            _library_fallback(f"self-attention with head dim {hd} (kernels: multiples of 8 up to 64)")
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
     return linear(o.transpose(1, 2).reshape(b, l, e), out_w, out_b)
 

@@ -114,6 +114,29 @@ def test_attention_forward_backward(cuda, B, L, masked):
     _close(dv, vr.grad, tol=2e-2, what="dv")
 
 
+@pytest.mark.parametrize("hd,B,L,masked", [(48, 2, 900, False), (48, 2, 300, True), (64, 2, 400, False), (64, 1, 498, True), (40, 1, 77, True)])
+def test_attention_head_dims_up_to_64(cuda, hd, B, L, masked):
+    """Head dims above 32 (48 = the AIFI layer of D-FINE-x, ref configs.py:182, hybrid_encoder.py:243-290) on the two-slab
+    instantiations of the attention kernels (48 / 40 zero-padded to 64) vs fp32 softmax attention."""
+    from custom_d_fine_amd import hip
+    H = 8
+    E = H * hd
+    g = torch.Generator().manual_seed(L + hd)
+    q, k, v, do = ((torch.randn(B, L, E, generator=g) * (1.2 if i < 2 else 1.0)).bfloat16().to(cuda) for i in range(4))
+    mask = _dn_mask(L, (L // 3) // 4 * 4, 4).to(cuda) if masked else None
+    m8 = None if mask is None else mask.contiguous().view(torch.uint8)
+    o, lse2 = hip.attn_forward(q, k, v, H, m8)
+    qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    ref = _attn_ref(qr, kr, vr, mask, H)
+    _close(o, ref, what="o")
+    ref.backward(do.float())
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    hip.attn_backward(q, k, v, o, do, lse2, H, dq, dk, dv, m8)
+    _close(dq, qr.grad, tol=2e-2, what="dq")
+    _close(dk, kr.grad, tol=2e-2, what="dk")
+    _close(dv, vr.grad, tol=2e-2, what="dv")
+
+
 def test_attention_online_softmax_rescale_branch(cuda):
     """Keys are streamed in blocks of 256 with a running max: force the max to jump in the LAST block (a key that matches
     its query far better than anything before) - a wrong rescale of the accumulated output would be O(1) wrong."""
