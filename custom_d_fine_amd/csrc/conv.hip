@@ -2408,7 +2408,8 @@ int dfine_conv1x1_seg_wgrad_bf16(const void *const *x_parts, const int *x_channe
 
 static void linear_wgrad_plan(int M, int N, int K, int *splits, int *rows) {
     const int pairs = ((N + 63) / 64) * ((K + 63) / 64);
-    int sp = 1024 / pairs;
+    static const int wgs = [] { const char *e = getenv("DFINE_LINEAR_WGRAD_WGS"); const int v = e ? atoi(e) : 256; return v < 16 ? 16 : v; }();     // (1024: +0.25 ms per step - 4x the partial sums)
+    int sp = wgs / pairs;
     if (sp < 1) sp = 1;
     if (sp > 128) sp = 128;
     int r = ((M + sp - 1) / sp + 63) / 64 * 64;
