@@ -2486,7 +2486,8 @@ int dfine_linear_wgrad_group_row(const void *x, const void *dy, float *ws, int M
 static int wgrad1_group_target() {
     // measured (D-FINE-m step, ms median): 256 -> 33.29 / 33.41, 128 -> 33.37, 64 -> 33.51 / 33.58, 32 -> 33.91: the kernels gain more
     // from the parallelism of many splits than the step loses to their partial sums (2.7 -> 1.6 GB at 64) - the default keeps 256
-    static const int t = [] { const char *e = getenv("DFINE_WGRAD1_GROUP_WGS"); const int v = e ? atoi(e) : 256; return v < 8 ? 8 : v; }();
+    // (re-measured at the end of round 5, 29.0 ms steps: 256 -> 29.04 / 29.03, 128 -> 29.02 / 29.01, 64 -> 29.18: 128 for half the partial sums)
+    static const int t = [] { const char *e = getenv("DFINE_WGRAD1_GROUP_WGS"); const int v = e ? atoi(e) : 128; return v < 8 ? 8 : v; }();
     return t;
 }
 
