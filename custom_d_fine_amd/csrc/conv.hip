@@ -2084,7 +2084,8 @@ static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B
     const size_t ldsb = slab_bytes * kc;
     const int vec = (W % 8 == 0) ? 8 : (W % 4 == 0 ? 4 : 2);
     const int nblk64 = (NP + 63) / 64;
-    const bool wide = (NP % 128 == 0) && ((int64_t)B * strips * (NP / 128) >= 512);
+    static const int wide_min = [] { const char *e = getenv("DFINE_CONV3_WIDE_MIN"); return e ? atoi(e) : 512; }();
+    const bool wide = (NP % 128 == 0) && ((int64_t)B * strips * (NP / 128) >= wide_min);
     const size_t ws_ep = (size_t)4 * 16 * (wide ? 2 : 1) * (16 * kMaxPixTiles + 8) * 2;
     int kc_ws = kc > 2 ? 2 : kc;                               // two buffers: the stage overhead is already hidden
     const size_t ws_slab = (size_t)(R + 2 * pad) * ws_pitch(W) * 64;
