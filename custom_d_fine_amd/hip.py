@@ -510,7 +510,7 @@ def dwconv_backward(x, w, dy, stride, pad, need_dx=True, need_dw=True, side_dw=F
     K = w.shape[-1]
     dx = torch.empty_like(x) if need_dx else None
     dw = torch.zeros(w.shape, device=x.device, dtype=torch.float32) if need_dw else None
-    if side_dw and need_dw and _side_ok():
+    if side_dw and need_dw and _side_ok("dw"):
         st = _side_fork(x.device)
         _check(_lib.dfine_dwconv_bwd(_ptr(x), _ptr(w), _ptr(dy), None, _ptr(dw), _dtype_code(x), B, C, H, W, K, stride, pad,
                                      st.cuda_stream), "dfine_dwconv_bwd")
@@ -980,7 +980,7 @@ def conv1x1_seg_wgrad(x_parts, dy, partials=False):
     dw = None if partials else torch.empty(cout, cin, 1, 1, device=dy.device, dtype=torch.float32)
     ws = torch.empty(int(_PURE.dfine_conv_wgrad_ws_floats(B, cin, cout, H, W, 1)), device=dy.device, dtype=torch.float32)
     xp, xc, xb = _seg_arrays(x_parts)
-    if partials and _side_ok():
+    if partials and _side_ok("seg"):
         st = _side_fork(dy.device)
         with _timed("conv1x1_wgrad", 2.0 * B * H * W * cin * cout, io=2.0 * B * H * W * (cin + cout) + 4.0 * cin * cout, stream=st.stream):
             _check(_lib.dfine_conv1x1_seg_wgrad_bf16(xp, xc, xb, len(x_parts), _ptr(dy), None, _ptr(ws), B, cin, cout, H, W,
@@ -1018,8 +1018,14 @@ CAPTURE_DUAL = None       # set by dl.engine.GraphedSegment while it captures a 
                           # side_launch() is told about every side-stream launch and decides where one pair ends and the next begins
 
 
-def _side_ok():
-    return WGRAD_STREAM and not _TIMING_ISOLATED and (CAPTURE_SIDE or CAPTURE_DUAL is not None or not torch.cuda.is_current_stream_capturing())
+# which weight-gradient launches go to the side stream (DFINE_SIDE_KINDS, comma separated): dw (depthwise), seg (part-wise 1x1), conv1,
+# conv3, group (grouped 1x1), linear (grouped token-stream linears), reduce (split reductions), stem
+_SIDE_KINDS = frozenset(k for k in os.environ.get("DFINE_SIDE_KINDS", "dw,seg,conv1,conv3,group,linear,reduce,stem").split(",") if k)
+
+
+def _side_ok(kind=None):
+    return (WGRAD_STREAM and not _TIMING_ISOLATED and (kind is None or kind in _SIDE_KINDS)
+            and (CAPTURE_SIDE or CAPTURE_DUAL is not None or not torch.cuda.is_current_stream_capturing()))
 
 
 def side_stream_ok():
@@ -1105,7 +1111,7 @@ def conv_wgrad_bf16(x, dy, ks, partials=False):
         need_pad = True
     if need_pad:
         padw = (x.shape[3] + 7) // 8 * 8 - x.shape[3]
-        if partials and _side_ok():
+        if partials and _side_ok("conv3" if ks == 3 else "conv1"):
             # the zero-padded copies are part of the weight-gradient work: made on the side stream too (their blocks belong to
             # its allocator pool and stay referenced until the join)
             st = _side_fork(x.device)
@@ -1124,11 +1130,11 @@ def conv_wgrad_bf16(x, dy, ks, partials=False):
         # a problem of a grouped launch is cut into fewer splits than a stand-alone one (dfine_conv_wgrad1_group_splits)
         ws = torch.empty(int(_PURE.dfine_conv_wgrad1_group_ws_floats(B, cin, cout, H * W)), device=x.device, dtype=torch.float32)
         _CW_PENDING.append((x, dy, ws, B, cin, cout, H * W))
-        if len(_CW_PENDING) >= _SIDE_GROUP_AT and _side_ok():
+        if len(_CW_PENDING) >= _SIDE_GROUP_AT and _side_ok("group"):
             _flush_conv_group(True)          # ... or in a few, on the side stream while backward goes on
         return ws, (int(_PURE.dfine_conv_wgrad1_group_splits(B, cin, cout, H * W)), cout, cin, 1, _p16(cout), _p16(cin))
     ws = torch.empty(int(_PURE.dfine_conv_wgrad_ws_floats(B, cin, cout, H, W, ks)), device=x.device, dtype=torch.float32)
-    if partials and _side_ok():
+    if partials and _side_ok("conv3" if ks == 3 else "conv1"):
         if st is None:
             st = _side_fork(x.device)
         with _timed(f"conv{ks}x{ks}_wgrad", 2.0 * B * H * W * cin * cout * ks * ks,
@@ -1151,7 +1157,7 @@ def multi_wgrad_reduce_blocks(splits, elems):
 def multi_wgrad_reduce(table, n_entries, max_blocks, io=0.0, side=False):
     """io: bytes of partial sums + destinations the launch streams (its roofline is HBM; no FLOPs of its own).
     side: on the side stream, behind the weight-gradient launches already queued there."""
-    if side and _side_ok():
+    if side and _side_ok("reduce"):
         st = _side_fork(table.device)             # (forked after the table's upload was enqueued on the current stream)
         with _timed("wgrad_reduce", 0.0, io=io, stream=st.stream):
             _check(_lib.dfine_multi_wgrad_reduce(_ptr(table), n_entries, int(max_blocks), st.cuda_stream), "dfine_multi_wgrad_reduce")
@@ -1403,7 +1409,7 @@ def linear_wgrad_partials(x2d, dy2d):
     ws = torch.empty(int(_PURE.dfine_linear_wgrad_ws_floats(M, N, K)), device=x2d.device, dtype=torch.float32)
     if _LW_GROUP:
         _LW_PENDING.append((x2d, dy2d, ws, M, N, K))
-        if len(_LW_PENDING) >= (_LW_GROUP_AT or 2 * _SIDE_GROUP_AT) and _side_ok():
+        if len(_LW_PENDING) >= (_LW_GROUP_AT or 2 * _SIDE_GROUP_AT) and _side_ok("linear"):
             _flush_linear_group(True)
     else:
         with _timed("linear_wgrad", 2.0 * M * N * K, io=2.0 * M * (N + K) + 4.0 * N * K):
@@ -1480,9 +1486,9 @@ def linear_wgrad_flush(side=False):
     caller continues there: an early reduction under the rest of backward)."""
     side = side and _side_ok()
     if _CW_PENDING:
-        _flush_conv_group(side)
+        _flush_conv_group(side and _side_ok("group"))
     if _LW_PENDING:
-        _flush_linear_group(side)
+        _flush_linear_group(side and _side_ok("linear"))
     while len(_LW_KEEP) > 4:
         _LW_KEEP.pop(0)
     if not side:
@@ -1590,7 +1596,7 @@ def stem_wgrad(x, dy, ks, stride, pad, side=False):
     B, cin, H, W = x.shape
     _, cout, ho, wo = dy.shape
     need = int(_PURE.dfine_stem_wgrad_ws_floats(B, cin, cout, ks, ho, wo))
-    side = side and _side_ok()
+    side = side and _side_ok("stem")
     st = _side_fork(x.device) if side else None
     key = (x.device.index, st.cuda_stream if side else _stream())
     ws = _STEM_WS.get(key)
@@ -1637,7 +1643,7 @@ def stem_wgrad2(xa, xb, dy, ks, stride, pad, side=False):
     cin = ca + xb.shape[1]
     _, cout, ho, wo = dy.shape
     need = int(_PURE.dfine_stem_wgrad_ws_floats(B, cin, cout, ks, ho, wo))
-    side = side and _side_ok()
+    side = side and _side_ok("stem")
     if side:
         backward_tail_begins()
     st = _side_fork(xa.device) if side else None
