@@ -38,14 +38,15 @@ class ConvNormLayer_fuse(nn.Module):
         self.ch_in, self.ch_out, self.kernel_size, self.stride = ch_in, ch_out, kernel_size, stride
         self.g, self.padding, self.bias = g, padding, bias
 
-    def forward(self, x):
+    def forward(self, x, fanin=None):
+        """fanin: kernels.GradFanIn of x (this unit is the consumer of x that runs its backward last)."""
         if hasattr(self, "conv_bn_fused"):                 # deployed form: BN folded into the conv
             if self._act_name is not None or isinstance(self.act, nn.Identity):
                 return kernels.conv_bias_act(x, self.conv_bn_fused, self._act_name)
             return self.act(kernels.conv_bias_act(x, self.conv_bn_fused, None))
         if self._act_name is not None or isinstance(self.act, nn.Identity):
-            return kernels.conv_bn_act(x, self.conv, self.norm, self._act_name, None)
-        return self.act(kernels.conv_bn_act(x, self.conv, self.norm, None, None))
+            return kernels.conv_bn_act(x, self.conv, self.norm, self._act_name, None, fanin=fanin)
+        return self.act(kernels.conv_bn_act(x, self.conv, self.norm, None, None, fanin=fanin))
 
     def get_equivalent_kernel_bias(self):
         return _fold_bn(self.conv, self.norm)
@@ -85,7 +86,9 @@ class SCDown(nn.Module):
         self.cv2 = ConvNormLayer_fuse(c2, c2, k, s, c2)
 
     def forward(self, x):
-        return self.cv2(self.cv1(x))
+        # (the gradient hand-off of x, if any, is left on the module by the caller: the unit sits inside an nn.Sequential, whose
+        # forward - and forward hooks - take no keyword arguments)
+        return self.cv2(self.cv1(x, fanin=self.__dict__.pop("_pending_fanin", None)))
 
 
 class VGGBlock(nn.Module):
@@ -357,8 +360,14 @@ class HybridEncoder(nn.Module):
                 up = kernels.upsample2_nearest(top)
             inner.insert(0, self.fpn_blocks[k]([up, proj[idx - 1]]))
 
-        outs = [inner[0]]
+        # outs[0], outs[1] have two consumers: the down-sampling unit of the next PAN level (a 1x1 convolution first) and the
+        # decoder (created later = its backward runs first): the decoder's gradient is parked and the 1x1 convolution's data
+        # gradient adds onto it in its epilogue instead of autograd adding two maps (kernels.GradFanIn / park_grad)
+        outs, fans = [inner[0]], []
         for idx in range(nlev - 1):
+            fan = kernels.GradFanIn() if kernels.grad_fanin_enabled(outs[-1]) else None
+            self.downsample_convs[idx][0].__dict__["_pending_fanin"] = fan
             down = self.downsample_convs[idx](outs[-1])
+            fans.append(fan)
             outs.append(self.pan_blocks[idx]([down, inner[idx + 1]]))
-        return outs
+        return [kernels.park_grad(o, f) for o, f in zip(outs, fans + [None])]

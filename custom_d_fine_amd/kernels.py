@@ -827,6 +827,37 @@ class GradFanIn:
         return buf
 
 
+class _ParkGrad(torch.autograd.Function):
+    """Identity whose backward PARKS the incoming gradient in a GradFanIn and reports None: for a map with two consumers of which
+    the one that runs its backward LAST is a dense convolution (it adds its data gradient onto the parked one in its epilogue,
+    _DenseConvBNAct) and the other one is anything else.  Put on the path to that other consumer."""
+
+    @staticmethod
+    def forward(ctx, x, fan):
+        ctx.fan = fan
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        fan, ctx.fan = ctx.fan, None
+        g = g.contiguous()
+        fan.buf = g if g.dtype == torch.bfloat16 else g.to(torch.bfloat16)
+        return None, None
+
+
+def park_grad(x, fan):
+    """x for the consumer whose backward runs FIRST (the one created later in the forward pass); `fan` was handed to the dense
+    convolution that consumes x too (conv_bn_act(..., fanin=fan)) and is armed if that unit can accumulate."""
+    # Only inside a captured segment (dl/engine.py): the convolution adds IN PLACE onto the parked tensor, and there that tensor is
+    # the segment's own static output-gradient buffer, refilled before every replay.  In an eager backward the incoming gradient may
+    # be a tensor the caller still owns (torch.autograd.backward(outs, grads)): it must not be written to - autograd adds as usual.
+    if (fan is None or not fan.armed or not x.requires_grad or x.dtype != torch.bfloat16
+            or not (_CAPTURE_POSSIBLE and torch.cuda.is_current_stream_capturing())):
+        return x
+    fan.parking = True
+    return _ParkGrad.apply(x, fan)
+
+
 class BNLink:
     """Hand-off of the BatchNorm-backward sums between a conv + BatchNorm unit (the PRODUCER of a map) and the convolution
     that forms the map's complete gradient in backward (its only CONSUMER, or - GradFanIn - the later of its two consumers,
