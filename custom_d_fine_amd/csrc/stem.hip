@@ -758,6 +758,9 @@ __global__ void stem_pool_fwd8_kernel(const uint16_t *__restrict__ x, uint16_t *
     *reinterpret_cast<uint4 *>(y + pl * H * W + (int64_t)yy * W + x0) = pack8(o);
 }
 
+// ACC: dx += the pool's gradient (dx holds the gradient of the map's other consumer: bf16 + bf16 in fp32, one rounding - what
+// autograd's add of the two gradient maps would give)
+template <bool ACC>
 __global__ void stem_pool_bwd8_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy, uint16_t *__restrict__ dx,
                                       int H, int W, int64_t planes) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -783,7 +786,17 @@ __global__ void stem_pool_bwd8_kernel(const uint16_t *__restrict__ x, const uint
         if (first_max4(n1[c], n1[c + 1], n2[c], n2[c + 1]) == 0) s += g1[c];
         o[j] = s;
     }
-    *reinterpret_cast<uint4 *>(dx + pl * H * W + (int64_t)yy * W + x0) = pack8(o);
+    uint4 *dst = reinterpret_cast<uint4 *>(dx + pl * H * W + (int64_t)yy * W + x0);
+    if (ACC) {
+        const uint4 old = *dst;
+        const uint32_t w[4] = {old.x, old.y, old.z, old.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float prev = (j & 1) ? __uint_as_float(w[j >> 1] & 0xffff0000u) : __uint_as_float(w[j >> 1] << 16);
+            o[j] = bf16_to_f32(f32_to_bf16(o[j])) + prev;
+        }
+    }
+    *dst = pack8(o);
 }
 
 struct StemCfg { int cin, cout, ks, s; };
@@ -1018,12 +1031,23 @@ int dfine_stem_pool_fwd(const void *x, void *y, int64_t planes, int H, int W, vo
     return check_launch();
 }
 
+// dx += the pool's gradient (W % 8 == 0 only): the gradient fan-in of stem1's output (pool + stem2a, ref hgnetv2.py:158-163) without
+// the element-wise add
+int dfine_stem_pool_bwd_acc(const void *x, const void *dy, void *dx, int64_t planes, int H, int W, void *stream) {
+    if (planes == 0) return DFINE_OK;
+    if (!x || !dy || !dx || H < 1 || W < 1 || W % 8) return DFINE_E_BADARG;
+    const int64_t n = planes * H * W;
+    hipLaunchKernelGGL(stem_pool_bwd8_kernel<true>, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)x, (const uint16_t *)dy, (uint16_t *)dx, H, W, planes);
+    return check_launch();
+}
+
 int dfine_stem_pool_bwd(const void *x, const void *dy, void *dx, int64_t planes, int H, int W, void *stream) {
     if (planes == 0) return DFINE_OK;
     if (!x || !dy || !dx || H < 1 || W < 1) return DFINE_E_BADARG;
     const int64_t n = planes * H * W;
     if (W % 8 == 0)
-        hipLaunchKernelGGL(stem_pool_bwd8_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(stem_pool_bwd8_kernel<false>, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                            (const uint16_t *)x, (const uint16_t *)dy, (uint16_t *)dx, H, W, planes);
     else
         hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,

@@ -90,9 +90,13 @@ class StemBlock(nn.Module):
         # the two F.pad(., (0,1,0,1)) of the reference are folded into their consumers: the 2x2 convs and
         # the max-pool read zeros past the bottom / right edge (HIP stem kernels; ATen composition on CPU)
         x = self.stem1(x)
-        branch = self.stem2b(self.stem2a(x, pad_br=True), pad_br=True)
+        # x has two consumers.  The pool is created first, so its backward runs last: stem2a's data gradient is parked and the
+        # pool's backward adds its own onto it (kernels.GradFanIn) - no element-wise add of two [B, mid, H/2, W/2] maps
+        fan = kernels.GradFanIn() if kernels._env("DFINE_STEM_FANIN", "1") == "1" else None
+        pooled = kernels.stem_pool(x, fanin=fan)
+        branch = self.stem2b(self.stem2a(kernels.park_grad(x, fan, owned=True), pad_br=True), pad_br=True)
         # the concatenation is never built on the GPU: stem3 reads both tensors in place (kernels._StemConv2)
-        return self.stem4(self.stem3([kernels.stem_pool(x), branch]))
+        return self.stem4(self.stem3([pooled, branch]))
 
 
 class EseModule(nn.Module):

@@ -154,6 +154,7 @@ _SIGNATURES = {
     "dfine_stem_wgrad2_bf16": (c_int, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_stem_pool_fwd": (c_int, [_P, _P, _L, _I, _I, _P]),
     "dfine_stem_pool_bwd": (c_int, [_P, _P, _P, _L, _I, _I, _P]),
+    "dfine_stem_pool_bwd_acc": (c_int, [_P, _P, _P, _L, _I, _I, _P]),
     "dfine_bn_act_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 for _name, (_res, _args) in _SIGNATURES.items():
@@ -1671,8 +1672,12 @@ def stem_pool_forward(x):
     return y
 
 
-def stem_pool_backward(x, dy):
+def stem_pool_backward(x, dy, acc=None):
+    """acc: a gradient of x from its other consumer (bf16, contiguous): the pool's gradient is added onto it in place."""
     B, C, H, W = x.shape
+    if acc is not None:
+        _check(_lib.dfine_stem_pool_bwd_acc(_ptr(x), _ptr(dy), _ptr(acc), B * C, H, W, _stream()), "dfine_stem_pool_bwd_acc")
+        return acc
     dx = torch.empty_like(x)
     _check(_lib.dfine_stem_pool_bwd(_ptr(x), _ptr(dy), _ptr(dx), B * C, H, W, _stream()), "dfine_stem_pool_bwd")
     return dx

@@ -845,14 +845,16 @@ class _ParkGrad(torch.autograd.Function):
         return None, None
 
 
-def park_grad(x, fan):
-    """x for the consumer whose backward runs FIRST (the one created later in the forward pass); `fan` was handed to the dense
-    convolution that consumes x too (conv_bn_act(..., fanin=fan)) and is armed if that unit can accumulate."""
+def park_grad(x, fan, owned=False):
+    """x for the consumer whose backward runs FIRST (the one created later in the forward pass); `fan` was handed to the unit
+    that consumes x too and runs its backward last (conv_bn_act(..., fanin=fan), stem_pool(x, fanin=fan)) and is armed if that
+    unit can accumulate.  owned: the parked gradient is always a fresh tensor of this module's own backward (a convolution's
+    data gradient) - then it may be written in place in an eager backward too."""
     # Only inside a captured segment (dl/engine.py): the convolution adds IN PLACE onto the parked tensor, and there that tensor is
     # the segment's own static output-gradient buffer, refilled before every replay.  In an eager backward the incoming gradient may
     # be a tensor the caller still owns (torch.autograd.backward(outs, grads)): it must not be written to - autograd adds as usual.
     if (fan is None or not fan.armed or not x.requires_grad or x.dtype != torch.bfloat16
-            or not (_CAPTURE_POSSIBLE and torch.cuda.is_current_stream_capturing())):
+            or not (owned or (_CAPTURE_POSSIBLE and torch.cuda.is_current_stream_capturing()))):
         return x
     fan.parking = True
     return _ParkGrad.apply(x, fan)
@@ -1319,9 +1321,15 @@ class _StemPool(torch.autograd.Function):
     """MaxPool2d(2, stride 1, ceil_mode) of F.pad(x, (0, 1, 0, 1)) without materialising the padded map."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, fanin=None):
+        """fanin: GradFanIn of x - the pool is created BEFORE x's other consumer (StemBlock), so its backward runs last and adds
+        its gradient onto the parked one."""
         x = x.contiguous()
         ctx.save_for_backward(x)
+        ctx.fanin = None
+        if fanin is not None and ctx.needs_input_grad[0] and x.dtype == torch.bfloat16 and x.shape[-1] % 8 == 0:
+            fanin.armed = True
+            ctx.fanin = fanin
         return _hip().stem_pool_forward(x)
 
     @staticmethod
@@ -1330,7 +1338,10 @@ class _StemPool(torch.autograd.Function):
         dy = dy.contiguous()
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
-        return _hip().stem_pool_backward(x, dy)
+        fan, ctx.fanin = ctx.fanin, None
+        if fan is not None and fan.parking:
+            return _hip().stem_pool_backward(x, dy, acc=fan.take()), None
+        return _hip().stem_pool_backward(x, dy), None
 
 
 def stem_fast_path(x):
@@ -1339,10 +1350,10 @@ def stem_fast_path(x):
             and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
 
 
-def stem_pool(x):
+def stem_pool(x, fanin=None):
     """pool(F.pad(x, (0,1,0,1))) of StemBlock (ref hgnetv2.py:158-160)."""
     if stem_fast_path(x) and x.dtype == torch.bfloat16:
-        return _StemPool.apply(x)
+        return _StemPool.apply(x, fanin)
     return F.max_pool2d(F.pad(x, (0, 1, 0, 1)), kernel_size=2, stride=1, ceil_mode=True)
 
 

@@ -700,6 +700,8 @@ int dfine_stem_wgrad2_bf16(const void *xa, const void *xb, int Ca, const void *d
                            int Cout, int H, int W, int Ho, int Wo, int KS, int stride, int pad, void *stream);
 int dfine_stem_pool_fwd(const void *x, void *y, int64_t planes, int H, int W, void *stream);
 int dfine_stem_pool_bwd(const void *x, const void *dy, void *dx, int64_t planes, int H, int W, void *stream);
+/* dx += the pool's gradient (W % 8 == 0): dx already holds the gradient of the map's other consumer (stem2a) */
+int dfine_stem_pool_bwd_acc(const void *x, const void *dy, void *dx, int64_t planes, int H, int W, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A5/A6  Residual / gate + LayerNorm of the token streams, one pass each way

@@ -70,6 +70,32 @@ def test_stem_pool_matches_aten_bit_exact(cuda, shape):
     assert ((x.grad != 0) == (xr.grad != 0)).all()              # same argmax choice on ties
 
 
+def test_stem_pool_backward_onto_parked_gradient(cuda):
+    """StemBlock's stem1 output feeds the pool and stem2a (ref hgnetv2.py:158-163): the pool's backward adds its gradient onto
+    stem2a's parked one - bit-identical to autograd's separate add of the two bf16 maps."""
+    from custom_d_fine_amd import hip, kernels
+    torch.manual_seed(4)
+    x = (torch.relu(torch.randn(3, 24, 40, 64, device=cuda)) * 0.7 - 0.1).to(torch.bfloat16)
+    dy = torch.randn_like(x)
+    other = torch.randn_like(x)
+    want = hip.stem_pool_backward(x, dy) + other
+    got = other.clone()
+    assert hip.stem_pool_backward(x, dy, acc=got) is got
+    assert torch.equal(got, want)
+
+    # through autograd, eager: pool created first -> its backward runs after the other consumer's
+    xa = x.clone().requires_grad_(True)
+    fan = kernels.GradFanIn()
+    with torch.autocast("cuda", dtype=torch.bfloat16):         # the stem kernels serve the autocast path
+        p = kernels.stem_pool(xa, fanin=fan)
+        q = kernels.park_grad(xa, fan, owned=True) * 1.5
+        assert fan.armed and fan.parking
+        torch.autograd.backward([p, q], [dy, other])
+        xb = x.clone().requires_grad_(True)
+        torch.autograd.backward([kernels.stem_pool(xb), xb * 1.5], [dy, other])
+    assert torch.equal(xa.grad, xb.grad)
+
+
 def test_stem_block_matches_aten_composition(cuda):
     """Whole StemBlock under bf16 autocast: the HIP path and the ATen bf16 path of the same module
     (DFINE_STEM=0) are compared with the module run in fp32; bf16 rounding flips ReLU / max-pool choices,
