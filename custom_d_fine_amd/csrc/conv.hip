@@ -2397,6 +2397,23 @@ int dfine_conv1x1_seg_fwd_bf16(const void *const *x_parts, const int *x_channels
     return launch_conv1x1(nullptr, (const uint16_t *)w2, nullptr, B, Cin, Cout, NP, KP, H * W, (hipStream_t)stream, &xs_, &ys_);
 }
 
+// y_parts += the same convolution: a data gradient added onto the channel slice of a wider gradient map that already holds the
+// other consumers' terms (RepNCSPELAN4: cv1's output feeds cv4 whole and the CSP branch through its upper half, ref
+// hybrid_encoder.py:196-206) - no data-gradient tensor of its own, no element-wise add, no zero-filled slice gradient.
+int dfine_conv1x1_seg_accum_bf16(const void *const *x_parts, const int *x_channels, const int *x_bstrides, int n_x, const void *w2,
+                                 void *const *y_parts, const int *y_channels, const int *y_bstrides, int n_y, int B, int Cin, int Cout,
+                                 int H, int W, void *stream) {
+    if (B == 0) return DFINE_OK;
+    ChanSegs xs_, ys_;
+    if (!w2 || !make_segs(&xs_, x_parts, x_channels, x_bstrides, n_x, Cin) ||
+        !make_segs(&ys_, (const void *const *)y_parts, y_channels, y_bstrides, n_y, Cout))
+        return DFINE_E_BADARG;
+    if ((H * W) % 8 || Cin % 2) return DFINE_E_BADARG;
+    const int NP = (Cout + 15) / 16 * 16, KP = (Cin + 31) / 32 * 32;
+    if (!conv1x1_glds_ok(Cin, KP, H * W)) return DFINE_E_BADARG;           // only the LDS-DMA kernel accumulates
+    return launch_conv1x1(nullptr, (const uint16_t *)w2, nullptr, B, Cin, Cout, NP, KP, H * W, (hipStream_t)stream, &xs_, &ys_, 1);
+}
+
 // weight gradient of the same: dw [Cout, Cin] f32 (overwritten), ws: dfine_conv_wgrad_ws_floats(B, Cin, Cout, H, W, 1) floats
 int dfine_conv1x1_seg_wgrad_bf16(const void *const *x_parts, const int *x_channels, const int *x_bstrides, int n_x, const void *dy,
                                  float *dw, float *ws,

@@ -38,15 +38,16 @@ class ConvNormLayer_fuse(nn.Module):
         self.ch_in, self.ch_out, self.kernel_size, self.stride = ch_in, ch_out, kernel_size, stride
         self.g, self.padding, self.bias = g, padding, bias
 
-    def forward(self, x, fanin=None):
-        """fanin: kernels.GradFanIn of x (this unit is the consumer of x that runs its backward last)."""
+    def forward(self, x, fanin=None, fans=None):
+        """fanin: kernels.GradFanIn of x (this unit is the consumer of x that runs its backward last, or one of a chain);
+        fans: one per part of a list input (this unit runs its backward first and parks the parts' gradients)."""
         if hasattr(self, "conv_bn_fused"):                 # deployed form: BN folded into the conv
             if self._act_name is not None or isinstance(self.act, nn.Identity):
                 return kernels.conv_bias_act(x, self.conv_bn_fused, self._act_name)
             return self.act(kernels.conv_bias_act(x, self.conv_bn_fused, None))
         if self._act_name is not None or isinstance(self.act, nn.Identity):
-            return kernels.conv_bn_act(x, self.conv, self.norm, self._act_name, None, fanin=fanin)
-        return self.act(kernels.conv_bn_act(x, self.conv, self.norm, None, None, fanin=fanin))
+            return kernels.conv_bn_act(x, self.conv, self.norm, self._act_name, None, fanin=fanin, fans=fans)
+        return self.act(kernels.conv_bn_act(x, self.conv, self.norm, None, None, fanin=fanin, fans=fans))
 
     def get_equivalent_kernel_bias(self):
         return _fold_bn(self.conv, self.norm)
@@ -145,8 +146,9 @@ class CSPLayer(nn.Module):
         self.conv3 = (ConvNormLayer_fuse(hidden, out_channels, 1, 1, bias=bias, act=act)
                       if hidden != out_channels else nn.Identity())
 
-    def forward(self, x):
-        y, r = self.conv1(x), self.conv2(x)
+    def forward(self, x, fanin=None):
+        """fanin: chain kernels.GradFanIn of x - both 1x1 convolutions add their data gradient onto x's parked gradient."""
+        y, r = self.conv1(x, fanin=fanin), self.conv2(x, fanin=fanin)
         blocks = list(self.bottlenecks)
         if blocks and all(isinstance(b, VGGBlock) for b in blocks):
             for b in blocks[:-1]:
@@ -173,9 +175,13 @@ class RepNCSPELAN4(nn.Module):
 
     def forward(self, x):
         y1 = self.cv1(x)                                   # x may be a list: the FPN / PAN concat, read in place
-        y2 = self.cv2(y1[:, self.c:])
-        y3 = self.cv3(y2)
-        return self.cv4([y1, y2, y3])                      # cat(split(y1), y2, y3) without building it
+        # y1 feeds cv4 whole and cv2's two 1x1 convolutions through its upper half, y2 feeds cv4 and cv3's two: cv4 (created
+        # last, backward first) parks their gradients and the branch convolutions add onto them in place (kernels.fan_slice)
+        s1, fan1 = kernels.fan_slice(y1, self.c, y1.shape[1] - self.c)
+        y2 = self.cv2[1](self.cv2[0](s1, fanin=fan1))
+        s2, fan2 = kernels.fan_slice(y2, 0, y2.shape[1])
+        y3 = self.cv3[1](self.cv3[0](s2, fanin=fan2))
+        return self.cv4([y1, y2, y3], fans=[fan1, fan2, None])     # cat(split(y1), y2, y3) without building it
 
 
 class MultiheadSelfAttention(nn.Module):

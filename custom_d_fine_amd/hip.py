@@ -86,6 +86,7 @@ _SIGNATURES = {
     "dfine_fdr_bwd": (c_int, [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_topk_anchors": (c_int, [_P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfine_conv1x1_seg_fwd_bf16": (c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_conv1x1_seg_accum_bf16": (c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_conv1x1_seg_wgrad_bf16": (c_int, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfine_conv_wgrad_splits": (c_int, [_I, _I, _I, _I, _I, _I]),
     "dfine_linear_wgrad_splits": (c_int, [_I, _I, _I]),
@@ -963,16 +964,17 @@ def is_channel_part(t):
         B == 1 or (t.stride(0) % hw == 0 and t.stride(0) >= C * hw)) and t.data_ptr() % 16 == 0
 
 
-def conv1x1_seg_forward(x_parts, w2, y_parts):
-    """1x1 conv over the channel concatenation of `x_parts` ([B, C_k, H, W] bf16 contiguous) written into the channel
-    concatenation `y_parts` (preallocated), packed weights `w2` ([sum C_out] x [sum C_in])."""
+def conv1x1_seg_forward(x_parts, w2, y_parts, accum=False):
+    """1x1 conv over the channel concatenation of `x_parts` ([B, C_k, H, W] bf16, contiguous or channel slices) written into
+    the channel concatenation `y_parts` (preallocated; accum: added onto it), packed weights `w2` ([sum C_out] x [sum C_in])."""
     B, _, H, W = x_parts[0].shape
     cin, cout = sum(t.shape[1] for t in x_parts), sum(t.shape[1] for t in y_parts)
     xp, xc, xb = _seg_arrays(x_parts)
     yp, yc, yb = _seg_arrays(y_parts)
-    with _timed("conv1x1", 2.0 * B * H * W * cin * cout, io=2.0 * B * H * W * (cin + cout) + 2.0 * cin * cout):
-        _check(_lib.dfine_conv1x1_seg_fwd_bf16(xp, xc, xb, len(x_parts), _ptr(w2), yp, yc, yb, len(y_parts), B, cin, cout, H, W,
-                                               _stream()), "dfine_conv1x1_seg_fwd_bf16")
+    fn, name = ((_lib.dfine_conv1x1_seg_accum_bf16, "dfine_conv1x1_seg_accum_bf16") if accum
+                else (_lib.dfine_conv1x1_seg_fwd_bf16, "dfine_conv1x1_seg_fwd_bf16"))
+    with _timed("conv1x1", 2.0 * B * H * W * cin * cout, io=2.0 * B * H * W * (cin + (2 if accum else 1) * cout) + 2.0 * cin * cout):
+        _check(fn(xp, xc, xb, len(x_parts), _ptr(w2), yp, yc, yb, len(y_parts), B, cin, cout, H, W, _stream()), name)
 
 
 def conv1x1_seg_wgrad(x_parts, dy, partials=False):

@@ -814,11 +814,14 @@ class GradFanIn:
     its own data gradient onto the parked one in its convolution's epilogue (dfine_conv_accum_bf16) and returns the sum.
     `armed` is set in the forward pass by the later consumer when it will be able to do that, `parking` by the earlier one
     (whose forward runs after it) when it will park - only then does the later consumer expect a parked gradient."""
-    __slots__ = ("armed", "parking", "buf", "bn", "part")
+    __slots__ = ("armed", "parking", "buf", "bn", "part", "chain", "lo", "pending")
 
-    def __init__(self):
+    def __init__(self, chain=False, lo=0):
         self.armed, self.parking, self.buf = False, False, None
         self.bn, self.part = None, None         # BNLink role (below): the map's producer is a BatchNorm unit
+        # chain role (fan_slice below): SEVERAL later consumers, all of them 1x1 convolutions reading channels lo.. of the map;
+        # each adds its data gradient onto that channel range of the parked gradient and leaves it parked; `pending` counts them
+        self.chain, self.lo, self.pending = chain, lo, 0
 
     def take(self):
         buf, self.buf = self.buf, None
@@ -858,6 +861,57 @@ def park_grad(x, fan, owned=False):
         return x
     fan.parking = True
     return _ParkGrad.apply(x, fan)
+
+
+class _ChainUse:
+    """Marks a GradFanIn handed to a part-wise convolution as the CONSUMER side of a chain (its `fans` are the parking side)."""
+    __slots__ = ("fan",)
+
+    def __init__(self, fan):
+        self.fan = fan
+
+
+class _FanSlice(torch.autograd.Function):
+    """x[:, lo:lo + n] for the consumers of a chain GradFanIn.  Backward: when the map's whole-tensor consumer parked its gradient
+    (the part-wise convolution that reads the map as one of its parts) and the slice's consumers added theirs onto channels
+    lo..lo + n of it, that buffer IS the map's gradient: returned as it stands.  Otherwise the plain slice gradient."""
+
+    @staticmethod
+    def forward(ctx, x, lo, n, fan):
+        ctx.fan, ctx.lo, ctx.n, ctx.shape = fan, lo, n, x.shape
+        ctx.set_materialize_grads(False)
+        return x.view_as(x) if (lo == 0 and n == x.shape[1]) else x[:, lo:lo + n]
+
+    @staticmethod
+    def backward(ctx, g):
+        fan, ctx.fan = ctx.fan, None
+        if fan.parking and fan.armed:
+            if fan.pending != 0:
+                raise RuntimeError("GradFanIn chain: a consumer's backward has not run yet (backward order violated)")
+            full = fan.take()
+            view = full[:, ctx.lo:ctx.lo + ctx.n]
+            if g is not None and g.data_ptr() != view.data_ptr():
+                view.copy_(g)           # a consumer outside the chain returned a gradient of its own: autograd added it to the slice
+            return full, None, None, None
+        if g is None:
+            return None, None, None, None
+        if ctx.lo == 0 and ctx.n == ctx.shape[1]:
+            return g, None, None, None
+        full = g.new_zeros(ctx.shape)
+        full[:, ctx.lo:ctx.lo + ctx.n] = g
+        return full, None, None, None
+
+
+def fan_slice(x, lo, n):
+    """(x[:, lo:lo + n], fan) for a map x = [B, C, H, W] that feeds a part-wise 1x1 convolution whole (conv_bn_act([.., x, ..],
+    fans=[.., fan, ..]): created LAST, so its backward runs first and parks x's gradient) and one or more 1x1 convolutions
+    through the channel slice (conv_bn_act(slice, fanin=fan)): RepNCSPELAN4's split and its branch outputs (ref
+    hybrid_encoder.py:196-206).  The reference lets autograd add the consumers' gradients, zero-fill the slice's gradient to the
+    full width and add again; here every consumer adds onto the parked map in its store epilogue (dfine_conv1x1_seg_accum_bf16)."""
+    if not (grad_fanin_enabled(x) and x.requires_grad and x.dtype == torch.bfloat16 and _env("DFINE_FAN_CHAIN", "1") == "1"):
+        return (x if (lo == 0 and n == x.shape[1]) else x[:, lo:lo + n]), None
+    fan = GradFanIn(chain=True, lo=lo)
+    return _FanSlice.apply(x, lo, n, fan), fan
 
 
 class BNLink:
@@ -933,6 +987,8 @@ class _DenseConvBNAct(torch.autograd.Function):
                 and hip.conv_epilogue_supported(B, cout, cin, H, W, ks)):      # (the data gradient: channels exchanged)
             fanin.armed = True
             ctx.fanin = fanin
+            if fanin.chain:
+                fanin.pending += 1
         ctx.bnsrc = bnsrc if ctx.needs_input_grad[0] else None
         part = None
         if training and B * H * W > _BN_STATS_MIN and (H * W) % 8 == 0 and cout <= 4096 and _env("DFINE_BN_LINK", "0") == "1":
@@ -983,9 +1039,20 @@ class _DenseConvBNAct(torch.autograd.Function):
         if need[0]:
             B, cin, H, W = x.shape
             if ctx.fanin is not None and ctx.fanin.parking:    # the other consumer's gradient is parked: add onto it in the epilogue
-                _bn_link_arm(ctx.fanin, B, cin, weight.shape[0], H, W, ks)     # ... which then holds the map's complete gradient
-                dx = hip.conv_accumulate_bf16(dc, _packed_weights(weight, True), ctx.fanin.take(), ks)
-                ctx.fanin = None
+                fan, ctx.fanin = ctx.fanin, None
+                if fan.chain:                                  # one of several: add onto the parked map and leave it there
+                    view = fan.buf if fan.buf.shape[1] == cin else fan.buf[:, fan.lo:fan.lo + cin]
+                    if view.is_contiguous():
+                        hip.conv_accumulate_bf16(dc, _packed_weights(weight, True), view, ks)
+                    elif ks == 1:
+                        hip.conv1x1_seg_forward((dc,), _packed_weights(weight, True), (view,), accum=True)
+                    else:
+                        view.add_(hip.conv_forward_bf16(dc, _packed_weights(weight, True), cin, ks))
+                    fan.pending -= 1
+                    dx = view if fan.pending == 0 else None            # (the last one tells _FanSlice the gradient is there)
+                else:
+                    _bn_link_arm(fan, B, cin, weight.shape[0], H, W, ks)       # ... which then holds the map's complete gradient
+                    dx = hip.conv_accumulate_bf16(dc, _packed_weights(weight, True), fan.take(), ks)
             else:
                 _bn_link_arm(ctx.bnsrc, B, cin, weight.shape[0], H, W, ks)
                 dx = hip.conv_forward_bf16(dc, _packed_weights(weight, True), weight.shape[1], ks)
@@ -1141,7 +1208,15 @@ class _DenseConvSeg(torch.autograd.Function):
         """fans: None, or one GradFanIn / None per part - armed ones receive that part's data gradient in backward (the part's
         other consumer then returns the sum), see GradFanIn."""
         hip = _hip()
-        ctx.fans = None
+        ctx.fans = ctx.chain = None
+        if fans is not None and len(fans) == 1 and isinstance(fans[0], _ChainUse):
+            f, fans = fans[0].fan, None
+            B, cin, H, W = xs[0].shape
+            if (len(xs) == 1 and ctx.needs_input_grad[2] and xs[0].dtype == torch.bfloat16
+                    and hip.conv_epilogue_supported(B, weight.shape[0], cin, H, W, 1)):
+                f.armed = True
+                f.pending += 1
+                ctx.chain = f
         if fans is not None:
             for i, f in enumerate(fans):
                 if f is not None and f.armed and ctx.needs_input_grad[2 + i] and xs[i].dtype == torch.bfloat16:
@@ -1166,7 +1241,14 @@ class _DenseConvSeg(torch.autograd.Function):
             dy = dy.to(torch.bfloat16)
         dxs = [None] * len(xs)
         need = ctx.needs_input_grad
-        if any(need[2:]):
+        chain, ctx.chain = ctx.chain, None
+        if chain is not None and chain.parking:
+            # the map's gradient is parked (by the part-wise convolution that reads it whole): add onto this unit's channels of it
+            view = chain.buf[:, chain.lo:chain.lo + xs[0].shape[1]]
+            hip.conv1x1_seg_forward((dy,), _packed_weights(weight, True), (view,), accum=True)
+            chain.pending -= 1
+            dxs = [view if chain.pending == 0 else None]       # (the last one tells _FanSlice the gradient is there)
+        elif any(need[2:]):
             outs = tuple(torch.empty(x.shape, device=x.device, dtype=x.dtype) for x in xs)
             hip.conv1x1_seg_forward((dy,), _packed_weights(weight, True), outs)
             dxs = [o if n else None for o, n in zip(outs, need[2:])]
@@ -1425,6 +1507,8 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
     if (torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and not x.is_contiguous() and conv.kernel_size == (1, 1)
             and x.dtype == torch.bfloat16 and _hip().is_channel_part(x)):
         x = [x]                       # a channel slice of a wider map (RepNCSPELAN4 split): read in place, no .contiguous() copy
+        if fanin is not None and fanin.chain:
+            fans = [_ChainUse(fanin)]
     if isinstance(x, (list, tuple)):
         # channel-wise concatenation kept as parts: the 1x1 MFMA kernels read them in place
         xs = x

@@ -449,6 +449,12 @@ int dfine_topk_anchors(const void *logits, int64_t sb, int64_t sq, int64_t *out_
 int dfine_conv1x1_seg_fwd_bf16(const void *const *x_parts, const int *x_channels, const int *x_bstrides, int n_x,
                                const void *w2, void *const *y_parts, const int *y_channels, const int *y_bstrides,
                                int n_y, int B, int Cin, int Cout, int H, int W, void *stream);
+/* y_parts += the same convolution (shapes of the LDS-DMA kernel only: DFINE_E_BADARG otherwise): the data gradient of a unit
+ * that reads a channel slice of a wider map, added onto that slice of the map's gradient (RepNCSPELAN4's split,
+ * src/d_fine/arch/hybrid_encoder.py:196-206). */
+int dfine_conv1x1_seg_accum_bf16(const void *const *x_parts, const int *x_channels, const int *x_bstrides, int n_x,
+                                 const void *w2, void *const *y_parts, const int *y_channels, const int *y_bstrides,
+                                 int n_y, int B, int Cin, int Cout, int H, int W, void *stream);
 int dfine_conv1x1_seg_wgrad_bf16(const void *const *x_parts, const int *x_channels, const int *x_bstrides, int n_x,
                                  const void *dy, float *dw, float *ws, int B, int Cin, int Cout, int H, int W,
                                  void *stream);
