@@ -532,7 +532,10 @@ class DFINETransformer(nn.Module):
             def take(t):
                 return t.gather(dim=1, index=ind.unsqueeze(-1).expand(-1, -1, t.shape[-1]))
 
-            top_mem = self._enc_output(take(memory) * take(keep.expand(memory.shape[0], -1, -1)))
+            # one autograd node hands out the selected rows AND the memory for the decoder's value path (forward() picks it up):
+            # its backward adds the rows' gradient onto the value path's in place instead of two full-size tensors being added
+            self.__dict__["_memory_for_value"], rows = kernels.take_rows_and_pass(memory, ind)
+            top_mem = self._enc_output(rows * take(keep.expand(memory.shape[0], -1, -1)))
             top_logits = self._enc_scores(top_mem)
             top_anchor = take(anchors)
         else:
@@ -609,6 +612,7 @@ class DFINETransformer(nn.Module):
 
         content, ref_unact, enc_boxes, enc_logits = self._get_decoder_input(
             memory, spatial_shapes, dn_logits, dn_boxes)
+        memory = self.__dict__.pop("_memory_for_value", memory)      # (training: through the query selection's autograd node)
 
         out_bboxes, out_logits, out_corners, out_refs, pre_bboxes, pre_logits, hs = self.decoder(
             content, ref_unact, memory, spatial_shapes, self.dec_bbox_head, self.dec_score_head,

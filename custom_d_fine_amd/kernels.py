@@ -863,6 +863,41 @@ def park_grad(x, fan, owned=False):
     return _ParkGrad.apply(x, fan)
 
 
+class _TakeRowsAndPass(torch.autograd.Function):
+    """(t, t.gather(1, ind[..., None].expand(-1, -1, C))) for t = [B, L, C] and DISTINCT indices per image: the encoder memory on
+    its way to the decoder's value path, and the rows the query selection picks from it (ref dfine_decoder.py:842-853,888-905).
+    ONE node for both consumers, so its backward sees both gradients: the selected rows are added onto the value path's
+    gradient in place - the reference zero-fills a [B, L, C] gradient, scatters 300 rows into it and lets autograd add the two
+    full-size tensors.  Same sums (one bf16 + bf16 add per element of the selected rows)."""
+
+    @staticmethod
+    def forward(ctx, t, ind):
+        ctx.save_for_backward(ind)
+        ctx.shape = t.shape
+        ctx.set_materialize_grads(False)
+        return t.view_as(t), t.gather(dim=1, index=ind.unsqueeze(-1).expand(-1, -1, t.shape[-1]))
+
+    @staticmethod
+    def backward(ctx, g_all, g_rows):
+        (ind,) = ctx.saved_tensors
+        if g_rows is None:
+            return g_all, None
+        idx = ind.unsqueeze(-1).expand(-1, -1, ctx.shape[-1])
+        if g_all is None:
+            return g_rows.new_zeros(ctx.shape).scatter_add_(1, idx, g_rows), None
+        # g_all is this graph's own tensor (the value path's gradient: a fresh sum of the decoder layers' terms), never a
+        # caller's: written in place
+        g_all = g_all.contiguous()
+        return g_all.scatter_add_(1, idx, g_rows.to(g_all.dtype)), None
+
+
+def take_rows_and_pass(t, ind):
+    """(t for its other consumer, rows ind [B, K] of t [B, L, C]); indices distinct per image.  See _TakeRowsAndPass."""
+    if t.is_cuda and t.requires_grad and torch.is_grad_enabled() and _env("DFINE_GRAD_FANIN", "1") == "1":
+        return _TakeRowsAndPass.apply(t, ind)
+    return t, t.gather(dim=1, index=ind.unsqueeze(-1).expand(-1, -1, t.shape[-1]))
+
+
 class _ChainUse:
     """Marks a GradFanIn handed to a part-wise convolution as the CONSUMER side of a chain (its `fans` are the parking side)."""
     __slots__ = ("fan",)

@@ -93,3 +93,33 @@ def test_fan_slice_with_a_consumer_outside_the_chain(cuda):
         return x.grad
 
     _cmp(run(True), run(False))
+
+
+def test_take_rows_and_pass_equals_gather_plus_autograd_add(cuda):
+    """The decoder's query selection (ref dfine_decoder.py:842-853): rows of the memory by top-k indices next to the value path."""
+    from custom_d_fine_amd import kernels
+    torch.manual_seed(3)
+    B, L, C, K = 4, 2100, 256, 300
+    t0 = torch.randn(B, L, C, device=cuda).bfloat16()
+    ind = torch.stack([torch.randperm(L, device=cuda)[:K] for _ in range(B)])
+    g_all, g_rows = torch.randn(B, L, C, device=cuda).bfloat16(), torch.randn(B, K, C, device=cuda).bfloat16()
+
+    def run(fused):
+        t = t0.clone().requires_grad_(True)
+        tt = t * 1.0
+        if fused:
+            full, rows = kernels.take_rows_and_pass(tt, ind)
+            assert type(rows.grad_fn).__name__ == "_TakeRowsAndPassBackward"
+        else:
+            full, rows = tt, tt.gather(1, ind.unsqueeze(-1).expand(-1, -1, C))
+        torch.autograd.backward([full * 1.0, rows * 1.0], [g_all.clone(), g_rows.clone()])
+        return full.detach(), rows.detach(), t.grad
+
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    # one consumer only: the other gradient is absent
+    t = t0.clone().requires_grad_(True)
+    full, rows = kernels.take_rows_and_pass(t * 1.0, ind)
+    rows.float().sum().backward()
+    assert torch.equal(t.grad.float().sum(dim=(1, 2)), torch.full((B,), float(K * C), device=cuda))
