@@ -1048,8 +1048,14 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
             if (n < Cout && wp * 16 * PXW + c8 < npix) {
                 uint16_t *yp = SEG ? ytab[wn * 16 * NTN + row] + p0 + wp * 16 * PXW + c8
                                    : const_cast<uint16_t *>(ys_.p[0]) + ylane + (int64_t)n * HW;
+                bool acc_row = accum != 0;
+                if (SEG) {          // several output parts: bit 0 of a part's base address says "add onto this part" (launch_conv1x1)
+                    const uintptr_t u = reinterpret_cast<uintptr_t>(yp);
+                    acc_row = acc_row || (u & 1);
+                    yp = reinterpret_cast<uint16_t *>(u & ~(uintptr_t)1);
+                }
                 uint4 v = *reinterpret_cast<const uint4 *>(ot + row * OP + c8);
-                if (accum) {                                  // y += conv(x): bf16 + bf16 in fp32, one rounding (like a separate add)
+                if (acc_row) {                                // y += conv(x): bf16 + bf16 in fp32, one rounding (like a separate add)
                     const uint4 o = *reinterpret_cast<const uint4 *>(yp);
                     const uint32_t a[4] = {v.x, v.y, v.z, v.w}, c[4] = {o.x, o.y, o.z, o.w};
                     uint32_t r[4];
@@ -1181,13 +1187,21 @@ static C1Cfg conv1x1_cfg(int B, int NP, int KP, int HW, bool seg, bool per_image
 
 static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B, int Cin, int Cout, int NP, int KP, int HW,
                           hipStream_t st, const ChanSegs *xsegs = nullptr, const ChanSegs *ysegs = nullptr, int accum = 0,
-                          int64_t w_bstride = 0) {
+                          int64_t w_bstride = 0, unsigned accum_parts = 0 /* bit k: add onto output part k (several parts) */) {
     const int ptiles = (HW + kTrPix - 1) / kTrPix;
     DfineConvEpilogue epv{};
     const bool has_ep = take_conv_epilogue(&epv);
     if (conv1x1_glds_ok(Cin, KP, HW)) {
-        const ChanSegs xs_ = xsegs ? *xsegs : one_seg(x, Cin), ys_ = ysegs ? *ysegs : one_seg(y, Cout);
+        const ChanSegs xs_ = xsegs ? *xsegs : one_seg(x, Cin);
+        ChanSegs ys_ = ysegs ? *ysegs : one_seg(y, Cout);
         const bool seg = xs_.n > 1 || ys_.n > 1;
+        if (accum_parts) {
+            if (has_ep) return DFINE_E_BADARG;
+            if (!seg) accum = 1;                                // one part in, one part out: the plain accumulate-into launch
+            else
+                for (int k = 0; k < ys_.n; ++k)
+                    if (accum_parts >> k & 1) ys_.p[k] = reinterpret_cast<const uint16_t *>(reinterpret_cast<uintptr_t>(ys_.p[k]) | 1);
+        }
         const C1Cfg cf = conv1x1_cfg(B, NP, KP, HW, seg, w_bstride != 0);
         const bool n256 = cf.n256, px256 = cf.px256, wide2 = cf.wide2, ring2 = cf.ring2, ximg = cf.ximg;
         const int tp = cf.tp, ptiles2 = cf.ptiles2, total2 = cf.total2, nblk2 = cf.nblk2;
@@ -1229,7 +1243,7 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
 #undef DFINE_G2L
         return check_launch();
     }
-    if (xsegs || ysegs || accum || w_bstride || has_ep) return DFINE_E_BADARG;  // the first-generation kernel takes whole tensors, shared weights, no accumulation, no epilogue sums
+    if (xsegs || ysegs || accum || accum_parts || w_bstride || has_ep) return DFINE_E_BADARG;  // the first-generation kernel takes whole tensors, shared weights, no accumulation, no epilogue sums
     const int vec = (HW % 8 == 0) ? 8 : (HW % 4 == 0 ? 4 : 2);
     static const int kc_env = [] { const char *e = getenv("DFINE_CONV_KC"); return e ? atoi(e) : 0; }();
     int kc = KP >= 128 ? 4 : (KP >= 64 ? 2 : 1);
@@ -2412,6 +2426,24 @@ int dfine_conv1x1_seg_accum_bf16(const void *const *x_parts, const int *x_channe
     const int NP = (Cout + 15) / 16 * 16, KP = (Cin + 31) / 32 * 32;
     if (!conv1x1_glds_ok(Cin, KP, H * W)) return DFINE_E_BADARG;           // only the LDS-DMA kernel accumulates
     return launch_conv1x1(nullptr, (const uint16_t *)w2, nullptr, B, Cin, Cout, NP, KP, H * W, (hipStream_t)stream, &xs_, &ys_, 1);
+}
+
+// ... onto SOME of the output parts (bit k of accum_parts), the others are overwritten: the data gradient of HG_Block's aggregation
+// written into one tensor per concatenated input, where the block input's tensor already holds the gradient of the residual
+// connection (ref hgnetv2.py:265-275).
+int dfine_conv1x1_seg_accum_parts_bf16(const void *const *x_parts, const int *x_channels, const int *x_bstrides, int n_x, const void *w2,
+                                       void *const *y_parts, const int *y_channels, const int *y_bstrides, int n_y, unsigned accum_parts,
+                                       int B, int Cin, int Cout, int H, int W, void *stream) {
+    if (B == 0) return DFINE_OK;
+    ChanSegs xs_, ys_;
+    if (!w2 || !make_segs(&xs_, x_parts, x_channels, x_bstrides, n_x, Cin) ||
+        !make_segs(&ys_, (const void *const *)y_parts, y_channels, y_bstrides, n_y, Cout))
+        return DFINE_E_BADARG;
+    if ((H * W) % 8 || Cin % 2 || (n_y < 32 && (accum_parts >> n_y))) return DFINE_E_BADARG;
+    const int NP = (Cout + 15) / 16 * 16, KP = (Cin + 31) / 32 * 32;
+    if (!conv1x1_glds_ok(Cin, KP, H * W)) return DFINE_E_BADARG;
+    return launch_conv1x1(nullptr, (const uint16_t *)w2, nullptr, B, Cin, Cout, NP, KP, H * W, (hipStream_t)stream, &xs_, &ys_, 0, 0,
+                          accum_parts);
 }
 
 // weight gradient of the same: dw [Cout, Cin] f32 (overwritten), ws: dfine_conv_wgrad_ws_floats(B, Cin, Cout, H, W, 1) floats

@@ -561,6 +561,9 @@ __global__ __launch_bounds__(kDwThreads) void dwconv_s2_fwd_stream_kernel(const 
 }
 
 // data gradient: a lane owns 4 dy columns = 8 dx columns; dy row oy feeds dx rows 2 oy (ky = 1), 2 oy - 1 (ky = 0) and 2 oy + 1 (ky = 2)
+// ACC: dx += (dx holds the gradient of the map's other consumer; this term is rounded to bf16 first, so the sum is the one
+// autograd's add of the two bf16 maps would give)
+template <bool ACC>
 __global__ __launch_bounds__(kDwThreads) void dwconv_s2_dgrad_stream_kernel(const uint16_t *__restrict__ dy, const float *__restrict__ w,
                                                                            uint16_t *__restrict__ dx, int C, int H, int W, int planes,
                                                                            int rows_per_chunk) {
@@ -610,8 +613,19 @@ __global__ __launch_bounds__(kDwThreads) void dwconv_s2_dgrad_stream_kernel(cons
             row_terms(gc, 2, odd);                                 // dx row 2 oy + 1: ky = 2 from dy row oy ...
             row_terms(gn, 0, odd);                                 // ... and ky = 0 from dy row oy + 1
             if (live) {
-                *reinterpret_cast<uint4 *>(dxp + (int64_t)(2 * (oy + u)) * W) = DwVec<8>::pack(even);
-                *reinterpret_cast<uint4 *>(dxp + (int64_t)(2 * (oy + u) + 1) * W) = DwVec<8>::pack(odd);
+                uint4 *pe = reinterpret_cast<uint4 *>(dxp + (int64_t)(2 * (oy + u)) * W);
+                uint4 *po = reinterpret_cast<uint4 *>(dxp + (int64_t)(2 * (oy + u) + 1) * W);
+                if (ACC) {
+                    float olde[8], oldo[8], te[8], to[8];
+                    DwVec<8>::unpack(*pe, olde);
+                    DwVec<8>::unpack(*po, oldo);
+                    DwVec<8>::unpack(DwVec<8>::pack(even), te);
+                    DwVec<8>::unpack(DwVec<8>::pack(odd), to);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { even[e] = te[e] + olde[e]; odd[e] = to[e] + oldo[e]; }
+                }
+                *pe = DwVec<8>::pack(even);
+                *po = DwVec<8>::pack(odd);
             }
 #pragma unroll
             for (int i = 0; i < 5; ++i) gc[i] = gn[i];
@@ -946,6 +960,21 @@ int dfine_dwconv_fwd(const void *x, const float *w, void *y, int dtype, int B, i
     return check_launch();
 }
 
+// dx += the data gradient of the 3x3 / stride-2 / pad-1 depthwise convolution (bf16; H even, W % 8 == 0, W <= 320: DFINE_E_BADARG
+// otherwise - the caller then adds separately).  HG_Stage.downsample is the second consumer of the previous stage's output, which
+// also leaves the backbone (ref hgnetv2.py:295-303,520-526): the encoder's gradient is already in dx.
+int dfine_dwconv_s2_dgrad_acc(const float *w, const void *dy, void *dx, int B, int C, int H, int W, void *stream) {
+    if (B == 0 || C == 0) return DFINE_OK;
+    if (!w || !dy || !dx || !dw_s2_ok(DFINE_BF16, H, W, 3, 2, 1)) return DFINE_E_BADARG;
+    const int OH = H / 2;
+    const int nv = W / 8, ppw = 64 / nv, planes = B * C;
+    const int waves = (planes + ppw - 1) / ppw;
+    const int rpc = dw_stream_rows(OH, waves);
+    hipLaunchKernelGGL(dwconv_s2_dgrad_stream_kernel<true>, dim3((waves + 3) / 4, (OH + rpc - 1) / rpc), dim3(kDwThreads), 0,
+                       (hipStream_t)stream, (const uint16_t *)dy, w, (uint16_t *)dx, C, H, W, planes, rpc);
+    return check_launch();
+}
+
 int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, float *dw_f32, int dtype,
                      int B, int C, int H, int W, int K, int stride, int pad, void *stream) {
     if (B == 0 || C == 0) return DFINE_OK;
@@ -983,7 +1012,7 @@ int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, fl
         const int nv = W / 8, ppw = 64 / nv, planes = B * C;
         const int waves = (planes + ppw - 1) / ppw;
         const int rpc = dw_stream_rows(OH, waves);
-        hipLaunchKernelGGL(dwconv_s2_dgrad_stream_kernel, dim3((waves + 3) / 4, (OH + rpc - 1) / rpc), dim3(kDwThreads), 0, st,
+        hipLaunchKernelGGL(dwconv_s2_dgrad_stream_kernel<false>, dim3((waves + 3) / 4, (OH + rpc - 1) / rpc), dim3(kDwThreads), 0, st,
                            (const uint16_t *)dy, w, (uint16_t *)dx, C, H, W, planes, rpc);
         if (int e = check_launch()) return e;
     } else if (dx && dw_s2_ok(dtype, H, W, K, stride, pad)) {

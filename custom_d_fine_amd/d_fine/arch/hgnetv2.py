@@ -159,7 +159,12 @@ class HG_Block(nn.Module):
             for layer in self.layers:
                 feats.append(layer(feats[-1]))
             y = self.aggregation(feats)    # channel concat of all maps, read in place by the 1x1 aggregation conv
-        return self.drop_path(y) + x if self.residual else y
+            fans = None
+        if not self.residual:
+            return y
+        # x has a third consumer, the residual connection: its gradient (the block output's) is parked first and the aggregation's
+        # and layer 0's data gradients are added onto it in place (captured segments only: see kernels.park_grad)
+        return self.drop_path(y) + (kernels.park_grad(x, fans[0]) if (fans is not None and kernels.fanin_outer_enabled()) else x)
 
 
 class HG_Stage(nn.Module):
@@ -181,7 +186,10 @@ class HG_Stage(nn.Module):
             for i in range(block_num)
         ])
 
-    def forward(self, x):
+    def forward(self, x, fanin=None):
+        """fanin: kernels.GradFanIn of x when x also leaves the backbone (HGNetv2.forward)."""
+        if fanin is not None and isinstance(self.downsample, ConvBNAct):
+            return self.blocks(self.downsample(x, fanin=fanin))
         return self.blocks(self.downsample(x))
 
 
@@ -259,7 +267,14 @@ class HGNetv2(nn.Module):
         x = self.stem(x)
         outs = []
         for i, stage in enumerate(self.stages):
-            x = stage(x)
+            # a returned map that the next stage reads too has two consumers: the gradient arriving from outside is parked and
+            # the stage's depthwise stride-2 convolution (created first = backward last) adds its data gradient onto it in place
+            # (captured segments only, see kernels.park_grad)
+            fan = kernels.GradFanIn() if (outs and outs[-1] is x and kernels.grad_fanin_enabled(x) and kernels.fanin_outer_enabled()) else None
+            y = stage(x, fanin=fan) if fan is not None else stage(x)
+            if fan is not None:
+                outs[-1] = kernels.park_grad(x, fan)
+            x = y
             if i in self.return_idx:
                 outs.append(x)
         return outs

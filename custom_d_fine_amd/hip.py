@@ -38,6 +38,7 @@ _SIGNATURES = {
     "dfine_lsap": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfine_dwconv_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_dwconv_bwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_dwconv_s2_dgrad_acc": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_bn_ws_floats": (_L, [_I, _I, _I]),
     "dfine_bn2_supported": (c_int, [_I, _I, _I]),
     "dfine_bn2_ws_floats": (_L, [_I, _I, _I]),
@@ -87,6 +88,7 @@ _SIGNATURES = {
     "dfine_topk_anchors": (c_int, [_P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfine_conv1x1_seg_fwd_bf16": (c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_conv1x1_seg_accum_bf16": (c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_conv1x1_seg_accum_parts_bf16": (c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _I, ctypes.c_uint, _I, _I, _I, _I, _I, _P]),
     "dfine_conv1x1_seg_wgrad_bf16": (c_int, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfine_conv_wgrad_splits": (c_int, [_I, _I, _I, _I, _I, _I]),
     "dfine_linear_wgrad_splits": (c_int, [_I, _I, _I]),
@@ -505,11 +507,21 @@ def dwconv_forward(x, w, stride, pad):
     return y
 
 
-def dwconv_backward(x, w, dy, stride, pad, need_dx=True, need_dw=True, side_dw=False):
+def dwconv_acc_supported(x, K, stride, pad):
+    B, C, H, W = x.shape
+    return x.dtype == torch.bfloat16 and K == 3 and stride == 2 and pad == 1 and H % 2 == 0 and W % 8 == 0 and W <= 320
+
+
+def dwconv_backward(x, w, dy, stride, pad, need_dx=True, need_dw=True, side_dw=False, acc=None):
     """side_dw: the weight gradient is launched on the side stream (see _side_fork); the caller guarantees that its only
-    consumer runs behind side_join() (the fused optimizer's gradient gather)."""
+    consumer runs behind side_join() (the fused optimizer's gradient gather).
+    acc: the gradient of x from its other consumer (dwconv_acc_supported shapes): the data gradient is added onto it in place."""
     B, C, H, W = x.shape
     K = w.shape[-1]
+    if acc is not None and need_dx:
+        _check(_lib.dfine_dwconv_s2_dgrad_acc(_ptr(w), _ptr(dy), _ptr(acc), B, C, H, W, _stream()), "dfine_dwconv_s2_dgrad_acc")
+        _, dw = dwconv_backward(x, w, dy, stride, pad, False, need_dw, side_dw) if need_dw else (None, None)
+        return acc, dw
     dx = torch.empty_like(x) if need_dx else None
     dw = torch.zeros(w.shape, device=x.device, dtype=torch.float32) if need_dw else None
     if side_dw and need_dw and _side_ok("dw"):
@@ -971,6 +983,13 @@ def conv1x1_seg_forward(x_parts, w2, y_parts, accum=False):
     cin, cout = sum(t.shape[1] for t in x_parts), sum(t.shape[1] for t in y_parts)
     xp, xc, xb = _seg_arrays(x_parts)
     yp, yc, yb = _seg_arrays(y_parts)
+    if accum not in (False, True):          # a sequence of flags, one per output part
+        mask = sum(1 << k for k, a in enumerate(accum) if a)
+        extra = sum(t.shape[1] for t, a in zip(y_parts, accum) if a)
+        with _timed("conv1x1", 2.0 * B * H * W * cin * cout, io=2.0 * B * H * W * (cin + cout + extra) + 2.0 * cin * cout):
+            _check(_lib.dfine_conv1x1_seg_accum_parts_bf16(xp, xc, xb, len(x_parts), _ptr(w2), yp, yc, yb, len(y_parts), mask, B, cin,
+                                                           cout, H, W, _stream()), "dfine_conv1x1_seg_accum_parts_bf16")
+        return
     fn, name = ((_lib.dfine_conv1x1_seg_accum_bf16, "dfine_conv1x1_seg_accum_bf16") if accum
                 else (_lib.dfine_conv1x1_seg_fwd_bf16, "dfine_conv1x1_seg_fwd_bf16"))
     with _timed("conv1x1", 2.0 * B * H * W * cin * cout, io=2.0 * B * H * W * (cin + (2 if accum else 1) * cout) + 2.0 * cin * cout):

@@ -407,10 +407,15 @@ class _DepthwiseConv(torch.autograd.Function):
     """Depthwise k x k conv, NCHW (HIP: dwconv.hip).  Weights stay fp32 master parameters."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, pad):
+    def forward(ctx, x, weight, stride, pad, fanin=None):
+        """fanin: GradFanIn of x - this layer is the consumer that runs its backward LAST and adds onto the parked gradient."""
         x = x.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad)
+        ctx.fanin = None
+        if fanin is not None and ctx.needs_input_grad[0] and _hip().dwconv_acc_supported(x, weight.shape[-1], stride, pad):
+            fanin.armed = True
+            ctx.fanin = fanin
         return _hip().dwconv_forward(x, weight.detach().float().contiguous(), stride, pad)
 
     @staticmethod
@@ -420,9 +425,11 @@ class _DepthwiseConv(torch.autograd.Function):
         dy = dy.contiguous()
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
+        fan, ctx.fanin = ctx.fanin, None
+        acc = fan.take() if (fan is not None and fan.parking) else None
         dx, dw = _hip().dwconv_backward(x, weight.detach().float().contiguous(), dy, stride, pad,
-                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1], side_dw=_side_wgrad_ok(weight))
-        return dx, (dw.to(weight.dtype) if dw is not None else None), None, None
+                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1], side_dw=_side_wgrad_ok(weight), acc=acc)
+        return dx, (dw.to(weight.dtype) if dw is not None else None), None, None, None
 
 
 class _BNAct(torch.autograd.Function):
@@ -856,8 +863,9 @@ def park_grad(x, fan, owned=False):
     # Only inside a captured segment (dl/engine.py): the convolution adds IN PLACE onto the parked tensor, and there that tensor is
     # the segment's own static output-gradient buffer, refilled before every replay.  In an eager backward the incoming gradient may
     # be a tensor the caller still owns (torch.autograd.backward(outs, grads)): it must not be written to - autograd adds as usual.
+    # (DFINE_PARK_EAGER=1: the tests' switch - their gradient tensors are clones they do not look at again)
     if (fan is None or not fan.armed or not x.requires_grad or x.dtype != torch.bfloat16
-            or not (owned or (_CAPTURE_POSSIBLE and torch.cuda.is_current_stream_capturing()))):
+            or not (owned or (_CAPTURE_POSSIBLE and torch.cuda.is_current_stream_capturing()) or _env("DFINE_PARK_EAGER", "0") == "1")):
         return x
     fan.parking = True
     return _ParkGrad.apply(x, fan)
@@ -1000,6 +1008,12 @@ def _bn_link_arm(link, B, cin, cout, H, W, ks):
 def grad_fanin_enabled(x):
     return (_env("DFINE_GRAD_FANIN", "1") == "1" and torch.is_tensor(x) and x.is_cuda and torch.is_grad_enabled()
             and _env("DFINE_HIP_UNITS", "1") == "1")
+
+
+def fanin_outer_enabled():
+    """The hand-offs across blocks (HG_Block's residual connection, the stage outputs that leave the backbone): DFINE_FANIN_OUTER=0
+    leaves those sums to autograd."""
+    return _env("DFINE_FANIN_OUTER", "1") == "1"
 
 
 class _DenseConvBNAct(torch.autograd.Function):
@@ -1284,15 +1298,20 @@ class _DenseConvSeg(torch.autograd.Function):
             chain.pending -= 1
             dxs = [view if chain.pending == 0 else None]       # (the last one tells _FanSlice the gradient is there)
         elif any(need[2:]):
-            outs = tuple(torch.empty(x.shape, device=x.device, dtype=x.dtype) for x in xs)
-            hip.conv1x1_seg_forward((dy,), _packed_weights(weight, True), outs)
+            fans, ctx.fans = ctx.fans, None
+            # a part whose GradFanIn ALREADY holds a gradient (HG_Block: the residual connection's, parked before this node ran):
+            # this data gradient is added onto it in the store epilogue
+            pre = [fans is not None and fans[i] is not None and fans[i].parking and fans[i].buf is not None
+                   and fans[i].buf.shape == x.shape and fans[i].buf.is_contiguous() for i, x in enumerate(xs)]
+            outs = tuple(fans[i].buf if p else torch.empty(x.shape, device=x.device, dtype=x.dtype) for i, (x, p) in enumerate(zip(xs, pre)))
+            hip.conv1x1_seg_forward((dy,), _packed_weights(weight, True), outs, accum=pre if any(pre) else False)
             dxs = [o if n else None for o, n in zip(outs, need[2:])]
-            fans = ctx.fans
             if fans is not None:
                 for i, f in enumerate(fans):
                     if f is not None and f.parking and dxs[i] is not None:
+                        if not pre[i] and f.buf is not None:            # a parked gradient this launch could not add onto
+                            dxs[i] = dxs[i] + f.buf
                         f.buf, dxs[i] = dxs[i], None        # parked for the part's other consumer (GradFanIn)
-                ctx.fans = None
         dw = None
         if need[0]:
             if ctx.slot is not None:
@@ -1597,7 +1616,8 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
         if route == 1:
             if x.dtype == torch.float32 and torch.is_autocast_enabled():
                 x = x.to(torch.get_autocast_dtype("cuda"))      # what autocast would do for F.conv2d
-            y = _bn_tail_fused(_DepthwiseConv, (x, conv.weight, conv.stride[0], conv.padding[0]), bn, a, lab, fanout=fanout)
+                fanin = None
+            y = _bn_tail_fused(_DepthwiseConv, (x, conv.weight, conv.stride[0], conv.padding[0], fanin), bn, a, lab, fanout=fanout)
             if y is not None:
                 return y
             y = _DepthwiseConv.apply(x, conv.weight, conv.stride[0], conv.padding[0])

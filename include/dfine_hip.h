@@ -166,6 +166,10 @@ int dfine_dwconv_fwd(const void *x, const float *w, void *y, int dtype, int B, i
                      int K, int stride, int pad, void *stream);
 int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, float *dw_f32,
                      int dtype, int B, int C, int H, int W, int K, int stride, int pad, void *stream);
+/* dx += the data gradient of the K = 3 / stride 2 / pad 1 layer (bf16, H even, W % 8 == 0, W <= 320; DFINE_E_BADARG otherwise):
+ * dx holds the gradient of the map's other consumer (HG_Stage.downsample reads a stage output that also leaves the backbone,
+ * src/d_fine/arch/hgnetv2.py:295-303,520-526). */
+int dfine_dwconv_s2_dgrad_acc(const float *w, const void *dy, void *dx, int B, int C, int H, int W, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A1/A2  Fused BatchNorm2d (+ activation) (+ LearnableAffineBlock), NCHW.
@@ -455,6 +459,11 @@ int dfine_conv1x1_seg_fwd_bf16(const void *const *x_parts, const int *x_channels
 int dfine_conv1x1_seg_accum_bf16(const void *const *x_parts, const int *x_channels, const int *x_bstrides, int n_x,
                                  const void *w2, void *const *y_parts, const int *y_channels, const int *y_bstrides,
                                  int n_y, int B, int Cin, int Cout, int H, int W, void *stream);
+/* ... added onto the output parts whose bit is set in accum_parts, the other parts are overwritten (HG_Block's aggregation data
+ * gradient onto the residual connection's gradient of the block input, src/d_fine/arch/hgnetv2.py:265-275). */
+int dfine_conv1x1_seg_accum_parts_bf16(const void *const *x_parts, const int *x_channels, const int *x_bstrides, int n_x,
+                                       const void *w2, void *const *y_parts, const int *y_channels, const int *y_bstrides,
+                                       int n_y, unsigned accum_parts, int B, int Cin, int Cout, int H, int W, void *stream);
 int dfine_conv1x1_seg_wgrad_bf16(const void *const *x_parts, const int *x_channels, const int *x_bstrides, int n_x,
                                  const void *dy, float *dw, float *ws, int B, int Cin, int Cout, int H, int W,
                                  void *stream);

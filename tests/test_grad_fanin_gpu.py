@@ -123,3 +123,114 @@ def test_take_rows_and_pass_equals_gather_plus_autograd_add(cuda):
     full, rows = kernels.take_rows_and_pass(t * 1.0, ind)
     rows.float().sum().backward()
     assert torch.equal(t.grad.float().sum(dim=(1, 2)), torch.full((B,), float(K * C), device=cuda))
+
+
+@pytest.mark.parametrize("B,C,H,W", [(4, 96, 80, 80), (2, 384, 40, 40), (3, 24, 36, 48)])
+def test_depthwise_s2_data_gradient_onto_parked_gradient(cuda, B, C, H, W):
+    """HG_Stage.downsample (3x3 / stride 2 depthwise, ref hgnetv2.py:295-303) as the later consumer of a stage output."""
+    from custom_d_fine_amd import hip
+    torch.manual_seed(C)
+    x = torch.randn(B, C, H, W, device=cuda).bfloat16()
+    w = torch.randn(C, 1, 3, 3, device=cuda)
+    dy = torch.randn(B, C, H // 2, W // 2, device=cuda).bfloat16()
+    other = torch.randn_like(x)
+    assert hip.dwconv_acc_supported(x, 3, 2, 1)
+    dx, _ = hip.dwconv_backward(x, w, dy, 2, 1, True, False)
+    got, _ = hip.dwconv_backward(x, w, dy, 2, 1, True, False, acc=other.clone())
+    assert torch.equal(got, dx + other)
+
+
+def test_part_wise_conv_adds_onto_some_output_parts(cuda):
+    """dfine_conv1x1_seg_accum_parts_bf16: the aggregation's data gradient of HG_Block, block-input part added onto the residual
+    connection's gradient, the other parts overwritten."""
+    from custom_d_fine_amd import hip
+    torch.manual_seed(9)
+    B, H, W, Cin = 3, 40, 40, 96
+    chans = (64, 32, 32, 48)
+    dy = torch.randn(B, Cin, H, W, device=cuda).bfloat16()
+    w = torch.randn(Cin, sum(chans), 1, 1, device=cuda) * Cin ** -0.5       # forward conv: sum(chans) -> Cin
+    w2 = hip.conv_pack_weights(w, True)
+    ref = [torch.empty(B, c, H, W, device=cuda, dtype=torch.bfloat16) for c in chans]
+    hip.conv1x1_seg_forward((dy,), w2, ref)
+    for flags in ([True, False, False, False], [False, True, False, True], [True, True, True, True]):
+        old = [torch.randn_like(r) for r in ref]
+        outs = [o.clone() if f else torch.full_like(o, float("nan")) for o, f in zip(old, flags)]
+        hip.conv1x1_seg_forward((dy,), w2, outs, accum=flags)
+        for o, r, p, f in zip(outs, ref, old, flags):
+            assert torch.equal(o, r + p if f else r)
+
+
+def _run_blocks(cuda, monkeypatch, park, build, x0, n_out):
+    from custom_d_fine_amd import kernels
+    monkeypatch.setenv("DFINE_PARK_EAGER", park)
+    kernels.reload_env()
+    torch.manual_seed(3)
+    mods = build()
+    x = x0.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        outs = mods(x * 1.0)
+    outs = outs if isinstance(outs, (list, tuple)) else [outs]
+    assert len(outs) == n_out
+    gen = torch.Generator(device=cuda).manual_seed(5)
+    torch.autograd.backward(list(outs), [torch.randn(o.shape, device=cuda, generator=gen).to(o.dtype) for o in outs])
+    return [o.detach() for o in outs], x.grad, {n: p.grad.float().clone() for n, p in mods.named_parameters()}
+
+
+@pytest.mark.parametrize("light", [True, False])
+def test_hg_block_residual_gradient_hand_off(cuda, monkeypatch, light):
+    """HG_Block with the residual connection (ref hgnetv2.py:265-275): the block input has three consumers.  Captured segments
+    park the connection's gradient and add the aggregation's and layer 0's data gradients onto it in place (DFINE_PARK_EAGER=1
+    runs that in an eager pass); the default eager pass lets autograd add.  Three-term bf16 sums in another order."""
+    from custom_d_fine_amd import kernels
+    from custom_d_fine_amd.d_fine.arch.hgnetv2 import HG_Block
+    x0 = torch.randn(4, 128, 40, 40, device=cuda).bfloat16()
+    build = lambda: HG_Block(128, 32, 128, 3, residual=True, kernel_size=5 if light else 3, light_block=light, use_lab=True,
+                             agg="se").to(cuda).train()
+    try:
+        y0, gx0, gp0 = _run_blocks(cuda, monkeypatch, "0", build, x0, 1)
+        y1, gx1, gp1 = _run_blocks(cuda, monkeypatch, "1", build, x0, 1)
+    finally:
+        monkeypatch.delenv("DFINE_PARK_EAGER", raising=False)
+        kernels.reload_env()
+    assert torch.equal(y0[0], y1[0])
+    assert (gx0.float() - gx1.float()).abs().max() <= 2 ** -6 * gx0.float().abs().max()
+    for n in gp0:                       # nothing upstream of the block input is inside the block: the parameters see the same terms
+        assert (gp0[n] - gp1[n]).abs().max() <= 1e-3 * gp0[n].abs().max() + 1e-6, n
+
+
+def test_stage_output_gradient_hand_off(cuda, monkeypatch):
+    """A stage output that leaves the backbone and feeds the next stage's depthwise stride-2 convolution (ref hgnetv2.py:295-303,
+    520-526): the outside gradient is parked and the depthwise data gradient is added onto it in place - the same two-term sum
+    autograd forms, bit for bit; upstream of it only the float atomics of the weight-gradient kernels differ."""
+    from custom_d_fine_amd import kernels
+    from custom_d_fine_amd.d_fine.arch.hgnetv2 import HG_Stage
+
+    class Two(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = HG_Stage(64, 32, 128, 1, 3, downsample=False, light_block=False, kernel_size=3, use_lab=True, agg="se")
+            self.b = HG_Stage(128, 32, 256, 2, 3, downsample=True, light_block=True, kernel_size=5, use_lab=True, agg="se")
+
+        def forward(self, x):
+            u = self.a(x)
+            fan = kernels.GradFanIn() if kernels.grad_fanin_enabled(u) else None
+            v = self.b(u, fanin=fan)
+            return [kernels.park_grad(u, fan), v]
+
+    x0 = torch.randn(4, 64, 40, 40, device=cuda).bfloat16()
+    build = lambda: Two().to(cuda).train()
+    try:
+        y0, gx0, gp0 = _run_blocks(cuda, monkeypatch, "0", build, x0, 2)
+        y1, gx1, gp1 = _run_blocks(cuda, monkeypatch, "1", build, x0, 2)
+    finally:
+        monkeypatch.delenv("DFINE_PARK_EAGER", raising=False)
+        kernels.reload_env()
+    for a, b in zip(y0, y1):
+        assert torch.equal(a, b)
+    # stage b has a residual block: three-term sums in another order downstream of the stage output
+    assert torch.nn.functional.cosine_similarity(gx0.float().flatten(), gx1.float().flatten(), dim=0) > 0.9995
+    # (convolution weights only: a BatchNorm scale / shift in front of a depthwise convolution + BatchNorm has an exactly zero
+    # gradient - what the kernels produce for those parameters is rounding noise, in either order)
+    for n in gp0:
+        if n.endswith("conv.weight"):
+            assert torch.nn.functional.cosine_similarity(gp0[n].flatten(), gp1[n].flatten(), dim=0) > 0.999, n

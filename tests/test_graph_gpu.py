@@ -30,20 +30,25 @@ def _segment_grads_eager(step, images, gouts):
     be = _BackboneEncoder(step.model.backbone, step.model.encoder)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         feats = be(images)
-    torch.autograd.backward(feats, gouts)
+    torch.autograd.backward(feats, [g.clone() for g in gouts])       # (clones: DFINE_PARK_EAGER adds onto them in place)
     fused._collect_grads()
     fused._uses.clear()
     return [f.detach().clone() for f in feats], fused.flat_grad.clone()
 
 
 @pytest.mark.parametrize("name,img,bs", [("n", 320, 4), ("m", 320, 2)])
-def test_graphed_segment_equals_eager_segment(cuda, name, img, bs):
+def test_graphed_segment_equals_eager_segment(cuda, monkeypatch, name, img, bs):
     torch.manual_seed(0)
     step = bench.build_step(name, img, cuda, torch.bfloat16)
     fused = step.fused
     images, _ = make_batch(bs, img, seed=3, device=cuda)
     from custom_d_fine_amd import kernels
     kernels.defer_bn_counters(True)
+    # the captured segment hands gradients of maps with several consumers from kernel to kernel where the eager pass lets
+    # autograd add them (kernels.park_grad: the in-place adds are only safe on the segment's own buffers); the eager reference
+    # of THIS test runs the same hand-offs on cloned output gradients, so both sides are the same launches
+    monkeypatch.setenv("DFINE_PARK_EAGER", "1")
+    kernels.reload_env()
     buf0 = fused.flat_buf.clone()
     be = _BackboneEncoder(step.model.backbone, step.model.encoder)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
@@ -96,6 +101,8 @@ def test_graphed_segment_equals_eager_segment(cuda, name, img, bs):
         assert not worst, (rep, noise, scale, sorted(worst, reverse=True)[:5])
     kernels._BN_PENDING.clear()
     kernels.defer_bn_counters(False)
+    monkeypatch.delenv("DFINE_PARK_EAGER")
+    kernels.reload_env()
 
 
 def _spy_grads(step, seen):
