@@ -142,3 +142,11 @@ if os.environ.get("TIMELINE_LONGEST"):
         for b2, e2, n2, s2 in allev:
             if s2 != main and b2 < e and e2 > b:
                 print(f"      beside: stream {s2} {b2 / 1e3:8.3f} + {e2 - b2:7.1f} us  {n2[:80]}")
+
+if os.environ.get("TIMELINE_SEQ"):
+    # the main stream's launches inside a time window "a,b" (ms) in order
+    wa, wb = (float(v) * 1e3 for v in os.environ["TIMELINE_SEQ"].split(","))
+    print(f"\nmain stream, {wa / 1e3:.2f} .. {wb / 1e3:.2f} ms in order:")
+    for b, e, n in streams[main]:
+        if b >= wa and b <= wb:
+            print(f"  {b / 1e3:8.3f} + {e - b:7.1f} us  {n[:150]}")
