@@ -1587,10 +1587,14 @@ def _stem_pad32(dy):
     return dy if wo % 32 == 0 else torch.nn.functional.pad(dy, (0, 32 - wo % 32))
 
 
-# measured (bench.py --steps 100, alternating, three pairs): 30.39 -> 30.25 ms per step - but the stem's weight-gradient kernels then
-# overlap the main stream's stem kernels and both run longer (family kernel time 16.5 -> 17.2 ms: the roofline fraction of the
-# timed mode drops 0.123 -> 0.118).  Off by default: 0.4 % of throughput is below what a single bench run resolves.
-_STEM_TAIL = os.environ.get("DFINE_STEM_TAIL", "0") == "1"
+# The end of a captured backward: the main stream is done ~0.9 ms before the side stream (tools/stream_timeline.py: the last side
+# graph - stage-1 3x3 weight gradient, the five stem weight gradients, the remaining grouped 1x1 / linear launches - only starts
+# when the last main graph has ended).  Mode 2 (default): the registered groups are launched and the pair is closed when the
+# backward pass reaches the stem, so everything but the stem's own weight gradients runs under the stem's data gradients: 28.39
+# -> 28.22 ms per step (same box, alternating), roofline fraction of the timed mode 0.127 -> 0.126.  Mode 1 also gives every stem
+# weight gradient its own pair (28.13 ms), but those HBM-bound kernels then run beside the stem's HBM-bound main-stream kernels
+# and both take longer (family kernel time +0.7 ms: fraction 0.123).  0: the chunking of the rest of the pass all the way.
+_STEM_TAIL = int(os.environ.get("DFINE_STEM_TAIL", "2"))     # 1: as described below; 2: only the early launch of the registered groups
 
 
 def backward_tail_begins():
@@ -1607,7 +1611,13 @@ def backward_tail_begins():
     if _LW_PENDING:
         _flush_linear_group(True)
     if CAPTURE_DUAL is not None:
-        CAPTURE_DUAL.every = 1
+        if _STEM_TAIL == 1:
+            CAPTURE_DUAL.every = 1
+        elif CAPTURE_DUAL.cur is not None and not getattr(CAPTURE_DUAL, "tail_cut", False):
+            CAPTURE_DUAL.tail_cut = True
+            # mode 2: the pair is closed by the next side launch (the first stem weight gradient): the side graph with the backlog and the
+            # groups launched above starts there, under the stem's data gradients; the stem's own weight gradients keep one pair
+            CAPTURE_DUAL.cur[2] = max(CAPTURE_DUAL.cur[2], CAPTURE_DUAL.every)
 
 
 def stem_wgrad(x, dy, ks, stride, pad, side=False):

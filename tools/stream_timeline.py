@@ -150,3 +150,16 @@ if os.environ.get("TIMELINE_SEQ"):
     for b, e, n in streams[main]:
         if b >= wa and b <= wb:
             print(f"  {b / 1e3:8.3f} + {e - b:7.1f} us  {n[:150]}")
+
+if os.environ.get("TIMELINE_HIST"):
+    # launches whose name contains the pattern: count and time per millisecond of the step, all streams
+    pat = os.environ["TIMELINE_HIST"]
+    hist = collections.defaultdict(lambda: [0, 0.0])
+    for s, iv in streams.items():
+        for b, e, n in iv:
+            if pat in n:
+                hist[(s, int(b // 1000))][0] += 1
+                hist[(s, int(b // 1000))][1] += e - b
+    print(f"\n'{pat}' per ms of the step (stream, ms): count, us")
+    for k in sorted(hist):
+        print(f"  stream {k[0]}  {k[1]:3d} ms  {hist[k][0]:4d}  {hist[k][1]:7.1f} us")
