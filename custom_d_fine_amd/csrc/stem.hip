@@ -622,6 +622,138 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(const uint16_t
     }
 }
 
+// The same weight gradient with the columns of a worker ordered (pair group, kx): a lane owns ONE (input channel, kernel row) pair
+// per group and forms the fragments of all KS kernel columns from the SAME aligned window of that row (+ one edge element) - the
+// kernel above gives every (channel, ky, kx) column a lane of its own and loads the window once per kx: 14 vector loads per 8
+// MFMAs, 1.8 GB of L1 traffic for the 354 MB of the 48 -> 24 layer (the kernel ran at a third of its HBM time, TA-bound).
+// Here: 2 + PG * (S + 1) loads per 2 * PG * KS MFMAs (11 per 18 for 3x3 / stride 2).  KS in {2, 3}; PAD / S as instantiated.
+template <int S, int KS, int PAD, int PG /* pair groups (16 pairs each) per worker */>
+__global__ __launch_bounds__(kStemThreads) void stem_wgrad_kx_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ x2, int CA,
+                                                                     const uint16_t *__restrict__ dy, float *__restrict__ part, int CIN,
+                                                                     int COUT, int H, int W, int Ho, int Wo, int ngroups, int nsplit,
+                                                                     int total_steps, int steps_per_split) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int worker = blockIdx.x * (kStemThreads / 64) + wave;
+    const int g = worker % ngroups, split = worker / ngroups;
+    if (split >= nsplit) return;
+    const int npairs = CIN * KS, ncols = npairs * KS;
+    int pr_off[PG], pr_ky[PG];
+    bool pr_b[PG];                                               // the pair's channel lives in the second source
+#pragma unroll
+    for (int q = 0; q < PG; ++q) {
+        const int p = (g * PG + q) * 16 + (lane & 15);
+        const bool ok = p < npairs;
+        const int ci = ok ? p / KS : 0;
+        pr_ky[q] = ok ? p - ci * KS : 0;
+        pr_b[q] = x2 != nullptr && ci >= CA;
+        pr_off[q] = ok ? (pr_b[q] ? ci - CA : ci) * H * W : -1;
+    }
+    stem_f32x4 acc[PG][KS][2];
+#pragma unroll
+    for (int q = 0; q < PG; ++q)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) { acc[q][kx][0] = stem_f32x4{0.f, 0.f, 0.f, 0.f}; acc[q][kx][1] = stem_f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int wsteps = Wo / 32;
+    const int kg = lane >> 4;
+    const int s0 = split * steps_per_split, s1 = min(total_steps, s0 + steps_per_split);
+    struct Stage {
+        uint4 a[2];
+        uint4 raw[PG][S];
+        uint32_t el[PG], er[PG];                                 // the element left of the window / right of it (stride 1)
+        bool ok[PG];
+    };
+    int pb = s0 / (Ho * wsteps), pr = s0 - pb * (Ho * wsteps), pyo = pr / wsteps, pxw = (pr - pyo * wsteps) * 32;
+    auto issue = [&](Stage &st) {
+        const int xo0 = pxw + 8 * kg;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int co = mt * 16 + (lane & 15);
+            st.a[mt] = make_uint4(0, 0, 0, 0);
+            if (co < COUT) st.a[mt] = *reinterpret_cast<const uint4 *>(dy + (((int64_t)pb * COUT + co) * Ho + pyo) * Wo + xo0);
+        }
+        const uint16_t *xb_a = x + (int64_t)pb * (x2 ? CA : CIN) * H * W;
+        const uint16_t *xb_b = x2 ? x2 + (int64_t)pb * (CIN - CA) * H * W : xb_a;
+        const int base = min(xo0 * S, W - 8 * S);                // (see stem_wgrad_kernel)
+#pragma unroll
+        for (int q = 0; q < PG; ++q) {
+            if ((g * PG + q) * 16 >= npairs) break;              // uniform
+            const int yi = pyo * S + pr_ky[q] - PAD;
+            const bool row_ok = pr_off[q] >= 0 && (unsigned)yi < (unsigned)H;
+            const uint16_t *rowp = (pr_b[q] ? xb_b : xb_a) + (row_ok ? pr_off[q] + yi * W : 0);
+            st.ok[q] = row_ok;
+            const stem_u32x4_u r0 = *reinterpret_cast<const stem_u32x4_u *>(rowp + base);
+            st.raw[q][0] = make_uint4(r0.x, r0.y, r0.z, r0.w);
+            if (S == 2) {
+                const stem_u32x4_u r1 = *reinterpret_cast<const stem_u32x4_u *>(rowp + base + 8);
+                st.raw[q][S - 1] = make_uint4(r1.x, r1.y, r1.z, r1.w);
+            }
+            st.el[q] = 0; st.er[q] = 0;
+            if (PAD > 0 && base > 0) st.el[q] = rowp[base - 1];
+            if (S == 1 && KS - 1 - PAD > 0 && base + 8 < W) st.er[q] = rowp[base + 8];
+        }
+        pxw += 32;
+        if (pxw >= Wo) { pxw = 0; if (++pyo == Ho) { pyo = 0; ++pb; } }
+    };
+    auto consume = [&](const Stage &st) {
+        const stem_bf16x8 a0 = __builtin_bit_cast(stem_bf16x8, st.a[0]), a1 = __builtin_bit_cast(stem_bf16x8, st.a[1]);
+#pragma unroll
+        for (int q = 0; q < PG; ++q) {
+            if ((g * PG + q) * 16 >= npairs) break;              // uniform
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                constexpr int dummy = 0; (void)dummy;
+                const int d = kx - PAD;                           // compile-time per unrolled kx
+                uint4 r;
+                if (S == 1) {
+                    const uint4 v = st.raw[q][0];
+                    if (d == 0) r = v;
+                    else if (d < 0) { r.x = (v.x << 16) | st.el[q]; r.y = (v.y << 16) | (v.x >> 16); r.z = (v.z << 16) | (v.y >> 16); r.w = (v.w << 16) | (v.z >> 16); }
+                    else { r.x = (v.x >> 16) | (v.y << 16); r.y = (v.y >> 16) | (v.z << 16); r.z = (v.z >> 16) | (v.w << 16); r.w = (v.w >> 16) | (st.er[q] << 16); }
+                } else {
+                    const uint4 p = st.raw[q][0], w2 = st.raw[q][S - 1];
+                    if (d == 0) {
+                        r.x = (p.x & 0xffffu) | (p.y << 16); r.y = (p.z & 0xffffu) | (p.w << 16);
+                        r.z = (w2.x & 0xffffu) | (w2.y << 16); r.w = (w2.z & 0xffffu) | (w2.w << 16);
+                    } else if (d > 0) {
+                        r.x = (p.x >> 16) | (p.y & 0xffff0000u); r.y = (p.z >> 16) | (p.w & 0xffff0000u);
+                        r.z = (w2.x >> 16) | (w2.y & 0xffff0000u); r.w = (w2.z >> 16) | (w2.w & 0xffff0000u);
+                    } else {
+                        r.x = st.el[q] | (p.x & 0xffff0000u);      r.y = (p.y >> 16) | (p.z & 0xffff0000u);
+                        r.z = (p.w >> 16) | (w2.x & 0xffff0000u);  r.w = (w2.y >> 16) | (w2.z & 0xffff0000u);
+                    }
+                }
+                if (!st.ok[q]) r = make_uint4(0, 0, 0, 0);
+                const stem_bf16x8 bf = __builtin_bit_cast(stem_bf16x8, r);
+                acc[q][kx][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bf, acc[q][kx][0], 0, 0, 0);
+                if (COUT > 16) acc[q][kx][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf, acc[q][kx][1], 0, 0, 0);
+            }
+        }
+    };
+    Stage stA, stB;
+    if (s0 < s1) issue(stA);
+    for (int step = s0; step < s1; step += 2) {
+        if (step + 1 < s1) issue(stB);
+        consume(stA);
+        if (step + 1 >= s1) break;
+        if (step + 2 < s1) issue(stA);
+        consume(stB);
+    }
+#pragma unroll
+    for (int q = 0; q < PG; ++q) {
+        const int p = (g * PG + q) * 16 + (lane & 15);
+        if (p >= npairs) continue;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = mt * 16 + 4 * kg + r;
+                    if (co < COUT) part[((int64_t)split * COUT + co) * ncols + p * KS + kx] = acc[q][kx][mt][r];
+                }
+    }
+}
+
 // dw (zeroed by the caller) += sum over this block's chunk of splits; 64 columns x 4 split lanes per block
 __global__ void stem_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, int nsplit, int total,
                                          int splits_per_block) {
@@ -952,9 +1084,20 @@ static int stem_dgrad_impl(const void *dy, const float *wq, void *dx, void *dx2,
     return DFINE_E_BADARG;
 }
 
-static void stem_wgrad_plan(int B, int Cin, int KS, int Ho, int Wo, int *ngroups, int *nsplit, int *steps) {
+// the (pair group, kx) kernel serves the 3x3 / stride-2 / pad-1 and the 2x2 / stride-1 / bottom-right-padded layers of StemBlock
+static bool stem_wgrad_kx_ok(int KS, int stride, int pad) {
+    static const int on = [] { const char *e = getenv("DFINE_STEM_WGRAD_KX"); return e ? atoi(e) : 1; }();
+    return on && ((KS == 3 && stride == 2 && pad == 1) || (KS == 2 && stride == 1 && pad == 0));
+}
+
+static int stem_wgrad_pg() {
+    static const int pg = [] { const char *e = getenv("DFINE_STEM_WGRAD_PG"); const int v = e ? atoi(e) : 3; return v == 2 ? 2 : 3; }();
+    return pg;
+}
+
+static void stem_wgrad_plan(int B, int Cin, int KS, int Ho, int Wo, int *ngroups, int *nsplit, int *steps, bool kx = false) {
     const int ntile = (Cin * KS * KS + 15) / 16;
-    *ngroups = (ntile + kStemNT - 1) / kStemNT;
+    *ngroups = kx ? (Cin * KS + 16 * stem_wgrad_pg() - 1) / (16 * stem_wgrad_pg()) : (ntile + kStemNT - 1) / kStemNT;
     const int total = B * Ho * (Wo / 32);
     int sp = 6144 / *ngroups;                          // ~6000 workers = 24 waves per CU
     const int cap = (int)(32000000 / ((int64_t)Cin * KS * KS * 32 * 4)) + 1;   // fp32 partials <= ~32 MB
@@ -966,9 +1109,10 @@ static void stem_wgrad_plan(int B, int Cin, int KS, int Ho, int Wo, int *ngroups
 }
 
 int64_t dfine_stem_wgrad_ws_floats(int B, int Cin, int Cout, int KS, int Ho, int Wo) {
-    int ng, ns, st;
+    int ng, ns, st, ns2 = 0;
     stem_wgrad_plan(B, Cin, KS, Ho, Wo, &ng, &ns, &st);
-    return (int64_t)ns * Cout * Cin * KS * KS;
+    if (KS == 2 || KS == 3) stem_wgrad_plan(B, Cin, KS, Ho, Wo, &ng, &ns2, &st, true);      // (whichever kernel the launch picks)
+    return (int64_t)(ns > ns2 ? ns : ns2) * Cout * Cin * KS * KS;
 }
 
 // dw [Cout,Cin,KS,KS] f32 (overwritten).  Wo % 32 == 0, Cout <= 32.
@@ -997,10 +1141,16 @@ static int stem_wgrad_impl(const void *x, const void *x2, int ca, const void *dy
     // KS = 3 without padding needs a shift of +2 - both would be silently wrong weight gradients, so they are refused.
     if (W % (8 * stride) != 0 || KS - 1 - pad > 1) return DFINE_E_BADARG;
     int ng, ns, steps;
-    stem_wgrad_plan(B, Cin, KS, Ho, Wo, &ng, &ns, &steps);
+    const bool kx = stem_wgrad_kx_ok(KS, stride, pad);
+    stem_wgrad_plan(B, Cin, KS, Ho, Wo, &ng, &ns, &steps, kx);
     const int workers = ng * ns;
     hipStream_t st = (hipStream_t)stream;
-    if (stride == 1)
+#define STEM_WKX(SS, KK, PP, GG) hipLaunchKernelGGL((stem_wgrad_kx_kernel<SS, KK, PP, GG>), dim3((workers + 3) / 4), dim3(kStemThreads), 0, st, \
+        (const uint16_t *)x, (const uint16_t *)x2, ca, (const uint16_t *)dy, ws, Cin, Cout, H, W, Ho, Wo, ng, ns, B * Ho * (Wo / 32), steps)
+    if (kx && KS == 3) { if (stem_wgrad_pg() == 2) STEM_WKX(2, 3, 1, 2); else STEM_WKX(2, 3, 1, 3); }
+    else if (kx) { if (stem_wgrad_pg() == 2) STEM_WKX(1, 2, 0, 2); else STEM_WKX(1, 2, 0, 3); }
+#undef STEM_WKX
+    else if (stride == 1)
         hipLaunchKernelGGL(stem_wgrad_kernel<1>, dim3((workers + 3) / 4), dim3(kStemThreads), 0, st, (const uint16_t *)x,
                            (const uint16_t *)x2, ca, (const uint16_t *)dy, ws, Cin, Cout, KS, pad, H, W, Ho, Wo, ng, ns, B * Ho * (Wo / 32), steps);
     else

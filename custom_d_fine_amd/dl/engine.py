@@ -101,6 +101,7 @@ class _DualCapture:
         self.cap_stream, self.side, self.pool, self.every = cap_stream, side, pool, max(int(every), 1)
         self.side_pool = torch.cuda.graph_pool_handle()      # two captures that are open at the same time cannot share a pool
         self.pairs, self.n, self.cur = [], 0, None
+        self.deferred = []          # per pair: its side graph holds launches that write partial sums for the deferred split reduction
 
     def begin(self):
         gm, gs = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -108,11 +109,11 @@ class _DualCapture:
             gm.capture_begin(pool=self.pool, capture_error_mode="relaxed")
         with torch.cuda.stream(self.side.stream):
             gs.capture_begin(pool=self.side_pool, capture_error_mode="relaxed")
-        self.cur = [gm, gs, 0]
+        self.cur = [gm, gs, 0, False]
 
     def end(self):
         import warnings
-        gm, gs, n = self.cur
+        gm, gs, n, deferred = self.cur
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")                  # "The CUDA Graph is empty": a pair without side-stream launches
             with torch.cuda.stream(self.side.stream):
@@ -120,13 +121,16 @@ class _DualCapture:
             with torch.cuda.stream(self.cap_stream):
                 gm.capture_end()
         self.pairs.append((gm, gs if n else None))
+        self.deferred.append(bool(n and deferred))
         self.cur = None
 
-    def side_launch(self):
+    def side_launch(self, direct=False):
         if self.cur[2] >= self.every:           # this launch opens the next pair
             self.end()
             self.begin()
         self.cur[2] += 1
+        if not direct:
+            self.cur[3] = True
 
 
 class GraphedSegment:
@@ -204,7 +208,7 @@ class GraphedSegment:
             with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None, cache_enabled=False):
                 return tuple(torch.func.functional_call(module, alias_map, tuple(self.static_in)))
 
-        def deliver(grads):
+        def deliver(grads, reduce=True):
             """Segment gradients -> flat gradient buffer (recorded at the end of the backward capture)."""
             hip.linear_wgrad_flush()                    # grouped weight-gradient launches of what is registered; joins the side stream
             real = [(g, fused.grad_offset(i)) for g, i in zip(grads, self.param_index) if g is not None]
@@ -213,7 +217,8 @@ class GraphedSegment:
                     raise RuntimeError("graphed segment: parameter gradients are expected in fp32")
             if real:
                 self._keep.append(hip.multi_copy_f32([g.contiguous() for g, _ in real], [o for _, o in real], fused.flat_grad, add=True))
-            fused._flush_deferred()                     # the deferred partial sums of the segment, reduced into flat_grad
+            if reduce:
+                fused._flush_deferred()                 # the deferred partial sums of the segment, reduced into flat_grad
 
         if fused._deferred or hip._CW_PENDING or hip._LW_PENDING:
             raise RuntimeError("GraphedSegment must be built between steps (weight gradients of a running backward are pending)")
@@ -226,7 +231,7 @@ class GraphedSegment:
         snap_mod = [(b, b.clone()) for b in module.buffers() if fused.flat_buf is None or not b.dtype.is_floating_point]
         snap_bn = dict(kernels._BN_PENDING)
         flags = (kernels._CAPTURE_POSSIBLE, kernels._CAPTURE_SHADOWS, hip.CAPTURE_SIDE, arch_utils.CAPTURE_KEEP)
-        self.bwd_pairs = None
+        self.bwd_pairs = self.bwd_reduce_graph = None
         group_at = hip._SIDE_GROUP_AT
         # grouped weight-gradient launches every few registrations: a replay has no host cost per launch (the eager step
         # groups 32 to save ~25 us of host time each), and small groups keep the side stream's work evenly spread
@@ -310,8 +315,21 @@ class GraphedSegment:
                     self.bwd_pairs = dual.pairs
                     self._keep.append(list(hip._SIDE_LIVE))       # inputs of the side graphs: referenced until every capture is done
                     hip._SIDE_LIVE.clear()
+                    # The split reduction of the deferred partial sums (2 GB read per D-FINE-m step, ~0.36 ms) does not need the
+                    # LAST side graph when that one holds direct weight gradients only (the stem's: hip.backward_tail_begins closed
+                    # the pair in front of them) and nothing is left to launch: it gets a graph of its own, replayed on the main
+                    # stream BESIDE the last side graph instead of behind it.  DFINE_GRAPH_TAIL_REDUCE=1; OFF by default: 28.43 -> 28.34 ms
+                    # per step, but the reduction (2 GB of reads) and the stem's weight gradients are both HBM-bound and run longer
+                    # side by side (stem family 1.29 -> 1.58 ms: roofline fraction of the timed mode 0.125 -> 0.1225).
+                    early = (os.environ.get("DFINE_GRAPH_TAIL_REDUCE", "0") == "1" and len(dual.pairs) > 1
+                             and dual.pairs[-1][1] is not None and not dual.deferred[-1]
+                             and not hip._CW_PENDING and not hip._LW_PENDING and bool(fused._deferred))
+                    if early:
+                        self.bwd_reduce_graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(self.bwd_reduce_graph, pool=self.fwd_graph.pool(), stream=cap_stream, capture_error_mode="relaxed"):
+                            fused._flush_deferred()
                     with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(), stream=cap_stream, capture_error_mode="relaxed"):
-                        deliver(grads[:len(aliases)])
+                        deliver(grads[:len(aliases)], reduce=not early)
                 else:
                     with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(), stream=cap_stream, capture_error_mode="relaxed"):
                         grads = torch.autograd.grad(self.static_out, aliases + wrt_inputs, self.static_gout, allow_unused=True)
@@ -379,15 +397,23 @@ class GraphedSegment:
                 if seg.bwd_pairs is not None:
                     cur, st = hip._stream(), hip.side_stream(seg.device)
                     serial = os.environ.get("DFINE_GRAPH_SERIAL") == "1"        # debugging: no overlap between the two streams
-                    for gm, gs in seg.bwd_pairs:
+                    last = len(seg.bwd_pairs) - 1
+                    for k, (gm, gs) in enumerate(seg.bwd_pairs):
                         gm.replay()
                         if gs is not None:
+                            tail_reduce = k == last and seg.bwd_reduce_graph is not None and not serial
+                            if tail_reduce:
+                                hip.stream_wait(st.cuda_stream, cur)      # the earlier side graphs: all the partial sums are there
                             hip.stream_wait(cur, st.cuda_stream)
                             with torch.cuda.stream(st.stream):
                                 gs.replay()
+                            if tail_reduce:
+                                seg.bwd_reduce_graph.replay()             # ... reduced beside the last side graph
                             if serial:
                                 hip.stream_wait(st.cuda_stream, cur)
                     hip.stream_wait(st.cuda_stream, cur)
+                    if seg.bwd_reduce_graph is not None and serial:
+                        seg.bwd_reduce_graph.replay()
                 seg.bwd_graph.replay()
                 f = seg.fused
                 if f.overlap and not f.accumulating:            # bucket bookkeeping of the overlapped all-reduce: this segment's
@@ -407,7 +433,7 @@ class GraphedSegment:
         `gc.freeze()` may have moved them to the permanent generation: an evicted segment would otherwise keep its graph
         memory pool for the life of the process."""
         self._fn = None
-        self.fwd_graph = self.bwd_graph = self.bwd_pairs = None
+        self.fwd_graph = self.bwd_graph = self.bwd_pairs = self.bwd_reduce_graph = None
         self.static_in = self.static_out = self.static_gout = self._static_grads = self.static_gin = None
         self._keep = []
         self._aliases = []

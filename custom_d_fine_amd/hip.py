@@ -525,7 +525,7 @@ def dwconv_backward(x, w, dy, stride, pad, need_dx=True, need_dw=True, side_dw=F
     dx = torch.empty_like(x) if need_dx else None
     dw = torch.zeros(w.shape, device=x.device, dtype=torch.float32) if need_dw else None
     if side_dw and need_dw and _side_ok("dw"):
-        st = _side_fork(x.device)
+        st = _side_fork(x.device, direct=True)
         _check(_lib.dfine_dwconv_bwd(_ptr(x), _ptr(w), _ptr(dy), None, _ptr(dw), _dtype_code(x), B, C, H, W, K, stride, pad,
                                      st.cuda_stream), "dfine_dwconv_bwd")
         _SIDE_LIVE.append((x, w, dy))         # (not dw: autograd only takes ownership of a gradient nobody else references - it would CLONE it, on the main stream)
@@ -1070,13 +1070,14 @@ class _SideStream:
         self.cuda_stream = self.stream.cuda_stream
 
 
-def _side_fork(dev):
-    """-> the side stream (`.cuda_stream` = raw handle), made to wait for everything enqueued on the current stream so far."""
+def _side_fork(dev, direct=False):
+    """-> the side stream (`.cuda_stream` = raw handle), made to wait for everything enqueued on the current stream so far.
+    direct: the launch writes a finished gradient tensor (depthwise, stem), not partial sums for the deferred split reduction."""
     st = _SIDE.get(dev.index)
     if st is None:
         st = _SIDE[dev.index] = _SideStream(dev)
     if CAPTURE_DUAL is not None:
-        CAPTURE_DUAL.side_launch()       # the replay orders the pair: main graph, event, side graph (dl/engine.py)
+        CAPTURE_DUAL.side_launch(direct)   # the replay orders the pair: main graph, event, side graph (dl/engine.py)
         return st
     if _lib.dfine_stream_fork(_stream(), st.cuda_stream) != 0:
         _check(-2, "dfine_stream_fork")
@@ -1629,7 +1630,7 @@ def stem_wgrad(x, dy, ks, stride, pad, side=False):
     _, cout, ho, wo = dy.shape
     need = int(_PURE.dfine_stem_wgrad_ws_floats(B, cin, cout, ks, ho, wo))
     side = side and _side_ok("stem")
-    st = _side_fork(x.device) if side else None
+    st = _side_fork(x.device, direct=True) if side else None
     key = (x.device.index, st.cuda_stream if side else _stream())
     ws = _STEM_WS.get(key)
     if ws is None or ws.numel() < need:
@@ -1678,7 +1679,7 @@ def stem_wgrad2(xa, xb, dy, ks, stride, pad, side=False):
     side = side and _side_ok("stem")
     if side:
         backward_tail_begins()
-    st = _side_fork(xa.device) if side else None
+    st = _side_fork(xa.device, direct=True) if side else None
     key = (xa.device.index, st.cuda_stream if side else _stream())
     ws = _STEM_WS.get(key)
     if ws is None or ws.numel() < need:
