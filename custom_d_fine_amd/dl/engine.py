@@ -159,8 +159,11 @@ class GraphedSegment:
     for a two-layer MLP (tools/graph_probe2.py)."""
 
     def __init__(self, module, sample_inputs, amp_dtype=None, fused=None, warmup=1, input_grads=False, clone_inputs=True,
-                 defer_backward=False):
-        """input_grads: the segment is not the first one of the model - its backward also produces the gradients of its
+                 defer_backward=False, cast_inputs=False):
+        """cast_inputs: floating-point inputs are KEPT in amp_dtype - the per-replay copy into the static input is the cast the
+        module's first layer would do (the stem convolution reads bf16: one pass over the images instead of a same-type copy plus a
+        cast inside the graph; only for inputs that need no gradient and that the module reads through autocast ops only).
+        input_grads: the segment is not the first one of the model - its backward also produces the gradients of its
         (floating-point) inputs, static tensors too (`static_gin`).  clone_inputs=False: the inputs ARE static tensors already (the
         outputs of the segment in front: no copy per replay).  defer_backward: only the forward is captured here; the caller
         finishes with `capture_backward(static_gout)` once it can say where the output gradients will be written (the
@@ -176,6 +179,8 @@ class GraphedSegment:
         self.input_grads = input_grads
         self.done_before = ()        # top-level modules whose backward is over when this segment's starts (set by the caller)
         self.static_in = [t.detach().clone() if clone_inputs else t.detach() for t in sample_inputs]
+        if cast_inputs and amp_dtype is not None and clone_inputs and not input_grads:
+            self.static_in = [t.to(amp_dtype) if t.dtype == torch.float32 else t for t in self.static_in]
         self.static_gin = None
         self._keep, self._pinned = [], hip.CaptureArena()
         self.preflush = os.environ.get("DFINE_GRAPH_PREFLUSH", "1") == "1"
@@ -522,6 +527,10 @@ class TrainStep:
                 self._graphs.pop(next(iter(self._graphs))).release()
             # (single rank: one segment - the split costs ~0.1 ms per step, 31.52 vs 31.38 ms, and buys nothing without an all-reduce)
             split = os.environ.get("DFINE_GRAPH_SPLIT")
+            # the images go into the static input as bf16 (the copy per step IS the stem's input cast): HGNetv2's stem is the
+            # only reader and takes bf16 under autocast (kernels.conv_bn_act route 4)
+            cast_in = (self.amp_dtype == torch.bfloat16 and os.environ.get("DFINE_GRAPH_CAST_INPUT", "1") == "1"
+                       and type(model.backbone).__name__ == "HGNetv2")
             if (split == "1") if split is not None else bool(self.fused.overlap):
                 # TWO segments, encoder | backbone: the encoder's gradients are delivered to the flat buffer (and its buckets'
                 # all-reduces started, data-parallel runs) when ITS backward replay ends, i.e. under the backbone's backward -
@@ -529,7 +538,7 @@ class TrainStep:
                 # backbone's static outputs in place and writes their gradients where the backbone's backward graph reads
                 # them: no map is copied between the two.
                 bb = GraphedSegment(_Backbone(model.backbone), (images,), amp_dtype=self.amp_dtype, fused=self.fused,
-                                    defer_backward=True)
+                                    defer_backward=True, cast_inputs=cast_in)
                 enc = GraphedSegment(_Encoder(model.encoder), tuple(bb.static_out), amp_dtype=self.amp_dtype, fused=self.fused,
                                      input_grads=True, clone_inputs=False)
                 bb.capture_backward(static_gout=enc.static_gin)
@@ -537,7 +546,7 @@ class TrainStep:
                 seg = _SegmentChain([bb, enc])
             else:
                 seg = GraphedSegment(_BackboneEncoder(model.backbone, model.encoder), (images,), amp_dtype=self.amp_dtype,
-                                     fused=self.fused)
+                                     fused=self.fused, cast_inputs=cast_in)
                 seg.done_before = ("decoder",)
             self._graphs[key] = seg
         with torch.autocast("cuda", enabled=False):
