@@ -266,7 +266,20 @@ struct BnFusedFin {
     const float *gamma, *beta;
     float *running_mean, *running_var, *mean_out, *invstd_out, *scale_out, *shift_out;
     float momentum, eps;
+    const uint16_t *res;               // y += res after the rounding of y (a residual connection behind the unit), or null
 };
+
+// the stored bf16 vector plus a residual vector, element-wise in fp32, rounded again: what a separate add of the two bf16 maps gives
+__device__ __forceinline__ uint4 bn_add_res(const uint4 &o, const uint16_t *res) {
+    const uint4 r = *reinterpret_cast<const uint4 *>(res);
+    const uint32_t a[4] = {o.x, o.y, o.z, o.w}, b[4] = {r.x, r.y, r.z, r.w};
+    uint32_t c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        c[k] = pack_bf16x2(__uint_as_float(a[k] << 16) + __uint_as_float(b[k] << 16),
+                           __uint_as_float(a[k] & 0xffff0000u) + __uint_as_float(b[k] & 0xffff0000u));
+    return make_uint4(c[0], c[1], c[2], c[3]);
+}
 struct BnFusedBwdFin {
     const float *part;                 // [C][nchunk][4]
     int nchunk;
@@ -339,6 +352,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_flat8_kernel(const uint16
             uint4 o;
             o.x = pack_bf16x2(a[0], a[1]); o.y = pack_bf16x2(a[2], a[3]);
             o.z = pack_bf16x2(a[4], a[5]); o.w = pack_bf16x2(a[6], a[7]);
+            if (fin.res) o = bn_add_res(o, fin.res + v * 8);
             *reinterpret_cast<uint4 *>(y + v * 8) = o;
         };
         apply(r0, v0, c0);
@@ -894,6 +908,7 @@ __global__ __launch_bounds__(kBnOneThreads) void bn_one_fwd_kernel(const uint16_
         uint4 o;
         o.x = pack_bf16x2(a[0], a[1]); o.y = pack_bf16x2(a[2], a[3]);
         o.z = pack_bf16x2(a[4], a[5]); o.w = pack_bf16x2(a[6], a[7]);
+        if (fin.res) o = bn_add_res(o, fin.res + off[k]);
         *reinterpret_cast<uint4 *>(y + off[k]) = o;
     }
 }
@@ -1127,21 +1142,35 @@ int64_t dfine_bn_ws_floats(int B, int C, int HW) {
     return (int64_t)C * nchunk * 4 + 2 * (int64_t)C;   // partials (max of fwd 2 / bwd 4) + coef
 }
 
+// One-shot request consumed by the next dfine_bn_act_fwd of the calling thread: y = unit(x) + res (bf16 [B, C, HW], same shape;
+// the unit's output is rounded to bf16 first - the sum a separate add pass would give).  HG_Block's residual connection behind the
+// aggregation's excitation unit (ref hgnetv2.py:274-275).  Served by the bf16 16-byte-vector kernels (HW % 8 == 0): a launch that
+// cannot returns DFINE_E_BADARG and drops the request.
+static thread_local const uint16_t *g_bn_res = nullptr;
+int dfine_bn_residual_once(const void *res) {
+    g_bn_res = (const uint16_t *)res;
+    return DFINE_OK;
+}
+
 int dfine_bn_act_fwd(const void *x, void *y, const float *gamma, const float *beta, float *running_mean,
                      float *running_var, const float *lab_scale, const float *lab_bias, float *save_mean, float *save_invstd,
                      float *scale, float *shift, float *ws, int dtype, int B, int C, int HW, int act,
                      int training, float momentum, float eps, void *stream) {
+    const uint16_t *res = g_bn_res;
+    g_bn_res = nullptr;
     if (B == 0 || C == 0 || HW == 0) return DFINE_OK;
     if (!x || !y || !scale || !shift || act < 0 || act > 2) return DFINE_E_BADARG;
     if (dtype != DFINE_F32 && dtype != DFINE_BF16) return DFINE_E_BADARG;
+    if (res && (dtype != DFINE_BF16 || (HW & 7) || C > 4096 || (int64_t)B * C * HW / 8 >= (int64_t)1 << 31)) return DFINE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const int cb = (C + 127) / 128;
     bool fuse_fin = false;
     BnFusedFin ffin{};
+    ffin.res = res;
     int vpt = 0;
     if (training && save_mean && save_invstd && bn_one_ok(dtype, B, HW, &vpt)) {
         BnFusedFin f1{nullptr, 0, (double)B * HW, gamma, beta, running_mean, running_var, save_mean, save_invstd, scale, shift,
-                      momentum, eps};
+                      momentum, eps, res};
 #define DFINE_BN1F(V, A) hipLaunchKernelGGL((bn_one_fwd_kernel<V, A>), dim3(C), dim3(kBnOneThreads), 0, st, (const uint16_t *)x, \
                                             (uint16_t *)y, lab_scale, lab_bias, C, HW, B, f1)
 #define DFINE_BN1F_A(V) { if (act == 0) DFINE_BN1F(V, 0); else if (act == 1) DFINE_BN1F(V, 1); else DFINE_BN1F(V, 2); }
@@ -1162,7 +1191,7 @@ int dfine_bn_act_fwd(const void *x, void *y, const float *gamma, const float *be
                    (int64_t)B * C * HW / 8 < (int64_t)1 << 31;       // = the conditions of the flat8 apply kernel below
         if (fuse_fin)
             ffin = BnFusedFin{ws, nchunk, (double)B * HW, gamma, beta, running_mean, running_var, save_mean, save_invstd,
-                              scale, shift, momentum, eps};
+                              scale, shift, momentum, eps, res};
         else
             hipLaunchKernelGGL(bn_finalize_kernel, dim3(cb), dim3(128), 0, st, ws, nchunk, C, (double)B * HW, gamma, beta,
                                running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);

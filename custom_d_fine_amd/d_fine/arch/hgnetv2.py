@@ -47,8 +47,9 @@ class ConvBNAct(nn.Module):
         self.act = nn.ReLU() if use_act else nn.Identity()
         self.lab = LearnableAffineBlock() if (use_act and use_lab) else nn.Identity()
 
-    def forward(self, x, pad_br=False, fanin=None, fans=None, fanout=None, bnsrc=None):
+    def forward(self, x, pad_br=False, fanin=None, fans=None, fanout=None, bnsrc=None, residual=None):
         """pad_br: the input stands for F.pad(x, (0, 1, 0, 1)) (StemBlock); the pad is applied inside.
+        residual: added to the unit's output (HG_Block's residual connection: in the BatchNorm apply pass where the unit is fused).
         fanin / fans: gradient hand-offs of HG_Block (kernels.GradFanIn); fanout / bnsrc: hand-offs of the BatchNorm-backward
         sums between this unit and the consumer of its output / the producer of its input (kernels.BNLink)."""
         if isinstance(self.conv, nn.Sequential):
@@ -58,7 +59,7 @@ class ConvBNAct(nn.Module):
             conv = self.conv
         lab = self.lab if isinstance(self.lab, LearnableAffineBlock) else None
         return kernels.conv_bn_act(x, conv, self.bn, "relu" if self.use_act else None, lab, pad_br=pad_br, fanin=fanin, fans=fans,
-                                   fanout=fanout, bnsrc=bnsrc)
+                                   fanout=fanout, bnsrc=bnsrc, residual=residual)
 
 
 class LightConvBNAct(nn.Module):
@@ -152,7 +153,16 @@ class HG_Block(nn.Module):
                 feats.append(layer(feats[-1], fanin=fan, fanout=fans[j + 1] if j + 1 < len(fans) else None))
             if isinstance(self.aggregation[1], ConvBNAct):       # squeeze -> excitation: one consumer
                 link = kernels.BNLink()
-                y = self.aggregation[1](self.aggregation[0](feats, fans=fans + [None], fanout=link), bnsrc=link)
+                mid = self.aggregation[0](feats, fans=fans + [None], fanout=link)
+                res = None
+                if self.residual and isinstance(self.drop_path, nn.Identity):
+                    # the residual connection rides in the excitation unit's BatchNorm apply pass; its gradient (the block
+                    # output's) is parked for the aggregation's and layer 0's data gradients to add onto (captured segments).
+                    # (made AFTER the squeeze unit: the parking node must run its backward before that unit's)
+                    res = kernels.park_grad(x, fans[0]) if kernels.fanin_outer_enabled() else x
+                y = self.aggregation[1](mid, bnsrc=link, residual=res)
+                if res is not None:
+                    return y
             else:
                 y = self.aggregation[1](self.aggregation[0](feats, fans=fans + [None]))
         else:

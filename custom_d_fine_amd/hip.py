@@ -45,6 +45,7 @@ _SIGNATURES = {
     "dfine_bn2_act_fwd": (c_int, [_P] * 14 + [_I, _I, _I, _I, _F, _F, _F, _F, _P]),
     "dfine_bn2_act_bwd": (c_int, [_P] * 11 + [_I, _I, _I, _I, _P]),
     "dfine_bn_act_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "dfine_bn_residual_once": (c_int, [_P]),
     "dfine_bn_act_fwd_part": (c_int, [_P] * 13 + [_I, _P, _I, _I, _I, _I, _F, _F, _P]),
     "dfine_bn_act_bwd_part": (c_int, [_P] * 12 + [_I, _P, _I, _I, _I, _I, _P]),
     "dfine_conv_epilogue_chunks": (c_int, [_I, _I, _I, _I, _I, _I, _I]),
@@ -566,8 +567,12 @@ def _bn_ws_need(B, C, HW):
     return n
 
 
+def bn_residual_supported(x):
+    return x.dtype == torch.bfloat16 and x.dim() == 4 and (x.shape[2] * x.shape[3]) % 8 == 0 and x.shape[1] <= 4096 and x.numel() // 8 < (1 << 31)
+
+
 def bn_act_forward(x, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, training,
-                   momentum, eps, part=None):
+                   momentum, eps, part=None, residual=None):
     """x [B, C, H, W] contiguous.  Returns (y, saved) where saved feeds bn_act_backward.
     (133 calls per train step: pointers of the four `stats` rows are computed, not sliced, and the HIP-event timing
     wrapper is skipped unless a bench asked for it.)
@@ -591,6 +596,8 @@ def bn_act_forward(x, gamma, beta, running_mean, running_var, lab_scale, lab_bia
     ws = _bn_workspace(dev, _bn_ws_need(B, C, HW))
     sp = stats.data_ptr()
     row = 4 * C
+    if residual is not None:       # y = unit(x) + residual in the apply pass (bn_residual_supported shapes; one-shot request)
+        _lib.dfine_bn_residual_once(residual.data_ptr())
     status = _lib.dfine_bn_act_fwd(x.data_ptr(), y.data_ptr(), _ptr(gamma), _ptr(beta), _ptr(running_mean),
                                    _ptr(running_var), _ptr(lab_scale), _ptr(lab_bias), sp, sp + row, sp + 2 * row,
                                    sp + 3 * row, ws.data_ptr(), _DTYPE[x.dtype], B, C, HW, _ACT[act],

@@ -851,7 +851,10 @@ class _ParkGrad(torch.autograd.Function):
     def backward(ctx, g):
         fan, ctx.fan = ctx.fan, None
         g = g.contiguous()
-        fan.buf = g if g.dtype == torch.bfloat16 else g.to(torch.bfloat16)
+        g = g if g.dtype == torch.bfloat16 else g.to(torch.bfloat16)
+        if fan.buf is not None:          # another consumer parked first (an unexpected backward order): nothing may be lost
+            g = g + fan.buf
+        fan.buf = g
         return None, None
 
 
@@ -1023,9 +1026,10 @@ class _DenseConvBNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, lab_scale, lab_bias, running_mean, running_var, act, training, momentum, eps,
-                fanin=None, fanout=None, bnsrc=None):
+                fanin=None, fanout=None, bnsrc=None, residual=None):
         """fanin: GradFanIn of x (this unit is its later consumer); fanout: BNLink / GradFanIn of the output (this unit is its
-        producer); bnsrc: BNLink of x when this unit is its ONLY consumer."""
+        producer); bnsrc: BNLink of x when this unit is its ONLY consumer; residual: added to the unit's output in the BatchNorm
+        apply pass (a residual connection behind the unit; its gradient is the output's)."""
         hip = _hip()
         x = x.contiguous()
         ks = weight.shape[-1]
@@ -1046,7 +1050,7 @@ class _DenseConvBNAct(torch.autograd.Function):
                 part = hip.arm_conv_stats(cout, nchunk, x.device)
         c = hip.conv_forward_bf16(x, _packed_weights(weight, False), cout, ks)
         y, stats = hip.bn_act_forward(c, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, training, momentum, eps,
-                                      part=part)
+                                      part=part, residual=None if residual is None else residual.contiguous())
         ctx.fanout = _bn_link_register(fanout, c, stats, lab_scale, act, training)
         ctx.save_for_backward(x, weight, c, stats, lab_scale)
         ctx.cfg = (act, training, gamma is not None, lab_scale is not None)
@@ -1115,7 +1119,7 @@ class _DenseConvBNAct(torch.autograd.Function):
                 wslot[0].use_done(wslot[1][0])
             else:
                 dw = hip.conv_wgrad_bf16(x, dc, ks).to(weight.dtype)
-        return dx, dw, dg, db, dls, dlb, None, None, None, None, None, None, None, None, None
+        return dx, dw, dg, db, dls, dlb, None, None, None, None, None, None, None, None, None, (dy if len(need) > 15 and need[15] else None)
 
 
 class _InnerCtx:
@@ -1547,8 +1551,29 @@ def _is_depthwise(conv, allow_bias=False):
 _ROUTES = [0]       # epoch token of the per-module route caches of conv_bn_act (replaced by reload_env)
 
 
+def _conv_bn_act_residual(x, conv, bn, a, lab, fanin, fanout, bnsrc, residual):
+    """conv_bn_act(x, ...) + residual as ONE fused dense unit (the add rides in the BatchNorm apply pass), or None when the
+    layer is not served that way (then the caller adds)."""
+    if not (torch.is_tensor(x) and x.is_cuda and x.is_contiguous() and x.dtype == torch.bfloat16 and a in (None, "relu", "silu", "swish")
+            and _env("DFINE_HIP_UNITS", "1") == "1" and _env("DFINE_BN_RESIDUAL", "1") == "1" and not _is_depthwise(conv)
+            and _mfma_conv_ok(conv, x) and _FUSE_CONV_BN and type(bn) is nn.BatchNorm2d and bn.track_running_stats
+            and bn.momentum is not None and _conv_plan_all_hip(x, conv.weight) and residual.dtype == torch.bfloat16
+            and residual.shape == (x.shape[0], conv.out_channels, x.shape[2], x.shape[3]) and _hip().bn_residual_supported(residual)):
+        return None
+    training = bn.training
+    if training:
+        if _BN_DEFER:
+            ent = _BN_PENDING.get(id(bn))
+            _BN_PENDING[id(bn)] = (bn.num_batches_tracked, 1 if ent is None else ent[1] + 1)
+        else:
+            bn.num_batches_tracked.add_(1)
+    return _DenseConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, lab.scale if lab is not None else None,
+                                 lab.bias if lab is not None else None, bn.running_mean, bn.running_var, a, training,
+                                 bn.momentum, bn.eps, fanin, fanout, bnsrc, residual)
+
+
 def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Optional[nn.Module],
-                pad_br: bool = False, fanin=None, fans=None, fanout=None, bnsrc=None):
+                pad_br: bool = False, fanin=None, fans=None, fanout=None, bnsrc=None, residual=None):
     """conv(bias=False) -> BN (batch stats in training) -> {None, relu, silu} -> scalar affine; the
     building block of HGNetv2 and the HybridEncoder.
     fanin / fans: GradFanIn hand-offs of the data gradient (fanin: this unit is the LATER consumer of x in backward; fans: one
@@ -1558,6 +1583,12 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
     GPU (bf16 autocast): dense 1x1 / 3x3, depthwise and stem convolutions and the whole BN/act/affine tail are HIP kernels;
     fp32 math and CPU tensors take the plain ATen composition below."""
     a = act.lower() if isinstance(act, str) else act
+    if residual is not None:
+        # only the fused dense unit adds it in its apply pass; every other route: the unit, then a plain add
+        y = _conv_bn_act_residual(x, conv, bn, a, lab, fanin, fanout, bnsrc, residual)
+        if y is not None:
+            return y
+        return conv_bn_act(x, conv, bn, act, lab, pad_br, fanin, fans, fanout, bnsrc) + residual
     if (torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and not x.is_contiguous() and conv.kernel_size == (1, 1)
             and x.dtype == torch.bfloat16 and _hip().is_channel_part(x)):
         x = [x]                       # a channel slice of a wider map (RepNCSPELAN4 split): read in place, no .contiguous() copy

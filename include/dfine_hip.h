@@ -192,6 +192,10 @@ int dfine_bn_act_fwd(const void *x, void *y, const float *gamma, const float *be
                      const float *lab_bias, float *save_mean, float *save_invstd, float *scale,
                      float *shift, float *ws, int dtype, int B, int C, int HW, int act, int training,
                      float momentum, float eps, void *stream);
+/* One-shot: the NEXT dfine_bn_act_fwd of the calling thread stores y = unit(x) + res (res bf16 [B, C, HW]; unit(x) rounded to bf16
+ * first - the sum a separate add of the two maps gives).  The residual connection of HG_Block behind the aggregation's second
+ * unit (src/d_fine/arch/hgnetv2.py:274-275).  bf16, HW % 8 == 0; a launch that cannot serve it returns DFINE_E_BADARG. */
+int dfine_bn_residual_once(const void *res);
 int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_mean,
                      const float *save_invstd, const float *scale, const float *shift,
                      const float *lab_scale, float *dgamma, float *dbeta, float *dlab, float *ws,

@@ -234,3 +234,28 @@ def test_stage_output_gradient_hand_off(cuda, monkeypatch):
     for n in gp0:
         if n.endswith("conv.weight"):
             assert torch.nn.functional.cosine_similarity(gp0[n].flatten(), gp1[n].flatten(), dim=0) > 0.999, n
+
+
+@pytest.mark.parametrize("light", [True, False])
+def test_hg_block_residual_in_the_batchnorm_apply_pass(cuda, monkeypatch, light):
+    """The residual connection of HG_Block (ref hgnetv2.py:274-275) added by the excitation unit's BatchNorm apply kernel
+    (dfine_bn_residual_once) against the separate add (DFINE_BN_RESIDUAL=0): the unit's output is rounded to bf16 before the
+    add, so outputs and gradients are bit-identical."""
+    from custom_d_fine_amd import kernels
+    from custom_d_fine_amd.d_fine.arch.hgnetv2 import HG_Block
+    x0 = torch.randn(4, 128, 40, 40, device=cuda).bfloat16()
+    build = lambda: HG_Block(128, 32, 128, 3, residual=True, kernel_size=5 if light else 3, light_block=light, use_lab=True,
+                             agg="se").to(cuda).train()
+    try:
+        monkeypatch.setenv("DFINE_BN_RESIDUAL", "0")
+        y0, gx0, gp0 = _run_blocks(cuda, monkeypatch, "0", build, x0, 1)
+        monkeypatch.setenv("DFINE_BN_RESIDUAL", "1")
+        y1, gx1, gp1 = _run_blocks(cuda, monkeypatch, "0", build, x0, 1)
+    finally:
+        monkeypatch.delenv("DFINE_BN_RESIDUAL", raising=False)
+        monkeypatch.delenv("DFINE_PARK_EAGER", raising=False)
+        kernels.reload_env()
+    assert torch.equal(y0[0], y1[0])
+    assert torch.equal(gx0, gx1)
+    for n in gp0:
+        assert (gp0[n] - gp1[n]).abs().max() <= 1e-3 * gp0[n].abs().max() + 1e-6, n
