@@ -1621,8 +1621,13 @@ def backward_tail_begins():
     if CAPTURE_DUAL is not None:
         if _STEM_TAIL == 1:
             CAPTURE_DUAL.every = 1
-        elif CAPTURE_DUAL.cur is not None and not getattr(CAPTURE_DUAL, "tail_cut", False):
-            CAPTURE_DUAL.tail_cut = True
+        elif CAPTURE_DUAL.cur is not None:
+            # (mode 3: a second cut in front of the third stem weight gradient - the first two run under the rest of the stem's
+            # data gradients, three trail)
+            n = getattr(CAPTURE_DUAL, "tail_calls", 0)
+            CAPTURE_DUAL.tail_calls = n + 1
+            if not (n == 0 or (_STEM_TAIL == 3 and n == 2)):
+                return
             # mode 2: the pair is closed by the next side launch (the first stem weight gradient): the side graph with the backlog and the
             # groups launched above starts there, under the stem's data gradients; the stem's own weight gradients keep one pair
             CAPTURE_DUAL.cur[2] = max(CAPTURE_DUAL.cur[2], CAPTURE_DUAL.every)
