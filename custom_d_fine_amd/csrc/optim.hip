@@ -186,6 +186,40 @@ int dfine_multi_copy_f32(const void *table, int n_entries, float *dst, void *str
     return check_launch();
 }
 
+// dst = src[0] + src[1] + ... + src[n - 1] (2 <= n <= 8 fp32 tensors of `count` elements, count % 4 == 0): the gradient of a
+// token-stream tensor with several consumers in one pass - autograd adds them pairwise (n - 1 launches, 3 (n - 1) tensor passes
+// against n + 1 here).  Left-to-right fp32 sum.
+struct SumSrcs { const float *p[8]; };
+__global__ __launch_bounds__(256) void sum_f32_kernel(SumSrcs srcs, int n, float *__restrict__ dst, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        float4 a = reinterpret_cast<const float4 *>(srcs.p[0])[i];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            if (k < n) {
+                const float4 b = reinterpret_cast<const float4 *>(srcs.p[k])[i];
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+        }
+        reinterpret_cast<float4 *>(dst)[i] = a;
+    }
+}
+
+int dfine_sum_f32(const void *const *srcs, int n, float *dst, int64_t count, void *stream) {
+    if (count == 0) return DFINE_OK;
+    if (!srcs || !dst || n < 2 || n > 8 || count < 0 || count % 4) return DFINE_E_BADARG;
+    SumSrcs s{};
+    for (int k = 0; k < n; ++k) {
+        if (!srcs[k] || ((uintptr_t)srcs[k] & 15)) return DFINE_E_BADARG;
+        s.p[k] = (const float *)srcs[k];
+    }
+    if ((uintptr_t)dst & 15) return DFINE_E_BADARG;
+    const int64_t nvec = count / 4;
+    int64_t blocks = (nvec + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sum_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, s, n, dst, nvec);
+    return check_launch();
+}
+
 // Same table; dst[dst_offset + i] += src[i].  Records of one launch must not overlap in dst (one block per record, plain
 // read-modify-write).
 int dfine_multi_add_f32(const void *table, int n_entries, float *dst, void *stream) {

@@ -119,8 +119,10 @@ class Gate(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, x1, x2):
-        g = kernels.linear(torch.cat([x1, x2], dim=-1), self.gate.weight, self.gate.bias)
-        return kernels.gate_layer_norm(g, x1, x2, self.norm)
+        # x1 may come as two aliases of one tensor (kernels.fan_out: the gradients of all its consumers are summed in one pass)
+        xa, xb = x1 if isinstance(x1, tuple) else (x1, x1)
+        g = kernels.linear(torch.cat([xa, x2], dim=-1), self.gate.weight, self.gate.bias)
+        return kernels.gate_layer_norm(g, xb, x2, self.norm)
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -159,12 +161,16 @@ class TransformerDecoderLayer(nn.Module):
 
     def forward(self, target, reference_points, value, spatial_shapes, attn_mask=None,
                 query_pos_embed=None):
-        qk = self.with_pos_embed(target, query_pos_embed)
-        target = kernels.add_layer_norm(target, self.dropout1(self.self_attn(qk, target, attn_mask=attn_mask)),
+        # the fp32 token stream has three consumers here and three behind the first LayerNorm: one alias each, so that their
+        # gradients are summed in ONE pass instead of pairwise by autograd (kernels.fan_out)
+        t_qk, t_v, t_res = kernels.fan_out(target, 3)
+        qk = self.with_pos_embed(t_qk, query_pos_embed)
+        target = kernels.add_layer_norm(t_res, self.dropout1(self.self_attn(qk, t_v, attn_mask=attn_mask)),
                                         self.norm1)
-        cross = self.cross_attn(self.with_pos_embed(target, query_pos_embed), reference_points,
+        t_q, t_cat, t_gate = kernels.fan_out(target, 3)
+        cross = self.cross_attn(self.with_pos_embed(t_q, query_pos_embed), reference_points,
                                 value, spatial_shapes)
-        target = self.gateway(target, self.dropout2(cross))
+        target = self.gateway((t_cat, t_gate), self.dropout2(cross))
         return kernels.add_layer_norm(target, self.dropout4(self.forward_ffn(target)), self.norm3, clamp=65504.0)
 
 
@@ -301,19 +307,26 @@ class TransformerDecoder(nn.Module):
             out = layer(out, ref_detach.unsqueeze(2), value, spatial_shapes, attn_mask, pos)
             if return_queries:
                 queries.append(out)
+            # the layer output feeds the heads below and the next layer: one alias per consumer (kernels.fan_out; aliases that
+            # stay unused bring no gradient)
+            taps = iter(kernels.fan_out(out, 5)) if (self.training and torch.is_grad_enabled()) else None
+            base = out
+
+            def tap():
+                return next(taps) if taps is not None else base
 
             if i == 0:
                 # classic sigmoid-space box head on the first layer seeds the FDR reference
                 # (.float(): ATen's mixed bf16 + fp32 add takes 45 - 90 us on a [B, Q, 4] tensor here, the cast + fp32 add 10 us -
                 # tools/probe/tiny_add.py; the promoted sum is the same number)
-                pre_bboxes = F.sigmoid(pre_bbox_head(out).float() + inverse_sigmoid(ref_detach))
+                pre_bboxes = F.sigmoid(pre_bbox_head(tap()).float() + inverse_sigmoid(ref_detach))
                 # (after deploy() the heads before eval_idx are nn.Identity placeholders: ref dfine_decoder.py:698-707)
-                pre_scores = kernels.linear(out, score_head[0].weight, score_head[0].bias) \
-                    if isinstance(score_head[0], nn.Linear) else score_head[0](out)
+                pre_scores = kernels.linear(tap(), score_head[0].weight, score_head[0].bias) \
+                    if isinstance(score_head[0], nn.Linear) else score_head[0](tap())
                 ref_initial = pre_bboxes.detach()
 
             # FDR: residual update of the edge distributions, decoded around the initial box
-            pred_corners = bbox_head[i](out + out_detach) + prev_corners
+            pred_corners = bbox_head[i](tap() + out_detach) + prev_corners
             # Integral + distance2bbox (+ the LQE statistics) in one HIP kernel; after deploy() the layers in front of eval_idx
             # carry an nn.Identity in place of their LQE (ref dfine_decoder.py:422-427) and only take the boxes
             fused_box = pred_corners.is_cuda and self.reg_max == 32
@@ -326,10 +339,10 @@ class TransformerDecoder(nn.Module):
 
             if self.training or i == self.eval_idx:
                 if fused:
-                    scores = kernels.linear(out, score_head[i].weight, score_head[i].bias) \
+                    scores = kernels.linear(tap(), score_head[i].weight, score_head[i].bias) \
                         + self.lqe_layers[i].reg_conf(stat)
                 else:
-                    scores = self.lqe_layers[i](score_head[i](out), pred_corners)
+                    scores = self.lqe_layers[i](score_head[i](tap()), pred_corners)
                 logits.append(scores)
                 boxes.append(box)
                 corners.append(pred_corners)
@@ -340,6 +353,7 @@ class TransformerDecoder(nn.Module):
             prev_corners = pred_corners
             ref_detach = box.detach()
             out_detach = out.detach()
+            out = tap()                                  # the next layer's input
 
         hs = torch.stack(queries) if return_queries else None
         return (torch.stack(boxes), torch.stack(logits), torch.stack(corners), torch.stack(refs),

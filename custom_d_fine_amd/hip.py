@@ -67,6 +67,7 @@ _SIGNATURES = {
     "dfine_ema_update": (c_int, [_P, _P, _L, _F, _P]),
     "dfine_multi_copy_f32": (c_int, [_P, _I, _P, _P]),
     "dfine_multi_add_f32": (c_int, [_P, _I, _P, _P]),
+    "dfine_sum_f32": (c_int, [_P, _I, _P, _L, _P]),
     "dfine_multi_cast_bf16": (c_int, [_P, _I, _P]),
     "dfine_conv_packed_elems": (_L, [_I, _I, _I, _I]),
     "dfine_conv_pack_weights": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
@@ -1236,6 +1237,15 @@ def multi_copy_f32(srcs, dst_offsets, dst_flat, chunk=1 << 16, add=False):
     fn = _lib.dfine_multi_add_f32 if add else _lib.dfine_multi_copy_f32
     _check(fn(_ptr(table), len(rows), _ptr(dst_flat), _stream()), "dfine_multi_add_f32" if add else "dfine_multi_copy_f32")
     return table      # keep alive until the stream has consumed it
+
+
+def sum_f32(tensors):
+    """Sum of 2 .. 8 contiguous fp32 tensors of one shape (numel % 4 == 0) in one pass -> a new tensor."""
+    n = len(tensors)
+    out = torch.empty_like(tensors[0])
+    ptrs = (c_void_p * n)(*[t.data_ptr() for t in tensors])
+    _check(_lib.dfine_sum_f32(ptrs, n, out.data_ptr(), out.numel(), _stream()), "dfine_sum_f32")
+    return out
 
 
 def multi_cast_bf16(table, n_entries):

@@ -874,6 +874,49 @@ def park_grad(x, fan, owned=False):
     return _ParkGrad.apply(x, fan)
 
 
+class _FanOut(torch.autograd.Function):
+    """k aliases of one fp32 token-stream tensor, one per consumer.  Backward: the consumers' gradients arrive TOGETHER and are
+    summed in one pass (dfine_sum_f32) - autograd adds them pairwise as they arrive (k - 1 launches, 3 (k - 1) tensor passes
+    against k + 1).  The decoder's LayerNorm outputs feed 3 - 6 consumers each (self-attention q/k and v inputs, the residual
+    path, the deformable attention's query, the gate, the FFN, the heads: ref dfine_decoder.py:214-255,456-476)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.set_materialize_grads(False)
+        ctx.k = k
+        outs = tuple(x.view_as(x) for _ in range(k))
+        memo = getattr(x, "_dfine_bf16", None)
+        if memo is not None and memo[0] == x._version:     # the bf16 copy the LayerNorm kernel wrote next to x (_bf16_2d)
+            for o in outs:
+                o._dfine_bf16 = (o._version, memo[1])
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [g for g in gs if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        g0 = live[0]
+        ok = all(g.dtype == torch.float32 and g.shape == g0.shape and g.is_contiguous() and g.data_ptr() % 16 == 0 for g in live)
+        if not ok or g0.numel() % 4 or len(live) > 8:
+            total = live[0]
+            for g in live[1:]:
+                total = total + g
+            return total, None
+        # (into a new tensor: an incoming gradient may be shared - AddBackward hands ONE tensor to both of its inputs)
+        return _hip().sum_f32(live), None
+
+
+def fan_out(x, k):
+    """k aliases of x for k consumers (see _FanOut); x itself k times where the fused sum does not apply."""
+    if (k < 2 or not torch.is_tensor(x) or not x.is_cuda or not x.requires_grad or x.dtype != torch.float32 or not torch.is_grad_enabled()
+            or _env("DFINE_FAN_OUT", "1") != "1"):
+        return (x,) * k
+    return _FanOut.apply(x, k)
+
+
 class _TakeRowsAndPass(torch.autograd.Function):
     """(t, t.gather(1, ind[..., None].expand(-1, -1, C))) for t = [B, L, C] and DISTINCT indices per image: the encoder memory on
     its way to the decoder's value path, and the rows the query selection picks from it (ref dfine_decoder.py:842-853,888-905).

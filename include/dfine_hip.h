@@ -348,6 +348,10 @@ int dfine_multi_copy_f32(const void *table, int n_entries, float *dst, void *str
  * AccumulateGrad does per parameter in src/dl/train.py:570-575 (`loss.backward()`), also across the micro-steps of a
  * gradient-accumulation window.  Records of one launch must not overlap in dst. */
 int dfine_multi_add_f32(const void *table, int n_entries, float *dst, void *stream);
+/* dst = srcs[0] + ... + srcs[n - 1] (HOST array of 2 <= n <= 8 device pointers, fp32, count % 4 == 0, 16-byte aligned; dst may be
+ * one of the sources): the gradient sum autograd forms pairwise for a decoder token-stream tensor with several consumers
+ * (src/d_fine/arch/dfine_decoder.py:214-255: every LayerNorm output feeds 2 - 3 sub-layers / the residual path / the heads). */
+int dfine_sum_f32(const void *const *srcs, int n, float *dst, int64_t count, void *stream);
 /* bf16 shadow copies of the fp32 master weights (what autocast's per-call casts of nn.Linear / nn.Conv2d weights
  * produce, the modules of src/d_fine/arch under torch.autocast in src/dl/train.py:524-531) refreshed once per optimizer step:
  * device table of {const float *src; bf16 *dst; int64 n} records. */

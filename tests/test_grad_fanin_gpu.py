@@ -259,3 +259,26 @@ def test_hg_block_residual_in_the_batchnorm_apply_pass(cuda, monkeypatch, light)
     assert torch.equal(gx0, gx1)
     for n in gp0:
         assert (gp0[n] - gp1[n]).abs().max() <= 1e-3 * gp0[n].abs().max() + 1e-6, n
+
+
+def test_fan_out_sums_the_consumers_gradients_in_one_pass(cuda):
+    """kernels.fan_out (decoder token streams, ref dfine_decoder.py:214-255): k aliases, one fused fp32 sum in backward - the same
+    gradient as autograd's pairwise adds up to the order of the fp32 additions (exact for three terms of this test's magnitudes
+    is not guaranteed: tolerance 1e-6 relative)."""
+    from custom_d_fine_amd import kernels
+    torch.manual_seed(7)
+    x0 = torch.randn(8, 492, 256, device=cuda)
+    gs = [torch.randn_like(x0) for _ in range(5)]
+
+    def run(fused):
+        x = x0.clone().requires_grad_(True)
+        y = x * 1.0
+        taps = kernels.fan_out(y, 5) if fused else (y,) * 5
+        if fused:
+            assert type(taps[0].grad_fn).__name__ == "_FanOutBackward"
+        outs = [taps[0] * 2.0, taps[1].sin(), taps[2] + 1.0, taps[4] * taps[4]]          # alias 3 stays unused
+        torch.autograd.backward(outs, gs[:4])
+        return x.grad
+
+    a, b = run(True), run(False)
+    assert (a - b).abs().max() <= 1e-6 * b.abs().max()
