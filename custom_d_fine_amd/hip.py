@@ -509,6 +509,24 @@ def dwconv_forward(x, w, stride, pad):
     return y
 
 
+def _dw_zeros(shape, dev):
+    """Zero-filled fp32 [C, 1, K, K] for a depthwise weight gradient (the kernel adds into it).  In a captured backward the ~20
+    depthwise layers of a step take slices of ONE zero-filled arena: one fill launch on the main stream instead of one each."""
+    if CAPTURE_DUAL is None:
+        return torch.zeros(shape, device=dev, dtype=torch.float32)
+    n = 1
+    for d in shape:
+        n *= int(d)
+    n_al = (n + 63) // 64 * 64
+    ar = getattr(CAPTURE_DUAL, "dw_arena", None)
+    if ar is None or ar[1] + n_al > ar[0].numel():
+        ar = [torch.zeros(max(1 << 18, n_al), device=dev, dtype=torch.float32), 0]
+        CAPTURE_DUAL.dw_arena = ar
+    off = ar[1]
+    ar[1] = off + n_al
+    return ar[0][off:off + n].view(shape)
+
+
 def dwconv_acc_supported(x, K, stride, pad):
     B, C, H, W = x.shape
     return x.dtype == torch.bfloat16 and K == 3 and stride == 2 and pad == 1 and H % 2 == 0 and W % 8 == 0 and W <= 320
@@ -525,7 +543,7 @@ def dwconv_backward(x, w, dy, stride, pad, need_dx=True, need_dw=True, side_dw=F
         _, dw = dwconv_backward(x, w, dy, stride, pad, False, need_dw, side_dw) if need_dw else (None, None)
         return acc, dw
     dx = torch.empty_like(x) if need_dx else None
-    dw = torch.zeros(w.shape, device=x.device, dtype=torch.float32) if need_dw else None
+    dw = _dw_zeros(w.shape, x.device) if need_dw else None
     if side_dw and need_dw and _side_ok("dw"):
         st = _side_fork(x.device, direct=True)
         _check(_lib.dfine_dwconv_bwd(_ptr(x), _ptr(w), _ptr(dy), None, _ptr(dw), _dtype_code(x), B, C, H, W, K, stride, pad,
