@@ -8,7 +8,8 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line (contract in the task statement).  `value` = images of all ranks / wall time of the K timed
-steps (barrier + device synchronize on both sides, max over ranks); `median_ms_per_step` = median of the K per-step
+steps (barrier + device synchronize on both sides, max over ranks; no instrumentation inside - every sampled / traced step runs
+after the second fence); `median_ms_per_step` = median of the K per-step
 durations (HIP events around every step).  Extra objects:
   roofline          the dominant kernel FAMILY by device time: the dense-convolution implicit GEMMs of backbone + encoder
                     (forward, data gradient, weight gradient, stem; MFMA roof).  achieved = algorithmic FLOPs of the family's
@@ -17,7 +18,7 @@ durations (HIP events around every step).  Extra objects:
                     gradients on a second stream -, taken from the device timestamps of every kernel of `--trace-steps` more
                     steps run right after the timed region under torch.profiler's in-process tracer (HIP events cannot
                     bracket kernels launched from a graph replay).  Sub-objects: `events` = the same sum from HIP events
-                    around every launch of ONE eager step inside the timed region (two streams; `--sample-every`), `isolated`
+                    around every launch of `--event-steps` eager two-stream steps run AFTER the timed region, `isolated`
                     = one eager step with everything on one stream (no neighbour kernels), `profile` = the figure
                     recomputed from the committed rocprofv3 --kernel-trace --stats summary of this command
                     (tools/roofline_from_stats.py; same kernel-name patterns, KERNEL_GROUPS).
@@ -238,9 +239,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--mask", type=int, default=0, help="1: segmentation head (BASELINE configs[4])")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (0 = skip)")
-    ap.add_argument("--sample-every", type=int, default=50,
-                    help="instrument every n-th timed step with HIP events around the kernel launches (0 = none); an instrumented "
-                         "step is ~15 ms slower, so the default samples one step of the 50")
+    ap.add_argument("--event-steps", type=int, default=1,
+                    help="eager steps with HIP events around the kernel launches, run AFTER the timed region (0 = no roofline objects)")
     ap.add_argument("--channels-last", type=int, default=0)
     ap.add_argument("--dry", action="store_true",
                     help="launcher check: spawn the ranks (capped at the visible devices), initialise the RCCL process group, run one "
@@ -309,25 +309,41 @@ def main():
     hip.enable_timing(MFMA_GROUPS + ("linear_wgrad", "linear", "attention", "msda_fwd", "msda_bwd"))
     hip.timing_active(False)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    sampled_steps = set()
-    if args.sample_every > 0:
-        sampled_steps = {i for i in range(args.steps) if i % args.sample_every == args.sample_every - 1} or {args.steps - 1}
     fence()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
-        hip.timing_active(i in sampled_steps)
         # a NEW target list per step, as a data loader hands over: the per-batch caches of matcher / criterion (target masks at
         # mask resolution, concatenated labels / boxes) are keyed on the list and must be rebuilt every step like in training
         step(images, list(targets))
         marks[i + 1].record()
-    hip.timing_active(False)
     fence()
     elapsed = time.perf_counter() - t0
     per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    # ---- everything below is instrumentation and runs OUTSIDE the timed region: `value` / `ms_per_step` come from the K
+    # un-instrumented steps above only (reference methodology: src/dl/bench.py:80-120 times only the call under test)
+    sampled_steps = list(range(args.event_steps))
+    eager_ms = []
     if sampled_steps:
-        # one more step, OUTSIDE the timed region, with everything on one stream: the same kernels without a neighbour
-        # (records under "iso:<key>"; `roofline` itself is the two-stream sample taken inside the timed region)
+        # `--event-steps` eager steps with HIP events around every reported launch (two streams, like the timed mode but
+        # host-paced), after one un-instrumented eager step: the FIRST eager step of a process grows the caching allocator's
+        # default-stream pool (the graph replays live in their own pool) - `eager_first_step` records what that costs
+        for k in range(1 + args.event_steps):
+            hip.timing_active(k > 0)
+            r0 = torch.cuda.memory_reserved(device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            h0 = time.perf_counter()
+            hip.force_eager(True)
+            e0.record()
+            step(images, list(targets))
+            e1.record()
+            hip.force_eager(False)
+            torch.cuda.synchronize()
+            eager_ms.append({"ms": round(e0.elapsed_time(e1), 2), "host_ms": round((time.perf_counter() - h0) * 1e3, 2),
+                             "reserved_growth_mb": round((torch.cuda.memory_reserved(device) - r0) / 2**20, 1),
+                             "instrumented": k > 0})
+        hip.timing_active(False)
+        # one more step with everything on one stream: the same kernels without a neighbour (records under "iso:<key>")
         hip.timing_active(True, isolated=True)
         step(images, targets)
         hip.timing_active(False)
@@ -359,12 +375,11 @@ def main():
         max_t = max(len(t["labels"]) for t in targets)
         dn = 2 * max_t * max(100 // max_t, 1)
         lq = 300 + dn
-        sampled = len(sampled_steps)
 
         MODES = {"traced": "timed mode: graph replay of backbone + encoder, weight gradients on the second stream; device timestamps of "
                            f"every kernel of {args.trace_steps} steps run right after the timed region, collected in-process through "
                            "torch.profiler (roctracer)",
-                 "events": "eager step inside the timed region on the same two streams, HIP events on the stream each launch goes to",
+                 "events": "eager step(s) after the timed region on the same two streams, HIP events on the stream each launch goes to",
                  "isolated": "one eager step after the timed region with every launch on ONE stream (no neighbour kernel), HIP events"}
 
         def event_sums(keys, iso):
@@ -448,7 +463,10 @@ def main():
                        "collective": f"RCCL all-reduce over {world} ranks" if world > 1 else "none",
                        "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
                        "ranks_seen": world, "per_rank_ms_per_step": [round(e / args.steps * 1e3, 3) for e in per_rank],
-                       "hip_graph": bool(getattr(step, "hip_graph", False)), "instrumented_steps": sampled},
+                       "hip_graph": bool(getattr(step, "hip_graph", False)), "instrumented_steps_in_timed_region": 0,
+                       # eager steps run after the timed region: [0] un-instrumented (the first eager step of the process: grows
+                       # the default-stream pool of the caching allocator), [1:] with HIP events around the reported launches
+                       "eager_steps_after_timed_region": eager_ms},
             "roofline": family,
             "roofline_kernels": [k for k in kernels_ if k is not None and k.get("launches_per_step", 0) > 0],
         }

@@ -512,6 +512,8 @@ class DFINECriterion(nn.Module):
         # fp32 division like the reference's torch.clamp(t / world, min=1).item()
         num_boxes_go = max(float(np.float32(tot[0]) / np.float32(world)), 1.0)
         num_boxes = max(float(np.float32(tot[1]) / np.float32(world)), 1.0)
+        # what the losses were normalised by (tests/test_dist_gpu.py checks them against the reference's definition)
+        self.__dict__["_last_norm"] = {"num_boxes": num_boxes, "num_boxes_go": num_boxes_go, "go_count": int(indices_go.src.size)}
 
         def go_or(own, go_for=("boxes", "local")):
             return lambda loss: (indices_go, num_boxes_go) if loss in go_for else (own, num_boxes)
@@ -703,6 +705,8 @@ class DFINECriterion(nn.Module):
             go_sum = go_f
         tot = host_all_reduce_sum([float(T)])
         num_boxes = max(float(np.float32(tot[0]) / np.float32(world)), 1.0)
+        # (the GO normaliser clamp(go_sum / world, 1) is formed on the device by dfine_criterion_scales; go_count stays there)
+        self.__dict__["_last_norm"] = {"num_boxes": num_boxes, "num_boxes_go": None, "go_count": go_count}
         n_aux = len(outputs["aux_outputs"])
         plans = [_DevPlan(head_plans[k], T) for k in range(len(heads))]
         go = _DevPlan(go_packed, go_packed.shape[1], go_count)

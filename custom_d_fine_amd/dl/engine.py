@@ -514,7 +514,7 @@ class TrainStep:
                      and hasattr(model, "backbone") and self._calls > self.graph_after and torch.is_grad_enabled())
         if use_graph:
             from .. import hip
-            use_graph = not hip._TIMING_ON       # per-launch HIP events only exist for eager launches
+            use_graph = not (hip._TIMING_ON or hip._FORCE_EAGER)       # per-launch HIP events only exist for eager launches
         if not use_graph:
             return model(images, targets=targets)
         key = (tuple(images.shape), images.dtype)

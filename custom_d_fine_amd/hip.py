@@ -196,10 +196,18 @@ _PURE = _PureQueries()
 # algorithmic work (FLOPs or bytes) of the launch.
 _TIMED = {}          # name -> list of (start_event, end_event, work, bound_seconds)
 MFMA_PEAK_FLOPS, HBM_PEAK_BYTES = 2.5e15, 8.0e12       # MI355X_MICROARCH.md: dense bf16 MFMA, HBM3E
-_TIMING_ON = False   # bench.py switches this per step (`timing_active`) to sample a subset of the timed steps
+_TIMING_ON = False   # bench.py switches this per step (`timing_active`): the steps it samples after its timed region
 _TIMING_ISOLATED = False   # True: the sampled step runs everything on ONE stream (no weight gradients beside the chain) and its
                            # records go under "iso:<key>"; False: the step keeps its two streams and side-stream launches are
                            # bracketed by events on the side stream - the mode the un-instrumented steps run in
+
+
+_FORCE_EAGER = False  # TrainStep runs backbone + encoder eagerly instead of replaying their graphs (bench.py's eager samples)
+
+
+def force_eager(flag):
+    global _FORCE_EAGER
+    _FORCE_EAGER = bool(flag)
 
 
 def enable_timing(names=None):
