@@ -690,7 +690,7 @@ int dfine_attn_bwd_ms(const void *q, const void *k, const void *v, const void *o
         return check_launch();
     }
     // keys per workgroup: 512 (<4, 8>, <8, 4>), 256 (<2, 8>), 128 (<2, 4>): fewer keys = more workgroups for the same L
-    static const int var = [] { const char *e = getenv("DFINE_ATTN_DKDV"); return e ? atoi(e) : 48; }();
+    constexpr int var = 48;
 #define DFINE_DKDV_M(KT_, NW_, MM_)                                                                                                    \
     { const int nk = (L + 16 * KT_ * NW_ - 1) / (16 * KT_ * NW_);                                                                      \
       hipLaunchKernelGGL((attn_bwd_dkdv_kernel<KT_, NW_, MM_>), dim3(B * H * nk), dim3(64 * NW_), 0, st, (const uint16_t *)q, (const uint16_t *)k, \

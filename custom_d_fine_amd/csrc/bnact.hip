@@ -22,10 +22,8 @@ namespace dfine {
 constexpr int kBnThreads = 256;
 // Workgroups of the flat apply kernels: few fat ones amortise the per-workgroup parameter / finalize prologue on the maps of
 // the 640 x 640 models (D-FINE-m: 6.12 -> 5.90 ms per step with 512 instead of 4096; 256: 6.28); the > 64 MB maps of the 960 x 960
-// models want the full grid (D-FINE-x + masks: 112.7 -> 109.8 ms per step).  DFINE_BN_GRID overrides.
+// models want the full grid (D-FINE-x + masks: 112.7 -> 109.8 ms per step).
 static int bn_grid_cap(int64_t nvec8) {
-    static const int env = [] { const char *e = getenv("DFINE_BN_GRID"); return e ? atoi(e) : 0; }();
-    if (env > 0) return env;
     return nvec8 <= ((int64_t)1 << 22) ? 512 : 4096;
 }
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
@@ -1084,47 +1082,8 @@ __global__ __launch_bounds__(kBnOneThreads) void bn_one_bwd_stream_kernel(
     }
 }
 
-// ---- partial sums produced by a convolution epilogue (epi_bn.h), part [nchunk][C][NV] -----------------------------------
-// Folded to S <= 32 slots per channel in the [C][S][NV] layout the flat apply kernels finish in their prologue (BnFusedFin /
-// BnFusedBwdFin): a workgroup = 16 channels x 16 chunk lanes, slice s takes chunks s, s + S, s + 2 S, ...; 16 channels x NV
-// floats of one chunk are 128 / 256 contiguous bytes.  Fixed summation order: deterministic.
-template <int NV>
-__global__ __launch_bounds__(kBnThreads) void bn_part_slice_kernel(const float *__restrict__ part, int nchunk, int C, int S,
-                                                                   float *__restrict__ out) {
-    __shared__ float red[16][16][NV];
-    const int ch = threadIdx.x & 15, k = threadIdx.x >> 4, c = blockIdx.x * 16 + ch, s = blockIdx.y;
-    float v[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = 0.f;
-    if (c < C)
-        for (int chunk = s + S * k; chunk < nchunk; chunk += 16 * S) {
-            const float *p = part + ((int64_t)chunk * C + c) * NV;
-            if (NV == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] += t.x; v[1] += t.y; }
-            else { const float4 t = *reinterpret_cast<const float4 *>(p); v[0] += t.x; v[1] += t.y; v[NV > 2 ? 2 : 0] += t.z; v[NV > 2 ? 3 : 0] += t.w; }
-        }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) red[k][ch][i] = v[i];
-    __syncthreads();
-    if (k == 0 && c < C) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            double t = 0.0;
-            for (int q = 0; q < 16; ++q) t += (double)red[q][ch][i];
-            out[((int64_t)c * S + s) * NV + i] = (float)t;
-        }
-    }
-}
-
-static int part_slices(int C, int nchunk) {
-    int S = kBnFuseMax / (C > 0 ? C : 1);
-    if (S > 32) S = 32;
-    if (S > nchunk) S = nchunk;
-    return S < 1 ? 1 : S;
-}
-
 static bool bn_one_ok(int dtype, int B, int HW, int *vpt) {
-    static const int on = [] { const char *e = getenv("DFINE_BN_ONE"); return e ? atoi(e) : 1; }();
-    if (!on || dtype != DFINE_BF16 || (HW & 7) || (int64_t)B * HW > kBnOneMaxElems) return false;
+    if (dtype != DFINE_BF16 || (HW & 7) || (int64_t)B * HW > kBnOneMaxElems) return false;
     const int per = (B * (HW >> 3) + kBnOneThreads - 1) / kBnOneThreads;
     *vpt = per <= 1 ? 1 : (per <= 2 ? 2 : (per <= 4 ? 4 : 8));
     return true;
@@ -1322,61 +1281,6 @@ int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<uint16_t>, grid, dim3(kBnThreads), 0, st, (const uint16_t *)x, (const uint16_t *)dy,
                            (uint16_t *)dx, save_mean, save_invstd, scale, shift, lab_scale, coef, C, HW, act, training);
-    return check_launch();
-}
-
-// Training-mode forward / backward with the reduction pass replaced by the partial sums of a convolution epilogue (epi_bn.h).
-// ws: 4 * 8192 + 2 C floats (the folded partials + the backward's coefficient pairs).
-int dfine_bn_act_fwd_part(const void *x, void *y, const float *gamma, const float *beta, float *running_mean,
-                          float *running_var, const float *lab_scale, const float *lab_bias, float *save_mean,
-                          float *save_invstd, float *scale, float *shift, const float *part, int nchunk, float *ws, int B,
-                          int C, int HW, int act, float momentum, float eps, void *stream) {
-    if (B == 0 || C == 0 || HW == 0) return DFINE_OK;
-    if (!x || !y || !save_mean || !save_invstd || !scale || !shift || !part || !ws || nchunk < 1 || act < 0 || act > 2) return DFINE_E_BADARG;
-    const int64_t nvec8 = (int64_t)B * C * HW / 8;
-    if ((HW & 7) || C > 4096 || nvec8 >= (int64_t)1 << 31) return DFINE_E_BADARG;
-    hipStream_t st = (hipStream_t)stream;
-    const int S = part_slices(C, nchunk);
-    hipLaunchKernelGGL(bn_part_slice_kernel<2>, dim3((C + 15) / 16, S), dim3(kBnThreads), 0, st, part, nchunk, C, S, ws);
-    int64_t nb8 = (nvec8 + kBnThreads * 4 - 1) / (kBnThreads * 4);
-    if (nb8 > bn_grid_cap(nvec8)) nb8 = bn_grid_cap(nvec8);
-    const size_t sm = sizeof(float) * 2 * C;
-    // (the per-channel finish is its own small launch: folded into the apply kernel's prologue, every one of its 512 workgroups
-    // re-reads C x S partials - 192 -> 384 @80x80: 65 -> 138 us)
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, ws, S, C, (double)B * HW, gamma, beta,
-                       running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
-    const BnFusedFin ffin{};
-#define DFINE_BNA8(A) hipLaunchKernelGGL(bn_apply_flat8_kernel<A>, dim3((unsigned)nb8), dim3(kBnThreads), sm, st, (const uint16_t *)x, \
-                                         (uint16_t *)y, scale, shift, lab_scale, lab_bias, C, HW, nvec8, ffin)
-    if (act == 0) DFINE_BNA8(0); else if (act == 1) DFINE_BNA8(1); else DFINE_BNA8(2);
-#undef DFINE_BNA8
-    return check_launch();
-}
-
-int dfine_bn_act_bwd_part(const void *x, const void *dy, void *dx, const float *save_mean, const float *save_invstd,
-                          const float *scale, const float *shift, const float *lab_scale, float *dgamma, float *dbeta,
-                          float *dlab, const float *part, int nchunk, float *ws, int B, int C, int HW, int act,
-                          void *stream) {
-    if (B == 0 || C == 0 || HW == 0) return DFINE_OK;
-    if (!x || !dy || !dx || !save_mean || !save_invstd || !scale || !shift || !part || !ws || nchunk < 1 || act < 0 || act > 2)
-        return DFINE_E_BADARG;
-    const int64_t nvec8 = (int64_t)B * C * HW / 8;
-    if ((HW & 7) || C > 2048 || nvec8 >= (int64_t)1 << 31) return DFINE_E_BADARG;
-    hipStream_t st = (hipStream_t)stream;
-    const int S = part_slices(C, nchunk);
-    hipLaunchKernelGGL(bn_part_slice_kernel<4>, dim3((C + 15) / 16, S), dim3(kBnThreads), 0, st, part, nchunk, C, S, ws);
-    float *coef = ws + (int64_t)4 * kBnFuseMax;
-    int64_t nb8 = (nvec8 + kBnThreads * 4 - 1) / (kBnThreads * 4);
-    if (nb8 > bn_grid_cap(nvec8)) nb8 = bn_grid_cap(nvec8);
-    const size_t sm = sizeof(float) * 6 * C;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, ws, S, C, (double)B * HW, dgamma, dbeta,
-                       dlab, coef);
-    const BnFusedBwdFin bfin{};
-#define DFINE_BNB8(A) hipLaunchKernelGGL(bn_bwd_apply_flat8_kernel<A>, dim3((unsigned)nb8), dim3(kBnThreads), sm, st, (const uint16_t *)x, \
-                                         (const uint16_t *)dy, (uint16_t *)dx, save_mean, save_invstd, scale, shift, lab_scale, coef, \
-                                         C, HW, nvec8, 1, bfin)
-    if (act == 0) DFINE_BNB8(0); else if (act == 1) DFINE_BNB8(1); else DFINE_BNB8(2);
-#undef DFINE_BNB8
     return check_launch();
 }
 

@@ -27,7 +27,6 @@
 //   MFMA   = v_mfma_f32_16x16x32_bf16: A lane l -> W2[n = l&15][c = 8*(l>>4)..+7],
 //            B lane l -> X_lds[pixel = l&15][c = 8*(l>>4)..+7], D lane l -> Y[n = 4*(l>>4)+reg][pixel = l&15].
 #include "common.h"
-#include "epi_bn.h"
 
 namespace dfine {
 
@@ -765,27 +764,14 @@ __device__ __forceinline__ void glds16(const uint16_t *gsrc, unsigned lds_addr) 
 #define DFINE_CONV1X1_ABLATE 0
 #endif
 constexpr int kAbl = DFINE_CONV1X1_ABLATE;
-// -DDFINE_CONV1X1_SPREAD=1: the streamed schedule issues the copies of stage s + 1 one piece behind every other MFMA group of
-// stage s instead of all of them behind the barrier.  Measured (tools/conv1x1_bench.py, 26 shapes): 1161 -> 1218 us, 512 -> 512
-// @80x80 158.6 -> 162.4: the copies queueing at the CU's address path in front of the first MFMA are not what the stage waits for.
-#ifndef DFINE_CONV1X1_SPREAD
-#define DFINE_CONV1X1_SPREAD 0
-#endif
-constexpr bool kIssueSpread = DFINE_CONV1X1_SPREAD != 0;
 
-// kernel argument of the BatchNorm-sum epilogue (epi_bn.h): nothing at all in the plain instantiations
-template <bool EPI> struct EpiArg { DfineConvEpilogue e; };
-template <> struct EpiArg<false> {};
-
-template <int NTN, int kG2Ring, int PXW, bool SEG, bool EPI = false>   // kG2Ring LDS stages (3: two in flight; 2 for <= 128 input channels); PXW 16-pixel
-                                                     // tiles per wave (4 / 8); SEG: input / output given as several parts; EPI: BatchNorm
-                                                     // sums of the stored values in the store loop
+template <int NTN, int kG2Ring, int PXW, bool SEG>   // kG2Ring LDS stages (3: two in flight; 2 for <= 128 input channels); PXW 16-pixel
+                                                     // tiles per wave (4 / 8); SEG: input / output given as several parts
 __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs xs_, const uint16_t *__restrict__ w2,
                                                                   const ChanSegs ys_, int Cin, int Cout, int NP, int KP,
                                                                   int HW, int ptiles, int total_tiles, int nblk, int accum,
                                                                   int64_t w_bstride /* elements between the images' weight sets: 0 = shared */,
-                                                                  int ximg /* tiles over the pixels of ALL images (B * HW), see below */,
-                                                                  const EpiArg<EPI> epa) {
+                                                                  int ximg /* tiles over the pixels of ALL images (B * HW), see below */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int TP = 32 * PXW;                                             // pixels per workgroup (128 or 256)
     constexpr int XPITCH = TP * 2;                                           // bytes per channel row
@@ -871,22 +857,6 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
         }
     };
 
-    // piece j (0 .. XPW + NTN - 1) of stage s alone: the streamed schedule spreads a stage's copies over the MFMA groups of the
-    // stage in front (kIssueSpread below)
-    auto issue_piece = [&](int s, int j) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (s % kG2Ring) * SB);
-        const int c0 = s * kG2Rows;
-        if (j < XPW) {
-            const int ch = min(c0 + x_row[j], Cin - 1);
-            if (!SEG) glds16(x_src[j] + (int64_t)ch * HW, __builtin_amdgcn_readfirstlane(base + (wave * XPW + j) * 1024));
-            else glds16(xtab[ch >> 3] + (int64_t)(ch & 7) * HW + x_px[j], __builtin_amdgcn_readfirstlane(base + (wave * XPW + j) * 1024));
-        } else {
-            const int jw = j - XPW;
-            const int k = min(c0 + w_k[jw], KP - 8);
-            glds16(w2 + (int64_t)w_row[jw] * KP + k, __builtin_amdgcn_readfirstlane(base + XB + (wave * NTN + jw) * 1024));
-        }
-    };
-
     f32x4v acc[NTN][PXW];
 #pragma unroll
     for (int t = 0; t < NTN; ++t)
@@ -914,12 +884,12 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
             if (!(kAbl & 4) || s < 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             const unsigned char *xs2 = lds + (s & 1) * SB, *ws2 = xs2 + XB;
-            // (kIssueSpread, off: the copies of stage s + 1 spread over the MFMA groups of the stage, order pinned by sched_barrier)
+            // (measured and dropped: the copies of stage s + 1 spread one piece behind every other MFMA group of the stage,
+            // order pinned by sched_barrier - 26 shapes 1161 -> 1218 us: the copies queueing at the CU's address path in front of
+            // the first MFMA are not what the stage waits for)
             const bool more = s + 1 < nstage && !((kAbl & 4) && s >= 1);
-            constexpr int kPieces = XPW + NTN, kGroups = 2 * PXW, kEvery = kGroups / kPieces > 0 ? kGroups / kPieces : 1;
-            if (more && !kIssueSpread) issue(s + 1);
+            if (more) issue(s + 1);
             const int nslab = s * kG2Rows + 32 < KP ? 2 : 1;
-            if (more && kIssueSpread && nslab == 1) issue(s + 1);        // (a one-slab stage has half the groups: up front)
 #pragma unroll
             for (int slab = 0; slab < 2; ++slab) {
                 if (slab >= nslab) break;
@@ -953,14 +923,6 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
 #pragma unroll
                     for (int t = 0; t < NTN; ++t)
                         acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[t], b1[j], acc[t][j], 0, 0, 0);
-                    if (kIssueSpread && nslab == 2) {
-                        const int grp = slab * PXW + j;                    // MFMA group of the stage: 0 .. 2 PXW - 1
-                        if (grp % kEvery == kEvery - 1 && grp / kEvery < kPieces) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (more) issue_piece(s + 1, grp / kEvery);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
                 }
             }
             continue;
@@ -1040,84 +1002,31 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
         const int bi = (int)(gp / HW);
         ylane = ((int64_t)bi * ys_.bs[0]) * HW + (gp - (int64_t)bi * HW);
     }
-    if constexpr (!EPI) {
 #pragma unroll
-        for (int it = 0; it < 16 * NTN / RPI; ++it) {
-            const int row = it * RPI + lane / LPO, c8 = (lane % LPO) * 8;
-            const int n = n0 + wn * 16 * NTN + row;
-            if (n < Cout && wp * 16 * PXW + c8 < npix) {
-                uint16_t *yp = SEG ? ytab[wn * 16 * NTN + row] + p0 + wp * 16 * PXW + c8
-                                   : const_cast<uint16_t *>(ys_.p[0]) + ylane + (int64_t)n * HW;
-                bool acc_row = accum != 0;
-                if (SEG) {          // several output parts: bit 0 of a part's base address says "add onto this part" (launch_conv1x1)
-                    const uintptr_t u = reinterpret_cast<uintptr_t>(yp);
-                    acc_row = acc_row || (u & 1);
-                    yp = reinterpret_cast<uint16_t *>(u & ~(uintptr_t)1);
-                }
-                uint4 v = *reinterpret_cast<const uint4 *>(ot + row * OP + c8);
-                if (acc_row) {                                // y += conv(x): bf16 + bf16 in fp32, one rounding (like a separate add)
-                    const uint4 o = *reinterpret_cast<const uint4 *>(yp);
-                    const uint32_t a[4] = {v.x, v.y, v.z, v.w}, c[4] = {o.x, o.y, o.z, o.w};
-                    uint32_t r[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        r[k] = pack_bf16x2(__uint_as_float(a[k] << 16) + __uint_as_float(c[k] << 16),
-                                           __uint_as_float(a[k] & 0xffff0000u) + __uint_as_float(c[k] & 0xffff0000u));
-                    v = make_uint4(r[0], r[1], r[2], r[3]);
-                }
-                *reinterpret_cast<uint4 *>(yp) = v;
+    for (int it = 0; it < 16 * NTN / RPI; ++it) {
+        const int row = it * RPI + lane / LPO, c8 = (lane % LPO) * 8;
+        const int n = n0 + wn * 16 * NTN + row;
+        if (n < Cout && wp * 16 * PXW + c8 < npix) {
+            uint16_t *yp = SEG ? ytab[wn * 16 * NTN + row] + p0 + wp * 16 * PXW + c8
+                               : const_cast<uint16_t *>(ys_.p[0]) + ylane + (int64_t)n * HW;
+            bool acc_row = accum != 0;
+            if (SEG) {          // several output parts: bit 0 of a part's base address says "add onto this part" (launch_conv1x1)
+                const uintptr_t u = reinterpret_cast<uintptr_t>(yp);
+                acc_row = acc_row || (u & 1);
+                yp = reinterpret_cast<uint16_t *>(u & ~(uintptr_t)1);
             }
-        }
-        return;
-    } else {
-        // Every global load of a batch of rows (the old values of an accumulating store, the BatchNorm input of the epilogue sums) is
-        // issued before the batch's first store: loads do not move above stores they might alias, and a load -> add -> store chain
-        // per row left the wave waiting out one memory round trip per row (up to 16 in a row).
-        const DfineConvEpilogue &ep = epa.e;
-        constexpr int NIT = 16 * NTN / RPI, EB = NIT < 4 ? NIT : 4;
-        const int c8 = (lane % LPO) * 8;
-        const bool col_ok = wp * 16 * PXW + c8 < npix;
-        const uint16_t *bnx = reinterpret_cast<const uint16_t *>(ep.bn_x);
+            uint4 v = *reinterpret_cast<const uint4 *>(ot + row * OP + c8);
+            if (acc_row) {                                // y += conv(x): bf16 + bf16 in fp32, one rounding (like a separate add)
+                const uint4 o = *reinterpret_cast<const uint4 *>(yp);
+                const uint32_t a[4] = {v.x, v.y, v.z, v.w}, c[4] = {o.x, o.y, o.z, o.w};
+                uint32_t r[4];
 #pragma unroll
-        for (int it0 = 0; it0 < NIT; it0 += EB) {
-            uint16_t *yp[EB];
-            uint4 old[EB], xin[EB];
-#pragma unroll
-            for (int k = 0; k < EB; ++k) {
-                const int row = (it0 + k) * RPI + lane / LPO;
-                const int n = n0 + wn * 16 * NTN + row;
-                const bool live = n < Cout && col_ok;
-                yp[k] = SEG ? ytab[wn * 16 * NTN + row] + p0 + wp * 16 * PXW + c8
-                            : const_cast<uint16_t *>(ys_.p[0]) + ylane + (int64_t)n * HW;
-                old[k] = make_uint4(0, 0, 0, 0); xin[k] = make_uint4(0, 0, 0, 0);
-                if (accum && live) old[k] = *reinterpret_cast<const uint4 *>(yp[k]);
-                if (ep.mode == 2 && live) xin[k] = *reinterpret_cast<const uint4 *>(bnx + (yp[k] - ys_.p[0]));
+                for (int k = 0; k < 4; ++k)
+                    r[k] = pack_bf16x2(__uint_as_float(a[k] << 16) + __uint_as_float(c[k] << 16),
+                                       __uint_as_float(a[k] & 0xffff0000u) + __uint_as_float(c[k] & 0xffff0000u));
+                v = make_uint4(r[0], r[1], r[2], r[3]);
             }
-#pragma unroll
-            for (int k = 0; k < EB; ++k) {
-                const int row = (it0 + k) * RPI + lane / LPO;
-                const int n = n0 + wn * 16 * NTN + row;
-                const bool live = n < Cout && col_ok;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (live) {
-                    v = *reinterpret_cast<const uint4 *>(ot + row * OP + c8);
-                    if (accum) {                              // y += conv(x): bf16 + bf16 in fp32, one rounding (like a separate add)
-                        const uint32_t a[4] = {v.x, v.y, v.z, v.w}, c[4] = {old[k].x, old[k].y, old[k].z, old[k].w};
-                        uint32_t r[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            r[q] = pack_bf16x2(__uint_as_float(a[q] << 16) + __uint_as_float(c[q] << 16),
-                                               __uint_as_float(a[q] & 0xffff0000u) + __uint_as_float(c[q] & 0xffff0000u));
-                        v = make_uint4(r[0], r[1], r[2], r[3]);
-                    }
-                    *reinterpret_cast<uint4 *>(yp[k]) = v;
-                }
-                if (ep.mode) {                                // (uniform) BatchNorm sums of the values just stored: one slot per
-                    float s4[4] = {0.f, 0.f, 0.f, 0.f};       // (channel, workgroup half); one output part only (launch_conv1x1)
-                    if (live) epi_bn_terms(ep, n, v, xin[k], s4);
-                    epi_bn_write<LPO>(ep, n, tile_id * 2 + wp, s4, n < Cout);
-                }
-            }
+            *reinterpret_cast<uint4 *>(yp) = v;
         }
     }
 }
@@ -1134,20 +1043,10 @@ static ChanSegs one_seg(const void *p, int C) {
     return sg;
 }
 
-// one-shot epilogue request (dfine_conv_epilogue_once): per host thread, consumed by the next convolution launch
-static thread_local DfineConvEpilogue g_epi_req;
-static thread_local bool g_epi_set = false;
-bool take_conv_epilogue(DfineConvEpilogue *out) {
-    if (!g_epi_set) return false;
-    *out = g_epi_req;
-    g_epi_set = false;
-    return true;
-}
-
 // tile choice of the LDS-DMA 1x1 kernel for one layer
 struct C1Cfg { bool n256, px256, wide2, ring2, ximg; int tp, ptiles2, total2, nblk2; };
 static C1Cfg conv1x1_cfg(int B, int NP, int KP, int HW, bool seg, bool per_image_weights) {
-    static const int px256_env = [] { const char *e = getenv("DFINE_CONV1X1_PX256"); return e ? atoi(e) : 1; }();
+    constexpr int px256_env = 1;
     // The kernel is bound by the ~10 B/clk/CU load path, so the tile is as large as the layer can fill the chip with:
     // 256 pixels x 128 channels (87 FLOP per loaded byte) for deep layers on big maps, 128 x 128 (64) / 128 x 64 otherwise.
     // Three tile regimes (tools/conv1x1_bench.py, 26 layer shapes of D-FINE-m, forward: 1364 us with the round-4 choice ->
@@ -1164,9 +1063,9 @@ static C1Cfg conv1x1_cfg(int B, int NP, int KP, int HW, bool seg, bool per_image
     const bool n128 = NP % 128 == 0;
     // whole tensors with shared weights: pixel tiles over the B * HW pixels of the batch whenever per-image tiles would
     // leave the last one partly empty (20 x 20 planes: 400 pixels = 3.1 tiles of 128; 40 x 40: 6.25 tiles of 256)
-    static const int ximg_env = [] { const char *e = getenv("DFINE_CONV1X1_XIMG"); return e ? atoi(e) : 1; }();
-    static const int n256_env = [] { const char *e = getenv("DFINE_CONV1X1_N256"); return e ? atoi(e) : 1; }();
-    static const int small_env = [] { const char *e = getenv("DFINE_CONV1X1_SMALL"); return e ? atoi(e) : 1; }();
+    constexpr int ximg_env = 1;
+    constexpr int n256_env = 1;
+    constexpr int small_env = 1;
     const bool xok = ximg_env && !seg && !per_image_weights;
     const int64_t gpix = (int64_t)B * HW;
     const int64_t t256 = xok ? (gpix + 255) / 256 : (int64_t)B * ((HW + 255) / 256);
@@ -1189,14 +1088,11 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
                           hipStream_t st, const ChanSegs *xsegs = nullptr, const ChanSegs *ysegs = nullptr, int accum = 0,
                           int64_t w_bstride = 0, unsigned accum_parts = 0 /* bit k: add onto output part k (several parts) */) {
     const int ptiles = (HW + kTrPix - 1) / kTrPix;
-    DfineConvEpilogue epv{};
-    const bool has_ep = take_conv_epilogue(&epv);
     if (conv1x1_glds_ok(Cin, KP, HW)) {
         const ChanSegs xs_ = xsegs ? *xsegs : one_seg(x, Cin);
         ChanSegs ys_ = ysegs ? *ysegs : one_seg(y, Cout);
         const bool seg = xs_.n > 1 || ys_.n > 1;
         if (accum_parts) {
-            if (has_ep) return DFINE_E_BADARG;
             if (!seg) accum = 1;                                // one part in, one part out: the plain accumulate-into launch
             else
                 for (int k = 0; k < ys_.n; ++k)
@@ -1205,9 +1101,6 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
         const C1Cfg cf = conv1x1_cfg(B, NP, KP, HW, seg, w_bstride != 0);
         const bool n256 = cf.n256, px256 = cf.px256, wide2 = cf.wide2, ring2 = cf.ring2, ximg = cf.ximg;
         const int tp = cf.tp, ptiles2 = cf.ptiles2, total2 = cf.total2, nblk2 = cf.nblk2;
-        if (has_ep && (ys_.n != 1 || ys_.bs[0] != Cout || w_bstride || !epv.part || epv.nchunk != 2 * total2 || epv.cout != Cout ||
-                       (epv.mode != 1 && epv.mode != 2) || (epv.mode == 2 && (!epv.bn_x || !epv.mean || !epv.invstd || !epv.scale || !epv.shift))))
-            return DFINE_E_BADARG;
         dim3 grid2(8 * ((total2 + 7) / 8) * nblk2);
         if (seg && Cin > 4096) return DFINE_E_BADARG;
         const size_t lds2 = n256 ? (size_t)8 * 64 * 136 * 2 + (seg ? 6144 : 0)
@@ -1215,26 +1108,20 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
         static bool attr2 = false;
         if (!attr2) {
             hipError_t e = hipSuccess, r;
-#define DFINE_G2_ATTR1(N, R, P, S, E, BYTES) \
-    if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<N, R, P, S, E>), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES)) != hipSuccess) e = r;
+#define DFINE_G2_ATTR1(N, R, P, S, BYTES) \
+    if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<N, R, P, S>), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES)) != hipSuccess) e = r;
 #define DFINE_G2_ATTR(N, R, P) \
-    DFINE_G2_ATTR1(N, R, P, false, false, R * (64 * 64 * P + 8192 * N)) DFINE_G2_ATTR1(N, R, P, true, false, R * (64 * 64 * P + 8192 * N) + 5120) \
-    DFINE_G2_ATTR1(N, R, P, false, true, R * (64 * 64 * P + 8192 * N)) DFINE_G2_ATTR1(N, R, P, true, true, R * (64 * 64 * P + 8192 * N) + 5120)
+    DFINE_G2_ATTR1(N, R, P, false, R * (64 * 64 * P + 8192 * N)) DFINE_G2_ATTR1(N, R, P, true, R * (64 * 64 * P + 8192 * N) + 5120)
             DFINE_G2_ATTR(1, 2, 4) DFINE_G2_ATTR(1, 3, 4) DFINE_G2_ATTR(2, 2, 4) DFINE_G2_ATTR(2, 3, 4) DFINE_G2_ATTR(2, 3, 8)
 #undef DFINE_G2_ATTR
-            DFINE_G2_ATTR1(4, 2, 8, false, false, 8 * 64 * 136 * 2) DFINE_G2_ATTR1(4, 2, 8, true, false, 8 * 64 * 136 * 2 + 6144)
-            DFINE_G2_ATTR1(4, 2, 8, false, true, 8 * 64 * 136 * 2) DFINE_G2_ATTR1(4, 2, 8, true, true, 8 * 64 * 136 * 2 + 6144)
+            DFINE_G2_ATTR1(4, 2, 8, false, 8 * 64 * 136 * 2) DFINE_G2_ATTR1(4, 2, 8, true, 8 * 64 * 136 * 2 + 6144)
 #undef DFINE_G2_ATTR1
             if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
             attr2 = true;
         }
-#define DFINE_G2L(N, R, P, S, E, ARG) \
-    hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, S, E>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum, w_bstride, ximg ? 1 : 0, ARG)
-#define DFINE_G2(N, R, P)                                                                                            \
-    { if (has_ep) { if (seg) DFINE_G2L(N, R, P, true, true, epa1); else DFINE_G2L(N, R, P, false, true, epa1); }     \
-      else { if (seg) DFINE_G2L(N, R, P, true, false, epa0); else DFINE_G2L(N, R, P, false, false, epa0); } }
-        const EpiArg<true> epa1{epv};
-        const EpiArg<false> epa0{};
+#define DFINE_G2L(N, R, P, S) \
+    hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, S>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum, w_bstride, ximg ? 1 : 0)
+#define DFINE_G2(N, R, P) { if (seg) DFINE_G2L(N, R, P, true); else DFINE_G2L(N, R, P, false); }
         if (n256) DFINE_G2(4, 2, 8)
         else if (px256) DFINE_G2(2, 3, 8)
         else if (wide2) { if (ring2) DFINE_G2(2, 2, 4) else DFINE_G2(2, 3, 4) }
@@ -1243,9 +1130,9 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
 #undef DFINE_G2L
         return check_launch();
     }
-    if (xsegs || ysegs || accum || accum_parts || w_bstride || has_ep) return DFINE_E_BADARG;  // the first-generation kernel takes whole tensors, shared weights, no accumulation, no epilogue sums
+    if (xsegs || ysegs || accum || accum_parts || w_bstride) return DFINE_E_BADARG;  // the first-generation kernel takes whole tensors, shared weights, no accumulation
     const int vec = (HW % 8 == 0) ? 8 : (HW % 4 == 0 ? 4 : 2);
-    static const int kc_env = [] { const char *e = getenv("DFINE_CONV_KC"); return e ? atoi(e) : 0; }();
+    constexpr int kc_env = 0;
     int kc = KP >= 128 ? 4 : (KP >= 64 ? 2 : 1);
     if (kc_env) kc = kc_env;
     while (kc > 1 && KP < 32 * kc) kc >>= 1;
@@ -1640,113 +1527,6 @@ __global__ __launch_bounds__(kW2Threads) void conv_wgrad1_group_kernel(const int
                                  B * cpi, cps, nct, (Cout + 15) / 16 * 16, (Cin + 15) / 16 * 16, npairs, splits, blockIdx.x);
 }
 
-// The same for layers with <= 128 channels on both sides (53 of the 1x1 weight gradients of a D-FINE-m step): 64 x 64 (n, c) tiles.
-// With ONE 128 x 128 tile per layer the only parallelism is the split of the pixels, and every split is a 64 KiB slab of partial
-// sums: 256 workgroups = 16.8 MB written and read again for a 26 MB layer (40 x 40), three 64-pixel stages per workgroup - the
-// grouped launches ran at 57 TFLOP/s, 5 x their HBM time.  Four tiles x 64 splits are the same 256 workgroups with a quarter of
-// the partial sums and four times the pixels per workgroup; the operands are read twice (L2: the four tiles of a split sit on
-// one XCD), a stage is 16 KiB, three workgroups fit a CU.
-__device__ __forceinline__ void conv_wgrad1_t64_body(const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy, float *__restrict__ part,
-                                                     int Cin, int Cout, int HW, int chunks_per_image, int total_chunks,
-                                                     int chunks_per_split, int nct, int NP16, int CP16, int npairs, int nsplits, const int bx) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int OPB = 64 * 128, SB = 2 * OPB;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int pair, split;
-    if ((nsplits & 7) == 0) {
-        const int xcd = bx & 7, slot = bx >> 3;
-        pair = slot % npairs; split = (slot / npairs) * 8 + xcd;
-    } else {
-        pair = bx % npairs; split = bx / npairs;
-    }
-    if (split >= nsplits) return;
-    const int nt = pair / nct, ct = pair - nt * nct;
-    const int n0 = nt * 64, c0 = ct * 64;
-    const int g = lane >> 4, i16 = lane & 15, wn = wave >> 1, wc = wave & 1;
-    const int q0 = split * chunks_per_split, q1 = min(total_chunks, q0 + chunks_per_split);
-    const int nstage = q1 - q0;
-    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero_page);
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
-    int row_a[2], kc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = (wave * 2 + j) * 8 + (lane >> 3);
-        row_a[j] = row;
-        kc[j] = ((lane & 7) ^ (row & 7)) << 3;
-    }
-    auto issue = [&](int s) {
-        const int q = q0 + s;
-        const int b = q / chunks_per_image, p0 = (q - b * chunks_per_image) * kW2Px;
-        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (s % kW2Ring) * SB);
-        const uint16_t *dyb = dy + (int64_t)b * Cout * HW + p0, *xb = x + (int64_t)b * Cin * HW + p0;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const bool pin = p0 + kc[j] < HW;
-            const int n = n0 + row_a[j], c = c0 + row_a[j];
-            glds16((pin && n < Cout) ? dyb + (int64_t)n * HW + kc[j] : zero, __builtin_amdgcn_readfirstlane(base + (wave * 2 + j) * 1024));
-            glds16((pin && c < Cin) ? xb + (int64_t)c * HW + kc[j] : zero, __builtin_amdgcn_readfirstlane(base + OPB + (wave * 2 + j) * 1024));
-        }
-    };
-    f32x4v acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    if (nstage > 0) issue(0);
-    if (nstage > 1) issue(1);
-    for (int s = 0; s < nstage; ++s) {
-        if (s + 1 < nstage) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const unsigned char *ta = lds + (s % kW2Ring) * SB, *tb = ta + OPB;
-        bf16x8 af[2][2], bfr[2][2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int row = wn * 32 + a * 16 + i16;
-                af[ks][a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(ta + row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4)));
-            }
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int row = wc * 32 + b * 16 + i16;
-                bfr[ks][b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(tb + row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4)));
-            }
-        }
-        if (s + 2 < nstage) issue(s + 2);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][a], bfr[ks][b], acc[a][b], 0, 0, 0);
-    }
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int c = c0 + wc * 32 + b * 16 + i16;
-        if (c >= CP16) continue;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wn * 32 + a * 16 + 4 * g + r;
-                if (n < NP16) part[((int64_t)split * NP16 + n) * CP16 + c] = acc[a][b][r];
-            }
-    }
-}
-
-__global__ __launch_bounds__(kW2Threads) void conv_wgrad1_group64_kernel(const int64_t *__restrict__ table) {
-    const int64_t *e = table + (int64_t)blockIdx.y * 8;
-    const int B = (int)e[3], Cin = (int)e[4], Cout = (int)e[5], HW = (int)e[6];
-    const int splits = (int)(e[7] & 0xffffffff), cps = (int)(e[7] >> 32);
-    const int cpi = (HW + kW2Px - 1) / kW2Px;
-    const int nnt = (Cout + 63) / 64, nct = (Cin + 63) / 64, npairs = nnt * nct;
-    if ((int)blockIdx.x >= 8 * ((splits + 7) / 8) * npairs) return;
-    conv_wgrad1_t64_body(reinterpret_cast<const uint16_t *>(e[0]), reinterpret_cast<const uint16_t *>(e[1]), reinterpret_cast<float *>(e[2]),
-                         Cin, Cout, HW, cpi, B * cpi, cps, nct, (Cout + 15) / 16 * 16, (Cin + 15) / 16 * 16, npairs, splits, blockIdx.x);
-}
-
 // wg_target: workgroups the problem should occupy - 256 (one per CU, one round: the load path of EVERY CU is needed) when it is
 // launched on its own; a problem of a GROUPED launch (dfine_conv_wgrad1_group: 8 - 32 problems side by side) fills the chip
 // with far fewer, and every split it does not use is a slab of fp32 partial sums that is not written and not read again by
@@ -2039,7 +1819,7 @@ static void wgrad_plan(int B, int Cin, int Cout, int H, int W, int KS, int *R, i
     int cap = (int)(24000000 / bytes_per_split);
     if (cap < 8) cap = 8;
     if (cap > 512) cap = 512;
-    static const int target = [] { const char *e = getenv("DFINE_WGRAD_BLOCKS"); return e ? atoi(e) : 1024; }();
+    constexpr int target = 1024;
     int sp = target / (pairs * KS);
     if (sp < 1) sp = 1;
     if (sp > cap) sp = cap;
@@ -2063,13 +1843,13 @@ static bool conv3x3_ws_ok(int B, int NP, int KP, int H, int W) {
     if (R > H) R = H;
     const int strips = (H + R - 1) / R;
     const size_t slab_bytes = (size_t)(R + 2) * (W + 2) * 64;
-    static const int kc_env = [] { const char *e = getenv("DFINE_CONV_KC"); return e ? atoi(e) : 0; }();
+    constexpr int kc_env = 0;
     int kc = KP >= 256 ? 4 : (KP >= 64 ? 2 : 1);
     if (kc_env) kc = kc_env;
     while (kc > 1 && (slab_bytes * kc > 65536 || KP < 32 * kc)) kc >>= 1;
     const int vec = (W % 8 == 0) ? 8 : (W % 4 == 0 ? 4 : 2);
     const bool wide = (NP % 128 == 0) && ((int64_t)B * strips * (NP / 128) >= 512);
-    static const int ws_env = [] { const char *e = getenv("DFINE_CONV3X3_WS"); return e ? atoi(e) : 1; }();
+    constexpr int ws_env = 1;
     const size_t ws_ep = (size_t)4 * 16 * (wide ? 2 : 1) * (16 * kMaxPixTiles + 8) * 2;
     const int kc_ws = kc > 2 ? 2 : kc;
     const size_t ws_slab = (size_t)(R + 2) * ws_pitch(W) * 64;
@@ -2079,9 +1859,6 @@ static bool conv3x3_ws_ok(int B, int NP, int KP, int H, int W) {
 
 static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B, int Cin, int Cout, int NP, int KP,
                        int H, int W, int KS, hipStream_t st, int accum = 0) {
-    DfineConvEpilogue epv{};
-    const bool has_ep = take_conv_epilogue(&epv);
-    if (has_ep) return DFINE_E_BADARG;                 // (the 3x3 kernels have no BatchNorm-sum epilogue: dfine_conv_epilogue_chunks says 0)
     if (KS == 3 && conv3x3_rows32_ok(NP, KP, H, W)) return conv3x3_rows32_launch(x, w2, y, B, Cin, Cout, NP, KP, H, W, accum, st);
     // strip height: as many rows as fit in 160 pixels
     int R = 160 / W;
@@ -2091,14 +1868,14 @@ static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B
     const int pad = KS / 2;
     const size_t slab_bytes = (size_t)(R + 2 * pad) * (W + 2 * pad) * 64;
     // slabs per stage: deep input-channel counts amortise the stage latency over 64 / 128 channels
-    static const int kc_env = [] { const char *e = getenv("DFINE_CONV_KC"); return e ? atoi(e) : 0; }();
+    constexpr int kc_env = 0;
     int kc = KP >= 256 ? 4 : (KP >= 64 ? 2 : 1);
     if (kc_env) kc = kc_env;
     while (kc > 1 && (slab_bytes * kc > 65536 || KP < 32 * kc)) kc >>= 1;
     const size_t ldsb = slab_bytes * kc;
     const int vec = (W % 8 == 0) ? 8 : (W % 4 == 0 ? 4 : 2);
     const int nblk64 = (NP + 63) / 64;
-    static const int wide_min = [] { const char *e = getenv("DFINE_CONV3_WIDE_MIN"); return e ? atoi(e) : 512; }();
+    constexpr int wide_min = 512;
     const bool wide = (NP % 128 == 0) && ((int64_t)B * strips * (NP / 128) >= wide_min);
     const size_t ws_ep = (size_t)4 * 16 * (wide ? 2 : 1) * (16 * kMaxPixTiles + 8) * 2;
     int kc_ws = kc > 2 ? 2 : kc;                               // two buffers: the stage overhead is already hidden
@@ -2253,24 +2030,6 @@ int dfine_conv_epilogue_supported(int B, int Cin, int Cout, int H, int W, int KS
     // kernel, whose per-element store reads the old value first)
     if (KS == 3) return (W % 2 == 0 && W <= 160) ? 1 : 0;
     return 0;
-}
-
-// BatchNorm sums in the store epilogue (DfineConvEpilogue, epi_bn.h): slots per channel the kernel serving this call writes
-// (0: no such epilogue for the shape).  n_x_parts > 1: the part-wise 1x1 convolution (dfine_conv1x1_seg_fwd_bf16).
-int dfine_conv_epilogue_chunks(int B, int Cin, int Cout, int H, int W, int KS, int n_x_parts) {
-    static const int on = [] { const char *e = getenv("DFINE_CONV_EPI_BN"); return e ? atoi(e) : 1; }();
-    if (!on || B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || Cin % 2 || KS != 1) return 0;
-    const int NP = (Cout + 15) / 16 * 16, KP = (Cin + 31) / 32 * 32, HW = H * W;
-    if (!conv1x1_glds_ok(Cin, KP, HW)) return 0;
-    return 2 * conv1x1_cfg(B, NP, KP, HW, n_x_parts > 1, false).total2;
-}
-
-int dfine_conv_epilogue_once(const DfineConvEpilogue *ep) {
-    if (!ep) { g_epi_set = false; return DFINE_OK; }
-    if ((ep->mode != 1 && ep->mode != 2) || !ep->part || ep->nchunk < 1) return DFINE_E_BADARG;
-    g_epi_req = *ep;
-    g_epi_set = true;
-    return DFINE_OK;
 }
 
 int dfine_conv_accum_bf16(const void *x, const void *w2, void *y, int B, int Cin, int Cout, int H, int W, int KS, void *stream) {
@@ -2458,7 +2217,7 @@ int dfine_conv1x1_seg_wgrad_bf16(const void *const *x_parts, const int *x_channe
 
 static void linear_wgrad_plan(int M, int N, int K, int *splits, int *rows) {
     const int pairs = ((N + 63) / 64) * ((K + 63) / 64);
-    static const int wgs = [] { const char *e = getenv("DFINE_LINEAR_WGRAD_WGS"); const int v = e ? atoi(e) : 256; return v < 16 ? 16 : v; }();     // (1024: +0.25 ms per step - 4x the partial sums)
+    constexpr int wgs = 256;     // (1024: +0.25 ms per step - 4x the partial sums)
     int sp = wgs / pairs;
     if (sp < 1) sp = 1;
     if (sp > 128) sp = 128;
@@ -2537,37 +2296,11 @@ static int wgrad1_group_target() {
     // measured (D-FINE-m step, ms median): 256 -> 33.29 / 33.41, 128 -> 33.37, 64 -> 33.51 / 33.58, 32 -> 33.91: the kernels gain more
     // from the parallelism of many splits than the step loses to their partial sums (2.7 -> 1.6 GB at 64) - the default keeps 256
     // (re-measured at the end of round 5, 29.0 ms steps: 256 -> 29.04 / 29.03, 128 -> 29.02 / 29.01, 64 -> 29.18: 128 for half the partial sums)
-    static const int t = [] { const char *e = getenv("DFINE_WGRAD1_GROUP_WGS"); const int v = e ? atoi(e) : 128; return v < 8 ? 8 : v; }();
-    return t;
-}
-
-// Tile class of a problem of the grouped launch: 64 (dfine_conv_wgrad1_group64: layers with <= 128 channels on both sides) or
-// 128 (dfine_conv_wgrad1_group).  The rows of one launch must all be of the launch's class.
-int dfine_conv_wgrad1_group_tile(int Cin, int Cout) {
-    // OFF by default: in the D-FINE-m step the 64-tile launches take the family from 3.27 to 2.92 ms of kernel time (and the deferred
-    // reduction from 0.59 to 0.54), but the step got 0.1 ms SLOWER (30.56 / 30.63 -> 30.65 .. 30.79 ms, six runs in one call): three
-    // of these small workgroups fit a CU and crowd the main stream's 1024-thread BatchNorm workgroups out of it.  DFINE_WGRAD1_T64=1.
-    static const int on = [] { const char *e = getenv("DFINE_WGRAD1_T64"); return e ? atoi(e) : 0; }();
-    return on && Cin <= 128 && Cout <= 128 ? 64 : 128;
+    return 128;
 }
 
 static void wgrad1_group_plan(int B, int Cin, int Cout, int HW, int *splits, int *cps) {
-    if (dfine_conv_wgrad1_group_tile(Cin, Cout) == 128) { wgrad1_plan(B, Cin, Cout, HW, splits, cps, wgrad1_group_target()); return; }
-    static const int target = [] { const char *e = getenv("DFINE_WGRAD1_T64_WGS"); const int v = e ? atoi(e) : 256; return v < 8 ? 8 : v; }();
-    const int cpi = (HW + kW2Px - 1) / kW2Px, total = B * cpi;
-    const int pairs = ((Cout + 63) / 64) * ((Cin + 63) / 64);
-    int sp = target / pairs;
-    if (sp < 1) sp = 1;
-    if (sp > total) sp = total;
-    int c = (total + sp - 1) / sp;
-    int spl = (total + c - 1) / c;
-    if (spl >= 8 && (spl & 7)) {                                            // whole splits per XCD
-        for (int u = c; u <= c * 4 / 3 + 1; ++u) {
-            const int t = (total + u - 1) / u;
-            if (t >= 8 && (t & 7) == 0) { c = u; spl = t; break; }
-        }
-    }
-    *splits = spl; *cps = c;
+    wgrad1_plan(B, Cin, Cout, HW, splits, cps, wgrad1_group_target());
 }
 
 // Splits (partial-sum slabs) and workspace floats of a problem of the GROUPED 1x1 weight-gradient launch.
@@ -2584,7 +2317,7 @@ int64_t dfine_conv_wgrad1_group_ws_floats(int B, int Cin, int Cout, int HW) {
 int dfine_conv_wgrad1_group_row(const void *x, const void *dy, float *ws, int B, int Cin, int Cout, int HW, int64_t *row) {
     if (!x || !dy || !ws || !row || B < 1 || Cin < 1 || Cout < 1 || !wgrad1_v2(1, HW)) return DFINE_E_BADARG;
     int splits, cps;
-    const int tile = dfine_conv_wgrad1_group_tile(Cin, Cout);
+    constexpr int tile = 128;
     wgrad1_group_plan(B, Cin, Cout, HW, &splits, &cps);
     row[0] = (int64_t)x; row[1] = (int64_t)dy; row[2] = (int64_t)ws; row[3] = B; row[4] = Cin; row[5] = Cout; row[6] = HW;
     row[7] = (int64_t)splits | ((int64_t)cps << 32);
@@ -2607,14 +2340,6 @@ int dfine_conv_wgrad1_group(const void *table, int n_problems, int max_blocks, v
 }
 
 // table: device int64 [n_problems][8] (rows from dfine_linear_wgrad_group_row); max_blocks = the largest row's workgroup count.
-int dfine_conv_wgrad1_group64(const void *table, int n_problems, int max_blocks, void *stream) {
-    if (n_problems == 0) return DFINE_OK;
-    if (!table || n_problems < 0 || max_blocks < 1) return DFINE_E_BADARG;
-    hipLaunchKernelGGL(conv_wgrad1_group64_kernel, dim3(max_blocks, n_problems), dim3(kW2Threads), (size_t)kW2Ring * 2 * 64 * 128,
-                       (hipStream_t)stream, (const int64_t *)table);
-    return check_launch();
-}
-
 int dfine_linear_wgrad_group(const void *table, int n_problems, int max_blocks, void *stream) {
     if (n_problems == 0) return DFINE_OK;
     if (!table || n_problems < 0 || max_blocks < 1) return DFINE_E_BADARG;

@@ -898,7 +898,7 @@ int dfine_dwconv_fwd(const void *x, const float *w, void *y, int dtype, int B, i
     if (OH < 1 || OW < 1) return DFINE_E_BADARG;
     hipStream_t st0 = (hipStream_t)stream;
     int vw = 0;
-    static const int stream_env = [] { const char *e = getenv("DFINE_DW_STREAM"); return e ? atoi(e) : 1; }();
+    constexpr int stream_env = 1;
     if (stream_env && dw_vec_ok(dtype, H, W, K, stride, pad, &vw) && W / vw <= 64) {
         const int nv = W / vw, ppw = 64 / nv, planes = B * C;
         const int waves = (planes + ppw - 1) / ppw;
@@ -985,7 +985,7 @@ int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, fl
     hipStream_t st = (hipStream_t)stream;
     int vw = 0;
     const bool vec = dw_vec_ok(dtype, H, W, K, stride, pad, &vw);
-    static const int stream_env = [] { const char *e = getenv("DFINE_DW_STREAM"); return e ? atoi(e) : 1; }();
+    constexpr int stream_env = 1;
     if (dx && vec && stream_env && W / vw <= 64) {
         const int nv = W / vw, ppw = 64 / nv, planes = B * C;
         const int waves = (planes + ppw - 1) / ppw;

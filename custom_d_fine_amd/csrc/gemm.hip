@@ -417,7 +417,7 @@ int dfine_linear_act_fwd(const void *x, const void *w, const float *bias, void *
     if (!x || !w || !y || M < 0 || N < 0 || K < 1 || ldx < K || ldw < K || ldy < N || act < 0 || act > 3) return DFINE_E_BADARG;
     const int nt_n = (N + kGBN - 1) / kGBN;
     hipStream_t st = (hipStream_t)stream;
-    static const int ring_env = [] { const char *e = getenv("DFINE_LINEAR_RING"); return e ? atoi(e) : -1; }();   // 0 off, 1/2/4 forces MT
+    constexpr int ring_env = -1;   // 0 off, 1/2/4 forces MT
     if (ring_env != 0 && (K % kGBK) == 0 && (ldx & 7) == 0 && (ldw & 7) == 0 && (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0) {
         // m tile: 256 rows once that still gives >= 4 rounds of workgroups (the 268 800-row encoder streams), 64 rows when
         // 128-row tiles would leave CUs idle, 128 otherwise

@@ -292,7 +292,7 @@ static int gemm_f32_launch(int akm, int bkm, const float *A, const float *B, con
     const int ch = splits > 1 ? chunk : K;
     hipStream_t st = (hipStream_t)stream;
     // large products: 128 x 128 tiles when they still make at least ~one workgroup per CU (DFINE_GEMM_F32_BIG=0: never)
-    static const int big_env = [] { const char *e = getenv("DFINE_GEMM_F32_BIG"); return e ? atoi(e) : 1; }();
+    constexpr int big_env = 1;
     const int bt_n = (N + kGbBN - 1) / kGbBN, bt_m = (M + kGbBM - 1) / kGbBM;
     if (big_env && M >= 96 && N >= 96 && (int64_t)bt_n * bt_m * batch * splits >= 224) {
         const int ntiles = bt_n * bt_m, per = (ntiles + 7) / 8;

@@ -455,7 +455,7 @@ static int head_losses_impl(
     if (n >= ((int64_t)1 << 31) - 2048 * kLT) return DFINE_E_BADARG;      // the kernels index the logits with 32 bits
     // (every block ends with ONE atomic onto the same loss scalar, and same-address atomics retire one after the other at L2:
     // 2 048 blocks made that tail the longest part of the launch)
-    static const int vb_cap = [] { const char *e = getenv("DFINE_VFL_BLOCKS"); return e ? atoi(e) : 512; }();
+    constexpr int vb_cap = 512;
     const int vb = (int)((n + kLT - 1) / kLT < vb_cap ? (n + kLT - 1) / kLT : vb_cap);
     if (corners && teacher_corners && (!teacher_logits || !grad_corners_ddf)) return DFINE_E_BADARG;
     const int nb_ddf = corners && teacher_corners ? (B * Q * 4 + kLT - 1) / kLT : 0;

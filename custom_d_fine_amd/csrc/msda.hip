@@ -735,7 +735,7 @@ static int launch_fwd(const void *value, const float *loc, const float *weight, 
                       int D, int Lq, const MsdaLevels &lv, float offset_scale, hipStream_t st) {
     const int total_q = B * Lq;
     if (total_q == 0) return DFINE_OK;
-    static const int fwd_variant = [] { const char *e = getenv("DFINE_MSDA_FWD"); return e ? atoi(e) : 1; }();
+    constexpr int fwd_variant = 1;
     if (fwd_variant == 1 && sizeof(T) == 2 && (D == 32 || D == 16 || D == 64)) {
 #define DFINE_FWD8(DD)                                                                         \
     {                                                                                          \
@@ -773,9 +773,9 @@ static int launch_bwd(const void *value, const float *loc, const float *weight, 
                       float offset_scale, hipStream_t st, int acc_mode = 0, float *fx_state = nullptr, float hit_bound = 1.f) {
     const int total_q = B * Lq;
     if (total_q == 0) return DFINE_OK;
-    static const int variant = [] { const char *e = getenv("DFINE_MSDA_BWD"); return e ? atoi(e) : 1; }();
+    constexpr int variant = 1;
     // DFINE_MSDA_MERGE=0: every contribution as its own atomic (A/B switch of the in-register merge, see the kernels)
-    static const int merge_env = [] { const char *e = getenv("DFINE_MSDA_MERGE"); return e ? atoi(e) : 1; }();
+    constexpr int merge_env = 1;
     const bool merge = merge_env && (int64_t)B * L < (int64_t)1 << 31;
     if (acc_mode == 2 || acc_mode == 3) {
         if (!(D == 32 || D == 16 || D == 64)) return DFINE_E_BADARG;

@@ -995,7 +995,7 @@ static int stem_conv_impl(const void *x, const void *x2, int ca, const float *wp
     const uint16_t *xs2 = (const uint16_t *)x2;
     uint16_t *ys = (uint16_t *)y;
     // stride-1 layers of a single input tensor: matrix-core kernel (DFINE_STEM_MFMA=0: the direct kernel)
-    static const int mfma_env = [] { const char *e = getenv("DFINE_STEM_MFMA"); return e ? atoi(e) : 1; }();
+    constexpr int mfma_env = 1;
 #define STEM_MFMA_CASE(CI, CO, K)                                                                                                   \
     if (mfma_env && !xs2 && stride == 1 && Cin == CI && Cout == CO && KS == K) {                                                       \
         constexpr int cp = (CI + 7) / 8 * 8;                                                                                        \
@@ -1017,7 +1017,7 @@ static int stem_conv_impl(const void *x, const void *x2, int ca, const float *wp
     STEM_MFMA_CASE(32, 16, 2) STEM_MFMA_CASE(16, 32, 2)
 #undef STEM_MFMA_CASE
     // 3x3 / stride 2 / pad 1 on whole 16-byte vectors (DFINE_STEM_VEC=0: the direct kernel)
-    static const int vec_env = [] { const char *e = getenv("DFINE_STEM_VEC"); return e ? atoi(e) : 1; }();
+    constexpr int vec_env = 1;
 #define STEM_VEC_CASE(CI, CO)                                                                                                       \
     if (vec_env && KS == 3 && stride == 2 && pad == 1 && Cin == CI && Cout == CO && W % 8 == 0 && Wo % 4 == 0 && W == 2 * Wo && H == 2 * Ho) { \
         dim3 gridv((Ho * (Wo / 4) + kStemThreads - 1) / kStemThreads, B);                                                           \
@@ -1091,7 +1091,7 @@ static bool stem_wgrad_kx_ok(int KS, int stride, int pad) {
 }
 
 static int stem_wgrad_pg() {
-    static const int pg = [] { const char *e = getenv("DFINE_STEM_WGRAD_PG"); const int v = e ? atoi(e) : 3; return v == 2 ? 2 : 3; }();
+    constexpr int pg = 3;
     return pg;
 }
 

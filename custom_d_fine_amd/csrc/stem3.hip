@@ -328,7 +328,7 @@ static int stem3_fwd_launch(const uint16_t *xa, const uint16_t *xb, const float 
     S3FwdArgs a;
     a.xa = xa; a.xb = xb; a.wp = wp; a.y = y; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
     a.cblocks = Wo / kS3OutCols;
-    static const int wgs = [] { const char *e = getenv("DFINE_STEM3_WGS"); return e ? atoi(e) : 512; }();
+    constexpr int wgs = 512;
     int bands = (wgs + B * a.cblocks - 1) / (B * a.cblocks);           // ~512 workgroups: two per CU
     if (bands > (Ho + 7) / 8) bands = (Ho + 7) / 8;                    // at least 8 output rows each (one halo row pair per band)
     if (bands < 1) bands = 1;
@@ -360,7 +360,7 @@ template <int CIN, int COUT>
 static int stem3_bwd_launch(const uint16_t *dy, const float *wq, uint16_t *dxa, uint16_t *dxb, int B, int Ho, int Wo, hipStream_t st) {
     S3BwdArgs a;
     a.dy = dy; a.wq = wq; a.dxa = dxa; a.dxb = dxb; a.Ho = Ho; a.Wo = Wo;
-    static const int wgs = [] { const char *e = getenv("DFINE_STEM3_WGS"); return e ? atoi(e) : 512; }();
+    constexpr int wgs = 512;
     int bands = (wgs + B - 1) / B;
     if (bands > (Ho + 7) / 8) bands = (Ho + 7) / 8;
     if (bands < 1) bands = 1;

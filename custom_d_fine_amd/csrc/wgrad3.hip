@@ -66,7 +66,7 @@ __device__ __forceinline__ void w3_wait_vmcnt(int n) {       // s_waitcnt takes 
 struct W3Frag { uint4 ce, ri, x0, x1, x2; };
 
 // PF units of rows in flight (loads issued PF units ahead of their MFMAs); kMaxP: bound of the LDS-DMA pieces a wave issues per unit.
-// OPT (bit set; DFINE_W3_OPT picks among the built ones for A/B runs): 1 = partial sums leave through an LDS image of the tile with
+// OPT (bit set; the library builds 5): 1 = partial sums leave through an LDS image of the tile with
 // 16-byte stores (else straight from the accumulators: 4 bytes per lane at a 36-byte stride), 4 = early / late issue of the next
 // unit's pieces by the two waves of a SIMD (see the loop).  Measured on the six 3x3 layer shapes of D-FINE-m (sum per step,
 // stand-alone): OPT 0 1.477 ms, 1 1.417, 5 1.324 (first-generation kernel: 1.78).  Tried and dropped: requesting the next K step's
@@ -316,7 +316,7 @@ static int w3_env(const char *name, int dflt) {
 
 // The row-streaming kernel takes W % 8 == 0 (16-byte chunks), W <= 160, H >= 1.  Returns false for anything else.
 bool wgrad3_rows_plan(int B, int Cin, int Cout, int H, int W, W3Plan *p) {
-    static const int env = w3_env("DFINE_WGRAD3_ROWS", 1), pf_env = w3_env("DFINE_W3_PF", 0), blocks_env = w3_env("DFINE_W3_BLOCKS", 0);
+    static const int env = w3_env("DFINE_WGRAD3_ROWS", 1);
     if (!env || W % 8 || W < 8 || W > 160 || H < 1 || B < 1) return false;
     const int w8 = W / 8;
     const int cpr = (w8 & 1) ? w8 + 2 : w8 + 1;        // odd; for even W / 8 the right pad is the next row image's left pad
@@ -337,7 +337,6 @@ bool wgrad3_rows_plan(int B, int Cin, int Cout, int H, int W, W3Plan *p) {
             if (w3_ring_bytes(64, 1, pf, cpr) > kLds) return false;
         }
     }
-    if (pf_env > 0 && pf_env < pf) pf = pf_env;
     const int wk = cfg == 0 ? 2 : 1, nw = cfg == 0 ? 8 : 4;
     size_t lds = w3_ring_bytes(T, wk, pf, cpr);
     if (lds < kOut) lds = kOut;
@@ -352,7 +351,7 @@ bool wgrad3_rows_plan(int B, int Cin, int Cout, int H, int W, W3Plan *p) {
     if (budget < 24000000) budget = 24000000;
     int cap = (int)(budget / bytes_per_split);
     if (cap < B) cap = B;
-    const int target = blocks_env > 0 ? blocks_env : (cfg == 0 ? 256 : 512);
+    const int target = cfg == 0 ? 256 : 512;
     int spi = (target / ntiles + B - 1) / B;
     if (spi < 1) spi = 1;
     if (spi * B > cap) spi = cap / B;
@@ -397,13 +396,7 @@ int wgrad3_rows_launch(const void *x, const void *dy, float *part, int B, int Ci
     a.ablate = abl;
     a.lds_bytes = (int)p.lds;
     a.NP16 = (Cout + 15) / 16 * 16; a.CP16 = (Cin + 15) / 16 * 16; a.ntiles = p.ntiles; a.nsplits = p.nsplits;
-    static const int opt = w3_env("DFINE_W3_OPT", 5);
-#define W3_GO(TNW, TCW, WK, WS, PF, MAXP)                                                   \
-    switch (opt) {                                                                          \
-        case 0: return w3_launch<TNW, TCW, WK, WS, PF, MAXP, 0>(a, p, st);                  \
-        case 1: return w3_launch<TNW, TCW, WK, WS, PF, MAXP, 1>(a, p, st);                  \
-        default: return w3_launch<TNW, TCW, WK, WS, PF, MAXP, 5>(a, p, st);                 \
-    }
+#define W3_GO(TNW, TCW, WK, WS, PF, MAXP) return w3_launch<TNW, TCW, WK, WS, PF, MAXP, 5>(a, p, st);
     if (p.cfg == 0) {
         if (p.pf == 3) W3_GO(2, 2, 2, 1, 3, 8)
         if (p.pf == 2) W3_GO(2, 2, 2, 1, 2, 8)

@@ -519,13 +519,12 @@ class DFINETransformer(nn.Module):
             self._anchor_cache[key] = self._generate_anchors(spatial_shapes, device=device)
         return self._anchor_cache[key]
 
-    def _invalid_rows(self, valid):
-        """Indices of the anchors outside (eps, 1 - eps) (ref dfine_decoder.py:803-826) - looked up once per anchor set."""
+    def _invalid_rows(self, spatial_shapes, valid):
+        """Indices of the anchors outside (eps, 1 - eps) (ref dfine_decoder.py:803-826): made once per anchor set and kept next to
+        it, keyed like `_anchor_cache` (the lookup is a host sync; the registered `valid_mask` buffer of eval mode has its own entry)."""
         cache = self.__dict__.setdefault("_invalid_cache", {})
-        key = (valid.data_ptr(), tuple(valid.shape))
+        key = (tuple(map(tuple, spatial_shapes)), str(valid.device), bool(self.training or self.eval_spatial_size is None))
         if key not in cache:
-            if len(cache) > 16:
-                cache.clear()
             cache[key] = (~valid.reshape(-1).bool()).nonzero().reshape(-1)
         return cache[key]
 
@@ -555,7 +554,7 @@ class DFINETransformer(nn.Module):
                 # every op of the scoring pass is row-wise and a masked row is all zeros: score the memory as it stands and give
                 # the few masked rows (the border anchors of the finest level) the score of a zero row afterwards - the same
                 # numbers as scoring keep * memory without the full-size multiply (86 us per step for D-FINE-m)
-                inv = self._invalid_rows(valid)
+                inv = self._invalid_rows(spatial_shapes, valid)
                 scores_all = self._enc_scores(self._enc_output(memory))
                 if inv.numel():
                     zero_score = self._enc_scores(self._enc_output(memory.new_zeros(1, 1, memory.shape[-1])))
@@ -567,12 +566,13 @@ class DFINETransformer(nn.Module):
 
             # one autograd node hands out the selected rows AND the memory for the decoder's value path (forward() picks it up):
             # its backward adds the rows' gradient onto the value path's in place instead of two full-size tensors being added
-            self.__dict__["_memory_for_value"], rows = kernels.take_rows_and_pass(memory, ind)
+            value_memory, rows = kernels.take_rows_and_pass(memory, ind)
             top_mem = self._enc_output(rows * take(keep.expand(memory.shape[0], -1, -1)))
             top_logits = self._enc_scores(top_mem)
             top_anchor = take(anchors)
         else:
             memory = keep * memory
+            value_memory = None
             out_mem = self._enc_output(memory)
             enc_logits = self._enc_scores(out_mem)
             top_mem, top_logits, top_anchor = self._select_topk(out_mem, enc_logits, anchors,
@@ -591,7 +591,8 @@ class DFINETransformer(nn.Module):
         if denoising_bbox_unact is not None:
             box_unact = torch.concat([denoising_bbox_unact, box_unact], dim=1)
             content = torch.concat([denoising_logits, content], dim=1)
-        return content, box_unact, enc_boxes, enc_logits_list
+        # (value_memory: the memory for the decoder's value path, through the query selection's autograd node - None: the caller's)
+        return content, box_unact, enc_boxes, enc_logits_list, value_memory
 
     def _topk_indices(self, outputs_logits, topk: int):
         if self.query_select_method == "default":
@@ -643,9 +644,10 @@ class DFINETransformer(nn.Module):
                 num_denoising=self.num_denoising, label_noise_ratio=self.label_noise_ratio,
                 box_noise_scale=1.0)  # the reference hard-codes 1.0 here (dfine_decoder.py:948)
 
-        content, ref_unact, enc_boxes, enc_logits = self._get_decoder_input(
+        content, ref_unact, enc_boxes, enc_logits, value_memory = self._get_decoder_input(
             memory, spatial_shapes, dn_logits, dn_boxes)
-        memory = self.__dict__.pop("_memory_for_value", memory)      # (training: through the query selection's autograd node)
+        if value_memory is not None:
+            memory = value_memory
 
         out_bboxes, out_logits, out_corners, out_refs, pre_bboxes, pre_logits, hs = self.decoder(
             content, ref_unact, memory, spatial_shapes, self.dec_bbox_head, self.dec_score_head,

@@ -47,11 +47,10 @@ class ConvBNAct(nn.Module):
         self.act = nn.ReLU() if use_act else nn.Identity()
         self.lab = LearnableAffineBlock() if (use_act and use_lab) else nn.Identity()
 
-    def forward(self, x, pad_br=False, fanin=None, fans=None, fanout=None, bnsrc=None, residual=None):
+    def forward(self, x, pad_br=False, fanin=None, fans=None, residual=None):
         """pad_br: the input stands for F.pad(x, (0, 1, 0, 1)) (StemBlock); the pad is applied inside.
         residual: added to the unit's output (HG_Block's residual connection: in the BatchNorm apply pass where the unit is fused).
-        fanin / fans: gradient hand-offs of HG_Block (kernels.GradFanIn); fanout / bnsrc: hand-offs of the BatchNorm-backward
-        sums between this unit and the consumer of its output / the producer of its input (kernels.BNLink)."""
+        fanin / fans: gradient hand-offs of HG_Block (kernels.GradFanIn)."""
         if isinstance(self.conv, nn.Sequential):
             x = self.conv[0](torch.cat(list(x), dim=1) if isinstance(x, (list, tuple)) else x)
             conv = self.conv[1]
@@ -59,7 +58,7 @@ class ConvBNAct(nn.Module):
             conv = self.conv
         lab = self.lab if isinstance(self.lab, LearnableAffineBlock) else None
         return kernels.conv_bn_act(x, conv, self.bn, "relu" if self.use_act else None, lab, pad_br=pad_br, fanin=fanin, fans=fans,
-                                   fanout=fanout, bnsrc=bnsrc, residual=residual)
+                                   residual=residual)
 
 
 class LightConvBNAct(nn.Module):
@@ -71,8 +70,8 @@ class LightConvBNAct(nn.Module):
         self.conv2 = ConvBNAct(out_chs, out_chs, kernel_size, groups=out_chs, use_act=True,
                                use_lab=use_lab)
 
-    def forward(self, x, fanin=None, fanout=None):
-        return self.conv2(self.conv1(x, fanin=fanin), fanout=fanout)
+    def forward(self, x, fanin=None):
+        return self.conv2(self.conv1(x, fanin=fanin))
 
 
 class StemBlock(nn.Module):
@@ -93,7 +92,7 @@ class StemBlock(nn.Module):
         x = self.stem1(x)
         # x has two consumers.  The pool is created first, so its backward runs last: stem2a's data gradient is parked and the
         # pool's backward adds its own onto it (kernels.GradFanIn) - no element-wise add of two [B, mid, H/2, W/2] maps
-        fan = kernels.GradFanIn() if kernels._env("DFINE_STEM_FANIN", "1") == "1" else None
+        fan = kernels.GradFanIn()
         pooled = kernels.stem_pool(x, fanin=fan)
         branch = self.stem2b(self.stem2a(kernels.park_grad(x, fan, owned=True), pad_br=True), pad_br=True)
         # the concatenation is never built on the GPU: stem3 reads both tensors in place (kernels._StemConv2)
@@ -146,21 +145,18 @@ class HG_Block(nn.Module):
         if kernels.grad_fanin_enabled(x):
             # every map but the last has two consumers (the next layer and the aggregation): their data gradients meet in
             # the next layer's convolution epilogue instead of an element-wise add (kernels.GradFanIn)
-            # ... and that epilogue then holds the complete gradient of the map: it also adds up the sums the BatchNorm
-            # backward of the layer that produced the map starts with (kernels.BNLink; fans[j + 1] = the map layer j writes)
             fans = [kernels.GradFanIn() for _ in self.layers]
-            for j, (layer, fan) in enumerate(zip(self.layers, fans)):
-                feats.append(layer(feats[-1], fanin=fan, fanout=fans[j + 1] if j + 1 < len(fans) else None))
+            for layer, fan in zip(self.layers, fans):
+                feats.append(layer(feats[-1], fanin=fan))
             if isinstance(self.aggregation[1], ConvBNAct):       # squeeze -> excitation: one consumer
-                link = kernels.BNLink()
-                mid = self.aggregation[0](feats, fans=fans + [None], fanout=link)
+                mid = self.aggregation[0](feats, fans=fans + [None])
                 res = None
                 if self.residual and isinstance(self.drop_path, nn.Identity):
                     # the residual connection rides in the excitation unit's BatchNorm apply pass; its gradient (the block
                     # output's) is parked for the aggregation's and layer 0's data gradients to add onto (captured segments).
                     # (made AFTER the squeeze unit: the parking node must run its backward before that unit's)
                     res = kernels.park_grad(x, fans[0]) if kernels.fanin_outer_enabled() else x
-                y = self.aggregation[1](mid, bnsrc=link, residual=res)
+                y = self.aggregation[1](mid, residual=res)
                 if res is not None:
                     return y
             else:

@@ -158,6 +158,9 @@ class GraphedSegment:
     legacy stream - a crash on this stack (tools/graph_probe6.py).  `torch.cuda.make_graphed_callables` segfaults here even
     for a two-layer MLP (tools/graph_probe2.py)."""
 
+    GROUP_AT = 8      # registered 1x1 / linear weight gradients per grouped launch inside a captured backward
+    CHUNK = 5         # side-stream launches per (main, side) graph pair (2 / 3 / 8: +0.2 / +0.2 / 0 ms per step)
+
     def __init__(self, module, sample_inputs, amp_dtype=None, fused=None, warmup=1, input_grads=False, clone_inputs=True,
                  defer_backward=False, cast_inputs=False):
         """cast_inputs: floating-point inputs are KEPT in amp_dtype - the per-replay copy into the static input is the cast the
@@ -183,7 +186,6 @@ class GraphedSegment:
             self.static_in = [t.to(amp_dtype) if t.dtype == torch.float32 else t for t in self.static_in]
         self.static_gin = None
         self._keep, self._pinned = [], hip.CaptureArena()
-        self.preflush = os.environ.get("DFINE_GRAPH_PREFLUSH", "1") == "1"
         self.side = os.environ.get("DFINE_GRAPH_SIDE", "dual")           # "dual" | "fork" | "0"
         if not hip.WGRAD_STREAM:
             self.side = "0"
@@ -213,7 +215,7 @@ class GraphedSegment:
             with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None, cache_enabled=False):
                 return tuple(torch.func.functional_call(module, alias_map, tuple(self.static_in)))
 
-        def deliver(grads, reduce=True):
+        def deliver(grads):
             """Segment gradients -> flat gradient buffer (recorded at the end of the backward capture)."""
             hip.linear_wgrad_flush()                    # grouped weight-gradient launches of what is registered; joins the side stream
             real = [(g, fused.grad_offset(i)) for g, i in zip(grads, self.param_index) if g is not None]
@@ -222,8 +224,7 @@ class GraphedSegment:
                     raise RuntimeError("graphed segment: parameter gradients are expected in fp32")
             if real:
                 self._keep.append(hip.multi_copy_f32([g.contiguous() for g, _ in real], [o for _, o in real], fused.flat_grad, add=True))
-            if reduce:
-                fused._flush_deferred()                 # the deferred partial sums of the segment, reduced into flat_grad
+            fused._flush_deferred()                     # the deferred partial sums of the segment, reduced into flat_grad
 
         if fused._deferred or hip._CW_PENDING or hip._LW_PENDING:
             raise RuntimeError("GraphedSegment must be built between steps (weight gradients of a running backward are pending)")
@@ -236,16 +237,12 @@ class GraphedSegment:
         snap_mod = [(b, b.clone()) for b in module.buffers() if fused.flat_buf is None or not b.dtype.is_floating_point]
         snap_bn = dict(kernels._BN_PENDING)
         flags = (kernels._CAPTURE_POSSIBLE, kernels._CAPTURE_SHADOWS, hip.CAPTURE_SIDE, arch_utils.CAPTURE_KEEP)
-        self.bwd_pairs = self.bwd_reduce_graph = None
+        self.bwd_pairs = None
         group_at = hip._SIDE_GROUP_AT
         # grouped weight-gradient launches every few registrations: a replay has no host cost per launch (the eager step
         # groups 32 to save ~25 us of host time each), and small groups keep the side stream's work evenly spread
-        hip._SIDE_GROUP_AT = int(os.environ.get("DFINE_GRAPH_GROUP_AT", "8"))
-        # (DFINE_GRAPH_EARLY_REDUCE=n: the partial sums of every n registered weight gradients reduced on the side stream while
-        # backward goes on - measured 33.17 / 33.24 against 33.12 / 33.27 ms per step without: the side stream is the one that
-        # finishes last, moving the reduction there gains nothing; off)
-        early_at = fused._early_at
-        fused._early_at = int(os.environ.get("DFINE_GRAPH_EARLY_REDUCE", "0")) or (1 << 30)
+        # (4 / 16 / 24 / 32 problems instead of 8: +0.05 / -0.05 / -0.08 / 0 ms per step, roofline fraction 0.122-0.125 against 0.127)
+        hip._SIDE_GROUP_AT = self.GROUP_AT
         try:
             # ---- eager warm-up on the capture stream: fills the shadow registries for the aliases, sizes the workspaces
             with torch.cuda.stream(cap_stream):
@@ -281,16 +278,14 @@ class GraphedSegment:
         finally:
             kernels._CAPTURE_POSSIBLE, kernels._CAPTURE_SHADOWS, hip.CAPTURE_SIDE, arch_utils.CAPTURE_KEEP = flags
             hip._SIDE_GROUP_AT = group_at
-            fused._early_at = early_at
             fused.accumulating = was_accumulating
 
         def capture_backward(static_gout=None):
             """Second half of the construction: the backward pass as a chain of (main, side) graph pairs + the delivery graph.
             static_gout: the tensors the output gradients arrive in (default: own zero-filled buffers)."""
             flags_b = (kernels._CAPTURE_POSSIBLE, kernels._CAPTURE_SHADOWS, hip.CAPTURE_SIDE, arch_utils.CAPTURE_KEEP)
-            group_at_b, early_at_b, was_acc = hip._SIDE_GROUP_AT, fused._early_at, fused.accumulating
-            hip._SIDE_GROUP_AT = int(os.environ.get("DFINE_GRAPH_GROUP_AT", "8"))
-            fused._early_at = int(os.environ.get("DFINE_GRAPH_EARLY_REDUCE", "0")) or (1 << 30)
+            group_at_b, was_acc = hip._SIDE_GROUP_AT, fused.accumulating
+            hip._SIDE_GROUP_AT = self.GROUP_AT
             fused.accumulating = True
             if fused._deferred or hip._CW_PENDING or hip._LW_PENDING:
                 raise RuntimeError("GraphedSegment.capture_backward: weight gradients of another backward are pending")
@@ -305,8 +300,7 @@ class GraphedSegment:
                 torch.cuda.synchronize(dev)
                 if self.side == "dual":
                     # the backward pass proper as a chain of (main, side) graph pairs, then the delivery of the gradients as one graph
-                    dual = _DualCapture(cap_stream, hip.side_stream(dev), self.fwd_graph.pool(),
-                                        os.environ.get("DFINE_GRAPH_CHUNK", "5"))
+                    dual = _DualCapture(cap_stream, hip.side_stream(dev), self.fwd_graph.pool(), self.CHUNK)
                     torch.cuda.synchronize(dev)
                     hip.CAPTURE_DUAL = dual
                     try:
@@ -320,21 +314,8 @@ class GraphedSegment:
                     self.bwd_pairs = dual.pairs
                     self._keep.append(list(hip._SIDE_LIVE))       # inputs of the side graphs: referenced until every capture is done
                     hip._SIDE_LIVE.clear()
-                    # The split reduction of the deferred partial sums (2 GB read per D-FINE-m step, ~0.36 ms) does not need the
-                    # LAST side graph when that one holds direct weight gradients only (the stem's: hip.backward_tail_begins closed
-                    # the pair in front of them) and nothing is left to launch: it gets a graph of its own, replayed on the main
-                    # stream BESIDE the last side graph instead of behind it.  DFINE_GRAPH_TAIL_REDUCE=1; OFF by default: 28.43 -> 28.34 ms
-                    # per step, but the reduction (2 GB of reads) and the stem's weight gradients are both HBM-bound and run longer
-                    # side by side (stem family 1.29 -> 1.58 ms: roofline fraction of the timed mode 0.125 -> 0.1225).
-                    early = (os.environ.get("DFINE_GRAPH_TAIL_REDUCE", "0") == "1" and len(dual.pairs) > 1
-                             and dual.pairs[-1][1] is not None and not dual.deferred[-1]
-                             and not hip._CW_PENDING and not hip._LW_PENDING and bool(fused._deferred))
-                    if early:
-                        self.bwd_reduce_graph = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(self.bwd_reduce_graph, pool=self.fwd_graph.pool(), stream=cap_stream, capture_error_mode="relaxed"):
-                            fused._flush_deferred()
                     with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(), stream=cap_stream, capture_error_mode="relaxed"):
-                        deliver(grads[:len(aliases)], reduce=not early)
+                        deliver(grads[:len(aliases)])
                 else:
                     with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(), stream=cap_stream, capture_error_mode="relaxed"):
                         grads = torch.autograd.grad(self.static_out, aliases + wrt_inputs, self.static_gout, allow_unused=True)
@@ -355,7 +336,7 @@ class GraphedSegment:
             finally:
                 kernels._CAPTURE_POSSIBLE, kernels._CAPTURE_SHADOWS, hip.CAPTURE_SIDE, arch_utils.CAPTURE_KEEP = flags_b
                 hip.CAPTURE_DUAL = None
-                hip._SIDE_GROUP_AT, fused._early_at, fused.accumulating = group_at_b, early_at_b, was_acc
+                hip._SIDE_GROUP_AT, fused.accumulating = group_at_b, was_acc
             self.capture_backward = None
 
         self.capture_backward = capture_backward
@@ -394,31 +375,20 @@ class GraphedSegment:
                 f = seg.fused
                 if seg.done_before:
                     f.module_backward_done(seg.done_before)     # e.g. the decoder's buckets, whatever parameter got no gradient
-                if seg.preflush and not f.accumulating and hip.side_stream_ok():
+                if not f.accumulating and hip.side_stream_ok():
                     # what the decoder's backward has registered so far - grouped weight-gradient launches still pending, partial
                     # sums to reduce - goes to the side stream now, under the segment's backward, instead of running serially
                     # in front of the optimizer step (joined by the optimizer's gather like every side-stream launch)
                     f._flush_deferred(side=True)
                 if seg.bwd_pairs is not None:
                     cur, st = hip._stream(), hip.side_stream(seg.device)
-                    serial = os.environ.get("DFINE_GRAPH_SERIAL") == "1"        # debugging: no overlap between the two streams
-                    last = len(seg.bwd_pairs) - 1
-                    for k, (gm, gs) in enumerate(seg.bwd_pairs):
+                    for gm, gs in seg.bwd_pairs:
                         gm.replay()
                         if gs is not None:
-                            tail_reduce = k == last and seg.bwd_reduce_graph is not None and not serial
-                            if tail_reduce:
-                                hip.stream_wait(st.cuda_stream, cur)      # the earlier side graphs: all the partial sums are there
                             hip.stream_wait(cur, st.cuda_stream)
                             with torch.cuda.stream(st.stream):
                                 gs.replay()
-                            if tail_reduce:
-                                seg.bwd_reduce_graph.replay()             # ... reduced beside the last side graph
-                            if serial:
-                                hip.stream_wait(st.cuda_stream, cur)
                     hip.stream_wait(st.cuda_stream, cur)
-                    if seg.bwd_reduce_graph is not None and serial:
-                        seg.bwd_reduce_graph.replay()
                 seg.bwd_graph.replay()
                 f = seg.fused
                 if f.overlap and not f.accumulating:            # bucket bookkeeping of the overlapped all-reduce: this segment's
@@ -438,7 +408,7 @@ class GraphedSegment:
         `gc.freeze()` may have moved them to the permanent generation: an evicted segment would otherwise keep its graph
         memory pool for the life of the process."""
         self._fn = None
-        self.fwd_graph = self.bwd_graph = self.bwd_pairs = self.bwd_reduce_graph = None
+        self.fwd_graph = self.bwd_graph = self.bwd_pairs = None
         self.static_in = self.static_out = self.static_gout = self._static_grads = self.static_gin = None
         self._keep = []
         self._aliases = []
@@ -529,8 +499,7 @@ class TrainStep:
             split = os.environ.get("DFINE_GRAPH_SPLIT")
             # the images go into the static input as bf16 (the copy per step IS the stem's input cast): HGNetv2's stem is the
             # only reader and takes bf16 under autocast (kernels.conv_bn_act route 4)
-            cast_in = (self.amp_dtype == torch.bfloat16 and os.environ.get("DFINE_GRAPH_CAST_INPUT", "1") == "1"
-                       and type(model.backbone).__name__ == "HGNetv2")
+            cast_in = self.amp_dtype == torch.bfloat16 and type(model.backbone).__name__ == "HGNetv2"
             if (split == "1") if split is not None else bool(self.fused.overlap):
                 # TWO segments, encoder | backbone: the encoder's gradients are delivered to the flat buffer (and its buckets'
                 # all-reduces started, data-parallel runs) when ITS backward replay ends, i.e. under the backbone's backward -

@@ -179,10 +179,7 @@ class FusedAdamWEMA:
         self._bucket_of = index_of
         self._deferred = []          # (param index, dst offset in flat_grad, workspace tensor, workspace offset, meta)
         self._uses = {}              # param index -> deferred uses still to come in this backward
-        self.defer_wgrads = os.environ.get("DFINE_DEFER_WGRAD", "1") == "1"
-        # deferred entries that trigger an early reduction on the side stream (0 = off, the default: no gain on the device side
-        # - the tail reduction is 0.7 ms - and each early flush costs ~0.2 ms of host time in a step that is host-bound again)
-        self._early_at = int(os.environ.get("DFINE_EARLY_REDUCE", "0")) or (1 << 30)
+        self.defer_wgrads = True
         for i, p in enumerate(self._params):
             p._dfine_slot = (self, i)
 
@@ -245,11 +242,9 @@ class FusedAdamWEMA:
         """Called from a backward op instead of returning a gradient tensor for parameter `index`: `ws` holds per-split
         partial sums (layout `meta` = (splits, Cout, Cin, taps, NP16, CP16)) of the gradient of the parameter's elements
         [dst_offset, dst_offset + Cout * Cin * taps)."""
+        # (measured and dropped: an early reduction of every n registered entries on the side stream - no gain on the device, the
+        # side stream is the one that finishes last, and ~0.2 ms of host time per flush)
         self._deferred.append((index, self._grad_offsets[index] + dst_offset, ws, ws_offset, meta))
-        if len(self._deferred) >= self._early_at and self.hip.side_stream_ok():
-            # the reduction of what is registered so far runs on the side stream under the rest of backward instead of in the
-            # serial tail in front of the optimizer step
-            self._flush_deferred(side=True)
 
     def grad_offset(self, index):
         return self._grad_offsets[index]
@@ -312,16 +307,6 @@ class FusedAdamWEMA:
         fg = self.flat_grad.data_ptr()
         rows = [(ws.data_ptr() + 4 * wo, fg + 4 * off, m[0], m[1], m[2], m[3], m[4], m[5]) for _, off, ws, wo, m in take]
         from ..d_fine.arch.utils import upload
-        if os.environ.get("DFINE_DEFER_DEBUG") == "1":
-            pb = sum(m[0] * m[4] * m[5] * m[3] * 4 for *_, m in take)
-            print(f"[deferred wgrads] {len(rows)} entries, {pb / 1e6:.1f} MB of partial sums, "
-                  f"max splits {max(m[0] for *_, m in take)}", flush=True)
-            import collections
-            agg = collections.Counter()
-            for *_, m in take:
-                agg[tuple(m[:4])] += m[0] * m[4] * m[5] * m[3] * 4
-            for k, v in agg.most_common(24):
-                print(f"    (splits, Cout, Cin, taps)={k}: {v / 1e6:.1f} MB", flush=True)
         # The kernel adds one table row per blockIdx.y into its destination with a plain read-modify-write: rows that share a
         # destination (a module applied several times in one forward - query_pos_head runs once per decoder layer - or one
         # row per micro-step of a gradient-accumulation window) must not run in the same launch.  Round r holds the r-th row

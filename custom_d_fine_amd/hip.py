@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DFINE_HIP_LIB") or os.path.join(_HERE, "csrc", "libdfine_hip.so")     # (override: A/B of two builds on one box)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -46,10 +46,6 @@ _SIGNATURES = {
     "dfine_bn2_act_bwd": (c_int, [_P] * 11 + [_I, _I, _I, _I, _P]),
     "dfine_bn_act_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     "dfine_bn_residual_once": (c_int, [_P]),
-    "dfine_bn_act_fwd_part": (c_int, [_P] * 13 + [_I, _P, _I, _I, _I, _I, _F, _F, _P]),
-    "dfine_bn_act_bwd_part": (c_int, [_P] * 12 + [_I, _P, _I, _I, _I, _I, _P]),
-    "dfine_conv_epilogue_chunks": (c_int, [_I, _I, _I, _I, _I, _I, _I]),
-    "dfine_conv_epilogue_once": (c_int, [_P]),
     "dfine_head_losses": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _P, _I,
                                    _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P,
                                    _P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -102,8 +98,6 @@ _SIGNATURES = {
     "dfine_conv_wgrad1_group_ws_floats": (_L, [_I, _I, _I, _I]),
     "dfine_conv_wgrad1_group_row": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_conv_wgrad1_group": (c_int, [_P, _I, _I, _P]),
-    "dfine_conv_wgrad1_group_tile": (c_int, [_I, _I]),
-    "dfine_conv_wgrad1_group64": (c_int, [_P, _I, _I, _P]),
     "dfine_linear_act_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_multi_cast_bf16_t": (c_int, [_P, _I, _P]),
     "dfine_act_fwd_bf16": (c_int, [_P, _P, _L, _I, _P]),
@@ -397,7 +391,7 @@ def msda_fused_forward(value, ref, offsets, logits, shapes, points, offset_scale
 # the atomic dwords of f32), 3 = int32 fixed point in 64-bit integer atomics (exact, order-independent), 0 = f32 atomics.
 # Default (-1): 2 for a bf16 model (the result is rounded to bf16 anyway), 0 for fp32 math (the fixed-point form resolves
 # ~1e-5 of max |grad_out| under its worst-case overflow bound: fine for training, coarser than the f32 atomics' 1e-7).
-MSDA_ACC_MODE = int(os.environ.get("DFINE_MSDA_ACC", "-1"))
+MSDA_ACC_MODE = -1       # (tests/test_msda_gpu.py, tests/test_bf16_anchor_gpu.py and tools/msda_acc_bench.py set it)
 
 
 def msda_grad_value_buffer(value, uses=1):
@@ -599,27 +593,15 @@ def bn_residual_supported(x):
 
 
 def bn_act_forward(x, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, training,
-                   momentum, eps, part=None, residual=None):
+                   momentum, eps, residual=None):
     """x [B, C, H, W] contiguous.  Returns (y, saved) where saved feeds bn_act_backward.
     (133 calls per train step: pointers of the four `stats` rows are computed, not sliced, and the HIP-event timing
-    wrapper is skipped unless a bench asked for it.)
-    part: [nchunk, C, 2] partial (sum, sum of squares) of x from the producing convolution's epilogue (arm_conv_stats) -
-    training mode only; the statistics pass over x is skipped."""
+    wrapper is skipped unless a bench asked for it.)"""
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // max(B * C, 1)
     dev = x.device
     y = torch.empty_like(x)
     stats = torch.empty(4, C, device=dev, dtype=torch.float32)     # mean, invstd, scale, shift
-    if part is not None:
-        sp, row = stats.data_ptr(), 4 * C
-        ws = _bn_workspace(dev, 4 * 8192 + 2 * C)
-        status = _lib.dfine_bn_act_fwd_part(x.data_ptr(), y.data_ptr(), _ptr(gamma), _ptr(beta), _ptr(running_mean),
-                                            _ptr(running_var), _ptr(lab_scale), _ptr(lab_bias), sp, sp + row, sp + 2 * row,
-                                            sp + 3 * row, part.data_ptr(), part.shape[0], ws.data_ptr(), B, C, HW, _ACT[act],
-                                            float(momentum), float(eps), _stream())
-        if status != 0:
-            _check(status, "dfine_bn_act_fwd_part")
-        return y, stats
     ws = _bn_workspace(dev, _bn_ws_need(B, C, HW))
     sp = stats.data_ptr()
     row = 4 * C
@@ -632,50 +614,6 @@ def bn_act_forward(x, gamma, beta, running_mean, running_var, lab_scale, lab_bia
     if status != 0:
         _check(status, "dfine_bn_act_fwd")
     return y, stats                # (eval mode: rows 0 / 1 hold the running mean and rsqrt(running_var + eps), written by the kernel)
-
-
-class _ConvEpilogue(ctypes.Structure):
-    """DfineConvEpilogue (include/dfine_hip.h)."""
-    _fields_ = [("mode", c_int), ("nchunk", c_int), ("act", c_int), ("cout", c_int), ("part", c_void_p),
-                ("bn_x", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
-                ("lab_scale", c_void_p)]
-
-
-_EPI_CHUNKS = {}
-
-
-def conv_epilogue_chunks(B, cin, cout, H, W, ks, n_x_parts=1):
-    """Partial-sum slots per output channel the convolution kernel for this call writes when a BatchNorm-sum epilogue is
-    armed (dfine_conv_epilogue_chunks); 0 = that kernel has none."""
-    key = (B, cin, cout, H, W, ks, n_x_parts)
-    n = _EPI_CHUNKS.get(key)
-    if n is None:
-        n = _EPI_CHUNKS[key] = int(_lib.dfine_conv_epilogue_chunks(B, cin, cout, H, W, ks, n_x_parts))
-    return n
-
-
-def arm_conv_stats(cout, nchunk, device):
-    """Arm the NEXT convolution launch of this thread to add up (sum, sum of squares) of its stored outputs per channel
-    (DfineConvEpilogue mode 1).  -> part [nchunk, cout, 2] f32 for bn_act_forward(part=...)."""
-    part = torch.empty(nchunk, cout, 2, device=device, dtype=torch.float32)
-    ep = _ConvEpilogue(1, nchunk, 0, cout, part.data_ptr(), None, None, None, None, None, None)
-    _check(_lib.dfine_conv_epilogue_once(ctypes.byref(ep)), "dfine_conv_epilogue_once")
-    return part
-
-
-def arm_conv_bn_bwd(cout, nchunk, bn_x, stats, lab_scale, act):
-    """Arm the NEXT convolution launch (a data gradient whose stored values are the dy of a BatchNorm with input `bn_x` and
-    saved `stats` [4, C]) to add up that BatchNorm's backward sums (DfineConvEpilogue mode 2).  -> part [nchunk, cout, 4]."""
-    part = torch.empty(nchunk, cout, 4, device=bn_x.device, dtype=torch.float32)
-    sp, row = stats.data_ptr(), 4 * cout
-    ep = _ConvEpilogue(2, nchunk, _ACT[act], cout, part.data_ptr(), bn_x.data_ptr(), sp, sp + row, sp + 2 * row, sp + 3 * row,
-                       _ptr(lab_scale))
-    _check(_lib.dfine_conv_epilogue_once(ctypes.byref(ep)), "dfine_conv_epilogue_once")
-    return part
-
-
-def disarm_conv_epilogue():
-    _lib.dfine_conv_epilogue_once(None)
 
 
 _EPI_OK = {}
@@ -699,7 +637,7 @@ def conv_accumulate_bf16(x, w2, y, ks):
     return y
 
 
-def bn_act_backward(x, dy, stats, lab_scale, act, training, need_affine=True, need_lab=True, dlab_ptr=None, part=None):
+def bn_act_backward(x, dy, stats, lab_scale, act, training, need_affine=True, need_lab=True, dlab_ptr=None):
     """-> (dx, dgamma, dbeta, dlab).  dgamma / dbeta are two separate tensors (autograd's AccumulateGrad takes ownership
     of a whole tensor but has to copy a view: 2 x 133 small device copies per D-FINE-m step).  `dlab_ptr`: device address
     of two adjacent floats the kernel ADDS the learnable-affine gradients to (the fused optimizer's flat gradient slots);
@@ -715,14 +653,6 @@ def bn_act_backward(x, dy, stats, lab_scale, act, training, need_affine=True, ne
     sp = stats.data_ptr()
     row = 4 * C
     dl = dlab_ptr if (need_lab and dlab_ptr is not None) else _ptr(dlab)
-    if part is not None:       # [nchunk, C, 4] sums from the epilogue of the data gradient that produced dy (arm_conv_bn_bwd)
-        ws = _bn_workspace(dev, 4 * 8192 + 2 * C)
-        status = _lib.dfine_bn_act_bwd_part(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), sp, sp + row, sp + 2 * row, sp + 3 * row,
-                                            _ptr(lab_scale), _ptr(dgamma), _ptr(dbeta), dl, part.data_ptr(), part.shape[0],
-                                            ws.data_ptr(), B, C, HW, _ACT[act], _stream())
-        if status != 0:
-            _check(status, "dfine_bn_act_bwd_part")
-        return dx, dgamma, dbeta, dlab
     status = _lib.dfine_bn_act_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), sp, sp + row, sp + 2 * row, sp + 3 * row,
                                    _ptr(lab_scale), _ptr(dgamma), _ptr(dbeta), dl, ws.data_ptr(),
                                    _DTYPE[x.dtype], B, C, HW, _ACT[act], 1 if training else 0, _stream())
@@ -1061,8 +991,8 @@ def conv1x1_seg_wgrad(x_parts, dy, partials=False):
 WGRAD_STREAM = os.environ.get("DFINE_WGRAD_STREAM", "1") == "1"
 _SIDE = {}
 _SIDE_LIVE = []
-_SIDE_PRIORITY = int(os.environ.get("DFINE_SIDE_PRIORITY", "0"))       # stream priority of the side stream (torch: lower number = higher priority)
-_SIDE_GROUP_AT = int(os.environ.get("DFINE_WGRAD_GROUP_AT", "32"))     # registered problems that trigger an early grouped launch (12 / 48 / never: +0.13 / 0 / +0.4 ms per step)
+_SIDE_PRIORITY = 0        # stream priority of the side stream (torch: lower number = higher priority; measured: no effect - tools/probe/main_prio.py)
+_SIDE_GROUP_AT = 32       # registered problems that trigger an early grouped launch (12 / 48 / never: +0.13 / 0 / +0.4 ms per step; tools/ab_step.py)
 
 
 CAPTURE_SIDE = False      # set by dl.engine.GraphedSegment while it captures: the side stream is forked into the capture (and joined
@@ -1074,13 +1004,11 @@ CAPTURE_DUAL = None       # set by dl.engine.GraphedSegment while it captures a 
                           # side_launch() is told about every side-stream launch and decides where one pair ends and the next begins
 
 
-# which weight-gradient launches go to the side stream (DFINE_SIDE_KINDS, comma separated): dw (depthwise), seg (part-wise 1x1), conv1,
-# conv3, group (grouped 1x1), linear (grouped token-stream linears), reduce (split reductions), stem
-_SIDE_KINDS = frozenset(k for k in os.environ.get("DFINE_SIDE_KINDS", "dw,seg,conv1,conv3,group,linear,reduce,stem").split(",") if k)
-
-
 def _side_ok(kind=None):
-    return (WGRAD_STREAM and not _TIMING_ISOLATED and (kind is None or kind in _SIDE_KINDS)
+    """kind: dw (depthwise), seg (part-wise 1x1), conv1, conv3, group (grouped 1x1), linear (grouped token-stream linears), reduce
+    (split reductions), stem - every kind of weight gradient pays its way on the side stream (measured: all 29.1 ms per step,
+    none 29.7, any subset 29.6-30.5), so the kind no longer selects anything."""
+    return (WGRAD_STREAM and not _TIMING_ISOLATED
             and (CAPTURE_SIDE or CAPTURE_DUAL is not None or not torch.cuda.is_current_stream_capturing()))
 
 
@@ -1182,7 +1110,7 @@ def conv_wgrad_bf16(x, dy, ks, partials=False):
     B, cin, H, W = x.shape
     cout = dy.shape[1]
     dw = None if partials else torch.empty(cout, cin, ks, ks, device=x.device, dtype=torch.float32)
-    if partials and ks == 1 and _CW_GROUP and (H * W) % 8 == 0:
+    if partials and ks == 1 and (H * W) % 8 == 0:
         # registered only: every 1x1 weight gradient of a flush runs in one launch (linear_wgrad_flush -> dfine_conv_wgrad1_group);
         # a problem of a grouped launch is cut into fewer splits than a stand-alone one (dfine_conv_wgrad1_group_splits)
         ws = torch.empty(int(_PURE.dfine_conv_wgrad1_group_ws_floats(B, cin, cout, H * W)), device=x.device, dtype=torch.float32)
@@ -1414,7 +1342,7 @@ def _mask_bits(mask):
     return _mask_forms(mask)[0]
 
 
-_MASK_SUMMARY = os.environ.get("DFINE_ATTN_MASK_SUMMARY", "1") == "1"
+_MASK_SUMMARY = True       # tile summaries of the attention mask (tools/probe/attn_real_mask.py flips it for its A/B)
 
 
 def _mask_forms(mask):
@@ -1459,9 +1387,6 @@ def attn_backward(q, k, v, o, dout, lse2, num_heads, dq, dk, dv, mask=None):
 _LW_WS = {}
 
 
-_LW_GROUP = os.environ.get("DFINE_LINEAR_WGRAD_GROUP", "1") == "1"
-_CW_GROUP = os.environ.get("DFINE_CONV_WGRAD_GROUP", "1") == "1"
-_LW_GROUP_AT = int(os.environ.get("DFINE_LW_GROUP_AT", "0"))     # registered linears that trigger a grouped side-stream launch (0: twice the conv threshold)
 _CW_PENDING = []            # (x, dy, ws, B, Cin, Cout, HW): 1x1 convolution weight gradients registered since the last flush
 _LW_PENDING = []            # (x2d, dy2d, ws, M, N, K) registered since the last linear_wgrad_flush
 
@@ -1473,50 +1398,41 @@ def linear_wgrad_partials(x2d, dy2d):
     M, K = x2d.shape
     N = dy2d.shape[1]
     ws = torch.empty(int(_PURE.dfine_linear_wgrad_ws_floats(M, N, K)), device=x2d.device, dtype=torch.float32)
-    if _LW_GROUP:
-        _LW_PENDING.append((x2d, dy2d, ws, M, N, K))
-        if len(_LW_PENDING) >= (_LW_GROUP_AT or 2 * _SIDE_GROUP_AT) and _side_ok("linear"):
-            _flush_linear_group(True)
-    else:
-        with _timed("linear_wgrad", 2.0 * M * N * K, io=2.0 * M * (N + K) + 4.0 * N * K):
-            _check(_lib.dfine_linear_wgrad_bf16(_ptr(x2d), _ptr(dy2d), None, None, _ptr(ws), M, N, K, _stream()),
-                   "dfine_linear_wgrad_bf16")
+    _LW_PENDING.append((x2d, dy2d, ws, M, N, K))
+    if len(_LW_PENDING) >= 2 * _SIDE_GROUP_AT and _side_ok("linear"):
+        _flush_linear_group(True)
     splits = int(_PURE.dfine_linear_wgrad_splits(M, N, K))
     np16, cp16 = _p16(N), _p16(K)
     return ws, (splits, N, K, 1, np16, cp16), (splits, N, 1, 1, np16, 1), splits * np16 * cp16
 
 
 def _flush_conv_group(side=False):
-    """The registered 1x1 weight gradients as grouped launches: one for the layers with <= 128 channels on both sides (64 x 64
-    tiles, dfine_conv_wgrad1_group64), one for the others (128 x 128 tiles)."""
+    """The registered 1x1 weight gradients as ONE grouped launch (128 x 128 (n, c) tiles, dfine_conv_wgrad1_group)."""
     import numpy as np
     from .d_fine.arch.utils import upload
-    pend_all = list(_CW_PENDING)
+    pend = list(_CW_PENDING)
     _CW_PENDING.clear()
-    for tile, launch, what in ((64, _lib.dfine_conv_wgrad1_group64, "dfine_conv_wgrad1_group64"),
-                               (128, _lib.dfine_conv_wgrad1_group, "dfine_conv_wgrad1_group")):
-        pend = [p for p in pend_all if int(_PURE.dfine_conv_wgrad1_group_tile(p[4], p[5])) == tile]
-        if not pend:
-            continue
-        table = np.empty((len(pend), 8), dtype=np.int64)
-        blocks, flops, io = 1, 0.0, 0.0
-        for i, (x, dy, ws, B, cin, cout, hw) in enumerate(pend):
-            n = int(_lib.dfine_conv_wgrad1_group_row(x.data_ptr(), dy.data_ptr(), ws.data_ptr(), B, cin, cout, hw, table[i].ctypes.data))
-            if n < 0:
-                raise RuntimeError("dfine_conv_wgrad1_group_row: bad arguments")
-            blocks = max(blocks, n)
-            flops += 2.0 * B * hw * cin * cout
-            io += 2.0 * B * hw * (cin + cout) + 4.0 * cin * cout
-        dev_table = upload(table, pend[0][0].device)
-        if side:
-            st = _side_fork(pend[0][0].device)         # (forked after the table's copy was enqueued)
-            with _timed("conv1x1_wgrad", flops, io=io, stream=st.stream):
-                _check(launch(_ptr(dev_table), len(pend), blocks, st.cuda_stream), what)
-            _SIDE_LIVE.append((pend, dev_table))
-            continue
-        with _timed("conv1x1_wgrad", flops, io=io):
-            _check(launch(_ptr(dev_table), len(pend), blocks, _stream()), what)
-        _LW_KEEP.append((pend, dev_table))
+    if not pend:
+        return
+    table = np.empty((len(pend), 8), dtype=np.int64)
+    blocks, flops, io = 1, 0.0, 0.0
+    for i, (x, dy, ws, B, cin, cout, hw) in enumerate(pend):
+        n = int(_lib.dfine_conv_wgrad1_group_row(x.data_ptr(), dy.data_ptr(), ws.data_ptr(), B, cin, cout, hw, table[i].ctypes.data))
+        if n < 0:
+            raise RuntimeError("dfine_conv_wgrad1_group_row: bad arguments")
+        blocks = max(blocks, n)
+        flops += 2.0 * B * hw * cin * cout
+        io += 2.0 * B * hw * (cin + cout) + 4.0 * cin * cout
+    dev_table = upload(table, pend[0][0].device)
+    if side:
+        st = _side_fork(pend[0][0].device)         # (forked after the table's copy was enqueued)
+        with _timed("conv1x1_wgrad", flops, io=io, stream=st.stream):
+            _check(_lib.dfine_conv_wgrad1_group(_ptr(dev_table), len(pend), blocks, st.cuda_stream), "dfine_conv_wgrad1_group")
+        _SIDE_LIVE.append((pend, dev_table))
+        return
+    with _timed("conv1x1_wgrad", flops, io=io):
+        _check(_lib.dfine_conv_wgrad1_group(_ptr(dev_table), len(pend), blocks, _stream()), "dfine_conv_wgrad1_group")
+    _LW_KEEP.append((pend, dev_table))
 
 
 def _flush_linear_group(side=False):
@@ -1633,39 +1549,28 @@ def _stem_pad32(dy):
 
 # The end of a captured backward: the main stream is done ~0.9 ms before the side stream (tools/stream_timeline.py: the last side
 # graph - stage-1 3x3 weight gradient, the five stem weight gradients, the remaining grouped 1x1 / linear launches - only starts
-# when the last main graph has ended).  Mode 2 (default): the registered groups are launched and the pair is closed when the
-# backward pass reaches the stem, so everything but the stem's own weight gradients runs under the stem's data gradients: 28.39
-# -> 28.22 ms per step (same box, alternating), roofline fraction of the timed mode 0.127 -> 0.126.  Mode 1 also gives every stem
-# weight gradient its own pair (28.13 ms), but those HBM-bound kernels then run beside the stem's HBM-bound main-stream kernels
-# and both take longer (family kernel time +0.7 ms: fraction 0.123).  0: the chunking of the rest of the pass all the way.
-_STEM_TAIL = int(os.environ.get("DFINE_STEM_TAIL", "2"))     # 1: as described below; 2: only the early launch of the registered groups
-
-
+# when the last main graph has ended).  So the registered groups are launched and the graph pair is closed when the backward pass
+# reaches the stem: everything but the stem's own weight gradients runs under the stem's data gradients (28.39 -> 28.22 ms per
+# step, same box, alternating; roofline fraction of the timed mode 0.127 -> 0.126).  Measured and dropped: every stem weight gradient
+# in its own pair (28.13 ms, but those HBM-bound kernels then run beside the stem's HBM-bound main-stream kernels and both take
+# longer: family kernel time +0.7 ms, fraction 0.123); a second cut in front of the third stem weight gradient (-0.065 ms, 0.1257).
 def backward_tail_begins():
     """Called when the backward pass reaches the stem, its last stretch.  The stem's weight gradients are the end of the side
     stream's work and each can only start once the main stream has produced its dy, so whatever else is still queued for the
     side stream must not sit behind them: the registered grouped weight gradients (1x1 convolutions, token-stream linears) are
     launched NOW, under the stem's data gradients; and a captured backward (dl/engine.py: chain of (main, side) graph pairs, a
-    side graph starts when its main graph has ended) closes a pair at every side launch from here on instead of every fifth,
-    so that a stem weight gradient waits for one stem layer of main-stream work, not for the rest of the pass."""
-    if not _STEM_TAIL or not _side_ok():
+    side graph starts when its main graph has ended) closes its current pair at the next side launch (the first stem weight
+    gradient): the side graph with the backlog starts there; the stem's own weight gradients keep one pair."""
+    if not _side_ok():
         return
     if _CW_PENDING:
         _flush_conv_group(True)
     if _LW_PENDING:
         _flush_linear_group(True)
-    if CAPTURE_DUAL is not None:
-        if _STEM_TAIL == 1:
-            CAPTURE_DUAL.every = 1
-        elif CAPTURE_DUAL.cur is not None:
-            # (mode 3: a second cut in front of the third stem weight gradient - the first two run under the rest of the stem's
-            # data gradients, three trail)
-            n = getattr(CAPTURE_DUAL, "tail_calls", 0)
-            CAPTURE_DUAL.tail_calls = n + 1
-            if not (n == 0 or (_STEM_TAIL == 3 and n == 2)):
-                return
-            # mode 2: the pair is closed by the next side launch (the first stem weight gradient): the side graph with the backlog and the
-            # groups launched above starts there, under the stem's data gradients; the stem's own weight gradients keep one pair
+    if CAPTURE_DUAL is not None and CAPTURE_DUAL.cur is not None:
+        n = getattr(CAPTURE_DUAL, "tail_calls", 0)
+        CAPTURE_DUAL.tail_calls = n + 1
+        if n == 0:
             CAPTURE_DUAL.cur[2] = max(CAPTURE_DUAL.cur[2], CAPTURE_DUAL.every)
 
 

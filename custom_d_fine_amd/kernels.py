@@ -103,9 +103,12 @@ class _ValueGradShare:
         self.acc = None
 
 
+_OWNED_VALUE_GRAD = [None]      # address of the value-path gradient _MSDAFused's shared accumulator has just produced
+
+
 def msda_share_value_grad(value):
     """Marks `value` as gathered by several msda_fused calls of one forward pass (the decoder calls it once per step)."""
-    if value.is_cuda and value.requires_grad and _env("DFINE_MSDA_SHARE", "1") == "1":
+    if value.is_cuda and value.requires_grad:
         value._dfine_share = _ValueGradShare()
     return value
 
@@ -147,6 +150,7 @@ class _MSDAFused(torch.autograd.Function):
         gv = None
         if share.pending == 0:
             gv, share.acc = hip.msda_finish_grad_value(share.acc, value.dtype), None
+            _OWNED_VALUE_GRAD[0] = gv.data_ptr()         # a fresh tensor of this pass (see _TakeRowsAndPass.backward)
         return gv, None, goff, glog, None, None, None
 
 
@@ -380,18 +384,9 @@ def head_losses(logits, boxes, corners, ref, teacher_corners, teacher_logits, cl
 # =============================================================================================
 # A1/A2  conv -> BatchNorm -> activation -> learnable affine units of backbone and encoder
 # =============================================================================================
-_STEM_WGRAD_SIDE = os.environ.get("DFINE_STEM_WGRAD_SIDE", "1") == "1"
-# DFINE_STEM_WGRAD_MAIN="c3,k2" keeps the weight gradients of the layers whose backward runs LAST (stem1: 3 input channels; stem2a /
-# stem2b: the 2x2 kernels) on the main stream, which has nothing left to do by then while the side stream still works through its
-# queue.  Measured equal (32.47 / 32.57 vs 32.58 / 32.51 ms per step): off by default.
-_STEM_WGRAD_MAIN = set(filter(None, os.environ.get("DFINE_STEM_WGRAD_MAIN", "").split(",")))
-
-
 def _stem_wgrad_side(weight):
-    if not _STEM_WGRAD_SIDE:
-        return False
-    if ("c3" in _STEM_WGRAD_MAIN and weight.shape[1] == 3) or ("k2" in _STEM_WGRAD_MAIN and weight.shape[2] == 2):
-        return False
+    # (measured equal, 32.47 / 32.57 vs 32.58 / 32.51 ms per step: the weight gradients of the layers whose backward runs LAST -
+    # stem1, the 2x2 kernels - kept on the main stream, which has nothing left to do by then)
     return _side_wgrad_ok(weight)
 
 
@@ -750,7 +745,7 @@ def _conv_plan(x, weight):
     return plan
 
 
-_FUSE_CONV_BN = os.environ.get("DFINE_FUSE_CONV_BN", "1") == "1"
+_FUSE_CONV_BN = True      # conv node + BatchNorm tail as ONE autograd node (tests may flip it to compare the two-node composition)
 
 
 def _conv_plan_all_hip(x, weight):
@@ -821,11 +816,10 @@ class GradFanIn:
     its own data gradient onto the parked one in its convolution's epilogue (dfine_conv_accum_bf16) and returns the sum.
     `armed` is set in the forward pass by the later consumer when it will be able to do that, `parking` by the earlier one
     (whose forward runs after it) when it will park - only then does the later consumer expect a parked gradient."""
-    __slots__ = ("armed", "parking", "buf", "bn", "part", "chain", "lo", "pending")
+    __slots__ = ("armed", "parking", "buf", "chain", "lo", "pending")
 
     def __init__(self, chain=False, lo=0):
         self.armed, self.parking, self.buf = False, False, None
-        self.bn, self.part = None, None         # BNLink role (below): the map's producer is a BatchNorm unit
         # chain role (fan_slice below): SEVERAL later consumers, all of them 1x1 convolutions reading channels lo.. of the map;
         # each adds its data gradient onto that channel range of the parked gradient and leaves it parked; `pending` counts them
         self.chain, self.lo, self.pending = chain, lo, 0
@@ -911,8 +905,7 @@ class _FanOut(torch.autograd.Function):
 
 def fan_out(x, k):
     """k aliases of x for k consumers (see _FanOut); x itself k times where the fused sum does not apply."""
-    if (k < 2 or not torch.is_tensor(x) or not x.is_cuda or not x.requires_grad or x.dtype != torch.float32 or not torch.is_grad_enabled()
-            or _env("DFINE_FAN_OUT", "1") != "1"):
+    if (k < 2 or not torch.is_tensor(x) or not x.is_cuda or not x.requires_grad or x.dtype != torch.float32 or not torch.is_grad_enabled()):
         return (x,) * k
     return _FanOut.apply(x, k)
 
@@ -939,10 +932,14 @@ class _TakeRowsAndPass(torch.autograd.Function):
         idx = ind.unsqueeze(-1).expand(-1, -1, ctx.shape[-1])
         if g_all is None:
             return g_rows.new_zeros(ctx.shape).scatter_add_(1, idx, g_rows), None
-        # g_all is this graph's own tensor (the value path's gradient: a fresh sum of the decoder layers' terms), never a
-        # caller's: written in place
-        g_all = g_all.contiguous()
-        return g_all.scatter_add_(1, idx, g_rows.to(g_all.dtype)), None
+        # Written in place only when g_all is provably this pass's own tensor - the value path's gradient fresh out of the shared
+        # deformable-attention accumulator (a view of it: same address).  Autograd does not promise an incoming gradient is
+        # unshared (AddBackward and view backward hand one tensor to several nodes): anything else is added out of place.
+        own = g_all.is_contiguous() and _OWNED_VALUE_GRAD[0] is not None and _OWNED_VALUE_GRAD[0] == g_all.data_ptr()
+        _OWNED_VALUE_GRAD[0] = None
+        if own:
+            return g_all.scatter_add_(1, idx, g_rows.to(g_all.dtype)), None
+        return g_all.scatter_add(1, idx, g_rows.to(g_all.dtype)), None
 
 
 def take_rows_and_pass(t, ind):
@@ -1003,63 +1000,14 @@ def fan_slice(x, lo, n):
     return _FanSlice.apply(x, lo, n, fan), fan
 
 
-class BNLink:
-    """Hand-off of the BatchNorm-backward sums between a conv + BatchNorm unit (the PRODUCER of a map) and the convolution
-    that forms the map's complete gradient in backward (its only CONSUMER, or - GradFanIn - the later of its two consumers,
-    which adds the parked gradient in its epilogue).  The reference's BatchNorm backward reads dy and its input once for
-    sum(dz), sum(dz * xhat) before it can form dx (ATen batch_norm_backward behind hgnetv2.py:75-80); here the consumer's
-    data-gradient kernel adds those sums up while it stores dy (DfineConvEpilogue mode 2, csrc/epi_bn.h).  Forward: the
-    producer leaves `bn` = (BatchNorm input, saved statistics, lab scale, activation); backward: the consumer arms its
-    data-gradient launch with it and leaves `part`, which the producer's BatchNorm backward takes in place of its reduction pass."""
-    __slots__ = ("bn", "part")
-
-    def __init__(self):
-        self.bn, self.part = None, None
-
-
-_BN_LINK_MIN = 16384      # B * H * W up to this: the BatchNorm backward is ONE launch with the channel in registers (bn_one_bwd)
-_BN_STATS_MIN = 65536     # ... and the forward ONE launch with one read (bn_one_fwd): nothing to save by statistics from the convolution
-
-
-def _bn_link_register(link, c, stats, lab_scale, act, training):
-    """Producer side, forward: may the consumer's epilogue take over this unit's backward reduction?"""
-    if (link is None or not training or c.dtype != torch.bfloat16 or _env("DFINE_BN_LINK", "0") != "1"):
-        return None
-    B, C, H, W = c.shape
-    if (H * W) % 8 or C > 2048 or B * H * W <= _BN_LINK_MIN:
-        return None
-    link.bn, link.part = (c, stats, lab_scale, act), None
-    return link
-
-
-def _bn_link_take(link):
-    """Producer side, backward: the sums the consumer left (None: it could not)."""
-    if link is None:
-        return None
-    part, link.part, link.bn = link.part, None, None
-    return part
-
-
-def _bn_link_arm(link, B, cin, cout, H, W, ks):
-    """Consumer side, backward, right before the data-gradient launch (cout -> cin channels) whose stored values are the
-    complete gradient of the linked map."""
-    if link is None or link.bn is None:
-        return
-    hip = _hip()
-    nchunk = hip.conv_epilogue_chunks(B, cout, cin, H, W, ks)
-    if nchunk > 0 and link.bn[0].shape[1] == cin:
-        link.part = hip.arm_conv_bn_bwd(cin, nchunk, *link.bn)
-
-
 def grad_fanin_enabled(x):
     return (_env("DFINE_GRAD_FANIN", "1") == "1" and torch.is_tensor(x) and x.is_cuda and torch.is_grad_enabled()
             and _env("DFINE_HIP_UNITS", "1") == "1")
 
 
 def fanin_outer_enabled():
-    """The hand-offs across blocks (HG_Block's residual connection, the stage outputs that leave the backbone): DFINE_FANIN_OUTER=0
-    leaves those sums to autograd."""
-    return _env("DFINE_FANIN_OUTER", "1") == "1"
+    """The hand-offs across blocks (HG_Block's residual connection, the stage outputs that leave the backbone)."""
+    return True
 
 
 class _DenseConvBNAct(torch.autograd.Function):
@@ -1069,9 +1017,8 @@ class _DenseConvBNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, lab_scale, lab_bias, running_mean, running_var, act, training, momentum, eps,
-                fanin=None, fanout=None, bnsrc=None, residual=None):
-        """fanin: GradFanIn of x (this unit is its later consumer); fanout: BNLink / GradFanIn of the output (this unit is its
-        producer); bnsrc: BNLink of x when this unit is its ONLY consumer; residual: added to the unit's output in the BatchNorm
+                fanin=None, residual=None):
+        """fanin: GradFanIn of x (this unit is its later consumer); residual: added to the unit's output in the BatchNorm
         apply pass (a residual connection behind the unit; its gradient is the output's)."""
         hip = _hip()
         x = x.contiguous()
@@ -1085,16 +1032,9 @@ class _DenseConvBNAct(torch.autograd.Function):
             ctx.fanin = fanin
             if fanin.chain:
                 fanin.pending += 1
-        ctx.bnsrc = bnsrc if ctx.needs_input_grad[0] else None
-        part = None
-        if training and B * H * W > _BN_STATS_MIN and (H * W) % 8 == 0 and cout <= 4096 and _env("DFINE_BN_LINK", "0") == "1":
-            nchunk = hip.conv_epilogue_chunks(B, cin, cout, H, W, ks)
-            if nchunk > 0:                                # the convolution adds up the batch statistics while it stores c
-                part = hip.arm_conv_stats(cout, nchunk, x.device)
         c = hip.conv_forward_bf16(x, _packed_weights(weight, False), cout, ks)
         y, stats = hip.bn_act_forward(c, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, training, momentum, eps,
-                                      part=part, residual=None if residual is None else residual.contiguous())
-        ctx.fanout = _bn_link_register(fanout, c, stats, lab_scale, act, training)
+                                      residual=None if residual is None else residual.contiguous())
         ctx.save_for_backward(x, weight, c, stats, lab_scale)
         ctx.cfg = (act, training, gamma is not None, lab_scale is not None)
         need = ctx.needs_input_grad
@@ -1120,9 +1060,7 @@ class _DenseConvBNAct(torch.autograd.Function):
             dy = dy.to(c.dtype)
         slot = ctx.slot
         dlab_ptr = slot[0].grad_ptr(slot[1][0]) if slot is not None else None
-        dc, dg, db, dlab = hip.bn_act_backward(c, dy, stats, lab_scale, act, training, has_affine, has_lab, dlab_ptr,
-                                               part=_bn_link_take(ctx.fanout))
-        ctx.fanout = None
+        dc, dg, db, dlab = hip.bn_act_backward(c, dy, stats, lab_scale, act, training, has_affine, has_lab, dlab_ptr)
         dls = dlb = None
         if slot is not None:
             for i in slot[1]:
@@ -1147,12 +1085,9 @@ class _DenseConvBNAct(torch.autograd.Function):
                     fan.pending -= 1
                     dx = view if fan.pending == 0 else None            # (the last one tells _FanSlice the gradient is there)
                 else:
-                    _bn_link_arm(fan, B, cin, weight.shape[0], H, W, ks)       # ... which then holds the map's complete gradient
                     dx = hip.conv_accumulate_bf16(dc, _packed_weights(weight, True), fan.take(), ks)
             else:
-                _bn_link_arm(ctx.bnsrc, B, cin, weight.shape[0], H, W, ks)
                 dx = hip.conv_forward_bf16(dc, _packed_weights(weight, True), weight.shape[1], ks)
-            ctx.bnsrc = None
         dw = None
         if need[1]:
             wslot = ctx.wslot
@@ -1162,7 +1097,7 @@ class _DenseConvBNAct(torch.autograd.Function):
                 wslot[0].use_done(wslot[1][0])
             else:
                 dw = hip.conv_wgrad_bf16(x, dc, ks).to(weight.dtype)
-        return dx, dw, dg, db, dls, dlb, None, None, None, None, None, None, None, None, None, (dy if len(need) > 15 and need[15] else None)
+        return dx, dw, dg, db, dls, dlb, None, None, None, None, None, None, None, (dy if len(need) > 13 and need[13] else None)
 
 
 class _InnerCtx:
@@ -1180,22 +1115,11 @@ class _ConvBNActAny(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inner, n, *args):
         conv_args = args[:n]
-        gamma, beta, lab_scale, lab_bias, running_mean, running_var, act, training, momentum, eps, fanout = args[n:]
+        gamma, beta, lab_scale, lab_bias, running_mean, running_var, act, training, momentum, eps = args[n:]
         ictx = _InnerCtx()
         ictx.needs_input_grad = ctx.needs_input_grad[2:2 + n]
-        part = None
-        if inner is _DenseConvSeg and training and _env("DFINE_BN_LINK", "0") == "1":
-            xs = conv_args[2:]                            # the part-wise 1x1 convolution adds up the batch statistics itself
-            B, _, H, W = xs[0].shape
-            cout, hip = conv_args[0].shape[0], _hip()
-            if B * H * W > _BN_STATS_MIN and (H * W) % 8 == 0 and cout <= 4096:
-                nchunk = hip.conv_epilogue_chunks(B, sum(t.shape[1] for t in xs), cout, H, W, 1, len(xs))
-                if nchunk > 0:
-                    part = hip.arm_conv_stats(cout, nchunk, xs[0].device)
         c = inner.forward(ictx, *conv_args)
-        y, stats = _hip().bn_act_forward(c, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, training, momentum, eps,
-                                         part=part)
-        ctx.fanout = _bn_link_register(fanout, c, stats, lab_scale, act, training)
+        y, stats = _hip().bn_act_forward(c, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, training, momentum, eps)
         ctx.save_for_backward(c, stats, lab_scale)
         ctx.inner, ctx.ictx, ctx.n = inner, ictx, n
         ctx.cfg = (act, training, gamma is not None, lab_scale is not None)
@@ -1218,9 +1142,7 @@ class _ConvBNActAny(torch.autograd.Function):
             dy = dy.to(c.dtype)
         slot = ctx.slot
         dlab_ptr = slot[0].grad_ptr(slot[1][0]) if slot is not None else None
-        dc, dg, db, dlab = _hip().bn_act_backward(c, dy, stats, lab_scale, act, training, has_affine, has_lab, dlab_ptr,
-                                                  part=_bn_link_take(ctx.fanout))
-        ctx.fanout = None
+        dc, dg, db, dlab = _hip().bn_act_backward(c, dy, stats, lab_scale, act, training, has_affine, has_lab, dlab_ptr)
         dls = dlb = None
         if slot is not None:
             for i in slot[1]:
@@ -1229,10 +1151,10 @@ class _ConvBNActAny(torch.autograd.Function):
             dls, dlb = dlab[0:1], dlab[1:2]
         inner_grads = ctx.inner.backward(ctx.ictx, dc)
         ctx.ictx = None
-        return (None, None) + tuple(inner_grads) + (dg, db, dls, dlb, None, None, None, None, None, None, None)
+        return (None, None) + tuple(inner_grads) + (dg, db, dls, dlb, None, None, None, None, None, None)
 
 
-def _bn_tail_fused(inner, conv_args, bn, a, lab, fanout=None):
+def _bn_tail_fused(inner, conv_args, bn, a, lab):
     """conv node + BatchNorm tail as one autograd node when the BatchNorm is a plain tracked nn.BatchNorm2d; None otherwise."""
     if not (_FUSE_CONV_BN and type(bn) is nn.BatchNorm2d and bn.track_running_stats and bn.momentum is not None):
         return None
@@ -1244,8 +1166,7 @@ def _bn_tail_fused(inner, conv_args, bn, a, lab, fanout=None):
         else:
             bn.num_batches_tracked.add_(1)
     return _ConvBNActAny.apply(inner, len(conv_args), *conv_args, bn.weight, bn.bias, lab.scale if lab is not None else None,
-                               lab.bias if lab is not None else None, bn.running_mean, bn.running_var, a, training, bn.momentum, bn.eps,
-                               fanout)
+                               lab.bias if lab is not None else None, bn.running_mean, bn.running_var, a, training, bn.momentum, bn.eps)
 
 
 class _DualConv(torch.autograd.Function):
@@ -1594,7 +1515,7 @@ def _is_depthwise(conv, allow_bias=False):
 _ROUTES = [0]       # epoch token of the per-module route caches of conv_bn_act (replaced by reload_env)
 
 
-def _conv_bn_act_residual(x, conv, bn, a, lab, fanin, fanout, bnsrc, residual):
+def _conv_bn_act_residual(x, conv, bn, a, lab, fanin, residual):
     """conv_bn_act(x, ...) + residual as ONE fused dense unit (the add rides in the BatchNorm apply pass), or None when the
     layer is not served that way (then the caller adds)."""
     if not (torch.is_tensor(x) and x.is_cuda and x.is_contiguous() and x.dtype == torch.bfloat16 and a in (None, "relu", "silu", "swish")
@@ -1612,26 +1533,24 @@ def _conv_bn_act_residual(x, conv, bn, a, lab, fanin, fanout, bnsrc, residual):
             bn.num_batches_tracked.add_(1)
     return _DenseConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, lab.scale if lab is not None else None,
                                  lab.bias if lab is not None else None, bn.running_mean, bn.running_var, a, training,
-                                 bn.momentum, bn.eps, fanin, fanout, bnsrc, residual)
+                                 bn.momentum, bn.eps, fanin, residual)
 
 
 def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Optional[nn.Module],
-                pad_br: bool = False, fanin=None, fans=None, fanout=None, bnsrc=None, residual=None):
+                pad_br: bool = False, fanin=None, fans=None, residual=None):
     """conv(bias=False) -> BN (batch stats in training) -> {None, relu, silu} -> scalar affine; the
     building block of HGNetv2 and the HybridEncoder.
     fanin / fans: GradFanIn hand-offs of the data gradient (fanin: this unit is the LATER consumer of x in backward; fans: one
     per part of a list input, this unit being the EARLIER one) - only honoured by the fused HIP units, ignored elsewhere.
-    fanout / bnsrc: BNLink hand-offs of the BatchNorm-backward sums (fanout: of this unit's output; bnsrc: of x, this unit
-    being its only consumer) - likewise.
     GPU (bf16 autocast): dense 1x1 / 3x3, depthwise and stem convolutions and the whole BN/act/affine tail are HIP kernels;
     fp32 math and CPU tensors take the plain ATen composition below."""
     a = act.lower() if isinstance(act, str) else act
     if residual is not None:
         # only the fused dense unit adds it in its apply pass; every other route: the unit, then a plain add
-        y = _conv_bn_act_residual(x, conv, bn, a, lab, fanin, fanout, bnsrc, residual)
+        y = _conv_bn_act_residual(x, conv, bn, a, lab, fanin, residual)
         if y is not None:
             return y
-        return conv_bn_act(x, conv, bn, act, lab, pad_br, fanin, fans, fanout, bnsrc) + residual
+        return conv_bn_act(x, conv, bn, act, lab, pad_br, fanin, fans) + residual
     if (torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and not x.is_contiguous() and conv.kernel_size == (1, 1)
             and x.dtype == torch.bfloat16 and _hip().is_channel_part(x)):
         x = [x]                       # a channel slice of a wider map (RepNCSPELAN4 split): read in place, no .contiguous() copy
@@ -1645,7 +1564,7 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
                 and conv.kernel_size == (1, 1) and len(xs) <= 8 and (xs[0].shape[-1] * xs[0].shape[-2]) % 8 == 0
                 and all(t.shape[1] % 8 == 0 for t in xs) and _mfma_conv_ok(conv, xs[0])):
             parts = [t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16) for t in xs]
-            y = _bn_tail_fused(_DenseConvSeg, (conv.weight, fans, *parts), bn, a, lab, fanout=fanout)
+            y = _bn_tail_fused(_DenseConvSeg, (conv.weight, fans, *parts), bn, a, lab)
             if y is not None:
                 return y
             y = _DenseConvSeg.apply(conv.weight, fans, *parts)
@@ -1691,7 +1610,7 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
             if x.dtype == torch.float32 and torch.is_autocast_enabled():
                 x = x.to(torch.get_autocast_dtype("cuda"))      # what autocast would do for F.conv2d
                 fanin = None
-            y = _bn_tail_fused(_DepthwiseConv, (x, conv.weight, conv.stride[0], conv.padding[0], fanin), bn, a, lab, fanout=fanout)
+            y = _bn_tail_fused(_DepthwiseConv, (x, conv.weight, conv.stride[0], conv.padding[0], fanin), bn, a, lab)
             if y is not None:
                 return y
             y = _DepthwiseConv.apply(x, conv.weight, conv.stride[0], conv.padding[0])
@@ -1708,7 +1627,7 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
                         bn.num_batches_tracked.add_(1)
                 return _DenseConvBNAct.apply(xb, conv.weight, bn.weight, bn.bias, lab.scale if lab is not None else None,
                                              lab.bias if lab is not None else None, bn.running_mean, bn.running_var, a, training,
-                                             bn.momentum, bn.eps, fanin if xb is x else None, fanout, bnsrc if xb is x else None)
+                                             bn.momentum, bn.eps, fanin if xb is x else None)
             y = _DenseConv.apply(xb, conv.weight)
         elif route == 3:
             # maps wider than the kernel's 160-pixel strips (the 240-wide stage of D-FINE-l / x at 960 x 960): two column halves

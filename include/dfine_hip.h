@@ -200,18 +200,8 @@ int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_
                      const float *save_invstd, const float *scale, const float *shift,
                      const float *lab_scale, float *dgamma, float *dbeta, float *dlab, float *ws,
                      int dtype, int B, int C, int HW, int act, int training, void *stream);
-/* The same two ops with the reduction pass replaced by partial sums a convolution epilogue produced (DfineConvEpilogue
- * below): part [nchunk][C][2] (fwd) / [nchunk][C][4] (bwd), training mode, bf16, HW % 8 == 0, C <= 2048.  A slice-sum
- * kernel (fixed summation order) folds the chunks to <= 32 per channel, the flat apply pass finishes them in its prologue.
- * ws: dfine_bn_ws_floats(B, C, HW) floats of scratch. */
-int dfine_bn_act_fwd_part(const void *x, void *y, const float *gamma, const float *beta, float *running_mean,
-                          float *running_var, const float *lab_scale, const float *lab_bias, float *save_mean,
-                          float *save_invstd, float *scale, float *shift, const float *part, int nchunk, float *ws, int B,
-                          int C, int HW, int act, float momentum, float eps, void *stream);
-int dfine_bn_act_bwd_part(const void *x, const void *dy, void *dx, const float *save_mean, const float *save_invstd,
-                          const float *scale, const float *shift, const float *lab_scale, float *dgamma, float *dbeta,
-                          float *dlab, const float *part, int nchunk, float *ws, int B, int C, int HW, int act,
-                          void *stream);
+
+
 
 /* RepVGG unit: y = act(BN_a(x1) + BN_b(x2)) [+ residual] in one op (training mode, bf16 NCHW, H*W % 8 == 0).
  * Replaces VGGBlock.forward's two ConvNormLayer BatchNorms + add + activation and CSPLayer's residual add
@@ -390,31 +380,6 @@ int dfine_conv1x1_accum_bf16(const void *x, const void *w2, void *y, int B, int 
 int dfine_conv_epilogue_supported(int B, int Cin, int Cout, int H, int W, int KS);
 int dfine_conv_accum_bf16(const void *x, const void *w2, void *y, int B, int Cin, int Cout, int H, int W, int KS,
                           void *stream);
-/* BatchNorm sums formed in the store epilogue of a convolution (csrc/epi_bn.h).  The reference runs bn(conv(x)) as separate
- * ops (src/d_fine/arch/hgnetv2.py:75-80, hybrid_encoder.py:40-45): the BatchNorm reads the map once more for its batch
- * statistics (forward) and reads dy and the map once more for sum(dz), sum(dz * xhat) (backward).  Here the convolution that
- * PRODUCES those values adds them up while it stores them:
- *   mode 1 (forward convolution): per output channel, (sum, sum of squares) of the bf16 values stored - part [nchunk][Cout][2];
- *   mode 2 (data gradient of the BatchNorm's consumer, stored value = dy, after the `accum` add if there is one): per channel
- *     (sum dz, sum dz * xhat, sum dy * act(z), sum dy) with z = bn_x * scale + shift, dz = dy * lab_scale * act'(z),
- *     xhat = (bn_x - mean) * invstd - part [nchunk][Cout][4] (the last two are zero without lab_scale).
- * nchunk = dfine_conv_epilogue_chunks(...) for the SAME call (0: that shape / kernel has no such epilogue); every slot is
- * written, no atomics; dfine_bn_act_fwd_part / dfine_bn_act_bwd_part take the buffer in place of their own reduction pass.
- * dfine_conv_epilogue_once() arms the request for the NEXT convolution launch of the calling thread (dfine_conv_fwd_bf16,
- * dfine_conv_accum_bf16, dfine_conv1x1_accum_bf16, dfine_conv1x1_seg_fwd_bf16 with one output part); a launch that cannot
- * honour it returns DFINE_E_BADARG and drops it. */
-typedef struct DfineConvEpilogue {
-    int mode;                /* 1 | 2 */
-    int nchunk;
-    int act;                 /* mode 2: 0 none, 1 ReLU, 2 SiLU */
-    int cout;                /* output channels of the armed convolution (the channel pitch of `part`) */
-    float *part;
-    const void *bn_x;        /* mode 2: the BatchNorm's input, bf16 [B, Cout, H, W] */
-    const float *mean, *invstd, *scale, *shift;   /* mode 2: [Cout] */
-    const float *lab_scale;  /* mode 2: 1 float or NULL */
-} DfineConvEpilogue;
-int dfine_conv_epilogue_chunks(int B, int Cin, int Cout, int H, int W, int KS, int n_x_parts);
-int dfine_conv_epilogue_once(const DfineConvEpilogue *ep);
 /* Weight gradient of the same convolution: dw [Cout, Cin, KS, KS] f32 (overwritten) from x [B,Cin,H,W]
  * and dy [B,Cout,H,W] (bf16); ws = dfine_conv_wgrad_ws_floats(...) floats of scratch (split-K
  * partial sums).  KS = 3: W % 8 == 0 and W <= 160.  KS = 1: (H*W) % 8 == 0. */
@@ -504,11 +469,6 @@ int dfine_conv_wgrad1_group_splits(int B, int Cin, int Cout, int HW);
 int64_t dfine_conv_wgrad1_group_ws_floats(int B, int Cin, int Cout, int HW);
 int dfine_conv_wgrad1_group_row(const void *x, const void *dy, float *ws, int B, int Cin, int Cout, int HW, int64_t *row);
 int dfine_conv_wgrad1_group(const void *table, int n_problems, int max_blocks, void *stream);
-/* Tile class of a problem (64: both channel counts <= 128, launched by dfine_conv_wgrad1_group64 on 64 x 64 (n, c) tiles - a
- * quarter of the partial-sum slabs for the same number of workgroups; 128: dfine_conv_wgrad1_group).  All rows of one launch
- * must be of the launch's class; rows come from dfine_conv_wgrad1_group_row either way. */
-int dfine_conv_wgrad1_group_tile(int Cin, int Cout);
-int dfine_conv_wgrad1_group64(const void *table, int n_problems, int max_blocks, void *stream);
 int dfine_multi_wgrad_reduce_blocks(int splits, int64_t elems);   /* blocks one row of the table needs */
 int dfine_multi_wgrad_reduce(const void *table, int n_entries, int max_blocks, void *stream);
 

@@ -70,7 +70,6 @@ def test_packed_weight_caches_follow_weight_updates(cuda):
 
     kernels._CONV_PLAN.clear()
     import os
-    os.environ["DFINE_CONV_TUNE"] = "hip"
     kernels.reload_env()
     try:
         y1 = run()
@@ -94,7 +93,6 @@ def test_packed_weight_caches_follow_weight_updates(cuda):
             lin_w.add_(1.0)
         assert torch.allclose(kernels.bf16_param(lin_w).float(), b1.float() + 1.0, atol=2e-2)
     finally:
-        os.environ.pop("DFINE_CONV_TUNE", None)
         kernels.reload_env()
 
 

@@ -186,7 +186,6 @@ def test_full_size_train_step_properties(cuda, monkeypatch):
     import bench
     from custom_d_fine_amd import kernels
     from custom_d_fine_amd.dl.synthetic import make_batch
-    monkeypatch.setenv("DFINE_CONV_TUNE", "hip")            # no per-shape timing runs inside a test
     kernels.reload_env()
     try:
         step = bench.build_step("m", 640, cuda, torch.bfloat16)
@@ -216,7 +215,6 @@ def test_full_size_train_step_properties(cuda, monkeypatch):
                 assert len(rows) == len(cols) == min(n, 300)
                 assert len(set(rows.tolist())) == len(rows) and sorted(cols.tolist()) == list(range(n))
     finally:
-        monkeypatch.delenv("DFINE_CONV_TUNE", raising=False)
         kernels.reload_env()
 
 

@@ -41,7 +41,6 @@ if len(sys.argv) > 2 and sys.argv[1] == "child":
         mod = nn.Sequential(ConvBNAct(64, 64, 3, groups=64, use_lab=True), ConvBNAct(64, 64, 5, groups=64, use_lab=True)).to(dev).train()
         print("OK", run_gc(mod, (torch.randn(8, 64, 40, 40, device=dev, requires_grad=True).bfloat16().detach().requires_grad_(True),)))
     elif case == "light_unit_hip_conv":
-        os.environ["DFINE_CONV_TUNE"] = "hip"
         mod = nn.Sequential(LightConvBNAct(64, 64, 5, use_lab=True), ConvBNAct(64, 64, 3, use_lab=True)).to(dev).train()
         print("OK", run_gc(mod, (torch.randn(8, 64, 40, 40, device=dev, requires_grad=True),)))
     elif case == "linear_only":

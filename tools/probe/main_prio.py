@@ -1,7 +1,9 @@
-"""Does a high-priority MAIN stream (torch priority -1) change the step time?  (side stream priority from DFINE_SIDE_PRIORITY)"""
+"""Does a high-priority MAIN stream (torch priority -1) change the step time?  (side stream priority: SIDE_PRIO -> hip._SIDE_PRIORITY)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, bench
+from custom_d_fine_amd import hip
+hip._SIDE_PRIORITY = int(os.environ.get("SIDE_PRIO", "0"))      # read when the side stream is first made
 from custom_d_fine_amd.dl.synthetic import make_batch
 dev = torch.device("cuda", 0)
 prio = int(os.environ.get("MAIN_PRIO", "0"))
@@ -16,4 +18,4 @@ with torch.cuda.stream(st):
     for _ in range(40):
         step(images, targets)
     torch.cuda.synchronize()
-    print(f"main prio {prio} side prio {os.environ.get('DFINE_SIDE_PRIORITY', '0')}: {(time.perf_counter() - t0) / 40 * 1e3:.3f} ms/step")
+    print(f"main prio {prio} side prio {hip._SIDE_PRIORITY}: {(time.perf_counter() - t0) / 40 * 1e3:.3f} ms/step")
