@@ -689,16 +689,15 @@ int dfine_attn_bwd_ms(const void *q, const void *k, const void *v, const void *o
 #undef DFINE_DKDV64
         return check_launch();
     }
-    // keys per workgroup: 512 (<4, 8>, <8, 4>), 256 (<2, 8>), 128 (<2, 4>): fewer keys = more workgroups for the same L
-    constexpr int var = 48;
+    // keys per workgroup: 512 as 8 waves x 64 keys (measured against <8, 4> (512 keys), <2, 8> (256), <4, 4> (256), <2, 4> (128): fewer keys =
+    // more workgroups for the same L, but every workgroup walks all the queries - none was faster at the decoder's L ~ 500)
 #define DFINE_DKDV_M(KT_, NW_, MM_)                                                                                                    \
     { const int nk = (L + 16 * KT_ * NW_ - 1) / (16 * KT_ * NW_);                                                                      \
       hipLaunchKernelGGL((attn_bwd_dkdv_kernel<KT_, NW_, MM_>), dim3(B * H * nk), dim3(64 * NW_), 0, st, (const uint16_t *)q, (const uint16_t *)k, \
                          (const uint16_t *)v, (const uint16_t *)dout, lse2, (const float *)delta, mask, mask_bits, msumT, (uint16_t *)dk, (uint16_t *)dv, \
                          B, L, H, ldq, ldk, ldv, lddo, lddk, lddv, scale, c); }
 #define DFINE_DKDV(KT_, NW_) { if (!mask) DFINE_DKDV_M(KT_, NW_, 0) else if (mask_bits) DFINE_DKDV_M(KT_, NW_, 2) else DFINE_DKDV_M(KT_, NW_, 1) }
-    if (var == 84) DFINE_DKDV(8, 4) else if (var == 28) DFINE_DKDV(2, 8) else if (var == 44) DFINE_DKDV(4, 4) else if (var == 24) DFINE_DKDV(2, 4)
-    else DFINE_DKDV(4, 8)
+    DFINE_DKDV(4, 8)
 #undef DFINE_DKDV_M
 #undef DFINE_DKDV
     return check_launch();

@@ -26,6 +26,11 @@ typedef __attribute__((ext_vector_type(4))) float g_f32x4;
 constexpr int kGemmThreads = 256;
 constexpr int kGBN = 128, kGBK = 64, kGPitch = 72;
 
+constexpr int kActMask = 5;      // "activation" code of the data-gradient form: Y = (X W^T) where aux[m][n] > 0, else 0 (aux rides in `bias`)
+
+// bf16 value > 0 (what ATen's threshold_backward tests on the saved ReLU output): not NaN-aware beyond "sign clear, non-zero"
+__device__ __forceinline__ bool relu_mask_keep(uint16_t bits) { return bits != 0 && !(bits & 0x8000u) && !((bits & 0x7f80u) == 0x7f80u && (bits & 0x7fu)); }
+
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == 1) return fmaxf(v, 0.f);
     if (act == 2) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));      // exact GELU (nn.GELU default)
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(kGemmThreads) void linear_act_kernel(const uint16_t
         const int n = n0 + wn * 64 + a * 16 + 4 * g;
         if (n >= N) continue;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
+        if (ACT != kActMask && bias) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (n + r < N) bv[r] = bias[n + r];
         }
@@ -142,6 +147,18 @@ __global__ __launch_bounds__(kGemmThreads) void linear_act_kernel(const uint16_t
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = act_apply(acc[a][b][r] + bv[r], ACT);
+            if (ACT == kActMask) {                       // ReLU backward by the saved output: keep where aux[m][n] > 0
+                const uint16_t *ap = reinterpret_cast<const uint16_t *>(bias) + (int64_t)m * ldy + n;
+                uint16_t av[4] = {0, 0, 0, 0};
+                if (vec_y && n + 3 < N) {
+                    const uint2 q = *reinterpret_cast<const uint2 *>(ap);
+                    av[0] = q.x & 0xffffu; av[1] = q.x >> 16; av[2] = q.y & 0xffffu; av[3] = q.y >> 16;
+                } else {
+                    for (int r = 0; r < 4 && n + r < N; ++r) av[r] = ap[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = relu_mask_keep(av[r]) ? v[r] : 0.f;
+            }
             if (OUT32) {
                 float *yp = reinterpret_cast<float *>(yv) + (int64_t)m * ldy + n;
                 if (vec_y && n + 3 < N) *reinterpret_cast<float4 *>(yp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -263,7 +280,7 @@ __global__ __launch_bounds__(kLRThreads) void linear_ring_kernel(const uint16_t 
         // the bias is fetched HERE: a load in the epilogue would be waited for with the copies of the next tile in front of it
         float bv[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) bv[e] = (bias && n + e < N) ? bias[n + e] : 0.f;
+        for (int e = 0; e < 16; ++e) bv[e] = (ACT != kActMask && bias && n + e < N) ? bias[n + e] : 0.f;
         for (int s = 0; s < nk; ++s, ++q) {
             // loads return in order: "at most (younger copies) outstanding" means this stage has landed (stores of the
             // previous tile may still be counted - the wait is then longer than needed, never shorter)
@@ -306,6 +323,23 @@ __global__ __launch_bounds__(kLRThreads) void linear_ring_kernel(const uint16_t 
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[4 * a + r] = act_apply(acc[a][b][r] + bv[4 * a + r], ACT);
+            if (ACT == kActMask) {                       // ReLU backward by the saved output: keep where aux[m][n] > 0
+                const uint16_t *ap = reinterpret_cast<const uint16_t *>(bias) + (int64_t)m * ldy + n;
+                if (full && (ldy & 7) == 0) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const uint4 q = reinterpret_cast<const uint4 *>(ap)[e];
+                        const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (!relu_mask_keep((uint16_t)(qw[j] & 0xffffu))) v[8 * e + 2 * j] = 0.f;
+                            if (!relu_mask_keep((uint16_t)(qw[j] >> 16))) v[8 * e + 2 * j + 1] = 0.f;
+                        }
+                    }
+                } else {
+                    for (int e = 0; e < 16 && n + e < N; ++e) if (!relu_mask_keep(ap[e])) v[e] = 0.f;
+                }
+            }
             if (OUT32) {
                 float *yp = reinterpret_cast<float *>(yv) + (int64_t)m * ldy + n;
                 if (full && (ldy & 3) == 0) {
@@ -411,10 +445,12 @@ using namespace dfine;
 
 extern "C" {
 
-int dfine_linear_act_fwd(const void *x, const void *w, const float *bias, void *y, int M, int N, int K, int ldx, int ldw,
+static int linear_launch(const void *x, const void *w, const float *bias, void *y, int M, int N, int K, int ldx, int ldw,
                          int ldy, int act, int out_f32, void *stream) {
     if (M == 0 || N == 0) return DFINE_OK;
-    if (!x || !w || !y || M < 0 || N < 0 || K < 1 || ldx < K || ldw < K || ldy < N || act < 0 || act > 3) return DFINE_E_BADARG;
+    if (!x || !w || !y || M < 0 || N < 0 || K < 1 || ldx < K || ldw < K || ldy < N || act < 0 || act > kActMask || act == 4 ||
+        (act == kActMask && out_f32))
+        return DFINE_E_BADARG;
     const int nt_n = (N + kGBN - 1) / kGBN;
     hipStream_t st = (hipStream_t)stream;
     constexpr int ring_env = -1;   // 0 off, 1/2/4 forces MT
@@ -440,6 +476,7 @@ int dfine_linear_act_fwd(const void *x, const void *w, const float *bias, void *
             hipError_t e = hipSuccess;
             DFINE_LR_ATTR_A(0, 1, 3) DFINE_LR_ATTR_A(1, 1, 3) DFINE_LR_ATTR_A(0, 2, 4) DFINE_LR_ATTR_A(1, 2, 4)
             DFINE_LR_ATTR_A(0, 4, 3) DFINE_LR_ATTR_A(1, 4, 3)
+            DFINE_LR_ATTR(kActMask, 0, 1, 3) DFINE_LR_ATTR(kActMask, 0, 2, 4) DFINE_LR_ATTR(kActMask, 0, 4, 3)
             if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
             ring_attr = true;
         }
@@ -454,6 +491,7 @@ int dfine_linear_act_fwd(const void *x, const void *w, const float *bias, void *
             case 0: DFINE_LR_O(0) break;
             case 1: DFINE_LR_O(1) break;
             case 2: DFINE_LR_O(2) break;
+            case kActMask: DFINE_LR_T(kActMask, 0) break;
             default: DFINE_LR_O(3) break;
         }
 #undef DFINE_LR_O
@@ -479,6 +517,7 @@ int dfine_linear_act_fwd(const void *x, const void *w, const float *bias, void *
         DFINE_LA_ATTR(0, 1, 4) DFINE_LA_ATTR(1, 1, 4) DFINE_LA_ATTR(2, 1, 4) DFINE_LA_ATTR(3, 1, 4)
         DFINE_LA_ATTR(0, 0, 2) DFINE_LA_ATTR(1, 0, 2) DFINE_LA_ATTR(2, 0, 2) DFINE_LA_ATTR(3, 0, 2)
         DFINE_LA_ATTR(0, 1, 2) DFINE_LA_ATTR(1, 1, 2) DFINE_LA_ATTR(2, 1, 2) DFINE_LA_ATTR(3, 1, 2)
+        DFINE_LA_ATTR(kActMask, 0, 4) DFINE_LA_ATTR(kActMask, 0, 2)
         if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
         attr_set = true;
     }
@@ -492,12 +531,29 @@ int dfine_linear_act_fwd(const void *x, const void *w, const float *bias, void *
         case 0: DFINE_LA_O(0) break;
         case 1: DFINE_LA_O(1) break;
         case 2: DFINE_LA_O(2) break;
+        case kActMask: DFINE_LA_T(kActMask, 0) break;
         default: DFINE_LA_O(3) break;
     }
 #undef DFINE_LA_O
 #undef DFINE_LA_T
 #undef DFINE_LA
     return check_launch();
+}
+
+int dfine_linear_act_fwd(const void *x, const void *w, const float *bias, void *y, int M, int N, int K, int ldx, int ldw,
+                         int ldy, int act, int out_f32, void *stream) {
+    if (act < 0 || act > 3) return DFINE_E_BADARG;
+    return linear_launch(x, w, bias, y, M, N, K, ldx, ldw, ldy, act, out_f32, stream);
+}
+
+// dX[M, N] = (dY[M, K] . W[N, K]^T) masked by a saved ReLU output: dX[m][n] = 0 where aux[m][n] <= 0 (aux bf16 [M, N], ld = ldy).
+// The data gradient of the layer BEHIND a Linear + ReLU with the ReLU's backward in its store epilogue (MLP / FFN of the decoder,
+// reference dfine_decoder.py:33-46,214-231: ATen runs threshold_backward as its own pass).  bf16 output; same shape rules as
+// dfine_linear_act_fwd.
+int dfine_linear_dgrad_relu(const void *x, const void *w, const void *aux, void *y, int M, int N, int K, int ldx, int ldw, int ldy,
+                            void *stream) {
+    if (!aux) return DFINE_E_BADARG;
+    return linear_launch(x, w, reinterpret_cast<const float *>(aux), y, M, N, K, ldx, ldw, ldy, kActMask, 0, stream);
 }
 
 // table: device int64 [n_entries][4] = {src fp32 [rows, cols], dst bf16 [cols, rows], rows, cols}

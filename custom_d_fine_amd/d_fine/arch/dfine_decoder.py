@@ -35,6 +35,8 @@ class MLP(nn.Module):
         self.act = get_activation(act)
 
     def forward(self, x):
+        if isinstance(self.act, nn.ReLU) and self.num_layers >= 2:
+            return kernels.mlp_relu(x, list(self.layers))       # one autograd node, ReLU backward in the data-gradient epilogues
         for layer in self.layers[:-1]:
             x = kernels.linear(x, layer.weight, layer.bias, act=self.act)
         last = self.layers[-1]
@@ -156,6 +158,8 @@ class TransformerDecoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, tgt):
+        if isinstance(self.activation, nn.ReLU) and (self.dropout3.p == 0.0 or not self.training):
+            return kernels.mlp_relu(tgt, [self.linear1, self.linear2])
         h = self.dropout3(kernels.linear(tgt, self.linear1.weight, self.linear1.bias, act=self.activation))
         return kernels.linear(h, self.linear2.weight, self.linear2.bias)
 

@@ -99,6 +99,7 @@ _SIGNATURES = {
     "dfine_conv_wgrad1_group_row": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dfine_conv_wgrad1_group": (c_int, [_P, _I, _I, _P]),
     "dfine_linear_act_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_linear_dgrad_relu": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_multi_cast_bf16_t": (c_int, [_P, _I, _P]),
     "dfine_act_fwd_bf16": (c_int, [_P, _P, _L, _I, _P]),
     "dfine_act_bwd_bf16": (c_int, [_P, _P, _P, _L, _I, _P]),
@@ -1273,6 +1274,20 @@ def linear_act(x2d, w, bias=None, act=0, out_f32=False, out=None):
         _check(_lib.dfine_linear_act_fwd(_ptr(x2d), _ptr(w), _ptr(bias), _ptr(out), M, N, K, ldx, ldw,
                                          out.stride(0) if M > 1 else N, int(act), int(out.dtype == torch.float32), _stream()),
                "dfine_linear_act_fwd")
+    return out
+
+
+def linear_dgrad_relu(d2, w_t, relu_out):
+    """(d2 [M, K] @ w_t [N, K]^T) masked by relu_out [M, N] > 0 -> [M, N] bf16: the data gradient of the layer behind a
+    Linear + ReLU with the ReLU's backward in the epilogue (dfine_linear_dgrad_relu)."""
+    M, K = d2.shape
+    N = w_t.shape[0]
+    assert w_t.shape[1] == K and (K == 1 or (d2.stride(1) == 1 and w_t.stride(1) == 1)) and relu_out.shape == (M, N) and relu_out.is_contiguous()
+    assert d2.dtype == torch.bfloat16 and w_t.dtype == torch.bfloat16 and relu_out.dtype == torch.bfloat16
+    out = torch.empty(M, N, device=d2.device, dtype=torch.bfloat16)
+    with _timed("linear", 2.0 * M * N * K, io=2.0 * (M * K + N * K + 2 * M * N)):
+        _check(_lib.dfine_linear_dgrad_relu(_ptr(d2), _ptr(w_t), _ptr(relu_out), _ptr(out), M, N, K, d2.stride(0) if M > 1 else K,
+                                            w_t.stride(0) if N > 1 else K, N, _stream()), "dfine_linear_dgrad_relu")
     return out
 
 

@@ -1995,6 +1995,87 @@ class _LinearAct(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _MLPRelu(torch.autograd.Function):
+    """Linear -> ReLU -> Linear [-> ReLU -> Linear ...] (MLP heads, the decoder's FFN: ref dfine_decoder.py:33-46,214-231) as ONE
+    autograd node.  Forward: the _LinearAct kernels, layer by layer.  Backward: the data gradient of layer i + 1 carries the
+    ReLU backward of layer i in its store epilogue (dfine_linear_dgrad_relu: masked by the saved output) - the reference, and
+    one _LinearAct per layer, run threshold_backward as a pass of its own between the two GEMMs (24 launches per D-FINE-m step);
+    the weight gradients are registered for the grouped launch as before.  Same values as the per-layer composition."""
+
+    @staticmethod
+    def forward(ctx, x, n, *params):
+        hip = _hip()
+        ws, bs = params[:n], params[n:]
+        h = _bf16_2d(x)
+        saved = [h]
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            y = torch.empty(h.shape[0], w.shape[0], device=x.device, dtype=torch.bfloat16)
+            hip.linear_act(h, bf16_param(w), _f32_vec(b), 1 if i + 1 < n else 0, out=y)
+            h = y
+            if i + 1 < n:
+                saved.append(h)
+        ctx.save_for_backward(*saved, *ws)
+        ctx.meta = (n, x.dtype, x.shape, tuple(b is not None for b in bs))
+        ctx.slots = []
+        need = ctx.needs_input_grad
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            slot = None
+            if need[2 + i] and (b is None or need[2 + n + i]):
+                slot = _defer_slot(w) if b is None else _defer_slot(w, b)
+                if slot is not None:
+                    for k in slot[1]:
+                        slot[0].note_use(k)
+            ctx.slots.append(slot)
+        return h.view(*x.shape[:-1], ws[-1].shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        hip = _hip()
+        n, xdt, xshape, has_bias = ctx.meta
+        saved = ctx.saved_tensors
+        acts, ws = saved[:n], saved[n:]
+        need = ctx.needs_input_grad
+        d2 = _bf16_2d(dy)
+        dws, dbs = [None] * n, [None] * n
+        dx = None
+        for i in range(n - 1, -1, -1):
+            w, xin, slot = ws[i], acts[i], ctx.slots[i]
+            want_db = has_bias[i] and need[2 + n + i]
+            # the data gradient first: the weight gradient below is only registered (grouped launch at the flush)
+            nxt = None
+            if i > 0:
+                nxt = hip.linear_dgrad_relu(d2, bf16_param_t(w), xin)
+            elif need[0]:
+                dx = hip.linear_act(d2, bf16_param_t(w), None, 0, out_f32=xdt == torch.float32).view(xshape)
+            if slot is not None:
+                fused, idx = slot
+                wsp, wmeta, bmeta, boff = hip.linear_wgrad_partials(xin, d2)
+                fused.defer_wgrad(idx[0], wsp, wmeta)
+                if has_bias[i]:
+                    fused.defer_wgrad(idx[1], wsp, bmeta, ws_offset=boff)
+                for k in idx:
+                    fused.use_done(k)
+            elif need[2 + i] or want_db:
+                res = hip.linear_wgrad_bf16(xin, d2, with_bias=want_db)
+                dws[i], dbs[i] = res if want_db else (res, None)
+                if dws[i].dtype != w.dtype:
+                    dws[i] = dws[i].to(w.dtype)
+            d2 = nxt
+        return (dx, None, *dws, *dbs)
+
+
+def mlp_relu(x, layers):
+    """layers[-1](relu(... relu(layers[0](x)))) for nn.Linear `layers` (>= 2).  CUDA under bf16 autocast: one autograd node with the
+    ReLU backward fused into the data-gradient GEMMs (_MLPRelu); otherwise the per-layer `linear` composition."""
+    ws = [m.weight for m in layers]
+    if (len(layers) >= 2 and x.numel() > 0 and all(_hip_linear_ok(x, w) for w in ws)
+            and all(w.shape[0] % 8 == 0 for w in ws[:-1]) and torch.is_grad_enabled()):
+        return _MLPRelu.apply(x, len(layers), *ws, *[m.bias for m in layers])
+    for m in layers[:-1]:
+        x = linear(x, m.weight, m.bias, act="relu")
+    return linear(x, layers[-1].weight, layers[-1].bias)
+
+
 class _ClampPos(torch.autograd.Function):
     """clamp(x, -10, 10) of the decoder's query position embedding (ref dfine_decoder.py:466) as one launch each way: ATen's
     ClampBackward1 is two compares, a logical and a multiply - 4 launches per decoder layer in the host-paced stretch of the

@@ -488,6 +488,12 @@ int dfine_multi_wgrad_reduce(const void *table, int n_entries, int max_blocks, v
  */
 int dfine_linear_act_fwd(const void *x, const void *w, const float *bias, void *y, int M, int N, int K, int ldx,
                          int ldw, int ldy, int act, int out_f32, void *stream);
+/* dX [M, N] bf16 = (dY [M, K] . W [N, K]^T) where aux[m][n] > 0, else 0 (aux bf16 [M, N], row stride ldy): the data gradient of the
+ * layer BEHIND a Linear + ReLU with that ReLU's backward in the store epilogue - the reference runs threshold_backward as its own
+ * pass between the layers of MLP / FFN (src/d_fine/arch/dfine_decoder.py:33-46,214-231).  Same values as the two-pass form (the
+ * mask is applied before the one rounding to bf16). */
+int dfine_linear_dgrad_relu(const void *x, const void *w, const void *aux, void *y, int M, int N, int K, int ldx, int ldw,
+                            int ldy, void *stream);
 int dfine_multi_cast_bf16_t(const void *table, int n_entries, void *stream);
 int dfine_act_fwd_bf16(const void *z, void *y, int64_t n, int act, void *stream);
 int dfine_act_bwd_bf16(const void *dy, const void *ref, void *out, int64_t n, int act, void *stream);

@@ -82,3 +82,45 @@ def test_embedding_backward_scan_kernel(cuda, n, rows, D, pad):
         out.backward(g.view(1, n, D))
         torch.cuda.synchronize()
         assert torch.allclose(emb.weight.grad, want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("dims,rows", [((256, 1024, 256), (32, 496)), ((256, 256, 256, 132), (32, 496)), ((4, 512, 256), (32, 496)),
+                                       ((20, 64, 1), (7, 301)), ((256, 256, 4), (3, 300))])
+def test_mlp_relu_fused_backward_matches_per_layer_composition(cuda, dims, rows):
+    """kernels.mlp_relu (one autograd node, the ReLU backward in the data-gradient epilogue: dfine_linear_dgrad_relu) against the
+    per-layer kernels.linear composition it replaces: outputs and every gradient BIT-identical (the mask is applied before the one
+    rounding to bf16), for the MLP shapes of the decoder (FFN, box heads, query position head 4 -> 512 -> 256, LQE 20 -> 64 -> 1);
+    and the masked data gradient against fp32 math on the same bf16-rounded operands."""
+    torch.manual_seed(len(dims) + dims[0])
+    layers = [torch.nn.Linear(a, b).to(cuda) for a, b in zip(dims[:-1], dims[1:])]
+    x = torch.randn(*rows, dims[0], device=cuda)
+
+    def run(fused):
+        xin = x.clone().requires_grad_(True)
+        for l in layers:
+            l.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if fused:
+                y = kernels.mlp_relu(xin, layers)
+            else:
+                h = xin
+                for l in layers[:-1]:
+                    h = kernels.linear(h, l.weight, l.bias, act="relu")
+                y = kernels.linear(h, layers[-1].weight, layers[-1].bias)
+        go = torch.randn(y.shape, device=cuda, generator=torch.Generator(device="cuda").manual_seed(5)).to(y.dtype)
+        y.backward(go)
+        return [y.detach(), xin.grad] + [l.weight.grad.clone() for l in layers] + [l.bias.grad.clone() for l in layers]
+
+    a, b = run(True), run(False)
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert u.dtype == v.dtype and torch.equal(u, v), f"tensor {i}: fused MLP differs from the per-layer composition"
+    # the epilogue form on its own, vs fp32
+    M, K, N = 4099, 132, 256
+    d2 = torch.randn(M, K, device=cuda).bfloat16()
+    wt = torch.randn(N, K, device=cuda).bfloat16()
+    h = torch.randn(M, N, device=cuda).relu().bfloat16()
+    h[0, :8] = torch.tensor([0.0, -0.0, 1e-30, float("inf"), float("nan"), 1.0, -1.0, 0.5], device=cuda).bfloat16()
+    got = hipmod.linear_dgrad_relu(d2, wt, h).float()
+    ref = (d2.float() @ wt.float().t()) * (h.float() > 0)
+    assert torch.allclose(got, ref, rtol=1e-2, atol=1e-2 * ref.abs().max().item())
+    assert torch.equal(got == 0, ~(h.float() > 0) | (ref == 0))
