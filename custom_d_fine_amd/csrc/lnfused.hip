@@ -287,16 +287,18 @@ static int ln_bwd_blocks(int64_t rows) {
 
 int64_t dfine_ln_fused_bwd_ws_floats(int64_t rows, int D) { return (int64_t)ln_bwd_blocks(rows) * 2 * D; }
 
-// da / db / dgate: storage types of a / b / gate (any may be NULL); dweight / dbias fp32 [D] (overwritten; both NULL =
-// not needed); ws: dfine_ln_fused_bwd_ws_floats(rows, D) floats (per-block column partial sums).
+// da / db / dgate: storage types of a / b / gate (any may be NULL); dweight / dbias fp32 [D] (overwritten); ws:
+// dfine_ln_fused_bwd_ws_floats(rows, D) floats - per-block column partial sums [blocks][2][D] (row 0: weight, row 1: bias), written
+// whenever ws is given; dweight / dbias both NULL with ws given = partial sums only (the caller reduces them later, e.g. with
+// the step's other deferred reductions: dfine_multi_wgrad_reduce rows {splits = blocks, Cout = D, Cin = taps = CP16 = 1, NP16 = 2 D}).
 int dfine_ln_fused_bwd(int mode, const void *a, int a_dt, const void *b, int b_dt, const void *gate, int g_dt,
                        const float *weight, const float *mean, const float *rstd, const float *dy, float clampv,
                        void *da, void *db, void *dgate, float *dweight, float *dbias, float *ws, int64_t rows, int D,
                        void *stream) {
     if (rows == 0) return DFINE_OK;
     if (!ln_args_ok(mode, a, b, gate, a_dt, b_dt, g_dt, D) || !weight || !mean || !rstd || !dy || rows < 0) return DFINE_E_BADARG;
-    const bool affine = dweight || dbias;
-    if (affine && !ws) return DFINE_E_BADARG;
+    if ((dweight || dbias) && !ws) return DFINE_E_BADARG;
+    const bool affine = ws != nullptr;
     LnArgs p{a, b, gate, a_dt, b_dt, g_dt, mode, clampv};
     const int blocks = ln_bwd_blocks(rows);
     float *partial = affine ? ws : nullptr;
@@ -304,7 +306,7 @@ int dfine_ln_fused_bwd(int mode, const void *a, int a_dt, const void *b, int b_d
                                                  (hipStream_t)stream, p, weight, mean, rstd, dy, da, db, dgate, partial,
                                                  rows, D))
     if (int e = check_launch()) return e;
-    if (affine)
+    if (dweight || dbias)
         hipLaunchKernelGGL(ln_colsum_reduce_kernel, dim3((D + 15) / 16, 2), dim3(256), 0, (hipStream_t)stream, ws, blocks, D,
                            dweight, dbias);
     return check_launch();

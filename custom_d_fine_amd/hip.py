@@ -1702,7 +1702,9 @@ def ln_fused_forward(mode, a, b, gate, weight, bias, eps, clampv, with_bf16=Fals
     return (y, mean, rstd, y16) if with_bf16 else (y, mean, rstd)
 
 
-def ln_fused_backward(mode, a, b, gate, weight, mean, rstd, dy, clampv, need_a, need_b, need_gate, need_affine):
+def ln_fused_backward(mode, a, b, gate, weight, mean, rstd, dy, clampv, need_a, need_b, need_gate, need_affine, partials=False):
+    """partials: the affine gradients are left as per-block partial sums - returns (da, db, dg, ws, blocks) with ws [blocks, 2, D]
+    (row 0: weight, row 1: bias) for a deferred reduction instead of (da, db, dg, dweight, dbias)."""
     D = a.shape[-1]
     rows = a.numel() // D
     da = torch.empty_like(a) if need_a else None
@@ -1711,12 +1713,15 @@ def ln_fused_backward(mode, a, b, gate, weight, mean, rstd, dy, clampv, need_a, 
     dw = dbias = ws = None
     if need_affine:
         # two tensors, not two rows of one: AccumulateGrad adopts a whole tensor but copies a view
-        dw = torch.empty(D, device=a.device, dtype=torch.float32)
-        dbias = torch.empty(D, device=a.device, dtype=torch.float32)
+        if not partials:
+            dw = torch.empty(D, device=a.device, dtype=torch.float32)
+            dbias = torch.empty(D, device=a.device, dtype=torch.float32)
         ws = torch.empty(int(_PURE.dfine_ln_fused_bwd_ws_floats(rows, D)), device=a.device, dtype=torch.float32)
     _check(_lib.dfine_ln_fused_bwd(mode, _ptr(a), _dt(a), _ptr(b), _dt(b), _ptr(gate), _dt(gate), _ptr(weight), _ptr(mean),
                                    _ptr(rstd), _ptr(dy), float(clampv), _ptr(da), _ptr(db), _ptr(dg), _ptr(dw), _ptr(dbias),
                                    _ptr(ws), rows, D, _stream()), "dfine_ln_fused_bwd")
+    if partials and need_affine:
+        return da, db, dg, ws, ws.numel() // (2 * D)
     return da, db, dg, dw, dbias
 
 

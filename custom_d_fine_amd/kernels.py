@@ -1842,6 +1842,9 @@ def _act_lab_torch(y, act, lab):
 _LN_DIMS = (64, 128, 256, 384, 512, 1024)
 
 
+LN_DEFER = True       # (tools/ab_step.py kernels.LN_DEFER)
+
+
 class _LNFused(torch.autograd.Function):
     """mode 0: LN(a + b); mode 1: LN(clamp(a + b)); mode 2: LN(sigmoid(g[:, :D]) * a + sigmoid(g[:, D:]) * b)."""
 
@@ -1859,6 +1862,14 @@ class _LNFused(torch.autograd.Function):
             y, mean, rstd = _hip().ln_fused_forward(mode, a, b, gate, weight, bias, eps, clampv)
         ctx.save_for_backward(a, b, gate, weight, mean, rstd)
         ctx.cfg = (mode, clampv, bias is not None)
+        # the affine gradients ride in the step's deferred split reduction (one launch for every conv / linear / LayerNorm
+        # parameter) instead of a column-sum launch per LayerNorm: 13 per D-FINE-m step
+        ctx.slot = None
+        if LN_DEFER and bias is not None and ctx.needs_input_grad[4] and ctx.needs_input_grad[5]:
+            ctx.slot = _defer_slot(weight, bias)
+            if ctx.slot is not None:
+                for i in ctx.slot[1]:
+                    ctx.slot[0].note_use(i)
         return y
 
     @staticmethod
@@ -1869,6 +1880,17 @@ class _LNFused(torch.autograd.Function):
         if dy.dtype != torch.float32:
             dy = dy.float()
         need = ctx.needs_input_grad
+        if ctx.slot is not None:
+            fused, idx = ctx.slot
+            da, db, dg, ws, blocks = _hip().ln_fused_backward(mode, a, b, gate, weight, mean, rstd, dy, clampv, need[1], need[2],
+                                                              need[3], True, partials=True)
+            D = weight.numel()
+            meta = (blocks, D, 1, 1, 2 * D, 1)               # [blocks][2 D] rows: a "bias" row of the deferred reduction
+            fused.defer_wgrad(idx[0], ws, meta)
+            fused.defer_wgrad(idx[1], ws, meta, ws_offset=D)
+            for i in idx:
+                fused.use_done(i)
+            return None, da, db, dg, None, None, None, None
         da, db, dg, dw, dbias = _hip().ln_fused_backward(mode, a, b, gate, weight, mean, rstd, dy, clampv, need[1],
                                                          need[2], need[3], need[4] or (has_bias and need[5]))
         return None, da, db, dg, (dw if need[4] else None), (dbias if has_bias and need[5] else None), None, None
@@ -2064,11 +2086,14 @@ class _MLPRelu(torch.autograd.Function):
         return (dx, None, *dws, *dbs)
 
 
+MLP_FUSED = True      # (tools/ab_step.py kernels.MLP_FUSED flips it for an in-process A/B)
+
+
 def mlp_relu(x, layers):
     """layers[-1](relu(... relu(layers[0](x)))) for nn.Linear `layers` (>= 2).  CUDA under bf16 autocast: one autograd node with the
     ReLU backward fused into the data-gradient GEMMs (_MLPRelu); otherwise the per-layer `linear` composition."""
     ws = [m.weight for m in layers]
-    if (len(layers) >= 2 and x.numel() > 0 and all(_hip_linear_ok(x, w) for w in ws)
+    if (MLP_FUSED and len(layers) >= 2 and x.numel() > 0 and all(_hip_linear_ok(x, w) for w in ws)
             and all(w.shape[0] % 8 == 0 for w in ws[:-1]) and torch.is_grad_enabled()):
         return _MLPRelu.apply(x, len(layers), *ws, *[m.bias for m in layers])
     for m in layers[:-1]:
