@@ -1046,7 +1046,6 @@ static ChanSegs one_seg(const void *p, int C) {
 // tile choice of the LDS-DMA 1x1 kernel for one layer
 struct C1Cfg { bool n256, px256, wide2, ring2, ximg; int tp, ptiles2, total2, nblk2; };
 static C1Cfg conv1x1_cfg(int B, int NP, int KP, int HW, bool seg, bool per_image_weights) {
-    constexpr int px256_env = 1;
     // The kernel is bound by the ~10 B/clk/CU load path, so the tile is as large as the layer can fill the chip with:
     // 256 pixels x 128 channels (87 FLOP per loaded byte) for deep layers on big maps, 128 x 128 (64) / 128 x 64 otherwise.
     // Three tile regimes (tools/conv1x1_bench.py, 26 layer shapes of D-FINE-m, forward: 1364 us with the round-4 choice ->
@@ -1063,16 +1062,13 @@ static C1Cfg conv1x1_cfg(int B, int NP, int KP, int HW, bool seg, bool per_image
     const bool n128 = NP % 128 == 0;
     // whole tensors with shared weights: pixel tiles over the B * HW pixels of the batch whenever per-image tiles would
     // leave the last one partly empty (20 x 20 planes: 400 pixels = 3.1 tiles of 128; 40 x 40: 6.25 tiles of 256)
-    constexpr int ximg_env = 1;
-    constexpr int n256_env = 1;
-    constexpr int small_env = 1;
-    const bool xok = ximg_env && !seg && !per_image_weights;
+    const bool xok = !seg && !per_image_weights;
     const int64_t gpix = (int64_t)B * HW;
     const int64_t t256 = xok ? (gpix + 255) / 256 : (int64_t)B * ((HW + 255) / 256);
-    const bool px256c = px256_env && n128 && !classic2 && (xok || HW % 256 == 0 || HW >= 1536) && t256 * (NP / 128) >= 256;
+    const bool px256c = n128 && !classic2 && (xok || HW % 256 == 0 || HW >= 1536) && t256 * (NP / 128) >= 256;
     const int64_t blk256 = t256 * (NP / 256);
-    c.n256 = n256_env && px256c && NP % 256 == 0 && KP >= 512 && blk256 >= 200 && !(blk256 > 256 && blk256 < 384);
-    const bool small = small_env && !c.n256 && !classic2;
+    c.n256 = px256c && NP % 256 == 0 && KP >= 512 && blk256 >= 200 && !(blk256 > 256 && blk256 < 384);
+    const bool small = !c.n256 && !classic2;
     c.ring2 = classic2 || small;
     c.px256 = c.n256 || (px256c && !small);
     c.tp = c.px256 ? 256 : kTrPix;
@@ -1132,9 +1128,7 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
     }
     if (xsegs || ysegs || accum || accum_parts || w_bstride) return DFINE_E_BADARG;  // the first-generation kernel takes whole tensors, shared weights, no accumulation
     const int vec = (HW % 8 == 0) ? 8 : (HW % 4 == 0 ? 4 : 2);
-    constexpr int kc_env = 0;
     int kc = KP >= 128 ? 4 : (KP >= 64 ? 2 : 1);
-    if (kc_env) kc = kc_env;
     while (kc > 1 && KP < 32 * kc) kc >>= 1;
     const bool wide = (NP % 128 == 0) && ((int64_t)B * ptiles * (NP / 128) >= 512);
     const int nblk = wide ? NP / 128 : (NP + 63) / 64;
@@ -1205,7 +1199,6 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_wgrad_kernel(      // tw
 #pragma unroll
         for (int t = 0; t < KS; ++t) acc[ct][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
     const int n_lane = nt64 * 64 + wave * 16 + (lane & 15);
-    const bool wave_active = nt64 * 64 + wave * 16 < Cout;
     const int c_base = ct64 * 64;
     const int nv = W / 8;
     const int nstage = 64 * R * nv;
@@ -1843,18 +1836,15 @@ static bool conv3x3_ws_ok(int B, int NP, int KP, int H, int W) {
     if (R > H) R = H;
     const int strips = (H + R - 1) / R;
     const size_t slab_bytes = (size_t)(R + 2) * (W + 2) * 64;
-    constexpr int kc_env = 0;
     int kc = KP >= 256 ? 4 : (KP >= 64 ? 2 : 1);
-    if (kc_env) kc = kc_env;
     while (kc > 1 && (slab_bytes * kc > 65536 || KP < 32 * kc)) kc >>= 1;
     const int vec = (W % 8 == 0) ? 8 : (W % 4 == 0 ? 4 : 2);
     const bool wide = (NP % 128 == 0) && ((int64_t)B * strips * (NP / 128) >= 512);
-    constexpr int ws_env = 1;
     const size_t ws_ep = (size_t)4 * 16 * (wide ? 2 : 1) * (16 * kMaxPixTiles + 8) * 2;
     const int kc_ws = kc > 2 ? 2 : kc;
     const size_t ws_slab = (size_t)(R + 2) * ws_pitch(W) * 64;
     const int ws_items = 16 * (R + 2) * (W / vec) * kc_ws;
-    return ws_env && NP % 64 == 0 && vec >= 4 && 2 * ws_slab * kc_ws + ws_ep <= 160 * 1024 && ws_items <= (vec == 8 ? 8 : 12) * 256;
+    return NP % 64 == 0 && vec >= 4 && 2 * ws_slab * kc_ws + ws_ep <= 160 * 1024 && ws_items <= (vec == 8 ? 8 : 12) * 256;
 }
 
 static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B, int Cin, int Cout, int NP, int KP,
@@ -1868,15 +1858,12 @@ static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B
     const int pad = KS / 2;
     const size_t slab_bytes = (size_t)(R + 2 * pad) * (W + 2 * pad) * 64;
     // slabs per stage: deep input-channel counts amortise the stage latency over 64 / 128 channels
-    constexpr int kc_env = 0;
     int kc = KP >= 256 ? 4 : (KP >= 64 ? 2 : 1);
-    if (kc_env) kc = kc_env;
     while (kc > 1 && (slab_bytes * kc > 65536 || KP < 32 * kc)) kc >>= 1;
     const size_t ldsb = slab_bytes * kc;
     const int vec = (W % 8 == 0) ? 8 : (W % 4 == 0 ? 4 : 2);
     const int nblk64 = (NP + 63) / 64;
-    constexpr int wide_min = 512;
-    const bool wide = (NP % 128 == 0) && ((int64_t)B * strips * (NP / 128) >= wide_min);
+    const bool wide = (NP % 128 == 0) && ((int64_t)B * strips * (NP / 128) >= 512);
     const size_t ws_ep = (size_t)4 * 16 * (wide ? 2 : 1) * (16 * kMaxPixTiles + 8) * 2;
     int kc_ws = kc > 2 ? 2 : kc;                               // two buffers: the stage overhead is already hidden
     const size_t ws_slab = (size_t)(R + 2 * pad) * ws_pitch(W) * 64;
@@ -2024,7 +2011,7 @@ int dfine_conv_fwd_bf16(const void *x, const void *w2, void *y, int B, int Cin, 
 // DFINE_E_BADARG otherwise, the caller then adds separately.
 int dfine_conv_epilogue_supported(int B, int Cin, int Cout, int H, int W, int KS) {
     if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || Cin % 2) return 0;
-    const int NP = (Cout + 15) / 16 * 16, KP = (Cin + 31) / 32 * 32;
+    const int KP = (Cin + 31) / 32 * 32;
     if (KS == 1) return conv1x1_glds_ok(Cin, KP, H * W) ? 1 : 0;
     // (3x3: the wave-specialised kernel, or - output channels not a multiple of 64: stage 1 of the backbone - the first-generation
     // kernel, whose per-element store reads the old value first)

@@ -898,8 +898,7 @@ int dfine_dwconv_fwd(const void *x, const float *w, void *y, int dtype, int B, i
     if (OH < 1 || OW < 1) return DFINE_E_BADARG;
     hipStream_t st0 = (hipStream_t)stream;
     int vw = 0;
-    constexpr int stream_env = 1;
-    if (stream_env && dw_vec_ok(dtype, H, W, K, stride, pad, &vw) && W / vw <= 64) {
+    if (dw_vec_ok(dtype, H, W, K, stride, pad, &vw) && W / vw <= 64) {
         const int nv = W / vw, ppw = 64 / nv, planes = B * C;
         const int waves = (planes + ppw - 1) / ppw;
         const int rpc = dw_stream_rows(H, waves);
@@ -924,7 +923,7 @@ int dfine_dwconv_fwd(const void *x, const float *w, void *y, int dtype, int B, i
 #undef DFINE_DWV
         return check_launch();
     }
-    if (stream_env && dw_s2_ok(dtype, H, W, K, stride, pad)) {
+    if (dw_s2_ok(dtype, H, W, K, stride, pad)) {
         const int nv = W / 8, ppw = 64 / nv, planes = B * C;
         const int waves = (planes + ppw - 1) / ppw;
         const int rpc = dw_stream_rows(OH, waves);
@@ -985,8 +984,7 @@ int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, fl
     hipStream_t st = (hipStream_t)stream;
     int vw = 0;
     const bool vec = dw_vec_ok(dtype, H, W, K, stride, pad, &vw);
-    constexpr int stream_env = 1;
-    if (dx && vec && stream_env && W / vw <= 64) {
+    if (dx && vec && W / vw <= 64) {
         const int nv = W / vw, ppw = 64 / nv, planes = B * C;
         const int waves = (planes + ppw - 1) / ppw;
         const int rpc = dw_stream_rows(H, waves);
@@ -1008,7 +1006,7 @@ int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, fl
         else { if (vw == 8) DFINE_DWV(3, 8); else DFINE_DWV(3, 4); }
 #undef DFINE_DWV
         if (int e = check_launch()) return e;
-    } else if (dx && stream_env && dw_s2_ok(dtype, H, W, K, stride, pad)) {
+    } else if (dx && dw_s2_ok(dtype, H, W, K, stride, pad)) {
         const int nv = W / 8, ppw = 64 / nv, planes = B * C;
         const int waves = (planes + ppw - 1) / ppw;
         const int rpc = dw_stream_rows(OH, waves);
@@ -1049,7 +1047,7 @@ int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, fl
         int per = 1;
         while ((int64_t)C * ((B + per - 1) / per) > 4096 && per < B) per *= 2;
         dim3 grid(C, (B + per - 1) / per);
-        if (vec && stream_env && W / vw <= 64) {
+        if (vec && W / vw <= 64) {
             const int nv = W / vw, ppw = 64 / nv;
             const int cwaves = (C + ppw - 1) / ppw, cblocks = (cwaves + 3) / 4;
             int perb = B;
@@ -1082,7 +1080,7 @@ int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, fl
 #undef DFINE_WGV
             return check_launch();
         }
-        if (stream_env && dw_s2_ok(dtype, H, W, K, stride, pad)) {
+        if (dw_s2_ok(dtype, H, W, K, stride, pad)) {
             const int nv = W / 8, ppw = 64 / nv;
             const int cwaves = (C + ppw - 1) / ppw, cblocks = (cwaves + 3) / 4;
             // ~2048 waves: images first (no halo rows), then row chunks

@@ -453,17 +453,15 @@ static int linear_launch(const void *x, const void *w, const float *bias, void *
         return DFINE_E_BADARG;
     const int nt_n = (N + kGBN - 1) / kGBN;
     hipStream_t st = (hipStream_t)stream;
-    constexpr int ring_env = -1;   // 0 off, 1/2/4 forces MT
-    if (ring_env != 0 && (K % kGBK) == 0 && (ldx & 7) == 0 && (ldw & 7) == 0 && (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0) {
+    if ((K % kGBK) == 0 && (ldx & 7) == 0 && (ldw & 7) == 0 && (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0) {
         // m tile: 256 rows once that still gives >= 4 rounds of workgroups (the 268 800-row encoder streams), 64 rows when
         // 128-row tiles would leave CUs idle, 128 otherwise
         const int64_t t128 = (int64_t)((M + 127) / 128) * nt_n;
         int mt = t128 >= 900 ? 4 : t128 >= 200 ? 2 : 1;
-        if (ring_env > 0) mt = ring_env;
         const int bm = 64 * mt, nt_m = (M + bm - 1) / bm, ring = mt == 2 ? 4 : 3;
         const size_t ldsb = (size_t)ring * (kGBN + bm) * 128;
         const int total_v = 8 * ((nt_m + 7) / 8) * nt_n;
-        static const int cus = [] { int d = 0, c = 0; hipGetDevice(&d); hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d); return c > 0 ? c : 256; }();
+        static const int cus = [] { int d = 0, c = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d); return c > 0 ? c : 256; }();
         const int resident = (cus & ~7) * (mt == 1 ? 2 : 1);                // workgroups that fit the chip at once (LDS bound)
         dim3 grid(total_v < resident ? total_v : resident);
         static bool ring_attr = false;

@@ -291,10 +291,9 @@ static int gemm_f32_launch(int akm, int bkm, const float *A, const float *B, con
         return DFINE_E_BADARG;
     const int ch = splits > 1 ? chunk : K;
     hipStream_t st = (hipStream_t)stream;
-    // large products: 128 x 128 tiles when they still make at least ~one workgroup per CU (DFINE_GEMM_F32_BIG=0: never)
-    constexpr int big_env = 1;
+    // large products: 128 x 128 tiles when they still make at least ~one workgroup per CU
     const int bt_n = (N + kGbBN - 1) / kGbBN, bt_m = (M + kGbBM - 1) / kGbBM;
-    if (big_env && M >= 96 && N >= 96 && (int64_t)bt_n * bt_m * batch * splits >= 224) {
+    if (M >= 96 && N >= 96 && (int64_t)bt_n * bt_m * batch * splits >= 224) {
         const int ntiles = bt_n * bt_m, per = (ntiles + 7) / 8;
         const dim3 gridb(8 * per, batch * splits);
 #define DFINE_GB(AK, BK) hipLaunchKernelGGL((gemm_f32_big_kernel<AK, BK>), gridb, dim3(kGfThreads), 0, st, A, B, bias, C, M, N, K, lda, ldb, \

@@ -735,8 +735,7 @@ static int launch_fwd(const void *value, const float *loc, const float *weight, 
                       int D, int Lq, const MsdaLevels &lv, float offset_scale, hipStream_t st) {
     const int total_q = B * Lq;
     if (total_q == 0) return DFINE_OK;
-    constexpr int fwd_variant = 1;
-    if (fwd_variant == 1 && sizeof(T) == 2 && (D == 32 || D == 16 || D == 64)) {
+    if (sizeof(T) == 2 && (D == 32 || D == 16 || D == 64)) {
 #define DFINE_FWD8(DD)                                                                         \
     {                                                                                          \
         constexpr int QPB = kThreads / (DD / 8);                                               \
@@ -773,10 +772,8 @@ static int launch_bwd(const void *value, const float *loc, const float *weight, 
                       float offset_scale, hipStream_t st, int acc_mode = 0, float *fx_state = nullptr, float hit_bound = 1.f) {
     const int total_q = B * Lq;
     if (total_q == 0) return DFINE_OK;
-    constexpr int variant = 1;
-    // DFINE_MSDA_MERGE=0: every contribution as its own atomic (A/B switch of the in-register merge, see the kernels)
-    constexpr int merge_env = 1;
-    const bool merge = merge_env && (int64_t)B * L < (int64_t)1 << 31;
+    // (merge: coinciding rows are merged in registers before the atomics, see the kernels)
+    const bool merge = (int64_t)B * L < (int64_t)1 << 31;
     if (acc_mode == 2 || acc_mode == 3) {
         if (!(D == 32 || D == 16 || D == 64)) return DFINE_E_BADARG;
         // scale bookkeeping of the scaled accumulator (see fx_update_kernel): three small launches in front of the gather
@@ -812,7 +809,7 @@ static int launch_bwd(const void *value, const float *loc, const float *weight, 
         return check_launch();
     }
     if (acc_mode != 0) return DFINE_E_BADARG;
-    if (variant == 1 && (D == 32 || D == 16 || D == 64)) {
+    if (D == 32 || D == 16 || D == 64) {
 #define DFINE_BWDW(DD)                                                                         \
     {                                                                                          \
         constexpr int QPB = kThreads / DD;                                                     \

@@ -995,9 +995,8 @@ static int stem_conv_impl(const void *x, const void *x2, int ca, const float *wp
     const uint16_t *xs2 = (const uint16_t *)x2;
     uint16_t *ys = (uint16_t *)y;
     // stride-1 layers of a single input tensor: matrix-core kernel (DFINE_STEM_MFMA=0: the direct kernel)
-    constexpr int mfma_env = 1;
 #define STEM_MFMA_CASE(CI, CO, K)                                                                                                   \
-    if (mfma_env && !xs2 && stride == 1 && Cin == CI && Cout == CO && KS == K) {                                                       \
+    if (!xs2 && stride == 1 && Cin == CI && Cout == CO && KS == K) {                                                       \
         constexpr int cp = (CI + 7) / 8 * 8;                                                                                        \
         const size_t lds = (size_t)(kSmRows + K - 1) * ((kSmCols + K - 1) * cp + (kSmCols + K - 1 + 7) / 8 * 8) * 2;                                                  \
         const int tx = (Wo + kSmCols - 1) / kSmCols, ty = (Ho + kSmRows - 1) / kSmRows, total = B * tx * ty;                        \
@@ -1017,9 +1016,8 @@ static int stem_conv_impl(const void *x, const void *x2, int ca, const float *wp
     STEM_MFMA_CASE(32, 16, 2) STEM_MFMA_CASE(16, 32, 2)
 #undef STEM_MFMA_CASE
     // 3x3 / stride 2 / pad 1 on whole 16-byte vectors (DFINE_STEM_VEC=0: the direct kernel)
-    constexpr int vec_env = 1;
 #define STEM_VEC_CASE(CI, CO)                                                                                                       \
-    if (vec_env && KS == 3 && stride == 2 && pad == 1 && Cin == CI && Cout == CO && W % 8 == 0 && Wo % 4 == 0 && W == 2 * Wo && H == 2 * Ho) { \
+    if (KS == 3 && stride == 2 && pad == 1 && Cin == CI && Cout == CO && W % 8 == 0 && Wo % 4 == 0 && W == 2 * Wo && H == 2 * Ho) { \
         dim3 gridv((Ho * (Wo / 4) + kStemThreads - 1) / kStemThreads, B);                                                           \
         hipLaunchKernelGGL((stem_conv_s2_vec_kernel<CI, CO>), gridv, dim3(kStemThreads), 0, st, xs, xs2, ca, wp, ys, H, W, Ho, Wo);   \
         return check_launch();                                                                                                      \
