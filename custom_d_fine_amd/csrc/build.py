@@ -23,6 +23,7 @@ SOURCES = {
     "stem.hip": ["-munsafe-fp-atomics"],
     "postproc.hip": ["-ffp-contract=off"],       # box arithmetic bit-identical to the reference's fp32 ops
     "data.hip": ["-ffp-contract=off"],           # the same for the augmentation box transform
+    "cdn.hip": ["-ffp-contract=off"],            # the denoising group's box noise: every fp32 operation individually rounded, like ATen's
 }
 
 

@@ -265,6 +265,68 @@ def _randint_like(t, low, high, dtype=None):
                          dtype=dtype or t.dtype).to(t.device)
 
 
+_CDN_MASKS = {}
+
+
+def _cdn_attn_mask(total, num_queries, g, device):
+    """Boolean self-attention mask of the denoising + matching queries (True = may not attend; ref arch/utils.py:442-455): a
+    function of (total, num_queries, group size) only, so it is built once per shape and SHARED between steps - callers must not
+    write to it (the attention kernels' bit-packed / tile-summary forms are cached on the tensor's address and version too)."""
+    key = (int(total), int(num_queries), int(g), str(device))
+    mask = _CDN_MASKS.get(key)
+    if mask is None:
+        if len(_CDN_MASKS) >= 64:
+            _CDN_MASKS.clear()
+        n = total + num_queries
+        mask = torch.zeros([n, n], dtype=torch.bool, device=device)
+        mask[total:, :total] = True  # matching queries never see the reconstruction part
+        gid = torch.arange(total, device=device) // g
+        mask[:total, :total] = gid[:, None] != gid[None, :]  # groups are mutually invisible
+        _CDN_MASKS[key] = mask
+    return mask
+
+
+def _cdn_group_torch(targets, counts, device, bs, gmax, groups, num_classes, label_noise_ratio, box_noise_scale):
+    """The padded class ids with label noise and the noised boxes in logit space as torch ops (CPU tensors, off-default noise
+    settings; the GPU runs csrc/cdn.hip, which restates exactly this sequence)."""
+    # pad labels / boxes to [bs, gmax].  The slot of every real GT is known from the host-side counts, so
+    # the padded tensors are filled with an index_copy through ONE async upload - a boolean-mask assignment
+    # or torch.tensor(list, device=cuda) would each block the host until the device queue drains.
+    slots = np.concatenate([i * gmax + np.arange(n, dtype=np.int64) for i, n in enumerate(counts)])
+    slots = upload(slots, device)
+    valid = torch.zeros(bs * gmax, dtype=torch.bool, device=device)
+    cls = torch.full([bs * gmax], num_classes, dtype=torch.int32, device=device)
+    box = torch.zeros([bs * gmax, 4], device=device)
+    if sum(counts):
+        valid.index_fill_(0, slots, True)
+        cls.index_copy_(0, slots, torch.cat([t["labels"] for t in targets]).to(torch.int32))
+        box.index_copy_(0, slots, torch.cat([t["boxes"] for t in targets]).to(box.dtype))
+    valid, cls, box = valid.view(bs, gmax), cls.view(bs, gmax), box.view(bs, gmax, 4)
+
+    cls = cls.tile([1, 2 * groups])
+    box = box.tile([1, 2 * groups, 1])
+    valid = valid.tile([1, 2 * groups])
+    neg = torch.zeros([bs, gmax * 2, 1], device=device)
+    neg[:, gmax:] = 1
+    neg = neg.tile([1, groups, 1])
+    if label_noise_ratio > 0:
+        flip = _rand_like(cls, dtype=torch.float) < (label_noise_ratio * 0.5)
+        rnd = _randint_like(flip, 0, num_classes, dtype=cls.dtype)
+        cls = torch.where(flip & valid, rnd, cls)
+
+    if box_noise_scale > 0:
+        xyxy = box_cxcywh_to_xyxy(box)
+        span = torch.tile(box[..., 2:] * 0.5, [1, 1, 2]) * box_noise_scale
+        sign = _randint_like(box, 0, 2) * 2.0 - 1.0
+        mag = _rand_like(box)
+        mag = (mag + 1.0) * neg + mag * (1 - neg)
+        xyxy = torch.clip(xyxy + sign * mag * span, min=0.0, max=1.0)
+        box = box_xyxy_to_cxcywh(xyxy)
+        box = torch.where(box < 0, -box, box)
+    box_unact = inverse_sigmoid(box)
+    return cls, box_unact
+
+
 def get_contrastive_denoising_training_group(
     targets, num_classes, num_queries, class_embed, num_denoising=100,
     label_noise_ratio=0.5, box_noise_scale=1.0,
@@ -287,26 +349,6 @@ def get_contrastive_denoising_training_group(
     groups = max(num_denoising // gmax, 1)
     bs = len(counts)
 
-    # pad labels / boxes to [bs, gmax].  The slot of every real GT is known from the host-side counts, so
-    # the padded tensors are filled with an index_copy through ONE async upload - a boolean-mask assignment
-    # or torch.tensor(list, device=cuda) would each block the host until the device queue drains.
-    slots = np.concatenate([i * gmax + np.arange(n, dtype=np.int64) for i, n in enumerate(counts)])
-    slots = upload(slots, device)
-    valid = torch.zeros(bs * gmax, dtype=torch.bool, device=device)
-    cls = torch.full([bs * gmax], num_classes, dtype=torch.int32, device=device)
-    box = torch.zeros([bs * gmax, 4], device=device)
-    if sum(counts):
-        valid.index_fill_(0, slots, True)
-        cls.index_copy_(0, slots, torch.cat([t["labels"] for t in targets]).to(torch.int32))
-        box.index_copy_(0, slots, torch.cat([t["boxes"] for t in targets]).to(box.dtype))
-    valid, cls, box = valid.view(bs, gmax), cls.view(bs, gmax), box.view(bs, gmax, 4)
-
-    cls = cls.tile([1, 2 * groups])
-    box = box.tile([1, 2 * groups, 1])
-    valid = valid.tile([1, 2 * groups])
-    neg = torch.zeros([bs, gmax * 2, 1], device=device)
-    neg[:, gmax:] = 1
-    neg = neg.tile([1, groups, 1])
     # positive (first-half) slots of every group that hold a real GT; known from the counts alone,
     # so built on the host (the reference derives them with a device nonzero + split)
     pos_np = [(np.arange(groups, dtype=np.int64)[:, None] * (2 * gmax) + np.arange(n, dtype=np.int64)[None, :]).reshape(-1)
@@ -314,30 +356,27 @@ def get_contrastive_denoising_training_group(
     pos_idx = tuple(torch.from_numpy(p) for p in pos_np)
     total = int(gmax * 2 * groups)
 
-    if label_noise_ratio > 0:
-        flip = _rand_like(cls, dtype=torch.float) < (label_noise_ratio * 0.5)
-        rnd = _randint_like(flip, 0, num_classes, dtype=cls.dtype)
-        cls = torch.where(flip & valid, rnd, cls)
-
-    if box_noise_scale > 0:
-        xyxy = box_cxcywh_to_xyxy(box)
-        span = torch.tile(box[..., 2:] * 0.5, [1, 1, 2]) * box_noise_scale
-        sign = _randint_like(box, 0, 2) * 2.0 - 1.0
-        mag = _rand_like(box)
-        mag = (mag + 1.0) * neg + mag * (1 - neg)
-        xyxy = torch.clip(xyxy + sign * mag * span, min=0.0, max=1.0)
-        box = box_xyxy_to_cxcywh(xyxy)
-        box = torch.where(box < 0, -box, box)
-        box_unact = inverse_sigmoid(box)
+    if device.type == "cuda" and label_noise_ratio > 0 and box_noise_scale > 0 and kernels.cdn_kernel_enabled():
+        # GPU: the padded labels / boxes, the label flips and the box noise in ONE launch (csrc/cdn.hip, bit-identical to the
+        # composition below); the four random tensors are drawn here, in the reference's order, shapes and dtypes
+        offsets = upload(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), device)
+        labels_cat = torch.cat([t["labels"] for t in targets]).to(torch.int64)
+        boxes_cat = torch.cat([t["boxes"] for t in targets]).to(torch.float32)
+        like_cls = torch.empty([bs, total], dtype=torch.int32, device=device)
+        like_box = torch.empty([bs, total, 4], dtype=torch.float32, device=device)
+        flip_rand = _rand_like(like_cls, dtype=torch.float)
+        rnd = _randint_like(like_cls.view(torch.int32), 0, num_classes, dtype=torch.int32)
+        sign01 = _randint_like(like_box, 0, 2)
+        mag = _rand_like(like_box)
+        cls, box_unact = kernels.cdn_group(labels_cat, boxes_cat, offsets, flip_rand, rnd, sign01, mag, bs, gmax, groups,
+                                           num_classes, label_noise_ratio * 0.5, box_noise_scale)
+    else:
+        cls, box_unact = _cdn_group_torch(targets, counts, device, bs, gmax, groups, num_classes, label_noise_ratio,
+                                          box_noise_scale)
 
     logits = kernels.embedding(class_embed, cls) if isinstance(class_embed, nn.Embedding) else class_embed(cls)
 
-    n = total + num_queries
-    mask = torch.zeros([n, n], dtype=torch.bool, device=device)
-    mask[total:, :total] = True  # matching queries never see the reconstruction part
-    g = gmax * 2
-    gid = torch.arange(total, device=device) // g
-    mask[:total, :total] = gid[:, None] != gid[None, :]  # groups are mutually invisible
+    mask = _cdn_attn_mask(total, num_queries, gmax * 2, device)
 
     meta = {"dn_positive_idx": pos_idx, "dn_num_group": groups, "dn_num_split": [total, num_queries],
             "dn_positive_flat": np.concatenate(pos_np)}

@@ -138,6 +138,7 @@ _SIGNATURES = {
     "dfine_affine_boxes": (c_int, [_P, _P, _P, _I, _P, _F, _F, _F, _F, _P]),
     "dfine_preprocess_u8": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_postprocess": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dfine_cdn_group": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
     "dfine_linear_wgrad_ws_floats": (_L, [_I, _I, _I]),
     "dfine_linear_wgrad_bf16": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dfine_ln_fused_fwd": (c_int, [_I, _P, _I, _P, _I, _P, _I, _P, _P, _F, _F, _P, _P, _P, _P, _L, _I, _P]),
@@ -449,6 +450,25 @@ def msda_fused_backward(value, ref, offsets, logits, grad_out, shapes, points, o
                                              _dtype_code(value), B, L, H, D, Lq, len(shapes), hw, pts,
                                              float(offset_scale), mode, fx_state, hit_bound, _stream()), "dfine_msda_fused_bwd_acc")
     return (None if gv_acc is not None else msda_finish_grad_value(gv, value.dtype)), goff.to(off_dtype), glog.to(log_dtype)
+
+
+# ------------------------------------------------------------------------------------- denoising group (A4)
+def cdn_group(labels, boxes, offsets, flip_rand, rnd_cls, sign01, mag, bs, gmax, groups, num_classes, flip_below, box_noise_scale):
+    """labels int64 [T], boxes f32 [T, 4] (the batch's targets concatenated), offsets int32 [bs + 1] on the device, the four random
+    tensors of the reference's draw order -> (cls int32 [bs, total], box_unact f32 [bs, total, 4]), total = 2 * groups * gmax
+    (dfine_cdn_group: one launch, bit-identical to the torch composition)."""
+    total = 2 * groups * gmax
+    dev = offsets.device
+    assert labels.dtype == torch.int64 and boxes.dtype == torch.float32 and offsets.dtype == torch.int32
+    assert flip_rand.dtype == torch.float32 and rnd_cls.dtype == torch.int32 and sign01.dtype == torch.float32 and mag.dtype == torch.float32
+    for t, shape in ((flip_rand, (bs, total)), (rnd_cls, (bs, total)), (sign01, (bs, total, 4)), (mag, (bs, total, 4))):
+        assert tuple(t.shape) == shape and t.is_contiguous()
+    cls = torch.empty(bs, total, device=dev, dtype=torch.int32)
+    unact = torch.empty(bs, total, 4, device=dev, dtype=torch.float32)
+    _check(_lib.dfine_cdn_group(_ptr(labels.contiguous()), _ptr(boxes.contiguous()), _ptr(offsets), _ptr(flip_rand), _ptr(rnd_cls),
+                                _ptr(sign01), _ptr(mag), _ptr(cls), _ptr(unact), bs, gmax, groups, int(num_classes), float(flip_below),
+                                float(box_noise_scale), _stream()), "dfine_cdn_group")
+    return cls, unact
 
 
 # ------------------------------------------------------------------------------------- matcher

@@ -214,6 +214,21 @@ def embedding(mod: nn.Embedding, idx):
     return mod(idx)
 
 
+CDN_KERNEL = True      # (tools/ab_step.py kernels.CDN_KERNEL)
+
+
+def cdn_kernel_enabled():
+    return CDN_KERNEL and _env("DFINE_HIP_UNITS", "1") == "1"
+
+
+def cdn_group(labels, boxes, offsets, flip_rand, rnd_cls, sign01, mag, bs, gmax, groups, num_classes, flip_below, box_noise_scale):
+    """Padded class ids with label noise + noised boxes in logit space of the denoising group, one launch (csrc/cdn.hip); no
+    gradient flows through it (the reference builds it from the targets)."""
+    with torch.no_grad():
+        return _hip().cdn_group(labels, boxes, offsets, flip_rand, rnd_cls, sign01, mag, bs, gmax, groups, num_classes,
+                                flip_below, box_noise_scale)
+
+
 class _Upsample2Nearest(torch.autograd.Function):
     """F.interpolate(x, scale_factor=2, mode="nearest") of a bf16 NCHW map (FPN top-down path): one data-movement pass each way
     (csrc/layout.hip) instead of ATen's gather kernels (78 / 73 us for the 40x40 -> 80x80 map of D-FINE-m bs 32)."""

@@ -754,6 +754,18 @@ int dfine_gemm_f32_nn(const float *A, const float *B, const float *bias, float *
 int dfine_gemm_f32(int a_kmajor, int b_kmajor, const float *A, const float *B, const float *bias, float *C, int batch, int M, int N, int K,
                    int lda, int ldb, int ldc, int64_t sa, int64_t sb, int64_t sc, int splits, int chunk, float alpha, int act, void *stream);
 
+/* A4  Contrastive-denoising query group (src/d_fine/arch/utils.py:357-467, get_contrastive_denoising_training_group): padded class
+ * ids with label noise and noised boxes in logit space for the 2 * groups * gmax denoising queries of every image, in ONE launch
+ * (the reference: a Python loop per image and per group + ~40 element-wise launches).  labels int64 [T] / boxes fp32 [T, 4]: the
+ * batch's targets concatenated; offsets int32 [bs + 1] (device): first target of every image.  The four random tensors are the
+ * reference's draws, made by the caller in its order: flip_rand fp32 [bs, total] (rand_like), rnd_cls int32 [bs, total]
+ * (randint_like 0 .. C - 1), sign01 fp32 [bs, total, 4] (randint_like 0 .. 1), mag fp32 [bs, total, 4] (rand_like); total =
+ * 2 * groups * gmax.  flip_below = label_noise_ratio * 0.5.  Out: cls int32 [bs, total] (num_classes in padded slots),
+ * box_unact fp32 [bs, total, 4] = inverse_sigmoid of the noised cxcywh box.  Bit-identical to the reference's fp32 op sequence. */
+int dfine_cdn_group(const int64_t *labels, const float *boxes, const int *offsets, const float *flip_rand, const int *rnd_cls,
+                    const float *sign01, const float *mag, int *cls_out, float *box_unact, int bs, int gmax, int groups,
+                    int num_classes, float flip_below, float box_noise_scale, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * (f2)  Instance-mask IoU of the evaluation hand-off.  Replaces Validator._pairwise_mask_iou
  * (src/dl/validator.py:283-293: uint8 masks -> fp32 matmul -> areas -> inter / union) and the pycocotools RLE round trip
