@@ -360,8 +360,11 @@ class TransformerDecoder(nn.Module):
             out = tap()                                  # the next layer's input
 
         hs = torch.stack(queries) if return_queries else None
-        return (torch.stack(boxes), torch.stack(logits), torch.stack(corners), torch.stack(refs),
-                pre_bboxes, pre_scores, hs)
+        # per-layer LISTS, not stacked tensors (the reference stacks, dfine_decoder.py:522-524, then indexes the layers apart
+        # again): a select on a stacked tensor costs a zero fill + copy + add per layer and head tensor in backward
+        if kernels.STACK_LAYER_OUTPUTS:          # (the reference's form; tools/ab_step.py kernels.STACK_LAYER_OUTPUTS for the A/B)
+            return torch.stack(boxes), torch.stack(logits), torch.stack(corners), torch.stack(refs), pre_bboxes, pre_scores, hs
+        return boxes, logits, corners, refs, pre_bboxes, pre_scores, hs
 
 
 class DFINETransformer(nn.Module):
@@ -664,10 +667,16 @@ class DFINETransformer(nn.Module):
             split = dn_meta["dn_num_split"]
             dn_pre_logits, pre_logits = torch.split(pre_logits, split, dim=1)
             dn_pre_bboxes, pre_bboxes = torch.split(pre_bboxes, split, dim=1)
-            dn_out_bboxes, out_bboxes = torch.split(out_bboxes, split, dim=2)
-            dn_out_logits, out_logits = torch.split(out_logits, split, dim=2)
-            dn_out_corners, out_corners = torch.split(out_corners, split, dim=2)
-            dn_out_refs, out_refs = torch.split(out_refs, split, dim=2)
+            def split_layers(layers):             # every layer's [B, dn + Q, .] into its denoising / matching parts (views)
+                if torch.is_tensor(layers):
+                    return torch.split(layers, split, dim=2)
+                parts = [torch.split(t, split, dim=1) for t in layers]
+                return [p[0] for p in parts], [p[1] for p in parts]
+
+            dn_out_bboxes, out_bboxes = split_layers(out_bboxes)
+            dn_out_logits, out_logits = split_layers(out_logits)
+            dn_out_corners, out_corners = split_layers(out_corners)
+            dn_out_refs, out_refs = split_layers(out_refs)
             if do_masks and hs is not None:
                 dn_hs, hs = torch.split(hs, split, dim=2)
 

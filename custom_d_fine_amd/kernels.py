@@ -215,6 +215,7 @@ def embedding(mod: nn.Embedding, idx):
 
 
 CDN_KERNEL = True      # (tools/ab_step.py kernels.CDN_KERNEL)
+STACK_LAYER_OUTPUTS = False      # the decoder hands its per-layer head outputs on as lists, not as stacked tensors (see TransformerDecoder.forward)
 
 
 def cdn_kernel_enabled():

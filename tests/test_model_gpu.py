@@ -468,7 +468,8 @@ def bf16_decoder_parity_table(cuda):
                 outs = [top_mem, dec._enc_scores(top_mem), dec.enc_bbox_head(top_mem)]
             elif name == "decoder.stack":
                 res = dec.decoder(*args, **kwargs)
-                outs = [res[0], res[1], res[2], res[4], res[5]]     # boxes, logits, corners of every layer + the pre heads
+                # boxes, logits, corners of every layer (per-layer lists since round 6) + the pre heads
+                outs = [torch.stack(r) if isinstance(r, (list, tuple)) else r for r in (res[0], res[1], res[2])] + [res[4], res[5]]
             else:
                 outs = [dec.decoder.layers[int(name.rsplit(".", 1)[1])](*args, **kwargs)]
         loss = sum((o.float() * helpers.make_cotangent(o.shape, 31 + i).to(cuda)).sum() for i, o in enumerate(outs))
