@@ -16,7 +16,7 @@ python tools/conv1x1_table.py --ks 3 2>&1 | grep -v -i "warn\|amdgpu.ids" > $O/c
 python tools/bn_microbench.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > $O/bn_microbench.txt
 python tools/step_events.py $O/step_events.jsonl > $O/step_events.log 2>&1
 python tools/step_phases.py $O/step_events.jsonl > $O/step_phases.txt 2>&1
-for sw in kernels.MLP_FUSED kernels.LN_DEFER; do python tools/ab_step.py $sw 2>&1 | tail -3; done > $O/ab_launch_fusions.txt
+for sw in kernels.MLP_FUSED kernels.LN_DEFER kernels.CDN_KERNEL kernels.STACK_LAYER_OUTPUTS; do python tools/ab_step.py $sw 2>&1 | tail -3; done > $O/ab_launch_fusions.txt
 python tools/f32_step_profile.py 2>&1 | grep -v -i "warn\|amdgpu.ids\|_warn_once" > $O/f32_step_profile.txt
 # HBM traffic counters of the family's reference layer (512 -> 512 @80x80 on the LDS-DMA 1x1 kernel), one --pmc pass per counter group
 tools/conv_pmc.sh ${R}_conv_pmc 512 512 80 1 fwd conv1x1_glds > $O/conv1x1_pmc.txt 2>&1
