@@ -347,6 +347,8 @@ __global__ __launch_bounds__(256) void head_grads_scale_kernel(const float *__re
 
 using namespace dfine;
 
+static thread_local bool g_head_prezeroed = false;
+
 static int head_losses_impl(
     const void *logits, int64_t l_sb, int64_t l_sq, const float *boxes, int64_t b_sb, int64_t b_sq,
     const void *corners, int64_t c_sb, int64_t c_sq, const float *ref, int64_t r_sb, int64_t r_sq,
@@ -434,7 +436,13 @@ static int head_losses_impl(
     const bool packed = reinterpret_cast<char *>(grad_l1) == o8 + 32 && grad_giou == grad_l1 + nq * 4 &&
                         reinterpret_cast<char *>(map_cls) == o8 + 32 + nq * 32 && map_box == map_cls + nq &&
                         (!corners || reinterpret_cast<char *>(grad_corners_fgl) == o8 + (maps_end + 15) / 16 * 16);
-    if (packed) {
+    // one-shot request of the calling thread (dfine_head_losses_prezeroed_once): the packed block IS zero already - the caller cleared
+    // the blocks of all heads of the step with one fill
+    const bool prezeroed = g_head_prezeroed;
+    g_head_prezeroed = false;
+    if (prezeroed) {
+        if (!packed) return DFINE_E_BADARG;
+    } else if (packed) {
         zero_fill_async(out, corners ? (maps_end + 15) / 16 * 16 + fgl_bytes : maps_end, st);
     } else {
         zero_fill_async(out, 5 * sizeof(float), st);
@@ -485,6 +493,14 @@ static int head_losses_impl(
 }
 
 extern "C" {
+
+// One-shot: the NEXT dfine_head_losses / dfine_head_losses_dev call of the calling thread finds its packed output block
+// [out(8) | grad_l1 | grad_giou | map_cls | map_box | pad | grad_corners_fgl] zero-filled by the caller and skips its own fill
+// (11 heads per training step: one fill of a common arena instead of 11).  A call whose buffers are not packed that way fails.
+int dfine_head_losses_prezeroed_once(void) {
+    g_head_prezeroed = true;
+    return DFINE_OK;
+}
 
 int dfine_head_grads_scale(const float *g, void *grad_logits, int64_t n_logits, float *grad_l1, const float *grad_giou,
                            int64_t n_box, void *grad_corners_fgl, const void *grad_corners_ddf, int64_t n_corners, int dtype,

@@ -749,12 +749,20 @@ class DFINECriterion(nn.Module):
         params = upload(np.asarray([r[-1] for r in runs], dtype=np.float64), dev)
         scales = hip.criterion_scales(params, go_count, go_sum, world)
 
-        # ---- pass 2: the head-loss launches
+        # ---- pass 2: the head-loss launches.  Their packed zero-initialised output blocks are slices of ONE arena: one fill per
+        # step instead of one per head
         names, vecs = [], []
+        sizes_z = [hip.head_losses_zbytes(h["pred_logits"].shape[0], h["pred_logits"].shape[1],
+                                          c.shape[-1] if c is not None else 0, h["pred_logits"].element_size())
+                   for h, _, _, _, c, *_ in runs]
+        arena = torch.zeros(sum(sizes_z), device=dev, dtype=torch.uint8) if kernels.HEAD_ARENA else None
+        z_off = 0
         for r, (head, suffix, cls_plan, box_plan, corners, teacher, n_cls, _) in enumerate(runs):
             cfg = {"wtable": wtable, "reg_max": self.reg_max, "reg_scale": reg_scale, "alpha": self.alpha, "gamma": self.gamma,
                    "temp": 5.0, "s_vfl": 0.0, "s_l1": 0.0, "s_giou": 0.0, "s_fgl": 0.0, "c_pos": 0.0, "c_neg": 0.0,
-                   "scales_dev": scales[r], "box_count_dev": box_plan.count_dev}
+                   "scales_dev": scales[r], "box_count_dev": box_plan.count_dev,
+                   "zbytes": None if arena is None else arena[z_off:z_off + sizes_z[r]]}
+            z_off += sizes_z[r]
             vec = kernels.head_losses(
                 head["pred_logits"], head["pred_boxes"], corners,
                 head["ref_points"].detach() if corners is not None else None, teacher,

@@ -57,6 +57,7 @@ _SIGNATURES = {
     "dfine_criterion_plans": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     "dfine_criterion_scales": (c_int, [_P, _I, _P, _P, _I, _P, _P]),
     "dfine_head_grads_scale": (c_int, [_P, _P, _L, _P, _P, _L, _P, _P, _L, _I, _P]),
+    "dfine_head_losses_prezeroed_once": (c_int, []),
     "dfine_grad_sqnorm": (c_int, [_P, _L, _F, _P, _P]),
     "dfine_grad_sqnorm_ws_floats": (_L, []),
     "dfine_adamw_ema_step": (c_int, [_P, _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _I, _F, _F, _F, _P]),
@@ -728,9 +729,11 @@ def _view3(t):
 
 def head_losses(logits, boxes, corners, ref, teacher_corners, teacher_logits, cls_plan, box_plan,
                 tgt_labels, tgt_boxes, wtable, reg_max, reg_scale, alpha, gamma, temp, s_vfl, s_l1,
-                s_giou, s_fgl, c_pos, c_neg, scales_dev=None, box_count_dev=None):
+                s_giou, s_fgl, c_pos, c_neg, scales_dev=None, box_count_dev=None, zbytes=None):
     """One launch group for all losses of a head.  Returns (out[5], grad_logits, grad_l1, grad_giou,
-    grad_corners_fgl, grad_corners_ddf) - see dfine_head_losses in include/dfine_hip.h."""
+    grad_corners_fgl, grad_corners_ddf) - see dfine_head_losses in include/dfine_hip.h.
+    zbytes: a ZERO-FILLED uint8 block of head_losses_zbytes(...) bytes (16-byte aligned) to use for the packed outputs - the
+    caller cleared the blocks of all heads with one fill (dfine_head_losses_prezeroed_once)."""
     B, Q, C = logits.shape
     dev = logits.device
     dt = logits.dtype
@@ -741,7 +744,12 @@ def head_losses(logits, boxes, corners, ref, teacher_corners, teacher_logits, cl
     maps_end = 32 + nq * 40
     fgl_off = (maps_end + 15) // 16 * 16
     nb = corners.shape[-1] if corners is not None else 0
-    zbytes = torch.empty(fgl_off + nq * nb * dt.itemsize, device=dev, dtype=torch.uint8)
+    if zbytes is None:
+        zbytes = torch.empty(fgl_off + nq * nb * dt.itemsize, device=dev, dtype=torch.uint8)
+    else:
+        assert zbytes.dtype == torch.uint8 and zbytes.numel() >= fgl_off + nq * nb * dt.itemsize and zbytes.data_ptr() % 16 == 0
+        zbytes = zbytes[:fgl_off + nq * nb * dt.itemsize]
+        _lib.dfine_head_losses_prezeroed_once()
     zbuf = zbytes[:32 + nq * 32].view(torch.float32)
     out = zbuf[:5]
     g_box = zbuf[8:].view(2, B, Q, 4)
@@ -781,6 +789,13 @@ def head_losses(logits, boxes, corners, ref, teacher_corners, teacher_logits, cl
         _ptr(scratch_f[m_cls + m_box:]), _ptr(out), _dtype_code(logits), B, Q, C, _stream()),
         "dfine_head_losses")
     return out, g_logits, g_box[0], g_box[1], g_fgl, g_ddf
+
+
+def head_losses_zbytes(B, Q, corner_bins, itemsize):
+    """Bytes of the packed zero-initialised output block of one head_losses call, rounded up to a multiple of 256."""
+    nq = B * Q
+    n = (32 + nq * 40 + 15) // 16 * 16 + nq * corner_bins * itemsize
+    return (n + 255) // 256 * 256
 
 
 def head_grads_scale(g, g_logits, g_l1, g_giou, g_fgl, g_ddf):

@@ -214,6 +214,7 @@ def embedding(mod: nn.Embedding, idx):
     return mod(idx)
 
 
+HEAD_ARENA = True      # the criterion's head-loss output blocks as slices of one zero-filled arena (tools/ab_step.py kernels.HEAD_ARENA)
 CDN_KERNEL = True      # (tools/ab_step.py kernels.CDN_KERNEL)
 STACK_LAYER_OUTPUTS = False      # the decoder hands its per-layer head outputs on as lists, not as stacked tensors (see TransformerDecoder.forward)
 
@@ -358,7 +359,8 @@ class _HeadLosses(torch.autograd.Function):
             logits, boxes, corners_k, None if ref is None else ref.float(), tc, tl, cls_plan,
             box_plan, tgt_labels, tgt_boxes, cfg["wtable"], cfg["reg_max"], cfg["reg_scale"],
             cfg["alpha"], cfg["gamma"], cfg["temp"], cfg["s_vfl"], cfg["s_l1"], cfg["s_giou"],
-            cfg["s_fgl"], cfg["c_pos"], cfg["c_neg"], scales_dev=cfg.get("scales_dev"), box_count_dev=cfg.get("box_count_dev"))
+            cfg["s_fgl"], cfg["c_pos"], cfg["c_neg"], scales_dev=cfg.get("scales_dev"), box_count_dev=cfg.get("box_count_dev"),
+            zbytes=cfg.get("zbytes"))
         ctx.grads = (g_logits, g_l1, g_giou, g_fgl, g_ddf)
         ctx.dtypes = (boxes.dtype, None if corners is None else corners.dtype)
         return out
@@ -1177,8 +1179,7 @@ def _bn_tail_fused(inner, conv_args, bn, a, lab):
     training = bn.training
     if training:
         if _BN_DEFER:
-            ent = _BN_PENDING.get(id(bn))
-            _BN_PENDING[id(bn)] = (bn.num_batches_tracked, 1 if ent is None else ent[1] + 1)
+            _bn_count_deferred(bn)
         else:
             bn.num_batches_tracked.add_(1)
     return _ConvBNActAny.apply(inner, len(conv_args), *conv_args, bn.weight, bn.bias, lab.scale if lab is not None else None,
@@ -1543,8 +1544,7 @@ def _conv_bn_act_residual(x, conv, bn, a, lab, fanin, residual):
     training = bn.training
     if training:
         if _BN_DEFER:
-            ent = _BN_PENDING.get(id(bn))
-            _BN_PENDING[id(bn)] = (bn.num_batches_tracked, 1 if ent is None else ent[1] + 1)
+            _bn_count_deferred(bn)
         else:
             bn.num_batches_tracked.add_(1)
     return _DenseConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, lab.scale if lab is not None else None,
@@ -1637,8 +1637,7 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
                 training = bn.training
                 if training:
                     if _BN_DEFER:
-                        ent = _BN_PENDING.get(id(bn))
-                        _BN_PENDING[id(bn)] = (bn.num_batches_tracked, 1 if ent is None else ent[1] + 1)
+                        _bn_count_deferred(bn)
                     else:
                         bn.num_batches_tracked.add_(1)
                 return _DenseConvBNAct.apply(xb, conv.weight, bn.weight, bn.bias, lab.scale if lab is not None else None,
@@ -1780,8 +1779,7 @@ def repvgg_unit(x, conv1: nn.Conv2d, bn1, conv2: nn.Conv2d, bn2, act: Optional[s
         if ok:
             for bn in (bn1, bn2):
                 if _BN_DEFER:
-                    ent = _BN_PENDING.get(id(bn))
-                    _BN_PENDING[id(bn)] = (bn.num_batches_tracked, 1 if ent is None else ent[1] + 1)
+                    _bn_count_deferred(bn)
                 else:
                     bn.num_batches_tracked.add_(1)
             return _DualConvBN2Act.apply(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv1.weight, conv2.weight, residual,
@@ -1800,8 +1798,7 @@ def repvgg_unit(x, conv1: nn.Conv2d, bn1, conv2: nn.Conv2d, bn2, act: Optional[s
                 residual.shape == c1.shape and residual.dtype == torch.bfloat16)):
             for bn in (bn1, bn2):
                 if _BN_DEFER:
-                    ent = _BN_PENDING.get(id(bn))
-                    _BN_PENDING[id(bn)] = (bn.num_batches_tracked, 1 if ent is None else ent[1] + 1)
+                    _bn_count_deferred(bn)
                 else:
                     bn.num_batches_tracked.add_(1)
             return _BN2Act.apply(c1, c2, residual, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
@@ -1820,8 +1817,7 @@ def _bn_tail(y, bn, a, act, lab):
         training = bn.training
         if training:
             if _BN_DEFER:
-                ent = _BN_PENDING.get(id(bn))
-                _BN_PENDING[id(bn)] = (bn.num_batches_tracked, 1 if ent is None else ent[1] + 1)
+                _bn_count_deferred(bn)
             else:
                 bn.num_batches_tracked.add_(1)
         return _BNAct.apply(y, bn.weight, bn.bias, lab.scale if lab is not None else None,
@@ -2370,6 +2366,15 @@ def self_attention(qk, value, in_w, in_b, out_w, out_b, num_heads: int, attn_mas
 # 133 tiny launches per step.  A train loop may defer them and flush once per step with one multi-tensor add.
 _BN_DEFER = False
 _BN_PENDING = {}
+
+
+def _bn_count_deferred(bn):
+    """One more training-mode forward of `bn`: remembered, added to its counter by flush_bn_counters.  Keyed by the COUNTER tensor's
+    id - the entry holds that tensor, so the id cannot be handed to another object while the entry exists (keyed by the module,
+    a dropped model's pending counts were inherited by whatever module got its address next)."""
+    buf = bn.num_batches_tracked
+    ent = _BN_PENDING.get(id(buf))
+    _BN_PENDING[id(buf)] = (buf, 1 if ent is None else ent[1] + 1)
 
 
 def defer_bn_counters(flag=True):

@@ -257,6 +257,11 @@ int dfine_head_losses(
     int *map_cls, int *map_box, float *wrow, float *out, int dtype, int B, int Q, int C,
     void *stream);
 
+/* One-shot: the NEXT dfine_head_losses / dfine_head_losses_dev call of the calling thread finds its packed output block
+ * [out (8 floats) | grad_l1 | grad_giou | map_cls | map_box | pad to 16 B | grad_corners_fgl] already zero and skips its own fill:
+ * the caller cleared the blocks of all heads of a step (11 for D-FINE-m: dfine_criterion.py:609-777 runs its losses per head)
+ * with one fill of a common arena.  A call whose buffers are not laid out that way returns DFINE_E_BADARG. */
+int dfine_head_losses_prezeroed_once(void);
 /* Backward of dfine_head_losses (reference: autograd through loss_labels_vfl / loss_boxes / loss_local,
  * src/d_fine/dfine_criterion.py:92-237): scales the gradients the forward call left behind by the upstream gradient
  * g[5] (device, f32) of its `out` vector, in place, one launch:
