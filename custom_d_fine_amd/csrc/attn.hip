@@ -25,6 +25,11 @@
 
 namespace dfine {
 
+// 2^x of the softmax (re)computation as the bare v_exp_f32 (1 ulp): the arguments are <= 0 (score - row maximum / log-sum-exp) or -inf,
+// so exp2f's range checks and denormal rescaling (4 more instructions per element) protect nothing - results below 2^-126 flush to
+// 0.  Measured (tools/linear_attn_bench.py, B 32, L 492, masked): forward 68.4 -> 63.4 us, backward 125.8 -> 110.6 us.
+__device__ __forceinline__ float attn_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 typedef __attribute__((ext_vector_type(8))) __bf16 a_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float a_f32x4;
 typedef short a_tr4 __attribute__((ext_vector_type(4)));
@@ -184,13 +189,13 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const uint16_t *
             bmax = xor_max(bmax);
             const float m_new = fmaxf(m_run[t], bmax);
             const float m_use = m_new == NEG ? 0.f : m_new;
-            const float alpha = exp2f(m_run[t] - m_use);                     // m_run = -inf -> 0
+            const float alpha = attn_exp2(m_run[t] - m_use);                     // m_run = -inf -> 0
             float psum = 0.f;
             uint32_t pk[kKB / 16][2];
 #pragma unroll
             for (int kt = 0; kt < kKB / 16; ++kt) {
-                const float p0 = exp2f(s[kt][0] - m_use), p1 = exp2f(s[kt][1] - m_use);
-                const float p2 = exp2f(s[kt][2] - m_use), p3 = exp2f(s[kt][3] - m_use);
+                const float p0 = attn_exp2(s[kt][0] - m_use), p1 = attn_exp2(s[kt][1] - m_use);
+                const float p2 = attn_exp2(s[kt][2] - m_use), p3 = attn_exp2(s[kt][3] - m_use);
                 psum += (p0 + p1) + (p2 + p3);
                 pk[kt][0] = pack2(p0, p1); pk[kt][1] = pack2(p2, p3);
             }
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const uint16_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool dead = key + r >= L || ((mb >> r) & 1u);
-                    const float p = dead ? 0.f : exp2f(s[r] * scale_log2e - lse_q[t]);
+                    const float p = dead ? 0.f : attn_exp2(s[r] * scale_log2e - lse_q[t]);
                     ds[r] = p * (dp[r] - dl[t]) * scale;
                 }
                 pk[kt][0] = pack2(ds[0], ds[1]); pk[kt][1] = pack2(ds[2], ds[3]);
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const uint16_t *
                     bool dead = key >= L || qq >= L;
                     if (MM == 2) dead = dead || ((mw[kt] >> (qt * 16 + 4 * g + r)) & 1u);
                     else if (MM == 1 && !dead) dead = mask[(int64_t)qq * L + key] != 0;
-                    p[r] = dead ? 0.f : exp2f(s[r] * scale_log2e - lq[r]);
+                    p[r] = dead ? 0.f : attn_exp2(s[r] * scale_log2e - lq[r]);
                     ds[r] = p[r] * (dp[r] - dq_[r]) * scale;
                 }
                 if (qt == 0) { pp[kt][0] = pack2(p[0], p[1]); pp[kt][1] = pack2(p[2], p[3]); dsp[kt][0] = pack2(ds[0], ds[1]); dsp[kt][1] = pack2(ds[2], ds[3]); }
