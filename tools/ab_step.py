@@ -43,7 +43,14 @@ def setting(on):
         name, vals = what.split("=")
         mod, attr = name.split(".")
         a, b = vals.split(",")
-        setattr({"hip": hip, "kernels": kernels}[mod], attr, type(getattr({"hip": hip, "kernels": kernels}[mod], attr))(b if on else a))
+        old = getattr({"hip": hip, "kernels": kernels}[mod], attr)
+        val = tuple(filter(None, (b if on else a).split("+"))) if isinstance(old, tuple) else type(old)(b if on else a)   # tuples: "c3+k2"
+        setattr({"hip": hip, "kernels": kernels}[mod], attr, val)
+        if os.environ.get("AB_RECAPTURE") == "1":      # the setting is baked into the captured graphs: build them again
+            torch.cuda.synchronize()
+            for seg in list(step._graphs.values()):
+                seg.release()
+            step._graphs.clear()
         if attr == "_SIDE_PRIORITY":                   # the side stream is made again with the new priority
             torch.cuda.synchronize()
             hip._SIDE.clear()
