@@ -19,11 +19,13 @@
 //                     taps for a range of (image, strip) units, fp32 partial sums per split (reduced by conv.hip's
 //                     conv_wgrad_reduce_kernel, same [split][n][c][tap] layout).
 #include "common.h"
+#include <type_traits>
 
 namespace dfine {
 
 typedef __attribute__((ext_vector_type(4))) float f4v;
-constexpr int kF32Threads = 256, kF32KC = 16, kF32MaxTiles = 10;
+constexpr int kF32Threads = 256, kF32KC = 16, kF32MaxTiles = 10, kF32WP = 20;   // kF32WP: weight row pitch in LDS (16-byte rows, the
+                                                                                 // 16 x 4 (n, k) reads of an A fragment on 64 distinct banks)
 
 // fp32 master [Cout][Cin][KS][KS] -> [KS*KS][NP][KP] fp32 (NP = n rounded up to 64, KP = k rounded up to 16, zero padded).
 // dgrad = 1: n = cin, k = cout, taps flipped.
@@ -43,14 +45,19 @@ __global__ void conv_pack_f32_kernel(const float *__restrict__ w, float *__restr
     }
 }
 
-template <int KS, int S>
-__global__ __launch_bounds__(kF32Threads) void conv_f32_kernel(const float *__restrict__ x, const float *__restrict__ w2, float *__restrict__ y,
+// NWN = waves along the output channels (a workgroup owns 16 NWN of them), the other 4 / NWN wave groups share the pixel tiles:
+// a 16-channel layer (the stem, stage 1) keeps all four waves busy on 640 pixels instead of three idle ones on 160.
+// Staging issues its global loads in batches (8 x-tile loads, all weight vectors of the stage) before the LDS stores: with one
+// load -> store pair per loop trip the stage was a chain of ~50 dependent memory round trips (15 us against 5 us of MFMA work).
+template <int KS, int S, int NWN>
+__global__ __launch_bounds__(kF32Threads, 2) void conv_f32_kernel(const float *__restrict__ x, const float *__restrict__ w2, float *__restrict__ y,
                                                                int Cin, int Cout, int NP, int KP, int Hi, int Wi, int Ho, int Wo, int pt, int pl,
-                                                               int R, int CW, int strips, int ctiles) {
+                                                               int R, int CW, int strips, int ctiles, int kc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    constexpr int TAPS = KS * KS;
+    constexpr int TAPS = KS * KS, NB = 16 * NWN, PW = 4 / NWN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int nw = wave % NWN, pw = wave / NWN;
     const int g = lane >> 4, i16 = lane & 15;
     int u = blockIdx.x;
     const int ct = u % ctiles; u /= ctiles;
@@ -60,16 +67,17 @@ __global__ __launch_bounds__(kF32Threads) void conv_f32_kernel(const float *__re
     const int TP = rows * cols;
     const int rows_l = (R - 1) * S + KS, WL = (CW - 1) * S + KS;
     const int iy0 = r0 * S - pt, ix0 = x0 * S - pl;
-    float *xs = reinterpret_cast<float *>(lds_raw);                    // [kF32KC][rows_l][WL]
-    float *ws = xs + kF32KC * rows_l * WL;                             // [TAPS][64][kF32KC + 1]
-    constexpr int WP = kF32KC + 1;
-    const int n0 = blockIdx.y * 64;
+    const int xelems = rows_l * WL;
+    float *xs = reinterpret_cast<float *>(lds_raw);                    // [kc][rows_l][WL]
+    float *ws = xs + ((kc * xelems + 3) & ~3);                         // [TAPS][NB][kF32WP]
+    const int n0 = blockIdx.y * NB;
     const int ntile = (TP + 15) / 16;
-    // LDS offset of this lane's pixel (tap 0) per pixel tile
+    const int ntw = __builtin_amdgcn_readfirstlane((ntile - pw + PW - 1) / PW);        // pixel tiles of this wave
+    // LDS offset of this lane's pixel (tap 0) per pixel tile of this wave (tiles pw, pw + PW, ...)
     int pl_off[kF32MaxTiles];
 #pragma unroll
     for (int jt = 0; jt < kF32MaxTiles; ++jt) {
-        int q = jt * 16 + i16;
+        int q = (pw + PW * jt) * 16 + i16;
         if (q >= TP) q = 0;
         const int oy = q / cols, ox = q - oy * cols;
         pl_off[jt] = (oy * S) * WL + ox * S;
@@ -78,75 +86,121 @@ __global__ __launch_bounds__(kF32Threads) void conv_f32_kernel(const float *__re
 #pragma unroll
     for (int jt = 0; jt < kF32MaxTiles; ++jt) acc[jt] = f4v{0.f, 0.f, 0.f, 0.f};
     const float *xb = x + (int64_t)b * Cin * Hi * Wi;
-    const int xelems = rows_l * WL;
+    constexpr int WV = TAPS * NB * 4, WIT = (WV + kF32Threads - 1) / kF32Threads;      // float4 vectors of a stage's weights
     for (int c0 = 0; c0 < KP; c0 += kF32KC) {
-        __syncthreads();
-        // one wave per (channel, tile row): the row / channel split runs on the scalar unit, lanes walk the columns (an integer
-        // division pair per ELEMENT made this loop the kernel's bottleneck on the 3-channel stem: 935 us for 1.4 GFLOP)
         const int kkn = (min(kF32KC, Cin - c0) + 3) >> 2;                  // 4-channel groups of this stage that hold data
-        for (int row = wv; row < 4 * kkn * rows_l; row += 4) {
-            const int c = row / rows_l, ly = row - c * rows_l;
-            const int iy = iy0 + ly;
-            const bool ok = c0 + c < Cin && iy >= 0 && iy < Hi;
-            const float *src = xb + ((int64_t)(c0 + c) * Hi + (ok ? iy : 0)) * Wi;
-            float *dst = xs + row * WL;
-            for (int lx = lane; lx < WL; lx += 64) {
-                const int ix = ix0 + lx;
-                dst[lx] = (ok && ix >= 0 && ix < Wi) ? src[ix] : 0.f;
+        float4 wreg[WIT];
+#pragma unroll
+        for (int j = 0; j < WIT; ++j) {
+            const int idx = tid + kF32Threads * j;
+            wreg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (WV % kF32Threads == 0 || idx < WV) {
+                const int k4 = idx & 3, n = (idx >> 2) % NB, tap = idx / (4 * NB);
+                wreg[j] = *reinterpret_cast<const float4 *>(w2 + ((int64_t)tap * NP + n0 + n) * KP + c0 + 4 * k4);
             }
         }
-        for (int i = tid; i < TAPS * 64 * kF32KC; i += kF32Threads) {
-            const int k = i % kF32KC, n = (i / kF32KC) % 64, tap = i / (kF32KC * 64);
-            ws[(tap * 64 + n) * WP + k] = w2[((int64_t)tap * NP + n0 + n) * KP + c0 + k];
+        __syncthreads();                                                   // the previous stage's MFMAs have read xs / ws
+#pragma unroll
+        for (int j = 0; j < WIT; ++j) {
+            const int idx = tid + kF32Threads * j;
+            if (WV % kF32Threads == 0 || idx < WV) {
+                const int k4 = idx & 3, n = (idx >> 2) % NB, tap = idx / (4 * NB);
+                *reinterpret_cast<float4 *>(ws + (tap * NB + n) * kF32WP + 4 * k4) = wreg[j];
+            }
+        }
+        // x tile: a wave takes (channel, tile row) rows wv, wv + 4, ...; four rows x two 64-column chunks are in flight at a time
+        // (the row / channel split runs on the scalar unit: an integer division pair per ELEMENT made this the bottleneck of the
+        // 3-channel stem)
+        const int nrows = 4 * kkn * rows_l;
+        for (int rb = wv; rb < nrows; rb += 16) {
+            const float *src[4];
+            bool ok[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rb + 4 * i;
+                const int c = row / rows_l, ly = row - c * rows_l;
+                const int iy = iy0 + ly;
+                ok[i] = row < nrows && c0 + c < Cin && iy >= 0 && iy < Hi;
+                src[i] = xb + ((int64_t)(ok[i] ? c0 + c : 0) * Hi + (ok[i] ? iy : 0)) * Wi;
+            }
+            for (int lx0 = 0; lx0 < WL; lx0 += 128) {
+                float v[4][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int ix = ix0 + lx0 + 64 * h + lane;
+                        v[i][h] = (ok[i] && ix >= 0 && ix < Wi) ? src[i][ix] : 0.f;
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int lx = lx0 + 64 * h + lane;
+                        if (rb + 4 * i < nrows && lx < WL) xs[(rb + 4 * i) * WL + lx] = v[i][h];
+                    }
+            }
         }
         __syncthreads();
+        // the MFMA section in three sizes (2 / 5 / 10 pixel tiles per wave, chosen per workgroup): a short strip does not pay for
+        // ten tiles, and every size is straight-line code on registers
+        auto stage_mfma = [&](auto nt_c) {
+            constexpr int NT = decltype(nt_c)::value;
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int toff = (tap / KS) * WL + (tap % KS);
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int toff = (tap / KS) * WL + (tap % KS);
 #pragma unroll
-            for (int kk = 0; kk < kF32KC / 4; ++kk) {
-                if (kk >= kkn) break;                                      // uniform: channel groups past Cin (the stem: 3 channels)
-                const float a = ws[(tap * 64 + wave * 16 + i16) * WP + kk * 4 + g];
-                const float *xr = xs + (kk * 4 + g) * xelems + toff;
+                for (int kk = 0; kk < kF32KC / 4; ++kk) {
+                    if (kk >= kkn) break;                                  // uniform: channel groups past Cin (the stem: 3 channels)
+                    const float a = ws[(tap * NB + nw * 16 + i16) * kF32WP + kk * 4 + g];
+                    const float *xr = xs + (kk * 4 + g) * xelems + toff;
 #pragma unroll
-                for (int jt = 0; jt < kF32MaxTiles; ++jt)      // tiles past the strip read pixel 0 and are never stored: no branches
-                    acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xr[pl_off[jt]], acc[jt], 0, 0, 0);
+                    for (int jt = 0; jt < NT; ++jt)            // tiles past the strip read pixel 0 and are never stored: no branches
+                        acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xr[pl_off[jt]], acc[jt], 0, 0, 0);
+                }
             }
-        }
+        };
+        if (ntw <= 2) stage_mfma(std::integral_constant<int, 2>{});
+        else if (ntw <= 5) stage_mfma(std::integral_constant<int, 5>{});
+        else stage_mfma(std::integral_constant<int, kF32MaxTiles>{});
     }
     float *yb = y + (int64_t)b * Cout * Ho * Wo;
 #pragma unroll
     for (int jt = 0; jt < kF32MaxTiles; ++jt) {
-        const int q = jt * 16 + i16;
-        if (jt < ntile && q < TP) {
+        const int t = pw + PW * jt;
+        const int q = t * 16 + i16;
+        if (t < ntile && q < TP) {
             const int oy = q / cols, ox = q - oy * cols;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wave * 16 + 4 * g + r;
+                const int n = n0 + nw * 16 + 4 * g + r;
                 if (n < Cout) yb[((int64_t)n * Ho + r0 + oy) * Wo + x0 + ox] = acc[jt][r];
             }
         }
     }
 }
 
-// part[split][NP16][CP16][TAPS]; block = (64-row n tile, 16-column c tile) x split
-template <int KS, int S>
+// part[split][NP16][CP16][TAPS]; block = (16 NWN-row n tile, 16-column c tile) x split.  NWN waves along the output channels;
+// the other 4 / NWN wave groups deal the pixel steps of a unit among themselves and write their own slab each
+// (slab = split * (4 / NWN) + group): a 16-channel layer keeps four waves busy instead of one.  Staging in batches of 8 loads.
+template <int KS, int S, int NWN>
 __global__ __launch_bounds__(kF32Threads) void wgrad_f32_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ part,
                                                                 int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int pt, int pl, int R, int CW,
                                                                 int strips, int ctiles, int total_units, int units_per_split, int nct, int NP16,
                                                                 int CP16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    constexpr int TAPS = KS * KS;
+    constexpr int TAPS = KS * KS, NB = 16 * NWN, PW = 4 / NWN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int nw = wave % NWN, pw = wave / NWN;
     const int g = lane >> 4, i16 = lane & 15;
     const int nt = blockIdx.x / nct, ctile = blockIdx.x - nt * nct;
-    const int n0 = nt * 64, c0 = ctile * 16;
+    const int n0 = nt * NB, c0 = ctile * 16;
     const int split = blockIdx.y;
     const int rows_l = (R - 1) * S + KS, WL = (CW - 1) * S + KS, xelems = rows_l * WL;
     const int TPmax = R * CW, DP = TPmax + 4;                              // dy tile pitch
     float *xs = reinterpret_cast<float *>(lds_raw);                       // [16 c][rows_l][WL]
-    float *ds = xs + 16 * xelems;                                          // [64 n][DP]
+    float *ds = xs + 16 * xelems;                                          // [NB n][DP]
     f4v acc[TAPS];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) acc[t] = f4v{0.f, 0.f, 0.f, 0.f};
@@ -162,30 +216,77 @@ __global__ __launch_bounds__(kF32Threads) void wgrad_f32_kernel(const float *__r
         const float *xb = x + (int64_t)b * Cin * Hi * Wi;
         const float *dyb = dy + (int64_t)b * Cout * Ho * Wo;
         __syncthreads();
-        for (int row = wv; row < 16 * rows_l; row += 4) {                  // (channel, tile row) per wave, lanes over the columns
-            const int c = row / rows_l, ly = row - c * rows_l;
-            const int iy = iy0 + ly;
-            const bool ok = c0 + c < Cin && iy >= 0 && iy < Hi;
-            const float *src = xb + ((int64_t)(c0 + c) * Hi + (ok ? iy : 0)) * Wi;
-            float *dst = xs + row * WL;
-            for (int lx = lane; lx < WL; lx += 64) {
-                const int ix = ix0 + lx;
-                dst[lx] = (ok && ix >= 0 && ix < Wi) ? src[ix] : 0.f;
+        {                                                                  // x tile: (channel, tile row) rows per wave, lanes over the columns
+            const int nrows = 16 * rows_l;
+            for (int rb = wv; rb < nrows; rb += 16) {
+                const float *src[4];
+                bool ok[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = rb + 4 * i;
+                    const int c = row / rows_l, ly = row - c * rows_l;
+                    const int iy = iy0 + ly;
+                    ok[i] = row < nrows && c0 + c < Cin && iy >= 0 && iy < Hi;
+                    src[i] = xb + ((int64_t)(ok[i] ? c0 + c : 0) * Hi + (ok[i] ? iy : 0)) * Wi;
+                }
+                for (int lx0 = 0; lx0 < WL; lx0 += 128) {
+                    float v[4][2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int ix = ix0 + lx0 + 64 * h + lane;
+                            v[i][h] = (ok[i] && ix >= 0 && ix < Wi) ? src[i][ix] : 0.f;
+                        }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int lx = lx0 + 64 * h + lane;
+                            if (rb + 4 * i < nrows && lx < WL) xs[(rb + 4 * i) * WL + lx] = v[i][h];
+                        }
+                }
             }
         }
         const int TP4 = (TP + 3) & ~3;
-        for (int row = wv; row < 64 * rows; row += 4) {                    // (output channel, output row) per wave
-            const int n = row / rows, oy = row - n * rows;
-            const bool ok = n0 + n < Cout;
-            const float *src = dyb + ((int64_t)(ok ? n0 + n : 0) * Ho + r0 + oy) * Wo + x0;
-            float *dst = ds + n * DP + oy * cols;
-            for (int ox = lane; ox < cols; ox += 64) dst[ox] = ok ? src[ox] : 0.f;
+        {                                                                  // dy tile: (output channel, output row) rows per wave
+            const int nrows = NB * rows;
+            for (int rb = wv; rb < nrows; rb += 16) {
+                const float *src[4];
+                float *dst[4];
+                bool ok[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = rb + 4 * i;
+                    const int n = row / rows, oy = row - n * rows;
+                    ok[i] = row < nrows && n0 + n < Cout;
+                    src[i] = dyb + ((int64_t)(ok[i] ? n0 + n : 0) * Ho + r0 + (row < nrows ? oy : 0)) * Wo + x0;
+                    dst[i] = ds + n * DP + oy * cols;
+                }
+                for (int lx0 = 0; lx0 < cols; lx0 += 128) {
+                    float v[4][2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int ox = lx0 + 64 * h + lane;
+                            v[i][h] = (ok[i] && ox < cols) ? src[i][ox] : 0.f;
+                        }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int ox = lx0 + 64 * h + lane;
+                            if (rb + 4 * i < nrows && ox < cols) dst[i][ox] = v[i][h];
+                        }
+                }
+            }
         }
         if (TP4 > TP)
-            for (int i = tid; i < 64 * (TP4 - TP); i += kF32Threads) ds[(i / (TP4 - TP)) * DP + TP + i % (TP4 - TP)] = 0.f;
+            for (int i = tid; i < NB * (TP4 - TP); i += kF32Threads) ds[(i / (TP4 - TP)) * DP + TP + i % (TP4 - TP)] = 0.f;
         __syncthreads();
-        for (int k0 = 0; k0 < TP4; k0 += 4) {
-            const float a = ds[(wave * 16 + i16) * DP + k0 + g];           // A[n = i16][k = pixel k0 + g]
+        for (int k0 = 4 * pw; k0 < TP4; k0 += 4 * PW) {
+            const float a = ds[(nw * 16 + i16) * DP + k0 + g];             // A[n = i16][k = pixel k0 + g]
             int q = k0 + g;                                               // B[k = pixel][c = i16]
             if (q >= TP) q = 0;                                           // its dy is zero
             const int oy = q / cols, ox = q - oy * cols;
@@ -195,14 +296,14 @@ __global__ __launch_bounds__(kF32Threads) void wgrad_f32_kernel(const float *__r
                 acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xr[(tap / KS) * WL + (tap % KS)], acc[tap], 0, 0, 0);
         }
     }
-    // D lane l reg r: n = 4 g + r (+ 16 wave), c = i16
+    // D lane l reg r: n = 4 g + r (+ 16 nw), c = i16
     const int c = c0 + i16;
     if (c < CP16) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int n = n0 + wave * 16 + 4 * g + r;
+            const int n = n0 + nw * 16 + 4 * g + r;
             if (n < NP16) {
-                float *dst = part + (((int64_t)split * NP16 + n) * CP16 + c) * TAPS;
+                float *dst = part + ((((int64_t)split * PW + pw) * NP16 + n) * CP16 + c) * TAPS;
 #pragma unroll
                 for (int t = 0; t < TAPS; ++t) dst[t] = acc[t][r];
             }
@@ -229,6 +330,32 @@ static void f32_plan(int Ho, int Wo, int *R, int *CW, int *strips, int *ctiles) 
     if (*R > Ho) *R = Ho;
     *strips = (Ho + *R - 1) / *R;
     *ctiles = (Wo + *CW - 1) / *CW;
+}
+
+// Forward plan: NWN waves along the output channels (1 / 2 / 4 for <= 16 / <= 32 / more channels), strips of R output rows x CW
+// columns with at most 160 * (4 / NWN) pixels (10 MFMA tiles per wave), the strip halved while the launch has fewer than ~3
+// workgroups per CU (small maps: 16 x 20 x 20 pixels made 48 workgroups of 160 pixels) and while the LDS tile exceeds half a CU's.
+static void f32_fwd_plan(int B, int Cin, int Cout, int Ho, int Wo, int KS, int S, int *NWN, int *R, int *CW, int *strips, int *ctiles, int *kc,
+                         size_t *ldsb) {
+    const int nb16 = (Cout + 15) / 16;
+    *NWN = nb16 >= 3 ? 4 : nb16;
+    *kc = Cin >= 16 ? 16 : (Cin + 3) / 4 * 4;
+    const int cap = 160 * (4 / *NWN);
+    *CW = Wo <= 160 ? Wo : 160;
+    while (Wo > 160 && Wo % *CW) --*CW;                   // equal column tiles where the width allows (320 -> 160)
+    *ctiles = (Wo + *CW - 1) / *CW;
+    int r = cap / *CW < 1 ? 1 : cap / *CW;
+    if (r > Ho) r = Ho;
+    const int nblk = (Cout + 16 * *NWN - 1) / (16 * *NWN);
+    auto lds = [&](int rr) {
+        const int rows_l = (rr - 1) * S + KS, WL = (*CW - 1) * S + KS;
+        return sizeof(float) * ((((size_t)*kc * rows_l * WL + 3) & ~(size_t)3) + (size_t)KS * KS * 16 * *NWN * kF32WP);
+    };
+    while (r > 1 && lds(r) > 80 * 1024) --r;
+    while (r > 1 && (int64_t)B * ((Ho + r - 1) / r) * *ctiles * nblk < 768) r = (r + 1) / 2;
+    *R = r;
+    *strips = (Ho + r - 1) / r;
+    *ldsb = lds(r);
 }
 
 }  // namespace dfine
@@ -260,19 +387,24 @@ int dfine_conv_f32_fwd(const float *x, const float *w2, float *y, int B, int Cin
     if (B == 0) return DFINE_OK;
     if (!x || !w2 || !y || Cin < 1 || Cout < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1 || KS < 1 || KS > 3 || (S != 1 && S != 2) || pt < 0 || pl < 0)
         return DFINE_E_BADARG;
-    int R, CW, strips, ctiles;
-    f32_plan(Ho, Wo, &R, &CW, &strips, &ctiles);
+    int NWN, R, CW, strips, ctiles, kc;
+    size_t ldsb;
+    f32_fwd_plan(B, Cin, Cout, Ho, Wo, KS, S, &NWN, &R, &CW, &strips, &ctiles, &kc, &ldsb);
     const int NP = (Cout + 63) / 64 * 64, KP = (Cin + 15) / 16 * 16;
-    const int rows_l = (R - 1) * S + KS, WL = (CW - 1) * S + KS;
-    const size_t ldsb = sizeof(float) * ((size_t)kF32KC * rows_l * WL + (size_t)KS * KS * 64 * (kF32KC + 1));
     if (ldsb > 160 * 1024) return DFINE_E_BADARG;
-    const dim3 grid(B * strips * ctiles, NP / 64);
+    const dim3 grid(B * strips * ctiles, (Cout + 16 * NWN - 1) / (16 * NWN));
     hipStream_t st = (hipStream_t)stream;
-#define DFINE_F32_CONV(KSS, SS)                                                                                                       \
+#define DFINE_F32_CONV_N(KSS, SS, NW)                                                                                                 \
     {                                                                                                                                 \
         static bool attr = false;                                                                                                     \
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f32_kernel<KSS, SS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
-        hipLaunchKernelGGL((conv_f32_kernel<KSS, SS>), grid, dim3(kF32Threads), ldsb, st, x, w2, y, Cin, Cout, NP, KP, Hi, Wi, Ho, Wo, pt, pl, R, CW, strips, ctiles); \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f32_kernel<KSS, SS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL((conv_f32_kernel<KSS, SS, NW>), grid, dim3(kF32Threads), ldsb, st, x, w2, y, Cin, Cout, NP, KP, Hi, Wi, Ho, Wo, pt, pl, R, CW, strips, ctiles, kc); \
+    }
+#define DFINE_F32_CONV(KSS, SS)                                                                                                       \
+    {                                                                                                                                 \
+        if (NWN == 1) DFINE_F32_CONV_N(KSS, SS, 1)                                                                                    \
+        else if (NWN == 2) DFINE_F32_CONV_N(KSS, SS, 2)                                                                               \
+        else DFINE_F32_CONV_N(KSS, SS, 4)                                                                                             \
     }
     if (KS == 1 && S == 1) DFINE_F32_CONV(1, 1)
     else if (KS == 1 && S == 2) DFINE_F32_CONV(1, 2)
@@ -281,17 +413,23 @@ int dfine_conv_f32_fwd(const float *x, const float *w2, float *y, int B, int Cin
     else if (KS == 3 && S == 1) DFINE_F32_CONV(3, 1)
     else DFINE_F32_CONV(3, 2)
 #undef DFINE_F32_CONV
+#undef DFINE_F32_CONV_N
     return check_launch();
 }
 
-static void f32_wgrad_plan(int B, int Cin, int Cout, int Ho, int Wo, int KS, int *R, int *CW, int *strips, int *ctiles, int *splits, int *ups) {
+static void f32_wgrad_plan(int B, int Cin, int Cout, int Ho, int Wo, int KS, int *NWN, int *R, int *CW, int *strips, int *ctiles, int *splits,
+                           int *ups) {
     f32_plan(Ho, Wo, R, CW, strips, ctiles);
+    const int nb16 = (Cout + 15) / 16;
+    *NWN = nb16 >= 3 ? 4 : nb16;
+    const int pw = 4 / *NWN;                              // slabs per block
     const int units = B * *strips * *ctiles;
-    const int tiles = ((Cout + 63) / 64) * ((Cin + 15) / 16);
+    const int tiles = ((Cout + 16 * *NWN - 1) / (16 * *NWN)) * ((Cin + 15) / 16);
     int sp = 2048 / tiles;
+    if (pw > 1) sp = sp / pw > 768 / tiles ? sp / pw : (768 / tiles < sp ? 768 / tiles : sp);
     if (sp < 1) sp = 1;
-    const int64_t bytes_per_split = (int64_t)((Cout + 15) / 16 * 16) * ((Cin + 15) / 16 * 16) * KS * KS * 4;
-    int cap = (int)(32000000 / bytes_per_split);
+    const int64_t bytes_per_slab = (int64_t)((Cout + 15) / 16 * 16) * ((Cin + 15) / 16 * 16) * KS * KS * 4;
+    int cap = (int)(32000000 / (bytes_per_slab * pw));
     if (cap < 4) cap = 4;
     if (sp > cap) sp = cap;
     if (sp > units) sp = units;
@@ -299,33 +437,40 @@ static void f32_wgrad_plan(int B, int Cin, int Cout, int Ho, int Wo, int KS, int
     *splits = (units + *ups - 1) / *ups;
 }
 
+// number of partial slabs dfine_conv_f32_wgrad writes
 int dfine_conv_f32_wgrad_splits(int B, int Cin, int Cout, int Ho, int Wo, int KS) {
-    int R, CW, strips, ctiles, splits, ups;
-    f32_wgrad_plan(B, Cin, Cout, Ho, Wo, KS, &R, &CW, &strips, &ctiles, &splits, &ups);
-    return splits;
+    int NWN, R, CW, strips, ctiles, splits, ups;
+    f32_wgrad_plan(B, Cin, Cout, Ho, Wo, KS, &NWN, &R, &CW, &strips, &ctiles, &splits, &ups);
+    return splits * (4 / NWN);
 }
 
-// part [splits][NP16][CP16][KS*KS] f32 (NP16 / CP16 = Cout / Cin rounded up to 16): per-split partial sums of
-// dW = sum_{b, p} dy x, to be reduced by dfine_multi_wgrad_reduce / summed by the caller.
+// part [slabs][NP16][CP16][KS*KS] f32 (NP16 / CP16 = Cout / Cin rounded up to 16, slabs = dfine_conv_f32_wgrad_splits): partial
+// sums of dW = sum_{b, p} dy x, to be reduced by dfine_multi_wgrad_reduce / summed by the caller.
 int dfine_conv_f32_wgrad(const float *x, const float *dy, float *part, int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int KS, int S,
                          int pt, int pl, void *stream) {
     if (B == 0) return DFINE_OK;
     if (!x || !dy || !part || Cin < 1 || Cout < 1 || KS < 1 || KS > 3 || (S != 1 && S != 2)) return DFINE_E_BADARG;
-    int R, CW, strips, ctiles, splits, ups;
-    f32_wgrad_plan(B, Cin, Cout, Ho, Wo, KS, &R, &CW, &strips, &ctiles, &splits, &ups);
+    int NWN, R, CW, strips, ctiles, splits, ups;
+    f32_wgrad_plan(B, Cin, Cout, Ho, Wo, KS, &NWN, &R, &CW, &strips, &ctiles, &splits, &ups);
     const int np16 = (Cout + 15) / 16 * 16, cp16 = (Cin + 15) / 16 * 16;
-    const int nnt = (Cout + 63) / 64, nct = (Cin + 15) / 16;
+    const int nnt = (Cout + 16 * NWN - 1) / (16 * NWN), nct = (Cin + 15) / 16;
     const int rows_l = (R - 1) * S + KS, WL = (CW - 1) * S + KS;
-    const size_t ldsb = sizeof(float) * ((size_t)16 * rows_l * WL + (size_t)64 * (R * CW + 4));
+    const size_t ldsb = sizeof(float) * ((size_t)16 * rows_l * WL + (size_t)16 * NWN * (R * CW + 4));
     if (ldsb > 160 * 1024) return DFINE_E_BADARG;
     const dim3 grid(nnt * nct, splits);
     hipStream_t st = (hipStream_t)stream;
-#define DFINE_F32_WG(KSS, SS)                                                                                                         \
+#define DFINE_F32_WG_N(KSS, SS, NW)                                                                                                   \
     {                                                                                                                                 \
         static bool attr = false;                                                                                                     \
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_f32_kernel<KSS, SS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
-        hipLaunchKernelGGL((wgrad_f32_kernel<KSS, SS>), grid, dim3(kF32Threads), ldsb, st, x, dy, part, Cin, Cout, Hi, Wi, Ho, Wo, pt, pl, R, CW, strips, ctiles, \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_f32_kernel<KSS, SS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL((wgrad_f32_kernel<KSS, SS, NW>), grid, dim3(kF32Threads), ldsb, st, x, dy, part, Cin, Cout, Hi, Wi, Ho, Wo, pt, pl, R, CW, strips, ctiles, \
                            B * strips * ctiles, ups, nct, np16, cp16);                                                                \
+    }
+#define DFINE_F32_WG(KSS, SS)                                                                                                         \
+    {                                                                                                                                 \
+        if (NWN == 1) DFINE_F32_WG_N(KSS, SS, 1)                                                                                      \
+        else if (NWN == 2) DFINE_F32_WG_N(KSS, SS, 2)                                                                                 \
+        else DFINE_F32_WG_N(KSS, SS, 4)                                                                                               \
     }
     if (KS == 1 && S == 1) DFINE_F32_WG(1, 1)
     else if (KS == 1 && S == 2) DFINE_F32_WG(1, 2)
@@ -334,6 +479,7 @@ int dfine_conv_f32_wgrad(const float *x, const float *dy, float *part, int B, in
     else if (KS == 3 && S == 1) DFINE_F32_WG(3, 1)
     else DFINE_F32_WG(3, 2)
 #undef DFINE_F32_WG
+#undef DFINE_F32_WG_N
     return check_launch();
 }
 
