@@ -1082,6 +1082,164 @@ __global__ __launch_bounds__(kBnOneThreads) void bn_one_bwd_stream_kernel(
     }
 }
 
+// fp32 maps (BASELINE config #2, no autocast): the same one-block-per-channel scheme with 16-byte vectors of four floats, both
+// directions as two streamed passes (the second one re-reads from L2 what the block itself just pulled in): one launch per unit
+// and direction instead of three (statistics / finalize / apply: 26 + 39 us per unit on the 40x40 / 20x20 planes of D-FINE-s,
+// launch-floor bound).
+template <int ACT>
+__global__ __launch_bounds__(kBnOneThreads) void bn_one_fwd_f32_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                                      const float *__restrict__ lab_s, const float *__restrict__ lab_b,
+                                                                      int C, int HW, int B, BnFusedFin fin) {
+    constexpr int act = ACT;
+    constexpr int kBatch = 4;
+    __shared__ float red[2 * kBnOneThreads / 64];
+    const int c = blockIdx.x;
+    const int nvhw = HW >> 2, nvec = B * nvhw;
+    const uint32_t sq = kBnOneThreads / nvhw, sr = kBnOneThreads % nvhw;
+    auto offset = [&](QR p) -> int64_t { return ((int64_t)p.q * C + c) * HW + p.r * 4; };
+    float v[2] = {0.f, 0.f};
+    {
+        QR pos = qr_init(threadIdx.x, nvhw);
+        for (int i0 = threadIdx.x; i0 < nvec; i0 += kBatch * kBnOneThreads) {
+            float4 xr[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                xr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i0 + k * kBnOneThreads < nvec) xr[k] = *reinterpret_cast<const float4 *>(x + offset(pos));
+                pos = qr_step(pos, sq, sr, nvhw);
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                v[0] += (xr[k].x + xr[k].y) + (xr[k].z + xr[k].w);
+                v[1] += (xr[k].x * xr[k].x + xr[k].y * xr[k].y) + (xr[k].z * xr[k].z + xr[k].w * xr[k].w);
+            }
+        }
+    }
+    block_reduce_one<2>(v, red);
+    const double mean = (double)v[0] / fin.count;
+    double var = (double)v[1] / fin.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)fin.eps));
+    const float g = fin.gamma ? fin.gamma[c] : 1.f, bt = fin.beta ? fin.beta[c] : 0.f;
+    const float sc = g * invstd, sh = bt - (float)mean * g * invstd;
+    if (threadIdx.x == 0) {
+        fin.mean_out[c] = (float)mean; fin.invstd_out[c] = invstd; fin.scale_out[c] = sc; fin.shift_out[c] = sh;
+        if (fin.running_mean) {
+            const double unbiased = fin.count > 1.0 ? var * fin.count / (fin.count - 1.0) : var;
+            fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * (float)mean;
+            fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unbiased;
+        }
+    }
+    const float ls = lab_s ? lab_s[0] : 1.f, lb = lab_b ? lab_b[0] : 0.f;
+    {
+        QR pos = qr_init(threadIdx.x, nvhw);
+        for (int i0 = threadIdx.x; i0 < nvec; i0 += kBatch * kBnOneThreads) {
+            float4 xr[kBatch];
+            int64_t off[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                off[k] = -1;
+                if (i0 + k * kBnOneThreads < nvec) { off[k] = offset(pos); xr[k] = *reinterpret_cast<const float4 *>(x + off[k]); }
+                pos = qr_step(pos, sq, sr, nvhw);
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                if (off[k] < 0) continue;
+                float4 o;
+                o.x = ls * act_fwd(xr[k].x * sc + sh, act) + lb; o.y = ls * act_fwd(xr[k].y * sc + sh, act) + lb;
+                o.z = ls * act_fwd(xr[k].z * sc + sh, act) + lb; o.w = ls * act_fwd(xr[k].w * sc + sh, act) + lb;
+                *reinterpret_cast<float4 *>(y + off[k]) = o;
+            }
+        }
+    }
+}
+
+template <int ACT, bool LAB>
+__global__ __launch_bounds__(kBnOneThreads) void bn_one_bwd_f32_kernel(
+    const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dx, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ lab_s,
+    float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dlab, int C, int HW, int B, double count) {
+    constexpr int act = ACT;
+    constexpr int kBatch = 2;                                           // x and dy: 4 vectors of a thread in flight
+    __shared__ float red[4 * kBnOneThreads / 64];
+    const int c = blockIdx.x;
+    const int nvhw = HW >> 2, nvec = B * nvhw;
+    const float mu = mean[c], is = invstd[c], sc = scale[c], sh = shift[c];
+    const float ls = lab_s ? lab_s[0] : 1.f;
+    const uint32_t sq = kBnOneThreads / nvhw, sr = kBnOneThreads % nvhw;
+    auto offset = [&](QR p) -> int64_t { return ((int64_t)p.q * C + c) * HW + p.r * 4; };
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        QR pos = qr_init(threadIdx.x, nvhw);
+        for (int i0 = threadIdx.x; i0 < nvec; i0 += kBatch * kBnOneThreads) {
+            float4 xr[kBatch], gr[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                xr[k] = make_float4(0.f, 0.f, 0.f, 0.f); gr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i0 + k * kBnOneThreads < nvec) {
+                    const int64_t o = offset(pos);
+                    xr[k] = *reinterpret_cast<const float4 *>(x + o);
+                    gr[k] = *reinterpret_cast<const float4 *>(dy + o);
+                }
+                pos = qr_step(pos, sq, sr, nvhw);
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const float a[4] = {xr[k].x, xr[k].y, xr[k].z, xr[k].w}, g[4] = {gr[k].x, gr[k].y, gr[k].z, gr[k].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {                       // padded slots carry g = 0 and contribute nothing
+                    const float z = a[e] * sc + sh;
+                    const float dz = g[e] * ls * act_grad(z, act);
+                    v[0] += dz; v[1] += dz * ((a[e] - mu) * is);
+                    if (LAB) { v[2] += g[e] * act_fwd(z, act); v[3] += g[e]; }
+                }
+            }
+        }
+    }
+    block_reduce_one<4>(v, red);
+    const float m0 = (float)((double)v[0] / count), m1 = (float)((double)v[1] / count);
+    if (threadIdx.x == 0) {
+        if (dgamma) dgamma[c] = v[1];
+        if (dbeta) dbeta[c] = v[0];
+        if (dlab) { unsafeAtomicAdd(dlab, v[2]); unsafeAtomicAdd(dlab + 1, v[3]); }   // zeroed by the caller
+    }
+    {
+        QR pos = qr_init(threadIdx.x, nvhw);
+        for (int i0 = threadIdx.x; i0 < nvec; i0 += kBatch * kBnOneThreads) {
+            float4 xr[kBatch], gr[kBatch];
+            int64_t off[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                off[k] = -1;
+                if (i0 + k * kBnOneThreads < nvec) {
+                    off[k] = offset(pos);
+                    xr[k] = *reinterpret_cast<const float4 *>(x + off[k]);
+                    gr[k] = *reinterpret_cast<const float4 *>(dy + off[k]);
+                }
+                pos = qr_step(pos, sq, sr, nvhw);
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                if (off[k] < 0) continue;
+                const float a[4] = {xr[k].x, xr[k].y, xr[k].z, xr[k].w}, g[4] = {gr[k].x, gr[k].y, gr[k].z, gr[k].w};
+                float w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {                       // the expression of bn_bwd_apply_flat_kernel<float>
+                    const float z = a[e] * sc + sh;
+                    const float dz = g[e] * ls * act_grad(z, act);
+                    w[e] = sc * (dz - m0 - ((a[e] - mu) * is) * m1);
+                }
+                *reinterpret_cast<float4 *>(dx + off[k]) = make_float4(w[0], w[1], w[2], w[3]);
+            }
+        }
+    }
+}
+
+static bool bn_one_f32_ok(int dtype, int B, int C, int HW) {
+    // (at least ~a quarter of the CUs: a 16-channel unit leaves the chip idle with one block per channel)
+    return dtype == DFINE_F32 && (HW & 3) == 0 && (int64_t)B * HW <= kBnOneMaxElems && HW >= 4 && C >= 64;
+}
+
 static bool bn_one_ok(int dtype, int B, int HW, int *vpt) {
     if (dtype != DFINE_BF16 || (HW & 7) || (int64_t)B * HW > kBnOneMaxElems) return false;
     const int per = (B * (HW >> 3) + kBnOneThreads - 1) / kBnOneThreads;
@@ -1127,6 +1285,15 @@ int dfine_bn_act_fwd(const void *x, void *y, const float *gamma, const float *be
     BnFusedFin ffin{};
     ffin.res = res;
     int vpt = 0;
+    if (training && save_mean && save_invstd && !res && bn_one_f32_ok(dtype, B, C, HW)) {
+        BnFusedFin f1{nullptr, 0, (double)B * HW, gamma, beta, running_mean, running_var, save_mean, save_invstd, scale, shift,
+                      momentum, eps, nullptr};
+#define DFINE_BN1F32(A) hipLaunchKernelGGL((bn_one_fwd_f32_kernel<A>), dim3(C), dim3(kBnOneThreads), 0, st, (const float *)x, (float *)y, \
+                                           lab_scale, lab_bias, C, HW, B, f1)
+        if (act == 0) DFINE_BN1F32(0); else if (act == 1) DFINE_BN1F32(1); else DFINE_BN1F32(2);
+#undef DFINE_BN1F32
+        return check_launch();
+    }
     if (training && save_mean && save_invstd && bn_one_ok(dtype, B, HW, &vpt)) {
         BnFusedFin f1{nullptr, 0, (double)B * HW, gamma, beta, running_mean, running_var, save_mean, save_invstd, scale, shift,
                       momentum, eps, res};
@@ -1199,6 +1366,16 @@ int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_
     if (training && (!save_mean || !save_invstd)) return DFINE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     int vpt = 0;
+    if (training && bn_one_f32_ok(dtype, B, C, HW)) {
+#define DFINE_BN1B32(A, LB) hipLaunchKernelGGL((bn_one_bwd_f32_kernel<A, LB>), dim3(C), dim3(kBnOneThreads), 0, st, (const float *)x, \
+                                               (const float *)dy, (float *)dx, save_mean, save_invstd, scale, shift, lab_scale, dgamma,  \
+                                               dbeta, dlab, C, HW, B, (double)B * HW)
+#define DFINE_BN1B32_L(A) { if (lab_scale) DFINE_BN1B32(A, true); else DFINE_BN1B32(A, false); }
+        if (act == 0) DFINE_BN1B32_L(0) else if (act == 1) DFINE_BN1B32_L(1) else DFINE_BN1B32_L(2)
+#undef DFINE_BN1B32_L
+#undef DFINE_BN1B32
+        return check_launch();
+    }
     // backward: only while x AND dy of the channel fit the 128-VGPR budget of a 1024-thread block (<= 2 vectors per
     // thread = B * HW <= 16 384: the 20x20 planes); the 8-vector instantiation spills ~260 registers
     if (training && bn_one_ok(dtype, B, HW, &vpt) && vpt <= 2) {

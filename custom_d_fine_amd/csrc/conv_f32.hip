@@ -352,7 +352,21 @@ static void f32_fwd_plan(int B, int Cin, int Cout, int Ho, int Wo, int KS, int S
         return sizeof(float) * ((((size_t)*kc * rows_l * WL + 3) & ~(size_t)3) + (size_t)KS * KS * 16 * *NWN * kF32WP);
     };
     while (r > 1 && lds(r) > 80 * 1024) --r;
-    while (r > 1 && (int64_t)B * ((Ho + r - 1) / r) * *ctiles * nblk < 768) r = (r + 1) / 2;
+    // strip height by a small cost model (measured constants): a launch runs in rounds of 512 workgroups (two per CU), a stage of
+    // a workgroup costs ~3 us of staging latency + 0.48 us per pixel tile of its MFMA section size (2 / 5 / 10 tiles per wave),
+    // twice that when two workgroups share the SIMDs.  Candidates: the largest strip and its halvings; ties go to the smaller.
+    auto cost = [&](int rr) {
+        const int64_t wgs = (int64_t)B * ((Ho + rr - 1) / rr) * *ctiles * nblk;
+        const int tw = (((rr * *CW + 15) / 16) + 4 / *NWN - 1) / (4 / *NWN);       // tiles per wave
+        const int sz = tw <= 2 ? 2 : tw <= 5 ? 5 : 10;
+        return (double)((wgs + 511) / 512) * (3.0 + 0.48 * sz * (wgs > 256 ? 2.0 : 1.0));
+    };
+    int best = r;
+    for (int rr = r; rr > 1;) {
+        rr = (rr + 1) / 2;
+        if (cost(rr) <= cost(best)) best = rr;
+    }
+    r = best;
     *R = r;
     *strips = (Ho + r - 1) / r;
     *ldsb = lds(r);

@@ -55,7 +55,8 @@ def test_depthwise_conv_bf16_vector_kernels(cuda, B, C, H, W, K, S):
 
 
 @pytest.mark.parametrize("act", [None, "relu", "silu"])
-@pytest.mark.parametrize("shape", [(4, 12, 20, 20), (2, 7, 9, 11), (3, 32, 80, 80)])
+@pytest.mark.parametrize("shape", [(4, 12, 20, 20), (2, 7, 9, 11), (3, 32, 80, 80),
+                                   (4, 64, 20, 20), (16, 72, 40, 40), (5, 65, 6, 10)])   # the last three: one block per channel (fp32)
 @pytest.mark.parametrize("lab", [False, True])
 def test_bn_act_train_fwd_bwd(cuda, act, shape, lab):
     torch.manual_seed(0)
