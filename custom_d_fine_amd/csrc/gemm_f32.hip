@@ -273,6 +273,42 @@ __global__ __launch_bounds__(kGfThreads, 2) void gemm_f32_big_kernel(const float
     }
 }
 
+
+// Column sums of a token-stream gradient dY [M, N] (the bias gradient of an fp32 linear), optionally behind the ReLU mask of the
+// layer's output (dYm = dY * (y > 0), written for the two gradient GEMMs): per-split partial rows part[split][N] for the step's
+// deferred reduction.  ATen's sum over dim 0 takes ~20 us for 8 MB (256 output columns = little parallelism) and the mask is a
+// compare + multiply pair of launches; this is one pass at copy speed.  Block = 256 threads = (256 / (N / 4)) row lanes x N / 4
+// four-column groups over `rows` consecutive rows.
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float *__restrict__ d, const float *__restrict__ y, float *__restrict__ dm,
+                                                         float *__restrict__ part, int M, int N, int rows) {
+    __shared__ float4 red[256];
+    const int ng = N >> 2, RL = 256 / ng;
+    const int rl = threadIdx.x / ng, cg = threadIdx.x - rl * ng;
+    const int m0 = blockIdx.x * rows, m1 = min(M, m0 + rows);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rl < RL) {
+        for (int m = m0 + rl; m < m1; m += RL) {
+            const int64_t o = (int64_t)m * N + 4 * cg;
+            float4 v = *reinterpret_cast<const float4 *>(d + o);
+            if (y) {
+                const float4 t = *reinterpret_cast<const float4 *>(y + o);
+                v.x = t.x > 0.f ? v.x : 0.f; v.y = t.y > 0.f ? v.y : 0.f; v.z = t.z > 0.f ? v.z : 0.f; v.w = t.w > 0.f ? v.w : 0.f;
+                *reinterpret_cast<float4 *>(dm + o) = v;
+            }
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        for (int r = 1; r < RL; ++r) {
+            const float4 t = red[r * ng + cg];
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        *reinterpret_cast<float4 *>(part + (int64_t)blockIdx.x * N + 4 * cg) = acc;
+    }
+}
+
 }  // namespace dfine
 
 using namespace dfine;
@@ -333,6 +369,25 @@ int dfine_gemm_f32_nn(const float *A, const float *B, const float *bias, float *
 int dfine_gemm_f32(int a_kmajor, int b_kmajor, const float *A, const float *B, const float *bias, float *C, int batch, int M, int N, int K,
                    int lda, int ldb, int ldc, int64_t sa, int64_t sb, int64_t sc, int splits, int chunk, float alpha, int act, void *stream) {
     return gemm_f32_launch(a_kmajor, b_kmajor, A, B, bias, C, batch, M, N, K, lda, ldb, ldc, sa, sb, sc, splits, chunk, alpha, act, stream);
+}
+
+
+// number of partial rows dfine_colsum_f32 writes for M rows
+int dfine_colsum_f32_splits(int M) {
+    int sp = (M + 31) / 32;
+    return sp > 256 ? 256 : (sp < 1 ? 1 : sp);
+}
+
+// part [splits][N] = per-split column sums of d [M, N] (N % 4 == 0, 4 <= N <= 1024), or - with relu_y [M, N] given - of
+// dm = d * (relu_y > 0), which is written as well.  The bias gradient of nn.Linear (+ the ReLU backward of the MLP layers,
+// ref dfine_decoder.py:33-46) in one pass.
+int dfine_colsum_f32(const float *d, const float *relu_y, float *dm, float *part, int M, int N, void *stream) {
+    if (M == 0) return DFINE_OK;
+    if (!d || !part || M < 0 || N < 4 || N > 1024 || (N & 3) || (relu_y && !dm)) return DFINE_E_BADARG;
+    const int splits = dfine_colsum_f32_splits(M);
+    const int rows = (M + splits - 1) / splits;
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3(splits), dim3(256), 0, (hipStream_t)stream, d, relu_y, dm, part, M, N, rows);
+    return check_launch();
 }
 
 }  // extern "C"

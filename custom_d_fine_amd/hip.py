@@ -131,6 +131,8 @@ _SIGNATURES = {
     "dfine_gemm_f32_nt": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, c_int64, c_int64, c_int64, _I, _I, _F, _I, _P]),
     "dfine_gemm_f32": (c_int, [_I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, c_int64, c_int64, c_int64, _I, _I, _F, _I, _P]),
     "dfine_gemm_f32_nn": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, c_int64, c_int64, c_int64, _F, _I, _P]),
+    "dfine_colsum_f32_splits": (c_int, [_I]),
+    "dfine_colsum_f32": (c_int, [_P, _P, _P, _P, _I, _I, _P]),
     "dfine_mask_bits_words": (c_int64, [c_int64]),
     "dfine_mask_pack_bits": (c_int, [_P, _I, _F, _I, c_int64, _P, _P]),
     "dfine_mask_iou_bits": (c_int, [_P, _P, _I, _I, c_int64, _P, _P]),
@@ -1913,6 +1915,25 @@ def gemm_f32(a, b, a_kmajor=False, b_kmajor=False, bias=None, alpha=1.0, act=0, 
                                    M if a_kmajor else K, N if b_kmajor else K, N, sa, sb, M * N, splits, chunk, float(alpha), int(act),
                                    _stream()), "dfine_gemm_f32")
     return out
+
+
+def colsum_f32_ok(d):
+    return d.dim() == 2 and d.dtype == torch.float32 and d.shape[1] % 4 == 0 and 4 <= d.shape[1] <= 1024 and d.shape[0] > 0
+
+
+def colsum_f32(d, relu_y=None):
+    """d [M, N] fp32 -> (part [splits, N] per-split column sums, dm): with relu_y [M, N] the sums are of dm = d * (relu_y > 0), which is
+    returned as a new tensor; without it dm is d itself (made contiguous)."""
+    d = d.contiguous()
+    M, N = d.shape
+    part = torch.empty(int(_lib.dfine_colsum_f32_splits(M)), N, device=d.device, dtype=torch.float32)
+    dm = d
+    if relu_y is not None:
+        relu_y = relu_y.contiguous()
+        dm = torch.empty_like(d)
+    _check(_lib.dfine_colsum_f32(d.data_ptr(), _ptr(relu_y), _ptr(dm) if relu_y is not None else None, part.data_ptr(), M, N, _stream()),
+           "dfine_colsum_f32")
+    return part, dm
 
 
 def conv1x1_f32(x, w2d):

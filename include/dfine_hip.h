@@ -754,6 +754,12 @@ int dfine_gemm_f32_nt(const float *A, const float *B, const float *bias, float *
  * (arch/hgnetv2.py:35-80, arch/hybrid_encoder.py:21-156): y[b] = W x[b], dx[b] = W^T dy[b], N = H * W. */
 int dfine_gemm_f32_nn(const float *A, const float *B, const float *bias, float *C, int batch, int M, int N, int K, int lda, int ldb,
                       int ldc, int64_t sa, int64_t sb, int64_t sc, float alpha, int act, void *stream);
+
+/* Bias gradient of an fp32 linear (ref src/d_fine/arch/dfine_decoder.py:33-46, nn.Linear backward): part [splits][N] = per-split column
+ * sums of d [M, N] - or of dm = d * (relu_y > 0), written too, when relu_y is given.  N % 4 == 0, N <= 1024;
+ * splits = dfine_colsum_f32_splits(M). */
+int dfine_colsum_f32_splits(int M);
+int dfine_colsum_f32(const float *d, const float *relu_y, float *dm, float *part, int M, int N, void *stream);
 /* General form: a_kmajor / b_kmajor != 0 - that operand is stored K-major ([K, M] / [K, N], rows contiguous in M / N): the
  * products with a transposed first factor (linear weight gradient dY^T x, P^T dO, dS^T Q) without transposed copies. */
 int dfine_gemm_f32(int a_kmajor, int b_kmajor, const float *A, const float *B, const float *bias, float *C, int batch, int M, int N, int K,

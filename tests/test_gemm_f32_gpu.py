@@ -154,3 +154,17 @@ def test_gemm_f32_large_tile_splits_and_shared_operand(cuda):
     _close(y.view(16, 640, 1600), w.double() @ dy.double(), 3e-6)
     tok = torch.randn(134400 // 8, 256, device=cuda)
     _close(hip.gemm_f32_nt(tok, w), tok.double() @ w.double().t(), 3e-6)
+
+
+@pytest.mark.parametrize("M,N,relu", [(7968, 256, False), (7968, 1024, True), (333, 80, True), (31, 4, False), (4800, 132, False)])
+def test_colsum_f32_bias_gradient_partials(cuda, M, N, relu):
+    """dfine_colsum_f32: per-split column sums (+ the ReLU mask of the layer's output) against fp64 torch."""
+    torch.manual_seed(M + N)
+    d = torch.randn(M, N, device=cuda)
+    y = torch.randn(M, N, device=cuda).relu() if relu else None
+    assert hip.colsum_f32_ok(d)
+    part, dm = hip.colsum_f32(d, y)
+    want_dm = d * (y > 0) if relu else d
+    assert torch.equal(dm, want_dm)
+    want = want_dm.double().sum(0)
+    assert (part.double().sum(0) - want).abs().max().item() <= 1e-5 * max(want.abs().max().item(), 1.0) * (M ** 0.5)

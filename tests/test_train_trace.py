@@ -68,7 +68,10 @@ def _check(model, ema, rec, loss_tol0, loss_tol, delta_cos, total_tol):
         dw, dg = (want - w0).flatten(), (got - w0).flatten()
         cos = torch.nn.functional.cosine_similarity(dw, dg, dim=0).item()
         assert cos >= delta_cos, (name, cos)
-        assert abs(dw.norm().item() / dg.norm().item() - 1) < 0.05, name                  # same step length (3 updates of ~lr each)
+        # same step length (3 updates of ~lr each).  A 16-element BatchNorm weight whose gradient is at rounding level in some channels
+        # takes +-lr steps of either sign there: one channel is 3 % of its norm (measured 1.048 - 1.062 over runs and summation
+        # orders, tools/probe/trace_margins.py); every tensor above 64 elements stays within 1 %
+        assert abs(dw.norm().item() / dg.norm().item() - 1) < (0.05 if dw.numel() > 64 else 0.10), name
     for key in [k for k in G.files if k.startswith("final_ema/")]:
         # momentum = 0.9998 (1 - exp(-i / 2000)) is ~5e-4 in the first iterations: the EMA copy follows the student closely
         name = key.split("/", 1)[1]
