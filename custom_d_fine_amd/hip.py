@@ -1936,15 +1936,25 @@ def colsum_f32(d, relu_y=None):
     return part, dm
 
 
+def planes_dense(x):
+    """True for an NCHW tensor whose images are dense [C, H, W] blocks at any image stride - a contiguous map or a channel slice
+    of one (x[:, a:b], a chunk of a concatenation or of its gradient): what the fp32 GEMM kernels read in place."""
+    B, C, H, W = x.shape
+    return x.stride(3) == 1 and x.stride(2) == W and x.stride(1) == H * W and (B == 1 or x.stride(0) >= C * H * W)
+
+
 def conv1x1_f32(x, w2d):
-    """x [B, Cin, H, W] fp32 contiguous, w2d [Cout, Cin] fp32 contiguous -> [B, Cout, H, W]: y[b] = w2d @ x[b] (dfine_gemm_f32_nn)."""
+    """x [B, Cin, H, W] fp32 (planes_dense: contiguous or a channel slice), w2d [Cout, Cin] fp32 contiguous -> [B, Cout, H, W]:
+    y[b] = w2d @ x[b] (dfine_gemm_f32_nn)."""
     B, cin, H, W = x.shape
     cout = w2d.shape[0]
     hw = H * W
+    if not planes_dense(x):
+        x = x.contiguous()
     y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
     with _timed("conv_f32", 2.0 * B * hw * cin * cout, io=4.0 * B * hw * (cin + cout)):
-        _check(_lib.dfine_gemm_f32_nn(w2d.data_ptr(), x.data_ptr(), None, y.data_ptr(), B, cout, hw, cin, cin, hw, hw, 0, cin * hw,
-                                      cout * hw, 1.0, 0, _stream()), "dfine_gemm_f32_nn")
+        _check(_lib.dfine_gemm_f32_nn(w2d.data_ptr(), x.data_ptr(), None, y.data_ptr(), B, cout, hw, cin, cin, hw, hw, 0,
+                                      x.stride(0) if B > 1 else cin * hw, cout * hw, 1.0, 0, _stream()), "dfine_gemm_f32_nn")
     return y
 
 
@@ -2026,7 +2036,7 @@ def conv_f32_wgrad(x, dy, ks, stride, pt, pl, partials=False):
         hw = hi * wi
         tiles = ((cout + 63) // 64) * ((cin + 63) // 64)
         sp = max(1, min(hw // 256, -(-512 // (tiles * B))))
-        part = gemm_f32_nt(dy.view(B, cout, hw), x.view(B, cin, hw), splits=sp)          # [B * splits, Cout, Cin]
+        part = gemm_f32_nt(dy.reshape(B, cout, hw), x.reshape(B, cin, hw), splits=sp)    # [B * splits, Cout, Cin] (slices read in place)
         if partials:
             return part.view(-1), (part.shape[0], cout, cin, 1, cout, cin)
         return part.sum(0).view(cout, cin, 1, 1)

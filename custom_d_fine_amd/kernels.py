@@ -2704,9 +2704,11 @@ class _DenseConvF32(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, stride, pt, pl, out_hw):
         hip = _hip()
-        x = x.contiguous()
         ks = weight.shape[-1]
-        if ks == 1 and stride == 1 and pt == 0 and pl == 0:
+        one = ks == 1 and stride == 1 and pt == 0 and pl == 0
+        if not (one and hip.planes_dense(x)):            # (the 1x1 GEMM reads a channel slice of a concatenation in place)
+            x = x.contiguous()
+        if one:
             y = hip.conv1x1_f32(x, weight.view(weight.shape[0], weight.shape[1]))      # y[b] = W x[b]: the fp32 GEMM kernel
         else:
             y = hip.conv_f32_forward(x, _packed_f32(weight, False), weight.shape[0], ks, stride, pt, pl, out_hw)
@@ -2723,7 +2725,9 @@ class _DenseConvF32(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         stride, pt, pl = ctx.cfg
         ks = weight.shape[-1]
-        dy = dy.float().contiguous()
+        dy = dy.float()
+        if not (ks == 1 and stride == 1 and pt == 0 and pl == 0 and hip.planes_dense(dy)):   # (a slice of a concatenation's gradient)
+            dy = dy.contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0] and ks == 1 and stride == 1 and pt == 0 and pl == 0:
             dx = hip.conv1x1_f32(dy, weight.view(weight.shape[0], weight.shape[1]).t().contiguous())      # dx[b] = W^T dy[b]

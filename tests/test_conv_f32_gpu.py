@@ -53,3 +53,31 @@ def test_conv_bn_act_takes_the_f32_kernel_without_autocast(cuda, monkeypatch):
     want = F.relu(bn(conv(x)))
     assert len(calls) == 1 and y.dtype == torch.float32
     assert (y - want).abs().max() <= 1e-4 * want.abs().max()
+
+
+def test_conv1x1_f32_reads_channel_slices_in_place(cuda, monkeypatch):
+    """A 1x1 convolution on a channel slice of a concatenation, with a gradient that is a slice of the concatenation's gradient:
+    forward, data gradient and weight gradient read the slices in place (no contiguous copies) and match conv2d."""
+    from custom_d_fine_amd import hip
+    torch.manual_seed(5)
+    conv = nn.Conv2d(32, 48, 1, bias=False).to(cuda)
+    full = torch.randn(3, 56, 20, 20, device=cuda, requires_grad=True)
+    x = full[:, 8:40]
+    assert not x.is_contiguous() and hip.planes_dense(x)
+    y = kernels.conv_f32(x, conv)
+    gfull = torch.randn(3, 64, 20, 20, device=cuda)
+    go = gfull[:, 4:52]
+    assert hip.planes_dense(go) and not go.is_contiguous()
+    seen = []
+    real = hip.conv1x1_f32
+    monkeypatch.setattr(hip, "conv1x1_f32", lambda a, w: (seen.append(a.is_contiguous()), real(a, w))[1])
+    y.backward(go)
+    assert seen == [False]                                                   # the data gradient took the slice itself
+    xr = full.detach().double()[:, 8:40].requires_grad_(True)
+    wr = conv.weight.detach().double().requires_grad_(True)
+    yr = F.conv2d(xr, wr)
+    yr.backward(go.double())
+    for a, b, name in ((y.detach(), yr.detach(), "y"), (full.grad[:, 8:40], xr.grad, "dx"), (conv.weight.grad, wr.grad, "dw")):
+        err = (a.double() - b).abs().max().item()
+        assert err <= 2e-5 * max(b.abs().max().item(), 1e-6), (name, err)
+    assert full.grad[:, :8].abs().max().item() == 0.0 and full.grad[:, 40:].abs().max().item() == 0.0

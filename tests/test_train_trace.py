@@ -81,7 +81,7 @@ def _check(model, ema, rec, loss_tol0, loss_tol, delta_cos, total_tol):
             continue
         dw, dg = (want - w0).flatten(), (got - w0).flatten()
         assert torch.nn.functional.cosine_similarity(dw, dg, dim=0).item() >= delta_cos, name
-        assert abs(dw.norm().item() / dg.norm().item() - 1) < 0.05, name
+        assert abs(dw.norm().item() / dg.norm().item() - 1) < (0.05 if dw.numel() > 64 else 0.10), name      # (as above)
         student = sd[name].detach().cpu().float()
         m = float(G[f"it{int(G['iters']) - 1}/ema_momentum"])
         assert (got - student).abs().max().item() <= 4 * m * (student - w0).abs().max().item() + 1e-7, name   # EMA ~ student this early
