@@ -1597,7 +1597,7 @@ __device__ __forceinline__ void linear_wgrad_body(const uint16_t *__restrict__ x
     // transpose-read delivers them - lane (column i, group g) gets rows 4g..4g+3 (first read) and 16+4g..16+4g+3
     // (second read) of its column; A and B use the same row order, and a sum over m does not care about it.
     // Row pitch 80 elements = 160 B: the 8 rows a 32-lane half touches hit 8 different 32-byte bank groups.
-    constexpr int PITCH = 80, ROWS = 64;                 // rows staged per barrier pair (two 32-row MFMA k-steps)
+    constexpr int PITCH = 80, ROWS = 64, NV = ROWS / 16;   // rows staged per barrier pair (two 32-row MFMA k-steps; 32: 74 -> 99 us, 128: 110 us at 1024 x 256)
     __shared__ __attribute__((aligned(16))) uint16_t s_dy[ROWS * PITCH];
     __shared__ __attribute__((aligned(16))) uint16_t s_x[ROWS * PITCH];
     typedef short tr4 __attribute__((ext_vector_type(4)));
@@ -1618,19 +1618,24 @@ __device__ __forceinline__ void linear_wgrad_body(const uint16_t *__restrict__ x
     const int st_ld = st_tile == 0 ? N : K;
     const int st_width = st_tile == 0 ? N - n0 : K - k0;
     const bool vec_ok = (st_ld & 7) == 0;                         // rows 16-byte aligned
+    const bool vec4_ok = (st_ld & 3) == 0;                        // rows 8-byte aligned
     uint16_t *st_dst = st_tile == 0 ? s_dy : s_x;
     const int g = lane >> 4, i = lane & 15;
     const int tr_off = (4 * g + (i >> 2)) * PITCH + 4 * (i & 3);
-    uint4 pf[4];
+    uint4 pf[NV];
     auto fetch = [&](int m0) {
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int vi = st_t + 128 * h;                       // 0 .. 511
+        for (int h = 0; h < NV; ++h) {
+            const int vi = st_t + 128 * h;                       // 0 .. 8 ROWS - 1
             const int row = vi >> 3, col = (vi & 7) * 8;
             const int m = m0 + row;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (m < m_end && vec_ok && col + 8 <= st_width) v = *reinterpret_cast<const uint4 *>(st_src + (int64_t)m * st_ld + col);
-            else if (m < m_end && col < st_width) {               // odd widths (132, 20, 4, 1 ...): element loads
+            else if (m < m_end && vec4_ok && col + 8 <= st_width) {   // rows 8-byte aligned (the 132-wide box head: 63 -> 20 us)
+                const uint2 lo = *reinterpret_cast<const uint2 *>(st_src + (int64_t)m * st_ld + col);
+                const uint2 hi = *reinterpret_cast<const uint2 *>(st_src + (int64_t)m * st_ld + col + 4);
+                v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            } else if (m < m_end && col < st_width) {             // odd widths (20, 4, 1 ... and row tails): element loads
                 uint16_t tmp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 for (int e = 0; e < min(8, st_width - col); ++e) tmp[e] = st_src[(int64_t)m * st_ld + col + e];
                 v = *reinterpret_cast<uint4 *>(tmp);
@@ -1641,7 +1646,7 @@ __device__ __forceinline__ void linear_wgrad_body(const uint16_t *__restrict__ x
     fetch(m_begin);
     for (int m0 = m_begin; m0 < m_end; m0 += ROWS) {
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
+        for (int h = 0; h < NV; ++h) {
             const int vi = st_t + 128 * h;
             *reinterpret_cast<uint4 *>(st_dst + (vi >> 3) * PITCH + (vi & 7) * 8) = pf[h];
         }
