@@ -19,7 +19,7 @@ python tools/step_phases.py $O/step_events.jsonl > $O/step_phases.txt 2>&1
 for sw in kernels.MLP_FUSED kernels.LN_DEFER kernels.CDN_KERNEL kernels.STACK_LAYER_OUTPUTS; do python tools/ab_step.py $sw 2>&1 | tail -3; done > $O/ab_launch_fusions.txt
 python tools/f32_step_profile.py 2>&1 | grep -v -i "warn\|amdgpu.ids\|_warn_once" > $O/f32_step_profile.txt
 python tools/f32_table.py --full 70 2>&1 | grep -v -i "warn\|amdgpu.ids" > $O/f32_table.txt
-python tools/probe/f32_aten_ops.py 2>&1 | grep -v -i "warn\|amdgpu.ids" | head -40 > $O/f32_aten_ops.txt
+python tools/probe/aten_ops.py 2>&1 | grep -v -i "warn\|amdgpu.ids" | head -40 > $O/f32_aten_ops.txt
 # HBM traffic counters of the family's reference layer (512 -> 512 @80x80 on the LDS-DMA 1x1 kernel), one --pmc pass per counter group
 tools/conv_pmc.sh ${R}_conv_pmc 512 512 80 1 fwd conv1x1_glds > $O/conv1x1_pmc.txt 2>&1
 python - $O/conv1x1_pmc.txt $R <<'PY' > $O/conv_pmc.json
