@@ -1461,6 +1461,17 @@ int dfine_bn_act_bwd(const void *x, const void *dy, void *dx, const float *save_
     return check_launch();
 }
 
+/* scale [C] = gamma / sqrt(running_var + eps), shift [C] = beta - running_mean * scale: an eval-mode BatchNorm as the
+ * per-channel affine dfine_conv_affine_once() takes (gamma / beta may be NULL: 1 / 0). */
+int dfine_bn_fold(const float *gamma, const float *beta, const float *running_mean, const float *running_var, float eps, int C,
+                  float *scale, float *shift, void *stream) {
+    if (C == 0) return DFINE_OK;
+    if (!running_mean || !running_var || !scale || !shift || C < 0) return DFINE_E_BADARG;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, C, gamma, beta, running_mean, running_var,
+                       eps, scale, shift, (float *)nullptr, (float *)nullptr);
+    return check_launch();
+}
+
 /* RepVGG unit  y = act(BN_a(x1) + BN_b(x2)) [+ residual]  (training mode, bf16): see the kernels above. */
 int dfine_bn2_supported(int B, int C, int HW) {
     int nchunk, per;

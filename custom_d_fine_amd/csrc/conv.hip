@@ -39,6 +39,22 @@ int wgrad3_rows_launch(const void *x, const void *dy, float *part, int B, int Ci
 
 // csrc/conv3s.hip: row-streaming 3x3 forward / data gradient for <= 32 channels on both sides
 bool conv3x3_rows32_ok(int NP, int KP, int H, int W);
+
+// Per-output-channel affine + activation applied to the fp32 accumulators in the store phase of the forward kernels:
+//     y[n] = lab[0] * act(scale[n] * conv[n] + shift[n]) + lab[1]
+// An eval-mode BatchNorm (scale / shift folded from the running statistics), a deployed layer's bias (scale = 1) and the
+// learnable affine block behind the activation (ref hgnetv2.py:35-80, hybrid_encoder.py:21-79) - the inference forward
+// then is ONE launch per conv -> BN -> act unit and the map is written once instead of written, read and written again.
+// scale == nullptr: plain store.
+struct EpiAffine {
+    const float *scale, *shift, *lab;
+    int act;
+};
+__device__ __forceinline__ float epi_act(float z, int act) {
+    if (act == 1) return fmaxf(z, 0.f);
+    if (act == 2) return z * __builtin_amdgcn_rcpf(1.f + __expf(-z));      // the expression of bnact.hip's act_fwd
+    return z;
+}
 int conv3x3_rows32_launch(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B, int Cin, int Cout, int NP, int KP, int H, int W,
                           int accum, hipStream_t st);
 
@@ -339,7 +355,8 @@ __host__ __device__ static inline int ws_pitch(int W) { return (W + 2 + 7) & ~7;
 template <int NTN, int VEC, int KC>
 __global__ __launch_bounds__(kWsThreads) void conv3x3_ws_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w2,
                                                                uint16_t *__restrict__ y, int Cin, int Cout, int NP, int KP, int H,
-                                                               int W, int R, int strips, int nblk, int units, int accum) {
+                                                               int W, int R, int strips, int nblk, int units, int accum,
+                                                               const EpiAffine epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int KS = 3, PAD = 1;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -521,12 +538,26 @@ __global__ __launch_bounds__(kWsThreads) void conv3x3_ws_kernel(const uint16_t *
         const int n_wave = nb * 64 * NTN + wave * 16 * NTN;
         constexpr int OP = 16 * kMaxPixTiles + 8;
         uint16_t *ot = reinterpret_cast<uint16_t *>(lds + 2 * buf_bytes) + wave * (16 * NTN * OP);
+        if (epi.scale) {                                         // eval-mode BatchNorm / bias + activation on the accumulators
+            const float ls = epi.lab ? epi.lab[0] : 1.f, lb = epi.lab ? epi.lab[1] : 0.f;
 #pragma unroll
-        for (int t = 0; t < NTN; ++t)
+            for (int t = 0; t < NTN; ++t)
 #pragma unroll
-            for (int jt = 0; jt < kMaxPixTiles; ++jt)
+                for (int r = 0; r < 4; ++r) {
+                    const int n = min(n_wave + t * 16 + 4 * (lane >> 4) + r, Cout - 1);
+                    const float sc = epi.scale[n], sh = epi.shift[n];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ot[(t * 16 + 4 * (lane >> 4) + r) * OP + jt * 16 + i16] = f32_to_bf16(acc[t][jt][r]);
+                    for (int jt = 0; jt < kMaxPixTiles; ++jt)
+                        ot[(t * 16 + 4 * (lane >> 4) + r) * OP + jt * 16 + i16] = f32_to_bf16(ls * epi_act(acc[t][jt][r] * sc + sh, epi.act) + lb);
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NTN; ++t)
+#pragma unroll
+                for (int jt = 0; jt < kMaxPixTiles; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ot[(t * 16 + 4 * (lane >> 4) + r) * OP + jt * 16 + i16] = f32_to_bf16(acc[t][jt][r]);
+        }
         uint16_t *yb = y + ((int64_t)b * Cout * H + r0) * W;
         const int cpr = TP / VEC;                                // chunks per channel row (W is a multiple of VEC)
         int row = lane / cpr, c = (lane - row * cpr) * VEC;      // 64 lanes walk the [16 NTN][cpr] chunk grid
@@ -771,7 +802,8 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
                                                                   const ChanSegs ys_, int Cin, int Cout, int NP, int KP,
                                                                   int HW, int ptiles, int total_tiles, int nblk, int accum,
                                                                   int64_t w_bstride /* elements between the images' weight sets: 0 = shared */,
-                                                                  int ximg /* tiles over the pixels of ALL images (B * HW), see below */) {
+                                                                  int ximg /* tiles over the pixels of ALL images (B * HW), see below */,
+                                                                  const EpiAffine epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int TP = 32 * PXW;                                             // pixels per workgroup (128 or 256)
     constexpr int XPITCH = TP * 2;                                           // bytes per channel row
@@ -987,12 +1019,26 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
     __builtin_amdgcn_s_barrier();                        // every wave is done reading the ring
     constexpr int OP = 16 * PXW + 8;                     // output tile pitch (elements)
     uint16_t *ot = reinterpret_cast<uint16_t *>(lds) + wave * (16 * NTN * OP);          // [16 NTN rows][16 PXW px]
+    if (epi.scale) {                                     // eval-mode BatchNorm / bias + activation on the accumulators, row by row
+        const float ls = epi.lab ? epi.lab[0] : 1.f, lb = epi.lab ? epi.lab[1] : 0.f;     // (a separate copy of the store loop: the
+#pragma unroll                                                                             //  training launches keep their registers)
+        for (int t = 0; t < NTN; ++t)
 #pragma unroll
-    for (int t = 0; t < NTN; ++t)
+            for (int r = 0; r < 4; ++r) {
+                const int n = min(n0 + wn * 16 * NTN + t * 16 + 4 * g + r, Cout - 1);
+                const float sc = epi.scale[n], sh = epi.shift[n];
 #pragma unroll
-        for (int j = 0; j < PXW; ++j)
+                for (int j = 0; j < PXW; ++j)
+                    ot[(t * 16 + 4 * g + r) * OP + j * 16 + i16] = f32_to_bf16(ls * epi_act(acc[t][j][r] * sc + sh, epi.act) + lb);
+            }
+    } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ot[(t * 16 + 4 * g + r) * OP + j * 16 + i16] = f32_to_bf16(acc[t][j][r]);
+        for (int t = 0; t < NTN; ++t)
+#pragma unroll
+            for (int j = 0; j < PXW; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ot[(t * 16 + 4 * g + r) * OP + j * 16 + i16] = f32_to_bf16(acc[t][j][r]);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     constexpr int LPO = 2 * PXW, RPI = 64 / LPO;         // lanes per output row, rows per iteration
     const int c8l = wp * 16 * PXW + (lane % LPO) * 8;    // this lane's 8-pixel chunk of the tile (the same for every row)
@@ -1082,7 +1128,8 @@ static C1Cfg conv1x1_cfg(int B, int NP, int KP, int HW, bool seg, bool per_image
 
 static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B, int Cin, int Cout, int NP, int KP, int HW,
                           hipStream_t st, const ChanSegs *xsegs = nullptr, const ChanSegs *ysegs = nullptr, int accum = 0,
-                          int64_t w_bstride = 0, unsigned accum_parts = 0 /* bit k: add onto output part k (several parts) */) {
+                          int64_t w_bstride = 0, unsigned accum_parts = 0 /* bit k: add onto output part k (several parts) */,
+                          const EpiAffine epi = EpiAffine{nullptr, nullptr, nullptr, 0}) {
     const int ptiles = (HW + kTrPix - 1) / kTrPix;
     if (conv1x1_glds_ok(Cin, KP, HW)) {
         const ChanSegs xs_ = xsegs ? *xsegs : one_seg(x, Cin);
@@ -1116,7 +1163,7 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
             attr2 = true;
         }
 #define DFINE_G2L(N, R, P, S) \
-    hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, S>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum, w_bstride, ximg ? 1 : 0)
+    hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, S>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum, w_bstride, ximg ? 1 : 0, epi)
 #define DFINE_G2(N, R, P) { if (seg) DFINE_G2L(N, R, P, true); else DFINE_G2L(N, R, P, false); }
         if (n256) DFINE_G2(4, 2, 8)
         else if (px256) DFINE_G2(2, 3, 8)
@@ -1126,7 +1173,7 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
 #undef DFINE_G2L
         return check_launch();
     }
-    if (xsegs || ysegs || accum || accum_parts || w_bstride) return DFINE_E_BADARG;  // the first-generation kernel takes whole tensors, shared weights, no accumulation
+    if (xsegs || ysegs || accum || accum_parts || w_bstride || epi.scale) return DFINE_E_BADARG;  // the first-generation kernel takes whole tensors, shared weights, no accumulation, no epilogue
     const int vec = (HW % 8 == 0) ? 8 : (HW % 4 == 0 ? 4 : 2);
     int kc = KP >= 128 ? 4 : (KP >= 64 ? 2 : 1);
     while (kc > 1 && KP < 32 * kc) kc >>= 1;
@@ -1853,8 +1900,9 @@ static bool conv3x3_ws_ok(int B, int NP, int KP, int H, int W) {
 }
 
 static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B, int Cin, int Cout, int NP, int KP,
-                       int H, int W, int KS, hipStream_t st, int accum = 0) {
-    if (KS == 3 && conv3x3_rows32_ok(NP, KP, H, W)) return conv3x3_rows32_launch(x, w2, y, B, Cin, Cout, NP, KP, H, W, accum, st);
+                       int H, int W, int KS, hipStream_t st, int accum = 0, const EpiAffine epi = EpiAffine{nullptr, nullptr, nullptr, 0}) {
+    if (KS == 3 && conv3x3_rows32_ok(NP, KP, H, W))
+        return epi.scale ? DFINE_E_BADARG : conv3x3_rows32_launch(x, w2, y, B, Cin, Cout, NP, KP, H, W, accum, st);
     // strip height: as many rows as fit in 160 pixels
     int R = 160 / W;
     if (R < 1) return DFINE_E_BADARG;
@@ -1892,7 +1940,7 @@ static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B
             attr_ws = true;
         }
 #define DFINE_WS(N, V, K) \
-    hipLaunchKernelGGL((conv3x3_ws_kernel<N, V, K>), dim3(8 * wpx), dim3(kWsThreads), 2 * ws_slab * kc_ws + ws_ep, st, x, w2, y, Cin, Cout, NP, KP, H, W, R, strips, nblk, units, accum)
+    hipLaunchKernelGGL((conv3x3_ws_kernel<N, V, K>), dim3(8 * wpx), dim3(kWsThreads), 2 * ws_slab * kc_ws + ws_ep, st, x, w2, y, Cin, Cout, NP, KP, H, W, R, strips, nblk, units, accum, epi)
 #define DFINE_WS_K(N, V) { if (kc_ws == 2) DFINE_WS(N, V, 2); else DFINE_WS(N, V, 1); }
 #define DFINE_WS_V(N) { if (vec == 8) DFINE_WS_K(N, 8) else DFINE_WS_K(N, 4) }
         if (ntn == 2) DFINE_WS_V(2) else DFINE_WS_V(1)
@@ -1901,6 +1949,7 @@ static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B
 #undef DFINE_WS
         return check_launch();
     }
+    if (epi.scale) return DFINE_E_BADARG;                // (the first-generation kernel has no epilogue)
     dim3 grid(B * strips, wide ? NP / 128 : nblk64);
 #define DFINE_CONV(KSS, NTNN, VECC, KCC)                                                                   \
     hipLaunchKernelGGL((conv_igemm_kernel<KSS, NTNN, VECC, KCC>), grid, dim3(kConvThreads), ldsb, st, x, w2, y, Cin, \
@@ -1993,8 +2042,32 @@ int dfine_conv_pack_weights_multi(const void *table, int n_entries, void *stream
 // y[B, Cout, H, W] = conv(x[B, Cin, H, W], packed weights), stride 1, padding KS/2, bf16.
 // `w2` comes from dfine_conv_pack_weights(dgrad = 0) - or (dgrad = 1) with Cin/Cout exchanged by the
 // caller, which makes this the data gradient dX = conv(dY, flipped-transposed weights).
+// One-shot request consumed by the next dfine_conv_fwd_bf16 / dfine_conv1x1_seg_fwd_bf16 of the calling thread:
+//     y[n] = lab[0] * act(scale[n] * conv[n] + shift[n]) + lab[1]      (act: 0 none, 1 ReLU, 2 SiLU; lab: 2 floats or NULL)
+// applied to the fp32 accumulators in the kernel's store phase - a conv -> eval-mode BatchNorm (or deployed bias) -> act
+// [-> learnable affine] unit as one launch.  Only the shapes dfine_conv_affine_supported() accepts are served; a launch that
+// cannot returns DFINE_E_BADARG and drops the request.
+static thread_local EpiAffine g_conv_epi = {nullptr, nullptr, nullptr, 0};
+int dfine_conv_affine_once(const float *scale, const float *shift, const float *lab, int act) {
+    g_conv_epi = EpiAffine{nullptr, nullptr, nullptr, 0};
+    if (!scale) return DFINE_OK;                          // (scale == NULL withdraws a pending request)
+    if (!shift || act < 0 || act > 2) return DFINE_E_BADARG;
+    g_conv_epi = EpiAffine{scale, shift, lab, act};
+    return DFINE_OK;
+}
+
+int dfine_conv_affine_supported(int B, int Cin, int Cout, int H, int W, int KS) {
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || Cin % 2) return 0;
+    const int NP = (Cout + 15) / 16 * 16, KP = (Cin + 31) / 32 * 32;
+    if (KS == 1) return ((H * W) % 2 == 0 && conv1x1_glds_ok(Cin, KP, H * W)) ? 1 : 0;
+    if (KS == 3) return (W % 2 == 0 && W <= 160 && !conv3x3_rows32_ok(NP, KP, H, W) && conv3x3_ws_ok(B, NP, KP, H, W)) ? 1 : 0;
+    return 0;
+}
+
 int dfine_conv_fwd_bf16(const void *x, const void *w2, void *y, int B, int Cin, int Cout, int H, int W, int KS,
                         void *stream) {
+    const EpiAffine epi = g_conv_epi;
+    g_conv_epi = EpiAffine{nullptr, nullptr, nullptr, 0};
     if (B == 0) return DFINE_OK;
     if (!x || !w2 || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (KS != 1 && KS != 3)) return DFINE_E_BADARG;
     if (Cin % 2) return DFINE_E_BADARG;
@@ -2002,12 +2075,12 @@ int dfine_conv_fwd_bf16(const void *x, const void *w2, void *y, int B, int Cin, 
     if (KS == 1) {             // no spatial structure: flattened planes, LDS transpose-read kernel
         if ((H * W) % 2) return DFINE_E_BADARG;
         return launch_conv1x1((const uint16_t *)x, (const uint16_t *)w2, (uint16_t *)y, B, Cin, Cout, NP, KP, H * W,
-                              (hipStream_t)stream);
+                              (hipStream_t)stream, nullptr, nullptr, 0, 0, 0, epi);
     }
     const int h = H, w = W;
     if (w % 2 || w > 160) return DFINE_E_BADARG;
     return launch_conv((const uint16_t *)x, (const uint16_t *)w2, (uint16_t *)y, B, Cin, Cout, NP, KP, h, w, KS,
-                       (hipStream_t)stream);
+                       (hipStream_t)stream, 0, epi);
 }
 
 // y += conv(x): a data gradient added onto the one already in y - the sum autograd forms for a map with two consumers
@@ -2152,6 +2225,8 @@ int dfine_conv_wgrad_bf16(const void *x, const void *dy, float *dw, float *ws, i
 int dfine_conv1x1_seg_fwd_bf16(const void *const *x_parts, const int *x_channels, const int *x_bstrides, int n_x, const void *w2,
                                void *const *y_parts, const int *y_channels, const int *y_bstrides, int n_y, int B, int Cin, int Cout,
                                int H, int W, void *stream) {
+    const EpiAffine epi = g_conv_epi;                     // (dfine_conv_affine_once)
+    g_conv_epi = EpiAffine{nullptr, nullptr, nullptr, 0};
     if (B == 0) return DFINE_OK;
     ChanSegs xs_, ys_;
     if (!w2 || !make_segs(&xs_, x_parts, x_channels, x_bstrides, n_x, Cin) ||
@@ -2159,7 +2234,7 @@ int dfine_conv1x1_seg_fwd_bf16(const void *const *x_parts, const int *x_channels
         return DFINE_E_BADARG;
     if ((H * W) % 8 || Cin % 2) return DFINE_E_BADARG;
     const int NP = (Cout + 15) / 16 * 16, KP = (Cin + 31) / 32 * 32;
-    return launch_conv1x1(nullptr, (const uint16_t *)w2, nullptr, B, Cin, Cout, NP, KP, H * W, (hipStream_t)stream, &xs_, &ys_);
+    return launch_conv1x1(nullptr, (const uint16_t *)w2, nullptr, B, Cin, Cout, NP, KP, H * W, (hipStream_t)stream, &xs_, &ys_, 0, 0, 0, epi);
 }
 
 // y_parts += the same convolution: a data gradient added onto the channel slice of a wider gradient map that already holds the

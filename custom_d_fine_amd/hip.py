@@ -79,6 +79,9 @@ _SIGNATURES = {
     "dfine_stream_destroy": (c_int, [_P]),
     "dfine_upload": (c_int, [_P, _P, _L, _P]),
     "dfine_conv_epilogue_supported": (c_int, [_I, _I, _I, _I, _I, _I]),
+    "dfine_conv_affine_once": (c_int, [_P, _P, _P, _I]),
+    "dfine_conv_affine_supported": (c_int, [_I, _I, _I, _I, _I, _I]),
+    "dfine_bn_fold": (c_int, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "dfine_conv_accum_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfine_conv_wgrad_ws_floats": (_L, [_I, _I, _I, _I, _I, _I]),
     "dfine_conv_wgrad_bf16": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -895,6 +898,53 @@ def conv_forward_bf16(x, w2, cout, ks):
     return y
 
 
+_AFF_OK = {}
+_ACT_CODE = {None: 0, "relu": 1, "silu": 2, "swish": 2}
+_CONV_FWD_IMPL = conv_forward_bf16          # (the module attribute is a shim while a program is exported)
+
+
+def conv_affine_supported(B, cin, cout, H, W, ks):
+    """Does the forward kernel for this shape take the affine + activation epilogue (dfine_conv_affine_supported)?"""
+    key = (B, cin, cout, H, W, ks)
+    ok = _AFF_OK.get(key)
+    if ok is None:
+        ok = _AFF_OK[key] = bool(_lib.dfine_conv_affine_supported(B, cin, cout, H, W, ks))
+    return ok
+
+
+def bn_fold(gamma, beta, running_mean, running_var, eps):
+    """-> (scale, shift) fp32 [C] of an eval-mode BatchNorm: gamma / sqrt(var + eps), beta - mean * scale (one launch)."""
+    C = running_mean.numel()
+    scale = torch.empty(C, device=running_mean.device, dtype=torch.float32)
+    shift = torch.empty(C, device=running_mean.device, dtype=torch.float32)
+    _check(_lib.dfine_bn_fold(_ptr(gamma), _ptr(beta), running_mean.data_ptr(), running_var.data_ptr(), float(eps), C, scale.data_ptr(),
+                              shift.data_ptr(), _stream()), "dfine_bn_fold")
+    return scale, shift
+
+
+def conv_forward_affine(x, w2, cout, ks, scale, shift, act, lab=None):
+    """lab[0] * act(scale[n] * conv(x)[n] + shift[n]) + lab[1] in the convolution's store phase (dfine_conv_affine_once +
+    dfine_conv_fwd_bf16): conv -> eval-mode BatchNorm / deployed bias -> activation as ONE launch.  Shapes of
+    conv_affine_supported only.  scale / shift fp32 [cout], lab fp32 [2] or None, act in (None, "relu", "silu")."""
+    _check(_lib.dfine_conv_affine_once(scale.data_ptr(), shift.data_ptr(), _ptr(lab), _ACT_CODE[act]), "dfine_conv_affine_once")
+    try:
+        return _CONV_FWD_IMPL(x, w2, cout, ks)
+    finally:
+        _lib.dfine_conv_affine_once(None, None, None, 0)          # (consumed by the launch; withdrawn if it never happened)
+
+
+def conv1x1_seg_forward_affine(x_parts, w2, cout, scale, shift, act, lab=None):
+    """The same epilogue behind the 1x1 convolution over the channel concatenation of `x_parts` (read in place) -> new [B, cout, H, W]."""
+    B, _, H, W = x_parts[0].shape
+    y = torch.empty(B, cout, H, W, device=x_parts[0].device, dtype=torch.bfloat16)
+    _check(_lib.dfine_conv_affine_once(scale.data_ptr(), shift.data_ptr(), _ptr(lab), _ACT_CODE[act]), "dfine_conv_affine_once")
+    try:
+        _SEG_FORWARD_IMPL(tuple(x_parts), w2, (y,))
+    finally:
+        _lib.dfine_conv_affine_once(None, None, None, 0)
+    return y
+
+
 def maps_to_tokens(maps):
     """List of [B, C, H_l, W_l] bf16 contiguous maps -> tokens [B, sum(H_l W_l), C] (levels in list order)."""
     B, C = maps[0].shape[0], maps[0].shape[1]
@@ -996,6 +1046,9 @@ def conv1x1_seg_forward(x_parts, w2, y_parts, accum=False):
                 else (_lib.dfine_conv1x1_seg_fwd_bf16, "dfine_conv1x1_seg_fwd_bf16"))
     with _timed("conv1x1", 2.0 * B * H * W * cin * cout, io=2.0 * B * H * W * (cin + (2 if accum else 1) * cout) + 2.0 * cin * cout):
         _check(fn(xp, xc, xb, len(x_parts), _ptr(w2), yp, yc, yb, len(y_parts), B, cin, cout, H, W, _stream()), name)
+
+
+_SEG_FORWARD_IMPL = conv1x1_seg_forward      # (the module attribute conv1x1_seg_forward is a shim while a program is exported)
 
 
 def conv1x1_seg_wgrad(x_parts, dy, partials=False):

@@ -85,6 +85,11 @@ class Torch_model:
         if self.model_path is not None:
             self.model.load_state_dict(torch.load(self.model_path, weights_only=True, map_location="cpu"), strict=False)
         self.model.eval().to(self.device)
+        if str(self.device).startswith("cuda"):
+            # the weights are fixed from here on: eval-mode BatchNorm folds are formed once, so that a conv -> BN -> act unit of the
+            # bf16 forward is a single launch (kernels.conv_bn_act: affine + activation in the convolution's store phase)
+            from .. import kernels
+            kernels.freeze_eval_affine(self.model)
 
     def _test_pred(self) -> None:
         img = np.random.randint(0, 255, size=(1100, 1000, self.channels), dtype=np.uint8)

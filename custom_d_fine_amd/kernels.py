@@ -1552,6 +1552,62 @@ def _conv_bn_act_residual(x, conv, bn, a, lab, fanin, residual):
                                  bn.momentum, bn.eps, fanin, residual)
 
 
+EVAL_EPILOGUE = True      # conv -> eval-mode BatchNorm / deployed bias -> act [-> LAB] as one launch when no gradient is recorded
+
+
+def _eval_fold(bn):
+    """(scale, shift) fp32 [C] of an eval-mode BatchNorm.  `freeze_eval_affine` stores them on the module for a model whose weights
+    no longer change (Torch_model); otherwise one fold launch per call (running statistics and affine are updated in place by
+    kernels that do not bump tensor versions: nothing to key a cache on)."""
+    hit = bn.__dict__.get("_dfine_fold")
+    if hit is not None:
+        return hit
+    return _hip().bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+
+
+def _lab_pair(lab):
+    if lab is None:
+        return None
+    hit = lab.__dict__.get("_dfine_pair")
+    if hit is not None:
+        return hit
+    return torch.cat([lab.scale.detach().reshape(1), lab.bias.detach().reshape(1)]).float()
+
+
+def freeze_eval_affine(model):
+    """Inference-only models (weights fixed from here on): the eval-mode BatchNorm folds and learnable-affine pairs are computed
+    once and kept on the modules, so that a conv -> BN -> act unit is exactly one launch.  Call again after loading new weights."""
+    n = 0
+    for m in model.modules():
+        if isinstance(m, nn.BatchNorm2d) or type(m).__name__ == "FrozenBatchNorm2d":
+            m.__dict__.pop("_dfine_fold", None)
+            if m.running_mean is not None and m.running_mean.is_cuda:
+                m.__dict__["_dfine_fold"] = _hip().bn_fold(m.weight, m.bias, m.running_mean, m.running_var, m.eps)
+                n += 1
+        elif type(m).__name__ == "LearnableAffineBlock":
+            m.__dict__.pop("_dfine_pair", None)
+            if m.scale.is_cuda:
+                m.__dict__["_dfine_pair"] = _lab_pair(m)
+    return n
+
+
+def _eval_unit_ok(bn, a):
+    return (EVAL_EPILOGUE and not torch.is_grad_enabled() and not bn.training and a in (None, "relu", "silu", "swish")
+            and getattr(bn, "running_mean", None) is not None and getattr(bn, "weight", None) is not None
+            and bn.running_mean.dtype == torch.float32 and bn.weight.dtype == torch.float32)
+
+
+def _conv_eval_affine(xb, conv, scale, shift, a, lab):
+    """The one-launch inference unit on a whole bf16 tensor, or None when the shape's kernel has no epilogue."""
+    hip = _hip()
+    B, cin, H, W = xb.shape
+    ks = conv.kernel_size[0]
+    if not hip.conv_affine_supported(B, cin, conv.out_channels, H, W, ks):
+        return None
+    return hip.conv_forward_affine(xb.contiguous(), _packed_weights(conv.weight, False), conv.out_channels, ks, scale, shift,
+                                   "silu" if a == "swish" else a, _lab_pair(lab))
+
+
 def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Optional[nn.Module],
                 pad_br: bool = False, fanin=None, fans=None, residual=None):
     """conv(bias=False) -> BN (batch stats in training) -> {None, relu, silu} -> scalar affine; the
@@ -1580,6 +1636,15 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
                 and conv.kernel_size == (1, 1) and len(xs) <= 8 and (xs[0].shape[-1] * xs[0].shape[-2]) % 8 == 0
                 and all(t.shape[1] % 8 == 0 for t in xs) and _mfma_conv_ok(conv, xs[0])):
             parts = [t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16) for t in xs]
+            if _eval_unit_ok(bn, a):
+                hip = _hip()
+                B, _, H, W = parts[0].shape
+                cin = sum(t.shape[1] for t in parts)
+                if hip.conv_affine_supported(B, cin, conv.out_channels, H, W, 1):
+                    parts = [t if hip.is_channel_part(t) else t.contiguous() for t in parts]
+                    scale, shift = _eval_fold(bn)
+                    return hip.conv1x1_seg_forward_affine(parts, _packed_weights(conv.weight, False), conv.out_channels, scale, shift,
+                                                          "silu" if a == "swish" else a, _lab_pair(lab))
             y = _bn_tail_fused(_DenseConvSeg, (conv.weight, fans, *parts), bn, a, lab)
             if y is not None:
                 return y
@@ -1632,6 +1697,10 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
             y = _DepthwiseConv.apply(x, conv.weight, conv.stride[0], conv.padding[0])
         elif route == 2:
             xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+            if _eval_unit_ok(bn, a):
+                y = _conv_eval_affine(xb, conv, *_eval_fold(bn), a, lab)
+                if y is not None:
+                    return y
             if (_FUSE_CONV_BN and type(bn) is nn.BatchNorm2d and bn.track_running_stats and bn.momentum is not None
                     and _conv_plan_all_hip(xb, conv.weight)):
                 training = bn.training
@@ -1683,6 +1752,10 @@ def conv_bias_act(x, conv: nn.Conv2d, act: Optional[str], residual=None):
         if unit is None:
             unit = _UNIT_BN[(x.device, c)] = (torch.ones(c, device=x.device), torch.zeros(c, device=x.device))
         xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+        if dense and EVAL_EPILOGUE and not torch.is_grad_enabled() and conv.bias.dtype == torch.float32:
+            y = _conv_eval_affine(xb, conv, unit[0], conv.bias.detach(), a, None)          # bias + activation in the store phase
+            if y is not None:
+                return y if residual is None else y + residual
         y = _DenseConv.apply(xb, conv.weight) if dense else _DepthwiseConv.apply(xb, conv.weight, conv.stride[0], conv.padding[0])
         y = _BNAct.apply(y, unit[0], conv.bias, None, None, unit[1], unit[0], a, False, 0.0, 0.0)
         return y if residual is None else y + residual

@@ -383,6 +383,17 @@ int dfine_conv1x1_accum_bf16(const void *x, const void *w2, void *y, int B, int 
  * dfine_conv_epilogue_supported() != 0 says whether the shape is served (1x1 on the LDS-DMA kernel, 3x3 on the
  * wave-specialised kernel); DFINE_E_BADARG otherwise. */
 int dfine_conv_epilogue_supported(int B, int Cin, int Cout, int H, int W, int KS);
+/* conv -> eval-mode BatchNorm (or the bias of a deployed layer) -> activation [-> learnable affine] as ONE launch
+ * (src/d_fine/arch/hgnetv2.py:35-80 ConvBNAct in eval mode, hybrid_encoder.py:21-79 ConvNormLayer_fuse after convert_to_deploy()):
+ * a one-shot request consumed by the next dfine_conv_fwd_bf16 / dfine_conv1x1_seg_fwd_bf16 of the calling thread,
+ *     y[n] = lab[0] * act(scale[n] * conv[n] + shift[n]) + lab[1]      (act 0 none / 1 ReLU / 2 SiLU; lab: 2 floats or NULL)
+ * on the fp32 accumulators in the kernel's store phase.  scale == NULL withdraws a pending request.  Served on the shapes
+ * dfine_conv_affine_supported() accepts; a forward launch that cannot returns DFINE_E_BADARG and drops the request.
+ * dfine_bn_fold: scale / shift of an eval-mode nn.BatchNorm2d / FrozenBatchNorm2d (gamma, beta may be NULL). */
+int dfine_conv_affine_once(const float *scale, const float *shift, const float *lab, int act);
+int dfine_conv_affine_supported(int B, int Cin, int Cout, int H, int W, int KS);
+int dfine_bn_fold(const float *gamma, const float *beta, const float *running_mean, const float *running_var, float eps, int C,
+                  float *scale, float *shift, void *stream);
 int dfine_conv_accum_bf16(const void *x, const void *w2, void *y, int B, int Cin, int Cout, int H, int W, int KS,
                           void *stream);
 /* Weight gradient of the same convolution: dw [Cout, Cin, KS, KS] f32 (overwritten) from x [B,Cin,H,W]

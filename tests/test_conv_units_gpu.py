@@ -231,3 +231,54 @@ def test_frozen_batchnorm_unit_takes_hip_tail(cuda, lab):
     assert (xg.grad.cpu() - xr.grad).norm() <= 6e-2 * xr.grad.norm()
     for k, v in state.items():
         assert torch.equal(g.bn.state_dict()[k].cpu(), v)
+
+
+@pytest.mark.parametrize("cin,cout,k,H,W,act,use_lab", [(128, 128, 1, 40, 40, "relu", False), (96, 192, 1, 80, 80, None, True),
+                                                        (64, 64, 3, 40, 40, "relu", True), (128, 256, 3, 20, 20, "silu", False),
+                                                        (256, 80, 1, 20, 20, "silu", False)])
+def test_eval_unit_is_one_launch_with_the_affine_epilogue(cuda, monkeypatch, cin, cout, k, H, W, act, use_lab):
+    """Inference (no_grad, eval-mode BatchNorm): conv -> BN -> act [-> LAB] runs as the convolution with the affine + activation
+    epilogue (dfine_conv_affine_once) - against the fp32 ATen composition of the same unit, and against the two-pass HIP form
+    (conv, then the BatchNorm / activation kernel) it replaces."""
+    from custom_d_fine_amd import hip
+    from custom_d_fine_amd.d_fine.arch.hgnetv2 import LearnableAffineBlock
+    torch.manual_seed(cin + cout + k)
+    conv = nn.Conv2d(cin, cout, k, 1, k // 2, bias=False).to(cuda)
+    bn = nn.BatchNorm2d(cout).to(cuda)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3); bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    bn.eval()
+    lab = LearnableAffineBlock(1.3, -0.2).to(cuda) if use_lab else None
+    x = torch.randn(4, cin, H, W, device=cuda)
+    calls = []
+    real = hip.conv_forward_affine
+    monkeypatch.setattr(hip, "conv_forward_affine", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y = kernels.conv_bn_act(x, conv, bn, act, lab)
+        monkeypatch.setattr(kernels, "EVAL_EPILOGUE", False)
+        y2 = kernels.conv_bn_act(x, conv, bn, act, lab)
+    assert len(calls) == 1 and y.dtype == torch.bfloat16
+    f = {None: lambda t: t, "relu": F.relu, "silu": F.silu}[act]
+    with torch.no_grad():
+        want = f(bn(F.conv2d(x.bfloat16().float(), conv.weight.bfloat16().float(), None, 1, k // 2)))
+        want = lab(want) if lab is not None else want
+    scale = want.abs().max().item()
+    assert (y.float() - want).abs().max().item() <= 1.2e-2 * scale              # one bf16 rounding of the result
+    assert (y2.float() - want).abs().max().item() <= 2.5e-2 * scale             # the two-pass form rounds the convolution first
+    assert (y.float() - y2.float()).abs().max().item() <= 2.5e-2 * scale
+
+
+def test_deployed_unit_bias_act_in_the_store_phase(cuda, monkeypatch):
+    from custom_d_fine_amd import hip
+    torch.manual_seed(3)
+    conv = nn.Conv2d(128, 128, 3, 1, 1, bias=True).to(cuda)
+    x = torch.randn(2, 128, 40, 40, device=cuda)
+    calls = []
+    real = hip.conv_forward_affine
+    monkeypatch.setattr(hip, "conv_forward_affine", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y = kernels.conv_bias_act(x, conv, "silu")
+    with torch.no_grad():
+        want = F.silu(F.conv2d(x.bfloat16().float(), conv.weight.bfloat16().float(), conv.bias, 1, 1))
+    assert len(calls) == 1
+    assert (y.float() - want).abs().max().item() <= 1.2e-2 * want.abs().max().item()

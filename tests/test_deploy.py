@@ -86,6 +86,11 @@ def test_deployed_encoder_runs_on_hip_kernels_bf16(cuda, monkeypatch):
         return real_conv2d(*a, **k)
 
     monkeypatch.setattr(hip, "conv_forward_bf16", dense)
+    # (inference: the dense units run as the convolution with the bias / BatchNorm + activation epilogue)
+    real_aff, real_seg_aff = hip.conv_forward_affine, hip.conv1x1_seg_forward_affine
+    monkeypatch.setattr(hip, "conv_forward_affine", lambda *a, **k: (calls.__setitem__("hip_dense", calls["hip_dense"] + 1), real_aff(*a, **k))[1])
+    monkeypatch.setattr(hip, "conv1x1_seg_forward_affine",
+                        lambda *a, **k: (calls.__setitem__("hip_dense", calls["hip_dense"] + 1), real_seg_aff(*a, **k))[1])
     monkeypatch.setattr(hip, "dwconv_forward", dw)
     monkeypatch.setattr(F, "conv2d", conv2d)
     monkeypatch.setattr(nn.Conv2d, "_conv_forward", lambda self, x, w, b: conv2d(x, w, b, self.stride, self.padding, self.dilation, self.groups))
