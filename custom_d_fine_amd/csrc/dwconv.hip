@@ -502,6 +502,19 @@ __global__ __launch_bounds__(kDwThreads) void dwconv_s2_wgrad_vec_kernel(const u
 // tiles.  Rows are cut into chunks (blockIdx.y) for parallelism: one halo row re-read per chunk.
 constexpr int kDwRowsAhead = 4;
 
+// eval-mode BatchNorm (folded to a per-channel scale / shift) + activation + learnable affine on the fp32 sums before the store:
+// y = lab[0] * act(scale[c] * conv + shift[c]) + lab[1] - the inference form of LightConvBNAct's depthwise unit as one launch
+// (ref hgnetv2.py:83-112).  scale == nullptr: plain store.
+struct DwEpi {
+    const float *scale, *shift, *lab;
+    int act;
+};
+__device__ __forceinline__ float dw_epi_act(float z, int act) {
+    if (act == 1) return fmaxf(z, 0.f);
+    if (act == 2) return z * __builtin_amdgcn_rcpf(1.f + __expf(-z));
+    return z;
+}
+
 __device__ __forceinline__ void dw_unpack9(const uint4 &r, uint32_t left_pair, bool first, float (&o)[9]) {
     // o[0] = column 8 v - 1 (the last element of the left neighbour's vector, zero at the plane edge), o[1..8] = own 8 columns
     o[0] = first ? 0.f : __uint_as_float(left_pair & 0xffff0000u);
@@ -512,9 +525,10 @@ __device__ __forceinline__ void dw_unpack9(const uint4 &r, uint32_t left_pair, b
 }
 
 // forward: y[oy][4 v + e] = sum_{ky, kx} w[ky][kx] x[2 oy + ky - 1][8 v + 2 e + kx - 1]
+template <bool EPI>          // EPI: the inference epilogue (a separate instantiation: the training kernel keeps its 69 registers)
 __global__ __launch_bounds__(kDwThreads) void dwconv_s2_fwd_stream_kernel(const uint16_t *__restrict__ x, const float *__restrict__ w,
                                                                          uint16_t *__restrict__ y, int C, int H, int W, int planes,
-                                                                         int rows_per_chunk) {
+                                                                         int rows_per_chunk, const DwEpi ep) {
     const int lane = threadIdx.x & 63, wv = blockIdx.x * (kDwThreads / 64) + (threadIdx.x >> 6);
     const int nv = W / 8, ppw = 64 / nv;
     const int pl = lane / nv, v = lane - pl * nv;
@@ -526,6 +540,9 @@ __global__ __launch_bounds__(kDwThreads) void dwconv_s2_fwd_stream_kernel(const 
     float wk[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
+    constexpr bool epi = EPI;
+    const float e_sc = epi ? ep.scale[c] : 1.f, e_sh = epi ? ep.shift[c] : 0.f;
+    const float e_ls = (epi && ep.lab) ? ep.lab[0] : 1.f, e_lb = (epi && ep.lab) ? ep.lab[1] : 0.f;
     const uint16_t *xp = x + (int64_t)(live ? plane : 0) * H * W + v * 8;
     uint16_t *yp = y + (int64_t)(live ? plane : 0) * OH * OW + v * 4;
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
@@ -553,6 +570,10 @@ __global__ __launch_bounds__(kDwThreads) void dwconv_s2_fwd_stream_kernel(const 
                 for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[e] = fmaf(wk[ky * 3 + kx], in[2 * e + kx], acc[e]);
+            }
+            if (epi) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = e_ls * dw_epi_act(acc[e] * e_sc + e_sh, ep.act) + e_lb;
             }
             if (live) *reinterpret_cast<uint2 *>(yp + (int64_t)(oy + u) * OW) = DwVec<4>::pack(acc);
             rp = rb[u];
@@ -736,10 +757,10 @@ __device__ __forceinline__ void dw_unpack_halo(const typename DwRaw<VW>::T &r, b
     o[VW + 3] = last ? 0.f : __uint_as_float(rw & 0xffff0000u);
 }
 
-template <int K, int VW, bool FLIP>
+template <int K, int VW, bool FLIP, bool EPI = false>   // EPI: the inference epilogue (forward only; its own instantiation)
 __global__ __launch_bounds__(kDwThreads) void dwconv_s1_stream_kernel(const uint16_t *__restrict__ x, const float *__restrict__ w,
                                                                      uint16_t *__restrict__ y, int C, int H, int W, int planes,
-                                                                     int rows_per_chunk) {
+                                                                     int rows_per_chunk, const DwEpi ep) {
     constexpr int P = K / 2;
     typedef typename DwRaw<VW>::T Raw;
     const int lane = threadIdx.x & 63, wv = blockIdx.x * (kDwThreads / 64) + (threadIdx.x >> 6);
@@ -752,6 +773,9 @@ __global__ __launch_bounds__(kDwThreads) void dwconv_s1_stream_kernel(const uint
     float wk[K * K];
 #pragma unroll
     for (int i = 0; i < K * K; ++i) wk[i] = w[c * K * K + (FLIP ? K * K - 1 - i : i)];
+    constexpr bool epi = EPI && !FLIP;
+    const float e_sc = epi ? ep.scale[c] : 1.f, e_sh = epi ? ep.shift[c] : 0.f;
+    const float e_ls = (epi && ep.lab) ? ep.lab[0] : 1.f, e_lb = (epi && ep.lab) ? ep.lab[1] : 0.f;
     const uint16_t *xp = x + (int64_t)(live ? plane : 0) * H * W + v * VW;
     uint16_t *yp = y + (int64_t)(live ? plane : 0) * H * W + v * VW;
     auto ld = [&](int row) { return (live && row >= 0 && row < H) ? *reinterpret_cast<const Raw *>(xp + (int64_t)row * W) : DwRaw<VW>::zero(); };
@@ -780,6 +804,10 @@ __global__ __launch_bounds__(kDwThreads) void dwconv_s1_stream_kernel(const uint
                 for (int kx = 0; kx < K; ++kx)
 #pragma unroll
                     for (int e = 0; e < VW; ++e) acc[e] = fmaf(wk[ky * K + kx], win[ky][e + kx + 2 - P], acc[e]);
+            if (epi) {
+#pragma unroll
+                for (int e = 0; e < VW; ++e) acc[e] = e_ls * dw_epi_act(acc[e] * e_sc + e_sh, ep.act) + e_lb;
+            }
             if (live) *reinterpret_cast<Raw *>(yp + (int64_t)(r + u) * W) = DwVec<VW>::pack(acc);
         }
     }
@@ -890,8 +918,30 @@ using namespace dfine;
 
 extern "C" {
 
+// One-shot request consumed by the next dfine_dwconv_fwd of the calling thread: y = lab[0] * act(scale[c] * conv + shift[c]) + lab[1]
+// on the fp32 sums before the store (act 0 none / 1 ReLU / 2 SiLU; lab 2 floats or NULL; scale == NULL withdraws the request).
+// Served by the bf16 streaming kernels (dfine_dwconv_affine_supported); a launch that cannot returns DFINE_E_BADARG.
+static thread_local DwEpi g_dw_epi = {nullptr, nullptr, nullptr, 0};
+int dfine_dwconv_affine_once(const float *scale, const float *shift, const float *lab, int act) {
+    g_dw_epi = DwEpi{nullptr, nullptr, nullptr, 0};
+    if (!scale) return DFINE_OK;
+    if (!shift || act < 0 || act > 2) return DFINE_E_BADARG;
+    g_dw_epi = DwEpi{scale, shift, lab, act};
+    return DFINE_OK;
+}
+
+int dfine_dwconv_affine_supported(int dtype, int H, int W, int K, int stride, int pad) {
+    int vw = 0;
+    if (dw_vec_ok(dtype, H, W, K, stride, pad, &vw) && W / vw <= 64) return 1;
+    if (dw_vec_ok(dtype, H, W, K, stride, pad, &vw)) return 0;
+    return dw_s2_ok(dtype, H, W, K, stride, pad) ? 1 : 0;
+}
+
 int dfine_dwconv_fwd(const void *x, const float *w, void *y, int dtype, int B, int C, int H, int W,
                      int K, int stride, int pad, void *stream) {
+    const DwEpi ep = g_dw_epi;
+    g_dw_epi = DwEpi{nullptr, nullptr, nullptr, 0};
+    if (ep.scale && !dfine_dwconv_affine_supported(dtype, H, W, K, stride, pad)) return DFINE_E_BADARG;
     if (B == 0 || C == 0) return DFINE_OK;
     if (!x || !w || !y || K < 1 || K > kMaxK || stride < 1 || pad < 0) return DFINE_E_BADARG;
     const int OH = (H + 2 * pad - K) / stride + 1, OW = (W + 2 * pad - K) / stride + 1;
@@ -903,10 +953,12 @@ int dfine_dwconv_fwd(const void *x, const float *w, void *y, int dtype, int B, i
         const int waves = (planes + ppw - 1) / ppw;
         const int rpc = dw_stream_rows(H, waves);
         const dim3 gs((waves + 3) / 4, (H + rpc - 1) / rpc);
-#define DFINE_DWS(KK, VV) hipLaunchKernelGGL((dwconv_s1_stream_kernel<KK, VV, false>), gs, dim3(kDwThreads), 0, st0, \
-                                             (const uint16_t *)x, w, (uint16_t *)y, C, H, W, planes, rpc)
-        if (K == 5) { if (vw == 8) DFINE_DWS(5, 8); else DFINE_DWS(5, 4); }
-        else { if (vw == 8) DFINE_DWS(3, 8); else DFINE_DWS(3, 4); }
+#define DFINE_DWS(KK, VV) { if (ep.scale) hipLaunchKernelGGL((dwconv_s1_stream_kernel<KK, VV, false, true>), gs, dim3(kDwThreads), 0, st0, \
+                                                            (const uint16_t *)x, w, (uint16_t *)y, C, H, W, planes, rpc, ep);      \
+                            else hipLaunchKernelGGL((dwconv_s1_stream_kernel<KK, VV, false, false>), gs, dim3(kDwThreads), 0, st0, \
+                                                    (const uint16_t *)x, w, (uint16_t *)y, C, H, W, planes, rpc, ep); }
+        if (K == 5) { if (vw == 8) DFINE_DWS(5, 8) else DFINE_DWS(5, 4) }
+        else { if (vw == 8) DFINE_DWS(3, 8) else DFINE_DWS(3, 4) }
 #undef DFINE_DWS
         return check_launch();
     }
@@ -927,8 +979,12 @@ int dfine_dwconv_fwd(const void *x, const float *w, void *y, int dtype, int B, i
         const int nv = W / 8, ppw = 64 / nv, planes = B * C;
         const int waves = (planes + ppw - 1) / ppw;
         const int rpc = dw_stream_rows(OH, waves);
-        hipLaunchKernelGGL(dwconv_s2_fwd_stream_kernel, dim3((waves + 3) / 4, (OH + rpc - 1) / rpc), dim3(kDwThreads), 0, st0,
-                           (const uint16_t *)x, w, (uint16_t *)y, C, H, W, planes, rpc);
+        if (ep.scale)
+            hipLaunchKernelGGL(dwconv_s2_fwd_stream_kernel<true>, dim3((waves + 3) / 4, (OH + rpc - 1) / rpc), dim3(kDwThreads), 0, st0,
+                               (const uint16_t *)x, w, (uint16_t *)y, C, H, W, planes, rpc, ep);
+        else
+            hipLaunchKernelGGL(dwconv_s2_fwd_stream_kernel<false>, dim3((waves + 3) / 4, (OH + rpc - 1) / rpc), dim3(kDwThreads), 0, st0,
+                               (const uint16_t *)x, w, (uint16_t *)y, C, H, W, planes, rpc, ep);
         return check_launch();
     }
     if (dw_s2_ok(dtype, H, W, K, stride, pad)) {
@@ -990,7 +1046,7 @@ int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, fl
         const int rpc = dw_stream_rows(H, waves);
         const dim3 gs((waves + 3) / 4, (H + rpc - 1) / rpc);
 #define DFINE_DWS(KK, VV) hipLaunchKernelGGL((dwconv_s1_stream_kernel<KK, VV, true>), gs, dim3(kDwThreads), 0, st, \
-                                             (const uint16_t *)dy, w, (uint16_t *)dx, C, H, W, planes, rpc)
+                                             (const uint16_t *)dy, w, (uint16_t *)dx, C, H, W, planes, rpc, DwEpi{nullptr, nullptr, nullptr, 0})
         if (K == 5) { if (vw == 8) DFINE_DWS(5, 8); else DFINE_DWS(5, 4); }
         else { if (vw == 8) DFINE_DWS(3, 8); else DFINE_DWS(3, 4); }
 #undef DFINE_DWS

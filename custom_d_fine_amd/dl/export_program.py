@@ -26,7 +26,7 @@ _EVAL_WRAPPERS = ("conv_pack_weights", "conv_forward_bf16", "bn_act_forward", "b
                   "stem_conv", "stem_conv2", "stem_pool_forward", "maps_to_tokens", "upsample2_nearest", "act_forward", "attn_forward",
                   "ln_fused_forward", "msda_fused_forward", "fdr_forward", "topk_anchors", "postprocess", "groupnorm_forward",
                   "bilinear_forward", "conv1x1_batched_weights", "gemm_f32", "gemm_f32_nt", "conv1x1_f32", "conv_f32_forward",
-                  "conv_f32_pack_weights", "conv_forward_affine", "conv1x1_seg_forward_affine", "bn_fold")
+                  "conv_f32_pack_weights", "conv_forward_affine", "conv1x1_seg_forward_affine", "bn_fold", "dwconv_forward_affine")
 
 
 def _encode(args, kwargs):

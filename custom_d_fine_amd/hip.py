@@ -80,6 +80,8 @@ _SIGNATURES = {
     "dfine_upload": (c_int, [_P, _P, _L, _P]),
     "dfine_conv_epilogue_supported": (c_int, [_I, _I, _I, _I, _I, _I]),
     "dfine_conv_affine_once": (c_int, [_P, _P, _P, _I]),
+    "dfine_dwconv_affine_once": (c_int, [_P, _P, _P, _I]),
+    "dfine_dwconv_affine_supported": (c_int, [_I, _I, _I, _I, _I, _I]),
     "dfine_conv_affine_supported": (c_int, [_I, _I, _I, _I, _I, _I]),
     "dfine_bn_fold": (c_int, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "dfine_conv_accum_bf16": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -536,6 +538,23 @@ def dwconv_forward(x, w, stride, pad):
         _check(_lib.dfine_dwconv_fwd(_ptr(x), _ptr(w), _ptr(y), _dtype_code(x), B, C, H, W, K, stride, pad,
                                      _stream()), "dfine_dwconv_fwd")
     return y
+
+
+def dwconv_affine_supported(x, K, stride, pad):
+    return x.dim() == 4 and bool(_lib.dfine_dwconv_affine_supported(_dtype_code(x), x.shape[2], x.shape[3], K, stride, pad))
+
+
+def dwconv_forward_affine(x, w, stride, pad, scale, shift, act, lab=None):
+    """lab[0] * act(scale[c] * dwconv(x)[c] + shift[c]) + lab[1] before the store (dfine_dwconv_affine_once + dfine_dwconv_fwd):
+    depthwise conv -> eval-mode BatchNorm -> activation as one launch.  Shapes of dwconv_affine_supported only."""
+    _check(_lib.dfine_dwconv_affine_once(scale.data_ptr(), shift.data_ptr(), _ptr(lab), _ACT_CODE[act]), "dfine_dwconv_affine_once")
+    try:
+        return _DW_FWD_IMPL(x, w, stride, pad)
+    finally:
+        _lib.dfine_dwconv_affine_once(None, None, None, 0)
+
+
+_DW_FWD_IMPL = dwconv_forward               # (the module attribute is a shim while a program is exported)
 
 
 def _dw_zeros(shape, dev):

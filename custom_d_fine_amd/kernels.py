@@ -1691,6 +1691,10 @@ def conv_bn_act(x, conv: nn.Conv2d, bn: nn.Module, act: Optional[str], lab: Opti
             if x.dtype == torch.float32 and torch.is_autocast_enabled():
                 x = x.to(torch.get_autocast_dtype("cuda"))      # what autocast would do for F.conv2d
                 fanin = None
+            if (_eval_unit_ok(bn, a) and x.dtype == torch.bfloat16
+                    and _hip().dwconv_affine_supported(x, conv.kernel_size[0], conv.stride[0], conv.padding[0])):
+                return _hip().dwconv_forward_affine(x.contiguous(), conv.weight.detach().float().contiguous(), conv.stride[0],
+                                                    conv.padding[0], *_eval_fold(bn), "silu" if a == "swish" else a, _lab_pair(lab))
             y = _bn_tail_fused(_DepthwiseConv, (x, conv.weight, conv.stride[0], conv.padding[0], fanin), bn, a, lab)
             if y is not None:
                 return y

@@ -164,6 +164,12 @@ int dfine_lsap(const float *cost, const int *tgt_offset, void *lsap_ws, int *mat
  */
 int dfine_dwconv_fwd(const void *x, const float *w, void *y, int dtype, int B, int C, int H, int W,
                      int K, int stride, int pad, void *stream);
+/* The depthwise unit of LightConvBNAct in eval mode (src/d_fine/arch/hgnetv2.py:83-112: depthwise conv -> BatchNorm -> ReLU [-> LAB]) as
+ * ONE launch: a one-shot request consumed by the next dfine_dwconv_fwd of the calling thread,
+ * y = lab[0] * act(scale[c] * conv + shift[c]) + lab[1] on the fp32 sums before the store (scale / shift from dfine_bn_fold;
+ * act 0 none / 1 ReLU / 2 SiLU; lab 2 floats or NULL; scale == NULL withdraws it).  Served where dfine_dwconv_affine_supported() != 0. */
+int dfine_dwconv_affine_once(const float *scale, const float *shift, const float *lab, int act);
+int dfine_dwconv_affine_supported(int dtype, int H, int W, int K, int stride, int pad);
 int dfine_dwconv_bwd(const void *x, const float *w, const void *dy, void *dx, float *dw_f32,
                      int dtype, int B, int C, int H, int W, int K, int stride, int pad, void *stream);
 /* dx += the data gradient of the K = 3 / stride 2 / pad 1 layer (bf16, H even, W % 8 == 0, W <= 320; DFINE_E_BADARG otherwise):

@@ -282,3 +282,30 @@ def test_deployed_unit_bias_act_in_the_store_phase(cuda, monkeypatch):
         want = F.silu(F.conv2d(x.bfloat16().float(), conv.weight.bfloat16().float(), conv.bias, 1, 1))
     assert len(calls) == 1
     assert (y.float() - want).abs().max().item() <= 1.2e-2 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("C,k,s,H,W,act,use_lab", [(128, 5, 1, 40, 40, "relu", True), (256, 3, 2, 40, 40, None, False), (96, 3, 1, 20, 20, "silu", False)])
+def test_eval_depthwise_unit_is_one_launch(cuda, monkeypatch, C, k, s, H, W, act, use_lab):
+    """Inference: depthwise conv -> eval-mode BatchNorm -> act [-> LAB] as the depthwise kernel with its affine epilogue
+    (dfine_dwconv_affine_once), against the fp32 ATen composition on the bf16-rounded operands."""
+    from custom_d_fine_amd import hip
+    from custom_d_fine_amd.d_fine.arch.hgnetv2 import LearnableAffineBlock
+    torch.manual_seed(C + k)
+    conv = nn.Conv2d(C, C, k, s, k // 2, groups=C, bias=False).to(cuda)
+    bn = nn.BatchNorm2d(C).to(cuda)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3); bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    bn.eval()
+    lab = LearnableAffineBlock(0.8, 0.1).to(cuda) if use_lab else None
+    x = torch.randn(4, C, H, W, device=cuda).bfloat16()
+    calls = []
+    real = hip.dwconv_forward_affine
+    monkeypatch.setattr(hip, "dwconv_forward_affine", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y = kernels.conv_bn_act(x, conv, bn, act, lab)
+    assert len(calls) == 1 and y.dtype == torch.bfloat16
+    f = {None: lambda t: t, "relu": F.relu, "silu": F.silu}[act]
+    with torch.no_grad():
+        want = f(bn(F.conv2d(x.float(), conv.weight.float(), None, s, k // 2, groups=C)))
+        want = lab(want) if lab is not None else want
+    assert (y.float() - want).abs().max().item() <= 1.2e-2 * want.abs().max().item()
