@@ -21,3 +21,6 @@ tot = sum(k.device_time_total for k in rows) / 3e3
 print(f"bs {bs}: device time per forward {tot:.2f} ms, {sum(k.count for k in rows) // 3} launches")
 for k in rows[:32]:
     print(f"{k.device_time_total / 3e3:7.3f} ms {k.count // 3:4d} x {k.device_time_total / max(k.count, 1):7.1f} us  {k.key[:105]}")
+print("by launch count:")
+for k in sorted(prof.key_averages(), key=lambda k: -k.count)[:40]:
+    print(f"{k.count // 3:4d} x {k.device_time_total / max(k.count, 1):7.1f} us  {k.key[:120]}")
