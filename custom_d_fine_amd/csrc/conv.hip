@@ -352,7 +352,7 @@ __host__ __device__ static inline int ws_pitch(int W) { return (W + 2 + 7) & ~7;
 // integer divisions, 24 shift / and / or to pair the channels and 8 swizzled addresses).  Now a fragment read is ONE add of a
 // wave-uniform offset to a per-lane base prepared per (tile, column offset), and a loader item is a table entry (LDS offset,
 // global offset, row, channel - two registers) + 8 v_perm_b32 + 8 writes with immediate offsets.
-template <int NTN, int VEC, int KC>
+template <int NTN, int VEC, int KC, bool EPI = false>   // EPI: the inference epilogue (its own instantiations: the training kernels keep their code)
 __global__ __launch_bounds__(kWsThreads) void conv3x3_ws_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w2,
                                                                uint16_t *__restrict__ y, int Cin, int Cout, int NP, int KP, int H,
                                                                int W, int R, int strips, int nblk, int units, int accum,
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(kWsThreads) void conv3x3_ws_kernel(const uint16_t *
         const int n_wave = nb * 64 * NTN + wave * 16 * NTN;
         constexpr int OP = 16 * kMaxPixTiles + 8;
         uint16_t *ot = reinterpret_cast<uint16_t *>(lds + 2 * buf_bytes) + wave * (16 * NTN * OP);
-        if (epi.scale) {                                         // eval-mode BatchNorm / bias + activation on the accumulators
+        if (EPI) {                                               // eval-mode BatchNorm / bias + activation on the accumulators
             const float ls = epi.lab ? epi.lab[0] : 1.f, lb = epi.lab ? epi.lab[1] : 0.f;
 #pragma unroll
             for (int t = 0; t < NTN; ++t)
@@ -796,7 +796,7 @@ __device__ __forceinline__ void glds16(const uint16_t *gsrc, unsigned lds_addr) 
 #endif
 constexpr int kAbl = DFINE_CONV1X1_ABLATE;
 
-template <int NTN, int kG2Ring, int PXW, bool SEG>   // kG2Ring LDS stages (3: two in flight; 2 for <= 128 input channels); PXW 16-pixel
+template <int NTN, int kG2Ring, int PXW, bool SEG, bool EPI = false>   // EPI: the inference epilogue (own instantiations); kG2Ring LDS stages (3: two in flight; 2 for <= 128 input channels); PXW 16-pixel
                                                      // tiles per wave (4 / 8); SEG: input / output given as several parts
 __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs xs_, const uint16_t *__restrict__ w2,
                                                                   const ChanSegs ys_, int Cin, int Cout, int NP, int KP,
@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(kG2Threads) void conv1x1_glds_kernel(const ChanSegs
     __builtin_amdgcn_s_barrier();                        // every wave is done reading the ring
     constexpr int OP = 16 * PXW + 8;                     // output tile pitch (elements)
     uint16_t *ot = reinterpret_cast<uint16_t *>(lds) + wave * (16 * NTN * OP);          // [16 NTN rows][16 PXW px]
-    if (epi.scale) {                                     // eval-mode BatchNorm / bias + activation on the accumulators, row by row
+    if (EPI) {                                           // eval-mode BatchNorm / bias + activation on the accumulators, row by row
         const float ls = epi.lab ? epi.lab[0] : 1.f, lb = epi.lab ? epi.lab[1] : 0.f;     // (a separate copy of the store loop: the
 #pragma unroll                                                                             //  training launches keep their registers)
         for (int t = 0; t < NTN; ++t)
@@ -1152,7 +1152,8 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
         if (!attr2) {
             hipError_t e = hipSuccess, r;
 #define DFINE_G2_ATTR1(N, R, P, S, BYTES) \
-    if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<N, R, P, S>), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES)) != hipSuccess) e = r;
+    if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<N, R, P, S, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES)) != hipSuccess) e = r; \
+    if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_glds_kernel<N, R, P, S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES)) != hipSuccess) e = r;
 #define DFINE_G2_ATTR(N, R, P) \
     DFINE_G2_ATTR1(N, R, P, false, R * (64 * 64 * P + 8192 * N)) DFINE_G2_ATTR1(N, R, P, true, R * (64 * 64 * P + 8192 * N) + 5120)
             DFINE_G2_ATTR(1, 2, 4) DFINE_G2_ATTR(1, 3, 4) DFINE_G2_ATTR(2, 2, 4) DFINE_G2_ATTR(2, 3, 4) DFINE_G2_ATTR(2, 3, 8)
@@ -1162,15 +1163,17 @@ static int launch_conv1x1(const uint16_t *x, const uint16_t *w2, uint16_t *y, in
             if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
             attr2 = true;
         }
-#define DFINE_G2L(N, R, P, S) \
-    hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, S>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum, w_bstride, ximg ? 1 : 0, epi)
-#define DFINE_G2(N, R, P) { if (seg) DFINE_G2L(N, R, P, true); else DFINE_G2L(N, R, P, false); }
+#define DFINE_G2LE(N, R, P, S, E) \
+    hipLaunchKernelGGL((conv1x1_glds_kernel<N, R, P, S, E>), grid2, dim3(kG2Threads), lds2, st, xs_, w2, ys_, Cin, Cout, NP, KP, HW, ptiles2, total2, nblk2, accum, w_bstride, ximg ? 1 : 0, epi)
+#define DFINE_G2L(N, R, P, S) { if (epi.scale) DFINE_G2LE(N, R, P, S, true); else DFINE_G2LE(N, R, P, S, false); }
+#define DFINE_G2(N, R, P) { if (seg) DFINE_G2L(N, R, P, true) else DFINE_G2L(N, R, P, false) }
         if (n256) DFINE_G2(4, 2, 8)
         else if (px256) DFINE_G2(2, 3, 8)
         else if (wide2) { if (ring2) DFINE_G2(2, 2, 4) else DFINE_G2(2, 3, 4) }
         else { if (ring2) DFINE_G2(1, 2, 4) else DFINE_G2(1, 3, 4) }
 #undef DFINE_G2
 #undef DFINE_G2L
+#undef DFINE_G2LE
         return check_launch();
     }
     if (xsegs || ysegs || accum || accum_parts || w_bstride || epi.scale) return DFINE_E_BADARG;  // the first-generation kernel takes whole tensors, shared weights, no accumulation, no epilogue
@@ -1665,7 +1668,6 @@ __device__ __forceinline__ void linear_wgrad_body(const uint16_t *__restrict__ x
     const int st_ld = st_tile == 0 ? N : K;
     const int st_width = st_tile == 0 ? N - n0 : K - k0;
     const bool vec_ok = (st_ld & 7) == 0;                         // rows 16-byte aligned
-    const bool vec4_ok = (st_ld & 3) == 0;                        // rows 8-byte aligned
     uint16_t *st_dst = st_tile == 0 ? s_dy : s_x;
     const int g = lane >> 4, i = lane & 15;
     const int tr_off = (4 * g + (i >> 2)) * PITCH + 4 * (i & 3);
@@ -1678,11 +1680,9 @@ __device__ __forceinline__ void linear_wgrad_body(const uint16_t *__restrict__ x
             const int m = m0 + row;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (m < m_end && vec_ok && col + 8 <= st_width) v = *reinterpret_cast<const uint4 *>(st_src + (int64_t)m * st_ld + col);
-            else if (m < m_end && vec4_ok && col + 8 <= st_width) {   // rows 8-byte aligned (the 132-wide box head: 63 -> 20 us)
-                const uint2 lo = *reinterpret_cast<const uint2 *>(st_src + (int64_t)m * st_ld + col);
-                const uint2 hi = *reinterpret_cast<const uint2 *>(st_src + (int64_t)m * st_ld + col + 4);
-                v = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            } else if (m < m_end && col < st_width) {             // odd widths (20, 4, 1 ... and row tails): element loads
+            else if (m < m_end && col < st_width) {               // odd widths (132, 20, 4, 1 ...): element loads
+                // (8-byte loads for the 132-wide box-head rows: 63 -> 43 us alone, but +0.33 ms per STEP - 27.34 -> 27.67 ms, three
+                // builds alternated on one box - the grouped launch's slow 132-wide workgroups evidently pace the others usefully)
                 uint16_t tmp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 for (int e = 0; e < min(8, st_width - col); ++e) tmp[e] = st_src[(int64_t)m * st_ld + col + e];
                 v = *reinterpret_cast<uint4 *>(tmp);
@@ -1932,21 +1932,24 @@ static int launch_conv(const uint16_t *x, const uint16_t *w2, uint16_t *y, int B
         if (!attr_ws) {
             hipError_t e = hipSuccess, r;
 #define DFINE_WS_ATTR(N, V, K) \
-    if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_ws_kernel<N, V, K>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) e = r;
+    if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_ws_kernel<N, V, K, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) e = r; \
+    if ((r = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_ws_kernel<N, V, K, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) e = r;
             DFINE_WS_ATTR(1, 8, 1) DFINE_WS_ATTR(1, 8, 2) DFINE_WS_ATTR(2, 8, 1) DFINE_WS_ATTR(2, 8, 2)
             DFINE_WS_ATTR(1, 4, 1) DFINE_WS_ATTR(1, 4, 2) DFINE_WS_ATTR(2, 4, 1) DFINE_WS_ATTR(2, 4, 2)
 #undef DFINE_WS_ATTR
             if (e != hipSuccess) { set_last_error(e); return DFINE_E_LAUNCH; }
             attr_ws = true;
         }
-#define DFINE_WS(N, V, K) \
-    hipLaunchKernelGGL((conv3x3_ws_kernel<N, V, K>), dim3(8 * wpx), dim3(kWsThreads), 2 * ws_slab * kc_ws + ws_ep, st, x, w2, y, Cin, Cout, NP, KP, H, W, R, strips, nblk, units, accum, epi)
-#define DFINE_WS_K(N, V) { if (kc_ws == 2) DFINE_WS(N, V, 2); else DFINE_WS(N, V, 1); }
+#define DFINE_WSE(N, V, K, E) \
+    hipLaunchKernelGGL((conv3x3_ws_kernel<N, V, K, E>), dim3(8 * wpx), dim3(kWsThreads), 2 * ws_slab * kc_ws + ws_ep, st, x, w2, y, Cin, Cout, NP, KP, H, W, R, strips, nblk, units, accum, epi)
+#define DFINE_WS(N, V, K) { if (epi.scale) DFINE_WSE(N, V, K, true); else DFINE_WSE(N, V, K, false); }
+#define DFINE_WS_K(N, V) { if (kc_ws == 2) DFINE_WS(N, V, 2) else DFINE_WS(N, V, 1) }
 #define DFINE_WS_V(N) { if (vec == 8) DFINE_WS_K(N, 8) else DFINE_WS_K(N, 4) }
         if (ntn == 2) DFINE_WS_V(2) else DFINE_WS_V(1)
 #undef DFINE_WS_V
 #undef DFINE_WS_K
 #undef DFINE_WS
+#undef DFINE_WSE
         return check_launch();
     }
     if (epi.scale) return DFINE_E_BADARG;                // (the first-generation kernel has no epilogue)
