@@ -46,7 +46,9 @@ import torch.distributed as dist  # noqa: E402
 LRS = {"n": (8e-4, 4e-4), "s": (2.5e-4, 6e-5), "m": (1.5e-4, 2e-5), "l": (1.6e-4, 1e-5), "x": (2e-4, 2e-6)}
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFS = 157.3    # f32-input MFMA peak = the fp32 vector rate (MI355X_MICROARCH.md): the roof of --dtype fp32 (config #2)
 MFMA_GROUPS = ("conv1x1", "conv3x3", "conv1x1_wgrad", "conv3x3_wgrad", "wgrad_reduce", "stem_conv", "stem_wgrad", "miopen_conv")
+F32_GROUPS = ("conv_f32", "linear_f32")       # event keys of the fp32 kernels (convolutions; GEMMs of 1x1 convolutions, linears, attention)
 
 
 # kernel-name patterns of the groups the line reports (shared with tools/roofline_from_stats.py, which applies them to a
@@ -65,12 +67,14 @@ KERNEL_GROUPS = (
     ("batchnorm", r"dfine::bn2?_"),
     ("depthwise", r"dfine::dwconv_"),
     ("aten", r"at::native::"),
+    ("f32_mfma", r"dfine::(conv_f32_kernel|wgrad_f32_kernel|gemm_f32_(big|nt)_kernel)"),
 )
 FAMILY_GROUPS = ("conv1x1", "conv3x3", "conv1x1_wgrad", "conv3x3_wgrad", "stem", "wgrad_reduce")
 # event keys (hip.py `_timed`) -> traced kernel group
 EVENT_TO_GROUP = {"conv1x1": "conv1x1", "conv3x3": "conv3x3", "conv1x1_wgrad": "conv1x1_wgrad", "conv3x3_wgrad": "conv3x3_wgrad",
                   "wgrad_reduce": "wgrad_reduce", "stem_conv": "stem", "stem_wgrad": "stem", "linear_wgrad": "linear_wgrad",
-                  "linear": "linear+attention", "attention": "linear+attention", "msda_fwd": "msda_fwd", "msda_bwd": "msda_bwd"}
+                  "linear": "linear+attention", "attention": "linear+attention", "msda_fwd": "msda_fwd", "msda_bwd": "msda_bwd",
+                  "conv_f32": "f32_mfma", "linear_f32": "f32_mfma"}
 
 
 def traced_groups(step, images, targets, n_steps=3):
@@ -306,7 +310,7 @@ def main():
     gc.freeze()                  # the long-lived heap (model, optimizer, caches) stays out of the cyclic collector's walks
     # events only around the launches the line reports: every event pair costs the host ~5 us, and a sampled step that is
     # host-paced overlaps its two streams less than the un-instrumented steps do
-    hip.enable_timing(MFMA_GROUPS + ("linear_wgrad", "linear", "attention", "msda_fwd", "msda_bwd"))
+    hip.enable_timing(MFMA_GROUPS + F32_GROUPS + ("linear_wgrad", "linear", "attention", "msda_fwd", "msda_bwd"))
     hip.timing_active(False)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     fence()
@@ -389,7 +393,7 @@ def main():
             # launches, ms, work (FLOPs or bytes), bound ms - per step
             return tuple(sum(t[i] for t in have) / per for i in (0, 2, 3, 4))
 
-        def mfma_entry(keys, label, traffic=None):
+        def mfma_entry(keys, label, traffic=None, peak_tfs=MFMA_BF16_PEAK_TFS):
             n, ms_ev, fl, bound_ms = event_sums(keys, False)
             _, ms_iso, _, _ = event_sums(keys, True)
             groups = sorted({EVENT_TO_GROUP[k] for k in keys if k in EVENT_TO_GROUP})
@@ -400,17 +404,17 @@ def main():
             def tf(t_ms):
                 return fl / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
 
-            ent = {"kernel": label, "bound": "mfma", "achieved": round(tf(ms), 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
-                   "frac": round(tf(ms) / MFMA_BF16_PEAK_TFS, 4), "traffic": traffic, "mode": MODES[mode],
+            ent = {"kernel": label, "bound": "mfma", "achieved": round(tf(ms), 1), "peak": peak_tfs, "unit": "TFLOP/s",
+                   "frac": round(tf(ms) / peak_tfs, 4), "traffic": traffic, "mode": MODES[mode],
                    # per-launch roofline: sum over the launches of max(FLOPs / 2.5 PFLOP/s, compulsory bytes / 8 TB/s) over
                    # the measured time - most layers of this network are HBM-bound (a 128 -> 128 1x1 layer has 64 FLOP / B)
                    "bound_ms_per_step": round(bound_ms, 3), "bound_frac": round(bound_ms / ms, 4) if ms > 0 else 0.0,
                    "launches_per_step": round(n_tr if mode == "traced" else n, 1), "ms_per_step": round(ms, 3),
                    "algorithmic_tflop_per_step": round(fl / 1e12, 3),
-                   "events": {"mode": MODES["events"], "ms_per_step": round(ms_ev, 3), "frac": round(tf(ms_ev) / MFMA_BF16_PEAK_TFS, 4),
+                   "events": {"mode": MODES["events"], "ms_per_step": round(ms_ev, 3), "frac": round(tf(ms_ev) / peak_tfs, 4),
                               "launches_per_step": round(n, 1)},
                    "isolated": {"mode": MODES["isolated"], "ms_per_step": round(ms_iso, 3),
-                                "frac": round(tf(ms_iso) / MFMA_BF16_PEAK_TFS, 4),
+                                "frac": round(tf(ms_iso) / peak_tfs, 4),
                                 "bound_frac": round(bound_ms / ms_iso, 4) if ms_iso > 0 else 0.0}}
             return ent
 
@@ -432,8 +436,14 @@ def main():
 
         fam_label = ("dense-conv implicit GEMMs of backbone + encoder: conv1x1_glds / conv3x3_ws / conv_igemm<3> (fwd + dgrad), "
                      "conv_wgrad1_glds / conv_wgrad3 + the deferred split reduction, stem_*")
-        family = mfma_entry(MFMA_GROUPS, fam_label, traffic=conv_pmc_traffic())
-        family["profile"] = profile_roofline()
+        if args.dtype == "fp32":
+            # config #2: every convolution / GEMM runs on the f32-input matrix cores - the family and its roof are those kernels'
+            family = mfma_entry(F32_GROUPS, "fp32 convolutions and GEMMs on the f32-input matrix cores: conv_f32_kernel / wgrad_f32_kernel "
+                                "(3x3, 2x2, strided), gemm_f32_big / gemm_f32_nt (1x1 convolutions and their weight gradients, linears, "
+                                "attention products)", peak_tfs=MFMA_F32_PEAK_TFS)
+        else:
+            family = mfma_entry(MFMA_GROUPS, fam_label, traffic=conv_pmc_traffic())
+            family["profile"] = profile_roofline()
         if traced:
             family["traced_kernel_ms_per_step"] = {g: round(v[0], 3) for g, v in traced.items()}
         kernels_ = [mfma_entry(("conv1x1",), "conv1x1_glds_kernel fwd+dgrad"),

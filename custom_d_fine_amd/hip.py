@@ -200,6 +200,7 @@ _PURE = _PureQueries()
 # algorithmic work (FLOPs or bytes) of the launch.
 _TIMED = {}          # name -> list of (start_event, end_event, work, bound_seconds)
 MFMA_PEAK_FLOPS, HBM_PEAK_BYTES = 2.5e15, 8.0e12       # MI355X_MICROARCH.md: dense bf16 MFMA, HBM3E
+F32_MFMA_PEAK_FLOPS = 157.3e12                           # f32-input MFMA (= the fp32 vector rate): the fp32 kernels' roof
 _TIMING_ON = False   # bench.py switches this per step (`timing_active`): the steps it samples after its timed region
 _TIMING_ISOLATED = False   # True: the sampled step runs everything on ONE stream (no weight gradients beside the chain) and its
                            # records go under "iso:<key>"; False: the step keeps its two streams and side-stream launches are
@@ -251,16 +252,17 @@ class _timed:
     """`with _timed(key, work):` - no-op unless bench.py enabled timing for `key` and the current step is sampled."""
     __slots__ = ("ev", "a", "work", "bound", "stream")
 
-    def __init__(self, name, work=0.0, io=0.0, stream=None):
+    def __init__(self, name, work=0.0, io=0.0, stream=None, peak=None):
         """work: algorithmic FLOPs (bytes for the HBM-bound keys); io: compulsory HBM bytes of an MFMA-keyed launch;
-        stream: the torch stream the launch goes to when that is not the current one (side-stream weight gradients)."""
+        stream: the torch stream the launch goes to when that is not the current one (side-stream weight gradients);
+        peak: matrix rate of the launch's arithmetic type when that is not bf16 (the fp32 kernels)."""
         self.ev = None
         if _TIMING_ON:
             want = _TIMED.get("*")
             if want is None or name in want:
                 self.ev = _TIMED.setdefault("iso:" + name if _TIMING_ISOLATED else name, [])
                 self.work = work
-                self.bound = max(work / MFMA_PEAK_FLOPS, io / HBM_PEAK_BYTES) if io else 0.0
+                self.bound = max(work / (peak or MFMA_PEAK_FLOPS), io / HBM_PEAK_BYTES) if io else 0.0
                 self.stream = stream
 
     def __enter__(self):
@@ -1953,7 +1955,7 @@ def gemm_f32_nt(a, b, bias=None, alpha=1.0, act=0, splits=1, out=None):
     if out is None:
         shape = (batch * splits, M, N) if splits > 1 else (tuple(a.shape[:-2]) + (M, N))
         out = torch.empty(shape, device=a.device, dtype=torch.float32)
-    with _timed("linear_f32", 2.0 * batch * M * N * K, io=4.0 * batch * (M * K + N * K + M * N)):
+    with _timed("linear_f32", 2.0 * batch * M * N * K, io=4.0 * batch * (M * K + N * K + M * N), peak=F32_MFMA_PEAK_FLOPS):
         _check(_lib.dfine_gemm_f32_nt(a3.data_ptr(), b3.data_ptr(), _ptr(bias), out.data_ptr(), batch, M, N, K, lda, ldb, N, sa, sb,
                                       M * N, splits, chunk, float(alpha), int(act), _stream()), "dfine_gemm_f32_nt")
     return out
@@ -1982,7 +1984,7 @@ def gemm_f32(a, b, a_kmajor=False, b_kmajor=False, bias=None, alpha=1.0, act=0, 
         splits = (K + chunk - 1) // chunk
     shape = (splits, M, N) if splits > 1 else (tuple(a.shape[:-2]) + (M, N))
     out = torch.empty(shape, device=a.device, dtype=torch.float32)
-    with _timed("linear_f32", 2.0 * batch * M * N * K, io=4.0 * batch * (M * K + N * K + M * N)):
+    with _timed("linear_f32", 2.0 * batch * M * N * K, io=4.0 * batch * (M * K + N * K + M * N), peak=F32_MFMA_PEAK_FLOPS):
         _check(_lib.dfine_gemm_f32(int(a_kmajor), int(b_kmajor), a.data_ptr(), b.data_ptr(), _ptr(bias), out.data_ptr(), batch, M, N, K,
                                    M if a_kmajor else K, N if b_kmajor else K, N, sa, sb, M * N, splits, chunk, float(alpha), int(act),
                                    _stream()), "dfine_gemm_f32")
@@ -2024,7 +2026,7 @@ def conv1x1_f32(x, w2d):
     if not planes_dense(x):
         x = x.contiguous()
     y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
-    with _timed("conv_f32", 2.0 * B * hw * cin * cout, io=4.0 * B * hw * (cin + cout)):
+    with _timed("conv_f32", 2.0 * B * hw * cin * cout, io=4.0 * B * hw * (cin + cout), peak=F32_MFMA_PEAK_FLOPS):
         _check(_lib.dfine_gemm_f32_nn(w2d.data_ptr(), x.data_ptr(), None, y.data_ptr(), B, cout, hw, cin, cin, hw, hw, 0,
                                       x.stride(0) if B > 1 else cin * hw, cout * hw, 1.0, 0, _stream()), "dfine_gemm_f32_nn")
     return y
@@ -2093,8 +2095,10 @@ def conv_f32_pack_weights(w, dgrad):
 def conv_f32_forward(x, w2, cout, ks, stride, pt, pl, out_hw):
     B, cin, hi, wi = x.shape
     y = torch.empty(B, cout, out_hw[0], out_hw[1], device=x.device, dtype=torch.float32)
-    _check(_lib.dfine_conv_f32_fwd(_ptr(x), _ptr(w2), _ptr(y), B, cin, cout, hi, wi, out_hw[0], out_hw[1], ks, stride, pt, pl, _stream()),
-           "dfine_conv_f32_fwd")
+    with _timed("conv_f32", 2.0 * B * out_hw[0] * out_hw[1] * cin * cout * ks * ks, io=4.0 * B * (hi * wi * cin + out_hw[0] * out_hw[1] * cout),
+                peak=F32_MFMA_PEAK_FLOPS):
+        _check(_lib.dfine_conv_f32_fwd(_ptr(x), _ptr(w2), _ptr(y), B, cin, cout, hi, wi, out_hw[0], out_hw[1], ks, stride, pt, pl, _stream()),
+               "dfine_conv_f32_fwd")
     return y
 
 
@@ -2115,8 +2119,9 @@ def conv_f32_wgrad(x, dy, ks, stride, pt, pl, partials=False):
     splits = int(_lib.dfine_conv_f32_wgrad_splits(B, cin, cout, ho, wo, ks))
     np16, cp16 = _p16(cout), _p16(cin)
     ws = torch.empty(splits * np16 * cp16 * ks * ks, device=x.device, dtype=torch.float32)
-    _check(_lib.dfine_conv_f32_wgrad(_ptr(x), _ptr(dy), _ptr(ws), B, cin, cout, hi, wi, ho, wo, ks, stride, pt, pl, _stream()),
-           "dfine_conv_f32_wgrad")
+    with _timed("conv_f32", 2.0 * B * ho * wo * cin * cout * ks * ks, io=4.0 * B * (hi * wi * cin + ho * wo * cout), peak=F32_MFMA_PEAK_FLOPS):
+        _check(_lib.dfine_conv_f32_wgrad(_ptr(x), _ptr(dy), _ptr(ws), B, cin, cout, hi, wi, ho, wo, ks, stride, pt, pl, _stream()),
+               "dfine_conv_f32_wgrad")
     if partials:
         return ws, (splits, cout, cin, ks * ks, np16, cp16)
     return ws.view(splits, np16, cp16, ks * ks).sum(0)[:cout, :cin].reshape(cout, cin, ks, ks).contiguous()
