@@ -1561,8 +1561,16 @@ def _eval_fold(bn):
     kernels that do not bump tensor versions: nothing to key a cache on)."""
     hit = bn.__dict__.get("_dfine_fold")
     if hit is not None:
-        return hit
+        if hit[0] == _fold_key(bn):
+            return hit[1]
+        del bn.__dict__["_dfine_fold"]            # weights were loaded / moved since freeze_eval_affine: fold per call again
     return _hip().bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+
+
+def _fold_key(bn):
+    """(address, version) of the four tensors a fold is made of: load_state_dict / copy_ / .to() all show in it (the training
+    kernels' in-place updates do not - a model that trains must not be frozen)."""
+    return tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
 
 
 def _lab_pair(lab):
@@ -1582,7 +1590,7 @@ def freeze_eval_affine(model):
         if isinstance(m, nn.BatchNorm2d) or type(m).__name__ == "FrozenBatchNorm2d":
             m.__dict__.pop("_dfine_fold", None)
             if m.running_mean is not None and m.running_mean.is_cuda:
-                m.__dict__["_dfine_fold"] = _hip().bn_fold(m.weight, m.bias, m.running_mean, m.running_var, m.eps)
+                m.__dict__["_dfine_fold"] = (_fold_key(m), _hip().bn_fold(m.weight, m.bias, m.running_mean, m.running_var, m.eps))
                 n += 1
         elif type(m).__name__ == "LearnableAffineBlock":
             m.__dict__.pop("_dfine_pair", None)

@@ -309,3 +309,32 @@ def test_eval_depthwise_unit_is_one_launch(cuda, monkeypatch, C, k, s, H, W, act
         want = f(bn(F.conv2d(x.float(), conv.weight.float(), None, s, k // 2, groups=C)))
         want = lab(want) if lab is not None else want
     assert (y.float() - want).abs().max().item() <= 1.2e-2 * want.abs().max().item()
+
+
+def test_frozen_eval_folds_follow_a_weight_reload(cuda):
+    """freeze_eval_affine keeps the BatchNorm folds on the modules (Torch_model: one launch per unit); loading other weights
+    afterwards must not serve the old folds."""
+    torch.manual_seed(9)
+    conv = nn.Conv2d(64, 64, 1, bias=False).to(cuda)
+    bn = nn.BatchNorm2d(64).to(cuda).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    unit = nn.Sequential(conv, bn)
+    assert kernels.freeze_eval_affine(unit) == 1 and "_dfine_fold" in bn.__dict__
+    x = torch.randn(2, 64, 20, 20, device=cuda)
+
+    def run():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return kernels.conv_bn_act(x, conv, bn, "relu", None).float()
+
+    def ref():
+        with torch.no_grad():
+            return F.relu(bn(F.conv2d(x.bfloat16().float(), conv.weight.bfloat16().float())))
+
+    assert (run() - ref()).abs().max() <= 1.2e-2 * ref().abs().max()
+    state = {k: v.clone() for k, v in bn.state_dict().items()}
+    state["weight"] = state["weight"] * 3.0
+    state["running_mean"] = state["running_mean"] + 1.0
+    bn.load_state_dict(state)
+    assert (run() - ref()).abs().max() <= 1.2e-2 * ref().abs().max()          # the stale fold would be off by the new scale / shift
+    assert "_dfine_fold" not in bn.__dict__
