@@ -338,3 +338,21 @@ def test_frozen_eval_folds_follow_a_weight_reload(cuda):
     bn.load_state_dict(state)
     assert (run() - ref()).abs().max() <= 1.2e-2 * ref().abs().max()          # the stale fold would be off by the new scale / shift
     assert "_dfine_fold" not in bn.__dict__
+
+
+def test_deployed_1x1_reads_a_concatenation_as_parts(cuda, monkeypatch):
+    """A deployed 1x1 layer on a list input (the FPN / PAN concatenations in front of the CSP layers): inference takes the part-wise
+    kernel with the bias + activation epilogue - no torch.cat - and matches the fp32 composition on the concatenated map."""
+    from custom_d_fine_amd import hip
+    torch.manual_seed(11)
+    conv = nn.Conv2d(256 + 128, 192, 1, bias=True).to(cuda)
+    a, b = torch.randn(2, 256, 40, 40, device=cuda).bfloat16(), torch.randn(2, 128, 40, 40, device=cuda).bfloat16()
+    cats = []
+    real_cat = torch.cat
+    monkeypatch.setattr(torch, "cat", lambda *ar, **kw: (cats.append(1), real_cat(*ar, **kw))[1])
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y = kernels.conv_bias_act([a, b], conv, "silu")
+    assert not cats and y.dtype == torch.bfloat16
+    with torch.no_grad():
+        want = F.silu(F.conv2d(real_cat([a, b], 1).float(), conv.weight.bfloat16().float(), conv.bias))
+    assert (y.float() - want).abs().max().item() <= 1.2e-2 * want.abs().max().item()

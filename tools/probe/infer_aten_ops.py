@@ -4,7 +4,7 @@ import torch
 from custom_d_fine_amd.infer.torch_model import Torch_model
 tm = Torch_model("m", None, 80, 640, 640, half=True, hip_graph=False)
 tm.model.deploy()
-x = torch.rand(1, 3, 640, 640, device="cuda")
+x = torch.rand(int(sys.argv[1]) if len(sys.argv) > 1 else 1, 3, 640, 640, device="cuda")
 with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
     for _ in range(3):
         tm.model(x)
