@@ -9,7 +9,7 @@ void set_last_error(hipError_t e) { g_last_error = hipGetErrorString(e); }
 }  // namespace dfine
 
 extern "C" {
-int dfine_abi_version(void) { return 2; }
+int dfine_abi_version(void) { return 3; }
 const char *dfine_last_error(void) { return dfine::g_last_error.c_str(); }
 
 // Stream `to` waits for everything enqueued on stream `from` so far (fork / join of the side stream that carries the weight

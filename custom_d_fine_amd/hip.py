@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DFINE_HIP_LIB") or os.path.join(_HERE, "csrc", "libdfine_hip.so")     # (override: A/B of two builds on one box)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
