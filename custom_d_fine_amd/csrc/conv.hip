@@ -1741,6 +1741,126 @@ __device__ __forceinline__ void linear_wgrad_body(const uint16_t *__restrict__ x
     }
 }
 
+// The same product on 128 x 128 output tiles (wave = 64 x 64 = 4 x 4 MFMA tiles, 64 accumulator registers): half the L2 traffic
+// and LDS fragment reads per MFMA of the 64 x 64 body - the body of the GROUPED launch (64 problems side by side fill the chip with
+// 64 workgroups each: 801 -> 725 us for a decoder step's list, tools/linear_wgrad_group_bench.py, and 27.42 -> 27.27 ms per step on a
+// same-box A/B of the two builds, tools/ab_trees.sh); a problem launched alone keeps the 64 x 64 body (256 workgroups: 74 us
+// against 148).  Row pitch 144 elements = 288 B: the 8 rows a 32-lane half touches fall on 8 different 32-byte bank groups.
+__device__ __forceinline__ void linear_wgrad_body128(const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy,
+                                                     float *__restrict__ part, float *__restrict__ db, int M, int N, int K,
+                                                     int rows_per_split, int nct128, int NP16, int CP16, int tile, int split) {
+    constexpr int PITCH = 144, ROWS = 64, NV = ROWS / 8;
+    __shared__ __attribute__((aligned(16))) uint16_t s_dy[ROWS * PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t s_x[ROWS * PITCH];
+    typedef short tr4 __attribute__((ext_vector_type(4)));
+    typedef short tr8 __attribute__((ext_vector_type(8)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wk = wave & 1;
+    const int nt = tile / nct128, ct = tile - nt * nct128;
+    const int n0 = nt * 128, k0 = ct * 128;
+    const int m_begin = split * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+    f32x4v acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    f32x4v acc_b[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc_b[a] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const bool want_db = db != nullptr && ct == 0 && wk == 0;
+    const int wn0 = n0 + wn * 64, wk0 = k0 + wk * 64;
+    const int na = min(4, max(0, (N - wn0 + 15) >> 4)), nb = min(4, max(0, (K - wk0 + 15) >> 4));
+    const int st_tile = tid >> 7, st_t = tid & 127;
+    const uint16_t *st_src = st_tile == 0 ? dy + n0 : x + k0;
+    const int st_ld = st_tile == 0 ? N : K;
+    const int st_width = st_tile == 0 ? N - n0 : K - k0;
+    const bool vec_ok = (st_ld & 7) == 0;
+    uint16_t *st_dst = st_tile == 0 ? s_dy : s_x;
+    const int g = lane >> 4, i = lane & 15;
+    const int tr_off = (4 * g + (i >> 2)) * PITCH + 4 * (i & 3);
+    uint4 pf[NV];
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int h = 0; h < NV; ++h) {
+            const int vi = st_t + 128 * h;
+            const int row = vi >> 4, col = (vi & 15) * 8;
+            const int m = m0 + row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m < m_end && vec_ok && col + 8 <= st_width) v = *reinterpret_cast<const uint4 *>(st_src + (int64_t)m * st_ld + col);
+            else if (m < m_end && col < st_width) {
+                uint16_t tmp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int e = 0; e < min(8, st_width - col); ++e) tmp[e] = st_src[(int64_t)m * st_ld + col + e];
+                v = *reinterpret_cast<uint4 *>(tmp);
+            }
+            pf[h] = v;
+        }
+    };
+    fetch(m_begin);
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+    for (int m0 = m_begin; m0 < m_end; m0 += ROWS) {
+#pragma unroll
+        for (int h = 0; h < NV; ++h) {
+            const int vi = st_t + 128 * h;
+            *reinterpret_cast<uint4 *>(st_dst + (vi >> 4) * PITCH + (vi & 15) * 8) = pf[h];
+        }
+        __syncthreads();
+        if (m0 + ROWS < m_end) fetch(m0 + ROWS);
+        if (na > 0 && nb > 0) {
+#pragma unroll
+            for (int ks = 0; ks < ROWS / 32; ++ks) {
+                bf16x8 af[4], bfr[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const uint16_t *pa = s_dy + ks * 32 * PITCH + tr_off + wn * 64 + a * 16;
+                    const tr4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4 __attribute__((address_space(3))) *)pa);
+                    const tr4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4 __attribute__((address_space(3))) *)(pa + 16 * PITCH));
+                    af[a] = __builtin_bit_cast(bf16x8, (tr8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint16_t *pb = s_x + ks * 32 * PITCH + tr_off + wk * 64 + b * 16;
+                    const tr4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4 __attribute__((address_space(3))) *)pb);
+                    const tr4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4 __attribute__((address_space(3))) *)(pb + 16 * PITCH));
+                    bfr[b] = __builtin_bit_cast(bf16x8, (tr8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (a >= na) break;
+                    if (want_db) acc_b[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], ones, acc_b[a], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        if (b >= nb) break;
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int c = wk0 + b * 16 + (lane & 15);
+        if (c >= CP16) continue;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = wn0 + a * 16 + 4 * (lane >> 4) + r;
+                if (n < NP16) part[((int64_t)split * NP16 + n) * CP16 + c] = acc[a][b][r];
+            }
+    }
+    if (want_db && (lane & 15) == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = wn0 + a * 16 + 4 * (lane >> 4) + r;
+                if (n < NP16) db[(int64_t)split * NP16 + n] = acc_b[a][r];
+            }
+    }
+}
+
 __global__ __launch_bounds__(kConvThreads) void linear_wgrad_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ dy,
                                                                     float *__restrict__ part, float *__restrict__ db, int M, int N,
                                                                     int K, int rows_per_split, int nct64, int NP16, int CP16) {
@@ -1755,13 +1875,13 @@ __global__ __launch_bounds__(kConvThreads) void linear_wgrad_kernel(const uint16
 __global__ __launch_bounds__(kConvThreads) void linear_wgrad_group_kernel(const int64_t *__restrict__ table) {
     const int64_t *e = table + (int64_t)blockIdx.y * 8;
     const int M = (int)e[3], N = (int)e[4], K = (int)e[5], rows = (int)e[6], splits = (int)e[7];
-    const int nnt64 = (N + 63) / 64, nct64 = (K + 63) / 64, ntiles = nnt64 * nct64;
+    const int nnt = (N + 127) / 128, nct = (K + 127) / 128, ntiles = nnt * nct;
     if ((int)blockIdx.x >= ntiles * splits) return;
     const int split = blockIdx.x / ntiles, tile = blockIdx.x - split * ntiles;
     const int np16 = (N + 15) / 16 * 16, cp16 = (K + 15) / 16 * 16;
     float *ws = reinterpret_cast<float *>(e[2]);
-    linear_wgrad_body(reinterpret_cast<const uint16_t *>(e[0]), reinterpret_cast<const uint16_t *>(e[1]), ws,
-                      ws + (int64_t)splits * np16 * cp16, M, N, K, rows, nct64, np16, cp16, tile, split);
+    linear_wgrad_body128(reinterpret_cast<const uint16_t *>(e[0]), reinterpret_cast<const uint16_t *>(e[1]), ws,
+                         ws + (int64_t)splits * np16 * cp16, M, N, K, rows, nct, np16, cp16, tile, split);
 }
 
 // Deferred split reduction of MANY weight gradients in one launch, accumulating into their final destination (the flat
@@ -2358,7 +2478,7 @@ int dfine_linear_wgrad_group_row(const void *x, const void *dy, float *ws, int M
     int splits, rows;
     linear_wgrad_plan(M, N, K, &splits, &rows);
     row[0] = (int64_t)x; row[1] = (int64_t)dy; row[2] = (int64_t)ws; row[3] = M; row[4] = N; row[5] = K; row[6] = rows; row[7] = splits;
-    return ((N + 63) / 64) * ((K + 63) / 64) * splits;
+    return ((N + 127) / 128) * ((K + 127) / 128) * splits;
 }
 
 // 1x1 weight gradients, grouped: row helper (returns the workgroup count, < 0 when this shape does not take the LDS-DMA kernel).
