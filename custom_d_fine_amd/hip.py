@@ -1104,7 +1104,9 @@ WGRAD_STREAM = os.environ.get("DFINE_WGRAD_STREAM", "1") == "1"
 _SIDE = {}
 _SIDE_LIVE = []
 _SIDE_PRIORITY = 0        # stream priority of the side stream (torch: lower number = higher priority; measured: no effect - tools/probe/main_prio.py)
-_SIDE_GROUP_AT = 32       # registered problems that trigger an early grouped launch (12 / 48 / never: +0.13 / 0 / +0.4 ms per step; tools/ab_step.py)
+_SIDE_GROUP_AT = 64       # registered 1x1 problems (twice as many linears) that trigger an early grouped launch; in-process A/B against
+                          # 32 with the 128-tile grouped linear kernel (tools/ab_step.py): 48 -0.05, 64 -0.08 / -0.11 / -0.19, 96 -0.11, never
+                          # -0.07 ms per step (round 5, 64-tile kernel: 12 / 48 / never = +0.13 / 0 / +0.4 against 32)
 
 
 CAPTURE_SIDE = False      # set by dl.engine.GraphedSegment while it captures: the side stream is forked into the capture (and joined
