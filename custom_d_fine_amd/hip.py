@@ -1104,9 +1104,10 @@ WGRAD_STREAM = os.environ.get("DFINE_WGRAD_STREAM", "1") == "1"
 _SIDE = {}
 _SIDE_LIVE = []
 _SIDE_PRIORITY = 0        # stream priority of the side stream (torch: lower number = higher priority; measured: no effect - tools/probe/main_prio.py)
-_SIDE_GROUP_AT = 64       # registered 1x1 problems (twice as many linears) that trigger an early grouped launch; in-process A/B against
-                          # 32 with the 128-tile grouped linear kernel (tools/ab_step.py): 48 -0.05, 64 -0.08 / -0.11 / -0.19, 96 -0.11, never
-                          # -0.07 ms per step (round 5, 64-tile kernel: 12 / 48 / never = +0.13 / 0 / +0.4 against 32)
+_SIDE_GROUP_AT = 32       # registered 1x1 convolution problems that trigger an early grouped launch (12 / 48 / never: +0.13 / 0 / +0.4 ms
+                          # per step; tools/ab_step.py with AB_RECAPTURE=1 - the value is baked into the captured backward graphs)
+_SIDE_LINEAR_GROUP_AT = 128   # the same for the token-stream linears of the (eager) decoder backward: 64 until round 6; with the 128-tile
+                          # grouped kernel, in-process A/B against 64: 96 -0.05, 128 -0.08 / -0.11 / -0.19, 192 -0.11, never -0.07 ms per step
 
 
 CAPTURE_SIDE = False      # set by dl.engine.GraphedSegment while it captures: the side stream is forked into the capture (and joined
@@ -1527,7 +1528,7 @@ def linear_wgrad_partials(x2d, dy2d):
     N = dy2d.shape[1]
     ws = torch.empty(int(_PURE.dfine_linear_wgrad_ws_floats(M, N, K)), device=x2d.device, dtype=torch.float32)
     _LW_PENDING.append((x2d, dy2d, ws, M, N, K))
-    if len(_LW_PENDING) >= 2 * _SIDE_GROUP_AT and _side_ok("linear"):
+    if len(_LW_PENDING) >= _SIDE_LINEAR_GROUP_AT and _side_ok("linear"):
         _flush_linear_group(True)
     splits = int(_PURE.dfine_linear_wgrad_splits(M, N, K))
     np16, cp16 = _p16(N), _p16(K)
