@@ -158,8 +158,10 @@ class GraphedSegment:
     legacy stream - a crash on this stack (tools/graph_probe6.py).  `torch.cuda.make_graphed_callables` segfaults here even
     for a two-layer MLP (tools/graph_probe2.py)."""
 
-    GROUP_AT = 8      # registered 1x1 / linear weight gradients per grouped launch inside a captured backward
-    CHUNK = 5         # side-stream launches per (main, side) graph pair (2 / 3 / 8: +0.2 / +0.2 / 0 ms per step)
+    GROUP_AT = 16     # registered 1x1 / linear weight gradients per grouped launch inside a captured backward
+    CHUNK = 8         # side-stream launches per (main, side) graph pair (2 / 3 / 8: +0.2 / +0.2 / 0 ms per step in round 5)
+    # (8, 5) until the end of round 6; (16, 8): 26.91 - 26.97 -> 26.80 - 26.83 ms per step, four same-box alternations of the two builds
+    # (tools/ab_trees.sh; in-process with AB_RECAPTURE=1 each of the two alone -0.04 .. -0.27)
 
     def __init__(self, module, sample_inputs, amp_dtype=None, fused=None, warmup=1, input_grads=False, clone_inputs=True,
                  defer_backward=False, cast_inputs=False):

@@ -43,9 +43,11 @@ def setting(on):
         name, vals = what.split("=")
         mod, attr = name.split(".")
         a, b = vals.split(",")
-        old = getattr({"hip": hip, "kernels": kernels}[mod], attr)
+        from custom_d_fine_amd.dl import engine
+        mods = {"hip": hip, "kernels": kernels, "seg": engine.GraphedSegment}        # seg.GROUP_AT=8,16 (class attributes; AB_RECAPTURE=1)
+        old = getattr(mods[mod], attr)
         val = tuple(filter(None, (b if on else a).split("+"))) if isinstance(old, tuple) else type(old)(b if on else a)   # tuples: "c3+k2"
-        setattr({"hip": hip, "kernels": kernels}[mod], attr, val)
+        setattr(mods[mod], attr, val)
         if os.environ.get("AB_RECAPTURE") == "1":      # the setting is baked into the captured graphs: build them again
             torch.cuda.synchronize()
             for seg in list(step._graphs.values()):
